@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by IMPORTING the reference (microsoft/UniRec) as a CPU oracle.
+
+Runs only in the build container, where /root/reference exists:
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tools/capture_goldens.py
+
+Nothing from the reference is copied: the fixtures are data (seeded inputs, the state_dict the
+reference initialised, and the outputs / gradients / updated parameters it computed).  The GPU box
+never sees /root/reference; tests there read only the committed .npz files.
+
+Fixture list follows SURVEY.md section 8c (G1..G10).
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _shims():
+    """stub optional imports that never touch hot-path arithmetic."""
+    import accelerate  # noqa: F401  (must be imported before stubbing wandb)
+    for name in ("feather", "wandb", "cvxpy"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sp = types.ModuleType("setproctitle")
+    sp.setproctitle = lambda *a, **k: None
+    sys.modules.setdefault("setproctitle", sp)
+    nb = types.ModuleType("numba")
+    nb.jit = lambda *a, **k: (lambda f: f)
+    nb.prange = range
+    sys.modules.setdefault("numba", nb)
+    tb = types.ModuleType("torch.utils.tensorboard")
+
+    class SummaryWriter:  # noqa: D401
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+    tb.SummaryWriter = SummaryWriter
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    sys.modules.setdefault("torch.utils.tensorboard.writer", tb)
+    np.Inf = np.inf
+
+
+def base_cfg(**kw):
+    cfg = dict(n_users=40, n_items=200, device="cpu", loss_type="bpr", embedding_size=32, hidden_size=32,
+               dropout_prob=0.0, init_method="normal", init_mean=0.0, init_std=0.02, has_user_emb=False,
+               has_user_bias=False, has_item_bias=False, distance_type="dot", tau=1.0,
+               train_file_format="user-item", exp_name="golden", n_layers=2, n_heads=2, inner_size=64,
+               hidden_dropout_prob=0.0, attn_dropout_prob=0.0, hidden_act="swish", layer_norm_eps=1e-10,
+               max_seq_len=10, use_position_emb=True)
+    cfg.update(kw)
+    return cfg
+
+
+def sd_np(model):
+    return {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def make_batch(rng, B, L, G, n_items, n_users, pad_counts=None):
+    item_seq = rng.integers(1, n_items, size=(B, L)).astype(np.int32)
+    if pad_counts is None:
+        pad_counts = rng.integers(0, L, size=B)
+    for b, p in enumerate(pad_counts):
+        item_seq[b, :p] = 0
+    item_id = rng.integers(1, n_items, size=(B, G)).astype(np.int64)
+    # force some duplicates between rows and between seq and candidates
+    item_id[1, 1] = item_id[0, 0]
+    item_seq[2, -1] = int(item_id[0, 0])
+    label = np.zeros((B, G), dtype=np.int32)
+    label[:, 0] = 1
+    user_id = rng.integers(1, n_users, size=(B,)).astype(np.int64)
+    seq_len = (item_seq > 0).sum(1).astype(np.int64)
+    return dict(user_id=user_id, item_id=item_id, label=label, item_seq=item_seq, item_seq_len=seq_len)
+
+
+def tt(batch):
+    return {k: torch.from_numpy(v) for k, v in batch.items()}
+
+
+def run_model(model, batch, want_layers=False):
+    """loss, scores, user_emb + dense grads from the reference model in train mode."""
+    model.train()
+    model.zero_grad()
+    tb = tt(batch)
+    loss, scores, user_emb, items_emb = model(user_id=tb["user_id"], item_id=tb["item_id"], label=tb["label"],
+                                              item_seq=tb["item_seq"], item_seq_len=tb["item_seq_len"],
+                                              return_loss_only=False)
+    loss.backward()
+    out = {"out.loss": loss.detach().numpy().copy(), "out.scores": scores.detach().numpy().copy(),
+           "out.user_emb": user_emb.detach().numpy().copy()}
+    for k, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        out["grad." + k] = g.detach().numpy().copy()
+    return out
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, f"{os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def pack(prefix, d):
+    return {prefix + k: v for k, v in d.items()}
+
+
+def main():
+    sys.path.insert(0, REF)
+    _shims()
+    from unirec.data.transform.addnegsamples import AddNegSamples
+    from unirec.data.transform.adduserhistory import AddUserHistory
+    from unirec.model.cf.mf import MF
+    from unirec.model.sequential.gru import GRU
+    from unirec.model.sequential.sasrec import SASRec
+
+    # ---------------------------------------------------------------- G1 sampler known answers
+    g1 = {}
+    random.seed(2022)
+    t = AddNegSamples(5, 60000, 4, user2history=np.array([None, np.array([5, 6, 7, 8]), np.array([9, 10])], dtype=object))
+    rows = [t(np.array([1, 7], dtype=object))[1] for _ in range(3)]
+    g1["kat_seed2022_n60000_k4"] = np.stack(rows)
+    # small catalogue: rejections + exhaustion (every id is in the history -> id 0 after 100 tries)
+    random.seed(7)
+    hist = np.empty(3, dtype=object)
+    hist[0] = None
+    hist[1] = np.arange(1, 12)
+    hist[2] = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])  # 12 free ids out of N=24
+    t2 = AddNegSamples(3, 24, 6, user2history=hist)
+    g1["small_rows_user"] = np.array([1, 2, 1, 2, 1], dtype=np.int64)
+    g1["small_rows_pos"] = np.array([3, 5, 7, 9, 11], dtype=np.int64)
+    g1["small_out"] = np.stack([t2(np.array([u, p], dtype=object))[1] for u, p in zip(g1["small_rows_user"], g1["small_rows_pos"])])
+    random.seed(11)
+    full = np.empty(2, dtype=object)
+    full[0] = None
+    full[1] = np.arange(1, 8)
+    t3 = AddNegSamples(2, 8, 3, user2history=full)
+    g1["exhaust_out"] = t3(np.array([1, 3], dtype=object))[1]
+    g1["after_exhaust_getrandbits32"] = np.array([random.getrandbits(32)], dtype=np.int64)  # stream position check
+    # popularity (alias) sampler
+    random.seed(5)
+    pop = np.arange(30, dtype=np.float64)
+    t4 = AddNegSamples(3, 30, 8, item_popularity=pop, neg_by_pop_alpha=0.5)
+    g1["pop"] = pop
+    g1["pop_out"] = np.stack([t4(np.array([1, 4], dtype=object))[1] for _ in range(4)])
+    save("g1_sampler", **g1)
+
+    # ---------------------------------------------------------------- G2 history / padding
+    g2 = {}
+    h = np.empty(4, dtype=object)
+    h[0] = None
+    h[1] = np.array([5, 6, 7, 8], dtype=np.int32)
+    h[2] = np.array([9, 10, 9, 11, 9, 12], dtype=np.int32)
+    h[3] = np.arange(1, 30, dtype=np.int32)
+    g2["h1"], g2["h2"], g2["h3"] = h[1], h[2], h[3]
+    for mode in ("autoregressive", "unorder", "autoagressive"):
+        for seq_last in (0, 1):
+            random.seed(3)
+            tr = AddUserHistory(h, mode, seq_last=seq_last)
+            outs = []
+            for (u, it) in [(1, 7), (2, 9), (2, 9), (2, 9), (3, 15), (7, 3), (1, np.array([7, 99, 6]))]:
+                hist_o, ln, _ = tr((u, it))
+                outs.append(np.concatenate([[ln], np.asarray(hist_o, dtype=np.int64)]))
+            g2[f"{mode}_sl{seq_last}"] = np.array(outs, dtype=object)
+    # object arrays are not portable; flatten to (lens, concat)
+    flat = {}
+    for k, v in list(g2.items()):
+        if v.dtype == object:
+            flat[k + ".lens"] = np.array([len(x) for x in v], dtype=np.int64)
+            flat[k + ".cat"] = np.concatenate([np.asarray(x, dtype=np.int64) for x in v])
+        else:
+            flat[k] = v
+    # padding rule (SeqRecDataset._padding) evaluated through a bare instance
+    from unirec.data.dataset.seqrecdataset import SeqRecDataset
+    ds = SeqRecDataset.__new__(SeqRecDataset)
+    ds.config = {"max_seq_len": 6}
+    for nm, x in (("short", [4, 5]), ("exact", [1, 2, 3, 4, 5, 6]), ("long", list(range(1, 10))), ("one", [0])):
+        flat["pad_" + nm] = ds._padding(np.array(x, dtype=np.int32))
+    save("g2_history", **flat)
+
+    # ---------------------------------------------------------------- G5/G6 SASRec fwd + bwd
+    rng = np.random.default_rng(2022)
+    for tag, kw in {
+        "sasrec_h2_swish_bpr": dict(n_heads=2, hidden_act="swish", loss_type="bpr"),
+        "sasrec_h16_gelu_softmax": dict(n_heads=16, hidden_act="gelu", loss_type="softmax", tau=0.7),
+        "sasrec_h4_relu_bpr_nopos": dict(n_heads=4, hidden_act="relu", loss_type="bpr", use_position_emb=False),
+        "sasrec_h2_tanh_bce_bias": dict(n_heads=2, hidden_act="tanh", loss_type="bce", has_item_bias=True,
+                                        has_user_bias=True),
+        "sasrec_h2_sigmoid_ccl": dict(n_heads=2, hidden_act="sigmoid", loss_type="ccl", ccl_w=150, ccl_m=0.4),
+        "sasrec_d64_1layer_fullsoftmax": dict(n_heads=4, embedding_size=64, hidden_size=64, n_layers=1,
+                                              loss_type="fullsoftmax", inner_size=96),
+    }.items():
+        cfg = base_cfg(model="SASRec", **kw)
+        torch.manual_seed(1234)
+        m = SASRec(cfg)
+        # move LayerNorm / bias params off their trivial init so their gradients are exercised
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if "LayerNorm" in k or k.endswith(".bias"):
+                    p.add_(0.05 * torch.randn_like(p))
+        B, L, G = 6, cfg["max_seq_len"], 5
+        batch = make_batch(rng, B, L, G, cfg["n_items"], cfg["n_users"], pad_counts=[0, 3, 9, 10, 5, 1])
+        if cfg["loss_type"] == "fullsoftmax":  # one positive id per row, no sampled negatives (recommender.py:47-50)
+            batch["item_id"] = batch["item_id"][:, 0].copy()
+            batch["label"] = batch["label"][:, 0].copy()
+        out = run_model(m, batch)
+        # intermediate activations for debugging parity (mask, x0, per-layer outputs)
+        m.eval()
+        with torch.no_grad():
+            seq = torch.from_numpy(batch["item_seq"])
+            out["mid.mask"] = m._get_attention_mask(seq).numpy()
+        save("g5_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}),
+             **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
+
+    # ---------------------------------------------------------------- G7 GRU
+    for tag, kw in {"gru_h32_bpr": dict(hidden_size=32, loss_type="bpr"),
+                    "gru_h48_softmax": dict(hidden_size=48, loss_type="softmax")}.items():
+        cfg = base_cfg(model="GRU", **kw)
+        torch.manual_seed(99)
+        m = GRU(cfg)
+        B, L, G = 5, cfg["max_seq_len"], 4
+        batch = make_batch(rng, B, L, G, cfg["n_items"], cfg["n_users"], pad_counts=[0, 4, 9, 10, 2])
+        out = run_model(m, batch)
+        save("g7_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}),
+             **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
+
+    # ---------------------------------------------------------------- G8 MF (+ scorer/loss with biases)
+    cfg = base_cfg(model="MF", has_user_emb=True, has_user_bias=True, has_item_bias=True, loss_type="bpr", tau=0.5,
+                   embedding_size=16, hidden_size=16)
+    torch.manual_seed(5)
+    m = MF(cfg)
+    batch = make_batch(rng, 7, 4, 6, cfg["n_items"], cfg["n_users"])
+    out = run_model(m, batch)
+    save("g8_mf_bpr_bias", **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}),
+         **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
+
+    # ---------------------------------------------------------------- G9 optimizer: 3 dense-Adam steps
+    for tag, wd, clip in (("wd0", 0.0, None), ("wd1e-6_clip", 1e-6, 0.1)):
+        cfg = base_cfg(model="SASRec", n_items=50, n_heads=2, loss_type="bpr", max_seq_len=6)
+        torch.manual_seed(77)
+        m = SASRec(cfg)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=wd)
+        arrs = pack("cfg.", {k: np.array(v) for k, v in cfg.items()})
+        arrs.update(pack("sd0.", sd_np(m)))
+        arrs["hp.wd"] = np.array(wd)
+        arrs["hp.clip"] = np.array(-1.0 if clip is None else clip)
+        for step in range(3):
+            batch = make_batch(rng, 4, 6, 3, cfg["n_items"], cfg["n_users"])
+            m.train()
+            tb = tt(batch)
+            loss, _, _, _ = m(user_id=tb["user_id"], item_id=tb["item_id"], label=tb["label"],
+                              item_seq=tb["item_seq"], item_seq_len=tb["item_seq_len"])
+            opt.zero_grad()
+            loss.backward()
+            if clip is not None:
+                torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
+            opt.step()
+            arrs.update(pack(f"in{step}.", batch))
+            arrs[f"loss{step}"] = loss.detach().numpy().copy()
+            arrs.update(pack(f"sd{step + 1}.", sd_np(m)))
+        save("g9_adam_" + tag, **arrs)
+
+
+if __name__ == "__main__":
+    main()
