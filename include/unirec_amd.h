@@ -1,0 +1,181 @@
+/* unirec_amd -- C ABI of the MI355X (gfx950) hot-path library for microsoft/UniRec.
+ *
+ * Drop-in boundary: the reference is pure Python on torch; the arithmetic of its
+ * training hot path lives in torch ops called from the files cited next to each entry point below
+ * (paths relative to the reference tree, tag 2024_08_07).  A maintainer binds these symbols with
+ * ctypes (INTEGRATION.md shows the stub); unirec_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; tensors are dense, row-major, fp32
+ *     unless stated; `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - all work is enqueued on `stream`, no hidden synchronisation, no allocation: scratch memory is
+ *     provided by the caller (sizes from the *_workspace_bytes queries);
+ *   - inputs are borrowed, outputs are written in place; functions return UR_OK (0) or a negative
+ *     UR_ERR_* code, and ur_last_error() then returns a thread-local message;
+ *   - ids: 0 is the padding id (row 0 of every table never receives a gradient).
+ */
+#ifndef UNIREC_AMD_H
+#define UNIREC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UR_OK 0
+#define UR_ERR_ARG (-1)         /* bad argument (null pointer, size, unsupported shape) */
+#define UR_ERR_HIP (-2)         /* a HIP runtime call or kernel launch failed */
+#define UR_ERR_UNSUPPORTED (-3) /* valid request that this build does not implement */
+
+/* hidden_act ids -- unirec/model/modules.py:337-345 (ACT2FN) */
+enum { UR_ACT_GELU = 0, UR_ACT_RELU = 1, UR_ACT_SWISH = 2, UR_ACT_TANH = 3, UR_ACT_SIGMOID = 4, UR_ACT_NONE = 5 };
+/* loss_type ids -- unirec/constants/loss_funcs.py:6-11 */
+enum { UR_LOSS_NONE = -1 /* scores only */, UR_LOSS_BCE = 0, UR_LOSS_BPR = 1, UR_LOSS_SOFTMAX = 2, UR_LOSS_CCL = 3, UR_LOSS_FULLSOFTMAX = 4 };
+
+const char* ur_last_error(void);
+int ur_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Embedding lookup: out[i,:] = table[idx[i],:]      (bit-exact copy)
+ * replaces nn.Embedding.forward as called by unirec/model/base/recommender.py:67 (forward_item_emb)
+ * and :137 (item_embedding_for_user); table created at unirec/model/base/reco_abc.py:168,170.
+ * idx_bytes = 4 (int32, the dtype of item_seq) or 8 (int64, the dtype of item_id). d % 4 == 0. */
+int ur_embedding_gather_f32(const float* table, int64_t n_rows, int d, const void* idx, int idx_bytes,
+                            int64_t n, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SASRec user encoder (unirec/model/sequential/sasrec.py:59-76 + unirec/model/modules.py:284-433):
+ *   x0 = LN(E[item_seq] + P[0..L-1]); n_layers x { MHA(+mask) -> FFN }; user_emb = x[:, L-1, :].
+ * Dropout is not applied (p = 0, as every reference example/benchmark script sets). */
+#define UR_MAX_LAYERS 8
+typedef struct UrSasrecCfg {
+  int32_t B;        /* sequences in this batch */
+  int32_t L;        /* max_seq_len */
+  int32_t d;        /* hidden_size == embedding_size (sasrec.py:25,60-66), d % 4 == 0, d <= 256 */
+  int32_t n_heads;  /* d % n_heads == 0 */
+  int32_t inner;    /* inner_size, % 4 == 0 */
+  int32_t n_layers; /* 1..UR_MAX_LAYERS */
+  int32_t act;      /* UR_ACT_* */
+  int32_t use_pos;  /* use_position_emb: adds P and enables the causal part of the mask (sasrec.py:43-52) */
+  float eps;        /* layer_norm_eps */
+  int32_t last_only; /* 1: exact last-position specialisation of the final layer */
+} UrSasrecCfg;
+
+/* Layout of the flat dense-parameter buffer (and of its gradient buffer). offsets_out receives
+ * UR_SASREC_N_GLOBAL + n_layers * UR_SASREC_N_PER_LAYER element offsets; returns the total number of
+ * floats, or a negative error code.
+ *   global   : [0] position_embedding.weight [(L+1),d]   [1] LayerNorm.weight [d]   [2] LayerNorm.bias [d]
+ *   per layer: [0] query.weight [1] key.weight [2] value.weight (contiguous => Wqkv [3d,d])
+ *              [3] query.bias   [4] key.bias   [5] value.bias   (contiguous => bqkv [3d])
+ *              [6] dense.weight [d,d] [7] dense.bias [8] attn LayerNorm.weight [9] attn LayerNorm.bias
+ *              [10] dense_1.weight [inner,d] [11] dense_1.bias [12] dense_2.weight [d,inner] [13] dense_2.bias
+ *              [14] ffn LayerNorm.weight [15] ffn LayerNorm.bias
+ * (state_dict names: SURVEY.md section 8b) */
+#define UR_SASREC_N_GLOBAL 3
+#define UR_SASREC_N_PER_LAYER 16
+int64_t ur_sasrec_param_layout(const UrSasrecCfg* cfg, int64_t* offsets_out);
+int64_t ur_sasrec_workspace_bytes(const UrSasrecCfg* cfg);
+
+/* forward: writes user_emb [B,d]; activations needed by the backward stay in `ws`. */
+int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
+                  const int32_t* item_seq, float* user_emb, void* ws, void* stream);
+/* backward (autograd of the above; the reference has no hand-written backward):
+ *   dense_grad  flat buffer, same layout as `dense`, OVERWRITTEN with d loss / d dense-params;
+ *   d_emb_rows  [B*L, d]: gradient w.r.t. the gathered rows E[item_seq[b,l]] (row-sparse form of
+ *               embedding_dense_backward; rows whose id is 0 are written as zeros: padding_idx=0). */
+int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
+                  const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
+                  float* d_emb_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused candidate gather + dot-product scorer + loss
+ *   scores[b,g] = ( <E[item_id[b,g]], user_emb[b]> + user_bias[user_id[b]] + item_bias[item_id[b,g]] ) / tau,
+ *   clamped to +-score_clip when score_clip > 0        (unirec/model/modules.py:49-67,
+ *                                                       unirec/model/base/recommender.py:76-96)
+ *   loss = _cal_loss(scores, label)                     (unirec/model/base/reco_abc.py:220-272,
+ *                                                       unirec/model/modules.py:15-35)
+ * The [B,G,d] candidate tensor is never materialised. */
+typedef struct UrLossCfg {
+  int32_t B, G, d;
+  int32_t loss_type;   /* UR_LOSS_BCE | BPR | SOFTMAX | CCL */
+  float tau;
+  float score_clip;    /* <= 0: off */
+  float ccl_w, ccl_m;
+} UrLossCfg;
+/* user_bias / item_bias / user_id may be NULL (bias off). label (int32 [B,G]) is required for BCE and
+ * SOFTMAX. Outputs: scores [B,G]; loss_out[2]: [0] = reduced loss (reduction=True), [1] = the mean's
+ * denominator (rows, elements or positives); loss_rows [2*B]: per-row numerators (for BPR/CCL the
+ * reduction=False row losses) followed by per-row denominators. */
+int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_emb, const float* item_table, int64_t n_items,
+                           const int64_t* item_id, const int32_t* label, const float* user_bias,
+                           const float* item_bias, const int64_t* user_id, float* scores, float* loss_rows,
+                           float* loss_out, void* stream);
+/* backward for upstream gradient d_loss (device scalar, NULL = 1.0); loss_out is the forward's output:
+ *   coef[b,g]   = d loss / d <E,u>            (so  dE[item_id[b,g]] += coef[b,g] * user_emb[b], implicit)
+ *   d_user[b,:] = sum_g coef[b,g] * E[item_id[b,g],:]
+ *   d_user_bias_rows[b] = sum_g coef[b,g]  (NULL to skip);  the item-bias row gradient equals coef. */
+int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_emb, const float* item_table, int64_t n_items,
+                           const int64_t* item_id, const int32_t* label, const float* scores,
+                           const float* loss_out, const float* d_loss, float* coef, float* d_user,
+                           float* d_user_bias_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row-sparse gradient of an embedding table (replaces embedding_dense_backward + the dense [N,d]
+ * gradient of nn.Embedding(padding_idx=0), unirec/model/base/reco_abc.py:170 / SURVEY.md K2).
+ * ur_rows_plan sorts the looked-up ids (stable LSD radix sort, deterministic), and produces
+ *   uniq_idx[u]  distinct ids in ascending order (id 0 included if looked up),
+ *   seg_start[u] start of id u's run in sorted_pos,     seg_start[n_uniq] = n,
+ *   sorted_pos[] lookup positions grouped by id (position p < n_a refers to ids_a, else to ids_b[p-n_a]),
+ *   n_uniq_dev[0] number of distinct ids (device int32; nothing is copied to the host).
+ * ids_a: int32 [n_a] (item_seq), ids_b: int64 [n_b] (item_id); either may be empty. */
+int64_t ur_rows_plan_workspace_bytes(int64_t n);
+int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
+                 int32_t* uniq_idx, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws,
+                 void* stream);
+/* uniq_grad[u,:] = sum over the run of uniq_idx[u] (in sorted, i.e. position, order) of
+ *   rows_a[p,:]                      for p <  n_a
+ *   coef_b[p-n_a] * vec_b[(p-n_a)/G,:] for p >= n_a     (the scorer's implicit candidate-row gradient)
+ * rows of id 0 are written as zeros. Also accumulates sum(uniq_grad^2) into sumsq_dev[0] when non-NULL. */
+int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
+                   const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
+                   const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer (torch.optim.Adam as built at unirec/facility/trainer.py:134-136 and stepped at :349;
+ * weight_decay is L2 added to the gradient; bias-corrected; denom = sqrt(v)/sqrt(1-b2^t) + eps).
+ * grad_scale_dev: optional device float multiplied into every gradient (global-norm clipping,
+ * trainer.py:347-348); NULL = 1. */
+typedef struct UrAdamCfg {
+  float lr, beta1, beta2, eps, weight_decay;
+  int32_t step; /* 1-based step count t of THIS update */
+} UrAdamCfg;
+int ur_dense_adam(const UrAdamCfg* cfg, float* param, const float* grad, float* m, float* v, int64_t n,
+                  const float* grad_scale_dev, void* stream);
+/* Row-wise Adam on the rows listed in uniq_idx (id 0 skipped).
+ * last_step == NULL : "rowwise" semantics, untouched rows do not move (torch SparseAdam-like, but with
+ *                     the global step in the bias correction).
+ * last_step != NULL : "lazy dense" semantics = the reference's dense Adam, evaluated lazily: int32
+ *                     last_step[N] remembers the step at which a row's (w,m,v) are valid; before the row
+ *                     is used, ur_lazy_adam_catchup applies the zero-gradient Adam steps it missed
+ *                     (exact for weight_decay == 0). */
+int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                        const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad,
+                        int32_t d, const float* grad_scale_dev, void* stream);
+/* brings rows uniq_idx[0..n_uniq) to the state "after step (cfg->step - 1)" */
+int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                         const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
+                         void* stream);
+/* same for a contiguous block of rows [row0, row0+n): flush before evaluation / checkpoint */
+int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, int64_t row0,
+                       int64_t n, int32_t d, void* stream);
+
+/* out[0] (+)= sum(x[i]^2), deterministic two-stage reduction; accumulate != 0 adds to out[0]. */
+int ur_sumsq(const float* x, int64_t n, float* out, int accumulate, void* ws_2048_floats, void* stream);
+/* scale_out[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))   (torch clip_grad_norm_ coefficient) */
+int ur_clip_coef(const float* sumsq, float max_norm, float* scale_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIREC_AMD_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of the C ABI declared in include/unirec_amd.h.
+
+The product path has NO CPU fallback: importing this module loads the in-tree HIP library and
+raises if it is missing (build it with ``python -m unirec_amd.build`` / ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunirec_amd.so")
+
+UR_MAX_LAYERS = 8
+UR_SASREC_N_GLOBAL = 3
+UR_SASREC_N_PER_LAYER = 16
+
+ACT_IDS = {"gelu": 0, "relu": 1, "swish": 2, "tanh": 3, "sigmoid": 4}
+LOSS_IDS = {"bce": 0, "bpr": 1, "softmax": 2, "ccl": 3, "fullsoftmax": 4}
+
+
+class UrSasrecCfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32), ("n_heads", C.c_int32),
+                ("inner", C.c_int32), ("n_layers", C.c_int32), ("act", C.c_int32), ("use_pos", C.c_int32),
+                ("eps", C.c_float), ("last_only", C.c_int32)]
+
+
+class UrLossCfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("G", C.c_int32), ("d", C.c_int32), ("loss_type", C.c_int32),
+                ("tau", C.c_float), ("score_clip", C.c_float), ("ccl_w", C.c_float), ("ccl_m", C.c_float)]
+
+
+class UrAdamCfg(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("step", C.c_int32)]
+
+
+class UrGruCfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32), ("H", C.c_int32)]
+
+
+P = C.c_void_p
+I64 = C.c_int64
+I32 = C.c_int32
+
+# name -> (restype, argtypes).  Every symbol include/unirec_amd.h declares must be listed here
+# (tests/test_abi.py parses the header and checks both directions).
+SIGNATURES = {
+    "ur_last_error": (C.c_char_p, []),
+    "ur_version": (C.c_int, []),
+    "ur_embedding_gather_f32": (C.c_int, [P, I64, C.c_int, P, C.c_int, I64, P, P]),
+    "ur_sasrec_param_layout": (I64, [C.POINTER(UrSasrecCfg), C.POINTER(I64)]),
+    "ur_sasrec_workspace_bytes": (I64, [C.POINTER(UrSasrecCfg)]),
+    "ur_sasrec_fwd": (C.c_int, [C.POINTER(UrSasrecCfg), P, I64, P, P, P, P, P]),
+    "ur_sasrec_bwd": (C.c_int, [C.POINTER(UrSasrecCfg), P, I64, P, P, P, P, P, P, P]),
+    "ur_gather_dot_loss_fwd": (C.c_int, [C.POINTER(UrLossCfg), P, P, I64, P, P, P, P, P, P, P, P, P]),
+    "ur_gather_dot_loss_bwd": (C.c_int, [C.POINTER(UrLossCfg), P, P, I64, P, P, P, P, P, P, P, P, P]),
+    "ur_rows_plan_workspace_bytes": (I64, [I64]),
+    "ur_rows_plan": (C.c_int, [P, I64, P, I64, I64, P, P, P, P, P, P]),
+    "ur_rows_reduce": (C.c_int, [P, P, P, P, I64, P, I64, P, P, I32, I32, P, P, P]),
+    "ur_dense_adam": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, P, P]),
+    "ur_sparse_adam_rows": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, P, I32, P, P]),
+    "ur_lazy_adam_catchup": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, I32, P]),
+    "ur_lazy_adam_flush": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, I64, I32, P]),
+    "ur_sumsq": (C.c_int, [P, I64, P, C.c_int, P, P]),
+    "ur_clip_coef": (C.c_int, [P, C.c_float, P, P]),
+}
+
+
+class UnirecAmdError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise UnirecAmdError(
+            f"{LIB_PATH} is missing: the HIP library has not been built (python -m unirec_amd.build). "
+            "unirec_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    """Raise UnirecAmdError (a RuntimeError, like TORCH_CHECK would) when a C call failed."""
+    if rc < 0:
+        msg = lib.ur_last_error()
+        raise UnirecAmdError(f"{what or 'unirec_amd'} failed (code {rc}): {msg.decode() if msg else ''}")
+    return rc

@@ -1,0 +1,69 @@
+"""Build the HIP C-ABI library in-tree:  python -m unirec_amd.build  ->  unirec_amd/libunirec_amd.so
+
+hipcc cross-compiles for gfx950 without a GPU.  Object files are cached in unirec_amd/csrc/_obj and
+rebuilt only when a source or header changed.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libunirec_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _digest(paths):
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build(verbose=True, force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "unirec_amd.h"))
+    jobs, objs = [], []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        tag = _digest([src] + hdrs)
+        obj = os.path.join(OBJ, f"{os.path.splitext(s)[0]}.{tag}.o")
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            for old in os.listdir(OBJ):
+                if old.startswith(os.path.splitext(s)[0] + "."):
+                    os.remove(os.path.join(OBJ, old))
+            lang = ["-x", "hip"] if s.endswith(".hip") else []
+            jobs.append((s, [HIPCC] + FLAGS + lang + ["-c", src, "-o", obj]))
+
+    def run(job):
+        name, cmd = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return name, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for name, rc, out in ex.map(run, jobs):
+                if verbose and out.strip():
+                    print(f"[{name}]\n{out}")
+                if rc != 0:
+                    raise RuntimeError(f"hipcc failed on {name}:\n{out}")
+    if jobs or force or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(f"built {LIB} ({len(jobs)} objects recompiled)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

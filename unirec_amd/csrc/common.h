@@ -1,0 +1,100 @@
+// Shared device/host helpers for the unirec_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/unirec_amd.h"
+
+namespace ur {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+// ---- error plumbing (thread-local message read back through ur_last_error) ----------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define UR_REQUIRE(cond, code, ...)              \
+  do {                                           \
+    if (!(cond)) return ::ur::fail((code), __VA_ARGS__); \
+  } while (0)
+
+#define UR_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return ::ur::fail(UR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+#define UR_LAUNCH_CHECK()                                                                    \
+  do {                                                                                       \
+    hipError_t _e = hipGetLastError();                                                       \
+    if (_e != hipSuccess)                                                                    \
+      return ::ur::fail(UR_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers -----------------------------------------------------------------------
+// xor-shuffle reduction across `width` consecutive lanes (width power of two <= 64).
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+// runtime-width variant (width power of two)
+__device__ __forceinline__ float group_sum_rt(float v, int width) {
+  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// activation ids shared with the host (UR_ACT_*)
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  switch (act) {
+    case UR_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    case UR_ACT_RELU: return fmaxf(x, 0.0f);
+    case UR_ACT_SWISH: return x / (1.0f + expf(-x));
+    case UR_ACT_TANH: return tanhf(x);
+    case UR_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    default: return x;
+  }
+}
+// derivative d act(x) / dx evaluated at the pre-activation x
+__device__ __forceinline__ float act_bwd(float x, int act) {
+  switch (act) {
+    case UR_ACT_GELU: {
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case UR_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+    case UR_ACT_SWISH: {
+      const float s = 1.0f / (1.0f + expf(-x));
+      return s * (1.0f + x * (1.0f - s));
+    }
+    case UR_ACT_TANH: {
+      const float t = tanhf(x);
+      return 1.0f - t * t;
+    }
+    case UR_ACT_SIGMOID: {
+      const float s = 1.0f / (1.0f + expf(-x));
+      return s * (1.0f - s);
+    }
+    default: return 1.0f;
+  }
+}
+
+}  // namespace ur

@@ -1,0 +1,394 @@
+// fp32 MFMA GEMMs for the SASRec / GRU dense contractions (v_mfma_f32_32x32x2_f32: exact fp32,
+// bit-equal to an fmaf chain -- MI355X_MICROARCH.md "Matrix cores").
+//
+//   gemm_nt : C[M,N] = epi( pro(A)[M,K] @ W[N,K]^T )        nn.Linear forward and, with a pre-transposed
+//             weight copy, the activation-gradient GEMM dX = dY @ W.
+//   gemm_tn : Out[R,Cc] = P[T,R]^T @ pro(Q)[T,Cc]            weight gradient dW = dY^T @ X (+ bias grad),
+//             split over the token dimension T with a deterministic second-stage reduction.
+//
+// Tiling: 256 threads = 4 waves in a 2x2 arrangement, each wave owns TM x TN MFMA tiles of 32x32.
+// Operands are staged global -> registers -> LDS (double buffered, one barrier per K-step); LDS rows
+// are padded to BK+4 floats so that the ds_read_b128 fragment reads are bank-conflict free.
+#include "common.h"
+#include "kernels.h"
+
+namespace ur {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LS = BK + 4;  // padded LDS row stride (floats)
+
+__device__ __forceinline__ float4 act4(float4 v, int act) {
+  v.x = act_fwd(v.x, act); v.y = act_fwd(v.y, act); v.z = act_fwd(v.z, act); v.w = act_fwd(v.w, act);
+  return v;
+}
+
+template <int BM, int BN, int PRO, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AV = BM / 32, WV = BN / 32;  // float4 loads per thread per K-step
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][BM*LS]
+  float* Ws = smem + 2 * BM * LS;   // [2][BN*LS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int c4 = tid & 7, lrow = tid >> 3;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[AV], rw[WV];
+  auto load_global = [&](int kt) {
+    const int k = kt * BK + c4 * 4;
+    const bool kin = k < a.K;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int m = m0 + lrow + 32 * i;
+      ra[i] = (kin && m < a.M) ? *(const float4*)(a.A + (long long)m * a.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int n = n0 + lrow + 32 * i;
+      rw[i] = (kin && n < a.N) ? *(const float4*)(a.W + (long long)n * a.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      float4 v = ra[i];
+      if (PRO == PRO_ACT) v = act4(v, a.act);
+      *(float4*)(As + buf * BM * LS + (lrow + 32 * i) * LS + c4 * 4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) *(float4*)(Ws + buf * BN * LS + (lrow + 32 * i) * LS + c4 * 4) = rw[i];
+  };
+
+  const int nk = (a.K + BK - 1) / BK;
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  const int frow = lane & 31, fk = 4 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_global(kt + 1);
+    const float* Ab = As + buf * BM * LS + (wr * (BM / 2) + frow) * LS + fk;
+    const float* Wb = Ws + buf * BN * LS + (wc * (BN / 2) + frow) * LS + fk;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const float4*)(Ab + i * 32 * LS + kk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *(const float4*)(Wb + j * 32 * LS + kk);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 inside the 32x32 tile
+  const int lcol = lane & 31, lrow4 = 4 * (lane >> 5);
+  if constexpr (EPI != EPI_BIAS_RES_LN) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wc * (BN / 2) + j * 32 + lcol;
+        if (n >= a.N) continue;
+        const float bias = (EPI == EPI_BIAS) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
+          if (m >= a.M) continue;
+          float v = acc[i][j][r] + bias;
+          if (EPI == EPI_MUL_DACT) v *= act_bwd(a.aux[(long long)m * a.ldaux + n], a.act);
+          if (EPI == EPI_ADD) v += a.aux[(long long)m * a.ldaux + n];
+          a.C[(long long)m * a.ldc + n] = v;
+        }
+      }
+  } else {
+    // t = acc + bias + residual staged through LDS (the staging buffers are free after the last barrier),
+    // then one 32-lane group per row computes LayerNorm and writes y, xhat, rstd.
+    constexpr int CS = BN + 4;
+    constexpr int NV = BN >= 128 ? BN / 128 : 1;
+    float* Cs = smem;  // [BM][CS]
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nl = wc * (BN / 2) + j * 32 + lcol, n = n0 + nl;
+        const float bias = (n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4, m = m0 + ml;
+          float v = acc[i][j][r] + bias;
+          if (m < a.M && n < a.N) v += a.aux[(long long)m * a.ldaux + n];
+          Cs[ml * CS + nl] = v;
+        }
+      }
+    __syncthreads();
+    const int g = tid >> 5, t = tid & 31;
+    const int n4 = a.N >> 2;
+    const float inv_n = 1.0f / (float)a.N;
+    for (int ml = g; ml < BM; ml += 8) {
+      const int m = m0 + ml;
+      if (m >= a.M) break;
+      float4 v[NV];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = t + 32 * k;
+        if (c < n4) {
+          v[k] = *(const float4*)(Cs + ml * CS + c * 4);
+          s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+      }
+      const float mean = group_sum<32>(s) * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = t + 32 * k;
+        if (c < n4) {
+          v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+          q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+        }
+      }
+      const float rstd = 1.0f / sqrtf(group_sum<32>(q) * inv_n + a.eps);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = t + 32 * k;
+        if (c < n4) {
+          const float4 gm = *(const float4*)(a.gamma + c * 4), bt = *(const float4*)(a.beta + c * 4);
+          float4 h, o;
+          h.x = v[k].x * rstd; h.y = v[k].y * rstd; h.z = v[k].z * rstd; h.w = v[k].w * rstd;
+          o.x = h.x * gm.x + bt.x; o.y = h.y * gm.y + bt.y; o.z = h.z * gm.z + bt.z; o.w = h.w * gm.w + bt.w;
+          *(float4*)(a.xhat + (long long)m * a.N + c * 4) = h;
+          *(float4*)(a.C + (long long)m * a.ldc + c * 4) = o;
+        }
+      }
+      if (t == 0) a.rstd[m] = rstd;
+    }
+  }
+}
+
+template <int BM, int BN, int PRO, int EPI>
+static int launch_nt(const GemmArgs& a, hipStream_t st) {
+  dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM));
+  const size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr;
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, PRO, EPI>), grid, dim3(256), lds, st, a);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+template <int PRO, int EPI>
+static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
+  // enough 128x128 tiles to fill 256 CUs twice? otherwise use 64-row tiles for more workgroups
+  const long long big = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
+  if (a.N <= 64) return launch_nt<64, 64, PRO, EPI>(a, st);
+  if (big >= 512) return launch_nt<128, 128, PRO, EPI>(a, st);
+  return launch_nt<64, 128, PRO, EPI>(a, st);
+}
+
+int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0) return UR_OK;
+  if ((a.K & 3) || (a.lda & 3) || (a.ldw & 3)) return fail(UR_ERR_ARG, "gemm_nt: K/lda/ldw must be multiples of 4 (K=%d)", a.K);
+  if (epi == EPI_BIAS_RES_LN) {
+    if (a.N > 256 || (a.N & 3) || a.ldc != a.N) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm needs N<=256, N%%4==0 (N=%d)", a.N);
+    if (a.N <= 128) return pro == PRO_ACT ? launch_nt<64, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
+                                          : launch_nt<64, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
+    return pro == PRO_ACT ? launch_nt<64, 256, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
+                          : launch_nt<64, 256, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
+  }
+  if (pro == PRO_ACT) {
+    if (epi == EPI_BIAS) return dispatch_tile<PRO_ACT, EPI_BIAS>(a, st);
+    return fail(UR_ERR_UNSUPPORTED, "gemm_nt: PRO_ACT with epilogue %d", epi);
+  }
+  switch (epi) {
+    case EPI_NONE: return dispatch_tile<PRO_NONE, EPI_NONE>(a, st);
+    case EPI_BIAS: return dispatch_tile<PRO_NONE, EPI_BIAS>(a, st);
+    case EPI_MUL_DACT: return dispatch_tile<PRO_NONE, EPI_MUL_DACT>(a, st);
+    case EPI_ADD: return dispatch_tile<PRO_NONE, EPI_ADD>(a, st);
+  }
+  return fail(UR_ERR_UNSUPPORTED, "gemm_nt: epilogue %d", epi);
+}
+
+// ======================================================================================== gemm_tn
+constexpr int TB = 128;  // output tile (rows of Out = columns of P) x (cols of Out = columns of Q)
+constexpr int BT = 32;   // tokens per LDS stage
+
+template <int PRO>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q,
+                                                      int ldq, int T, int R, int Cc, int tok_per_split, int act,
+                                                      float* __restrict__ part, float* __restrict__ bias_part) {
+  __shared__ __attribute__((aligned(16))) float Ps[2][BT * TB];
+  __shared__ __attribute__((aligned(16))) float Qs[2][BT * TB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int c0 = blockIdx.x * TB, r0 = blockIdx.y * TB, sp = blockIdx.z;
+  const int t_begin = sp * tok_per_split;
+  const int t_end = min(T, t_begin + tok_per_split);
+  const int c4 = tid & 31, trow = tid >> 5;  // 8 token rows per pass, 4 passes
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum = 0.f;
+
+  float4 rp[4], rq[4];
+  auto load_global = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + trow + 8 * i;
+      const bool tin = t < t_end;
+      const int r = r0 + c4 * 4, c = c0 + c4 * 4;
+      rp[i] = (tin && r < R) ? *(const float4*)(P + (long long)t * ldp + r) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rq[i] = (tin && c < Cc) ? *(const float4*)(Q + (long long)t * ldq + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(float4*)(&Ps[buf][(trow + 8 * i) * TB + c4 * 4]) = rp[i];
+      float4 v = rq[i];
+      if (PRO == PRO_ACT) v = act4(v, act);
+      *(float4*)(&Qs[buf][(trow + 8 * i) * TB + c4 * 4]) = v;
+    }
+  };
+
+  const int nt = (t_end - t_begin + BT - 1) / BT;
+  if (nt > 0) {
+    load_global(t_begin);
+    store_lds(0);
+  }
+  __syncthreads();
+  const int fcol = lane & 31, ft = lane >> 5;
+  for (int it = 0; it < nt; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nt) load_global(t_begin + (it + 1) * BT);
+    const float* Pb = &Ps[buf][ft * TB + wr * 64 + fcol];
+    const float* Qb = &Qs[buf][ft * TB + wc * 64 + fcol];
+#pragma unroll
+    for (int kk = 0; kk < BT; kk += 2) {
+      const float a0 = Pb[kk * TB], a1 = Pb[kk * TB + 32];
+      const float b0 = Qb[kk * TB], b1 = Qb[kk * TB + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (bias_part != nullptr && blockIdx.x == 0 && tid < TB) {
+#pragma unroll 8
+      for (int t = 0; t < BT; ++t) bsum += Ps[buf][t * TB + tid];
+    }
+    if (it + 1 < nt) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* out = part + (long long)sp * R * Cc;
+  const int lcol = lane & 31, lrow4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + lcol;
+      if (c >= Cc) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = r0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
+        if (rr < R) out[(long long)rr * Cc + c] = acc[i][j][r];
+      }
+    }
+  if (bias_part != nullptr && blockIdx.x == 0 && tid < TB && r0 + tid < R) bias_part[(long long)sp * R + r0 + tid] = bsum;
+}
+
+// out[i] = sum_s part[s*n + i], fixed order
+__global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long long n, int cols, float* __restrict__ out,
+                                     int ldo) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += part[(long long)s * n + i];
+  out[(i / cols) * ldo + (i % cols)] = acc;
+}
+
+static int tn_splits(int T, int R, int Cc) {
+  const int tiles = cdiv(R, TB) * cdiv(Cc, TB);
+  int s = cdiv(512, tiles);
+  const int smax = cdiv(T, 256);
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  return s;
+}
+
+long long gemm_tn_ws_floats(int T, int R, int Cc) {
+  const int s = tn_splits(T, R, Cc);
+  return (long long)s * R * Cc + (long long)s * R;
+}
+
+int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act, float* out,
+            int ldo, float* bias_out, float* ws, hipStream_t st) {
+  if ((R & 3) || (Cc & 3) || (ldp & 3) || (ldq & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
+  const int S = tn_splits(T, R, Cc);
+  int tps = cdiv(T, S);
+  tps = cdiv(tps, BT) * BT;
+  float* part = ws;
+  float* bias_part = bias_out ? ws + (long long)S * R * Cc : nullptr;
+  dim3 grid(cdiv(Cc, TB), cdiv(R, TB), S);
+  if (pro_act_on_q)
+    hipLaunchKernelGGL((gemm_tn_kernel<PRO_ACT>), grid, dim3(256), 0, st, P, ldp, Q, ldq, T, R, Cc, tps, act, part, bias_part);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<PRO_NONE>), grid, dim3(256), 0, st, P, ldp, Q, ldq, T, R, Cc, tps, act, part, bias_part);
+  UR_LAUNCH_CHECK();
+  const long long n = (long long)R * Cc;
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, S, n, Cc, out, ldo);
+  UR_LAUNCH_CHECK();
+  if (bias_out) {
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(R, 256)), dim3(256), 0, st, bias_part, S, (long long)R, R, bias_out, R);
+    UR_LAUNCH_CHECK();
+  }
+  return UR_OK;
+}
+
+// ------------------------------------------------------------------------------------- transpose
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int rows, int cols,
+                                                        float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    if (by + j < rows && bx + tx < cols) tile[j][tx] = src[(long long)(by + j) * cols + bx + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (bx + j < cols && by + tx < rows) dst[(long long)(bx + j) * rows + by + tx] = tile[tx][j];
+}
+
+int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, st, src, rows, cols, dst);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+}  // namespace ur

@@ -1,0 +1,58 @@
+// Internal launcher declarations shared between the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ur {
+
+constexpr int LN_BWD_MAX_BLOCKS = 512;
+
+// ---- rowops.hip
+int gather_rows(const float* table, const void* idx, int idx_bytes, long long n, int d, float* out, hipStream_t st);
+int embed_ln_fwd(const int* seq, const float* table, const float* pos, const float* gamma, const float* beta, float eps,
+                 int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st);
+int ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, int M, int d, float* y,
+           float* xhat, float* rstd, hipStream_t st);
+// part_ws: LN_BWD_MAX_BLOCKS * 2 * d floats
+int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* add_in,
+           const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st);
+int pos_grad(const float* dx, int B, int L, int d, float* dpos, hipStream_t st);
+
+// ---- gemm.hip
+// C[M,N] = epi( pro(A)[M,K] @ W[N,K]^T )
+enum GemmPro { PRO_NONE = 0, PRO_ACT = 1 };
+enum GemmEpi {
+  EPI_NONE = 0,      // C = acc
+  EPI_BIAS = 1,      // C = acc + bias[n]
+  EPI_BIAS_RES_LN = 2,  // t = acc + bias[n] + res[m,n]; C = LN(t)*gamma+beta; also xhat, rstd
+  EPI_MUL_DACT = 3,  // C = acc * act'(aux[m,n])
+  EPI_ADD = 4,       // C = acc + aux[m,n]
+};
+struct GemmArgs {
+  const float* A; int lda;
+  const float* W; int ldw;
+  float* C; int ldc;
+  int M, N, K;
+  int act;              // for PRO_ACT / EPI_MUL_DACT
+  const float* bias;    // [N]
+  const float* aux; int ldaux;   // residual / addend / pre-activation
+  const float* gamma; const float* beta; float eps;
+  float* xhat; float* rstd;      // EPI_BIAS_RES_LN outputs
+};
+int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st);
+
+// Out[R,Cc] = P[T,R]^T @ pro(Q)[T,Cc];  bias_out[R] = colsum(P) (nullable). Deterministic split over T.
+// ws: gemm_tn_ws_floats(R, Cc) floats.
+long long gemm_tn_ws_floats(int T, int R, int Cc);
+int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act,
+            float* out, int ldo, float* bias_out, float* ws, hipStream_t st);
+// dst[c,r] = src[r,c]
+int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
+
+// ---- attention.hip
+long long attn_lse_floats(int B, int H, int L);
+int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int causal, float* ctx, float* lse,
+             int q_last_only, hipStream_t st);
+int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dctx, const float* lse, int B, int L,
+             int d, int H, int causal, float* dqkv, int q_last_only, hipStream_t st);
+
+}  // namespace ur

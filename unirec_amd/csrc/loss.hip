@@ -1,0 +1,312 @@
+// Fused candidate gather + dot-product scorer + loss, forward and backward.
+// One workgroup per batch row b; a group of TPR lanes owns one candidate at a time: it reads the
+// candidate's table row once (coalesced float4), dots it with the user vector held in registers and
+// emits one float -- the [B,G,d] candidate tensor of the reference never exists.
+#include "common.h"
+#include "kernels.h"
+
+namespace ur {
+
+constexpr float kEps = 1e-8f;  // unirec/constants/global_variables.py:4
+constexpr int MAXV = 4;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = group_max<64>(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = -INFINITY;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s = fmaxf(s, red[w]);
+  return s;
+}
+
+template <int TPR>
+__global__ __launch_bounds__(256) void scorer_loss_fwd_kernel(UrLossCfg c, const float4* __restrict__ user_emb,
+                                                              const float4* __restrict__ table, const long long* __restrict__ item_id,
+                                                              const int* __restrict__ label, const float* __restrict__ user_bias,
+                                                              const float* __restrict__ item_bias, const long long* __restrict__ user_id,
+                                                              float* __restrict__ scores, float* __restrict__ loss_rows,
+                                                              float* __restrict__ cnt_rows) {
+  extern __shared__ float sc[];  // [G] scores of this row, then 8 floats of reduction scratch
+  float* red = sc + c.G;
+  const int b = blockIdx.x, G = c.G, d4 = c.d / 4;
+  const int groups = 256 / TPR, g0 = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  float4 u[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int col = t + k * TPR;
+    u[k] = col < d4 ? user_emb[(long long)b * d4 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float ub = user_bias ? user_bias[user_id[b]] : 0.f;
+  const float inv_tau = 1.0f / c.tau;
+  for (int g = g0; g < G; g += groups) {
+    const long long id = item_id[(long long)b * G + g];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int col = t + k * TPR;
+      if (col < d4) {
+        const float4 e = table[id * d4 + col];
+        s += (e.x * u[k].x + e.y * u[k].y) + (e.z * u[k].z + e.w * u[k].w);
+      }
+    }
+    s = group_sum<TPR>(s);
+    if (t == 0) {
+      s += ub;
+      if (item_bias) s += item_bias[id];
+      s = s / c.tau;
+      if (c.score_clip > 0.f) s = fminf(fmaxf(s, -c.score_clip), c.score_clip);
+      sc[g] = s;
+      scores[(long long)b * G + g] = s;
+    }
+  }
+  (void)inv_tau;
+  __syncthreads();
+  // ---- per-row loss
+  float part = 0.f, cnt = 0.f;
+  if (c.loss_type < 0) {  // UR_LOSS_NONE: scores only
+    cnt = 1.f;
+  } else if (c.loss_type == UR_LOSS_BPR) {
+    const float s0 = sc[0];
+    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) part += -logf(kEps + 1.0f / (1.0f + expf(-(s0 - sc[g]))));
+    part = block_sum(part, red) / (float)(G - 1);
+    cnt = 1.f;
+  } else if (c.loss_type == UR_LOSS_SOFTMAX) {
+    float m = -INFINITY;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) m = fmaxf(m, sc[g]);
+    m = block_max(m, red);
+    float l = 0.f;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) l += expf(sc[g] - m);
+    const float lse = m + logf(block_sum(l, red));
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+      if (label[(long long)b * G + g] > 0) {
+        part += lse - sc[g];
+        cnt += 1.f;
+      }
+    part = block_sum(part, red);
+    cnt = block_sum(cnt, red);
+  } else if (c.loss_type == UR_LOSS_BCE) {
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+      const float p = 1.0f / (1.0f + expf(-sc[g]));  // clamp(sigmoid, -EPS, 1-EPS) is the identity in fp32
+      const float y = (float)label[(long long)b * G + g];
+      part += -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+    }
+    part = block_sum(part, red);
+    cnt = (float)G;
+  } else {  // CCL
+    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) part += fmaxf(sc[g] - c.ccl_m, 0.f);
+    part = 1.f - sc[0] + c.ccl_w * block_sum(part, red) / (float)(G - 1);
+    cnt = 1.f;
+  }
+  if (threadIdx.x == 0) {
+    loss_rows[b] = part;
+    cnt_rows[b] = cnt;
+  }
+}
+
+// loss = sum(loss_rows) / sum(cnt_rows)   (single block, fixed order)
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ loss_rows, const float* __restrict__ cnt_rows,
+                                                          int B, float* __restrict__ out) {
+  __shared__ float red[8];
+  float s = 0.f, n = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    s += loss_rows[i];
+    n += cnt_rows[i];
+  }
+  s = block_sum(s, red);
+  n = block_sum(n, red);
+  if (threadIdx.x == 0) {
+    out[0] = s / n;
+    out[1] = n;
+  }
+}
+
+template <int TPR>
+__global__ __launch_bounds__(256) void scorer_loss_bwd_kernel(UrLossCfg c, const float4* __restrict__ user_emb,
+                                                              const float4* __restrict__ table, const long long* __restrict__ item_id,
+                                                              const int* __restrict__ label, const float* __restrict__ scores,
+                                                              const float* __restrict__ d_loss, const float* __restrict__ norm,
+                                                              float* __restrict__ coef, float4* __restrict__ d_user,
+                                                              float* __restrict__ d_user_bias_rows) {
+  extern __shared__ float sh[];  // [G] coef, then [groups][d] partial d_user, then 8 scratch
+  constexpr int groups = 256 / TPR;
+  const int b = blockIdx.x, G = c.G, d4 = c.d / 4, d = c.d;
+  float* cf = sh;
+  float* acc_lds = sh + G;
+  float* red = acc_lds + groups * d;
+  const int g0 = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const float up = (d_loss ? d_loss[0] : 1.0f);
+  const float total = norm[1];  // denominator of the mean (rows, pairs or positives)
+  const float* s = scores + (long long)b * G;
+  // ---- d loss / d score'
+  if (c.loss_type == UR_LOSS_BPR) {
+    float a0 = 0.f;
+    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) {
+      const float sg = 1.0f / (1.0f + expf(-(s[0] - s[g])));
+      const float w = sg * (1.f - sg) / (kEps + sg) / ((float)(G - 1) * total);
+      cf[g] = w;
+      a0 -= w;
+    }
+    a0 = block_sum(a0, red);
+    if (threadIdx.x == 0) cf[0] = a0;
+  } else if (c.loss_type == UR_LOSS_SOFTMAX) {
+    float m = -INFINITY;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) m = fmaxf(m, s[g]);
+    m = block_max(m, red);
+    float l = 0.f, np = 0.f;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+      l += expf(s[g] - m);
+      np += (label[(long long)b * G + g] > 0) ? 1.f : 0.f;
+    }
+    l = block_sum(l, red);
+    np = block_sum(np, red);
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+      cf[g] = (np * expf(s[g] - m) / l - ((label[(long long)b * G + g] > 0) ? 1.f : 0.f)) / total;
+  } else if (c.loss_type == UR_LOSS_BCE) {
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+      const float p = 1.0f / (1.0f + expf(-s[g]));
+      const float y = (float)label[(long long)b * G + g];
+      // d/ds of -(y log p + (1-y) log(1-p)) with torch's log clamp at -100 (gradient 0 where clamped)
+      const float gp = (logf(p) > -100.f ? y * (1.f - p) : 0.f) - (logf(1.f - p) > -100.f ? (1.f - y) * p : 0.f);
+      cf[g] = -gp / total;
+    }
+  } else {  // CCL
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+      cf[g] = (g == 0) ? -1.f / total : ((s[g] - c.ccl_m > 0.f) ? c.ccl_w / ((float)(G - 1) * total) : 0.f);
+  }
+  __syncthreads();
+  float bsum = 0.f;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float v = cf[g] * up / c.tau;
+    if (c.score_clip > 0.f && fabsf(s[g]) >= c.score_clip) v = 0.f;
+    cf[g] = v;
+    coef[(long long)b * G + g] = v;
+    bsum += v;
+  }
+  if (d_user_bias_rows) {
+    bsum = block_sum(bsum, red);
+    if (threadIdx.x == 0) d_user_bias_rows[b] = bsum;
+  }
+  __syncthreads();
+  // ---- d_user[b,:] = sum_g coef[g] * E[item_id[b,g],:]
+  float4 acc[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = g0; g < G; g += groups) {
+    const long long id = item_id[(long long)b * G + g];
+    const float w = cf[g];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int col = t + k * TPR;
+      if (col < d4) {
+        const float4 e = table[id * d4 + col];
+        acc[k].x = fmaf(w, e.x, acc[k].x); acc[k].y = fmaf(w, e.y, acc[k].y);
+        acc[k].z = fmaf(w, e.z, acc[k].z); acc[k].w = fmaf(w, e.w, acc[k].w);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int col = t + k * TPR;
+    if (col < d4) *(float4*)(acc_lds + g0 * d + col * 4) = acc[k];
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < d; col += blockDim.x) {
+    float v = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < groups; ++gg) v += acc_lds[gg * d + col];
+    ((float*)d_user)[(long long)b * d + col] = v;
+  }
+}
+
+static inline int pick_tpr(int d) {
+  int d4 = d / 4, t = 4;
+  while (t < d4 && t < 32) t <<= 1;
+  return t;
+}
+
+}  // namespace ur
+
+using namespace ur;
+
+static int check_loss_cfg(const UrLossCfg* c, const char* who, bool fwd = false) {
+  UR_REQUIRE(c != nullptr, UR_ERR_ARG, "%s: null cfg", who);
+  UR_REQUIRE(c->B > 0 && c->G > 0, UR_ERR_ARG, "%s: B=%d G=%d", who, c->B, c->G);
+  UR_REQUIRE(c->d > 0 && c->d % 4 == 0 && c->d <= 512, UR_ERR_ARG, "%s: d=%d must be a multiple of 4, <= 512", who, c->d);
+  UR_REQUIRE(c->G <= 8192, UR_ERR_UNSUPPORTED, "%s: group size G=%d > 8192", who, c->G);
+  UR_REQUIRE(c->loss_type >= (fwd ? UR_LOSS_NONE : UR_LOSS_BCE) && c->loss_type <= UR_LOSS_CCL, UR_ERR_UNSUPPORTED,
+             "%s: loss_type=%d is not a sampled loss (fullsoftmax scores all N items: not implemented)", who, c->loss_type);
+  UR_REQUIRE((c->loss_type != UR_LOSS_BPR && c->loss_type != UR_LOSS_CCL) || c->G >= 2, UR_ERR_ARG, "%s: pairwise loss needs G >= 2", who);
+  UR_REQUIRE(c->tau != 0.f, UR_ERR_ARG, "%s: tau == 0", who);
+  return UR_OK;
+}
+
+extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_emb, const float* item_table, int64_t n_items,
+                                      const int64_t* item_id, const int32_t* label, const float* user_bias,
+                                      const float* item_bias, const int64_t* user_id, float* scores, float* loss_rows,
+                                      float* loss_out, void* stream) {
+  int rc = check_loss_cfg(cfg, "ur_gather_dot_loss_fwd", true);
+  if (rc) return rc;
+  UR_REQUIRE(user_emb && item_table && item_id && scores && loss_rows && loss_out, UR_ERR_ARG, "ur_gather_dot_loss_fwd: null pointer");
+  UR_REQUIRE(n_items > 0, UR_ERR_ARG, "ur_gather_dot_loss_fwd: n_items");
+  UR_REQUIRE(label || (cfg->loss_type != UR_LOSS_BCE && cfg->loss_type != UR_LOSS_SOFTMAX), UR_ERR_ARG,
+             "ur_gather_dot_loss_fwd: label is required for bce/softmax");
+  UR_REQUIRE(!user_bias || user_id, UR_ERR_ARG, "ur_gather_dot_loss_fwd: user_bias needs user_id");
+  hipStream_t st = as_stream(stream);
+  const int tpr = pick_tpr(cfg->d);
+  const size_t lds = (cfg->G + 8) * sizeof(float);
+  float* cnt_rows = loss_rows + cfg->B;  // loss_rows buffer is [2*B]: losses then counts
+#define GO(T) hipLaunchKernelGGL((scorer_loss_fwd_kernel<T>), dim3(cfg->B), dim3(256), lds, st, *cfg, (const float4*)user_emb, \
+                                 (const float4*)item_table, (const long long*)item_id, label, user_bias, item_bias,            \
+                                 (const long long*)user_id, scores, loss_rows, cnt_rows)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, loss_rows, cnt_rows, cfg->B, loss_out);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_emb, const float* item_table, int64_t n_items,
+                                      const int64_t* item_id, const int32_t* label, const float* scores,
+                                      const float* loss_out, const float* d_loss, float* coef, float* d_user,
+                                      float* d_user_bias_rows, void* stream) {
+  int rc = check_loss_cfg(cfg, "ur_gather_dot_loss_bwd");
+  if (rc) return rc;
+  UR_REQUIRE(user_emb && item_table && item_id && scores && loss_out && coef && d_user, UR_ERR_ARG,
+             "ur_gather_dot_loss_bwd: null pointer");
+  UR_REQUIRE(label || (cfg->loss_type != UR_LOSS_BCE && cfg->loss_type != UR_LOSS_SOFTMAX), UR_ERR_ARG,
+             "ur_gather_dot_loss_bwd: label is required for bce/softmax");
+  (void)n_items;
+  hipStream_t st = as_stream(stream);
+  const int tpr = pick_tpr(cfg->d);
+  const int groups = 256 / tpr;
+  const size_t lds = ((size_t)cfg->G + (size_t)groups * cfg->d + 8) * sizeof(float);
+  UR_REQUIRE(lds <= 64 * 1024, UR_ERR_UNSUPPORTED, "ur_gather_dot_loss_bwd: LDS need %zu bytes", lds);
+#define GO(T) hipLaunchKernelGGL((scorer_loss_bwd_kernel<T>), dim3(cfg->B), dim3(256), lds, st, *cfg, (const float4*)user_emb, \
+                                 (const float4*)item_table, (const long long*)item_id, label, scores, d_loss, loss_out, coef,  \
+                                 (float4*)d_user, d_user_bias_rows)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}

@@ -1,0 +1,110 @@
+// Dense Adam over the flat dense-parameter buffer, gradient-norm helpers, and the library's error plumbing.
+#include <stdarg.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ur {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// torch.optim.Adam single-tensor update (weight_decay folded into the gradient)
+__global__ __launch_bounds__(256) void dense_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                         float wd, float bc1, float bc2s, const float* __restrict__ scale_dev) {
+  const float scale = scale_dev ? *scale_dev : 1.0f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float w = p[i];
+    const float gr = g[i] * scale + wd * w;
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = w - (lr / bc1) * (mi / (sqrtf(vi) / bc2s + eps));
+  }
+}
+
+// stage 1: part[blk] = sum over a contiguous slice; stage 2: single block sums the parts in order
+__global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ x, long long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  const long long per = (n + gridDim.x - 1) / gridDim.x;
+  const long long b = (long long)blockIdx.x * per, e = b + per < n ? b + per : n;
+  float s = 0.f;
+  for (long long i = b + threadIdx.x; i < e; i += blockDim.x) s = fmaf(x[i], x[i], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_stage2(const float* __restrict__ part, int nparts, float* __restrict__ out, int accumulate) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    out[0] = accumulate ? out[0] + t : t;
+  }
+}
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ out) {
+  const float c = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+  out[0] = c < 1.f ? c : 1.f;
+}
+
+}  // namespace ur
+
+using namespace ur;
+
+extern "C" const char* ur_last_error(void) { return g_err; }
+extern "C" int ur_version(void) { return 100; }
+
+extern "C" int ur_dense_adam(const UrAdamCfg* cfg, float* param, const float* grad, float* m, float* v, int64_t n,
+                             const float* grad_scale_dev, void* stream) {
+  UR_REQUIRE(cfg && param && grad && m && v, UR_ERR_ARG, "ur_dense_adam: null pointer");
+  UR_REQUIRE(cfg->step >= 1 && n >= 0, UR_ERR_ARG, "ur_dense_adam: step=%d n=%lld", cfg->step, (long long)n);
+  if (n == 0) return UR_OK;
+  const float bc1 = 1.f - powf(cfg->beta1, (float)cfg->step);
+  const float bc2s = sqrtf(1.f - powf(cfg->beta2, (float)cfg->step));
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dense_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, m, v, (long long)n,
+                     cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, bc1, bc2s, grad_scale_dev);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_sumsq(const float* x, int64_t n, float* out, int accumulate, void* ws_2048_floats, void* stream) {
+  UR_REQUIRE(x && out && ws_2048_floats && n >= 0, UR_ERR_ARG, "ur_sumsq: bad argument");
+  hipStream_t st = as_stream(stream);
+  int nparts = (int)((n + 4095) / 4096);
+  if (nparts > 2048) nparts = 2048;
+  if (nparts < 1) nparts = 1;
+  hipLaunchKernelGGL(sumsq_stage1, dim3(nparts), dim3(256), 0, st, x, (long long)n, (float*)ws_2048_floats);
+  UR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, st, (const float*)ws_2048_floats, nparts, out, accumulate);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_clip_coef(const float* sumsq, float max_norm, float* scale_out, void* stream) {
+  UR_REQUIRE(sumsq && scale_out && max_norm > 0.f, UR_ERR_ARG, "ur_clip_coef: bad argument");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, as_stream(stream), sumsq, max_norm, scale_out);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}

@@ -1,0 +1,348 @@
+// Row-wise HBM-bound kernels: embedding gather, fused gather+pos+LayerNorm, LayerNorm backward.
+// One row is owned by a group of TPR consecutive lanes (TPR | 64), each lane holding float4 column
+// chunks c = t, t+TPR, ...; row reductions are xor-shuffles inside the group (no LDS).
+#include "common.h"
+#include "kernels.h"
+
+namespace ur {
+
+static inline int pick_tpr(int d) {
+  int d4 = d / 4, t = 4;
+  while (t < d4 && t < 32) t <<= 1;
+  return t;  // 4, 8, 16 or 32; rows wider than 4*TPR floats loop (VPT <= MAXV)
+}
+constexpr int MAXV = 4;  // float4 chunks per lane: d <= 4*32*4 = 512
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------ gather
+// UNROLL rows in flight per lane group: random 512-B row reads need many outstanding loads per CU.
+template <typename IdxT, int TPR, int UNROLL>
+__global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ table, const IdxT* __restrict__ idx,
+                                                     long long n, int d4, float4* __restrict__ out) {
+  const int groups = 256 / TPR;
+  const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const long long stride = (long long)gridDim.x * groups * UNROLL;
+  for (long long base = ((long long)blockIdx.x * groups + g) * UNROLL; base < n; base += stride) {
+    long long id[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) id[u] = (base + u < n) ? (long long)idx[base + u] : 0;
+    for (int c = t; c < d4; c += TPR) {
+      float4 v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = table[id[u] * d4 + c];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        if (base + u < n) __builtin_nontemporal_store(*(const vf4*)&v[u], (vf4*)&out[(base + u) * d4 + c]);
+    }
+  }
+}
+
+template <typename IdxT>
+static int launch_gather(const float* table, const void* idx, long long n, int d, float* out, hipStream_t st) {
+  const int d4 = d / 4;
+  const int tpr = pick_tpr(d);
+  const int groups = 256 / tpr;
+  constexpr int U = 4;
+  long long blocks = (n + (long long)groups * U - 1) / ((long long)groups * U);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+#define GO(T) hipLaunchKernelGGL((gather_kernel<IdxT, T, U>), dim3((unsigned)blocks), dim3(256), 0, st, \
+                                 (const float4*)table, (const IdxT*)idx, n, d4, (float4*)out)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+int gather_rows(const float* table, const void* idx, int idx_bytes, long long n, int d, float* out, hipStream_t st) {
+  if (n == 0) return UR_OK;
+  return idx_bytes == 8 ? launch_gather<long long>(table, idx, n, d, out, st) : launch_gather<int>(table, idx, n, d, out, st);
+}
+
+// ------------------------------------------------------------------------- gather + pos + LayerNorm
+// x0[b,l,:] = LN(E[item_seq[b,l]] + P[l])  (sasrec.py:60-69). Writes y, xhat, rstd.
+template <int TPR>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict__ seq, const float4* __restrict__ table,
+                                                           const float4* __restrict__ pos, const float4* __restrict__ gamma,
+                                                           const float4* __restrict__ beta, float eps, int M, int L, int d4,
+                                                           float4* __restrict__ y, float4* __restrict__ xhat,
+                                                           float* __restrict__ rstd_out) {
+  const int groups = 256 / TPR;
+  const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const float inv_d = 1.0f / (float)(d4 * 4);
+  for (int row = blockIdx.x * groups + g; row < M; row += gridDim.x * groups) {
+    const long long id = seq[row];
+    const int l = row % L;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        float4 a = table[id * d4 + c];
+        if (pos) {
+          const float4 p = pos[(long long)l * d4 + c];
+          a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+        }
+        v[k] = a;
+        s += (a.x + a.y) + (a.z + a.w);
+      }
+    }
+    const float mean = group_sum<TPR>(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+        q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(group_sum<TPR>(q) * inv_d + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        const float4 gm = gamma[c], bt = beta[c];
+        float4 h, o;
+        h.x = v[k].x * rstd; h.y = v[k].y * rstd; h.z = v[k].z * rstd; h.w = v[k].w * rstd;
+        o.x = h.x * gm.x + bt.x; o.y = h.y * gm.y + bt.y; o.z = h.z * gm.z + bt.z; o.w = h.w * gm.w + bt.w;
+        xhat[(long long)row * d4 + c] = h;
+        y[(long long)row * d4 + c] = o;
+      }
+    }
+    if (t == 0) rstd_out[row] = rstd;
+  }
+}
+
+int embed_ln_fwd(const int* seq, const float* table, const float* pos, const float* gamma, const float* beta,
+                 float eps, int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st) {
+  const int tpr = pick_tpr(d), groups = 256 / tpr;
+  int blocks = cdiv(M, groups);
+  if (blocks > 4096) blocks = 4096;
+#define GO(T) hipLaunchKernelGGL((embed_ln_fwd_kernel<T>), dim3(blocks), dim3(256), 0, st, seq, (const float4*)table, \
+                                 (const float4*)pos, (const float4*)gamma, (const float4*)beta, eps, M, L, d / 4,      \
+                                 (float4*)y, (float4*)xhat, rstd)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+// ------------------------------------------------------------------------- residual + LayerNorm fwd
+// y = LN(x + res) (res may be null); fallback for rows wider than the GEMM-fused epilogue supports.
+template <int TPR>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ res,
+                                                     const float4* __restrict__ gamma, const float4* __restrict__ beta,
+                                                     float eps, int M, int d4, float4* __restrict__ y,
+                                                     float4* __restrict__ xhat, float* __restrict__ rstd_out) {
+  const int groups = 256 / TPR;
+  const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const float inv_d = 1.0f / (float)(d4 * 4);
+  for (int row = blockIdx.x * groups + g; row < M; row += gridDim.x * groups) {
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        float4 a = x[(long long)row * d4 + c];
+        if (res) {
+          const float4 r = res[(long long)row * d4 + c];
+          a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
+        v[k] = a;
+        s += (a.x + a.y) + (a.z + a.w);
+      }
+    }
+    const float mean = group_sum<TPR>(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+        q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(group_sum<TPR>(q) * inv_d + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        const float4 gm = gamma[c], bt = beta[c];
+        float4 h, o;
+        h.x = v[k].x * rstd; h.y = v[k].y * rstd; h.z = v[k].z * rstd; h.w = v[k].w * rstd;
+        o.x = h.x * gm.x + bt.x; o.y = h.y * gm.y + bt.y; o.z = h.z * gm.z + bt.z; o.w = h.w * gm.w + bt.w;
+        xhat[(long long)row * d4 + c] = h;
+        y[(long long)row * d4 + c] = o;
+      }
+    }
+    if (t == 0) rstd_out[row] = rstd;
+  }
+}
+
+int ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, int M, int d, float* y,
+           float* xhat, float* rstd, hipStream_t st) {
+  const int tpr = pick_tpr(d), groups = 256 / tpr;
+  int blocks = cdiv(M, groups);
+  if (blocks > 4096) blocks = 4096;
+#define GO(T) hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float4*)x, (const float4*)res, \
+                                 (const float4*)gamma, (const float4*)beta, eps, M, d / 4, (float4*)y, (float4*)xhat, rstd)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+// ------------------------------------------------------------------------------- LayerNorm backward
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+// dx_out = dx (+ add_in when non-null: the residual branch's gradient; add_in may alias dx_out)
+// zero_rows_of_id0: when seq != null, rows whose id is 0 are written as zeros (padding_idx).
+// Per-block partials of dgamma = sum dy*xhat and dbeta = sum dy go to part[blk][2][d].
+template <int TPR>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ xhat,
+                                                     const float* __restrict__ rstd, const float4* __restrict__ gamma,
+                                                     const float4* add_in, const int* __restrict__ seq, int M, int d4,
+                                                     float4* dx_out, float* __restrict__ part) {
+  constexpr int groups = 256 / TPR;
+  const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const float inv_d = 1.0f / (float)(d4 * 4);
+  float4 dg[MAXV], db[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) dg[k] = db[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int row = blockIdx.x * groups + g; row < M; row += gridDim.x * groups) {
+    float4 gy[MAXV], h[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        const float4 y = dy[(long long)row * d4 + c];
+        h[k] = xhat[(long long)row * d4 + c];
+        const float4 gm = gamma[c];
+        dg[k].x += y.x * h[k].x; dg[k].y += y.y * h[k].y; dg[k].z += y.z * h[k].z; dg[k].w += y.w * h[k].w;
+        db[k].x += y.x; db[k].y += y.y; db[k].z += y.z; db[k].w += y.w;
+        gy[k].x = y.x * gm.x; gy[k].y = y.y * gm.y; gy[k].z = y.z * gm.z; gy[k].w = y.w * gm.w;
+        s1 += (gy[k].x + gy[k].y) + (gy[k].z + gy[k].w);
+        s2 += (gy[k].x * h[k].x + gy[k].y * h[k].y) + (gy[k].z * h[k].z + gy[k].w * h[k].w);
+      }
+    }
+    const float m1 = group_sum<TPR>(s1) * inv_d;
+    const float m2 = group_sum<TPR>(s2) * inv_d;
+    const float r = rstd[row];
+    const bool zero = seq != nullptr && seq[row] == 0;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        float4 o;
+        o.x = r * (gy[k].x - m1 - h[k].x * m2);
+        o.y = r * (gy[k].y - m1 - h[k].y * m2);
+        o.z = r * (gy[k].z - m1 - h[k].z * m2);
+        o.w = r * (gy[k].w - m1 - h[k].w * m2);
+        if (add_in) {
+          const float4 a = add_in[(long long)row * d4 + c];
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        if (zero) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        dx_out[(long long)row * d4 + c] = o;
+      }
+    }
+  }
+  // block-level reduction of dgamma/dbeta over the `groups` row groups (fixed order => deterministic)
+  __shared__ float red[groups][2][MAXV * TPR * 4 + 4];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = t + k * TPR;
+    if (c < d4) {
+      *(float4*)&red[g][0][c * 4] = dg[k];
+      *(float4*)&red[g][1][c * 4] = db[k];
+    }
+  }
+  __syncthreads();
+  const int d = d4 * 4;
+  for (int i = threadIdx.x; i < 2 * d; i += 256) {
+    const int which = i / d, col = i % d;
+    float acc = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < groups; ++gg) acc += red[gg][which][col];
+    part[((long long)blockIdx.x * 2 + which) * d + col] = acc;
+  }
+}
+
+// out[which*d + col] = sum_blk part[blk][which][col]   (which in {0: dgamma, 1: dbeta})
+__global__ void colsum_partials_kernel(const float* __restrict__ part, int nblk, int width, float* __restrict__ out0,
+                                       float* __restrict__ out1, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= width) return;
+  float acc = 0.f;
+  for (int b = 0; b < nblk; ++b) acc += part[(long long)b * width + i];
+  if (i < d) out0[i] = acc;
+  else out1[i - d] = acc;
+}
+
+int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* add_in,
+           const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st) {
+  const int tpr = pick_tpr(d), groups = 256 / tpr;
+  int blocks = cdiv(M, groups * 4);
+  if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+#define GO(T) hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float4*)dy, (const float4*)xhat, \
+                                 rstd, (const float4*)gamma, (const float4*)add_in, seq, M, d / 4, (float4*)dx, part_ws)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(2 * d, 256)), dim3(256), 0, st, part_ws, blocks, 2 * d, dgamma, dbeta, d);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+// --------------------------------------------------------------- position-embedding gradient
+// dpos[l,:] = sum_b dx[b,l,:]   (position_embedding has no padding index: sasrec.py:25)
+__global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dx, int B, int L, int d,
+                                                       float* __restrict__ dpos) {
+  const int l = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += dx[((long long)b * L + l) * d + c];
+    dpos[(long long)l * d + c] = acc;
+  }
+}
+
+int pos_grad(const float* dx, int B, int L, int d, float* dpos, hipStream_t st) {
+  hipLaunchKernelGGL(pos_grad_kernel, dim3(L), dim3(d < 256 ? ((d + 63) / 64) * 64 : 256), 0, st, dx, B, L, d, dpos);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+}  // namespace ur
+
+extern "C" int ur_embedding_gather_f32(const float* table, int64_t n_rows, int d, const void* idx, int idx_bytes,
+                                       int64_t n, float* out, void* stream) {
+  UR_REQUIRE(table && ((out && idx) || n == 0), UR_ERR_ARG, "ur_embedding_gather_f32: null pointer");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512, UR_ERR_ARG, "ur_embedding_gather_f32: d=%d must be a multiple of 4, <= 512", d);
+  UR_REQUIRE(idx_bytes == 4 || idx_bytes == 8, UR_ERR_ARG, "ur_embedding_gather_f32: idx_bytes=%d (4 or 8)", idx_bytes);
+  UR_REQUIRE(n >= 0 && n_rows > 0, UR_ERR_ARG, "ur_embedding_gather_f32: n=%lld n_rows=%lld", (long long)n, (long long)n_rows);
+  return ur::gather_rows(table, idx, idx_bytes, n, d, out, ur::as_stream(stream));
+}

@@ -1,0 +1,513 @@
+// Row-sparse embedding gradient: sort the looked-up ids, segment-reduce the row gradients in a fixed
+// order (deterministic, no float atomics), and update only the touched rows.
+//
+//   ur_rows_plan   : ids -> (uniq_idx, seg_start, sorted_pos, n_uniq)        stable LSD radix sort
+//   ur_rows_reduce : explicit rows + implicit (coef * vec) rows -> uniq_grad
+//   ur_sparse_adam_rows / ur_lazy_adam_catchup / ur_lazy_adam_flush          row-wise Adam
+//
+// The sort works at wavefront granularity: every wave owns a contiguous chunk of CH keys and walks it
+// 64 keys at a time, so stability follows from program order; ranks inside a 64-key group come from
+// __ballot match masks (no LDS atomics in the scatter), digit bases from a tiny single-block scan.
+#include "common.h"
+#include "kernels.h"
+
+namespace ur {
+
+constexpr int CH = 1024;     // keys per wave
+constexpr int RADIX = 256;   // 8-bit digits
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+  const unsigned lane = threadIdx.x & 63;
+  return lane ? (~0ull >> (64 - lane)) : 0ull;
+}
+// mask of active lanes holding the same 8-bit digit as this lane
+__device__ __forceinline__ unsigned long long match_digit(unsigned dgt, bool active) {
+  unsigned long long m = __ballot(active);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const unsigned long long bal = __ballot((dgt >> b) & 1u);
+    m &= ((dgt >> b) & 1u) ? bal : ~bal;
+  }
+  return m;
+}
+
+__global__ void build_keys_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
+                                  long long n_b, unsigned* __restrict__ keys, int* __restrict__ vals) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_a + n_b) return;
+  keys[i] = (i < n_a) ? (unsigned)ids_a[i] : (unsigned)ids_b[i - n_a];
+  vals[i] = (int)i;
+}
+
+// hist[digit * nwaves + wave] = number of keys of this wave's chunk with that digit
+__global__ __launch_bounds__(256) void radix_hist_kernel(const unsigned* __restrict__ keys, long long n, int shift, int nwaves,
+                                                         int* __restrict__ hist) {
+  __shared__ int cnt[4][RADIX];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + w;
+  for (int i = lane; i < RADIX; i += 64) cnt[w][i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  if (wave < nwaves) {
+    const long long base = (long long)wave * CH;
+    for (int it = 0; it < CH / 64; ++it) {
+      const long long i = base + it * 64 + lane;
+      if (i < n) atomicAdd(&cnt[w][(keys[i] >> shift) & 0xFF], 1);
+    }
+  }
+  __syncthreads();
+  if (wave < nwaves)
+    for (int dgt = lane; dgt < RADIX; dgt += 64) hist[(long long)dgt * nwaves + wave] = cnt[w][dgt];
+}
+
+// in-place exclusive scan of `len` ints by ONE block of 1024 threads; total -> *total_out (nullable)
+__global__ __launch_bounds__(1024) void scan_exclusive_kernel(int* __restrict__ data, long long len, int* __restrict__ total_out) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const long long per = (len + 1023) / 1024;
+  const long long b = (long long)t * per, e = b + per < len ? b + per : len;
+  int s = 0;
+  for (long long i = b; i < e; ++i) s += data[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = (t == 0) ? 0 : part[t - 1];
+  for (long long i = b; i < e; ++i) {
+    const int v = data[i];
+    data[i] = run;
+    run += v;
+  }
+  if (total_out && t == 1023) *total_out = part[1023];
+}
+
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in,
+                                                            long long n, int shift, int nwaves, const int* __restrict__ hist_scanned,
+                                                            unsigned* __restrict__ keys_out, int* __restrict__ vals_out) {
+  __shared__ int cnt[4][RADIX];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + w;
+  if (wave >= nwaves) return;
+  for (int dgt = lane; dgt < RADIX; dgt += 64) cnt[w][dgt] = hist_scanned[(long long)dgt * nwaves + wave];
+  __builtin_amdgcn_wave_barrier();
+  const long long base = (long long)wave * CH;
+  const unsigned long long lt = lanemask_lt();
+  for (int it = 0; it < CH / 64; ++it) {
+    const long long i = base + it * 64 + lane;
+    const bool active = i < n;
+    const unsigned key = active ? keys_in[i] : 0u;
+    const int val = active ? vals_in[i] : 0;
+    const unsigned dgt = (key >> shift) & 0xFF;
+    const unsigned long long m = match_digit(dgt, active);
+    const int rank = __popcll(m & lt);
+    int pos = 0;
+    if (active) pos = cnt[w][dgt] + rank;
+    __builtin_amdgcn_wave_barrier();
+    if (active && rank == 0) cnt[w][dgt] += __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (active) {
+      keys_out[pos] = key;
+      vals_out[pos] = val;
+    }
+  }
+}
+
+// ---- segment heads: count per wave -> scan -> write (uniq_idx, seg_start)
+__global__ __launch_bounds__(256) void heads_count_kernel(const unsigned* __restrict__ keys, long long n, int nwaves,
+                                                          int* __restrict__ counts) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + w;
+  if (wave >= nwaves) return;
+  const long long base = (long long)wave * CH;
+  int c = 0;
+  for (int it = 0; it < CH / 64; ++it) {
+    const long long i = base + it * 64 + lane;
+    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
+    c += __popcll(__ballot(head));
+  }
+  if (lane == 0) counts[wave] = c;
+}
+
+__global__ __launch_bounds__(256) void heads_write_kernel(const unsigned* __restrict__ keys, long long n, int nwaves,
+                                                          const int* __restrict__ counts_scanned, const int* __restrict__ n_uniq,
+                                                          int* __restrict__ uniq_idx, int* __restrict__ seg_start) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + w;
+  if (wave >= nwaves) return;
+  const long long base = (long long)wave * CH;
+  int run = counts_scanned[wave];
+  const unsigned long long lt = lanemask_lt();
+  for (int it = 0; it < CH / 64; ++it) {
+    const long long i = base + it * 64 + lane;
+    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
+    const unsigned long long m = __ballot(head);
+    if (head) {
+      const int seg = run + __popcll(m & lt);
+      uniq_idx[seg] = (int)keys[i];
+      seg_start[seg] = (int)i;
+    }
+    run += __popcll(m);
+  }
+  if (wave == 0 && lane == 0) seg_start[*n_uniq] = (int)n;
+}
+
+// ------------------------------------------------------------------------------- segment reduce
+constexpr int MAXV = 4;
+template <int TPR>
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict__ uniq_idx, const int* __restrict__ seg_start,
+                                                          const int* __restrict__ sorted_pos, const int* __restrict__ n_uniq_dev,
+                                                          long long n, const float4* __restrict__ rows_a, long long n_a,
+                                                          const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G,
+                                                          int d4, float4* __restrict__ out, int zero_tail) {
+  constexpr int groups = 256 / TPR;
+  const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const int n_uniq = *n_uniq_dev;
+  for (long long u = (long long)blockIdx.x * groups + g; u < n; u += (long long)gridDim.x * groups) {
+    if (u >= n_uniq) {
+      if (!zero_tail) return;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int c = t + k * TPR;
+        if (c < d4) out[u * d4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      continue;
+    }
+    float4 acc[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (uniq_idx[u] != 0) {
+      const int s = seg_start[u], e = seg_start[u + 1];
+      for (int q = s; q < e; ++q) {
+        const long long p = sorted_pos[q];
+        if (p < n_a) {
+#pragma unroll
+          for (int k = 0; k < MAXV; ++k) {
+            const int c = t + k * TPR;
+            if (c < d4) {
+              const float4 r = rows_a[p * d4 + c];
+              acc[k].x += r.x; acc[k].y += r.y; acc[k].z += r.z; acc[k].w += r.w;
+            }
+          }
+        } else {
+          const long long pb = p - n_a;
+          const float w = coef_b[pb];
+          const long long row = pb / G;
+#pragma unroll
+          for (int k = 0; k < MAXV; ++k) {
+            const int c = t + k * TPR;
+            if (c < d4) {
+              const float4 r = vec_b[row * d4 + c];
+              acc[k].x = fmaf(w, r.x, acc[k].x); acc[k].y = fmaf(w, r.y, acc[k].y);
+              acc[k].z = fmaf(w, r.z, acc[k].z); acc[k].w = fmaf(w, r.w, acc[k].w);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) out[u * d4 + c] = acc[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- row-wise Adam
+struct AdamK {
+  float lr, b1, b2, eps, wd;
+  int step;
+};
+
+// zero-gradient Adam steps t = from+1 .. to applied to one element (reference semantics: dense Adam moves
+// every row every step; here the missed steps are replayed when the row is next needed).
+constexpr int LAZY_EXACT_STEPS = 512;
+__device__ __forceinline__ void lazy_replay(float& w, float& m, float& v, int from, int to, const AdamK& a) {
+  int k = to - from;
+  if (k <= 0) return;
+  float b1t = powf(a.b1, (float)from), b2t = powf(a.b2, (float)from);
+  const int exact = (a.wd != 0.f) ? k : min(k, LAZY_EXACT_STEPS);
+  for (int j = 0; j < exact; ++j) {
+    b1t *= a.b1;
+    b2t *= a.b2;
+    const float gr = a.wd * w;
+    m = a.b1 * m + (1.f - a.b1) * gr;
+    v = a.b2 * v + (1.f - a.b2) * gr * gr;
+    const float denom = sqrtf(v) / sqrtf(1.f - b2t) + a.eps;
+    w -= (a.lr / (1.f - b1t)) * (m / denom);
+  }
+  if (exact < k) {  // wd == 0: beyond LAZY_EXACT_STEPS the update b1^j*m/(...) is below fp32 resolution; decay the moments
+    m *= powf(a.b1, (float)(k - exact));
+    v *= powf(a.b2, (float)(k - exact));
+  }
+}
+
+__device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float gr, const AdamK& a, float bc1, float bc2s) {
+  gr += a.wd * w;
+  m = a.b1 * m + (1.f - a.b1) * gr;
+  v = a.b2 * v + (1.f - a.b2) * gr * gr;
+  const float denom = sqrtf(v) / bc2s + a.eps;
+  w -= (a.lr / bc1) * (m / denom);
+}
+
+// MODE 0: update with gradient (catch-up first when last_step != null); MODE 1: catch-up only (to step-1)
+template <int TPR, int MODE>
+__global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
+                                                          float4* __restrict__ var, int* __restrict__ last_step,
+                                                          const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
+                                                          long long n_max, const float4* __restrict__ grad, int d4,
+                                                          const float* __restrict__ scale_dev) {
+  constexpr int groups = 256 / TPR;
+  const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const int n_uniq = (int)min((long long)*n_uniq_dev, n_max);
+  const float scale = scale_dev ? *scale_dev : 1.0f;
+  const float bc1 = 1.f - powf(a.b1, (float)a.step), bc2s = sqrtf(1.f - powf(a.b2, (float)a.step));
+  for (int u = blockIdx.x * groups + g; u < n_uniq; u += gridDim.x * groups) {
+    const long long row = uniq_idx[u];
+    if (row == 0) continue;
+    const int last = last_step ? last_step[row] : a.step - 1;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        float4 w = table[row * d4 + c], m = mom[row * d4 + c], v = var[row * d4 + c];
+        if (last_step) {
+          lazy_replay(w.x, m.x, v.x, last, a.step - 1, a);
+          lazy_replay(w.y, m.y, v.y, last, a.step - 1, a);
+          lazy_replay(w.z, m.z, v.z, last, a.step - 1, a);
+          lazy_replay(w.w, m.w, v.w, last, a.step - 1, a);
+        }
+        if (MODE == 0) {
+          const float4 gr = grad[(long long)u * d4 + c];
+          adam_elem(w.x, m.x, v.x, gr.x * scale, a, bc1, bc2s);
+          adam_elem(w.y, m.y, v.y, gr.y * scale, a, bc1, bc2s);
+          adam_elem(w.z, m.z, v.z, gr.z * scale, a, bc1, bc2s);
+          adam_elem(w.w, m.w, v.w, gr.w * scale, a, bc1, bc2s);
+        }
+        table[row * d4 + c] = w;
+        mom[row * d4 + c] = m;
+        var[row * d4 + c] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (last_step && t == 0) last_step[row] = (MODE == 0) ? a.step : a.step - 1;
+  }
+}
+
+// catch-up of a contiguous block of rows to `step` (flush before evaluation / checkpoint)
+template <int TPR>
+__global__ __launch_bounds__(256) void lazy_flush_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
+                                                         float4* __restrict__ var, int* __restrict__ last_step, long long row0,
+                                                         long long n, int d4) {
+  constexpr int groups = 256 / TPR;
+  const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  for (long long r = (long long)blockIdx.x * groups + g; r < n; r += (long long)gridDim.x * groups) {
+    const long long row = row0 + r;
+    if (row == 0) continue;
+    const int last = last_step[row];
+    if (last >= a.step) continue;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        float4 w = table[row * d4 + c], m = mom[row * d4 + c], v = var[row * d4 + c];
+        lazy_replay(w.x, m.x, v.x, last, a.step, a);
+        lazy_replay(w.y, m.y, v.y, last, a.step, a);
+        lazy_replay(w.z, m.z, v.z, last, a.step, a);
+        lazy_replay(w.w, m.w, v.w, last, a.step, a);
+        table[row * d4 + c] = w;
+        mom[row * d4 + c] = m;
+        var[row * d4 + c] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (t == 0) last_step[row] = a.step;
+  }
+}
+
+static inline int pick_tpr(int d) {
+  int d4 = d / 4, t = 4;
+  while (t < d4 && t < 32) t <<= 1;
+  return t;
+}
+static inline int bits_for(long long n_rows) {
+  int b = 1;
+  while (b < 32 && (1LL << b) < n_rows) ++b;
+  return b;
+}
+
+struct PlanWs {
+  unsigned *keys0, *keys1;
+  int *vals_tmp, *hist, *counts;
+  long long bytes;
+};
+static PlanWs carve_plan(long long n, char* base) {
+  PlanWs w;
+  long long o = 0;
+  auto take = [&](long long bytes) {
+    char* p = base ? base + o : nullptr;
+    o += (bytes + 255) & ~255LL;
+    return p;
+  };
+  const long long nwaves = (n + CH - 1) / CH;
+  w.keys0 = (unsigned*)take(n * 4);
+  w.keys1 = (unsigned*)take(n * 4);
+  w.vals_tmp = (int*)take(n * 4);
+  w.hist = (int*)take(nwaves * RADIX * 4);
+  w.counts = (int*)take((nwaves + 1) * 4);
+  w.bytes = o;
+  return w;
+}
+
+}  // namespace ur
+
+using namespace ur;
+
+extern "C" int64_t ur_rows_plan_workspace_bytes(int64_t n) {
+  if (n < 0) return UR_ERR_ARG;
+  return carve_plan(n > 0 ? n : 1, nullptr).bytes;
+}
+
+extern "C" int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
+                            int32_t* uniq_idx, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws,
+                            void* stream) {
+  const long long n = n_a + n_b;
+  UR_REQUIRE(n_a >= 0 && n_b >= 0 && n > 0 && n < (1LL << 31), UR_ERR_ARG, "ur_rows_plan: n_a=%lld n_b=%lld", (long long)n_a, (long long)n_b);
+  UR_REQUIRE((ids_a || n_a == 0) && (ids_b || n_b == 0) && uniq_idx && seg_start && sorted_pos && n_uniq_dev && ws, UR_ERR_ARG,
+             "ur_rows_plan: null pointer");
+  UR_REQUIRE(n_rows > 0 && n_rows <= (1LL << 31), UR_ERR_ARG, "ur_rows_plan: n_rows=%lld", (long long)n_rows);
+  hipStream_t st = as_stream(stream);
+  PlanWs w = carve_plan(n, (char*)ws);
+  const int nwaves = (int)((n + CH - 1) / CH);
+  const int nblk = cdiv(nwaves, 4);
+  const int passes = (bits_for(n_rows) + 7) / 8;
+  // ping-pong so that the LAST pass writes vals into sorted_pos
+  unsigned* kbuf[2] = {w.keys0, w.keys1};
+  int* vbuf[2];
+  vbuf[passes & 1] = sorted_pos;       // after `passes` swaps the result sits in index (passes & 1)
+  vbuf[(passes & 1) ^ 1] = w.vals_tmp;
+  hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids_a, (long long)n_a, (const long long*)ids_b,
+                     (long long)n_b, kbuf[0], vbuf[0]);
+  UR_LAUNCH_CHECK();
+  int cur = 0;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], n, shift, nwaves, w.hist);
+    UR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, st, w.hist, (long long)nwaves * RADIX, (int*)nullptr);
+    UR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], vbuf[cur], n, shift, nwaves, w.hist,
+                       kbuf[cur ^ 1], vbuf[cur ^ 1]);
+    UR_LAUNCH_CHECK();
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(heads_count_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], n, nwaves, w.counts);
+  UR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, st, w.counts, (long long)nwaves, n_uniq_dev);
+  UR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(heads_write_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], n, nwaves, w.counts, n_uniq_dev, uniq_idx, seg_start);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
+                              const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
+                              const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, void* stream) {
+  UR_REQUIRE(uniq_idx && seg_start && sorted_pos && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_rows_reduce: null pointer");
+  UR_REQUIRE(n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_rows_reduce: n=%lld n_a=%lld", (long long)n, (long long)n_a);
+  UR_REQUIRE((rows_a || n_a == 0) && ((coef_b && vec_b && G > 0) || n_a == n), UR_ERR_ARG, "ur_rows_reduce: missing source");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512, UR_ERR_ARG, "ur_rows_reduce: d=%d", d);
+  hipStream_t st = as_stream(stream);
+  const int tpr = pick_tpr(d), groups = 256 / tpr;
+  int blocks = cdiv(n, groups);
+  if (blocks > 8192) blocks = 8192;
+  const int zero_tail = sumsq_dev != nullptr;
+#define GO(T) hipLaunchKernelGGL((rows_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
+                                 (long long)n, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,          \
+                                 (float4*)uniq_grad, zero_tail)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                              const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* grad, int d,
+                              const float* scale, hipStream_t st) {
+  AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step};
+  const int tpr = pick_tpr(d), groups = 256 / tpr;
+  int blocks = cdiv(n_max, groups);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+#define GO(T, MD) hipLaunchKernelGGL((sparse_adam_kernel<T, MD>), dim3(blocks), dim3(256), 0, st, a, (float4*)table, (float4*)m, \
+                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale)
+#define SW(MD)            \
+  switch (tpr) {          \
+    case 4: GO(4, MD); break;   \
+    case 8: GO(8, MD); break;   \
+    case 16: GO(16, MD); break; \
+    default: GO(32, MD); break; \
+  }
+  if (mode == 0) { SW(0) } else { SW(1) }
+#undef SW
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+static int check_adam(const UrAdamCfg* c, const char* who) {
+  UR_REQUIRE(c != nullptr, UR_ERR_ARG, "%s: null cfg", who);
+  UR_REQUIRE(c->step >= 1, UR_ERR_ARG, "%s: step=%d must be >= 1", who, c->step);
+  UR_REQUIRE(c->beta1 >= 0.f && c->beta1 < 1.f && c->beta2 >= 0.f && c->beta2 < 1.f, UR_ERR_ARG, "%s: betas", who);
+  return UR_OK;
+}
+
+extern "C" int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                                   const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad,
+                                   int32_t d, const float* grad_scale_dev, void* stream) {
+  int rc = check_adam(cfg, "ur_sparse_adam_rows");
+  if (rc) return rc;
+  UR_REQUIRE(table && m && v && uniq_idx && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_sparse_adam_rows: null pointer");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_sparse_adam_rows: d=%d n_max=%lld", d, (long long)n_max);
+  return launch_sparse_adam(0, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, uniq_grad, d, grad_scale_dev, as_stream(stream));
+}
+
+extern "C" int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                                    const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d, void* stream) {
+  int rc = check_adam(cfg, "ur_lazy_adam_catchup");
+  if (rc) return rc;
+  UR_REQUIRE(table && m && v && last_step && uniq_idx && n_uniq_dev, UR_ERR_ARG, "ur_lazy_adam_catchup: null pointer");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_lazy_adam_catchup: d=%d", d);
+  return launch_sparse_adam(1, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, nullptr, d, nullptr, as_stream(stream));
+}
+
+extern "C" int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, int64_t row0,
+                                  int64_t n, int32_t d, void* stream) {
+  UR_REQUIRE(cfg != nullptr && cfg->step >= 0, UR_ERR_ARG, "ur_lazy_adam_flush: cfg");
+  UR_REQUIRE(table && m && v && last_step, UR_ERR_ARG, "ur_lazy_adam_flush: null pointer");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n >= 0 && row0 >= 0, UR_ERR_ARG, "ur_lazy_adam_flush: d=%d", d);
+  if (n == 0) return UR_OK;
+  AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step};
+  const int tpr = pick_tpr(d), groups = 256 / tpr;
+  long long blocks = (n + groups - 1) / groups;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t st = as_stream(stream);
+#define GO(T) hipLaunchKernelGGL((lazy_flush_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, a, (float4*)table, (float4*)m, \
+                                 (float4*)v, last_step, (long long)row0, (long long)n, d / 4)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}

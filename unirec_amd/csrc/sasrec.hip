@@ -1,0 +1,255 @@
+// SASRec user encoder: forward / backward orchestration over the kernels of rowops / gemm / attention.
+// Stateless: every call receives the flat parameter buffer, the caller-owned workspace and a stream.
+//
+// Forward per layer (reference: unirec/model/modules.py:284-316, 347-355, 379-382):
+//   qkv = x Wqkv^T + bqkv                      gemm_nt  EPI_BIAS            (3 nn.Linear fused: weights contiguous)
+//   ctx = softmax(QK^T/sqrt(hd) + mask) V      attn_fwd
+//   a   = LN(ctx Wo^T + bo + x)                gemm_nt  EPI_BIAS_RES_LN
+//   h1  = a W1^T + b1                          gemm_nt  EPI_BIAS            (pre-activation kept for backward)
+//   y   = LN(act(h1) W2^T + b2 + a)            gemm_nt  PRO_ACT + EPI_BIAS_RES_LN
+#include "common.h"
+#include "kernels.h"
+
+namespace ur {
+
+struct Layout {
+  long long off[UR_SASREC_N_GLOBAL + UR_MAX_LAYERS * UR_SASREC_N_PER_LAYER];
+  long long total;
+};
+
+static Layout make_layout(const UrSasrecCfg& c) {
+  Layout l;
+  long long o = 0;
+  const long long d = c.d, I = c.inner;
+  int k = 0;
+  auto put = [&](long long n) { l.off[k++] = o; o += n; };
+  put((long long)(c.L + 1) * d);  // position_embedding.weight
+  put(d);                          // LayerNorm.weight
+  put(d);                          // LayerNorm.bias
+  for (int i = 0; i < c.n_layers; ++i) {
+    put(d * d); put(d * d); put(d * d);  // q,k,v weights (contiguous => Wqkv)
+    put(d); put(d); put(d);              // q,k,v biases
+    put(d * d); put(d);                  // dense
+    put(d); put(d);                      // attn LN
+    put(I * d); put(I);                  // dense_1
+    put(d * I); put(d);                  // dense_2
+    put(d); put(d);                      // ffn LN
+  }
+  l.total = o;
+  return l;
+}
+
+struct LayerP {
+  const float *wqkv, *bqkv, *wo, *bo, *g1, *b1ln, *w1, *b1, *w2, *b2, *g2, *b2ln;
+};
+static LayerP layer_ptrs(const float* base, const Layout& l, int i) {
+  const long long* o = l.off + UR_SASREC_N_GLOBAL + i * UR_SASREC_N_PER_LAYER;
+  LayerP p;
+  p.wqkv = base + o[0]; p.bqkv = base + o[3]; p.wo = base + o[6]; p.bo = base + o[7];
+  p.g1 = base + o[8]; p.b1ln = base + o[9]; p.w1 = base + o[10]; p.b1 = base + o[11];
+  p.w2 = base + o[12]; p.b2 = base + o[13]; p.g2 = base + o[14]; p.b2ln = base + o[15];
+  return p;
+}
+
+// ---- workspace carving (float units, every region 64-float aligned)
+struct LayerWs {
+  float *qkv, *lse, *ctx, *a, *ahat, *rstd1, *h1, *y, *yhat, *rstd2;
+  float *wqkvT, *woT, *w1T, *w2T;
+};
+struct Ws {
+  float *x0, *x0hat, *rstd0;
+  LayerWs layer[UR_MAX_LAYERS];
+  float *g_y, *g_t, *g_a, *g_h1, *g_qkv, *g_ctx, *tn_ws, *ln_part;
+  long long total_floats;
+};
+
+static Ws carve(const UrSasrecCfg& c, float* base) {
+  Ws w;
+  long long o = 0;
+  auto take = [&](long long n) {
+    float* p = base ? base + o : nullptr;
+    o += (n + 63) & ~63LL;
+    return p;
+  };
+  const long long M = (long long)c.B * c.L, d = c.d, I = c.inner;
+  w.x0 = take(M * d); w.x0hat = take(M * d); w.rstd0 = take(M);
+  for (int i = 0; i < c.n_layers; ++i) {
+    LayerWs& lw = w.layer[i];
+    lw.qkv = take(M * 3 * d); lw.lse = take(attn_lse_floats(c.B, c.n_heads, c.L)); lw.ctx = take(M * d);
+    lw.a = take(M * d); lw.ahat = take(M * d); lw.rstd1 = take(M); lw.h1 = take(M * I);
+    lw.y = take(M * d); lw.yhat = take(M * d); lw.rstd2 = take(M);
+    lw.wqkvT = take(3 * d * d); lw.woT = take(d * d); lw.w1T = take(I * d); lw.w2T = take(I * d);
+  }
+  w.g_y = take(M * d); w.g_t = take(M * d); w.g_a = take(M * d); w.g_h1 = take(M * I);
+  w.g_qkv = take(M * 3 * d); w.g_ctx = take(M * d);
+  long long tn = 0;
+  const int T = (int)M;
+  tn = gemm_tn_ws_floats(T, c.d, c.inner);
+  if (gemm_tn_ws_floats(T, c.inner, c.d) > tn) tn = gemm_tn_ws_floats(T, c.inner, c.d);
+  if (gemm_tn_ws_floats(T, 3 * c.d, c.d) > tn) tn = gemm_tn_ws_floats(T, 3 * c.d, c.d);
+  if (gemm_tn_ws_floats(T, c.d, c.d) > tn) tn = gemm_tn_ws_floats(T, c.d, c.d);
+  w.tn_ws = take(tn);
+  w.ln_part = take((long long)LN_BWD_MAX_BLOCKS * 2 * d);
+  w.total_floats = o;
+  return w;
+}
+
+static int check_cfg(const UrSasrecCfg* c) {
+  UR_REQUIRE(c != nullptr, UR_ERR_ARG, "sasrec: null cfg");
+  UR_REQUIRE(c->B > 0 && c->L > 0, UR_ERR_ARG, "sasrec: B=%d L=%d", c->B, c->L);
+  UR_REQUIRE(c->d > 0 && c->d % 4 == 0 && c->d <= 256, UR_ERR_UNSUPPORTED, "sasrec: hidden size d=%d must be a multiple of 4 and <= 256", c->d);
+  UR_REQUIRE(c->inner > 0 && c->inner % 4 == 0, UR_ERR_ARG, "sasrec: inner_size=%d must be a multiple of 4", c->inner);
+  UR_REQUIRE(c->n_heads > 0 && c->d % c->n_heads == 0, UR_ERR_ARG, "sasrec: d=%d not divisible by n_heads=%d", c->d, c->n_heads);
+  UR_REQUIRE(c->n_layers >= 1 && c->n_layers <= UR_MAX_LAYERS, UR_ERR_ARG, "sasrec: n_layers=%d", c->n_layers);
+  UR_REQUIRE(c->act >= UR_ACT_GELU && c->act <= UR_ACT_SIGMOID, UR_ERR_ARG, "sasrec: act=%d", c->act);
+  UR_REQUIRE((long long)c->B * c->L < (1LL << 31), UR_ERR_ARG, "sasrec: B*L too large");
+  return UR_OK;
+}
+
+// dst[b,:] = src[b, L-1, :]
+__global__ void take_last_kernel(const float* __restrict__ src, int B, int L, int d, float* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * d) return;
+  const long long b = i / d, c = i % d;
+  dst[i] = src[(b * L + (L - 1)) * d + c];
+}
+// dst[b,l,:] = (l == L-1) ? src[b,:] : 0
+__global__ void put_last_kernel(const float* __restrict__ src, int B, int L, int d, float* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * L * d) return;
+  const long long c = i % d, row = i / d, l = row % L, b = row / L;
+  dst[i] = (l == L - 1) ? src[b * d + c] : 0.f;
+}
+// dpos[l,:] = sum_b dx[b,l,:]; afterwards rows of dx whose id is 0 are zeroed (padding_idx=0)
+__global__ __launch_bounds__(256) void pos_grad_zero_kernel(float* __restrict__ dx, const int* __restrict__ seq, int B, int L,
+                                                            int d, float* __restrict__ dpos) {
+  const int l = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const long long row = (long long)b * L + l;
+      acc += dx[row * d + c];
+      if (seq[row] == 0) dx[row * d + c] = 0.f;
+    }
+    if (dpos) dpos[(long long)l * d + c] = acc;
+  }
+}
+
+}  // namespace ur
+
+using namespace ur;
+
+extern "C" int64_t ur_sasrec_param_layout(const UrSasrecCfg* cfg, int64_t* offsets_out) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  Layout l = make_layout(*cfg);
+  if (offsets_out)
+    for (int i = 0; i < UR_SASREC_N_GLOBAL + cfg->n_layers * UR_SASREC_N_PER_LAYER; ++i) offsets_out[i] = l.off[i];
+  return l.total;
+}
+
+extern "C" int64_t ur_sasrec_workspace_bytes(const UrSasrecCfg* cfg) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  return carve(*cfg, nullptr).total_floats * (int64_t)sizeof(float);
+}
+
+extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
+                             const int32_t* item_seq, float* user_emb, void* ws, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  UR_REQUIRE(item_table && dense && item_seq && user_emb && ws, UR_ERR_ARG, "ur_sasrec_fwd: null pointer");
+  UR_REQUIRE(n_items > 0, UR_ERR_ARG, "ur_sasrec_fwd: n_items=%lld", (long long)n_items);
+  const UrSasrecCfg& c = *cfg;
+  hipStream_t st = as_stream(stream);
+  const Layout lay = make_layout(c);
+  Ws w = carve(c, (float*)ws);
+  const int M = c.B * c.L, d = c.d, I = c.inner;
+  const float* pos = c.use_pos ? dense + lay.off[0] : nullptr;
+  rc = embed_ln_fwd(item_seq, item_table, pos, dense + lay.off[1], dense + lay.off[2], c.eps, M, c.L, d, w.x0, w.x0hat, w.rstd0, st);
+  if (rc) return rc;
+  const float* x = w.x0;
+  for (int i = 0; i < c.n_layers; ++i) {
+    const LayerP p = layer_ptrs(dense, lay, i);
+    LayerWs& lw = w.layer[i];
+    GemmArgs g{};
+    g.A = x; g.lda = d; g.W = p.wqkv; g.ldw = d; g.C = lw.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d; g.bias = p.bqkv;
+    if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
+    if ((rc = attn_fwd(lw.qkv, item_seq, c.B, c.L, d, c.n_heads, c.use_pos, lw.ctx, lw.lse, 0, st))) return rc;
+    g = GemmArgs{};
+    g.A = lw.ctx; g.lda = d; g.W = p.wo; g.ldw = d; g.C = lw.a; g.ldc = d; g.M = M; g.N = d; g.K = d; g.bias = p.bo;
+    g.aux = x; g.ldaux = d; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1;
+    if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS_RES_LN, st))) return rc;
+    g = GemmArgs{};
+    g.A = lw.a; g.lda = d; g.W = p.w1; g.ldw = d; g.C = lw.h1; g.ldc = I; g.M = M; g.N = I; g.K = d; g.bias = p.b1;
+    if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
+    g = GemmArgs{};
+    g.A = lw.h1; g.lda = I; g.W = p.w2; g.ldw = I; g.C = lw.y; g.ldc = d; g.M = M; g.N = d; g.K = I; g.bias = p.b2; g.act = c.act;
+    g.aux = lw.a; g.ldaux = d; g.gamma = p.g2; g.beta = p.b2ln; g.eps = c.eps; g.xhat = lw.yhat; g.rstd = lw.rstd2;
+    if ((rc = gemm_nt(g, PRO_ACT, EPI_BIAS_RES_LN, st))) return rc;
+    x = lw.y;
+  }
+  hipLaunchKernelGGL(take_last_kernel, dim3(cdiv((long long)c.B * d, 256)), dim3(256), 0, st, x, c.B, c.L, d, user_emb);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
+                             const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
+                             float* d_emb_rows, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  UR_REQUIRE(dense && item_seq && d_user_emb && ws && dense_grad && d_emb_rows, UR_ERR_ARG, "ur_sasrec_bwd: null pointer");
+  (void)item_table; (void)n_items;
+  const UrSasrecCfg& c = *cfg;
+  hipStream_t st = as_stream(stream);
+  const Layout lay = make_layout(c);
+  Ws w = carve(c, (float*)ws);
+  const int M = c.B * c.L, d = c.d, I = c.inner;
+  UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
+  hipLaunchKernelGGL(put_last_kernel, dim3(cdiv((long long)M * d, 256)), dim3(256), 0, st, d_user_emb, c.B, c.L, d, w.g_y);
+  UR_LAUNCH_CHECK();
+  for (int i = c.n_layers - 1; i >= 0; --i) {
+    const LayerP p = layer_ptrs(dense, lay, i);
+    const long long* o = lay.off + UR_SASREC_N_GLOBAL + i * UR_SASREC_N_PER_LAYER;
+    float* G = dense_grad;
+    LayerWs& lw = w.layer[i];
+    const float* x_in = (i == 0) ? w.x0 : w.layer[i - 1].y;
+    // weight transposes for the activation-gradient GEMMs
+    if ((rc = transpose(p.wqkv, 3 * d, d, lw.wqkvT, st))) return rc;
+    if ((rc = transpose(p.wo, d, d, lw.woT, st))) return rc;
+    if ((rc = transpose(p.w1, I, d, lw.w1T, st))) return rc;
+    if ((rc = transpose(p.w2, d, I, lw.w2T, st))) return rc;
+    // ---- feed-forward block
+    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, w.g_t, G + o[14], G + o[15], w.ln_part, st))) return rc;
+    if ((rc = gemm_tn(w.g_t, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13], w.tn_ws, st))) return rc;
+    GemmArgs g{};
+    g.A = w.g_t; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = w.g_h1; g.ldc = I; g.M = M; g.N = I; g.K = d;
+    g.aux = lw.h1; g.ldaux = I; g.act = c.act;
+    if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
+    if ((rc = gemm_tn(w.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11], w.tn_ws, st))) return rc;
+    g = GemmArgs{};
+    g.A = w.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.N = d; g.K = I; g.aux = w.g_t; g.ldaux = d;
+    if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
+    // ---- attention block
+    if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, w.g_t, G + o[8], G + o[9], w.ln_part, st))) return rc;
+    if ((rc = gemm_tn(w.g_t, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7], w.tn_ws, st))) return rc;
+    g = GemmArgs{};
+    g.A = w.g_t; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.N = d; g.K = d;
+    if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
+    if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, w.g_qkv, 0, st))) return rc;
+    if ((rc = gemm_tn(w.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3], w.tn_ws, st))) return rc;
+    g = GemmArgs{};
+    g.A = w.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
+    g.aux = w.g_t; g.ldaux = d;
+    if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
+  }
+  // ---- input block: LN0 backward -> row gradients of E[item_seq] and of the position table
+  if ((rc = ln_bwd(w.g_y, w.x0hat, w.rstd0, dense + lay.off[1], nullptr, nullptr, M, d, d_emb_rows, dense_grad + lay.off[1],
+                   dense_grad + lay.off[2], w.ln_part, st)))
+    return rc;
+  hipLaunchKernelGGL(pos_grad_zero_kernel, dim3(c.L), dim3(d < 256 ? ((d + 63) / 64) * 64 : 256), 0, st, d_emb_rows, item_seq,
+                     c.B, c.L, d, c.use_pos ? dense_grad + lay.off[0] : nullptr);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}

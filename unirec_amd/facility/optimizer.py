@@ -1,0 +1,134 @@
+"""Optimizer for unirec_amd models: dense Adam over the flat buffer + row-wise Adam over the tables.
+
+Reference behaviour being replaced: ``torch.optim.Adam(model.parameters())`` over every parameter,
+including the dense [N,d] embedding gradient (unirec/facility/trainer.py:134-136,349), preceded by an
+optional global-norm clip (:347-348).
+
+table_mode
+  "lazy_dense" (default) -- reproduces the reference's *dense* Adam exactly (for weight_decay == 0):
+        rows that a batch does not touch still move in the reference (their momentum keeps pushing
+        them); here those zero-gradient steps are replayed lazily, the next time the row is looked up
+        (``plan_batch`` -> ur_lazy_adam_catchup) or when ``flush()`` is called (evaluation, checkpoint).
+  "rowwise"  -- production semantics: only touched rows are updated (SparseAdam-like); half the traffic.
+"""
+import torch
+
+from .. import ops
+
+
+class SparseDenseAdam:
+    def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, grad_clip=None,
+                 table_mode="lazy_dense"):
+        assert table_mode in ("lazy_dense", "rowwise")
+        self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
+        self.grad_clip = grad_clip if grad_clip and grad_clip > 0 else None
+        self.table_mode = table_mode
+        self.t = 0
+        dev = model.device
+        self.dense_m = torch.zeros_like(model.dense.data)
+        self.dense_v = torch.zeros_like(model.dense.data)
+        self.extra = [p for n, p in model.named_parameters() if n in ("user_bias", "item_bias")]
+        self.extra_state = [(torch.zeros_like(p.data), torch.zeros_like(p.data)) for p in self.extra]
+        self.tables = {}
+        for name in ("item_embedding", "user_embedding"):
+            if hasattr(model, name):
+                w = getattr(model, name).weight.data
+                st = dict(w=w, m=torch.zeros_like(w), v=torch.zeros_like(w))
+                st["last"] = torch.zeros(w.shape[0], dtype=torch.int32, device=dev) if table_mode == "lazy_dense" else None
+                self.tables[name] = st
+        self._plans = {}
+        self._scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [0] sumsq, [1] clip coef
+        self._sumsq_ws = torch.empty(2048, dtype=torch.float32, device=dev)
+        self.param_groups = [dict(lr=lr)]  # enough of torch's surface for schedulers / logging
+
+    # ------------------------------------------------------------------ torch.optim surface
+    def zero_grad(self, set_to_none=True):
+        self.model.dense.grad = None
+        for p in self.extra:
+            p.grad = None
+        self.model.sparse_grads.clear()
+
+    def state_dict(self):
+        return dict(t=self.t, dense_m=self.dense_m, dense_v=self.dense_v, param_groups=self.param_groups,
+                    tables={k: {kk: vv for kk, vv in v.items() if kk != "w"} for k, v in self.tables.items()})
+
+    def _cfg(self, step):
+        return ops.adam_cfg(self.param_groups[0]["lr"], step, self.wd, self.betas[0], self.betas[1], self.eps)
+
+    # ------------------------------------------------------------------ per-batch plan (before forward)
+    def plan_batch(self, item_seq=None, item_id=None, user_id=None):
+        """Sort/unique the ids this batch will look up; in lazy_dense mode bring those rows up to date."""
+        self._plans = {}
+        ids_a = item_seq.reshape(-1).to(torch.int32).contiguous() if item_seq is not None else None
+        ids_b = item_id.reshape(-1).contiguous() if item_id is not None else None
+        if "item_embedding" in self.tables and (ids_a is not None or ids_b is not None):
+            self._plans["item_embedding"] = ops.rows_plan(ids_a, ids_b, self.tables["item_embedding"]["w"].shape[0])
+        if "user_embedding" in self.tables and user_id is not None:
+            self._plans["user_embedding"] = ops.rows_plan(user_id.reshape(-1).to(torch.int32).contiguous(), None,
+                                                          self.tables["user_embedding"]["w"].shape[0])
+        if self.table_mode == "lazy_dense" and self.t > 0:
+            cfg = self._cfg(self.t + 1)
+            for name, pl in self._plans.items():
+                st = self.tables[name]
+                ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
+
+    def flush(self):
+        """lazy_dense: apply all pending zero-gradient steps to every row (before eval / checkpoint)."""
+        if self.table_mode != "lazy_dense" or self.t == 0:
+            return
+        cfg = self._cfg(self.t)
+        for st in self.tables.values():
+            ops.lazy_adam_flush(cfg, st["w"], st["m"], st["v"], st["last"])
+
+    # ------------------------------------------------------------------ step
+    def _collect(self, name):
+        """-> (ids_a, rows_a, ids_b, coef, vec, G) for one table from model.sparse_grads."""
+        a = [g for g in self.model.sparse_grads if g["table"] == name and "ids_a" in g]
+        b = [g for g in self.model.sparse_grads if g["table"] == name and "ids_b" in g]
+        if len(b) > 1:
+            raise NotImplementedError("more than one scorer call per step")
+        ids_a = rows = None
+        if a:
+            ids_a = a[0]["ids_a"] if len(a) == 1 else torch.cat([g["ids_a"] for g in a])
+            rows = a[0]["rows"] if len(a) == 1 else torch.cat([g["rows"] for g in a])
+        if b:
+            return ids_a, rows, b[0]["ids_b"].reshape(-1), b[0]["coef"], b[0]["vec"], b[0]["G"]
+        return ids_a, rows, None, None, None, 1
+
+    def step(self):
+        model = self.model
+        self.t += 1
+        cfg = self._cfg(self.t)
+        reduced = {}
+        for name, st in self.tables.items():
+            ids_a, rows, ids_b, coef, vec, G = self._collect(name)
+            if ids_a is None and ids_b is None:
+                continue
+            pl = self._plans.get(name)
+            if pl is None:
+                if self.table_mode == "lazy_dense" and self.t > 1:
+                    raise RuntimeError("lazy_dense mode: call optimizer.plan_batch(...) before the forward pass")
+                pl = ops.rows_plan(ids_a.contiguous() if ids_a is not None else None, ids_b, st["w"].shape[0])
+            d = st["w"].shape[1]
+            reduced[name] = (pl, ops.rows_reduce(pl, rows, coef, vec, G, d, zero_tail=self.grad_clip is not None))
+        scale = None
+        if self.grad_clip is not None:
+            ss = self._scalars[0:1]
+            ops.sumsq(model.dense.grad, ss, accumulate=False, ws=self._sumsq_ws)
+            for p in self.extra:
+                if p.grad is not None:
+                    ops.sumsq(p.grad, ss, accumulate=True, ws=self._sumsq_ws)
+            for pl, ug in reduced.values():
+                ops.sumsq(ug, ss, accumulate=True, ws=self._sumsq_ws)
+            scale = self._scalars[1:2]
+            ops.clip_coef(ss, self.grad_clip, scale)
+        if model.dense.grad is not None:
+            ops.dense_adam(cfg, model.dense.data, model.dense.grad, self.dense_m, self.dense_v, scale)
+        for p, (m, v) in zip(self.extra, self.extra_state):
+            if p.grad is not None:
+                ops.dense_adam(cfg, p.data, p.grad.contiguous(), m, v, scale)
+        for name, (pl, ug) in reduced.items():
+            st = self.tables[name]
+            ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
+        self._plans = {}
+        model.sparse_grads.clear()

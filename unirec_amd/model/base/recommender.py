@@ -1,0 +1,169 @@
+"""BaseRecommender -- mirror of unirec/model/base/recommender.py:14-197 on the HIP ops.
+
+``forward`` keeps the reference's positional signature and return convention
+(training: ``(loss, None, None, None)`` or all four; eval: ``(None, scores, user_emb, items_emb)``).
+The scorer + loss is ONE fused HIP op (gather + dot + loss); the candidate tensor ``items_emb``
+[B,G,d] is only materialised when the caller asks for it (eval / ``return_loss_only=False``).
+"""
+import inspect
+
+import numpy as np
+import torch
+
+from ... import ops
+from .reco_abc import AbstractRecommender
+
+
+class _ScoreLossFn(torch.autograd.Function):
+    """loss = _cal_loss(_predict_layer(user_emb, E[item_id]))  -- recommender.py:76-96, reco_abc.py:220-272."""
+
+    @staticmethod
+    def forward(ctx, user_emb, model, item_id, label, user_id):
+        B, G = item_id.shape
+        cfg = ops.loss_cfg(B, G, model.embedding_size, model.loss_type, model.tau, model.SCORE_CLIP,
+                           model.config.get("ccl_w", 0.0), model.config.get("ccl_m", 0.0))
+        ub = model.user_bias.data if model.has_user_bias else None
+        ib = model.item_bias.data if model.has_item_bias else None
+        table = model.item_embedding.weight.data
+        user_emb = user_emb.contiguous()
+        scores, loss_rows, loss_out = ops.gather_dot_loss_fwd(cfg, user_emb, table, item_id, label, ub, ib,
+                                                              user_id if ub is not None else None)
+        ctx.model, ctx.cfg = model, cfg
+        ctx.save_for_backward(user_emb, item_id, label if label is not None else item_id.new_empty(0), scores, loss_out,
+                              user_id if user_id is not None else item_id.new_empty(0))
+        ctx.mark_non_differentiable(scores, loss_rows)
+        return loss_out[0], scores, loss_rows
+
+    @staticmethod
+    def backward(ctx, d_loss, _ds, _dr):
+        user_emb, item_id, label, scores, loss_out, user_id = ctx.saved_tensors
+        model, cfg = ctx.model, ctx.cfg
+        label = label if label.numel() else None
+        d_loss = d_loss.contiguous().view(1).float()
+        coef, d_user, d_ub = ops.gather_dot_loss_bwd(cfg, user_emb, model.item_embedding.weight.data, item_id, label, scores,
+                                                     loss_out, d_loss, want_user_bias=model.has_user_bias)
+        # implicit row gradient of the candidates: dE[item_id[b,g]] += coef[b,g] * user_emb[b]
+        model.sparse_grads.append(dict(table="item_embedding", ids_b=item_id, coef=coef, vec=user_emb, G=cfg.G))
+        if model.has_item_bias:   # bias vectors are tiny 1-d parameters: plain device index_add (not on the hot path)
+            g = torch.zeros_like(model.item_bias)
+            g.index_add_(0, item_id.reshape(-1), coef.reshape(-1))
+            model.item_bias.grad = g if model.item_bias.grad is None else model.item_bias.grad + g
+        if model.has_user_bias:
+            g = torch.zeros_like(model.user_bias)
+            g.index_add_(0, user_id, d_ub)
+            model.user_bias.grad = g if model.user_bias.grad is None else model.user_bias.grad + g
+        return d_user, None, None, None, None
+
+
+class _TableLookupFn(torch.autograd.Function):
+    """user_emb = U[user_id] with a row-sparse gradient (MF: recommender.py:42-44)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, table_name, idx):
+        ctx.model, ctx.table_name = model, table_name
+        ctx.save_for_backward(idx)
+        return getattr(model, table_name)(idx)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (idx,) = ctx.saved_tensors
+        ctx.model.sparse_grads.append(dict(table=ctx.table_name, ids_a=idx.to(torch.int32).contiguous(),
+                                           rows=d_out.contiguous().view(-1, d_out.shape[-1])))
+        return None, None, None, None
+
+
+class BaseRecommender(AbstractRecommender):
+    def _init_attributes(self):
+        super()._init_attributes()
+        self.dnn_inner_size = self.embedding_size
+        self.time_seq = 0
+
+    def _init_modules(self):
+        scorer_type = self.config["distance_type"]
+        if scorer_type != "dot":
+            raise NotImplementedError(f"distance_type={scorer_type!r}: only the dot-product scorer is on the accelerated path")
+        # autograd needs one differentiable input to hang the table-lookup node on
+        object.__setattr__(self, "_anchor", torch.zeros(1, device=self.device, requires_grad=True))
+        super()._init_modules()
+
+    def _define_model_layers(self):
+        pass
+
+    def add_annotation(self):
+        super().add_annotation()
+        self.annotations.append("BaseRecommender")
+
+    # ---- encoders ---------------------------------------------------------------------------
+    def forward_user_emb(self, user_id=None, item_seq=None, item_seq_len=None, item_seq_features=None, time_seq=None):
+        if torch.is_grad_enabled() and self.training:
+            return _TableLookupFn.apply(self._anchor, self, "user_embedding", user_id.contiguous())
+        return self.user_embedding(user_id)
+
+    def forward_item_emb(self, items, item_features=None):
+        return self.item_embedding(items)
+
+    def item_embedding_for_user(self, item_seq, item_seq_features=None, time_seq=None):
+        return self.item_embedding(item_seq)
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, user_id=None, item_id=None, label=None, item_features=None, item_seq=None, item_seq_len=None,
+                item_seq_features=None, time_seq=None, session_id=None, reduction=True, return_loss_only=True, max_len=None):
+        if self.loss_type == "fullsoftmax" and self.training:
+            raise NotImplementedError("fullsoftmax scores all N items per row: listed as a next row (DESIGN.md section 7)")
+        if item_id.dim() == 1:
+            item_id = item_id.unsqueeze(1)
+            label = label.unsqueeze(1) if label is not None and label.dim() == 1 else label
+        squeeze = False
+        item_id = item_id.contiguous()
+        user_emb = self.forward_user_emb(user_id, item_seq, item_seq_len, item_seq_features, time_seq)
+        if self.group_size > 0 and self.training:
+            # reference reshapes scores to [-1, group_size] (reco_abc.py:233-236): rows of one group share a user
+            raise NotImplementedError("group_size > 0 (user-item-label rows) is not on the accelerated path")
+        lab = label.to(torch.int32).contiguous() if label is not None else None
+        if self.training:
+            loss, scores, loss_rows = _ScoreLossFn.apply(user_emb, self, item_id, lab, user_id)
+            if not reduction:
+                if self.loss_type in ("bpr", "ccl"):
+                    loss = loss_rows[: item_id.shape[0]]
+                else:
+                    raise NotImplementedError("reduction=False is implemented for bpr/ccl only")
+            if return_loss_only:
+                return loss, None, None, None
+            return loss, scores, user_emb, self.forward_item_emb(item_id)
+        scores = self._predict_layer(user_emb, None, user_id, item_id)
+        if squeeze:
+            scores = scores.squeeze(1)
+        return None, scores, user_emb, self.forward_item_emb(item_id)
+
+    def _predict_layer(self, user_emb, items_emb, user_id, item_id):
+        """scores only (no loss), through the same fused gather-dot kernel; items_emb is ignored."""
+        if item_id.dim() == 1:
+            item_id = item_id.unsqueeze(1)
+        B, G = item_id.shape
+        cfg = ops.loss_cfg(B, G, self.embedding_size, "bpr", self.tau, self.SCORE_CLIP)
+        cfg.loss_type = -1  # UR_LOSS_NONE: scores only
+        ub = self.user_bias.data if self.has_user_bias else None
+        ib = self.item_bias.data if self.has_item_bias else None
+        scores, _, _ = ops.gather_dot_loss_fwd(cfg, user_emb.detach().contiguous(), self.item_embedding.weight.data,
+                                               item_id.contiguous(), None, ub, ib, user_id if ub is not None else None)
+        return scores
+
+    def predict(self, interaction):
+        inputs = {k: v for k, v in interaction.items() if k in inspect.signature(self.forward_user_emb).parameters}
+        with torch.no_grad():
+            user_emb = self.forward_user_emb(**inputs)
+            scores = self._predict_layer(user_emb, None, interaction.get("user_id"), interaction["item_id"])
+        return scores.detach().cpu().numpy()
+
+    def forward_all_item_emb(self, batch_size=None, numpy=True):
+        w = self.item_embedding.weight.detach()
+        return w.cpu().numpy() if numpy else w.clone()
+
+    def get_all_item_bias(self):
+        return self.item_bias.detach().cpu().numpy()
+
+    def get_user_bias(self, interaction):
+        return self.user_bias[interaction["user_id"]].detach().cpu().numpy()
+
+    def topk(self, interaction, k, user_hist=None, candidates=None):
+        raise NotImplementedError("full-item top-k is a 'next' row (SURVEY.md section 8 f1), not part of the training hot path")

@@ -1,0 +1,193 @@
+"""Torch-tensor front end of the C ABI: validates tensors, passes raw device pointers and the current
+HIP stream.  PyTorch is only the allocator / stream provider here; all arithmetic is in the HIP library.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_IDS, LOSS_IDS, UrAdamCfg, UrLossCfg, UrSasrecCfg, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk(t, dtype, name, allow_none=False):
+    if t is None:
+        if allow_none:
+            return
+        raise _lib.UnirecAmdError(f"{name}: tensor required")
+    if not t.is_cuda:
+        raise _lib.UnirecAmdError(f"{name}: expected a GPU tensor (unirec_amd has no CPU path), got {t.device}")
+    if t.dtype != dtype:
+        raise _lib.UnirecAmdError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.UnirecAmdError(f"{name}: tensor must be contiguous")
+
+
+# --------------------------------------------------------------------------------------------- gather
+def embedding_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """out[..., :] = table[idx[...], :]  (bit-exact).  idx: int32 or int64, any shape."""
+    _chk(table, torch.float32, "table")
+    if idx.dtype not in (torch.int32, torch.int64):
+        raise _lib.UnirecAmdError(f"idx: expected int32/int64, got {idx.dtype}")
+    _chk(idx, idx.dtype, "idx")
+    n_rows, d = table.shape
+    out = torch.empty(*idx.shape, d, dtype=torch.float32, device=table.device)
+    check(lib.ur_embedding_gather_f32(_p(table), n_rows, d, _p(idx), idx.element_size(), idx.numel(), _p(out), _stream()),
+          "ur_embedding_gather_f32")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- SASRec
+def sasrec_cfg(B, L, d, n_heads, inner, n_layers, act, use_pos, eps, last_only=0) -> UrSasrecCfg:
+    return UrSasrecCfg(B, L, d, n_heads, inner, n_layers, ACT_IDS[act], int(bool(use_pos)), float(eps), int(last_only))
+
+
+def sasrec_param_layout(cfg: UrSasrecCfg):
+    n = _lib.UR_SASREC_N_GLOBAL + cfg.n_layers * _lib.UR_SASREC_N_PER_LAYER
+    offs = (C.c_int64 * n)()
+    total = check(lib.ur_sasrec_param_layout(C.byref(cfg), offs), "ur_sasrec_param_layout")
+    return list(offs), int(total)
+
+
+def sasrec_workspace(cfg: UrSasrecCfg, device) -> torch.Tensor:
+    nbytes = check(lib.ur_sasrec_workspace_bytes(C.byref(cfg)), "ur_sasrec_workspace_bytes")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def sasrec_fwd(cfg, item_table, dense, item_seq, ws):
+    _chk(item_table, torch.float32, "item_table")
+    _chk(dense, torch.float32, "dense")
+    _chk(item_seq, torch.int32, "item_seq")
+    assert item_seq.shape == (cfg.B, cfg.L), (item_seq.shape, cfg.B, cfg.L)
+    user_emb = torch.empty(cfg.B, cfg.d, dtype=torch.float32, device=dense.device)
+    check(lib.ur_sasrec_fwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(user_emb),
+                            _p(ws), _stream()), "ur_sasrec_fwd")
+    return user_emb
+
+
+def sasrec_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws):
+    _chk(d_user_emb, torch.float32, "d_user_emb")
+    dense_grad = torch.empty_like(dense)
+    d_emb_rows = torch.empty(cfg.B * cfg.L, cfg.d, dtype=torch.float32, device=dense.device)
+    check(lib.ur_sasrec_bwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(d_user_emb),
+                            _p(ws), _p(dense_grad), _p(d_emb_rows), _stream()), "ur_sasrec_bwd")
+    return dense_grad, d_emb_rows
+
+
+# --------------------------------------------------------------------------------------------- scorer + loss
+def loss_cfg(B, G, d, loss_type, tau=1.0, score_clip=-1.0, ccl_w=0.0, ccl_m=0.0) -> UrLossCfg:
+    return UrLossCfg(B, G, d, LOSS_IDS[loss_type], float(tau), float(score_clip if score_clip else -1.0), float(ccl_w), float(ccl_m))
+
+
+def gather_dot_loss_fwd(cfg, user_emb, item_table, item_id, label=None, user_bias=None, item_bias=None, user_id=None):
+    _chk(user_emb, torch.float32, "user_emb")
+    _chk(item_table, torch.float32, "item_table")
+    _chk(item_id, torch.int64, "item_id")
+    _chk(label, torch.int32, "label", allow_none=True)
+    _chk(user_bias, torch.float32, "user_bias", allow_none=True)
+    _chk(item_bias, torch.float32, "item_bias", allow_none=True)
+    _chk(user_id, torch.int64, "user_id", allow_none=True)
+    dev = user_emb.device
+    scores = torch.empty(cfg.B, cfg.G, dtype=torch.float32, device=dev)
+    loss_rows = torch.empty(2 * cfg.B, dtype=torch.float32, device=dev)
+    loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+    check(lib.ur_gather_dot_loss_fwd(C.byref(cfg), _p(user_emb), _p(item_table), item_table.shape[0], _p(item_id), _p(label),
+                                     _p(user_bias), _p(item_bias), _p(user_id), _p(scores), _p(loss_rows), _p(loss_out),
+                                     _stream()), "ur_gather_dot_loss_fwd")
+    return scores, loss_rows, loss_out
+
+
+def gather_dot_loss_bwd(cfg, user_emb, item_table, item_id, label, scores, loss_out, d_loss=None, want_user_bias=False):
+    dev = user_emb.device
+    coef = torch.empty(cfg.B, cfg.G, dtype=torch.float32, device=dev)
+    d_user = torch.empty(cfg.B, cfg.d, dtype=torch.float32, device=dev)
+    d_ub = torch.empty(cfg.B, dtype=torch.float32, device=dev) if want_user_bias else None
+    _chk(d_loss, torch.float32, "d_loss", allow_none=True)
+    check(lib.ur_gather_dot_loss_bwd(C.byref(cfg), _p(user_emb), _p(item_table), item_table.shape[0], _p(item_id), _p(label),
+                                     _p(scores), _p(loss_out), _p(d_loss), _p(coef), _p(d_user), _p(d_ub), _stream()),
+          "ur_gather_dot_loss_bwd")
+    return coef, d_user, d_ub
+
+
+# --------------------------------------------------------------------------------------------- sparse rows
+class RowsPlan:
+    """Result of ur_rows_plan (all device tensors; n_uniq stays on the device)."""
+    __slots__ = ("n", "n_a", "uniq_idx", "seg_start", "sorted_pos", "n_uniq")
+
+
+def rows_plan(ids_a, ids_b, n_rows) -> RowsPlan:
+    """ids_a: int32 tensor or None, ids_b: int64 tensor or None (flattened internally)."""
+    dev = (ids_a if ids_a is not None else ids_b).device
+    n_a = ids_a.numel() if ids_a is not None else 0
+    n_b = ids_b.numel() if ids_b is not None else 0
+    _chk(ids_a, torch.int32, "ids_a", allow_none=True)
+    _chk(ids_b, torch.int64, "ids_b", allow_none=True)
+    n = n_a + n_b
+    pl = RowsPlan()
+    pl.n, pl.n_a = n, n_a
+    pl.uniq_idx = torch.empty(n, dtype=torch.int32, device=dev)
+    pl.seg_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    pl.sorted_pos = torch.empty(n, dtype=torch.int32, device=dev)
+    pl.n_uniq = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(check(lib.ur_rows_plan_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    check(lib.ur_rows_plan(_p(ids_a), n_a, _p(ids_b), n_b, int(n_rows), _p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos),
+                           _p(pl.n_uniq), _p(ws), _stream()), "ur_rows_plan")
+    return pl
+
+
+def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False) -> torch.Tensor:
+    _chk(rows_a, torch.float32, "rows_a", allow_none=True)
+    _chk(coef_b, torch.float32, "coef_b", allow_none=True)
+    _chk(vec_b, torch.float32, "vec_b", allow_none=True)
+    out = torch.empty(pl.n, d, dtype=torch.float32, device=pl.uniq_idx.device)
+    flag = out if zero_tail else None  # non-null sumsq pointer = "zero the rows beyond n_uniq"
+    check(lib.ur_rows_reduce(_p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, _p(rows_a), pl.n_a,
+                             _p(coef_b), _p(vec_b), int(G), int(d), _p(out), _p(flag), _stream()), "ur_rows_reduce")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- optimizer
+def adam_cfg(lr, step, wd=0.0, b1=0.9, b2=0.999, eps=1e-8) -> UrAdamCfg:
+    return UrAdamCfg(float(lr), float(b1), float(b2), float(eps), float(wd), int(step))
+
+
+def dense_adam(cfg, param, grad, m, v, grad_scale=None):
+    for t, nm in ((param, "param"), (grad, "grad"), (m, "m"), (v, "v")):
+        _chk(t, torch.float32, nm)
+    check(lib.ur_dense_adam(C.byref(cfg), _p(param), _p(grad), _p(m), _p(v), param.numel(), _p(grad_scale), _stream()),
+          "ur_dense_adam")
+
+
+def sparse_adam_rows(cfg, table, m, v, pl: RowsPlan, uniq_grad, last_step=None, grad_scale=None):
+    _chk(table, torch.float32, "table")
+    _chk(last_step, torch.int32, "last_step", allow_none=True)
+    check(lib.ur_sparse_adam_rows(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
+                                  _p(uniq_grad), table.shape[1], _p(grad_scale), _stream()), "ur_sparse_adam_rows")
+
+
+def lazy_adam_catchup(cfg, table, m, v, last_step, pl: RowsPlan):
+    _chk(last_step, torch.int32, "last_step")
+    check(lib.ur_lazy_adam_catchup(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
+                                   table.shape[1], _stream()), "ur_lazy_adam_catchup")
+
+
+def lazy_adam_flush(cfg, table, m, v, last_step, row0=0, n=None):
+    n = table.shape[0] - row0 if n is None else n
+    check(lib.ur_lazy_adam_flush(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), row0, n, table.shape[1], _stream()),
+          "ur_lazy_adam_flush")
+
+
+def sumsq(x, out, accumulate=False, ws=None):
+    ws = ws if ws is not None else torch.empty(2048, dtype=torch.float32, device=x.device)
+    check(lib.ur_sumsq(_p(x), x.numel(), _p(out), int(accumulate), _p(ws), _stream()), "ur_sumsq")
+
+
+def clip_coef(sumsq_t, max_norm, out):
+    check(lib.ur_clip_coef(_p(sumsq_t), float(max_norm), _p(out), _stream()), "ur_clip_coef")
