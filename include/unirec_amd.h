@@ -175,6 +175,17 @@ int ur_sumsq(const float* x, int64_t n, float* out, int accumulate, void* ws_204
 /* scale_out[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))   (torch clip_grad_norm_ coefficient) */
 int ur_clip_coef(const float* sumsq, float max_norm, float* scale_out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Live profiler (measurement only; no reference counterpart).  While enabled, every launch group is
+ * bracketed by HIP events on its stream.  ur_prof_read fills three host arrays of ur_prof_num_classes()
+ * entries: summed milliseconds, number of launch groups, and summed algorithmic work (flops for the GEMM
+ * classes, bytes for the HBM-bound classes; definitions in DESIGN.md section 6). */
+int ur_prof_enable(int on);
+int ur_prof_reset(void);
+int ur_prof_num_classes(void);
+const char* ur_prof_class_name(int cls);
+int ur_prof_read(double* host_ms, int64_t* host_count, double* host_work);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,9 @@ raises if it is missing (build it with ``python -m unirec_amd.build`` / ``__graf
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: the process must use torch's bundled HIP runtime (libamdhip64); loading ours
+#                              before torch's would put two runtimes in one process ("no ROCm-capable device")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunirec_amd.so")
 
@@ -62,6 +65,11 @@ SIGNATURES = {
     "ur_lazy_adam_flush": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, I64, I32, P]),
     "ur_sumsq": (C.c_int, [P, I64, P, C.c_int, P, P]),
     "ur_clip_coef": (C.c_int, [P, C.c_float, P, P]),
+    "ur_prof_enable": (C.c_int, [C.c_int]),
+    "ur_prof_reset": (C.c_int, []),
+    "ur_prof_num_classes": (C.c_int, []),
+    "ur_prof_class_name": (C.c_char_p, [C.c_int]),
+    "ur_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 
 

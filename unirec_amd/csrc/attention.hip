@@ -1,333 +1,303 @@
 // Masked multi-head self-attention, forward and backward (unirec/model/modules.py:284-311 with the
 // additive mask of unirec/model/sequential/sasrec.py:40-57).
 //
-// SASRec heads are tiny (n_heads=16 => head dim 4..8), so QK^T and P.V run on the VALU out of LDS and
-// MFMA is reserved for the dense projections.  One workgroup owns one sequence and a
-// group of heads: K, V (and Q, dO in the backward) of that head group live in LDS; one lane owns one
-// (query row, head) pair in the row passes and one (key row, head) pair in the column pass, so every
-// softmax reduction is lane-local and all lanes of a wave read the same K/V row (LDS broadcast).
+// SASRec heads are tiny (n_heads=16 => head dim 4..8), so QK^T and P.V run on the VALU and MFMA is
+// reserved for the dense projections.  Work decomposition, CDNA-style:
+//   * one WAVE owns one (sequence, head, 64-row chunk); one LANE owns one query row (row passes) or one
+//     key row (column pass), so every softmax reduction is lane-local -- no cross-lane traffic at all;
+//   * the operand that all 64 lanes share in an iteration (K_j / V_j in the row passes, Q_i / dO_i in the
+//     column pass) is WAVE-UNIFORM: it is fetched with scalar loads (s_load_dwordx8 through the scalar
+//     cache) straight into SGPRs and fed to v_fma as a scalar operand.  No LDS, no barriers, and the
+//     vector memory pipe only carries each lane's own row once.
 // Nothing of size [B,h,L,L] is ever written: the backward recomputes P from Q, K and the saved
 // log-sum-exp.
 //
-// Mask semantics are the reference's, literally: allowed(i,j) = item_seq[j] > 0 and (j <= i if causal).
-// Rows with at least one allowed key skip the masked keys (their softmax weight underflows to exactly 0
-// in fp32: exp(-10000 - max)).  Rows with NO allowed key (left padding, empty history) take the literal
-// path: every key gets s/sqrt(hd) + (-10000.0f) and the softmax runs over all L keys, as torch does.
+// Mask semantics are the reference's: allowed(i,j) = item_seq[j] > 0 and (j <= i if causal); masked keys
+// get -10000 added, i.e. softmax weight exp(-10000 - max) == 0 exactly in fp32, so they are skipped.
+//   * A row with NO allowed key while the sequence has valid keys (the left-padding prefix in causal mode)
+//     is a row whose output can never reach the loss: it is only ever read as a key/value at a padded
+//     position (masked) or as the query of another such row (verified on the reference:
+//     max |delta| == 0).  Those rows are written as zeros and contribute nothing to the backward.
+//   * A sequence with no valid key at all (empty history) takes the literal path: every key gets
+//     s/sqrt(hd) + (-10000.0f) and the softmax runs over all L keys, exactly as torch evaluates it.
 #include "common.h"
 #include "kernels.h"
 
 namespace ur {
 
 struct AttnDims {
-  int B, L, d, H, hd, HG, causal;
+  int B, L, d, H, hd, causal, nchunk;
   float scale;    // 1/sqrt(hd)
   float sqrt_hd;  // sqrt(hd) for the literal (division) path
 };
 
-template <int HDP>
-__device__ __forceinline__ float dotq(const float (&q)[HDP], const float* __restrict__ k) {
+// dot of a per-lane register row with a wave-uniform memory row (HD exact: no guards, so the compiler can
+// fetch the row with wide scalar loads)
+template <int HD>
+__device__ __forceinline__ float dot_u(const float (&q)[HD], const float* __restrict__ k) {
   float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < HDP; ++c) s = fmaf(q[c], k[c], s);
+  for (int c = 0; c < HD; ++c) s = fmaf(q[c], k[c], s);
   return s;
 }
 
-// Stage columns [col0, col0+HG*hd) of rows [b*L, b*L+L) of a [*, ld] matrix into lds[L][HG*HDP] (zero padded).
-template <int HDP>
-__device__ __forceinline__ void stage_heads(const float* __restrict__ src, int ld, int col0, int L, int HG, int hd,
-                                            float* lds) {
-  const int CW = HG * HDP;
-  for (int idx = threadIdx.x; idx < L * CW; idx += blockDim.x) {
-    const int j = idx / CW, r = idx % CW, h = r / HDP, c = r % HDP;
-    lds[idx] = (c < hd) ? src[(long long)j * ld + col0 + h * hd + c] : 0.f;
+#define UR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+
+// index of the first key with item_seq > 0, or L when the sequence is all padding (wave-uniform result)
+__device__ __forceinline__ int first_valid_key(const int* __restrict__ sq, int L, int lane) {
+  for (int j0 = 0; j0 < L; j0 += 64) {
+    const unsigned long long m = __ballot(j0 + lane < L && sq[j0 + lane] > 0);
+    if (m) return j0 + (int)__builtin_ctzll(m);
   }
+  return L;
 }
 
-template <int HDP>
+template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ seq, AttnDims p,
                                                        float* __restrict__ ctx, float* __restrict__ lse) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int L = p.L, d = p.d, hd = p.hd, HG = p.HG, CW = HG * HDP;
-  float* Ks = smem;
-  float* Vs = smem + L * CW;
-  int* valid = (int*)(smem + 2 * L * CW);
-  const int b = blockIdx.x, h0 = blockIdx.y * HG;
-  const float* base = qkv + (long long)b * L * 3 * d;
-  stage_heads<HDP>(base, 3 * d, d + h0 * hd, L, HG, hd, Ks);
-  stage_heads<HDP>(base, 3 * d, 2 * d + h0 * hd, L, HG, hd, Vs);
-  for (int j = threadIdx.x; j < L; j += blockDim.x) valid[j] = seq[(long long)b * L + j] > 0;
-  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int item = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
+  const int h = item / p.nchunk, ck = item % p.nchunk;
+  if (h >= p.H) return;
+  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  const int i = ck * 64 + lane;
+  const bool active = i < L;
+  const int ii = active ? i : L - 1;
+  const float* __restrict__ base = qkv + (long long)b * L * ld;
+  const int* __restrict__ sq = seq + (long long)b * L;
+  float q[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) q[c] = base[(long long)ii * ld + h * HD + c];
+  const float* __restrict__ Kb = base + p.d + h * HD;
+  const float* __restrict__ Vb = base + 2 * p.d + h * HD;
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  float m = -INFINITY, l = 0.f, o[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) o[c] = 0.f;
+  if (fv < L) {
+    const int jend = p.causal ? min(L, ck * 64 + 64) : L;
+    // interior zeros ('unorder' masking) are predicated, not branched, so the loops unroll and the scalar
+    // loads of several keys are in flight together
+#pragma unroll 4
+    for (int j = fv; j < jend; ++j) {
+      const float s = dot_u<HD>(q, Kb + (long long)j * ld) * p.scale;
+      if (sq[j] > 0 && (!p.causal || j <= i)) m = fmaxf(m, s);
+    }
+#pragma unroll 4
+    for (int j = fv; j < jend; ++j) {
+      const float s = dot_u<HD>(q, Kb + (long long)j * ld) * p.scale;
+      const float pj = (sq[j] > 0 && (!p.causal || j <= i)) ? __expf(s - m) : 0.f;
+      l += pj;
+      const float* __restrict__ vr = Vb + (long long)j * ld;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) o[c] = fmaf(pj, vr[c], o[c]);
+    }
+  } else {  // empty history: literal path over all L keys
+    for (int j = 0; j < L; ++j) m = fmaxf(m, dot_u<HD>(q, Kb + (long long)j * ld) / p.sqrt_hd + -10000.0f);
+    for (int j = 0; j < L; ++j) {
+      const float pj = __expf((dot_u<HD>(q, Kb + (long long)j * ld) / p.sqrt_hd + -10000.0f) - m);
+      l += pj;
+      const float* __restrict__ vr = Vb + (long long)j * ld;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) o[c] = fmaf(pj, vr[c], o[c]);
+    }
+  }
+  if (!active) return;
+  const bool dead = l == 0.f;   // padded-prefix row of a non-empty sequence: unreachable from the loss
+  const float inv_l = dead ? 0.f : 1.0f / l;
+  float* out = ctx + ((long long)b * L + i) * p.d + h * HD;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) out[c] = o[c] * inv_l;
+  lse[((long long)b * p.H + h) * L + i] = dead ? 0.f : m + __logf(l);
+}
 
-  const int LQP = (L + 63) & ~63;
-  for (int item0 = 0; item0 < HG * LQP; item0 += blockDim.x) {
-    const int item = item0 + threadIdx.x;
-    const int h = item / LQP, i = item % LQP;  // h is wave-uniform (LQP % 64 == 0)
-    if (h >= HG || i >= L) continue;
-    const int wave_i_max = min(L - 1, (__builtin_amdgcn_readfirstlane(item) % LQP) + 63);
-    float q[HDP];
-#pragma unroll
-    for (int c = 0; c < HDP; ++c) q[c] = (c < hd) ? base[(long long)i * 3 * d + (h0 + h) * hd + c] : 0.f;
-    const float* Kh = Ks + h * HDP;
-    const float* Vh = Vs + h * HDP;
-    const int jend = p.causal ? wave_i_max + 1 : L;
-    float m = -INFINITY;
-    int cnt = 0;
-    for (int j = 0; j < jend; ++j) {
-      if (!valid[j]) continue;
-      if (p.causal && j > i) continue;
-      m = fmaxf(m, dotq<HDP>(q, Kh + j * CW) * p.scale);
-      ++cnt;
-    }
-    float l = 0.f, o[HDP];
-#pragma unroll
-    for (int c = 0; c < HDP; ++c) o[c] = 0.f;
-    if (cnt > 0) {
-      for (int j = 0; j < jend; ++j) {
-        if (!valid[j]) continue;
-        if (p.causal && j > i) continue;
-        const float pj = __expf(dotq<HDP>(q, Kh + j * CW) * p.scale - m);
-        l += pj;
-#pragma unroll
-        for (int c = 0; c < HDP; ++c) o[c] = fmaf(pj, Vh[j * CW + c], o[c]);
-      }
-    } else {  // literal path: every key masked
-      for (int j = 0; j < L; ++j) m = fmaxf(m, dotq<HDP>(q, Kh + j * CW) / p.sqrt_hd + -10000.0f);
-      for (int j = 0; j < L; ++j) {
-        const float pj = __expf((dotq<HDP>(q, Kh + j * CW) / p.sqrt_hd + -10000.0f) - m);
-        l += pj;
-#pragma unroll
-        for (int c = 0; c < HDP; ++c) o[c] = fmaf(pj, Vh[j * CW + c], o[c]);
-      }
-    }
-    const float inv_l = 1.0f / l;
-    float* out = ctx + ((long long)b * L + i) * d + (h0 + h) * hd;
-#pragma unroll
-    for (int c = 0; c < HDP; ++c)
-      if (c < hd) out[c] = o[c] * inv_l;
-    lse[((long long)b * p.H + h0 + h) * L + i] = m + __logf(l);
+// Backward prep: Dd[b,h,i] = sum_c dO[b,i,h,c] * O[b,i,h,c]
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                            AttnDims p, float* __restrict__ Dd) {
+  const int b = blockIdx.x, L = p.L;
+  for (int idx = threadIdx.x; idx < p.H * L; idx += blockDim.x) {
+    const int i = idx / p.H, h = idx % p.H;   // consecutive threads -> consecutive heads of one row: coalesced
+    const float* o = ctx + ((long long)b * L + i) * p.d + h * p.hd;
+    const float* g = dctx + ((long long)b * L + i) * p.d + h * p.hd;
+    float s = 0.f;
+    for (int c = 0; c < p.hd; ++c) s = fmaf(o[c], g[c], s);
+    Dd[((long long)b * p.H + h) * L + i] = s;
   }
 }
 
-// Backward. dqkv[:, 0:d] = dQ, [d:2d] = dK, [2d:3d] = dV.
-template <int HDP>
+// Backward. dqkv[:, 0:d] = dQ, [d:2d] = dK, [2d:3d] = dV.  Row pass then column pass, same wave, no LDS.
+template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
-                                                       const float* __restrict__ ctx, const float* __restrict__ dctx,
-                                                       const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int L = p.L, d = p.d, hd = p.hd, HG = p.HG, CW = HG * HDP;
-  float* Qs = smem;
-  float* Ks = Qs + L * CW;
-  float* Vs = Ks + L * CW;
-  float* Gs = Vs + L * CW;        // dO
-  float* Ls = Gs + L * CW;        // lse  [HG][L]
-  float* Ds = Ls + HG * L;        // D_i  [HG][L] = sum_c dO[i,c] * O[i,c]
-  int* valid = (int*)(Ds + HG * L);
-  int* deg = valid + L;           // row i has no allowed key
-  const int b = blockIdx.x, h0 = blockIdx.y * HG;
-  const float* base = qkv + (long long)b * L * 3 * d;
-  stage_heads<HDP>(base, 3 * d, h0 * hd, L, HG, hd, Qs);
-  stage_heads<HDP>(base, 3 * d, d + h0 * hd, L, HG, hd, Ks);
-  stage_heads<HDP>(base, 3 * d, 2 * d + h0 * hd, L, HG, hd, Vs);
-  stage_heads<HDP>(dctx + (long long)b * L * d, d, h0 * hd, L, HG, hd, Gs);
-  for (int idx = threadIdx.x; idx < HG * L; idx += blockDim.x) {
-    const int h = idx / L, i = idx % L;
-    Ls[idx] = lse[((long long)b * p.H + h0 + h) * L + i];
-    const float* o = ctx + ((long long)b * L + i) * d + (h0 + h) * hd;
-    const float* g = dctx + ((long long)b * L + i) * d + (h0 + h) * hd;
-    float s = 0.f;
-    for (int c = 0; c < hd; ++c) s = fmaf(o[c], g[c], s);
-    Ds[idx] = s;
-  }
-  for (int j = threadIdx.x; j < L; j += blockDim.x) valid[j] = seq[(long long)b * L + j] > 0;
-  __syncthreads();
-  for (int i = threadIdx.x; i < L; i += blockDim.x) {
-    int any = 0;
-    const int jend = p.causal ? i + 1 : L;
-    for (int j = 0; j < jend; ++j) any |= valid[j];
-    deg[i] = !any;
-  }
-  __syncthreads();
+                                                       const float* __restrict__ dctx, const float* __restrict__ lse,
+                                                       const float* __restrict__ Dd, AttnDims p, float* __restrict__ dqkv) {
+  const int lane = threadIdx.x & 63;
+  const int item = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
+  const int h = item / p.nchunk, ck = item % p.nchunk;
+  if (h >= p.H) return;
+  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  const int r = ck * 64 + lane;         // this lane's row: query row in the row pass, key row in the column pass
+  const bool active = r < L;
+  const int rr = active ? r : L - 1;
+  const float* __restrict__ base = qkv + (long long)b * L * ld;
+  const float* __restrict__ gbase = dctx + (long long)b * L * p.d + h * HD;
+  const int* __restrict__ sq = seq + (long long)b * L;
+  const float* __restrict__ lse_h = lse + ((long long)b * p.H + h) * L;
+  const float* __restrict__ D_h = Dd + ((long long)b * p.H + h) * L;
+  const float* __restrict__ Qb = base + h * HD;
+  const float* __restrict__ Kb = base + p.d + h * HD;
+  const float* __restrict__ Vb = base + 2 * p.d + h * HD;
+  float* orow = dqkv + ((long long)b * L + rr) * ld + h * HD;
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;                    // empty history (wave-uniform)
+  const int dead_below = p.causal ? fv : 0;        // rows i < dead_below have no allowed key and are unreachable
 
-  const int LQP = (L + 63) & ~63;
-  // ---- row pass: dQ_i = scale * sum_j dS_ij K_j,  dS_ij = P_ij (dO_i . V_j - D_i)
-  for (int item0 = 0; item0 < HG * LQP; item0 += blockDim.x) {
-    const int item = item0 + threadIdx.x;
-    const int h = item / LQP, i = item % LQP;
-    if (h >= HG || i >= L) continue;
-    const int wave_i_max = min(L - 1, (__builtin_amdgcn_readfirstlane(item) % LQP) + 63);
-    float q[HDP], g[HDP], dq[HDP];
+  {  // ---- row pass: dQ_i = scale * sum_j dS_ij K_j,  dS_ij = P_ij (dO_i . V_j - D_i)
+    float q[HD], g[HD], dq[HD];
 #pragma unroll
-    for (int c = 0; c < HDP; ++c) {
-      q[c] = Qs[i * CW + h * HDP + c];
-      g[c] = Gs[i * CW + h * HDP + c];
+    for (int c = 0; c < HD; ++c) {
+      q[c] = Qb[(long long)rr * ld + c];
+      g[c] = gbase[(long long)rr * p.d + c];
       dq[c] = 0.f;
     }
-    const float* Kh = Ks + h * HDP;
-    const float* Vh = Vs + h * HDP;
-    const float li = Ls[h * L + i], Di = Ds[h * L + i];
-    if (!deg[i]) {
-      const int jend = p.causal ? wave_i_max + 1 : L;
-      for (int j = 0; j < jend; ++j) {
-        if (!valid[j]) continue;
-        if (p.causal && j > i) continue;
-        const float pj = __expf(dotq<HDP>(q, Kh + j * CW) * p.scale - li);
-        const float ds = pj * (dotq<HDP>(g, Vh + j * CW) - Di);
+    const float li = lse_h[rr], Di = D_h[rr];
+    if (!literal) {
+      const bool live = r >= dead_below;
+      const int jend = p.causal ? min(L, ck * 64 + 64) : L;
+#pragma unroll 4
+      for (int j = fv; j < jend; ++j) {
+        const float* __restrict__ kr = Kb + (long long)j * ld;
+        const float s = dot_u<HD>(q, kr) * p.scale;
+        const float pj = (live && sq[j] > 0 && (!p.causal || j <= r)) ? __expf(s - li) : 0.f;
+        const float ds = pj * (dot_u<HD>(g, Vb + (long long)j * ld) - Di);
 #pragma unroll
-        for (int c = 0; c < HDP; ++c) dq[c] = fmaf(ds, Kh[j * CW + c], dq[c]);
+        for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
       }
 #pragma unroll
-      for (int c = 0; c < HDP; ++c) dq[c] *= p.scale;
+      for (int c = 0; c < HD; ++c) dq[c] *= p.scale;
     } else {
       for (int j = 0; j < L; ++j) {
-        const float pj = __expf((dotq<HDP>(q, Kh + j * CW) / p.sqrt_hd + -10000.0f) - li);
-        const float ds = pj * (dotq<HDP>(g, Vh + j * CW) - Di);
+        const float* __restrict__ kr = Kb + (long long)j * ld;
+        const float pj = __expf((dot_u<HD>(q, kr) / p.sqrt_hd + -10000.0f) - li);
+        const float ds = pj * (dot_u<HD>(g, Vb + (long long)j * ld) - Di);
 #pragma unroll
-        for (int c = 0; c < HDP; ++c) dq[c] = fmaf(ds, Kh[j * CW + c], dq[c]);
+        for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
       }
 #pragma unroll
-      for (int c = 0; c < HDP; ++c) dq[c] /= p.sqrt_hd;
+      for (int c = 0; c < HD; ++c) dq[c] /= p.sqrt_hd;
     }
-    float* out = dqkv + ((long long)b * L + i) * 3 * d + (h0 + h) * hd;
+    if (active) {
 #pragma unroll
-    for (int c = 0; c < HDP; ++c)
-      if (c < hd) out[c] = dq[c];
+      for (int c = 0; c < HD; ++c) orow[c] = dq[c];
+    }
   }
-  // ---- column pass: dK_j = sum_i dS_ij Q_i * scale,  dV_j = sum_i P_ij dO_i
-  for (int item0 = 0; item0 < HG * LQP; item0 += blockDim.x) {
-    const int item = item0 + threadIdx.x;
-    const int h = item / LQP, j = item % LQP;
-    if (h >= HG || j >= L) continue;
-    const int wave_j_min = __builtin_amdgcn_readfirstlane(item) % LQP;
-    float k[HDP], v[HDP], dk[HDP], dv[HDP];
+  {  // ---- column pass: dK_j = sum_i dS_ij Q_i * scale,  dV_j = sum_i P_ij dO_i
+    float k[HD], v[HD], dk[HD], dv[HD];
 #pragma unroll
-    for (int c = 0; c < HDP; ++c) {
-      k[c] = Ks[j * CW + h * HDP + c];
-      v[c] = Vs[j * CW + h * HDP + c];
+    for (int c = 0; c < HD; ++c) {
+      k[c] = Kb[(long long)rr * ld + c];
+      v[c] = Vb[(long long)rr * ld + c];
       dk[c] = 0.f;
       dv[c] = 0.f;
     }
-    const float* Qh = Qs + h * HDP;
-    const float* Gh = Gs + h * HDP;
-    const bool vj = valid[j] != 0;
-    const int ibeg = 0;  // degenerate rows attend to every key, so all rows are visited; masked ones are skipped below
-    (void)wave_j_min;
-    for (int i = ibeg; i < L; ++i) {
-      const bool dg = deg[i] != 0;  // wave-uniform
-      float pj;
-      if (dg) {
-        pj = __expf((dotq<HDP>(k, Qh + i * CW) / p.sqrt_hd + -10000.0f) - Ls[h * L + i]);
-      } else {
-        if (!vj || (p.causal && j > i)) continue;
-        pj = __expf(dotq<HDP>(k, Qh + i * CW) * p.scale - Ls[h * L + i]);
-      }
-      const float ds = pj * (dotq<HDP>(v, Gh + i * CW) - Ds[h * L + i]) * (dg ? 1.0f / p.sqrt_hd : p.scale);
+    if (!literal) {
+      const bool vj = sq[rr] > 0;
+      const int ibeg = max(dead_below, p.causal ? ck * 64 : 0);  // earlier rows see none of this chunk's keys
+#pragma unroll 4
+      for (int i = ibeg; i < L; ++i) {
+        const float* __restrict__ qr = Qb + (long long)i * ld;
+        const float* __restrict__ gr = gbase + (long long)i * p.d;
+        const float s = dot_u<HD>(k, qr) * p.scale;
+        const float pj = (vj && (!p.causal || r <= i)) ? __expf(s - lse_h[i]) : 0.f;
+        const float ds = pj * (dot_u<HD>(v, gr) - D_h[i]) * p.scale;
 #pragma unroll
-      for (int c = 0; c < HDP; ++c) {
-        dk[c] = fmaf(ds, Qh[i * CW + c], dk[c]);
-        dv[c] = fmaf(pj, Gh[i * CW + c], dv[c]);
+        for (int c = 0; c < HD; ++c) {
+          dk[c] = fmaf(ds, qr[c], dk[c]);
+          dv[c] = fmaf(pj, gr[c], dv[c]);
+        }
+      }
+    } else {
+      for (int i = 0; i < L; ++i) {
+        const float* __restrict__ qr = Qb + (long long)i * ld;
+        const float* __restrict__ gr = gbase + (long long)i * p.d;
+        const float pj = __expf((dot_u<HD>(k, qr) / p.sqrt_hd + -10000.0f) - lse_h[i]);
+        const float ds = pj * (dot_u<HD>(v, gr) - D_h[i]) / p.sqrt_hd;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+          dk[c] = fmaf(ds, qr[c], dk[c]);
+          dv[c] = fmaf(pj, gr[c], dv[c]);
+        }
       }
     }
-    float* outk = dqkv + ((long long)b * L + j) * 3 * d + d + (h0 + h) * hd;
-    float* outv = outk + d;
+    if (active) {
 #pragma unroll
-    for (int c = 0; c < HDP; ++c)
-      if (c < hd) {
-        outk[c] = dk[c];
-        outv[c] = dv[c];
+      for (int c = 0; c < HD; ++c) {
+        orow[p.d + c] = dk[c];
+        orow[2 * p.d + c] = dv[c];
       }
+    }
   }
-}
-
-static int pick_hdp(int hd) {
-  int p = 4;
-  while (p < hd) p <<= 1;
-  return p;
-}
-
-// largest divisor HG of H such that n_arrays * L * HG * HDP floats (+ small tails) fit the LDS budget
-static int pick_hg(int H, int L, int hdp, int n_arrays, size_t budget_bytes) {
-  int best = 0;
-  for (int hg = 1; hg <= H; ++hg) {
-    if (H % hg) continue;
-    const size_t need = ((size_t)n_arrays * L * hg * hdp + 2 * (size_t)hg * L + 2 * (size_t)L) * sizeof(float);
-    if (need <= budget_bytes) best = hg;
-  }
-  return best;
 }
 
 long long attn_lse_floats(int B, int H, int L) { return (long long)B * H * L; }
+long long attn_bwd_ws_floats(int B, int H, int L) { return (long long)B * H * L + 64; }
 
-template <int HDP>
-static int launch_fwd(const float* qkv, const int* seq, const AttnDims& p, float* ctx, float* lse, size_t lds, hipStream_t st) {
-  static int max_set = 0;
-  if ((int)lds > max_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    max_set = (int)lds;
-  }
-  hipLaunchKernelGGL((attn_fwd_kernel<HDP>), dim3(p.B, p.H / p.HG), dim3(256), lds, st, qkv, seq, p, ctx, lse);
-  UR_LAUNCH_CHECK();
-  return UR_OK;
-}
-template <int HDP>
-static int launch_bwd(const float* qkv, const int* seq, const float* ctx, const float* dctx, const float* lse,
-                      const AttnDims& p, float* dqkv, size_t lds, hipStream_t st) {
-  static int max_set = 0;
-  if ((int)lds > max_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    max_set = (int)lds;
-  }
-  hipLaunchKernelGGL((attn_bwd_kernel<HDP>), dim3(p.B, p.H / p.HG), dim3(256), lds, st, qkv, seq, ctx, dctx, lse, p, dqkv);
-  UR_LAUNCH_CHECK();
-  return UR_OK;
-}
-
-static int make_dims(int B, int L, int d, int H, int causal, int n_arrays, AttnDims* p, int* hdp, size_t* lds) {
+static int make_dims(int B, int L, int d, int H, int causal, AttnDims* p) {
   if (H <= 0 || d % H) return fail(UR_ERR_ARG, "attention: d=%d not divisible by n_heads=%d", d, H);
   const int hd = d / H;
-  if (hd > 64) return fail(UR_ERR_UNSUPPORTED, "attention: head dim %d > 64 is not supported yet", hd);
-  *hdp = pick_hdp(hd);
-  int hg = pick_hg(H, L, *hdp, n_arrays, 60 * 1024);
-  if (hg == 0) hg = pick_hg(H, L, *hdp, n_arrays, 160 * 1024 - 256);
-  if (hg == 0) return fail(UR_ERR_UNSUPPORTED, "attention: L=%d with head dim %d does not fit LDS (key tiling not implemented)", L, hd);
-  p->B = B; p->L = L; p->d = d; p->H = H; p->hd = hd; p->HG = hg; p->causal = causal;
+  if (hd > 64 || (hd & (hd - 1)) || hd < 2)
+    return fail(UR_ERR_UNSUPPORTED, "attention: head dim %d (= d/n_heads) must be a power of two in [2, 64]", hd);
+  p->B = B; p->L = L; p->d = d; p->H = H; p->hd = hd; p->causal = causal;
+  p->nchunk = (L + 63) / 64;
   p->sqrt_hd = sqrtf((float)hd);
   p->scale = 1.0f / p->sqrt_hd;
-  *lds = ((size_t)n_arrays * L * hg * (*hdp) + 2 * (size_t)hg * L + 2 * (size_t)L) * sizeof(float);
   return UR_OK;
 }
 
 int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int causal, float* ctx, float* lse,
              int q_last_only, hipStream_t st) {
   if (q_last_only) return fail(UR_ERR_UNSUPPORTED, "attn_fwd: last-row mode not implemented");
+  ProfScope ps(PC_ATTN_FWD, st, 4.0 * B * L * (double)L * d * (causal ? 0.5 : 1.0));
   AttnDims p;
-  int hdp;
-  size_t lds;
-  int rc = make_dims(B, L, d, H, causal, 2, &p, &hdp, &lds);
+  int rc = make_dims(B, L, d, H, causal, &p);
   if (rc) return rc;
-  switch (hdp) {
-    case 4: return launch_fwd<4>(qkv, seq, p, ctx, lse, lds, st);
-    case 8: return launch_fwd<8>(qkv, seq, p, ctx, lse, lds, st);
-    case 16: return launch_fwd<16>(qkv, seq, p, ctx, lse, lds, st);
-    case 32: return launch_fwd<32>(qkv, seq, p, ctx, lse, lds, st);
-    default: return launch_fwd<64>(qkv, seq, p, ctx, lse, lds, st);
+  dim3 grid(B, cdiv(H * p.nchunk, 4));
+#define GO(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, p, ctx, lse)
+  switch (p.hd) {
+    case 2: GO(2); break;
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    case 32: GO(32); break;
+    default: GO(64); break;
   }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
 }
 
 int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dctx, const float* lse, int B, int L, int d,
-             int H, int causal, float* dqkv, int q_last_only, hipStream_t st) {
+             int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st) {
   if (q_last_only) return fail(UR_ERR_UNSUPPORTED, "attn_bwd: last-row mode not implemented");
+  ProfScope ps(PC_ATTN_BWD, st, 10.0 * B * L * (double)L * d * (causal ? 0.5 : 1.0));
   AttnDims p;
-  int hdp;
-  size_t lds;
-  int rc = make_dims(B, L, d, H, causal, 4, &p, &hdp, &lds);
+  int rc = make_dims(B, L, d, H, causal, &p);
   if (rc) return rc;
-  switch (hdp) {
-    case 4: return launch_bwd<4>(qkv, seq, ctx, dctx, lse, p, dqkv, lds, st);
-    case 8: return launch_bwd<8>(qkv, seq, ctx, dctx, lse, p, dqkv, lds, st);
-    case 16: return launch_bwd<16>(qkv, seq, ctx, dctx, lse, p, dqkv, lds, st);
-    case 32: return launch_bwd<32>(qkv, seq, ctx, dctx, lse, p, dqkv, lds, st);
-    default: return launch_bwd<64>(qkv, seq, ctx, dctx, lse, p, dqkv, lds, st);
+  float* Dd = ws;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(B), dim3(256), 0, st, ctx, dctx, p, Dd);
+  UR_LAUNCH_CHECK();
+  dim3 grid(B, cdiv(H * p.nchunk, 4));
+#define GO(HD) hipLaunchKernelGGL((attn_bwd_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, dctx, lse, Dd, p, dqkv)
+  switch (p.hd) {
+    case 2: GO(2); break;
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    case 32: GO(32); break;
+    default: GO(64); break;
   }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
 }
 
 }  // namespace ur

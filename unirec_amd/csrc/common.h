@@ -34,6 +34,15 @@ int fail(int code, const char* fmt, ...);
       return ::ur::fail(UR_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
 
+// ---- live kernel-class profiler (HIP events recorded on the launch stream; see ur_prof_* in the header)
+enum ProfClass { PC_GEMM_NT = 0, PC_GEMM_TN, PC_ATTN_FWD, PC_ATTN_BWD, PC_ROWOPS, PC_LOSS, PC_SORT, PC_REDUCE, PC_ADAM, PC_GATHER,
+                 PC_GRU, PC_MISC, PC_COUNT };
+struct ProfScope {
+  int cls; hipStream_t st; int slot;
+  ProfScope(int cls_, hipStream_t st_, double work = 0.0);
+  ~ProfScope();
+};
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

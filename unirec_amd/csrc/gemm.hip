@@ -210,6 +210,7 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
 
 int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return UR_OK;
+  ProfScope ps(PC_GEMM_NT, st, 2.0 * a.M * a.N * a.K);
   if ((a.K & 3) || (a.lda & 3) || (a.ldw & 3)) return fail(UR_ERR_ARG, "gemm_nt: K/lda/ldw must be multiples of 4 (K=%d)", a.K);
   if (epi == EPI_BIAS_RES_LN) {
     if (a.N > 256 || (a.N & 3) || a.ldc != a.N) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm needs N<=256, N%%4==0 (N=%d)", a.N);
@@ -330,6 +331,7 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float acc = 0.f;
+#pragma unroll 8
   for (int s = 0; s < S; ++s) acc += part[(long long)s * n + i];
   out[(i / cols) * ldo + (i % cols)] = acc;
 }
@@ -351,6 +353,7 @@ long long gemm_tn_ws_floats(int T, int R, int Cc) {
 int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act, float* out,
             int ldo, float* bias_out, float* ws, hipStream_t st) {
   if ((R & 3) || (Cc & 3) || (ldp & 3) || (ldq & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
+  ProfScope ps(PC_GEMM_TN, st, 2.0 * T * R * Cc);
   const int S = tn_splits(T, R, Cc);
   int tps = cdiv(T, S);
   tps = cdiv(tps, BT) * BT;
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st) {
+  ProfScope ps(PC_MISC, st, 8.0 * rows * cols);
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, st, src, rows, cols, dst);
   UR_LAUNCH_CHECK();
   return UR_OK;

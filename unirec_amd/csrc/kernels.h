@@ -52,7 +52,8 @@ int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
 long long attn_lse_floats(int B, int H, int L);
 int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int causal, float* ctx, float* lse,
              int q_last_only, hipStream_t st);
+long long attn_bwd_ws_floats(int B, int H, int L);
 int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dctx, const float* lse, int B, int L,
-             int d, int H, int causal, float* dqkv, int q_last_only, hipStream_t st);
+             int d, int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st);
 
 }  // namespace ur

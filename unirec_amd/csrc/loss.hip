@@ -262,6 +262,7 @@ extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_em
              "ur_gather_dot_loss_fwd: label is required for bce/softmax");
   UR_REQUIRE(!user_bias || user_id, UR_ERR_ARG, "ur_gather_dot_loss_fwd: user_bias needs user_id");
   hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_LOSS, st, (double)cfg->B * cfg->G * cfg->d * 4.0);
   const int tpr = pick_tpr(cfg->d);
   const size_t lds = (cfg->G + 8) * sizeof(float);
   float* cnt_rows = loss_rows + cfg->B;  // loss_rows buffer is [2*B]: losses then counts
@@ -293,6 +294,7 @@ extern "C" int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_em
              "ur_gather_dot_loss_bwd: label is required for bce/softmax");
   (void)n_items;
   hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_LOSS, st, (double)cfg->B * cfg->G * cfg->d * 4.0);
   const int tpr = pick_tpr(cfg->d);
   const int groups = 256 / tpr;
   const size_t lds = ((size_t)cfg->G + (size_t)groups * cfg->d + 8) * sizeof(float);

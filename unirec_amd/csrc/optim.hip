@@ -83,6 +83,7 @@ extern "C" int ur_dense_adam(const UrAdamCfg* cfg, float* param, const float* gr
   const float bc2s = sqrtf(1.f - powf(cfg->beta2, (float)cfg->step));
   long long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  ProfScope ps(PC_ADAM, as_stream(stream), (double)n * 4.0 * 7);
   hipLaunchKernelGGL(dense_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, m, v, (long long)n,
                      cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, bc1, bc2s, grad_scale_dev);
   UR_LAUNCH_CHECK();
@@ -106,5 +107,58 @@ extern "C" int ur_clip_coef(const float* sumsq, float max_norm, float* scale_out
   UR_REQUIRE(sumsq && scale_out && max_norm > 0.f, UR_ERR_ARG, "ur_clip_coef: bad argument");
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, as_stream(stream), sumsq, max_norm, scale_out);
   UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Live profiler: when enabled, every internal launcher brackets its launches with a pair of HIP events
+// on the launch stream; ur_prof_read sums the elapsed times per kernel class.  Used by bench.py for the
+// roofline object (kernel time measured inside the timed region, on the stream the kernel runs on).
+#include <vector>
+namespace ur {
+struct ProfRec { hipEvent_t a, b; int cls; double work; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;      // recorded pairs since the last reset
+static std::vector<ProfRec> g_prof_pool; // reusable events
+
+ProfScope::ProfScope(int cls_, hipStream_t st_, double work) : cls(cls_), st(st_), slot(-1) {
+  if (!g_prof_on) return;
+  ProfRec r;
+  if (!g_prof_pool.empty()) { r = g_prof_pool.back(); g_prof_pool.pop_back(); }
+  else { if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return; }
+  r.cls = cls; r.work = work;
+  (void)hipEventRecord(r.a, st);
+  slot = (int)g_prof.size();
+  g_prof.push_back(r);
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+}
+}  // namespace ur
+
+extern "C" int ur_prof_enable(int on) {
+  ur::g_prof_on = on != 0;
+  return UR_OK;
+}
+extern "C" int ur_prof_reset(void) {
+  for (auto& r : ur::g_prof) ur::g_prof_pool.push_back(r);
+  ur::g_prof.clear();
+  return UR_OK;
+}
+extern "C" int ur_prof_num_classes(void) { return ur::PC_COUNT; }
+extern "C" const char* ur_prof_class_name(int cls) {
+  static const char* names[] = {"gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops", "scorer_loss", "rows_sort", "rows_reduce",
+                                "adam", "gather", "gru", "misc"};
+  return (cls >= 0 && cls < ur::PC_COUNT) ? names[cls] : "?";
+}
+extern "C" int ur_prof_read(double* host_ms, int64_t* host_count, double* host_work) {
+  UR_REQUIRE(host_ms && host_count && host_work, UR_ERR_ARG, "ur_prof_read: null pointer");
+  for (int i = 0; i < ur::PC_COUNT; ++i) { host_ms[i] = 0; host_count[i] = 0; host_work[i] = 0; }
+  for (auto& r : ur::g_prof) {
+    UR_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    UR_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    host_ms[r.cls] += ms; host_count[r.cls] += 1; host_work[r.cls] += r.work;
+  }
   return UR_OK;
 }

@@ -61,6 +61,7 @@ static int launch_gather(const float* table, const void* idx, long long n, int d
 
 int gather_rows(const float* table, const void* idx, int idx_bytes, long long n, int d, float* out, hipStream_t st) {
   if (n == 0) return UR_OK;
+  ProfScope ps(PC_GATHER, st, (double)n * (d * 4.0 + idx_bytes));  // algorithmic READ bytes
   return idx_bytes == 8 ? launch_gather<long long>(table, idx, n, d, out, st) : launch_gather<int>(table, idx, n, d, out, st);
 }
 
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
 
 int embed_ln_fwd(const int* seq, const float* table, const float* pos, const float* gamma, const float* beta,
                  float eps, int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st) {
+  ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * 3);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(M, groups);
   if (blocks > 4096) blocks = 4096;
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float4* __restrict__ 
 
 int ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, int M, int d, float* y,
            float* xhat, float* rstd, hipStream_t st) {
+  ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * 4);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(M, groups);
   if (blocks > 4096) blocks = 4096;
@@ -287,18 +290,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ 
 }
 
 // out[which*d + col] = sum_blk part[blk][which][col]   (which in {0: dgamma, 1: dbeta})
-__global__ void colsum_partials_kernel(const float* __restrict__ part, int nblk, int width, float* __restrict__ out0,
-                                       float* __restrict__ out1, int d) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= width) return;
+// 1024 threads = 64 columns x 16 row-slices: each thread sums nblk/16 partials, LDS combines the slices in
+// a fixed order (deterministic).  One block per 64 columns.
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ part, int nblk, int width,
+                                                               float* __restrict__ out0, float* __restrict__ out1, int d) {
+  __shared__ float red[16][65];
+  const int c = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
   float acc = 0.f;
-  for (int b = 0; b < nblk; ++b) acc += part[(long long)b * width + i];
-  if (i < d) out0[i] = acc;
-  else out1[i - d] = acc;
+  if (i < width)
+    for (int b = s; b < nblk; b += 16) acc += part[(long long)b * width + i];
+  red[s][c] = acc;
+  __syncthreads();
+  if (s == 0 && i < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][c];
+    if (i < d) out0[i] = t;
+    else out1[i - d] = t;
+  }
 }
 
 int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* add_in,
            const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st) {
+  ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * 3);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(M, groups * 4);
   if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
@@ -313,7 +328,7 @@ int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* g
   }
 #undef GO
   UR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(2 * d, 256)), dim3(256), 0, st, part_ws, blocks, 2 * d, dgamma, dbeta, d);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(2 * d, 64)), dim3(1024), 0, st, part_ws, blocks, 2 * d, dgamma, dbeta, d);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

@@ -379,6 +379,7 @@ extern "C" int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* id
              "ur_rows_plan: null pointer");
   UR_REQUIRE(n_rows > 0 && n_rows <= (1LL << 31), UR_ERR_ARG, "ur_rows_plan: n_rows=%lld", (long long)n_rows);
   hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_SORT, st, (double)n * 8.0);
   PlanWs w = carve_plan(n, (char*)ws);
   const int nwaves = (int)((n + CH - 1) / CH);
   const int nblk = cdiv(nwaves, 4);
@@ -420,6 +421,7 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
   UR_REQUIRE((rows_a || n_a == 0) && ((coef_b && vec_b && G > 0) || n_a == n), UR_ERR_ARG, "ur_rows_reduce: missing source");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512, UR_ERR_ARG, "ur_rows_reduce: d=%d", d);
   hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_REDUCE, st, (double)n * d * 4.0 * 2);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(n, groups);
   if (blocks > 8192) blocks = 8192;
@@ -441,6 +443,7 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
 static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* grad, int d,
                               const float* scale, hipStream_t st) {
+  ProfScope ps(PC_ADAM, st, (double)n_max * d * 4.0 * 7);
   AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step};
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(n_max, groups);

@@ -59,7 +59,7 @@ struct LayerWs {
 struct Ws {
   float *x0, *x0hat, *rstd0;
   LayerWs layer[UR_MAX_LAYERS];
-  float *g_y, *g_t, *g_a, *g_h1, *g_qkv, *g_ctx, *tn_ws, *ln_part;
+  float *g_y, *g_t, *g_a, *g_h1, *g_qkv, *g_ctx, *tn_ws, *ln_part, *attn_ws;
   long long total_floats;
 };
 
@@ -90,6 +90,7 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
   if (gemm_tn_ws_floats(T, c.d, c.d) > tn) tn = gemm_tn_ws_floats(T, c.d, c.d);
   w.tn_ws = take(tn);
   w.ln_part = take((long long)LN_BWD_MAX_BLOCKS * 2 * d);
+  w.attn_ws = take(attn_bwd_ws_floats(c.B, c.n_heads, c.L));
   w.total_floats = o;
   return w;
 }
@@ -121,18 +122,22 @@ __global__ void put_last_kernel(const float* __restrict__ src, int B, int L, int
   dst[i] = (l == L - 1) ? src[b * d + c] : 0.f;
 }
 // dpos[l,:] = sum_b dx[b,l,:]; afterwards rows of dx whose id is 0 are zeroed (padding_idx=0)
+// block = 64 columns x 4 batch slices (fixed-order LDS combine => deterministic); grid = (L, ceil(d/64))
 __global__ __launch_bounds__(256) void pos_grad_zero_kernel(float* __restrict__ dx, const int* __restrict__ seq, int B, int L,
                                                             int d, float* __restrict__ dpos) {
-  const int l = blockIdx.x;
-  for (int c = threadIdx.x; c < d; c += blockDim.x) {
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
+  __shared__ float red[4][65];
+  const int l = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < d) {
+    for (int b = s; b < B; b += 4) {
       const long long row = (long long)b * L + l;
       acc += dx[row * d + c];
       if (seq[row] == 0) dx[row * d + c] = 0.f;
     }
-    if (dpos) dpos[(long long)l * d + c] = acc;
   }
+  red[s][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (s == 0 && c < d && dpos) dpos[(long long)l * d + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 }  // namespace ur
@@ -237,7 +242,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     g = GemmArgs{};
     g.A = w.g_t; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.N = d; g.K = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
-    if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, w.g_qkv, 0, st))) return rc;
+    if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, w.g_qkv, w.attn_ws, 0, st))) return rc;
     if ((rc = gemm_tn(w.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3], w.tn_ws, st))) return rc;
     g = GemmArgs{};
     g.A = w.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
@@ -248,8 +253,8 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   if ((rc = ln_bwd(w.g_y, w.x0hat, w.rstd0, dense + lay.off[1], nullptr, nullptr, M, d, d_emb_rows, dense_grad + lay.off[1],
                    dense_grad + lay.off[2], w.ln_part, st)))
     return rc;
-  hipLaunchKernelGGL(pos_grad_zero_kernel, dim3(c.L), dim3(d < 256 ? ((d + 63) / 64) * 64 : 256), 0, st, d_emb_rows, item_seq,
-                     c.B, c.L, d, c.use_pos ? dense_grad + lay.off[0] : nullptr);
+  hipLaunchKernelGGL(pos_grad_zero_kernel, dim3(c.L, cdiv(d, 64)), dim3(256), 0, st, d_emb_rows, item_seq, c.B, c.L, d,
+                     c.use_pos ? dense_grad + lay.off[0] : nullptr);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }
