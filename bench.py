@@ -183,12 +183,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if os.environ.get("UR_BENCH_SHARE_DEVICE") == "1":   # debugging aid only: several ranks on one GPU (1-GPU dev boxes)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group(os.environ.get("UR_BENCH_BACKEND", "nccl"),
+                                device_id=device if os.environ.get("UR_BENCH_BACKEND", "nccl") == "nccl" else None)
 
     from unirec_amd import _lib, ops
     from unirec_amd.facility.optimizer import SparseDenseAdam

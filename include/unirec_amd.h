@@ -133,6 +133,17 @@ int64_t ur_rows_plan_workspace_bytes(int64_t n);
 int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
                  int32_t* uniq_idx, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws,
                  void* stream);
+/* Row-sharded table (row i lives on rank i % world at local row i / world; SURVEY.md 8e -- not in the reference,
+ * whose only strategy is DDP over a replicated dense table: unirec/facility/trainer.py:67).  Same as ur_rows_plan,
+ * but the sort key is owner * ceil(n_rows/world) + local_row, so uniq_key[] is grouped by owner rank and
+ * owner_counts_dev[r] (device int32[world]) = number of distinct rows requested from rank r: the all-to-all split. */
+int ur_rows_plan_sharded(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
+                         int32_t world, int32_t* uniq_key, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev,
+                         int32_t* owner_counts_dev, void* ws, void* stream);
+/* idx_a[p] (p < n_a) / idx_b[p - n_a] = u for every lookup position p in the run of unique key u: the batch's
+ * lookups re-expressed as indices into the compact [n_uniq, d] table of fetched rows. */
+int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n, int64_t n_a,
+                     int32_t* idx_a, int64_t* idx_b, void* stream);
 /* uniq_grad[u,:] = sum over the run of uniq_idx[u] (in sorted, i.e. position, order) of
  *   rows_a[p,:]                      for p <  n_a
  *   coef_b[p-n_a] * vec_b[(p-n_a)/G,:] for p >= n_a     (the scorer's implicit candidate-row gradient)

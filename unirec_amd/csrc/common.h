@@ -75,9 +75,9 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
   switch (act) {
     case UR_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
     case UR_ACT_RELU: return fmaxf(x, 0.0f);
-    case UR_ACT_SWISH: return x / (1.0f + expf(-x));
+    case UR_ACT_SWISH: return __fdividef(x, 1.0f + __expf(-x));   // v_exp_f32 + v_rcp_f32: ~1e-7 relative
     case UR_ACT_TANH: return tanhf(x);
-    case UR_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    case UR_ACT_SIGMOID: return __fdividef(1.0f, 1.0f + __expf(-x));
     default: return x;
   }
 }
@@ -91,7 +91,7 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
     }
     case UR_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
     case UR_ACT_SWISH: {
-      const float s = 1.0f / (1.0f + expf(-x));
+      const float s = __fdividef(1.0f, 1.0f + __expf(-x));
       return s * (1.0f + x * (1.0f - s));
     }
     case UR_ACT_TANH: {

@@ -9,6 +9,10 @@
 // Tiling: 256 threads = 4 waves in a 2x2 arrangement, each wave owns TM x TN MFMA tiles of 32x32.
 // Operands are staged global -> registers -> LDS (double buffered, one barrier per K-step); LDS rows
 // are padded to BK+4 floats so that the ds_read_b128 fragment reads are bank-conflict free.
+// Epilogue: the accumulator tile goes through LDS (the staging buffers are free by then) so that every
+// global access of the epilogue -- C, the residual / pre-activation operand, xhat -- is a coalesced
+// 16-byte-per-lane row access; writing the MFMA fragment layout directly costs 64 dword stores per lane
+// and made the store tail as long as the K loop.
 #include "common.h"
 #include "kernels.h"
 
@@ -45,19 +49,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // out-of-range rows are clamped (their results are never stored); only the K tail needs zero fill
+  const float* Ap[AV];
+  const float* Wp[WV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) Ap[i] = a.A + (long long)min(m0 + lrow + 32 * i, a.M - 1) * a.lda + c4 * 4;
+#pragma unroll
+  for (int i = 0; i < WV; ++i) Wp[i] = a.W + (long long)min(n0 + lrow + 32 * i, a.N - 1) * a.ldw + c4 * 4;
+
   float4 ra[AV], rw[WV];
   auto load_global = [&](int kt) {
-    const int k = kt * BK + c4 * 4;
-    const bool kin = k < a.K;
+    const int k = kt * BK;
+    if (k + c4 * 4 < a.K) {
 #pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      const int m = m0 + lrow + 32 * i;
-      ra[i] = (kin && m < a.M) ? *(const float4*)(a.A + (long long)m * a.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+      for (int i = 0; i < AV; ++i) ra[i] = *(const float4*)(Ap[i] + k);
 #pragma unroll
-    for (int i = 0; i < WV; ++i) {
-      const int n = n0 + lrow + 32 * i;
-      rw[i] = (kin && n < a.N) ? *(const float4*)(a.W + (long long)n * a.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < WV; ++i) rw[i] = *(const float4*)(Wp[i] + k);
+    } else {
+#pragma unroll
+      for (int i = 0; i < AV; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < WV; ++i) rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_lds = [&](int buf) {
@@ -102,47 +114,52 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue.  acc[r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 inside the 32x32 tile
-  const int lcol = lane & 31, lrow4 = 4 * (lane >> 5);
+  // ---- epilogue.  acc[r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 inside the 32x32 tile.
+  constexpr int CS = BN + 4;
+  float* Cs = smem;  // [BM][CS] -- staging buffers are dead after the loop's final barrier
+  {
+    const int lcol = lane & 31, lrow4 = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nl = wc * (BN / 2) + j * 32 + lcol;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
+          Cs[ml * CS + nl] = acc[i][j][r];
+        }
+      }
+  }
+  __syncthreads();
   if constexpr (EPI != EPI_BIAS_RES_LN) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wc * (BN / 2) + j * 32 + lcol;
-        if (n >= a.N) continue;
-        const float bias = (EPI == EPI_BIAS) ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
-          if (m >= a.M) continue;
-          float v = acc[i][j][r] + bias;
-          if (EPI == EPI_MUL_DACT) v *= act_bwd(a.aux[(long long)m * a.ldaux + n], a.act);
-          if (EPI == EPI_ADD) v += a.aux[(long long)m * a.ldaux + n];
-          a.C[(long long)m * a.ldc + n] = v;
+    constexpr int RT = BN / 4;         // threads per row (one float4 each)
+    constexpr int RPP = 256 / RT;      // rows per pass
+    const int t = tid % RT, g = tid / RT;
+    const int n = n0 + t * 4;
+    if (n < a.N) {  // N % 4 == 0
+      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (EPI == EPI_BIAS) bias = *(const float4*)(a.bias + n);
+#pragma unroll 4
+      for (int ml = g; ml < BM; ml += RPP) {
+        const int m = m0 + ml;
+        if (m >= a.M) break;
+        float4 v = *(const float4*)(Cs + ml * CS + t * 4);
+        if (EPI == EPI_BIAS) { v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w; }
+        if (EPI == EPI_MUL_DACT) {
+          const float4 h = *(const float4*)(a.aux + (long long)m * a.ldaux + n);
+          v.x *= act_bwd(h.x, a.act); v.y *= act_bwd(h.y, a.act); v.z *= act_bwd(h.z, a.act); v.w *= act_bwd(h.w, a.act);
         }
+        if (EPI == EPI_ADD) {
+          const float4 h = *(const float4*)(a.aux + (long long)m * a.ldaux + n);
+          v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+        }
+        *(float4*)(a.C + (long long)m * a.ldc + n) = v;
       }
+    }
   } else {
-    // t = acc + bias + residual staged through LDS (the staging buffers are free after the last barrier),
-    // then one 32-lane group per row computes LayerNorm and writes y, xhat, rstd.
-    constexpr int CS = BN + 4;
+    // t = acc + bias + residual; one 32-lane group per row computes LayerNorm and writes y, xhat, rstd.
     constexpr int NV = BN >= 128 ? BN / 128 : 1;
-    float* Cs = smem;  // [BM][CS]
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nl = wc * (BN / 2) + j * 32 + lcol, n = n0 + nl;
-        const float bias = (n < a.N) ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ml = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4, m = m0 + ml;
-          float v = acc[i][j][r] + bias;
-          if (m < a.M && n < a.N) v += a.aux[(long long)m * a.ldaux + n];
-          Cs[ml * CS + nl] = v;
-        }
-      }
-    __syncthreads();
     const int g = tid >> 5, t = tid & 31;
     const int n4 = a.N >> 2;
     const float inv_n = 1.0f / (float)a.N;
@@ -155,8 +172,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
       for (int k = 0; k < NV; ++k) {
         const int c = t + 32 * k;
         if (c < n4) {
-          v[k] = *(const float4*)(Cs + ml * CS + c * 4);
-          s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+          float4 x = *(const float4*)(Cs + ml * CS + c * 4);
+          const float4 bs = *(const float4*)(a.bias + c * 4);
+          const float4 rs = *(const float4*)(a.aux + (long long)m * a.ldaux + c * 4);
+          x.x += bs.x + rs.x; x.y += bs.y + rs.y; x.z += bs.z + rs.z; x.w += bs.w + rs.w;
+          v[k] = x;
+          s += (x.x + x.y) + (x.z + x.w);
         }
       }
       const float mean = group_sum<32>(s) * inv_n;
@@ -190,7 +211,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 template <int BM, int BN, int PRO, int EPI>
 static int launch_nt(const GemmArgs& a, hipStream_t st) {
   dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM));
-  const size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
+  size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
+  const size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
+  if (cs > lds) lds = cs;
   static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
@@ -211,9 +234,10 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
 int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return UR_OK;
   ProfScope ps(PC_GEMM_NT, st, 2.0 * a.M * a.N * a.K);
-  if ((a.K & 3) || (a.lda & 3) || (a.ldw & 3)) return fail(UR_ERR_ARG, "gemm_nt: K/lda/ldw must be multiples of 4 (K=%d)", a.K);
+  if ((a.K & 3) || (a.N & 3) || (a.lda & 3) || (a.ldw & 3) || (a.ldc & 3) || (a.aux && (a.ldaux & 3)))
+    return fail(UR_ERR_ARG, "gemm_nt: N, K and all leading dimensions must be multiples of 4 (N=%d K=%d)", a.N, a.K);
   if (epi == EPI_BIAS_RES_LN) {
-    if (a.N > 256 || (a.N & 3) || a.ldc != a.N) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm needs N<=256, N%%4==0 (N=%d)", a.N);
+    if (a.N > 256 || a.ldc != a.N) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm needs N<=256 (N=%d)", a.N);
     if (a.N <= 128) return pro == PRO_ACT ? launch_nt<64, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
                                           : launch_nt<64, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
     return pro == PRO_ACT ? launch_nt<64, 256, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
@@ -240,8 +264,9 @@ template <int PRO>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q,
                                                       int ldq, int T, int R, int Cc, int tok_per_split, int act,
                                                       float* __restrict__ part, float* __restrict__ bias_part) {
-  __shared__ __attribute__((aligned(16))) float Ps[2][BT * TB];
-  __shared__ __attribute__((aligned(16))) float Qs[2][BT * TB];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ps = smem;                  // [2][BT*TB]
+  float* Qs = smem + 2 * BT * TB;    // [2][BT*TB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int c0 = blockIdx.x * TB, r0 = blockIdx.y * TB, sp = blockIdx.z;
@@ -258,24 +283,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum = 0.f;
 
+  const bool rin = r0 + c4 * 4 < R, cin = c0 + c4 * 4 < Cc;
+  const float* Pp = P + (rin ? r0 + c4 * 4 : 0);
+  const float* Qp = Q + (cin ? c0 + c4 * 4 : 0);
   float4 rp[4], rq[4];
   auto load_global = [&](int t0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int t = t0 + trow + 8 * i;
       const bool tin = t < t_end;
-      const int r = r0 + c4 * 4, c = c0 + c4 * 4;
-      rp[i] = (tin && r < R) ? *(const float4*)(P + (long long)t * ldp + r) : make_float4(0.f, 0.f, 0.f, 0.f);
-      rq[i] = (tin && c < Cc) ? *(const float4*)(Q + (long long)t * ldq + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int tt = tin ? t : t_end - 1;
+      float4 p = *(const float4*)(Pp + (long long)tt * ldp);
+      float4 q = *(const float4*)(Qp + (long long)tt * ldq);
+      if (!(tin && rin)) p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!(tin && cin)) q = make_float4(0.f, 0.f, 0.f, 0.f);
+      rp[i] = p;
+      rq[i] = q;
     }
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *(float4*)(&Ps[buf][(trow + 8 * i) * TB + c4 * 4]) = rp[i];
+      *(float4*)(Ps + buf * BT * TB + (trow + 8 * i) * TB + c4 * 4) = rp[i];
       float4 v = rq[i];
       if (PRO == PRO_ACT) v = act4(v, act);
-      *(float4*)(&Qs[buf][(trow + 8 * i) * TB + c4 * 4]) = v;
+      *(float4*)(Qs + buf * BT * TB + (trow + 8 * i) * TB + c4 * 4) = v;
     }
   };
 
@@ -289,8 +321,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   for (int it = 0; it < nt; ++it) {
     const int buf = it & 1;
     if (it + 1 < nt) load_global(t_begin + (it + 1) * BT);
-    const float* Pb = &Ps[buf][ft * TB + wr * 64 + fcol];
-    const float* Qb = &Qs[buf][ft * TB + wc * 64 + fcol];
+    const float* Pb = Ps + buf * BT * TB + ft * TB + wr * 64 + fcol;
+    const float* Qb = Qs + buf * BT * TB + ft * TB + wc * 64 + fcol;
 #pragma unroll
     for (int kk = 0; kk < BT; kk += 2) {
       const float a0 = Pb[kk * TB], a1 = Pb[kk * TB + 32];
@@ -302,38 +334,52 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     }
     if (bias_part != nullptr && blockIdx.x == 0 && tid < TB) {
 #pragma unroll 8
-      for (int t = 0; t < BT; ++t) bsum += Ps[buf][t * TB + tid];
+      for (int t = 0; t < BT; ++t) bsum += Ps[buf * BT * TB + t * TB + tid];
     }
     if (it + 1 < nt) store_lds(buf ^ 1);
     __syncthreads();
   }
 
+  // epilogue through LDS -> coalesced float4 row stores of the partial tile
+  constexpr int CS = TB + 4;
+  float* Cs = smem;  // [TB][CS] = 67.6 KB (launch reserves max(staging, this))
+  {
+    const int lcol = lane & 31, lrow4 = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cs[(wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4) * CS + wc * 64 + j * 32 + lcol] = acc[i][j][r];
+  }
+  __syncthreads();
   float* out = part + (long long)sp * R * Cc;
-  const int lcol = lane & 31, lrow4 = 4 * (lane >> 5);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = c0 + wc * 64 + j * 32 + lcol;
-      if (c >= Cc) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = r0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
-        if (rr < R) out[(long long)rr * Cc + c] = acc[i][j][r];
+  {
+    const int t = tid & 31, g = tid >> 5;
+    const int c = c0 + t * 4;
+    if (c < Cc)
+      for (int rl = g; rl < TB; rl += 8) {
+        const int rr = r0 + rl;
+        if (rr >= R) break;
+        *(float4*)(out + (long long)rr * Cc + c) = *(const float4*)(Cs + rl * CS + t * 4);
       }
-    }
+  }
   if (bias_part != nullptr && blockIdx.x == 0 && tid < TB && r0 + tid < R) bias_part[(long long)sp * R + r0 + tid] = bsum;
 }
 
-// out[i] = sum_s part[s*n + i], fixed order
+// out[i] = sum_s part[s*n + i], fixed order; 4 consecutive elements per thread
 __global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long long n, int cols, float* __restrict__ out,
                                      int ldo) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
-  float acc = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-  for (int s = 0; s < S; ++s) acc += part[(long long)s * n + i];
-  out[(i / cols) * ldo + (i % cols)] = acc;
+  for (int s = 0; s < S; ++s) {
+    const float4 v = *(const float4*)(part + (long long)s * n + i);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *(float4*)(out + (i / cols) * ldo + (i % cols)) = acc;   // cols % 4 == 0 keeps the 4 elements in one row
 }
 
 static int tn_splits(int T, int R, int Cc) {
@@ -347,12 +393,13 @@ static int tn_splits(int T, int R, int Cc) {
 
 long long gemm_tn_ws_floats(int T, int R, int Cc) {
   const int s = tn_splits(T, R, Cc);
-  return (long long)s * R * Cc + (long long)s * R;
+  return (long long)s * R * Cc + (long long)s * R + 64;
 }
 
 int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act, float* out,
             int ldo, float* bias_out, float* ws, hipStream_t st) {
-  if ((R & 3) || (Cc & 3) || (ldp & 3) || (ldq & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
+  if ((R & 3) || (Cc & 3) || (ldp & 3) || (ldq & 3) || (ldo & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
+  if (T <= 0) return fail(UR_ERR_ARG, "gemm_tn: T=%d", T);
   ProfScope ps(PC_GEMM_TN, st, 2.0 * T * R * Cc);
   const int S = tn_splits(T, R, Cc);
   int tps = cdiv(T, S);
@@ -360,16 +407,23 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
   float* part = ws;
   float* bias_part = bias_out ? ws + (long long)S * R * Cc : nullptr;
   dim3 grid(cdiv(Cc, TB), cdiv(R, TB), S);
+  const size_t lds = (size_t)TB * (TB + 4) * sizeof(float);  // >= 4*BT*TB staging
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   if (pro_act_on_q)
-    hipLaunchKernelGGL((gemm_tn_kernel<PRO_ACT>), grid, dim3(256), 0, st, P, ldp, Q, ldq, T, R, Cc, tps, act, part, bias_part);
+    hipLaunchKernelGGL((gemm_tn_kernel<PRO_ACT>), grid, dim3(256), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, act, part, bias_part);
   else
-    hipLaunchKernelGGL((gemm_tn_kernel<PRO_NONE>), grid, dim3(256), 0, st, P, ldp, Q, ldq, T, R, Cc, tps, act, part, bias_part);
+    hipLaunchKernelGGL((gemm_tn_kernel<PRO_NONE>), grid, dim3(256), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, act, part, bias_part);
   UR_LAUNCH_CHECK();
   const long long n = (long long)R * Cc;
-  hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, S, n, Cc, out, ldo);
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, part, S, n, Cc, out, ldo);
   UR_LAUNCH_CHECK();
   if (bias_out) {
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(R, 256)), dim3(256), 0, st, bias_part, S, (long long)R, R, bias_out, R);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(R / 4, 256)), dim3(256), 0, st, bias_part, S, (long long)R, R, bias_out, R);
     UR_LAUNCH_CHECK();
   }
   return UR_OK;

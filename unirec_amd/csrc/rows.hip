@@ -32,10 +32,14 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned dgt, bool act
 }
 
 __global__ void build_keys_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
-                                  long long n_b, unsigned* __restrict__ keys, int* __restrict__ vals) {
+                                  long long n_b, unsigned* __restrict__ keys, int* __restrict__ vals, int W, long long n_local) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_a + n_b) return;
-  keys[i] = (i < n_a) ? (unsigned)ids_a[i] : (unsigned)ids_b[i - n_a];
+  const long long id = (i < n_a) ? (long long)ids_a[i] : ids_b[i - n_a];
+  // row-sharded table: row `id` lives on rank id % W at local row id / W; sorting by (owner, local row)
+  // makes every owner's requests contiguous (the all-to-all split sizes are the per-owner unique counts)
+  // local row 0 is the padding row on EVERY rank (real items start at local row 1), so "row 0 never moves" holds per shard
+  keys[i] = (W > 1) ? (id ? (unsigned)((id % W) * n_local + id / W + 1) : 0u) : (unsigned)id;
   vals[i] = (int)i;
 }
 
@@ -133,7 +137,8 @@ __global__ __launch_bounds__(256) void heads_count_kernel(const unsigned* __rest
 
 __global__ __launch_bounds__(256) void heads_write_kernel(const unsigned* __restrict__ keys, long long n, int nwaves,
                                                           const int* __restrict__ counts_scanned, const int* __restrict__ n_uniq,
-                                                          int* __restrict__ uniq_idx, int* __restrict__ seg_start) {
+                                                          int* __restrict__ uniq_idx, int* __restrict__ seg_start,
+                                                          int* __restrict__ owner_counts, long long n_local) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + w;
   if (wave >= nwaves) return;
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(256) void heads_write_kernel(const unsigned* __rest
       const int seg = run + __popcll(m & lt);
       uniq_idx[seg] = (int)keys[i];
       seg_start[seg] = (int)i;
+      if (owner_counts) atomicAdd(&owner_counts[keys[i] / n_local], 1);   // integer atomics: deterministic totals
     }
     run += __popcll(m);
   }
@@ -370,9 +376,9 @@ extern "C" int64_t ur_rows_plan_workspace_bytes(int64_t n) {
   return carve_plan(n > 0 ? n : 1, nullptr).bytes;
 }
 
-extern "C" int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
-                            int32_t* uniq_idx, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws,
-                            void* stream) {
+static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows, int W,
+                          int32_t* uniq_idx, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev,
+                          int32_t* owner_counts_dev, void* ws, void* stream) {
   const long long n = n_a + n_b;
   UR_REQUIRE(n_a >= 0 && n_b >= 0 && n > 0 && n < (1LL << 31), UR_ERR_ARG, "ur_rows_plan: n_a=%lld n_b=%lld", (long long)n_a, (long long)n_b);
   UR_REQUIRE((ids_a || n_a == 0) && (ids_b || n_b == 0) && uniq_idx && seg_start && sorted_pos && n_uniq_dev && ws, UR_ERR_ARG,
@@ -383,14 +389,17 @@ extern "C" int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* id
   PlanWs w = carve_plan(n, (char*)ws);
   const int nwaves = (int)((n + CH - 1) / CH);
   const int nblk = cdiv(nwaves, 4);
-  const int passes = (bits_for(n_rows) + 7) / 8;
+  const long long n_local = (W > 1) ? (n_rows + W - 1) / W + 1 : n_rows;   // rows per shard incl. its padding row 0
+  UR_REQUIRE(n_local * W <= (1LL << 31), UR_ERR_ARG, "ur_rows_plan: sharded key space too large");
+  const int passes = (bits_for(W > 1 ? n_local * W : n_rows) + 7) / 8;
+  if (owner_counts_dev) UR_HIP(hipMemsetAsync(owner_counts_dev, 0, sizeof(int) * W, st));
   // ping-pong so that the LAST pass writes vals into sorted_pos
   unsigned* kbuf[2] = {w.keys0, w.keys1};
   int* vbuf[2];
   vbuf[passes & 1] = sorted_pos;       // after `passes` swaps the result sits in index (passes & 1)
   vbuf[(passes & 1) ^ 1] = w.vals_tmp;
   hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids_a, (long long)n_a, (const long long*)ids_b,
-                     (long long)n_b, kbuf[0], vbuf[0]);
+                     (long long)n_b, kbuf[0], vbuf[0], W, n_local);
   UR_LAUNCH_CHECK();
   int cur = 0;
   for (int p = 0; p < passes; ++p) {
@@ -408,7 +417,51 @@ extern "C" int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* id
   UR_LAUNCH_CHECK();
   hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, st, w.counts, (long long)nwaves, n_uniq_dev);
   UR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(heads_write_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], n, nwaves, w.counts, n_uniq_dev, uniq_idx, seg_start);
+  hipLaunchKernelGGL(heads_write_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], n, nwaves, w.counts, n_uniq_dev, uniq_idx, seg_start,
+                     owner_counts_dev, n_local);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
+                            int32_t* uniq_idx, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws,
+                            void* stream) {
+  return rows_plan_impl(ids_a, n_a, ids_b, n_b, n_rows, 1, uniq_idx, seg_start, sorted_pos, n_uniq_dev, nullptr, ws, stream);
+}
+
+extern "C" int ur_rows_plan_sharded(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
+                                    int32_t world, int32_t* uniq_key, int32_t* seg_start, int32_t* sorted_pos,
+                                    int32_t* n_uniq_dev, int32_t* owner_counts_dev, void* ws, void* stream) {
+  UR_REQUIRE(world >= 1 && world <= 1024 && owner_counts_dev, UR_ERR_ARG, "ur_rows_plan_sharded: world=%d", world);
+  return rows_plan_impl(ids_a, n_a, ids_b, n_b, n_rows, world, uniq_key, seg_start, sorted_pos, n_uniq_dev, owner_counts_dev, ws,
+                        stream);
+}
+
+// idx_a[p] / idx_b[p - n_a] = u for every lookup position p in the run of unique key u: the lookups re-expressed
+// as indices into the compact table of unique rows (row 0 = the padding row iff key 0 is present).
+__global__ __launch_bounds__(256) void compact_index_kernel(const int* __restrict__ seg_start, const int* __restrict__ sorted_pos,
+                                                            const int* __restrict__ n_uniq_dev, long long n, long long n_a,
+                                                            int* __restrict__ idx_a, long long* __restrict__ idx_b) {
+  const int n_uniq = *n_uniq_dev;
+  const int g = threadIdx.x >> 3, t = threadIdx.x & 7;   // 8 lanes per segment
+  for (long long u = (long long)blockIdx.x * 32 + g; u < n_uniq; u += (long long)gridDim.x * 32) {
+    const int s = seg_start[u], e = seg_start[u + 1];
+    for (int q = s + t; q < e; q += 8) {
+      const long long p = sorted_pos[q];
+      if (p < n_a) idx_a[p] = (int)u;
+      else idx_b[p - n_a] = u;
+    }
+  }
+}
+
+extern "C" int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n,
+                                int64_t n_a, int32_t* idx_a, int64_t* idx_b, void* stream) {
+  UR_REQUIRE(seg_start && sorted_pos && n_uniq_dev && n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_compact_index: bad argument");
+  UR_REQUIRE((idx_a || n_a == 0) && (idx_b || n_a == n), UR_ERR_ARG, "ur_compact_index: null output");
+  int blocks = cdiv(n, 32);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(compact_index_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), seg_start, sorted_pos, n_uniq_dev,
+                     (long long)n, (long long)n_a, idx_a, (long long*)idx_b);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

@@ -142,6 +142,38 @@ def rows_plan(ids_a, ids_b, n_rows) -> RowsPlan:
     return pl
 
 
+def rows_plan_sharded(ids_a, ids_b, n_rows, world):
+    """Like rows_plan, but keys are (owner = id % world, local row = id // world); returns (plan, owner_counts[world] int32 dev).
+    plan.uniq_idx holds the sharded keys owner * ceil(n_rows/world) + local_row."""
+    dev = (ids_a if ids_a is not None else ids_b).device
+    n_a = ids_a.numel() if ids_a is not None else 0
+    n_b = ids_b.numel() if ids_b is not None else 0
+    _chk(ids_a, torch.int32, "ids_a", allow_none=True)
+    _chk(ids_b, torch.int64, "ids_b", allow_none=True)
+    n = n_a + n_b
+    pl = RowsPlan()
+    pl.n, pl.n_a = n, n_a
+    pl.uniq_idx = torch.empty(n, dtype=torch.int32, device=dev)
+    pl.seg_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    pl.sorted_pos = torch.empty(n, dtype=torch.int32, device=dev)
+    pl.n_uniq = torch.empty(1, dtype=torch.int32, device=dev)
+    counts = torch.empty(world, dtype=torch.int32, device=dev)
+    ws = torch.empty(check(lib.ur_rows_plan_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    check(lib.ur_rows_plan_sharded(_p(ids_a), n_a, _p(ids_b), n_b, int(n_rows), int(world), _p(pl.uniq_idx), _p(pl.seg_start),
+                                   _p(pl.sorted_pos), _p(pl.n_uniq), _p(counts), _p(ws), _stream()), "ur_rows_plan_sharded")
+    return pl, counts
+
+
+def compact_index(pl: RowsPlan):
+    """-> (idx_a int32[n_a], idx_b int64[n - n_a]): every lookup as an index into the compact table of unique rows."""
+    dev = pl.uniq_idx.device
+    idx_a = torch.empty(pl.n_a, dtype=torch.int32, device=dev) if pl.n_a else None
+    idx_b = torch.empty(pl.n - pl.n_a, dtype=torch.int64, device=dev) if pl.n > pl.n_a else None
+    check(lib.ur_compact_index(_p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, pl.n_a, _p(idx_a), _p(idx_b), _stream()),
+          "ur_compact_index")
+    return idx_a, idx_b
+
+
 def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False) -> torch.Tensor:
     _chk(rows_a, torch.float32, "rows_a", allow_none=True)
     _chk(coef_b, torch.float32, "coef_b", allow_none=True)
