@@ -187,6 +187,34 @@ int ur_sumsq(const float* x, int64_t n, float* out, int accumulate, void* ws_204
 int ur_clip_coef(const float* sumsq, float max_norm, float* scale_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Negative sampling and row construction (replaces the per-sample Python of
+ * unirec/data/transform/addnegsamples.py:90-115, unirec/data/transform/adduserhistory.py:32-73,
+ * unirec/data/dataset/seqrecdataset.py:38-68, unirec/utils/sampling.py:9-31).
+ *
+ * HOST generator (all pointers are HOST pointers): CPython-compatible MT19937; a stream created with seed s
+ * produces exactly what `random.seed(s)` + the reference transforms produce on one stream (num_workers=0). */
+void* ur_host_sampler_create(uint64_t seed);
+void ur_host_sampler_destroy(void* sampler);
+uint64_t ur_host_sampler_getrandbits(void* sampler, int k);          /* random.getrandbits(k), k <= 64 */
+double ur_host_sampler_random(void* sampler);                         /* random.random() */
+int64_t ur_host_sampler_randint(void* sampler, int64_t a, int64_t b); /* random.randint(a, b) */
+/* popularity-biased negatives: host_weights[n] = pop^alpha / sum with weight[0] = 0 (addnegsamples.py:58-62) */
+int ur_host_sampler_set_alias(void* sampler, const double* host_weights, int64_t n);
+/* One batch of rows (SeqRecDataset.__getitem__ order of RNG use: negatives, then the history cut).
+ * hist_ptr[n_users+1] + hist_items: histories in interaction order; hist_sorted: same ranges sorted ascending.
+ * mask_mode 0 = 'unorder', 1 = 'autoregressive', 2 = other (history unchanged).  item_seq may be NULL (MF). */
+int ur_host_build_rows(void* sampler, const int64_t* user_id, const int64_t* pos_item, int64_t n, int64_t n_users,
+                       int64_t n_items, int32_t n_neg, const int64_t* hist_ptr, const int32_t* hist_items,
+                       const int32_t* hist_sorted, int32_t reject_history, int32_t mask_mode, int32_t seq_last,
+                       int32_t L, int64_t* item_id, int32_t* item_seq, int64_t* seq_len);
+/* DEVICE sampler: same rule (uniform [1,N-1], reject positive + history, <= 100 tries, else 0) on Philox4x32-10
+ * keyed by `seed` with counter (step, row, slot, try): order-independent, bit-exact vs oracle/philox_ref.py.
+ * item_id int64[B, K+1] (column 0 = positive), label int32[B, K+1] = [1,0,..,0] (nullable).  hist_* nullable. */
+int ur_sample_negatives(const int64_t* user_id, const int64_t* pos_item, int32_t B, int32_t K, int64_t n_items,
+                        int64_t n_users, const int64_t* hist_ptr, const int32_t* hist_sorted, uint64_t seed,
+                        uint32_t step, int64_t* item_id, int32_t* label, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Live profiler (measurement only; no reference counterpart).  While enabled, every launch group is
  * bracketed by HIP events on its stream.  ur_prof_read fills three host arrays of ur_prof_num_classes()
  * entries: summed milliseconds, number of launch groups, and summed algorithmic work (flops for the GEMM

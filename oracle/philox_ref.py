@@ -1,0 +1,61 @@
+"""numpy restatement of the DEVICE negative sampler (oracle; test infrastructure only).
+
+Rule restated from the reference (unirec/data/transform/addnegsamples.py:67-80,97-108): uniform over [1, N-1],
+reject the row's positive and the user's history, at most 100 tries, else id 0.  The random source is NOT the
+reference's (CPython MT19937, reproduced by oracle/data_ref.py and unirec_amd's host sampler) but the
+counter-based Philox4x32-10 (Salmon et al., SC'11; constants as in Random123), keyed by the 64-bit seed with
+counter (step, row, slot, try) -- so "parity" for this kernel means bit-exact against THIS restatement plus the
+distributional checks in tests/ (uniformity chi-square, no history hits).
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = 0x9E3779B9, 0xBB67AE85
+MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """vectorised over equal-shaped uint32 arrays; returns 4 uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint64) for x in (c0, c1, c2, c3))
+    k0, k1 = int(k0), int(k1)
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK
+        c0, c1, c2, c3 = hi1 ^ c1 ^ np.uint64(k0), lo1, hi0 ^ c3 ^ np.uint64(k1), lo0
+        k0 = (k0 + W0) & 0xFFFFFFFF
+        k1 = (k1 + W1) & 0xFFFFFFFF
+    return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
+
+
+def sample_negatives(user_id, pos_item, K, n_items, hist_ptr=None, hist_sorted=None, seed=0, step=0):
+    """-> item_id int64[B, K+1] with the positive in column 0."""
+    pos_item = np.asarray(pos_item, dtype=np.int64)
+    B = len(pos_item)
+    out = np.zeros((B, K + 1), dtype=np.int64)
+    out[:, 0] = pos_item
+    rng_range = n_items - 1
+    bits = int(rng_range).bit_length()
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for b in range(B):
+        hist = ()
+        if hist_ptr is not None and user_id is not None and 0 <= user_id[b] < len(hist_ptr) - 1:
+            hist = hist_sorted[hist_ptr[user_id[b]]:hist_ptr[user_id[b] + 1]]
+        hist = set(int(x) for x in hist)
+        for k in range(1, K + 1):
+            tr = np.arange(100, dtype=np.uint64)
+            w = philox4x32_10(np.full(100, step), np.full(100, b), np.full(100, k - 1), tr, k0, k1)
+            for t in range(100):
+                r = rng_range
+                for q in range(4):
+                    c = int(w[q][t]) >> (32 - bits)
+                    if r >= rng_range and c < rng_range:
+                        r = c
+                if r >= rng_range:
+                    r = (int(w[3][t]) * rng_range) >> 32
+                cand = 1 + r
+                if cand != int(pos_item[b]) and cand not in hist:
+                    out[b, k] = cand
+                    break
+    return out

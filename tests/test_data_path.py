@@ -1,0 +1,149 @@
+"""Data path: the native host row builder is bit-exact against the golden vectors captured
+from the imported reference and against the oracle; the device sampler is bit-exact against oracle/philox_ref.py and
+passes the distribution checks."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import data_ref, philox_ref
+from unirec_amd.data.rows import HistoryCSR, HostRowBuilder
+
+
+def _u2h(*hists):
+    a = np.empty(len(hists), dtype=object)
+    for i, h in enumerate(hists):
+        a[i] = None if h is None else np.asarray(h, dtype=np.int32)
+    return a
+
+
+def test_host_sampler_matches_reference_known_answers():
+    z = np.load(os.path.join(GOLDEN, "g1_sampler.npz"))
+    # random.seed(2022); AddNegSamples(5, 60000, 4, user2history={1:[5,6,7,8], 2:[9,10]})
+    b = HostRowBuilder(5, 60000, 4, history=HistoryCSR(_u2h(None, [5, 6, 7, 8], [9, 10])), seed=2022)
+    rows = np.concatenate([b.build([1], [7], with_seq=False)["item_id"] for _ in range(3)])
+    assert rows.dtype == np.int64 and np.array_equal(rows, z["kat_seed2022_n60000_k4"])
+    assert rows[0].tolist() == [7, 34841, 18935, 29007, 35767]
+    # the same three rows in ONE native call (stream order is row-major)
+    b = HostRowBuilder(5, 60000, 4, history=HistoryCSR(_u2h(None, [5, 6, 7, 8], [9, 10])), seed=2022)
+    assert np.array_equal(b.build([1, 1, 1], [7, 7, 7], with_seq=False)["item_id"], z["kat_seed2022_n60000_k4"])
+    # rejections in a small catalogue
+    b = HostRowBuilder(3, 24, 6, history=HistoryCSR(_u2h(None, np.arange(1, 12), np.arange(1, 12))), seed=7)
+    out = b.build(z["small_rows_user"], z["small_rows_pos"], with_seq=False)["item_id"]
+    assert np.array_equal(out, z["small_out"])
+    # exhaustion: every id is in the history -> 100 tries each, then id 0; stream position afterwards identical
+    b = HostRowBuilder(2, 8, 3, history=HistoryCSR(_u2h(None, np.arange(1, 8))), seed=11)
+    out = b.build([1], [3], with_seq=False)["item_id"][0]
+    assert np.array_equal(out, z["exhaust_out"]) and out[1:].tolist() == [0, 0, 0]
+    from unirec_amd._lib import lib
+    assert lib.ur_host_sampler_getrandbits(b._h, 32) == int(z["after_exhaust_getrandbits32"][0])
+    # popularity (alias) sampler
+    b = HostRowBuilder(3, 30, 8, seed=5, item_popularity=z["pop"], neg_by_pop_alpha=0.5)
+    rows = np.concatenate([b.build([1], [4], with_seq=False)["item_id"] for _ in range(4)])
+    assert np.array_equal(rows, z["pop_out"])
+
+
+def test_add_neg_samples_class_is_drop_in():
+    from unirec_amd.data.transform.addnegsamples import AddNegSamples
+    z = np.load(os.path.join(GOLDEN, "g1_sampler.npz"))
+    t = AddNegSamples(5, 60000, 4, user2history=_u2h(None, [5, 6, 7, 8], [9, 10]), seed=2022)
+    rows = [t(np.array([1, 7], dtype=object))[1] for _ in range(3)]
+    assert np.array_equal(np.stack(rows), z["kat_seed2022_n60000_k4"])
+
+
+def test_history_cut_and_padding_match_reference():
+    z = np.load(os.path.join(GOLDEN, "g2_history.npz"))
+    h = _u2h(None, z["h1"], z["h2"], z["h3"])
+    calls = [(1, 7), (2, 9), (2, 9), (2, 9), (3, 15), (7, 3)]
+    L = 40
+    for mode in ("autoregressive", "unorder", "autoagressive"):
+        for sl in (0, 1):
+            # n_neg = 0: the id group is just the positive, and no negative draws perturb the stream (golden: seed 3)
+            b = HostRowBuilder(8, 1000, 0, L, HistoryCSR(h, 8), reject_history=True, mask_mode=mode, seq_last=sl, seed=3)
+            lens, cat = z[f"{mode}_sl{sl}.lens"], z[f"{mode}_sl{sl}.cat"]
+            off = 0
+            for (u, it), n in zip(calls, lens):
+                ref_len, ref_hist = int(cat[off]), cat[off + 1:off + n]
+                off += n
+                r = b.build([u], [it])
+                assert int(r["item_seq_len"][0]) == min(ref_len, L), (mode, sl, u)
+                assert np.array_equal(r["item_seq"][0], data_ref.left_pad(ref_hist, L)), (mode, sl, u)
+    b = HostRowBuilder(4, 1000, 0, 6, HistoryCSR(_u2h(None, [4, 5], [1, 2, 3, 4, 5, 6], list(range(1, 10)))), mask_mode="x")
+    r = b.build([1, 2, 3, 9], [999, 999, 999, 999])
+    assert np.array_equal(r["item_seq"][0], z["pad_short"]) and np.array_equal(r["item_seq"][1], z["pad_exact"])
+    assert np.array_equal(r["item_seq"][2], z["pad_long"]) and np.array_equal(r["item_seq"][3], z["pad_one"])
+    assert r["item_seq_len"].tolist() == [2, 6, 6, 1]
+
+
+def test_whole_rows_match_oracle_stream():
+    """negatives + autoregressive cut + padding on ONE stream, row after row (SeqRecDataset.__getitem__ order)."""
+    rng = np.random.default_rng(0)
+    n_users, n_items, K, L = 30, 400, 5, 12
+    u2h = _u2h(None, *[rng.integers(1, n_items, rng.integers(1, 25)) for _ in range(n_users - 1)])
+    sets = [None if h is None else set(int(x) for x in h) for h in u2h]
+    users = rng.integers(1, n_users, 200)
+    items = np.array([int(rng.choice(u2h[u])) for u in users])
+    for mode, sl in (("autoregressive", 0), ("autoregressive", 1), ("unorder", 0)):
+        ref = data_ref.MT19937(99)
+        b = HostRowBuilder(n_users, n_items, K, L, HistoryCSR(u2h), mask_mode=mode, seq_last=sl, seed=99)
+        got = b.build(users, items)
+        for r in range(len(users)):
+            _, ids, lab, seq, ln = data_ref.make_row(ref, int(users[r]), int(items[r]), n_items=n_items, n_neg=K, max_seq_len=L,
+                                                     user2history=u2h, history_sets=sets, mask_mode=mode, seq_last=sl)
+            assert np.array_equal(got["item_id"][r], ids) and np.array_equal(got["label"][r], lab)
+            assert np.array_equal(got["item_seq"][r], seq) and got["item_seq_len"][r] == ln
+
+
+def test_datasets_and_transforms_compose_like_the_reference():
+    from unirec_amd.data.dataset.seqrecdataset import SeqRecDataset
+    from unirec_amd.data.transform.addnegsamples import AddNegSamples
+    from unirec_amd.data.transform.adduserhistory import AddUserHistory
+    u2h = _u2h(None, [5, 6, 7, 8], [9, 10, 11])
+    cfg = {"max_seq_len": 5, "seed": 1}
+    ds = SeqRecDataset(cfg, transform=AddNegSamples(3, 50, 2, user2history=u2h, seed=1), data=np.array([[1, 7], [2, 11], [1, 8]]))
+    ds.add_user_history_transform(AddUserHistory(u2h, "autoregressive", seq_last=1))
+    assert list(ds.return_key_2_index) == ["user_id", "item_id", "label", "item_seq", "item_seq_len"]
+    u, ids, lab, seq, ln = ds[0]
+    assert u == 1 and ids[0] == 7 and lab.tolist() == [1, 0, 0] and seq.tolist() == [0, 0, 0, 5, 6] and ln == 2
+    bt = ds.get_batch(np.array([1, 2]))
+    assert bt["item_seq"].tolist() == [[0, 0, 0, 9, 10], [0, 0, 5, 6, 7]] and bt["item_id"].shape == (2, 3)
+    assert not (set(bt["item_id"][1, 1:].tolist()) & {5, 6, 7, 8})
+
+
+@pytest.mark.gpu
+def test_device_sampler_bit_exact_vs_philox_oracle_and_distribution():
+    from unirec_amd.data.rows import sample_negatives_device
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1)
+    n_users, n_items, K, B = 20, 97, 6, 64
+    u2h = _u2h(None, *[rng.integers(1, n_items, rng.integers(1, 40)) for _ in range(n_users - 1)])
+    csr = HistoryCSR(u2h)
+    users = rng.integers(0, n_users + 3, B)           # includes unknown users (id >= n_users) and user 0 (no history)
+    pos = rng.integers(1, n_items, B)
+    for step in (0, 5):
+        ids, lab = sample_negatives_device(torch.from_numpy(pos).to(dev), K, n_items, torch.from_numpy(users).to(dev), csr, seed=2022, step=step)
+        ref = philox_ref.sample_negatives(users, pos, K, n_items, csr.ptr, csr.sorted, seed=2022, step=step)
+        assert torch.equal(ids.cpu(), torch.from_numpy(ref))            # bit-exact
+        assert lab.cpu().tolist() == [[1] + [0] * K] * B
+    ids = ids.cpu().numpy()
+    for b in range(B):
+        h = set() if not (0 <= users[b] < n_users) or u2h[users[b]] is None else set(int(x) for x in u2h[users[b]])
+        for c in ids[b, 1:]:
+            assert c == 0 or (1 <= c < n_items and c != pos[b] and c not in h)
+    # uniformity over [1, N-1] without a history: chi-square at 5 sigma
+    N, Bn, Kn = 1000, 2048, 64
+    big, _ = sample_negatives_device(torch.full((Bn,), N + 5, dtype=torch.int64, device=dev).clamp_(max=N - 1), Kn, N, seed=7, step=1)
+    x = big[:, 1:].reshape(-1).cpu().numpy()
+    cnt = np.bincount(x, minlength=N)[1:N]
+    cnt = np.delete(cnt, N - 2)                                      # the positive (id N-1) is excluded by construction
+    e = cnt.sum() / len(cnt)
+    chi2 = ((cnt - e) ** 2 / e).sum()
+    dof = len(cnt) - 1
+    assert abs(chi2 - dof) < 5 * np.sqrt(2 * dof), (chi2, dof)
+    assert x.min() >= 1 and x.max() <= N - 2
+    # exhaustion -> 0
+    csr2 = HistoryCSR(_u2h(None, np.arange(1, 8)))
+    ex, _ = sample_negatives_device(torch.tensor([3], device=dev), 3, 8, torch.tensor([1], device=dev), csr2, seed=1)
+    assert ex.cpu().tolist() == [[3, 0, 0, 0]]

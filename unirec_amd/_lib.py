@@ -67,6 +67,14 @@ SIGNATURES = {
     "ur_lazy_adam_flush": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, I64, I32, P]),
     "ur_sumsq": (C.c_int, [P, I64, P, C.c_int, P, P]),
     "ur_clip_coef": (C.c_int, [P, C.c_float, P, P]),
+    "ur_host_sampler_create": (P, [C.c_uint64]),
+    "ur_host_sampler_destroy": (None, [P]),
+    "ur_host_sampler_getrandbits": (C.c_uint64, [P, C.c_int]),
+    "ur_host_sampler_random": (C.c_double, [P]),
+    "ur_host_sampler_randint": (I64, [P, I64, I64]),
+    "ur_host_sampler_set_alias": (C.c_int, [P, P, I64]),
+    "ur_host_build_rows": (C.c_int, [P, P, P, I64, I64, I64, I32, P, P, P, I32, I32, I32, I32, P, P, P]),
+    "ur_sample_negatives": (C.c_int, [P, P, I32, I32, I64, I64, P, P, C.c_uint64, C.c_uint32, P, P, P]),
     "ur_prof_enable": (C.c_int, [C.c_int]),
     "ur_prof_reset": (C.c_int, []),
     "ur_prof_num_classes": (C.c_int, []),

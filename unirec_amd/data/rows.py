@@ -1,0 +1,107 @@
+"""Batched, native construction of training rows (host C++ and device HIP) behind the reference's transform names.
+
+``HistoryCSR`` is the flat form of the reference's ``user2history`` (object ndarray of per-user int32 arrays,
+unirec/utils/general.py:111-149): ptr[n_users+1], items (interaction order), sorted (membership tests).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .._lib import check, lib
+
+MASK_MODES = {"unorder": 0, "autoregressive": 1}
+
+
+class HistoryCSR:
+    def __init__(self, user2history, n_users=None):
+        n = len(user2history) if n_users is None else n_users
+        lens = np.zeros(n, dtype=np.int64)
+        for u in range(min(n, len(user2history))):
+            h = user2history[u]
+            lens[u] = 0 if h is None else len(h)
+        self.ptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=self.ptr[1:])
+        self.items = np.zeros(int(self.ptr[-1]), dtype=np.int32)
+        for u in range(min(n, len(user2history))):
+            if lens[u]:
+                self.items[self.ptr[u]:self.ptr[u + 1]] = np.asarray(user2history[u], dtype=np.int32)
+        self.sorted = self.items.copy()
+        for u in range(n):
+            if lens[u] > 1:
+                self.sorted[self.ptr[u]:self.ptr[u + 1]].sort()
+        self.n_users = n
+        self._dev = None
+
+    def to_device(self, device):
+        if self._dev is None or self._dev[0].device != torch.device(device):
+            self._dev = (torch.from_numpy(self.ptr).to(device), torch.from_numpy(self.sorted).to(device))
+        return self._dev
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
+
+
+class HostRowBuilder:
+    """CPython-`random`-compatible stream + the reference's per-row rules, for a whole batch in one native call."""
+
+    def __init__(self, n_users, n_items, n_neg, max_seq_len=0, history: HistoryCSR = None, reject_history=True,
+                 mask_mode="unorder", seq_last=0, seed=2022, item_popularity=None, neg_by_pop_alpha=1.0):
+        self.n_users, self.n_items, self.n_neg, self.L = n_users, n_items, n_neg, max_seq_len
+        self.history, self.reject = history, bool(reject_history and history is not None)
+        self.mask_mode = MASK_MODES.get(mask_mode, 2)   # unknown strings leave the history untouched (reference behaviour)
+        self.seq_last = int(bool(seq_last))
+        self._h = lib.ur_host_sampler_create(int(seed) & 0xFFFFFFFFFFFFFFFF)
+        if item_popularity is not None:
+            w = np.power(np.asarray(item_popularity).astype(float), neg_by_pop_alpha)   # addnegsamples.py:58-62
+            w /= np.sum(w)
+            w[0] = 0
+            w = np.ascontiguousarray(w, dtype=np.float64)
+            check(lib.ur_host_sampler_set_alias(self._h, _hp(w), len(w)), "ur_host_sampler_set_alias")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.ur_host_sampler_destroy(self._h)
+            self._h = None
+
+    def randint(self, a, b):
+        return lib.ur_host_sampler_randint(self._h, a, b)
+
+    def build(self, user_id, pos_item, with_seq=True):
+        """-> dict(user_id int64[n], item_id int64[n,G], label int32[n,G], item_seq int32[n,L], item_seq_len int64[n])."""
+        user_id = np.ascontiguousarray(user_id, dtype=np.int64)
+        pos_item = np.ascontiguousarray(pos_item, dtype=np.int64)
+        n, G = len(user_id), self.n_neg + 1
+        item_id = np.empty((n, G), dtype=np.int64)
+        with_seq = with_seq and self.history is not None and self.L > 0
+        seq = np.empty((n, self.L), dtype=np.int32) if with_seq else None
+        slen = np.empty(n, dtype=np.int64) if with_seq else None
+        h = self.history
+        check(lib.ur_host_build_rows(self._h, _hp(user_id), _hp(pos_item), n, h.n_users if h else 0, self.n_items, self.n_neg,
+                                     _hp(h.ptr) if h else None, _hp(h.items) if h else None, _hp(h.sorted) if h else None,
+                                     int(self.reject), self.mask_mode, self.seq_last, self.L, _hp(item_id), _hp(seq), _hp(slen)),
+              "ur_host_build_rows")
+        label = np.zeros((n, G), dtype=np.int32)
+        label[:, 0] = 1
+        out = dict(user_id=user_id, item_id=item_id, label=label)
+        if with_seq:
+            out["item_seq"], out["item_seq_len"] = seq, slen
+        return out
+
+
+def sample_negatives_device(pos_item, K, n_items, user_id=None, history: HistoryCSR = None, seed=2022, step=0):
+    """Device sampler (Philox, order-independent): -> (item_id int64[B,K+1], label int32[B,K+1]) on pos_item's device."""
+    assert pos_item.is_cuda and pos_item.dtype == torch.int64
+    B = pos_item.numel()
+    dev = pos_item.device
+    item_id = torch.empty(B, K + 1, dtype=torch.int64, device=dev)
+    label = torch.empty(B, K + 1, dtype=torch.int32, device=dev)
+    ptr = srt = None
+    if history is not None:
+        ptr, srt = history.to_device(dev)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)  # noqa: E731
+    check(lib.ur_sample_negatives(p(user_id), p(pos_item.contiguous()), B, K, n_items, history.n_users if history else 0, p(ptr), p(srt),
+                                  int(seed) & 0xFFFFFFFFFFFFFFFF, int(step) & 0xFFFFFFFF, p(item_id), p(label),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ur_sample_negatives")
+    return item_id, label

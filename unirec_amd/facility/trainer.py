@@ -1,0 +1,149 @@
+"""Trainer -- mirror of unirec/facility/trainer.py:21-458 for the accelerated path.
+
+Same constructor / method names (``Trainer(config, model, accelerator)``, ``fit``, ``evaluate``, ``save_model``,
+``load_model``, ``set_user_history``, ``reset_evaluator``) and the same checkpoint dict keys
+(``config, cur_epoch, cur_step, best_valid_score, state_dict, optimizer, scheduler``: trainer.py:390-398).
+The loop body (trainer.py:327-357) becomes: plan ids -> forward -> backward -> clip -> step, with the loss kept on
+the device and read back once per epoch instead of two host syncs per step."""
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from .optimizer import SparseDenseAdam
+
+
+class BatchLoader:
+    """Index batches over a unirec_amd dataset; rank r takes batches r, r+W, ... (Accelerate's default sharding,
+    SURVEY.md Appendix B), the last partial batch is kept."""
+
+    def __init__(self, dataset, batch_size, shuffle=False, seed=2022, rank=0, world=1, device="cuda:0"):
+        self.dataset, self.batch_size, self.shuffle, self.seed = dataset, batch_size, shuffle, seed
+        self.rank, self.world, self.device, self.epoch = rank, world, torch.device(device), 0
+
+    def __len__(self):
+        nb = (len(self.dataset) + self.batch_size - 1) // self.batch_size
+        return (nb - self.rank + self.world - 1) // self.world
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = np.random.default_rng(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
+        self.epoch += 1
+        nb = (n + self.batch_size - 1) // self.batch_size
+        for b in range(self.rank, nb, self.world):
+            rows = self.dataset.get_batch(order[b * self.batch_size:(b + 1) * self.batch_size])
+            yield {k: torch.from_numpy(v).to(self.device, non_blocking=True) for k, v in rows.items()}
+
+
+class Trainer(object):
+    def __init__(self, config, model, accelerator=None):
+        self.config, self.model, self.accelerator = config, model, accelerator
+        self.exp_name = config.get("exp_name", __name__)
+        self.logger = logging.getLogger(self.exp_name)
+        self.learning_rate = config.get("learning_rate", 1e-3)
+        self.epochs = config.get("epochs", 0)
+        self.early_stop = config.get("early_stop", 0)
+        self.weight_decay = config.get("weight_decay", 0)
+        self.key_metric = config.get("key_metric", "hit@5")
+        self.checkpoint_dir = os.path.join(config.get("output_path", "./output"), config.get("checkpoint_dir", "checkpoint"))
+        self.saved_model_file = os.path.join(self.checkpoint_dir, f"{self.exp_name}.pth")
+        gc = config.get("grad_clip_value", None)
+        self.grad_clip_value = gc if gc and gc > 0 else None
+        if config.get("optimizer", "adam") != "adam":
+            raise NotImplementedError("only Adam is on the accelerated path (reference default, base.yaml:39)")
+        self.optimizer = SparseDenseAdam(model, lr=self.learning_rate, weight_decay=self.weight_decay, grad_clip=self.grad_clip_value,
+                                         table_mode=config.get("embedding_optimizer", "lazy_dense"))
+        self.scheduler = None
+        self.best_valid_score, self.cur_step, self.start_epoch = None, 1, 0
+        self.step_losses = []
+
+    def set_user_history(self, user_history):
+        self.user_history = user_history
+
+    def reset_evaluator(self, data_format=None, eval_protocol=None):
+        self.eval_protocol = eval_protocol
+
+    # ------------------------------------------------------------------ the step (trainer.py:327-357)
+    def train_step(self, batch):
+        opt, model = self.optimizer, self.model
+        model.train()
+        opt.zero_grad()
+        opt.plan_batch(item_seq=batch.get("item_seq"), item_id=batch["item_id"],
+                       user_id=batch.get("user_id") if hasattr(model, "user_embedding") else None)
+        kw = {k: batch[k] for k in ("user_id", "item_id", "label", "item_seq", "item_seq_len") if k in batch}
+        loss, _, _, _ = model(**kw)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    def fit(self, train_data, valid_data=None, save_model=True, load_pretrained_model=False, model_file=None, verbose=2):
+        if load_pretrained_model:
+            if model_file is None:
+                raise ValueError("`model_file` should be given when `load_pretrained_model` is set to True.")
+            self.load_model(model_file)
+        for epoch_idx in range(self.start_epoch, self.epochs):
+            if valid_data is not None:
+                res = self.evaluate(valid_data, load_best_model=False)
+                score = res[self.key_metric]
+                better = self.best_valid_score is None or score > self.best_valid_score
+                if better:
+                    self.best_valid_score, self.cur_step = score, 0
+                    if save_model:
+                        self.save_model(self.saved_model_file, self.optimizer, self.scheduler, epoch_idx, self.cur_step, res, self.config)
+                else:
+                    self.cur_step += 1
+                self.logger.info("epoch %d evaluating [%s: %f]", epoch_idx, self.key_metric, score)
+                if self.early_stop and self.cur_step >= self.early_stop:
+                    break
+            t0 = time.time()
+            losses = [self.train_step(b) for b in train_data]
+            stacked = torch.stack(losses)
+            nan = torch.isnan(stacked)
+            if bool(nan.any()):
+                self.logger.error("Training loss is nan in %d steps of epoch %d", int(nan.sum()), epoch_idx + 1)
+            self.step_losses.extend(stacked.tolist())   # one host sync per epoch
+            # reported train loss = SUM over batches of the batch loss (trainer.py:354-355)
+            self.logger.info("epoch %d training [time: %.2fs, train loss: %.4f]", epoch_idx + 1, time.time() - t0,
+                             float(stacked[~nan].sum()))
+        return self.best_valid_score
+
+    # ------------------------------------------------------------------ evaluation (one_vs_k: positive in column 0)
+    @torch.no_grad()
+    def evaluate(self, eval_data, load_best_model=True, model_file=None, verbose=0, predict_only=False):
+        if load_best_model and os.path.exists(model_file or self.saved_model_file):
+            self.load_model(model_file or self.saved_model_file)
+        self.optimizer.flush()
+        self.model.eval()
+        ranks = []
+        for batch in eval_data:
+            kw = {k: batch[k] for k in ("user_id", "item_id", "item_seq", "item_seq_len") if k in batch}
+            _, scores, _, _ = self.model(**kw)
+            if predict_only:
+                ranks.append(scores.cpu().numpy())
+                continue
+            ranks.append((scores[:, 1:] > scores[:, :1]).sum(1).cpu().numpy())   # 0-based rank of the positive
+        if predict_only:
+            return np.concatenate(ranks)
+        r = np.concatenate(ranks).astype(np.float64)
+        G = scores.shape[1]
+        out = {"mrr": float(np.mean(1.0 / (r + 1))), "group_auc": float(np.mean((G - 1 - r) / max(G - 1, 1)))}
+        for k in (1, 3, 5, 10, 20):
+            out[f"hit@{k}"] = float(np.mean(r < k))
+            out[f"ndcg@{k}"] = float(np.mean(np.where(r < k, 1.0 / np.log2(r + 2), 0.0)))
+        return out
+
+    # ------------------------------------------------------------------ checkpoints (trainer.py:368-412)
+    def save_model(self, filename, optimizer=None, scheduler=None, epoch=0, step=0, valid_result=None, config=None):
+        os.makedirs(os.path.dirname(filename), exist_ok=True)
+        self.optimizer.flush()
+        torch.save({"config": {k: v for k, v in (config or self.config).items() if k != "device"}, "cur_epoch": epoch,
+                    "cur_step": step, "best_valid_score": self.best_valid_score,
+                    "state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                    "optimizer": {"t": self.optimizer.t}, "scheduler": None}, filename)
+
+    def load_model(self, model_file):
+        ck = torch.load(model_file, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(ck["state_dict"], strict=False)
+        self.model.check_views()
