@@ -89,6 +89,26 @@ int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_ite
                   float* d_emb_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * GRU user encoder (unirec/model/sequential/gru.py:13-35; arithmetic of torch.nn.GRU, 1 layer, batch_first,
+ * h0 = 0, gate order r,z,n; all L steps run including the left padding; user_emb = dense(h_{L-1})).
+ * Flat dense buffer layout (ur_gru_param_layout fills 6 offsets, returns the total float count):
+ *   [0] gru_layers.weight_ih_l0 [3H,d]  [1] gru_layers.weight_hh_l0 [3H,H]  [2] gru_layers.bias_ih_l0 [3H]
+ *   [3] gru_layers.bias_hh_l0 [3H]      [4] dense.weight [d,H]              [5] dense.bias [d] */
+typedef struct UrGruCfg {
+  int32_t B, L;
+  int32_t d; /* embedding_size, % 4 == 0 */
+  int32_t H; /* hidden_size, % 4 == 0 */
+} UrGruCfg;
+int64_t ur_gru_param_layout(const UrGruCfg* cfg, int64_t* offsets_out);
+int64_t ur_gru_workspace_bytes(const UrGruCfg* cfg);
+int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t n_items, const float* dense, const int32_t* item_seq,
+               float* user_emb, void* ws, void* stream);
+/* dense_grad: every element written; d_emb_rows [B*L, d] in item_seq.reshape(-1) order (rows of id 0 hold the
+ * gradient w.r.t. the zero padding vector and are discarded by ur_rows_reduce: padding_idx=0). */
+int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t n_items, const float* dense, const int32_t* item_seq,
+               const float* d_user_emb, void* ws, float* dense_grad, float* d_emb_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused candidate gather + dot-product scorer + loss
  *   scores[b,g] = ( <E[item_id[b,g]], user_emb[b]> + user_bias[user_id[b]] + item_bias[item_id[b,g]] ) / tau,
  *   clamped to +-score_clip when score_clip > 0        (unirec/model/modules.py:49-67,

@@ -28,10 +28,11 @@ def _t(d):
 
 def _build(cfg, sd):
     from unirec_amd.model.cf.mf import MF
+    from unirec_amd.model.sequential.gru import GRU
     from unirec_amd.model.sequential.sasrec import SASRec
     cfg = dict(cfg)
     cfg["device"] = "cuda:0"
-    cls = {"SASRec": SASRec, "MF": MF}[cfg["model"]]
+    cls = {"SASRec": SASRec, "MF": MF, "GRU": GRU}[cfg["model"]]
     m = cls(cfg)
     missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     assert not unexpected, unexpected
@@ -74,7 +75,7 @@ def test_gather_bit_exact(d, idt):
 
 
 # ------------------------------------------------------------------------------------------ golden models
-MODEL_FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "g[58]_*.npz"))
+MODEL_FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "g[578]_*.npz"))
                         if "fullsoftmax" not in p)
 
 
@@ -112,8 +113,8 @@ def test_model_forward_backward_vs_reference_golden(name):
             got = named[k].grad.cpu().numpy()
         else:
             p = named[k]
-            off = (p.data_ptr() - m.dense.data_ptr()) // 4
-            got = m.dense.grad[off:off + p.numel()].view(p.shape).cpu().numpy()
+            off = (p.data_ptr() - m.dense_flat.data_ptr()) // 4
+            got = m.dense_flat.grad[off:off + p.numel()].view(p.shape).cpu().numpy()
             offs_checked += 1
         np.testing.assert_allclose(got, ref, rtol=rt, atol=at, err_msg=k)
     assert offs_checked or cfg["model"] == "MF"
@@ -156,8 +157,8 @@ def test_sasrec_larger_random_vs_oracle():
                 got = _dense_table_grad(m, "item_embedding", 3000, d)
             else:
                 p = named[k]
-                off = (p.data_ptr() - m.dense.data_ptr()) // 4
-                got = m.dense.grad[off:off + p.numel()].view(p.shape).cpu().numpy()
+                off = (p.data_ptr() - m.dense_flat.data_ptr()) // 4
+                got = m.dense_flat.grad[off:off + p.numel()].view(p.shape).cpu().numpy()
             if k.endswith("key.bias"):  # analytically zero (softmax shift invariance): rounding noise on both sides
                 assert np.abs(got).max() < 1e-6 and np.abs(ref.numpy()).max() < 1e-6, k
                 continue

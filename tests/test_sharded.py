@@ -149,7 +149,7 @@ def _gpu_worker(rank, world, port, q):
             losses.append(float(st.step(mine)))
         st.flush()
         full = st.gather_table().cpu()
-        dense = st.model.dense.data.cpu()
+        dense = st.model.dense_flat.data.cpu()
         all_losses = [None] * world
         dist.all_gather_object(all_losses, losses)
         if rank == 0:
@@ -159,7 +159,7 @@ def _gpu_worker(rank, world, port, q):
             one.flush()
             # global-mean loss == mean of the equal-sized rank means; parameters after 3 steps agree
             np.testing.assert_allclose(np.mean(all_losses, axis=0), ref_losses, rtol=1e-5)
-            np.testing.assert_allclose(dense.numpy(), one.model.dense.data.cpu().numpy(), rtol=1e-4, atol=2e-5)  # Adam amplifies rounding noise on ~zero gradients (key.bias): atol = 2% of an lr-sized step
+            np.testing.assert_allclose(dense.numpy(), one.model.dense_flat.data.cpu().numpy(), rtol=1e-4, atol=2e-5)  # Adam amplifies rounding noise on ~zero gradients (key.bias): atol = 2% of an lr-sized step
             np.testing.assert_allclose(full.numpy(), one.table.cpu().numpy(), rtol=1e-4, atol=2e-5)
         dist.barrier()
         q.put((rank, "ok"))
@@ -200,7 +200,7 @@ def test_sharded_step_world1_equals_plain_path():
         st = ShardedSasrecStep(cfg, dev, rank=0, world=1, table_mode=mode)
         m = SASRec(cfg)
         with torch.no_grad():
-            m.dense.data.copy_(st.model.dense.data)
+            m.dense_flat.data.copy_(st.model.dense_flat.data)
             m.item_embedding.weight.copy_(st.table)
         opt = SparseDenseAdam(m, lr=1e-3, table_mode=mode)
         m.train()
@@ -219,5 +219,5 @@ def test_sharded_step_world1_equals_plain_path():
             np.testing.assert_allclose(float(l1), float(l2.detach()), rtol=1e-6)
         st.flush()
         opt.flush()
-        np.testing.assert_allclose(st.model.dense.data.cpu().numpy(), m.dense.data.cpu().numpy(), rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(st.model.dense_flat.data.cpu().numpy(), m.dense_flat.data.cpu().numpy(), rtol=1e-6, atol=1e-8)
         np.testing.assert_allclose(st.gather_table().cpu().numpy(), m.item_embedding.weight.detach().cpu().numpy(), rtol=1e-6, atol=1e-8)

@@ -33,7 +33,7 @@ def _setup(model_name, loss):
     return cfg, ds
 
 
-@pytest.mark.parametrize("model_name,loss", [("SASRec", "bpr"), ("SASRec", "softmax"), ("MF", "bpr")])
+@pytest.mark.parametrize("model_name,loss", [("SASRec", "bpr"), ("SASRec", "softmax"), ("MF", "bpr"), ("GRU", "softmax")])
 def test_fit_losses_follow_the_oracle(model_name, loss):
     from oracle import model_ref
     from unirec_amd.facility.trainer import BatchLoader, Trainer

@@ -54,6 +54,10 @@ SIGNATURES = {
     "ur_sasrec_workspace_bytes": (I64, [C.POINTER(UrSasrecCfg)]),
     "ur_sasrec_fwd": (C.c_int, [C.POINTER(UrSasrecCfg), P, I64, P, P, P, P, P]),
     "ur_sasrec_bwd": (C.c_int, [C.POINTER(UrSasrecCfg), P, I64, P, P, P, P, P, P, P]),
+    "ur_gru_param_layout": (I64, [C.POINTER(UrGruCfg), C.POINTER(I64)]),
+    "ur_gru_workspace_bytes": (I64, [C.POINTER(UrGruCfg)]),
+    "ur_gru_fwd": (C.c_int, [C.POINTER(UrGruCfg), P, I64, P, P, P, P, P]),
+    "ur_gru_bwd": (C.c_int, [C.POINTER(UrGruCfg), P, I64, P, P, P, P, P, P, P]),
     "ur_gather_dot_loss_fwd": (C.c_int, [C.POINTER(UrLossCfg), P, P, I64, P, P, P, P, P, P, P, P, P]),
     "ur_gather_dot_loss_bwd": (C.c_int, [C.POINTER(UrLossCfg), P, P, I64, P, P, P, P, P, P, P, P, P]),
     "ur_rows_plan_workspace_bytes": (I64, [I64]),

@@ -25,8 +25,8 @@ class SparseDenseAdam:
         self.table_mode = table_mode
         self.t = 0
         dev = model.device
-        self.dense_m = torch.zeros_like(model.dense.data)
-        self.dense_v = torch.zeros_like(model.dense.data)
+        self.dense_m = torch.zeros_like(model.dense_flat.data)
+        self.dense_v = torch.zeros_like(model.dense_flat.data)
         self.extra = [p for n, p in model.named_parameters() if n in ("user_bias", "item_bias")]
         self.extra_state = [(torch.zeros_like(p.data), torch.zeros_like(p.data)) for p in self.extra]
         self.tables = {}
@@ -43,7 +43,7 @@ class SparseDenseAdam:
 
     # ------------------------------------------------------------------ torch.optim surface
     def zero_grad(self, set_to_none=True):
-        self.model.dense.grad = None
+        self.model.dense_flat.grad = None
         for p in self.extra:
             p.grad = None
         self.model.sparse_grads.clear()
@@ -114,7 +114,7 @@ class SparseDenseAdam:
         scale = None
         if self.grad_clip is not None:
             ss = self._scalars[0:1]
-            ops.sumsq(model.dense.grad, ss, accumulate=False, ws=self._sumsq_ws)
+            ops.sumsq(model.dense_flat.grad, ss, accumulate=False, ws=self._sumsq_ws)
             for p in self.extra:
                 if p.grad is not None:
                     ops.sumsq(p.grad, ss, accumulate=True, ws=self._sumsq_ws)
@@ -122,8 +122,8 @@ class SparseDenseAdam:
                 ops.sumsq(ug, ss, accumulate=True, ws=self._sumsq_ws)
             scale = self._scalars[1:2]
             ops.clip_coef(ss, self.grad_clip, scale)
-        if model.dense.grad is not None:
-            ops.dense_adam(cfg, model.dense.data, model.dense.grad, self.dense_m, self.dense_v, scale)
+        if model.dense_flat.grad is not None:
+            ops.dense_adam(cfg, model.dense_flat.data, model.dense_flat.grad, self.dense_m, self.dense_v, scale)
         for p, (m, v) in zip(self.extra, self.extra_state):
             if p.grad is not None:
                 ops.dense_adam(cfg, p.data, p.grad.contiguous(), m, v, scale)

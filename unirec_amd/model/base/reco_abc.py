@@ -7,7 +7,7 @@ reference, but no arithmetic happens here: every tensor op is a call into the HI
 * embedding tables are ``SparseTable`` modules: ``weight`` has the reference's name and shape but is
   updated by row-sparse gradients; no dense ``[N, d]`` gradient is ever created.  After
   ``loss.backward()`` the row gradients are queued in ``model.sparse_grads`` for the optimizer.
-* all other ("dense") parameters are views into ONE flat fp32 buffer ``model.dense`` so the HIP
+* all other ("dense") parameters are views into ONE flat fp32 buffer ``model.dense_flat`` so the HIP
   encoder, the optimizer and the gradient all-reduce each see a single array.
 """
 import logging
@@ -110,22 +110,22 @@ class AbstractRecommender(nn.Module):
     def _alloc_dense(self, total):
         """Allocate the flat buffer of all dense parameters; kept OUT of the module registry."""
         flat = nn.Parameter(torch.zeros(total, dtype=torch.float32, device=self.device))
-        object.__setattr__(self, "dense", flat)
+        object.__setattr__(self, "dense_flat", flat)
         return flat
 
     def _view(self, off, shape):
         n = int(np.prod(shape))
-        return nn.Parameter(self.dense.data[off:off + n].view(*shape))
+        return nn.Parameter(self.dense_flat.data[off:off + n].view(*shape))
 
     def check_views(self):
         """Parameters must still alias the flat buffer (``.to()`` / manual reassignment would break it)."""
-        lo = self.dense.data_ptr()
-        hi = lo + self.dense.numel() * 4
+        lo = self.dense_flat.data_ptr()
+        hi = lo + self.dense_flat.numel() * 4
         for name, p in self.named_parameters():
             if name in self._sparse_param_names():
                 continue
             if p.dim() and p.requires_grad and not (lo <= p.data_ptr() < hi) and name not in ("user_bias", "item_bias"):
-                raise RuntimeError(f"parameter {name} no longer aliases model.dense; do not move/replace parameters")
+                raise RuntimeError(f"parameter {name} no longer aliases model.dense_flat; do not move/replace parameters")
 
     def _sparse_param_names(self):
         return {"item_embedding.weight", "user_embedding.weight"}

@@ -3,7 +3,7 @@
 Same config keys (sasrec.py:12-20) and the same state_dict names as the reference
 (``position_embedding.weight``, ``LayerNorm.*``, ``trm_encoder.layer.{i}.multi_head_attention.{query,key,value,dense}.*``,
 ``...multi_head_attention.LayerNorm.*``, ``trm_encoder.layer.{i}.feed_forward.{dense_1,dense_2,LayerNorm}.*``);
-every one of them is a view into ``model.dense`` at the offset the C ABI reports
+every one of them is a view into ``model.dense_flat`` at the offset the C ABI reports
 (``ur_sasrec_param_layout``), so ``ur_sasrec_fwd/_bwd`` read the weights without any packing step.
 """
 import torch
@@ -28,7 +28,7 @@ class _SasrecEncoderFn(torch.autograd.Function):
     def backward(ctx, d_user):
         (item_seq,) = ctx.saved_tensors
         model = ctx.model
-        dense_grad, d_rows = ops.sasrec_bwd(ctx.cfg, model.item_embedding.weight.data, model.dense.data, item_seq,
+        dense_grad, d_rows = ops.sasrec_bwd(ctx.cfg, model.item_embedding.weight.data, model.dense_flat.data, item_seq,
                                             d_user.contiguous(), ctx.ws)
         model.sparse_grads.append(dict(table="item_embedding", ids_a=item_seq.reshape(-1), rows=d_rows))
         return dense_grad, None, None
@@ -102,6 +102,6 @@ class SASRec(BaseRecommender):
         if item_seq.shape[1] != self.max_seq_len:
             raise ValueError(f"item_seq has length {item_seq.shape[1]}, expected max_seq_len={self.max_seq_len}")
         if torch.is_grad_enabled() and self.training:
-            return _SasrecEncoderFn.apply(self.dense, self, item_seq)
+            return _SasrecEncoderFn.apply(self.dense_flat, self, item_seq)
         cfg = self._cfg(item_seq.shape[0])
-        return ops.sasrec_fwd(cfg, self.item_embedding.weight.data, self.dense.data, item_seq, self._workspace(cfg))
+        return ops.sasrec_fwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, self._workspace(cfg))

@@ -81,6 +81,40 @@ def sasrec_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws):
     return dense_grad, d_emb_rows
 
 
+# --------------------------------------------------------------------------------------------- GRU
+def gru_cfg(B, L, d, H):
+    return _lib.UrGruCfg(B, L, d, H)
+
+
+def gru_param_layout(cfg):
+    offs = (C.c_int64 * 6)()
+    total = check(lib.ur_gru_param_layout(C.byref(cfg), offs), "ur_gru_param_layout")
+    return list(offs), int(total)
+
+
+def gru_workspace(cfg, device):
+    return torch.empty(check(lib.ur_gru_workspace_bytes(C.byref(cfg)), "ur_gru_workspace_bytes"), dtype=torch.uint8, device=device)
+
+
+def gru_fwd(cfg, item_table, dense, item_seq, ws):
+    _chk(item_table, torch.float32, "item_table")
+    _chk(dense, torch.float32, "dense")
+    _chk(item_seq, torch.int32, "item_seq")
+    user_emb = torch.empty(cfg.B, cfg.d, dtype=torch.float32, device=dense.device)
+    check(lib.ur_gru_fwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(user_emb), _p(ws), _stream()),
+          "ur_gru_fwd")
+    return user_emb
+
+
+def gru_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws):
+    _chk(d_user_emb, torch.float32, "d_user_emb")
+    dense_grad = torch.empty_like(dense)
+    d_emb_rows = torch.empty(cfg.B * cfg.L, cfg.d, dtype=torch.float32, device=dense.device)
+    check(lib.ur_gru_bwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(d_user_emb), _p(ws),
+                         _p(dense_grad), _p(d_emb_rows), _stream()), "ur_gru_bwd")
+    return dense_grad, d_emb_rows
+
+
 # --------------------------------------------------------------------------------------------- scorer + loss
 def loss_cfg(B, G, d, loss_type, tau=1.0, score_clip=-1.0, ccl_w=0.0, ccl_m=0.0) -> UrLossCfg:
     return UrLossCfg(B, G, d, LOSS_IDS[loss_type], float(tau), float(score_clip if score_clip else -1.0), float(ccl_w), float(ccl_m))

@@ -80,7 +80,7 @@ class ShardedSasrecStep:
         self.model = SASRec(cfg)
         self.model.train()
         if world > 1:
-            dist.broadcast(self.model.dense.data, src=0)
+            dist.broadcast(self.model.dense_flat.data, src=0)
         g = torch.Generator(device=device).manual_seed(seed + 1000 * rank + 1)
         self.table = torch.empty(self.n_local, self.d, dtype=torch.float32, device=device)
         self.table.normal_(0.0, model_cfg.get("init_std", 0.02), generator=g)
@@ -88,8 +88,8 @@ class ShardedSasrecStep:
         self.m = torch.zeros_like(self.table)
         self.v = torch.zeros_like(self.table)
         self.last = torch.zeros(self.n_local, dtype=torch.int32, device=device) if table_mode == "lazy_dense" else None
-        self.dense_m = torch.zeros_like(self.model.dense.data)
-        self.dense_v = torch.zeros_like(self.model.dense.data)
+        self.dense_m = torch.zeros_like(self.model.dense_flat.data)
+        self.dense_v = torch.zeros_like(self.model.dense_flat.data)
         self.lr, self.wd, self.t = lr, weight_decay, 0
         self.inv_w = torch.full((1,), 1.0 / world, dtype=torch.float32, device=device)
         self.zero_id = torch.zeros(1, dtype=torch.int64, device=device)
@@ -128,12 +128,12 @@ class ShardedSasrecStep:
         # 4. forward / backward on the compact table (same kernels as the single-GPU path)
         cfg = m._cfg(B)
         ws = m._workspace(cfg)
-        user_emb = ops.sasrec_fwd(cfg, compact, m.dense.data, seq_c, ws)
+        user_emb = ops.sasrec_fwd(cfg, compact, m.dense_flat.data, seq_c, ws)
         lcfg = ops.loss_cfg(B, G, d, self.loss_type, self.tau)
         lab = label.to(torch.int32).contiguous() if label is not None else None
         scores, _, loss_out = ops.gather_dot_loss_fwd(lcfg, user_emb, compact, item_c, lab)
         coef, d_user, _ = ops.gather_dot_loss_bwd(lcfg, user_emb, compact, item_c, lab, scores, loss_out)
-        dense_grad, d_rows = ops.sasrec_bwd(cfg, compact, m.dense.data, seq_c, d_user, ws)
+        dense_grad, d_rows = ops.sasrec_bwd(cfg, compact, m.dense_flat.data, seq_c, d_user, ws)
         # 5. row gradients of the unique keys, then all-to-all #3 to the owners
         coef_b = torch.cat([coef.reshape(-1), self.zero_coef])
         ug = ops.rows_reduce(pl, d_rows, coef_b, user_emb, G, d)[:n_uniq]
@@ -143,7 +143,7 @@ class ShardedSasrecStep:
         # 6. dense parameters: one flat all-reduce (sum), mean applied inside the Adam kernel
         if W > 1:
             dist.all_reduce(dense_grad)
-        ops.dense_adam(acfg, m.dense.data, dense_grad, self.dense_m, self.dense_v, self.inv_w)
+        ops.dense_adam(acfg, m.dense_flat.data, dense_grad, self.dense_m, self.dense_v, self.inv_w)
         return loss_out[0]
 
     def flush(self):
