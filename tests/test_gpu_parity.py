@@ -79,9 +79,13 @@ MODEL_FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join
                         if "fullsoftmax" not in p)
 
 
+@pytest.mark.parametrize("last_row_only", [1, 0])
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
-def test_model_forward_backward_vs_reference_golden(name):
+def test_model_forward_backward_vs_reference_golden(name, last_row_only):
     cfg, g = load_golden(name)
+    if cfg["model"] != "SASRec" and not last_row_only:
+        pytest.skip("last_row_only only exists for SASRec")
+    cfg["last_row_only"] = last_row_only   # 1: exact last-row specialisation of the final layer; 0: every row
     dev = _dev()
     m = _build(cfg, g["sd"])
     batch = {k: v.to(dev) for k, v in _t(g["in"]).items()}

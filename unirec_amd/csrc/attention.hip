@@ -238,6 +238,118 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Last-row specialisation: in the final layer only the query at position L-1 can reach the loss,
+// so attention degenerates to ONE query per (sequence, head).  Here one wave = one (sequence, head), lanes = keys:
+// the softmax max / sum and the P.V contraction are wavefront xor-shuffle reductions.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restrict__ q_last, const float* __restrict__ qkv,
+                                                            const int* __restrict__ seq, AttnDims p, float* __restrict__ ctx_last,
+                                                            float* __restrict__ lse_last) {
+  const int lane = threadIdx.x & 63;
+  const int h = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
+  if (h >= p.H) return;
+  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  const float* __restrict__ base = qkv + (long long)b * L * ld;
+  const int* __restrict__ sq = seq + (long long)b * L;
+  const float* __restrict__ qr = q_last + (long long)b * p.d + h * HD;   // wave-uniform row
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  float m = -INFINITY, l = 0.f, o[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) o[c] = 0.f;
+  for (int j0 = 0; j0 < L; j0 += 64) {
+    const int j = j0 + lane;
+    const bool in = j < L;
+    const int jj = in ? j : L - 1;
+    float kr[HD], vr[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      kr[c] = base[(long long)jj * ld + p.d + h * HD + c];
+      vr[c] = base[(long long)jj * ld + 2 * p.d + h * HD + c];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) s = fmaf(qr[c], kr[c], s);
+    const bool allowed = in && (literal || sq[jj] > 0);
+    const float sv = allowed ? (literal ? s / p.sqrt_hd + -10000.0f : s * p.scale) : -INFINITY;
+    const float mn = fmaxf(m, group_max<64>(sv));
+    if (mn == -INFINITY) continue;   // nothing allowed so far (uniform)
+    const float corr = __expf(m - mn);
+    const float pj = allowed ? __expf(sv - mn) : 0.f;
+    l = l * corr + wave_sum(pj);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) o[c] = o[c] * corr + wave_sum(pj * vr[c]);
+    m = mn;
+  }
+  const float inv_l = 1.0f / l;
+#pragma unroll
+  for (int c = 0; c < HD; ++c)
+    if (lane == c) ctx_last[(long long)b * p.d + h * HD + c] = o[c] * inv_l;
+  if (lane == 0) lse_last[(long long)b * p.H + h] = m + __logf(l);
+}
+
+// dq_last [B,d]; dK, dV written into dqkv[:, d:3d] for ALL rows (zeros where the key is masked); dqkv[:, 0:d] untouched.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restrict__ q_last, const float* __restrict__ qkv,
+                                                            const int* __restrict__ seq, const float* __restrict__ ctx_last,
+                                                            const float* __restrict__ dctx_last, const float* __restrict__ lse_last,
+                                                            AttnDims p, float* __restrict__ dq_last, float* __restrict__ dqkv) {
+  const int lane = threadIdx.x & 63;
+  const int h = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
+  if (h >= p.H) return;
+  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  const float* __restrict__ base = qkv + (long long)b * L * ld;
+  const int* __restrict__ sq = seq + (long long)b * L;
+  const float* __restrict__ qr = q_last + (long long)b * p.d + h * HD;
+  const float* __restrict__ gr = dctx_last + (long long)b * p.d + h * HD;
+  const float* __restrict__ orow = ctx_last + (long long)b * p.d + h * HD;
+  const float ls = lse_last[(long long)b * p.H + h];
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  const float f = literal ? 1.0f / p.sqrt_hd : p.scale;
+  float D = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) D = fmaf(gr[c], orow[c], D);
+  float dq[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) dq[c] = 0.f;
+  for (int j0 = 0; j0 < L; j0 += 64) {
+    const int j = j0 + lane;
+    const bool in = j < L;
+    const int jj = in ? j : L - 1;
+    float kr[HD], vr[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      kr[c] = base[(long long)jj * ld + p.d + h * HD + c];
+      vr[c] = base[(long long)jj * ld + 2 * p.d + h * HD + c];
+    }
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      s = fmaf(qr[c], kr[c], s);
+      dp = fmaf(gr[c], vr[c], dp);
+    }
+    const bool allowed = in && (literal || sq[jj] > 0);
+    const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
+    const float pj = allowed ? __expf(sv - ls) : 0.f;
+    const float ds = pj * (dp - D) * f;
+    if (in) {
+      float* out = dqkv + ((long long)b * L + j) * ld + h * HD;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        out[p.d + c] = ds * qr[c];
+        out[2 * p.d + c] = pj * gr[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dq[c] += wave_sum(ds * kr[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < HD; ++c)
+    if (lane == c) dq_last[(long long)b * p.d + h * HD + c] = dq[c];
+}
+
 long long attn_lse_floats(int B, int H, int L) { return (long long)B * H * L; }
 long long attn_bwd_ws_floats(int B, int H, int L) { return (long long)B * H * L + 64; }
 
@@ -287,6 +399,48 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
   UR_LAUNCH_CHECK();
   dim3 grid(B, cdiv(H * p.nchunk, 4));
 #define GO(HD) hipLaunchKernelGGL((attn_bwd_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, dctx, lse, Dd, p, dqkv)
+  switch (p.hd) {
+    case 2: GO(2); break;
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    case 32: GO(32); break;
+    default: GO(64); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, int L, int d, int H, float* ctx_last,
+                  float* lse_last, hipStream_t st) {
+  ProfScope ps(PC_ATTN_FWD, st, 4.0 * B * (double)L * d);
+  AttnDims p;
+  int rc = make_dims(B, L, d, H, 1, &p);
+  if (rc) return rc;
+  dim3 grid(B, cdiv(H, 4));
+#define GO(HD) hipLaunchKernelGGL((attn_last_fwd_kernel<HD>), grid, dim3(256), 0, st, q_last, qkv, seq, p, ctx_last, lse_last)
+  switch (p.hd) {
+    case 2: GO(2); break;
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    case 32: GO(32); break;
+    default: GO(64); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+int attn_last_bwd(const float* q_last, const float* qkv, const int* seq, const float* ctx_last, const float* dctx_last,
+                  const float* lse_last, int B, int L, int d, int H, float* dq_last, float* dqkv, hipStream_t st) {
+  ProfScope ps(PC_ATTN_BWD, st, 8.0 * B * (double)L * d);
+  AttnDims p;
+  int rc = make_dims(B, L, d, H, 1, &p);
+  if (rc) return rc;
+  dim3 grid(B, cdiv(H, 4));
+#define GO(HD) hipLaunchKernelGGL((attn_last_bwd_kernel<HD>), grid, dim3(256), 0, st, q_last, qkv, seq, ctx_last, dctx_last, lse_last, p, dq_last, dqkv)
   switch (p.hd) {
     case 2: GO(2); break;
     case 4: GO(4); break;

@@ -56,4 +56,9 @@ long long attn_bwd_ws_floats(int B, int H, int L);
 int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dctx, const float* lse, int B, int L,
              int d, int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st);
 
+int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, int L, int d, int H, float* ctx_last,
+                  float* lse_last, hipStream_t st);
+int attn_last_bwd(const float* q_last, const float* qkv, const int* seq, const float* ctx_last, const float* dctx_last,
+                  const float* lse_last, int B, int L, int d, int H, float* dq_last, float* dqkv, hipStream_t st);
+
 }  // namespace ur

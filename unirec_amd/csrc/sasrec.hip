@@ -60,6 +60,7 @@ struct Ws {
   float *x0, *x0hat, *rstd0;
   LayerWs layer[UR_MAX_LAYERS];
   float *g_y, *g_t, *g_a, *g_h1, *g_qkv, *g_ctx, *tn_ws, *ln_part, *attn_ws;
+  float *x_last, *q_last, *dq_last, *t_last, *lse_last;   // last-row specialisation of the final layer ([B,d] each)
   long long total_floats;
 };
 
@@ -91,6 +92,8 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
   w.tn_ws = take(tn);
   w.ln_part = take((long long)LN_BWD_MAX_BLOCKS * 2 * d);
   w.attn_ws = take(attn_bwd_ws_floats(c.B, c.n_heads, c.L));
+  w.x_last = take((long long)c.B * d); w.q_last = take((long long)c.B * d); w.dq_last = take((long long)c.B * d);
+  w.t_last = take((long long)c.B * d); w.lse_last = take((long long)c.B * c.n_heads);
   w.total_floats = o;
   return w;
 }
@@ -113,6 +116,13 @@ __global__ void take_last_kernel(const float* __restrict__ src, int B, int L, in
   if (i >= (long long)B * d) return;
   const long long b = i / d, c = i % d;
   dst[i] = src[(b * L + (L - 1)) * d + c];
+}
+// dst[b, L-1, :] += src[b,:]
+__global__ void add_last_rows_kernel(const float* __restrict__ src, int B, int L, int d, float* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * d) return;
+  const long long b = i / d, c = i % d;
+  dst[(b * L + (L - 1)) * d + c] += src[i];
 }
 // dst[b,l,:] = (l == L-1) ? src[b,:] : 0
 __global__ void put_last_kernel(const float* __restrict__ src, int B, int L, int d, float* __restrict__ dst) {
@@ -178,6 +188,30 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     const LayerP p = layer_ptrs(dense, lay, i);
     LayerWs& lw = w.layer[i];
     GemmArgs g{};
+    if (c.last_only && i == c.n_layers - 1) {
+      // Final layer, exact last-row specialisation: K,V for every position, everything else for row L-1 only.
+      const int B = c.B;
+      hipLaunchKernelGGL(take_last_kernel, dim3(cdiv((long long)B * d, 256)), dim3(256), 0, st, x, B, c.L, d, w.x_last);
+      UR_LAUNCH_CHECK();
+      g.A = x; g.lda = d; g.W = p.wqkv + (long long)d * d; g.ldw = d; g.C = lw.qkv + d; g.ldc = 3 * d; g.M = M; g.N = 2 * d; g.K = d;
+      g.bias = p.bqkv + d;
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
+      g = GemmArgs{};
+      g.A = w.x_last; g.lda = d; g.W = p.wqkv; g.ldw = d; g.C = w.q_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bqkv;
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
+      if ((rc = attn_last_fwd(w.q_last, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st))) return rc;
+      g = GemmArgs{};
+      g.A = lw.ctx; g.lda = d; g.W = p.wo; g.ldw = d; g.C = lw.a; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bo;
+      g.aux = w.x_last; g.ldaux = d; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1;
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS_RES_LN, st))) return rc;
+      g = GemmArgs{};
+      g.A = lw.a; g.lda = d; g.W = p.w1; g.ldw = d; g.C = lw.h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.bias = p.b1;
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
+      g = GemmArgs{};
+      g.A = lw.h1; g.lda = I; g.W = p.w2; g.ldw = I; g.C = user_emb; g.ldc = d; g.M = B; g.N = d; g.K = I; g.bias = p.b2; g.act = c.act;
+      g.aux = lw.a; g.ldaux = d; g.gamma = p.g2; g.beta = p.b2ln; g.eps = c.eps; g.xhat = lw.yhat; g.rstd = lw.rstd2;
+      return gemm_nt(g, PRO_ACT, EPI_BIAS_RES_LN, st);
+    }
     g.A = x; g.lda = d; g.W = p.wqkv; g.ldw = d; g.C = lw.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d; g.bias = p.bqkv;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
     if ((rc = attn_fwd(lw.qkv, item_seq, c.B, c.L, d, c.n_heads, c.use_pos, lw.ctx, lw.lse, 0, st))) return rc;
@@ -212,8 +246,10 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   Ws w = carve(c, (float*)ws);
   const int M = c.B * c.L, d = c.d, I = c.inner;
   UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
-  hipLaunchKernelGGL(put_last_kernel, dim3(cdiv((long long)M * d, 256)), dim3(256), 0, st, d_user_emb, c.B, c.L, d, w.g_y);
-  UR_LAUNCH_CHECK();
+  if (!c.last_only) {
+    hipLaunchKernelGGL(put_last_kernel, dim3(cdiv((long long)M * d, 256)), dim3(256), 0, st, d_user_emb, c.B, c.L, d, w.g_y);
+    UR_LAUNCH_CHECK();
+  }
   for (int i = c.n_layers - 1; i >= 0; --i) {
     const LayerP p = layer_ptrs(dense, lay, i);
     const long long* o = lay.off + UR_SASREC_N_GLOBAL + i * UR_SASREC_N_PER_LAYER;
@@ -225,6 +261,37 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     if ((rc = transpose(p.wo, d, d, lw.woT, st))) return rc;
     if ((rc = transpose(p.w1, I, d, lw.w1T, st))) return rc;
     if ((rc = transpose(p.w2, d, I, lw.w2T, st))) return rc;
+    if (c.last_only && i == c.n_layers - 1) {
+      // final layer: only row L-1 carries gradient (d_user_emb); K,V gradients still cover every position
+      const int B = c.B;
+      GemmArgs g{};
+      if ((rc = ln_bwd(d_user_emb, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, B, d, w.g_t, G + o[14], G + o[15], w.ln_part, st))) return rc;
+      if ((rc = gemm_tn(w.g_t, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13], w.tn_ws, st))) return rc;
+      g.A = w.g_t; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = w.g_h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.aux = lw.h1; g.ldaux = I; g.act = c.act;
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
+      if ((rc = gemm_tn(w.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11], w.tn_ws, st))) return rc;
+      g = GemmArgs{};
+      g.A = w.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = B; g.N = d; g.K = I; g.aux = w.g_t; g.ldaux = d;
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
+      if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, B, d, w.g_t, G + o[8], G + o[9], w.ln_part, st))) return rc;
+      if ((rc = gemm_tn(w.g_t, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7], w.tn_ws, st))) return rc;
+      g = GemmArgs{};
+      g.A = w.g_t; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
+      if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, w.g_qkv, st))) return rc;
+      // dWq from the B last rows, dWk/dWv from all rows
+      if ((rc = gemm_tn(w.dq_last, d, w.x_last, d, B, d, d, 0, 0, G + o[0], d, G + o[3], w.tn_ws, st))) return rc;
+      if ((rc = gemm_tn(w.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4], w.tn_ws, st))) return rc;
+      g = GemmArgs{};   // g_x = [dK dV] Wkv  for every row
+      g.A = w.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 2 * d;
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
+      g = GemmArgs{};   // rows L-1 additionally get dq Wq + the residual branch of the attention LayerNorm
+      g.A = w.dq_last; g.lda = d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.t_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.aux = w.g_t; g.ldaux = d;
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
+      hipLaunchKernelGGL(add_last_rows_kernel, dim3(cdiv((long long)B * d, 256)), dim3(256), 0, st, w.t_last, B, c.L, d, w.g_y);
+      UR_LAUNCH_CHECK();
+      continue;
+    }
     // ---- feed-forward block
     if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, w.g_t, G + o[14], G + o[15], w.ln_part, st))) return rc;
     if ((rc = gemm_tn(w.g_t, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13], w.tn_ws, st))) return rc;
