@@ -235,6 +235,20 @@ int ur_sample_negatives(const int64_t* user_id, const int64_t* pos_item, int32_t
                         uint32_t step, int64_t* item_id, int32_t* label, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The two fp32-MFMA GEMM kernels of the encoders, exposed for unit tests and micro-benchmarks.
+ *   ur_gemm_nt: C[M,N] = epi( pro(A)[M,K] @ W[N,K]^T )  == nn.Linear (unirec/model/modules.py:285-287,312,347-350)
+ *     pro: 0 none, 1 activation `act` on A;  epi: 0 none, 1 +bias[N], 2 LayerNorm(acc+bias+aux) (writes xhat, rstd; N<=256),
+ *     3 * act'(aux), 4 + aux.   N, K and every leading dimension % 4 == 0.
+ *   ur_gemm_tn: out[R,Cc] = P[T,R]^T @ pro(Q)[T,Cc], bias_out[R] = column sums of P (nullable): the weight / bias
+ *     gradient of nn.Linear; deterministic split over T; ws: ur_gemm_tn_workspace_floats(T,R,Cc) floats. */
+int ur_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int pro, int epi,
+               int act, const float* bias, const float* aux, int ldaux, const float* gamma, const float* beta, float eps,
+               float* xhat, float* rstd, void* stream);
+int64_t ur_gemm_tn_workspace_floats(int T, int R, int Cc);
+int ur_gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act, float* out,
+               int ldo, float* bias_out, float* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Live profiler (measurement only; no reference counterpart).  While enabled, every launch group is
  * bracketed by HIP events on its stream.  ur_prof_read fills three host arrays of ur_prof_num_classes()
  * entries: summed milliseconds, number of launch groups, and summed algorithmic work (flops for the GEMM

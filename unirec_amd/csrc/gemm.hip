@@ -368,24 +368,37 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   if (bias_part != nullptr && blockIdx.x == 0 && tid < TB && r0 + tid < R) bias_part[(long long)sp * R + r0 + tid] = bsum;
 }
 
-// out[i] = sum_s part[s*n + i], fixed order; 4 consecutive elements per thread
+// out[i] = sum_s part[s*n + i] (fixed order; 4 consecutive elements per thread); the same launch also reduces the
+// bias partials bias_part[s*R + r] -> bias_out[r] (threads past n/4)
 __global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long long n, int cols, float* __restrict__ out,
-                                     int ldo) {
-  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                                     int ldo, const float* __restrict__ bias_part, int R, float* __restrict__ bias_out) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nq = n / 4;
+  if (q < nq) {
+    const long long i = q * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-  for (int s = 0; s < S; ++s) {
-    const float4 v = *(const float4*)(part + (long long)s * n + i);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    for (int s = 0; s < S; ++s) {
+      const float4 v = *(const float4*)(part + (long long)s * n + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *(float4*)(out + (i / cols) * ldo + (i % cols)) = acc;   // cols % 4 == 0 keeps the 4 elements in one row
+  } else if (bias_out != nullptr && q - nq < R / 4) {
+    const long long i = (q - nq) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) {
+      const float4 v = *(const float4*)(bias_part + (long long)s * R + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *(float4*)(bias_out + i) = acc;
   }
-  *(float4*)(out + (i / cols) * ldo + (i % cols)) = acc;   // cols % 4 == 0 keeps the 4 elements in one row
 }
 
 static int tn_splits(int T, int R, int Cc) {
   const int tiles = cdiv(R, TB) * cdiv(Cc, TB);
   int s = cdiv(512, tiles);
-  const int smax = cdiv(T, 256);
+  const int smax = cdiv(T, T <= 4096 ? 64 : 128);   // >= 2 (small T) / 4 LDS stages of 32 tokens per split
   if (s > smax) s = smax;
   if (s < 1) s = 1;
   return s;
@@ -420,12 +433,9 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
     hipLaunchKernelGGL((gemm_tn_kernel<PRO_NONE>), grid, dim3(256), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, act, part, bias_part);
   UR_LAUNCH_CHECK();
   const long long n = (long long)R * Cc;
-  hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, part, S, n, Cc, out, ldo);
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n / 4 + (bias_out ? R / 4 : 0), 256)), dim3(256), 0, st, part, S, n, Cc, out, ldo,
+                     bias_part, R, bias_out);
   UR_LAUNCH_CHECK();
-  if (bias_out) {
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(R / 4, 256)), dim3(256), 0, st, bias_part, S, (long long)R, R, bias_out, R);
-    UR_LAUNCH_CHECK();
-  }
   return UR_OK;
 }
 
@@ -450,3 +460,20 @@ int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st) 
 }
 
 }  // namespace ur
+
+// ---- raw entry points (unit tests and micro-benchmarks of the GEMM kernels; see include/unirec_amd.h)
+extern "C" int ur_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int pro,
+                          int epi, int act, const float* bias, const float* aux, int ldaux, const float* gamma, const float* beta,
+                          float eps, float* xhat, float* rstd, void* stream) {
+  UR_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, UR_ERR_ARG, "ur_gemm_nt: bad argument");
+  ur::GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act; g.bias = bias;
+  g.aux = aux; g.ldaux = ldaux; g.gamma = gamma; g.beta = beta; g.eps = eps; g.xhat = xhat; g.rstd = rstd;
+  return ur::gemm_nt(g, pro, epi, ur::as_stream(stream));
+}
+extern "C" int64_t ur_gemm_tn_workspace_floats(int T, int R, int Cc) { return ur::gemm_tn_ws_floats(T, R, Cc); }
+extern "C" int ur_gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act,
+                          float* out, int ldo, float* bias_out, float* ws, void* stream) {
+  UR_REQUIRE(P && Q && out && ws, UR_ERR_ARG, "ur_gemm_tn: null pointer");
+  return ur::gemm_tn(P, ldp, Q, ldq, T, R, Cc, pro_act_on_q, act, out, ldo, bias_out, ws, ur::as_stream(stream));
+}

@@ -233,6 +233,7 @@ constexpr int LAZY_EXACT_STEPS = 512;
 __device__ __forceinline__ void lazy_replay(float& w, float& m, float& v, int from, int to, const AdamK& a) {
   int k = to - from;
   if (k <= 0) return;
+  if (a.wd == 0.f && m == 0.f && v == 0.f) return;   // never touched (or fully decayed): zero-gradient steps are no-ops
   float b1t = powf(a.b1, (float)from), b2t = powf(a.b2, (float)from);
   const int exact = (a.wd != 0.f) ? k : min(k, LAZY_EXACT_STEPS);
   for (int j = 0; j < exact; ++j) {

@@ -132,22 +132,27 @@ __global__ void put_last_kernel(const float* __restrict__ src, int B, int L, int
   dst[i] = (l == L - 1) ? src[b * d + c] : 0.f;
 }
 // dpos[l,:] = sum_b dx[b,l,:]; afterwards rows of dx whose id is 0 are zeroed (padding_idx=0)
-// block = 64 columns x 4 batch slices (fixed-order LDS combine => deterministic); grid = (L, ceil(d/64))
-__global__ __launch_bounds__(256) void pos_grad_zero_kernel(float* __restrict__ dx, const int* __restrict__ seq, int B, int L,
-                                                            int d, float* __restrict__ dpos) {
-  __shared__ float red[4][65];
-  const int l = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6;
+// block = 64 columns x 16 batch slices (fixed-order LDS combine => deterministic); grid = (L, ceil(d/64))
+__global__ __launch_bounds__(1024) void pos_grad_zero_kernel(float* __restrict__ dx, const int* __restrict__ seq, int B, int L,
+                                                             int d, float* __restrict__ dpos) {
+  __shared__ float red[16][65];
+  const int l = blockIdx.x, cl = threadIdx.x & 63, c = blockIdx.y * 64 + cl, s = threadIdx.x >> 6;
   float acc = 0.f;
   if (c < d) {
-    for (int b = s; b < B; b += 4) {
+    for (int b = s; b < B; b += 16) {
       const long long row = (long long)b * L + l;
       acc += dx[row * d + c];
       if (seq[row] == 0) dx[row * d + c] = 0.f;
     }
   }
-  red[s][threadIdx.x & 63] = acc;
+  red[s][cl] = acc;
   __syncthreads();
-  if (s == 0 && c < d && dpos) dpos[(long long)l * d + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (s == 0 && c < d && dpos) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    dpos[(long long)l * d + c] = t;
+  }
 }
 
 }  // namespace ur
@@ -320,7 +325,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   if ((rc = ln_bwd(w.g_y, w.x0hat, w.rstd0, dense + lay.off[1], nullptr, nullptr, M, d, d_emb_rows, dense_grad + lay.off[1],
                    dense_grad + lay.off[2], w.ln_part, st)))
     return rc;
-  hipLaunchKernelGGL(pos_grad_zero_kernel, dim3(c.L, cdiv(d, 64)), dim3(256), 0, st, d_emb_rows, item_seq, c.B, c.L, d,
+  hipLaunchKernelGGL(pos_grad_zero_kernel, dim3(c.L, cdiv(d, 64)), dim3(1024), 0, st, d_emb_rows, item_seq, c.B, c.L, d,
                      c.use_pos ? dense_grad + lay.off[0] : nullptr);
   UR_LAUNCH_CHECK();
   return UR_OK;
