@@ -254,6 +254,7 @@ int ur_gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, i
  * entries: summed milliseconds, number of launch groups, and summed algorithmic work (flops for the GEMM
  * classes, bytes for the HBM-bound classes; definitions in DESIGN.md section 6). */
 int ur_prof_enable(int on);
+int ur_prof_set_mask(uint32_t class_mask); /* bit c = bracket kernel class c (default: all); fewer events = less perturbation */
 int ur_prof_reset(void);
 int ur_prof_num_classes(void);
 const char* ur_prof_class_name(int cls);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "ur_gemm_tn_workspace_floats": (I64, [C.c_int, C.c_int, C.c_int]),
     "ur_gemm_tn": (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),
     "ur_prof_enable": (C.c_int, [C.c_int]),
+    "ur_prof_set_mask": (C.c_int, [C.c_uint32]),
     "ur_prof_reset": (C.c_int, []),
     "ur_prof_num_classes": (C.c_int, []),
     "ur_prof_class_name": (C.c_char_p, [C.c_int]),

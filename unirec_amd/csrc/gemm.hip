@@ -13,6 +13,8 @@
 // global access of the epilogue -- C, the residual / pre-activation operand, xhat -- is a coalesced
 // 16-byte-per-lane row access; writing the MFMA fragment layout directly costs 64 dword stores per lane
 // and made the store tail as long as the K loop.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -226,8 +228,9 @@ template <int PRO, int EPI>
 static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
   // enough 128x128 tiles to fill 256 CUs twice? otherwise use 64-row tiles for more workgroups
   const long long big = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
+  static const int force = getenv("UR_GEMM_TILE") ? atoi(getenv("UR_GEMM_TILE")) : 0;   // tuning aid: 64 or 128 rows
   if (a.N <= 64) return launch_nt<64, 64, PRO, EPI>(a, st);
-  if (big >= 512) return launch_nt<128, 128, PRO, EPI>(a, st);
+  if (force == 128 || (force == 0 && big >= 512)) return launch_nt<128, 128, PRO, EPI>(a, st);
   return launch_nt<64, 128, PRO, EPI>(a, st);
 }
 

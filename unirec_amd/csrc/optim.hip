@@ -118,11 +118,12 @@ extern "C" int ur_clip_coef(const float* sumsq, float max_norm, float* scale_out
 namespace ur {
 struct ProfRec { hipEvent_t a, b; int cls; double work; };
 static bool g_prof_on = false;
+static unsigned g_prof_mask = 0xffffffffu;   // bit c set = kernel class c is bracketed
 static std::vector<ProfRec> g_prof;      // recorded pairs since the last reset
 static std::vector<ProfRec> g_prof_pool; // reusable events
 
 ProfScope::ProfScope(int cls_, hipStream_t st_, double work) : cls(cls_), st(st_), slot(-1) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || !((g_prof_mask >> cls_) & 1u)) return;
   ProfRec r;
   if (!g_prof_pool.empty()) { r = g_prof_pool.back(); g_prof_pool.pop_back(); }
   else { if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return; }
@@ -138,6 +139,10 @@ ProfScope::~ProfScope() {
 
 extern "C" int ur_prof_enable(int on) {
   ur::g_prof_on = on != 0;
+  return UR_OK;
+}
+extern "C" int ur_prof_set_mask(uint32_t class_mask) {
+  ur::g_prof_mask = class_mask;
   return UR_OK;
 }
 extern "C" int ur_prof_reset(void) {

@@ -275,6 +275,10 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
     const long long row = uniq_idx[u];
     if (row == 0) continue;
     const int last = last_step ? last_step[row] : a.step - 1;
+    if (MODE == 1 && last == 0 && a.wd == 0.f) {   // never updated: m = v = 0, every zero-gradient step is a no-op
+      if (t == 0) last_step[row] = a.step - 1;
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int c = t + k * TPR;
