@@ -48,25 +48,43 @@ __global__ __launch_bounds__(256) void scorer_loss_fwd_kernel(UrLossCfg c, const
   }
   const float ub = user_bias ? user_bias[user_id[b]] : 0.f;
   const float inv_tau = 1.0f / c.tau;
-  for (int g = g0; g < G; g += groups) {
-    const long long id = item_id[(long long)b * G + g];
-    float s = 0.f;
+  // UNR candidate rows in flight per lane group: the rows are random 512-B reads of a table far larger than any
+  // cache, so memory-level parallelism (not arithmetic) sets the rate
+  constexpr int UNR = 4;
+  for (int gb = g0 * UNR; gb < G; gb += groups * UNR) {
+    long long id[UNR];
+    float s[UNR];
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      id[q] = (gb + q < G) ? item_id[(long long)b * G + gb + q] : 0;
+      s[q] = 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int col = t + k * TPR;
       if (col < d4) {
-        const float4 e = table[id * d4 + col];
-        s += (e.x * u[k].x + e.y * u[k].y) + (e.z * u[k].z + e.w * u[k].w);
+        float4 e[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) e[q] = table[id[q] * d4 + col];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) s[q] += (e[q].x * u[k].x + e[q].y * u[k].y) + (e[q].z * u[k].z + e[q].w * u[k].w);
       }
     }
-    s = group_sum<TPR>(s);
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) s[q] = group_sum<TPR>(s[q]);
     if (t == 0) {
-      s += ub;
-      if (item_bias) s += item_bias[id];
-      s = s / c.tau;
-      if (c.score_clip > 0.f) s = fminf(fmaxf(s, -c.score_clip), c.score_clip);
-      sc[g] = s;
-      scores[(long long)b * G + g] = s;
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) {
+        const int g = gb + q;
+        if (g < G) {
+          float v = s[q] + ub;
+          if (item_bias) v += item_bias[id[q]];
+          v = v / c.tau;
+          if (c.score_clip > 0.f) v = fminf(fmaxf(v, -c.score_clip), c.score_clip);
+          sc[g] = v;
+          scores[(long long)b * G + g] = v;
+        }
+      }
     }
   }
   (void)inv_tau;
@@ -201,16 +219,28 @@ __global__ __launch_bounds__(256) void scorer_loss_bwd_kernel(UrLossCfg c, const
   float4 acc[MAXV];
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int g = g0; g < G; g += groups) {
-    const long long id = item_id[(long long)b * G + g];
-    const float w = cf[g];
+  constexpr int UNR = 4;   // candidate rows in flight per lane group (see the forward kernel)
+  for (int gb = g0 * UNR; gb < G; gb += groups * UNR) {
+    long long id[UNR];
+    float w[UNR];
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      const bool in = gb + q < G;
+      id[q] = in ? item_id[(long long)b * G + gb + q] : 0;
+      w[q] = in ? cf[gb + q] : 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int col = t + k * TPR;
       if (col < d4) {
-        const float4 e = table[id * d4 + col];
-        acc[k].x = fmaf(w, e.x, acc[k].x); acc[k].y = fmaf(w, e.y, acc[k].y);
-        acc[k].z = fmaf(w, e.z, acc[k].z); acc[k].w = fmaf(w, e.w, acc[k].w);
+        float4 e[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) e[q] = table[id[q] * d4 + col];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+          acc[k].x = fmaf(w[q], e[q].x, acc[k].x); acc[k].y = fmaf(w[q], e[q].y, acc[k].y);
+          acc[k].z = fmaf(w[q], e[q].z, acc[k].z); acc[k].w = fmaf(w[q], e[q].w, acc[k].w);
+        }
       }
     }
   }
