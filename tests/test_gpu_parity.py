@@ -177,6 +177,7 @@ def test_rows_plan_and_reduce_vs_numpy():
     dev = _dev()
     rng = np.random.default_rng(0)
     for (n_a, n_b, G, n_rows, d) in ((700, 330, 11, 97, 32), (5000, 4004, 1001, 60000, 64), (1, 0, 1, 10, 128),
+                                     (3000, 1200, 3, 5, 64), (900, 0, 1, 3, 128),   # hot ids: runs >> 64 take the block-cooperative path
                                      (0, 2048, 4, 3_000_000, 128)):
         ids_a = rng.integers(0, n_rows, n_a).astype(np.int32)
         ids_b = rng.integers(0, n_rows, n_b).astype(np.int64)

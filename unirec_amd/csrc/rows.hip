@@ -162,6 +162,40 @@ __global__ __launch_bounds__(256) void heads_write_kernel(const unsigned* __rest
 
 // ------------------------------------------------------------------------------- segment reduce
 constexpr int MAXV = 4;
+constexpr int LONG_SEG = 64;   // runs longer than this (hot items under Zipfian ids) are reduced by the whole block
+
+// acc += gradient row of lookup position p (explicit row, or coef * vec for the scorer's implicit candidate rows)
+template <int TPR>
+__device__ __forceinline__ void add_pos(float4 (&acc)[MAXV], long long p, long long n_a, const float4* __restrict__ rows_a,
+                                        const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G, int d4, int t) {
+  if (p < n_a) {
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        const float4 r = rows_a[p * d4 + c];
+        acc[k].x += r.x; acc[k].y += r.y; acc[k].z += r.z; acc[k].w += r.w;
+      }
+    }
+  } else {
+    const long long pb = p - n_a;
+    const float w = coef_b[pb];
+    const long long row = pb / G;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        const float4 r = vec_b[row * d4 + c];
+        acc[k].x = fmaf(w, r.x, acc[k].x); acc[k].y = fmaf(w, r.y, acc[k].y);
+        acc[k].z = fmaf(w, r.z, acc[k].z); acc[k].w = fmaf(w, r.w, acc[k].w);
+      }
+    }
+  }
+}
+
+// One lane group per unique id; positions are summed in sorted (= lookup) order.  Runs longer than LONG_SEG are
+// handled by all groups of the block together: group g takes positions s+g, s+g+groups, ..., the partial sums are
+// combined through LDS in group order -- still a fixed summation order, so results are bit-reproducible.
 template <int TPR>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict__ uniq_idx, const int* __restrict__ seg_start,
                                                           const int* __restrict__ sorted_pos, const int* __restrict__ n_uniq_dev,
@@ -169,55 +203,74 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
                                                           const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G,
                                                           int d4, float4* __restrict__ out, int zero_tail) {
   constexpr int groups = 256 / TPR;
+  __shared__ float4 part[groups][MAXV * TPR];
+  __shared__ int long_flag[groups];
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int n_uniq = *n_uniq_dev;
-  for (long long u = (long long)blockIdx.x * groups + g; u < n; u += (long long)gridDim.x * groups) {
-    if (u >= n_uniq) {
-      if (!zero_tail) return;
-#pragma unroll
-      for (int k = 0; k < MAXV; ++k) {
-        const int c = t + k * TPR;
-        if (c < d4) out[u * d4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      continue;
-    }
-    float4 acc[MAXV];
-#pragma unroll
-    for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (uniq_idx[u] != 0) {
-      const int s = seg_start[u], e = seg_start[u + 1];
-      for (int q = s; q < e; ++q) {
-        const long long p = sorted_pos[q];
-        if (p < n_a) {
+  for (long long base = (long long)blockIdx.x * groups; base < n; base += (long long)gridDim.x * groups) {
+    if (base >= n_uniq && !zero_tail) break;   // block-uniform
+    const long long u = base + g;
+    int s = 0, e = 0;
+    bool is_long = false;
+    if (u < n) {
+      if (u >= n_uniq) {
+        if (zero_tail) {
 #pragma unroll
           for (int k = 0; k < MAXV; ++k) {
             const int c = t + k * TPR;
-            if (c < d4) {
-              const float4 r = rows_a[p * d4 + c];
-              acc[k].x += r.x; acc[k].y += r.y; acc[k].z += r.z; acc[k].w += r.w;
-            }
+            if (c < d4) out[u * d4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
-        } else {
-          const long long pb = p - n_a;
-          const float w = coef_b[pb];
-          const long long row = pb / G;
+        }
+      } else {
+        float4 acc[MAXV];
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (uniq_idx[u] != 0) {
+          s = seg_start[u];
+          e = seg_start[u + 1];
+          is_long = e - s > LONG_SEG;
+          if (!is_long)
+            for (int q = s; q < e; ++q) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
+        }
+        if (!is_long) {
 #pragma unroll
           for (int k = 0; k < MAXV; ++k) {
             const int c = t + k * TPR;
-            if (c < d4) {
-              const float4 r = vec_b[row * d4 + c];
-              acc[k].x = fmaf(w, r.x, acc[k].x); acc[k].y = fmaf(w, r.y, acc[k].y);
-              acc[k].z = fmaf(w, r.z, acc[k].z); acc[k].w = fmaf(w, r.w, acc[k].w);
-            }
+            if (c < d4) out[u * d4 + c] = acc[k];
           }
         }
       }
     }
+    if (t == 0) long_flag[g] = is_long ? 1 : 0;
+    __syncthreads();
+    for (int gi = 0; gi < groups; ++gi) {
+      if (!long_flag[gi]) continue;            // block-uniform
+      const long long ul = base + gi;
+      const int sl = seg_start[ul], el = seg_start[ul + 1];
+      float4 acc[MAXV];
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-      const int c = t + k * TPR;
-      if (c < d4) out[u * d4 + c] = acc[k];
+      for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = sl + g; q < el; q += groups) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) part[g][k * TPR + t] = acc[k];
+      __syncthreads();
+      if (g == 0) {
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+          const int c = t + k * TPR;
+          if (c < d4) {
+            float4 r = part[0][k * TPR + t];
+            for (int gg = 1; gg < groups; ++gg) {
+              const float4 x = part[gg][k * TPR + t];
+              r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
+            }
+            out[ul * d4 + c] = r;
+          }
+        }
+      }
+      __syncthreads();
     }
+    __syncthreads();   // long_flag is rewritten by the next iteration
   }
 }
 
