@@ -350,6 +350,210 @@ __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restr
     if (lane == c) dq_last[(long long)b * p.d + h * HD + c] = dq[c];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Register-broadcast variants for small heads (head dim <= 16, SASRec's default 16 heads): the shared operand row is
+// not re-fetched from memory at all.  Each lane keeps ITS OWN key row (K_j, V_j) -- or query row in the column
+// pass -- in VGPRs, and iteration j broadcasts lane j's registers to the whole wave with v_readlane_b32 (the value
+// lands in an SGPR and feeds v_fma as a scalar operand).  Per wave the only memory traffic is one row per lane per
+// 64-key chunk; the scalar-cache refill traffic that bounded the s_load variants above is gone.
+__device__ __forceinline__ float bcast(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restrict__ qkv, const int* __restrict__ seq, AttnDims p,
+                                                          float* __restrict__ ctx, float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63;
+  const int item = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
+  const int h = item / p.nchunk, ck = item % p.nchunk;
+  if (h >= p.H) return;
+  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  const int i = ck * 64 + lane;
+  const bool active = i < L;
+  const int ii = active ? i : L - 1;
+  const float* __restrict__ base = qkv + (long long)b * L * ld;
+  const int* __restrict__ sq = seq + (long long)b * L;
+  float q[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) q[c] = base[(long long)ii * ld + h * HD + c];
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  const int nkc = (p.causal && !literal) ? ck + 1 : p.nchunk;   // key chunks this query chunk can see
+  const int c0 = literal ? 0 : fv >> 6;
+  float m = -INFINITY, l = 0.f, o[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) o[c] = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int kc = c0; kc < nkc; ++kc) {
+      const int jl = kc * 64 + lane, jc = min(jl, L - 1);
+      float kreg[HD], vreg[HD];
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        kreg[c] = base[(long long)jc * ld + p.d + h * HD + c];
+        vreg[c] = pass ? base[(long long)jc * ld + 2 * p.d + h * HD + c] : 0.f;
+      }
+      const unsigned long long vmask = literal ? ~0ull : __ballot(jl < L && sq[jc] > 0);
+      const int jn = min(64, L - kc * 64);
+      const int j0 = (!literal && kc == c0) ? (fv & 63) : 0;
+#pragma unroll 4
+      for (int jj = j0; jj < jn; ++jj) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) s = fmaf(q[c], bcast(kreg[c], jj), s);
+        const int j = kc * 64 + jj;
+        const bool ok = ((vmask >> jj) & 1ull) && (literal || !p.causal || j <= i);
+        const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
+        if (pass == 0) {
+          if (ok) m = fmaxf(m, sv);
+        } else {
+          const float pj = ok ? __expf(sv - m) : 0.f;
+          l += pj;
+#pragma unroll
+          for (int c = 0; c < HD; ++c) o[c] = fmaf(pj, bcast(vreg[c], jj), o[c]);
+        }
+      }
+    }
+  }
+  if (!active) return;
+  const bool dead = l == 0.f;   // padded-prefix row of a non-empty sequence: unreachable from the loss
+  const float inv_l = dead ? 0.f : 1.0f / l;
+  float* out = ctx + ((long long)b * L + i) * p.d + h * HD;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) out[c] = o[c] * inv_l;
+  lse[((long long)b * p.H + h) * L + i] = dead ? 0.f : m + __logf(l);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_rl_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
+                                                          const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                          const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
+  const int lane = threadIdx.x & 63;
+  const int item = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
+  const int h = item / p.nchunk, ck = item % p.nchunk;
+  if (h >= p.H) return;
+  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  const int r = ck * 64 + lane;          // this lane's row: query row in the row pass, key row in the column pass
+  const bool active = r < L;
+  const int rr = active ? r : L - 1;
+  const float* __restrict__ base = qkv + (long long)b * L * ld;
+  const float* __restrict__ gbase = dctx + (long long)b * L * p.d + h * HD;
+  const float* __restrict__ obase = ctx + (long long)b * L * p.d + h * HD;
+  const int* __restrict__ sq = seq + (long long)b * L;
+  const float* __restrict__ lse_h = lse + ((long long)b * p.H + h) * L;
+  float* orow = dqkv + ((long long)b * L + rr) * ld + h * HD;
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  const int dead_below = (p.causal && !literal) ? fv : 0;   // query rows below this have no allowed key
+  const float f = literal ? 1.0f / p.sqrt_hd : p.scale;
+  // own row as a query: q, dO, lse, D = dO . O
+  float q[HD], g[HD];
+  float Dr = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) {
+    q[c] = base[(long long)rr * ld + h * HD + c];
+    g[c] = gbase[(long long)rr * p.d + c];
+    Dr = fmaf(g[c], obase[(long long)rr * p.d + c], Dr);
+  }
+  const float lr = lse_h[rr];
+  {  // ---- row pass: dQ_i = f * sum_j dS_ij K_j
+    float dq[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dq[c] = 0.f;
+    const bool live = literal || r >= dead_below;
+    const int nkc = (p.causal && !literal) ? ck + 1 : p.nchunk;
+    const int c0 = literal ? 0 : fv >> 6;
+    for (int kc = c0; kc < nkc; ++kc) {
+      const int jl = kc * 64 + lane, jc = min(jl, L - 1);
+      float kreg[HD], vreg[HD];
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        kreg[c] = base[(long long)jc * ld + p.d + h * HD + c];
+        vreg[c] = base[(long long)jc * ld + 2 * p.d + h * HD + c];
+      }
+      const unsigned long long vmask = literal ? ~0ull : __ballot(jl < L && sq[jc] > 0);
+      const int jn = min(64, L - kc * 64);
+      const int j0 = (!literal && kc == c0) ? (fv & 63) : 0;
+#pragma unroll 4
+      for (int jj = j0; jj < jn; ++jj) {
+        float kj[HD];
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+          kj[c] = bcast(kreg[c], jj);
+          s = fmaf(q[c], kj[c], s);
+          dp = fmaf(g[c], bcast(vreg[c], jj), dp);
+        }
+        const int j = kc * 64 + jj;
+        const bool ok = live && ((vmask >> jj) & 1ull) && (literal || !p.causal || j <= r);
+        const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
+        const float ds = ok ? __expf(sv - lr) * (dp - Dr) : 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kj[c], dq[c]);
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < HD; ++c) orow[c] = dq[c] * f;
+    }
+  }
+  {  // ---- column pass: dK_j = f * sum_i dS_ij Q_i ,  dV_j = sum_i P_ij dO_i   (own row as a key)
+    float k[HD], v[HD], dk[HD], dv[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      k[c] = base[(long long)rr * ld + p.d + h * HD + c];
+      v[c] = base[(long long)rr * ld + 2 * p.d + h * HD + c];
+      dk[c] = 0.f;
+      dv[c] = 0.f;
+    }
+    const bool vj = literal || sq[rr] > 0;
+    const int qc0 = (p.causal && !literal) ? max(ck, dead_below >> 6) : 0;   // earlier query chunks see none of these keys
+    for (int qc = qc0; qc < p.nchunk; ++qc) {
+      // lane t of the wave holds query row qc*64+t for broadcasting (for qc == ck that is this lane's own row)
+      const int il = qc * 64 + lane, ic = min(il, L - 1);
+      float qreg[HD], greg[HD];
+      float Dq = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        qreg[c] = base[(long long)ic * ld + h * HD + c];
+        greg[c] = gbase[(long long)ic * p.d + c];
+        Dq = fmaf(greg[c], obase[(long long)ic * p.d + c], Dq);
+      }
+      const float lq = lse_h[ic];
+      const int in = min(64, L - qc * 64);
+      const int i0 = (qc == (dead_below >> 6)) ? (dead_below & 63) : 0;
+#pragma unroll 4
+      for (int it = i0; it < in; ++it) {
+        float qi[HD], gi[HD];
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+          qi[c] = bcast(qreg[c], it);
+          gi[c] = bcast(greg[c], it);
+          s = fmaf(k[c], qi[c], s);
+          dp = fmaf(v[c], gi[c], dp);
+        }
+        const int i = qc * 64 + it;
+        const bool ok = vj && (literal || !p.causal || r <= i);
+        const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
+        const float pj = ok ? __expf(sv - bcast(lq, it)) : 0.f;
+        const float ds = pj * (dp - bcast(Dq, it));
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+          dk[c] = fmaf(ds, qi[c], dk[c]);
+          dv[c] = fmaf(pj, gi[c], dv[c]);
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        orow[p.d + c] = dk[c] * f;
+        orow[2 * p.d + c] = dv[c];
+      }
+    }
+  }
+}
+
 long long attn_lse_floats(int B, int H, int L) { return (long long)B * H * L; }
 long long attn_bwd_ws_floats(int B, int H, int L) { return (long long)B * H * L + 64; }
 
@@ -374,15 +578,17 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
   if (rc) return rc;
   dim3 grid(B, cdiv(H * p.nchunk, 4));
 #define GO(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, p, ctx, lse)
-  switch (p.hd) {
-    case 2: GO(2); break;
-    case 4: GO(4); break;
-    case 8: GO(8); break;
-    case 16: GO(16); break;
+#define GR(HD) hipLaunchKernelGGL((attn_fwd_rl_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, p, ctx, lse)
+  switch (p.hd) {   // small heads: register-broadcast kernels; large heads: scalar-load kernels
+    case 2: GR(2); break;
+    case 4: GR(4); break;
+    case 8: GR(8); break;
+    case 16: GR(16); break;
     case 32: GO(32); break;
     default: GO(64); break;
   }
 #undef GO
+#undef GR
   UR_LAUNCH_CHECK();
   return UR_OK;
 }
@@ -395,19 +601,23 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
   int rc = make_dims(B, L, d, H, causal, &p);
   if (rc) return rc;
   float* Dd = ws;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(B), dim3(256), 0, st, ctx, dctx, p, Dd);
-  UR_LAUNCH_CHECK();
   dim3 grid(B, cdiv(H * p.nchunk, 4));
+  if (p.hd > 16) {
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(B), dim3(256), 0, st, ctx, dctx, p, Dd);
+    UR_LAUNCH_CHECK();
+  }
 #define GO(HD) hipLaunchKernelGGL((attn_bwd_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, dctx, lse, Dd, p, dqkv)
+#define GR(HD) hipLaunchKernelGGL((attn_bwd_rl_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv)
   switch (p.hd) {
-    case 2: GO(2); break;
-    case 4: GO(4); break;
-    case 8: GO(8); break;
-    case 16: GO(16); break;
+    case 2: GR(2); break;
+    case 4: GR(4); break;
+    case 8: GR(8); break;
+    case 16: GR(16); break;
     case 32: GO(32); break;
     default: GO(64); break;
   }
 #undef GO
+#undef GR
   UR_LAUNCH_CHECK();
   return UR_OK;
 }
