@@ -37,6 +37,7 @@ struct GemmArgs {
   const float* aux; int ldaux;   // residual / addend / pre-activation
   const float* gamma; const float* beta; float eps;
   float* xhat; float* rstd;      // EPI_BIAS_RES_LN outputs
+  int debug;                     // tuning aid (UR_GEMM_DEBUG): 1 = skip epilogue, 2 = skip K-loop global loads
 };
 int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st);
 
