@@ -377,41 +377,76 @@ __global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restric
 #pragma unroll
   for (int c = 0; c < HD; ++c) q[c] = base[(long long)ii * ld + h * HD + c];
   const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
-  const bool literal = fv >= L;
-  const int nkc = (p.causal && !literal) ? ck + 1 : p.nchunk;   // key chunks this query chunk can see
-  const int c0 = literal ? 0 : fv >> 6;
   float m = -INFINITY, l = 0.f, o[HD];
 #pragma unroll
   for (int c = 0; c < HD; ++c) o[c] = 0.f;
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int kc = c0; kc < nkc; ++kc) {
-      const int jl = kc * 64 + lane, jc = min(jl, L - 1);
-      float kreg[HD], vreg[HD];
+  if (fv < L) {
+    // scores are pre-scaled: q <- q / sqrt(hd), so s = q . k needs no multiply in the loop
 #pragma unroll
-      for (int c = 0; c < HD; ++c) {
-        kreg[c] = base[(long long)jc * ld + p.d + h * HD + c];
-        vreg[c] = pass ? base[(long long)jc * ld + 2 * p.d + h * HD + c] : 0.f;
-      }
-      const unsigned long long vmask = literal ? ~0ull : __ballot(jl < L && sq[jc] > 0);
-      const int jn = min(64, L - kc * 64);
-      const int j0 = (!literal && kc == c0) ? (fv & 63) : 0;
-#pragma unroll 4
-      for (int jj = j0; jj < jn; ++jj) {
-        float s = 0.f;
+    for (int c = 0; c < HD; ++c) q[c] *= p.scale;
+    const int nkc = p.causal ? ck + 1 : p.nchunk;   // key chunks this query chunk can see
+    const int c0 = fv >> 6;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int kc = c0; kc < nkc; ++kc) {
+        const int jl = kc * 64 + lane, jc = min(jl, L - 1);
+        float kreg[HD], vreg[HD];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) s = fmaf(q[c], bcast(kreg[c], jj), s);
-        const int j = kc * 64 + jj;
-        const bool ok = ((vmask >> jj) & 1ull) && (literal || !p.causal || j <= i);
-        const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
-        if (pass == 0) {
-          if (ok) m = fmaxf(m, sv);
-        } else {
-          const float pj = ok ? __expf(sv - m) : 0.f;
-          l += pj;
+        for (int c = 0; c < HD; ++c) {
+          kreg[c] = base[(long long)jc * ld + p.d + h * HD + c];
+          vreg[c] = pass ? base[(long long)jc * ld + 2 * p.d + h * HD + c] : 0.f;
+        }
+        const unsigned long long vmask = __ballot(jl < L && sq[jc] > 0);
+        const int jn = min(64, L - kc * 64);
+        const int j0 = (kc == c0) ? (fv & 63) : 0;
+        const int ilim = p.causal ? i - kc * 64 : 64;   // key jj is visible iff jj <= ilim
+        // two keys per iteration: the two broadcast->fma chains interleave, hiding the VALU->SGPR->VALU wait states
+        int jj = j0;
+        for (; jj + 1 < jn; jj += 2) {
+          float ka[HD], kb[HD];
 #pragma unroll
-          for (int c = 0; c < HD; ++c) o[c] = fmaf(pj, bcast(vreg[c], jj), o[c]);
+          for (int c = 0; c < HD; ++c) { ka[c] = bcast(kreg[c], jj); kb[c] = bcast(kreg[c], jj + 1); }
+          float sa = 0.f, sb = 0.f;
+#pragma unroll
+          for (int c = 0; c < HD; ++c) { sa = fmaf(q[c], ka[c], sa); sb = fmaf(q[c], kb[c], sb); }
+          const bool oka = ((vmask >> jj) & 1ull) && jj <= ilim, okb = ((vmask >> (jj + 1)) & 1ull) && jj + 1 <= ilim;
+          if (pass == 0) {
+            m = fmaxf(m, fmaxf(oka ? sa : -INFINITY, okb ? sb : -INFINITY));
+          } else {
+            const float pa = oka ? __expf(sa - m) : 0.f, pb = okb ? __expf(sb - m) : 0.f;
+            l += pa + pb;
+            float va[HD], vb[HD];
+#pragma unroll
+            for (int c = 0; c < HD; ++c) { va[c] = bcast(vreg[c], jj); vb[c] = bcast(vreg[c], jj + 1); }
+#pragma unroll
+            for (int c = 0; c < HD; ++c) o[c] = fmaf(pb, vb[c], fmaf(pa, va[c], o[c]));
+          }
+        }
+        if (jj < jn) {
+          float sa = 0.f;
+#pragma unroll
+          for (int c = 0; c < HD; ++c) sa = fmaf(q[c], bcast(kreg[c], jj), sa);
+          const bool oka = ((vmask >> jj) & 1ull) && jj <= ilim;
+          if (pass == 0) {
+            if (oka) m = fmaxf(m, sa);
+          } else {
+            const float pa = oka ? __expf(sa - m) : 0.f;
+            l += pa;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) o[c] = fmaf(pa, bcast(vreg[c], jj), o[c]);
+          }
         }
       }
+    }
+  } else {  // empty history: literal path over all L keys (rare; plain loops)
+    const float* __restrict__ Kb = base + p.d + h * HD;
+    const float* __restrict__ Vb = base + 2 * p.d + h * HD;
+    for (int j = 0; j < L; ++j) m = fmaxf(m, dot_u<HD>(q, Kb + (long long)j * ld) / p.sqrt_hd + -10000.0f);
+    for (int j = 0; j < L; ++j) {
+      const float pj = __expf((dot_u<HD>(q, Kb + (long long)j * ld) / p.sqrt_hd + -10000.0f) - m);
+      l += pj;
+      const float* __restrict__ vr = Vb + (long long)j * ld;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) o[c] = fmaf(pj, vr[c], o[c]);
     }
   }
   if (!active) return;

@@ -22,18 +22,19 @@ namespace ur {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
-constexpr int LS = BK + 4;  // padded LDS row stride (floats)
 
 __device__ __forceinline__ float4 act4(float4 v, int act) {
   v.x = act_fwd(v.x, act); v.y = act_fwd(v.y, act); v.z = act_fwd(v.z, act); v.w = act_fwd(v.w, act);
   return v;
 }
 
-template <int BM, int BN, int PRO, int EPI>
+template <int BM, int BN, int PRO, int EPI, int BK = 32>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+  constexpr int LS = BK + 4;            // padded LDS row stride (floats): conflict-free ds_read_b128 for BK = 16 and 32
+  constexpr int C4N = BK / 4;           // float4 columns per tile row
+  constexpr int RPT = 256 / C4N;        // tile rows covered per pass of the 256 threads
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AV = BM / 32, WV = BN / 32;  // float4 loads per thread per K-step
+  constexpr int AV = BM / RPT, WV = BN / RPT;  // float4 loads per thread per K-step
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][BM*LS]
   float* Ws = smem + 2 * BM * LS;   // [2][BN*LS]
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   const int mt = (qid / ntn) * 8 + xcd, nt_ = qid % ntn;
   if (mt >= ntm) return;
   const int m0 = mt * BM, n0 = nt_ * BN;
-  const int c4 = tid & 7, lrow = tid >> 3;
+  const int c4 = tid % C4N, lrow = tid / C4N;
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -62,9 +63,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   const float* Ap[AV];
   const float* Wp[WV];
 #pragma unroll
-  for (int i = 0; i < AV; ++i) Ap[i] = a.A + (long long)min(m0 + lrow + 32 * i, a.M - 1) * a.lda + c4 * 4;
+  for (int i = 0; i < AV; ++i) Ap[i] = a.A + (long long)min(m0 + lrow + RPT * i, a.M - 1) * a.lda + c4 * 4;
 #pragma unroll
-  for (int i = 0; i < WV; ++i) Wp[i] = a.W + (long long)min(n0 + lrow + 32 * i, a.N - 1) * a.ldw + c4 * 4;
+  for (int i = 0; i < WV; ++i) Wp[i] = a.W + (long long)min(n0 + lrow + RPT * i, a.N - 1) * a.ldw + c4 * 4;
 
   float4 ra[AV], rw[WV];
   auto load_global = [&](int kt) {
@@ -86,10 +87,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     for (int i = 0; i < AV; ++i) {
       float4 v = ra[i];
       if (PRO == PRO_ACT) v = act4(v, a.act);
-      *(float4*)(As + buf * BM * LS + (lrow + 32 * i) * LS + c4 * 4) = v;
+      *(float4*)(As + buf * BM * LS + (lrow + RPT * i) * LS + c4 * 4) = v;
     }
 #pragma unroll
-    for (int i = 0; i < WV; ++i) *(float4*)(Ws + buf * BN * LS + (lrow + 32 * i) * LS + c4 * 4) = rw[i];
+    for (int i = 0; i < WV; ++i) *(float4*)(Ws + buf * BN * LS + (lrow + RPT * i) * LS + c4 * 4) = rw[i];
   };
 
   const int nk = (a.K + BK - 1) / BK;
@@ -222,16 +223,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   }
 }
 
-template <int BM, int BN, int PRO, int EPI>
+template <int BM, int BN, int PRO, int EPI, int BK = 32>
 static int launch_nt(const GemmArgs& a, hipStream_t st) {
+  constexpr int LS = BK + 4;
   dim3 grid(8 * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN));
   size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
   const size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
   if (cs > lds) lds = cs;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI>,
+  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI, BK>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, PRO, EPI>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, PRO, EPI, BK>), grid, dim3(256), lds, st, a);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }
@@ -242,6 +244,10 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
   const long long big = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
   static const int force = getenv("UR_GEMM_TILE") ? atoi(getenv("UR_GEMM_TILE")) : 0;   // tuning aid: 64 or 128 rows
   if (a.N <= 64) return launch_nt<64, 64, PRO, EPI>(a, st);
+  // short K, wide N (QKV, FFN-1, d-act): the 16-deep K-step variant keeps 4 workgroups per CU resident and measured
+  // 6-10 % faster at M = 25600; elsewhere the 32-deep step wins
+  if (force == 16 || (force == 0 && a.K <= 128 && a.N >= 256)) return launch_nt<64, 128, PRO, EPI, 16>(a, st);
+  if (force == 1616) return launch_nt<128, 128, PRO, EPI, 16>(a, st);
   if (force == 128 || (force == 0 && big >= 512)) return launch_nt<128, 128, PRO, EPI>(a, st);
   return launch_nt<64, 128, PRO, EPI>(a, st);
 }
