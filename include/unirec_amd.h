@@ -249,6 +249,22 @@ int ur_gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, i
                int ldo, float* bias_out, float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Full-item ranking for the one_vs_all evaluation protocol.
+ * Replaces Evaluator.evaluate_with_full_items (unirec/facility/evaluation/evaluator_abc.py:189-278: table copied to
+ * numpy, user_emb @ item_emb.T on the CPU, a Python loop that sets scores[history] = -inf, column 0 overwritten
+ * with the target's score) followed by numba get_rank (unirec/facility/evaluation/onepos.py:20-31:
+ * rank = #{columns 1.. : score > score[0]}).  Same result without materialising the [B, n_items] scores:
+ *   rank[b] = #{ n in [0,n_items), n != target_b, n != 0, n not in history(user_b) : s(b,n) > s(b,target_b) }
+ *   s(b,n)  = (user_emb[b] . item_table[n] + user_bias[user_b] + item_bias[n]) / tau        (tau > 0)
+ * target_score[b] = s(b, target_b).   history: CSR over users (hist_ptr[n_users+1], hist_sorted ascending within a
+ * user, duplicates allowed); users outside [0,n_users) or hist_ptr == NULL have no history.
+ * rank: int32[B]; thr_ws: B floats of scratch.  d % 4 == 0, d <= 512. */
+int ur_full_rank(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d,
+                 const int64_t* target, const int64_t* user_id, const int64_t* hist_ptr, const int32_t* hist_sorted,
+                 int64_t n_users, const float* user_bias, const float* item_bias, float tau, int32_t* rank,
+                 float* target_score, float* thr_ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Live profiler (measurement only; no reference counterpart).  While enabled, every launch group is
  * bracketed by HIP events on its stream.  ur_prof_read fills three host arrays of ur_prof_num_classes()
  * entries: summed milliseconds, number of launch groups, and summed algorithmic work (flops for the GEMM

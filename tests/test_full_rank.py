@@ -1,0 +1,146 @@
+"""one_vs_all full-item ranking: oracle/eval_ref.py vs the reference's recorded ranks (CPU), and
+ur_full_rank / Trainer.evaluate_full_items vs both (GPU).  Ranks are integers: the bar is exact equality, except that
+two fp32 summation orders may disagree on items whose score ties the target's to ~1e-6 -- the GPU tests bound the
+difference by the number of such near-ties counted in fp64 (zero on the golden fixtures)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import eval_ref, model_ref
+
+FIX = ["g11_fullrank_mf_bias_tau", "g11_fullrank_sasrec"]
+TIE_MARGIN = 2e-6
+
+
+def _hist(g):
+    ptr, items = g["hist"]["ptr"], g["hist"]["items"]
+    u2h = np.empty(len(ptr) - 1, dtype=object)
+    for u in range(len(u2h)):
+        u2h[u] = items[ptr[u]:ptr[u + 1]] if ptr[u + 1] > ptr[u] else None
+    return u2h
+
+
+def _user_emb_cpu(cfg, P, g, bi):
+    if cfg["model"] == "MF":
+        return model_ref.mf_user_emb(P, torch.from_numpy(g[f"in{bi}"]["user_id"])).numpy()
+    return model_ref.sasrec_user_emb(P, torch.from_numpy(g[f"in{bi}"]["item_seq"]), cfg).numpy()
+
+
+@pytest.mark.parametrize("name", FIX)
+def test_oracle_rank_matches_reference(name):
+    cfg, g = load_golden(name)
+    P = {k: torch.from_numpy(v) for k, v in g["sd"].items()}
+    u2h = _hist(g)
+    ranks = []
+    for bi in range(2):
+        uid, tgt = g[f"in{bi}"]["user_id"], g[f"in{bi}"]["item_id"]
+        ue = _user_emb_cpu(cfg, P, g, bi)
+        ub = g["sd"]["user_bias"][uid] if cfg["has_user_bias"] else None
+        ib = g["sd"]["item_bias"] if cfg["has_item_bias"] else None
+        s = eval_ref.full_scores(ue, g["sd"]["item_embedding.weight"], ub, ib, cfg["tau"])
+        r, _ = eval_ref.full_rank(s, uid, tgt, u2h)
+        assert np.array_equal(r, g[f"out{bi}"]["rank"])
+        ranks.append(r)
+    m = eval_ref.metrics_from_rank(np.concatenate(ranks), cfg["n_items"])
+    for k, v in g["metric"].items():
+        np.testing.assert_allclose(m[k], float(v), rtol=1e-12, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _gpu_rank(ue, table, tgt, uid, u2h, ub, ib, tau):
+    from unirec_amd import ops
+    from unirec_amd.data.rows import HistoryCSR
+    dev = "cuda:0"
+    hp = hs = None
+    if u2h is not None:
+        hp, hs = HistoryCSR(u2h).to_device(dev)
+    t = lambda a, dt: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    r, ts = ops.full_rank(t(ue, torch.float32), t(table, torch.float32), t(tgt, torch.int64), t(uid, torch.int64), hp, hs,
+                          t(ub, torch.float32), t(ib, torch.float32), tau)
+    return r.cpu().numpy(), ts.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FIX)
+def test_gpu_rank_matches_reference_golden(name):
+    cfg, g = load_golden(name)
+    P = {k: torch.from_numpy(v) for k, v in g["sd"].items()}
+    u2h = _hist(g)
+    for bi in range(2):
+        uid, tgt = g[f"in{bi}"]["user_id"], g[f"in{bi}"]["item_id"]
+        ue = _user_emb_cpu(cfg, P, g, bi)
+        r, _ = _gpu_rank(ue, g["sd"]["item_embedding.weight"], tgt, uid, u2h,
+                         g["sd"]["user_bias"] if cfg["has_user_bias"] else None,
+                         g["sd"]["item_bias"] if cfg["has_item_bias"] else None, float(cfg["tau"]))
+        assert np.array_equal(r, g[f"out{bi}"]["rank"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d,B,bias,hist", [(1017, 32, 77, False, True), (128, 64, 5, True, False), (100, 16, 3, True, True),
+                                             (60001, 64, 300, True, True), (40960, 128, 513, False, True),
+                                             (5000, 200, 64, True, True)])
+def test_gpu_rank_matches_oracle(N, d, B, bias, hist):
+    rng = np.random.default_rng(N + d)
+    table = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    ue = rng.normal(0, 0.1, (B, d)).astype(np.float32)
+    n_users = 50
+    uid = rng.integers(0, n_users + 5, B).astype(np.int64)          # some users beyond the history table
+    tgt = rng.integers(1, N, B).astype(np.int64)
+    u2h = None
+    if hist:
+        u2h = np.empty(n_users, dtype=object)
+        for u in range(n_users):
+            h = rng.integers(0, N, rng.integers(0, 400))
+            u2h[u] = None if len(h) == 0 else np.concatenate([h, h[:3]])     # duplicates; item 0 appears for some users
+        for b in range(0, B, 4):                                             # targets that are also in the history
+            if uid[b] < n_users and u2h[uid[b]] is not None and u2h[uid[b]][0] > 0:
+                tgt[b] = u2h[uid[b]][0]
+    tgt[-1] = N - 1                                                          # a target in the GEMM's N tail
+    ub = rng.normal(0, 0.1, n_users + 5).astype(np.float32) if bias else None
+    ib = rng.normal(0, 0.1, N).astype(np.float32) if bias else None
+    tau = 0.7 if bias else 1.0
+    r, ts = _gpu_rank(ue, table, tgt, uid, u2h, ub, ib, tau)
+    s64 = eval_ref.full_scores(ue, table, None if ub is None else ub[uid], ib, tau, dtype=np.float64)
+    ties = eval_ref.near_ties(s64, uid, tgt, TIE_MARGIN)
+    r_ref, ts_ref = eval_ref.full_rank(s64.copy(), uid, tgt, u2h)
+    np.testing.assert_allclose(ts, ts_ref, rtol=1e-4, atol=1e-6)
+    assert (np.abs(r.astype(np.int64) - r_ref) <= ties).all(), (r[:8], r_ref[:8], ties[:8])
+    assert (r == r_ref).mean() > 0.98
+
+
+@pytest.mark.gpu
+def test_trainer_one_vs_all_matches_oracle():
+    from unirec_amd.facility.trainer import Trainer
+    from unirec_amd.utils.argument_parser import parse_arguments
+    from unirec_amd.utils.general import get_class_instance, init_seed
+    rng = np.random.default_rng(8)
+    n_users, n_items, L = 60, 2000, 12
+    cfg = parse_arguments(dict(model="SASRec", n_users=n_users, n_items=n_items, device="cuda:0", loss_type="softmax", embedding_size=32,
+                               hidden_size=32, inner_size=64, n_heads=4, max_seq_len=L, epochs=0, batch_size=64, seed=5))
+    init_seed(5)
+    model = get_class_instance("SASRec", "unirec_amd/model")(cfg)
+    tr = Trainer(cfg, model)
+    u2h = np.empty(n_users, dtype=object)
+    for u in range(n_users):
+        u2h[u] = rng.integers(1, n_items, rng.integers(1, 80)).astype(np.int64)
+    tr.set_user_history(u2h)
+    tr.reset_evaluator("user-item", "one_vs_all")
+    batches = []
+    for _ in range(3):
+        B = 50
+        seq = rng.integers(1, n_items, (B, L)).astype(np.int32)
+        for b in range(B):
+            seq[b, : rng.integers(0, L)] = 0
+        batches.append({"user_id": torch.from_numpy(rng.integers(0, n_users, B)).cuda(), "item_id": torch.from_numpy(rng.integers(1, n_items, B)).cuda(),
+                        "item_seq": torch.from_numpy(seq).cuda(), "item_seq_len": torch.from_numpy((seq > 0).sum(1)).cuda()})
+    res = tr.evaluate(batches, load_best_model=False)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ranks = []
+    for b in batches:
+        ue = model_ref.sasrec_user_emb(P, b["item_seq"].cpu().long(), cfg).numpy()
+        s = eval_ref.full_scores(ue, P["item_embedding.weight"].numpy(), None, None, 1.0, dtype=np.float64)
+        ranks.append(eval_ref.full_rank(s, b["user_id"].cpu().numpy(), b["item_id"].cpu().numpy(), u2h)[0])
+    ref = eval_ref.metrics_from_rank(np.concatenate(ranks), n_items)
+    for k in ("mrr", "group_auc", "hit@10", "ndcg@10"):
+        np.testing.assert_allclose(res[k], ref[k], rtol=2e-3, atol=1e-4, err_msg=k)

@@ -103,7 +103,12 @@ def run_model(model, batch, want_layers=False):
     return out
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]   # e.g. `capture_goldens.py g11` rewrites only g11_* files
+
+
 def save(name, **arrs):
+    if ONLY and not any(name.startswith(p) for p in ONLY):
+        return
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrs)
@@ -268,6 +273,67 @@ def main():
             arrs[f"loss{step}"] = loss.detach().numpy().copy()
             arrs.update(pack(f"sd{step + 1}.", sd_np(m)))
         save("g9_adam_" + tag, **arrs)
+
+    # ---------------------------------------------------------------- G11 one_vs_all full-item evaluation
+    # OnePositiveEvaluator.evaluate_with_full_items run on the reference's own models; get_rank's output is recorded.
+    import unirec.facility.evaluation.onepos as onepos
+
+    class _Acc:   # the two Accelerate calls the evaluator makes, single process
+        device, is_local_main_process = "cpu", True
+        unwrap_model = staticmethod(lambda m: m)
+        gather_for_metrics = staticmethod(lambda t: t)
+
+    class _Data(list):
+        pass
+
+    rng11 = np.random.default_rng(1111)
+    for tag, mk in {"mf_bias_tau": lambda: (MF, base_cfg(model="MF", n_items=517, has_user_emb=True, has_user_bias=True,
+                                                       has_item_bias=True, tau=0.5, embedding_size=16, hidden_size=16)),
+                    "sasrec": lambda: (SASRec, base_cfg(model="SASRec", n_items=640, n_heads=2))}.items():
+        cls, cfg = mk()
+        torch.manual_seed(11)
+        m = cls(cfg)
+        if cfg["has_item_bias"]:
+            with torch.no_grad():
+                m.item_bias.normal_(0, 0.02)
+                m.user_bias.normal_(0, 0.02)
+        n_users, n_items, L = cfg["n_users"], cfg["n_items"], cfg["max_seq_len"]
+        u2h = np.empty(n_users, dtype=object)
+        for u in range(n_users):
+            u2h[u] = None if u % 7 == 0 else rng11.integers(0 if u % 5 == 0 else 1, n_items, rng11.integers(1, 60)).astype(np.int64)
+        batches, raw = [], []
+        for bi in range(2):
+            B = 9
+            user = rng11.integers(0, n_users + (3 if bi else 0), size=B).astype(np.int64)   # ids >= len(history): no history
+            user = np.minimum(user, n_users - 1) if cfg["has_user_emb"] else user
+            item = rng11.integers(1, n_items, size=B).astype(np.int64)
+            if u2h[user[0]] is not None:
+                item[0] = u2h[user[0]][0] if u2h[user[0]][0] > 0 else item[0]                 # a target that is also in the history
+            seq = rng11.integers(1, n_items, size=(B, L)).astype(np.int64)
+            for b in range(B):
+                seq[b, : rng11.integers(0, L)] = 0
+            raw.append((user, item, seq))
+            batches.append([torch.from_numpy(user), torch.from_numpy(item), torch.from_numpy(seq),
+                            torch.from_numpy((seq > 0).sum(1))])
+        data = _Data(batches)
+        data.dataset = types.SimpleNamespace(return_key_2_index={"user_id": 0, "item_id": 1, "item_seq": 2, "item_seq_len": 3},
+                                             config={"data_format": "user-item"})
+        ranks = []
+        orig = onepos.get_rank
+        onepos.get_rank = lambda S: ranks.append(orig(S).copy()) or ranks[-1]
+        ev = onepos.OnePositiveEvaluator("['hit@1;5;10', 'ndcg@5;10', 'mrr', 'group_auc']", -1, cfg, _Acc())
+        res = ev.evaluate_with_full_items(data, m, u2h)
+        onepos.get_rank = orig
+        arrs = pack("cfg.", {k: np.array(v) for k, v in cfg.items()})
+        arrs.update(pack("sd.", sd_np(m)))
+        arrs["hist.ptr"] = np.cumsum([0] + [0 if h is None else len(h) for h in u2h]).astype(np.int64)
+        arrs["hist.items"] = np.concatenate([h for h in u2h if h is not None]).astype(np.int64)
+        for bi, (user, item, seq) in enumerate(raw):
+            arrs[f"in{bi}.user_id"], arrs[f"in{bi}.item_id"], arrs[f"in{bi}.item_seq"] = user, item, seq
+            arrs[f"out{bi}.rank"] = ranks[bi].astype(np.int64)
+        for k, v in res.items():
+            arrs["metric." + k] = np.array(v, dtype=np.float64)
+        save("g11_fullrank_" + tag, **arrs)
 
 
 if __name__ == "__main__":

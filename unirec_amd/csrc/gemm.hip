@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     constexpr int RPP = 256 / RT;      // rows per pass
     const int t = tid % RT, g = tid / RT;
     const int n = n0 + t * 4;
-    if (n < a.N) {  // N % 4 == 0
+    if (n < a.N || EPI == EPI_COUNT_GT) {  // N % 4 == 0 (COUNT_GT requires N % BN == 0 so every lane is in range)
       float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
       if (EPI == EPI_BIAS) bias = *(const float4*)(a.bias + n);
 #pragma unroll 4
@@ -168,6 +168,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         if (EPI == EPI_ADD) {
           const float4 h = *(const float4*)(a.aux + (long long)m * a.ldaux + n);
           v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+        }
+        if (EPI == EPI_COUNT_GT) {
+          // full-item ranking: nothing is stored; count the columns of this tile whose score (acc + bias[n]) beats the
+          // row's threshold aux[m], reduce over the RT lanes that share the row, one integer atomic per (row, tile)
+          float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.bias) bs = *(const float4*)(a.bias + n);
+          const float th = a.aux[m];
+          const long long sk = (a.skip ? a.skip[m] : -1) - n;   // column of this float4 to leave out (0..3) or none
+          float cnt = ((v.x + bs.x > th && sk != 0) ? 1.f : 0.f) + ((v.y + bs.y > th && sk != 1) ? 1.f : 0.f) +
+                      ((v.z + bs.z > th && sk != 2) ? 1.f : 0.f) + ((v.w + bs.w > th && sk != 3) ? 1.f : 0.f);
+          cnt = group_sum<RT>(cnt);
+          if (t == 0 && cnt > 0.f) atomicAdd((int*)a.C + m, (int)cnt);
+          continue;
         }
         *(float4*)(a.C + (long long)m * a.ldc + n) = v;
       }
@@ -257,7 +270,7 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
   ProfScope ps(PC_GEMM_NT, st, 2.0 * a.M * a.N * a.K);
   static const int dbg_env = getenv("UR_GEMM_DEBUG") ? atoi(getenv("UR_GEMM_DEBUG")) : 0;
   const_cast<GemmArgs&>(a).debug = dbg_env;
-  if ((a.K & 3) || (a.N & 3) || (a.lda & 3) || (a.ldw & 3) || (a.ldc & 3) || (a.aux && (a.ldaux & 3)))
+  if ((a.K & 3) || (a.N & 3) || (a.lda & 3) || (a.ldw & 3) || (epi != EPI_COUNT_GT && ((a.ldc & 3) || (a.aux && (a.ldaux & 3)))))
     return fail(UR_ERR_ARG, "gemm_nt: N, K and all leading dimensions must be multiples of 4 (N=%d K=%d)", a.N, a.K);
   if (epi == EPI_BIAS_RES_LN) {
     if (a.N > 256 || a.ldc != a.N) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm needs N<=256 (N=%d)", a.N);
@@ -275,6 +288,9 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
     case EPI_BIAS: return dispatch_tile<PRO_NONE, EPI_BIAS>(a, st);
     case EPI_MUL_DACT: return dispatch_tile<PRO_NONE, EPI_MUL_DACT>(a, st);
     case EPI_ADD: return dispatch_tile<PRO_NONE, EPI_ADD>(a, st);
+    case EPI_COUNT_GT:
+      if (a.N % 128) return fail(UR_ERR_ARG, "gemm_nt: EPI_COUNT_GT needs N %% 128 == 0 (N=%d)", a.N);
+      return launch_nt<128, 128, PRO_NONE, EPI_COUNT_GT>(a, st);
   }
   return fail(UR_ERR_UNSUPPORTED, "gemm_nt: epilogue %d", epi);
 }

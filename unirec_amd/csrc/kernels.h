@@ -26,6 +26,7 @@ enum GemmEpi {
   EPI_BIAS_RES_LN = 2,  // t = acc + bias[n] + res[m,n]; C = LN(t)*gamma+beta; also xhat, rstd
   EPI_MUL_DACT = 3,  // C = acc * act'(aux[m,n])
   EPI_ADD = 4,       // C = acc + aux[m,n]
+  EPI_COUNT_GT = 5,  // nothing stored: ((int*)C)[m] += #{n != skip[m] : acc + bias[n] > aux[m]}   (full-item ranking)
 };
 struct GemmArgs {
   const float* A; int lda;
@@ -37,6 +38,7 @@ struct GemmArgs {
   const float* aux; int ldaux;   // residual / addend / pre-activation
   const float* gamma; const float* beta; float eps;
   float* xhat; float* rstd;      // EPI_BIAS_RES_LN outputs
+  const long long* skip;         // EPI_COUNT_GT: per-row column left out of the count (nullable)
   int debug;                     // tuning aid (UR_GEMM_DEBUG): 1 = skip epilogue, 2 = skip K-loop global loads
 };
 int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st);

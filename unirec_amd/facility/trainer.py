@@ -109,15 +109,61 @@ class Trainer(object):
                              float(stacked[~nan].sum()))
         return self.best_valid_score
 
-    # ------------------------------------------------------------------ evaluation (one_vs_k: positive in column 0)
+    # ------------------------------------------------------------------ evaluation
+    @staticmethod
+    def _metrics_from_rank(r, n_scores):
+        """hit/ndcg/mrr/group_auc from the 0-based rank of the positive (unirec/facility/evaluation/onepos.py:100-175)."""
+        r = np.asarray(r, dtype=np.float64)
+        out = {"mrr": float(np.mean(1.0 / (r + 1))), "group_auc": float(np.mean((n_scores - 1 - r) / max(n_scores - 1, 1)))}
+        for k in (1, 3, 5, 10, 20, 50, 100):
+            out[f"hit@{k}"] = float(np.mean(r < k))
+            out[f"ndcg@{k}"] = float(np.mean(np.where(r < k, 1.0 / np.log2(r + 2), 0.0)))
+        return out
+
+    def _history_csr(self, device):
+        """Device CSR of ``set_user_history``'s table (object array user -> item ids, or a HistoryCSR), built once."""
+        from ..data.rows import HistoryCSR
+        uh = getattr(self, "user_history", None)
+        if uh is None:
+            return None, None
+        if getattr(self, "_hist_src", None) is not uh:
+            self._hist_csr = uh if isinstance(uh, HistoryCSR) else HistoryCSR(uh)
+            self._hist_src = uh
+        return self._hist_csr.to_device(device)
+
+    @torch.no_grad()
+    def evaluate_full_items(self, eval_data):
+        """one_vs_all protocol: rank of the target among ALL items except item 0 and the user's history
+        (Evaluator.evaluate_with_full_items, unirec/facility/evaluation/evaluator_abc.py:189-278).  One fused
+        GEMM+count per batch on the device; the reference's random +-1e-8 tie-breaking noise is not reproduced."""
+        from .. import ops
+        model = self.model
+        ranks = []
+        for batch in eval_data:
+            kw = {k: batch[k] for k in ("user_id", "item_seq", "item_seq_len") if k in batch}
+            user_emb = model.forward_user_emb(**kw).contiguous()
+            target = batch["item_id"].reshape(user_emb.shape[0], -1)[:, 0].contiguous()
+            hp, hs = self._history_csr(user_emb.device)
+            uid = batch.get("user_id")
+            if uid is None:
+                hp = hs = None
+            rank, _ = ops.full_rank(user_emb, model.item_embedding.weight.data, target, user_id=uid, hist_ptr=hp, hist_sorted=hs,
+                                    user_bias=model.user_bias.data if model.has_user_bias else None,
+                                    item_bias=model.item_bias.data if model.has_item_bias else None, tau=model.tau)
+            ranks.append(rank)
+        r = torch.cat(ranks).cpu().numpy()
+        return self._metrics_from_rank(r, model.n_items)
+
     @torch.no_grad()
     def evaluate(self, eval_data, load_best_model=True, model_file=None, verbose=0, predict_only=False):
         if load_best_model and os.path.exists(model_file or self.saved_model_file):
             self.load_model(model_file or self.saved_model_file)
         self.optimizer.flush()
         self.model.eval()
+        if getattr(self, "eval_protocol", None) == "one_vs_all" and not predict_only:
+            return self.evaluate_full_items(eval_data)
         ranks = []
-        for batch in eval_data:
+        for batch in eval_data:   # one_vs_k: positive in column 0
             kw = {k: batch[k] for k in ("user_id", "item_id", "item_seq", "item_seq_len") if k in batch}
             _, scores, _, _ = self.model(**kw)
             if predict_only:
@@ -126,13 +172,7 @@ class Trainer(object):
             ranks.append((scores[:, 1:] > scores[:, :1]).sum(1).cpu().numpy())   # 0-based rank of the positive
         if predict_only:
             return np.concatenate(ranks)
-        r = np.concatenate(ranks).astype(np.float64)
-        G = scores.shape[1]
-        out = {"mrr": float(np.mean(1.0 / (r + 1))), "group_auc": float(np.mean((G - 1 - r) / max(G - 1, 1)))}
-        for k in (1, 3, 5, 10, 20):
-            out[f"hit@{k}"] = float(np.mean(r < k))
-            out[f"ndcg@{k}"] = float(np.mean(np.where(r < k, 1.0 / np.log2(r + 2), 0.0)))
-        return out
+        return self._metrics_from_rank(np.concatenate(ranks), scores.shape[1])
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:368-412)
     def save_model(self, filename, optimizer=None, scheduler=None, epoch=0, step=0, valid_result=None, config=None):

@@ -258,3 +258,29 @@ def sumsq(x, out, accumulate=False, ws=None):
 
 def clip_coef(sumsq_t, max_norm, out):
     check(lib.ur_clip_coef(_p(sumsq_t), float(max_norm), _p(out), _stream()), "ur_clip_coef")
+
+
+# --------------------------------------------------------------------------------------------- full-item ranking
+def full_rank(user_emb, item_table, target, user_id=None, hist_ptr=None, hist_sorted=None, user_bias=None, item_bias=None,
+              tau=1.0):
+    """rank[b] = number of items (not 0, not the target, not in the user's history) scoring above the target.
+    Returns (rank int32[B], target_score float32[B]).  See include/unirec_amd.h: ur_full_rank."""
+    _chk(user_emb, torch.float32, "user_emb")
+    _chk(item_table, torch.float32, "item_table")
+    _chk(target, torch.int64, "target")
+    _chk(user_id, torch.int64, "user_id", allow_none=True)
+    _chk(hist_ptr, torch.int64, "hist_ptr", allow_none=True)
+    _chk(hist_sorted, torch.int32, "hist_sorted", allow_none=True)
+    _chk(user_bias, torch.float32, "user_bias", allow_none=True)
+    _chk(item_bias, torch.float32, "item_bias", allow_none=True)
+    B, d = user_emb.shape
+    n_items = item_table.shape[0]
+    if item_table.shape[1] != d or target.numel() != B:
+        raise _lib.UnirecAmdError("full_rank: shape mismatch")
+    rank = torch.empty(B, dtype=torch.int32, device=user_emb.device)
+    ts = torch.empty(B, dtype=torch.float32, device=user_emb.device)
+    thr = torch.empty(B, dtype=torch.float32, device=user_emb.device)
+    n_users = hist_ptr.numel() - 1 if hist_ptr is not None else 0
+    check(lib.ur_full_rank(_p(user_emb), _p(item_table), n_items, B, d, _p(target), _p(user_id), _p(hist_ptr), _p(hist_sorted),
+                           n_users, _p(user_bias), _p(item_bias), float(tau), _p(rank), _p(ts), _p(thr), _stream()), "ur_full_rank")
+    return rank, ts
