@@ -79,7 +79,7 @@ def test_gpu_rank_matches_reference_golden(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,d,B,bias,hist", [(1017, 32, 77, False, True), (128, 64, 5, True, False), (100, 16, 3, True, True),
                                              (60001, 64, 300, True, True), (40960, 128, 513, False, True),
-                                             (5000, 200, 64, True, True)])
+                                             (5000, 200, 64, True, True), (3000, 32, 4200, True, True), (700, 100, 130, False, True)])
 def test_gpu_rank_matches_oracle(N, d, B, bias, hist):
     rng = np.random.default_rng(N + d)
     table = rng.normal(0, 0.1, (N, d)).astype(np.float32)

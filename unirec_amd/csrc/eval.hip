@@ -3,9 +3,12 @@
 // to numpy, computes user_emb @ item_emb.T on the CPU, masks each user's history in a Python loop and counts
 // scores above the target with numba get_rank (unirec/facility/evaluation/onepos.py:20-31).  Here:
 //   rank[b] = #{ n in [0,N) minus {target} : s_bn > s_bt }  -  #{ n in distinct(history_b U {0}) minus {target} : s_bn > s_bt }
-// The first term is ONE fp32-MFMA GEMM [B,d] x [d,N] whose epilogue compares and counts (gemm_nt EPI_COUNT_GT): the
-// [B,N] score matrix is never written.  The second term is a sparse gather-dot over each user's (sorted) history.
+// The first term is a streaming fp32-MFMA contraction [B,d] x [d,N] that compares and counts in registers
+// (rank_stream_kernel, d <= 128; wider d: gemm_nt with the EPI_COUNT_GT epilogue): the [B,N] score matrix is never
+// written.  The second term is a sparse gather-dot over each user's (sorted) history.
 // Scores are compared in the un-normalised space  u.E_n + item_bias[n]  (user bias cancels, tau > 0 is monotone).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -115,6 +118,203 @@ __global__ __launch_bounds__(256) void rank_adjust_kernel(const float4* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ streaming rank
+// Workgroup = 512 threads = 8 waves (2 x 4), tile = 128 users x 256 items, K = d <= 128 in 32-wide chunks.
+// The 128 x d user tile is loaded into LDS ONCE; the workgroup then streams its share of the item table through a
+// double-buffered 256 x 32 LDS stage (one barrier per stage, global loads of stage s+1 in flight during the MFMAs of
+// stage s).  The comparison "score > target score" happens on the MFMA accumulators in registers; per-row counts
+// stay in registers for the whole stream and leave as ONE integer atomic per (row, wave) at the end.
+// The target's own score is produced by the same MFMA sequence (a first "diagonal" tile whose item rows are the
+// gathered targets), so it is bit-identical to the value the stream computes for the target's column and the strict
+// ">" never counts the target itself.
+// Grid: workgroup id b -> XCD b % 8.  All user tiles of one item split get the same XCD and adjacent ids, so the item
+// rows they share are fetched from HBM into one L2 once.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct RankArgs {
+  const float* user_emb; const float* table; const float* item_bias; const float* user_bias;
+  const long long* target; const long long* user_id;
+  long long N; int B, d, splits; float tau;
+  float* thr; float* target_score; int* counts;
+};
+
+template <int KC>
+__global__ __launch_bounds__(512) void rank_stream_kernel(RankArgs a) {
+  constexpr int BM = 128, BN = 256, LSA = 32 * KC + 4, LSW = 36;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [BM][LSA]
+  float* Ws = As + BM * LSA;         // [2][BN][LSW]
+  float* thr_s = Ws + 2 * BN * LSW;  // [BM]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntm = (a.B + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int mt = q % ntm, split = (q / ntm) * 8 + xcd;
+  const int m0 = mt * BM;
+  const long long ntn = (a.N + BN - 1) / BN, tps = (ntn + a.splits - 1) / a.splits;
+  const long long t_begin = (long long)split * tps, t_end = min(ntn, t_begin + tps);
+  if (t_begin >= t_end && split != 0) return;   // split 0 always runs: it publishes thr / target_score
+
+  // ---- user tile -> LDS (zero fill beyond B and beyond d)
+  for (int idx = tid; idx < BM * 8 * KC; idx += 512) {
+    const int row = idx / (8 * KC), k = (idx % (8 * KC)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m0 + row < a.B && k < a.d) v = *(const float4*)(a.user_emb + (long long)(m0 + row) * a.d + k);
+    *(float4*)(As + row * LSA + k) = v;
+  }
+
+  const int c4 = tid & 7, lrow = tid >> 3;   // stage copy: 8 threads x 16 B per 128-B row segment, 64 rows per pass
+  const float* Wp[4];
+  float4 rw[4];
+  auto set_rows = [&](long long tile) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = lrow + 64 * p;
+      long long n;
+      if (tile < 0) n = a.target[min(m0 + (row & (BM - 1)), a.B - 1)];   // diagonal tile: the targets' rows
+      else n = min(tile * BN + row, a.N - 1);
+      Wp[p] = a.table + n * a.d + c4 * 4;
+    }
+  };
+  auto load_global = [&](int kc) {
+    const int k = kc * 32 + c4 * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rw[p] = k < a.d ? *(const float4*)(Wp[p] + kc * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *(float4*)(Ws + buf * BN * LSW + (lrow + 64 * p) * LSW + c4 * 4) = rw[p];
+  };
+
+  floatx16 acc[2][2];
+  int cnt[2][16];
+  float thr_r[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      cnt[i][r] = 0;
+      thr_r[i][r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j][r] = 0.f;
+    }
+
+  const int frow = lane & 31, fk = 4 * (lane >> 5), lcol = lane & 31, lrow4 = 4 * (lane >> 5);
+  long long tile = -1;
+  set_rows(tile);
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  int buf = 0;
+  for (;;) {
+    // per-column bias of this tile (consumed after the KC stages below)
+    float bias[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wc * 64 + j * 32 + lcol;
+      if (tile < 0) {
+        bias[j] = a.item_bias ? a.item_bias[a.target[min(m0 + (col & (BM - 1)), a.B - 1)]] : 0.f;
+      } else {
+        const long long n = tile * BN + col;
+        bias[j] = n < a.N ? (a.item_bias ? a.item_bias[n] : 0.f) : -INFINITY;   // columns beyond N never count
+      }
+    }
+    const long long next_tile = tile < 0 ? t_begin : tile + 1;
+    const bool has_next = next_tile < t_end;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      bool staged = true;
+      if (kc + 1 < KC) load_global(kc + 1);
+      else if (has_next) { set_rows(next_tile); load_global(0); }
+      else staged = false;
+      const float* Ab = As + (wr * 64 + frow) * LSA + kc * 32 + fk;
+      const float* Wb = Ws + buf * BN * LSW + (wc * 64 + frow) * LSW + fk;
+#pragma unroll
+      for (int kk = 0; kk < 32; kk += 8) {
+        float4 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *(const float4*)(Ab + i * 32 * LSA + kk);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = *(const float4*)(Wb + j * 32 * LSW + kk);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      if (staged) store_lds(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+    // ---- epilogue on the accumulators: acc[i][j][r] is row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
+    if (tile < 0) {
+      if (wc == wr) {   // waves holding the diagonal 64x64 blocks
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if ((r & 3) + 8 * (r >> 2) + lrow4 == lcol) thr_s[wr * 64 + i * 32 + lcol] = acc[i][i][r] + bias[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
+          thr_r[i][r] = m0 + row < a.B ? thr_s[row] : INFINITY;
+        }
+      if (split == 0 && tid < BM && m0 + tid < a.B) {
+        const int m = m0 + tid;
+        a.thr[m] = thr_s[tid];
+        a.target_score[m] = (thr_s[tid] + (a.user_bias ? a.user_bias[a.user_id[m]] : 0.f)) / a.tau;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cnt[i][r] += (acc[i][j][r] + bias[j] > thr_r[i][r]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (!has_next) break;
+    tile = next_tile;
+  }
+  // ---- counts: sum over the 32 lanes (columns) that share each row, one atomic per (row, wave)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int v = cnt[i][r];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
+      if (lcol == 0 && m < a.B && v > 0) atomicAdd(a.counts + m, v);
+    }
+}
+
+template <int KC>
+static int launch_rank_stream(const RankArgs& a, hipStream_t st) {
+  constexpr size_t lds = (size_t)(128 * (32 * KC + 4) + 2 * 256 * 36 + 128) * sizeof(float);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)rank_stream_kernel<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr;
+  const int ntm = cdiv(a.B, 128);
+  hipLaunchKernelGGL((rank_stream_kernel<KC>), dim3(ntm * a.splits), dim3(512), lds, st, a);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
 }  // namespace ur
 
 using namespace ur;
@@ -129,30 +329,53 @@ extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int6
   UR_REQUIRE(!hist_ptr || (hist_sorted && user_id), UR_ERR_ARG, "ur_full_rank: history needs user_id and hist_sorted");
   UR_REQUIRE(!user_bias || user_id, UR_ERR_ARG, "ur_full_rank: user_bias needs user_id");
   hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_MISC, st, 2.0 * B * (double)n_items * d);
   const int tpr = pick_tpr(d), groups = 256 / tpr, d4 = d / 4;
+  UR_HIP(hipMemsetAsync(rank, 0, sizeof(int32_t) * B, st));
+  int64_t n_tail = n_items;   // items [n_tail, n_items) are left to the adjust kernel
+  if (d <= 128) {
+    // streaming kernel: user blocks of <= 4096 rows (32 user tiles x 8 item splits = 256 workgroups = one per CU)
+    for (int b0 = 0; b0 < B; b0 += 4096) {
+      RankArgs a{};
+      a.B = std::min(4096, B - b0);
+      a.user_emb = user_emb + (size_t)b0 * d; a.table = item_table; a.item_bias = item_bias; a.user_bias = user_bias;
+      a.target = (const long long*)target + b0; a.user_id = user_id ? (const long long*)user_id + b0 : nullptr;
+      a.N = n_items; a.d = d; a.tau = tau;
+      a.thr = thr_ws + b0; a.target_score = target_score + b0; a.counts = rank + b0;
+      const int ntm = cdiv(a.B, 128);
+      a.splits = 8 * std::max(1, 32 / ntm);
+      int rc = d <= 32 ? launch_rank_stream<1>(a, st) : d <= 64 ? launch_rank_stream<2>(a, st)
+             : d <= 96 ? launch_rank_stream<3>(a, st) : launch_rank_stream<4>(a, st);
+      if (rc) return rc;
+    }
+  } else {
 #define GO(T) hipLaunchKernelGGL((target_score_kernel<T>), dim3(cdiv(B, groups)), dim3(256), 0, st, (const float4*)user_emb,          \
                                  (const float4*)item_table, (const long long*)target, (const long long*)user_id, user_bias, item_bias,  \
                                  tau, B, d4, thr_ws, target_score)
-  switch (tpr) {
-    case 4: GO(4); break;
-    case 8: GO(8); break;
-    case 16: GO(16); break;
-    default: GO(32); break;
-  }
+    switch (tpr) {
+      case 4: GO(4); break;
+      case 8: GO(8); break;
+      case 16: GO(16); break;
+      default: GO(32); break;
+    }
 #undef GO
-  UR_LAUNCH_CHECK();
-  UR_HIP(hipMemsetAsync(rank, 0, sizeof(int32_t) * B, st));
-  const int64_t n_main = (n_items / 128) * 128;
-  if (n_main > 0) {
-    GemmArgs g{};
-    g.A = user_emb; g.lda = d; g.W = item_table; g.ldw = d; g.C = (float*)rank; g.ldc = 0; g.M = B; g.N = (int)n_main; g.K = d;
-    g.bias = item_bias; g.aux = thr_ws; g.ldaux = 0; g.skip = (const long long*)target;
-    int rc = gemm_nt(g, PRO_NONE, EPI_COUNT_GT, st);
-    if (rc) return rc;
+    UR_LAUNCH_CHECK();
+    // generic GEMM with the count epilogue, in item chunks that keep the grid below HIP's 2^32-thread limit
+    n_tail = (n_items / 128) * 128;
+    const int64_t tiles_m8 = 8 * (int64_t)cdiv(cdiv(B, 128), 8);
+    const int64_t chunk = std::max<int64_t>(1, (1LL << 23) / tiles_m8) * 128;
+    for (int64_t n0 = 0; n0 < n_tail; n0 += chunk) {
+      GemmArgs g{};
+      g.A = user_emb; g.lda = d; g.W = item_table + (size_t)n0 * d; g.ldw = d; g.C = (float*)rank; g.ldc = 0; g.M = B;
+      g.N = (int)std::min<int64_t>(chunk, n_tail - n0); g.K = d;
+      g.bias = item_bias ? item_bias + n0 : nullptr; g.aux = thr_ws; g.ldaux = 0; g.skip = (const long long*)target; g.skip_base = n0;
+      int rc = gemm_nt(g, PRO_NONE, EPI_COUNT_GT, st);
+      if (rc) return rc;
+    }
   }
 #define GO(T) hipLaunchKernelGGL((rank_adjust_kernel<T>), dim3(B), dim3(256), 0, st, (const float4*)user_emb, (const float4*)item_table, \
                                  (const long long*)target, (const long long*)user_id, (const long long*)hist_ptr, hist_sorted,            \
-                                 (long long)n_users, item_bias, thr_ws, (long long)n_main, (long long)n_items, d4, rank)
+                                 (long long)n_users, item_bias, thr_ws, (long long)n_tail, (long long)n_items, d4, rank)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
           float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
           if (a.bias) bs = *(const float4*)(a.bias + n);
           const float th = a.aux[m];
-          const long long sk = (a.skip ? a.skip[m] : -1) - n;   // column of this float4 to leave out (0..3) or none
+          const long long sk = (a.skip ? a.skip[m] - a.skip_base : -1) - n;   // column of this float4 to leave out (0..3) or none
           float cnt = ((v.x + bs.x > th && sk != 0) ? 1.f : 0.f) + ((v.y + bs.y > th && sk != 1) ? 1.f : 0.f) +
                       ((v.z + bs.z > th && sk != 2) ? 1.f : 0.f) + ((v.w + bs.w > th && sk != 3) ? 1.f : 0.f);
           cnt = group_sum<RT>(cnt);
@@ -239,7 +239,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 template <int BM, int BN, int PRO, int EPI, int BK = 32>
 static int launch_nt(const GemmArgs& a, hipStream_t st) {
   constexpr int LS = BK + 4;
-  dim3 grid(8 * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN));
+  const long long nblk = 8LL * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN);
+  if (nblk * 256 >= (1LL << 32)) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: %lld workgroups exceed HIP's 2^32-thread grid limit", nblk);
+  dim3 grid((unsigned)nblk);
   size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
   const size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
   if (cs > lds) lds = cs;

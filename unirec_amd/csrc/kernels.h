@@ -38,7 +38,7 @@ struct GemmArgs {
   const float* aux; int ldaux;   // residual / addend / pre-activation
   const float* gamma; const float* beta; float eps;
   float* xhat; float* rstd;      // EPI_BIAS_RES_LN outputs
-  const long long* skip;         // EPI_COUNT_GT: per-row column left out of the count (nullable)
+  const long long* skip; long long skip_base;   // EPI_COUNT_GT: column skip[m] - skip_base of row m is left out (nullable)
   int debug;                     // tuning aid (UR_GEMM_DEBUG): 1 = skip epilogue, 2 = skip K-loop global loads
 };
 int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st);
