@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-bench", action="store_true")
+    ap.add_argument("--autograd", action="store_true", help="step through model(...) + loss.backward() instead of forward_backward()")
+    ap.add_argument("--no-prefetch", action="store_true", help="sort each batch's ids inside its own step (no side-stream lookahead)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--cpu-baseline-items", type=int, default=1_000_000)
     return ap.parse_args()
@@ -234,11 +236,18 @@ def main():
         model.train()
         info = {"parallelism": "single"}
 
-        def step_fn(batch):
+        def step_fn(batch, nxt=None):
             opt.zero_grad()
             opt.plan_batch(item_seq=batch["item_seq"], item_id=batch["item_id"])
-            loss, _, _, _ = model(item_id=batch["item_id"], label=batch["label"], item_seq=batch["item_seq"])
-            loss.backward()
+            if nxt is not None and not a.no_prefetch:
+                # input-pipeline lookahead: the NEXT batch's id sort runs on a side stream under this step's compute
+                # (every step still issues exactly one plan; the trainer does the same, facility/trainer.py fit())
+                opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
+            if a.autograd:
+                loss, _, _, _ = model(item_id=batch["item_id"], label=batch["label"], item_seq=batch["item_seq"])
+                loss.backward()
+            else:   # the trainer's default: the same launches in a straight line, no autograd graph (facility/trainer.py)
+                loss = model.forward_backward(item_id=batch["item_id"], label=batch["label"], item_seq=batch["item_seq"])
             opt.step()
             return loss
 
@@ -265,7 +274,7 @@ def main():
     _lib.lib.ur_prof_reset()
     _lib.lib.ur_prof_enable(0 if a.no_prof else 1)
     for i in range(a.warmup):
-        loss = step_fn(batches[i % len(batches)])
+        loss = step_fn(batches[i % len(batches)], batches[(i + 1) % len(batches)])
     barrier()
     _lib.lib.ur_prof_enable(0)
     warm = prof_read()
@@ -282,7 +291,7 @@ def main():
     for i in range(a.steps):
         if dom is not None:
             _lib.lib.ur_prof_enable(1 if i % 4 == 0 else 0)
-        loss = step_fn(batches[(a.warmup + i) % len(batches)])
+        loss = step_fn(batches[(a.warmup + i) % len(batches)], batches[(a.warmup + i + 1) % len(batches)])
     barrier()
     dt = time.perf_counter() - t0
     _lib.lib.ur_prof_enable(0)

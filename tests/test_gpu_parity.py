@@ -178,7 +178,9 @@ def test_rows_plan_and_reduce_vs_numpy():
     rng = np.random.default_rng(0)
     for (n_a, n_b, G, n_rows, d) in ((700, 330, 11, 97, 32), (5000, 4004, 1001, 60000, 64), (1, 0, 1, 10, 128),
                                      (3000, 1200, 3, 5, 64), (900, 0, 1, 3, 128),   # hot ids: runs >> 64 take the block-cooperative path
-                                     (0, 2048, 4, 3_000_000, 128)):
+                                     (0, 2048, 4, 3_000_000, 128),
+                                     (30000, 2768, 4, 100_000_000, 32),    # n = 32768: largest single-launch plan
+                                     (80000, 20000, 5, 100_000_000, 32)):   # n > 65536: multi-launch plan
         ids_a = rng.integers(0, n_rows, n_a).astype(np.int32)
         ids_b = rng.integers(0, n_rows, n_b).astype(np.int64)
         rows_a = rng.standard_normal((n_a, d)).astype(np.float32)
@@ -268,3 +270,40 @@ def test_rowwise_mode_only_touches_looked_up_rows():
     # first step of row-wise Adam == first step of dense Adam on the touched rows
     ref = torch.from_numpy(g["sd1"]["item_embedding.weight"])
     np.testing.assert_allclose(after[changed].cpu().numpy(), ref[changed.cpu()].numpy(), rtol=2e-4, atol=5e-7)
+
+
+# ------------------------------------------------------------------------------------------ fused step == autograd step
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_forward_backward_equals_autograd_path(name):
+    """model.forward_backward (the trainer's default) issues the same launches as model(...) + loss.backward():
+    loss, dense gradient, bias gradients and the row-sparse gradient pieces must be bit-identical."""
+    cfg, g = load_golden(name)
+    dev = _dev()
+    batch = {k: v.to(dev) for k, v in _t(g["in"]).items()}
+    kw = dict(user_id=batch["user_id"], item_id=batch["item_id"], label=batch["label"], item_seq=batch["item_seq"],
+              item_seq_len=batch["item_seq_len"])
+    out = []
+    for fused in (False, True):
+        m = _build(cfg, g["sd"])
+        m.train()
+        if fused:
+            loss = m.forward_backward(**kw)
+        else:
+            loss, _, _, _ = m(**kw)
+            loss.backward()
+        pieces = []
+        for sg in m.sparse_grads:
+            pieces.append({k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in sg.items()})
+        out.append((loss.detach().clone(), None if m.dense_flat.grad is None else m.dense_flat.grad.clone(),
+                    [None if p.grad is None else p.grad.clone() for n, p in m.named_parameters() if n in ("user_bias", "item_bias")],
+                    pieces))
+    (l0, d0, b0, s0), (l1, d1, b1, s1) = out
+    assert torch.equal(l0, l1)
+    assert (d0 is None) == (d1 is None) and (d0 is None or torch.equal(d0, d1))
+    assert len(b0) == len(b1) and all(torch.equal(x, y) for x, y in zip(b0, b1))
+    assert len(s0) == len(s1)
+    for x, y in zip(s0, s1):
+        assert x.keys() == y.keys() and x["table"] == y["table"]
+        for k in x:
+            if torch.is_tensor(x[k]):
+                assert torch.equal(x[k].reshape(-1), y[k].reshape(-1)), k

@@ -8,6 +8,8 @@
 // The sort works at wavefront granularity: every wave owns a contiguous chunk of CH keys and walks it
 // 64 keys at a time, so stability follows from program order; ranks inside a 64-key group come from
 // __ballot match masks (no LDS atomics in the scatter), digit bases from a tiny single-block scan.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -158,6 +160,155 @@ __global__ __launch_bounds__(256) void heads_write_kernel(const unsigned* __rest
     run += __popcll(m);
   }
   if (wave == 0 && lane == 0) seg_start[*n_uniq] = (int)n;
+}
+
+
+// ---- the whole plan in ONE launch for small batches (n <= SMALL_N): one workgroup of 16 waves runs the same
+// wave-granular stable LSD sort with its histograms in LDS and the key / value ping-pong in (L2-resident) global
+// scratch.  16 launches (~120 us of launch floors at n = 28 K) become one (~25 us).
+constexpr int SMALL_IT = 32;                  // 64-key groups per wave
+constexpr int SMALL_N = 16 * SMALL_IT * 64;   // = 32768
+constexpr int SW = 16;   // waves in the single workgroup
+
+// exclusive prefix of v over the 1024 threads of the block (scratch: 16 ints of LDS); returns the prefix, total in *tot
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* scratch, int* tot) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  if (lane == 63) scratch[w] = inc;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < SW; ++i) {
+    const int x = scratch[i];
+    base += i < w ? x : 0;
+    total += x;
+  }
+  __syncthreads();
+  if (tot) *tot = total;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void plan_small_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
+                                                          long long n_b, int W, long long n_local, int passes, unsigned* keys0,
+                                                          unsigned* keys1, int* vals0, int* vals1, int* __restrict__ uniq_idx,
+                                                          int* __restrict__ seg_start, int* __restrict__ n_uniq_dev,
+                                                          int* __restrict__ owner_counts) {
+  __shared__ int cnt[SW][RADIX];
+  __shared__ int scratch[SW];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int n = (int)(n_a + n_b);
+  const int cw = (((n + SW - 1) / SW + 63) / 64) * 64;   // keys per wave (multiple of 64)
+  const int base = w * cw, iters = cw / 64;
+  for (int i = tid; i < n; i += 1024) {
+    const long long id = (i < n_a) ? (long long)ids_a[i] : ids_b[i - n_a];
+    keys0[i] = (W > 1) ? (id ? (unsigned)((id % W) * n_local + id / W + 1) : 0u) : (unsigned)id;
+    vals0[i] = i;
+  }
+  if (owner_counts) for (int i = tid; i < W; i += 1024) owner_counts[i] = 0;
+  __syncthreads();
+  unsigned* kin = keys0; unsigned* kout = keys1;
+  int* vin = vals0; int* vout = vals1;
+  const unsigned long long lt = lanemask_lt();
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    // the wave's whole chunk goes to registers first: SMALL_IT independent loads in flight instead of one
+    // L2 round trip per 64 keys (a single workgroup has no other waves to hide that latency behind)
+    unsigned rk[SMALL_IT];
+    int rv[SMALL_IT];
+#pragma unroll
+    for (int it = 0; it < SMALL_IT; ++it) {
+      const int i = base + it * 64 + lane;
+      const bool active = it < iters && i < n;
+      rk[it] = active ? kin[i] : 0u;
+      rv[it] = active ? vin[i] : 0;
+    }
+    for (int i = lane; i < RADIX; i += 64) cnt[w][i] = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < SMALL_IT; ++it) {
+      const int i = base + it * 64 + lane;
+      if (it < iters && i < n) atomicAdd(&cnt[w][(rk[it] >> shift) & 0xFF], 1);
+    }
+    __syncthreads();
+    {   // exclusive scan in (digit, wave) order: thread t owns entries 4t .. 4t+3 of the [RADIX][SW] ordering
+      int v[4], s = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = tid * 4 + k;
+        v[k] = cnt[e % SW][e / SW];
+        s += v[k];
+      }
+      int run = block_excl_scan_1024(s, scratch, nullptr);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = tid * 4 + k;
+        cnt[e % SW][e / SW] = run;
+        run += v[k];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SMALL_IT; ++it) {
+      if (it < iters) {   // wave-uniform
+        const int i = base + it * 64 + lane;
+        const bool active = i < n;
+        const unsigned key = rk[it];
+        const unsigned dgt = (key >> shift) & 0xFF;
+        const unsigned long long m = match_digit(dgt, active);
+        const int rank = __popcll(m & lt);
+        int pos = 0;
+        if (active) pos = cnt[w][dgt] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (active && rank == 0) cnt[w][dgt] += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (active) {
+          kout[pos] = key;
+          vout[pos] = rv[it];
+        }
+      }
+    }
+    __syncthreads();   // workgroup-scope release/acquire: the 16 waves share one CU and its vector L1
+    unsigned* tk = kin; kin = kout; kout = tk;
+    int* tv = vin; vin = vout; vout = tv;
+  }
+  // ---- segment heads (keys and their left neighbours preloaded, same reason as above)
+  unsigned hk[SMALL_IT];
+  unsigned hbits = 0;   // bit `it`: this lane's key of group `it` starts a run
+  int c = 0;
+#pragma unroll
+  for (int it = 0; it < SMALL_IT; ++it) {
+    const int i = base + it * 64 + lane;
+    const bool active = it < iters && i < n;
+    hk[it] = active ? kin[i] : 0u;
+    const unsigned prev = (active && i > 0) ? kin[i - 1] : 0u;
+    const bool head = active && (i == 0 || hk[it] != prev);
+    hbits |= head ? (1u << it) : 0u;
+    c += __popcll(__ballot(head));
+  }
+  int total = 0;
+  const int mine = block_excl_scan_1024(lane == 0 ? c : 0, scratch, &total);
+  int run = __shfl(mine, 0, 64);   // lane 0 holds the wave's exclusive prefix
+#pragma unroll
+  for (int it = 0; it < SMALL_IT; ++it) {
+    const bool head = (hbits >> it) & 1u;
+    const unsigned long long m = __ballot(head);
+    if (head) {
+      const int seg = run + __popcll(m & lt);
+      uniq_idx[seg] = (int)hk[it];
+      seg_start[seg] = base + it * 64 + lane;
+      if (owner_counts) atomicAdd(&owner_counts[hk[it] / n_local], 1);
+    }
+    run += __popcll(m);
+  }
+  if (tid == 0) {
+    *n_uniq_dev = total;
+    seg_start[total] = n;
+  }
 }
 
 // ------------------------------------------------------------------------------- segment reduce
@@ -450,12 +601,19 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
   const long long n_local = (W > 1) ? (n_rows + W - 1) / W + 1 : n_rows;   // rows per shard incl. its padding row 0
   UR_REQUIRE(n_local * W <= (1LL << 31), UR_ERR_ARG, "ur_rows_plan: sharded key space too large");
   const int passes = (bits_for(W > 1 ? n_local * W : n_rows) + 7) / 8;
-  if (owner_counts_dev) UR_HIP(hipMemsetAsync(owner_counts_dev, 0, sizeof(int) * W, st));
   // ping-pong so that the LAST pass writes vals into sorted_pos
   unsigned* kbuf[2] = {w.keys0, w.keys1};
   int* vbuf[2];
   vbuf[passes & 1] = sorted_pos;       // after `passes` swaps the result sits in index (passes & 1)
   vbuf[(passes & 1) ^ 1] = w.vals_tmp;
+  static const bool no_small = getenv("UR_PLAN_MULTI") != nullptr;   // test hook: force the multi-launch path
+  if (n <= SMALL_N && !no_small) {
+    hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(1024), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b, W,
+                       n_local, passes, kbuf[0], kbuf[1], vbuf[0], vbuf[1], uniq_idx, seg_start, n_uniq_dev, owner_counts_dev);
+    UR_LAUNCH_CHECK();
+    return UR_OK;
+  }
+  if (owner_counts_dev) UR_HIP(hipMemsetAsync(owner_counts_dev, 0, sizeof(int) * W, st));
   hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids_a, (long long)n_a, (const long long*)ids_b,
                      (long long)n_b, kbuf[0], vbuf[0], W, n_local);
   UR_LAUNCH_CHECK();

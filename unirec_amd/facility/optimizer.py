@@ -37,6 +37,7 @@ class SparseDenseAdam:
                 st["last"] = torch.zeros(w.shape[0], dtype=torch.int32, device=dev) if table_mode == "lazy_dense" else None
                 self.tables[name] = st
         self._plans = {}
+        self._prefetched, self._side = None, None
         self._scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [0] sumsq, [1] clip coef
         self._sumsq_ws = torch.empty(2048, dtype=torch.float32, device=dev)
         self.param_groups = [dict(lr=lr)]  # enough of torch's surface for schedulers / logging
@@ -56,16 +57,46 @@ class SparseDenseAdam:
         return ops.adam_cfg(self.param_groups[0]["lr"], step, self.wd, self.betas[0], self.betas[1], self.eps)
 
     # ------------------------------------------------------------------ per-batch plan (before forward)
-    def plan_batch(self, item_seq=None, item_id=None, user_id=None):
-        """Sort/unique the ids this batch will look up; in lazy_dense mode bring those rows up to date."""
-        self._plans = {}
+    def _make_plans(self, item_seq, item_id, user_id):
+        plans = {}
         ids_a = item_seq.reshape(-1).to(torch.int32).contiguous() if item_seq is not None else None
         ids_b = item_id.reshape(-1).contiguous() if item_id is not None else None
         if "item_embedding" in self.tables and (ids_a is not None or ids_b is not None):
-            self._plans["item_embedding"] = ops.rows_plan(ids_a, ids_b, self.tables["item_embedding"]["w"].shape[0])
+            plans["item_embedding"] = ops.rows_plan(ids_a, ids_b, self.tables["item_embedding"]["w"].shape[0])
         if "user_embedding" in self.tables and user_id is not None:
-            self._plans["user_embedding"] = ops.rows_plan(user_id.reshape(-1).to(torch.int32).contiguous(), None,
-                                                          self.tables["user_embedding"]["w"].shape[0])
+            plans["user_embedding"] = ops.rows_plan(user_id.reshape(-1).to(torch.int32).contiguous(), None,
+                                                    self.tables["user_embedding"]["w"].shape[0])
+        return plans
+
+    @staticmethod
+    def _ids_key(item_seq, item_id, user_id):
+        return tuple((t.data_ptr(), t.numel()) if t is not None else None for t in (item_seq, item_id, user_id))
+
+    def prefetch_plan(self, item_seq=None, item_id=None, user_id=None):
+        """Sort/unique the ids of the NEXT batch on a side stream, so that the (latency-bound, ~0.15 ms) plan overlaps
+        with the current step's forward/backward.  The plan depends on the ids only, never on the model state."""
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.model.device)
+        self._side.wait_stream(main)   # the ids may still be in flight (H2D copy) on the main stream
+        with torch.cuda.stream(self._side):
+            plans = self._make_plans(item_seq, item_id, user_id)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        for pl in plans.values():      # allocated on the side stream, consumed (and freed) under the main one
+            for t in (pl.uniq_idx, pl.seg_start, pl.sorted_pos, pl.n_uniq):
+                t.record_stream(main)
+        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev)
+
+    def plan_batch(self, item_seq=None, item_id=None, user_id=None):
+        """Sort/unique the ids this batch will look up (or adopt the plan `prefetch_plan` made for the same tensors);
+        in lazy_dense mode bring those rows up to date."""
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] == self._ids_key(item_seq, item_id, user_id):
+            torch.cuda.current_stream().wait_event(pre[2])
+            self._plans = pre[1]
+        else:
+            self._plans = self._make_plans(item_seq, item_id, user_id)
         if self.table_mode == "lazy_dense" and self.t > 0:
             cfg = self._cfg(self.t + 1)
             for name, pl in self._plans.items():

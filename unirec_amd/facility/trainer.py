@@ -66,15 +66,25 @@ class Trainer(object):
         self.eval_protocol = eval_protocol
 
     # ------------------------------------------------------------------ the step (trainer.py:327-357)
-    def train_step(self, batch):
+    def _plan_ids(self, batch):
+        return dict(item_seq=batch.get("item_seq"), item_id=batch["item_id"],
+                    user_id=batch.get("user_id") if hasattr(self.model, "user_embedding") else None)
+
+    def train_step(self, batch, next_batch=None):
+        """One optimisation step.  `next_batch` (optional) lets the id sort of the following batch run on a side
+        stream underneath this step's forward/backward."""
         opt, model = self.optimizer, self.model
         model.train()
         opt.zero_grad()
-        opt.plan_batch(item_seq=batch.get("item_seq"), item_id=batch["item_id"],
-                       user_id=batch.get("user_id") if hasattr(model, "user_embedding") else None)
+        opt.plan_batch(**self._plan_ids(batch))
+        if next_batch is not None:
+            opt.prefetch_plan(**self._plan_ids(next_batch))
         kw = {k: batch[k] for k in ("user_id", "item_id", "label", "item_seq", "item_seq_len") if k in batch}
-        loss, _, _, _ = model(**kw)
-        loss.backward()
+        if self.config.get("fused_step", True):
+            loss = model.forward_backward(**kw)       # same launches as forward + backward, no autograd graph
+        else:
+            loss, _, _, _ = model(**kw)
+            loss.backward()
         opt.step()
         return loss.detach()
 
@@ -98,7 +108,12 @@ class Trainer(object):
                 if self.early_stop and self.cur_step >= self.early_stop:
                     break
             t0 = time.time()
-            losses = [self.train_step(b) for b in train_data]
+            losses, it = [], iter(train_data)
+            cur = next(it, None)
+            while cur is not None:          # one batch of lookahead: the next batch's plan overlaps this step
+                nxt = next(it, None)
+                losses.append(self.train_step(cur, nxt))
+                cur = nxt
             stacked = torch.stack(losses)
             nan = torch.isnan(stacked)
             if bool(nan.any()):

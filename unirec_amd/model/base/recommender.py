@@ -135,6 +135,55 @@ class BaseRecommender(AbstractRecommender):
             scores = scores.squeeze(1)
         return None, scores, user_emb, self.forward_item_emb(item_id)
 
+    # ---- fused training step (no autograd graph) ------------------------------------------------
+    def _encode_train(self, user_id, item_seq):
+        """-> (user_emb, state for _encode_backward).  MF: the user table lookup."""
+        return self.user_embedding(user_id), user_id
+
+    def _encode_backward(self, state, d_user):
+        self.sparse_grads.append(dict(table="user_embedding", ids_a=state.to(torch.int32).contiguous(),
+                                      rows=d_user.view(-1, d_user.shape[-1])))
+
+    def forward_backward(self, user_id=None, item_id=None, label=None, item_seq=None, item_seq_len=None, **_unused):
+        """``loss = model(...); loss.backward()`` (unirec/facility/trainer.py:340-346) as one straight-line sequence of
+        the same HIP launches, without building/walking an autograd graph: leaves ``dense_flat.grad``, the bias
+        gradients and ``sparse_grads`` exactly as ``backward()`` would, and returns the (detached) loss.
+        The autograd engine hands backward to its device thread, which leaves the GPU idle for ~0.1 ms per step at
+        this step size; the trainer therefore uses this entry point (config ``fused_step``, default on)."""
+        if not self.training:
+            raise RuntimeError("forward_backward is a training-mode entry point")
+        if self.loss_type == "fullsoftmax":
+            raise NotImplementedError("fullsoftmax scores all N items per row: listed as a next row (DESIGN.md section 7)")
+        if self.group_size > 0:
+            raise NotImplementedError("group_size > 0 (user-item-label rows) is not on the accelerated path")
+        if item_id.dim() == 1:
+            item_id = item_id.unsqueeze(1)
+            label = label.unsqueeze(1) if label is not None and label.dim() == 1 else label
+        item_id = item_id.contiguous()
+        lab = label.to(torch.int32).contiguous() if label is not None else None
+        user_emb, state = self._encode_train(user_id, item_seq)
+        user_emb = user_emb.contiguous()
+        B, G = item_id.shape
+        cfg = ops.loss_cfg(B, G, self.embedding_size, self.loss_type, self.tau, self.SCORE_CLIP,
+                           self.config.get("ccl_w", 0.0), self.config.get("ccl_m", 0.0))
+        ub = self.user_bias.data if self.has_user_bias else None
+        ib = self.item_bias.data if self.has_item_bias else None
+        table = self.item_embedding.weight.data
+        scores, _, loss_out = ops.gather_dot_loss_fwd(cfg, user_emb, table, item_id, lab, ub, ib, user_id if ub is not None else None)
+        coef, d_user, d_ub = ops.gather_dot_loss_bwd(cfg, user_emb, table, item_id, lab, scores, loss_out, None,
+                                                     want_user_bias=self.has_user_bias)
+        self.sparse_grads.append(dict(table="item_embedding", ids_b=item_id, coef=coef, vec=user_emb, G=G))
+        if self.has_item_bias:
+            g = torch.zeros_like(self.item_bias)
+            g.index_add_(0, item_id.reshape(-1), coef.reshape(-1))
+            self.item_bias.grad = g
+        if self.has_user_bias:
+            g = torch.zeros_like(self.user_bias)
+            g.index_add_(0, user_id, d_ub)
+            self.user_bias.grad = g
+        self._encode_backward(state, d_user)
+        return loss_out[0]
+
     def _predict_layer(self, user_emb, items_emb, user_id, item_id):
         """scores only (no loss), through the same fused gather-dot kernel; items_emb is ignored."""
         if item_id.dim() == 1:

@@ -98,6 +98,20 @@ class SASRec(BaseRecommender):
         self.trm_encoder = nn.Module()
         self.trm_encoder.layer = nn.ModuleList(layers)
 
+    def _encode_train(self, user_id, item_seq):
+        item_seq = item_seq.to(torch.int32).contiguous()
+        if item_seq.shape[1] != self.max_seq_len:
+            raise ValueError(f"item_seq has length {item_seq.shape[1]}, expected max_seq_len={self.max_seq_len}")
+        cfg = self._cfg(item_seq.shape[0])
+        ws = self._workspace(cfg)
+        return ops.sasrec_fwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, ws), (cfg, ws, item_seq)
+
+    def _encode_backward(self, state, d_user):
+        cfg, ws, item_seq = state
+        dense_grad, d_rows = ops.sasrec_bwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, d_user, ws)
+        self.dense_flat.grad = dense_grad
+        self.sparse_grads.append(dict(table="item_embedding", ids_a=item_seq.reshape(-1), rows=d_rows))
+
     def forward_user_emb(self, user_id=None, item_seq=None, item_seq_len=None, item_seq_features=None, time_seq=None):
         item_seq = item_seq.to(torch.int32).contiguous()
         if item_seq.shape[1] != self.max_seq_len:

@@ -98,7 +98,7 @@ class ShardedSasrecStep:
         self.tau = model_cfg.get("tau", 1.0)
 
     # ---- the step ------------------------------------------------------------------------------------------
-    def step(self, batch):
+    def step(self, batch, next_batch=None):
         m, W, d = self.model, self.world, self.d
         item_seq, item_id, label = batch["item_seq"], batch["item_id"], batch.get("label")
         B, L = item_seq.shape
