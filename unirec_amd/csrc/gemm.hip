@@ -457,8 +457,53 @@ long long gemm_tn_ws_floats(int T, int R, int Cc) {
   return (long long)s * R * Cc + (long long)s * R + 64;
 }
 
+// ---- all queued split reductions in one launch.  Block = 16 float4 columns x 16 slices: slice k sums the partials
+// s = k, k+16, ...; the 16 slice sums are combined through LDS in slice order (fixed order: bit-reproducible).
+__global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceBatch rb) {
+  __shared__ float4 red[16][16];
+  int j = 0;
+  while (j + 1 < rb.n && (int)blockIdx.x >= rb.item[j + 1].first_block) ++j;
+  const ReduceItem it = rb.item[j];
+  const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long long i = ((long long)(blockIdx.x - it.first_block) * 16 + c) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < it.n) {
+    const float* p = it.part + i;
+#pragma unroll 4
+    for (int s = sl; s < it.S; s += 16) {
+      const float4 v = *(const float4*)(p + (long long)s * it.stride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[sl][c] = acc;
+  __syncthreads();
+  if (sl == 0 && i < it.n) {
+    float4 t = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = red[k][c];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *(float4*)(it.out + (i / it.cols) * it.ldo + (i % it.cols)) = t;
+  }
+}
+
+int reduce_batch(ReduceBatch& rb, hipStream_t st) {
+  if (rb.n <= 0) return UR_OK;
+  ProfScope ps(PC_GEMM_TN, st, 0.0);
+  int blocks = 0;
+  for (int i = 0; i < rb.n; ++i) {
+    rb.item[i].first_block = blocks;
+    blocks += cdiv(rb.item[i].n / 4, 16);
+  }
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, rb);
+  UR_LAUNCH_CHECK();
+  rb.n = 0;
+  return UR_OK;
+}
+
 int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act, float* out,
-            int ldo, float* bias_out, float* ws, hipStream_t st) {
+            int ldo, float* bias_out, float* ws, hipStream_t st, ReduceBatch* defer) {
   if ((R & 3) || (Cc & 3) || (ldp & 3) || (ldq & 3) || (ldo & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
   if (T <= 0) return fail(UR_ERR_ARG, "gemm_tn: T=%d", T);
   ProfScope ps(PC_GEMM_TN, st, 2.0 * T * R * Cc);
@@ -481,6 +526,15 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
     hipLaunchKernelGGL((gemm_tn_kernel<PRO_NONE>), grid, dim3(256), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part);
   UR_LAUNCH_CHECK();
   const long long n = (long long)R * Cc;
+  if (defer) {
+    if (defer->full(2)) {
+      int rc = reduce_batch(*defer, st);
+      if (rc) return rc;
+    }
+    defer->add(part, n, S, n, Cc, out, ldo);
+    if (bias_out) defer->add(bias_part, R, S, R, R, bias_out, R);
+    return UR_OK;
+  }
   hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n / 4 + (bias_out ? R / 4 : 0), 256)), dim3(256), 0, st, part, S, n, Cc, out, ldo,
                      bias_part, R, bias_out);
   UR_LAUNCH_CHECK();
@@ -503,6 +557,35 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st) {
   ProfScope ps(PC_MISC, st, 8.0 * rows * cols);
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, st, src, rows, cols, dst);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+// several transposes in ONE launch (all weight matrices of the encoder before its backward pass: 8 launches -> 1)
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb) {
+  __shared__ float tile[32][33];
+  int j = 0;
+  while (j + 1 < tb.n && (int)blockIdx.x >= tb.item[j + 1].first_block) ++j;
+  const TransposeItem it = tb.item[j];
+  const int t = blockIdx.x - it.first_block, tcols = (it.cols + 31) / 32;
+  const int bx = (t % tcols) * 32, by = (t / tcols) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8)
+    if (by + r < it.rows && bx + tx < it.cols) tile[r][tx] = it.src[(long long)(by + r) * it.cols + bx + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (bx + r < it.cols && by + tx < it.rows) it.dst[(long long)(bx + r) * it.rows + by + tx] = tile[tx][r];
+}
+
+int transpose_batch(TransposeBatch& tb, hipStream_t st) {
+  if (tb.n <= 0) return UR_OK;
+  ProfScope ps(PC_MISC, st, 0.0);
+  int blocks = 0;
+  for (int i = 0; i < tb.n; ++i) {
+    tb.item[i].first_block = blocks;
+    blocks += cdiv(tb.item[i].cols, 32) * cdiv(tb.item[i].rows, 32);
+  }
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(blocks), dim3(256), 0, st, tb);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

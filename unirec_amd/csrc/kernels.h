@@ -13,8 +13,29 @@ int embed_ln_fwd(const int* seq, const float* table, const float* pos, const flo
 int ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, int M, int d, float* y,
            float* xhat, float* rstd, hipStream_t st);
 // part_ws: LN_BWD_MAX_BLOCKS * 2 * d floats
+// Deferred split reductions.  The weight / bias / LayerNorm-affine gradients are only consumed by the optimizer, so
+// the second stage of every split reduction of a backward pass (out[i] = sum_s part[s*stride + i], fixed order) is
+// queued here and executed by ONE launch at the end (reduce_batch) instead of one small launch per GEMM / LayerNorm.
+struct ReduceItem {
+  const float* part; float* out;
+  long long stride, n;      // n elements (multiple of 4); partial s starts at part + s*stride
+  int S, cols, ldo;         // element i goes to out[(i / cols) * ldo + i % cols]
+  int first_block;
+};
+struct ReduceBatch {
+  static constexpr int MAX = 48;
+  ReduceItem item[MAX]; int n = 0;
+  bool full(int need) const { return n + need > MAX; }
+  void add(const float* part, long long stride, int S, long long n_el, int cols, float* out, int ldo) {
+    item[n++] = ReduceItem{part, out, stride, n_el, S, cols, ldo, 0};
+  }
+};
+int reduce_batch(ReduceBatch& rb, hipStream_t st);   // runs and empties the queue
+
+// defer != nullptr: part_ws must stay untouched until reduce_batch(*defer) has run
 int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* add_in,
-           const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st);
+           const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st,
+           ReduceBatch* defer = nullptr);
 int pos_grad(const float* dx, int B, int L, int d, float* dpos, hipStream_t st);
 
 // ---- gemm.hip
@@ -47,9 +68,20 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st);
 // ws: gemm_tn_ws_floats(R, Cc) floats.
 long long gemm_tn_ws_floats(int T, int R, int Cc);
 int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act,
-            float* out, int ldo, float* bias_out, float* ws, hipStream_t st);
+            float* out, int ldo, float* bias_out, float* ws, hipStream_t st, ReduceBatch* defer = nullptr);
 // dst[c,r] = src[r,c]
 int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
+struct TransposeItem { const float* src; float* dst; int rows, cols, first_block; };
+struct TransposeBatch {
+  static constexpr int MAX = 32;
+  TransposeItem item[MAX]; int n = 0;
+  bool add(const float* src, int rows, int cols, float* dst) {
+    if (n >= MAX) return false;
+    item[n++] = TransposeItem{src, dst, rows, cols, 0};
+    return true;
+  }
+};
+int transpose_batch(TransposeBatch& tb, hipStream_t st);   // every queued transpose in one launch
 
 // ---- attention.hip
 long long attn_lse_floats(int B, int H, int L);

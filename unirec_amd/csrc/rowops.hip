@@ -312,7 +312,8 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
 }
 
 int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* add_in,
-           const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st) {
+           const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st,
+           ReduceBatch* defer) {
   ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * 3);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(M, groups * 4);
@@ -328,6 +329,15 @@ int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* g
   }
 #undef GO
   UR_LAUNCH_CHECK();
+  if (defer) {   // part_ws[blk][2d] = per-block (dgamma | dbeta) partial sums
+    if (defer->full(2)) {
+      int rc = reduce_batch(*defer, st);
+      if (rc) return rc;
+    }
+    defer->add(part_ws, 2 * d, blocks, d, d, dgamma, d);
+    defer->add(part_ws + d, 2 * d, blocks, d, d, dbeta, d);
+    return UR_OK;
+  }
   hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(2 * d, 64)), dim3(1024), 0, st, part_ws, blocks, 2 * d, dgamma, dbeta, d);
   UR_LAUNCH_CHECK();
   return UR_OK;

@@ -61,7 +61,7 @@ struct Ws {
   LayerWs layer[UR_MAX_LAYERS];
   float *g_y, *g_t, *g_a, *g_h1, *g_qkv, *g_ctx, *tn_ws, *ln_part, *attn_ws;
   float *x_last, *q_last, *dq_last, *t_last, *lse_last;   // last-row specialisation of the final layer ([B,d] each)
-  long long total_floats;
+  long long total_floats, tn_floats, ln_floats;
 };
 
 static Ws carve(const UrSasrecCfg& c, float* base) {
@@ -83,14 +83,15 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
   }
   w.g_y = take(M * d); w.g_t = take(M * d); w.g_a = take(M * d); w.g_h1 = take(M * I);
   w.g_qkv = take(M * 3 * d); w.g_ctx = take(M * d);
-  long long tn = 0;
+  // split-reduction partials: every weight-gradient GEMM / LayerNorm backward of one backward pass keeps its own region
+  // (they are all reduced by ONE launch at the end of ur_sasrec_bwd)
   const int T = (int)M;
-  tn = gemm_tn_ws_floats(T, c.d, c.inner);
-  if (gemm_tn_ws_floats(T, c.inner, c.d) > tn) tn = gemm_tn_ws_floats(T, c.inner, c.d);
-  if (gemm_tn_ws_floats(T, 3 * c.d, c.d) > tn) tn = gemm_tn_ws_floats(T, 3 * c.d, c.d);
-  if (gemm_tn_ws_floats(T, c.d, c.d) > tn) tn = gemm_tn_ws_floats(T, c.d, c.d);
-  w.tn_ws = take(tn);
-  w.ln_part = take((long long)LN_BWD_MAX_BLOCKS * 2 * d);
+  auto r64 = [](long long n) { return (n + 63) & ~63LL; };
+  w.tn_floats = c.n_layers * (r64(gemm_tn_ws_floats(T, c.d, c.inner)) + r64(gemm_tn_ws_floats(T, c.inner, c.d)) +
+                              r64(gemm_tn_ws_floats(T, 3 * c.d, c.d)) + 2 * r64(gemm_tn_ws_floats(T, c.d, c.d)));
+  w.tn_ws = take(w.tn_floats);
+  w.ln_floats = (2LL * c.n_layers + 1) * LN_BWD_MAX_BLOCKS * 2 * d;
+  w.ln_part = take(w.ln_floats);
   w.attn_ws = take(attn_bwd_ws_floats(c.B, c.n_heads, c.L));
   w.x_last = take((long long)c.B * d); w.q_last = take((long long)c.B * d); w.dq_last = take((long long)c.B * d);
   w.t_last = take((long long)c.B * d); w.lse_last = take((long long)c.B * c.n_heads);
@@ -251,9 +252,35 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   Ws w = carve(c, (float*)ws);
   const int M = c.B * c.L, d = c.d, I = c.inner;
   UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
+  ReduceBatch rb;                       // second stages of all split reductions: one launch at the end
+  float* tn_cur = w.tn_ws;
+  float* ln_cur = w.ln_part;
+  auto tn_take = [&](int T_, int R_, int C_) {
+    float* p = tn_cur;
+    tn_cur += (gemm_tn_ws_floats(T_, R_, C_) + 63) & ~63LL;
+    return p;
+  };
+  auto ln_take = [&]() {
+    float* p = ln_cur;
+    ln_cur += (long long)LN_BWD_MAX_BLOCKS * 2 * d;
+    return p;
+  };
   if (!c.last_only) {
     hipLaunchKernelGGL(put_last_kernel, dim3(cdiv((long long)M * d, 256)), dim3(256), 0, st, d_user_emb, c.B, c.L, d, w.g_y);
     UR_LAUNCH_CHECK();
+  }
+  {   // weight transposes for the activation-gradient GEMMs of every layer, one launch (up to 8 layers per launch)
+    TransposeBatch tb;
+    for (int i = 0; i < c.n_layers; ++i) {
+      const LayerP p = layer_ptrs(dense, lay, i);
+      LayerWs& lw = w.layer[i];
+      if (tb.n + 4 > TransposeBatch::MAX) {
+        if ((rc = transpose_batch(tb, st))) return rc;
+        tb.n = 0;
+      }
+      tb.add(p.wqkv, 3 * d, d, lw.wqkvT); tb.add(p.wo, d, d, lw.woT); tb.add(p.w1, I, d, lw.w1T); tb.add(p.w2, d, I, lw.w2T);
+    }
+    if ((rc = transpose_batch(tb, st))) return rc;
   }
   for (int i = c.n_layers - 1; i >= 0; --i) {
     const LayerP p = layer_ptrs(dense, lay, i);
@@ -261,32 +288,27 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     float* G = dense_grad;
     LayerWs& lw = w.layer[i];
     const float* x_in = (i == 0) ? w.x0 : w.layer[i - 1].y;
-    // weight transposes for the activation-gradient GEMMs
-    if ((rc = transpose(p.wqkv, 3 * d, d, lw.wqkvT, st))) return rc;
-    if ((rc = transpose(p.wo, d, d, lw.woT, st))) return rc;
-    if ((rc = transpose(p.w1, I, d, lw.w1T, st))) return rc;
-    if ((rc = transpose(p.w2, d, I, lw.w2T, st))) return rc;
     if (c.last_only && i == c.n_layers - 1) {
       // final layer: only row L-1 carries gradient (d_user_emb); K,V gradients still cover every position
       const int B = c.B;
       GemmArgs g{};
-      if ((rc = ln_bwd(d_user_emb, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, B, d, w.g_t, G + o[14], G + o[15], w.ln_part, st))) return rc;
-      if ((rc = gemm_tn(w.g_t, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13], w.tn_ws, st))) return rc;
+      if ((rc = ln_bwd(d_user_emb, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, B, d, w.g_t, G + o[14], G + o[15], ln_take(), st, &rb))) return rc;
+      if ((rc = gemm_tn(w.g_t, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13], tn_take(B, d, I), st, &rb))) return rc;
       g.A = w.g_t; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = w.g_h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.aux = lw.h1; g.ldaux = I; g.act = c.act;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
-      if ((rc = gemm_tn(w.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11], w.tn_ws, st))) return rc;
+      if ((rc = gemm_tn(w.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11], tn_take(B, I, d), st, &rb))) return rc;
       g = GemmArgs{};
       g.A = w.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = B; g.N = d; g.K = I; g.aux = w.g_t; g.ldaux = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
-      if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, B, d, w.g_t, G + o[8], G + o[9], w.ln_part, st))) return rc;
-      if ((rc = gemm_tn(w.g_t, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7], w.tn_ws, st))) return rc;
+      if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, B, d, w.g_t, G + o[8], G + o[9], ln_take(), st, &rb))) return rc;
+      if ((rc = gemm_tn(w.g_t, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7], tn_take(B, d, d), st, &rb))) return rc;
       g = GemmArgs{};
       g.A = w.g_t; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
       if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, w.g_qkv, st))) return rc;
       // dWq from the B last rows, dWk/dWv from all rows
-      if ((rc = gemm_tn(w.dq_last, d, w.x_last, d, B, d, d, 0, 0, G + o[0], d, G + o[3], w.tn_ws, st))) return rc;
-      if ((rc = gemm_tn(w.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4], w.tn_ws, st))) return rc;
+      if ((rc = gemm_tn(w.dq_last, d, w.x_last, d, B, d, d, 0, 0, G + o[0], d, G + o[3], tn_take(B, d, d), st, &rb))) return rc;
+      if ((rc = gemm_tn(w.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4], tn_take(M, 2 * d, d), st, &rb))) return rc;
       g = GemmArgs{};   // g_x = [dK dV] Wkv  for every row
       g.A = w.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 2 * d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
@@ -298,24 +320,24 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       continue;
     }
     // ---- feed-forward block
-    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, w.g_t, G + o[14], G + o[15], w.ln_part, st))) return rc;
-    if ((rc = gemm_tn(w.g_t, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13], w.tn_ws, st))) return rc;
+    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, w.g_t, G + o[14], G + o[15], ln_take(), st, &rb))) return rc;
+    if ((rc = gemm_tn(w.g_t, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13], tn_take(M, d, I), st, &rb))) return rc;
     GemmArgs g{};
     g.A = w.g_t; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = w.g_h1; g.ldc = I; g.M = M; g.N = I; g.K = d;
     g.aux = lw.h1; g.ldaux = I; g.act = c.act;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
-    if ((rc = gemm_tn(w.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11], w.tn_ws, st))) return rc;
+    if ((rc = gemm_tn(w.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11], tn_take(M, I, d), st, &rb))) return rc;
     g = GemmArgs{};
     g.A = w.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.N = d; g.K = I; g.aux = w.g_t; g.ldaux = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
     // ---- attention block
-    if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, w.g_t, G + o[8], G + o[9], w.ln_part, st))) return rc;
-    if ((rc = gemm_tn(w.g_t, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7], w.tn_ws, st))) return rc;
+    if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, w.g_t, G + o[8], G + o[9], ln_take(), st, &rb))) return rc;
+    if ((rc = gemm_tn(w.g_t, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7], tn_take(M, d, d), st, &rb))) return rc;
     g = GemmArgs{};
     g.A = w.g_t; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.N = d; g.K = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
     if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, w.g_qkv, w.attn_ws, 0, st))) return rc;
-    if ((rc = gemm_tn(w.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3], w.tn_ws, st))) return rc;
+    if ((rc = gemm_tn(w.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3], tn_take(M, 3 * d, d), st, &rb))) return rc;
     g = GemmArgs{};
     g.A = w.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
     g.aux = w.g_t; g.ldaux = d;
@@ -323,10 +345,11 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   }
   // ---- input block: LN0 backward -> row gradients of E[item_seq] and of the position table
   if ((rc = ln_bwd(w.g_y, w.x0hat, w.rstd0, dense + lay.off[1], nullptr, nullptr, M, d, d_emb_rows, dense_grad + lay.off[1],
-                   dense_grad + lay.off[2], w.ln_part, st)))
+                   dense_grad + lay.off[2], ln_take(), st, &rb)))
     return rc;
   hipLaunchKernelGGL(pos_grad_zero_kernel, dim3(c.L, cdiv(d, 64)), dim3(1024), 0, st, d_emb_rows, item_seq, c.B, c.L, d,
                      c.use_pos ? dense_grad + lay.off[0] : nullptr);
   UR_LAUNCH_CHECK();
-  return UR_OK;
+  UR_REQUIRE(tn_cur <= w.tn_ws + w.tn_floats && ln_cur <= w.ln_part + w.ln_floats, UR_ERR_ARG, "ur_sasrec_bwd: partial-sum workspace overrun");
+  return reduce_batch(rb, st);
 }
