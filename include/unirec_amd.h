@@ -83,7 +83,8 @@ int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_ite
 /* backward (autograd of the above; the reference has no hand-written backward):
  *   dense_grad  flat buffer, same layout as `dense`, OVERWRITTEN with d loss / d dense-params;
  *   d_emb_rows  [B*L, d]: gradient w.r.t. the gathered rows E[item_seq[b,l]] (row-sparse form of
- *               embedding_dense_backward; rows whose id is 0 are written as zeros: padding_idx=0). */
+ *               embedding_dense_backward; rows whose id is 0 hold the gradient w.r.t. the zero padding vector
+ *               and are discarded by ur_rows_reduce: padding_idx=0). */
 int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                   const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
                   float* d_emb_rows, void* stream);

@@ -168,6 +168,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         if (EPI == EPI_ADD) {
           const float4 h = *(const float4*)(a.aux + (long long)m * a.ldaux + n);
           v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+          if (a.aux2) {
+            const float4 h2 = *(const float4*)(a.aux2 + (long long)m * a.ldaux2 + n);
+            v.x += h2.x; v.y += h2.y; v.z += h2.z; v.w += h2.w;
+          }
         }
         if (EPI == EPI_COUNT_GT) {
           // full-item ranking: nothing is stored; count the columns of this tile whose score (acc + bias[n]) beats the
@@ -272,7 +276,7 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
   ProfScope ps(PC_GEMM_NT, st, 2.0 * a.M * a.N * a.K);
   static const int dbg_env = getenv("UR_GEMM_DEBUG") ? atoi(getenv("UR_GEMM_DEBUG")) : 0;
   const_cast<GemmArgs&>(a).debug = dbg_env;
-  if ((a.K & 3) || (a.N & 3) || (a.lda & 3) || (a.ldw & 3) || (epi != EPI_COUNT_GT && ((a.ldc & 3) || (a.aux && (a.ldaux & 3)))))
+  if ((a.K & 3) || (a.N & 3) || (a.lda & 3) || (a.ldw & 3) || (epi != EPI_COUNT_GT && ((a.ldc & 3) || (a.aux && (a.ldaux & 3)) || (a.aux2 && (a.ldaux2 & 3)))))
     return fail(UR_ERR_ARG, "gemm_nt: N, K and all leading dimensions must be multiples of 4 (N=%d K=%d)", a.N, a.K);
   if (epi == EPI_BIAS_RES_LN) {
     if (a.N > 256 || a.ldc != a.N) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm needs N<=256 (N=%d)", a.N);

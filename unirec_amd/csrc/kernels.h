@@ -57,6 +57,7 @@ struct GemmArgs {
   int act;              // for PRO_ACT / EPI_MUL_DACT
   const float* bias;    // [N]
   const float* aux; int ldaux;   // residual / addend / pre-activation
+  const float* aux2; int ldaux2; // EPI_ADD: optional second addend (nullable)
   const float* gamma; const float* beta; float eps;
   float* xhat; float* rstd;      // EPI_BIAS_RES_LN outputs
   const long long* skip; long long skip_base;   // EPI_COUNT_GT: column skip[m] - skip_base of row m is left out (nullable)

@@ -60,7 +60,7 @@ struct Ws {
   float *x0, *x0hat, *rstd0;
   LayerWs layer[UR_MAX_LAYERS];
   float *g_y, *g_t, *g_a, *g_h1, *g_qkv, *g_ctx, *tn_ws, *ln_part, *attn_ws;
-  float *x_last, *q_last, *dq_last, *t_last, *lse_last;   // last-row specialisation of the final layer ([B,d] each)
+  float *q_last, *dq_last, *lse_last;   // last-row specialisation of the final layer ([B,d] each)
   long long total_floats, tn_floats, ln_floats;
 };
 
@@ -93,8 +93,8 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
   w.ln_floats = (2LL * c.n_layers + 1) * LN_BWD_MAX_BLOCKS * 2 * d;
   w.ln_part = take(w.ln_floats);
   w.attn_ws = take(attn_bwd_ws_floats(c.B, c.n_heads, c.L));
-  w.x_last = take((long long)c.B * d); w.q_last = take((long long)c.B * d); w.dq_last = take((long long)c.B * d);
-  w.t_last = take((long long)c.B * d); w.lse_last = take((long long)c.B * c.n_heads);
+  w.q_last = take((long long)c.B * d); w.dq_last = take((long long)c.B * d);
+  w.lse_last = take((long long)c.B * c.n_heads);
   w.total_floats = o;
   return w;
 }
@@ -118,13 +118,6 @@ __global__ void take_last_kernel(const float* __restrict__ src, int B, int L, in
   const long long b = i / d, c = i % d;
   dst[i] = src[(b * L + (L - 1)) * d + c];
 }
-// dst[b, L-1, :] += src[b,:]
-__global__ void add_last_rows_kernel(const float* __restrict__ src, int B, int L, int d, float* __restrict__ dst) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)B * d) return;
-  const long long b = i / d, c = i % d;
-  dst[(b * L + (L - 1)) * d + c] += src[i];
-}
 // dst[b,l,:] = (l == L-1) ? src[b,:] : 0
 __global__ void put_last_kernel(const float* __restrict__ src, int B, int L, int d, float* __restrict__ dst) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,30 +125,6 @@ __global__ void put_last_kernel(const float* __restrict__ src, int B, int L, int
   const long long c = i % d, row = i / d, l = row % L, b = row / L;
   dst[i] = (l == L - 1) ? src[b * d + c] : 0.f;
 }
-// dpos[l,:] = sum_b dx[b,l,:]; afterwards rows of dx whose id is 0 are zeroed (padding_idx=0)
-// block = 64 columns x 16 batch slices (fixed-order LDS combine => deterministic); grid = (L, ceil(d/64))
-__global__ __launch_bounds__(1024) void pos_grad_zero_kernel(float* __restrict__ dx, const int* __restrict__ seq, int B, int L,
-                                                             int d, float* __restrict__ dpos) {
-  __shared__ float red[16][65];
-  const int l = blockIdx.x, cl = threadIdx.x & 63, c = blockIdx.y * 64 + cl, s = threadIdx.x >> 6;
-  float acc = 0.f;
-  if (c < d) {
-    for (int b = s; b < B; b += 16) {
-      const long long row = (long long)b * L + l;
-      acc += dx[row * d + c];
-      if (seq[row] == 0) dx[row * d + c] = 0.f;
-    }
-  }
-  red[s][cl] = acc;
-  __syncthreads();
-  if (s == 0 && c < d && dpos) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][cl];
-    dpos[(long long)l * d + c] = t;
-  }
-}
-
 }  // namespace ur
 
 using namespace ur;
@@ -197,18 +166,18 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     if (c.last_only && i == c.n_layers - 1) {
       // Final layer, exact last-row specialisation: K,V for every position, everything else for row L-1 only.
       const int B = c.B;
-      hipLaunchKernelGGL(take_last_kernel, dim3(cdiv((long long)B * d, 256)), dim3(256), 0, st, x, B, c.L, d, w.x_last);
-      UR_LAUNCH_CHECK();
+      const float* x_last = x + (long long)(c.L - 1) * d;   // rows (b, L-1): a strided view, leading dimension L*d
+      const int ld_last = c.L * d;
       g.A = x; g.lda = d; g.W = p.wqkv + (long long)d * d; g.ldw = d; g.C = lw.qkv + d; g.ldc = 3 * d; g.M = M; g.N = 2 * d; g.K = d;
       g.bias = p.bqkv + d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
       g = GemmArgs{};
-      g.A = w.x_last; g.lda = d; g.W = p.wqkv; g.ldw = d; g.C = w.q_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bqkv;
+      g.A = x_last; g.lda = ld_last; g.W = p.wqkv; g.ldw = d; g.C = w.q_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bqkv;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
       if ((rc = attn_last_fwd(w.q_last, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st))) return rc;
       g = GemmArgs{};
       g.A = lw.ctx; g.lda = d; g.W = p.wo; g.ldw = d; g.C = lw.a; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bo;
-      g.aux = w.x_last; g.ldaux = d; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1;
+      g.aux = x_last; g.ldaux = ld_last; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS_RES_LN, st))) return rc;
       g = GemmArgs{};
       g.A = lw.a; g.lda = d; g.W = p.w1; g.ldw = d; g.C = lw.h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.bias = p.b1;
@@ -307,16 +276,16 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
       if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, w.g_qkv, st))) return rc;
       // dWq from the B last rows, dWk/dWv from all rows
-      if ((rc = gemm_tn(w.dq_last, d, w.x_last, d, B, d, d, 0, 0, G + o[0], d, G + o[3], tn_take(B, d, d), st, &rb))) return rc;
+      if ((rc = gemm_tn(w.dq_last, d, x_in + (long long)(c.L - 1) * d, c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3], tn_take(B, d, d), st, &rb))) return rc;
       if ((rc = gemm_tn(w.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4], tn_take(M, 2 * d, d), st, &rb))) return rc;
       g = GemmArgs{};   // g_x = [dK dV] Wkv  for every row
       g.A = w.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 2 * d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
       g = GemmArgs{};   // rows L-1 additionally get dq Wq + the residual branch of the attention LayerNorm
-      g.A = w.dq_last; g.lda = d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.t_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.aux = w.g_t; g.ldaux = d;
+      float* gy_last = w.g_y + (long long)(c.L - 1) * d;   // in place on the strided last rows (each element: one thread reads then writes it)
+      g.A = w.dq_last; g.lda = d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = gy_last; g.ldc = c.L * d; g.M = B; g.N = d; g.K = d;
+      g.aux = w.g_t; g.ldaux = d; g.aux2 = gy_last; g.ldaux2 = c.L * d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
-      hipLaunchKernelGGL(add_last_rows_kernel, dim3(cdiv((long long)B * d, 256)), dim3(256), 0, st, w.t_last, B, c.L, d, w.g_y);
-      UR_LAUNCH_CHECK();
       continue;
     }
     // ---- feed-forward block
@@ -347,9 +316,12 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   if ((rc = ln_bwd(w.g_y, w.x0hat, w.rstd0, dense + lay.off[1], nullptr, nullptr, M, d, d_emb_rows, dense_grad + lay.off[1],
                    dense_grad + lay.off[2], ln_take(), st, &rb)))
     return rc;
-  hipLaunchKernelGGL(pos_grad_zero_kernel, dim3(c.L, cdiv(d, 64)), dim3(1024), 0, st, d_emb_rows, item_seq, c.B, c.L, d,
-                     c.use_pos ? dense_grad + lay.off[0] : nullptr);
-  UR_LAUNCH_CHECK();
+  // position-table gradient dP[l,:] = sum_b dx[b,l,:] (no padding index: sasrec.py:25): a split reduction over b with
+  // partial stride L*d, queued with the others.  Row L of the table is never looked up (dense_grad was zeroed).
+  if (c.use_pos) {
+    if (rb.full(1) && (rc = reduce_batch(rb, st))) return rc;
+    rb.add(d_emb_rows, (long long)c.L * d, c.B, (long long)c.L * d, c.L * d, dense_grad + lay.off[0], c.L * d);
+  }
   UR_REQUIRE(tn_cur <= w.tn_ws + w.tn_floats && ln_cur <= w.ln_part + w.ln_floats, UR_ERR_ARG, "ur_sasrec_bwd: partial-sum workspace overrun");
   return reduce_batch(rb, st);
 }
