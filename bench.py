@@ -251,7 +251,9 @@ def main():
             opt.step()
             return loss
 
-    batches = synth_batches(a, a.n_items, device, 2022 + 7919 * rank)
+    # one distinct batch per step (+1 for the lookahead): cycling a few batches would make every looked-up row "touched
+    # 8 steps ago", which is not what uniform ids over n_items rows look like (and costs a 7-step lazy-Adam replay per row)
+    batches = synth_batches(a, a.n_items, device, 2022 + 7919 * rank, n_batches=min(a.warmup + a.steps + 1, 1024))
 
     def barrier():
         if world > 1:

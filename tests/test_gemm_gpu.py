@@ -1,0 +1,98 @@
+"""The two fp32-MFMA GEMM kernels behind nn.Linear (ur_gemm_nt / ur_gemm_tn) against an fp64 restatement, every
+prologue / epilogue, ragged and strided shapes, small and large M.
+Tolerance: 1e-4 relative to the largest output magnitude (fp32 accumulation of K <= 1024 products)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ACT = 2   # UR_ACT_SWISH
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def _dswish(x):
+    s = torch.sigmoid(x)
+    return s * (1 + x * (1 - s))
+
+
+def _close(got, ref, tol=1e-4):
+    ref = ref.to(torch.float64)
+    scale = max(1e-6, float(ref.abs().max()))
+    err = float((got.to(torch.float64).cpu() - ref.cpu()).abs().max()) / scale
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("M,N,K", [(25600, 384, 128), (700, 128, 512), (512, 512, 128), (512, 128, 128), (33, 100, 36), (1, 128, 128),
+                                   (1025, 256, 64), (2000, 132, 260), (64, 200, 512)])
+@pytest.mark.parametrize("pro,epi", [(0, 0), (0, 1), (0, 2), (1, 2), (0, 3), (0, 4)])
+def test_gemm_nt(M, N, K, pro, epi):
+    from unirec_amd._lib import check, lib
+    if epi == 2 and N > 256:
+        pytest.skip("fused LayerNorm epilogue: N <= 256")
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(M * 7 + N * 3 + K)
+    lda, ldw, ldaux = K + 8, K + 4, N + 12          # strided operands
+    A = torch.randn(M, lda, device=dev, generator=g)
+    W = torch.randn(N, ldw, device=dev, generator=g) * 0.1
+    aux = torch.randn(M, ldaux, device=dev, generator=g)
+    bias = torch.randn(N, device=dev, generator=g)
+    gamma, beta = torch.randn(N, device=dev, generator=g), torch.randn(N, device=dev, generator=g)
+    Cc = torch.full((M, N), float("nan"), device=dev)
+    xhat, rstd = torch.empty(M, N, device=dev), torch.empty(M, device=dev)
+    check(lib.ur_gemm_nt(_p(A), lda, _p(W), ldw, _p(Cc), N, M, N, K, pro, epi, ACT, _p(bias), _p(aux), ldaux, _p(gamma), _p(beta),
+                         1e-10, _p(xhat), _p(rstd), _st()), "ur_gemm_nt")
+    A64, W64, aux64 = A[:, :K].double(), W[:, :K].double(), aux[:, :N].double()
+    acc = (_swish(A64) if pro else A64) @ W64.T
+    if epi == 0:
+        ref = acc
+    elif epi == 1:
+        ref = acc + bias.double()
+    elif epi == 2:
+        t = acc + bias.double() + aux64
+        mu = t.mean(1, keepdim=True)
+        var = ((t - mu) ** 2).mean(1, keepdim=True)
+        xh = (t - mu) / torch.sqrt(var + 1e-10)
+        ref = xh * gamma.double() + beta.double()
+        _close(xhat, xh, 2e-4)
+        _close(rstd, 1 / torch.sqrt(var + 1e-10).squeeze(1), 2e-4)
+    elif epi == 3:
+        ref = acc * _dswish(aux64)
+    else:
+        ref = acc + aux64
+    _close(Cc, ref, 2e-4 if epi == 2 else 1e-4)
+
+
+@pytest.mark.parametrize("T,R,Cc_", [(25600, 128, 512), (25600, 384, 128), (512, 128, 128), (700, 100, 36), (5, 128, 128), (3000, 260, 132)])
+@pytest.mark.parametrize("act_on_q", [0, 1])
+def test_gemm_tn(T, R, Cc_, act_on_q):
+    from unirec_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(T + R + Cc_)
+    ldp, ldq = R + 4, Cc_ + 8
+    P = torch.randn(T, ldp, device=dev, generator=g)
+    Q = torch.randn(T, ldq, device=dev, generator=g)
+    out = torch.full((R, Cc_), float("nan"), device=dev)
+    bo = torch.full((R,), float("nan"), device=dev)
+    ws = torch.empty(int(lib.ur_gemm_tn_workspace_floats(T, R, Cc_)), device=dev)
+    for _ in range(2):   # twice: the second run must be bit-identical (fixed-order split reduction)
+        check(lib.ur_gemm_tn(_p(P), ldp, _p(Q), ldq, T, R, Cc_, act_on_q, ACT, _p(out), Cc_, _p(bo), _p(ws), _st()), "ur_gemm_tn")
+        if _ == 0:
+            first = (out.clone(), bo.clone())
+    assert torch.equal(first[0], out) and torch.equal(first[1], bo)
+    P64, Q64 = P[:, :R].double(), Q[:, :Cc_].double()
+    ref = P64.T @ (_swish(Q64) if act_on_q else Q64)
+    _close(out, ref)
+    _close(bo, P64.sum(0))

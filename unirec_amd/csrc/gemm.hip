@@ -28,6 +28,104 @@ __device__ __forceinline__ float4 act4(float4 v, int act) {
   return v;
 }
 
+// Epilogue shared by the GEMM kernels: the BM x BN accumulator tile sits in LDS (row stride BN+4); every global
+// access -- C, the residual / pre-activation operand, xhat -- is a coalesced 16-byte-per-lane row access.
+template <int BM, int BN, int EPI>
+__device__ __forceinline__ void epilogue_from_lds(const float* Cs, int m0, int n0, int tid, const GemmArgs& a) {
+  constexpr int CS = BN + 4;
+  if constexpr (EPI != EPI_BIAS_RES_LN) {
+    constexpr int RT = BN / 4;         // threads per row (one float4 each)
+    constexpr int RPP = 256 / RT;      // rows per pass
+    const int t = tid % RT, g = tid / RT;
+    const int n = n0 + t * 4;
+    if (n < a.N || EPI == EPI_COUNT_GT) {  // N % 4 == 0 (COUNT_GT requires N % BN == 0 so every lane is in range)
+      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (EPI == EPI_BIAS) bias = *(const float4*)(a.bias + n);
+#pragma unroll 4
+      for (int ml = g; ml < BM; ml += RPP) {
+        const int m = m0 + ml;
+        if (m >= a.M) break;
+        float4 v = *(const float4*)(Cs + ml * CS + t * 4);
+        if (EPI == EPI_BIAS) { v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w; }
+        if (EPI == EPI_MUL_DACT) {
+          const float4 h = *(const float4*)(a.aux + (long long)m * a.ldaux + n);
+          v.x *= act_bwd(h.x, a.act); v.y *= act_bwd(h.y, a.act); v.z *= act_bwd(h.z, a.act); v.w *= act_bwd(h.w, a.act);
+        }
+        if (EPI == EPI_ADD) {
+          const float4 h = *(const float4*)(a.aux + (long long)m * a.ldaux + n);
+          v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+          if (a.aux2) {
+            const float4 h2 = *(const float4*)(a.aux2 + (long long)m * a.ldaux2 + n);
+            v.x += h2.x; v.y += h2.y; v.z += h2.z; v.w += h2.w;
+          }
+        }
+        if (EPI == EPI_COUNT_GT) {
+          // full-item ranking: nothing is stored; count the columns of this tile whose score (acc + bias[n]) beats the
+          // row's threshold aux[m], reduce over the RT lanes that share the row, one integer atomic per (row, tile)
+          float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.bias) bs = *(const float4*)(a.bias + n);
+          const float th = a.aux[m];
+          const long long sk = (a.skip ? a.skip[m] - a.skip_base : -1) - n;   // column of this float4 to leave out (0..3) or none
+          float cnt = ((v.x + bs.x > th && sk != 0) ? 1.f : 0.f) + ((v.y + bs.y > th && sk != 1) ? 1.f : 0.f) +
+                      ((v.z + bs.z > th && sk != 2) ? 1.f : 0.f) + ((v.w + bs.w > th && sk != 3) ? 1.f : 0.f);
+          cnt = group_sum<RT>(cnt);
+          if (t == 0 && cnt > 0.f) atomicAdd((int*)a.C + m, (int)cnt);
+          continue;
+        }
+        *(float4*)(a.C + (long long)m * a.ldc + n) = v;
+      }
+    }
+  } else {
+    // t = acc + bias + residual; one 32-lane group per row computes LayerNorm and writes y, xhat, rstd.
+    constexpr int NV = BN >= 128 ? BN / 128 : 1;
+    const int g = tid >> 5, t = tid & 31;
+    const int n4 = a.N >> 2;
+    const float inv_n = 1.0f / (float)a.N;
+    for (int ml = g; ml < BM; ml += 8) {
+      const int m = m0 + ml;
+      if (m >= a.M) break;
+      float4 v[NV];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = t + 32 * k;
+        if (c < n4) {
+          float4 x = *(const float4*)(Cs + ml * CS + c * 4);
+          const float4 bs = *(const float4*)(a.bias + c * 4);
+          const float4 rs = *(const float4*)(a.aux + (long long)m * a.ldaux + c * 4);
+          x.x += bs.x + rs.x; x.y += bs.y + rs.y; x.z += bs.z + rs.z; x.w += bs.w + rs.w;
+          v[k] = x;
+          s += (x.x + x.y) + (x.z + x.w);
+        }
+      }
+      const float mean = group_sum<32>(s) * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = t + 32 * k;
+        if (c < n4) {
+          v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+          q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+        }
+      }
+      const float rstd = 1.0f / sqrtf(group_sum<32>(q) * inv_n + a.eps);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = t + 32 * k;
+        if (c < n4) {
+          const float4 gm = *(const float4*)(a.gamma + c * 4), bt = *(const float4*)(a.beta + c * 4);
+          float4 h, o;
+          h.x = v[k].x * rstd; h.y = v[k].y * rstd; h.z = v[k].z * rstd; h.w = v[k].w * rstd;
+          o.x = h.x * gm.x + bt.x; o.y = h.y * gm.y + bt.y; o.z = h.z * gm.z + bt.z; o.w = h.w * gm.w + bt.w;
+          *(float4*)(a.xhat + (long long)m * a.N + c * 4) = h;
+          *(float4*)(a.C + (long long)m * a.ldc + c * 4) = o;
+        }
+      }
+      if (t == 0) a.rstd[m] = rstd;
+    }
+  }
+}
+
 template <int BM, int BN, int PRO, int EPI, int BK = 32>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   constexpr int LS = BK + 4;            // padded LDS row stride (floats): conflict-free ds_read_b128 for BK = 16 and 32
@@ -147,97 +245,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
       }
   }
   __syncthreads();
-  if constexpr (EPI != EPI_BIAS_RES_LN) {
-    constexpr int RT = BN / 4;         // threads per row (one float4 each)
-    constexpr int RPP = 256 / RT;      // rows per pass
-    const int t = tid % RT, g = tid / RT;
-    const int n = n0 + t * 4;
-    if (n < a.N || EPI == EPI_COUNT_GT) {  // N % 4 == 0 (COUNT_GT requires N % BN == 0 so every lane is in range)
-      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (EPI == EPI_BIAS) bias = *(const float4*)(a.bias + n);
-#pragma unroll 4
-      for (int ml = g; ml < BM; ml += RPP) {
-        const int m = m0 + ml;
-        if (m >= a.M) break;
-        float4 v = *(const float4*)(Cs + ml * CS + t * 4);
-        if (EPI == EPI_BIAS) { v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w; }
-        if (EPI == EPI_MUL_DACT) {
-          const float4 h = *(const float4*)(a.aux + (long long)m * a.ldaux + n);
-          v.x *= act_bwd(h.x, a.act); v.y *= act_bwd(h.y, a.act); v.z *= act_bwd(h.z, a.act); v.w *= act_bwd(h.w, a.act);
-        }
-        if (EPI == EPI_ADD) {
-          const float4 h = *(const float4*)(a.aux + (long long)m * a.ldaux + n);
-          v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
-          if (a.aux2) {
-            const float4 h2 = *(const float4*)(a.aux2 + (long long)m * a.ldaux2 + n);
-            v.x += h2.x; v.y += h2.y; v.z += h2.z; v.w += h2.w;
-          }
-        }
-        if (EPI == EPI_COUNT_GT) {
-          // full-item ranking: nothing is stored; count the columns of this tile whose score (acc + bias[n]) beats the
-          // row's threshold aux[m], reduce over the RT lanes that share the row, one integer atomic per (row, tile)
-          float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (a.bias) bs = *(const float4*)(a.bias + n);
-          const float th = a.aux[m];
-          const long long sk = (a.skip ? a.skip[m] - a.skip_base : -1) - n;   // column of this float4 to leave out (0..3) or none
-          float cnt = ((v.x + bs.x > th && sk != 0) ? 1.f : 0.f) + ((v.y + bs.y > th && sk != 1) ? 1.f : 0.f) +
-                      ((v.z + bs.z > th && sk != 2) ? 1.f : 0.f) + ((v.w + bs.w > th && sk != 3) ? 1.f : 0.f);
-          cnt = group_sum<RT>(cnt);
-          if (t == 0 && cnt > 0.f) atomicAdd((int*)a.C + m, (int)cnt);
-          continue;
-        }
-        *(float4*)(a.C + (long long)m * a.ldc + n) = v;
-      }
-    }
-  } else {
-    // t = acc + bias + residual; one 32-lane group per row computes LayerNorm and writes y, xhat, rstd.
-    constexpr int NV = BN >= 128 ? BN / 128 : 1;
-    const int g = tid >> 5, t = tid & 31;
-    const int n4 = a.N >> 2;
-    const float inv_n = 1.0f / (float)a.N;
-    for (int ml = g; ml < BM; ml += 8) {
-      const int m = m0 + ml;
-      if (m >= a.M) break;
-      float4 v[NV];
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int c = t + 32 * k;
-        if (c < n4) {
-          float4 x = *(const float4*)(Cs + ml * CS + c * 4);
-          const float4 bs = *(const float4*)(a.bias + c * 4);
-          const float4 rs = *(const float4*)(a.aux + (long long)m * a.ldaux + c * 4);
-          x.x += bs.x + rs.x; x.y += bs.y + rs.y; x.z += bs.z + rs.z; x.w += bs.w + rs.w;
-          v[k] = x;
-          s += (x.x + x.y) + (x.z + x.w);
-        }
-      }
-      const float mean = group_sum<32>(s) * inv_n;
-      float q = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int c = t + 32 * k;
-        if (c < n4) {
-          v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
-          q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
-        }
-      }
-      const float rstd = 1.0f / sqrtf(group_sum<32>(q) * inv_n + a.eps);
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int c = t + 32 * k;
-        if (c < n4) {
-          const float4 gm = *(const float4*)(a.gamma + c * 4), bt = *(const float4*)(a.beta + c * 4);
-          float4 h, o;
-          h.x = v[k].x * rstd; h.y = v[k].y * rstd; h.z = v[k].z * rstd; h.w = v[k].w * rstd;
-          o.x = h.x * gm.x + bt.x; o.y = h.y * gm.y + bt.y; o.z = h.z * gm.z + bt.z; o.w = h.w * gm.w + bt.w;
-          *(float4*)(a.xhat + (long long)m * a.N + c * 4) = h;
-          *(float4*)(a.C + (long long)m * a.ldc + c * 4) = o;
-        }
-      }
-      if (t == 0) a.rstd[m] = rstd;
-    }
-  }
+  epilogue_from_lds<BM, BN, EPI>(Cs, m0, n0, tid, a);
 }
 
 template <int BM, int BN, int PRO, int EPI, int BK = 32>

@@ -434,24 +434,33 @@ struct AdamK {
 // zero-gradient Adam steps t = from+1 .. to applied to one element (reference semantics: dense Adam moves
 // every row every step; here the missed steps are replayed when the row is next needed).
 constexpr int LAZY_EXACT_STEPS = 512;
-__device__ __forceinline__ void lazy_replay(float& w, float& m, float& v, int from, int to, const AdamK& a) {
-  int k = to - from;
+// One float4 of (w, m, v).  The per-step scalars (bias corrections) are computed once per step for the 4 elements.
+__device__ __forceinline__ void lazy_replay4(float4& w, float4& m, float4& v, int from, int to, const AdamK& a) {
+  const int k = to - from;
   if (k <= 0) return;
-  if (a.wd == 0.f && m == 0.f && v == 0.f) return;   // never touched (or fully decayed): zero-gradient steps are no-ops
+  const bool dead = (m.x == 0.f && m.y == 0.f && m.z == 0.f && m.w == 0.f) && (v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f);
+  if (a.wd == 0.f && dead) return;   // never touched (or fully decayed): zero-gradient steps are no-ops
   float b1t = powf(a.b1, (float)from), b2t = powf(a.b2, (float)from);
   const int exact = (a.wd != 0.f) ? k : min(k, LAZY_EXACT_STEPS);
+  const float c1m = 1.f - a.b1, c2m = 1.f - a.b2;
   for (int j = 0; j < exact; ++j) {
     b1t *= a.b1;
     b2t *= a.b2;
-    const float gr = a.wd * w;
-    m = a.b1 * m + (1.f - a.b1) * gr;
-    v = a.b2 * v + (1.f - a.b2) * gr * gr;
-    const float denom = sqrtf(v) / sqrtf(1.f - b2t) + a.eps;
-    w -= (a.lr / (1.f - b1t)) * (m / denom);
+    const float inv_s2 = 1.0f / sqrtf(1.f - b2t), step = a.lr / (1.f - b1t);
+#define UR_LAZY_ELEM(W, M, V)                                   \
+    {                                                           \
+      const float gr = a.wd * W;                                \
+      M = a.b1 * M + c1m * gr;                                  \
+      V = a.b2 * V + c2m * gr * gr;                             \
+      W -= step * (M / (sqrtf(V) * inv_s2 + a.eps));            \
+    }
+    UR_LAZY_ELEM(w.x, m.x, v.x) UR_LAZY_ELEM(w.y, m.y, v.y) UR_LAZY_ELEM(w.z, m.z, v.z) UR_LAZY_ELEM(w.w, m.w, v.w)
+#undef UR_LAZY_ELEM
   }
   if (exact < k) {  // wd == 0: beyond LAZY_EXACT_STEPS the update b1^j*m/(...) is below fp32 resolution; decay the moments
-    m *= powf(a.b1, (float)(k - exact));
-    v *= powf(a.b2, (float)(k - exact));
+    const float f1 = powf(a.b1, (float)(k - exact)), f2 = powf(a.b2, (float)(k - exact));
+    m.x *= f1; m.y *= f1; m.z *= f1; m.w *= f1;
+    v.x *= f2; v.y *= f2; v.z *= f2; v.w *= f2;
   }
 }
 
@@ -489,10 +498,7 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
       if (c < d4) {
         float4 w = table[row * d4 + c], m = mom[row * d4 + c], v = var[row * d4 + c];
         if (last_step) {
-          lazy_replay(w.x, m.x, v.x, last, a.step - 1, a);
-          lazy_replay(w.y, m.y, v.y, last, a.step - 1, a);
-          lazy_replay(w.z, m.z, v.z, last, a.step - 1, a);
-          lazy_replay(w.w, m.w, v.w, last, a.step - 1, a);
+          lazy_replay4(w, m, v, last, a.step - 1, a);
         }
         if (MODE == 0) {
           const float4 gr = grad[(long long)u * d4 + c];
@@ -528,10 +534,7 @@ __global__ __launch_bounds__(256) void lazy_flush_kernel(AdamK a, float4* __rest
       const int c = t + k * TPR;
       if (c < d4) {
         float4 w = table[row * d4 + c], m = mom[row * d4 + c], v = var[row * d4 + c];
-        lazy_replay(w.x, m.x, v.x, last, a.step, a);
-        lazy_replay(w.y, m.y, v.y, last, a.step, a);
-        lazy_replay(w.z, m.z, v.z, last, a.step, a);
-        lazy_replay(w.w, m.w, v.w, last, a.step, a);
+        lazy_replay4(w, m, v, last, a.step, a);
         table[row * d4 + c] = w;
         mom[row * d4 + c] = m;
         var[row * d4 + c] = v;
