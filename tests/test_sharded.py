@@ -53,6 +53,7 @@ def _worker(rank, world, port, N, d, q):
         send_counts = [int(((uniq // n_local) == r).sum()) for r in range(world)]
         x = RowExchange(world, rank)
         recv_counts = x.exchange_counts(send_counts)
+        assert x.exchange_counts_dev(torch.tensor(send_counts, dtype=torch.int32)) == (send_counts, recv_counts)
         req = x.all_to_all_rows((uniq % n_local).to(torch.int32), send_counts, recv_counts)
         assert int(req.max()) < n_local and len(req) == sum(recv_counts)
         compact = x.all_to_all_rows(shard[req.long()], recv_counts, send_counts)      # rows come back in key order

@@ -40,6 +40,20 @@ class RowExchange:
         dist.all_to_all_single(out, t, group=self.group)
         return [int(x) for x in out.tolist()]
 
+    def exchange_counts_dev(self, counts_dev: torch.Tensor):
+        """counts_dev: int32/int64 [world] ON THE DEVICE (rows this rank wants from each owner).  Exchanges them without
+        a host round trip and reads send + recv counts back together: ONE host sync per step instead of two."""
+        send = counts_dev.to(torch.int64)
+        if self.world == 1:
+            c = [int(x) for x in send.tolist()]
+            return c, list(c)
+        nccl = dist.get_backend(self.group) == "nccl"
+        src = send if nccl else send.cpu()
+        recv = torch.empty_like(src)
+        dist.all_to_all_single(recv, src, group=self.group)
+        both = torch.cat([src, recv]).tolist()
+        return [int(x) for x in both[: self.world]], [int(x) for x in both[self.world:]]
+
     def all_to_all_rows(self, send: torch.Tensor, send_counts: List[int], recv_counts: List[int]) -> torch.Tensor:
         """send: [sum(send_counts), ...] blocks ordered by destination rank -> [sum(recv_counts), ...] ordered by source."""
         if self.world == 1:
@@ -109,12 +123,11 @@ class ShardedSasrecStep:
         ids_a = item_seq.reshape(-1)
         ids_b = torch.cat([item_id.reshape(-1), self.zero_id])
         pl, counts_dev = ops.rows_plan_sharded(ids_a, ids_b, self.N, W)
-        send_counts = [int(x) for x in counts_dev.tolist()]          # the one host sync of the step (W ints)
+        send_counts, recv_counts = self.xchg.exchange_counts_dev(counts_dev)   # the one host sync of the step (2W ints)
         n_uniq = sum(send_counts)
         keys = pl.uniq_idx[:n_uniq]
         req_send = (keys % self.n_local).to(torch.int32) if W > 1 else keys
         # 2. all-to-all #1: row ids -> owners
-        recv_counts = self.xchg.exchange_counts(send_counts)
         req = self.xchg.all_to_all_rows(req_send, send_counts, recv_counts)
         own = ops.rows_plan(req.contiguous(), None, self.n_local)
         if self.last is not None and self.t > 1:
