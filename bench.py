@@ -28,6 +28,10 @@ HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 
 
+# algorithmic activation traffic of the GEMM classes per step at the default workload, MB
+ALGO_BYTES_PER_STEP = {"gemm_nt": 598.0, "gemm_tn": 247.0}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,6 +329,16 @@ def main():
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "launches": c["launches"],
                 "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2)}
+    # HBM bytes per launch of the dominant class: PMC counters cannot be collected from inside this process, so the
+    # figure is the committed rocprofv3 --pmc summary of the SAME workload (profiles/r01_pmc_hbm_traffic.json:
+    # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction); null when the summary is absent
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+    if roof is not None and os.path.exists(pmc) and a.n_items == 100_000_000 and a.batch == 512:
+        per_class = json.load(open(pmc)).get("per_class", {})
+        if dom in per_class:
+            roof["traffic"] = per_class[dom]["hbm_bytes_per_launch"]
+            roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json)"
+            roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * 1e6 / max(1, c["launches"] / max(1, (a.steps + 3) // 4)))
     emb_bytes_per_example = 8 * (L + G) * d * 4   # fwd read + bwd/opt touched rows (w,m,v,grad)
     out = {
         "metric": "training_examples_per_sec", "value": round(ex_per_s, 1), "unit": "examples/s", "n_gpus": world,

@@ -20,24 +20,27 @@ def main():
     model = SASRec(cfg)
     opt = SparseDenseAdam(model, lr=1e-3, table_mode=a.table_mode)
     model.train()
-    batches = bench.synth_batches(a, a.n_items, dev, 1)
+    batches = bench.synth_batches(a, a.n_items, dev, 1, n_batches=64)
 
     def step(b, nxt):
         opt.zero_grad()
         opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
         if not a.no_prefetch:
             opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
-        loss, _, _, _ = model(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
-        loss.backward()
+        if a.autograd:
+            loss, _, _, _ = model(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
+            loss.backward()
+        else:
+            model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
         opt.step()
 
     for i in range(10):
-        step(batches[i % 8], batches[(i + 1) % 8])
+        step(batches[i % 64], batches[(i + 1) % 64])
     torch.cuda.synchronize()
     K = 50
     t0 = time.perf_counter()
     for i in range(K):
-        step(batches[i % 8], batches[(i + 1) % 8])
+        step(batches[i % 64], batches[(i + 1) % 64])
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
