@@ -7,6 +7,8 @@
 //   a   = LN(ctx Wo^T + bo + x)                gemm_nt  EPI_BIAS_RES_LN
 //   h1  = a W1^T + b1                          gemm_nt  EPI_BIAS            (pre-activation kept for backward)
 //   y   = LN(act(h1) W2^T + b2 + a)            gemm_nt  PRO_ACT + EPI_BIAS_RES_LN
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -55,11 +57,12 @@ static LayerP layer_ptrs(const float* base, const Layout& l, int i) {
 struct LayerWs {
   float *qkv, *lse, *ctx, *a, *ahat, *rstd1, *h1, *y, *yhat, *rstd2;
   float *wqkvT, *woT, *w1T, *w2T;
+  float *g_tf, *g_ta, *g_h1, *g_qkv;   // backward: LN-backward outputs (FFN / attention block), d h1, d qkv
 };
 struct Ws {
   float *x0, *x0hat, *rstd0;
   LayerWs layer[UR_MAX_LAYERS];
-  float *g_y, *g_t, *g_a, *g_h1, *g_qkv, *g_ctx, *tn_ws, *ln_part, *attn_ws;
+  float *g_y, *g_a, *g_ctx, *tn_ws, *ln_part, *attn_ws;
   float *q_last, *dq_last, *lse_last;   // last-row specialisation of the final layer ([B,d] each)
   long long total_floats, tn_floats, ln_floats;
 };
@@ -80,9 +83,11 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
     lw.a = take(M * d); lw.ahat = take(M * d); lw.rstd1 = take(M); lw.h1 = take(M * I);
     lw.y = take(M * d); lw.yhat = take(M * d); lw.rstd2 = take(M);
     lw.wqkvT = take(3 * d * d); lw.woT = take(d * d); lw.w1T = take(I * d); lw.w2T = take(I * d);
+    // backward scratch that the weight-gradient GEMMs read: per layer, written once per backward pass, so those GEMMs
+    // can run on the side stream without write-after-read hazards against the activation-gradient chain
+    lw.g_tf = take(M * d); lw.g_ta = take(M * d); lw.g_h1 = take(M * I); lw.g_qkv = take(M * 3 * d);
   }
-  w.g_y = take(M * d); w.g_t = take(M * d); w.g_a = take(M * d); w.g_h1 = take(M * I);
-  w.g_qkv = take(M * 3 * d); w.g_ctx = take(M * d);
+  w.g_y = take(M * d); w.g_a = take(M * d); w.g_ctx = take(M * d);
   // split-reduction partials: every weight-gradient GEMM / LayerNorm backward of one backward pass keeps its own region
   // (they are all reduced by ONE launch at the end of ur_sasrec_bwd)
   const int T = (int)M;
@@ -143,6 +148,34 @@ extern "C" int64_t ur_sasrec_workspace_bytes(const UrSasrecCfg* cfg) {
   if (rc) return rc;
   return carve(*cfg, nullptr).total_floats * (int64_t)sizeof(float);
 }
+
+
+// ---- side stream for the weight-gradient GEMMs.  dW / db are consumed only by the optimizer, so they do not belong
+// on the critical path dY -> dX: each gemm_tn is forked onto a second HIP stream as soon as its input gradient exists
+// (event on the main stream), and joined before the final reduce_batch.  Fills the CUs that the latency-bound small
+// kernels of the chain (last-row layer, LayerNorm backward, attention) leave idle.  UR_SASREC_SIDE=0 disables it.
+namespace {
+struct SideCtx {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[24];
+  hipEvent_t done = nullptr;
+  bool ok = false;
+};
+SideCtx* side_ctx() {
+  static SideCtx* ctx = []() -> SideCtx* {
+    const char* e = getenv("UR_SASREC_SIDE");
+    if (e && atoi(e) == 0) return nullptr;
+    SideCtx* c = new SideCtx();
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (auto& ev : c->ev)
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    c->ok = true;
+    return c;
+  }();
+  return ctx;
+}
+}  // namespace
 
 extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                              const int32_t* item_seq, float* user_emb, void* ws, void* stream) {
@@ -234,6 +267,20 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     ln_cur += (long long)LN_BWD_MAX_BLOCKS * 2 * d;
     return p;
   };
+  // weight-gradient GEMM, forked onto the side stream (its inputs are complete at this point of the main stream)
+  SideCtx* sc = (c.n_layers <= 2) ? side_ctx() : nullptr;   // the queue of deferred reductions must not flush mid-pass
+  int n_fork = 0;
+  auto tn = [&](const float* P, int ldp, const float* Q, int ldq, int T_, int R_, int C_, int pro_act, int act, float* out, int ldo,
+                float* bias_out) -> int {
+    hipStream_t s2 = st;
+    if (sc && n_fork < 24) {
+      UR_HIP(hipEventRecord(sc->ev[n_fork], st));
+      UR_HIP(hipStreamWaitEvent(sc->stream, sc->ev[n_fork], 0));
+      ++n_fork;
+      s2 = sc->stream;
+    }
+    return gemm_tn(P, ldp, Q, ldq, T_, R_, C_, pro_act, act, out, ldo, bias_out, tn_take(T_, R_, C_), s2, &rb);
+  };
   if (!c.last_only) {
     hipLaunchKernelGGL(put_last_kernel, dim3(cdiv((long long)M * d, 256)), dim3(256), 0, st, d_user_emb, c.B, c.L, d, w.g_y);
     UR_LAUNCH_CHECK();
@@ -261,55 +308,55 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       // final layer: only row L-1 carries gradient (d_user_emb); K,V gradients still cover every position
       const int B = c.B;
       GemmArgs g{};
-      if ((rc = ln_bwd(d_user_emb, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, B, d, w.g_t, G + o[14], G + o[15], ln_take(), st, &rb))) return rc;
-      if ((rc = gemm_tn(w.g_t, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13], tn_take(B, d, I), st, &rb))) return rc;
-      g.A = w.g_t; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = w.g_h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.aux = lw.h1; g.ldaux = I; g.act = c.act;
+      if ((rc = ln_bwd(d_user_emb, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, B, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb))) return rc;
+      if ((rc = tn(lw.g_tf, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
+      g.A = lw.g_tf; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.aux = lw.h1; g.ldaux = I; g.act = c.act;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
-      if ((rc = gemm_tn(w.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11], tn_take(B, I, d), st, &rb))) return rc;
+      if ((rc = tn(lw.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
       g = GemmArgs{};
-      g.A = w.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = B; g.N = d; g.K = I; g.aux = w.g_t; g.ldaux = d;
+      g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = B; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
-      if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, B, d, w.g_t, G + o[8], G + o[9], ln_take(), st, &rb))) return rc;
-      if ((rc = gemm_tn(w.g_t, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7], tn_take(B, d, d), st, &rb))) return rc;
+      if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, B, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb))) return rc;
+      if ((rc = tn(lw.g_ta, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
       g = GemmArgs{};
-      g.A = w.g_t; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
+      g.A = lw.g_ta; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
-      if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, w.g_qkv, st))) return rc;
+      if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, lw.g_qkv, st))) return rc;
       // dWq from the B last rows, dWk/dWv from all rows
-      if ((rc = gemm_tn(w.dq_last, d, x_in + (long long)(c.L - 1) * d, c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3], tn_take(B, d, d), st, &rb))) return rc;
-      if ((rc = gemm_tn(w.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4], tn_take(M, 2 * d, d), st, &rb))) return rc;
+      if ((rc = tn(w.dq_last, d, x_in + (long long)(c.L - 1) * d, c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
+      if ((rc = tn(lw.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4]))) return rc;
       g = GemmArgs{};   // g_x = [dK dV] Wkv  for every row
-      g.A = w.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 2 * d;
+      g.A = lw.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 2 * d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
       g = GemmArgs{};   // rows L-1 additionally get dq Wq + the residual branch of the attention LayerNorm
       float* gy_last = w.g_y + (long long)(c.L - 1) * d;   // in place on the strided last rows (each element: one thread reads then writes it)
       g.A = w.dq_last; g.lda = d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = gy_last; g.ldc = c.L * d; g.M = B; g.N = d; g.K = d;
-      g.aux = w.g_t; g.ldaux = d; g.aux2 = gy_last; g.ldaux2 = c.L * d;
+      g.aux = lw.g_ta; g.ldaux = d; g.aux2 = gy_last; g.ldaux2 = c.L * d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
       continue;
     }
     // ---- feed-forward block
-    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, w.g_t, G + o[14], G + o[15], ln_take(), st, &rb))) return rc;
-    if ((rc = gemm_tn(w.g_t, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13], tn_take(M, d, I), st, &rb))) return rc;
+    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb))) return rc;
+    if ((rc = tn(lw.g_tf, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
     GemmArgs g{};
-    g.A = w.g_t; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = w.g_h1; g.ldc = I; g.M = M; g.N = I; g.K = d;
+    g.A = lw.g_tf; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = M; g.N = I; g.K = d;
     g.aux = lw.h1; g.ldaux = I; g.act = c.act;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
-    if ((rc = gemm_tn(w.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11], tn_take(M, I, d), st, &rb))) return rc;
+    if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
     g = GemmArgs{};
-    g.A = w.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.N = d; g.K = I; g.aux = w.g_t; g.ldaux = d;
+    g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
     // ---- attention block
-    if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, w.g_t, G + o[8], G + o[9], ln_take(), st, &rb))) return rc;
-    if ((rc = gemm_tn(w.g_t, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7], tn_take(M, d, d), st, &rb))) return rc;
+    if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb))) return rc;
+    if ((rc = tn(lw.g_ta, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
     g = GemmArgs{};
-    g.A = w.g_t; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.N = d; g.K = d;
+    g.A = lw.g_ta; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.N = d; g.K = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
-    if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, w.g_qkv, w.attn_ws, 0, st))) return rc;
-    if ((rc = gemm_tn(w.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3], tn_take(M, 3 * d, d), st, &rb))) return rc;
+    if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st))) return rc;
+    if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
     g = GemmArgs{};
-    g.A = w.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
-    g.aux = w.g_t; g.ldaux = d;
+    g.A = lw.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
+    g.aux = lw.g_ta; g.ldaux = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
   }
   // ---- input block: LN0 backward -> row gradients of E[item_seq] and of the position table
@@ -323,5 +370,9 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     rb.add(d_emb_rows, (long long)c.L * d, c.B, (long long)c.L * d, c.L * d, dense_grad + lay.off[0], c.L * d);
   }
   UR_REQUIRE(tn_cur <= w.tn_ws + w.tn_floats && ln_cur <= w.ln_part + w.ln_floats, UR_ERR_ARG, "ur_sasrec_bwd: partial-sum workspace overrun");
+  if (n_fork > 0) {   // join: the partial sums written on the side stream are read by the reduction below
+    UR_HIP(hipEventRecord(sc->done, sc->stream));
+    UR_HIP(hipStreamWaitEvent(st, sc->done, 0));
+  }
   return reduce_batch(rb, st);
 }
