@@ -270,8 +270,13 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   // weight-gradient GEMM, forked onto the side stream (its inputs are complete at this point of the main stream)
   SideCtx* sc = (c.n_layers <= 2) ? side_ctx() : nullptr;   // the queue of deferred reductions must not flush mid-pass
   int n_fork = 0;
-  auto tn = [&](const float* P, int ldp, const float* Q, int ldq, int T_, int R_, int C_, int pro_act, int act, float* out, int ldo,
-                float* bias_out) -> int {
+  struct PendingTn { const float *P, *Q; int ldp, ldq, T, R, C, pro_act, act, ldo; float *out, *bias_out, *ws; };
+  PendingTn pend[8];
+  int n_pend = 0;
+  // launch the queued weight-gradient GEMMs: on the side stream behind ONE event of the main stream (every queued GEMM's
+  // inputs are complete at the point of the main stream where fork() is called), or in line when there is no side stream
+  auto fork = [&]() -> int {
+    if (n_pend == 0) return UR_OK;
     hipStream_t s2 = st;
     if (sc && n_fork < 24) {
       UR_HIP(hipEventRecord(sc->ev[n_fork], st));
@@ -279,7 +284,22 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       ++n_fork;
       s2 = sc->stream;
     }
-    return gemm_tn(P, ldp, Q, ldq, T_, R_, C_, pro_act, act, out, ldo, bias_out, tn_take(T_, R_, C_), s2, &rb);
+    for (int i = 0; i < n_pend; ++i) {
+      const PendingTn& t = pend[i];
+      int rc2 = gemm_tn(t.P, t.ldp, t.Q, t.ldq, t.T, t.R, t.C, t.pro_act, t.act, t.out, t.ldo, t.bias_out, t.ws, s2, &rb);
+      if (rc2) return rc2;
+    }
+    n_pend = 0;
+    return UR_OK;
+  };
+  auto tn = [&](const float* P, int ldp, const float* Q, int ldq, int T_, int R_, int C_, int pro_act, int act, float* out, int ldo,
+                float* bias_out) -> int {
+    if (n_pend == 8) {
+      int rc2 = fork();
+      if (rc2) return rc2;
+    }
+    pend[n_pend++] = PendingTn{P, Q, ldp, ldq, T_, R_, C_, pro_act, act, ldo, out, bias_out, tn_take(T_, R_, C_)};
+    return sc ? UR_OK : fork();
   };
   if (!c.last_only) {
     hipLaunchKernelGGL(put_last_kernel, dim3(cdiv((long long)M * d, 256)), dim3(256), 0, st, d_user_emb, c.B, c.L, d, w.g_y);
@@ -313,6 +333,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       g.A = lw.g_tf; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.aux = lw.h1; g.ldaux = I; g.act = c.act;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
       if ((rc = tn(lw.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
+      if ((rc = fork())) return rc;
       g = GemmArgs{};
       g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = B; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
@@ -325,6 +346,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       // dWq from the B last rows, dWk/dWv from all rows
       if ((rc = tn(w.dq_last, d, x_in + (long long)(c.L - 1) * d, c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
       if ((rc = tn(lw.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4]))) return rc;
+      if ((rc = fork())) return rc;
       g = GemmArgs{};   // g_x = [dK dV] Wkv  for every row
       g.A = lw.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 2 * d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
@@ -343,6 +365,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     g.aux = lw.h1; g.ldaux = I; g.act = c.act;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
     if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
+    if ((rc = fork())) return rc;
     g = GemmArgs{};
     g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
@@ -354,6 +377,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
     if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st))) return rc;
     if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
+    if ((rc = fork())) return rc;
     g = GemmArgs{};
     g.A = lw.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
     g.aux = lw.g_ta; g.ldaux = d;
@@ -370,6 +394,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     rb.add(d_emb_rows, (long long)c.L * d, c.B, (long long)c.L * d, c.L * d, dense_grad + lay.off[0], c.L * d);
   }
   UR_REQUIRE(tn_cur <= w.tn_ws + w.tn_floats && ln_cur <= w.ln_part + w.ln_floats, UR_ERR_ARG, "ur_sasrec_bwd: partial-sum workspace overrun");
+  if ((rc = fork())) return rc;
   if (n_fork > 0) {   // join: the partial sums written on the side stream are read by the reduction below
     UR_HIP(hipEventRecord(sc->done, sc->stream));
     UR_HIP(hipStreamWaitEvent(st, sc->done, 0));

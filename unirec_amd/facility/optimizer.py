@@ -57,16 +57,20 @@ class SparseDenseAdam:
         return ops.adam_cfg(self.param_groups[0]["lr"], step, self.wd, self.betas[0], self.betas[1], self.eps)
 
     # ------------------------------------------------------------------ per-batch plan (before forward)
-    def _make_plans(self, item_seq, item_id, user_id):
-        plans = {}
+    def _plan_inputs(self, item_seq, item_id, user_id):
+        """-> {table: (ids_a int32 | None, ids_b int64 | None)} for the tables this batch looks up."""
+        req = {}
         ids_a = item_seq.reshape(-1).to(torch.int32).contiguous() if item_seq is not None else None
         ids_b = item_id.reshape(-1).contiguous() if item_id is not None else None
         if "item_embedding" in self.tables and (ids_a is not None or ids_b is not None):
-            plans["item_embedding"] = ops.rows_plan(ids_a, ids_b, self.tables["item_embedding"]["w"].shape[0])
+            req["item_embedding"] = (ids_a, ids_b)
         if "user_embedding" in self.tables and user_id is not None:
-            plans["user_embedding"] = ops.rows_plan(user_id.reshape(-1).to(torch.int32).contiguous(), None,
-                                                    self.tables["user_embedding"]["w"].shape[0])
-        return plans
+            req["user_embedding"] = (user_id.reshape(-1).to(torch.int32).contiguous(), None)
+        return req
+
+    def _make_plans(self, item_seq, item_id, user_id):
+        return {name: ops.rows_plan(a, b, self.tables[name]["w"].shape[0])
+                for name, (a, b) in self._plan_inputs(item_seq, item_id, user_id).items()}
 
     @staticmethod
     def _ids_key(item_seq, item_id, user_id):
@@ -78,22 +82,26 @@ class SparseDenseAdam:
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.model.device)
+        # every buffer is allocated (and later released) under the MAIN stream; the side stream only fills them.  No
+        # record_stream bookkeeping: that would put one event packet per tensor into the main queue when they are freed
+        req = self._plan_inputs(item_seq, item_id, user_id)
+        bufs = {name: ops.rows_plan_alloc((a.numel() if a is not None else 0) + (b.numel() if b is not None else 0),
+                                          a.numel() if a is not None else 0, self.model.device) for name, (a, b) in req.items()}
         self._side.wait_stream(main)   # the ids may still be in flight (H2D copy) on the main stream
         with torch.cuda.stream(self._side):
-            plans = self._make_plans(item_seq, item_id, user_id)
+            plans = {name: ops.rows_plan(a, b, self.tables[name]["w"].shape[0], out=bufs[name]) for name, (a, b) in req.items()}
             ev = torch.cuda.Event()
             ev.record(self._side)
-        for pl in plans.values():      # allocated on the side stream, consumed (and freed) under the main one
-            for t in (pl.uniq_idx, pl.seg_start, pl.sorted_pos, pl.n_uniq):
-                t.record_stream(main)
-        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev)
+        # keep ids + workspaces alive until the plan is adopted (the side stream reads / writes them asynchronously)
+        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev, (req, bufs))
 
     def plan_batch(self, item_seq=None, item_id=None, user_id=None):
         """Sort/unique the ids this batch will look up (or adopt the plan `prefetch_plan` made for the same tensors);
         in lazy_dense mode bring those rows up to date."""
         pre, self._prefetched = self._prefetched, None
-        if pre is not None and pre[0] == self._ids_key(item_seq, item_id, user_id):
+        if pre is not None:   # always order the main stream after the side stream's use of the prefetch buffers
             torch.cuda.current_stream().wait_event(pre[2])
+        if pre is not None and pre[0] == self._ids_key(item_seq, item_id, user_id):
             self._plans = pre[1]
         else:
             self._plans = self._make_plans(item_seq, item_id, user_id)

@@ -157,14 +157,8 @@ class RowsPlan:
     __slots__ = ("n", "n_a", "uniq_idx", "seg_start", "sorted_pos", "n_uniq")
 
 
-def rows_plan(ids_a, ids_b, n_rows) -> RowsPlan:
-    """ids_a: int32 tensor or None, ids_b: int64 tensor or None (flattened internally)."""
-    dev = (ids_a if ids_a is not None else ids_b).device
-    n_a = ids_a.numel() if ids_a is not None else 0
-    n_b = ids_b.numel() if ids_b is not None else 0
-    _chk(ids_a, torch.int32, "ids_a", allow_none=True)
-    _chk(ids_b, torch.int64, "ids_b", allow_none=True)
-    n = n_a + n_b
+def rows_plan_alloc(n, n_a, dev):
+    """Output buffers + workspace of a plan over n ids (allocated on the CURRENT stream)."""
     pl = RowsPlan()
     pl.n, pl.n_a = n, n_a
     pl.uniq_idx = torch.empty(n, dtype=torch.int32, device=dev)
@@ -172,6 +166,21 @@ def rows_plan(ids_a, ids_b, n_rows) -> RowsPlan:
     pl.sorted_pos = torch.empty(n, dtype=torch.int32, device=dev)
     pl.n_uniq = torch.empty(1, dtype=torch.int32, device=dev)
     ws = torch.empty(check(lib.ur_rows_plan_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    return pl, ws
+
+
+def rows_plan(ids_a, ids_b, n_rows, out=None) -> RowsPlan:
+    """ids_a: int32 tensor or None, ids_b: int64 tensor or None (flattened internally).
+    out: (RowsPlan, workspace) from rows_plan_alloc -- lets a caller that launches the plan on a side stream keep the
+    buffers' allocation (and release) on its main stream."""
+    dev = (ids_a if ids_a is not None else ids_b).device
+    n_a = ids_a.numel() if ids_a is not None else 0
+    n_b = ids_b.numel() if ids_b is not None else 0
+    _chk(ids_a, torch.int32, "ids_a", allow_none=True)
+    _chk(ids_b, torch.int64, "ids_b", allow_none=True)
+    n = n_a + n_b
+    pl, ws = out if out is not None else rows_plan_alloc(n, n_a, dev)
+    assert pl.n == n and pl.n_a == n_a
     check(lib.ur_rows_plan(_p(ids_a), n_a, _p(ids_b), n_b, int(n_rows), _p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos),
                            _p(pl.n_uniq), _p(ws), _stream()), "ur_rows_plan")
     return pl
