@@ -29,6 +29,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 
 
 # algorithmic activation traffic of the GEMM classes per step at the default workload, MB
+PROF_EVERY = 10   # the dominant kernel class is bracketed with HIP events on every PROF_EVERY-th timed step
 ALGO_BYTES_PER_STEP = {"gemm_nt": 598.0, "gemm_tn": 247.0}
 
 
@@ -288,7 +289,7 @@ def main():
         raise SystemExit("non-finite loss in warm-up")
     dom = max(warm, key=lambda k: warm[k]["ms"]) if not a.no_prof else None
     # ---- timed region: exactly --steps steps.  Only the dominant kernel class is bracketed (HIP events on the launch
-    # stream), and only on every 4th step, so the measurement perturbs `value` by < 1 %.
+    # stream), and only on every PROF_EVERY-th step, so the measurement perturbs `value` by ~1 %.
     _lib.lib.ur_prof_reset()
     if dom is not None:
         _lib.lib.ur_prof_set_mask(1 << names.index(dom))
@@ -296,7 +297,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         if dom is not None:
-            _lib.lib.ur_prof_enable(1 if i % 4 == 0 else 0)
+            _lib.lib.ur_prof_enable(1 if i % PROF_EVERY == 0 else 0)
         loss = step_fn(batches[(a.warmup + i) % len(batches)], batches[(a.warmup + i + 1) % len(batches)])
     barrier()
     dt = time.perf_counter() - t0
@@ -338,7 +339,7 @@ def main():
         if dom in per_class:
             roof["traffic"] = per_class[dom]["hbm_bytes_per_launch"]
             roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json)"
-            roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * 1e6 / max(1, c["launches"] / max(1, (a.steps + 3) // 4)))
+            roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * 1e6 / max(1, c["launches"] / max(1, (a.steps + PROF_EVERY - 1) // PROF_EVERY)))
     emb_bytes_per_example = 8 * (L + G) * d * 4   # fwd read + bwd/opt touched rows (w,m,v,grad)
     out = {
         "metric": "training_examples_per_sec", "value": round(ex_per_s, 1), "unit": "examples/s", "n_gpus": world,

@@ -126,19 +126,23 @@ __device__ __forceinline__ void epilogue_from_lds(const float* Cs, int m0, int n
   }
 }
 
-template <int BM, int BN, int PRO, int EPI, int BK = 32>
+// PF = global-load prefetch distance in K-steps (register slots).  1: the next tile is in flight during the current
+// one (enough when several workgroups share a CU); 4: for launches with few workgroups (M <= 1024 rows), where nothing
+// else hides the L2/HBM round trip of every K-step.
+template <int BM, int BN, int PRO, int EPI, int BK = 32, int PF = 1>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   constexpr int LS = BK + 4;            // padded LDS row stride (floats): conflict-free ds_read_b128 for BK = 16 and 32
   constexpr int C4N = BK / 4;           // float4 columns per tile row
   constexpr int RPT = 256 / C4N;        // tile rows covered per pass of the 256 threads
-  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int WM = BM >= 64 ? 2 : 1, WN = 4 / WM;    // wave grid (BM = 32: all four waves side by side along N)
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int AV = BM / RPT, WV = BN / RPT;  // float4 loads per thread per K-step
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][BM*LS]
   float* Ws = smem + 2 * BM * LS;   // [2][BN*LS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   // XCD-aware tile mapping: workgroup id b runs on XCD b % 8 (each XCD has its own L2).  All N-tiles of one M-tile are
   // given ids congruent mod 8, so the A tile they share is fetched into ONE L2 instead of one per N-tile
   // (rocprof FETCH_SIZE on the QKV GEMM: 41 MB -> 14 MB).
@@ -165,62 +169,69 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < WV; ++i) Wp[i] = a.W + (long long)min(n0 + lrow + RPT * i, a.N - 1) * a.ldw + c4 * 4;
 
-  float4 ra[AV], rw[WV];
-  auto load_global = [&](int kt) {
+  float4 ra[PF][AV], rw[PF][WV];
+  auto load_global = [&](int kt, int slot) {
     const int k = kt * BK;
     if (k + c4 * 4 < a.K) {
 #pragma unroll
-      for (int i = 0; i < AV; ++i) ra[i] = *(const float4*)(Ap[i] + k);
+      for (int i = 0; i < AV; ++i) ra[slot][i] = *(const float4*)(Ap[i] + k);
 #pragma unroll
-      for (int i = 0; i < WV; ++i) rw[i] = *(const float4*)(Wp[i] + k);
+      for (int i = 0; i < WV; ++i) rw[slot][i] = *(const float4*)(Wp[i] + k);
     } else {
 #pragma unroll
-      for (int i = 0; i < AV; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < AV; ++i) ra[slot][i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int i = 0; i < WV; ++i) rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < WV; ++i) rw[slot][i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](int buf, int slot) {
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
-      float4 v = ra[i];
+      float4 v = ra[slot][i];
       if (PRO == PRO_ACT) v = act4(v, a.act);
       *(float4*)(As + buf * BM * LS + (lrow + RPT * i) * LS + c4 * 4) = v;
     }
 #pragma unroll
-    for (int i = 0; i < WV; ++i) *(float4*)(Ws + buf * BN * LS + (lrow + RPT * i) * LS + c4 * 4) = rw[i];
+    for (int i = 0; i < WV; ++i) *(float4*)(Ws + buf * BN * LS + (lrow + RPT * i) * LS + c4 * 4) = rw[slot][i];
   };
 
   const int nk = (a.K + BK - 1) / BK;
   const int dbg = a.debug;
-  load_global(0);
-  store_lds(0);
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (u < nk) load_global(u, u);
+  store_lds(0, 0);
   __syncthreads();
   const int frow = lane & 31, fk = 4 * (lane >> 5);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk && !(dbg & 2)) load_global(kt + 1);
-    const float* Ab = As + buf * BM * LS + (wr * (BM / 2) + frow) * LS + fk;
-    const float* Wb = Ws + buf * BN * LS + (wc * (BN / 2) + frow) * LS + fk;
+  for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 8) {
-      float4 af[TM], bf[TN];
+    for (int u = 0; u < PF; ++u) {   // tile kt lives in register slot kt % PF == u (kt0 is a multiple of PF)
+      const int kt = kt0 + u;
+      if (kt >= nk) break;
+      const int buf = kt & 1;
+      if (kt + PF < nk && !(dbg & 2)) load_global(kt + PF, u);   // slot u is free: tile kt went to LDS one step ago
+      const float* Ab = As + buf * BM * LS + (wr * (BM / WM) + frow) * LS + fk;
+      const float* Wb = Ws + buf * BN * LS + (wc * (BN / WN) + frow) * LS + fk;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *(const float4*)(Ab + i * 32 * LS + kk);
+      for (int kk = 0; kk < BK; kk += 8) {
+        float4 af[TM], bf[TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *(const float4*)(Wb + j * 32 * LS + kk);
+        for (int i = 0; i < TM; ++i) af[i] = *(const float4*)(Ab + i * 32 * LS + kk);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) bf[j] = *(const float4*)(Wb + j * 32 * LS + kk);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      if (kt + 1 < nk) store_lds(buf ^ 1, (u + 1) % PF);
+      __syncthreads();
     }
-    if (kt + 1 < nk) store_lds(buf ^ 1);
-    __syncthreads();
   }
 
   if (dbg & 1) {   // tuning aid: no epilogue at all (keeps the accumulators alive through one dummy store)
@@ -236,10 +247,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int nl = wc * (BN / 2) + j * 32 + lcol;
+        const int nl = wc * (BN / WN) + j * 32 + lcol;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int ml = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
+          const int ml = wr * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
           Cs[ml * CS + nl] = acc[i][j][r];
         }
       }
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   epilogue_from_lds<BM, BN, EPI>(Cs, m0, n0, tid, a);
 }
 
-template <int BM, int BN, int PRO, int EPI, int BK = 32>
+template <int BM, int BN, int PRO, int EPI, int BK = 32, int PF = 1>
 static int launch_nt(const GemmArgs& a, hipStream_t st) {
   constexpr int LS = BK + 4;
   const long long nblk = 8LL * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN);
@@ -257,12 +268,20 @@ static int launch_nt(const GemmArgs& a, hipStream_t st) {
   size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
   const size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
   if (cs > lds) lds = cs;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI, BK>,
+  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI, BK, PF>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, PRO, EPI, BK>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, PRO, EPI, BK, PF>), grid, dim3(256), lds, st, a);
   UR_LAUNCH_CHECK();
   return UR_OK;
+}
+
+// Few rows (the last-row layer, the GRU's per-step GEMM): 64-row tiles leave most CUs idle and each workgroup MFMA-bound
+// on its own K loop (M = 512, N = 128, K = 512: 8 workgroups x 13.7 us of MFMA).  32-row tiles double the workgroups.
+static bool small_m(const GemmArgs& a) {
+  static const int force = getenv("UR_GEMM_SMALLM") ? atoi(getenv("UR_GEMM_SMALLM")) : -1;   // tuning aid: 0 = never, 1 = always
+  if (force >= 0) return force == 1;
+  return a.M <= 1024;
 }
 
 template <int PRO, int EPI>
@@ -271,6 +290,7 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
   const long long big = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
   static const int force = getenv("UR_GEMM_TILE") ? atoi(getenv("UR_GEMM_TILE")) : 0;   // tuning aid: 64 or 128 rows
   if (a.N <= 64) return launch_nt<64, 64, PRO, EPI>(a, st);
+  if (small_m(a)) return launch_nt<32, 128, PRO, EPI>(a, st);
   // short K, wide N (QKV, FFN-1, d-act): the 16-deep K-step variant keeps 4 workgroups per CU resident and measured
   // 6-10 % faster at M = 25600; elsewhere the 32-deep step wins
   if (force == 16 || (force == 0 && a.K <= 128 && a.N >= 256)) return launch_nt<64, 128, PRO, EPI, 16>(a, st);
@@ -288,6 +308,9 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
     return fail(UR_ERR_ARG, "gemm_nt: N, K and all leading dimensions must be multiples of 4 (N=%d K=%d)", a.N, a.K);
   if (epi == EPI_BIAS_RES_LN) {
     if (a.N > 256 || a.ldc != a.N) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm needs N<=256 (N=%d)", a.N);
+    if (a.N <= 128 && small_m(a))
+      return pro == PRO_ACT ? launch_nt<32, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
+                            : launch_nt<32, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
     if (a.N <= 128) return pro == PRO_ACT ? launch_nt<64, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
                                           : launch_nt<64, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
     return pro == PRO_ACT ? launch_nt<64, 256, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
