@@ -145,9 +145,9 @@ def _gpu_worker(rank, world, port, q):
         st.table[local[owner == rank].to(dev)] = T0[owner == rank].to(dev)
         B = 16
         losses = []
-        for b in _batches(3, B * world):
-            mine = {k: v[rank * B:(rank + 1) * B].to(dev).contiguous() for k, v in b.items()}
-            losses.append(float(st.step(mine)))
+        mine = [{k: v[rank * B:(rank + 1) * B].to(dev).contiguous() for k, v in b.items()} for b in _batches(3, B * world)]
+        for i, b in enumerate(mine):   # with the plan lookahead (next batch's id sort on a side stream); the 1-rank run has none
+            losses.append(float(st.step(b, mine[i + 1] if i + 1 < len(mine) else None)))
         st.flush()
         full = st.gather_table().cpu()
         dense = st.model.dense_flat.data.cpu()

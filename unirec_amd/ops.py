@@ -186,23 +186,22 @@ def rows_plan(ids_a, ids_b, n_rows, out=None) -> RowsPlan:
     return pl
 
 
-def rows_plan_sharded(ids_a, ids_b, n_rows, world):
+def rows_plan_sharded(ids_a, ids_b, n_rows, world, out=None):
     """Like rows_plan, but keys are (owner = id % world, local row = id // world); returns (plan, owner_counts[world] int32 dev).
-    plan.uniq_idx holds the sharded keys owner * ceil(n_rows/world) + local_row."""
+    plan.uniq_idx holds the sharded keys owner * ceil(n_rows/world) + local_row.
+    out: ((RowsPlan, workspace), counts) preallocated by the caller (rows_plan_alloc + an int32[world] tensor)."""
     dev = (ids_a if ids_a is not None else ids_b).device
     n_a = ids_a.numel() if ids_a is not None else 0
     n_b = ids_b.numel() if ids_b is not None else 0
     _chk(ids_a, torch.int32, "ids_a", allow_none=True)
     _chk(ids_b, torch.int64, "ids_b", allow_none=True)
     n = n_a + n_b
-    pl = RowsPlan()
-    pl.n, pl.n_a = n, n_a
-    pl.uniq_idx = torch.empty(n, dtype=torch.int32, device=dev)
-    pl.seg_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
-    pl.sorted_pos = torch.empty(n, dtype=torch.int32, device=dev)
-    pl.n_uniq = torch.empty(1, dtype=torch.int32, device=dev)
-    counts = torch.empty(world, dtype=torch.int32, device=dev)
-    ws = torch.empty(check(lib.ur_rows_plan_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    if out is not None:
+        (pl, ws), counts = out
+        assert pl.n == n and pl.n_a == n_a and counts.numel() == world
+    else:
+        pl, ws = rows_plan_alloc(n, n_a, dev)
+        counts = torch.empty(world, dtype=torch.int32, device=dev)
     check(lib.ur_rows_plan_sharded(_p(ids_a), n_a, _p(ids_b), n_b, int(n_rows), int(world), _p(pl.uniq_idx), _p(pl.seg_start),
                                    _p(pl.sorted_pos), _p(pl.n_uniq), _p(counts), _p(ws), _stream()), "ur_rows_plan_sharded")
     return pl, counts

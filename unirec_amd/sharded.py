@@ -110,6 +110,7 @@ class ShardedSasrecStep:
         self.zero_coef = torch.zeros(1, dtype=torch.float32, device=device)
         self.loss_type = model_cfg["loss_type"]
         self.tau = model_cfg.get("tau", 1.0)
+        self._side, self._prefetched = None, None
 
     # ---- the step ------------------------------------------------------------------------------------------
     def step(self, batch, next_batch=None):
@@ -119,10 +120,12 @@ class ShardedSasrecStep:
         G = item_id.shape[1]
         self.t += 1
         acfg = ops.adam_cfg(self.lr, self.t, self.wd)
-        # 1. plan: unique (owner, row) keys of this batch; a trailing lookup of id 0 pins compact row 0 = padding row
-        ids_a = item_seq.reshape(-1)
-        ids_b = torch.cat([item_id.reshape(-1), self.zero_id])
-        pl, counts_dev = ops.rows_plan_sharded(ids_a, ids_b, self.N, W)
+        # 1. plan: unique (owner, row) keys of this batch; a trailing lookup of id 0 pins compact row 0 = padding row.
+        #    Local work that depends on the ids only: the plan of the NEXT batch is started on a side stream here (no
+        #    collective runs there), so from the second step on this is just an event wait.
+        pl, counts_dev = self._take_plan(batch)
+        if next_batch is not None:
+            self._prefetch_plan(next_batch)
         send_counts, recv_counts = self.xchg.exchange_counts_dev(counts_dev)   # the one host sync of the step (2W ints)
         n_uniq = sum(send_counts)
         keys = pl.uniq_idx[:n_uniq]
@@ -158,6 +161,35 @@ class ShardedSasrecStep:
             dist.all_reduce(dense_grad)
         ops.dense_adam(acfg, m.dense_flat.data, dense_grad, self.dense_m, self.dense_v, self.inv_w)
         return loss_out[0]
+
+    # ---- plan lookahead (ids only; mirrors SparseDenseAdam.prefetch_plan) ------------------------------------
+    def _plan_ids(self, batch):
+        return batch["item_seq"].reshape(-1), torch.cat([batch["item_id"].reshape(-1), self.zero_id])
+
+    def _prefetch_plan(self, batch):
+        if not batch["item_seq"].is_cuda:
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ids_a, ids_b = self._plan_ids(batch)                 # built (and later released) under the main stream
+        n, n_a = ids_a.numel() + ids_b.numel(), ids_a.numel()
+        bufs = (ops.rows_plan_alloc(n, n_a, self.device), torch.empty(self.world, dtype=torch.int32, device=self.device))
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            pl, counts = ops.rows_plan_sharded(ids_a, ids_b, self.N, self.world, out=bufs)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._prefetched = ((batch["item_seq"].data_ptr(), batch["item_id"].data_ptr()), pl, counts, ev, (ids_a, ids_b, bufs))
+
+    def _take_plan(self, batch):
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None:
+            torch.cuda.current_stream().wait_event(pre[3])
+            if pre[0] == (batch["item_seq"].data_ptr(), batch["item_id"].data_ptr()):
+                return pre[1], pre[2]
+        ids_a, ids_b = self._plan_ids(batch)
+        return ops.rows_plan_sharded(ids_a, ids_b, self.N, self.world)
 
     def flush(self):
         if self.last is not None and self.t > 0:
