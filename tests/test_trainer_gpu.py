@@ -58,3 +58,38 @@ def test_fit_losses_follow_the_oracle(model_name, loss):
         np.testing.assert_allclose(v.cpu().numpy(), P[k].numpy(), rtol=1e-3, atol=1e-4, err_msg=k)
     res = tr.evaluate(BatchLoader(ds2, 64, device="cuda:0"), load_best_model=False)
     assert 0.0 <= res["hit@5"] <= 1.0 and 0.0 < res["mrr"] <= 1.0
+
+
+def test_prepared_dataset_directory_trains_and_evaluates():
+    """SURVEY.md 8 f3 end to end: the reference's on-disk files (tests/golden/g12_dataset) -> datasets -> Trainer.fit ->
+    one_vs_all evaluation with the history loaded from user_history.pkl."""
+    import os
+    from conftest import GOLDEN
+    from unirec_amd.data.dataset.seqrecdataset import SeqRecDataset
+    from unirec_amd.data.transform.addnegsamples import AddNegSamples
+    from unirec_amd.data.transform.adduserhistory import AddUserHistory
+    from unirec_amd.facility.trainer import BatchLoader, Trainer
+    from unirec_amd.utils.argument_parser import parse_arguments
+    from unirec_amd.utils.file_io import load_data_info
+    from unirec_amd.utils.general import get_class_instance, init_seed, load_user_history
+    ddir = os.path.join(GOLDEN, "g12_dataset")
+    info = load_data_info(ddir)
+    u2h, _ = load_user_history(ddir, "user_history", n_users=info["n_users"], format=info["user_history_file_format"])
+    cfg = parse_arguments(dict(model="SASRec", n_users=info["n_users"], n_items=info["n_items"], device="cuda:0", loss_type="softmax",
+                               embedding_size=32, hidden_size=32, inner_size=64, n_heads=4, max_seq_len=8, epochs=2, batch_size=64,
+                               seed=3, n_sample_neg_train=4, history_mask_mode="autoregressive"))
+    init_seed(3)
+
+    def dataset(name):
+        ds = SeqRecDataset(cfg, path=ddir, filename=name, transform=AddNegSamples(info["n_users"], info["n_items"], 4, user2history=u2h, seed=3))
+        ds.add_user_history_transform(AddUserHistory(u2h, "autoregressive", seq_last=0))
+        return ds
+    model = get_class_instance("SASRec", "unirec_amd/model")(cfg)
+    tr = Trainer(cfg, model)
+    tr.fit(BatchLoader(dataset("train"), 64, device="cuda:0"), save_model=False)
+    assert len(tr.step_losses) == 2 * 5 and np.isfinite(tr.step_losses).all()
+    assert np.mean(tr.step_losses[5:]) < np.mean(tr.step_losses[:5])           # it learns something
+    tr.set_user_history(u2h)
+    tr.reset_evaluator("user-item", "one_vs_all")
+    res = tr.evaluate(BatchLoader(dataset("valid"), 64, device="cuda:0"), load_best_model=False)
+    assert 0.0 < res["mrr"] <= 1.0 and 0.0 <= res["hit@10"] <= 1.0 and 0.0 < res["group_auc"] <= 1.0

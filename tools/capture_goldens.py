@@ -335,6 +335,44 @@ def main():
             arrs["metric." + k] = np.array(v, dtype=np.float64)
         save("g11_fullrank_" + tag, **arrs)
 
+    # ---------------------------------------------------------------- G12 on-disk formats (prepared-dataset directory)
+    # small pickled frames in the reference's formats + what the reference's own loaders make of them
+    if not ONLY or any("g12".startswith(p) or p.startswith("g12") for p in ONLY):
+        import pandas as pd
+        from unirec.utils.general import load_user_history
+        from unirec.data.dataset.basedataset import BaseDataset as RefBaseDataset
+        ddir = os.path.join(OUT, "g12_dataset")
+        os.makedirs(ddir, exist_ok=True)
+        r12 = np.random.default_rng(1212)
+        n_users, n_items = 30, 90
+        users = r12.integers(1, n_users, 400)
+        users = users[users != 7]                                    # user 7 has no interactions
+        items = r12.integers(1, n_items, len(users))
+        full = pd.DataFrame({"user_id": users.astype(np.int64), "item_id": items.astype(np.int64)})
+        full.iloc[:300].to_pickle(os.path.join(ddir, "train.pkl"))
+        full.iloc[300:].reset_index(drop=True).to_pickle(os.path.join(ddir, "valid.pkl"))
+        full.to_pickle(os.path.join(ddir, "user_history.pkl"))      # 'user-item' history: one interaction per row
+        seq_df = full.groupby("user_id")["item_id"].apply(lambda x: np.array(x, dtype=np.int32)).to_frame().reset_index()
+        seq_df.columns = ["user_id", "item_seq"]
+        seq_df.to_pickle(os.path.join(ddir, "user_history_seq.pkl"))  # 'user-item_seq' history: one row per user
+        with open(os.path.join(ddir, "data.info"), "w") as f:
+            import json
+            json.dump({"n_users": n_users, "n_items": n_items, "train_file_format": "user-item", "user_history_file_format": "user-item"}, f)
+        h1, _ = load_user_history(ddir, "user_history", n_users=n_users, format="user-item")
+        h5, _ = load_user_history(ddir, "user_history_seq", n_users=n_users, format="user-item_seq")
+        h_inf, _ = load_user_history(ddir, "user_history", n_users=None, format="user-item")
+        ds = RefBaseDataset.__new__(RefBaseDataset)
+        import logging
+        ds.logger = logging.getLogger("g12")
+        train = ds.load_data(ddir, "train")
+        arrs = {"n_users": np.array(n_users), "inferred_n_users": np.array(len(h_inf)),
+                "train": train[["user_id", "item_id"]].values.astype(np.int64)}
+        for tag, h in (("h1", h1), ("h5", h5)):
+            arrs[tag + ".ptr"] = np.cumsum([0] + [0 if x is None else len(x) for x in h]).astype(np.int64)
+            arrs[tag + ".items"] = np.concatenate([np.asarray(x) for x in h if x is not None]).astype(np.int64)
+            arrs[tag + ".isnone"] = np.array([x is None for x in h])
+        save("g12_on_disk_expected", **arrs)
+
 
 if __name__ == "__main__":
     main()

@@ -33,6 +33,23 @@ class HistoryCSR:
         self.n_users = n
         self._dev = None
 
+    # ---- flat binary form (convert a pickled user_history once, reload in milliseconds) ----------------------
+    def save(self, filename):
+        """<filename>.npz with ptr int64[n_users+1] and items int32[nnz] in per-user (time) order."""
+        np.savez(filename, ptr=self.ptr, items=self.items)
+
+    @classmethod
+    def load(cls, filename):
+        z = np.load(filename if str(filename).endswith(".npz") else str(filename) + ".npz")
+        self = cls.__new__(cls)
+        self.ptr, self.items = z["ptr"].astype(np.int64), z["items"].astype(np.int32)
+        self.n_users = len(self.ptr) - 1
+        self.sorted = self.items.copy()
+        for u in np.flatnonzero(np.diff(self.ptr) > 1):
+            self.sorted[self.ptr[u]:self.ptr[u + 1]].sort()
+        self._dev = None
+        return self
+
     def to_device(self, device):
         if self._dev is None or self._dev[0].device != torch.device(device):
             self._dev = (torch.from_numpy(self.ptr).to(device), torch.from_numpy(self.sorted).to(device))
