@@ -235,6 +235,19 @@ int ur_sample_negatives(const int64_t* user_id, const int64_t* pos_item, int32_t
                         int64_t n_users, const int64_t* hist_ptr, const int32_t* hist_sorted, uint64_t seed,
                         uint32_t step, int64_t* item_id, int32_t* label, void* stream);
 
+/* DEVICE history rows: item_seq[b,:] = left_pad(AddUserHistory(history(user_b), ids_b), L) for a
+ * whole batch from a CSR history resident in HBM -- adduserhistory.py:32-73 + seqrecdataset.py:60-68 without the
+ * per-sample Python __getitem__.  hist_items: per-user interaction (time) order.  item_id int64[B,G]: the row's id group
+ * (positive in column 0).  mask_mode 0 'unorder', 1 'autoregressive', 2 unchanged; seq_last as the reference's.
+ * match_all 0: only the positive can occur in the history (negatives sampled with history rejection); 1: compare all G.
+ * The autoregressive cut without seq_last picks occurrence (philox4x32_10(step,row,0xFFFFFFFF,0)[0] * count) >> 32
+ * (bit-exact vs oracle/philox_ref.py; the host builder reproduces the reference's MT19937 stream instead).
+ * item_seq int32[B,L]; seq_len int64[B] (nullable) = min(len(history'), L), 1 for users without history. */
+int ur_device_build_seq(const int64_t* user_id, const int64_t* item_id, int32_t B, int32_t G, int64_t n_users,
+                        const int64_t* hist_ptr, const int32_t* hist_items, int32_t mask_mode, int32_t seq_last,
+                        int32_t match_all, int32_t L, uint64_t seed, uint32_t step, int32_t* item_seq, int64_t* seq_len,
+                        void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The two fp32-MFMA GEMM kernels of the encoders, exposed for unit tests and micro-benchmarks.
  *   ur_gemm_nt: C[M,N] = epi( pro(A)[M,K] @ W[N,K]^T )  == nn.Linear (unirec/model/modules.py:285-287,312,347-350)

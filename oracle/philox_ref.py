@@ -59,3 +59,40 @@ def sample_negatives(user_id, pos_item, K, n_items, hist_ptr=None, hist_sorted=N
                     out[b, k] = cand
                     break
     return out
+
+
+def build_seq(user_id, item_id, hist_ptr, hist_items, L, mask_mode="autoregressive", seq_last=0, match_all=False, seed=0, step=0):
+    """numpy restatement of ur_device_build_seq: AddUserHistory (unirec/data/transform/adduserhistory.py:32-73) + left
+    padding (unirec/data/dataset/seqrecdataset.py:60-68); the autoregressive cut picks occurrence
+    (philox(step, row, 0xFFFFFFFF, 0)[0] * count) >> 32 unless seq_last.  -> (item_seq int32[B,L], seq_len int64[B])."""
+    item_id = np.asarray(item_id, dtype=np.int64)
+    B = len(user_id)
+    n_users = len(hist_ptr) - 1
+    seq = np.zeros((B, L), dtype=np.int32)
+    slen = np.zeros(B, dtype=np.int64)
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for b in range(B):
+        u = int(user_id[b])
+        hist = np.asarray(hist_items[hist_ptr[u]:hist_ptr[u + 1]], dtype=np.int32) if 0 <= u < n_users else np.zeros(0, np.int32)
+        if len(hist) == 0:
+            slen[b] = min(1, L)          # the reference substitutes [0]
+            continue
+        ids = set(int(x) for x in item_id[b]) if match_all else {int(item_id[b, 0])}
+        hit = np.array([int(h) in ids for h in hist])
+        if mask_mode == "unorder":
+            hist = np.where(hit, 0, hist).astype(np.int32)
+        elif mask_mode == "autoregressive" and hit.any():
+            occ = np.flatnonzero(hit)
+            if seq_last:
+                t = len(occ) - 1
+            else:
+                w = philox4x32_10([step], [b], [0xFFFFFFFF], [0], k0, k1)
+                t = (int(w[0][0]) * len(occ)) >> 32
+            hist = hist[: occ[t]]
+        n = len(hist)
+        if n >= L:
+            seq[b] = hist[n - L:]
+        elif n:
+            seq[b, L - n:] = hist
+        slen[b] = min(n, L)
+    return seq, slen

@@ -147,3 +147,44 @@ def test_device_sampler_bit_exact_vs_philox_oracle_and_distribution():
     csr2 = HistoryCSR(_u2h(None, np.arange(1, 8)))
     ex, _ = sample_negatives_device(torch.tensor([3], device=dev), 3, 8, torch.tensor([1], device=dev), csr2, seed=1)
     assert ex.cpu().tolist() == [[3, 0, 0, 0]]
+
+
+# ------------------------------------------------------------------------------------------ device row builder (8 f2)
+def _random_history(rng, n_users, n_items, max_len):
+    u2h = np.empty(n_users, dtype=object)
+    for u in range(n_users):
+        n = int(rng.integers(0, max_len))
+        u2h[u] = None if (n == 0 or u % 9 == 0) else rng.integers(1, n_items, n).astype(np.int32)
+    return u2h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mask_mode,seq_last,reject", [("autoregressive", 0, True), ("autoregressive", 1, True), ("unorder", 0, True),
+                                                       ("autoregressive", 0, False), ("unorder", 0, False)])
+def test_device_row_builder_bit_exact_vs_philox_oracle(mask_mode, seq_last, reject):
+    import torch
+    from oracle import data_ref, philox_ref
+    from unirec_amd.data.rows import DeviceRowBuilder, HistoryCSR
+    rng = np.random.default_rng(17)
+    n_users, n_items, K, L, B = 70, 60, 5, 12, 300      # small catalogue: repeated items, positives occurring several times
+    u2h = _random_history(rng, n_users, n_items, 150)
+    csr = HistoryCSR(u2h)
+    user = rng.integers(0, n_users + 4, B).astype(np.int64)          # some users beyond the table
+    pos = rng.integers(1, n_items, B).astype(np.int64)
+    for b in range(0, B, 2):                                          # make the positive an item of the user's history
+        if user[b] < n_users and u2h[user[b]] is not None:
+            pos[b] = int(rng.choice(u2h[user[b]]))
+    bld = DeviceRowBuilder(n_users, n_items, K, L, csr, reject_history=reject, mask_mode=mask_mode, seq_last=seq_last, seed=99)
+    out = bld.build(torch.from_numpy(user).cuda(), torch.from_numpy(pos).cuda(), step=7)
+    item_id = out["item_id"].cpu().numpy()
+    ref_ids = philox_ref.sample_negatives(user, pos, K, n_items, csr.ptr if reject else None, csr.sorted if reject else None, seed=99, step=7)
+    assert np.array_equal(item_id, ref_ids)
+    seq, slen = philox_ref.build_seq(user, item_id, csr.ptr, csr.items, L, mask_mode, seq_last, match_all=not reject, seed=99, step=7)
+    assert np.array_equal(out["item_seq"].cpu().numpy(), seq)
+    assert np.array_equal(out["item_seq_len"].cpu().numpy(), slen)
+    assert np.array_equal(out["label"].cpu().numpy()[:, 0], np.ones(B, np.int32)) and out["label"].sum().item() == B
+    if seq_last or mask_mode == "unorder":
+        # no random choice involved: must equal the reference-pinned host restatement (oracle/data_ref.py) too
+        for b in range(B):
+            h, hl = data_ref.add_user_history(None, int(user[b]), item_id[b], u2h, mask_mode, seq_last)
+            assert np.array_equal(data_ref.left_pad(h, L), seq[b]) and min(hl, L) == slen[b], b

@@ -70,6 +70,73 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(const long long* 
   item_id[t] = picked;
 }
 
+
+// ------------------------------------------------------------------------------------------------ history rows
+// item_seq[b,:] for a batch, on the device: AddUserHistory (unirec/data/transform/adduserhistory.py:
+// 32-73) + the left padding of SeqRecDataset (unirec/data/dataset/seqrecdataset.py:60-68) over a CSR history in HBM.
+//   'unorder'        : history items that occur in the row's id group are zeroed;
+//   'autoregressive' : the history is cut before one occurrence of an id of the group -- the last one (seq_last) or a
+//                      uniformly chosen one: index = (philox(step, row, 0xFFFFFFFF, 0)[0] * count) >> 32;
+//   then the last L items, left-padded with 0.  A user without history yields the reference's [0] (length 1).
+// One wave per row.  match_all = 0: only the positive (column 0) can occur in the history (negatives were sampled with
+// history rejection); 1: every id of the group is compared.
+__global__ __launch_bounds__(256) void build_seq_kernel(const long long* __restrict__ user_id, const long long* __restrict__ item_id,
+                                                        int B, int G, long long n_users, const long long* __restrict__ hist_ptr,
+                                                        const int* __restrict__ hist_items, int mask_mode, int seq_last, int match_all,
+                                                        int L, uint32_t seed_lo, uint32_t seed_hi, uint32_t step,
+                                                        int* __restrict__ item_seq, long long* __restrict__ seq_len) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;   // wave-uniform
+  const long long u = user_id[b];
+  const bool known = u >= 0 && u < n_users;
+  const long long hb = known ? hist_ptr[u] : 0, he = known ? hist_ptr[u + 1] : 0;
+  const long long len = he - hb;
+  const long long* ids = item_id + (long long)b * G;
+  const long long pos = ids[0];
+  auto match = [&](int h) -> bool {
+    if (!match_all) return (long long)h == pos;
+    bool m = false;
+    for (int g = 0; g < G; ++g) m |= ids[g] == (long long)h;
+    return m;
+  };
+  long long keep = len;   // history[:keep] survives
+  if (mask_mode == 1 && len > 0) {
+    int count = 0;
+    for (long long c = 0; c < len; c += 64) {
+      const long long i = c + lane;
+      count += __popcll(__ballot(i < len && match(hist_items[hb + i])));
+    }
+    if (count > 0) {
+      int t = count - 1;
+      if (!seq_last) {
+        uint32_t w[4];
+        philox4x32_10(step, (uint32_t)b, 0xFFFFFFFFu, 0u, seed_lo, seed_hi, w);
+        t = (int)(((unsigned long long)w[0] * (unsigned)count) >> 32);
+      }
+      int run = 0;
+      for (long long c = 0; c < len; c += 64) {   // position of the t-th occurrence
+        const long long i = c + lane;
+        unsigned long long m = __ballot(i < len && match(hist_items[hb + i]));
+        const int n = __popcll(m);
+        if (run + n > t) {
+          for (int k = t - run; k > 0; --k) m &= m - 1;
+          keep = c + (__ffsll((long long)m) - 1);
+          break;
+        }
+        run += n;
+      }
+    }
+  }
+  for (int j = lane; j < L; j += 64) {
+    const long long src = keep - L + j;
+    int v = src >= 0 ? hist_items[hb + src] : 0;
+    if (mask_mode == 0 && src >= 0 && match(v)) v = 0;
+    item_seq[(long long)b * L + j] = v;
+  }
+  if (lane == 0 && seq_len) seq_len[b] = len == 0 ? (L < 1 ? L : 1) : (keep < L ? keep : L);
+}
+
 }  // namespace ur
 
 using namespace ur;
@@ -86,6 +153,22 @@ extern "C" int ur_sample_negatives(const int64_t* user_id, const int64_t* pos_it
   hipLaunchKernelGGL(sample_negatives_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const long long*)user_id,
                      (const long long*)pos_item, B, K, (long long)n_items, (long long)n_users, (const long long*)hist_ptr, hist_sorted,
                      (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step, (long long*)item_id, label);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_device_build_seq(const int64_t* user_id, const int64_t* item_id, int32_t B, int32_t G, int64_t n_users,
+                                   const int64_t* hist_ptr, const int32_t* hist_items, int32_t mask_mode, int32_t seq_last,
+                                   int32_t match_all, int32_t L, uint64_t seed, uint32_t step, int32_t* item_seq, int64_t* seq_len,
+                                   void* stream) {
+  UR_REQUIRE(user_id && item_id && hist_ptr && hist_items && item_seq, UR_ERR_ARG, "ur_device_build_seq: null pointer");
+  UR_REQUIRE(B > 0 && G > 0 && L > 0 && n_users >= 0, UR_ERR_ARG, "ur_device_build_seq: B=%d G=%d L=%d", B, G, L);
+  UR_REQUIRE(mask_mode >= 0 && mask_mode <= 2, UR_ERR_ARG, "ur_device_build_seq: mask_mode=%d", mask_mode);
+  hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_MISC, st, (double)B * L * 4.0);
+  hipLaunchKernelGGL(build_seq_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, (const long long*)user_id, (const long long*)item_id, B, G,
+                     (long long)n_users, (const long long*)hist_ptr, hist_items, mask_mode, seq_last, match_all, L,
+                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step, item_seq, (long long*)seq_len);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

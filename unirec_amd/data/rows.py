@@ -55,6 +55,12 @@ class HistoryCSR:
             self._dev = (torch.from_numpy(self.ptr).to(device), torch.from_numpy(self.sorted).to(device))
         return self._dev
 
+    def items_to_device(self, device):
+        """hist_items (per-user time order) on the device, for the device row builder."""
+        if getattr(self, "_dev_items", None) is None or self._dev_items.device != torch.device(device):
+            self._dev_items = torch.from_numpy(self.items).to(device)
+        return self._dev_items
+
 
 def _hp(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
@@ -122,3 +128,44 @@ def sample_negatives_device(pos_item, K, n_items, user_id=None, history: History
                                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(step) & 0xFFFFFFFF, p(item_id), p(label),
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ur_sample_negatives")
     return item_id, label
+
+
+class DeviceRowBuilder:
+    """Device-resident input pipeline: a batch of (user, positive item) pairs already in HBM becomes
+    item_id / label / item_seq / item_seq_len with two launches (ur_sample_negatives, ur_device_build_seq) and no host
+    round trip.  Same rules as AddNegSamples + AddUserHistory + left padding; the random source is the counter-based
+    Philox generator (order independent, keyed by (seed, step, row, slot)), not the reference's MT19937 stream -- that
+    one is reproduced by HostRowBuilder."""
+    MASK = {"unorder": 0, "autoregressive": 1}
+
+    def __init__(self, n_users, n_items, n_neg, max_seq_len=0, history: HistoryCSR = None, reject_history=True,
+                 mask_mode="autoregressive", seq_last=0, seed=2022, device="cuda:0"):
+        self.n_users, self.n_items, self.n_neg, self.L = n_users, n_items, n_neg, max_seq_len
+        self.history, self.reject, self.seq_last, self.seed = history, bool(reject_history), int(seq_last), int(seed)
+        self.mask_mode = self.MASK.get(mask_mode, 2)
+        self.device = torch.device(device)
+        self.step = 0
+
+    def build(self, user_id, pos_item, with_seq=True, step=None):
+        """user_id, pos_item: int64 device tensors [B]."""
+        step = self.step if step is None else int(step)
+        self.step = step + 1
+        dev = pos_item.device
+        B, G = pos_item.numel(), self.n_neg + 1
+        item_id, label = sample_negatives_device(pos_item, self.n_neg, self.n_items, user_id,
+                                                 self.history if self.reject else None, self.seed, step)
+        out = dict(user_id=user_id, item_id=item_id, label=label)
+        if with_seq and self.L > 0:
+            if self.history is None:
+                raise RuntimeError("item_seq needs a user history")
+            ptr, _ = self.history.to_device(dev)
+            items = self.history.items_to_device(dev)
+            seq = torch.empty(B, self.L, dtype=torch.int32, device=dev)
+            slen = torch.empty(B, dtype=torch.int64, device=dev)
+            p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            check(lib.ur_device_build_seq(p(user_id.contiguous()), p(item_id), B, G, self.history.n_users, p(ptr), p(items), self.mask_mode,
+                                          self.seq_last, 0 if self.reject else 1, self.L, self.seed & 0xFFFFFFFFFFFFFFFF,
+                                          step & 0xFFFFFFFF, p(seq), p(slen), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                  "ur_device_build_seq")
+            out["item_seq"], out["item_seq_len"] = seq, slen
+        return out

@@ -37,6 +37,37 @@ class BatchLoader:
             yield {k: torch.from_numpy(v).to(self.device, non_blocking=True) for k, v in rows.items()}
 
 
+class DeviceBatchLoader:
+    """Device-resident input pipeline: the (user, item) interaction pairs live in HBM and every batch
+    is built there by ``DeviceRowBuilder`` (negatives, history cut, left padding: two launches, no host work, no H2D
+    copy).  Sharding and last-partial-batch behaviour as ``BatchLoader``."""
+
+    def __init__(self, pairs, builder, batch_size, shuffle=False, seed=2022, rank=0, world=1, with_seq=True):
+        dev = builder.device
+        self.pairs = (pairs if torch.is_tensor(pairs) else torch.from_numpy(np.asarray(pairs).astype(np.int64))).to(dev).contiguous()
+        self.builder, self.batch_size, self.shuffle, self.seed = builder, batch_size, shuffle, seed
+        self.rank, self.world, self.with_seq, self.epoch = rank, world, with_seq, 0
+
+    def __len__(self):
+        nb = (len(self.pairs) + self.batch_size - 1) // self.batch_size
+        return (nb - self.rank + self.world - 1) // self.world
+
+    def __iter__(self):
+        n, B = len(self.pairs), self.batch_size
+        dev = self.pairs.device
+        if self.shuffle:
+            g = torch.Generator(device=dev).manual_seed(self.seed + self.epoch)
+            order = torch.randperm(n, generator=g, device=dev)
+        else:
+            order = torch.arange(n, device=dev)
+        nb = (n + B - 1) // B
+        base = self.epoch * nb
+        self.epoch += 1
+        for b in range(self.rank, nb, self.world):
+            sel = self.pairs[order[b * B:(b + 1) * B]]
+            yield self.builder.build(sel[:, 0].contiguous(), sel[:, 1].contiguous(), with_seq=self.with_seq, step=base + b)
+
+
 class Trainer(object):
     def __init__(self, config, model, accelerator=None):
         self.config, self.model, self.accelerator = config, model, accelerator
