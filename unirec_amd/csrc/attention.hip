@@ -20,6 +20,8 @@
 //     max |delta| == 0).  Those rows are written as zeros and contribute nothing to the backward.
 //   * A sequence with no valid key at all (empty history) takes the literal path: every key gets
 //     s/sqrt(hd) + (-10000.0f) and the softmax runs over all L keys, exactly as torch evaluates it.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -592,6 +594,158 @@ __global__ __launch_bounds__(256) void attn_bwd_rl_kernel(const float* __restric
 long long attn_lse_floats(int B, int H, int L) { return (long long)B * H * L; }
 long long attn_bwd_ws_floats(int B, int H, int L) { return (long long)B * H * L + 64; }
 
+// ------------------------------------------------------------------------------------------------------------
+// MFMA forward for short sequences (L <= 64) and small heads (head dim 4 / 8 / 16): one wave per (sequence, head).
+//   S^T[j,i] = K_j . Q_i   : v_mfma_f32_32x32x2_f32 with A = K rows, B = Q rows; the k index of an MFMA step is a
+//                            free permutation, so lane-half h2 feeds dims [h2*HD/2, (h2+1)*HD/2) (one vector load).
+//                            Accumulator register r of lane (i = lane&31, h2) is key j = (r&3)+8*(r>>2)+4*h2:
+//                            every lane owns ONE query and 16 keys per 32x32 tile -> the softmax is lane-local plus
+//                            one cross-half shuffle.
+//   O^T[c,i] = sum_j V[j,c] P[i,j] : the probabilities are used AS THEY SIT in the accumulators as the B operand of
+//                            step r (again a k permutation: step r <-> keys {(r&3)+8*(r>>2)+4*h2}); A = V gathered in
+//                            that key order.  Lane (i, h2) ends with O[i, 4*h2 .. 4*h2+3] (+8 for HD = 16): one
+//                            16-byte store.
+// Masks, dead rows and the literal (-10000) path of an all-padding sequence are those of attn_fwd_rl_kernel.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, const int* __restrict__ seq, AttnDims p,
+                                                            float* __restrict__ ctx, float* __restrict__ lse) {
+  constexpr int KH = HD / 2;
+  const int lane = threadIdx.x & 63;
+  const int h = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
+  if (h >= p.H) return;
+  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  const int c32 = lane & 31, h2 = lane >> 5;
+  const float* __restrict__ base = qkv + (long long)b * L * ld + h * HD;
+  const int* __restrict__ sq = seq + (long long)b * L;
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  const bool causal = p.causal && !literal;
+  const unsigned long long kmask = __ballot(lane < L && (literal || sq[min(lane, L - 1)] > 0));   // bit j: key j may be attended
+  const int nt = L > 32 ? 2 : 1;   // 32-row tiles along keys and queries
+
+  // all global loads of the wave are issued here, in one batch: Q / K fragments and V as whole rows (lane = key);
+  // V reaches its MFMA operand layout through a 64 x HD LDS tile (one global round trip per wave instead of three)
+  __shared__ float vs_all[4][64][HD + 1];
+  float (*vs)[HD + 1] = vs_all[threadIdx.x >> 6];
+  float qf[2][KH], kf[2][KH], vrow[HD];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = min(t * 32 + c32, L - 1);
+#pragma unroll
+    for (int c = 0; c < KH; ++c) {
+      qf[t][c] = base[(long long)row * ld + h2 * KH + c];
+      kf[t][c] = base[(long long)row * ld + p.d + h2 * KH + c];
+    }
+  }
+  {
+    const int row = min(lane, L - 1);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) vrow[c] = base[(long long)row * ld + 2 * p.d + c];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) vs[lane][c] = vrow[c];
+  }
+  // ---- scores (transposed): st[jt][it][r] = K_{32 jt + jl(r)} . Q_{32 it + c32}
+  floatx16 st[2][2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[jt][it][r] = 0.f;
+      if (jt < nt && it < nt && !(causal && jt > it)) {   // wave-uniform; (key tile 1, query tile 0) is fully causal-masked
+#pragma unroll
+        for (int c = 0; c < KH; ++c) st[jt][it] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[jt][c], qf[it][c], st[jt][it], 0, 0, 0);
+      }
+    }
+  // ---- lane-local softmax over this lane's keys, both halves combined with one shuffle.  Work in base 2:
+  // p = 2^(s*log2e - m2).  Visibility of key j = 32 jt + jl + 4 h2 for query i = 32 it + c32 is a bit test on a
+  // per-lane 32-bit mask (key validity & causal limit), jl = (r&3) + 8 (r>>2) being a compile-time constant.
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  const unsigned km[2] = {(unsigned)(kmask >> (4 * h2)), (unsigned)(kmask >> (32 + 4 * h2))};
+  const int lim = c32 - 4 * h2;                                  // diagonal tiles: jl <= lim
+  const unsigned cm = !causal ? 0xFFFFFFFFu : (lim < 0 ? 0u : (lim >= 31 ? 0xFFFFFFFFu : ((2u << lim) - 1u)));
+  const float sc2 = p.scale * LOG2E;
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (it >= nt) break;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      if (jt >= nt || (causal && jt > it)) continue;
+      const unsigned vis = km[jt] & ((causal && jt == it) ? cm : 0xFFFFFFFFu);
+      if (literal) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sv = (st[jt][it][r] / p.sqrt_hd + -10000.0f) * LOG2E;
+          st[jt][it][r] = (vis >> ((r & 3) + 8 * (r >> 2))) & 1u ? sv : -INFINITY;
+          m[it] = fmaxf(m[it], st[jt][it][r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          st[jt][it][r] = (vis >> ((r & 3) + 8 * (r >> 2))) & 1u ? st[jt][it][r] * sc2 : -INFINITY;
+          m[it] = fmaxf(m[it], st[jt][it][r]);
+        }
+      }
+    }
+    m[it] = fmaxf(m[it], __shfl_xor(m[it], 32, 64));
+    const float mm = m[it] == -INFINITY ? 0.f : m[it];   // dead row: every exponent is -inf -> p = 0
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      if (jt >= nt || (causal && jt > it)) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(st[jt][it][r] - mm);   // v_exp_f32; exp2(-inf) = 0 for masked keys
+        st[jt][it][r] = pv;
+        l[it] += pv;
+      }
+    }
+    l[it] += __shfl_xor(l[it], 32, 64);
+  }
+  // ---- O^T = V^T P^T
+  floatx16 oa[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oa[it][r] = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    if (jt >= nt) break;
+    float vf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;   // keys >= L carry probability 0 (their LDS rows repeat row L-1)
+      vf[r] = c32 < HD ? vs[j][c32] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      if (it >= nt || (causal && jt > it)) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oa[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[jt][it][r], oa[it], 0, 0, 0);
+    }
+  }
+  // ---- normalise and store: lane (i, h2) holds O[i, 4*h2 + (0..3)] in oa[.][0..3] (and 8 + ... in [4..7] for HD = 16)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = it * 32 + c32;
+    if (it >= nt || i >= L) continue;
+    const bool dead = l[it] == 0.f;   // padded-prefix row of a non-empty sequence: unreachable from the loss
+    const float inv_l = dead ? 0.f : 1.0f / l[it];
+    float* out = ctx + ((long long)b * L + i) * p.d + h * HD;
+    if (HD >= 8 || h2 == 0) {
+      float4 o = make_float4(oa[it][0] * inv_l, oa[it][1] * inv_l, oa[it][2] * inv_l, oa[it][3] * inv_l);
+      *(float4*)(out + 4 * h2) = o;
+    }
+    if (HD == 16) {
+      float4 o = make_float4(oa[it][4] * inv_l, oa[it][5] * inv_l, oa[it][6] * inv_l, oa[it][7] * inv_l);
+      *(float4*)(out + 8 + 4 * h2) = o;
+    }
+    if (h2 == 0) lse[((long long)b * p.H + h) * L + i] = dead ? 0.f : (m[it] + __log2f(l[it])) * LN2;
+  }
+}
+
 static int make_dims(int B, int L, int d, int H, int causal, AttnDims* p) {
   if (H <= 0 || d % H) return fail(UR_ERR_ARG, "attention: d=%d not divisible by n_heads=%d", d, H);
   const int hd = d / H;
@@ -611,6 +765,15 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
   AttnDims p;
   int rc = make_dims(B, L, d, H, causal, &p);
   if (rc) return rc;
+  static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
+  if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
+    dim3 g2(B, cdiv(H, 4));
+    if (p.hd == 4) hipLaunchKernelGGL((attn_fwd_mfma_kernel<4>), g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
+    else if (p.hd == 8) hipLaunchKernelGGL((attn_fwd_mfma_kernel<8>), g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
+    else hipLaunchKernelGGL((attn_fwd_mfma_kernel<16>), g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
+    UR_LAUNCH_CHECK();
+    return UR_OK;
+  }
   dim3 grid(B, cdiv(H * p.nchunk, 4));
 #define GO(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, p, ctx, lse)
 #define GR(HD) hipLaunchKernelGGL((attn_fwd_rl_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, p, ctx, lse)
