@@ -746,6 +746,174 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// MFMA backward, same scope (L <= 64, head dim 4 / 8 / 16), one wave per (sequence, head), two phases:
+//   A (lane = query i):  S^T = K Q^T and dP^T = V dO^T by MFMA; dS^T = P^T (dP^T - D_i) lane-locally;
+//                        dQ^T = K^T dS^T with dS^T used as the B operand where it sits (k permutation as in the forward).
+//   B (lane = key j):    S = Q K^T and dP = dO V^T by MFMA (same values, other layout: registers run over queries);
+//                        dV^T = dO^T P and dK^T = Q^T dS, again with P / dS straight from the accumulators.
+// Q, K, V, dO rows go through per-wave LDS tiles once (lane = row, one global round trip); the "gathered" A operands
+// (rows picked in accumulator-register order) and the per-query lse / D values are read from there.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
+                                                            const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                            const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
+  constexpr int KH = HD / 2, LDSW = HD + 1;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int h = UR_UNIFORM((int)(blockIdx.y * 4 + w));
+  if (h >= p.H) return;
+  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  const int c32 = lane & 31, h2 = lane >> 5;
+  const float* __restrict__ base = qkv + (long long)b * L * ld + h * HD;
+  const int* __restrict__ sq = seq + (long long)b * L;
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  const bool causal = p.causal && !literal;
+  const unsigned long long kmask = __ballot(lane < L && (literal || sq[min(lane, L - 1)] > 0));
+  const unsigned long long qmask = __ballot(lane < L);
+  const int nt = L > 32 ? 2 : 1;
+  const float f = literal ? 1.0f / p.sqrt_hd : p.scale;   // d(score)/d(q.k)
+  const float sc2 = f * LOG2E;
+
+  __shared__ float tiles[4][4][64][LDSW];   // [wave][Q,K,V,dO][row][dim]
+  __shared__ float rowv[4][2][64];          // [wave][lse*log2e, D][row]
+  float (*qs)[LDSW] = tiles[w][0];
+  float (*ks)[LDSW] = tiles[w][1];
+  float (*vs)[LDSW] = tiles[w][2];
+  float (*gs)[LDSW] = tiles[w][3];
+  {
+    const int row = min(lane, L - 1);
+    const float* qr = base + (long long)row * ld;
+    const float* gr = dctx + ((long long)b * L + row) * p.d + h * HD;
+    const float* orr = ctx + ((long long)b * L + row) * p.d + h * HD;
+    float D = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      const float g = gr[c];
+      qs[lane][c] = qr[c];
+      ks[lane][c] = qr[p.d + c];
+      vs[lane][c] = qr[2 * p.d + c];
+      gs[lane][c] = g;
+      D = fmaf(g, orr[c], D);
+    }
+    rowv[w][0][lane] = lse[((long long)b * p.H + h) * L + row] * LOG2E;
+    rowv[w][1][lane] = D;
+  }
+  // row-type MFMA fragments: row 32 t + c32, dims h2*KH .. h2*KH + KH-1
+  float qf[2][KH], kf[2][KH], vf[2][KH], gf[2][KH];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < KH; ++c) {
+      qf[t][c] = qs[t * 32 + c32][h2 * KH + c];
+      kf[t][c] = ks[t * 32 + c32][h2 * KH + c];
+      vf[t][c] = vs[t * 32 + c32][h2 * KH + c];
+      gf[t][c] = gs[t * 32 + c32][h2 * KH + c];
+    }
+  float* orow = dqkv + (long long)b * L * ld + h * HD;
+
+  // =========================================================================== phase A: lane = query i
+  {
+    const unsigned km[2] = {(unsigned)(kmask >> (4 * h2)), (unsigned)(kmask >> (32 + 4 * h2))};
+    const int lim = c32 - 4 * h2;   // diagonal tiles: key register jl visible iff jl <= lim
+    const unsigned cm = !causal ? 0xFFFFFFFFu : (lim < 0 ? 0u : (lim >= 31 ? 0xFFFFFFFFu : ((2u << lim) - 1u)));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      if (it >= nt) break;
+      const int i = it * 32 + c32;
+      const float lse2 = rowv[w][0][i], Di = rowv[w][1][i];
+      floatx16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        if (jt >= nt || (causal && jt > it)) continue;
+        floatx16 sT, dpT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < KH; ++c) {
+          sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[jt][c], qf[it][c], sT, 0, 0, 0);
+          dpT = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[jt][c], gf[it][c], dpT, 0, 0, 0);
+        }
+        const unsigned vis = km[jt] & ((causal && jt == it) ? cm : 0xFFFFFFFFu);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = literal ? (sT[r] / p.sqrt_hd + -10000.0f) * LOG2E : sT[r] * sc2;
+          const float pv = (vis >> ((r & 3) + 8 * (r >> 2))) & 1u ? __builtin_amdgcn_exp2f(e - lse2) : 0.f;
+          sT[r] = pv * (dpT[r] - Di);   // dS^T
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float kg = c32 < HD ? ks[jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2][c32] : 0.f;
+          dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kg, sT[r], dq, 0, 0, 0);
+        }
+      }
+      if (i < L) {
+        float* out = orow + (long long)i * ld;
+        if (HD >= 8 || h2 == 0) *(float4*)(out + 4 * h2) = make_float4(dq[0] * f, dq[1] * f, dq[2] * f, dq[3] * f);
+        if (HD == 16) *(float4*)(out + 8 + 4 * h2) = make_float4(dq[4] * f, dq[5] * f, dq[6] * f, dq[7] * f);
+      }
+    }
+  }
+  // =========================================================================== phase B: lane = key j
+  {
+    const int limB = c32 - 4 * h2;   // diagonal tiles: query register il visible iff il >= limB
+    const unsigned cmB = !causal ? 0xFFFFFFFFu : (limB <= 0 ? 0xFFFFFFFFu : (limB >= 32 ? 0u : ~((1u << limB) - 1u)));
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      if (jt >= nt) break;
+      const int j = jt * 32 + c32;
+      const bool kv = (kmask >> j) & 1ull;
+      floatx16 dk, dv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        if (it >= nt || (causal && jt > it)) continue;
+        floatx16 sM, dpM;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sM[r] = 0.f; dpM[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < KH; ++c) {
+          sM = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[it][c], kf[jt][c], sM, 0, 0, 0);
+          dpM = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[it][c], vf[jt][c], dpM, 0, 0, 0);
+        }
+        const unsigned qm = (unsigned)(qmask >> (32 * it + 4 * h2));   // query rows < L
+        const unsigned vis = kv ? (qm & ((causal && jt == it) ? cmB : 0xFFFFFFFFu)) : 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int il = (r & 3) + 8 * (r >> 2), i = it * 32 + il + 4 * h2;
+          const float e = literal ? (sM[r] / p.sqrt_hd + -10000.0f) * LOG2E : sM[r] * sc2;
+          const float pv = (vis >> il) & 1u ? __builtin_amdgcn_exp2f(e - rowv[w][0][i]) : 0.f;
+          sM[r] = pv;                                  // P
+          dpM[r] = pv * (dpM[r] - rowv[w][1][i]);      // dS
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          const float gg = c32 < HD ? gs[i][c32] : 0.f;
+          const float qg = c32 < HD ? qs[i][c32] : 0.f;
+          dv = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, sM[r], dv, 0, 0, 0);
+          dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qg, dpM[r], dk, 0, 0, 0);
+        }
+      }
+      if (j < L) {
+        float* out = orow + (long long)j * ld;
+        if (HD >= 8 || h2 == 0) {
+          *(float4*)(out + p.d + 4 * h2) = make_float4(dk[0] * f, dk[1] * f, dk[2] * f, dk[3] * f);
+          *(float4*)(out + 2 * p.d + 4 * h2) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        }
+        if (HD == 16) {
+          *(float4*)(out + p.d + 8 + 4 * h2) = make_float4(dk[4] * f, dk[5] * f, dk[6] * f, dk[7] * f);
+          *(float4*)(out + 2 * p.d + 8 + 4 * h2) = make_float4(dv[4], dv[5], dv[6], dv[7]);
+        }
+      }
+    }
+  }
+}
+
 static int make_dims(int B, int L, int d, int H, int causal, AttnDims* p) {
   if (H <= 0 || d % H) return fail(UR_ERR_ARG, "attention: d=%d not divisible by n_heads=%d", d, H);
   const int hd = d / H;
@@ -798,6 +966,15 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
   AttnDims p;
   int rc = make_dims(B, L, d, H, causal, &p);
   if (rc) return rc;
+  static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
+  if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
+    dim3 g2(B, cdiv(H, 4));
+    if (p.hd == 4) hipLaunchKernelGGL((attn_bwd_mfma_kernel<4>), g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
+    else if (p.hd == 8) hipLaunchKernelGGL((attn_bwd_mfma_kernel<8>), g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
+    else hipLaunchKernelGGL((attn_bwd_mfma_kernel<16>), g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
+    UR_LAUNCH_CHECK();
+    return UR_OK;
+  }
   float* Dd = ws;
   dim3 grid(B, cdiv(H * p.nchunk, 4));
   if (p.hd > 16) {
