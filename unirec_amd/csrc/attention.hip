@@ -240,6 +240,31 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
+// HD contiguous floats <-> registers with 16-byte accesses when the head dim allows (rows are 16-B aligned: d % 4 == 0)
+template <int HD>
+__device__ __forceinline__ void load_vec(const float* __restrict__ src, float (&dst)[HD]) {
+  if constexpr (HD % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 v = *(const float4*)(src + c);
+      dst[c] = v.x; dst[c + 1] = v.y; dst[c + 2] = v.z; dst[c + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dst[c] = src[c];
+  }
+}
+template <int HD>
+__device__ __forceinline__ void store_vec(float* __restrict__ dst, const float (&src)[HD]) {
+  if constexpr (HD % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) *(float4*)(dst + c) = make_float4(src[c], src[c + 1], src[c + 2], src[c + 3]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dst[c] = src[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Last-row specialisation: in the final layer only the query at position L-1 can reach the loss,
 // so attention degenerates to ONE query per (sequence, head).  Here one wave = one (sequence, head), lanes = keys:
@@ -265,11 +290,8 @@ __global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restr
     const bool in = j < L;
     const int jj = in ? j : L - 1;
     float kr[HD], vr[HD];
-#pragma unroll
-    for (int c = 0; c < HD; ++c) {
-      kr[c] = base[(long long)jj * ld + p.d + h * HD + c];
-      vr[c] = base[(long long)jj * ld + 2 * p.d + h * HD + c];
-    }
+    load_vec<HD>(base + (long long)jj * ld + p.d + h * HD, kr);
+    load_vec<HD>(base + (long long)jj * ld + 2 * p.d + h * HD, vr);
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < HD; ++c) s = fmaf(qr[c], kr[c], s);
@@ -321,11 +343,8 @@ __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restr
     const bool in = j < L;
     const int jj = in ? j : L - 1;
     float kr[HD], vr[HD];
-#pragma unroll
-    for (int c = 0; c < HD; ++c) {
-      kr[c] = base[(long long)jj * ld + p.d + h * HD + c];
-      vr[c] = base[(long long)jj * ld + 2 * p.d + h * HD + c];
-    }
+    load_vec<HD>(base + (long long)jj * ld + p.d + h * HD, kr);
+    load_vec<HD>(base + (long long)jj * ld + 2 * p.d + h * HD, vr);
     float s = 0.f, dp = 0.f;
 #pragma unroll
     for (int c = 0; c < HD; ++c) {
@@ -338,11 +357,14 @@ __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restr
     const float ds = pj * (dp - D) * f;
     if (in) {
       float* out = dqkv + ((long long)b * L + j) * ld + h * HD;
+      float dkr[HD], dvr[HD];
 #pragma unroll
       for (int c = 0; c < HD; ++c) {
-        out[p.d + c] = ds * qr[c];
-        out[2 * p.d + c] = pj * gr[c];
+        dkr[c] = ds * qr[c];
+        dvr[c] = pj * gr[c];
       }
+      store_vec<HD>(out + p.d, dkr);
+      store_vec<HD>(out + 2 * p.d, dvr);
     }
 #pragma unroll
     for (int c = 0; c < HD; ++c) dq[c] += wave_sum(ds * kr[c]);
