@@ -480,7 +480,8 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long
 
 static int tn_splits(int T, int R, int Cc) {
   const int tiles = cdiv(R, TB) * cdiv(Cc, TB);
-  int s = cdiv(512, tiles);
+  static const int target = getenv("UR_TN_BLOCKS") ? atoi(getenv("UR_TN_BLOCKS")) : 512;   // tuning aid
+  int s = cdiv(target, tiles);
   const int smax = cdiv(T, T <= 4096 ? 64 : 128);   // >= 2 (small T) / 4 LDS stages of 32 tokens per split
   if (s > smax) s = smax;
   if (s < 1) s = 1;
