@@ -278,6 +278,18 @@ int ur_full_rank(const float* user_emb, const float* item_table, int64_t n_items
                  int64_t n_users, const float* user_bias, const float* item_bias, float tau, int32_t* rank,
                  float* target_score, float* thr_ws, void* stream);
 
+/* Full-item top-k retrieval -- BaseRecommender.topk with candidates=None (unirec/model/base/recommender.py:149-197:
+ * scores of all items, all_scores[row, user_hist] = -inf, torch.topk) and the scoring loop of main/reco_topk.py:22-96.
+ *   topk_scores[b, :], topk_ids[b, :] = the k best items of row b by s(b,n) = (u_b . E_n + user_bias + item_bias[n]) / tau,
+ *   excluding item 0 (the padding row) and history(user_b) (CSR as in ur_full_rank), sorted by (score desc, id asc);
+ *   rows with fewer than k admissible items are padded with (-inf, -1).  k <= 1024.  The [B, n_items] score matrix is
+ * only ever materialised one 2^20-item chunk at a time (ws: ur_full_topk_workspace_bytes). */
+int64_t ur_full_topk_workspace_bytes(int32_t B, int64_t n_items, int32_t k);
+int ur_full_topk(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d, int32_t k,
+                 const int64_t* user_id, const int64_t* hist_ptr, const int32_t* hist_sorted, int64_t n_users,
+                 const float* user_bias, const float* item_bias, float tau, float* topk_scores, int64_t* topk_ids, void* ws,
+                 void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Live profiler (measurement only; no reference counterpart).  While enabled, every launch group is
  * bracketed by HIP events on its stream.  ur_prof_read fills three host arrays of ur_prof_num_classes()

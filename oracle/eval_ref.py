@@ -54,3 +54,23 @@ def metrics_from_rank(rank, n_scores, ks=(1, 5, 10)):
         out[f"hit@{k}"] = float(np.mean(r < k))
         out[f"ndcg@{k}"] = float(np.mean(np.where(r < k, 1.0 / np.log2(r + 2), 0.0)))
     return out
+
+
+def full_topk(scores, k, user_hist_rows=None):
+    """BaseRecommender.topk with candidates=None (unirec/model/base/recommender.py:149-197): scores[row, history] = -inf,
+    then the k best per row, best first (ties: smaller id first, as torch.topk does not specify).  Item 0 is masked too
+    (the reference masks it through the zero padding of user_hist).  scores is modified in place.
+    user_hist_rows: list of per-row id arrays (or None).  -> (scores [B,k], ids int64 [B,k])."""
+    B, N = scores.shape
+    scores[:, 0] = -np.inf
+    if user_hist_rows is not None:
+        for b, h in enumerate(user_hist_rows):
+            if h is not None and len(h):
+                scores[b, np.asarray(h, dtype=np.int64)] = -np.inf
+    order = np.lexsort((np.broadcast_to(np.arange(N), scores.shape), -scores), axis=1)[:, :k]
+    top = np.take_along_axis(scores, order, axis=1)
+    ids = np.where(np.isinf(top), -1, order)
+    if k > N:   # fewer items than k: pad with (-inf, -1)
+        top = np.concatenate([top, np.full((B, k - N), -np.inf, dtype=top.dtype)], 1)
+        ids = np.concatenate([ids, np.full((B, k - N), -1, dtype=ids.dtype)], 1)
+    return top, ids.astype(np.int64)

@@ -144,3 +144,87 @@ def test_trainer_one_vs_all_matches_oracle():
     ref = eval_ref.metrics_from_rank(np.concatenate(ranks), n_items)
     for k in ("mrr", "group_auc", "hit@10", "ndcg@10"):
         np.testing.assert_allclose(res[k], ref[k], rtol=2e-3, atol=1e-4, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------ top-k (8 f1, second half)
+TOPK_FIX = ["g13_topk_mf_bias_tau", "g13_topk_sasrec"]
+
+
+def _topk_inputs(name):
+    cfg, g = load_golden(name)
+    P = {k: torch.from_numpy(v) for k, v in g["sd"].items()}
+    uid, hist = g["in"]["user_id"], g["in"]["user_hist"]
+    if cfg["model"] == "MF":
+        ue = model_ref.mf_user_emb(P, torch.from_numpy(uid)).numpy()
+    else:
+        ue = model_ref.sasrec_user_emb(P, torch.from_numpy(g["in"]["item_seq"]), cfg).numpy()
+    return cfg, g, ue, uid, hist
+
+
+@pytest.mark.parametrize("name", TOPK_FIX)
+def test_oracle_topk_matches_reference(name):
+    cfg, g, ue, uid, hist = _topk_inputs(name)
+    s = eval_ref.full_scores(ue, g["sd"]["item_embedding.weight"], g["sd"]["user_bias"][uid] if cfg["has_user_bias"] else None,
+                             g["sd"]["item_bias"] if cfg["has_item_bias"] else None, cfg["tau"])
+    sc, ids = eval_ref.full_topk(s, int(g["k"][""]), [h for h in hist])
+    assert np.array_equal(ids, g["out"]["ids"])
+    np.testing.assert_allclose(sc, g["out"]["scores"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TOPK_FIX)
+def test_gpu_topk_matches_reference_golden(name):
+    from unirec_amd.utils.general import get_class_instance
+    cfg, g, ue, uid, hist = _topk_inputs(name)
+    cfg = dict(cfg, device="cuda:0")
+    m = get_class_instance(cfg["model"], "unirec_amd/model")(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g["sd"].items()}, strict=False)
+    m.check_views()
+    m.eval()
+    inter = {"user_id": torch.from_numpy(uid).cuda(), "item_seq": torch.from_numpy(g["in"]["item_seq"]).cuda()}
+    sc, ids = m.topk(inter, int(g["k"][""]), user_hist=torch.from_numpy(hist).cuda())
+    assert np.array_equal(ids.cpu().numpy(), g["out"]["ids"])
+    np.testing.assert_allclose(sc.cpu().numpy(), g["out"]["scores"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d,B,k,bias", [(1017, 32, 40, 10, True), (5003, 64, 33, 100, False), (300, 16, 7, 400, True),
+                                          (2_300_001, 32, 9, 50, True), (40960, 128, 130, 1024, False)])
+def test_gpu_topk_matches_oracle(N, d, B, k, bias):
+    from unirec_amd import ops
+    from unirec_amd.data.rows import HistoryCSR
+    rng = np.random.default_rng(N + k)
+    table = rng.normal(0, 0.1, (N, d)).astype(np.float32)
+    ue = rng.normal(0, 0.1, (B, d)).astype(np.float32)
+    n_users = 20
+    uid = rng.integers(0, n_users + 3, B).astype(np.int64)
+    u2h = np.empty(n_users, dtype=object)
+    for u in range(n_users):
+        h = rng.integers(0, N, rng.integers(0, 300))
+        u2h[u] = None if len(h) == 0 else np.concatenate([h, h[:2]])
+    if N == 300:
+        u2h[1] = np.arange(1, 290)                      # fewer than k admissible items for this user
+    ub = rng.normal(0, 0.1, n_users + 3).astype(np.float32) if bias else None
+    ib = rng.normal(0, 0.1, N).astype(np.float32) if bias else None
+    tau = 0.7 if bias else 1.0
+    dev = "cuda:0"
+    hp, hs = HistoryCSR(u2h).to_device(dev)
+    t = lambda a, dt: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    sc, ids = ops.full_topk(t(ue, torch.float32), t(table, torch.float32), k, t(uid, torch.int64), hp, hs, t(ub, torch.float32),
+                            t(ib, torch.float32), tau)
+    sc, ids = sc.cpu().numpy(), ids.cpu().numpy()
+    s64 = eval_ref.full_scores(ue, table, None if ub is None else ub[uid], ib, tau, dtype=np.float64)
+    rows = [u2h[u] if u < n_users else None for u in uid]
+    ref_sc, ref_ids = eval_ref.full_topk(s64.copy(), k, rows)
+    fin = np.isfinite(ref_sc)
+    assert np.array_equal(np.isfinite(sc), fin) and (ids[~fin] == -1).all()
+    np.testing.assert_allclose(sc[fin], ref_sc[fin], rtol=1e-4, atol=1e-6)
+    assert (np.diff(sc, axis=1)[fin[:, 1:]] <= 0).all()                                   # best first
+    for b in range(B):                                                                     # same set up to fp32 near-ties at the cut
+        got, want = set(ids[b][fin[b]].tolist()), set(ref_ids[b][fin[b]].tolist())
+        odd = got ^ want
+        if odd:
+            cut = ref_sc[b][fin[b]][-1]
+            assert all(abs(s64[b, n] - cut) < 2e-6 for n in odd), (b, odd)
+        h = rows[b]
+        assert 0 not in got and (h is None or not (got & set(np.asarray(h).tolist())))

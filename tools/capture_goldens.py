@@ -373,6 +373,36 @@ def main():
             arrs[tag + ".isnone"] = np.array([x is None for x in h])
         save("g12_on_disk_expected", **arrs)
 
+    # ---------------------------------------------------------------- G13 full-item top-k (BaseRecommender.topk)
+    r13 = np.random.default_rng(1313)
+    for tag, mk in {"mf_bias_tau": lambda: (MF, base_cfg(model="MF", n_items=517, has_user_emb=True, has_user_bias=True,
+                                                       has_item_bias=True, tau=0.5, embedding_size=16, hidden_size=16)),
+                    "sasrec": lambda: (SASRec, base_cfg(model="SASRec", n_items=640, n_heads=2))}.items():
+        cls, cfg = mk()
+        torch.manual_seed(13)
+        m = cls(cfg)
+        m.eval()
+        if cfg["has_item_bias"]:
+            with torch.no_grad():
+                m.item_bias.normal_(0, 0.02)
+                m.user_bias.normal_(0, 0.02)
+        B, H, L, k = 11, 25, cfg["max_seq_len"], 10
+        user = r13.integers(1, cfg["n_users"], B).astype(np.int64)
+        seq = r13.integers(1, cfg["n_items"], (B, L)).astype(np.int64)
+        for b in range(B):
+            seq[b, : r13.integers(0, L)] = 0
+        hist = r13.integers(1, cfg["n_items"], (B, H)).astype(np.int64)
+        for b in range(B):
+            hist[b, : r13.integers(1, H)] = 0          # every row keeps >= 1 padding zero (so item 0 is masked, as here)
+        inter = {"user_id": torch.from_numpy(user), "item_seq": torch.from_numpy(seq), "item_seq_len": torch.from_numpy((seq > 0).sum(1))}
+        with torch.no_grad():
+            sc, ids = m.topk(inter, k, user_hist=torch.from_numpy(hist))
+        arrs = pack("cfg.", {kk: np.array(v) for kk, v in cfg.items()})
+        arrs.update(pack("sd.", sd_np(m)))
+        arrs.update({"in.user_id": user, "in.item_seq": seq, "in.user_hist": hist, "out.scores": sc.numpy().copy(), "out.ids": ids.numpy().copy(),
+                     "k": np.array(k)})
+        save("g13_topk_" + tag, **arrs)
+
 
 if __name__ == "__main__":
     main()

@@ -14,6 +14,7 @@
 
 namespace ur {
 
+constexpr long long UR_TOPK_CHUNK = 1LL << 20;   // items scored per pass of ur_full_topk ([B, chunk] fp32 scratch)
 constexpr int MAXV = 4;
 static inline int pick_tpr(int d) {
   int d4 = d / 4, t = 4;
@@ -315,6 +316,153 @@ static int launch_rank_stream(const RankArgs& a, hipStream_t st) {
   return UR_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ full-item top-k
+// model.topk (unirec/model/base/recommender.py:149-197): scores of ALL items, the user's history set to -inf, torch.topk.
+// Here in item chunks: gemm_nt writes the chunk's scores [B, C], mask_scores_kernel applies the history / padding-row
+// mask, row_topk_kernel keeps the chunk's k best per row (radix select on the order-preserving integer image of the
+// floats, then a bitonic sort of the k survivors); the per-chunk winners are merged by the same kernel at the end.
+
+// S[b, n - c0] = -inf for n in history(b) U {0}, n in [c0, c0 + cn)
+__global__ __launch_bounds__(256) void mask_scores_kernel(float* __restrict__ S, long long ld, int B, long long c0, long long cn,
+                                                          const long long* __restrict__ user_id, const long long* __restrict__ hist_ptr,
+                                                          const int* __restrict__ hist_sorted, long long n_users) {
+  const int b = blockIdx.x;
+  float* row = S + (long long)b * ld;
+  if (threadIdx.x == 0 && c0 == 0) row[0] = -INFINITY;   // item 0 is the padding row
+  if (!hist_ptr) return;
+  const long long u = user_id[b];
+  if (u < 0 || u >= n_users) return;
+  const long long hb = hist_ptr[u], he = hist_ptr[u + 1];
+  for (long long q = hb + threadIdx.x; q < he; q += 256) {
+    const long long n = hist_sorted[q];
+    if (n >= c0 && n < c0 + cn) row[n - c0] = -INFINITY;
+  }
+}
+
+__device__ __forceinline__ unsigned f2key(float x) {   // ascending unsigned order == ascending float order
+  const unsigned u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// One workgroup per row.  vals[n] (+ ids[n] or implicit id = id_base + index) -> the k largest, sorted by (value desc,
+// id asc), written to out_vals / out_ids at out_off (missing entries: -inf / -1).  k <= 1024.
+__global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__ vals, long long ld, const long long* __restrict__ ids,
+                                                       long long ld_ids, long long n, long long id_base, int k,
+                                                       float* __restrict__ out_vals, long long* __restrict__ out_ids, long long out_ld,
+                                                       long long out_off) {
+  __shared__ int hist[256];
+  __shared__ unsigned s_prefix, s_mask;
+  __shared__ int s_need, s_cnt_gt, s_cnt_eq;
+  __shared__ unsigned skey[1024];
+  __shared__ long long sid[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* v = vals + (long long)b * ld;
+  const long long* vid = ids ? ids + (long long)b * ld_ids : nullptr;
+  const int kk = (int)min((long long)k, n);
+  if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_need = kk; }
+  __syncthreads();
+  // ---- radix select: after the 4 passes s_prefix is the key of the kk-th largest value
+  for (int pass = 0; pass < 4 && kk > 0; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix, mask = s_mask;
+    for (long long i = tid; i < n; i += 256) {
+      const unsigned key = f2key(v[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFF], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int need = s_need, dgt = 255;
+      for (; dgt > 0; --dgt) {
+        if (hist[dgt] >= need) break;
+        need -= hist[dgt];
+      }
+      s_need = need;   // rank of the wanted element inside bucket dgt
+      s_prefix = prefix | ((unsigned)dgt << shift);
+      s_mask = mask | (0xFFu << shift);
+    }
+    __syncthreads();
+  }
+  // ---- collect: everything above the threshold key, then as many equal keys as are still needed
+  const unsigned thr = s_prefix;
+  if (tid == 0) { s_cnt_gt = 0; s_cnt_eq = 0; }
+  for (int i = tid; i < 1024; i += 256) { skey[i] = 0u; sid[i] = 0x7FFFFFFFFFFFFFFFLL; }   // padding sorts last
+  __syncthreads();
+  const int n_eq = s_need;   // how many values equal to the threshold belong to the top kk
+  for (long long i = tid; i < n && kk > 0; i += 256) {
+    const unsigned key = f2key(v[i]);
+    if (key > thr) {
+      const int pos = atomicAdd(&s_cnt_gt, 1);
+      skey[pos] = key;
+      sid[pos] = vid ? vid[i] : id_base + i;
+    }
+  }
+  __syncthreads();
+  const int n_gt = s_cnt_gt;   // == kk - n_eq
+  for (long long i = tid; i < n && kk > 0; i += 256) {
+    const unsigned key = f2key(v[i]);
+    if (key == thr) {
+      const int e = atomicAdd(&s_cnt_eq, 1);
+      if (e < n_eq) {
+        skey[n_gt + e] = key;
+        sid[n_gt + e] = vid ? vid[i] : id_base + i;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- bitonic sort of the 1024 slots by (key desc, id asc)
+  int np2 = 1;
+  while (np2 < kk) np2 <<= 1;
+  if (np2 < 2) np2 = 2;
+  for (int size = 2; size <= np2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < np2 / 2; t += 256) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool desc_block = ((lo & size) == 0);   // first half of each `size` block sorted "best first"
+        const unsigned ka = skey[lo], kb = skey[hi];
+        const long long ia = sid[lo], ib = sid[hi];
+        const bool a_first = ka > kb || (ka == kb && ia < ib);   // a is better than b
+        if (a_first != desc_block) { skey[lo] = kb; skey[hi] = ka; sid[lo] = ib; sid[hi] = ia; }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < k; i += 256) {
+    float val = -INFINITY;
+    long long id = -1;
+    if (i < kk) {
+      const unsigned key = skey[i];
+      val = __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+      id = sid[i];
+    }
+    out_vals[(long long)b * out_ld + out_off + i] = val;
+    out_ids[(long long)b * out_ld + out_off + i] = id;
+  }
+}
+
+// scores of a few trailing items the GEMM cannot take (N % 4): S[b, col0 + t] = u_b . E[n0 + t] + bias
+__global__ __launch_bounds__(256) void tail_scores_kernel(const float* __restrict__ user_emb, const float* __restrict__ table,
+                                                          const float* __restrict__ item_bias, int B, int d, long long n0, int nt,
+                                                          float* __restrict__ S, long long ld, long long col0) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * nt) return;
+  const int b = idx / nt, t = idx % nt;
+  float s = 0.f;
+  for (int c = 0; c < d; ++c) s = fmaf(user_emb[(long long)b * d + c], table[(n0 + t) * d + c], s);
+  S[(long long)b * ld + col0 + t] = s + (item_bias ? item_bias[n0 + t] : 0.f);
+}
+
+// final (score + user_bias) / tau on the k winners (monotone: applied after the selection)
+__global__ void topk_finish_kernel(float* __restrict__ vals, long long* __restrict__ ids, const long long* __restrict__ user_id,
+                                   const float* __restrict__ user_bias, float tau, int B, int k) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * k) return;
+  const int b = i / k;
+  if (vals[i] != -INFINITY) vals[i] = (vals[i] + (user_bias ? user_bias[user_id[b]] : 0.f)) / tau;
+  else ids[i] = -1;   // fewer than k admissible items: masked entries are reported as (-inf, -1)
+}
+
 }  // namespace ur
 
 using namespace ur;
@@ -383,6 +531,64 @@ extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int6
     default: GO(32); break;
   }
 #undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int64_t ur_full_topk_workspace_bytes(int32_t B, int64_t n_items, int32_t k) {
+  if (B <= 0 || n_items <= 0 || k <= 0) return UR_ERR_ARG;
+  const long long chunk = std::min<long long>((n_items + 3) & ~3LL, UR_TOPK_CHUNK);
+  const long long nchunks = (n_items + chunk - 1) / chunk;
+  return (long long)B * chunk * 4 + (long long)B * nchunks * k * (4 + 8) + 1024;
+}
+
+extern "C" int ur_full_topk(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d, int32_t k,
+                            const int64_t* user_id, const int64_t* hist_ptr, const int32_t* hist_sorted, int64_t n_users,
+                            const float* user_bias, const float* item_bias, float tau, float* topk_scores, int64_t* topk_ids, void* ws,
+                            void* stream) {
+  UR_REQUIRE(user_emb && item_table && topk_scores && topk_ids && ws, UR_ERR_ARG, "ur_full_topk: null pointer");
+  UR_REQUIRE(B > 0 && d > 0 && d % 4 == 0 && n_items > 0 && n_items < (1LL << 31), UR_ERR_ARG, "ur_full_topk: shape");
+  UR_REQUIRE(k > 0 && k <= 1024, UR_ERR_UNSUPPORTED, "ur_full_topk: k=%d (1..1024)", k);
+  UR_REQUIRE(tau > 0.f, UR_ERR_ARG, "ur_full_topk: tau must be > 0");
+  UR_REQUIRE(!hist_ptr || (hist_sorted && user_id), UR_ERR_ARG, "ur_full_topk: history needs user_id and hist_sorted");
+  UR_REQUIRE(!user_bias || user_id, UR_ERR_ARG, "ur_full_topk: user_bias needs user_id");
+  hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_MISC, st, 2.0 * B * (double)n_items * d);
+  const long long chunk = std::min<long long>((n_items + 3) & ~3LL, UR_TOPK_CHUNK);
+  const long long nchunks = (n_items + chunk - 1) / chunk;
+  float* S = (float*)ws;                                               // [B, chunk]
+  float* cand_v = S + (long long)B * chunk;                            // [B, nchunks * k]
+  long long* cand_i = (long long*)(((uintptr_t)(cand_v + (long long)B * nchunks * k) + 15) & ~(uintptr_t)15);
+  for (long long ci = 0; ci < nchunks; ++ci) {
+    const long long c0 = ci * chunk, cn = std::min(chunk, n_items - c0), cn4 = cn & ~3LL;
+    if (cn4 > 0) {
+      GemmArgs g{};
+      g.A = user_emb; g.lda = d; g.W = item_table + (size_t)c0 * d; g.ldw = d; g.C = S; g.ldc = (int)chunk; g.M = B; g.N = (int)cn4; g.K = d;
+      g.bias = item_bias ? item_bias + c0 : nullptr;
+      int rc = gemm_nt(g, PRO_NONE, item_bias ? EPI_BIAS : EPI_NONE, st);
+      if (rc) return rc;
+    }
+    if (cn > cn4) {
+      hipLaunchKernelGGL(tail_scores_kernel, dim3(cdiv((long long)B * (cn - cn4), 256)), dim3(256), 0, st, user_emb, item_table, item_bias, B, d,
+                         c0 + cn4, (int)(cn - cn4), S, chunk, cn4);
+      UR_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(mask_scores_kernel, dim3(B), dim3(256), 0, st, S, chunk, B, c0, cn, (const long long*)user_id,
+                       (const long long*)hist_ptr, hist_sorted, (long long)n_users);
+    UR_LAUNCH_CHECK();
+    float* ov = nchunks == 1 ? topk_scores : cand_v;
+    long long* oi = nchunks == 1 ? (long long*)topk_ids : cand_i;
+    hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, S, chunk, (const long long*)nullptr, 0LL, cn, c0, k, ov, oi,
+                       nchunks == 1 ? (long long)k : nchunks * k, nchunks == 1 ? 0LL : ci * k);
+    UR_LAUNCH_CHECK();
+  }
+  if (nchunks > 1) {
+    hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, cand_v, nchunks * k, cand_i, nchunks * k, nchunks * k, 0LL, k,
+                       topk_scores, (long long*)topk_ids, (long long)k, 0LL);
+    UR_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(topk_finish_kernel, dim3(cdiv((long long)B * k, 256)), dim3(256), 0, st, topk_scores, (long long*)topk_ids, (const long long*)user_id,
+                     user_bias, tau, B, k);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

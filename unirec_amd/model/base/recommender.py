@@ -215,4 +215,33 @@ class BaseRecommender(AbstractRecommender):
         return self.user_bias[interaction["user_id"]].detach().cpu().numpy()
 
     def topk(self, interaction, k, user_hist=None, candidates=None):
-        raise NotImplementedError("full-item top-k is a 'next' row (SURVEY.md section 8 f1), not part of the training hot path")
+        """Top-k items for a batch of users -- recommender.py:149-197 with candidates=None (all items).
+        user_hist: the reference's padded [B, H] tensor of history items (0 = padding), or a HistoryCSR (then
+        interaction['user_id'] selects the rows), or None.  Returns (scores [B,k], ids [B,k]) on the device, best first.
+        Item 0 (the padding row) is never returned."""
+        if candidates is not None:
+            raise NotImplementedError("topk over an explicit candidate list: use predict() on the candidates")
+        inputs = {kk: v for kk, v in interaction.items() if kk in inspect.signature(self.forward_user_emb).parameters}
+        with torch.no_grad():
+            user_emb = self.forward_user_emb(**inputs).contiguous()
+        B = user_emb.shape[0]
+        dev = user_emb.device
+        uid = interaction.get("user_id")
+        hp = hs = None
+        hist_uid = uid
+        if user_hist is not None:
+            if torch.is_tensor(user_hist):   # padded per-row histories -> a batch-local CSR (rows sorted, zeros first)
+                hs = torch.sort(user_hist.to(dev).to(torch.int32), dim=1).values.reshape(-1).contiguous()
+                hp = (torch.arange(B + 1, device=dev, dtype=torch.int64) * user_hist.shape[1]).contiguous()
+                hist_uid = torch.arange(B, device=dev, dtype=torch.int64)
+            else:
+                hp, hs = user_hist.to_device(dev)
+        if self.has_user_bias and hist_uid is not uid:
+            # two different row keys (history rows vs user ids): fold the user bias in afterwards
+            scores, ids = ops.full_topk(user_emb, self.item_embedding.weight.data, k, hist_uid, hp, hs, None,
+                                        self.item_bias.data if self.has_item_bias else None, 1.0)
+            scores = torch.where(torch.isinf(scores), scores, (scores + self.user_bias.data[uid].unsqueeze(1)) / self.tau)
+            return scores, ids
+        return ops.full_topk(user_emb, self.item_embedding.weight.data, k, hist_uid if (hp is not None or self.has_user_bias) else None,
+                             hp, hs, self.user_bias.data if self.has_user_bias else None,
+                             self.item_bias.data if self.has_item_bias else None, self.tau)

@@ -292,3 +292,25 @@ def full_rank(user_emb, item_table, target, user_id=None, hist_ptr=None, hist_so
     check(lib.ur_full_rank(_p(user_emb), _p(item_table), n_items, B, d, _p(target), _p(user_id), _p(hist_ptr), _p(hist_sorted),
                            n_users, _p(user_bias), _p(item_bias), float(tau), _p(rank), _p(ts), _p(thr), _stream()), "ur_full_rank")
     return rank, ts
+
+
+def full_topk(user_emb, item_table, k, user_id=None, hist_ptr=None, hist_sorted=None, user_bias=None, item_bias=None, tau=1.0):
+    """-> (scores float32[B,k], ids int64[B,k]): the k best items per row (not item 0, not in the user's history), best
+    first.  See include/unirec_amd.h: ur_full_topk."""
+    _chk(user_emb, torch.float32, "user_emb")
+    _chk(item_table, torch.float32, "item_table")
+    _chk(user_id, torch.int64, "user_id", allow_none=True)
+    _chk(hist_ptr, torch.int64, "hist_ptr", allow_none=True)
+    _chk(hist_sorted, torch.int32, "hist_sorted", allow_none=True)
+    _chk(user_bias, torch.float32, "user_bias", allow_none=True)
+    _chk(item_bias, torch.float32, "item_bias", allow_none=True)
+    B, d = user_emb.shape
+    n_items = item_table.shape[0]
+    dev = user_emb.device
+    scores = torch.empty(B, k, dtype=torch.float32, device=dev)
+    ids = torch.empty(B, k, dtype=torch.int64, device=dev)
+    ws = torch.empty(check(lib.ur_full_topk_workspace_bytes(B, n_items, k), "ur_full_topk_workspace_bytes"), dtype=torch.uint8, device=dev)
+    n_users = hist_ptr.numel() - 1 if hist_ptr is not None else 0
+    check(lib.ur_full_topk(_p(user_emb), _p(item_table), n_items, B, d, int(k), _p(user_id), _p(hist_ptr), _p(hist_sorted), n_users,
+                           _p(user_bias), _p(item_bias), float(tau), _p(scores), _p(ids), _p(ws), _stream()), "ur_full_topk")
+    return scores, ids
