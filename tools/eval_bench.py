@@ -43,6 +43,16 @@ def main():
             print(json.dumps({"op": "ur_full_rank", "n_items": N, "batch": B, "d": a.d, "ms": round(ms, 3),
                               "users_per_s": round(B / ms * 1e3, 1), "tflops": round(2.0 * B * N * a.d / ms / 1e9, 2),
                               "table_read_GBps": round(N * a.d * 4 / ms / 1e6, 1), "mean_rank": float(r.float().mean())}))
+            if B <= 512:
+                ops.full_topk(ue, table, 100, uid, hp, hs)
+                torch.cuda.synchronize()
+                e0.record()
+                sc, ids = ops.full_topk(ue, table, 100, uid, hp, hs)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                print(json.dumps({"op": "ur_full_topk", "k": 100, "n_items": N, "batch": B, "d": a.d, "ms": round(ms, 3),
+                                  "users_per_s": round(B / ms * 1e3, 1), "best_score_mean": float(sc[:, 0].mean())}))
         del table
 
 
