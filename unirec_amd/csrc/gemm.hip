@@ -600,6 +600,13 @@ int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st) 
 // several transposes in ONE launch (all weight matrices of the encoder before its backward pass: 8 launches -> 1)
 __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb) {
   __shared__ float tile[32][33];
+  if (tb.zero_ptr && (int)blockIdx.x >= tb.zero_first_block) {   // rider: zero-fill (the backward's gradient buffer)
+    const long long i0 = ((long long)(blockIdx.x - tb.zero_first_block) * 256 + threadIdx.x) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (i0 + q * 4 < tb.zero_n) *(float4*)(tb.zero_ptr + i0 + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   int j = 0;
   while (j + 1 < tb.n && (int)blockIdx.x >= tb.item[j + 1].first_block) ++j;
   const TransposeItem it = tb.item[j];
@@ -620,6 +627,10 @@ int transpose_batch(TransposeBatch& tb, hipStream_t st) {
   for (int i = 0; i < tb.n; ++i) {
     tb.item[i].first_block = blocks;
     blocks += cdiv(tb.item[i].cols, 32) * cdiv(tb.item[i].rows, 32);
+  }
+  if (tb.zero_ptr) {
+    tb.zero_first_block = blocks;
+    blocks += cdiv(tb.zero_n, 4096);
   }
   hipLaunchKernelGGL(transpose_batch_kernel, dim3(blocks), dim3(256), 0, st, tb);
   UR_LAUNCH_CHECK();

@@ -76,6 +76,7 @@ struct TransposeItem { const float* src; float* dst; int rows, cols, first_block
 struct TransposeBatch {
   static constexpr int MAX = 32;
   TransposeItem item[MAX]; int n = 0;
+  float* zero_ptr = nullptr; long long zero_n = 0; int zero_first_block = 0;   // optional: also zero-fill a buffer (n % 4 == 0)
   bool add(const float* src, int rows, int cols, float* dst) {
     if (n >= MAX) return false;
     item[n++] = TransposeItem{src, dst, rows, cols, 0};

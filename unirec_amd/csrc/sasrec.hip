@@ -253,7 +253,6 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   const Layout lay = make_layout(c);
   Ws w = carve(c, (float*)ws);
   const int M = c.B * c.L, d = c.d, I = c.inner;
-  UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
   ReduceBatch rb;                       // second stages of all split reductions: one launch at the end
   float* tn_cur = w.tn_ws;
   float* ln_cur = w.ln_part;
@@ -305,14 +304,18 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     hipLaunchKernelGGL(put_last_kernel, dim3(cdiv((long long)M * d, 256)), dim3(256), 0, st, d_user_emb, c.B, c.L, d, w.g_y);
     UR_LAUNCH_CHECK();
   }
-  {   // weight transposes for the activation-gradient GEMMs of every layer, one launch (up to 8 layers per launch)
+  {   // weight transposes for the activation-gradient GEMMs of every layer, one launch (up to 8 layers per launch);
+      // the same launch zero-fills dense_grad (slots nobody writes: unused position rows, absent parameters)
     TransposeBatch tb;
+    if (lay.total % 4 == 0) { tb.zero_ptr = dense_grad; tb.zero_n = lay.total; }
+    else UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
     for (int i = 0; i < c.n_layers; ++i) {
       const LayerP p = layer_ptrs(dense, lay, i);
       LayerWs& lw = w.layer[i];
       if (tb.n + 4 > TransposeBatch::MAX) {
         if ((rc = transpose_batch(tb, st))) return rc;
         tb.n = 0;
+        tb.zero_ptr = nullptr;
       }
       tb.add(p.wqkv, 3 * d, d, lw.wqkvT); tb.add(p.wo, d, d, lw.woT); tb.add(p.w1, I, d, lw.w1T); tb.add(p.w2, d, I, lw.w2T);
     }
@@ -375,6 +378,9 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     g = GemmArgs{};
     g.A = lw.g_ta; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.N = d; g.K = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
+    // fork dWo now: it then runs underneath the attention backward instead of queueing up behind it at the very end of
+    // the pass, where the side stream would finish after the main one (one more event, ~30 us off the tail)
+    if ((rc = fork())) return rc;
     if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st))) return rc;
     if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
     if ((rc = fork())) return rc;
