@@ -60,6 +60,8 @@ typedef struct UrSasrecCfg {
   int32_t use_pos;  /* use_position_emb: adds P and enables the causal part of the mask (sasrec.py:43-52) */
   float eps;        /* layer_norm_eps */
   int32_t last_only; /* 1: exact last-position specialisation of the final layer */
+  int32_t skip_padding; /* 1: the left-padded prefix of every sequence gets no rows at all (exact: those positions cannot
+                           reach the loss); used when L <= 64 and head dim is 4/8/16, ignored otherwise */
 } UrSasrecCfg;
 
 /* Layout of the flat dense-parameter buffer (and of its gradient buffer). offsets_out receives

@@ -31,7 +31,14 @@ struct AttnDims {
   int B, L, d, H, hd, causal, nchunk;
   float scale;    // 1/sqrt(hd)
   float sqrt_hd;  // sqrt(hd) for the literal (division) path
+  const int* seq_base;   // compacted rows (nullable): position l of sequence b is row seq_base[b] + l, for l >= seq_pad[b]
+  const int* seq_pad;
 };
+// first row of sequence b's (virtual) position 0 and the number of leading positions that have no row
+__device__ __forceinline__ void seq_rows(const AttnDims& p, int b, long long& row0, int& pad) {
+  row0 = p.seq_base ? (long long)p.seq_base[b] : (long long)b * p.L;
+  pad = p.seq_base ? p.seq_pad[b] : 0;
+}
 
 // dot of a per-lane register row with a wave-uniform memory row (HD exact: no guards, so the compiler can
 // fetch the row with wide scalar loads)
@@ -277,7 +284,10 @@ __global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restr
   const int h = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
   if (h >= p.H) return;
   const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
-  const float* __restrict__ base = qkv + (long long)b * L * ld;
+  long long row0;
+  int pad;
+  seq_rows(p, b, row0, pad);
+  const float* __restrict__ base = qkv + row0 * ld;
   const int* __restrict__ sq = seq + (long long)b * L;
   const float* __restrict__ qr = q_last + (long long)b * p.d + h * HD;   // wave-uniform row
   const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
@@ -288,14 +298,14 @@ __global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restr
   for (int j0 = 0; j0 < L; j0 += 64) {
     const int j = j0 + lane;
     const bool in = j < L;
-    const int jj = in ? j : L - 1;
+    const int jj = max(in ? j : L - 1, pad);
     float kr[HD], vr[HD];
     load_vec<HD>(base + (long long)jj * ld + p.d + h * HD, kr);
     load_vec<HD>(base + (long long)jj * ld + 2 * p.d + h * HD, vr);
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < HD; ++c) s = fmaf(qr[c], kr[c], s);
-    const bool allowed = in && (literal || sq[jj] > 0);
+    const bool allowed = in && (literal || sq[min(j, L - 1)] > 0);   // the mask is indexed by position, not by (clamped) row
     const float sv = allowed ? (literal ? s / p.sqrt_hd + -10000.0f : s * p.scale) : -INFINITY;
     const float mn = fmaxf(m, group_max<64>(sv));
     if (mn == -INFINITY) continue;   // nothing allowed so far (uniform)
@@ -323,7 +333,10 @@ __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restr
   const int h = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
   if (h >= p.H) return;
   const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
-  const float* __restrict__ base = qkv + (long long)b * L * ld;
+  long long row0;
+  int pad;
+  seq_rows(p, b, row0, pad);
+  const float* __restrict__ base = qkv + row0 * ld;
   const int* __restrict__ sq = seq + (long long)b * L;
   const float* __restrict__ qr = q_last + (long long)b * p.d + h * HD;
   const float* __restrict__ gr = dctx_last + (long long)b * p.d + h * HD;
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restr
   for (int j0 = 0; j0 < L; j0 += 64) {
     const int j = j0 + lane;
     const bool in = j < L;
-    const int jj = in ? j : L - 1;
+    const int jj = max(in ? j : L - 1, pad);
     float kr[HD], vr[HD];
     load_vec<HD>(base + (long long)jj * ld + p.d + h * HD, kr);
     load_vec<HD>(base + (long long)jj * ld + 2 * p.d + h * HD, vr);
@@ -351,12 +364,12 @@ __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restr
       s = fmaf(qr[c], kr[c], s);
       dp = fmaf(gr[c], vr[c], dp);
     }
-    const bool allowed = in && (literal || sq[jj] > 0);
+    const bool allowed = in && (literal || sq[min(j, L - 1)] > 0);   // the mask is indexed by position, not by (clamped) row
     const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
     const float pj = allowed ? __expf(sv - ls) : 0.f;
     const float ds = pj * (dp - D) * f;
-    if (in) {
-      float* out = dqkv + ((long long)b * L + j) * ld + h * HD;
+    if (in && j >= pad) {
+      float* out = dqkv + (row0 + j) * ld + h * HD;
       float dkr[HD], dvr[HD];
 #pragma unroll
       for (int c = 0; c < HD; ++c) {
@@ -639,7 +652,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
   if (h >= p.H) return;
   const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
   const int c32 = lane & 31, h2 = lane >> 5;
-  const float* __restrict__ base = qkv + (long long)b * L * ld + h * HD;
+  long long row0;
+  int pad;
+  seq_rows(p, b, row0, pad);
+  const float* __restrict__ base = qkv + row0 * ld + h * HD;
   const int* __restrict__ sq = seq + (long long)b * L;
   const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
   const bool literal = fv >= L;
@@ -654,7 +670,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
   float qf[2][KH], kf[2][KH], vrow[HD];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int row = min(t * 32 + c32, L - 1);
+    const int row = max(min(t * 32 + c32, L - 1), pad);
 #pragma unroll
     for (int c = 0; c < KH; ++c) {
       qf[t][c] = base[(long long)row * ld + h2 * KH + c];
@@ -662,7 +678,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
     }
   }
   {
-    const int row = min(lane, L - 1);
+    const int row = max(min(lane, L - 1), pad);
 #pragma unroll
     for (int c = 0; c < HD; ++c) vrow[c] = base[(long long)row * ld + 2 * p.d + c];
 #pragma unroll
@@ -752,10 +768,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int i = it * 32 + c32;
-    if (it >= nt || i >= L) continue;
+    if (it >= nt || i >= L || i < pad) continue;
     const bool dead = l[it] == 0.f;   // padded-prefix row of a non-empty sequence: unreachable from the loss
     const float inv_l = dead ? 0.f : 1.0f / l[it];
-    float* out = ctx + ((long long)b * L + i) * p.d + h * HD;
+    float* out = ctx + (row0 + i) * p.d + h * HD;
     if (HD >= 8 || h2 == 0) {
       float4 o = make_float4(oa[it][0] * inv_l, oa[it][1] * inv_l, oa[it][2] * inv_l, oa[it][3] * inv_l);
       *(float4*)(out + 4 * h2) = o;
@@ -787,13 +803,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
   if (h >= p.H) return;
   const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
   const int c32 = lane & 31, h2 = lane >> 5;
-  const float* __restrict__ base = qkv + (long long)b * L * ld + h * HD;
+  long long row0;
+  int pad;
+  seq_rows(p, b, row0, pad);
+  const float* __restrict__ base = qkv + row0 * ld + h * HD;
   const int* __restrict__ sq = seq + (long long)b * L;
   const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
   const bool literal = fv >= L;
   const bool causal = p.causal && !literal;
   const unsigned long long kmask = __ballot(lane < L && (literal || sq[min(lane, L - 1)] > 0));
-  const unsigned long long qmask = __ballot(lane < L);
+  const unsigned long long qmask = __ballot(lane < L && lane >= pad);   // query rows that exist (compact mode: not the padded prefix)
   const int nt = L > 32 ? 2 : 1;
   const float f = literal ? 1.0f / p.sqrt_hd : p.scale;   // d(score)/d(q.k)
   const float sc2 = f * LOG2E;
@@ -805,10 +824,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
   float (*vs)[LDSW] = tiles[w][2];
   float (*gs)[LDSW] = tiles[w][3];
   {
-    const int row = min(lane, L - 1);
+    const int row = max(min(lane, L - 1), pad);
     const float* qr = base + (long long)row * ld;
-    const float* gr = dctx + ((long long)b * L + row) * p.d + h * HD;
-    const float* orr = ctx + ((long long)b * L + row) * p.d + h * HD;
+    const float* gr = dctx + (row0 + row) * p.d + h * HD;
+    const float* orr = ctx + (row0 + row) * p.d + h * HD;
     float D = 0.f;
 #pragma unroll
     for (int c = 0; c < HD; ++c) {
@@ -833,7 +852,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
       vf[t][c] = vs[t * 32 + c32][h2 * KH + c];
       gf[t][c] = gs[t * 32 + c32][h2 * KH + c];
     }
-  float* orow = dqkv + (long long)b * L * ld + h * HD;
+  float* orow = dqkv + row0 * ld + h * HD;
 
   // =========================================================================== phase A: lane = query i
   {
@@ -872,7 +891,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
           dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kg, sT[r], dq, 0, 0, 0);
         }
       }
-      if (i < L) {
+      if (i < L && i >= pad) {
         float* out = orow + (long long)i * ld;
         if (HD >= 8 || h2 == 0) *(float4*)(out + 4 * h2) = make_float4(dq[0] * f, dq[1] * f, dq[2] * f, dq[3] * f);
         if (HD == 16) *(float4*)(out + 8 + 4 * h2) = make_float4(dq[4] * f, dq[5] * f, dq[6] * f, dq[7] * f);
@@ -921,7 +940,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
           dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qg, dpM[r], dk, 0, 0, 0);
         }
       }
-      if (j < L) {
+      if (j < L && j >= pad) {
         float* out = orow + (long long)j * ld;
         if (HD >= 8 || h2 == 0) {
           *(float4*)(out + p.d + 4 * h2) = make_float4(dk[0] * f, dk[1] * f, dk[2] * f, dk[3] * f);
@@ -945,16 +964,27 @@ static int make_dims(int B, int L, int d, int H, int causal, AttnDims* p) {
   p->nchunk = (L + 63) / 64;
   p->sqrt_hd = sqrtf((float)hd);
   p->scale = 1.0f / p->sqrt_hd;
+  p->seq_base = nullptr;
+  p->seq_pad = nullptr;
   return UR_OK;
 }
 
+bool attn_compact_supported(int L, int d, int H) {
+  if (H <= 0 || d % H) return false;
+  const int hd = d / H;
+  return L <= 64 && (hd == 4 || hd == 8 || hd == 16) && getenv("UR_ATTN_NO_MFMA") == nullptr;
+}
+
 int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int causal, float* ctx, float* lse,
-             int q_last_only, hipStream_t st) {
+             int q_last_only, hipStream_t st, const int* seq_base, const int* seq_pad) {
   if (q_last_only) return fail(UR_ERR_UNSUPPORTED, "attn_fwd: last-row mode not implemented");
   ProfScope ps(PC_ATTN_FWD, st, 4.0 * B * L * (double)L * d * (causal ? 0.5 : 1.0));
   AttnDims p;
   int rc = make_dims(B, L, d, H, causal, &p);
   if (rc) return rc;
+  p.seq_base = seq_base;
+  p.seq_pad = seq_pad;
+  if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need L <= 64 and head dim 4/8/16");
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
   if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
     dim3 g2(B, cdiv(H, 4));
@@ -982,12 +1012,15 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
 }
 
 int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dctx, const float* lse, int B, int L, int d,
-             int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st) {
+             int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st, const int* seq_base, const int* seq_pad) {
   if (q_last_only) return fail(UR_ERR_UNSUPPORTED, "attn_bwd: last-row mode not implemented");
   ProfScope ps(PC_ATTN_BWD, st, 10.0 * B * L * (double)L * d * (causal ? 0.5 : 1.0));
   AttnDims p;
   int rc = make_dims(B, L, d, H, causal, &p);
   if (rc) return rc;
+  p.seq_base = seq_base;
+  p.seq_pad = seq_pad;
+  if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need L <= 64 and head dim 4/8/16");
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
   if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
     dim3 g2(B, cdiv(H, 4));
@@ -1020,11 +1053,13 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
 }
 
 int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, int L, int d, int H, float* ctx_last,
-                  float* lse_last, hipStream_t st) {
+                  float* lse_last, hipStream_t st, const int* seq_base, const int* seq_pad) {
   ProfScope ps(PC_ATTN_FWD, st, 4.0 * B * (double)L * d);
   AttnDims p;
   int rc = make_dims(B, L, d, H, 1, &p);
   if (rc) return rc;
+  p.seq_base = seq_base;
+  p.seq_pad = seq_pad;
   dim3 grid(B, cdiv(H, 4));
 #define GO(HD) hipLaunchKernelGGL((attn_last_fwd_kernel<HD>), grid, dim3(256), 0, st, q_last, qkv, seq, p, ctx_last, lse_last)
   switch (p.hd) {
@@ -1041,11 +1076,14 @@ int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, 
 }
 
 int attn_last_bwd(const float* q_last, const float* qkv, const int* seq, const float* ctx_last, const float* dctx_last,
-                  const float* lse_last, int B, int L, int d, int H, float* dq_last, float* dqkv, hipStream_t st) {
+                  const float* lse_last, int B, int L, int d, int H, float* dq_last, float* dqkv, hipStream_t st,
+                  const int* seq_base, const int* seq_pad) {
   ProfScope ps(PC_ATTN_BWD, st, 8.0 * B * (double)L * d);
   AttnDims p;
   int rc = make_dims(B, L, d, H, 1, &p);
   if (rc) return rc;
+  p.seq_base = seq_base;
+  p.seq_pad = seq_pad;
   dim3 grid(B, cdiv(H, 4));
 #define GO(HD) hipLaunchKernelGGL((attn_last_bwd_kernel<HD>), grid, dim3(256), 0, st, q_last, qkv, seq, ctx_last, dctx_last, lse_last, p, dq_last, dqkv)
   switch (p.hd) {

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   float* As = smem;                 // [2][BM*LS]
   float* Ws = smem + 2 * BM * LS;   // [2][BN*LS]
 
+  if (a.m_dev) a.M = min(a.M, *a.m_dev);   // compacted token rows: the row count lives on the device
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
   // XCD-aware tile mapping: workgroup id b runs on XCD b % 8 (each XCD has its own L2).  All N-tiles of one M-tile are
@@ -339,7 +340,9 @@ constexpr int BT = 32;   // tokens per LDS stage
 template <int PRO>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q,
                                                       int ldq, int T, int R, int Cc, int tok_per_split, int n_splits, int act,
-                                                      float* __restrict__ part, float* __restrict__ bias_part) {
+                                                      float* __restrict__ part, float* __restrict__ bias_part,
+                                                      const int* __restrict__ t_dev) {
+  if (t_dev) T = min(T, *t_dev);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ps = smem;                  // [2][BT*TB]
   float* Qs = smem + 2 * BT * TB;    // [2][BT*TB]
@@ -539,7 +542,7 @@ int reduce_batch(ReduceBatch& rb, hipStream_t st) {
 }
 
 int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act, float* out,
-            int ldo, float* bias_out, float* ws, hipStream_t st, ReduceBatch* defer) {
+            int ldo, float* bias_out, float* ws, hipStream_t st, ReduceBatch* defer, const int* t_dev) {
   if ((R & 3) || (Cc & 3) || (ldp & 3) || (ldq & 3) || (ldo & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
   if (T <= 0) return fail(UR_ERR_ARG, "gemm_tn: T=%d", T);
   ProfScope ps(PC_GEMM_TN, st, 2.0 * T * R * Cc);
@@ -557,9 +560,9 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
     attr_set = true;
   }
   if (pro_act_on_q)
-    hipLaunchKernelGGL((gemm_tn_kernel<PRO_ACT>), grid, dim3(256), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part);
+    hipLaunchKernelGGL((gemm_tn_kernel<PRO_ACT>), grid, dim3(256), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev);
   else
-    hipLaunchKernelGGL((gemm_tn_kernel<PRO_NONE>), grid, dim3(256), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part);
+    hipLaunchKernelGGL((gemm_tn_kernel<PRO_NONE>), grid, dim3(256), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev);
   UR_LAUNCH_CHECK();
   const long long n = (long long)R * Cc;
   if (defer) {

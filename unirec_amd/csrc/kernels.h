@@ -8,8 +8,10 @@ constexpr int LN_BWD_MAX_BLOCKS = 512;
 
 // ---- rowops.hip
 int gather_rows(const float* table, const void* idx, int idx_bytes, long long n, int d, float* out, hipStream_t st);
+// tok (nullable): compact row r is token tok[r] of seq (= b*L + l); m_dev (nullable): device-side row count
 int embed_ln_fwd(const int* seq, const float* table, const float* pos, const float* gamma, const float* beta, float eps,
-                 int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st);
+                 int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st, const int* tok = nullptr,
+                 const int* m_dev = nullptr);
 int ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, int M, int d, float* y,
            float* xhat, float* rstd, hipStream_t st);
 // part_ws: LN_BWD_MAX_BLOCKS * 2 * d floats
@@ -33,9 +35,11 @@ struct ReduceBatch {
 int reduce_batch(ReduceBatch& rb, hipStream_t st);   // runs and empties the queue
 
 // defer != nullptr: part_ws must stay untouched until reduce_batch(*defer) has run
+// m_dev (nullable): device-side row count (M is then the maximum); out_rows (nullable): dx row r is written to row
+// out_rows[r] of dx (compact -> padded layout)
 int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* add_in,
            const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st,
-           ReduceBatch* defer = nullptr);
+           ReduceBatch* defer = nullptr, const int* m_dev = nullptr, const int* out_rows = nullptr);
 int pos_grad(const float* dx, int B, int L, int d, float* dpos, hipStream_t st);
 
 // ---- gemm.hip
@@ -60,6 +64,7 @@ struct GemmArgs {
   const float* aux2; int ldaux2; // EPI_ADD: optional second addend (nullable)
   const float* gamma; const float* beta; float eps;
   float* xhat; float* rstd;      // EPI_BIAS_RES_LN outputs
+  const int* m_dev;              // nullable: device-side row count, M = min(M, *m_dev) (compacted token rows)
   const long long* skip; long long skip_base;   // EPI_COUNT_GT: column skip[m] - skip_base of row m is left out (nullable)
   int debug;                     // tuning aid (UR_GEMM_DEBUG): 1 = skip epilogue, 2 = skip K-loop global loads
 };
@@ -69,7 +74,8 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st);
 // ws: gemm_tn_ws_floats(R, Cc) floats.
 long long gemm_tn_ws_floats(int T, int R, int Cc);
 int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act,
-            float* out, int ldo, float* bias_out, float* ws, hipStream_t st, ReduceBatch* defer = nullptr);
+            float* out, int ldo, float* bias_out, float* ws, hipStream_t st, ReduceBatch* defer = nullptr,
+            const int* t_dev = nullptr);   // t_dev (nullable): device-side token count, T = min(T, *t_dev)
 // dst[c,r] = src[r,c]
 int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
 struct TransposeItem { const float* src; float* dst; int rows, cols, first_block; };
@@ -87,15 +93,21 @@ int transpose_batch(TransposeBatch& tb, hipStream_t st);   // every queued trans
 
 // ---- attention.hip
 long long attn_lse_floats(int B, int H, int L);
+// Compacted token rows (padding skipped): seq_base / seq_pad (nullable, int[B]): position l of sequence b lives in row
+// seq_base[b] + l of qkv / ctx / dqkv for l >= seq_pad[b]; the padded prefix has no rows.  Supported by the MFMA
+// kernels (L <= 64, head dim 4/8/16: attn_compact_supported) and the last-row kernels.
+bool attn_compact_supported(int L, int d, int H);
 int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int causal, float* ctx, float* lse,
-             int q_last_only, hipStream_t st);
+             int q_last_only, hipStream_t st, const int* seq_base = nullptr, const int* seq_pad = nullptr);
 long long attn_bwd_ws_floats(int B, int H, int L);
 int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dctx, const float* lse, int B, int L,
-             int d, int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st);
+             int d, int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st,
+             const int* seq_base = nullptr, const int* seq_pad = nullptr);
 
 int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, int L, int d, int H, float* ctx_last,
-                  float* lse_last, hipStream_t st);
+                  float* lse_last, hipStream_t st, const int* seq_base = nullptr, const int* seq_pad = nullptr);
 int attn_last_bwd(const float* q_last, const float* qkv, const int* seq, const float* ctx_last, const float* dctx_last,
-                  const float* lse_last, int B, int L, int d, int H, float* dq_last, float* dqkv, hipStream_t st);
+                  const float* lse_last, int B, int L, int d, int H, float* dq_last, float* dqkv, hipStream_t st,
+                  const int* seq_base = nullptr, const int* seq_pad = nullptr);
 
 }  // namespace ur

@@ -72,13 +72,16 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
                                                            const float4* __restrict__ pos, const float4* __restrict__ gamma,
                                                            const float4* __restrict__ beta, float eps, int M, int L, int d4,
                                                            float4* __restrict__ y, float4* __restrict__ xhat,
-                                                           float* __restrict__ rstd_out) {
+                                                           float* __restrict__ rstd_out, const int* __restrict__ tok,
+                                                           const int* __restrict__ m_dev) {
   const int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const float inv_d = 1.0f / (float)(d4 * 4);
+  if (m_dev) M = min(M, *m_dev);
   for (int row = blockIdx.x * groups + g; row < M; row += gridDim.x * groups) {
-    const long long id = seq[row];
-    const int l = row % L;
+    const int full = tok ? tok[row] : row;   // position of this (compact) row in the padded [B, L] token grid
+    const long long id = seq[full];
+    const int l = full % L;
     float4 v[MAXV];
     float s = 0.f;
 #pragma unroll
@@ -122,14 +125,15 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
 }
 
 int embed_ln_fwd(const int* seq, const float* table, const float* pos, const float* gamma, const float* beta,
-                 float eps, int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st) {
+                 float eps, int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st, const int* tok,
+                 const int* m_dev) {
   ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * 3);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(M, groups);
   if (blocks > 4096) blocks = 4096;
 #define GO(T) hipLaunchKernelGGL((embed_ln_fwd_kernel<T>), dim3(blocks), dim3(256), 0, st, seq, (const float4*)table, \
                                  (const float4*)pos, (const float4*)gamma, (const float4*)beta, eps, M, L, d / 4,      \
-                                 (float4*)y, (float4*)xhat, rstd)
+                                 (float4*)y, (float4*)xhat, rstd, tok, m_dev)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;
@@ -222,10 +226,12 @@ template <int TPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ xhat,
                                                      const float* __restrict__ rstd, const float4* __restrict__ gamma,
                                                      const float4* add_in, const int* __restrict__ seq, int M, int d4,
-                                                     float4* dx_out, float* __restrict__ part) {
+                                                     float4* dx_out, float* __restrict__ part, const int* __restrict__ m_dev,
+                                                     const int* __restrict__ out_rows) {
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const float inv_d = 1.0f / (float)(d4 * 4);
+  if (m_dev) M = min(M, *m_dev);
   float4 dg[MAXV], db[MAXV];
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) dg[k] = db[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ 
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
         if (zero) o = make_float4(0.f, 0.f, 0.f, 0.f);
-        dx_out[(long long)row * d4 + c] = o;
+        dx_out[(long long)(out_rows ? out_rows[row] : row) * d4 + c] = o;
       }
     }
   }
@@ -313,14 +319,15 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
 
 int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* add_in,
            const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st,
-           ReduceBatch* defer) {
+           ReduceBatch* defer, const int* m_dev, const int* out_rows) {
   ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * 3);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(M, groups * 4);
   if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
 #define GO(T) hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float4*)dy, (const float4*)xhat, \
-                                 rstd, (const float4*)gamma, (const float4*)add_in, seq, M, d / 4, (float4*)dx, part_ws)
+                                 rstd, (const float4*)gamma, (const float4*)add_in, seq, M, d / 4, (float4*)dx, part_ws, m_dev, \
+                                 out_rows)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

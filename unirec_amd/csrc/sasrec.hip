@@ -64,6 +64,8 @@ struct Ws {
   LayerWs layer[UR_MAX_LAYERS];
   float *g_y, *g_a, *g_ctx, *tn_ws, *ln_part, *attn_ws;
   float *q_last, *dq_last, *lse_last;   // last-row specialisation of the final layer ([B,d] each)
+  float *x_last, *t_last;               // compact mode: gathered last rows of the layer input / their gradient
+  int *tok_full, *seq_base, *seq_pad, *last_row, *m_valid;   // compact mode: row maps (see compact_plan_kernel)
   long long total_floats, tn_floats, ln_floats;
 };
 
@@ -100,6 +102,9 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
   w.attn_ws = take(attn_bwd_ws_floats(c.B, c.n_heads, c.L));
   w.q_last = take((long long)c.B * d); w.dq_last = take((long long)c.B * d);
   w.lse_last = take((long long)c.B * c.n_heads);
+  w.x_last = take((long long)c.B * d); w.t_last = take((long long)c.B * d);
+  w.tok_full = (int*)take(M); w.seq_base = (int*)take(c.B); w.seq_pad = (int*)take(c.B); w.last_row = (int*)take(c.B);
+  w.m_valid = (int*)take(64);
   w.total_floats = o;
   return w;
 }
@@ -130,6 +135,76 @@ __global__ void put_last_kernel(const float* __restrict__ src, int B, int L, int
   const long long c = i % d, row = i / d, l = row % L, b = row / L;
   dst[i] = (l == L - 1) ? src[b * d + c] : 0.f;
 }
+
+// ---- padding skipped ("compact" token rows).  Sequences are left-padded, so the tokens of sequence b that can reach
+// the loss are positions pad_b .. L-1 (pad_b = first non-zero position; an all-padding sequence keeps all L positions: its
+// uniform attention over the padding rows IS what the reference computes).  Every token-parallel kernel of the layer
+// stack then runs over M' = sum_b (L - pad_b) compact rows instead of B*L:
+//   tok_full[r]  = b*L + l of compact row r          seq_base[b] = (first compact row of b) - pad_b  (row of (b,l) = seq_base[b] + l)
+//   seq_pad[b]   = pad_b                             last_row[b] = compact row of (b, L-1)          m_valid[0] = M'
+// M' stays on the device: grids are sized for B*L and surplus workgroups exit.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void compact_plan_kernel(const int* __restrict__ seq, int B, int L, int* __restrict__ tok_full,
+                                                            int* __restrict__ seq_base, int* __restrict__ seq_pad,
+                                                            int* __restrict__ last_row, int* __restrict__ m_valid) {
+  __shared__ int sc[1024];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < B; c0 += 1024) {
+    const int b = c0 + tid;
+    int pad = 0, len = 0;
+    if (b < B) {
+      int fv = L;
+      for (int l = 0; l < L; ++l)
+        if (seq[(long long)b * L + l] > 0) { fv = l; break; }
+      pad = fv == L ? 0 : fv;
+      len = L - pad;
+    }
+    sc[tid] = len;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+      const int v = tid >= off ? sc[tid - off] : 0;
+      __syncthreads();
+      sc[tid] += v;
+      __syncthreads();
+    }
+    const int base = carry_s + sc[tid] - len;    // first compact row of sequence b
+    if (b < B) {
+      seq_base[b] = base - pad;
+      seq_pad[b] = pad;
+      last_row[b] = base + len - 1;
+      for (int l = pad; l < L; ++l) tok_full[base + l - pad] = b * L + l;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s += sc[1023];
+    __syncthreads();
+  }
+  if (tid == 0) m_valid[0] = carry_s;
+}
+// dst[b,:] = src[idx[b],:]
+__global__ void gather_rows_idx_kernel(const float* __restrict__ src, const int* __restrict__ idx, int B, int d, float* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * d) return;
+  const long long b = i / d, c = i % d;
+  dst[i] = src[(long long)idx[b] * d + c];
+}
+// dst[idx[b],:] += src[b,:]     (idx injective)
+__global__ void scatter_add_rows_idx_kernel(const float* __restrict__ src, const int* __restrict__ idx, int B, int d, float* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * d) return;
+  const long long b = i / d, c = i % d;
+  dst[(long long)idx[b] * d + c] += src[i];
+}
+// dst[idx[b],:] = src[b,:]
+__global__ void put_rows_idx_kernel(const float* __restrict__ src, const int* __restrict__ idx, int B, int d, float* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * d) return;
+  const long long b = i / d, c = i % d;
+  dst[(long long)idx[b] * d + c] = src[i];
+}
+
+
 }  // namespace ur
 
 using namespace ur;
@@ -189,7 +264,18 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
   Ws w = carve(c, (float*)ws);
   const int M = c.B * c.L, d = c.d, I = c.inner;
   const float* pos = c.use_pos ? dense + lay.off[0] : nullptr;
-  rc = embed_ln_fwd(item_seq, item_table, pos, dense + lay.off[1], dense + lay.off[2], c.eps, M, c.L, d, w.x0, w.x0hat, w.rstd0, st);
+  // compact mode: the padded prefix of every sequence has no rows at all (see compact_plan_kernel)
+  const bool compact = c.skip_padding && attn_compact_supported(c.L, d, c.n_heads);
+  const int* mv = compact ? w.m_valid : nullptr;
+  const int* sbase = compact ? w.seq_base : nullptr;
+  const int* spad = compact ? w.seq_pad : nullptr;
+  if (compact) {
+    hipLaunchKernelGGL(compact_plan_kernel, dim3(1), dim3(1024), 0, st, item_seq, c.B, c.L, w.tok_full, w.seq_base, w.seq_pad, w.last_row,
+                       w.m_valid);
+    UR_LAUNCH_CHECK();
+  }
+  rc = embed_ln_fwd(item_seq, item_table, pos, dense + lay.off[1], dense + lay.off[2], c.eps, M, c.L, d, w.x0, w.x0hat, w.rstd0, st,
+                    compact ? w.tok_full : nullptr, mv);
   if (rc) return rc;
   const float* x = w.x0;
   for (int i = 0; i < c.n_layers; ++i) {
@@ -200,14 +286,20 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       // Final layer, exact last-row specialisation: K,V for every position, everything else for row L-1 only.
       const int B = c.B;
       const float* x_last = x + (long long)(c.L - 1) * d;   // rows (b, L-1): a strided view, leading dimension L*d
-      const int ld_last = c.L * d;
+      int ld_last = c.L * d;
+      if (compact) {   // the last rows are not equally spaced any more: gather them
+        hipLaunchKernelGGL(gather_rows_idx_kernel, dim3(cdiv((long long)B * d, 256)), dim3(256), 0, st, x, w.last_row, B, d, w.x_last);
+        UR_LAUNCH_CHECK();
+        x_last = w.x_last;
+        ld_last = d;
+      }
       g.A = x; g.lda = d; g.W = p.wqkv + (long long)d * d; g.ldw = d; g.C = lw.qkv + d; g.ldc = 3 * d; g.M = M; g.N = 2 * d; g.K = d;
-      g.bias = p.bqkv + d;
+      g.bias = p.bqkv + d; g.m_dev = mv;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
       g = GemmArgs{};
       g.A = x_last; g.lda = ld_last; g.W = p.wqkv; g.ldw = d; g.C = w.q_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bqkv;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
-      if ((rc = attn_last_fwd(w.q_last, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st))) return rc;
+      if ((rc = attn_last_fwd(w.q_last, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st, sbase, spad))) return rc;
       g = GemmArgs{};
       g.A = lw.ctx; g.lda = d; g.W = p.wo; g.ldw = d; g.C = lw.a; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bo;
       g.aux = x_last; g.ldaux = ld_last; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1;
@@ -221,22 +313,24 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       return gemm_nt(g, PRO_ACT, EPI_BIAS_RES_LN, st);
     }
     g.A = x; g.lda = d; g.W = p.wqkv; g.ldw = d; g.C = lw.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d; g.bias = p.bqkv;
+    g.m_dev = mv;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
-    if ((rc = attn_fwd(lw.qkv, item_seq, c.B, c.L, d, c.n_heads, c.use_pos, lw.ctx, lw.lse, 0, st))) return rc;
+    if ((rc = attn_fwd(lw.qkv, item_seq, c.B, c.L, d, c.n_heads, c.use_pos, lw.ctx, lw.lse, 0, st, sbase, spad))) return rc;
     g = GemmArgs{};
     g.A = lw.ctx; g.lda = d; g.W = p.wo; g.ldw = d; g.C = lw.a; g.ldc = d; g.M = M; g.N = d; g.K = d; g.bias = p.bo;
-    g.aux = x; g.ldaux = d; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1;
+    g.aux = x; g.ldaux = d; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1; g.m_dev = mv;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS_RES_LN, st))) return rc;
     g = GemmArgs{};
-    g.A = lw.a; g.lda = d; g.W = p.w1; g.ldw = d; g.C = lw.h1; g.ldc = I; g.M = M; g.N = I; g.K = d; g.bias = p.b1;
+    g.A = lw.a; g.lda = d; g.W = p.w1; g.ldw = d; g.C = lw.h1; g.ldc = I; g.M = M; g.N = I; g.K = d; g.bias = p.b1; g.m_dev = mv;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
     g = GemmArgs{};
     g.A = lw.h1; g.lda = I; g.W = p.w2; g.ldw = I; g.C = lw.y; g.ldc = d; g.M = M; g.N = d; g.K = I; g.bias = p.b2; g.act = c.act;
-    g.aux = lw.a; g.ldaux = d; g.gamma = p.g2; g.beta = p.b2ln; g.eps = c.eps; g.xhat = lw.yhat; g.rstd = lw.rstd2;
+    g.aux = lw.a; g.ldaux = d; g.gamma = p.g2; g.beta = p.b2ln; g.eps = c.eps; g.xhat = lw.yhat; g.rstd = lw.rstd2; g.m_dev = mv;
     if ((rc = gemm_nt(g, PRO_ACT, EPI_BIAS_RES_LN, st))) return rc;
     x = lw.y;
   }
-  hipLaunchKernelGGL(take_last_kernel, dim3(cdiv((long long)c.B * d, 256)), dim3(256), 0, st, x, c.B, c.L, d, user_emb);
+  if (compact) hipLaunchKernelGGL(gather_rows_idx_kernel, dim3(cdiv((long long)c.B * d, 256)), dim3(256), 0, st, x, w.last_row, c.B, d, user_emb);
+  else hipLaunchKernelGGL(take_last_kernel, dim3(cdiv((long long)c.B * d, 256)), dim3(256), 0, st, x, c.B, c.L, d, user_emb);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }
@@ -253,6 +347,10 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   const Layout lay = make_layout(c);
   Ws w = carve(c, (float*)ws);
   const int M = c.B * c.L, d = c.d, I = c.inner;
+  const bool compact = c.skip_padding && attn_compact_supported(c.L, d, c.n_heads);   // row maps were built by ur_sasrec_fwd
+  const int* mv = compact ? w.m_valid : nullptr;
+  const int* sbase = compact ? w.seq_base : nullptr;
+  const int* spad = compact ? w.seq_pad : nullptr;
   ReduceBatch rb;                       // second stages of all split reductions: one launch at the end
   float* tn_cur = w.tn_ws;
   float* ln_cur = w.ln_part;
@@ -269,7 +367,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   // weight-gradient GEMM, forked onto the side stream (its inputs are complete at this point of the main stream)
   SideCtx* sc = (c.n_layers <= 2) ? side_ctx() : nullptr;   // the queue of deferred reductions must not flush mid-pass
   int n_fork = 0;
-  struct PendingTn { const float *P, *Q; int ldp, ldq, T, R, C, pro_act, act, ldo; float *out, *bias_out, *ws; };
+  struct PendingTn { const float *P, *Q; int ldp, ldq, T, R, C, pro_act, act, ldo; float *out, *bias_out, *ws; const int* t_dev; };
   PendingTn pend[8];
   int n_pend = 0;
   // launch the queued weight-gradient GEMMs: on the side stream behind ONE event of the main stream (every queued GEMM's
@@ -285,7 +383,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     }
     for (int i = 0; i < n_pend; ++i) {
       const PendingTn& t = pend[i];
-      int rc2 = gemm_tn(t.P, t.ldp, t.Q, t.ldq, t.T, t.R, t.C, t.pro_act, t.act, t.out, t.ldo, t.bias_out, t.ws, s2, &rb);
+      int rc2 = gemm_tn(t.P, t.ldp, t.Q, t.ldq, t.T, t.R, t.C, t.pro_act, t.act, t.out, t.ldo, t.bias_out, t.ws, s2, &rb, t.t_dev);
       if (rc2) return rc2;
     }
     n_pend = 0;
@@ -297,13 +395,19 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       int rc2 = fork();
       if (rc2) return rc2;
     }
-    pend[n_pend++] = PendingTn{P, Q, ldp, ldq, T_, R_, C_, pro_act, act, ldo, out, bias_out, tn_take(T_, R_, C_)};
+    pend[n_pend++] = PendingTn{P, Q, ldp, ldq, T_, R_, C_, pro_act, act, ldo, out, bias_out, tn_take(T_, R_, C_), T_ == M ? mv : nullptr};
     return sc ? UR_OK : fork();
   };
   if (!c.last_only) {
-    hipLaunchKernelGGL(put_last_kernel, dim3(cdiv((long long)M * d, 256)), dim3(256), 0, st, d_user_emb, c.B, c.L, d, w.g_y);
+    if (compact) {
+      UR_HIP(hipMemsetAsync(w.g_y, 0, (size_t)M * d * sizeof(float), st));
+      hipLaunchKernelGGL(put_rows_idx_kernel, dim3(cdiv((long long)c.B * d, 256)), dim3(256), 0, st, d_user_emb, w.last_row, c.B, d, w.g_y);
+    } else {
+      hipLaunchKernelGGL(put_last_kernel, dim3(cdiv((long long)M * d, 256)), dim3(256), 0, st, d_user_emb, c.B, c.L, d, w.g_y);
+    }
     UR_LAUNCH_CHECK();
   }
+  if (compact) UR_HIP(hipMemsetAsync(d_emb_rows, 0, (size_t)M * d * sizeof(float), st));   // padded positions: zero rows
   {   // weight transposes for the activation-gradient GEMMs of every layer, one launch (up to 8 layers per launch);
       // the same launch zero-fills dense_grad (slots nobody writes: unused position rows, absent parameters)
     TransposeBatch tb;
@@ -345,15 +449,23 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       g = GemmArgs{};
       g.A = lw.g_ta; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
-      if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, lw.g_qkv, st))) return rc;
+      if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, lw.g_qkv, st, sbase, spad))) return rc;
       // dWq from the B last rows, dWk/dWv from all rows
-      if ((rc = tn(w.dq_last, d, x_in + (long long)(c.L - 1) * d, c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
+      if ((rc = tn(w.dq_last, d, compact ? w.x_last : x_in + (long long)(c.L - 1) * d, compact ? d : c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
       if ((rc = tn(lw.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4]))) return rc;
       if ((rc = fork())) return rc;
       g = GemmArgs{};   // g_x = [dK dV] Wkv  for every row
-      g.A = lw.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 2 * d;
+      g.A = lw.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = 2 * d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
       g = GemmArgs{};   // rows L-1 additionally get dq Wq + the residual branch of the attention LayerNorm
+      if (compact) {   // last rows are irregularly spaced: dq Wq + g_ta into a [B,d] buffer, then add it onto those rows
+        g.A = w.dq_last; g.lda = d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.t_last; g.ldc = d; g.M = B; g.N = d; g.K = d;
+        g.aux = lw.g_ta; g.ldaux = d;
+        if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
+        hipLaunchKernelGGL(scatter_add_rows_idx_kernel, dim3(cdiv((long long)B * d, 256)), dim3(256), 0, st, w.t_last, w.last_row, B, d, w.g_y);
+        UR_LAUNCH_CHECK();
+        continue;
+      }
       float* gy_last = w.g_y + (long long)(c.L - 1) * d;   // in place on the strided last rows (each element: one thread reads then writes it)
       g.A = w.dq_last; g.lda = d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = gy_last; g.ldc = c.L * d; g.M = B; g.N = d; g.K = d;
       g.aux = lw.g_ta; g.ldaux = d; g.aux2 = gy_last; g.ldaux2 = c.L * d;
@@ -361,37 +473,37 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       continue;
     }
     // ---- feed-forward block
-    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb))) return rc;
+    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb, mv))) return rc;
     if ((rc = tn(lw.g_tf, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
     GemmArgs g{};
-    g.A = lw.g_tf; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = M; g.N = I; g.K = d;
+    g.A = lw.g_tf; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = M; g.m_dev = mv; g.N = I; g.K = d;
     g.aux = lw.h1; g.ldaux = I; g.act = c.act;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
     if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
     if ((rc = fork())) return rc;
     g = GemmArgs{};
-    g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
+    g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
     // ---- attention block
-    if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb))) return rc;
+    if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb, mv))) return rc;
     if ((rc = tn(lw.g_ta, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
     g = GemmArgs{};
-    g.A = lw.g_ta; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.N = d; g.K = d;
+    g.A = lw.g_ta; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
     // fork dWo now: it then runs underneath the attention backward instead of queueing up behind it at the very end of
     // the pass, where the side stream would finish after the main one (one more event, ~30 us off the tail)
     if ((rc = fork())) return rc;
-    if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st))) return rc;
+    if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad))) return rc;
     if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
     if ((rc = fork())) return rc;
     g = GemmArgs{};
-    g.A = lw.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.N = d; g.K = 3 * d;
+    g.A = lw.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = 3 * d;
     g.aux = lw.g_ta; g.ldaux = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
   }
   // ---- input block: LN0 backward -> row gradients of E[item_seq] and of the position table
   if ((rc = ln_bwd(w.g_y, w.x0hat, w.rstd0, dense + lay.off[1], nullptr, nullptr, M, d, d_emb_rows, dense_grad + lay.off[1],
-                   dense_grad + lay.off[2], ln_take(), st, &rb)))
+                   dense_grad + lay.off[2], ln_take(), st, &rb, mv, compact ? w.tok_full : nullptr)))
     return rc;
   // position-table gradient dP[l,:] = sum_b dx[b,l,:] (no padding index: sasrec.py:25): a split reduction over b with
   // partial stride L*d, queued with the others.  Row L of the table is never looked up (dense_grad was zeroed).

@@ -54,7 +54,8 @@ class SASRec(BaseRecommender):
     def _cfg(self, B):
         return ops.sasrec_cfg(B, self.max_seq_len, self.hidden_size, self.n_heads, self.inner_size, self.n_layers,
                               self.hidden_act, self.use_pos_emb, self.layer_norm_eps,
-                              last_only=int(self.config.get("last_row_only", 1)))
+                              last_only=int(self.config.get("last_row_only", 1)),
+                              skip_padding=int(self.config.get("skip_padding", 1)))
 
     def _workspace(self, cfg):
         key = cfg.B

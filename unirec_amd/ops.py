@@ -45,9 +45,10 @@ def embedding_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------- SASRec
-def sasrec_cfg(B, L, d, n_heads, inner, n_layers, act, use_pos, eps, last_only=1) -> UrSasrecCfg:
-    """last_only=1: exact last-row specialisation of the final layer (only position L-1 reaches the loss)."""
-    return UrSasrecCfg(B, L, d, n_heads, inner, n_layers, ACT_IDS[act], int(bool(use_pos)), float(eps), int(last_only))
+def sasrec_cfg(B, L, d, n_heads, inner, n_layers, act, use_pos, eps, last_only=1, skip_padding=1) -> UrSasrecCfg:
+    """last_only=1: exact last-row specialisation of the final layer (only position L-1 reaches the loss).
+    skip_padding=1: padded prefixes get no token rows (exact; applies when L <= 64 and head dim is 4/8/16)."""
+    return UrSasrecCfg(B, L, d, n_heads, inner, n_layers, ACT_IDS[act], int(bool(use_pos)), float(eps), int(last_only), int(skip_padding))
 
 
 def sasrec_param_layout(cfg: UrSasrecCfg):
