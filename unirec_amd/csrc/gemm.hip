@@ -292,6 +292,9 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
   static const int force = getenv("UR_GEMM_TILE") ? atoi(getenv("UR_GEMM_TILE")) : 0;   // tuning aid: 64 or 128 rows
   if (a.N <= 64) return launch_nt<64, 64, PRO, EPI>(a, st);
   if (small_m(a)) return launch_nt<32, 128, PRO, EPI>(a, st);
+  // compacted rows and a one-tile-wide output: the 64-row grid (M/64 workgroups, ~1.5 per CU) hides the rows that were
+  // skipped behind wave quantisation; 32-row tiles let the saving through
+  if (a.m_dev && a.N <= 128) return launch_nt<32, 128, PRO, EPI>(a, st);
   // short K, wide N (QKV, FFN-1, d-act): the 16-deep K-step variant keeps 4 workgroups per CU resident and measured
   // 6-10 % faster at M = 25600; elsewhere the 32-deep step wins
   if (force == 16 || (force == 0 && a.K <= 128 && a.N >= 256)) return launch_nt<64, 128, PRO, EPI, 16>(a, st);
@@ -309,7 +312,7 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
     return fail(UR_ERR_ARG, "gemm_nt: N, K and all leading dimensions must be multiples of 4 (N=%d K=%d)", a.N, a.K);
   if (epi == EPI_BIAS_RES_LN) {
     if (a.N > 256 || a.ldc != a.N) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm needs N<=256 (N=%d)", a.N);
-    if (a.N <= 128 && small_m(a))
+    if (a.N <= 128 && (small_m(a) || a.m_dev))
       return pro == PRO_ACT ? launch_nt<32, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
                             : launch_nt<32, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
     if (a.N <= 128) return pro == PRO_ACT ? launch_nt<64, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
@@ -342,7 +345,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                                                       int ldq, int T, int R, int Cc, int tok_per_split, int n_splits, int act,
                                                       float* __restrict__ part, float* __restrict__ bias_part,
                                                       const int* __restrict__ t_dev) {
-  if (t_dev) T = min(T, *t_dev);
+  if (t_dev) {   // compacted token rows: spread the ACTUAL tokens over the splits (the host sized the split for the maximum)
+    T = min(T, *t_dev);
+    tok_per_split = (((T + n_splits - 1) / n_splits + BT - 1) / BT) * BT;
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ps = smem;                  // [2][BT*TB]
   float* Qs = smem + 2 * BT * TB;    // [2][BT*TB]

@@ -147,37 +147,51 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(const int* __restric
                                                             int* __restrict__ seq_base, int* __restrict__ seq_pad,
                                                             int* __restrict__ last_row, int* __restrict__ m_valid) {
   __shared__ int sc[1024];
+  __shared__ int s_pad[1024];
   __shared__ int carry_s;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
   for (int c0 = 0; c0 < B; c0 += 1024) {
-    const int b = c0 + tid;
-    int pad = 0, len = 0;
-    if (b < B) {
-      int fv = L;
-      for (int l = 0; l < L; ++l)
-        if (seq[(long long)b * L + l] > 0) { fv = l; break; }
-      pad = fv == L ? 0 : fv;
-      len = L - pad;
+    // first non-zero position of each sequence: one wave per sequence, lanes = positions (coalesced), ballot + ctz
+    for (int q = wave; q < 1024; q += 16) {
+      const int b = c0 + q;
+      int pad = 0, len = 0;
+      if (b < B) {   // wave-uniform
+        int fv = L;
+        for (int l0 = 0; l0 < L && fv == L; l0 += 64) {
+          const unsigned long long m = __ballot(l0 + lane < L && seq[(long long)b * L + l0 + lane] > 0);
+          if (m) fv = l0 + (int)__builtin_ctzll(m);
+        }
+        pad = fv == L ? 0 : fv;
+        len = L - pad;
+      }
+      if (lane == 0) { sc[q] = len; s_pad[q] = pad; }
     }
-    sc[tid] = len;
     __syncthreads();
+    const int len = sc[tid];
     for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
       const int v = tid >= off ? sc[tid - off] : 0;
       __syncthreads();
       sc[tid] += v;
       __syncthreads();
     }
-    const int base = carry_s + sc[tid] - len;    // first compact row of sequence b
-    if (b < B) {
-      seq_base[b] = base - pad;
-      seq_pad[b] = pad;
-      last_row[b] = base + len - 1;
-      for (int l = pad; l < L; ++l) tok_full[base + l - pad] = b * L + l;
+    const int total = sc[1023];
+    const int base = carry_s + sc[tid] - len;    // first compact row of sequence c0 + tid
+    __syncthreads();
+    sc[tid] = base;
+    if (c0 + tid < B) {
+      seq_base[c0 + tid] = base - s_pad[tid];
+      seq_pad[c0 + tid] = s_pad[tid];
+      last_row[c0 + tid] = base + len - 1;
     }
     __syncthreads();
-    if (tid == 1023) carry_s += sc[1023];
+    for (int q = wave; q < 1024 && c0 + q < B; q += 16) {   // token map, one wave per sequence (coalesced)
+      const int b = c0 + q, pad = s_pad[q], bs = sc[q];
+      for (int l = pad + lane; l < L; l += 64) tok_full[bs + l - pad] = b * L + l;
+    }
+    __syncthreads();
+    if (tid == 0) carry_s += total;
     __syncthreads();
   }
   if (tid == 0) m_valid[0] = carry_s;
