@@ -609,7 +609,14 @@ int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st) 
 // several transposes in ONE launch (all weight matrices of the encoder before its backward pass: 8 launches -> 1)
 __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb) {
   __shared__ float tile[32][33];
-  if (tb.zero_ptr && (int)blockIdx.x >= tb.zero_first_block) {   // rider: zero-fill (the backward's gradient buffer)
+  if (tb.zero2_ptr && (int)blockIdx.x >= tb.zero2_first_block) {   // riders: zero-fill (the backward's gradient buffers)
+    const long long i0 = ((long long)(blockIdx.x - tb.zero2_first_block) * 256 + threadIdx.x) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (i0 + q * 4 < tb.zero2_n) *(float4*)(tb.zero2_ptr + i0 + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  if (tb.zero_ptr && (int)blockIdx.x >= tb.zero_first_block) {
     const long long i0 = ((long long)(blockIdx.x - tb.zero_first_block) * 256 + threadIdx.x) * 16;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -640,6 +647,10 @@ int transpose_batch(TransposeBatch& tb, hipStream_t st) {
   if (tb.zero_ptr) {
     tb.zero_first_block = blocks;
     blocks += cdiv(tb.zero_n, 4096);
+  }
+  if (tb.zero2_ptr) {
+    tb.zero2_first_block = blocks;
+    blocks += cdiv(tb.zero2_n, 4096);
   }
   hipLaunchKernelGGL(transpose_batch_kernel, dim3(blocks), dim3(256), 0, st, tb);
   UR_LAUNCH_CHECK();

@@ -83,6 +83,7 @@ struct TransposeBatch {
   static constexpr int MAX = 32;
   TransposeItem item[MAX]; int n = 0;
   float* zero_ptr = nullptr; long long zero_n = 0; int zero_first_block = 0;   // optional: also zero-fill a buffer (n % 4 == 0)
+  float* zero2_ptr = nullptr; long long zero2_n = 0; int zero2_first_block = 0; // ... and a second one
   bool add(const float* src, int rows, int cols, float* dst) {
     if (n >= MAX) return false;
     item[n++] = TransposeItem{src, dst, rows, cols, 0};

@@ -146,30 +146,25 @@ __global__ void put_last_kernel(const float* __restrict__ src, int B, int L, int
 __global__ __launch_bounds__(1024) void compact_plan_kernel(const int* __restrict__ seq, int B, int L, int* __restrict__ tok_full,
                                                             int* __restrict__ seq_base, int* __restrict__ seq_pad,
                                                             int* __restrict__ last_row, int* __restrict__ m_valid) {
-  __shared__ int sc[1024];
-  __shared__ int s_pad[1024];
+  __shared__ int sc[1024];      // scan scratch, then the first compact row of each sequence of the chunk
+  __shared__ int s_pad[1024];   // first non-zero position (L if none)
   __shared__ int carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   if (tid == 0) carry_s = 0;
-  __syncthreads();
   for (int c0 = 0; c0 < B; c0 += 1024) {
-    // first non-zero position of each sequence: one wave per sequence, lanes = positions (coalesced), ballot + ctz
-    for (int q = wave; q < 1024; q += 16) {
-      const int b = c0 + q;
-      int pad = 0, len = 0;
-      if (b < B) {   // wave-uniform
-        int fv = L;
-        for (int l0 = 0; l0 < L && fv == L; l0 += 64) {
-          const unsigned long long m = __ballot(l0 + lane < L && seq[(long long)b * L + l0 + lane] > 0);
-          if (m) fv = l0 + (int)__builtin_ctzll(m);
-        }
-        pad = fv == L ? 0 : fv;
-        len = L - pad;
-      }
-      if (lane == 0) { sc[q] = len; s_pad[q] = pad; }
-    }
+    const int nb = min(1024, B - c0);
+    s_pad[tid] = L;
     __syncthreads();
-    const int len = sc[tid];
+    // one thread per token, all loads independent and coalesced; LDS atomicMin finds each sequence's first item
+    for (int idx = tid; idx < nb * L; idx += 1024)
+      if (seq[(long long)c0 * L + idx] > 0) atomicMin(&s_pad[idx / L], idx % L);
+    __syncthreads();
+    const int pad = tid < nb ? (s_pad[tid] == L ? 0 : s_pad[tid]) : 0;   // all padding: keep every position
+    const int len = tid < nb ? L - pad : 0;
+    __syncthreads();
+    s_pad[tid] = pad;
+    sc[tid] = len;
+    __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
       const int v = tid >= off ? sc[tid - off] : 0;
       __syncthreads();
@@ -180,15 +175,15 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(const int* __restric
     const int base = carry_s + sc[tid] - len;    // first compact row of sequence c0 + tid
     __syncthreads();
     sc[tid] = base;
-    if (c0 + tid < B) {
-      seq_base[c0 + tid] = base - s_pad[tid];
-      seq_pad[c0 + tid] = s_pad[tid];
+    if (tid < nb) {
+      seq_base[c0 + tid] = base - pad;
+      seq_pad[c0 + tid] = pad;
       last_row[c0 + tid] = base + len - 1;
     }
     __syncthreads();
-    for (int q = wave; q < 1024 && c0 + q < B; q += 16) {   // token map, one wave per sequence (coalesced)
-      const int b = c0 + q, pad = s_pad[q], bs = sc[q];
-      for (int l = pad + lane; l < L; l += 64) tok_full[bs + l - pad] = b * L + l;
+    for (int idx = tid; idx < nb * L; idx += 1024) {   // token map, one thread per token
+      const int b = idx / L, l = idx % L;
+      if (l >= s_pad[b]) tok_full[sc[b] + l - s_pad[b]] = c0 * L + idx;
     }
     __syncthreads();
     if (tid == 0) carry_s += total;
@@ -421,12 +416,13 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     }
     UR_LAUNCH_CHECK();
   }
-  if (compact) UR_HIP(hipMemsetAsync(d_emb_rows, 0, (size_t)M * d * sizeof(float), st));   // padded positions: zero rows
+
   {   // weight transposes for the activation-gradient GEMMs of every layer, one launch (up to 8 layers per launch);
       // the same launch zero-fills dense_grad (slots nobody writes: unused position rows, absent parameters)
     TransposeBatch tb;
     if (lay.total % 4 == 0) { tb.zero_ptr = dense_grad; tb.zero_n = lay.total; }
     else UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
+    if (compact) { tb.zero2_ptr = d_emb_rows; tb.zero2_n = (long long)M * d; }   // padded positions: zero gradient rows
     for (int i = 0; i < c.n_layers; ++i) {
       const LayerP p = layer_ptrs(dense, lay, i);
       LayerWs& lw = w.layer[i];
@@ -434,6 +430,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
         if ((rc = transpose_batch(tb, st))) return rc;
         tb.n = 0;
         tb.zero_ptr = nullptr;
+        tb.zero2_ptr = nullptr;
       }
       tb.add(p.wqkv, 3 * d, d, lw.wqkvT); tb.add(p.wo, d, d, lw.woT); tb.add(p.w1, I, d, lw.w1T); tb.add(p.w2, d, I, lw.w2T);
     }
