@@ -309,11 +309,29 @@ def main():
         dt = float(t.item())
     final_loss = float(loss.detach())
     classes = prof_read()
+    # ---- after the timed region: the same class once more with the backward's side stream switched off, i.e. launch
+    # durations that are not stretched by the weight-gradient GEMMs running concurrently (reported as roofline.isolated)
+    iso = None
+    if dom is not None and world == 1:
+        prev = _lib.lib.ur_sasrec_set_side_stream(0)
+        _lib.lib.ur_prof_reset()
+        _lib.lib.ur_prof_enable(1)
+        for i in range(10):
+            step_fn(batches[(a.warmup + i) % len(batches)], None)
+        barrier()
+        _lib.lib.ur_prof_enable(0)
+        _lib.lib.ur_sasrec_set_side_stream(prev)
+        iso = prof_read()[dom]
     _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
     if rank != 0:
         return
 
     B, L, G, d = a.batch, a.seq_len, a.negatives + 1, a.d
+    # fraction of the B*L token slots that hold real tokens (left padding skipped; an all-padding row keeps its L slots)
+    seqs = torch.stack([b["item_seq"] for b in batches[a.warmup:a.warmup + a.steps]])
+    first = (seqs > 0).int().argmax(-1)
+    lens = torch.where((seqs > 0).any(-1), L - first, torch.full_like(first, L))
+    valid_frac = float(lens.float().mean() / L) if (L <= 64 and (d // a.heads) in (4, 8, 16)) else 1.0
     ex_per_s = world * B * a.steps / dt
     ms_per_step = dt / a.steps * 1e3
     # dominant kernel class by measured device time inside the timed region
@@ -321,10 +339,18 @@ def main():
     if c["ms"] <= 0:
         roof = None   # --no-prof: kernels were not bracketed
     elif dom in ("gemm_nt", "gemm_tn"):
-        achieved = c["work"] / (c["ms"] * 1e-3) / 1e12
+        # the library counts 2*M*N*K with the PADDED row count M = B*L; with padding skipped (the default) only the rows
+        # of real tokens are computed, so the algorithmic flops are scaled by the batches' real-token fraction
+        achieved = c["work"] * valid_frac / (c["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": f"{dom}_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(achieved, 2),
                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                "launches": c["launches"], "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2)}
+                "launches": c["launches"], "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2),
+                "real_token_fraction": round(valid_frac, 4)}
+        if iso is not None and iso["ms"] > 0:
+            ach_iso = iso["work"] * valid_frac / (iso["ms"] * 1e-3) / 1e12
+            roof["isolated"] = {"achieved": round(ach_iso, 2), "frac": round(ach_iso / MFMA_F32_PEAK_TFLOPS, 4), "launches": iso["launches"],
+                                "avg_launch_us": round(iso["ms"] * 1e3 / max(1, iso["launches"]), 2),
+                                "note": "same class, 10 extra steps after the timed region with the side stream off (no concurrent dW GEMMs)"}
     else:
         achieved = c["work"] / (c["ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -339,7 +365,7 @@ def main():
         if dom in per_class:
             roof["traffic"] = per_class[dom]["hbm_bytes_per_launch"]
             roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json)"
-            roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * 1e6 / max(1, c["launches"] / max(1, (a.steps + PROF_EVERY - 1) // PROF_EVERY)))
+            roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * valid_frac * 1e6 / max(1, c["launches"] / max(1, (a.steps + PROF_EVERY - 1) // PROF_EVERY)))
     emb_bytes_per_example = 8 * (L + G) * d * 4   # fwd read + bwd/opt touched rows (w,m,v,grad)
     out = {
         "metric": "training_examples_per_sec", "value": round(ex_per_s, 1), "unit": "examples/s", "n_gpus": world,

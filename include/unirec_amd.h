@@ -91,6 +91,11 @@ int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_ite
                   const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
                   float* d_emb_rows, void* stream);
 
+/* ur_sasrec_bwd forks its weight-gradient GEMMs onto a second HIP stream (joined before it returns, so the call stays
+ * stream-ordered for the caller).  0 keeps everything on the caller's stream (measurement of isolated kernel durations,
+ * debugging); returns the previous setting.  Default 1 (also: environment UR_SASREC_SIDE=0). */
+int ur_sasrec_set_side_stream(int on);
+
 /* ---------------------------------------------------------------------------------------------
  * GRU user encoder (unirec/model/sequential/gru.py:13-35; arithmetic of torch.nn.GRU, 1 layer, batch_first,
  * h0 = 0, gate order r,z,n; all L steps run including the left padding; user_emb = dense(h_{L-1})).

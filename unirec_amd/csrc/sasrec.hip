@@ -245,7 +245,9 @@ struct SideCtx {
   hipEvent_t done = nullptr;
   bool ok = false;
 };
+int g_side_enabled = 1;   // runtime switch (ur_sasrec_set_side_stream)
 SideCtx* side_ctx() {
+  if (!g_side_enabled) return nullptr;
   static SideCtx* ctx = []() -> SideCtx* {
     const char* e = getenv("UR_SASREC_SIDE");
     if (e && atoi(e) == 0) return nullptr;
@@ -529,4 +531,10 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     UR_HIP(hipStreamWaitEvent(st, sc->done, 0));
   }
   return reduce_batch(rb, st);
+}
+
+extern "C" int ur_sasrec_set_side_stream(int on) {
+  const int prev = g_side_enabled;
+  g_side_enabled = on ? 1 : 0;
+  return prev;
 }
