@@ -453,8 +453,7 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       g.A = lw.g_tf; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.aux = lw.h1; g.ldaux = I; g.act = c.act;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
       if ((rc = tn(lw.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
-      if ((rc = fork())) return rc;
-      g = GemmArgs{};
+      g = GemmArgs{};   // (the small weight-gradient GEMMs of this layer are forked together, once, below)
       g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = B; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
       if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, B, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb))) return rc;
