@@ -91,6 +91,17 @@ int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_ite
                   const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
                   float* d_emb_rows, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Pooled-history user encoders: AvgHist (unirec/model/sequential/avghist.py:35-42) and SVD++
+ * (unirec/model/sequential/svdplusplus.py:32-40):
+ *   user_emb[b,:] = base[b,:] + (seq_len[b] + 1)^(-alpha) * sum_l E[item_seq[b,l],:]      (base nullable; E[0] = 0)
+ * backward: d_rows[b*L + l,:] = (seq_len[b] + 1)^(-alpha) * d_user_emb[b,:]  (row-sparse gradient of E in item_seq order;
+ * d base = d_user_emb).  item_seq int32[B,L], seq_len int64[B]. */
+int ur_pool_rows_fwd(const float* table, int64_t n_rows, int32_t d, const int32_t* item_seq, const int64_t* seq_len,
+                     const float* base, float alpha, int32_t B, int32_t L, float* user_emb, void* stream);
+int ur_pool_rows_bwd(const float* d_user_emb, const int64_t* seq_len, float alpha, int32_t B, int32_t L, int32_t d,
+                     float* d_rows, void* stream);
+
 /* ur_sasrec_bwd forks its weight-gradient GEMMs onto a second HIP stream (joined before it returns, so the call stays
  * stream-ordered for the caller).  0 keeps everything on the caller's stream (measurement of isolated kernel durations,
  * debugging); returns the previous setting.  Default 1 (also: environment UR_SASREC_SIDE=0). */

@@ -236,6 +236,10 @@ def model_forward(P: Params, batch: dict, cfg: dict, reduction: bool = True, col
         user_emb = gru_user_emb(P, batch["item_seq"], cfg, collect)
     elif model == "MF":
         user_emb = mf_user_emb(P, batch["user_id"])
+    elif model in ("AvgHist", "SVDPlusPlus"):
+        dst = "item_dst_embedding.weight" if (model == "SVDPlusPlus" or cfg.get("asymmetric", True)) else "item_embedding.weight"
+        user_emb = pooled_user_emb(P, batch["item_seq"], batch["item_seq_len"], float(cfg.get("user_sequence_alpha", 0.5)), dst,
+                                   batch["user_id"] if model == "SVDPlusPlus" else None)
     else:
         raise KeyError(model)
     scores = scores_dot(user_emb, items_emb, P, batch.get("user_id"), in_item_id, cfg)
@@ -254,7 +258,7 @@ def grads_of(P: Params, batch: dict, cfg: dict):
     G = {}
     for k, v in Q.items():
         g = v.grad if v.grad is not None else torch.zeros_like(v)
-        if k in ("item_embedding.weight", "user_embedding.weight"):
+        if k in ("item_embedding.weight", "user_embedding.weight", "item_dst_embedding.weight"):
             g = g.clone()
             g[0].zero_()
         G[k] = g
@@ -301,3 +305,15 @@ def train_step(P: Params, state: dict, batch: dict, cfg: dict, lr: float = 1e-3,
     with torch.no_grad():
         adam_step_(P, G, state, lr, wd)
     return float(loss)
+
+
+def pooled_user_emb(P: Params, item_seq: Tensor, item_seq_len: Tensor, alpha: float, dst_key: str,
+                    user_id: Optional[Tensor] = None) -> Tensor:
+    """AvgHist (unirec/model/sequential/avghist.py:35-42) and, with user_id, SVD++ (svdplusplus.py:32-40):
+    [U[user] +] (len + 1)^(-alpha) * sum_l E_dst[item_seq[:, l]]."""
+    emb = embedding(P[dst_key], item_seq.long())
+    coeff = torch.pow((item_seq_len + 1).float(), -alpha).unsqueeze(1)
+    out = coeff * emb.sum(1)
+    if user_id is not None:
+        out = embedding(P["user_embedding.weight"], user_id.long()) + out
+    return out

@@ -403,6 +403,26 @@ def main():
                      "k": np.array(k)})
         save("g13_topk_" + tag, **arrs)
 
+    # ---------------------------------------------------------------- G14 pooled-history encoders (AvgHist, SVD++)
+    from unirec.model.sequential.avghist import AvgHist
+    from unirec.model.sequential.svdplusplus import SVDPlusPlus
+    r14 = np.random.default_rng(1414)
+    for tag, cls, kw in (("avghist_asym_bpr", AvgHist, dict(model="AvgHist", asymmetric=True, user_sequence_alpha=0.5, loss_type="bpr")),
+                         ("avghist_sym_softmax", AvgHist, dict(model="AvgHist", asymmetric=False, user_sequence_alpha=0.3, loss_type="softmax")),
+                         ("svdpp_bce_bias", SVDPlusPlus, dict(model="SVDPlusPlus", user_sequence_alpha=0.5, loss_type="bce", has_user_emb=True,
+                                                              has_user_bias=True, has_item_bias=True, tau=0.8))):
+        cfg = base_cfg(**kw)
+        torch.manual_seed(14)
+        m = cls(cfg)
+        if kw.get("asymmetric", True):   # make the two tables differ (they are equal copies at construction)
+            with torch.no_grad():
+                m.item_dst_embedding.weight.add_(torch.randn_like(m.item_dst_embedding.weight) * 0.01)
+                m.item_dst_embedding.weight[0].zero_()
+        B, L, G = 9, cfg["max_seq_len"], 5
+        batch = make_batch(r14, B, L, G, cfg["n_items"], cfg["n_users"])
+        out = run_model(m, batch)
+        save("g14_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
+
 
 if __name__ == "__main__":
     main()

@@ -85,6 +85,8 @@ SIGNATURES = {
                              P, P, C.c_float, P, P, P]),
     "ur_gemm_tn_workspace_floats": (I64, [C.c_int, C.c_int, C.c_int]),
     "ur_gemm_tn": (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),
+    "ur_pool_rows_fwd": (C.c_int, [P, I64, C.c_int32, P, P, P, C.c_float, C.c_int32, C.c_int32, P, P]),
+    "ur_pool_rows_bwd": (C.c_int, [P, P, C.c_float, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "ur_sasrec_set_side_stream": (C.c_int, [C.c_int]),
     "ur_full_rank": (C.c_int, [P, P, I64, C.c_int32, C.c_int32, P, P, P, P, I64, P, P, C.c_float, P, P, P, P]),
     "ur_full_topk_workspace_bytes": (I64, [C.c_int32, I64, C.c_int32]),

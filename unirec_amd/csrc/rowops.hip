@@ -368,6 +368,57 @@ int pos_grad(const float* dx, int B, int L, int d, float* dpos, hipStream_t st) 
   return UR_OK;
 }
 
+
+// ------------------------------------------------------------------------------- pooled history (AvgHist / SVD++)
+// user_emb[b,:] = (seq_len[b] + 1)^(-alpha) * sum_l E[item_seq[b,l],:]   (+ base[b,:] when non-null)
+// unirec/model/sequential/avghist.py:35-42, svdplusplus.py:32-40.  One lane group per row, float4 per lane.
+template <int TPR>
+__global__ __launch_bounds__(256) void pool_rows_fwd_kernel(const float4* __restrict__ table, const int* __restrict__ seq,
+                                                            const long long* __restrict__ seq_len, const float4* __restrict__ base,
+                                                            float alpha, int B, int L, int d4, float4* __restrict__ out) {
+  constexpr int groups = 256 / TPR;
+  const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const int b = blockIdx.x * groups + g;
+  if (b >= B) return;
+  const float coef = powf((float)(seq_len[b] + 1), -alpha);
+  float4 acc[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int l = 0; l < L; ++l) {   // fixed summation order over positions
+    const long long id = seq[(long long)b * L + l];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) {
+        const float4 e = table[id * d4 + c];
+        acc[k].x += e.x; acc[k].y += e.y; acc[k].z += e.z; acc[k].w += e.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = t + k * TPR;
+    if (c < d4) {
+      float4 o = make_float4(coef * acc[k].x, coef * acc[k].y, coef * acc[k].z, coef * acc[k].w);
+      if (base) {
+        const float4 u = base[(long long)b * d4 + c];
+        o.x = u.x + o.x; o.y = u.y + o.y; o.z = u.z + o.z; o.w = u.w + o.w;
+      }
+      out[(long long)b * d4 + c] = o;
+    }
+  }
+}
+// rows[b*L + l, :] = (seq_len[b] + 1)^(-alpha) * d_user[b,:]: the gradient of every gathered history row
+__global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const float4* __restrict__ d_user, const long long* __restrict__ seq_len,
+                                                            float alpha, int B, int L, int d4, float4* __restrict__ rows) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * L * d4) return;
+  const long long c = i % d4, row = i / d4, b = row / L;
+  const float coef = powf((float)(seq_len[b] + 1), -alpha);
+  const float4 g = d_user[b * d4 + c];
+  rows[i] = make_float4(coef * g.x, coef * g.y, coef * g.z, coef * g.w);
+}
+
 }  // namespace ur
 
 extern "C" int ur_embedding_gather_f32(const float* table, int64_t n_rows, int d, const void* idx, int idx_bytes,
@@ -377,4 +428,36 @@ extern "C" int ur_embedding_gather_f32(const float* table, int64_t n_rows, int d
   UR_REQUIRE(idx_bytes == 4 || idx_bytes == 8, UR_ERR_ARG, "ur_embedding_gather_f32: idx_bytes=%d (4 or 8)", idx_bytes);
   UR_REQUIRE(n >= 0 && n_rows > 0, UR_ERR_ARG, "ur_embedding_gather_f32: n=%lld n_rows=%lld", (long long)n, (long long)n_rows);
   return ur::gather_rows(table, idx, idx_bytes, n, d, out, ur::as_stream(stream));
+}
+
+extern "C" int ur_pool_rows_fwd(const float* table, int64_t n_rows, int32_t d, const int32_t* item_seq, const int64_t* seq_len,
+                                const float* base, float alpha, int32_t B, int32_t L, float* user_emb, void* stream) {
+  UR_REQUIRE(table && item_seq && seq_len && user_emb, UR_ERR_ARG, "ur_pool_rows_fwd: null pointer");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && B > 0 && L > 0 && n_rows > 0, UR_ERR_ARG, "ur_pool_rows_fwd: d=%d B=%d L=%d", d, B, L);
+  hipStream_t st = ur::as_stream(stream);
+  ur::ProfScope ps(ur::PC_ROWOPS, st, (double)B * L * d * 4.0);
+  const int tpr = ur::pick_tpr(d), groups = 256 / tpr;
+#define GO(T) hipLaunchKernelGGL((ur::pool_rows_fwd_kernel<T>), dim3(ur::cdiv(B, groups)), dim3(256), 0, st, (const float4*)table, item_seq, \
+                                 (const long long*)seq_len, (const float4*)base, alpha, B, L, d / 4, (float4*)user_emb)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_pool_rows_bwd(const float* d_user_emb, const int64_t* seq_len, float alpha, int32_t B, int32_t L, int32_t d,
+                                float* d_rows, void* stream) {
+  UR_REQUIRE(d_user_emb && seq_len && d_rows, UR_ERR_ARG, "ur_pool_rows_bwd: null pointer");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && B > 0 && L > 0, UR_ERR_ARG, "ur_pool_rows_bwd: d=%d B=%d L=%d", d, B, L);
+  hipStream_t st = ur::as_stream(stream);
+  ur::ProfScope ps(ur::PC_ROWOPS, st, (double)B * L * d * 4.0);
+  hipLaunchKernelGGL(ur::pool_rows_bwd_kernel, dim3(ur::cdiv((long long)B * L * (d / 4), 256)), dim3(256), 0, st, (const float4*)d_user_emb,
+                     (const long long*)seq_len, alpha, B, L, d / 4, (float4*)d_rows);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
 }

@@ -30,8 +30,8 @@ class SparseDenseAdam:
         self.extra = [p for n, p in model.named_parameters() if n in ("user_bias", "item_bias")]
         self.extra_state = [(torch.zeros_like(p.data), torch.zeros_like(p.data)) for p in self.extra]
         self.tables = {}
-        for name in ("item_embedding", "user_embedding"):
-            if hasattr(model, name):
+        for name in ("item_embedding", "user_embedding", "item_dst_embedding"):
+            if hasattr(model, name) and not (name == "item_dst_embedding" and model.item_dst_embedding is model.item_embedding):
                 w = getattr(model, name).weight.data
                 st = dict(w=w, m=torch.zeros_like(w), v=torch.zeros_like(w))
                 st["last"] = torch.zeros(w.shape[0], dtype=torch.int32, device=dev) if table_mode == "lazy_dense" else None
@@ -58,14 +58,22 @@ class SparseDenseAdam:
 
     # ------------------------------------------------------------------ per-batch plan (before forward)
     def _plan_inputs(self, item_seq, item_id, user_id):
-        """-> {table: (ids_a int32 | None, ids_b int64 | None)} for the tables this batch looks up."""
+        """-> {table: (ids_a int32 | None, ids_b int64 | None)} for the tables this batch looks up.  Which batch field feeds
+        which table comes from ``model.lookup_tables()`` (default: item table <- item_seq rows + item_id candidates,
+        user table <- user_id)."""
+        src_a = {"item_seq": item_seq, "user_id": user_id, "item_id": item_id}
+        spec = self.model.lookup_tables() if hasattr(self.model, "lookup_tables") else {
+            "item_embedding": ("item_seq", "item_id"), "user_embedding": ("user_id", None)}
         req = {}
-        ids_a = item_seq.reshape(-1).to(torch.int32).contiguous() if item_seq is not None else None
-        ids_b = item_id.reshape(-1).contiguous() if item_id is not None else None
-        if "item_embedding" in self.tables and (ids_a is not None or ids_b is not None):
-            req["item_embedding"] = (ids_a, ids_b)
-        if "user_embedding" in self.tables and user_id is not None:
-            req["user_embedding"] = (user_id.reshape(-1).to(torch.int32).contiguous(), None)
+        for name, (ka, kb) in spec.items():
+            if name not in self.tables:
+                continue
+            ta = src_a.get(ka) if ka else None
+            tb = src_a.get(kb) if kb else None
+            a = ta.reshape(-1).to(torch.int32).contiguous() if ta is not None else None
+            b = tb.reshape(-1).to(torch.int64).contiguous() if tb is not None else None
+            if a is not None or b is not None:
+                req[name] = (a, b)
         return req
 
     def _make_plans(self, item_seq, item_id, user_id):

@@ -128,7 +128,7 @@ class AbstractRecommender(nn.Module):
                 raise RuntimeError(f"parameter {name} no longer aliases model.dense_flat; do not move/replace parameters")
 
     def _sparse_param_names(self):
-        return {"item_embedding.weight", "user_embedding.weight"}
+        return {"item_embedding.weight", "user_embedding.weight", "item_dst_embedding.weight", "item_src_embedding.weight"}
 
     def _init_params(self):  # reco_abc.py:210-218 + :19-58
         method = self.init_method
@@ -152,7 +152,7 @@ class AbstractRecommender(nn.Module):
                         nn.init.xavier_uniform_(p)
                     else:
                         raise KeyError(method)
-            for t in ("item_embedding", "user_embedding"):
+            for t in ("item_embedding", "user_embedding", "item_dst_embedding"):
                 if hasattr(self, t):
                     getattr(self, t).weight[0].zero_()  # padding row
 

@@ -135,8 +135,17 @@ class BaseRecommender(AbstractRecommender):
             scores = scores.squeeze(1)
         return None, scores, user_emb, self.forward_item_emb(item_id)
 
+    def lookup_tables(self):
+        """Which batch field indexes which row-sparse table: {table: (explicit-row ids, scorer candidate ids)}; the optimizer
+        plans the batch's id sort from it.  Default: MF-style (user table <- user_id, item table <- scorer candidates);
+        sequence models add item_seq to the item table."""
+        spec = {"item_embedding": ("item_seq" if "SeqRecBase" in self.annotations else None, "item_id")}
+        if hasattr(self, "user_embedding"):
+            spec["user_embedding"] = ("user_id", None)
+        return spec
+
     # ---- fused training step (no autograd graph) ------------------------------------------------
-    def _encode_train(self, user_id, item_seq):
+    def _encode_train(self, user_id, item_seq, item_seq_len=None):
         """-> (user_emb, state for _encode_backward).  MF: the user table lookup."""
         return self.user_embedding(user_id), user_id
 
@@ -161,7 +170,7 @@ class BaseRecommender(AbstractRecommender):
             label = label.unsqueeze(1) if label is not None and label.dim() == 1 else label
         item_id = item_id.contiguous()
         lab = label.to(torch.int32).contiguous() if label is not None else None
-        user_emb, state = self._encode_train(user_id, item_seq)
+        user_emb, state = self._encode_train(user_id, item_seq, item_seq_len)
         user_emb = user_emb.contiguous()
         B, G = item_id.shape
         cfg = ops.loss_cfg(B, G, self.embedding_size, self.loss_type, self.tau, self.SCORE_CLIP,

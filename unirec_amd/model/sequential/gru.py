@@ -58,7 +58,7 @@ class GRU(BaseRecommender):
             for p in self.gru_layers.parameters():
                 p.uniform_(-k, k)
 
-    def _encode_train(self, user_id, item_seq):
+    def _encode_train(self, user_id, item_seq, item_seq_len=None):
         item_seq = item_seq.to(torch.int32).contiguous()
         cfg = self._cfg(item_seq.shape[0])
         ws = self._workspace(cfg)

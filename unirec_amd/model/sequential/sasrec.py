@@ -99,7 +99,7 @@ class SASRec(BaseRecommender):
         self.trm_encoder = nn.Module()
         self.trm_encoder.layer = nn.ModuleList(layers)
 
-    def _encode_train(self, user_id, item_seq):
+    def _encode_train(self, user_id, item_seq, item_seq_len=None):
         item_seq = item_seq.to(torch.int32).contiguous()
         if item_seq.shape[1] != self.max_seq_len:
             raise ValueError(f"item_seq has length {item_seq.shape[1]}, expected max_seq_len={self.max_seq_len}")

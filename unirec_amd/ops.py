@@ -315,3 +315,26 @@ def full_topk(user_emb, item_table, k, user_id=None, hist_ptr=None, hist_sorted=
     check(lib.ur_full_topk(_p(user_emb), _p(item_table), n_items, B, d, int(k), _p(user_id), _p(hist_ptr), _p(hist_sorted), n_users,
                            _p(user_bias), _p(item_bias), float(tau), _p(scores), _p(ids), _p(ws), _stream()), "ur_full_topk")
     return scores, ids
+
+
+# --------------------------------------------------------------------------------------------- pooled history (AvgHist / SVD++)
+def pool_rows_fwd(table, item_seq, seq_len, alpha, base=None):
+    _chk(table, torch.float32, "table")
+    _chk(item_seq, torch.int32, "item_seq")
+    _chk(seq_len, torch.int64, "seq_len")
+    _chk(base, torch.float32, "base", allow_none=True)
+    B, L = item_seq.shape
+    d = table.shape[1]
+    out = torch.empty(B, d, dtype=torch.float32, device=table.device)
+    check(lib.ur_pool_rows_fwd(_p(table), table.shape[0], d, _p(item_seq), _p(seq_len), _p(base), float(alpha), B, L, _p(out), _stream()),
+          "ur_pool_rows_fwd")
+    return out
+
+
+def pool_rows_bwd(d_user, seq_len, alpha, L):
+    _chk(d_user, torch.float32, "d_user")
+    _chk(seq_len, torch.int64, "seq_len")
+    B, d = d_user.shape
+    rows = torch.empty(B * L, d, dtype=torch.float32, device=d_user.device)
+    check(lib.ur_pool_rows_bwd(_p(d_user), _p(seq_len), float(alpha), B, L, d, _p(rows), _stream()), "ur_pool_rows_bwd")
+    return rows
