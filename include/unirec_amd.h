@@ -309,6 +309,29 @@ int ur_full_topk(const float* user_emb, const float* item_table, int64_t n_items
                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * fullsoftmax training loss: every item is a candidate.
+ * Replaces BaseRecommender.forward with loss_type 'fullsoftmax' (unirec/model/base/recommender.py:46-55) + _cal_loss
+ * (unirec/model/base/reco_abc.py:266-270):  loss = mean_b( logsumexp_n s(b,n) - s(b,target_b) ) over ALL n in [0,n_items),
+ * s(b,n) = (u_b . E_n + user_bias[user_b] + item_bias[n]) / tau, clamped to +-score_clip when score_clip > 0.
+ *   fwd: target_score[B] = s(b,target_b) (from ur_gather_dot_loss_fwd with UR_LOSS_NONE); writes lse[B], loss_out[2].
+ *   bwd: d_user_emb [B,d]; d_item_table [n_items,d] DENSE and overwritten (row 0 = 0: padding_idx); d_item_bias [n_items]
+ *        (required iff item_bias); d user_bias is identically 0.  d_loss: device scalar (nullable = 1).
+ * The [B, n_items] scores exist one 2^20-item chunk at a time (ws: ur_full_softmax_workspace_bytes). */
+int64_t ur_full_softmax_workspace_bytes(int32_t B, int32_t d, int64_t n_items);
+int ur_full_softmax_fwd(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d,
+                        const int64_t* target, const int64_t* user_id, const float* user_bias, const float* item_bias,
+                        float tau, float score_clip, const float* target_score, float* lse, float* loss_out, void* ws,
+                        void* stream);
+int ur_full_softmax_bwd(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d,
+                        const int64_t* target, const int64_t* user_id, const float* user_bias, const float* item_bias,
+                        float tau, float score_clip, const float* lse, const float* d_loss, float* d_user_emb,
+                        float* d_item_table, float* d_item_bias, void* ws, void* stream);
+/* dense[uniq_idx[u], :] += rows[u, :] for u < *n_uniq_dev (unique rows: no conflicts) -- folds the encoder's row-sparse
+ * gradient into the dense table gradient of a fullsoftmax step. */
+int ur_rows_scatter_add(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* rows, int32_t d,
+                        float* dense, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Live profiler (measurement only; no reference counterpart).  While enabled, every launch group is
  * bracketed by HIP events on its stream.  ur_prof_read fills three host arrays of ur_prof_num_classes()
  * entries: summed milliseconds, number of launch groups, and summed algorithmic work (flops for the GEMM

@@ -346,3 +346,77 @@ def test_skip_padding_forward_is_bit_identical(last_row_only, B, L, d, heads, la
     g0, g1 = outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()
     np.testing.assert_allclose(g1, g0, rtol=2e-4, atol=1e-6 * max(1.0, float(np.abs(g0).max())))
     np.testing.assert_allclose(outs[1][3], outs[0][3], rtol=2e-4, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------ fullsoftmax (8 f4)
+def _fullsoftmax_table_grad(m, n_rows, d):
+    """dense table gradient of a fullsoftmax step = dense part + the encoder's row-sparse part."""
+    from unirec_amd import ops
+    from unirec_amd.facility.optimizer import SparseDenseAdam
+    dense = m.dense_table_grads["item_embedding"].clone()
+    opt = SparseDenseAdam.__new__(SparseDenseAdam)
+    opt.model = m
+    ids_a, rows, ids_b, coef, vec, G = SparseDenseAdam._collect(opt, "item_embedding")
+    if ids_a is not None:
+        pl = ops.rows_plan(ids_a.contiguous(), None, n_rows)
+        ops.rows_scatter_add(pl, ops.rows_reduce(pl, rows, None, None, 1, d), dense)
+    return dense.cpu().numpy()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_fullsoftmax_vs_reference_golden(fused):
+    cfg, g = load_golden("g5_sasrec_d64_1layer_fullsoftmax")
+    dev = _dev()
+    m = _build(cfg, g["sd"])
+    batch = {k: v.to(dev) for k, v in _t(g["in"]).items()}
+    m.train()
+    kw = dict(user_id=batch["user_id"], item_id=batch["item_id"], label=batch["label"], item_seq=batch["item_seq"],
+              item_seq_len=batch["item_seq_len"])
+    if fused:
+        loss = m.forward_backward(**kw)
+    else:
+        loss, _, _, _ = m(**kw)
+        loss.backward()
+    np.testing.assert_allclose(float(loss), float(g["out"]["loss"]), rtol=RTOL)
+    named = dict(m.named_parameters())
+    for k, ref in g["grad"].items():
+        if k == "item_embedding.weight":
+            got = _fullsoftmax_table_grad(m, ref.shape[0], ref.shape[1])
+        else:
+            p = named[k]
+            off = (p.data_ptr() - m.dense_flat.data_ptr()) // 4
+            got = m.dense_flat.grad[off:off + p.numel()].view(p.shape).cpu().numpy()
+        if k.endswith("key.bias"):
+            assert np.abs(got).max() < 1e-6 and np.abs(ref).max() < 1e-6
+            continue
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("model_name,B,N,bias", [("MF", 37, 3001, True), ("SASRec", 10, 5003, False)])
+def test_fullsoftmax_vs_oracle(model_name, B, N, bias):
+    from oracle import model_ref
+    from unirec_amd.utils.argument_parser import parse_arguments
+    from unirec_amd.utils.general import get_class_instance
+    dev = _dev()
+    rng = np.random.default_rng(N)
+    cfg = parse_arguments(dict(model=model_name, n_users=50, n_items=N, device="cuda:0", loss_type="fullsoftmax", embedding_size=32,
+                               hidden_size=32, inner_size=64, n_heads=4, n_layers=1, max_seq_len=12, seed=2, has_user_emb=model_name == "MF",
+                               has_user_bias=bias, has_item_bias=bias, tau=0.6 if bias else 1.0))
+    torch.manual_seed(2)
+    m = get_class_instance(model_name, "unirec_amd/model")(cfg)
+    seq = rng.integers(1, N, (B, 12)).astype(np.int32)
+    for b in range(B):
+        seq[b, : rng.integers(0, 12)] = 0
+    batch = dict(user_id=torch.from_numpy(rng.integers(1, 50, B)), item_id=torch.from_numpy(rng.integers(1, N, B)),
+                 item_seq=torch.from_numpy(seq), item_seq_len=torch.from_numpy((seq > 0).sum(1)))
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    ref_loss, _, _, G = model_ref.grads_of(P, {k: (v.long() if k != "item_seq" else v) for k, v in batch.items()}, cfg)
+    m.train()
+    loss = m.forward_backward(**{k: v.to(dev) for k, v in batch.items()})
+    np.testing.assert_allclose(float(loss), float(ref_loss), rtol=RTOL)
+    got = _fullsoftmax_table_grad(m, N, 32)
+    ref = G["item_embedding.weight"].numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * max(1.0, np.abs(ref).max()))
+    if bias:
+        np.testing.assert_allclose(m.item_bias.grad.cpu().numpy(), G["item_bias"].numpy(), rtol=2e-4, atol=1e-7)
+        assert float(m.user_bias.grad.abs().max()) == 0.0 and float(G["user_bias"].abs().max()) < 1e-6

@@ -133,3 +133,25 @@ def test_fit_with_the_device_resident_input_pipeline():
     tr.fit(loader, save_model=False)
     per_epoch = np.array(tr.step_losses).reshape(3, -1).mean(1)
     assert np.isfinite(per_epoch).all() and per_epoch[2] < per_epoch[0]
+
+
+def test_fit_fullsoftmax_follows_the_oracle():
+    """fullsoftmax end to end: dense table gradient + dense Adam on the table, encoder rows folded in, vs the oracle."""
+    from oracle import model_ref
+    from unirec_amd.facility.trainer import BatchLoader, Trainer
+    from unirec_amd.utils.general import get_class_instance, init_seed
+    cfg, ds = _setup("SASRec", "fullsoftmax")
+    init_seed(cfg["seed"])
+    model = get_class_instance("SASRec", "unirec_amd/model")(cfg)
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tr = Trainer(cfg, model)
+    batches = [{k: v.cpu() for k, v in b.items()} for b in BatchLoader(ds, cfg["batch_size"], device="cuda:0")]
+    cfg2, ds2 = _setup("SASRec", "fullsoftmax")
+    tr.fit(BatchLoader(ds2, cfg["batch_size"], device="cuda:0"))
+    state = {}
+    ref = [model_ref.train_step(P, state, dict(b, item_id=b["item_id"][:, 0]), cfg, lr=cfg["learning_rate"]) for b in batches]
+    np.testing.assert_allclose(tr.step_losses, ref, rtol=2e-4)
+    for k, v in model.state_dict().items():
+        if k.endswith("key.bias"):
+            continue
+        np.testing.assert_allclose(v.cpu().numpy(), P[k].numpy(), rtol=1e-3, atol=1e-4, err_msg=k)

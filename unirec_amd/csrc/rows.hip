@@ -579,6 +579,23 @@ static PlanWs carve_plan(long long n, char* base) {
   return w;
 }
 
+
+// dense[uniq_idx[u], :] += rows[u, :]   (unique rows; row 0 skipped: padding)
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
+                                                               long long n_max, const float4* __restrict__ rows, int d4,
+                                                               float4* __restrict__ dense) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n = min((long long)*n_uniq_dev, n_max);
+  if (i >= n * d4) return;
+  const long long u = i / d4, c = i % d4;
+  const long long row = uniq_idx[u];
+  if (row == 0) return;
+  float4 a = dense[row * d4 + c];
+  const float4 b = rows[i];
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  dense[row * d4 + c] = a;
+}
+
 }  // namespace ur
 
 using namespace ur;
@@ -783,6 +800,15 @@ extern "C" int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, 
     default: GO(32); break;
   }
 #undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_rows_scatter_add(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* rows, int32_t d,
+                                   float* dense, void* stream) {
+  UR_REQUIRE(uniq_idx && n_uniq_dev && rows && dense && n_max > 0 && d > 0 && d % 4 == 0, UR_ERR_ARG, "ur_rows_scatter_add: bad argument");
+  hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(cdiv(n_max * (d / 4), 256)), dim3(256), 0, as_stream(stream), uniq_idx, n_uniq_dev,
+                     (long long)n_max, (const float4*)rows, d / 4, (float4*)dense);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

@@ -35,6 +35,8 @@ class SparseDenseAdam:
                 w = getattr(model, name).weight.data
                 st = dict(w=w, m=torch.zeros_like(w), v=torch.zeros_like(w))
                 st["last"] = torch.zeros(w.shape[0], dtype=torch.int32, device=dev) if table_mode == "lazy_dense" else None
+                if name == "item_embedding" and getattr(model, "loss_type", None) == "fullsoftmax":
+                    st["last"] = None      # fullsoftmax: a dense [N,d] gradient every step -> plain dense Adam on this table
                 self.tables[name] = st
         self._plans = {}
         self._prefetched, self._side = None, None
@@ -48,6 +50,7 @@ class SparseDenseAdam:
         for p in self.extra:
             p.grad = None
         self.model.sparse_grads.clear()
+        self.model.dense_table_grads.clear()
 
     def state_dict(self):
         return dict(t=self.t, dense_m=self.dense_m, dense_v=self.dense_v, param_groups=self.param_groups,
@@ -117,7 +120,8 @@ class SparseDenseAdam:
             cfg = self._cfg(self.t + 1)
             for name, pl in self._plans.items():
                 st = self.tables[name]
-                ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
+                if st["last"] is not None:
+                    ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
 
     def flush(self):
         """lazy_dense: apply all pending zero-gradient steps to every row (before eval / checkpoint)."""
@@ -125,7 +129,8 @@ class SparseDenseAdam:
             return
         cfg = self._cfg(self.t)
         for st in self.tables.values():
-            ops.lazy_adam_flush(cfg, st["w"], st["m"], st["v"], st["last"])
+            if st["last"] is not None:
+                ops.lazy_adam_flush(cfg, st["w"], st["m"], st["v"], st["last"])
 
     # ------------------------------------------------------------------ step
     def _collect(self, name):
@@ -158,6 +163,12 @@ class SparseDenseAdam:
                 pl = ops.rows_plan(ids_a.contiguous() if ids_a is not None else None, ids_b, st["w"].shape[0])
             d = st["w"].shape[1]
             reduced[name] = (pl, ops.rows_reduce(pl, rows, coef, vec, G, d, zero_tail=self.grad_clip is not None))
+        # fullsoftmax: the table's gradient is dense; the encoder's row-sparse part is folded into it
+        dense_tables = dict(model.dense_table_grads)
+        for name, dg in dense_tables.items():
+            if name in reduced:
+                pl, ug = reduced.pop(name)
+                ops.rows_scatter_add(pl, ug, dg)
         scale = None
         if self.grad_clip is not None:
             ss = self._scalars[0:1]
@@ -167,6 +178,8 @@ class SparseDenseAdam:
                     ops.sumsq(p.grad, ss, accumulate=True, ws=self._sumsq_ws)
             for pl, ug in reduced.values():
                 ops.sumsq(ug, ss, accumulate=True, ws=self._sumsq_ws)
+            for dg in dense_tables.values():
+                ops.sumsq(dg, ss, accumulate=True, ws=self._sumsq_ws)
             scale = self._scalars[1:2]
             ops.clip_coef(ss, self.grad_clip, scale)
         if model.dense_flat.grad is not None:
@@ -177,5 +190,9 @@ class SparseDenseAdam:
         for name, (pl, ug) in reduced.items():
             st = self.tables[name]
             ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
+        for name, dg in dense_tables.items():
+            st = self.tables[name]
+            ops.dense_adam(cfg, st["w"], dg, st["m"], st["v"], scale)
         self._plans = {}
         model.sparse_grads.clear()
+        model.dense_table_grads.clear()

@@ -51,6 +51,7 @@ class AbstractRecommender(nn.Module):
         self.__optimized_by_SGD__ = True
         self.config = config
         self.sparse_grads = []     # filled by backward: dicts consumed by facility.optimizer
+        self.dense_table_grads = {}  # fullsoftmax: {table name: dense [N,d] gradient} (every row moves)
         self._init_attributes()
         self._init_modules()
         self.annotations = []

@@ -55,6 +55,29 @@ class _ScoreLossFn(torch.autograd.Function):
         return d_user, None, None, None, None
 
 
+class _FullSoftmaxFn(torch.autograd.Function):
+    """loss = mean_b(logsumexp_n s(b,n) - s(b,target_b)) over ALL items -- recommender.py:46-55, reco_abc.py:266-270."""
+
+    @staticmethod
+    def forward(ctx, user_emb, model, target, user_id):
+        user_emb = user_emb.contiguous()
+        ub = model.user_bias.data if model.has_user_bias else None
+        ib = model.item_bias.data if model.has_item_bias else None
+        loss_out, lse, ws = ops.full_softmax_fwd(user_emb, model.item_embedding.weight.data, target, user_id if ub is not None else None,
+                                                 ub, ib, model.tau, model.SCORE_CLIP)
+        ctx.model, ctx.ws = model, ws
+        ctx.save_for_backward(user_emb, target, lse, user_id if user_id is not None else target.new_empty(0))
+        return loss_out[0]
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        user_emb, target, lse, user_id = ctx.saved_tensors
+        model = ctx.model
+        model._full_softmax_backward(user_emb, target, lse, ctx.ws, user_id if user_id.numel() else None,
+                                     d_loss.contiguous().view(1).float())
+        return model._fs_d_user, None, None, None
+
+
 class _TableLookupFn(torch.autograd.Function):
     """user_emb = U[user_id] with a row-sparse gradient (MF: recommender.py:42-44)."""
 
@@ -109,7 +132,12 @@ class BaseRecommender(AbstractRecommender):
     def forward(self, user_id=None, item_id=None, label=None, item_features=None, item_seq=None, item_seq_len=None,
                 item_seq_features=None, time_seq=None, session_id=None, reduction=True, return_loss_only=True, max_len=None):
         if self.loss_type == "fullsoftmax" and self.training:
-            raise NotImplementedError("fullsoftmax scores all N items per row: listed as a next row (DESIGN.md section 7)")
+            # label = item_id, candidates = every item (recommender.py:47-50)
+            if not (reduction and return_loss_only):
+                raise NotImplementedError("fullsoftmax: the [B, n_items] score matrix is never materialised (reduction / return_loss_only)")
+            user_emb = self.forward_user_emb(user_id, item_seq, item_seq_len, item_seq_features, time_seq)
+            target = item_id.reshape(item_id.shape[0], -1)[:, 0].contiguous()
+            return _FullSoftmaxFn.apply(user_emb, self, target, user_id), None, None, None
         if item_id.dim() == 1:
             item_id = item_id.unsqueeze(1)
             label = label.unsqueeze(1) if label is not None and label.dim() == 1 else label
@@ -135,11 +163,24 @@ class BaseRecommender(AbstractRecommender):
             scores = scores.squeeze(1)
         return None, scores, user_emb, self.forward_item_emb(item_id)
 
+    def _full_softmax_backward(self, user_emb, target, lse, ws, user_id, d_loss):
+        ub = self.user_bias.data if self.has_user_bias else None
+        ib = self.item_bias.data if self.has_item_bias else None
+        d_user, d_table, d_ib = ops.full_softmax_bwd(user_emb, self.item_embedding.weight.data, target, lse, ws,
+                                                     user_id if ub is not None else None, ub, ib, self.tau, self.SCORE_CLIP, d_loss)
+        self.dense_table_grads["item_embedding"] = d_table      # dense: every row of the table moves (the reference's cost too)
+        if self.has_item_bias:
+            self.item_bias.grad = d_ib
+        if self.has_user_bias:
+            self.user_bias.grad = torch.zeros_like(self.user_bias)   # softmax is shift invariant along n: exactly 0
+        object.__setattr__(self, "_fs_d_user", d_user)
+
     def lookup_tables(self):
         """Which batch field indexes which row-sparse table: {table: (explicit-row ids, scorer candidate ids)}; the optimizer
         plans the batch's id sort from it.  Default: MF-style (user table <- user_id, item table <- scorer candidates);
         sequence models add item_seq to the item table."""
-        spec = {"item_embedding": ("item_seq" if "SeqRecBase" in self.annotations else None, "item_id")}
+        cand = None if self.loss_type == "fullsoftmax" else "item_id"   # fullsoftmax: the candidates' gradient is dense
+        spec = {"item_embedding": ("item_seq" if "SeqRecBase" in self.annotations else None, cand)}
         if hasattr(self, "user_embedding"):
             spec["user_embedding"] = ("user_id", None)
         return spec
@@ -162,7 +203,16 @@ class BaseRecommender(AbstractRecommender):
         if not self.training:
             raise RuntimeError("forward_backward is a training-mode entry point")
         if self.loss_type == "fullsoftmax":
-            raise NotImplementedError("fullsoftmax scores all N items per row: listed as a next row (DESIGN.md section 7)")
+            user_emb, state = self._encode_train(user_id, item_seq, item_seq_len)
+            user_emb = user_emb.contiguous()
+            target = item_id.reshape(item_id.shape[0], -1)[:, 0].contiguous()
+            ub = self.user_bias.data if self.has_user_bias else None
+            ib = self.item_bias.data if self.has_item_bias else None
+            uid = user_id if ub is not None else None
+            loss_out, lse, ws = ops.full_softmax_fwd(user_emb, self.item_embedding.weight.data, target, uid, ub, ib, self.tau, self.SCORE_CLIP)
+            self._full_softmax_backward(user_emb, target, lse, ws, user_id, None)
+            self._encode_backward(state, self._fs_d_user)
+            return loss_out[0]
         if self.group_size > 0:
             raise NotImplementedError("group_size > 0 (user-item-label rows) is not on the accelerated path")
         if item_id.dim() == 1:

@@ -338,3 +338,44 @@ def pool_rows_bwd(d_user, seq_len, alpha, L):
     rows = torch.empty(B * L, d, dtype=torch.float32, device=d_user.device)
     check(lib.ur_pool_rows_bwd(_p(d_user), _p(seq_len), float(alpha), B, L, d, _p(rows), _stream()), "ur_pool_rows_bwd")
     return rows
+
+
+# --------------------------------------------------------------------------------------------- fullsoftmax
+def full_softmax_fwd(user_emb, item_table, target, user_id=None, user_bias=None, item_bias=None, tau=1.0, score_clip=-1.0):
+    """-> (loss_out float32[2] = [mean loss, B], lse float32[B], workspace) -- see include/unirec_amd.h: ur_full_softmax_fwd."""
+    _chk(user_emb, torch.float32, "user_emb")
+    _chk(item_table, torch.float32, "item_table")
+    _chk(target, torch.int64, "target")
+    B, d = user_emb.shape
+    N = item_table.shape[0]
+    dev = user_emb.device
+    cfg = loss_cfg(B, 1, d, "bpr", tau, score_clip)
+    cfg.loss_type = -1   # UR_LOSS_NONE: the target's score through the same scorer kernel
+    ts, _, _ = gather_dot_loss_fwd(cfg, user_emb, item_table, target.view(B, 1).contiguous(), None, user_bias, item_bias,
+                                   user_id if user_bias is not None else None)
+    lse = torch.empty(B, dtype=torch.float32, device=dev)
+    loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+    ws = torch.empty(check(lib.ur_full_softmax_workspace_bytes(B, d, N), "ur_full_softmax_workspace_bytes"), dtype=torch.uint8, device=dev)
+    check(lib.ur_full_softmax_fwd(_p(user_emb), _p(item_table), N, B, d, _p(target), _p(user_id), _p(user_bias), _p(item_bias), float(tau),
+                                  float(score_clip if score_clip else -1.0), _p(ts.view(-1)), _p(lse), _p(loss_out), _p(ws), _stream()),
+          "ur_full_softmax_fwd")
+    return loss_out, lse, ws
+
+
+def full_softmax_bwd(user_emb, item_table, target, lse, ws, user_id=None, user_bias=None, item_bias=None, tau=1.0, score_clip=-1.0,
+                     d_loss=None):
+    """-> (d_user [B,d], d_table [N,d] dense, d_item_bias [N] | None)."""
+    B, d = user_emb.shape
+    N = item_table.shape[0]
+    dev = user_emb.device
+    d_user = torch.empty(B, d, dtype=torch.float32, device=dev)
+    d_table = torch.empty(N, d, dtype=torch.float32, device=dev)
+    d_ib = torch.empty(N, dtype=torch.float32, device=dev) if item_bias is not None else None
+    check(lib.ur_full_softmax_bwd(_p(user_emb), _p(item_table), N, B, d, _p(target), _p(user_id), _p(user_bias), _p(item_bias), float(tau),
+                                  float(score_clip if score_clip else -1.0), _p(lse), _p(d_loss), _p(d_user), _p(d_table), _p(d_ib), _p(ws),
+                                  _stream()), "ur_full_softmax_bwd")
+    return d_user, d_table, d_ib
+
+
+def rows_scatter_add(pl: RowsPlan, rows, dense):
+    check(lib.ur_rows_scatter_add(_p(pl.uniq_idx), _p(pl.n_uniq), pl.n, _p(rows), rows.shape[1], _p(dense), _stream()), "ur_rows_scatter_add")
