@@ -129,7 +129,7 @@ def _batches(n_steps, B):
     return out
 
 
-def _gpu_worker(rank, world, port, q):
+def _gpu_worker(rank, world, port, q, kind="SASRec"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share cuda:0; rows are staged via host
@@ -139,7 +139,8 @@ def _gpu_worker(rank, world, port, q):
         torch.cuda.set_device(dev)
         T0 = torch.randn(3001, 64, generator=torch.Generator().manual_seed(5)) * 0.05
         T0[0] = 0
-        st = ShardedSasrecStep(_CFG, dev, rank, world, table_mode="lazy_dense")
+        cfg_k = dict(_CFG, model=kind)
+        st = ShardedSasrecStep(cfg_k, dev, rank, world, table_mode="lazy_dense")
         owner, local = owner_and_local(torch.arange(3001), world)
         st.table.zero_()
         st.table[local[owner == rank].to(dev)] = T0[owner == rank].to(dev)
@@ -154,7 +155,7 @@ def _gpu_worker(rank, world, port, q):
         all_losses = [None] * world
         dist.all_gather_object(all_losses, losses)
         if rank == 0:
-            one = ShardedSasrecStep(_CFG, dev, 0, 1, table_mode="lazy_dense")
+            one = ShardedSasrecStep(cfg_k, dev, 0, 1, table_mode="lazy_dense")
             one.table.copy_(T0.to(dev))
             ref_losses = [float(one.step({k: v.to(dev) for k, v in b.items()})) for b in _batches(3, B * world)]
             one.flush()
@@ -172,12 +173,13 @@ def _gpu_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_two_ranks_equal_one_rank_with_the_concatenated_batch():
-    """SURVEY.md 8e parity test: W ranks x batch B == 1 rank x batch W*B (losses and updated parameters)."""
+@pytest.mark.parametrize("kind", ["SASRec", "GRU"])
+def test_two_ranks_equal_one_rank_with_the_concatenated_batch(kind):
+    """SURVEY.md 8e parity test: W ranks x batch B == 1 rank x batch W*B (losses and updated parameters); GRU = config C4."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -187,12 +189,15 @@ def test_two_ranks_equal_one_rank_with_the_concatenated_batch():
 
 
 @pytest.mark.gpu
-def test_sharded_step_world1_equals_plain_path():
+@pytest.mark.parametrize("kind", ["SASRec", "GRU"])
+def test_sharded_step_world1_equals_plain_path(kind):
     from unirec_amd.facility.optimizer import SparseDenseAdam
-    from unirec_amd.model.sequential.sasrec import SASRec
+    from unirec_amd.model.sequential.gru import GRU
+    from unirec_amd.model.sequential.sasrec import SASRec as _S
     from unirec_amd.sharded import ShardedSasrecStep
+    SASRec = GRU if kind == "GRU" else _S
     dev = torch.device("cuda:0")
-    cfg = dict(model="SASRec", n_users=10, n_items=5000, device="cuda:0", loss_type="bpr", embedding_size=64, hidden_size=64,
+    cfg = dict(model=kind, n_users=10, n_items=5000, device="cuda:0", loss_type="bpr", embedding_size=64, hidden_size=64,
                dropout_prob=0.0, init_method="normal", init_mean=0.0, init_std=0.05, has_user_emb=False, has_user_bias=False,
                has_item_bias=False, distance_type="dot", tau=1.0, train_file_format="user-item", exp_name="t", n_layers=2,
                n_heads=16, inner_size=128, hidden_dropout_prob=0.0, attn_dropout_prob=0.0, hidden_act="swish",

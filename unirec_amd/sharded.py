@@ -78,10 +78,12 @@ def owner_and_local(ids: torch.Tensor, world: int):
 
 
 class ShardedSasrecStep:
-    """One training step of SASRec (+ sampled loss) over a row-sharded table. step(batch) -> local loss (device scalar)."""
+    """One training step of a sequence encoder (SASRec or GRU, ``model_cfg['model']``) + sampled loss over a row-sharded
+    table.  step(batch) -> local loss (device scalar).  (The class keeps its first name; GRU = BASELINE config C4.)"""
 
     def __init__(self, model_cfg: dict, device, rank: int, world: int, lr=1e-3, weight_decay=0.0, table_mode="lazy_dense",
                  batch_size=None, seed=2022):
+        from .model.sequential.gru import GRU
         from .model.sequential.sasrec import SASRec
         self.rank, self.world, self.device = rank, world, device
         self.N, self.d = model_cfg["n_items"], model_cfg["embedding_size"]
@@ -91,7 +93,10 @@ class ShardedSasrecStep:
         cfg["n_items"] = 8            # the model object only carries the dense parameters here
         cfg["device"] = str(device)
         torch.manual_seed(seed)       # identical dense init on every rank
-        self.model = SASRec(cfg)
+        self.kind = model_cfg.get("model", "SASRec")
+        if self.kind not in ("SASRec", "GRU"):
+            raise NotImplementedError(f"row-sharded training is built for SASRec and GRU, not {self.kind}")
+        self.model = (GRU if self.kind == "GRU" else SASRec)(cfg)
         self.model.train()
         if world > 1:
             dist.broadcast(self.model.dense_flat.data, src=0)
@@ -144,12 +149,13 @@ class ShardedSasrecStep:
         # 4. forward / backward on the compact table (same kernels as the single-GPU path)
         cfg = m._cfg(B)
         ws = m._workspace(cfg)
-        user_emb = ops.sasrec_fwd(cfg, compact, m.dense_flat.data, seq_c, ws)
+        enc_fwd, enc_bwd = (ops.gru_fwd, ops.gru_bwd) if self.kind == "GRU" else (ops.sasrec_fwd, ops.sasrec_bwd)
+        user_emb = enc_fwd(cfg, compact, m.dense_flat.data, seq_c, ws)
         lcfg = ops.loss_cfg(B, G, d, self.loss_type, self.tau)
         lab = label.to(torch.int32).contiguous() if label is not None else None
         scores, _, loss_out = ops.gather_dot_loss_fwd(lcfg, user_emb, compact, item_c, lab)
         coef, d_user, _ = ops.gather_dot_loss_bwd(lcfg, user_emb, compact, item_c, lab, scores, loss_out)
-        dense_grad, d_rows = ops.sasrec_bwd(cfg, compact, m.dense_flat.data, seq_c, d_user, ws)
+        dense_grad, d_rows = enc_bwd(cfg, compact, m.dense_flat.data, seq_c, d_user, ws)
         # 5. row gradients of the unique keys, then all-to-all #3 to the owners
         coef_b = torch.cat([coef.reshape(-1), self.zero_coef])
         ug = ops.rows_reduce(pl, d_rows, coef_b, user_emb, G, d)[:n_uniq]
