@@ -92,6 +92,24 @@ int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_ite
                   float* d_emb_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * AttHist user encoder (unirec/model/sequential/atthist.py:9-23 + AttentionMergeLayer,
+ * unirec/model/modules.py:226-244): z = E[item_seq] W^T + b; p = softmax_l(z . h) over ALL L positions (no mask);
+ * user_emb = sum_l p_l z_l.  Flat dense buffer: [0] attention.dense.weight [d,d]  [1] attention.dense.bias [d]
+ * [2] attention.h [d] (the reference's [d,1]).  ur_atthist_param_layout fills 3 offsets and returns the total. */
+typedef struct UrAttHistCfg {
+  int32_t B, L;
+  int32_t d; /* embedding_size, % 4 == 0, <= 512 */
+} UrAttHistCfg;
+int64_t ur_atthist_param_layout(const UrAttHistCfg* cfg, int64_t* offsets_out);
+int64_t ur_atthist_workspace_bytes(const UrAttHistCfg* cfg);
+int ur_atthist_fwd(const UrAttHistCfg* cfg, const float* item_table, int64_t n_items, const float* dense, const int32_t* item_seq,
+                   float* user_emb, void* ws, void* stream);
+/* dense_grad: every element written; d_emb_rows [B*L, d] in item_seq.reshape(-1) order (rows of id 0 are discarded by
+ * ur_rows_reduce: padding_idx=0). */
+int ur_atthist_bwd(const UrAttHistCfg* cfg, const float* item_table, int64_t n_items, const float* dense, const int32_t* item_seq,
+                   const float* d_user_emb, void* ws, float* dense_grad, float* d_emb_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Pooled-history user encoders: AvgHist (unirec/model/sequential/avghist.py:35-42) and SVD++
  * (unirec/model/sequential/svdplusplus.py:32-40):
  *   user_emb[b,:] = base[b,:] + (seq_len[b] + 1)^(-alpha) * sum_l E[item_seq[b,l],:]      (base nullable; E[0] = 0)

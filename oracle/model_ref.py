@@ -236,6 +236,8 @@ def model_forward(P: Params, batch: dict, cfg: dict, reduction: bool = True, col
         user_emb = gru_user_emb(P, batch["item_seq"], cfg, collect)
     elif model == "MF":
         user_emb = mf_user_emb(P, batch["user_id"])
+    elif model == "AttHist":
+        user_emb = atthist_user_emb(P, batch["item_seq"])
     elif model in ("AvgHist", "SVDPlusPlus"):
         dst = "item_dst_embedding.weight" if (model == "SVDPlusPlus" or cfg.get("asymmetric", True)) else "item_embedding.weight"
         user_emb = pooled_user_emb(P, batch["item_seq"], batch["item_seq_len"], float(cfg.get("user_sequence_alpha", 0.5)), dst,
@@ -317,3 +319,11 @@ def pooled_user_emb(P: Params, item_seq: Tensor, item_seq_len: Tensor, alpha: fl
     if user_id is not None:
         out = embedding(P["user_embedding.weight"], user_id.long()) + out
     return out
+
+
+def atthist_user_emb(P: Params, item_seq: Tensor) -> Tensor:
+    """AttHist (unirec/model/sequential/atthist.py:17-23) = AttentionMergeLayer (unirec/model/modules.py:236-244) on the
+    gathered history: z = E[seq] W^T + b; p = softmax_l(z . h) (no mask); sum_l p_l z_l."""
+    z = linear(embedding(P["item_embedding.weight"], item_seq.long()), P["attention.dense.weight"], P["attention.dense.bias"])
+    p = torch.softmax(torch.matmul(z, P["attention.h"]).squeeze(-1), dim=-1)
+    return torch.matmul(p.unsqueeze(-1).transpose(-1, -2), z).squeeze(1)

@@ -34,7 +34,8 @@ def _build(cfg, sd):
     cfg["device"] = "cuda:0"
     from unirec_amd.model.sequential.avghist import AvgHist
     from unirec_amd.model.sequential.svdplusplus import SVDPlusPlus
-    cls = {"SASRec": SASRec, "MF": MF, "GRU": GRU, "AvgHist": AvgHist, "SVDPlusPlus": SVDPlusPlus}[cfg["model"]]
+    from unirec_amd.model.sequential.atthist import AttHist
+    cls = {"SASRec": SASRec, "MF": MF, "GRU": GRU, "AvgHist": AvgHist, "SVDPlusPlus": SVDPlusPlus, "AttHist": AttHist}[cfg["model"]]
     m = cls(cfg)
     missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     assert not unexpected, unexpected
@@ -77,7 +78,7 @@ def test_gather_bit_exact(d, idt):
 
 
 # ------------------------------------------------------------------------------------------ golden models
-MODEL_FIXTURES = sorted(os.path.basename(p)[:-4] for pat in ("g[578]_*.npz", "g14_*.npz") for p in glob.glob(os.path.join(GOLDEN, pat))
+MODEL_FIXTURES = sorted(os.path.basename(p)[:-4] for pat in ("g[578]_*.npz", "g14_*.npz", "g15_*.npz") for p in glob.glob(os.path.join(GOLDEN, pat))
                         if "fullsoftmax" not in p)
 
 

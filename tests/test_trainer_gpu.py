@@ -35,7 +35,7 @@ def _setup(model_name, loss):
 
 
 @pytest.mark.parametrize("model_name,loss", [("SASRec", "bpr"), ("SASRec", "softmax"), ("MF", "bpr"), ("GRU", "softmax"),
-                                             ("AvgHist", "bpr"), ("SVDPlusPlus", "softmax")])
+                                             ("AvgHist", "bpr"), ("SVDPlusPlus", "softmax"), ("AttHist", "softmax")])
 def test_fit_losses_follow_the_oracle(model_name, loss):
     from oracle import model_ref
     from unirec_amd.facility.trainer import BatchLoader, Trainer

@@ -423,6 +423,19 @@ def main():
         out = run_model(m, batch)
         save("g14_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
 
+    # ---------------------------------------------------------------- G15 AttHist
+    from unirec.model.sequential.atthist import AttHist
+    r15 = np.random.default_rng(1515)
+    for tag, kw in (("atthist_bpr", dict(loss_type="bpr")), ("atthist_softmax_bias", dict(loss_type="softmax", has_item_bias=True, tau=0.7))):
+        cfg = base_cfg(model="AttHist", **kw)
+        torch.manual_seed(15)
+        m = AttHist(cfg)
+        with torch.no_grad():
+            m.attention.h.mul_(0.3)      # keep the softmax away from saturation
+        batch = make_batch(r15, 8, cfg["max_seq_len"], 4, cfg["n_items"], cfg["n_users"])
+        out = run_model(m, batch)
+        save("g15_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
+
 
 if __name__ == "__main__":
     main()

@@ -26,6 +26,10 @@ class UrSasrecCfg(C.Structure):
                 ("eps", C.c_float), ("last_only", C.c_int32), ("skip_padding", C.c_int32)]
 
 
+class UrAttHistCfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32)]
+
+
 class UrLossCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("G", C.c_int32), ("d", C.c_int32), ("loss_type", C.c_int32),
                 ("tau", C.c_float), ("score_clip", C.c_float), ("ccl_w", C.c_float), ("ccl_m", C.c_float)]
@@ -85,6 +89,10 @@ SIGNATURES = {
                              P, P, C.c_float, P, P, P]),
     "ur_gemm_tn_workspace_floats": (I64, [C.c_int, C.c_int, C.c_int]),
     "ur_gemm_tn": (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),
+    "ur_atthist_param_layout": (I64, [P, P]),
+    "ur_atthist_workspace_bytes": (I64, [P]),
+    "ur_atthist_fwd": (C.c_int, [P, P, I64, P, P, P, P, P]),
+    "ur_atthist_bwd": (C.c_int, [P, P, I64, P, P, P, P, P, P, P]),
     "ur_pool_rows_fwd": (C.c_int, [P, I64, C.c_int32, P, P, P, C.c_float, C.c_int32, C.c_int32, P, P]),
     "ur_pool_rows_bwd": (C.c_int, [P, P, C.c_float, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "ur_sasrec_set_side_stream": (C.c_int, [C.c_int]),

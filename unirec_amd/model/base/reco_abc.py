@@ -144,6 +144,8 @@ class AbstractRecommender(nn.Module):
                     p.zero_()
                 elif name.startswith("gru_layers."):
                     continue  # nn.GRU keeps torch's default U(-1/sqrt(H), 1/sqrt(H)) (set by the GRU model)
+                elif name == "attention.h":
+                    p.normal_(0.0, 1.0)   # a bare nn.Parameter(torch.randn(...)): no init hook touches it (modules.py:233)
                 elif p.dim() >= 2:
                     if method == "normal":
                         p.normal_(mean=mean, std=std)

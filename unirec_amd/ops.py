@@ -379,3 +379,37 @@ def full_softmax_bwd(user_emb, item_table, target, lse, ws, user_id=None, user_b
 
 def rows_scatter_add(pl: RowsPlan, rows, dense):
     check(lib.ur_rows_scatter_add(_p(pl.uniq_idx), _p(pl.n_uniq), pl.n, _p(rows), rows.shape[1], _p(dense), _stream()), "ur_rows_scatter_add")
+
+
+# --------------------------------------------------------------------------------------------- AttHist
+def atthist_cfg(B, L, d):
+    return _lib.UrAttHistCfg(B, L, d)
+
+
+def atthist_param_layout(cfg):
+    offs = (C.c_int64 * 3)()
+    total = check(lib.ur_atthist_param_layout(C.byref(cfg), offs), "ur_atthist_param_layout")
+    return list(offs), int(total)
+
+
+def atthist_workspace(cfg, device):
+    return torch.empty(check(lib.ur_atthist_workspace_bytes(C.byref(cfg)), "ur_atthist_workspace_bytes"), dtype=torch.uint8, device=device)
+
+
+def atthist_fwd(cfg, item_table, dense, item_seq, ws):
+    _chk(item_table, torch.float32, "item_table")
+    _chk(dense, torch.float32, "dense")
+    _chk(item_seq, torch.int32, "item_seq")
+    user_emb = torch.empty(cfg.B, cfg.d, dtype=torch.float32, device=dense.device)
+    check(lib.ur_atthist_fwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(user_emb), _p(ws), _stream()),
+          "ur_atthist_fwd")
+    return user_emb
+
+
+def atthist_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws):
+    _chk(d_user_emb, torch.float32, "d_user_emb")
+    dense_grad = torch.empty_like(dense)
+    d_emb_rows = torch.empty(cfg.B * cfg.L, cfg.d, dtype=torch.float32, device=dense.device)
+    check(lib.ur_atthist_bwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(d_user_emb), _p(ws),
+                             _p(dense_grad), _p(d_emb_rows), _stream()), "ur_atthist_bwd")
+    return dense_grad, d_emb_rows
