@@ -92,6 +92,37 @@ int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_ite
                   float* d_emb_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * ConvFormer / FASTConvFormer user encoders (unirec/model/sequential/convformer.py:16-129,
+ * fastconvformer.py:20-81).  x0 = LN(E[item_seq] + P[0..L-1]); per layer y1 = LN(mix(x) + x), y = LN(act(y1 W1^T + b1) W2^T
+ * + b2 + y1); no attention mask.  mix: depth-wise Conv1d over the sequence with a (K-1)-row prefix (padding_mode 0
+ * circular / 1 reflect / 2 constant), or, fast = 1, the FFT layer's circular convolution (1/sqrt(L)) sum_k w[k,c] x[(l-k) mod L,c]
+ * evaluated in the time domain.  Output: position L-1, or (seq_merge) sum_l x[:,l,:] 10^(seq_decay (1 - l/(L-1))) /
+ * sqrt(item_seq_len + 1).
+ * Flat dense buffer (ur_convformer_param_layout fills 3 + 10*n_layers offsets, returns the total):
+ *   global [0] position_embedding.weight [L,d]  [1] LayerNorm.weight  [2] LayerNorm.bias
+ *   layer  [0] mixer weight ([d,K] = nn.Conv1d [d,1,K]; fast: [K,d] = conv_weight [1,K,d])  [1] mixer bias [d] (fast: unused)
+ *          [2],[3] filterlayer.LayerNorm  [4],[5] intermediate.dense_1 [I,d],[I]  [6],[7] dense_2 [d,I],[d]  [8],[9] intermediate.LayerNorm */
+typedef struct UrConvFormerCfg {
+  int32_t B, L, d, inner, n_layers;
+  int32_t act;          /* UR_ACT_* */
+  int32_t conv_size;    /* K <= L */
+  int32_t padding_mode; /* 0 circular, 1 reflect, 2 constant */
+  int32_t fast;         /* 1: FASTConvFormer's spectral layer */
+  int32_t seq_merge;
+  float eps, seq_decay;
+} UrConvFormerCfg;
+int64_t ur_convformer_param_layout(const UrConvFormerCfg* cfg, int64_t* offsets_out);
+int64_t ur_convformer_workspace_bytes(const UrConvFormerCfg* cfg);
+/* seq_len int64[B] = item_seq_len (only read when seq_merge) */
+int ur_convformer_fwd(const UrConvFormerCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
+                      const int32_t* item_seq, const int64_t* seq_len, float* user_emb, void* ws, void* stream);
+/* dense_grad: every element written; d_emb_rows [B*L, d] in item_seq.reshape(-1) order (rows of id 0 are discarded by
+ * ur_rows_reduce: padding_idx=0). */
+int ur_convformer_bwd(const UrConvFormerCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
+                      const int32_t* item_seq, const int64_t* seq_len, const float* d_user_emb, void* ws, float* dense_grad,
+                      float* d_emb_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * AttHist user encoder (unirec/model/sequential/atthist.py:9-23 + AttentionMergeLayer,
  * unirec/model/modules.py:226-244): z = E[item_seq] W^T + b; p = softmax_l(z . h) over ALL L positions (no mask);
  * user_emb = sum_l p_l z_l.  Flat dense buffer: [0] attention.dense.weight [d,d]  [1] attention.dense.bias [d]

@@ -238,6 +238,8 @@ def model_forward(P: Params, batch: dict, cfg: dict, reduction: bool = True, col
         user_emb = mf_user_emb(P, batch["user_id"])
     elif model == "AttHist":
         user_emb = atthist_user_emb(P, batch["item_seq"])
+    elif model in ("ConvFormer", "FASTConvFormer"):
+        user_emb = convformer_user_emb(P, batch["item_seq"], batch.get("item_seq_len"), cfg, fast=model == "FASTConvFormer")
     elif model in ("AvgHist", "SVDPlusPlus"):
         dst = "item_dst_embedding.weight" if (model == "SVDPlusPlus" or cfg.get("asymmetric", True)) else "item_embedding.weight"
         user_emb = pooled_user_emb(P, batch["item_seq"], batch["item_seq_len"], float(cfg.get("user_sequence_alpha", 0.5)), dst,
@@ -327,3 +329,37 @@ def atthist_user_emb(P: Params, item_seq: Tensor) -> Tensor:
     z = linear(embedding(P["item_embedding.weight"], item_seq.long()), P["attention.dense.weight"], P["attention.dense.bias"])
     p = torch.softmax(torch.matmul(z, P["attention.h"]).squeeze(-1), dim=-1)
     return torch.matmul(p.unsqueeze(-1).transpose(-1, -2), z).squeeze(1)
+
+
+def convformer_user_emb(P: Params, item_seq: Tensor, item_seq_len: Optional[Tensor], cfg: dict, fast: bool = False) -> Tensor:
+    """ConvFormer (unirec/model/sequential/convformer.py:52-72, 88-129) and FASTConvFormer (fastconvformer.py:47-62)."""
+    L, eps = cfg["max_seq_len"], float(cfg["layer_norm_eps"])
+    K = cfg["conv_size"]
+    act = "gelu" if fast else cfg.get("hidden_act", "gelu")
+    x = embedding(P["item_embedding.weight"], item_seq.long()) + P["position_embedding.weight"][:L].unsqueeze(0)
+    x = layer_norm(x, P["LayerNorm.weight"], P["LayerNorm.bias"], eps)
+    for i in range(cfg["n_layers"]):
+        pre = f"encoder.{i}."
+        if fast:
+            w = torch.cat([P[pre + "filterlayer.conv_weight"], torch.zeros(1, L - K, x.shape[-1])], dim=1)
+            h = torch.fft.irfft(torch.fft.rfft(x, dim=1, norm="ortho") * torch.fft.rfft(w, dim=1, norm="ortho"), n=L, dim=1, norm="ortho")
+        else:
+            xt = x.transpose(1, 2)
+            pad = K - 1
+            mode = cfg.get("padding_mode", "circular")
+            if mode == "circular":
+                xt = torch.cat((xt[:, :, L - pad:] if pad else xt[:, :, :0], xt), dim=2)
+            elif mode == "reflect":
+                xt = torch.cat((torch.flip(xt, dims=[2])[:, :, 0:pad], xt), dim=2)
+            else:
+                xt = torch.cat((torch.zeros(xt.size(0), xt.size(1), pad), xt), dim=2)
+            h = torch.nn.functional.conv1d(xt, P[pre + "filterlayer.conv.depthwise_conv.weight"], P[pre + "filterlayer.conv.depthwise_conv.bias"],
+                                           groups=x.shape[-1]).transpose(1, 2)
+        y1 = layer_norm(h + x, P[pre + "filterlayer.LayerNorm.weight"], P[pre + "filterlayer.LayerNorm.bias"], eps)
+        hh = activation(linear(y1, P[pre + "intermediate.dense_1.weight"], P[pre + "intermediate.dense_1.bias"]), act)
+        hh = linear(hh, P[pre + "intermediate.dense_2.weight"], P[pre + "intermediate.dense_2.bias"])
+        x = layer_norm(hh + y1, P[pre + "intermediate.LayerNorm.weight"], P[pre + "intermediate.LayerNorm.bias"], eps)
+    if cfg.get("seq_merge", False):
+        decay = torch.logspace(float(cfg.get("seq_decay", -0.3)), 0, steps=L).unsqueeze(0).unsqueeze(-1)
+        return (x * decay).sum(1) / (item_seq_len.unsqueeze(-1) + 1).pow(0.5)
+    return x[:, -1, :]

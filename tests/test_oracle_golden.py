@@ -13,7 +13,7 @@ from oracle import data_ref, model_ref
 
 RTOL, ATOL = 1e-4, 1e-6   # north_star: logits / loss within 1e-4 relative fp32; grads 1e-4 rel + 1e-6 abs
 
-MODEL_FIXTURES = sorted(os.path.basename(p)[:-4] for pat in ("g[578]_*.npz", "g14_*.npz", "g15_*.npz") for p in glob.glob(os.path.join(GOLDEN, pat)))
+MODEL_FIXTURES = sorted(os.path.basename(p)[:-4] for pat in ("g[578]_*.npz", "g14_*.npz", "g15_*.npz", "g16_*.npz") for p in glob.glob(os.path.join(GOLDEN, pat)))
 
 
 def _t(d):

@@ -24,7 +24,9 @@ def _setup(model_name, loss):
     cfg = parse_arguments(dict(model=model_name, n_users=n_users, n_items=n_items, device="cuda:0", loss_type=loss, embedding_size=32,
                                hidden_size=32, inner_size=64, n_heads=4, max_seq_len=12, epochs=1, batch_size=64, seed=5,
                                n_sample_neg_train=4, history_mask_mode="autoregressive", user_sequence_alpha=0.5, asymmetric=True,
-                               **({"has_user_emb": True} if model_name == "SVDPlusPlus" else {})))
+                               **({"has_user_emb": True} if model_name == "SVDPlusPlus" else {}),
+                               **(dict(conv_size=5, padding_mode="reflect", n_layers=2, layer_norm_eps=1e-9, seq_merge=model_name == "ConvFormer",
+                                       seq_decay=-0.3, init_ratio=0.05, hidden_act="gelu") if "ConvFormer" in model_name else {})))
     neg = AddNegSamples(n_users, n_items, 4, user2history=u2h, seed=5)
     if model_name == "MF":
         ds = BaseDataset(cfg, transform=neg, data=data)
@@ -35,7 +37,8 @@ def _setup(model_name, loss):
 
 
 @pytest.mark.parametrize("model_name,loss", [("SASRec", "bpr"), ("SASRec", "softmax"), ("MF", "bpr"), ("GRU", "softmax"),
-                                             ("AvgHist", "bpr"), ("SVDPlusPlus", "softmax"), ("AttHist", "softmax")])
+                                             ("AvgHist", "bpr"), ("SVDPlusPlus", "softmax"), ("AttHist", "softmax"),
+                                             ("ConvFormer", "softmax"), ("FASTConvFormer", "bpr")])
 def test_fit_losses_follow_the_oracle(model_name, loss):
     from oracle import model_ref
     from unirec_amd.facility.trainer import BatchLoader, Trainer

@@ -436,6 +436,23 @@ def main():
         out = run_model(m, batch)
         save("g15_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
 
+    # ---------------------------------------------------------------- G16 ConvFormer / FASTConvFormer
+    from unirec.model.sequential.convformer import ConvFormer
+    from unirec.model.sequential.fastconvformer import FASTConvFormer
+    r16 = np.random.default_rng(1616)
+    common = dict(n_layers=2, inner_size=64, hidden_dropout_prob=0.0, hidden_act="gelu", layer_norm_eps=1e-9, seq_decay=-0.3, init_ratio=0.05)
+    for tag, cls, kw in (("convformer_circ_full", ConvFormer, dict(model="ConvFormer", conv_size=10, padding_mode="circular", seq_merge=False, loss_type="bpr")),
+                         ("convformer_reflect_k4_merge", ConvFormer, dict(model="ConvFormer", conv_size=4, padding_mode="reflect", seq_merge=True, loss_type="softmax", hidden_act="swish")),
+                         ("convformer_const_k7", ConvFormer, dict(model="ConvFormer", conv_size=7, padding_mode="constant", seq_merge=False, loss_type="bce")),
+                         ("fastconvformer_k6", FASTConvFormer, dict(model="FASTConvFormer", conv_size=6, padding_mode=0, seq_merge=False, loss_type="bpr")),
+                         ("fastconvformer_full_merge", FASTConvFormer, dict(model="FASTConvFormer", conv_size=10, padding_mode=0, seq_merge=True, loss_type="softmax"))):
+        cfg = base_cfg(**dict(common, **kw))
+        torch.manual_seed(16)
+        m = cls(cfg)
+        batch = make_batch(r16, 7, cfg["max_seq_len"], 4, cfg["n_items"], cfg["n_users"])
+        out = run_model(m, batch)
+        save("g16_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
+
 
 if __name__ == "__main__":
     main()

@@ -26,6 +26,12 @@ class UrSasrecCfg(C.Structure):
                 ("eps", C.c_float), ("last_only", C.c_int32), ("skip_padding", C.c_int32)]
 
 
+class UrConvFormerCfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32), ("inner", C.c_int32), ("n_layers", C.c_int32), ("act", C.c_int32),
+                ("conv_size", C.c_int32), ("padding_mode", C.c_int32), ("fast", C.c_int32), ("seq_merge", C.c_int32),
+                ("eps", C.c_float), ("seq_decay", C.c_float)]
+
+
 class UrAttHistCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32)]
 
@@ -89,6 +95,10 @@ SIGNATURES = {
                              P, P, C.c_float, P, P, P]),
     "ur_gemm_tn_workspace_floats": (I64, [C.c_int, C.c_int, C.c_int]),
     "ur_gemm_tn": (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),
+    "ur_convformer_param_layout": (I64, [P, P]),
+    "ur_convformer_workspace_bytes": (I64, [P]),
+    "ur_convformer_fwd": (C.c_int, [P, P, I64, P, P, P, P, P, P]),
+    "ur_convformer_bwd": (C.c_int, [P, P, I64, P, P, P, P, P, P, P, P]),
     "ur_atthist_param_layout": (I64, [P, P]),
     "ur_atthist_workspace_bytes": (I64, [P]),
     "ur_atthist_fwd": (C.c_int, [P, P, I64, P, P, P, P, P]),

@@ -140,10 +140,14 @@ class AbstractRecommender(nn.Module):
                     continue
                 if name.endswith("LayerNorm.weight"):
                     p.fill_(1.0)
+                elif "depthwise_conv" in name:
+                    continue   # nn.Conv1d of the ConvFormer layers: initialised at construction, no init hook touches it
                 elif name.endswith(".bias") or name.endswith("LayerNorm.bias"):
                     p.zero_()
                 elif name.startswith("gru_layers."):
                     continue  # nn.GRU keeps torch's default U(-1/sqrt(H), 1/sqrt(H)) (set by the GRU model)
+                elif "depthwise_conv" in name or name.endswith("conv_weight"):
+                    continue   # set at construction by the ConvFormer / FASTConvFormer layers (no init hook touches them)
                 elif name == "attention.h":
                     p.normal_(0.0, 1.0)   # a bare nn.Parameter(torch.randn(...)): no init hook touches it (modules.py:233)
                 elif p.dim() >= 2:

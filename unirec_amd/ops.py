@@ -413,3 +413,43 @@ def atthist_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws):
     check(lib.ur_atthist_bwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(d_user_emb), _p(ws),
                              _p(dense_grad), _p(d_emb_rows), _stream()), "ur_atthist_bwd")
     return dense_grad, d_emb_rows
+
+
+# --------------------------------------------------------------------------------------------- ConvFormer / FASTConvFormer
+PADDING_MODES = {"circular": 0, "reflect": 1, "constant": 2}
+
+
+def convformer_cfg(B, L, d, inner, n_layers, act, conv_size, padding_mode, fast, seq_merge, eps, seq_decay):
+    pm = PADDING_MODES[padding_mode] if isinstance(padding_mode, str) else int(padding_mode)
+    return _lib.UrConvFormerCfg(B, L, d, inner, n_layers, ACT_IDS[act], conv_size, pm, int(bool(fast)), int(bool(seq_merge)), float(eps),
+                                float(seq_decay))
+
+
+def convformer_param_layout(cfg):
+    offs = (C.c_int64 * (3 + 10 * cfg.n_layers))()
+    total = check(lib.ur_convformer_param_layout(C.byref(cfg), offs), "ur_convformer_param_layout")
+    return list(offs), int(total)
+
+
+def convformer_workspace(cfg, device):
+    return torch.empty(check(lib.ur_convformer_workspace_bytes(C.byref(cfg)), "ur_convformer_workspace_bytes"), dtype=torch.uint8, device=device)
+
+
+def convformer_fwd(cfg, item_table, dense, item_seq, seq_len, ws):
+    _chk(item_table, torch.float32, "item_table")
+    _chk(dense, torch.float32, "dense")
+    _chk(item_seq, torch.int32, "item_seq")
+    _chk(seq_len, torch.int64, "seq_len", allow_none=True)
+    user_emb = torch.empty(cfg.B, cfg.d, dtype=torch.float32, device=dense.device)
+    check(lib.ur_convformer_fwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(seq_len), _p(user_emb), _p(ws),
+                                _stream()), "ur_convformer_fwd")
+    return user_emb
+
+
+def convformer_bwd(cfg, item_table, dense, item_seq, seq_len, d_user_emb, ws):
+    _chk(d_user_emb, torch.float32, "d_user_emb")
+    dense_grad = torch.empty_like(dense)
+    d_emb_rows = torch.empty(cfg.B * cfg.L, cfg.d, dtype=torch.float32, device=dense.device)
+    check(lib.ur_convformer_bwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(seq_len), _p(d_user_emb),
+                                _p(ws), _p(dense_grad), _p(d_emb_rows), _stream()), "ur_convformer_bwd")
+    return dense_grad, d_emb_rows
