@@ -47,7 +47,7 @@ int ur_embedding_gather_f32(const float* table, int64_t n_rows, int d, const voi
 /* ---------------------------------------------------------------------------------------------
  * SASRec user encoder (unirec/model/sequential/sasrec.py:59-76 + unirec/model/modules.py:284-433):
  *   x0 = LN(E[item_seq] + P[0..L-1]); n_layers x { MHA(+mask) -> FFN }; user_emb = x[:, L-1, :].
- * Dropout is not applied (p = 0, as every reference example/benchmark script sets). */
+ * Dropout: see p_hidden / p_attn below. */
 #define UR_MAX_LAYERS 8
 typedef struct UrSasrecCfg {
   int32_t B;        /* sequences in this batch */
@@ -62,6 +62,15 @@ typedef struct UrSasrecCfg {
   int32_t last_only; /* 1: exact last-position specialisation of the final layer */
   int32_t skip_padding; /* 1: the left-padded prefix of every sequence gets no rows at all (exact: those positions cannot
                            reach the loss); used when L <= 64 and head dim is 4/8/16, ignored otherwise */
+  /* Training-time dropout (sasrec.py:69 on the embedded input; modules.py:307 on the attention probabilities; modules.py:313,
+   * 352 on the two block outputs before the residual): probabilities in [0,1), 0 = off (evaluation).  The keep mask is a
+   * counter-based hash of (drop_seed, drop_step, site, element) -- see DropSpec in csrc/common.h and oracle/dropout_ref.py --
+   * never stored: ur_sasrec_bwd must be called with the SAME (drop_seed, drop_step) as the forward it differentiates.  The
+   * caller advances drop_step every training step. */
+  float p_hidden;       /* hidden_dropout_prob */
+  float p_attn;         /* attn_dropout_prob */
+  int64_t drop_seed;
+  int64_t drop_step;
 } UrSasrecCfg;
 
 /* Layout of the flat dense-parameter buffer (and of its gradient buffer). offsets_out receives

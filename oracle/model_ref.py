@@ -70,8 +70,9 @@ def sasrec_attention_mask(item_seq: Tensor, use_pos_emb: bool = True) -> Tensor:
 
 
 def multi_head_attention(x: Tensor, mask: Tensor, P: Params, pre: str, n_heads: int, eps: float,
-                         collect: Optional[dict] = None) -> Tensor:
-    """unirec/model/modules.py:284-316 with dropout p=0."""
+                         collect: Optional[dict] = None, drop_attn: Optional[Tensor] = None, drop_out: Optional[Tensor] = None) -> Tensor:
+    """unirec/model/modules.py:284-316.  drop_attn [B,h,L,L] / drop_out [B,L,d]: dropout multipliers (0 or 1/(1-p)) of
+    attn_dropout (:307, on the probabilities) and out_dropout (:313, on the dense output before the residual); None = p 0."""
     B, L, d = x.shape
     hd = d // n_heads
     q = linear(x, P[pre + "query.weight"], P[pre + "query.bias"])
@@ -85,23 +86,31 @@ def multi_head_attention(x: Tensor, mask: Tensor, P: Params, pre: str, n_heads: 
     s = s / math.sqrt(hd)
     s = s + mask
     p = torch.softmax(s, dim=-1)
+    if drop_attn is not None:
+        p = p * drop_attn
     ctx = torch.matmul(p, split(v)).permute(0, 2, 1, 3).contiguous().view(B, L, d)
     h = linear(ctx, P[pre + "dense.weight"], P[pre + "dense.bias"])
+    if drop_out is not None:
+        h = h * drop_out
     out = layer_norm(h + x, P[pre + "LayerNorm.weight"], P[pre + "LayerNorm.bias"], eps)
     if collect is not None:
         collect[pre + "ctx"] = ctx
     return out
 
 
-def feed_forward(x: Tensor, P: Params, pre: str, act: str, eps: float) -> Tensor:
-    """unirec/model/modules.py:347-355 with dropout p=0."""
+def feed_forward(x: Tensor, P: Params, pre: str, act: str, eps: float, drop: Optional[Tensor] = None) -> Tensor:
+    """unirec/model/modules.py:347-355; drop [B,L,d]: multipliers of the dropout at :352 (after dense_2, before the residual)."""
     h = activation(linear(x, P[pre + "dense_1.weight"], P[pre + "dense_1.bias"]), act)
     h = linear(h, P[pre + "dense_2.weight"], P[pre + "dense_2.bias"])
+    if drop is not None:
+        h = h * drop
     return layer_norm(h + x, P[pre + "LayerNorm.weight"], P[pre + "LayerNorm.bias"], eps)
 
 
-def sasrec_user_emb(P: Params, item_seq: Tensor, cfg: dict, collect: Optional[dict] = None) -> Tensor:
-    """unirec/model/sequential/sasrec.py:59-76 (dropout 0) -> [B,d]."""
+def sasrec_user_emb(P: Params, item_seq: Tensor, cfg: dict, collect: Optional[dict] = None, drop: Optional[dict] = None) -> Tensor:
+    """unirec/model/sequential/sasrec.py:59-76 -> [B,d].  drop: None (evaluation / p = 0) or the dropout multiplier tensors
+    {"embed" [B,L,d] (:69), "attn{i}" [B,h,L,L], "out{i}" [B,L,d], "ffn{i}" [B,L,d]} of a training forward."""
+    dm = (lambda k: None) if drop is None else (lambda k: torch.as_tensor(drop[k]) if k in drop else None)
     eps = float(cfg["layer_norm_eps"])
     use_pos = bool(cfg.get("use_position_emb", True))
     x = embedding(P["item_embedding.weight"], item_seq)
@@ -109,14 +118,16 @@ def sasrec_user_emb(P: Params, item_seq: Tensor, cfg: dict, collect: Optional[di
         L = item_seq.shape[1]
         x = x + P["position_embedding.weight"][:L].unsqueeze(0)
     x = layer_norm(x, P["LayerNorm.weight"], P["LayerNorm.bias"], eps)
+    if dm("embed") is not None:
+        x = x * dm("embed")
     mask = sasrec_attention_mask(item_seq, use_pos)
     if collect is not None:
         collect["mask"] = mask
         collect["x0"] = x
     for i in range(int(cfg["n_layers"])):
         pre = f"trm_encoder.layer.{i}."
-        x = multi_head_attention(x, mask, P, pre + "multi_head_attention.", int(cfg["n_heads"]), eps, collect)
-        x = feed_forward(x, P, pre + "feed_forward.", cfg["hidden_act"], eps)
+        x = multi_head_attention(x, mask, P, pre + "multi_head_attention.", int(cfg["n_heads"]), eps, collect, dm(f"attn{i}"), dm(f"out{i}"))
+        x = feed_forward(x, P, pre + "feed_forward.", cfg["hidden_act"], eps, dm(f"ffn{i}"))
         if collect is not None:
             collect[f"layer{i}"] = x
     return x[:, -1, :]
@@ -231,7 +242,7 @@ def model_forward(P: Params, batch: dict, cfg: dict, reduction: bool = True, col
         in_item_id = item_id
     items_emb = embedding(P["item_embedding.weight"], in_item_id)
     if model == "SASRec":
-        user_emb = sasrec_user_emb(P, batch["item_seq"], cfg, collect)
+        user_emb = sasrec_user_emb(P, batch["item_seq"], cfg, collect, drop=batch.get("drop_masks"))
     elif model == "GRU":
         user_emb = gru_user_emb(P, batch["item_seq"], cfg, collect)
     elif model == "MF":

@@ -32,6 +32,47 @@ def test_forward_backward_matches_reference(name):
         np.testing.assert_allclose(G[k].numpy(), ref, rtol=RTOL, atol=ATOL, err_msg=k)
 
 
+@pytest.mark.parametrize("name", ["g17_sasrec_dropout_bpr", "g17_sasrec_dropout_softmax_nopos"])
+def test_dropout_placement_and_scaling_match_reference(name):
+    """The reference SASRec in training mode with its nn.Dropout modules replaced by recorded Bernoulli/(1-p) multipliers
+    (tools/capture_goldens.py G17); the oracle replays the same multipliers at the sites it claims they sit at."""
+    cfg, g = load_golden(name)
+    P, batch = _t(g["sd"]), _t(g["in"])
+    assert any((v == 0).any() for v in g["mask"].values())       # dropout was really on
+    batch["drop_masks"] = _t(g["mask"])
+    loss, scores, user_emb, G = model_ref.grads_of(P, batch, cfg)
+    np.testing.assert_allclose(user_emb.numpy(), g["out"]["user_emb"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(loss.numpy(), g["out"]["loss"], rtol=RTOL, atol=ATOL)
+    for k, ref in g["grad"].items():
+        np.testing.assert_allclose(G[k].numpy(), ref, rtol=RTOL, atol=ATOL, err_msg=k)
+    batch.pop("drop_masks")
+    _, _, ue0, _ = model_ref.grads_of(P, batch, cfg)
+    assert not np.allclose(ue0.numpy(), g["out"]["user_emb"], rtol=1e-2)   # ... and it matters
+
+
+def test_device_dropout_hash_restatement():
+    """oracle/dropout_ref.py: known answers of mix32 (computed by hand from its definition in C unsigned arithmetic),
+    keep rate, independence of the sites / steps, p = 0."""
+    from oracle import dropout_ref as dr
+    assert int(dr.mix32(0)) == 0
+    x = 1                                            # the definition, step by step, in Python integers
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF; x ^= x >> 16
+    assert int(dr.mix32(1)) == x
+    assert dr.threshold(0.5) == 2 ** 31 and dr.threshold(0.0) == 0
+    m = dr.mask(512, 256, 0.3, seed=2022, step=7, site=6)
+    assert set(np.unique(m)) == {np.float32(0.0), np.float32(1.0) / (np.float32(1.0) - np.float32(0.3))}
+    keep = (m > 0).mean()
+    assert abs(keep - 0.7) < 4 * np.sqrt(0.21 / m.size)
+    assert abs((m > 0).mean(0) - 0.7).max() < 0.12 and abs((m > 0).mean(1) - 0.7).max() < 0.15     # no dead rows / columns
+    m2 = dr.mask(512, 256, 0.3, seed=2022, step=8, site=6)
+    m3 = dr.mask(512, 256, 0.3, seed=2022, step=7, site=7)
+    for other in (m2, m3):
+        agree = ((m > 0) == (other > 0)).mean()
+        assert abs(agree - (0.49 + 0.09)) < 0.01       # independent masks agree with probability p^2 + (1-p)^2
+    assert (dr.mask(4, 8, 0.0, 1, 1, 1) == 1).all()
+    assert np.array_equal(m, dr.mask(512, 256, 0.3, seed=2022, step=7, site=6))
+
+
 def test_mask_matches_reference():
     cfg, g = load_golden("g5_sasrec_h2_swish_bpr")
     m = model_ref.sasrec_attention_mask(torch.from_numpy(g["in"]["item_seq"]), True)

@@ -453,6 +453,39 @@ def main():
         out = run_model(m, batch)
         save("g16_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
 
+    # ---------------------------------------------------------------- G17 SASRec in training mode WITH dropout
+    # Pins WHERE the reference drops and how it scales (sasrec.py:69; modules.py:307,313,352).  torch's nn.Dropout draws from
+    # torch's generator, which the device does not reproduce; so every nn.Dropout module of the reference model gets its
+    # forward replaced by "multiply with a recorded Bernoulli(1-p)/(1-p) tensor" (= F.dropout's definition), the tensors are
+    # stored in the fixture and the oracle replays them.
+    r17 = np.random.default_rng(1717)
+    for tag, kw in (("sasrec_dropout_bpr", dict(loss_type="bpr", hidden_dropout_prob=0.3, attn_dropout_prob=0.2, n_heads=4)),
+                    ("sasrec_dropout_softmax_nopos", dict(loss_type="softmax", hidden_dropout_prob=0.5, attn_dropout_prob=0.5, n_heads=2,
+                                                          use_position_emb=False))):
+        cfg = base_cfg(model="SASRec", **kw)
+        torch.manual_seed(17)
+        m = SASRec(cfg)
+        m.train()
+        gen = torch.Generator().manual_seed(171717)
+        masks = {}
+
+        def patch(mod, name):
+            def fwd(x, _mod=mod, _name=name):
+                mk = (torch.rand(x.shape, generator=gen) >= _mod.p).float() / (1.0 - _mod.p)
+                masks[_name] = mk.numpy().copy()
+                return x * mk
+            mod.forward = fwd
+        patch(m.dropout, "embed")
+        for i, layer in enumerate(m.trm_encoder.layer):
+            patch(layer.multi_head_attention.attn_dropout, f"attn{i}")
+            patch(layer.multi_head_attention.out_dropout, f"out{i}")
+            patch(layer.feed_forward.dropout, f"ffn{i}")
+        batch = make_batch(r17, 6, cfg["max_seq_len"], 4, cfg["n_items"], cfg["n_users"])
+        out = run_model(m, batch)
+        assert len(masks) == 1 + 3 * cfg["n_layers"], sorted(masks)
+        save("g17_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch),
+             **pack("mask.", masks), **out)
+
 
 if __name__ == "__main__":
     main()

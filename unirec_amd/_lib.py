@@ -23,7 +23,8 @@ LOSS_IDS = {"bce": 0, "bpr": 1, "softmax": 2, "ccl": 3, "fullsoftmax": 4}
 class UrSasrecCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32), ("n_heads", C.c_int32),
                 ("inner", C.c_int32), ("n_layers", C.c_int32), ("act", C.c_int32), ("use_pos", C.c_int32),
-                ("eps", C.c_float), ("last_only", C.c_int32), ("skip_padding", C.c_int32)]
+                ("eps", C.c_float), ("last_only", C.c_int32), ("skip_padding", C.c_int32),
+                ("p_hidden", C.c_float), ("p_attn", C.c_float), ("drop_seed", C.c_int64), ("drop_step", C.c_int64)]
 
 
 class UrConvFormerCfg(C.Structure):

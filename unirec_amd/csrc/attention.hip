@@ -33,7 +33,16 @@ struct AttnDims {
   float sqrt_hd;  // sqrt(hd) for the literal (division) path
   const int* seq_base;   // compacted rows (nullable): position l of sequence b is row seq_base[b] + l, for l >= seq_pad[b]
   const int* seq_pad;
+  unsigned dkey, dthresh;   // dropout on the probabilities (dthresh == 0: off): row id (b*H + h)*L + i, column j
+  float dscale;
 };
+__device__ __forceinline__ unsigned attn_rowkey(const AttnDims& p, int b, int h, int i) {
+  return mix32((unsigned)((b * p.H + h) * p.L + i) ^ p.dkey);
+}
+// multiplier of P[i,j] (1 when dropout is off)
+__device__ __forceinline__ float attn_keep(const AttnDims& p, unsigned rowkey, int j) {
+  return p.dthresh ? drop_mul(rowkey, (unsigned)j, p.dthresh, p.dscale) : 1.0f;
+}
 // first row of sequence b's (virtual) position 0 and the number of leading positions that have no row
 __device__ __forceinline__ void seq_rows(const AttnDims& p, int b, long long& row0, int& pad) {
   row0 = p.seq_base ? (long long)p.seq_base[b] : (long long)b * p.L;
@@ -80,6 +89,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   const float* __restrict__ Kb = base + p.d + h * HD;
   const float* __restrict__ Vb = base + 2 * p.d + h * HD;
   const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const unsigned rk = attn_rowkey(p, b, h, ii);
   float m = -INFINITY, l = 0.f, o[HD];
 #pragma unroll
   for (int c = 0; c < HD; ++c) o[c] = 0.f;
@@ -97,18 +107,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
       const float s = dot_u<HD>(q, Kb + (long long)j * ld) * p.scale;
       const float pj = (sq[j] > 0 && (!p.causal || j <= i)) ? __expf(s - m) : 0.f;
       l += pj;
+      const float pd = pj * attn_keep(p, rk, j);
       const float* __restrict__ vr = Vb + (long long)j * ld;
 #pragma unroll
-      for (int c = 0; c < HD; ++c) o[c] = fmaf(pj, vr[c], o[c]);
+      for (int c = 0; c < HD; ++c) o[c] = fmaf(pd, vr[c], o[c]);
     }
   } else {  // empty history: literal path over all L keys
     for (int j = 0; j < L; ++j) m = fmaxf(m, dot_u<HD>(q, Kb + (long long)j * ld) / p.sqrt_hd + -10000.0f);
     for (int j = 0; j < L; ++j) {
       const float pj = __expf((dot_u<HD>(q, Kb + (long long)j * ld) / p.sqrt_hd + -10000.0f) - m);
       l += pj;
+      const float pd = pj * attn_keep(p, rk, j);
       const float* __restrict__ vr = Vb + (long long)j * ld;
 #pragma unroll
-      for (int c = 0; c < HD; ++c) o[c] = fmaf(pj, vr[c], o[c]);
+      for (int c = 0; c < HD; ++c) o[c] = fmaf(pd, vr[c], o[c]);
     }
   }
   if (!active) return;
@@ -169,6 +181,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       dq[c] = 0.f;
     }
     const float li = lse_h[rr], Di = D_h[rr];
+    const unsigned rk = attn_rowkey(p, b, h, rr);
     if (!literal) {
       const bool live = r >= dead_below;
       const int jend = p.causal ? min(L, ck * 64 + 64) : L;
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const float* __restrict__ kr = Kb + (long long)j * ld;
         const float s = dot_u<HD>(q, kr) * p.scale;
         const float pj = (live && sq[j] > 0 && (!p.causal || j <= r)) ? __expf(s - li) : 0.f;
-        const float ds = pj * (dot_u<HD>(g, Vb + (long long)j * ld) - Di);
+        const float ds = pj * (attn_keep(p, rk, j) * dot_u<HD>(g, Vb + (long long)j * ld) - Di);
 #pragma unroll
         for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
       }
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       for (int j = 0; j < L; ++j) {
         const float* __restrict__ kr = Kb + (long long)j * ld;
         const float pj = __expf((dot_u<HD>(q, kr) / p.sqrt_hd + -10000.0f) - li);
-        const float ds = pj * (dot_u<HD>(g, Vb + (long long)j * ld) - Di);
+        const float ds = pj * (attn_keep(p, rk, j) * dot_u<HD>(g, Vb + (long long)j * ld) - Di);
 #pragma unroll
         for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
       }
@@ -217,11 +230,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const float* __restrict__ gr = gbase + (long long)i * p.d;
         const float s = dot_u<HD>(k, qr) * p.scale;
         const float pj = (vj && (!p.causal || r <= i)) ? __expf(s - lse_h[i]) : 0.f;
-        const float ds = pj * (dot_u<HD>(v, gr) - D_h[i]) * p.scale;
+        const float mk = attn_keep(p, attn_rowkey(p, b, h, i), rr);
+        const float ds = pj * (mk * dot_u<HD>(v, gr) - D_h[i]) * p.scale;
+        const float pd = pj * mk;
 #pragma unroll
         for (int c = 0; c < HD; ++c) {
           dk[c] = fmaf(ds, qr[c], dk[c]);
-          dv[c] = fmaf(pj, gr[c], dv[c]);
+          dv[c] = fmaf(pd, gr[c], dv[c]);
         }
       }
     } else {
@@ -229,11 +244,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const float* __restrict__ qr = Qb + (long long)i * ld;
         const float* __restrict__ gr = gbase + (long long)i * p.d;
         const float pj = __expf((dot_u<HD>(k, qr) / p.sqrt_hd + -10000.0f) - lse_h[i]);
-        const float ds = pj * (dot_u<HD>(v, gr) - D_h[i]) / p.sqrt_hd;
+        const float mk = attn_keep(p, attn_rowkey(p, b, h, i), rr);
+        const float ds = pj * (mk * dot_u<HD>(v, gr) - D_h[i]) / p.sqrt_hd;
+        const float pd = pj * mk;
 #pragma unroll
         for (int c = 0; c < HD; ++c) {
           dk[c] = fmaf(ds, qr[c], dk[c]);
-          dv[c] = fmaf(pj, gr[c], dv[c]);
+          dv[c] = fmaf(pd, gr[c], dv[c]);
         }
       }
     }
@@ -292,6 +309,7 @@ __global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restr
   const float* __restrict__ qr = q_last + (long long)b * p.d + h * HD;   // wave-uniform row
   const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
   const bool literal = fv >= L;
+  const unsigned rk = attn_rowkey(p, b, h, L - 1);
   float m = -INFINITY, l = 0.f, o[HD];
 #pragma unroll
   for (int c = 0; c < HD; ++c) o[c] = 0.f;
@@ -312,8 +330,9 @@ __global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restr
     const float corr = __expf(m - mn);
     const float pj = allowed ? __expf(sv - mn) : 0.f;
     l = l * corr + wave_sum(pj);
+    const float pd = pj * attn_keep(p, rk, j);
 #pragma unroll
-    for (int c = 0; c < HD; ++c) o[c] = o[c] * corr + wave_sum(pj * vr[c]);
+    for (int c = 0; c < HD; ++c) o[c] = o[c] * corr + wave_sum(pd * vr[c]);
     m = mn;
   }
   const float inv_l = 1.0f / l;
@@ -348,6 +367,7 @@ __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restr
   float D = 0.f;
 #pragma unroll
   for (int c = 0; c < HD; ++c) D = fmaf(gr[c], orow[c], D);
+  const unsigned rk = attn_rowkey(p, b, h, L - 1);
   float dq[HD];
 #pragma unroll
   for (int c = 0; c < HD; ++c) dq[c] = 0.f;
@@ -367,14 +387,15 @@ __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restr
     const bool allowed = in && (literal || sq[min(j, L - 1)] > 0);   // the mask is indexed by position, not by (clamped) row
     const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
     const float pj = allowed ? __expf(sv - ls) : 0.f;
-    const float ds = pj * (dp - D) * f;
+    const float mk = attn_keep(p, rk, j);
+    const float ds = pj * (mk * dp - D) * f;
     if (in && j >= pad) {
       float* out = dqkv + (row0 + j) * ld + h * HD;
       float dkr[HD], dvr[HD];
 #pragma unroll
       for (int c = 0; c < HD; ++c) {
         dkr[c] = ds * qr[c];
-        dvr[c] = pj * gr[c];
+        dvr[c] = pj * mk * gr[c];
       }
       store_vec<HD>(out + p.d, dkr);
       store_vec<HD>(out + 2 * p.d, dvr);
@@ -414,6 +435,7 @@ __global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restric
 #pragma unroll
   for (int c = 0; c < HD; ++c) q[c] = base[(long long)ii * ld + h * HD + c];
   const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const unsigned rk = attn_rowkey(p, b, h, ii);
   float m = -INFINITY, l = 0.f, o[HD];
 #pragma unroll
   for (int c = 0; c < HD; ++c) o[c] = 0.f;
@@ -449,8 +471,9 @@ __global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restric
           if (pass == 0) {
             m = fmaxf(m, fmaxf(oka ? sa : -INFINITY, okb ? sb : -INFINITY));
           } else {
-            const float pa = oka ? __expf(sa - m) : 0.f, pb = okb ? __expf(sb - m) : 0.f;
+            float pa = oka ? __expf(sa - m) : 0.f, pb = okb ? __expf(sb - m) : 0.f;
             l += pa + pb;
+            if (p.dthresh) { pa *= attn_keep(p, rk, kc * 64 + jj); pb *= attn_keep(p, rk, kc * 64 + jj + 1); }
             float va[HD], vb[HD];
 #pragma unroll
             for (int c = 0; c < HD; ++c) { va[c] = bcast(vreg[c], jj); vb[c] = bcast(vreg[c], jj + 1); }
@@ -466,8 +489,9 @@ __global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restric
           if (pass == 0) {
             if (oka) m = fmaxf(m, sa);
           } else {
-            const float pa = oka ? __expf(sa - m) : 0.f;
+            float pa = oka ? __expf(sa - m) : 0.f;
             l += pa;
+            pa *= attn_keep(p, rk, kc * 64 + jj);
 #pragma unroll
             for (int c = 0; c < HD; ++c) o[c] = fmaf(pa, bcast(vreg[c], jj), o[c]);
           }
@@ -481,9 +505,10 @@ __global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restric
     for (int j = 0; j < L; ++j) {
       const float pj = __expf((dot_u<HD>(q, Kb + (long long)j * ld) / p.sqrt_hd + -10000.0f) - m);
       l += pj;
+      const float pd = pj * attn_keep(p, rk, j);
       const float* __restrict__ vr = Vb + (long long)j * ld;
 #pragma unroll
-      for (int c = 0; c < HD; ++c) o[c] = fmaf(pj, vr[c], o[c]);
+      for (int c = 0; c < HD; ++c) o[c] = fmaf(pd, vr[c], o[c]);
     }
   }
   if (!active) return;
@@ -527,6 +552,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rl_kernel(const float* __restric
     Dr = fmaf(g[c], obase[(long long)rr * p.d + c], Dr);
   }
   const float lr = lse_h[rr];
+  const unsigned rk = attn_rowkey(p, b, h, rr);
   {  // ---- row pass: dQ_i = f * sum_j dS_ij K_j
     float dq[HD];
 #pragma unroll
@@ -558,7 +584,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rl_kernel(const float* __restric
         const int j = kc * 64 + jj;
         const bool ok = live && ((vmask >> jj) & 1ull) && (literal || !p.causal || j <= r);
         const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
-        const float ds = ok ? __expf(sv - lr) * (dp - Dr) : 0.f;
+        const float ds = ok ? __expf(sv - lr) * (attn_keep(p, rk, j) * dp - Dr) : 0.f;
 #pragma unroll
         for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kj[c], dq[c]);
       }
@@ -608,11 +634,13 @@ __global__ __launch_bounds__(256) void attn_bwd_rl_kernel(const float* __restric
         const bool ok = vj && (literal || !p.causal || r <= i);
         const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
         const float pj = ok ? __expf(sv - bcast(lq, it)) : 0.f;
-        const float ds = pj * (dp - bcast(Dq, it));
+        const float mk = attn_keep(p, attn_rowkey(p, b, h, i), rr);
+        const float ds = pj * (mk * dp - bcast(Dq, it));
+        const float pd = pj * mk;
 #pragma unroll
         for (int c = 0; c < HD; ++c) {
           dk[c] = fmaf(ds, qi[c], dk[c]);
-          dv[c] = fmaf(pj, gi[c], dv[c]);
+          dv[c] = fmaf(pd, gi[c], dv[c]);
         }
       }
     }
@@ -741,6 +769,16 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
       }
     }
     l[it] += __shfl_xor(l[it], 32, 64);
+    if (p.dthresh) {   // dropout on the probabilities (the normaliser l is that of the undropped softmax)
+      const unsigned rk = attn_rowkey(p, b, h, it * 32 + c32);
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        if (jt >= nt || (causal && jt > it)) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          st[jt][it][r] *= drop_mul(rk, (unsigned)(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2), p.dthresh, p.dscale);
+      }
+    }
   }
   // ---- O^T = V^T P^T
   floatx16 oa[2];
@@ -819,6 +857,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
 
   __shared__ float tiles[4][4][64][LDSW];   // [wave][Q,K,V,dO][row][dim]
   __shared__ float rowv[4][2][64];          // [wave][lse*log2e, D][row]
+  __shared__ unsigned rowk[4][64];          // [wave][row]: dropout row key of query `row`
   float (*qs)[LDSW] = tiles[w][0];
   float (*ks)[LDSW] = tiles[w][1];
   float (*vs)[LDSW] = tiles[w][2];
@@ -840,6 +879,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
     }
     rowv[w][0][lane] = lse[((long long)b * p.H + h) * L + row] * LOG2E;
     rowv[w][1][lane] = D;
+    rowk[w][lane] = attn_rowkey(p, b, h, min(lane, L - 1));
   }
   // row-type MFMA fragments: row 32 t + c32, dims h2*KH .. h2*KH + KH-1
   float qf[2][KH], kf[2][KH], vf[2][KH], gf[2][KH];
@@ -864,6 +904,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
       if (it >= nt) break;
       const int i = it * 32 + c32;
       const float lse2 = rowv[w][0][i], Di = rowv[w][1][i];
+      const unsigned rk = rowk[w][i];
       floatx16 dq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -883,7 +924,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
           const float e = literal ? (sT[r] / p.sqrt_hd + -10000.0f) * LOG2E : sT[r] * sc2;
           const float pv = (vis >> ((r & 3) + 8 * (r >> 2))) & 1u ? __builtin_amdgcn_exp2f(e - lse2) : 0.f;
-          sT[r] = pv * (dpT[r] - Di);   // dS^T
+          const float mk = attn_keep(p, rk, jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2);
+          sT[r] = pv * (mk * dpT[r] - Di);   // dS^T
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -928,8 +970,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
           const int il = (r & 3) + 8 * (r >> 2), i = it * 32 + il + 4 * h2;
           const float e = literal ? (sM[r] / p.sqrt_hd + -10000.0f) * LOG2E : sM[r] * sc2;
           const float pv = (vis >> il) & 1u ? __builtin_amdgcn_exp2f(e - rowv[w][0][i]) : 0.f;
-          sM[r] = pv;                                  // P
-          dpM[r] = pv * (dpM[r] - rowv[w][1][i]);      // dS
+          const float mk = p.dthresh ? drop_mul(rowk[w][i], (unsigned)j, p.dthresh, p.dscale) : 1.0f;
+          sM[r] = pv * mk;                             // dropout(P)
+          dpM[r] = pv * (mk * dpM[r] - rowv[w][1][i]); // dS
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -966,6 +1009,7 @@ static int make_dims(int B, int L, int d, int H, int causal, AttnDims* p) {
   p->scale = 1.0f / p->sqrt_hd;
   p->seq_base = nullptr;
   p->seq_pad = nullptr;
+  p->dkey = 0; p->dthresh = 0; p->dscale = 1.0f;
   return UR_OK;
 }
 
@@ -976,7 +1020,7 @@ bool attn_compact_supported(int L, int d, int H) {
 }
 
 int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int causal, float* ctx, float* lse,
-             int q_last_only, hipStream_t st, const int* seq_base, const int* seq_pad) {
+             int q_last_only, hipStream_t st, const int* seq_base, const int* seq_pad, const DropSpec* drop) {
   if (q_last_only) return fail(UR_ERR_UNSUPPORTED, "attn_fwd: last-row mode not implemented");
   ProfScope ps(PC_ATTN_FWD, st, 4.0 * B * L * (double)L * d * (causal ? 0.5 : 1.0));
   AttnDims p;
@@ -984,6 +1028,7 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
   if (rc) return rc;
   p.seq_base = seq_base;
   p.seq_pad = seq_pad;
+  if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need L <= 64 and head dim 4/8/16");
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
   if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
@@ -1012,7 +1057,8 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
 }
 
 int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dctx, const float* lse, int B, int L, int d,
-             int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st, const int* seq_base, const int* seq_pad) {
+             int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st, const int* seq_base, const int* seq_pad,
+             const DropSpec* drop) {
   if (q_last_only) return fail(UR_ERR_UNSUPPORTED, "attn_bwd: last-row mode not implemented");
   ProfScope ps(PC_ATTN_BWD, st, 10.0 * B * L * (double)L * d * (causal ? 0.5 : 1.0));
   AttnDims p;
@@ -1020,6 +1066,7 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
   if (rc) return rc;
   p.seq_base = seq_base;
   p.seq_pad = seq_pad;
+  if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need L <= 64 and head dim 4/8/16");
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
   if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
@@ -1053,13 +1100,14 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
 }
 
 int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, int L, int d, int H, float* ctx_last,
-                  float* lse_last, hipStream_t st, const int* seq_base, const int* seq_pad) {
+                  float* lse_last, hipStream_t st, const int* seq_base, const int* seq_pad, const DropSpec* drop) {
   ProfScope ps(PC_ATTN_FWD, st, 4.0 * B * (double)L * d);
   AttnDims p;
   int rc = make_dims(B, L, d, H, 1, &p);
   if (rc) return rc;
   p.seq_base = seq_base;
   p.seq_pad = seq_pad;
+  if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   dim3 grid(B, cdiv(H, 4));
 #define GO(HD) hipLaunchKernelGGL((attn_last_fwd_kernel<HD>), grid, dim3(256), 0, st, q_last, qkv, seq, p, ctx_last, lse_last)
   switch (p.hd) {
@@ -1077,13 +1125,14 @@ int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, 
 
 int attn_last_bwd(const float* q_last, const float* qkv, const int* seq, const float* ctx_last, const float* dctx_last,
                   const float* lse_last, int B, int L, int d, int H, float* dq_last, float* dqkv, hipStream_t st,
-                  const int* seq_base, const int* seq_pad) {
+                  const int* seq_base, const int* seq_pad, const DropSpec* drop) {
   ProfScope ps(PC_ATTN_BWD, st, 8.0 * B * (double)L * d);
   AttnDims p;
   int rc = make_dims(B, L, d, H, 1, &p);
   if (rc) return rc;
   p.seq_base = seq_base;
   p.seq_pad = seq_pad;
+  if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   dim3 grid(B, cdiv(H, 4));
 #define GO(HD) hipLaunchKernelGGL((attn_last_bwd_kernel<HD>), grid, dim3(256), 0, st, q_last, qkv, seq, ctx_last, dctx_last, lse_last, p, dq_last, dqkv)
   switch (p.hd) {

@@ -68,6 +68,54 @@ __device__ __forceinline__ float group_sum_rt(float v, int width) {
   return v;
 }
 
+// ---- dropout (training only).  Inverted dropout on a grid of elements (row id, column): the keep decision is a pure
+// function of (stream key, row id, column) -- nothing is stored, the backward re-evaluates it -- built from the 32-bit
+// integer finaliser `mix32` (xorshift-multiply; the "lowbias32" constants):
+//   rowkey = mix32(row_id ^ key)      keep <=> mix32(rowkey + column * 0x9E3779B9) >= thresh        value *= keep ? 1/(1-p) : 0
+// key = drop_stream_key(seed, step, site) is one per (seed, training step, dropout site); thresh = floor(p * 2^32).
+// The random source is this hash, not torch's Philox stream: parity is against oracle/dropout_ref.py, which restates it.
+struct DropSpec {
+  unsigned key, thresh;   // thresh == 0: dropout off
+  float scale;            // 1 / (1 - p)
+  const int* rows;        // row id of buffer row r: rows[r] when non-null, else r * mul + add
+  int mul, add;
+};
+__host__ __device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+static inline unsigned drop_stream_key(long long seed, long long step, unsigned site) {
+  unsigned k = mix32((unsigned)seed ^ 0x85ebca6bu);
+  k = mix32(k ^ (unsigned)((unsigned long long)seed >> 32));
+  k = mix32(k ^ (unsigned)step);
+  k = mix32(k ^ (unsigned)((unsigned long long)step >> 32));
+  return mix32(k + site * 0x9E3779B9u);
+}
+// p in [0,1): the spec of one site (row map filled in by the caller)
+static inline DropSpec drop_spec(float p, long long seed, long long step, unsigned site) {
+  DropSpec s{};
+  if (p > 0.f) {
+    double t = (double)p * 4294967296.0;
+    s.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    s.scale = 1.0f / (1.0f - p);
+    s.key = drop_stream_key(seed, step, site);
+  }
+  s.mul = 1;
+  return s;
+}
+__device__ __forceinline__ unsigned drop_rowkey(const DropSpec& s, int r) {
+  const int id = s.rows ? s.rows[r] : r * s.mul + s.add;
+  return mix32((unsigned)id ^ s.key);
+}
+__device__ __forceinline__ float drop_mul(unsigned rowkey, unsigned col, unsigned thresh, float scale) {
+  return mix32(rowkey + col * 0x9E3779B9u) >= thresh ? scale : 0.f;
+}
+__device__ __forceinline__ float4 drop4(float4 v, unsigned rowkey, unsigned col0, const DropSpec& s) {
+  v.x *= drop_mul(rowkey, col0, s.thresh, s.scale); v.y *= drop_mul(rowkey, col0 + 1, s.thresh, s.scale);
+  v.z *= drop_mul(rowkey, col0 + 2, s.thresh, s.scale); v.w *= drop_mul(rowkey, col0 + 3, s.thresh, s.scale);
+  return v;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // activation ids shared with the host (UR_ACT_*)

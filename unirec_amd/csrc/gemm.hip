@@ -86,6 +86,7 @@ __device__ __forceinline__ void epilogue_from_lds(const float* Cs, int m0, int n
       if (m >= a.M) break;
       float4 v[NV];
       float s = 0.f;
+      const unsigned rk = a.drop.thresh ? drop_rowkey(a.drop, m) : 0u;
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const int c = t + 32 * k;
@@ -93,7 +94,13 @@ __device__ __forceinline__ void epilogue_from_lds(const float* Cs, int m0, int n
           float4 x = *(const float4*)(Cs + ml * CS + c * 4);
           const float4 bs = *(const float4*)(a.bias + c * 4);
           const float4 rs = *(const float4*)(a.aux + (long long)m * a.ldaux + c * 4);
-          x.x += bs.x + rs.x; x.y += bs.y + rs.y; x.z += bs.z + rs.z; x.w += bs.w + rs.w;
+          if (a.drop.thresh) {   // t = dropout(acc + bias) + res
+            x.x += bs.x; x.y += bs.y; x.z += bs.z; x.w += bs.w;
+            x = drop4(x, rk, (unsigned)(c * 4), a.drop);
+            x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w;
+          } else {
+            x.x += bs.x + rs.x; x.y += bs.y + rs.y; x.z += bs.z + rs.z; x.w += bs.w + rs.w;
+          }
           v[k] = x;
           s += (x.x + x.y) + (x.z + x.w);
         }

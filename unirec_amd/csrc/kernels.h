@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "common.h"
+
 namespace ur {
 
 constexpr int LN_BWD_MAX_BLOCKS = 512;
@@ -11,7 +13,7 @@ int gather_rows(const float* table, const void* idx, int idx_bytes, long long n,
 // tok (nullable): compact row r is token tok[r] of seq (= b*L + l); m_dev (nullable): device-side row count
 int embed_ln_fwd(const int* seq, const float* table, const float* pos, const float* gamma, const float* beta, float eps,
                  int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st, const int* tok = nullptr,
-                 const int* m_dev = nullptr);
+                 const int* m_dev = nullptr, const DropSpec* drop = nullptr);   // drop: y <- dropout(y), row id = token b*L + l
 int ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, int M, int d, float* y,
            float* xhat, float* rstd, hipStream_t st);
 // part_ws: LN_BWD_MAX_BLOCKS * 2 * d floats
@@ -39,7 +41,10 @@ int reduce_batch(ReduceBatch& rb, hipStream_t st);   // runs and empties the que
 // out_rows[r] of dx (compact -> padded layout)
 int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* add_in,
            const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st,
-           ReduceBatch* defer = nullptr, const int* m_dev = nullptr, const int* out_rows = nullptr);
+           ReduceBatch* defer = nullptr, const int* m_dev = nullptr, const int* out_rows = nullptr,
+           const DropSpec* in_drop = nullptr, const DropSpec* out_drop = nullptr, float* dx_drop = nullptr);
+// in_drop: dy is the gradient of dropout(LN(.)) -- it is masked on read.  out_drop + dx_drop: the LayerNorm input was
+// dropout(h) + residual -- dx (gradient of the sum, for the residual branch) AND dx_drop = dropout-masked dx (gradient of h).
 int pos_grad(const float* dx, int B, int L, int d, float* dpos, hipStream_t st);
 
 // ---- gemm.hip
@@ -65,6 +70,7 @@ struct GemmArgs {
   const float* gamma; const float* beta; float eps;
   float* xhat; float* rstd;      // EPI_BIAS_RES_LN outputs
   const int* m_dev;              // nullable: device-side row count, M = min(M, *m_dev) (compacted token rows)
+  DropSpec drop;                 // EPI_BIAS_RES_LN: t = dropout(acc + bias) + res  (thresh == 0: off)
   const long long* skip; long long skip_base;   // EPI_COUNT_GT: column skip[m] - skip_base of row m is left out (nullable)
   int debug;                     // tuning aid (UR_GEMM_DEBUG): 1 = skip epilogue, 2 = skip K-loop global loads
 };
@@ -98,17 +104,20 @@ long long attn_lse_floats(int B, int H, int L);
 // seq_base[b] + l of qkv / ctx / dqkv for l >= seq_pad[b]; the padded prefix has no rows.  Supported by the MFMA
 // kernels (L <= 64, head dim 4/8/16: attn_compact_supported) and the last-row kernels.
 bool attn_compact_supported(int L, int d, int H);
+// drop (nullable): dropout on the probabilities (row id = (b*H + h)*L + query position, column = key position)
 int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int causal, float* ctx, float* lse,
-             int q_last_only, hipStream_t st, const int* seq_base = nullptr, const int* seq_pad = nullptr);
+             int q_last_only, hipStream_t st, const int* seq_base = nullptr, const int* seq_pad = nullptr,
+             const DropSpec* drop = nullptr);
 long long attn_bwd_ws_floats(int B, int H, int L);
 int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dctx, const float* lse, int B, int L,
              int d, int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st,
-             const int* seq_base = nullptr, const int* seq_pad = nullptr);
+             const int* seq_base = nullptr, const int* seq_pad = nullptr, const DropSpec* drop = nullptr);
 
 int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, int L, int d, int H, float* ctx_last,
-                  float* lse_last, hipStream_t st, const int* seq_base = nullptr, const int* seq_pad = nullptr);
+                  float* lse_last, hipStream_t st, const int* seq_base = nullptr, const int* seq_pad = nullptr,
+                  const DropSpec* drop = nullptr);
 int attn_last_bwd(const float* q_last, const float* qkv, const int* seq, const float* ctx_last, const float* dctx_last,
                   const float* lse_last, int B, int L, int d, int H, float* dq_last, float* dqkv, hipStream_t st,
-                  const int* seq_base = nullptr, const int* seq_pad = nullptr);
+                  const int* seq_base = nullptr, const int* seq_pad = nullptr, const DropSpec* drop = nullptr);
 
 }  // namespace ur

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
                                                            const float4* __restrict__ beta, float eps, int M, int L, int d4,
                                                            float4* __restrict__ y, float4* __restrict__ xhat,
                                                            float* __restrict__ rstd_out, const int* __restrict__ tok,
-                                                           const int* __restrict__ m_dev) {
+                                                           const int* __restrict__ m_dev, DropSpec drop) {
   const int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const float inv_d = 1.0f / (float)(d4 * 4);
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
         h.x = v[k].x * rstd; h.y = v[k].y * rstd; h.z = v[k].z * rstd; h.w = v[k].w * rstd;
         o.x = h.x * gm.x + bt.x; o.y = h.y * gm.y + bt.y; o.z = h.z * gm.z + bt.z; o.w = h.w * gm.w + bt.w;
         xhat[(long long)row * d4 + c] = h;
+        if (drop.thresh) o = drop4(o, mix32((unsigned)full ^ drop.key), (unsigned)(c * 4), drop);
         y[(long long)row * d4 + c] = o;
       }
     }
@@ -126,14 +127,15 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
 
 int embed_ln_fwd(const int* seq, const float* table, const float* pos, const float* gamma, const float* beta,
                  float eps, int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st, const int* tok,
-                 const int* m_dev) {
+                 const int* m_dev, const DropSpec* drop) {
+  const DropSpec ds = drop ? *drop : DropSpec{};
   ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * 3);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(M, groups);
   if (blocks > 4096) blocks = 4096;
 #define GO(T) hipLaunchKernelGGL((embed_ln_fwd_kernel<T>), dim3(blocks), dim3(256), 0, st, seq, (const float4*)table, \
                                  (const float4*)pos, (const float4*)gamma, (const float4*)beta, eps, M, L, d / 4,      \
-                                 (float4*)y, (float4*)xhat, rstd, tok, m_dev)
+                                 (float4*)y, (float4*)xhat, rstd, tok, m_dev, ds)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ 
                                                      const float* __restrict__ rstd, const float4* __restrict__ gamma,
                                                      const float4* add_in, const int* __restrict__ seq, int M, int d4,
                                                      float4* dx_out, float* __restrict__ part, const int* __restrict__ m_dev,
-                                                     const int* __restrict__ out_rows) {
+                                                     const int* __restrict__ out_rows, DropSpec in_drop, DropSpec out_drop,
+                                                     float4* __restrict__ dx_drop) {
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const float inv_d = 1.0f / (float)(d4 * 4);
@@ -238,11 +241,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ 
   for (int row = blockIdx.x * groups + g; row < M; row += gridDim.x * groups) {
     float4 gy[MAXV], h[MAXV];
     float s1 = 0.f, s2 = 0.f;
+    const unsigned rk_in = in_drop.thresh ? drop_rowkey(in_drop, row) : 0u;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int c = t + k * TPR;
       if (c < d4) {
-        const float4 y = dy[(long long)row * d4 + c];
+        float4 y = dy[(long long)row * d4 + c];
+        if (in_drop.thresh) y = drop4(y, rk_in, (unsigned)(c * 4), in_drop);
         h[k] = xhat[(long long)row * d4 + c];
         const float4 gm = gamma[c];
         dg[k].x += y.x * h[k].x; dg[k].y += y.y * h[k].y; dg[k].z += y.z * h[k].z; dg[k].w += y.w * h[k].w;
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ 
     const float m2 = group_sum<TPR>(s2) * inv_d;
     const float r = rstd[row];
     const bool zero = seq != nullptr && seq[row] == 0;
+    const unsigned rk_out = out_drop.thresh ? drop_rowkey(out_drop, row) : 0u;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int c = t + k * TPR;
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ 
         }
         if (zero) o = make_float4(0.f, 0.f, 0.f, 0.f);
         dx_out[(long long)(out_rows ? out_rows[row] : row) * d4 + c] = o;
+        if (out_drop.thresh) dx_drop[(long long)row * d4 + c] = drop4(o, rk_out, (unsigned)(c * 4), out_drop);
       }
     }
   }
@@ -319,15 +326,18 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
 
 int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* add_in,
            const int* seq, int M, int d, float* dx, float* dgamma, float* dbeta, float* part_ws, hipStream_t st,
-           ReduceBatch* defer, const int* m_dev, const int* out_rows) {
+           ReduceBatch* defer, const int* m_dev, const int* out_rows, const DropSpec* in_drop, const DropSpec* out_drop,
+           float* dx_drop) {
   ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * 3);
+  const DropSpec di = in_drop ? *in_drop : DropSpec{}, d_o = out_drop ? *out_drop : DropSpec{};
+  if (d_o.thresh && (!dx_drop || out_rows)) return fail(UR_ERR_ARG, "ln_bwd: out_drop needs dx_drop and no out_rows");
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(M, groups * 4);
   if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
 #define GO(T) hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float4*)dy, (const float4*)xhat, \
                                  rstd, (const float4*)gamma, (const float4*)add_in, seq, M, d / 4, (float4*)dx, part_ws, m_dev, \
-                                 out_rows)
+                                 out_rows, di, d_o, (float4*)dx_drop)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

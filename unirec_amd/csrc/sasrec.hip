@@ -58,6 +58,7 @@ struct LayerWs {
   float *qkv, *lse, *ctx, *a, *ahat, *rstd1, *h1, *y, *yhat, *rstd2;
   float *wqkvT, *woT, *w1T, *w2T;
   float *g_tf, *g_ta, *g_h1, *g_qkv;   // backward: LN-backward outputs (FFN / attention block), d h1, d qkv
+  float *g_tfd, *g_tad;                // hidden dropout on: dropout-masked g_tf / g_ta (what the block's GEMMs consume)
 };
 struct Ws {
   float *x0, *x0hat, *rstd0;
@@ -88,6 +89,8 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
     // backward scratch that the weight-gradient GEMMs read: per layer, written once per backward pass, so those GEMMs
     // can run on the side stream without write-after-read hazards against the activation-gradient chain
     lw.g_tf = take(M * d); lw.g_ta = take(M * d); lw.g_h1 = take(M * I); lw.g_qkv = take(M * 3 * d);
+    lw.g_tfd = lw.g_tf; lw.g_tad = lw.g_ta;
+    if (c.p_hidden > 0.f) { lw.g_tfd = take(M * d); lw.g_tad = take(M * d); }
   }
   w.g_y = take(M * d); w.g_a = take(M * d); w.g_ctx = take(M * d);
   // split-reduction partials: every weight-gradient GEMM / LayerNorm backward of one backward pass keeps its own region
@@ -118,7 +121,20 @@ static int check_cfg(const UrSasrecCfg* c) {
   UR_REQUIRE(c->n_layers >= 1 && c->n_layers <= UR_MAX_LAYERS, UR_ERR_ARG, "sasrec: n_layers=%d", c->n_layers);
   UR_REQUIRE(c->act >= UR_ACT_GELU && c->act <= UR_ACT_SIGMOID, UR_ERR_ARG, "sasrec: act=%d", c->act);
   UR_REQUIRE((long long)c->B * c->L < (1LL << 31), UR_ERR_ARG, "sasrec: B*L too large");
+  UR_REQUIRE(c->p_hidden >= 0.f && c->p_hidden < 1.f && c->p_attn >= 0.f && c->p_attn < 1.f, UR_ERR_ARG,
+             "sasrec: dropout probabilities must be in [0, 1): hidden %g attn %g", (double)c->p_hidden, (double)c->p_attn);
+  UR_REQUIRE(c->p_attn == 0.f || (long long)c->B * c->n_heads * c->L < (1LL << 31), UR_ERR_ARG, "sasrec: B*n_heads*L too large for attention dropout");
   return UR_OK;
+}
+
+// dropout sites of one pass.  Row ids are TOKEN ids b*L + l whatever the row layout (padded, compact, last rows only), so
+// the mask does not depend on skip_padding / last_only.
+enum { DROP_SITE_EMBED = 0, DROP_SITE_ATTN = 1, DROP_SITE_OUT = 2, DROP_SITE_FFN = 3 };
+static DropSpec site_spec(const UrSasrecCfg& c, int layer, int site, const int* rows, int mul = 1, int add = 0) {
+  const float p = site == DROP_SITE_ATTN ? c.p_attn : c.p_hidden;
+  DropSpec s = drop_spec(p, c.drop_seed, c.drop_step, (unsigned)(site == DROP_SITE_EMBED ? 0 : 4 * (layer + 1) + site));
+  s.rows = rows; s.mul = mul; s.add = add;
+  return s;
 }
 
 // dst[b,:] = src[b, L-1, :]
@@ -285,14 +301,17 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
                        w.m_valid);
     UR_LAUNCH_CHECK();
   }
+  const int* tokmap = compact ? w.tok_full : nullptr;   // buffer row -> token id (identity when not compact)
+  const DropSpec d_emb = site_spec(c, 0, DROP_SITE_EMBED, nullptr);
   rc = embed_ln_fwd(item_seq, item_table, pos, dense + lay.off[1], dense + lay.off[2], c.eps, M, c.L, d, w.x0, w.x0hat, w.rstd0, st,
-                    compact ? w.tok_full : nullptr, mv);
+                    tokmap, mv, &d_emb);
   if (rc) return rc;
   const float* x = w.x0;
   for (int i = 0; i < c.n_layers; ++i) {
     const LayerP p = layer_ptrs(dense, lay, i);
     LayerWs& lw = w.layer[i];
     GemmArgs g{};
+    const DropSpec d_attn = site_spec(c, i, DROP_SITE_ATTN, nullptr);
     if (c.last_only && i == c.n_layers - 1) {
       // Final layer, exact last-row specialisation: K,V for every position, everything else for row L-1 only.
       const int B = c.B;
@@ -310,10 +329,11 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       g = GemmArgs{};
       g.A = x_last; g.lda = ld_last; g.W = p.wqkv; g.ldw = d; g.C = w.q_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bqkv;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
-      if ((rc = attn_last_fwd(w.q_last, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st, sbase, spad))) return rc;
+      if ((rc = attn_last_fwd(w.q_last, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st, sbase, spad, &d_attn))) return rc;
       g = GemmArgs{};
       g.A = lw.ctx; g.lda = d; g.W = p.wo; g.ldw = d; g.C = lw.a; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bo;
       g.aux = x_last; g.ldaux = ld_last; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1;
+      g.drop = site_spec(c, i, DROP_SITE_OUT, nullptr, c.L, c.L - 1);   // row b of these [B, .] GEMMs is token (b, L-1)
       if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS_RES_LN, st))) return rc;
       g = GemmArgs{};
       g.A = lw.a; g.lda = d; g.W = p.w1; g.ldw = d; g.C = lw.h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.bias = p.b1;
@@ -321,15 +341,17 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       g = GemmArgs{};
       g.A = lw.h1; g.lda = I; g.W = p.w2; g.ldw = I; g.C = user_emb; g.ldc = d; g.M = B; g.N = d; g.K = I; g.bias = p.b2; g.act = c.act;
       g.aux = lw.a; g.ldaux = d; g.gamma = p.g2; g.beta = p.b2ln; g.eps = c.eps; g.xhat = lw.yhat; g.rstd = lw.rstd2;
+      g.drop = site_spec(c, i, DROP_SITE_FFN, nullptr, c.L, c.L - 1);
       return gemm_nt(g, PRO_ACT, EPI_BIAS_RES_LN, st);
     }
     g.A = x; g.lda = d; g.W = p.wqkv; g.ldw = d; g.C = lw.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d; g.bias = p.bqkv;
     g.m_dev = mv;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
-    if ((rc = attn_fwd(lw.qkv, item_seq, c.B, c.L, d, c.n_heads, c.use_pos, lw.ctx, lw.lse, 0, st, sbase, spad))) return rc;
+    if ((rc = attn_fwd(lw.qkv, item_seq, c.B, c.L, d, c.n_heads, c.use_pos, lw.ctx, lw.lse, 0, st, sbase, spad, &d_attn))) return rc;
     g = GemmArgs{};
     g.A = lw.ctx; g.lda = d; g.W = p.wo; g.ldw = d; g.C = lw.a; g.ldc = d; g.M = M; g.N = d; g.K = d; g.bias = p.bo;
     g.aux = x; g.ldaux = d; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1; g.m_dev = mv;
+    g.drop = site_spec(c, i, DROP_SITE_OUT, tokmap);
     if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS_RES_LN, st))) return rc;
     g = GemmArgs{};
     g.A = lw.a; g.lda = d; g.W = p.w1; g.ldw = d; g.C = lw.h1; g.ldc = I; g.M = M; g.N = I; g.K = d; g.bias = p.b1; g.m_dev = mv;
@@ -337,6 +359,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     g = GemmArgs{};
     g.A = lw.h1; g.lda = I; g.W = p.w2; g.ldw = I; g.C = lw.y; g.ldc = d; g.M = M; g.N = d; g.K = I; g.bias = p.b2; g.act = c.act;
     g.aux = lw.a; g.ldaux = d; g.gamma = p.g2; g.beta = p.b2ln; g.eps = c.eps; g.xhat = lw.yhat; g.rstd = lw.rstd2; g.m_dev = mv;
+    g.drop = site_spec(c, i, DROP_SITE_FFN, tokmap);
     if ((rc = gemm_nt(g, PRO_ACT, EPI_BIAS_RES_LN, st))) return rc;
     x = lw.y;
   }
@@ -444,24 +467,33 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     float* G = dense_grad;
     LayerWs& lw = w.layer[i];
     const float* x_in = (i == 0) ? w.x0 : w.layer[i - 1].y;
+    const int* tokmap = compact ? w.tok_full : nullptr;
+    const DropSpec d_attn = site_spec(c, i, DROP_SITE_ATTN, nullptr);
+    const bool last_rows = c.last_only && i == c.n_layers - 1;
+    const DropSpec d_out = last_rows ? site_spec(c, i, DROP_SITE_OUT, nullptr, c.L, c.L - 1) : site_spec(c, i, DROP_SITE_OUT, tokmap);
+    const DropSpec d_ffn = last_rows ? site_spec(c, i, DROP_SITE_FFN, nullptr, c.L, c.L - 1) : site_spec(c, i, DROP_SITE_FFN, tokmap);
     if (c.last_only && i == c.n_layers - 1) {
       // final layer: only row L-1 carries gradient (d_user_emb); K,V gradients still cover every position
       const int B = c.B;
       GemmArgs g{};
-      if ((rc = ln_bwd(d_user_emb, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, B, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb))) return rc;
-      if ((rc = tn(lw.g_tf, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
-      g.A = lw.g_tf; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.aux = lw.h1; g.ldaux = I; g.act = c.act;
+      if ((rc = ln_bwd(d_user_emb, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, B, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb,
+                       nullptr, nullptr, nullptr, &d_ffn, lw.g_tfd)))
+        return rc;
+      if ((rc = tn(lw.g_tfd, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
+      g.A = lw.g_tfd; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = B; g.N = I; g.K = d; g.aux = lw.h1; g.ldaux = I; g.act = c.act;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
       if ((rc = tn(lw.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
       g = GemmArgs{};   // (the small weight-gradient GEMMs of this layer are forked together, once, below)
       g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = B; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
-      if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, B, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb))) return rc;
-      if ((rc = tn(lw.g_ta, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
+      if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, B, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb,
+                       nullptr, nullptr, nullptr, &d_out, lw.g_tad)))
+        return rc;
+      if ((rc = tn(lw.g_tad, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
       g = GemmArgs{};
-      g.A = lw.g_ta; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
+      g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
-      if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, lw.g_qkv, st, sbase, spad))) return rc;
+      if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, lw.g_qkv, st, sbase, spad, &d_attn))) return rc;
       // dWq from the B last rows, dWk/dWv from all rows
       if ((rc = tn(w.dq_last, d, compact ? w.x_last : x_in + (long long)(c.L - 1) * d, compact ? d : c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
       if ((rc = tn(lw.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4]))) return rc;
@@ -485,10 +517,12 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
       continue;
     }
     // ---- feed-forward block
-    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb, mv))) return rc;
-    if ((rc = tn(lw.g_tf, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
+    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb, mv,
+                     nullptr, nullptr, &d_ffn, lw.g_tfd)))
+      return rc;
+    if ((rc = tn(lw.g_tfd, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
     GemmArgs g{};
-    g.A = lw.g_tf; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = M; g.m_dev = mv; g.N = I; g.K = d;
+    g.A = lw.g_tfd; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = M; g.m_dev = mv; g.N = I; g.K = d;
     g.aux = lw.h1; g.ldaux = I; g.act = c.act;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
     if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
@@ -497,15 +531,17 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
     // ---- attention block
-    if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb, mv))) return rc;
-    if ((rc = tn(lw.g_ta, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
+    if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb, mv,
+                     nullptr, nullptr, &d_out, lw.g_tad)))
+      return rc;
+    if ((rc = tn(lw.g_tad, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
     g = GemmArgs{};
-    g.A = lw.g_ta; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = d;
+    g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
     // fork dWo now: it then runs underneath the attention backward instead of queueing up behind it at the very end of
     // the pass, where the side stream would finish after the main one (one more event, ~30 us off the tail)
     if ((rc = fork())) return rc;
-    if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad))) return rc;
+    if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad, &d_attn))) return rc;
     if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
     if ((rc = fork())) return rc;
     g = GemmArgs{};
@@ -513,9 +549,11 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
     g.aux = lw.g_ta; g.ldaux = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
   }
-  // ---- input block: LN0 backward -> row gradients of E[item_seq] and of the position table
+  // ---- input block: LN0 backward -> row gradients of E[item_seq] and of the position table  (x0 = dropout(LN0(.)): g_y is
+  // masked on read)
+  DropSpec d_emb = site_spec(c, 0, DROP_SITE_EMBED, compact ? w.tok_full : nullptr);
   if ((rc = ln_bwd(w.g_y, w.x0hat, w.rstd0, dense + lay.off[1], nullptr, nullptr, M, d, d_emb_rows, dense_grad + lay.off[1],
-                   dense_grad + lay.off[2], ln_take(), st, &rb, mv, compact ? w.tok_full : nullptr)))
+                   dense_grad + lay.off[2], ln_take(), st, &rb, mv, compact ? w.tok_full : nullptr, &d_emb)))
     return rc;
   // position-table gradient dP[l,:] = sum_b dx[b,l,:] (no padding index: sasrec.py:25): a split reduction over b with
   // partial stride L*d, queued with the others.  Row L of the table is never looked up (dense_grad was zeroed).

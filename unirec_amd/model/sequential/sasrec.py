@@ -17,7 +17,7 @@ from ..base.reco_abc import ParamHolder
 class _SasrecEncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, model, item_seq):
-        cfg = model._cfg(item_seq.shape[0])
+        cfg = model._cfg(item_seq.shape[0], train=True)
         ws = model._workspace(cfg)
         user_emb = ops.sasrec_fwd(cfg, model.item_embedding.weight.data, dense.data, item_seq, ws)
         ctx.model, ctx.cfg, ctx.ws = model, cfg, ws
@@ -39,8 +39,8 @@ class SASRec(BaseRecommender):
         self.n_layers = config["n_layers"]
         self.n_heads = config["n_heads"]
         self.inner_size = config["inner_size"]
-        self.hidden_dropout_prob = config["hidden_dropout_prob"]
-        self.attn_dropout_prob = config["attn_dropout_prob"]
+        self.hidden_dropout_prob = float(config["hidden_dropout_prob"])
+        self.attn_dropout_prob = float(config["attn_dropout_prob"])
         self.hidden_act = config["hidden_act"]
         self.layer_norm_eps = float(config["layer_norm_eps"])
         self.max_seq_len = config["max_seq_len"]
@@ -51,17 +51,25 @@ class SASRec(BaseRecommender):
         super().add_annotation()
         self.annotations.append("SeqRecBase")
 
-    def _cfg(self, B):
+    def _cfg(self, B, train=False):
+        """train=True: dropout on (nn.Dropout semantics: only in training mode), one fresh mask stream per call."""
+        drop = train and self.training and (self.hidden_dropout_prob > 0 or self.attn_dropout_prob > 0)
+        if drop:
+            self._drop_step += 1
         return ops.sasrec_cfg(B, self.max_seq_len, self.hidden_size, self.n_heads, self.inner_size, self.n_layers,
                               self.hidden_act, self.use_pos_emb, self.layer_norm_eps,
                               last_only=int(self.config.get("last_row_only", 1)),
-                              skip_padding=int(self.config.get("skip_padding", 1)))
+                              skip_padding=int(self.config.get("skip_padding", 1)),
+                              p_hidden=self.hidden_dropout_prob if drop else 0.0, p_attn=self.attn_dropout_prob if drop else 0.0,
+                              drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0), drop_step=self._drop_step)
 
     def _workspace(self, cfg):
         key = cfg.B
         ws = self._ws_cache.get(key)
         if ws is None:
-            ws = ops.sasrec_workspace(cfg, self.device)
+            big = ops.sasrec_cfg(cfg.B, cfg.L, cfg.d, cfg.n_heads, cfg.inner, cfg.n_layers, self.hidden_act, cfg.use_pos, cfg.eps,
+                                 p_hidden=self.hidden_dropout_prob)     # the training layout (dropout scratch included) fits both
+            ws = ops.sasrec_workspace(big, self.device)
             self._ws_cache = {key: ws}  # keep one: batch size is fixed in training
         return ws
 
@@ -69,10 +77,8 @@ class SASRec(BaseRecommender):
         if self.hidden_size != self.embedding_size:
             raise ValueError("SASRec adds position embeddings of hidden_size to item embeddings of embedding_size: "
                              "they must be equal (sasrec.py:25,60-66)")
-        if (self.hidden_dropout_prob or self.attn_dropout_prob) and not self.config.get("allow_dropout_ignored", False):
-            self.logger.warning("unirec_amd SASRec runs with dropout 0 (hidden_dropout_prob/attn_dropout_prob ignored); "
-                                "the reference's example and benchmark scripts use 0 as well")
         object.__setattr__(self, "_ws_cache", {})
+        object.__setattr__(self, "_drop_step", 0)
         d, I, L = self.hidden_size, self.inner_size, self.max_seq_len
         offs, total = ops.sasrec_param_layout(self._cfg(1))
         self._alloc_dense(total)
@@ -103,7 +109,7 @@ class SASRec(BaseRecommender):
         item_seq = item_seq.to(torch.int32).contiguous()
         if item_seq.shape[1] != self.max_seq_len:
             raise ValueError(f"item_seq has length {item_seq.shape[1]}, expected max_seq_len={self.max_seq_len}")
-        cfg = self._cfg(item_seq.shape[0])
+        cfg = self._cfg(item_seq.shape[0], train=True)
         ws = self._workspace(cfg)
         return ops.sasrec_fwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, ws), (cfg, ws, item_seq)
 

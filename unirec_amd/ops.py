@@ -45,10 +45,14 @@ def embedding_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------- SASRec
-def sasrec_cfg(B, L, d, n_heads, inner, n_layers, act, use_pos, eps, last_only=1, skip_padding=1) -> UrSasrecCfg:
+def sasrec_cfg(B, L, d, n_heads, inner, n_layers, act, use_pos, eps, last_only=1, skip_padding=1, p_hidden=0.0, p_attn=0.0,
+               drop_seed=0, drop_step=0) -> UrSasrecCfg:
     """last_only=1: exact last-row specialisation of the final layer (only position L-1 reaches the loss).
-    skip_padding=1: padded prefixes get no token rows (exact; applies when L <= 64 and head dim is 4/8/16)."""
-    return UrSasrecCfg(B, L, d, n_heads, inner, n_layers, ACT_IDS[act], int(bool(use_pos)), float(eps), int(last_only), int(skip_padding))
+    skip_padding=1: padded prefixes get no token rows (exact; applies when L <= 64 and head dim is 4/8/16).
+    p_hidden / p_attn: training-time dropout; the mask is a function of (drop_seed, drop_step), the backward must get the
+    same cfg as the forward."""
+    return UrSasrecCfg(B, L, d, n_heads, inner, n_layers, ACT_IDS[act], int(bool(use_pos)), float(eps), int(last_only), int(skip_padding),
+                       float(p_hidden), float(p_attn), int(drop_seed), int(drop_step))
 
 
 def sasrec_param_layout(cfg: UrSasrecCfg):

@@ -92,6 +92,7 @@ class ShardedSasrecStep:
         cfg = dict(model_cfg)
         cfg["n_items"] = 8            # the model object only carries the dense parameters here
         cfg["device"] = str(device)
+        cfg["dropout_seed"] = int(cfg.get("seed", seed) or 0) * 65536 + rank   # independent dropout masks on every rank
         torch.manual_seed(seed)       # identical dense init on every rank
         self.kind = model_cfg.get("model", "SASRec")
         if self.kind not in ("SASRec", "GRU"):
@@ -147,7 +148,7 @@ class ShardedSasrecStep:
         seq_c = idx_a.view(B, L)
         item_c = idx_b[: B * G].view(B, G).contiguous()
         # 4. forward / backward on the compact table (same kernels as the single-GPU path)
-        cfg = m._cfg(B)
+        cfg = m._cfg(B) if self.kind == "GRU" else m._cfg(B, train=True)   # SASRec: training-time dropout as configured
         ws = m._workspace(cfg)
         enc_fwd, enc_bwd = (ops.gru_fwd, ops.gru_bwd) if self.kind == "GRU" else (ops.sasrec_fwd, ops.sasrec_bwd)
         user_emb = enc_fwd(cfg, compact, m.dense_flat.data, seq_c, ws)
