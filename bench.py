@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true", help="sort each batch's ids inside its own step (no side-stream lookahead)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--cpu-baseline-items", type=int, default=1_000_000)
+    ap.add_argument("--dropout", type=float, default=0.0, help="hidden_dropout_prob = attn_dropout_prob (the reference's SASRec.yaml "
+                    "default is 0.5; its example / benchmark scripts and the headline line use 0)")
     return ap.parse_args()
 
 
@@ -62,8 +64,8 @@ def model_config(a, device):
     return dict(model="SASRec", n_users=162_542, n_items=a.n_items, device=device, loss_type=a.loss, embedding_size=a.d,
                 hidden_size=a.d, dropout_prob=0.0, init_method="normal", init_mean=0.0, init_std=0.02, has_user_emb=False,
                 has_user_bias=False, has_item_bias=False, distance_type="dot", tau=1.0, train_file_format="user-item",
-                exp_name="bench", n_layers=a.layers, n_heads=a.heads, inner_size=a.inner, hidden_dropout_prob=0.0,
-                attn_dropout_prob=0.0, hidden_act="swish", layer_norm_eps=1e-10, max_seq_len=a.seq_len, use_position_emb=True)
+                exp_name="bench", n_layers=a.layers, n_heads=a.heads, inner_size=a.inner, hidden_dropout_prob=a.dropout,
+                attn_dropout_prob=a.dropout, seed=2022, hidden_act="swish", layer_norm_eps=1e-10, max_seq_len=a.seq_len, use_position_emb=True)
 
 
 def synth_batches(a, n_items, device, seed, n_batches=8):
@@ -373,7 +375,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"SASRec n_items={a.n_items} d={d} seq_len={L} n_layers={a.layers} n_heads={a.heads} inner={a.inner} "
                                f"act=swish, {a.negatives} uniform negatives, {a.loss} loss, per-GPU batch {B}, ids={a.ids}, "
-                               f"embedding optimizer={a.table_mode} Adam",
+                               f"embedding optimizer={a.table_mode} Adam, dropout={a.dropout:g}",
                    "global_batch": world * B, "seq_len": L, "parallelism": info["parallelism"]},
         "hbm_embedding_GBps_algorithmic": round(ex_per_s * emb_bytes_per_example / 1e9, 2),
         "final_loss": round(final_loss, 6),

@@ -119,6 +119,8 @@ typedef struct UrConvFormerCfg {
   int32_t fast;         /* 1: FASTConvFormer's spectral layer */
   int32_t seq_merge;
   float eps, seq_decay;
+  float p_hidden;       /* hidden_dropout_prob (training; convformer.py:59,97,115): masks as in UrSasrecCfg, 0 = off */
+  int64_t drop_seed, drop_step;
 } UrConvFormerCfg;
 int64_t ur_convformer_param_layout(const UrConvFormerCfg* cfg, int64_t* offsets_out);
 int64_t ur_convformer_workspace_bytes(const UrConvFormerCfg* cfg);

@@ -64,3 +64,13 @@ def sasrec_masks(B, L, d, n_heads, n_layers, p_hidden, p_attn, seed, step):
         m[f"out{i}"] = mask(B * L, d, p_hidden, seed, step, 4 * (i + 1) + 2).reshape(B, L, d)
         m[f"ffn{i}"] = mask(B * L, d, p_hidden, seed, step, 4 * (i + 1) + 3).reshape(B, L, d)
     return m
+
+
+def convformer_masks(B, L, d, n_layers, p_hidden, seed, step):
+    """multipliers of one ConvFormer / FASTConvFormer training forward (csrc/convformer.hip cf_site), keyed as
+    oracle/model_ref.convformer_user_emb(drop=...) expects."""
+    m = {"embed": mask(B * L, d, p_hidden, seed, step, 0).reshape(B, L, d)}
+    for i in range(n_layers):
+        m[f"out{i}"] = mask(B * L, d, p_hidden, seed, step, 4 * (i + 1) + 2).reshape(B, L, d)
+        m[f"ffn{i}"] = mask(B * L, d, p_hidden, seed, step, 4 * (i + 1) + 3).reshape(B, L, d)
+    return m

@@ -250,7 +250,8 @@ def model_forward(P: Params, batch: dict, cfg: dict, reduction: bool = True, col
     elif model == "AttHist":
         user_emb = atthist_user_emb(P, batch["item_seq"])
     elif model in ("ConvFormer", "FASTConvFormer"):
-        user_emb = convformer_user_emb(P, batch["item_seq"], batch.get("item_seq_len"), cfg, fast=model == "FASTConvFormer")
+        user_emb = convformer_user_emb(P, batch["item_seq"], batch.get("item_seq_len"), cfg, fast=model == "FASTConvFormer",
+                                       drop=batch.get("drop_masks"))
     elif model in ("AvgHist", "SVDPlusPlus"):
         dst = "item_dst_embedding.weight" if (model == "SVDPlusPlus" or cfg.get("asymmetric", True)) else "item_embedding.weight"
         user_emb = pooled_user_emb(P, batch["item_seq"], batch["item_seq_len"], float(cfg.get("user_sequence_alpha", 0.5)), dst,
@@ -342,13 +343,18 @@ def atthist_user_emb(P: Params, item_seq: Tensor) -> Tensor:
     return torch.matmul(p.unsqueeze(-1).transpose(-1, -2), z).squeeze(1)
 
 
-def convformer_user_emb(P: Params, item_seq: Tensor, item_seq_len: Optional[Tensor], cfg: dict, fast: bool = False) -> Tensor:
-    """ConvFormer (unirec/model/sequential/convformer.py:52-72, 88-129) and FASTConvFormer (fastconvformer.py:47-62)."""
+def convformer_user_emb(P: Params, item_seq: Tensor, item_seq_len: Optional[Tensor], cfg: dict, fast: bool = False,
+                        drop: Optional[dict] = None) -> Tensor:
+    """ConvFormer (unirec/model/sequential/convformer.py:52-72, 88-129) and FASTConvFormer (fastconvformer.py:47-62).
+    drop: None or the training dropout multipliers {"embed" (:59), "out{i}" (:97 / fastconvformer.py:58), "ffn{i}" (:115)}, each [B,L,d]."""
+    dm = (lambda k: None) if drop is None else (lambda k: torch.as_tensor(drop[k]) if k in drop else None)
     L, eps = cfg["max_seq_len"], float(cfg["layer_norm_eps"])
     K = cfg["conv_size"]
     act = "gelu" if fast else cfg.get("hidden_act", "gelu")
     x = embedding(P["item_embedding.weight"], item_seq.long()) + P["position_embedding.weight"][:L].unsqueeze(0)
     x = layer_norm(x, P["LayerNorm.weight"], P["LayerNorm.bias"], eps)
+    if dm("embed") is not None:
+        x = x * dm("embed")
     for i in range(cfg["n_layers"]):
         pre = f"encoder.{i}."
         if fast:
@@ -366,9 +372,13 @@ def convformer_user_emb(P: Params, item_seq: Tensor, item_seq_len: Optional[Tens
                 xt = torch.cat((torch.zeros(xt.size(0), xt.size(1), pad), xt), dim=2)
             h = torch.nn.functional.conv1d(xt, P[pre + "filterlayer.conv.depthwise_conv.weight"], P[pre + "filterlayer.conv.depthwise_conv.bias"],
                                            groups=x.shape[-1]).transpose(1, 2)
+        if dm(f"out{i}") is not None:
+            h = h * dm(f"out{i}")
         y1 = layer_norm(h + x, P[pre + "filterlayer.LayerNorm.weight"], P[pre + "filterlayer.LayerNorm.bias"], eps)
         hh = activation(linear(y1, P[pre + "intermediate.dense_1.weight"], P[pre + "intermediate.dense_1.bias"]), act)
         hh = linear(hh, P[pre + "intermediate.dense_2.weight"], P[pre + "intermediate.dense_2.bias"])
+        if dm(f"ffn{i}") is not None:
+            hh = hh * dm(f"ffn{i}")
         x = layer_norm(hh + y1, P[pre + "intermediate.LayerNorm.weight"], P[pre + "intermediate.LayerNorm.bias"], eps)
     if cfg.get("seq_merge", False):
         decay = torch.logspace(float(cfg.get("seq_decay", -0.3)), 0, steps=L).unsqueeze(0).unsqueeze(-1)

@@ -145,3 +145,53 @@ def test_mean_of_dropped_forward_is_unbiased_at_the_first_site():
     assert abs(kept / n - 0.5) < 0.01
     err = (acc / n - x0).abs().max() / x0.abs().max()
     assert err < 0.25, float(err)      # 400 Bernoulli(1/2) draws per element: sd of the mean = |x| / 20
+
+
+@pytest.mark.parametrize("model_name", ["ConvFormer", "FASTConvFormer"])
+@pytest.mark.parametrize("padding_mode,seq_merge,K", [("circular", False, 10), ("reflect", True, 4), ("constant", False, 7)])
+def test_convformer_dropout_forward_backward_vs_oracle(model_name, padding_mode, seq_merge, K):
+    """hidden dropout of ConvFormer / FASTConvFormer (convformer.py:59,97,115; fastconvformer.py:58): the embedded input, the
+    mixer output and the feed-forward output, each before its residual LayerNorm."""
+    from oracle import dropout_ref, model_ref
+    from unirec_amd.model.sequential.convformer import ConvFormer
+    from unirec_amd.model.sequential.fastconvformer import FASTConvFormer
+    dev = _dev()
+    d, I, L, B, G, p = 32, 64, 10, 9, 5, 0.4
+    cfg = dict(n_users=10, n_items=3000, device="cuda:0", loss_type="softmax", embedding_size=d, hidden_size=d, dropout_prob=0.0,
+               init_method="normal", init_mean=0.0, init_std=0.05, has_user_emb=False, distance_type="dot", tau=1.0,
+               train_file_format="user-item", exp_name="t", n_layers=2, inner_size=I, hidden_dropout_prob=p, hidden_act="gelu",
+               layer_norm_eps=1e-9, max_seq_len=L, model=model_name, seed=77, conv_size=K, padding_mode=padding_mode, seq_merge=seq_merge,
+               seq_decay=-0.3, init_ratio=0.05)
+    torch.manual_seed(K)
+    m = (ConvFormer if model_name == "ConvFormer" else FASTConvFormer)(cfg)
+    batch = _batch(B, L, G)
+    batch["item_seq_len"] = (batch["item_seq"] > 0).sum(1).to(torch.int64)
+    P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    m.train()
+    loss, scores, ue, _ = m(item_id=batch["item_id"].to(dev), label=batch["label"].to(dev), item_seq=batch["item_seq"].to(dev),
+                            item_seq_len=batch["item_seq_len"].to(dev), return_loss_only=False)
+    assert m._drop_step == 1
+    ob = dict(batch)
+    ob["drop_masks"] = dropout_ref.convformer_masks(B, L, d, 2, p, cfg["seed"], 1)
+    loss_r, scores_r, ue_r, G_r = model_ref.grads_of(P, ob, cfg)
+    np.testing.assert_allclose(ue.detach().cpu().numpy(), ue_r.numpy(), rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(float(loss), float(loss_r), rtol=RTOL)
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k, ref in G_r.items():
+        if k == "item_embedding.weight":
+            got = _dense_table_grad(m, "item_embedding", 3000, d)
+        else:
+            pp = named[k]
+            if not pp.requires_grad:
+                continue
+            off = (pp.data_ptr() - m.dense_flat.data_ptr()) // 4
+            got = m.dense_flat.grad[off:off + pp.numel()].view(pp.shape).cpu().numpy()
+        scale = max(1e-8, float(np.abs(ref.numpy()).max()))
+        np.testing.assert_allclose(got / scale, ref.numpy() / scale, rtol=2e-4, atol=2e-5, err_msg=k)
+    m.sparse_grads.clear()
+    m.eval()
+    with torch.no_grad():
+        e1 = m.forward_user_emb(item_seq=batch["item_seq"].to(dev), item_seq_len=batch["item_seq_len"].to(dev))
+        e2 = m.forward_user_emb(item_seq=batch["item_seq"].to(dev), item_seq_len=batch["item_seq_len"].to(dev))
+    assert torch.equal(e1, e2)      # evaluation: no dropout

@@ -486,6 +486,35 @@ def main():
         save("g17_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch),
              **pack("mask.", masks), **out)
 
+    # ---------------------------------------------------------------- G18 ConvFormer / FASTConvFormer in training mode WITH dropout
+    # (recorded-mask replay as G17; sites convformer.py:59,97,115 and fastconvformer.py:58)
+    r18 = np.random.default_rng(1818)
+    for tag, cls, kw in (("convformer_dropout", ConvFormer, dict(model="ConvFormer", conv_size=5, padding_mode="reflect", seq_merge=True, loss_type="softmax")),
+                         ("fastconvformer_dropout", FASTConvFormer, dict(model="FASTConvFormer", conv_size=6, padding_mode=0, seq_merge=False, loss_type="bpr"))):
+        cfg = base_cfg(**dict(common, **kw))
+        cfg["hidden_dropout_prob"] = 0.4
+        torch.manual_seed(18)
+        m = cls(cfg)
+        m.train()
+        gen = torch.Generator().manual_seed(181818)
+        masks = {}
+
+        def patch(mod, name):
+            def fwd(x, _mod=mod, _name=name):
+                mk = (torch.rand(x.shape, generator=gen) >= _mod.p).float() / (1.0 - _mod.p)
+                masks[_name] = mk.numpy().copy()
+                return x * mk
+            mod.forward = fwd
+        patch(m.dropout, "embed")
+        for i, layer in enumerate(m.encoder):
+            patch(layer.filterlayer.out_dropout, f"out{i}")
+            patch(layer.intermediate.dropout, f"ffn{i}")
+        batch = make_batch(r18, 6, cfg["max_seq_len"], 4, cfg["n_items"], cfg["n_users"])
+        out = run_model(m, batch)
+        assert len(masks) == 1 + 2 * cfg["n_layers"], sorted(masks)
+        save("g18_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch),
+             **pack("mask.", masks), **out)
+
 
 if __name__ == "__main__":
     main()

@@ -30,7 +30,7 @@ class UrSasrecCfg(C.Structure):
 class UrConvFormerCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32), ("inner", C.c_int32), ("n_layers", C.c_int32), ("act", C.c_int32),
                 ("conv_size", C.c_int32), ("padding_mode", C.c_int32), ("fast", C.c_int32), ("seq_merge", C.c_int32),
-                ("eps", C.c_float), ("seq_decay", C.c_float)]
+                ("eps", C.c_float), ("seq_decay", C.c_float), ("p_hidden", C.c_float), ("drop_seed", C.c_int64), ("drop_step", C.c_int64)]
 
 
 class UrAttHistCfg(C.Structure):

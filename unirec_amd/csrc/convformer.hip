@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void cf_mix_ln_fwd_kernel(const float4* __rest
                                                             const float* __restrict__ bias, const float4* __restrict__ gamma,
                                                             const float4* __restrict__ beta, float eps, int B, int L, int K, int d4, int fast,
                                                             int mode, float scale, float4* __restrict__ y, float4* __restrict__ xhat,
-                                                            float* __restrict__ rstd_out) {
+                                                            float* __restrict__ rstd_out, DropSpec drop) {
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int M = B * L, d = d4 * 4;
@@ -95,8 +95,14 @@ __global__ __launch_bounds__(256) void cf_mix_ln_fwd_kernel(const float4* __rest
         const float4 r = x[(long long)row * d4 + c];
         float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!fast) bb = *(const float4*)(bias + c * 4);
-        v[q].x = v[q].x * scale + bb.x + r.x; v[q].y = v[q].y * scale + bb.y + r.y;
-        v[q].z = v[q].z * scale + bb.z + r.z; v[q].w = v[q].w * scale + bb.w + r.w;
+        if (drop.thresh) {   // t = dropout(mix(x)) + x   (convformer.py:97, fastconvformer.py:58)
+          float4 h = make_float4(v[q].x * scale + bb.x, v[q].y * scale + bb.y, v[q].z * scale + bb.z, v[q].w * scale + bb.w);
+          h = drop4(h, mix32((unsigned)row ^ drop.key), (unsigned)(c * 4), drop);
+          v[q] = make_float4(h.x + r.x, h.y + r.y, h.z + r.z, h.w + r.w);
+        } else {
+          v[q].x = v[q].x * scale + bb.x + r.x; v[q].y = v[q].y * scale + bb.y + r.y;
+          v[q].z = v[q].z * scale + bb.z + r.z; v[q].w = v[q].w * scale + bb.w + r.w;
+        }
         s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
       }
     }
@@ -125,9 +131,11 @@ __global__ __launch_bounds__(256) void cf_mix_ln_fwd_kernel(const float4* __rest
   }
 }
 
-// dx[b,j] = dt[b,j] (residual) + scale * sum_{(l,k): src(l,k) = j} w[.,k] dt[b,l]        one lane group per row (b,j)
+// dx[b,j] = dres[b,j] (residual) + scale * sum_{(l,k): src(l,k) = j} w[.,k] dt[b,l]        one lane group per row (b,j)
+// (dt = gradient of the mixer output: the dropout-masked LayerNorm-input gradient; dres = the unmasked one; same buffer without dropout)
 template <int TPR>
-__global__ __launch_bounds__(256) void cf_mix_bwd_x_kernel(const float4* __restrict__ dt, const float* __restrict__ w, int B, int L, int K,
+__global__ __launch_bounds__(256) void cf_mix_bwd_x_kernel(const float4* __restrict__ dt, const float4* __restrict__ dres,
+                                                           const float* __restrict__ w, int B, int L, int K,
                                                            int d4, int fast, int mode, float scale, float4* __restrict__ dx) {
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void cf_mix_bwd_x_kernel(const float4* __restr
     for (int q = 0; q < CF_MAXV; ++q) {
       const int c = t + q * TPR;
       if (c < d4) {
-        const float4 r = dt[(long long)row * d4 + c];
+        const float4 r = dres[(long long)row * d4 + c];
         dx[(long long)row * d4 + c] = make_float4(acc[q].x * scale + r.x, acc[q].y * scale + r.y, acc[q].z * scale + r.z, acc[q].w * scale + r.w);
       }
     }
@@ -231,7 +239,7 @@ struct CfLayerWs {
 struct CfWs {
   float *x0, *x0hat, *rstd0;
   CfLayerWs layer[UR_MAX_LAYERS];
-  float *g_y, *g_t, *g_a, *g_h1, *tn_ws, *ln_part, *mix_part;
+  float *g_y, *g_t, *g_td, *g_a, *g_h1, *tn_ws, *ln_part, *mix_part;   // g_td: dropout-masked g_t (hidden dropout on)
   long long tn_floats, ln_floats, mix_floats, total;
 };
 constexpr int CF_W_SPLITS = 64;
@@ -251,6 +259,7 @@ static CfWs cf_carve(const UrConvFormerCfg& c, float* base) {
     lw.y = take(M * d); lw.yhat = take(M * d); lw.rstd2 = take(M); lw.w1T = take(I * d); lw.w2T = take(I * d);
   }
   w.g_y = take(M * d); w.g_t = take(M * d); w.g_a = take(M * d); w.g_h1 = take(M * I);
+  w.g_td = c.p_hidden > 0.f ? take(M * d) : w.g_t;
   auto r64 = [](long long n) { return (n + 63) & ~63LL; };
   w.tn_floats = c.n_layers * (r64(gemm_tn_ws_floats((int)M, (int)d, (int)I)) + r64(gemm_tn_ws_floats((int)M, (int)I, (int)d)));
   w.tn_ws = take(w.tn_floats);
@@ -262,6 +271,11 @@ static CfWs cf_carve(const UrConvFormerCfg& c, float* base) {
   return w;
 }
 
+// dropout sites (row id = token b*L + l): 0 = embedded input; layer i: 4(i+1)+2 mixer output, 4(i+1)+3 feed-forward output
+static DropSpec cf_site(const UrConvFormerCfg& c, int layer, int site) {
+  return drop_spec(c.p_hidden, c.drop_seed, c.drop_step, (unsigned)(site == 0 ? 0 : 4 * (layer + 1) + site));
+}
+
 static int cf_check(const UrConvFormerCfg* c) {
   UR_REQUIRE(c != nullptr, UR_ERR_ARG, "convformer: null cfg");
   UR_REQUIRE(c->B > 0 && c->L > 0 && (long long)c->B * c->L < (1LL << 31), UR_ERR_ARG, "convformer: B=%d L=%d", c->B, c->L);
@@ -271,6 +285,7 @@ static int cf_check(const UrConvFormerCfg* c) {
   UR_REQUIRE(c->conv_size >= 1 && c->conv_size <= c->L, UR_ERR_ARG, "convformer: conv_size=%d must be in [1, max_seq_len]", c->conv_size);
   UR_REQUIRE(c->padding_mode >= 0 && c->padding_mode <= 2, UR_ERR_ARG, "convformer: padding_mode=%d", c->padding_mode);
   UR_REQUIRE(c->act >= UR_ACT_GELU && c->act <= UR_ACT_SIGMOID, UR_ERR_ARG, "convformer: act=%d", c->act);
+  UR_REQUIRE(c->p_hidden >= 0.f && c->p_hidden < 1.f, UR_ERR_ARG, "convformer: hidden dropout %g not in [0, 1)", (double)c->p_hidden);
   return UR_OK;
 }
 
@@ -313,8 +328,9 @@ extern "C" int ur_convformer_fwd(const UrConvFormerCfg* cfg, const float* item_t
   CfWs w = cf_carve(c, (float*)ws);
   const int M = c.B * c.L, d = c.d, I = c.inner, tpr = cf_tpr(d), groups = 256 / tpr;
   const float scale = c.fast ? 1.0f / sqrtf((float)c.L) : 1.0f;
+  const DropSpec d_emb = cf_site(c, 0, 0);
   if ((rc = embed_ln_fwd(item_seq, item_table, dense + lay.off[0], dense + lay.off[1], dense + lay.off[2], c.eps, M, c.L, d, w.x0, w.x0hat,
-                         w.rstd0, st)))
+                         w.rstd0, st, nullptr, nullptr, &d_emb)))
     return rc;
   const float* x = w.x0;
   for (int i = 0; i < c.n_layers; ++i) {
@@ -324,9 +340,10 @@ extern "C" int ur_convformer_fwd(const UrConvFormerCfg* cfg, const float* item_t
       ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * (c.conv_size + 3));
       int blocks = cdiv(M, groups);
       if (blocks > 8192) blocks = 8192;
+      const DropSpec d_mix = cf_site(c, i, 2);
 #define GO(T) hipLaunchKernelGGL((cf_mix_ln_fwd_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float4*)x, dense + o[0], dense + o[1],      \
                                  (const float4*)(dense + o[2]), (const float4*)(dense + o[3]), c.eps, c.B, c.L, c.conv_size, d / 4, c.fast, \
-                                 c.padding_mode, scale, (float4*)lw.y1, (float4*)lw.y1hat, lw.rstd1)
+                                 c.padding_mode, scale, (float4*)lw.y1, (float4*)lw.y1hat, lw.rstd1, d_mix)
       CF_TPR_SWITCH(tpr, GO)
 #undef GO
       UR_LAUNCH_CHECK();
@@ -337,6 +354,7 @@ extern "C" int ur_convformer_fwd(const UrConvFormerCfg* cfg, const float* item_t
     g = GemmArgs{};
     g.A = lw.h1; g.lda = I; g.W = dense + o[6]; g.ldw = I; g.C = lw.y; g.ldc = d; g.M = M; g.N = d; g.K = I; g.bias = dense + o[7]; g.act = c.act;
     g.aux = lw.y1; g.ldaux = d; g.gamma = dense + o[8]; g.beta = dense + o[9]; g.eps = c.eps; g.xhat = lw.yhat; g.rstd = lw.rstd2;
+    g.drop = cf_site(c, i, 3);
     if ((rc = gemm_nt(g, PRO_ACT, EPI_BIAS_RES_LN, st))) return rc;
     x = lw.y;
   }
@@ -391,24 +409,29 @@ extern "C" int ur_convformer_bwd(const UrConvFormerCfg* cfg, const float* item_t
     float* G = dense_grad;
     const float* x_in = (i == 0) ? w.x0 : w.layer[i - 1].y;
     // ---- feed-forward block (as sasrec.hip)
-    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, dense + o[8], nullptr, nullptr, M, d, w.g_t, G + o[8], G + o[9], ln_take(), st, &rb))) return rc;
-    if ((rc = gemm_tn(w.g_t, d, lw.h1, I, M, d, I, 1, c.act, G + o[6], I, G + o[7], tn_take(M, d, I), st, &rb))) return rc;
+    const DropSpec d_ffn = cf_site(c, i, 3), d_mix = cf_site(c, i, 2);
+    if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, dense + o[8], nullptr, nullptr, M, d, w.g_t, G + o[8], G + o[9], ln_take(), st, &rb, nullptr,
+                     nullptr, nullptr, &d_ffn, w.g_td)))
+      return rc;
+    if ((rc = gemm_tn(w.g_td, d, lw.h1, I, M, d, I, 1, c.act, G + o[6], I, G + o[7], tn_take(M, d, I), st, &rb))) return rc;
     GemmArgs g{};
-    g.A = w.g_t; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = w.g_h1; g.ldc = I; g.M = M; g.N = I; g.K = d; g.aux = lw.h1; g.ldaux = I; g.act = c.act;
+    g.A = w.g_td; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = w.g_h1; g.ldc = I; g.M = M; g.N = I; g.K = d; g.aux = lw.h1; g.ldaux = I; g.act = c.act;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
     if ((rc = gemm_tn(w.g_h1, I, lw.y1, d, M, I, d, 0, 0, G + o[4], d, G + o[5], tn_take(M, I, d), st, &rb))) return rc;
     g = GemmArgs{};
     g.A = w.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.N = d; g.K = I; g.aux = w.g_t; g.ldaux = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
     // ---- mixer block: LayerNorm backward -> d t, then the three gradients of t = mix(x) + x
-    if ((rc = ln_bwd(w.g_a, lw.y1hat, lw.rstd1, dense + o[2], nullptr, nullptr, M, d, w.g_t, G + o[2], G + o[3], ln_take(), st, &rb))) return rc;
+    if ((rc = ln_bwd(w.g_a, lw.y1hat, lw.rstd1, dense + o[2], nullptr, nullptr, M, d, w.g_t, G + o[2], G + o[3], ln_take(), st, &rb, nullptr,
+                     nullptr, nullptr, &d_mix, w.g_td)))
+      return rc;
     {
       ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * (2 * K + 2));
       const int sps = cdiv(c.B, CF_W_SPLITS), S = cdiv(c.B, sps);
       float* part_w = mix_cur;
       float* part_b = mix_cur + (long long)S * d * K;
       mix_cur += (long long)CF_W_SPLITS * (d * K + d);
-      hipLaunchKernelGGL(cf_mix_bwd_w_kernel, dim3(K, S), dim3(d < 256 ? ((d + 63) / 64) * 64 : 256), 0, st, w.g_t, x_in, c.B, c.L, K, d, c.fast,
+      hipLaunchKernelGGL(cf_mix_bwd_w_kernel, dim3(K, S), dim3(d < 256 ? ((d + 63) / 64) * 64 : 256), 0, st, w.g_td, x_in, c.B, c.L, K, d, c.fast,
                          c.padding_mode, scale, sps, part_w, c.fast ? nullptr : part_b);
       UR_LAUNCH_CHECK();
       if (rb.full(2) && (rc = reduce_batch(rb, st))) return rc;
@@ -416,15 +439,16 @@ extern "C" int ur_convformer_bwd(const UrConvFormerCfg* cfg, const float* item_t
       if (!c.fast) rb.add(part_b, d, S, d, d, G + o[1], d);
       int blocks = cdiv(M, groups);
       if (blocks > 8192) blocks = 8192;
-#define GO(T) hipLaunchKernelGGL((cf_mix_bwd_x_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float4*)w.g_t, dense + o[0], c.B, c.L, K, d / 4, \
+#define GO(T) hipLaunchKernelGGL((cf_mix_bwd_x_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float4*)w.g_td, (const float4*)w.g_t, dense + o[0], c.B, c.L, K, d / 4, \
                                  c.fast, c.padding_mode, scale, (float4*)w.g_y)
       CF_TPR_SWITCH(tpr, GO)
 #undef GO
       UR_LAUNCH_CHECK();
     }
   }
+  const DropSpec d_emb = cf_site(c, 0, 0);
   if ((rc = ln_bwd(w.g_y, w.x0hat, w.rstd0, dense + lay.off[1], nullptr, nullptr, M, d, d_emb_rows, dense_grad + lay.off[1],
-                   dense_grad + lay.off[2], ln_take(), st, &rb)))
+                   dense_grad + lay.off[2], ln_take(), st, &rb, nullptr, nullptr, &d_emb)))
     return rc;
   if (rb.full(1) && (rc = reduce_batch(rb, st))) return rc;
   rb.add(d_emb_rows, (long long)c.L * d, c.B, (long long)c.L * d, c.L * d, dense_grad + lay.off[0], c.L * d);   // dP[l] = sum_b dx[b,l]

@@ -12,7 +12,7 @@ from ..base.reco_abc import ParamHolder
 class _ConvFormerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, model, item_seq, item_seq_len):
-        cfg = model._cfg(item_seq.shape[0])
+        cfg = model._cfg(item_seq.shape[0], train=True)
         ws = model._workspace(cfg)
         out = ops.convformer_fwd(cfg, model.item_embedding.weight.data, dense.data, item_seq, item_seq_len, ws)
         ctx.model, ctx.cfg, ctx.ws = model, cfg, ws
@@ -39,6 +39,7 @@ class ConvFormer(BaseRecommender):
         self.inner_size = config["inner_size"]
         self.hidden_act = config.get("hidden_act", "gelu")
         self.layer_norm_eps = float(config["layer_norm_eps"])
+        self.hidden_dropout_prob = float(config.get("hidden_dropout_prob", 0.0))
         self.max_seq_len = config["max_seq_len"]
         self.seq_decay = float(config.get("seq_decay", -0.3))
         self.seq_merge = bool(config.get("seq_merge", False))
@@ -58,14 +59,20 @@ class ConvFormer(BaseRecommender):
     def _padding_mode(self):
         return self.padding_mode
 
-    def _cfg(self, B):
+    def _cfg(self, B, train=False, p_hidden=None):
+        """train=True: hidden dropout on when the module is in training mode (nn.Dropout semantics), a fresh mask stream per call."""
+        drop = train and self.training and self.hidden_dropout_prob > 0
+        if drop:
+            self._drop_step += 1
+        p = p_hidden if p_hidden is not None else (self.hidden_dropout_prob if drop else 0.0)
         return ops.convformer_cfg(B, self.max_seq_len, self.hidden_size, self.inner_size, self.n_layers, self._act(), self.conv_size,
-                                  self._padding_mode(), self.FAST, self.seq_merge, self.layer_norm_eps, self.seq_decay)
+                                  self._padding_mode(), self.FAST, self.seq_merge, self.layer_norm_eps, self.seq_decay, p_hidden=p,
+                                  drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0), drop_step=self._drop_step)
 
     def _workspace(self, cfg):
         ws = self._ws_cache.get(cfg.B)
         if ws is None:
-            ws = ops.convformer_workspace(cfg, self.device)
+            ws = ops.convformer_workspace(self._cfg(cfg.B, p_hidden=self.hidden_dropout_prob), self.device)   # the training layout fits both
             self._ws_cache = {cfg.B: ws}
         return ws
 
@@ -83,6 +90,7 @@ class ConvFormer(BaseRecommender):
         if self.hidden_size != self.embedding_size:
             raise ValueError("ConvFormer adds position embeddings of hidden_size to item embeddings of embedding_size: they must be equal")
         object.__setattr__(self, "_ws_cache", {})
+        object.__setattr__(self, "_drop_step", 0)
         d, I, L, K = self.hidden_size, self.inner_size, self.max_seq_len, self.conv_size
         offs, total = ops.convformer_param_layout(self._cfg(1))
         self._alloc_dense(total)
@@ -113,7 +121,7 @@ class ConvFormer(BaseRecommender):
 
     def _encode_train(self, user_id, item_seq, item_seq_len=None):
         item_seq, item_seq_len = self._prep(item_seq, item_seq_len)
-        cfg = self._cfg(item_seq.shape[0])
+        cfg = self._cfg(item_seq.shape[0], train=True)
         ws = self._workspace(cfg)
         out = ops.convformer_fwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, item_seq_len, ws)
         return out, (cfg, ws, item_seq, item_seq_len)

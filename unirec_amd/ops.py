@@ -423,10 +423,11 @@ def atthist_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws):
 PADDING_MODES = {"circular": 0, "reflect": 1, "constant": 2}
 
 
-def convformer_cfg(B, L, d, inner, n_layers, act, conv_size, padding_mode, fast, seq_merge, eps, seq_decay):
+def convformer_cfg(B, L, d, inner, n_layers, act, conv_size, padding_mode, fast, seq_merge, eps, seq_decay, p_hidden=0.0, drop_seed=0,
+                   drop_step=0):
     pm = PADDING_MODES[padding_mode] if isinstance(padding_mode, str) else int(padding_mode)
     return _lib.UrConvFormerCfg(B, L, d, inner, n_layers, ACT_IDS[act], conv_size, pm, int(bool(fast)), int(bool(seq_merge)), float(eps),
-                                float(seq_decay))
+                                float(seq_decay), float(p_hidden), int(drop_seed), int(drop_step))
 
 
 def convformer_param_layout(cfg):
