@@ -141,6 +141,10 @@ int ur_convformer_bwd(const UrConvFormerCfg* cfg, const float* item_table, int64
 typedef struct UrAttHistCfg {
   int32_t B, L;
   int32_t d; /* embedding_size, % 4 == 0, <= 512 */
+  /* training-time dropout on the pooled output (modules.py:231,242; config dropout_prob), 0 = off; masks as in UrSasrecCfg,
+   * row id = b */
+  float p_drop;
+  int64_t drop_seed, drop_step;
 } UrAttHistCfg;
 int64_t ur_atthist_param_layout(const UrAttHistCfg* cfg, int64_t* offsets_out);
 int64_t ur_atthist_workspace_bytes(const UrAttHistCfg* cfg);
@@ -177,6 +181,10 @@ typedef struct UrGruCfg {
   int32_t B, L;
   int32_t d; /* embedding_size, % 4 == 0 */
   int32_t H; /* hidden_size, % 4 == 0 */
+  /* training-time dropout on the gathered embeddings (gru.py:17,29; config dropout_prob), 0 = off.  Masks as in UrSasrecCfg
+   * (counter-based hash, same (drop_seed, drop_step) for the backward); row id of element (b, t, :) is t*B + b. */
+  float p_drop;
+  int64_t drop_seed, drop_step;
 } UrGruCfg;
 int64_t ur_gru_param_layout(const UrGruCfg* cfg, int64_t* offsets_out);
 int64_t ur_gru_workspace_bytes(const UrGruCfg* cfg);

@@ -74,3 +74,12 @@ def convformer_masks(B, L, d, n_layers, p_hidden, seed, step):
         m[f"out{i}"] = mask(B * L, d, p_hidden, seed, step, 4 * (i + 1) + 2).reshape(B, L, d)
         m[f"ffn{i}"] = mask(B * L, d, p_hidden, seed, step, 4 * (i + 1) + 3).reshape(B, L, d)
     return m
+
+
+def gru_masks(B, L, d, p, seed, step):
+    """GRU embedding dropout (csrc/gru.hip): the device rows are time-major, row id of (b, t) = t*B + b."""
+    return {"embed": np.ascontiguousarray(mask(L * B, d, p, seed, step, 0).reshape(L, B, d).transpose(1, 0, 2))}
+
+
+def atthist_masks(B, d, p, seed, step):
+    return {"out": mask(B, d, p, seed, step, 0)}

@@ -134,7 +134,7 @@ def sasrec_user_emb(P: Params, item_seq: Tensor, cfg: dict, collect: Optional[di
 
 
 # ----------------------------------------------------------------------------- GRU
-def gru_user_emb(P: Params, item_seq: Tensor, cfg: dict, collect: Optional[dict] = None) -> Tensor:
+def gru_user_emb(P: Params, item_seq: Tensor, cfg: dict, collect: Optional[dict] = None, drop: Optional[dict] = None) -> Tensor:
     """unirec/model/sequential/gru.py:27-35.  torch.nn.GRU (1 layer, batch_first, h0=0) restated
     with the published gate equations (gate order r,z,n in weight_ih_l0/weight_hh_l0 rows):
 
@@ -144,6 +144,8 @@ def gru_user_emb(P: Params, item_seq: Tensor, cfg: dict, collect: Optional[dict]
         h' = (1 - z) * n + z * h
     All L steps run, including the left padding (zero vectors)."""
     x = embedding(P["item_embedding.weight"], item_seq)  # [B,L,d]
+    if drop is not None:
+        x = x * torch.as_tensor(drop["embed"])           # emb_dropout (gru.py:29), multipliers [B,L,d]
     w_ih, w_hh = P["gru_layers.weight_ih_l0"], P["gru_layers.weight_hh_l0"]
     b_ih, b_hh = P["gru_layers.bias_ih_l0"], P["gru_layers.bias_hh_l0"]
     H = w_hh.shape[1]
@@ -244,11 +246,11 @@ def model_forward(P: Params, batch: dict, cfg: dict, reduction: bool = True, col
     if model == "SASRec":
         user_emb = sasrec_user_emb(P, batch["item_seq"], cfg, collect, drop=batch.get("drop_masks"))
     elif model == "GRU":
-        user_emb = gru_user_emb(P, batch["item_seq"], cfg, collect)
+        user_emb = gru_user_emb(P, batch["item_seq"], cfg, collect, drop=batch.get("drop_masks"))
     elif model == "MF":
         user_emb = mf_user_emb(P, batch["user_id"])
     elif model == "AttHist":
-        user_emb = atthist_user_emb(P, batch["item_seq"])
+        user_emb = atthist_user_emb(P, batch["item_seq"], drop=batch.get("drop_masks"))
     elif model in ("ConvFormer", "FASTConvFormer"):
         user_emb = convformer_user_emb(P, batch["item_seq"], batch.get("item_seq_len"), cfg, fast=model == "FASTConvFormer",
                                        drop=batch.get("drop_masks"))
@@ -335,12 +337,15 @@ def pooled_user_emb(P: Params, item_seq: Tensor, item_seq_len: Tensor, alpha: fl
     return out
 
 
-def atthist_user_emb(P: Params, item_seq: Tensor) -> Tensor:
+def atthist_user_emb(P: Params, item_seq: Tensor, drop: Optional[dict] = None) -> Tensor:
     """AttHist (unirec/model/sequential/atthist.py:17-23) = AttentionMergeLayer (unirec/model/modules.py:236-244) on the
     gathered history: z = E[seq] W^T + b; p = softmax_l(z . h) (no mask); sum_l p_l z_l."""
     z = linear(embedding(P["item_embedding.weight"], item_seq.long()), P["attention.dense.weight"], P["attention.dense.bias"])
     p = torch.softmax(torch.matmul(z, P["attention.h"]).squeeze(-1), dim=-1)
-    return torch.matmul(p.unsqueeze(-1).transpose(-1, -2), z).squeeze(1)
+    out = torch.matmul(p.unsqueeze(-1).transpose(-1, -2), z).squeeze(1)
+    if drop is not None:
+        out = out * torch.as_tensor(drop["out"])         # emb_dropout on the pooled vector (modules.py:242), multipliers [B,d]
+    return out
 
 
 def convformer_user_emb(P: Params, item_seq: Tensor, item_seq_len: Optional[Tensor], cfg: dict, fast: bool = False,

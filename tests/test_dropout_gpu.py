@@ -195,3 +195,46 @@ def test_convformer_dropout_forward_backward_vs_oracle(model_name, padding_mode,
         e1 = m.forward_user_emb(item_seq=batch["item_seq"].to(dev), item_seq_len=batch["item_seq_len"].to(dev))
         e2 = m.forward_user_emb(item_seq=batch["item_seq"].to(dev), item_seq_len=batch["item_seq_len"].to(dev))
     assert torch.equal(e1, e2)      # evaluation: no dropout
+
+
+@pytest.mark.parametrize("model_name", ["GRU", "AttHist"])
+def test_gru_and_atthist_dropout_vs_oracle(model_name):
+    """config dropout_prob: GRU drops the gathered embeddings (gru.py:29), AttHist the pooled output (modules.py:242)."""
+    from oracle import dropout_ref, model_ref
+    from unirec_amd.model.sequential.atthist import AttHist
+    from unirec_amd.model.sequential.gru import GRU
+    dev = _dev()
+    d, L, B, G, p = 32, 12, 11, 5, 0.35
+    cfg = dict(n_users=10, n_items=3000, device="cuda:0", loss_type="softmax", embedding_size=d, hidden_size=24 if model_name == "GRU" else d,
+               dropout_prob=p, init_method="normal", init_mean=0.0, init_std=0.05, has_user_emb=False, distance_type="dot", tau=1.0,
+               train_file_format="user-item", exp_name="t", max_seq_len=L, model=model_name, seed=5)
+    torch.manual_seed(3)
+    m = (GRU if model_name == "GRU" else AttHist)(cfg)
+    batch = _batch(B, L, G)
+    P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    m.train()
+    loss, scores, ue, _ = m(item_id=batch["item_id"].to(dev), label=batch["label"].to(dev), item_seq=batch["item_seq"].to(dev),
+                            return_loss_only=False)
+    assert m._drop_step == 1
+    ob = dict(batch)
+    ob["drop_masks"] = dropout_ref.gru_masks(B, L, d, p, 5, 1) if model_name == "GRU" else dropout_ref.atthist_masks(B, d, p, 5, 1)
+    loss_r, scores_r, ue_r, G_r = model_ref.grads_of(P, ob, cfg)
+    np.testing.assert_allclose(ue.detach().cpu().numpy(), ue_r.numpy(), rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(float(loss), float(loss_r), rtol=RTOL)
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k, ref in G_r.items():
+        if k == "item_embedding.weight":
+            got = _dense_table_grad(m, "item_embedding", 3000, d)
+        else:
+            pp = named[k]
+            off = (pp.data_ptr() - m.dense_flat.data_ptr()) // 4
+            got = m.dense_flat.grad[off:off + pp.numel()].view(pp.shape).cpu().numpy()
+        scale = max(1e-8, float(np.abs(ref.numpy()).max()))
+        np.testing.assert_allclose(got / scale, ref.numpy() / scale, rtol=2e-4, atol=2e-5, err_msg=k)
+    m.sparse_grads.clear()
+    m.eval()
+    with torch.no_grad():
+        e1 = m.forward_user_emb(item_seq=batch["item_seq"].to(dev))
+    ob.pop("drop_masks")
+    np.testing.assert_allclose(e1.cpu().numpy(), model_ref.grads_of(P, ob, cfg)[2].numpy(), rtol=RTOL, atol=1e-5)   # evaluation: none

@@ -116,7 +116,7 @@ def test_trainer_one_vs_all_matches_oracle():
     from unirec_amd.utils.general import get_class_instance, init_seed
     rng = np.random.default_rng(8)
     n_users, n_items, L = 60, 2000, 12
-    cfg = parse_arguments(dict(model="SASRec", n_users=n_users, n_items=n_items, device="cuda:0", loss_type="softmax", embedding_size=32,
+    cfg = parse_arguments(dict(hidden_dropout_prob=0.0, attn_dropout_prob=0.0, model="SASRec", n_users=n_users, n_items=n_items, device="cuda:0", loss_type="softmax", embedding_size=32,
                                hidden_size=32, inner_size=64, n_heads=4, max_seq_len=L, epochs=0, batch_size=64, seed=5))
     init_seed(5)
     model = get_class_instance("SASRec", "unirec_amd/model")(cfg)

@@ -340,7 +340,7 @@ def test_skip_padding_forward_is_bit_identical(last_row_only, B, L, d, heads, la
     label[:, 0] = 1
     outs = []
     for sp in (0, 1):
-        cfg = parse_arguments(dict(model="SASRec", n_users=10, n_items=900, device="cuda:0", loss_type="softmax", embedding_size=d,
+        cfg = parse_arguments(dict(hidden_dropout_prob=0.0, attn_dropout_prob=0.0, model="SASRec", n_users=10, n_items=900, device="cuda:0", loss_type="softmax", embedding_size=d,
                                    hidden_size=d, inner_size=2 * d, n_heads=heads, n_layers=layers, max_seq_len=L, seed=3,
                                    last_row_only=last_row_only, skip_padding=sp))
         torch.manual_seed(3)
@@ -406,7 +406,7 @@ def test_fullsoftmax_vs_oracle(model_name, B, N, bias):
     from unirec_amd.utils.general import get_class_instance
     dev = _dev()
     rng = np.random.default_rng(N)
-    cfg = parse_arguments(dict(model=model_name, n_users=50, n_items=N, device="cuda:0", loss_type="fullsoftmax", embedding_size=32,
+    cfg = parse_arguments(dict(hidden_dropout_prob=0.0, attn_dropout_prob=0.0, model=model_name, n_users=50, n_items=N, device="cuda:0", loss_type="fullsoftmax", embedding_size=32,
                                hidden_size=32, inner_size=64, n_heads=4, n_layers=1, max_seq_len=12, seed=2, has_user_emb=model_name == "MF",
                                has_user_bias=bias, has_item_bias=bias, tau=0.6 if bias else 1.0))
     torch.manual_seed(2)

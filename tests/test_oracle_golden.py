@@ -33,7 +33,7 @@ def test_forward_backward_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["g17_sasrec_dropout_bpr", "g17_sasrec_dropout_softmax_nopos", "g18_convformer_dropout",
-                                  "g18_fastconvformer_dropout"])
+                                  "g18_fastconvformer_dropout", "g19_gru_dropout", "g19_atthist_dropout"])
 def test_dropout_placement_and_scaling_match_reference(name):
     """The reference SASRec in training mode with its nn.Dropout modules replaced by recorded Bernoulli/(1-p) multipliers
     (tools/capture_goldens.py G17); the oracle replays the same multipliers at the sites it claims they sit at."""

@@ -515,6 +515,33 @@ def main():
         save("g18_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch),
              **pack("mask.", masks), **out)
 
+    # ---------------------------------------------------------------- G19 GRU / AttHist in training mode WITH dropout_prob
+    # (recorded-mask replay as G17; sites gru.py:29 and modules.py:242)
+    from unirec.model.sequential.atthist import AttHist
+    r19 = np.random.default_rng(1919)
+    for tag, cls, kw, mods in (("gru_dropout", GRU, dict(model="GRU", loss_type="softmax", hidden_size=24), lambda m: {"embed": m.emb_dropout}),
+                               ("atthist_dropout", AttHist, dict(model="AttHist", loss_type="bpr"), lambda m: {"out": m.attention.emb_dropout})):
+        cfg = base_cfg(dropout_prob=0.3, **kw)
+        torch.manual_seed(19)
+        m = cls(cfg)
+        m.train()
+        gen = torch.Generator().manual_seed(191919)
+        masks = {}
+
+        def patch(mod, name):
+            def fwd(x, _mod=mod, _name=name):
+                mk = (torch.rand(x.shape, generator=gen) >= _mod.p).float() / (1.0 - _mod.p)
+                masks[_name] = mk.numpy().copy()
+                return x * mk
+            mod.forward = fwd
+        for name, mod in mods(m).items():
+            patch(mod, name)
+        batch = make_batch(r19, 6, cfg["max_seq_len"], 4, cfg["n_items"], cfg["n_users"])
+        out = run_model(m, batch)
+        assert len(masks) == 1, sorted(masks)
+        save("g19_" + tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch),
+             **pack("mask.", masks), **out)
+
 
 if __name__ == "__main__":
     main()

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--n-users", type=int, default=100_000)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--dropout", type=float, default=0.0, help="hidden / attention dropout (reference yaml default: 0.5)")
     ap.add_argument("--host", action="store_true", help="build rows with the native HOST builder instead")
     a = ap.parse_args()
     rng = np.random.default_rng(0)
@@ -40,7 +41,8 @@ def main():
     pos = items[ptr[users] + (rng.random(n_pairs) * lens[users]).astype(np.int64)]
     pairs = np.stack([users, pos.astype(np.int64)], 1)
     cfg = parse_arguments(dict(model="SASRec", n_users=a.n_users, n_items=a.n_items, device="cuda:0", loss_type="bpr", embedding_size=128,
-                               hidden_size=128, inner_size=512, n_heads=16, n_layers=2, max_seq_len=50, epochs=1, batch_size=a.batch, seed=1))
+                               hidden_size=128, inner_size=512, n_heads=16, n_layers=2, max_seq_len=50, epochs=1, batch_size=a.batch, seed=1,
+                               hidden_dropout_prob=a.dropout, attn_dropout_prob=a.dropout))
     init_seed(1)
     model = get_class_instance("SASRec", "unirec_amd/model")(cfg)
     tr = Trainer(cfg, model)

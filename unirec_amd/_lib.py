@@ -34,7 +34,7 @@ class UrConvFormerCfg(C.Structure):
 
 
 class UrAttHistCfg(C.Structure):
-    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32)]
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32), ("p_drop", C.c_float), ("drop_seed", C.c_int64), ("drop_step", C.c_int64)]
 
 
 class UrLossCfg(C.Structure):
@@ -48,7 +48,8 @@ class UrAdamCfg(C.Structure):
 
 
 class UrGruCfg(C.Structure):
-    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32), ("H", C.c_int32)]
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32), ("H", C.c_int32),
+                ("p_drop", C.c_float), ("drop_seed", C.c_int64), ("drop_step", C.c_int64)]
 
 
 P = C.c_void_p

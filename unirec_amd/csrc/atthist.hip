@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void atthist_merge_bwd_kernel(const float4* __
 }
 
 struct AttHistWs {
-  float *x, *z, *p, *dz, *wT, *dh_part, *tn_ws;
+  float *x, *z, *p, *dz, *wT, *dh_part, *tn_ws, *g_out;
   long long floats;
 };
 static AttHistWs atthist_carve(const UrAttHistCfg& c, float* base) {
@@ -104,6 +104,7 @@ static AttHistWs atthist_carve(const UrAttHistCfg& c, float* base) {
   const long long M = (long long)c.B * c.L, d = c.d;
   w.x = take(M * d); w.z = take(M * d); w.p = take(M); w.dz = take(M * d); w.wT = take(d * d); w.dh_part = take((long long)c.B * d);
   w.tn_ws = take(gemm_tn_ws_floats((int)M, (int)d, (int)d));
+  w.g_out = take((long long)c.B * d);
   w.floats = o;
   return w;
 }
@@ -111,6 +112,7 @@ static int atthist_check(const UrAttHistCfg* c) {
   UR_REQUIRE(c != nullptr, UR_ERR_ARG, "atthist: null cfg");
   UR_REQUIRE(c->B > 0 && c->L > 0 && c->d > 0 && c->d % 4 == 0 && c->d <= 512, UR_ERR_ARG, "atthist: B=%d L=%d d=%d", c->B, c->L, c->d);
   UR_REQUIRE((long long)c->B * c->L < (1LL << 31) && c->L <= 4096, UR_ERR_ARG, "atthist: B*L / L too large");
+  UR_REQUIRE(c->p_drop >= 0.f && c->p_drop < 1.f, UR_ERR_ARG, "atthist: dropout_prob %g not in [0, 1)", (double)c->p_drop);
   return UR_OK;
 }
 
@@ -150,6 +152,7 @@ extern "C" int ur_atthist_fwd(const UrAttHistCfg* cfg, const float* item_table, 
   hipLaunchKernelGGL(atthist_merge_fwd_kernel, dim3(cdiv(c.B, 4)), dim3(256), 4 * c.L * sizeof(float), st, (const float4*)w.z, (const float4*)h,
                      c.B, c.L, d / 4, w.p, (float4*)user_emb);
   UR_LAUNCH_CHECK();
+  if (c.p_drop > 0.f) return drop_rows(user_emb, c.B, d, drop_spec(c.p_drop, c.drop_seed, c.drop_step, 0), user_emb, st);
   return UR_OK;
 }
 
@@ -166,6 +169,10 @@ extern "C" int ur_atthist_bwd(const UrAttHistCfg* cfg, const float* item_table, 
   const int M = c.B * c.L, d = c.d;
   const float *W = dense, *h = dense + (long long)d * d + d;
   float *dW = dense_grad, *db = dense_grad + (long long)d * d, *dh = dense_grad + (long long)d * d + d;
+  if (c.p_drop > 0.f) {   // gradient of the merge output = dropout-masked gradient of user_emb
+    if ((rc = drop_rows(d_user_emb, c.B, d, drop_spec(c.p_drop, c.drop_seed, c.drop_step, 0), w.g_out, st))) return rc;
+    d_user_emb = w.g_out;
+  }
   {
     ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * 3);
     hipLaunchKernelGGL(atthist_merge_bwd_kernel, dim3(cdiv(c.B, 4)), dim3(256), 4 * c.L * sizeof(float), st, (const float4*)w.z, (const float4*)h,

@@ -61,6 +61,7 @@ static int gru_check(const UrGruCfg* c) {
   UR_REQUIRE(c->d > 0 && c->d % 4 == 0 && c->d <= 512, UR_ERR_ARG, "gru: embedding_size d=%d must be a multiple of 4, <= 512", c->d);
   UR_REQUIRE(c->H > 0 && c->H % 4 == 0, UR_ERR_ARG, "gru: hidden_size H=%d must be a multiple of 4", c->H);
   UR_REQUIRE((long long)c->B * c->L < (1LL << 31), UR_ERR_ARG, "gru: B*L too large");
+  UR_REQUIRE(c->p_drop >= 0.f && c->p_drop < 1.f, UR_ERR_ARG, "gru: dropout_prob %g not in [0, 1)", (double)c->p_drop);
   return UR_OK;
 }
 
@@ -155,6 +156,7 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
     UR_LAUNCH_CHECK();
   }
   if ((rc = gather_rows(item_table, w.seq_tm, 4, M, d, w.x, st))) return rc;
+  if (c.p_drop > 0.f && (rc = drop_rows(w.x, M, d, drop_spec(c.p_drop, c.drop_seed, c.drop_step, 0), w.x, st))) return rc;
   GemmArgs g{};
   g.A = w.x; g.lda = d; g.W = dense + lay.w_ih; g.ldw = d; g.C = w.gi; g.ldc = 3 * H; g.M = M; g.N = 3 * H; g.K = d; g.bias = dense + lay.b_ih;
   if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
@@ -216,6 +218,7 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   g = GemmArgs{};   // dx = dgi W_ih
   g.A = w.dgi; g.lda = 3 * H; g.W = w.w_ihT; g.ldw = 3 * H; g.C = w.dx_tm; g.ldc = d; g.M = M; g.N = d; g.K = 3 * H;
   if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
+  if (c.p_drop > 0.f && (rc = drop_rows(w.dx_tm, M, d, drop_spec(c.p_drop, c.drop_seed, c.drop_step, 0), w.dx_tm, st))) return rc;
   ProfScope ps(PC_GRU, st, 0);
   hipLaunchKernelGGL(rows_batch_major_kernel, dim3(cdiv((long long)M * (d / 4), 256)), dim3(256), 0, st, (const float4*)w.dx_tm, B, L, d / 4,
                      (float4*)d_emb_rows);

@@ -14,6 +14,8 @@ int gather_rows(const float* table, const void* idx, int idx_bytes, long long n,
 int embed_ln_fwd(const int* seq, const float* table, const float* pos, const float* gamma, const float* beta, float eps,
                  int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st, const int* tok = nullptr,
                  const int* m_dev = nullptr, const DropSpec* drop = nullptr);   // drop: y <- dropout(y), row id = token b*L + l
+// out[r,:] = dropout(x[r,:]), row id of row r per `drop` (out may alias x; drop off: a copy, or nothing when aliased)
+int drop_rows(const float* x, long long rows, int d, const DropSpec& drop, float* out, hipStream_t st);
 int ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, int M, int d, float* y,
            float* xhat, float* rstd, hipStream_t st);
 // part_ws: LN_BWD_MAX_BLOCKS * 2 * d floats

@@ -147,6 +147,26 @@ int embed_ln_fwd(const int* seq, const float* table, const float* pos, const flo
   return UR_OK;
 }
 
+// ------------------------------------------------------------------------- stand-alone dropout
+// out[r,:] = dropout(x[r,:]) (out may alias x): for the encoders whose dropout sits on a plain tensor (GRU: the gathered
+// embeddings, gru.py:29; AttHist: the pooled output, modules.py:242).  The backward applies the same call to the gradient.
+__global__ __launch_bounds__(256) void drop_rows_kernel(const float4* x, long long rows, int d4, DropSpec drop, float4* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * d4) return;
+  const int r = (int)(i / d4), c = (int)(i % d4);
+  out[i] = drop4(x[i], drop_rowkey(drop, r), (unsigned)(c * 4), drop);
+}
+int drop_rows(const float* x, long long rows, int d, const DropSpec& drop, float* out, hipStream_t st) {
+  if (!drop.thresh) {
+    if (out != x) UR_HIP(hipMemcpyAsync(out, x, (size_t)rows * d * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return UR_OK;
+  }
+  ProfScope ps(PC_ROWOPS, st, (double)rows * d * 4.0 * 2);
+  hipLaunchKernelGGL(drop_rows_kernel, dim3(cdiv(rows * (d / 4), 256)), dim3(256), 0, st, (const float4*)x, rows, d / 4, drop, (float4*)out);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
 // ------------------------------------------------------------------------- residual + LayerNorm fwd
 // y = LN(x + res) (res may be null); fallback for rows wider than the GEMM-fused epilogue supports.
 template <int TPR>

@@ -11,7 +11,7 @@ from ..base.reco_abc import ParamHolder
 class _AttHistFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, model, item_seq):
-        cfg = model._cfg(item_seq.shape[0], item_seq.shape[1])
+        cfg = model._cfg(item_seq.shape[0], item_seq.shape[1], train=True)
         ws = model._workspace(cfg)
         out = ops.atthist_fwd(cfg, model.item_embedding.weight.data, dense.data, item_seq, ws)
         ctx.model, ctx.cfg, ctx.ws = model, cfg, ws
@@ -32,8 +32,15 @@ class AttHist(BaseRecommender):
         super().add_annotation()
         self.annotations.append("SeqRecBase")
 
-    def _cfg(self, B, L):
-        return ops.atthist_cfg(B, L, self.embedding_size)
+    def _cfg(self, B, L, train=False):
+        """train=True: dropout on the pooled output (modules.py:231,242, config dropout_prob) when the module is in training mode."""
+        p = float(self.dropout_prob or 0.0)
+        drop = train and self.training and p > 0
+        if drop:
+            object.__setattr__(self, "_drop_step", getattr(self, "_drop_step", 0) + 1)
+        return ops.atthist_cfg(B, L, self.embedding_size, p_drop=p if drop else 0.0,
+                               drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0),
+                               drop_step=getattr(self, "_drop_step", 0))
 
     def _workspace(self, cfg):
         key = (cfg.B, cfg.L)
@@ -55,7 +62,7 @@ class AttHist(BaseRecommender):
 
     def _encode_train(self, user_id, item_seq, item_seq_len=None):
         item_seq = item_seq.to(torch.int32).contiguous()
-        cfg = self._cfg(*item_seq.shape)
+        cfg = self._cfg(*item_seq.shape, train=True)
         ws = self._workspace(cfg)
         return ops.atthist_fwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, ws), (cfg, ws, item_seq)
 

@@ -13,7 +13,7 @@ from ..base.reco_abc import ParamHolder
 class _GruEncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, model, item_seq):
-        cfg = model._cfg(item_seq.shape[0])
+        cfg = model._cfg(item_seq.shape[0], train=True)
         ws = model._workspace(cfg)
         out = ops.gru_fwd(cfg, model.item_embedding.weight.data, dense.data, item_seq, ws)
         ctx.model, ctx.cfg, ctx.ws = model, cfg, ws
@@ -34,8 +34,15 @@ class GRU(BaseRecommender):
         super().add_annotation()
         self.annotations.append("SeqRecBase")
 
-    def _cfg(self, B):
-        return ops.gru_cfg(B, self.config["max_seq_len"], self.embedding_size, self.hidden_size)
+    def _cfg(self, B, train=False):
+        """train=True: embedding dropout (gru.py:17,29, config dropout_prob) when the module is in training mode."""
+        p = float(self.dropout_prob or 0.0)
+        drop = train and self.training and p > 0
+        if drop:
+            object.__setattr__(self, "_drop_step", getattr(self, "_drop_step", 0) + 1)
+        return ops.gru_cfg(B, self.config["max_seq_len"], self.embedding_size, self.hidden_size, p_drop=p if drop else 0.0,
+                           drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0),
+                           drop_step=getattr(self, "_drop_step", 0))
 
     def _workspace(self, cfg):
         ws = self._ws_cache.get(cfg.B)
@@ -60,7 +67,7 @@ class GRU(BaseRecommender):
 
     def _encode_train(self, user_id, item_seq, item_seq_len=None):
         item_seq = item_seq.to(torch.int32).contiguous()
-        cfg = self._cfg(item_seq.shape[0])
+        cfg = self._cfg(item_seq.shape[0], train=True)
         ws = self._workspace(cfg)
         return ops.gru_fwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, ws), (cfg, ws, item_seq)
 

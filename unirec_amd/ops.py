@@ -88,8 +88,8 @@ def sasrec_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws):
 
 
 # --------------------------------------------------------------------------------------------- GRU
-def gru_cfg(B, L, d, H):
-    return _lib.UrGruCfg(B, L, d, H)
+def gru_cfg(B, L, d, H, p_drop=0.0, drop_seed=0, drop_step=0):
+    return _lib.UrGruCfg(B, L, d, H, float(p_drop), int(drop_seed), int(drop_step))
 
 
 def gru_param_layout(cfg):
@@ -386,8 +386,8 @@ def rows_scatter_add(pl: RowsPlan, rows, dense):
 
 
 # --------------------------------------------------------------------------------------------- AttHist
-def atthist_cfg(B, L, d):
-    return _lib.UrAttHistCfg(B, L, d)
+def atthist_cfg(B, L, d, p_drop=0.0, drop_seed=0, drop_step=0):
+    return _lib.UrAttHistCfg(B, L, d, float(p_drop), int(drop_seed), int(drop_step))
 
 
 def atthist_param_layout(cfg):

@@ -9,10 +9,18 @@ BASE = dict(seed=2022, init_method="normal", init_std=0.02, init_mean=0.0, sched
             train_file_format="user-item", key_metric="hit@5", metrics="['hit@1;5;10', 'ndcg@5;10', 'mrr', 'group_auc']",
             embedding_optimizer="lazy_dense", output_path="./output", verbose=1)
 MODEL = {
-    "SASRec": dict(n_layers=2, n_heads=16, inner_size=512, hidden_dropout_prob=0.0, attn_dropout_prob=0.0, hidden_act="swish",
-                   layer_norm_eps=1e-10),   # reference yaml has dropout 0.5; every example script overrides it with 0
+    # the reference's config/model/*.yaml, value for value
+    "SASRec": dict(n_layers=2, n_heads=16, inner_size=512, hidden_dropout_prob=0.5, attn_dropout_prob=0.5, hidden_act="swish",
+                   layer_norm_eps=1e-10),
     "GRU": dict(embedding_size=64, max_seq_len=10, hidden_size=768),
     "MF": dict(embedding_size=64, has_user_emb=True),
+    "ConvFormer": dict(n_layers=2, conv_size=50, inner_size=256, hidden_dropout_prob=0.5, padding_mode="circular", hidden_act="gelu",
+                       layer_norm_eps=1e-9, seq_decay=-0.3, seq_merge=False, init_ratio=0.005),
+    "FASTConvFormer": dict(n_layers=2, conv_size=50, inner_size=256, hidden_dropout_prob=0.5, padding_mode="constant", hidden_act="gelu",
+                           layer_norm_eps=1e-9, seq_decay=-0.3, seq_merge=False, init_ratio=0.005),
+    "AvgHist": dict(embedding_size=64, asymmetric=True, user_sequence_alpha=0.5, max_seq_len=10),
+    "SVDPlusPlus": dict(embedding_size=64, user_sequence_alpha=0.5, max_seq_len=10, has_user_emb=True),
+    "AttHist": dict(embedding_size=64, max_seq_len=10),
 }
 
 
