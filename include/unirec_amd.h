@@ -264,9 +264,20 @@ int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start, const int3
  * weight_decay is L2 added to the gradient; bias-corrected; denom = sqrt(v)/sqrt(1-b2^t) + eps).
  * grad_scale_dev: optional device float multiplied into every gradient (global-norm clipping,
  * trainer.py:347-348); NULL = 1. */
+/* algo: which torch.optim rule (the reference passes only lr and weight_decay, trainer.py:134-152, so every other
+ * hyper-parameter is torch's default and is what the host fills in):
+ *   UR_OPT_ADAM     Adam(betas 0.9/0.999, eps 1e-8), weight_decay = L2 added to the gradient
+ *   UR_OPT_ADAMW    same moments, decoupled decay w *= 1 - lr*wd
+ *   UR_OPT_SGD      plain SGD (momentum 0); m, v unused
+ *   UR_OPT_ADAGRAD  state_sum in v (eps 1e-10, lr_decay 0); m unused
+ *   UR_OPT_RMSPROP  square_avg in v, alpha in beta2 (0.99), eps 1e-8, momentum 0, not centered; m unused
+ * ('sparse_adam' has no meaning for the reference's dense nn.Embedding gradients -- torch raises; here it selects Adam
+ *  with the row-wise table mode.) */
+enum { UR_OPT_ADAM = 0, UR_OPT_ADAMW = 1, UR_OPT_SGD = 2, UR_OPT_ADAGRAD = 3, UR_OPT_RMSPROP = 4 };
 typedef struct UrAdamCfg {
   float lr, beta1, beta2, eps, weight_decay;
   int32_t step; /* 1-based step count t of THIS update */
+  int32_t algo; /* UR_OPT_* */
 } UrAdamCfg;
 int ur_dense_adam(const UrAdamCfg* cfg, float* param, const float* grad, float* m, float* v, int64_t n,
                   const float* grad_scale_dev, void* stream);

@@ -314,14 +314,46 @@ def adam_step_(P: Params, G: Params, state: dict, lr: float, wd: float = 0.0,
         p.addcdiv_(m, denom, value=-lr / bc1)
 
 
+def optimizer_step_(P: Params, G: Params, state: dict, algo: str, lr: float, wd: float = 0.0) -> None:
+    """The torch.optim rule Trainer._build_optimizer constructs for config['optimizer'] (unirec/facility/trainer.py:134-152; only
+    lr and weight_decay are passed, the rest are torch's defaults), dense over EVERY element, restated from the published
+    update rules:  adam / adamw (betas 0.9, 0.999, eps 1e-8; L2-in-gradient vs decoupled decay), sgd (momentum 0),
+    adagrad (eps 1e-10, lr_decay 0, accumulator 0), rmsprop (alpha 0.99, eps 1e-8, momentum 0, not centered)."""
+    if algo == "adam":
+        return adam_step_(P, G, state, lr, wd)
+    t = state["t"] = state.get("t", 0) + 1
+    for k, w in P.items():
+        g = G[k]
+        st = state.setdefault(k, {"m": torch.zeros_like(w), "v": torch.zeros_like(w)})
+        if algo == "adamw":
+            w.mul_(1.0 - lr * wd)
+            st["m"].mul_(0.9).add_(g, alpha=0.1)
+            st["v"].mul_(0.999).addcmul_(g, g, value=0.001)
+            bc1, bc2 = 1.0 - 0.9 ** t, 1.0 - 0.999 ** t
+            w.addcdiv_(st["m"], (st["v"].sqrt() / math.sqrt(bc2)).add_(1e-8), value=-lr / bc1)
+            continue
+        if wd != 0:
+            g = g + wd * w
+        if algo == "sgd":
+            w.add_(g, alpha=-lr)
+        elif algo == "adagrad":
+            st["v"].addcmul_(g, g, value=1.0)
+            w.addcdiv_(g, st["v"].sqrt().add_(1e-10), value=-lr)
+        elif algo == "rmsprop":
+            st["v"].mul_(0.99).addcmul_(g, g, value=0.01)
+            w.addcdiv_(g, st["v"].sqrt().add_(1e-8), value=-lr)
+        else:
+            raise KeyError(algo)
+
+
 def train_step(P: Params, state: dict, batch: dict, cfg: dict, lr: float = 1e-3, wd: float = 0.0,
-               grad_clip: Optional[float] = None) -> float:
+               grad_clip: Optional[float] = None, algo: str = "adam") -> float:
     """One iteration of the Trainer.fit loop body (unirec/facility/trainer.py:340-349)."""
     loss, _, _, G = grads_of(P, batch, cfg)
     if grad_clip is not None and grad_clip > 0:
         clip_grad_norm_(G, grad_clip)
     with torch.no_grad():
-        adam_step_(P, G, state, lr, wd)
+        optimizer_step_(P, G, state, algo, lr, wd)
     return float(loss)
 
 

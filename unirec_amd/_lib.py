@@ -44,7 +44,7 @@ class UrLossCfg(C.Structure):
 
 class UrAdamCfg(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float), ("step", C.c_int32)]
+                ("weight_decay", C.c_float), ("step", C.c_int32), ("algo", C.c_int32)]
 
 
 class UrGruCfg(C.Structure):

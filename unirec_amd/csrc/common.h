@@ -68,6 +68,45 @@ __device__ __forceinline__ float group_sum_rt(float v, int width) {
   return v;
 }
 
+// ---- optimizer update rules (torch.optim semantics as constructed at unirec/facility/trainer.py:134-152: only lr and
+// weight_decay are passed, everything else is torch's default).  State: m, v (Adam / AdamW), v = state_sum (Adagrad),
+// v = square_avg (RMSprop, alpha carried in b2), none (SGD).
+struct AdamK {
+  float lr, b1, b2, eps, wd;
+  int step, algo;
+};
+// one element, gradient gr (already scaled / clipped); bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t)
+__device__ __forceinline__ void opt_elem(float& w, float& m, float& v, float gr, const AdamK& a, float bc1, float bc2s) {
+  switch (a.algo) {
+    case UR_OPT_ADAMW:      // decoupled decay, then Adam on the raw gradient
+      w *= 1.f - a.lr * a.wd;
+      m = a.b1 * m + (1.f - a.b1) * gr;
+      v = a.b2 * v + (1.f - a.b2) * gr * gr;
+      w -= (a.lr / bc1) * (m / (sqrtf(v) / bc2s + a.eps));
+      break;
+    case UR_OPT_SGD:        // momentum 0
+      gr += a.wd * w;
+      w -= a.lr * gr;
+      break;
+    case UR_OPT_ADAGRAD:    // lr_decay 0, initial accumulator 0
+      gr += a.wd * w;
+      v += gr * gr;
+      w -= a.lr * (gr / (sqrtf(v) + a.eps));
+      break;
+    case UR_OPT_RMSPROP:    // momentum 0, not centered; alpha = b2
+      gr += a.wd * w;
+      v = a.b2 * v + (1.f - a.b2) * gr * gr;
+      w -= a.lr * (gr / (sqrtf(v) + a.eps));
+      break;
+    default:                // Adam: L2 folded into the gradient
+      gr += a.wd * w;
+      m = a.b1 * m + (1.f - a.b1) * gr;
+      v = a.b2 * v + (1.f - a.b2) * gr * gr;
+      w -= (a.lr / bc1) * (m / (sqrtf(v) / bc2s + a.eps));
+      break;
+  }
+}
+
 // ---- dropout (training only).  Inverted dropout on a grid of elements (row id, column): the keep decision is a pure
 // function of (stream key, row id, column) -- nothing is stored, the backward re-evaluates it -- built from the 32-bit
 // integer finaliser `mix32` (xorshift-multiply; the "lowbias32" constants):

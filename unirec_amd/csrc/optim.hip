@@ -22,19 +22,17 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-// torch.optim.Adam single-tensor update (weight_decay folded into the gradient)
+// torch.optim single-tensor update of the flat dense-parameter buffer (rule: opt_elem in common.h)
 __global__ __launch_bounds__(256) void dense_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                         float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                                         float wd, float bc1, float bc2s, const float* __restrict__ scale_dev) {
+                                                         float* __restrict__ v, long long n, AdamK a, float bc1, float bc2s,
+                                                         const float* __restrict__ scale_dev) {
   const float scale = scale_dev ? *scale_dev : 1.0f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float w = p[i];
-    const float gr = g[i] * scale + wd * w;
-    const float mi = b1 * m[i] + (1.f - b1) * gr;
-    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    float w = p[i], mi = m[i], vi = v[i];
+    opt_elem(w, mi, vi, g[i] * scale, a, bc1, bc2s);
     m[i] = mi;
     v[i] = vi;
-    p[i] = w - (lr / bc1) * (mi / (sqrtf(vi) / bc2s + eps));
+    p[i] = w;
   }
 }
 
@@ -78,6 +76,7 @@ extern "C" int ur_dense_adam(const UrAdamCfg* cfg, float* param, const float* gr
                              const float* grad_scale_dev, void* stream) {
   UR_REQUIRE(cfg && param && grad && m && v, UR_ERR_ARG, "ur_dense_adam: null pointer");
   UR_REQUIRE(cfg->step >= 1 && n >= 0, UR_ERR_ARG, "ur_dense_adam: step=%d n=%lld", cfg->step, (long long)n);
+  UR_REQUIRE(cfg->algo >= UR_OPT_ADAM && cfg->algo <= UR_OPT_RMSPROP, UR_ERR_ARG, "ur_dense_adam: algo=%d", cfg->algo);
   if (n == 0) return UR_OK;
   const float bc1 = 1.f - powf(cfg->beta1, (float)cfg->step);
   const float bc2s = sqrtf(1.f - powf(cfg->beta2, (float)cfg->step));
@@ -85,7 +84,7 @@ extern "C" int ur_dense_adam(const UrAdamCfg* cfg, float* param, const float* gr
   if (blocks > 2048) blocks = 2048;
   ProfScope ps(PC_ADAM, as_stream(stream), (double)n * 4.0 * 7);
   hipLaunchKernelGGL(dense_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, m, v, (long long)n,
-                     cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, bc1, bc2s, grad_scale_dev);
+                     AdamK{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo}, bc1, bc2s, grad_scale_dev);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

@@ -426,13 +426,12 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
 }
 
 // ------------------------------------------------------------------------------- row-wise Adam
-struct AdamK {
-  float lr, b1, b2, eps, wd;
-  int step;
-};
-
-// zero-gradient Adam steps t = from+1 .. to applied to one element (reference semantics: dense Adam moves
-// every row every step; here the missed steps are replayed when the row is next needed).
+// zero-gradient optimizer steps t = from+1 .. to applied to one element (reference semantics: the dense torch optimizer
+// moves every row every step; here the missed steps are replayed when the row is next needed).
+//   Adam / AdamW: the momentum keeps moving the weight; replayed exactly for up to LAZY_EXACT_STEPS steps (beyond that the
+//                 update b1^j * m / (...) is below fp32 resolution and only the moments decay, in closed form); with
+//                 weight_decay != 0 every step is replayed.
+//   SGD, Adagrad: a zero gradient is a no-op (weight_decay == 0); RMSprop: only square_avg decays (closed form).
 constexpr int LAZY_EXACT_STEPS = 512;
 // One float4 of (w, m, v).  The per-step scalars (bias corrections) are computed once per step for the 4 elements.
 __device__ __forceinline__ void lazy_replay4(float4& w, float4& m, float4& v, int from, int to, const AdamK& a) {
@@ -440,16 +439,33 @@ __device__ __forceinline__ void lazy_replay4(float4& w, float4& m, float4& v, in
   if (k <= 0) return;
   const bool dead = (m.x == 0.f && m.y == 0.f && m.z == 0.f && m.w == 0.f) && (v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f);
   if (a.wd == 0.f && dead) return;   // never touched (or fully decayed): zero-gradient steps are no-ops
+  if (a.algo >= UR_OPT_SGD) {
+    if (a.wd == 0.f) {
+      if (a.algo == UR_OPT_RMSPROP) {
+        const float f2 = powf(a.b2, (float)k);
+        v.x *= f2; v.y *= f2; v.z *= f2; v.w *= f2;
+      }
+      return;
+    }
+    for (int j = 0; j < k; ++j) {   // weight decay acts on every row every step: replay (cost grows with the gap)
+      opt_elem(w.x, m.x, v.x, 0.f, a, 1.f, 1.f); opt_elem(w.y, m.y, v.y, 0.f, a, 1.f, 1.f);
+      opt_elem(w.z, m.z, v.z, 0.f, a, 1.f, 1.f); opt_elem(w.w, m.w, v.w, 0.f, a, 1.f, 1.f);
+    }
+    return;
+  }
   float b1t = powf(a.b1, (float)from), b2t = powf(a.b2, (float)from);
   const int exact = (a.wd != 0.f) ? k : min(k, LAZY_EXACT_STEPS);
   const float c1m = 1.f - a.b1, c2m = 1.f - a.b2;
+  const bool decoupled = a.algo == UR_OPT_ADAMW;
+  const float shrink = 1.f - a.lr * a.wd;
   for (int j = 0; j < exact; ++j) {
     b1t *= a.b1;
     b2t *= a.b2;
     const float inv_s2 = 1.0f / sqrtf(1.f - b2t), step = a.lr / (1.f - b1t);
 #define UR_LAZY_ELEM(W, M, V)                                   \
     {                                                           \
-      const float gr = a.wd * W;                                \
+      const float gr = decoupled ? 0.f : a.wd * W;              \
+      if (decoupled) W *= shrink;                               \
       M = a.b1 * M + c1m * gr;                                  \
       V = a.b2 * V + c2m * gr * gr;                             \
       W -= step * (M / (sqrtf(V) * inv_s2 + a.eps));            \
@@ -462,14 +478,6 @@ __device__ __forceinline__ void lazy_replay4(float4& w, float4& m, float4& v, in
     m.x *= f1; m.y *= f1; m.z *= f1; m.w *= f1;
     v.x *= f2; v.y *= f2; v.z *= f2; v.w *= f2;
   }
-}
-
-__device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float gr, const AdamK& a, float bc1, float bc2s) {
-  gr += a.wd * w;
-  m = a.b1 * m + (1.f - a.b1) * gr;
-  v = a.b2 * v + (1.f - a.b2) * gr * gr;
-  const float denom = sqrtf(v) / bc2s + a.eps;
-  w -= (a.lr / bc1) * (m / denom);
 }
 
 // MODE 0: update with gradient (catch-up first when last_step != null); MODE 1: catch-up only (to step-1)
@@ -502,10 +510,10 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
         }
         if (MODE == 0) {
           const float4 gr = grad[(long long)u * d4 + c];
-          adam_elem(w.x, m.x, v.x, gr.x * scale, a, bc1, bc2s);
-          adam_elem(w.y, m.y, v.y, gr.y * scale, a, bc1, bc2s);
-          adam_elem(w.z, m.z, v.z, gr.z * scale, a, bc1, bc2s);
-          adam_elem(w.w, m.w, v.w, gr.w * scale, a, bc1, bc2s);
+          opt_elem(w.x, m.x, v.x, gr.x * scale, a, bc1, bc2s);
+          opt_elem(w.y, m.y, v.y, gr.y * scale, a, bc1, bc2s);
+          opt_elem(w.z, m.z, v.z, gr.z * scale, a, bc1, bc2s);
+          opt_elem(w.w, m.w, v.w, gr.w * scale, a, bc1, bc2s);
         }
         table[row * d4 + c] = w;
         mom[row * d4 + c] = m;
@@ -733,7 +741,7 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* grad, int d,
                               const float* scale, hipStream_t st) {
   ProfScope ps(PC_ADAM, st, (double)n_max * d * 4.0 * 7);
-  AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step};
+  AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(n_max, groups);
   if (blocks > 8192) blocks = 8192;
@@ -786,7 +794,7 @@ extern "C" int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, 
   UR_REQUIRE(table && m && v && last_step, UR_ERR_ARG, "ur_lazy_adam_flush: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n >= 0 && row0 >= 0, UR_ERR_ARG, "ur_lazy_adam_flush: d=%d", d);
   if (n == 0) return UR_OK;
-  AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step};
+  AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   long long blocks = (n + groups - 1) / groups;
   if (blocks > 16384) blocks = 16384;

@@ -17,9 +17,17 @@ from .. import ops
 
 
 class SparseDenseAdam:
-    def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, grad_clip=None,
-                 table_mode="lazy_dense"):
+    def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=None, eps=None, grad_clip=None,
+                 table_mode="lazy_dense", algo="adam"):
+        """algo: the torch.optim rule the reference's Trainer._build_optimizer would construct (trainer.py:134-152):
+        adam (default) / adamw / sgd / adagrad / rmsprop; betas / eps None = torch's defaults for that rule."""
         assert table_mode in ("lazy_dense", "rowwise")
+        if algo not in ops.OPT_ALGOS:
+            raise ValueError(f"unknown optimizer rule {algo!r}")
+        d1, d2, de = ops.OPT_DEFAULTS[algo]
+        self.algo = algo
+        betas = (d1, d2) if betas is None else betas
+        eps = de if eps is None else eps
         self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
         self.grad_clip = grad_clip if grad_clip and grad_clip > 0 else None
         self.table_mode = table_mode
@@ -57,7 +65,7 @@ class SparseDenseAdam:
                     tables={k: {kk: vv for kk, vv in v.items() if kk != "w"} for k, v in self.tables.items()})
 
     def _cfg(self, step):
-        return ops.adam_cfg(self.param_groups[0]["lr"], step, self.wd, self.betas[0], self.betas[1], self.eps)
+        return ops.adam_cfg(self.param_groups[0]["lr"], step, self.wd, self.betas[0], self.betas[1], self.eps, algo=self.algo)
 
     # ------------------------------------------------------------------ per-batch plan (before forward)
     def _plan_inputs(self, item_seq, item_id, user_id):

@@ -6,6 +6,7 @@ Same constructor / method names (``Trainer(config, model, accelerator)``, ``fit`
 The loop body (trainer.py:327-357) becomes: plan ids -> forward -> backward -> clip -> step, with the loss kept on
 the device and read back once per epoch instead of two host syncs per step."""
 import logging
+import math
 import os
 import time
 
@@ -68,6 +69,61 @@ class DeviceBatchLoader:
             yield self.builder.build(sel[:, 0].contiguous(), sel[:, 1].contiguous(), with_seq=self.with_seq, step=base + b)
 
 
+class StepLRByScore:
+    """What the reference's 'step' scheduler does: StepLR(step_size=1, gamma=factor) stepped as ``scheduler.step(valid_score)``
+    (trainer.py:156,307).  StepLR.step(epoch) with an explicit argument takes the closed form
+    lr = base_lr * gamma ** (epoch // step_size) -- and the argument is the validation score, so the exponent is
+    floor(valid_score): the learning rate stays at base_lr for every metric below 1."""
+
+    def __init__(self, optimizer, gamma):
+        self.optimizer, self.gamma = optimizer, gamma
+        self.base_lrs = [g["lr"] for g in optimizer.param_groups]
+        self.last_epoch = 0
+
+    def step(self, epoch):
+        self.last_epoch = math.floor(epoch)
+        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = base * self.gamma ** (self.last_epoch // 1)
+
+    def state_dict(self):
+        return {"gamma": self.gamma, "base_lrs": self.base_lrs, "last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.gamma, self.base_lrs, self.last_epoch = sd["gamma"], list(sd["base_lrs"]), sd["last_epoch"]
+
+
+class ReduceLROnPlateauMax:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='max', factor, patience=1, threshold=1e-4 'rel', cooldown=0, min_lr=0,
+    eps=1e-8) as built at trainer.py:158-159."""
+
+    def __init__(self, optimizer, factor, patience=1, threshold=1e-4, min_lr=0.0, eps=1e-8):
+        if factor >= 1.0:
+            raise ValueError("Factor should be < 1.0.")
+        self.optimizer, self.factor, self.patience, self.threshold, self.min_lr, self.eps = optimizer, factor, patience, threshold, min_lr, eps
+        self.best, self.num_bad_epochs, self.last_epoch = -math.inf, 0, 0
+
+    def step(self, metrics):
+        current = float(metrics)
+        self.last_epoch += 1
+        if current > self.best * (self.threshold + 1.0):
+            self.best, self.num_bad_epochs = current, 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            for g in self.optimizer.param_groups:
+                old = float(g["lr"])
+                new = max(old * self.factor, self.min_lr)
+                if old - new > self.eps:
+                    g["lr"] = new
+            self.num_bad_epochs = 0
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, sd):
+        self.__dict__.update(sd)
+
+
 class Trainer(object):
     def __init__(self, config, model, accelerator=None):
         self.config, self.model, self.accelerator = config, model, accelerator
@@ -82,13 +138,35 @@ class Trainer(object):
         self.saved_model_file = os.path.join(self.checkpoint_dir, f"{self.exp_name}.pth")
         gc = config.get("grad_clip_value", None)
         self.grad_clip_value = gc if gc and gc > 0 else None
-        if config.get("optimizer", "adam") != "adam":
-            raise NotImplementedError("only Adam is on the accelerated path (reference default, base.yaml:39)")
-        self.optimizer = SparseDenseAdam(model, lr=self.learning_rate, weight_decay=self.weight_decay, grad_clip=self.grad_clip_value,
-                                         table_mode=config.get("embedding_optimizer", "lazy_dense"))
-        self.scheduler = None
+        self.optimizer = self._build_optimizer(config.get("optimizer", "adam"))
+        self.scheduler = self._build_scheduler(config.get("scheduler", "off"), config.get("scheduler_factor", 0.1))
         self.best_valid_score, self.cur_step, self.start_epoch = None, 1, 0
         self.step_losses = []
+
+    def _build_optimizer(self, opt_type):
+        """Trainer._build_optimizer (unirec/facility/trainer.py:134-152): same names, same fall-back."""
+        table_mode = self.config.get("embedding_optimizer", "lazy_dense")
+        wd = self.weight_decay
+        if opt_type == "sparse_adam":
+            # torch.optim.SparseAdam refuses the dense gradients the reference's nn.Embedding produces; its meaning -- Adam that
+            # only moves the rows a batch touches, no weight decay -- is this backend's row-wise table mode
+            if wd > 0:
+                self.logger.warning("Sparse Adam cannot argument received argument [weight_decay]")
+            opt_type, table_mode, wd = "adam", "rowwise", 0.0
+        elif opt_type not in ("adam", "sgd", "adagrad", "rmsprop", "adamw"):
+            self.logger.warning("Received unrecognized optimizer, set default Adam optimizer")
+            opt_type, wd = "adam", 0.0          # the reference's fall-back drops weight_decay too (trainer.py:151)
+        return SparseDenseAdam(self.model, lr=self.learning_rate, weight_decay=wd, grad_clip=self.grad_clip_value, table_mode=table_mode,
+                               algo=opt_type)
+
+    def _build_scheduler(self, scheduler_type, factor):
+        """Trainer._build_scheduler (trainer.py:154-162); stepped after each validation of epochs > 0 with the validation score
+        (trainer.py:306-307)."""
+        if scheduler_type == "step":
+            return StepLRByScore(self.optimizer, factor)
+        if scheduler_type == "reduce":
+            return ReduceLROnPlateauMax(self.optimizer, factor)
+        return None
 
     def set_user_history(self, user_history):
         self.user_history = user_history
@@ -138,6 +216,9 @@ class Trainer(object):
                 self.logger.info("epoch %d evaluating [%s: %f]", epoch_idx, self.key_metric, score)
                 if self.early_stop and self.cur_step >= self.early_stop:
                     break
+                if self.scheduler and epoch_idx > 0:
+                    self.scheduler.step(score)
+                    self.logger.info("epoch: %d, learning rate: %s", epoch_idx, self.optimizer.param_groups[0]["lr"])
             t0 = time.time()
             losses, it = [], iter(train_data)
             cur = next(it, None)
@@ -227,7 +308,8 @@ class Trainer(object):
         torch.save({"config": {k: v for k, v in (config or self.config).items() if k != "device"}, "cur_epoch": epoch,
                     "cur_step": step, "best_valid_score": self.best_valid_score,
                     "state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
-                    "optimizer": {"t": self.optimizer.t}, "scheduler": None}, filename)
+                    "optimizer": {"t": self.optimizer.t, "algo": self.optimizer.algo, "param_groups": self.optimizer.param_groups},
+                    "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None}, filename)
 
     def load_model(self, model_file):
         ck = torch.load(model_file, map_location="cpu", weights_only=False)

@@ -234,8 +234,17 @@ def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False) -> t
 
 
 # --------------------------------------------------------------------------------------------- optimizer
-def adam_cfg(lr, step, wd=0.0, b1=0.9, b2=0.999, eps=1e-8) -> UrAdamCfg:
-    return UrAdamCfg(float(lr), float(b1), float(b2), float(eps), float(wd), int(step))
+OPT_ALGOS = {"adam": 0, "adamw": 1, "sgd": 2, "adagrad": 3, "rmsprop": 4}
+# torch's defaults for what the reference does not pass (trainer.py:134-152): (beta1, beta2 | alpha, eps)
+OPT_DEFAULTS = {"adam": (0.9, 0.999, 1e-8), "adamw": (0.9, 0.999, 1e-8), "sgd": (0.0, 0.0, 0.0), "adagrad": (0.0, 0.0, 1e-10),
+                "rmsprop": (0.0, 0.99, 1e-8)}
+
+
+def adam_cfg(lr, step, wd=0.0, b1=None, b2=None, eps=None, algo="adam") -> UrAdamCfg:
+    """optimizer-step configuration (`algo`: adam / adamw / sgd / adagrad / rmsprop, torch.optim semantics)"""
+    d1, d2, de = OPT_DEFAULTS[algo]
+    return UrAdamCfg(float(lr), float(d1 if b1 is None else b1), float(d2 if b2 is None else b2), float(de if eps is None else eps),
+                     float(wd), int(step), OPT_ALGOS[algo])
 
 
 def dense_adam(cfg, param, grad, m, v, grad_scale=None):
