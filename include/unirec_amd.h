@@ -375,6 +375,23 @@ int ur_full_rank(const float* user_emb, const float* item_table, int64_t n_items
                  int64_t n_users, const float* user_bias, const float* item_bias, float tau, int32_t* rank,
                  float* target_score, float* thr_ws, void* stream);
 
+/* The same count over a ROW-SHARDED catalogue ("full-item eval shards the [B,N] score matmul by the same
+ * row ownership"): item i lives on rank i % W at local row i / W + 1, local row 0 is each shard's padding row.  Every rank holds
+ * the user vectors of ALL ranks (all-gather) and runs, on its own shard,
+ *   phase 1: thr[b] = u_b . E_local[local_target[b]] + item_bias_local[...]   (0 when local_target[b] < 0: not this rank's row)
+ *            -> all-reduce(sum) of thr: every rank now holds the target scores, each produced by the MFMA sequence of the shard
+ *               that owns the target, so phase 2 on that shard never counts the target itself;
+ *   phase 2: rank_partial[b] = #{ local rows n >= 1, n != local_target[b], n not in local history(user_b) : s(b,n) > thr[b] }
+ *            -> all-reduce(sum) of rank_partial = the rank over the whole catalogue.
+ * hist_sorted_local: the users' histories restricted to this rank's items, in LOCAL row ids, ascending (CSR hist_ptr).
+ * n_local: rows to scan = this rank's last valid local row + 1 (allocated rows beyond it are ignored); excl_row: one more
+ * local row that is not an item and must not count (rank 0's local row 1, the slot global id 0 would take), or -1.
+ * No collective inside: the two all-reduces are the caller's (torch.distributed over RCCL). */
+int ur_full_rank_shard(int32_t phase, const float* user_emb, const float* shard_table, int64_t n_local, int32_t B, int32_t d,
+                       const int64_t* local_target, const int64_t* user_id, const int64_t* hist_ptr,
+                       const int32_t* hist_sorted_local, int64_t n_users, const float* item_bias_local, int64_t excl_row,
+                       float* thr, int32_t* rank_partial, void* stream);
+
 /* Full-item top-k retrieval -- BaseRecommender.topk with candidates=None (unirec/model/base/recommender.py:149-197:
  * scores of all items, all_scores[row, user_hist] = -inf, torch.topk) and the scoring loop of main/reco_topk.py:22-96.
  *   topk_scores[b, :], topk_ids[b, :] = the k best items of row b by s(b,n) = (u_b . E_n + user_bias + item_bias[n]) / tau,

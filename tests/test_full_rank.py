@@ -228,3 +228,47 @@ def test_gpu_topk_matches_oracle(N, d, B, k, bias):
             assert all(abs(s64[b, n] - cut) < 2e-6 for n in odd), (b, odd)
         h = rows[b]
         assert 0 not in got and (h is None or not (got & set(np.asarray(h).tolist())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,W,with_bias", [(64, 2, False), (64, 3, True), (160, 2, True), (128, 4, False)])
+def test_sharded_two_phase_count_equals_the_whole_catalogue(d, W, with_bias):
+    """ur_full_rank_shard (SURVEY.md 8e): W shards of a row-sharded table (item i -> shard i % W, local row i // W + 1), the two
+    phases run shard by shard in ONE process and the all-reduces replaced by sums == ur_full_rank on the whole table (exact)."""
+    from unirec_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(d + W)
+    N, B, n_users = 2777, 37, 20
+    table = torch.randn(N, d, generator=g) * 0.3
+    table[0] = 0
+    bias = (torch.randn(N, generator=g) * 0.1) if with_bias else None
+    ue = torch.randn(B, d, generator=g)
+    tgt = torch.randint(1, N, (B,), generator=g)
+    uid = torch.randint(0, n_users + 2, (B,), generator=g)
+    lens = torch.randint(0, 60, (n_users,), generator=g)
+    hp = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)])
+    raw = torch.randint(1, N, (int(lens.sum()),), generator=g, dtype=torch.int32)
+    hs = torch.cat([raw[int(hp[u]):int(hp[u + 1])].sort().values for u in range(n_users)])
+    want, _ = ops.full_rank(ue.to(dev), table.to(dev), tgt.to(dev), user_id=uid.to(dev), hist_ptr=hp.to(dev), hist_sorted=hs.to(dev),
+                            item_bias=bias.to(dev) if with_bias else None)
+    n_local = (N + W - 1) // W + 1
+    shards, sbias, args = [], [], []
+    for r in range(W):
+        t = torch.full((n_local, d), 7.0)          # unused rows hold garbage that WOULD count: they must be ignored
+        b = torch.full((n_local,), 3.0)
+        ids = torch.arange(1, N)[torch.arange(1, N) % W == r]
+        t[ids // W + 1] = table[ids]
+        b[ids // W + 1] = bias[ids] if with_bias else 0.0
+        t[0] = 0
+        b[0] = bias[0] if with_bias else 0.0
+        shards.append(t.to(dev)); sbias.append(b.to(dev) if with_bias else None)
+        own = hs % W == r
+        csum = torch.cat([torch.zeros(1, dtype=torch.int64), own.to(torch.int64).cumsum(0)])
+        n_rows, excl = ((N - 1) // W + 2, 1) if r == 0 else (((N - 1 - r) // W + 1) + 1, -1)
+        ltgt = torch.where(tgt % W == r, tgt // W + 1, torch.full_like(tgt, -1))
+        args.append((ltgt.to(dev), csum[hp].contiguous().to(dev), (hs[own] // W + 1).to(torch.int32).to(dev), n_rows, excl))
+    thr = sum(ops.full_rank_shard(1, ue.to(dev), shards[r], args[r][0], item_bias_local=sbias[r], n_rows=args[r][3]) for r in range(W))
+    got = sum(ops.full_rank_shard(2, ue.to(dev), shards[r], args[r][0], thr=thr.contiguous(), user_id=uid.to(dev), hist_ptr=args[r][1],
+                                  hist_sorted_local=args[r][2], item_bias_local=sbias[r], n_rows=args[r][3], excl_row=args[r][4])
+              for r in range(W))
+    assert torch.equal(got.cpu().to(torch.int32), want.cpu()), (got.cpu(), want.cpu())

@@ -152,6 +152,21 @@ def _gpu_worker(rank, world, port, q, kind="SASRec"):
         st.flush()
         full = st.gather_table().cpu()
         dense = st.model.dense_flat.data.cpu()
+        # ---- full-item ranking over the sharded table == ur_full_rank over the gathered table (exact integers)
+        from unirec_amd import ops
+        gh = torch.Generator().manual_seed(100 + rank)
+        uid = torch.randint(0, 12, (B,), generator=gh).to(dev)                # users 10, 11: outside the history table
+        tgt = mine[0]["item_id"][:, 0].contiguous()
+        lens = torch.randint(0, 40, (10,), generator=torch.Generator().manual_seed(7))
+        hp = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).to(dev)
+        hs_g = torch.randint(1, 3001, (int(lens.sum()),), generator=torch.Generator().manual_seed(8), dtype=torch.int32)
+        hs = torch.cat([hs_g[int(hp[u]):int(hp[u + 1])].sort().values for u in range(10)]).to(dev)
+        got = st.full_item_ranks(mine[0]["item_seq"], tgt, user_id=uid, hist_ptr=hp, hist_sorted=hs)
+        want, _ = ops.full_rank(st.encode(mine[0]["item_seq"]), full.to(dev), tgt, user_id=uid, hist_ptr=hp, hist_sorted=hs)
+        assert torch.equal(got.cpu(), want.cpu()), (got.cpu(), want.cpu())
+        got2 = st.full_item_ranks(mine[0]["item_seq"], tgt)                    # no history
+        want2, _ = ops.full_rank(st.encode(mine[0]["item_seq"]), full.to(dev), tgt)
+        assert torch.equal(got2.cpu(), want2.cpu()) and int(want2.max()) > 0
         all_losses = [None] * world
         dist.all_gather_object(all_losses, losses)
         if rank == 0:

@@ -52,12 +52,12 @@ __global__ __launch_bounds__(256) void target_score_kernel(const float4* __restr
     const int c = t + k * TPR;
     u[k] = c < d4 ? user_emb[(long long)b * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const long long id = target[b];
-  float s = row_dot<TPR>(table, id, u, d4, t);
+  const long long id = target[b];   // < 0: the target is not a row of this table (row-sharded catalogue): thr = 0
+  float s = row_dot<TPR>(table, id < 0 ? 0 : id, u, d4, t);
   if (t == 0) {
-    if (item_bias) s += item_bias[id];
-    thr[b] = s;
-    target_score[b] = (s + (user_bias ? user_bias[user_id[b]] : 0.f)) / tau;
+    if (item_bias) s += item_bias[id < 0 ? 0 : id];
+    thr[b] = id < 0 ? 0.f : s;
+    if (target_score) target_score[b] = (s + (user_bias ? user_bias[user_id[b]] : 0.f)) / tau;
   }
 }
 
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void rank_adjust_kernel(const float4* __restri
                                                           const long long* __restrict__ hist_ptr, const int* __restrict__ hist_sorted,
                                                           long long n_users, const float* __restrict__ item_bias,
                                                           const float* __restrict__ thr, long long n_lo, long long n_hi, int d4,
-                                                          int* __restrict__ counts) {
+                                                          int* __restrict__ counts, long long excl) {
   constexpr int groups = 256 / TPR;
   __shared__ int acc[2];
   const int b = blockIdx.x, g = threadIdx.x / TPR, t = threadIdx.x % TPR;
@@ -115,6 +115,10 @@ __global__ __launch_bounds__(256) void rank_adjust_kernel(const float4* __restri
       const float s = row_dot<TPR>(table, 0, u, d4, t) + (item_bias ? item_bias[0] : 0.f);
       extra += s > th;
     }
+    if (excl >= 0 && excl != tgt) {   // a second row that is not an item (row-sharded table: the unused local row 1 of rank 0)
+      const float s = row_dot<TPR>(table, excl, u, d4, t) + (item_bias ? item_bias[excl] : 0.f);
+      extra += s > th;
+    }
     if (t == 0) atomicAdd(&counts[b], acc[0] - acc[1] - extra);
   }
 }
@@ -138,6 +142,7 @@ struct RankArgs {
   const long long* target; const long long* user_id;
   long long N; int B, d, splits; float tau;
   float* thr; float* target_score; int* counts;
+  int mode;   // 0: thresholds from the diagonal tile, then count;  1: thresholds only (target < 0 -> 0);  2: count against the given thr
 };
 
 template <int KC>
@@ -155,8 +160,8 @@ __global__ __launch_bounds__(512) void rank_stream_kernel(RankArgs a) {
   const int mt = q % ntm, split = (q / ntm) * 8 + xcd;
   const int m0 = mt * BM;
   const long long ntn = (a.N + BN - 1) / BN, tps = (ntn + a.splits - 1) / a.splits;
-  const long long t_begin = (long long)split * tps, t_end = min(ntn, t_begin + tps);
-  if (t_begin >= t_end && split != 0) return;   // split 0 always runs: it publishes thr / target_score
+  const long long t_begin = (long long)split * tps, t_end = a.mode == 1 ? t_begin : min(ntn, t_begin + tps);
+  if (a.mode == 1 ? split != 0 : (t_begin >= t_end && (split != 0 || a.mode == 2))) return;   // split 0 publishes thr / target_score
 
   // ---- user tile -> LDS (zero fill beyond B and beyond d)
   for (int idx = tid; idx < BM * 8 * KC; idx += 512) {
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(512) void rank_stream_kernel(RankArgs a) {
     for (int p = 0; p < 4; ++p) {
       const int row = lrow + 64 * p;
       long long n;
-      if (tile < 0) n = a.target[min(m0 + (row & (BM - 1)), a.B - 1)];   // diagonal tile: the targets' rows
+      if (tile < 0) n = max(a.target[min(m0 + (row & (BM - 1)), a.B - 1)], 0LL);   // diagonal tile: the targets' rows
       else n = min(tile * BN + row, a.N - 1);
       Wp[p] = a.table + n * a.d + c4 * 4;
     }
@@ -203,7 +208,16 @@ __global__ __launch_bounds__(512) void rank_stream_kernel(RankArgs a) {
     }
 
   const int frow = lane & 31, fk = 4 * (lane >> 5), lcol = lane & 31, lrow4 = 4 * (lane >> 5);
-  long long tile = -1;
+  long long tile = a.mode == 2 ? t_begin : -1;
+  if (a.mode == 2) {   // thresholds given (computed by the shard that owns each target, with the same MFMA sequence)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        thr_r[i][r] = row < a.B ? a.thr[row] : INFINITY;
+      }
+  }
   set_rows(tile);
   load_global(0);
   store_lds(0);
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(512) void rank_stream_kernel(RankArgs a) {
     for (int j = 0; j < 2; ++j) {
       const int col = wc * 64 + j * 32 + lcol;
       if (tile < 0) {
-        bias[j] = a.item_bias ? a.item_bias[a.target[min(m0 + (col & (BM - 1)), a.B - 1)]] : 0.f;
+        bias[j] = a.item_bias ? a.item_bias[max(a.target[min(m0 + (col & (BM - 1)), a.B - 1)], 0LL)] : 0.f;
       } else {
         const long long n = tile * BN + col;
         bias[j] = n < a.N ? (a.item_bias ? a.item_bias[n] : 0.f) : -INFINITY;   // columns beyond N never count
@@ -272,8 +286,8 @@ __global__ __launch_bounds__(512) void rank_stream_kernel(RankArgs a) {
         }
       if (split == 0 && tid < BM && m0 + tid < a.B) {
         const int m = m0 + tid;
-        a.thr[m] = thr_s[tid];
-        a.target_score[m] = (thr_s[tid] + (a.user_bias ? a.user_bias[a.user_id[m]] : 0.f)) / a.tau;
+        a.thr[m] = (a.mode == 1 && a.target[m] < 0) ? 0.f : thr_s[tid];
+        if (a.target_score) a.target_score[m] = (thr_s[tid] + (a.user_bias ? a.user_bias[a.user_id[m]] : 0.f)) / a.tau;
       }
     } else {
 #pragma unroll
@@ -467,11 +481,13 @@ __global__ void topk_finish_kernel(float* __restrict__ vals, long long* __restri
 
 using namespace ur;
 
-extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d,
-                            const int64_t* target, const int64_t* user_id, const int64_t* hist_ptr, const int32_t* hist_sorted,
-                            int64_t n_users, const float* user_bias, const float* item_bias, float tau, int32_t* rank,
-                            float* target_score, float* thr_ws, void* stream) {
-  UR_REQUIRE(user_emb && item_table && target && rank && target_score && thr_ws, UR_ERR_ARG, "ur_full_rank: null pointer");
+// mode 0: the whole catalogue (ur_full_rank);  1 / 2: the two phases of the row-sharded count (ur_full_rank_shard)
+static int full_rank_impl(int mode, const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d,
+                          const int64_t* target, const int64_t* user_id, const int64_t* hist_ptr, const int32_t* hist_sorted,
+                          int64_t n_users, const float* user_bias, const float* item_bias, float tau, int32_t* rank,
+                          float* target_score, float* thr_ws, void* stream, int64_t excl_row = -1) {
+  UR_REQUIRE(user_emb && item_table && target && thr_ws && (mode == 1 || rank) && (mode != 0 || target_score), UR_ERR_ARG,
+             "ur_full_rank: null pointer");
   UR_REQUIRE(B > 0 && d > 0 && d % 4 == 0 && d <= 512 && n_items > 0 && n_items < (1LL << 31), UR_ERR_ARG, "ur_full_rank: shape");
   UR_REQUIRE(tau > 0.f, UR_ERR_ARG, "ur_full_rank: tau must be > 0 (scores are compared un-normalised)");
   UR_REQUIRE(!hist_ptr || (hist_sorted && user_id), UR_ERR_ARG, "ur_full_rank: history needs user_id and hist_sorted");
@@ -479,7 +495,7 @@ extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int6
   hipStream_t st = as_stream(stream);
   ProfScope ps(PC_MISC, st, 2.0 * B * (double)n_items * d);
   const int tpr = pick_tpr(d), groups = 256 / tpr, d4 = d / 4;
-  UR_HIP(hipMemsetAsync(rank, 0, sizeof(int32_t) * B, st));
+  if (mode != 1) UR_HIP(hipMemsetAsync(rank, 0, sizeof(int32_t) * B, st));
   int64_t n_tail = n_items;   // items [n_tail, n_items) are left to the adjust kernel
   if (d <= 128) {
     // streaming kernel: user blocks of <= 4096 rows (32 user tiles x 8 item splits = 256 workgroups = one per CU)
@@ -488,8 +504,8 @@ extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int6
       a.B = std::min(4096, B - b0);
       a.user_emb = user_emb + (size_t)b0 * d; a.table = item_table; a.item_bias = item_bias; a.user_bias = user_bias;
       a.target = (const long long*)target + b0; a.user_id = user_id ? (const long long*)user_id + b0 : nullptr;
-      a.N = n_items; a.d = d; a.tau = tau;
-      a.thr = thr_ws + b0; a.target_score = target_score + b0; a.counts = rank + b0;
+      a.N = n_items; a.d = d; a.tau = tau; a.mode = mode;
+      a.thr = thr_ws + b0; a.target_score = target_score ? target_score + b0 : nullptr; a.counts = rank ? rank + b0 : nullptr;
       const int ntm = cdiv(a.B, 128);
       a.splits = 8 * std::max(1, 32 / ntm);
       int rc = d <= 32 ? launch_rank_stream<1>(a, st) : d <= 64 ? launch_rank_stream<2>(a, st)
@@ -497,6 +513,7 @@ extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int6
       if (rc) return rc;
     }
   } else {
+    if (mode != 2) {
 #define GO(T) hipLaunchKernelGGL((target_score_kernel<T>), dim3(cdiv(B, groups)), dim3(256), 0, st, (const float4*)user_emb,          \
                                  (const float4*)item_table, (const long long*)target, (const long long*)user_id, user_bias, item_bias,  \
                                  tau, B, d4, thr_ws, target_score)
@@ -508,6 +525,8 @@ extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int6
     }
 #undef GO
     UR_LAUNCH_CHECK();
+    }
+    if (mode == 1) return UR_OK;
     // generic GEMM with the count epilogue, in item chunks that keep the grid below HIP's 2^32-thread limit
     n_tail = (n_items / 128) * 128;
     const int64_t tiles_m8 = 8 * (int64_t)cdiv(cdiv(B, 128), 8);
@@ -521,9 +540,10 @@ extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int6
       if (rc) return rc;
     }
   }
+  if (mode == 1) return UR_OK;
 #define GO(T) hipLaunchKernelGGL((rank_adjust_kernel<T>), dim3(B), dim3(256), 0, st, (const float4*)user_emb, (const float4*)item_table, \
                                  (const long long*)target, (const long long*)user_id, (const long long*)hist_ptr, hist_sorted,            \
-                                 (long long)n_users, item_bias, thr_ws, (long long)n_tail, (long long)n_items, d4, rank)
+                                 (long long)n_users, item_bias, thr_ws, (long long)n_tail, (long long)n_items, d4, rank, (long long)excl_row)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;
@@ -533,6 +553,24 @@ extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int6
 #undef GO
   UR_LAUNCH_CHECK();
   return UR_OK;
+}
+
+extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d,
+                            const int64_t* target, const int64_t* user_id, const int64_t* hist_ptr, const int32_t* hist_sorted,
+                            int64_t n_users, const float* user_bias, const float* item_bias, float tau, int32_t* rank,
+                            float* target_score, float* thr_ws, void* stream) {
+  return full_rank_impl(0, user_emb, item_table, n_items, B, d, target, user_id, hist_ptr, hist_sorted, n_users, user_bias, item_bias, tau,
+                        rank, target_score, thr_ws, stream);
+}
+
+extern "C" int ur_full_rank_shard(int32_t phase, const float* user_emb, const float* shard_table, int64_t n_local, int32_t B, int32_t d,
+                                  const int64_t* local_target, const int64_t* user_id, const int64_t* hist_ptr,
+                                  const int32_t* hist_sorted_local, int64_t n_users, const float* item_bias_local, int64_t excl_row,
+                                  float* thr, int32_t* rank_partial, void* stream) {
+  UR_REQUIRE(phase == 1 || phase == 2, UR_ERR_ARG, "ur_full_rank_shard: phase=%d", phase);
+  UR_REQUIRE(excl_row < n_local, UR_ERR_ARG, "ur_full_rank_shard: excl_row=%lld", (long long)excl_row);
+  return full_rank_impl(phase, user_emb, shard_table, n_local, B, d, local_target, user_id, phase == 2 ? hist_ptr : nullptr,
+                        phase == 2 ? hist_sorted_local : nullptr, n_users, nullptr, item_bias_local, 1.0f, rank_partial, nullptr, thr, stream, excl_row);
 }
 
 extern "C" int64_t ur_full_topk_workspace_bytes(int32_t B, int64_t n_items, int32_t k) {

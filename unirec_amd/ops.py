@@ -308,6 +308,34 @@ def full_rank(user_emb, item_table, target, user_id=None, hist_ptr=None, hist_so
     return rank, ts
 
 
+def full_rank_shard(phase, user_emb, shard_table, local_target, thr=None, user_id=None, hist_ptr=None, hist_sorted_local=None,
+                    item_bias_local=None, n_rows=None, excl_row=-1):
+    """One phase of the row-sharded full-item count on THIS rank's shard (include/unirec_amd.h: ur_full_rank_shard).
+    phase 1 -> thr float32[B] (this shard's contribution: the score of the targets it owns, 0 elsewhere; all-reduce it);
+    phase 2 (thr = the all-reduced thresholds) -> rank_partial int32[B] (all-reduce it).
+    n_rows: rows of the shard that are scanned (default all); excl_row: a local row that is not an item (or -1)."""
+    _chk(user_emb, torch.float32, "user_emb")
+    _chk(shard_table, torch.float32, "shard_table")
+    _chk(local_target, torch.int64, "local_target")
+    _chk(user_id, torch.int64, "user_id", allow_none=True)
+    _chk(hist_ptr, torch.int64, "hist_ptr", allow_none=True)
+    _chk(hist_sorted_local, torch.int32, "hist_sorted_local", allow_none=True)
+    _chk(item_bias_local, torch.float32, "item_bias_local", allow_none=True)
+    B, d = user_emb.shape
+    if phase == 1:
+        thr = torch.empty(B, dtype=torch.float32, device=user_emb.device)
+        rank = None
+    else:
+        _chk(thr, torch.float32, "thr")
+        rank = torch.empty(B, dtype=torch.int32, device=user_emb.device)
+    n_users = hist_ptr.numel() - 1 if hist_ptr is not None else 0
+    check(lib.ur_full_rank_shard(int(phase), _p(user_emb), _p(shard_table), int(n_rows) if n_rows is not None else shard_table.shape[0], B, d,
+                                 _p(local_target), _p(user_id), _p(hist_ptr), _p(hist_sorted_local), n_users, _p(item_bias_local),
+                                 int(excl_row), _p(thr), _p(rank), _stream()),
+          "ur_full_rank_shard")
+    return thr if phase == 1 else rank
+
+
 def full_topk(user_emb, item_table, k, user_id=None, hist_ptr=None, hist_sorted=None, user_bias=None, item_bias=None, tau=1.0):
     """-> (scores float32[B,k], ids int64[B,k]): the k best items per row (not item 0, not in the user's history), best
     first.  See include/unirec_amd.h: ur_full_topk."""

@@ -65,6 +65,29 @@ class RowExchange:
         return out.to(send.device) if stage else out
 
 
+    def _staged(self, t: torch.Tensor):
+        return t.is_cuda and self.world > 1 and dist.get_backend(self.group) != "nccl"
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return t
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            return h.to(t.device)
+        dist.all_reduce(t, group=self.group)
+        return t
+
+    def all_gather_cat(self, t: torch.Tensor) -> torch.Tensor:
+        """equal-shaped [n, ...] from every rank -> [world * n, ...] in rank order"""
+        if self.world == 1:
+            return t
+        src = t.contiguous().cpu() if self._staged(t) else t.contiguous()
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(parts, src, group=self.group)
+        return torch.cat(parts).to(t.device)
+
+
 def shard_rows(n_items: int, world: int) -> int:
     """rows per shard INCLUDING its padding row 0 (must match rows.hip build_keys_kernel)."""
     return (n_items + world - 1) // world + 1 if world > 1 else n_items
@@ -197,6 +220,66 @@ class ShardedSasrecStep:
                 return pre[1], pre[2]
         ids_a, ids_b = self._plan_ids(batch)
         return ops.rows_plan_sharded(ids_a, ids_b, self.N, self.world)
+
+    # ---- evaluation over the sharded table -------------------------------------------------
+    @torch.no_grad()
+    def encode(self, item_seq):
+        """user_emb [B,d] of this rank's sequences, evaluation mode: the rows are fetched through the same two all-to-alls as
+        in step() (call flush() first when the table is lazily updated)."""
+        m, W = self.model, self.world
+        item_seq = item_seq.to(torch.int32).contiguous()
+        B, L = item_seq.shape
+        pl, counts_dev = ops.rows_plan_sharded(item_seq.reshape(-1), self.zero_id, self.N, W)
+        send_counts, recv_counts = self.xchg.exchange_counts_dev(counts_dev)
+        keys = pl.uniq_idx[: sum(send_counts)]
+        req_send = (keys % self.n_local).to(torch.int32) if W > 1 else keys
+        req = self.xchg.all_to_all_rows(req_send, send_counts, recv_counts)
+        compact = self.xchg.all_to_all_rows(ops.embedding_gather(self.table, req), recv_counts, send_counts)
+        idx_a, _ = ops.compact_index(pl)
+        was_training = m.training
+        m.eval()
+        cfg = m._cfg(B)
+        enc_fwd = ops.gru_fwd if self.kind == "GRU" else ops.sasrec_fwd
+        out = enc_fwd(cfg, compact, m.dense_flat.data, idx_a.view(B, L), m._workspace(cfg)).clone()
+        m.train(was_training)
+        return out
+
+    def local_history(self, hist_ptr, hist_sorted):
+        """CSR history (global ids, ascending per user) -> the same CSR restricted to this rank's items, in local row ids."""
+        if hist_ptr is None or self.world == 1:
+            return hist_ptr, hist_sorted
+        W, r = self.world, self.rank
+        own = (hist_sorted % W == r) & (hist_sorted > 0)
+        csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=own.device), own.to(torch.int64).cumsum(0)])
+        return csum[hist_ptr].contiguous(), (hist_sorted[own] // W + 1).to(torch.int32).contiguous()
+
+    @torch.no_grad()
+    def full_item_ranks(self, item_seq, target, user_id=None, hist_ptr=None, hist_sorted=None, local_hist=None):
+        """one_vs_all rank (Evaluator.evaluate_with_full_items semantics, as ops.full_rank) of this rank's B rows over the
+        row-SHARDED catalogue: all-gather the user vectors, every rank counts on its own shard, two small all-reduces
+        (thresholds, counts).  Every rank must call it with the same B.  -> int32[B]."""
+        W, r = self.world, self.rank
+        ue = self.encode(item_seq)
+        B = ue.shape[0]
+        target = target.reshape(B, -1)[:, 0].to(torch.int64).contiguous()
+        ue_all, tgt_all = self.xchg.all_gather_cat(ue), self.xchg.all_gather_cat(target)
+        uid_all = self.xchg.all_gather_cat(user_id.to(torch.int64).contiguous()) if user_id is not None else None
+        ltgt = tgt_all if W == 1 else torch.where(tgt_all % W == r, tgt_all // W + 1, torch.full_like(tgt_all, -1))
+        hp, hs = local_hist if local_hist is not None else self.local_history(hist_ptr, hist_sorted)
+        if uid_all is None:
+            hp = hs = None
+        # valid local rows: rank 0 holds ids W, 2W, .. at local rows 2.. (row 1 is the slot id 0 would take: never an item);
+        # rank r > 0 holds ids r, r + W, .. at local rows 1..
+        if W == 1:
+            n_rows, excl = self.N, -1
+        elif r == 0:
+            n_rows, excl = (self.N - 1) // W + 2, 1
+        else:
+            n_rows, excl = ((self.N - 1 - r) // W + 1 if self.N - 1 >= r else 0) + 1, -1
+        thr = self.xchg.all_reduce_sum(ops.full_rank_shard(1, ue_all, self.table, ltgt, n_rows=n_rows))
+        part = ops.full_rank_shard(2, ue_all, self.table, ltgt, thr=thr, user_id=uid_all, hist_ptr=hp, hist_sorted_local=hs,
+                                   n_rows=n_rows, excl_row=excl)
+        return self.xchg.all_reduce_sum(part)[r * B:(r + 1) * B]
 
     def flush(self):
         if self.last is not None and self.t > 0:
