@@ -331,6 +331,17 @@ int ur_host_build_rows(void* sampler, const int64_t* user_id, const int64_t* pos
 int ur_sample_negatives(const int64_t* user_id, const int64_t* pos_item, int32_t B, int32_t K, int64_t n_items,
                         int64_t n_users, const int64_t* hist_ptr, const int32_t* hist_sorted, uint64_t seed,
                         uint32_t step, int64_t* item_id, int32_t* label, void* stream);
+/* Popularity-biased variant (AddNegSamples with item_popularity and neg_by_pop_alpha, unirec/data/transform/addnegsamples.py:
+ * 58-62,75-80 + the alias method of unirec/utils/sampling.py:9-31): a try draws x = random() * n_items, i = int(x) and takes
+ * alias_idx[i] if x - i > alias_odds[i] else i; random() is CPython's 53-bit construction from two Philox words.  Same
+ * rejection rule / 100 tries / counter layout as ur_sample_negatives.  alias_odds double[n_items], alias_idx int64[n_items]
+ * on the DEVICE, as built on the host by ur_alias_table_build. */
+int ur_sample_negatives_pop(const int64_t* user_id, const int64_t* pos_item, int32_t B, int32_t K, int64_t n_items,
+                            int64_t n_users, const int64_t* hist_ptr, const int32_t* hist_sorted, const double* alias_odds,
+                            const int64_t* alias_idx, uint64_t seed, uint32_t step, int64_t* item_id, int32_t* label, void* stream);
+/* HOST: the alias table of prepare_aliased_randomizer (unirec/utils/sampling.py:9-24) for weights w[n]: odds[n], alias[n]
+ * (-1 where the reference keeps (1, None)); same traversal order, so the same table. */
+int ur_alias_table_build(const double* host_weights, int64_t n, double* host_odds, int64_t* host_alias);
 
 /* DEVICE history rows: item_seq[b,:] = left_pad(AddUserHistory(history(user_b), ids_b), L) for a
  * whole batch from a CSR history resident in HBM -- adduserhistory.py:32-73 + seqrecdataset.py:60-68 without the

@@ -29,8 +29,10 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
 
 
-def sample_negatives(user_id, pos_item, K, n_items, hist_ptr=None, hist_sorted=None, seed=0, step=0):
-    """-> item_id int64[B, K+1] with the positive in column 0."""
+def sample_negatives(user_id, pos_item, K, n_items, hist_ptr=None, hist_sorted=None, seed=0, step=0, alias=None):
+    """-> item_id int64[B, K+1] with the positive in column 0.  alias: None or (odds, idx) -- the popularity-biased draw of
+    unirec/utils/sampling.py:26-30 (x = random()*N; i = int(x); idx[i] if x - i > odds[i] else i) with random() =
+    ((w0 >> 5) * 2^26 + (w1 >> 6)) / 2^53 from the try's first two Philox words (CPython's construction)."""
     pos_item = np.asarray(pos_item, dtype=np.int64)
     B = len(pos_item)
     out = np.zeros((B, K + 1), dtype=np.int64)
@@ -55,6 +57,13 @@ def sample_negatives(user_id, pos_item, K, n_items, hist_ptr=None, hist_sorted=N
                 if r >= rng_range:
                     r = (int(w[3][t]) * rng_range) >> 32
                 cand = 1 + r
+                if alias is not None:
+                    u = ((int(w[0][t]) >> 5) * 67108864.0 + (int(w[1][t]) >> 6)) / 9007199254740992.0
+                    x = u * n_items
+                    i = int(x)
+                    cand = int(alias[1][i]) if (x - i) > alias[0][i] else i
+                    if cand <= 0:
+                        continue
                 if cand != int(pos_item[b]) and cand not in hist:
                     out[b, k] = cand
                     break

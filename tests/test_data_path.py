@@ -149,6 +149,65 @@ def test_device_sampler_bit_exact_vs_philox_oracle_and_distribution():
     assert ex.cpu().tolist() == [[3, 0, 0, 0]]
 
 
+def test_native_alias_table_equals_the_reference_algorithm():
+    """ur_alias_table_build == oracle/data_ref.alias_table (itself pinned to the reference's sampler by g1's pop_out)."""
+    from oracle import data_ref
+    from unirec_amd.data.rows import alias_table, pop_sample_ratio
+    rng = np.random.default_rng(4)
+    for n, alpha in ((30, 0.5), (257, 1.0), (1000, 0.25)):
+        pop = rng.integers(0, 50, n).astype(np.float64)
+        pop[rng.integers(1, n, 5)] = 0          # unseen items
+        w = pop_sample_ratio(pop, alpha)
+        assert np.array_equal(w, data_ref.pop_sample_ratio(pop, alpha))
+        odds, idx = alias_table(w)
+        ro, ri = data_ref.alias_table(list(w))
+        assert np.array_equal(odds, np.asarray(ro, dtype=np.float64)) and np.array_equal(idx, np.asarray(ri, dtype=np.int64))
+
+
+@pytest.mark.gpu
+def test_device_popularity_sampler_bit_exact_and_distribution():
+    """neg_by_pop_alpha > 0 on the device (SURVEY.md 8 a1 + f2): alias draw from Philox words, bit-exact vs oracle/philox_ref.py,
+    empirical frequencies = pop^alpha / sum, history / positive rejection as in the uniform sampler."""
+    from unirec_amd.data.rows import DeviceRowBuilder, alias_table, pop_sample_ratio, sample_negatives_device
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2)
+    n_users, n_items, K, B = 20, 97, 6, 64
+    pop = rng.integers(0, 30, n_items).astype(np.float64)
+    pop[[5, 17]] = 0
+    w = pop_sample_ratio(pop, 0.75)
+    odds, idx = alias_table(w)
+    alias_dev = (torch.from_numpy(odds).to(dev), torch.from_numpy(idx).to(dev))
+    u2h = _u2h(None, *[rng.integers(1, n_items, rng.integers(1, 40)) for _ in range(n_users - 1)])
+    csr = HistoryCSR(u2h)
+    users = rng.integers(0, n_users + 3, B)
+    pos = rng.integers(1, n_items, B)
+    for step in (0, 9):
+        ids, _ = sample_negatives_device(torch.from_numpy(pos).to(dev), K, n_items, torch.from_numpy(users).to(dev), csr, seed=31, step=step,
+                                         alias=alias_dev)
+        ref = philox_ref.sample_negatives(users, pos, K, n_items, csr.ptr, csr.sorted, seed=31, step=step, alias=(odds, idx))
+        assert torch.equal(ids.cpu(), torch.from_numpy(ref))
+    got = ids.cpu().numpy()
+    for b in range(B):
+        h = set() if not (0 <= users[b] < n_users) or u2h[users[b]] is None else set(int(x) for x in u2h[users[b]])
+        for c in got[b, 1:]:
+            assert c == 0 or (1 <= c < n_items and c != pos[b] and c not in h and w[c] > 0)
+    # frequencies: no history, positive = an item of weight 0 -> draws follow w exactly
+    Bn, Kn = 4096, 64
+    big, _ = sample_negatives_device(torch.full((Bn,), 5, dtype=torch.int64, device=dev), Kn, n_items, seed=3, step=2, alias=alias_dev)
+    x = big[:, 1:].reshape(-1).cpu().numpy()
+    cnt = np.bincount(x, minlength=n_items).astype(np.float64)
+    assert cnt[0] == 0 and cnt[5] == 0 and cnt[17] == 0
+    e = w / w.sum() * cnt.sum()
+    nz = e > 0
+    chi2 = ((cnt[nz] - e[nz]) ** 2 / e[nz]).sum()
+    dof = int(nz.sum()) - 1
+    assert abs(chi2 - dof) < 5 * np.sqrt(2 * dof), (chi2, dof)
+    # through the row builder
+    bld = DeviceRowBuilder(n_users, n_items, K, history=csr, seed=31, device="cuda:0", item_popularity=pop, neg_by_pop_alpha=0.75)
+    out = bld.build(torch.from_numpy(users).to(dev), torch.from_numpy(pos).to(dev), with_seq=False, step=9)
+    assert torch.equal(out["item_id"].cpu(), torch.from_numpy(ref))
+
+
 # ------------------------------------------------------------------------------------------ device row builder (8 f2)
 def _random_history(rng, n_users, n_items, max_len):
     u2h = np.empty(n_users, dtype=object)

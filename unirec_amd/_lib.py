@@ -91,6 +91,8 @@ SIGNATURES = {
     "ur_host_sampler_set_alias": (C.c_int, [P, P, I64]),
     "ur_host_build_rows": (C.c_int, [P, P, P, I64, I64, I64, I32, P, P, P, I32, I32, I32, I32, P, P, P]),
     "ur_sample_negatives": (C.c_int, [P, P, I32, I32, I64, I64, P, P, C.c_uint64, C.c_uint32, P, P, P]),
+    "ur_sample_negatives_pop": (C.c_int, [P, P, I32, I32, I64, I64, P, P, P, P, C.c_uint64, C.c_uint32, P, P, P]),
+    "ur_alias_table_build": (C.c_int, [P, I64, P, P]),
     "ur_device_build_seq": (C.c_int, [P, P, C.c_int32, C.c_int32, I64, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                       C.c_uint32, P, P, P]),
     "ur_gemm_nt": (C.c_int, [P, C.c_int, P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, C.c_int,

@@ -95,16 +95,14 @@ extern "C" uint64_t ur_host_sampler_getrandbits(void* h, int k) { return ((Sampl
 extern "C" double ur_host_sampler_random(void* h) { return ((Sampler*)h)->rng.random(); }
 extern "C" int64_t ur_host_sampler_randint(void* h, int64_t a, int64_t b) { return a + (int64_t)((Sampler*)h)->rng.randbelow((uint64_t)(b - a + 1)); }
 
-// popularity-biased negatives: weights w[i] (already pop^alpha / sum with w[0] = 0); alias table as
-// unirec/utils/sampling.py:9-24 builds it (same traversal order => same table).
-extern "C" int ur_host_sampler_set_alias(void* h, const double* w, int64_t n) {
-  UR_REQUIRE(h && w && n > 0, UR_ERR_ARG, "ur_host_sampler_set_alias: bad argument");
-  Sampler* s = (Sampler*)h;
+// Alias table as unirec/utils/sampling.py:9-24 builds it (same traversal order => same table): odds[i] in [0,1], alias[i]
+// (-1 where the reference keeps (1, None)).  Host pointers.
+extern "C" int ur_alias_table_build(const double* w, int64_t n, double* odds, int64_t* alias) {
+  UR_REQUIRE(w && odds && alias && n > 0, UR_ERR_ARG, "ur_alias_table_build: bad argument");
   double sum = 0;
   for (int64_t i = 0; i < n; ++i) sum += w[i];
   const double avg = sum / (double)n;
-  s->odds.assign(n, 1.0);
-  s->alias.assign(n, -1);
+  for (int64_t i = 0; i < n; ++i) { odds[i] = 1.0; alias[i] = -1; }
   int64_t si = 0, bi = 0;   // generators over smalls (w < avg) and bigs (w >= avg), both in index order
   auto next_small = [&](int64_t from) { while (from < n && !(w[from] < avg)) ++from; return from; };
   auto next_big = [&](int64_t from) { while (from < n && !(w[from] >= avg)) ++from; return from; };
@@ -113,8 +111,8 @@ extern "C" int ur_host_sampler_set_alias(void* h, const double* w, int64_t n) {
   int64_t small_i = si < n ? si : -1, big_i = bi < n ? bi : -1;
   double small_v = small_i >= 0 ? w[small_i] / avg : 0, big_v = big_i >= 0 ? w[big_i] / avg : 0;
   while (big_i >= 0 && small_i >= 0) {
-    s->odds[small_i] = small_v;
-    s->alias[small_i] = big_i;
+    odds[small_i] = small_v;
+    alias[small_i] = big_i;
     big_v = big_v - (1.0 - small_v);
     if (big_v < 1.0) {
       small_i = big_i; small_v = big_v;
@@ -128,6 +126,15 @@ extern "C" int ur_host_sampler_set_alias(void* h, const double* w, int64_t n) {
     }
   }
   return UR_OK;
+}
+
+// popularity-biased negatives: weights w[i] (already pop^alpha / sum with w[0] = 0)
+extern "C" int ur_host_sampler_set_alias(void* h, const double* w, int64_t n) {
+  UR_REQUIRE(h && w && n > 0, UR_ERR_ARG, "ur_host_sampler_set_alias: bad argument");
+  Sampler* s = (Sampler*)h;
+  s->odds.assign(n, 1.0);
+  s->alias.assign(n, -1);
+  return ur_alias_table_build(w, n, s->odds.data(), s->alias.data());
 }
 
 static inline int64_t draw_one(Sampler* s, int64_t n_items) {

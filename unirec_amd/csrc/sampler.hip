@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(const long long* 
                                                                int B, int K, long long n_items, long long n_users,
                                                                const long long* __restrict__ hist_ptr, const int* __restrict__ hist_sorted,
                                                                uint32_t seed_lo, uint32_t seed_hi, uint32_t step,
-                                                               long long* __restrict__ item_id, int* __restrict__ label) {
+                                                               long long* __restrict__ item_id, int* __restrict__ label,
+                                                               const double* __restrict__ alias_odds, const long long* __restrict__ alias_idx) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= B * (K + 1)) return;
   const int b = t / (K + 1), k = t % (K + 1);
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(const long long* 
   const long long u = user_id ? user_id[b] : -1;
   const bool known = hist_ptr && u >= 0 && u < n_users;
   const long long hb = known ? hist_ptr[u] : 0, he = known ? hist_ptr[u + 1] : 0;
-  const uint32_t range = (uint32_t)(n_items - 1);          // candidates are 1 + [0, range)
+  const uint32_t range = (uint32_t)(n_items - 1);          // uniform draw: candidates are 1 + [0, range)
   int bits = 0;
   for (uint32_t r = range; r; r >>= 1) ++bits;              // CPython-style: top `bits` bits, reject >= range
   long long picked = 0;
@@ -55,7 +56,16 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(const long long* 
       if (r >= range && c < range) r = c;
     }
     if (r >= range) r = (uint32_t)(((unsigned long long)w[3] * range) >> 32);   // p < 2^-4 per try: multiply-shift fallback
-    const long long cand = 1 + (long long)r;
+    long long cand = 1 + (long long)r;
+    if (alias_odds) {
+      // popularity-biased draw (unirec/utils/sampling.py:26-30): x = random() * N; i = int(x); alias[i] if x - i > odds[i] else i,
+      // with random() built from two words the way CPython does it: (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53
+      const double u = ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6)) * (1.0 / 9007199254740992.0);
+      const double x = u * (double)n_items;
+      const long long i = (long long)x;
+      cand = (x - (double)i) > alias_odds[i] ? alias_idx[i] : i;
+      if (cand <= 0) continue;   // item 0 (weight 0) can only come out with x - i == 0: not a candidate
+    }
     bool ok = cand != pos;
     if (ok && he > hb) {                                     // binary search in the user's sorted history
       long long lo = hb, hi = he;
@@ -141,9 +151,9 @@ __global__ __launch_bounds__(256) void build_seq_kernel(const long long* __restr
 
 using namespace ur;
 
-extern "C" int ur_sample_negatives(const int64_t* user_id, const int64_t* pos_item, int32_t B, int32_t K, int64_t n_items,
-                                   int64_t n_users, const int64_t* hist_ptr, const int32_t* hist_sorted, uint64_t seed,
-                                   uint32_t step, int64_t* item_id, int32_t* label, void* stream) {
+static int sample_negatives_impl(const int64_t* user_id, const int64_t* pos_item, int32_t B, int32_t K, int64_t n_items, int64_t n_users,
+                                 const int64_t* hist_ptr, const int32_t* hist_sorted, const double* alias_odds, const int64_t* alias_idx,
+                                 uint64_t seed, uint32_t step, int64_t* item_id, int32_t* label, void* stream) {
   UR_REQUIRE(pos_item && item_id && B > 0 && K >= 0, UR_ERR_ARG, "ur_sample_negatives: bad argument");
   UR_REQUIRE(n_items > 1 && n_items <= (1LL << 32), UR_ERR_ARG, "ur_sample_negatives: n_items=%lld", (long long)n_items);
   UR_REQUIRE(!hist_ptr || (hist_sorted && user_id), UR_ERR_ARG, "ur_sample_negatives: history needs user_id and hist_sorted");
@@ -152,9 +162,26 @@ extern "C" int ur_sample_negatives(const int64_t* user_id, const int64_t* pos_it
   const long long n = (long long)B * (K + 1);
   hipLaunchKernelGGL(sample_negatives_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const long long*)user_id,
                      (const long long*)pos_item, B, K, (long long)n_items, (long long)n_users, (const long long*)hist_ptr, hist_sorted,
-                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step, (long long*)item_id, label);
+                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step, (long long*)item_id, label, alias_odds,
+                     (const long long*)alias_idx);
   UR_LAUNCH_CHECK();
   return UR_OK;
+}
+
+extern "C" int ur_sample_negatives(const int64_t* user_id, const int64_t* pos_item, int32_t B, int32_t K, int64_t n_items,
+                                   int64_t n_users, const int64_t* hist_ptr, const int32_t* hist_sorted, uint64_t seed,
+                                   uint32_t step, int64_t* item_id, int32_t* label, void* stream) {
+  return sample_negatives_impl(user_id, pos_item, B, K, n_items, n_users, hist_ptr, hist_sorted, nullptr, nullptr, seed, step, item_id, label,
+                               stream);
+}
+
+extern "C" int ur_sample_negatives_pop(const int64_t* user_id, const int64_t* pos_item, int32_t B, int32_t K, int64_t n_items,
+                                       int64_t n_users, const int64_t* hist_ptr, const int32_t* hist_sorted, const double* alias_odds,
+                                       const int64_t* alias_idx, uint64_t seed, uint32_t step, int64_t* item_id, int32_t* label,
+                                       void* stream) {
+  UR_REQUIRE(alias_odds && alias_idx, UR_ERR_ARG, "ur_sample_negatives_pop: null alias table");
+  return sample_negatives_impl(user_id, pos_item, B, K, n_items, n_users, hist_ptr, hist_sorted, alias_odds, alias_idx, seed, step, item_id,
+                               label, stream);
 }
 
 extern "C" int ur_device_build_seq(const int64_t* user_id, const int64_t* item_id, int32_t B, int32_t G, int64_t n_users,

@@ -77,10 +77,7 @@ class HostRowBuilder:
         self.seq_last = int(bool(seq_last))
         self._h = lib.ur_host_sampler_create(int(seed) & 0xFFFFFFFFFFFFFFFF)
         if item_popularity is not None:
-            w = np.power(np.asarray(item_popularity).astype(float), neg_by_pop_alpha)   # addnegsamples.py:58-62
-            w /= np.sum(w)
-            w[0] = 0
-            w = np.ascontiguousarray(w, dtype=np.float64)
+            w = pop_sample_ratio(item_popularity, neg_by_pop_alpha)
             check(lib.ur_host_sampler_set_alias(self._h, _hp(w), len(w)), "ur_host_sampler_set_alias")
 
     def __del__(self):
@@ -113,8 +110,25 @@ class HostRowBuilder:
         return out
 
 
-def sample_negatives_device(pos_item, K, n_items, user_id=None, history: HistoryCSR = None, seed=2022, step=0):
-    """Device sampler (Philox, order-independent): -> (item_id int64[B,K+1], label int32[B,K+1]) on pos_item's device."""
+def pop_sample_ratio(item_popularity, alpha):
+    """AddNegSamples._construct_item_sample_ratio (unirec/data/transform/addnegsamples.py:58-62)."""
+    w = np.power(np.asarray(item_popularity).astype(float), alpha)
+    w /= np.sum(w)
+    w[0] = 0
+    return np.ascontiguousarray(w, dtype=np.float64)
+
+
+def alias_table(weights):
+    """-> (odds float64[n], alias int64[n]): prepare_aliased_randomizer's table (unirec/utils/sampling.py:9-24), built natively."""
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    odds, alias = np.empty(len(w), dtype=np.float64), np.empty(len(w), dtype=np.int64)
+    check(lib.ur_alias_table_build(_hp(w), len(w), _hp(odds), _hp(alias)), "ur_alias_table_build")
+    return odds, alias
+
+
+def sample_negatives_device(pos_item, K, n_items, user_id=None, history: HistoryCSR = None, seed=2022, step=0, alias=None):
+    """Device sampler (Philox, order-independent): -> (item_id int64[B,K+1], label int32[B,K+1]) on pos_item's device.
+    alias: None (uniform over [1, n_items-1]) or (odds float64[n_items], idx int64[n_items]) DEVICE tensors (popularity-biased)."""
     assert pos_item.is_cuda and pos_item.dtype == torch.int64
     B = pos_item.numel()
     dev = pos_item.device
@@ -124,6 +138,13 @@ def sample_negatives_device(pos_item, K, n_items, user_id=None, history: History
     if history is not None:
         ptr, srt = history.to_device(dev)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)  # noqa: E731
+    if alias is not None:
+        odds, idx = alias
+        assert odds.is_cuda and odds.dtype == torch.float64 and idx.dtype == torch.int64 and odds.numel() == n_items == idx.numel()
+        check(lib.ur_sample_negatives_pop(p(user_id), p(pos_item.contiguous()), B, K, n_items, history.n_users if history else 0, p(ptr),
+                                          p(srt), p(odds), p(idx), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step) & 0xFFFFFFFF, p(item_id),
+                                          p(label), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ur_sample_negatives_pop")
+        return item_id, label
     check(lib.ur_sample_negatives(p(user_id), p(pos_item.contiguous()), B, K, n_items, history.n_users if history else 0, p(ptr), p(srt),
                                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(step) & 0xFFFFFFFF, p(item_id), p(label),
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ur_sample_negatives")
@@ -139,8 +160,12 @@ class DeviceRowBuilder:
     MASK = {"unorder": 0, "autoregressive": 1}
 
     def __init__(self, n_users, n_items, n_neg, max_seq_len=0, history: HistoryCSR = None, reject_history=True,
-                 mask_mode="autoregressive", seq_last=0, seed=2022, device="cuda:0"):
+                 mask_mode="autoregressive", seq_last=0, seed=2022, device="cuda:0", item_popularity=None, neg_by_pop_alpha=1.0):
         self.n_users, self.n_items, self.n_neg, self.L = n_users, n_items, n_neg, max_seq_len
+        self.alias = None
+        if item_popularity is not None:       # popularity-biased negatives: the alias table lives in HBM
+            odds, idx = alias_table(pop_sample_ratio(item_popularity, neg_by_pop_alpha))
+            self.alias = (torch.from_numpy(odds).to(device), torch.from_numpy(idx).to(device))
         self.history, self.reject, self.seq_last, self.seed = history, bool(reject_history), int(seq_last), int(seed)
         self.mask_mode = self.MASK.get(mask_mode, 2)
         self.device = torch.device(device)
@@ -153,7 +178,7 @@ class DeviceRowBuilder:
         dev = pos_item.device
         B, G = pos_item.numel(), self.n_neg + 1
         item_id, label = sample_negatives_device(pos_item, self.n_neg, self.n_items, user_id,
-                                                 self.history if self.reject else None, self.seed, step)
+                                                 self.history if self.reject else None, self.seed, step, alias=self.alias)
         out = dict(user_id=user_id, item_id=item_id, label=label)
         if with_seq and self.L > 0:
             if self.history is None:
