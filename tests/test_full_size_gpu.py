@@ -1,0 +1,144 @@
+"""BASELINE.json's FULL sizes on one MI355X (configs C5: SASRec N = 100 M x 128, L = 50, K = 4, B = 512; C3: N = 2 M, L = 200,
+K = 1000 softmax, B = 128; C4's encoder: GRU N = 10 M, H = d = 128).
+
+A training step only ever touches the rows its batch looks up, so the reference's arithmetic at full size can be restated
+EXACTLY on the compact sub-table of those rows: ids are re-indexed to their rank among the batch's unique ids, the oracle
+(reference formulas, dense gradient, dense Adam) runs on that [n_uniq, d] table in a second, and everything is compared --
+loss, user embedding, dense gradients, the updated rows.  The rest of the 51 GB table is checked through the properties that do not
+depend on size: untouched rows (sampled) are bit-identical before and after, their moments stay zero, the padding row stays zero."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def _cfg(model, N, d, L, **kw):
+    cfg = dict(model=model, n_users=10, n_items=N, device="cuda:0", loss_type="bpr", embedding_size=d, hidden_size=d, dropout_prob=0.0,
+               init_method="normal", init_mean=0.0, init_std=0.02, has_user_emb=False, has_user_bias=False, has_item_bias=False,
+               distance_type="dot", tau=1.0, train_file_format="user-item", exp_name="t", n_layers=2, n_heads=16, inner_size=512,
+               hidden_dropout_prob=0.0, attn_dropout_prob=0.0, hidden_act="swish", layer_norm_eps=1e-10, max_seq_len=L,
+               use_position_emb=True, seed=2022)
+    cfg.update(kw)
+    return cfg
+
+
+def _batch(N, B, L, K, seed, dev):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    seq = torch.randint(1, N, (B, L), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    lens = torch.randint(1, L + 1, (B,), generator=g, device=dev)
+    lens[::4] = L
+    seq = torch.where(torch.arange(L, device=dev)[None, :] >= (L - lens)[:, None], seq, torch.zeros_like(seq))
+    seq[0, L - 1] = N - 1                      # the last row of the table is looked up
+    item_id = torch.randint(1, N, (B, K + 1), generator=g, device=dev)
+    label = torch.zeros(B, K + 1, dtype=torch.int32, device=dev)
+    label[:, 0] = 1
+    return dict(item_seq=seq.contiguous(), item_id=item_id, label=label)
+
+
+def _check_step_at_full_size(model_cls, cfg, B, K, lr=1e-3):
+    from oracle import model_ref
+    from unirec_amd.facility.optimizer import SparseDenseAdam
+    dev = torch.device("cuda:0")
+    N, d, L = cfg["n_items"], cfg["embedding_size"], cfg["max_seq_len"]
+    torch.manual_seed(1)
+    m = model_cls(cfg)
+    table = m.item_embedding.weight.data
+    assert table.shape == (N, d)
+    opt = SparseDenseAdam(m, lr=lr, table_mode="lazy_dense")
+    batch = _batch(N, B, L, K, 7, dev)
+    # ---- the compact restatement
+    ids = torch.unique(torch.cat([batch["item_seq"].reshape(-1).to(torch.int64), batch["item_id"].reshape(-1),
+                                  torch.zeros(1, dtype=torch.int64, device=dev)]))          # sorted, ids[0] == 0
+    seq_c = torch.searchsorted(ids, batch["item_seq"].to(torch.int64)).to(torch.int32)
+    item_c = torch.searchsorted(ids, batch["item_id"])
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if k != "item_embedding.weight"}
+    P["item_embedding.weight"] = table[ids].cpu().clone()
+    cb = dict(item_seq=seq_c.cpu(), item_id=item_c.cpu(), label=batch["label"].cpu(), user_id=torch.ones(B, dtype=torch.int64))
+    ccfg = dict(cfg, n_items=int(ids.numel()))
+    # ---- untouched rows to watch
+    g = torch.Generator(device=dev).manual_seed(99)
+    watch = torch.randint(1, N, (8192,), generator=g, device=dev)
+    watch = watch[~torch.isin(watch, ids)]
+    before = table[watch].clone()
+    # ---- one HIP step
+    m.train()
+    opt.zero_grad()
+    opt.plan_batch(item_seq=batch["item_seq"], item_id=batch["item_id"])
+    loss, scores, ue, _ = m(item_id=batch["item_id"], label=batch["label"], item_seq=batch["item_seq"], return_loss_only=False)
+    loss.backward()
+    dense_grad = m.dense_flat.grad.clone()
+    opt.step()
+    opt.flush()
+    # ---- oracle: forward / backward / dense Adam on the compact table
+    loss_r, scores_r, ue_r, G_r = model_ref.grads_of(P, cb, ccfg)
+    np.testing.assert_allclose(float(loss), float(loss_r), rtol=RTOL)
+    np.testing.assert_allclose(ue.detach().cpu().numpy(), ue_r.numpy(), rtol=RTOL, atol=1e-5)
+    named = dict(m.named_parameters())
+    for k, ref in G_r.items():
+        if k == "item_embedding.weight" or k.endswith("key.bias"):
+            continue
+        p = named[k]
+        off = (p.data_ptr() - m.dense_flat.data_ptr()) // 4
+        got = dense_grad[off:off + p.numel()].view(p.shape).cpu().numpy()
+        scale = max(1e-8, float(np.abs(ref.numpy()).max()))
+        np.testing.assert_allclose(got / scale, ref.numpy() / scale, rtol=2e-4, atol=2e-5, err_msg=k)
+    state = {}
+    with torch.no_grad():
+        model_ref.adam_step_(P, G_r, state, lr)
+    new_rows = table[ids].cpu().numpy()
+    ref_rows = P["item_embedding.weight"].numpy()
+    gmag = np.abs(G_r["item_embedding.weight"].numpy())
+    sure = gmag > 1e-7 * gmag.max()          # elements whose gradient is not rounding noise: Adam moves them by ~lr * sign
+    assert np.abs(new_rows - ref_rows)[sure].max() < lr * 0.05 and sure.mean() > 0.5
+    assert np.abs(new_rows - ref_rows).max() <= 2 * lr + 1e-6
+    # ---- size-independent properties of everything else
+    assert torch.equal(table[watch], before)                                    # untouched rows: bit-identical
+    st = opt.tables["item_embedding"]
+    assert not st["m"][watch].any() and not st["v"][watch].any()
+    assert not table[0].any()                                                   # padding row
+    assert st["m"][ids[1:]].abs().sum() > 0                                     # touched rows carry moments
+    assert torch.equal(table[N - 1].cpu(), torch.from_numpy(new_rows[-1])) and int(ids[-1]) == N - 1
+    del m, opt
+    torch.cuda.empty_cache()
+
+
+def test_c5_sasrec_100m_items_step_equals_the_oracle_on_the_touched_rows():
+    from unirec_amd.model.sequential.sasrec import SASRec
+    _check_step_at_full_size(SASRec, _cfg("SASRec", 100_000_000, 128, 50), B=512, K=4)
+
+
+def test_c3_sasrec_2m_items_L200_K1000_softmax_step():
+    from unirec_amd.model.sequential.sasrec import SASRec
+    _check_step_at_full_size(SASRec, _cfg("SASRec", 2_000_000, 128, 200, loss_type="softmax"), B=128, K=1000)
+
+
+def test_c4_gru_10m_items_step():
+    from unirec_amd.model.sequential.gru import GRU
+    _check_step_at_full_size(GRU, _cfg("GRU", 10_000_000, 128, 50, loss_type="softmax"), B=512, K=4)
+
+
+def test_full_rank_and_topk_agree_at_100m_items():
+    """ur_full_rank and ur_full_topk at N = 100 M: the i-th best item of a row has rank i; scaling the user vectors leaves every
+    rank unchanged (no biases); a target inside the history still gets its rank among the others."""
+    from unirec_amd import ops
+    dev = torch.device("cuda:0")
+    N, d, B, k = 100_000_000, 128, 64, 8
+    g = torch.Generator(device=dev).manual_seed(5)
+    table = torch.empty(N, d, device=dev).normal_(0.0, 0.02, generator=g)
+    table[0] = 0
+    ue = torch.randn(B, d, generator=g, device=dev)
+    sc, ids = ops.full_topk(ue, table, k)
+    assert int(ids.min()) >= 1 and int(ids.max()) < N and bool((sc[:, :-1] >= sc[:, 1:]).all())
+    distinct = (sc[:, :-1] > sc[:, 1:]).all(1)
+    for j in (0, 3, k - 1):
+        r, ts = ops.full_rank(ue, table, ids[:, j].contiguous())
+        assert torch.equal(r[distinct].cpu(), torch.full((int(distinct.sum()),), j, dtype=torch.int32))
+        np.testing.assert_allclose(ts.cpu().numpy(), sc[:, j].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    tgt = torch.randint(1, N, (B,), generator=g, device=dev)
+    r1, _ = ops.full_rank(ue, table, tgt)
+    r2, _ = ops.full_rank(ue * 4.0, table, tgt)             # power-of-two scale: every score scales exactly
+    assert torch.equal(r1, r2) and int(r1.max()) < N
+    del table
+    torch.cuda.empty_cache()
