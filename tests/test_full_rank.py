@@ -189,7 +189,8 @@ def test_gpu_topk_matches_reference_golden(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,d,B,k,bias", [(1017, 32, 40, 10, True), (5003, 64, 33, 100, False), (300, 16, 7, 400, True),
-                                          (2_300_001, 32, 9, 50, True), (40960, 128, 130, 1024, False)])
+                                          (2_300_001, 32, 9, 50, True), (40960, 128, 130, 1024, False),
+                                          (3_200_003, 128, 70, 20, False), (2_200_000, 64, 5, 1000, True)])   # >= 3 chunks: pruned path (+ overflow fallback)
 def test_gpu_topk_matches_oracle(N, d, B, k, bias):
     from unirec_amd import ops
     from unirec_amd.data.rows import HistoryCSR
@@ -272,3 +273,15 @@ def test_sharded_two_phase_count_equals_the_whole_catalogue(d, W, with_bias):
                                   hist_sorted_local=args[r][2], item_bias_local=sbias[r], n_rows=args[r][3], excl_row=args[r][4])
               for r in range(W))
     assert torch.equal(got.cpu().to(torch.int32), want.cpu()), (got.cpu(), want.cpu())
+
+
+@pytest.mark.gpu
+def test_topk_candidate_overflow_falls_back_to_the_chunked_path():
+    """UR_TOPK_CAP=16 forces every row's candidate list of the pruned path to overflow; the result must still be the oracle's."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, UR_TOPK_CAP="16")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "test_gpu_topk_matches_oracle and 3200003"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

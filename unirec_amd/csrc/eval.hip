@@ -7,7 +7,10 @@
 // (rank_stream_kernel, d <= 128; wider d: gemm_nt with the EPI_COUNT_GT epilogue): the [B,N] score matrix is never
 // written.  The second term is a sparse gather-dot over each user's (sorted) history.
 // Scores are compared in the un-normalised space  u.E_n + item_bias[n]  (user bias cancels, tau > 0 is monotone).
+#include <stdlib.h>
+
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -142,7 +145,9 @@ struct RankArgs {
   const long long* target; const long long* user_id;
   long long N; int B, d, splits; float tau;
   float* thr; float* target_score; int* counts;
-  int mode;   // 0: thresholds from the diagonal tile, then count;  1: thresholds only (target < 0 -> 0);  2: count against the given thr
+  int mode;   // 0: thresholds from the diagonal tile, then count;  1: thresholds only (target < 0 -> 0);  2: count against the given thr;
+              // 3: EMIT every (score, item) with score > thr[row] into the row's candidate list (top-k pruning), counts = list lengths
+  float* cand_v; long long* cand_i; int cap;
 };
 
 template <int KC>
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(512) void rank_stream_kernel(RankArgs a) {
   const int m0 = mt * BM;
   const long long ntn = (a.N + BN - 1) / BN, tps = (ntn + a.splits - 1) / a.splits;
   const long long t_begin = (long long)split * tps, t_end = a.mode == 1 ? t_begin : min(ntn, t_begin + tps);
-  if (a.mode == 1 ? split != 0 : (t_begin >= t_end && (split != 0 || a.mode == 2))) return;   // split 0 publishes thr / target_score
+  if (a.mode == 1 ? split != 0 : (t_begin >= t_end && (split != 0 || a.mode >= 2))) return;   // split 0 publishes thr / target_score
 
   // ---- user tile -> LDS (zero fill beyond B and beyond d)
   for (int idx = tid; idx < BM * 8 * KC; idx += 512) {
@@ -208,8 +213,8 @@ __global__ __launch_bounds__(512) void rank_stream_kernel(RankArgs a) {
     }
 
   const int frow = lane & 31, fk = 4 * (lane >> 5), lcol = lane & 31, lrow4 = 4 * (lane >> 5);
-  long long tile = a.mode == 2 ? t_begin : -1;
-  if (a.mode == 2) {   // thresholds given (computed by the shard that owns each target, with the same MFMA sequence)
+  long long tile = a.mode >= 2 ? t_begin : -1;
+  if (a.mode >= 2) {   // thresholds given (computed by the shard that owns each target, with the same MFMA sequence)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -289,6 +294,24 @@ __global__ __launch_bounds__(512) void rank_stream_kernel(RankArgs a) {
         a.thr[m] = (a.mode == 1 && a.target[m] < 0) ? 0.f : thr_s[tid];
         if (a.target_score) a.target_score[m] = (thr_s[tid] + (a.user_bias ? a.user_bias[a.user_id[m]] : 0.f)) / a.tau;
       }
+    } else if (a.mode == 3) {
+      // top-k pruning: the thresholds are (a lower bound of) each row's k-th best score, so almost nothing passes
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r] + bias[j];
+            if (v > thr_r[i][r]) {
+              const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
+              const int slot = atomicAdd(a.counts + m, 1);
+              if (slot < a.cap) {
+                a.cand_v[(long long)m * a.cap + slot] = v;
+                a.cand_i[(long long)m * a.cap + slot] = tile * BN + wc * 64 + j * 32 + lcol;
+              }
+            }
+          }
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -477,6 +500,39 @@ __global__ void topk_finish_kernel(float* __restrict__ vals, long long* __restri
   else ids[i] = -1;   // fewer than k admissible items: masked entries are reported as (-inf, -1)
 }
 
+// pruned top-k, step 1: thr[b] = (k-th best score of the first chunk) lowered by a rounding margin -- the first chunk was scored
+// by gemm_nt, the stream accumulates in another order
+__global__ void topk_threshold_kernel(const float* __restrict__ kth, long long ld, int B, float* __restrict__ thr) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float v = kth[(long long)b * ld];
+  thr[b] = v == -INFINITY ? -INFINITY : v - (1e-4f * fabsf(v) + 1e-6f);
+}
+// pruned top-k, step 3: candidates that are the padding row or in the user's history leave (score = -inf)
+__global__ __launch_bounds__(256) void cand_filter_kernel(float* __restrict__ cand_v, const long long* __restrict__ cand_i, int cap,
+                                                          const int* __restrict__ counts, const long long* __restrict__ user_id,
+                                                          const long long* __restrict__ hist_ptr, const int* __restrict__ hist_sorted,
+                                                          long long n_users) {
+  const int b = blockIdx.x;
+  const int n = min(counts[b], cap);
+  const long long u = (hist_ptr && user_id) ? user_id[b] : -1;
+  const bool known = hist_ptr && u >= 0 && u < n_users;
+  const long long hb = known ? hist_ptr[u] : 0, he = known ? hist_ptr[u + 1] : 0;
+  for (int q = threadIdx.x; q < n; q += 256) {
+    const long long id = cand_i[(long long)b * cap + q];
+    bool drop = id == 0;
+    if (!drop && he > hb) {
+      long long lo = hb, hi = he;
+      while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (hist_sorted[mid] < id) lo = mid + 1; else hi = mid;
+      }
+      drop = lo < he && hist_sorted[lo] == id;
+    }
+    if (drop) cand_v[(long long)b * cap + q] = -INFINITY;
+  }
+}
+
 }  // namespace ur
 
 using namespace ur;
@@ -577,7 +633,7 @@ extern "C" int64_t ur_full_topk_workspace_bytes(int32_t B, int64_t n_items, int3
   if (B <= 0 || n_items <= 0 || k <= 0) return UR_ERR_ARG;
   const long long chunk = std::min<long long>((n_items + 3) & ~3LL, UR_TOPK_CHUNK);
   const long long nchunks = (n_items + chunk - 1) / chunk;
-  return (long long)B * chunk * 4 + (long long)B * nchunks * k * (4 + 8) + 1024;
+  return (long long)B * chunk * 4 + (long long)B * nchunks * k * (4 + 8) + 1024 + (long long)B * 16 + 4096;
 }
 
 extern "C" int ur_full_topk(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d, int32_t k,
@@ -597,7 +653,17 @@ extern "C" int ur_full_topk(const float* user_emb, const float* item_table, int6
   float* S = (float*)ws;                                               // [B, chunk]
   float* cand_v = S + (long long)B * chunk;                            // [B, nchunks * k]
   long long* cand_i = (long long*)(((uintptr_t)(cand_v + (long long)B * nchunks * k) + 15) & ~(uintptr_t)15);
-  for (long long ci = 0; ci < nchunks; ++ci) {
+  // ---- pruned path (large catalogues): the first chunk goes through the loop below and yields a lower bound of every row's
+  // k-th best score; then ALL items are streamed once by the ranking kernel in EMIT mode -- scores stay in the MFMA accumulators,
+  // only the few that beat the bound are written -- and the k best of those candidates are the answer.  No [B, N] score ever
+  // reaches HBM.  Falls back to the chunked path when a row's candidate list overflows (k * N / chunk too large).
+  static const bool no_prune = getenv("UR_TOPK_NO_PRUNE") != nullptr;   // test / tuning hook
+  static const long long cap_env = getenv("UR_TOPK_CAP") ? atoll(getenv("UR_TOPK_CAP")) : 0;   // test hook: force list overflows
+  const long long cap = cap_env > 0 ? cap_env : std::min<long long>(chunk / 4, std::max<long long>(4096, 8LL * k * nchunks));
+  const bool prune = !no_prune && d <= 128 && nchunks >= 3 && B <= 4096;
+  int* cnt = (int*)(((uintptr_t)(cand_i + (long long)B * nchunks * k) + 15) & ~(uintptr_t)15);   // [B] list lengths
+  float* thr = (float*)(cnt + B);                                                                  // [B]
+  auto topk_chunk = [&](long long ci) -> int {
     const long long c0 = ci * chunk, cn = std::min(chunk, n_items - c0), cn4 = cn & ~3LL;
     if (cn4 > 0) {
       GemmArgs g{};
@@ -619,8 +685,50 @@ extern "C" int ur_full_topk(const float* user_emb, const float* item_table, int6
     hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, S, chunk, (const long long*)nullptr, 0LL, cn, c0, k, ov, oi,
                        nchunks == 1 ? (long long)k : nchunks * k, nchunks == 1 ? 0LL : ci * k);
     UR_LAUNCH_CHECK();
+    return UR_OK;
+  };
+  for (long long ci = 0; ci < (prune ? 1 : nchunks); ++ci) {
+    int rc = topk_chunk(ci);
+    if (rc) return rc;
   }
-  if (nchunks > 1) {
+  if (prune) {
+    // thresholds from the first chunk's k-th best (slot k-1 of its sorted winners; -inf when it had fewer than k admissible items)
+    hipLaunchKernelGGL(topk_threshold_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, cand_v + (k - 1), nchunks * k, B, thr);
+    UR_LAUNCH_CHECK();
+    float* ev = S;                                                                       // [B, cap] -- the score chunk is dead now
+    long long* ei = (long long*)(((uintptr_t)(S + (long long)B * cap) + 15) & ~(uintptr_t)15);   // [B, cap]
+    UR_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * B, st));
+    UR_HIP(hipMemsetD32Async((hipDeviceptr_t)ev, 0xFF800000u, (size_t)B * cap, st));   // -inf: unused slots never win
+    RankArgs a{};
+    a.B = B; a.user_emb = user_emb; a.table = item_table; a.item_bias = item_bias; a.N = n_items; a.d = d; a.tau = 1.f; a.mode = 3;
+    a.thr = thr; a.counts = cnt; a.cand_v = ev; a.cand_i = ei; a.cap = (int)cap;
+    const int ntm = cdiv(B, 128);
+    a.splits = 8 * std::max(1, 32 / ntm);
+    int rc = d <= 32 ? launch_rank_stream<1>(a, st) : d <= 64 ? launch_rank_stream<2>(a, st)
+           : d <= 96 ? launch_rank_stream<3>(a, st) : launch_rank_stream<4>(a, st);
+    if (rc) return rc;
+    std::vector<int> h_cnt(B);
+    UR_HIP(hipMemcpyAsync(h_cnt.data(), cnt, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    UR_HIP(hipStreamSynchronize(st));
+    bool overflow = false;
+    for (int b = 0; b < B; ++b) overflow |= h_cnt[b] > cap;
+    if (!overflow) {
+      hipLaunchKernelGGL(cand_filter_kernel, dim3(B), dim3(256), 0, st, ev, ei, (int)cap, cnt, (const long long*)user_id,
+                         (const long long*)hist_ptr, hist_sorted, (long long)n_users);
+      UR_LAUNCH_CHECK();
+      hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, ev, cap, ei, cap, cap, 0LL, k, topk_scores, (long long*)topk_ids,
+                         (long long)k, 0LL);
+      UR_LAUNCH_CHECK();
+    } else {   // a candidate list overflowed: redo the remaining chunks the slow way (chunk 0's winners are still in place)
+      for (long long ci = 1; ci < nchunks; ++ci) {
+        int rc2 = topk_chunk(ci);
+        if (rc2) return rc2;
+      }
+      hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, cand_v, nchunks * k, cand_i, nchunks * k, nchunks * k, 0LL, k,
+                         topk_scores, (long long*)topk_ids, (long long)k, 0LL);
+      UR_LAUNCH_CHECK();
+    }
+  } else if (nchunks > 1) {
     hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, cand_v, nchunks * k, cand_i, nchunks * k, nchunks * k, 0LL, k,
                        topk_scores, (long long*)topk_ids, (long long)k, 0LL);
     UR_LAUNCH_CHECK();
