@@ -653,18 +653,23 @@ extern "C" int ur_full_topk(const float* user_emb, const float* item_table, int6
   float* S = (float*)ws;                                               // [B, chunk]
   float* cand_v = S + (long long)B * chunk;                            // [B, nchunks * k]
   long long* cand_i = (long long*)(((uintptr_t)(cand_v + (long long)B * nchunks * k) + 15) & ~(uintptr_t)15);
-  // ---- pruned path (large catalogues): the first chunk goes through the loop below and yields a lower bound of every row's
+  // ---- pruned path (catalogues of 256 K items and more): a first range goes through the score-matrix pipeline and yields a lower bound of every row's
   // k-th best score; then ALL items are streamed once by the ranking kernel in EMIT mode -- scores stay in the MFMA accumulators,
   // only the few that beat the bound are written -- and the k best of those candidates are the answer.  No [B, N] score ever
   // reaches HBM.  Falls back to the chunked path when a row's candidate list overflows (k * N / chunk too large).
   static const bool no_prune = getenv("UR_TOPK_NO_PRUNE") != nullptr;   // test / tuning hook
   static const long long cap_env = getenv("UR_TOPK_CAP") ? atoll(getenv("UR_TOPK_CAP")) : 0;   // test hook: force list overflows
-  const long long cap = cap_env > 0 ? cap_env : std::min<long long>(chunk / 4, std::max<long long>(4096, 8LL * k * nchunks));
-  const bool prune = !no_prune && d <= 128 && nchunks >= 3 && B <= 4096;
+  // size of the first range: large enough that few items beat its k-th best (expected survivors per row: k * N / first),
+  // small enough that the score-matrix pipeline over it is a fraction of the streaming pass
+  const long long first = std::min<long long>(chunk, std::max<long long>(65536, (n_items / 16) & ~3LL));
+  const long long cap = cap_env > 0 ? cap_env
+                                    : std::min<long long>(chunk / 4, std::max<long long>(4096, 8LL * k * ((n_items + first - 1) / first)));
+  const bool prune = !no_prune && d <= 128 && n_items >= 262144 && B <= 4096 && (long long)k * 64 <= first;
   int* cnt = (int*)(((uintptr_t)(cand_i + (long long)B * nchunks * k) + 15) & ~(uintptr_t)15);   // [B] list lengths
   float* thr = (float*)(cnt + B);                                                                  // [B]
-  auto topk_chunk = [&](long long ci) -> int {
-    const long long c0 = ci * chunk, cn = std::min(chunk, n_items - c0), cn4 = cn & ~3LL;
+  // k best of items [c0, c0 + cn) -> slot `slot` of the per-chunk winners (or the final output when direct)
+  auto topk_range = [&](long long c0, long long cn, long long slot, bool direct) -> int {
+    const long long cn4 = cn & ~3LL;
     if (cn4 > 0) {
       GemmArgs g{};
       g.A = user_emb; g.lda = d; g.W = item_table + (size_t)c0 * d; g.ldw = d; g.C = S; g.ldc = (int)chunk; g.M = B; g.N = (int)cn4; g.K = d;
@@ -680,16 +685,22 @@ extern "C" int ur_full_topk(const float* user_emb, const float* item_table, int6
     hipLaunchKernelGGL(mask_scores_kernel, dim3(B), dim3(256), 0, st, S, chunk, B, c0, cn, (const long long*)user_id,
                        (const long long*)hist_ptr, hist_sorted, (long long)n_users);
     UR_LAUNCH_CHECK();
-    float* ov = nchunks == 1 ? topk_scores : cand_v;
-    long long* oi = nchunks == 1 ? (long long*)topk_ids : cand_i;
+    float* ov = direct ? topk_scores : cand_v;
+    long long* oi = direct ? (long long*)topk_ids : cand_i;
     hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, S, chunk, (const long long*)nullptr, 0LL, cn, c0, k, ov, oi,
-                       nchunks == 1 ? (long long)k : nchunks * k, nchunks == 1 ? 0LL : ci * k);
+                       direct ? (long long)k : nchunks * k, direct ? 0LL : slot * k);
     UR_LAUNCH_CHECK();
     return UR_OK;
   };
-  for (long long ci = 0; ci < (prune ? 1 : nchunks); ++ci) {
-    int rc = topk_chunk(ci);
+  auto topk_chunk = [&](long long ci) -> int { return topk_range(ci * chunk, std::min(chunk, n_items - ci * chunk), ci, nchunks == 1); };
+  if (prune) {
+    int rc = topk_range(0, first, 0, false);
     if (rc) return rc;
+  } else {
+    for (long long ci = 0; ci < nchunks; ++ci) {
+      int rc = topk_chunk(ci);
+      if (rc) return rc;
+    }
   }
   if (prune) {
     // thresholds from the first chunk's k-th best (slot k-1 of its sorted winners; -inf when it had fewer than k admissible items)
@@ -719,14 +730,16 @@ extern "C" int ur_full_topk(const float* user_emb, const float* item_table, int6
       hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, ev, cap, ei, cap, cap, 0LL, k, topk_scores, (long long*)topk_ids,
                          (long long)k, 0LL);
       UR_LAUNCH_CHECK();
-    } else {   // a candidate list overflowed: redo the remaining chunks the slow way (chunk 0's winners are still in place)
-      for (long long ci = 1; ci < nchunks; ++ci) {
+    } else {   // a candidate list overflowed: the chunked path, from the start
+      for (long long ci = 0; ci < nchunks; ++ci) {
         int rc2 = topk_chunk(ci);
         if (rc2) return rc2;
       }
-      hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, cand_v, nchunks * k, cand_i, nchunks * k, nchunks * k, 0LL, k,
-                         topk_scores, (long long*)topk_ids, (long long)k, 0LL);
-      UR_LAUNCH_CHECK();
+      if (nchunks > 1) {
+        hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, cand_v, nchunks * k, cand_i, nchunks * k, nchunks * k, 0LL, k,
+                           topk_scores, (long long*)topk_ids, (long long)k, 0LL);
+        UR_LAUNCH_CHECK();
+      }
     }
   } else if (nchunks > 1) {
     hipLaunchKernelGGL(row_topk_kernel, dim3(B), dim3(256), 0, st, cand_v, nchunks * k, cand_i, nchunks * k, nchunks * k, 0LL, k,
