@@ -39,9 +39,11 @@ struct AttnDims {
 __device__ __forceinline__ unsigned attn_rowkey(const AttnDims& p, int b, int h, int i) {
   return mix32((unsigned)((b * p.H + h) * p.L + i) ^ p.dkey);
 }
-// multiplier of P[i,j] (1 when dropout is off)
+// multiplier of P[i,j]; DROP is a compile-time switch: the kernels without dropout carry none of this
+template <bool DROP>
 __device__ __forceinline__ float attn_keep(const AttnDims& p, unsigned rowkey, int j) {
-  return p.dthresh ? drop_mul(rowkey, (unsigned)j, p.dthresh, p.dscale) : 1.0f;
+  if constexpr (DROP) return drop_mul(rowkey, (unsigned)j, p.dthresh, p.dscale);
+  else return 1.0f;
 }
 // first row of sequence b's (virtual) position 0 and the number of leading positions that have no row
 __device__ __forceinline__ void seq_rows(const AttnDims& p, int b, long long& row0, int& pad) {
@@ -70,7 +72,7 @@ __device__ __forceinline__ int first_valid_key(const int* __restrict__ sq, int L
   return L;
 }
 
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ seq, AttnDims p,
                                                        float* __restrict__ ctx, float* __restrict__ lse) {
   const int lane = threadIdx.x & 63;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
       const float s = dot_u<HD>(q, Kb + (long long)j * ld) * p.scale;
       const float pj = (sq[j] > 0 && (!p.causal || j <= i)) ? __expf(s - m) : 0.f;
       l += pj;
-      const float pd = pj * attn_keep(p, rk, j);
+      const float pd = pj * attn_keep<DROP>(p, rk, j);
       const float* __restrict__ vr = Vb + (long long)j * ld;
 #pragma unroll
       for (int c = 0; c < HD; ++c) o[c] = fmaf(pd, vr[c], o[c]);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     for (int j = 0; j < L; ++j) {
       const float pj = __expf((dot_u<HD>(q, Kb + (long long)j * ld) / p.sqrt_hd + -10000.0f) - m);
       l += pj;
-      const float pd = pj * attn_keep(p, rk, j);
+      const float pd = pj * attn_keep<DROP>(p, rk, j);
       const float* __restrict__ vr = Vb + (long long)j * ld;
 #pragma unroll
       for (int c = 0; c < HD; ++c) o[c] = fmaf(pd, vr[c], o[c]);
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
 }
 
 // Backward. dqkv[:, 0:d] = dQ, [d:2d] = dK, [2d:3d] = dV.  Row pass then column pass, same wave, no LDS.
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
                                                        const float* __restrict__ dctx, const float* __restrict__ lse,
                                                        const float* __restrict__ Dd, AttnDims p, float* __restrict__ dqkv) {
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const float* __restrict__ kr = Kb + (long long)j * ld;
         const float s = dot_u<HD>(q, kr) * p.scale;
         const float pj = (live && sq[j] > 0 && (!p.causal || j <= r)) ? __expf(s - li) : 0.f;
-        const float ds = pj * (attn_keep(p, rk, j) * dot_u<HD>(g, Vb + (long long)j * ld) - Di);
+        const float ds = pj * (attn_keep<DROP>(p, rk, j) * dot_u<HD>(g, Vb + (long long)j * ld) - Di);
 #pragma unroll
         for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
       }
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       for (int j = 0; j < L; ++j) {
         const float* __restrict__ kr = Kb + (long long)j * ld;
         const float pj = __expf((dot_u<HD>(q, kr) / p.sqrt_hd + -10000.0f) - li);
-        const float ds = pj * (attn_keep(p, rk, j) * dot_u<HD>(g, Vb + (long long)j * ld) - Di);
+        const float ds = pj * (attn_keep<DROP>(p, rk, j) * dot_u<HD>(g, Vb + (long long)j * ld) - Di);
 #pragma unroll
         for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
       }
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const float* __restrict__ gr = gbase + (long long)i * p.d;
         const float s = dot_u<HD>(k, qr) * p.scale;
         const float pj = (vj && (!p.causal || r <= i)) ? __expf(s - lse_h[i]) : 0.f;
-        const float mk = attn_keep(p, attn_rowkey(p, b, h, i), rr);
+        const float mk = attn_keep<DROP>(p, attn_rowkey(p, b, h, i), rr);
         const float ds = pj * (mk * dot_u<HD>(v, gr) - D_h[i]) * p.scale;
         const float pd = pj * mk;
 #pragma unroll
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const float* __restrict__ qr = Qb + (long long)i * ld;
         const float* __restrict__ gr = gbase + (long long)i * p.d;
         const float pj = __expf((dot_u<HD>(k, qr) / p.sqrt_hd + -10000.0f) - lse_h[i]);
-        const float mk = attn_keep(p, attn_rowkey(p, b, h, i), rr);
+        const float mk = attn_keep<DROP>(p, attn_rowkey(p, b, h, i), rr);
         const float ds = pj * (mk * dot_u<HD>(v, gr) - D_h[i]) / p.sqrt_hd;
         const float pd = pj * mk;
 #pragma unroll
@@ -293,7 +295,7 @@ __device__ __forceinline__ void store_vec(float* __restrict__ dst, const float (
 // Last-row specialisation: in the final layer only the query at position L-1 can reach the loss,
 // so attention degenerates to ONE query per (sequence, head).  Here one wave = one (sequence, head), lanes = keys:
 // the softmax max / sum and the P.V contraction are wavefront xor-shuffle reductions.
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restrict__ q_last, const float* __restrict__ qkv,
                                                             const int* __restrict__ seq, AttnDims p, float* __restrict__ ctx_last,
                                                             float* __restrict__ lse_last) {
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restr
     const float corr = __expf(m - mn);
     const float pj = allowed ? __expf(sv - mn) : 0.f;
     l = l * corr + wave_sum(pj);
-    const float pd = pj * attn_keep(p, rk, j);
+    const float pd = pj * attn_keep<DROP>(p, rk, j);
 #pragma unroll
     for (int c = 0; c < HD; ++c) o[c] = o[c] * corr + wave_sum(pd * vr[c]);
     m = mn;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restr
 }
 
 // dq_last [B,d]; dK, dV written into dqkv[:, d:3d] for ALL rows (zeros where the key is masked); dqkv[:, 0:d] untouched.
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restrict__ q_last, const float* __restrict__ qkv,
                                                             const int* __restrict__ seq, const float* __restrict__ ctx_last,
                                                             const float* __restrict__ dctx_last, const float* __restrict__ lse_last,
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restr
     const bool allowed = in && (literal || sq[min(j, L - 1)] > 0);   // the mask is indexed by position, not by (clamped) row
     const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
     const float pj = allowed ? __expf(sv - ls) : 0.f;
-    const float mk = attn_keep(p, rk, j);
+    const float mk = attn_keep<DROP>(p, rk, j);
     const float ds = pj * (mk * dp - D) * f;
     if (in && j >= pad) {
       float* out = dqkv + (row0 + j) * ld + h * HD;
@@ -418,7 +420,7 @@ __device__ __forceinline__ float bcast(float v, int src_lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restrict__ qkv, const int* __restrict__ seq, AttnDims p,
                                                           float* __restrict__ ctx, float* __restrict__ lse) {
   const int lane = threadIdx.x & 63;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restric
           } else {
             float pa = oka ? __expf(sa - m) : 0.f, pb = okb ? __expf(sb - m) : 0.f;
             l += pa + pb;
-            if (p.dthresh) { pa *= attn_keep(p, rk, kc * 64 + jj); pb *= attn_keep(p, rk, kc * 64 + jj + 1); }
+            if constexpr (DROP) { pa *= attn_keep<DROP>(p, rk, kc * 64 + jj); pb *= attn_keep<DROP>(p, rk, kc * 64 + jj + 1); }
             float va[HD], vb[HD];
 #pragma unroll
             for (int c = 0; c < HD; ++c) { va[c] = bcast(vreg[c], jj); vb[c] = bcast(vreg[c], jj + 1); }
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restric
           } else {
             float pa = oka ? __expf(sa - m) : 0.f;
             l += pa;
-            pa *= attn_keep(p, rk, kc * 64 + jj);
+            pa *= attn_keep<DROP>(p, rk, kc * 64 + jj);
 #pragma unroll
             for (int c = 0; c < HD; ++c) o[c] = fmaf(pa, bcast(vreg[c], jj), o[c]);
           }
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restric
     for (int j = 0; j < L; ++j) {
       const float pj = __expf((dot_u<HD>(q, Kb + (long long)j * ld) / p.sqrt_hd + -10000.0f) - m);
       l += pj;
-      const float pd = pj * attn_keep(p, rk, j);
+      const float pd = pj * attn_keep<DROP>(p, rk, j);
       const float* __restrict__ vr = Vb + (long long)j * ld;
 #pragma unroll
       for (int c = 0; c < HD; ++c) o[c] = fmaf(pd, vr[c], o[c]);
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(256) void attn_fwd_rl_kernel(const float* __restric
   lse[((long long)b * p.H + h) * L + i] = dead ? 0.f : m + __logf(l);
 }
 
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_rl_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
                                                           const float* __restrict__ ctx, const float* __restrict__ dctx,
                                                           const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rl_kernel(const float* __restric
         const int j = kc * 64 + jj;
         const bool ok = live && ((vmask >> jj) & 1ull) && (literal || !p.causal || j <= r);
         const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
-        const float ds = ok ? __expf(sv - lr) * (attn_keep(p, rk, j) * dp - Dr) : 0.f;
+        const float ds = ok ? __expf(sv - lr) * (attn_keep<DROP>(p, rk, j) * dp - Dr) : 0.f;
 #pragma unroll
         for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kj[c], dq[c]);
       }
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rl_kernel(const float* __restric
         const bool ok = vj && (literal || !p.causal || r <= i);
         const float sv = literal ? s / p.sqrt_hd + -10000.0f : s * p.scale;
         const float pj = ok ? __expf(sv - bcast(lq, it)) : 0.f;
-        const float mk = attn_keep(p, attn_rowkey(p, b, h, i), rr);
+        const float mk = attn_keep<DROP>(p, attn_rowkey(p, b, h, i), rr);
         const float ds = pj * (mk * dp - bcast(Dq, it));
         const float pd = pj * mk;
 #pragma unroll
@@ -671,7 +673,7 @@ long long attn_bwd_ws_floats(int B, int H, int L) { return (long long)B * H * L 
 // Masks, dead rows and the literal (-10000) path of an all-padding sequence are those of attn_fwd_rl_kernel.
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, const int* __restrict__ seq, AttnDims p,
                                                             float* __restrict__ ctx, float* __restrict__ lse) {
   constexpr int KH = HD / 2;
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
       }
     }
     l[it] += __shfl_xor(l[it], 32, 64);
-    if (p.dthresh) {   // dropout on the probabilities (the normaliser l is that of the undropped softmax)
+    if constexpr (DROP) {   // dropout on the probabilities (the normaliser l is that of the undropped softmax)
       const unsigned rk = attn_rowkey(p, b, h, it * 32 + c32);
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
@@ -830,7 +832,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
 //                        dV^T = dO^T P and dK^T = Q^T dS, again with P / dS straight from the accumulators.
 // Q, K, V, dO rows go through per-wave LDS tiles once (lane = row, one global round trip); the "gathered" A operands
 // (rows picked in accumulator-register order) and the per-query lse / D values are read from there.
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
                                                             const float* __restrict__ ctx, const float* __restrict__ dctx,
                                                             const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
           const float e = literal ? (sT[r] / p.sqrt_hd + -10000.0f) * LOG2E : sT[r] * sc2;
           const float pv = (vis >> ((r & 3) + 8 * (r >> 2))) & 1u ? __builtin_amdgcn_exp2f(e - lse2) : 0.f;
-          const float mk = attn_keep(p, rk, jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2);
+          const float mk = attn_keep<DROP>(p, rk, jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2);
           sT[r] = pv * (mk * dpT[r] - Di);   // dS^T
         }
 #pragma unroll
@@ -970,7 +972,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
           const int il = (r & 3) + 8 * (r >> 2), i = it * 32 + il + 4 * h2;
           const float e = literal ? (sM[r] / p.sqrt_hd + -10000.0f) * LOG2E : sM[r] * sc2;
           const float pv = (vis >> il) & 1u ? __builtin_amdgcn_exp2f(e - rowv[w][0][i]) : 0.f;
-          const float mk = p.dthresh ? drop_mul(rowk[w][i], (unsigned)j, p.dthresh, p.dscale) : 1.0f;
+          const float mk = DROP ? drop_mul(rowk[w][i], (unsigned)j, p.dthresh, p.dscale) : 1.0f;
           sM[r] = pv * mk;                             // dropout(P)
           dpM[r] = pv * (mk * dpM[r] - rowv[w][1][i]); // dS
         }
@@ -997,6 +999,13 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
     }
   }
 }
+
+// launches KERNEL<HD, true> when dropout is on (p.dthresh != 0), KERNEL<HD, false> otherwise
+#define UR_ATTN_LAUNCH(KERNEL, HD, ...)                                   \
+  do {                                                                    \
+    if (p.dthresh) hipLaunchKernelGGL((KERNEL<HD, true>), __VA_ARGS__);   \
+    else hipLaunchKernelGGL((KERNEL<HD, false>), __VA_ARGS__);            \
+  } while (0)
 
 static int make_dims(int B, int L, int d, int H, int causal, AttnDims* p) {
   if (H <= 0 || d % H) return fail(UR_ERR_ARG, "attention: d=%d not divisible by n_heads=%d", d, H);
@@ -1033,15 +1042,15 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
   if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
     dim3 g2(B, cdiv(H, 4));
-    if (p.hd == 4) hipLaunchKernelGGL((attn_fwd_mfma_kernel<4>), g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
-    else if (p.hd == 8) hipLaunchKernelGGL((attn_fwd_mfma_kernel<8>), g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
-    else hipLaunchKernelGGL((attn_fwd_mfma_kernel<16>), g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
+    if (p.hd == 4) UR_ATTN_LAUNCH(attn_fwd_mfma_kernel, 4, g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
+    else if (p.hd == 8) UR_ATTN_LAUNCH(attn_fwd_mfma_kernel, 8, g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
+    else UR_ATTN_LAUNCH(attn_fwd_mfma_kernel, 16, g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
     UR_LAUNCH_CHECK();
     return UR_OK;
   }
   dim3 grid(B, cdiv(H * p.nchunk, 4));
-#define GO(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, p, ctx, lse)
-#define GR(HD) hipLaunchKernelGGL((attn_fwd_rl_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, p, ctx, lse)
+#define GO(HD) UR_ATTN_LAUNCH(attn_fwd_kernel, HD, grid, dim3(256), 0, st, qkv, seq, p, ctx, lse)
+#define GR(HD) UR_ATTN_LAUNCH(attn_fwd_rl_kernel, HD, grid, dim3(256), 0, st, qkv, seq, p, ctx, lse)
   switch (p.hd) {   // small heads: register-broadcast kernels; large heads: scalar-load kernels
     case 2: GR(2); break;
     case 4: GR(4); break;
@@ -1071,9 +1080,9 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
   if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
     dim3 g2(B, cdiv(H, 4));
-    if (p.hd == 4) hipLaunchKernelGGL((attn_bwd_mfma_kernel<4>), g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
-    else if (p.hd == 8) hipLaunchKernelGGL((attn_bwd_mfma_kernel<8>), g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
-    else hipLaunchKernelGGL((attn_bwd_mfma_kernel<16>), g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
+    if (p.hd == 4) UR_ATTN_LAUNCH(attn_bwd_mfma_kernel, 4, g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
+    else if (p.hd == 8) UR_ATTN_LAUNCH(attn_bwd_mfma_kernel, 8, g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
+    else UR_ATTN_LAUNCH(attn_bwd_mfma_kernel, 16, g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
     UR_LAUNCH_CHECK();
     return UR_OK;
   }
@@ -1083,8 +1092,8 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(B), dim3(256), 0, st, ctx, dctx, p, Dd);
     UR_LAUNCH_CHECK();
   }
-#define GO(HD) hipLaunchKernelGGL((attn_bwd_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, dctx, lse, Dd, p, dqkv)
-#define GR(HD) hipLaunchKernelGGL((attn_bwd_rl_kernel<HD>), grid, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv)
+#define GO(HD) UR_ATTN_LAUNCH(attn_bwd_kernel, HD, grid, dim3(256), 0, st, qkv, seq, dctx, lse, Dd, p, dqkv)
+#define GR(HD) UR_ATTN_LAUNCH(attn_bwd_rl_kernel, HD, grid, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv)
   switch (p.hd) {
     case 2: GR(2); break;
     case 4: GR(4); break;
@@ -1109,7 +1118,7 @@ int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, 
   p.seq_pad = seq_pad;
   if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   dim3 grid(B, cdiv(H, 4));
-#define GO(HD) hipLaunchKernelGGL((attn_last_fwd_kernel<HD>), grid, dim3(256), 0, st, q_last, qkv, seq, p, ctx_last, lse_last)
+#define GO(HD) UR_ATTN_LAUNCH(attn_last_fwd_kernel, HD, grid, dim3(256), 0, st, q_last, qkv, seq, p, ctx_last, lse_last)
   switch (p.hd) {
     case 2: GO(2); break;
     case 4: GO(4); break;
@@ -1134,7 +1143,7 @@ int attn_last_bwd(const float* q_last, const float* qkv, const int* seq, const f
   p.seq_pad = seq_pad;
   if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   dim3 grid(B, cdiv(H, 4));
-#define GO(HD) hipLaunchKernelGGL((attn_last_bwd_kernel<HD>), grid, dim3(256), 0, st, q_last, qkv, seq, ctx_last, dctx_last, lse_last, p, dq_last, dqkv)
+#define GO(HD) UR_ATTN_LAUNCH(attn_last_bwd_kernel, HD, grid, dim3(256), 0, st, q_last, qkv, seq, ctx_last, dctx_last, lse_last, p, dq_last, dqkv)
   switch (p.hd) {
     case 2: GO(2); break;
     case 4: GO(4); break;
