@@ -6,3 +6,4 @@ python bench.py $F --batch 4096 2>/dev/null | python -c "$P" C5_B4096
 python bench.py $F --ids zipf 2>/dev/null | python -c "$P" C5_zipf
 python bench.py $F --table-mode rowwise 2>/dev/null | python -c "$P" C5_rowwise
 python bench.py $F --autograd --no-prefetch 2>/dev/null | python -c "$P" C5_autograd_noprefetch
+python bench.py $F --dropout 0.5 2>/dev/null | python -c "$P" C5_dropout0.5
