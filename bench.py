@@ -181,7 +181,7 @@ def gather_microbench(table, device):
         best = ms if best is None else min(best, ms)
         del out
     read = n * (d * 4 + 8) / (best * 1e-3) / 1e9
-    copy = {"bound": "hbm", "kernel": "gather_kernel<int64,32,4> (gather that WRITES the rows back: n*d*4 B of stores compete for HBM)",
+    copy = {"bound": "hbm", "kernel": "gather_kernel<int64,32,4> (gather that WRITES the rows back: n*d*4 B of stores compete for HBM; non-temporal loads and stores)",
             "achieved": round(read, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(read / HBM_PEAK_GBPS, 4),
             "read_plus_write_GBps": round(n * (2 * d * 4 + 8) / (best * 1e-3) / 1e9, 1), "n_lookups": n, "table_rows": N,
             "ms": round(best, 4), "traffic": None}
@@ -205,7 +205,7 @@ def gather_microbench(table, device):
         best2 = ms if best2 is None else min(best2, ms)
     n2 = B * G
     read2 = n2 * (d * 4 + 8) / (best2 * 1e-3) / 1e9
-    copy["fused_gather_dot"] = {"bound": "hbm", "kernel": "scorer_loss_fwd_kernel<32> (gather + dot, scores only)",
+    copy["fused_gather_dot"] = {"bound": "hbm", "kernel": "scorer_loss_fwd_kernel<32,8> (gather + dot, scores only; 8 rows in flight per lane group, non-temporal row loads)",
                                 "achieved": round(read2, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": round(read2 / HBM_PEAK_GBPS, 4), "n_lookups": n2, "table_rows": N, "ms": round(best2, 4)}
     return copy

@@ -2,6 +2,8 @@
 // One workgroup per batch row b; a group of TPR lanes owns one candidate at a time: it reads the
 // candidate's table row once (coalesced float4), dots it with the user vector held in registers and
 // emits one float -- the [B,G,d] candidate tensor of the reference never exists.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -29,7 +31,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return s;
 }
 
-template <int TPR>
+template <int TPR, int UNR>
 __global__ __launch_bounds__(256) void scorer_loss_fwd_kernel(UrLossCfg c, const float4* __restrict__ user_emb,
                                                               const float4* __restrict__ table, const long long* __restrict__ item_id,
                                                               const int* __restrict__ label, const float* __restrict__ user_bias,
@@ -50,7 +52,6 @@ __global__ __launch_bounds__(256) void scorer_loss_fwd_kernel(UrLossCfg c, const
   const float inv_tau = 1.0f / c.tau;
   // UNR candidate rows in flight per lane group: the rows are random 512-B reads of a table far larger than any
   // cache, so memory-level parallelism (not arithmetic) sets the rate
-  constexpr int UNR = 4;
   for (int gb = g0 * UNR; gb < G; gb += groups * UNR) {
     long long id[UNR];
     float s[UNR];
@@ -65,7 +66,11 @@ __global__ __launch_bounds__(256) void scorer_loss_fwd_kernel(UrLossCfg c, const
       if (col < d4) {
         float4 e[UNR];
 #pragma unroll
-        for (int q = 0; q < UNR; ++q) e[q] = table[id[q] * d4 + col];
+        for (int q = 0; q < UNR; ++q) {
+          typedef float vf4_t __attribute__((ext_vector_type(4)));
+          const vf4_t t4 = __builtin_nontemporal_load((const vf4_t*)&table[id[q] * d4 + col]);   // rows are read once: do not keep them in L2
+          e[q] = make_float4(t4.x, t4.y, t4.z, t4.w);
+        }
 #pragma unroll
         for (int q = 0; q < UNR; ++q) s[q] += (e[q].x * u[k].x + e[q].y * u[k].y) + (e[q].z * u[k].z + e[q].w * u[k].w);
       }
@@ -235,7 +240,11 @@ __global__ __launch_bounds__(256) void scorer_loss_bwd_kernel(UrLossCfg c, const
       if (col < d4) {
         float4 e[UNR];
 #pragma unroll
-        for (int q = 0; q < UNR; ++q) e[q] = table[id[q] * d4 + col];
+        for (int q = 0; q < UNR; ++q) {
+          typedef float vf4_t __attribute__((ext_vector_type(4)));
+          const vf4_t t4 = __builtin_nontemporal_load((const vf4_t*)&table[id[q] * d4 + col]);   // rows are read once: do not keep them in L2
+          e[q] = make_float4(t4.x, t4.y, t4.z, t4.w);
+        }
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
           acc[k].x = fmaf(w[q], e[q].x, acc[k].x); acc[k].y = fmaf(w[q], e[q].y, acc[k].y);
@@ -296,9 +305,12 @@ extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_em
   const int tpr = pick_tpr(cfg->d);
   const size_t lds = (cfg->G + 8) * sizeof(float);
   float* cnt_rows = loss_rows + cfg->B;  // loss_rows buffer is [2*B]: losses then counts
-#define GO(T) hipLaunchKernelGGL((scorer_loss_fwd_kernel<T>), dim3(cfg->B), dim3(256), lds, st, *cfg, (const float4*)user_emb, \
+  static const int unr_env = getenv("UR_SCORER_UNR") ? atoi(getenv("UR_SCORER_UNR")) : 0;   // tuning aid
+  const int unr = unr_env ? unr_env : 8;
+#define GO1(T, U) hipLaunchKernelGGL((scorer_loss_fwd_kernel<T, U>), dim3(cfg->B), dim3(256), lds, st, *cfg, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, user_bias, item_bias,            \
                                  (const long long*)user_id, scores, loss_rows, cnt_rows)
+#define GO(T) do { if (unr == 2) GO1(T, 2); else if (unr == 16) GO1(T, 16); else if (unr == 4) GO1(T, 4); else GO1(T, 8); } while (0)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

@@ -29,7 +29,10 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ 
     for (int c = t; c < d4; c += TPR) {
       float4 v[UNROLL];
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) v[u] = table[id[u] * d4 + c];
+      for (int u = 0; u < UNROLL; ++u) {
+        const vf4 t4 = __builtin_nontemporal_load((const vf4*)&table[id[u] * d4 + c]);   // read once: streaming hint
+        v[u] = make_float4(t4.x, t4.y, t4.z, t4.w);
+      }
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u)
         if (base + u < n) __builtin_nontemporal_store(*(const vf4*)&v[u], (vf4*)&out[(base + u) * d4 + c]);

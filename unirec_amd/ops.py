@@ -31,14 +31,19 @@ def _chk(t, dtype, name, allow_none=False):
 
 
 # --------------------------------------------------------------------------------------------- gather
-def embedding_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-    """out[..., :] = table[idx[...], :]  (bit-exact).  idx: int32 or int64, any shape."""
+def embedding_gather(table: torch.Tensor, idx: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """out[..., :] = table[idx[...], :]  (bit-exact).  idx: int32 or int64, any shape.  out: optional preallocated result."""
     _chk(table, torch.float32, "table")
     if idx.dtype not in (torch.int32, torch.int64):
         raise _lib.UnirecAmdError(f"idx: expected int32/int64, got {idx.dtype}")
     _chk(idx, idx.dtype, "idx")
     n_rows, d = table.shape
-    out = torch.empty(*idx.shape, d, dtype=torch.float32, device=table.device)
+    if out is None:
+        out = torch.empty(*idx.shape, d, dtype=torch.float32, device=table.device)
+    else:
+        _chk(out, torch.float32, "out")
+        if out.numel() != idx.numel() * d:
+            raise _lib.UnirecAmdError("embedding_gather: out has the wrong size")
     check(lib.ur_embedding_gather_f32(_p(table), n_rows, d, _p(idx), idx.element_size(), idx.numel(), _p(out), _stream()),
           "ur_embedding_gather_f32")
     return out
