@@ -7,6 +7,8 @@
 //   user_emb = h_{L-1} W_d^T + b_d               only the last step is projected (gru.py:31-33 projects all L and slices)
 // Activations are kept TIME-MAJOR ([L][B][.]) so that every step's matrices are contiguous and the weight gradients
 // are two big token-dimension GEMMs after the backward sweep.  Backward = BPTT with saved gates.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -119,6 +121,163 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restri
   dh_carry[i] = g * z;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent recurrence (H <= 128, H % 16 == 0): ONE launch runs all L steps.  The per-step product
+// h_{t-1} W_hh^T is tiny ([B,H] x [H,3H]) and strictly sequential in t, so the per-step formulation above is bound by
+// 2 L launches (C4: 100 launches of ~10 us per pass).  Here a workgroup owns 16 sequences for the whole sweep:
+//   * wave q owns hidden units [16q, 16q+16) of ALL THREE gates, with its slice of W_hh resident in VGPRs for the
+//     whole kernel as v_mfma_f32_16x16x4_f32 B-fragments (3 * H/4 = 96 registers at H = 128) -- the weights are
+//     read from HBM once per workgroup, not once per step;
+//   * h_{t-1} [16, H] lives in LDS (double-buffered) and is the A operand (16-byte LDS reads; the k index of an MFMA
+//     step is a free permutation, so lane-quarter kq feeds k = 16 s + 4 kq + i);
+//   * the accumulators of the three gates land lane-locally (row = 4 kq + r, column = hidden unit), so the gate
+//     non-linearities and the state update need no exchange; gi_t is prefetched from HBM under the MFMAs.
+// One __syncthreads per step.  The backward kernel mirrors it: dh lives in registers (the accumulator layout of
+// dh_{t-1} = dgh_t W_hh + dh_t z is exactly the layout the cell backward of step t-1 reads), dgh_t [16, 3H] goes through
+// LDS as the A operand, W_hh columns stay in registers.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int GRU_SEQ_ROWS = 16;
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void gru_seq_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                           const float* __restrict__ b_hh, int B, int L, float* __restrict__ h_all,
+                                                           float* __restrict__ r_s, float* __restrict__ z_s, float* __restrict__ n_s,
+                                                           float* __restrict__ hn_s) {
+  constexpr int KS = H / 16;          // 16-wide k blocks
+  constexpr int LD = H + 4;           // LDS row stride
+  __shared__ __attribute__((aligned(16))) float hs[2][GRU_SEQ_ROWS][LD];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c16 = lane & 15, kq = lane >> 4;
+  const int j = 16 * q + c16;          // hidden unit of this lane's accumulator column
+  const int b0 = blockIdx.x * GRU_SEQ_ROWS;
+  // resident weights: wf[g][s][i] = W_hh[g*H + j][16 s + 4 kq + i]
+  float4 wf[3][KS];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wf[g][s] = *(const float4*)(w_hh + (long long)(g * H + j) * H + 16 * s + 4 * kq);
+  const float bh_r = b_hh[j], bh_z = b_hh[H + j], bh_n = b_hh[2 * H + j];
+  for (int i = threadIdx.x; i < GRU_SEQ_ROWS * LD; i += blockDim.x) (&hs[0][0][0])[i] = 0.f;   // h_0 = 0
+  __syncthreads();
+  for (int t = 0; t < L; ++t) {
+    const int cur = t & 1;
+    // this lane's gi values (rows 4 kq + r): issued before the MFMAs, consumed after
+    float gir[4], giz[4], gin[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = min(b0 + 4 * kq + r, B - 1);
+      const float* gp = gi + ((long long)t * B + b) * 3 * H;
+      gir[r] = gp[j]; giz[r] = gp[H + j]; gin[r] = gp[2 * H + j];
+    }
+    floatx4 ar = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 a4 = *(const float4*)&hs[cur][c16][16 * s + 4 * kq];
+      ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wf[0][s].x, ar, 0, 0, 0);
+      az = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wf[1][s].x, az, 0, 0, 0);
+      an = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wf[2][s].x, an, 0, 0, 0);
+      ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wf[0][s].y, ar, 0, 0, 0);
+      az = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wf[1][s].y, az, 0, 0, 0);
+      an = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wf[2][s].y, an, 0, 0, 0);
+      ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wf[0][s].z, ar, 0, 0, 0);
+      az = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wf[1][s].z, az, 0, 0, 0);
+      an = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wf[2][s].z, an, 0, 0, 0);
+      ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wf[0][s].w, ar, 0, 0, 0);
+      az = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wf[1][s].w, az, 0, 0, 0);
+      an = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wf[2][s].w, an, 0, 0, 0);
+    }
+    // accumulator register r: row 4 kq + r, column j
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * kq + r, b = b0 + m;
+      const float rr = 1.0f / (1.0f + expf(-(gir[r] + (ar[r] + bh_r))));
+      const float zz = 1.0f / (1.0f + expf(-(giz[r] + (az[r] + bh_z))));
+      const float hn = an[r] + bh_n;
+      const float nn = tanhf(gin[r] + rr * hn);
+      const float hnew = (1.0f - zz) * nn + zz * hs[cur][m][j];
+      hs[cur ^ 1][m][j] = hnew;
+      if (b < B) {
+        const long long o = ((long long)t * B + b) * H + j;
+        h_all[o + (long long)B * H] = hnew;
+        r_s[o] = rr; z_s[o] = zz; n_s[o] = nn; hn_s[o] = hn;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// backward sweep: dh_in [B,H] = gradient w.r.t. h_L; writes dgi, dgh [L][B][3H] (time-major)
+template <int H>
+__global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(const float* __restrict__ dh_in, const float* __restrict__ w_hh,
+                                                           const float* __restrict__ r_s, const float* __restrict__ z_s,
+                                                           const float* __restrict__ n_s, const float* __restrict__ hn_s,
+                                                           const float* __restrict__ h_all, int B, int L, float* __restrict__ dgi,
+                                                           float* __restrict__ dgh) {
+  constexpr int KS = 3 * H / 16;      // 16-wide blocks of the contraction index c in [0, 3H)
+  constexpr int LD = 3 * H + 4;
+  __shared__ __attribute__((aligned(16))) float dg[GRU_SEQ_ROWS][LD];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c16 = lane & 15, kq = lane >> 4;
+  const int j = 16 * q + c16;          // column of dh this lane owns (= hidden unit of its cell backward)
+  const int b0 = blockIdx.x * GRU_SEQ_ROWS;
+  // resident weights: wf[s][i] = W_hh[16 s + 4 kq + i][j]   (B operand of dh_{t-1}[m, j] = sum_c dgh[m, c] W_hh[c, j])
+  float wf[KS][4];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[s][i] = w_hh[(long long)(16 * s + 4 * kq + i) * H + j];
+  float dh[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dh[r] = dh_in[(long long)min(b0 + 4 * kq + r, B - 1) * H + j];
+  for (int t = L - 1; t >= 0; --t) {
+    float carry[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * kq + r, b = min(b0 + m, B - 1);
+      const long long o = ((long long)t * B + b) * H + j;
+      const float g = dh[r], rr = r_s[o], zz = z_s[o], nn = n_s[o], hn = hn_s[o], hp = h_all[o];
+      const float dn = g * (1.0f - zz);
+      const float dz = g * (hp - nn);
+      const float dan = dn * (1.0f - nn * nn);
+      const float daz = dz * zz * (1.0f - zz);
+      const float dar = dan * hn * rr * (1.0f - rr);
+      const float dhn = dan * rr;
+      dg[m][j] = dar; dg[m][H + j] = daz; dg[m][2 * H + j] = dhn;
+      carry[r] = g * zz;
+      if (b0 + m < B) {
+        float* gio = dgi + ((long long)t * B + b) * 3 * H;
+        float* gho = dgh + ((long long)t * B + b) * 3 * H;
+        gio[j] = dar; gio[H + j] = daz; gio[2 * H + j] = dan;
+        gho[j] = dar; gho[H + j] = daz; gho[2 * H + j] = dhn;
+      }
+    }
+    __syncthreads();
+    floatx4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};   // two chains: hide the 40-cycle dependent latency
+#pragma unroll
+    for (int s = 0; s < KS; s += 2) {
+      const float4 x0 = *(const float4*)&dg[c16][16 * s + 4 * kq];
+      const float4 x1 = *(const float4*)&dg[c16][16 * (s + 1) + 4 * kq];
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, wf[s][0], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, wf[s + 1][0], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, wf[s][1], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, wf[s + 1][1], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, wf[s][2], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, wf[s + 1][2], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, wf[s][3], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, wf[s + 1][3], a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh[r] = (a0[r] + a1[r]) + carry[r];
+    __syncthreads();   // dg is rewritten by the next step
+  }
+}
+
+static bool gru_seq_supported(int H) {
+  static const bool off = getenv("UR_GRU_NO_SEQ") != nullptr;   // test / tuning hook
+  return !off && (H == 32 || H == 64 || H == 128);
+}
+
 }  // namespace ur
 
 using namespace ur;
@@ -161,6 +320,15 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   g.A = w.x; g.lda = d; g.W = dense + lay.w_ih; g.ldw = d; g.C = w.gi; g.ldc = 3 * H; g.M = M; g.N = 3 * H; g.K = d; g.bias = dense + lay.b_ih;
   if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
   UR_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * H, st));
+  if (gru_seq_supported(H)) {   // the whole recurrence in one launch
+    ProfScope ps(PC_GRU, st, 0);
+    const dim3 grid(cdiv(B, GRU_SEQ_ROWS));
+#define GO(HH) hipLaunchKernelGGL((gru_seq_fwd_kernel<HH>), grid, dim3(HH * 4), 0, st, w.gi, dense + lay.w_hh, dense + lay.b_hh, B, L, w.h_all, \
+                                  w.r, w.z, w.n, w.hn)
+    if (H == 32) GO(32); else if (H == 64) GO(64); else GO(128);
+#undef GO
+    UR_LAUNCH_CHECK();
+  } else
   for (int t = 0; t < L; ++t) {
     const long long o = (long long)t * B * H;
     g = GemmArgs{};
@@ -199,6 +367,15 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   GemmArgs g{};
   g.A = d_user_emb; g.lda = d; g.W = w.w_dT; g.ldw = d; g.C = w.dh; g.ldc = H; g.M = B; g.N = H; g.K = d;
   if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
+  if (gru_seq_supported(H)) {   // the whole backward sweep in one launch
+    ProfScope ps(PC_GRU, st, 0);
+    const dim3 grid(cdiv(B, GRU_SEQ_ROWS));
+#define GO(HH) hipLaunchKernelGGL((gru_seq_bwd_kernel<HH>), grid, dim3(HH * 4), 0, st, w.dh, dense + lay.w_hh, w.r, w.z, w.n, w.hn, w.h_all, B, L, \
+                                  w.dgi, w.dgh)
+    if (H == 32) GO(32); else if (H == 64) GO(64); else GO(128);
+#undef GO
+    UR_LAUNCH_CHECK();
+  } else
   for (int t = L - 1; t >= 0; --t) {
     const long long o = (long long)t * B * H, o3 = (long long)t * B * 3 * H;
     {
