@@ -1000,6 +1000,121 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// 16x16x4-MFMA attention for ANY sequence length (head dim 4 / 8 / 16), forward.  The 32x32 kernels above keep the whole
+// [L, L] score block of a (sequence, head) in accumulators, which stops at L = 64 and wastes most of every 32-row MFMA on
+// an 8-wide head; here the block is walked in 16 x 16 tiles, flash-attention style:
+//   * one wave = one (sequence, head, chunk of 64 queries); K and V rows of the keys the chunk can see are staged ONCE in
+//     the wave's LDS slice;
+//   * S^T tile [16 keys, 16 queries] = K Q^T by HD/4 v_mfma_f32_16x16x4_f32 (lane quarter kq feeds dims kq*HD/4 + s: the k
+//     index of an MFMA step is a free permutation); accumulator register r of lane (query c16, kq) is key 4 kq + r, so a lane
+//     owns ONE query and four of the tile's keys -- the running max is shared by two shuffles, the running sum stays a
+//     per-lane partial (combined once at the end);
+//   * O^T [features, queries] += V^T P^T by 4 MFMAs with the probabilities used AS THEY SIT in the accumulators as the B
+//     operand (step r <-> keys 4 kq + r); the online-softmax rescale is a per-lane scalar because column = query.
+// Masks, dead rows, the literal (-10000) path of an all-padding sequence, compacted rows and dropout are those of the
+// kernels above.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int attn_m16_lds_floats_per_wave(int L, int hd) { return 2 * L * (hd + 4) + ((L + 3) & ~3); }
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256) void attn_fwd_m16_kernel(const float* __restrict__ qkv, const int* __restrict__ seq, AttnDims p,
+                                                           float* __restrict__ ctx, float* __restrict__ lse) {
+  constexpr int KS = HD / 4;            // MFMA steps of a score tile; also the floats of a row fragment per lane quarter
+  constexpr int LDK = HD + 4;           // LDS row stride of the K / V tiles
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  extern __shared__ __attribute__((aligned(16))) float smem_m16[];
+  // a workgroup = one (sequence, head) and up to four 64-query chunks (one per wave): K / V are staged once per workgroup
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cpb = (p.nchunk + 3) >> 2;                       // workgroups per head
+  const int h = blockIdx.y / cpb, qc = (blockIdx.y % cpb) * 4 + w;
+  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  const int c16 = lane & 15, kq = lane >> 4;
+  long long row0;
+  int pad;
+  seq_rows(p, b, row0, pad);
+  const float* __restrict__ base = qkv + row0 * ld + h * HD;
+  const int* __restrict__ sq = seq + (long long)b * L;
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  const bool causal = p.causal && !literal;
+  const int q_begin = qc * 64, q_end = min(L, q_begin + 64);
+  const int kend = causal ? q_end : L;                       // keys this chunk can see
+  const int kstage = causal ? min(L, ((int)(blockIdx.y % cpb) * 4 + 4) * 64) : L;   // keys any wave of this workgroup can see
+  float* ks = smem_m16;                                      // [L][LDK]
+  float* vs = ks + L * LDK;                                  // [L][LDK]
+  float* kvalid = vs + L * LDK;                              // [L] 1 = key may be attended
+  // ---- stage K, V rows [0, kstage) and the key mask (thread = row, 16-byte copies)
+  for (int j = threadIdx.x; j < kstage; j += 256) {
+    const float* src = base + (long long)max(j, pad) * ld;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      *(float4*)(ks + j * LDK + c) = *(const float4*)(src + p.d + c);
+      *(float4*)(vs + j * LDK + c) = *(const float4*)(src + 2 * p.d + c);
+    }
+    kvalid[j] = (literal || sq[j] > 0) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  if (q_begin >= L) return;                                  // surplus wave of the last workgroup of a head
+  const float sc2 = p.scale * LOG2E;
+  const int jt0 = literal ? 0 : fv >> 4;                     // key tiles before the first valid key hold nothing
+  for (int it = q_begin >> 4; it * 16 < q_end; ++it) {
+    const int i = it * 16 + c16;                              // this lane's query
+    const int irow = max(min(i, L - 1), pad);
+    float qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = base[(long long)irow * ld + kq * KS + s];
+    const unsigned rk = attn_rowkey(p, b, h, min(i, L - 1));
+    float m = -INFINITY, l = 0.f;
+    floatx4 oa = {0.f, 0.f, 0.f, 0.f};
+    const int jt_end = causal ? it + 1 : (kend + 15) >> 4;
+    for (int jt = jt0; jt < jt_end; ++jt) {
+      const int jrow = min(jt * 16 + c16, kend - 1);
+      floatx4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) st = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[jrow * LDK + kq * KS + s], qf[s], st, 0, 0, 0);
+      float e[4], tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jt * 16 + 4 * kq + r;
+        const bool ok = j < kend && kvalid[min(j, kend - 1)] != 0.f && (!causal || j <= i);
+        e[r] = ok ? (literal ? (st[r] / p.sqrt_hd + -10000.0f) * LOG2E : st[r] * sc2) : -INFINITY;
+        tmax = fmaxf(tmax, e[r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m, tmax);
+      const float mm = m_new == -INFINITY ? 0.f : m_new;      // nothing visible for this query so far: every exponent is -inf -> 0
+      const float corr = __builtin_amdgcn_exp2f(m - mm);      // exp2(-inf) = 0 on the first visible tile (no lane-divergent skip:
+      float pr[4];                                            // the MFMAs below take operands from every lane)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[r] = __builtin_amdgcn_exp2f(e[r] - mm);
+        l = (r == 0 ? l * corr : l) + pr[r];
+        if constexpr (DROP) pr[r] *= attn_keep<DROP>(p, rk, jt * 16 + 4 * kq + r);
+      }
+      oa[0] *= corr; oa[1] *= corr; oa[2] *= corr; oa[3] *= corr;
+      m = m_new;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = min(jt * 16 + 4 * kq + r, kend - 1);
+        const float vv = c16 < HD ? vs[j * LDK + c16] : 0.f;
+        oa = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pr[r], oa, 0, 0, 0);
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (i < q_end && i >= pad) {
+      const bool dead = l == 0.f;   // padded-prefix row of a non-empty sequence: unreachable from the loss
+      const float inv_l = dead ? 0.f : 1.0f / l;
+      if (4 * kq < HD) *(float4*)(ctx + (row0 + i) * p.d + h * HD + 4 * kq) = make_float4(oa[0] * inv_l, oa[1] * inv_l, oa[2] * inv_l, oa[3] * inv_l);
+      if (kq == 0) lse[((long long)b * p.H + h) * L + i] = dead ? 0.f : (m + __log2f(l)) * LN2;
+    }
+  }
+}
+
 // launches KERNEL<HD, true> when dropout is on (p.dthresh != 0), KERNEL<HD, false> otherwise
 #define UR_ATTN_LAUNCH(KERNEL, HD, ...)                                   \
   do {                                                                    \
@@ -1022,6 +1137,16 @@ static int make_dims(int B, int L, int d, int H, int causal, AttnDims* p) {
   return UR_OK;
 }
 
+static bool attn_m16_supported(int L, int hd) {
+  static const bool off = getenv("UR_ATTN_NO_M16") != nullptr;   // test / tuning hook
+  return !off && (hd == 4 || hd == 8 || hd == 16) && (long long)attn_m16_lds_floats_per_wave(L, hd) * 4 <= 64 * 1024;
+}
+// 16x16-tile kernels for L <= 64 too?  (UR_ATTN_M16=1; default: the 32x32 single-block kernels)
+static bool attn_m16_short() {
+  static const bool on = getenv("UR_ATTN_M16") != nullptr && atoi(getenv("UR_ATTN_M16")) != 0;
+  return on;
+}
+
 bool attn_compact_supported(int L, int d, int H) {
   if (H <= 0 || d % H) return false;
   const int hd = d / H;
@@ -1040,6 +1165,21 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
   if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need L <= 64 and head dim 4/8/16");
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
+  if (attn_m16_supported(L, p.hd) && !no_mfma && (L > 64 || attn_m16_short())) {
+    const size_t lds = (size_t)attn_m16_lds_floats_per_wave(L, p.hd) * sizeof(float);
+    dim3 g3(B, H * cdiv(p.nchunk, 4));
+#define GM(HD)                                                                                                                     \
+    do {                                                                                                                             \
+      static const hipError_t a0 = hipFuncSetAttribute((const void*)attn_fwd_m16_kernel<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      static const hipError_t a1 = hipFuncSetAttribute((const void*)attn_fwd_m16_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      (void)a0; (void)a1;                                                                                                            \
+      UR_ATTN_LAUNCH(attn_fwd_m16_kernel, HD, g3, dim3(256), lds, st, qkv, seq, p, ctx, lse);                                        \
+    } while (0)
+    if (p.hd == 4) GM(4); else if (p.hd == 8) GM(8); else GM(16);
+#undef GM
+    UR_LAUNCH_CHECK();
+    return UR_OK;
+  }
   if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
     dim3 g2(B, cdiv(H, 4));
     if (p.hd == 4) UR_ATTN_LAUNCH(attn_fwd_mfma_kernel, 4, g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
