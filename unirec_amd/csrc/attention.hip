@@ -1115,6 +1115,144 @@ __global__ __launch_bounds__(256) void attn_fwd_m16_kernel(const float* __restri
   }
 }
 
+// 16x16x4-MFMA attention backward for any L (head dim 4 / 8 / 16).  A workgroup = one (sequence, head): Q, K, V, dO rows and the
+// per-query lse / D = dO . O are staged once in LDS; the four waves then take the 16-row tiles round-robin, twice:
+//   A (lane = query i): S^T, dP^T tiles by MFMA, dS^T = P^T (m dP^T - D_i) lane-locally, dQ^T += K^T dS^T with dS^T as the
+//     B operand straight from the accumulators;
+//   B (lane = key j):   S, dP tiles (registers run over queries), dV^T += dO^T (P m), dK^T += Q^T dS.
+// Nothing [L, L]-shaped is stored; dropout masks are re-evaluated from (row id, column).
+__host__ __device__ inline int attn_m16_bwd_lds_floats(int L, int hd) { return 4 * L * (hd + 4) + 3 * ((L + 3) & ~3); }
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_m16_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
+                                                           const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                           const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
+  constexpr int KS = HD / 4, LDK = HD + 4;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) float smem_m16[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int h = blockIdx.y, b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  const int c16 = lane & 15, kq = lane >> 4;
+  long long row0;
+  int pad;
+  seq_rows(p, b, row0, pad);
+  const float* __restrict__ base = qkv + row0 * ld + h * HD;
+  const int* __restrict__ sq = seq + (long long)b * L;
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  const bool causal = p.causal && !literal;
+  const float f = literal ? 1.0f / p.sqrt_hd : p.scale;   // d(score) / d(q . k)
+  const float sc2 = f * LOG2E;
+  const int Lp = (L + 3) & ~3;
+  float* Qs = smem_m16;
+  float* Ks = Qs + L * LDK;
+  float* Vs = Ks + L * LDK;
+  float* Gs = Vs + L * LDK;
+  float* lse2s = Gs + L * LDK;     // lse * log2(e) per query
+  float* Ds = lse2s + Lp;          // dO . O per query
+  float* kvalid = Ds + Lp;         // 1 = key may be attended
+  for (int j = threadIdx.x; j < L; j += 256) {
+    const long long row = row0 + max(j, pad);
+    const float* src = qkv + row * ld + h * HD;
+    const float* gr = dctx + row * p.d + h * HD;
+    const float* orr = ctx + row * p.d + h * HD;
+    float D = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 g4 = *(const float4*)(gr + c), o4 = *(const float4*)(orr + c);
+      *(float4*)(Qs + j * LDK + c) = *(const float4*)(src + c);
+      *(float4*)(Ks + j * LDK + c) = *(const float4*)(src + p.d + c);
+      *(float4*)(Vs + j * LDK + c) = *(const float4*)(src + 2 * p.d + c);
+      *(float4*)(Gs + j * LDK + c) = g4;
+      D += (g4.x * o4.x + g4.y * o4.y) + (g4.z * o4.z + g4.w * o4.w);
+    }
+    lse2s[j] = lse[((long long)b * p.H + h) * L + j] * LOG2E;
+    Ds[j] = D;
+    kvalid[j] = (literal || sq[j] > 0) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  (void)base;
+  const int nt = (L + 15) >> 4;
+  const int jt0 = literal ? 0 : fv >> 4;
+  float* orow = dqkv + row0 * ld + h * HD;
+  // =========================================================================== phase A: lane = query
+  for (int it = w; it < nt; it += 4) {
+    const int i = it * 16 + c16, ic = min(i, L - 1);
+    float qf[KS], gf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { qf[s] = Qs[ic * LDK + kq * KS + s]; gf[s] = Gs[ic * LDK + kq * KS + s]; }
+    const float lse2 = lse2s[ic], Di = Ds[ic];
+    const unsigned rk = attn_rowkey(p, b, h, ic);
+    floatx4 dq = {0.f, 0.f, 0.f, 0.f};
+    const int jt_end = causal ? it + 1 : nt;
+    for (int jt = jt0; jt < jt_end; ++jt) {
+      const int jr = min(jt * 16 + c16, L - 1);
+      floatx4 sT = {0.f, 0.f, 0.f, 0.f}, dpT = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sT = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[jr * LDK + kq * KS + s], qf[s], sT, 0, 0, 0);
+        dpT = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[jr * LDK + kq * KS + s], gf[s], dpT, 0, 0, 0);
+      }
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jt * 16 + 4 * kq + r, jc = min(j, L - 1);
+        const bool ok = j < L && kvalid[jc] != 0.f && (!causal || j <= i);
+        const float e = literal ? (sT[r] / p.sqrt_hd + -10000.0f) * LOG2E : sT[r] * sc2;
+        const float pv = ok ? __builtin_amdgcn_exp2f(e - lse2) : 0.f;
+        ds[r] = pv * (attn_keep<DROP>(p, rk, j) * dpT[r] - Di);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jc = min(jt * 16 + 4 * kq + r, L - 1);
+        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(c16 < HD ? Ks[jc * LDK + c16] : 0.f, ds[r], dq, 0, 0, 0);
+      }
+    }
+    if (i < L && i >= pad && 4 * kq < HD)
+      *(float4*)(orow + (long long)i * ld + 4 * kq) = make_float4(dq[0] * f, dq[1] * f, dq[2] * f, dq[3] * f);
+  }
+  // =========================================================================== phase B: lane = key
+  for (int jt = 3 - w; jt < nt; jt += 4) {   // (3 - w: the waves that got the long query tiles get the short key tiles)
+    const int j = jt * 16 + c16, jc = min(j, L - 1);
+    float kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { kf[s] = Ks[jc * LDK + kq * KS + s]; vf[s] = Vs[jc * LDK + kq * KS + s]; }
+    const bool kv = j < L && kvalid[jc] != 0.f;
+    floatx4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    for (int it = causal ? jt : 0; it < nt; ++it) {
+      const int ir = min(it * 16 + c16, L - 1);
+      floatx4 sM = {0.f, 0.f, 0.f, 0.f}, dpM = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sM = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[ir * LDK + kq * KS + s], kf[s], sM, 0, 0, 0);
+        dpM = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[ir * LDK + kq * KS + s], vf[s], dpM, 0, 0, 0);
+      }
+      float pd[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = it * 16 + 4 * kq + r, ic = min(i, L - 1);
+        const bool ok = kv && i < L && i >= pad && (!causal || j <= i);
+        const float e = literal ? (sM[r] / p.sqrt_hd + -10000.0f) * LOG2E : sM[r] * sc2;
+        const float pv = ok ? __builtin_amdgcn_exp2f(e - lse2s[ic]) : 0.f;
+        const float mk = DROP ? drop_mul(attn_rowkey(p, b, h, ic), (unsigned)j, p.dthresh, p.dscale) : 1.0f;
+        pd[r] = pv * mk;
+        ds[r] = pv * (mk * dpM[r] - Ds[ic]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ic = min(it * 16 + 4 * kq + r, L - 1);
+        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(c16 < HD ? Gs[ic * LDK + c16] : 0.f, pd[r], dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_16x16x4f32(c16 < HD ? Qs[ic * LDK + c16] : 0.f, ds[r], dk, 0, 0, 0);
+      }
+    }
+    if (j < L && j >= pad && 4 * kq < HD) {
+      float* out = orow + (long long)j * ld;
+      *(float4*)(out + p.d + 4 * kq) = make_float4(dk[0] * f, dk[1] * f, dk[2] * f, dk[3] * f);
+      *(float4*)(out + 2 * p.d + 4 * kq) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    }
+  }
+}
+
 // launches KERNEL<HD, true> when dropout is on (p.dthresh != 0), KERNEL<HD, false> otherwise
 #define UR_ATTN_LAUNCH(KERNEL, HD, ...)                                   \
   do {                                                                    \
@@ -1218,6 +1356,23 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
   if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need L <= 64 and head dim 4/8/16");
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
+  static const bool bwd32 = getenv("UR_ATTN_BWD32") != nullptr;   // tuning hook: the 32x32 single-block backward for L <= 64
+  if (attn_m16_supported(L, p.hd) && (long long)attn_m16_bwd_lds_floats(L, p.hd) * 4 <= 80 * 1024 && !no_mfma && (L > 64 || !bwd32)) {
+    // (also for L <= 64: measured 99 vs 112-122 us at B = 512, L = 50, 16 heads of 8 -- the 16-row tiles waste less of each MFMA)
+    const size_t lds = (size_t)attn_m16_bwd_lds_floats(L, p.hd) * sizeof(float);
+    dim3 g3(B, H);
+#define GM(HD)                                                                                                                     \
+    do {                                                                                                                             \
+      static const hipError_t a0 = hipFuncSetAttribute((const void*)attn_bwd_m16_kernel<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      static const hipError_t a1 = hipFuncSetAttribute((const void*)attn_bwd_m16_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      (void)a0; (void)a1;                                                                                                            \
+      UR_ATTN_LAUNCH(attn_bwd_m16_kernel, HD, g3, dim3(256), lds, st, qkv, seq, ctx, dctx, lse, p, dqkv);                             \
+    } while (0)
+    if (p.hd == 4) GM(4); else if (p.hd == 8) GM(8); else GM(16);
+#undef GM
+    UR_LAUNCH_CHECK();
+    return UR_OK;
+  }
   if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
     dim3 g2(B, cdiv(H, 4));
     if (p.hd == 4) UR_ATTN_LAUNCH(attn_bwd_mfma_kernel, 4, g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
