@@ -61,7 +61,8 @@ typedef struct UrSasrecCfg {
   float eps;        /* layer_norm_eps */
   int32_t last_only; /* 1: exact last-position specialisation of the final layer */
   int32_t skip_padding; /* 1: the left-padded prefix of every sequence gets no rows at all (exact: those positions cannot
-                           reach the loss); used when L <= 64 and head dim is 4/8/16, ignored otherwise */
+                           reach the loss); used when the head dim is 4/8/16 and the sequence fits the MFMA attention kernels
+                           (L <= 400 at head dim 8, 249 at 16), ignored otherwise */
   /* Training-time dropout (sasrec.py:69 on the embedded input; modules.py:307 on the attention probabilities; modules.py:313,
    * 352 on the two block outputs before the residual): probabilities in [0,1), 0 = off (evaluation).  The keep mask is a
    * counter-based hash of (drop_seed, drop_step, site, element) -- see DropSpec in csrc/common.h and oracle/dropout_ref.py --

@@ -1288,7 +1288,9 @@ static bool attn_m16_short() {
 bool attn_compact_supported(int L, int d, int H) {
   if (H <= 0 || d % H) return false;
   const int hd = d / H;
-  return L <= 64 && (hd == 4 || hd == 8 || hd == 16) && getenv("UR_ATTN_NO_MFMA") == nullptr;
+  if (getenv("UR_ATTN_NO_MFMA") != nullptr || !(hd == 4 || hd == 8 || hd == 16)) return false;
+  if (L <= 64) return true;                                  // 32x32 single-block kernels / 16x16 backward
+  return attn_m16_supported(L, hd) && (long long)attn_m16_bwd_lds_floats(L, hd) * 4 <= 80 * 1024;   // 16x16-tile kernels, both passes
 }
 
 int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int causal, float* ctx, float* lse,
@@ -1301,7 +1303,7 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
   p.seq_base = seq_base;
   p.seq_pad = seq_pad;
   if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
-  if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need L <= 64 and head dim 4/8/16");
+  if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need head dim 4/8/16 and a sequence that fits the MFMA kernels");
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
   if (attn_m16_supported(L, p.hd) && !no_mfma && (L > 64 || attn_m16_short())) {
     const size_t lds = (size_t)attn_m16_lds_floats_per_wave(L, p.hd) * sizeof(float);
@@ -1354,7 +1356,7 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
   p.seq_base = seq_base;
   p.seq_pad = seq_pad;
   if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
-  if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need L <= 64 and head dim 4/8/16");
+  if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need head dim 4/8/16 and a sequence that fits the MFMA kernels");
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
   static const bool bwd32 = getenv("UR_ATTN_BWD32") != nullptr;   // tuning hook: the 32x32 single-block backward for L <= 64
   if (attn_m16_supported(L, p.hd) && (long long)attn_m16_bwd_lds_floats(L, p.hd) * 4 <= 80 * 1024 && !no_mfma && (L > 64 || !bwd32)) {
