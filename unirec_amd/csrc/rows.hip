@@ -461,14 +461,17 @@ __device__ __forceinline__ void lazy_replay4(float4& w, float4& m, float4& v, in
   for (int j = 0; j < exact; ++j) {
     b1t *= a.b1;
     b2t *= a.b2;
-    const float inv_s2 = 1.0f / sqrtf(1.f - b2t), step = a.lr / (1.f - b1t);
+    // hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32: 1 ulp) instead of the IEEE-exact division and sqrt
+    // sequences: a replayed step moves a weight by ~lr * b1^j, so the difference is ~1e-7 of an already tiny step, far inside
+    // the parity tolerance, and the replay of a frequently revisited table (C3: every row every ~13 steps) is VALU-bound
+    const float inv_s2 = __builtin_amdgcn_rsqf(1.f - b2t), step = a.lr * __builtin_amdgcn_rcpf(1.f - b1t);
 #define UR_LAZY_ELEM(W, M, V)                                   \
     {                                                           \
       const float gr = decoupled ? 0.f : a.wd * W;              \
       if (decoupled) W *= shrink;                               \
       M = a.b1 * M + c1m * gr;                                  \
       V = a.b2 * V + c2m * gr * gr;                             \
-      W -= step * (M / (sqrtf(V) * inv_s2 + a.eps));            \
+      W -= step * (M * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(V) * inv_s2 + a.eps)); \
     }
     UR_LAZY_ELEM(w.x, m.x, v.x) UR_LAZY_ELEM(w.y, m.y, v.y) UR_LAZY_ELEM(w.z, m.z, v.z) UR_LAZY_ELEM(w.w, m.w, v.w)
 #undef UR_LAZY_ELEM
