@@ -31,17 +31,19 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return s;
 }
 
-template <int TPR, int UNR>
-__global__ __launch_bounds__(256) void scorer_loss_fwd_kernel(UrLossCfg c, const float4* __restrict__ user_emb,
+// NT threads per workgroup: 256, or 1024 for few rows with many candidates (C3: B = 128 rows of 1001 candidates leave half of the
+// CUs without a workgroup; four times the lane groups per row = four times the candidate rows in flight)
+template <int TPR, int UNR, int NT>
+__global__ __launch_bounds__(NT) void scorer_loss_fwd_kernel(UrLossCfg c, const float4* __restrict__ user_emb,
                                                               const float4* __restrict__ table, const long long* __restrict__ item_id,
                                                               const int* __restrict__ label, const float* __restrict__ user_bias,
                                                               const float* __restrict__ item_bias, const long long* __restrict__ user_id,
                                                               float* __restrict__ scores, float* __restrict__ loss_rows,
                                                               float* __restrict__ cnt_rows) {
-  extern __shared__ float sc[];  // [G] scores of this row, then 8 floats of reduction scratch
+  extern __shared__ float sc[];  // [G] scores of this row, then 16 floats of reduction scratch
   float* red = sc + c.G;
   const int b = blockIdx.x, G = c.G, d4 = c.d / 4;
-  const int groups = 256 / TPR, g0 = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const int groups = NT / TPR, g0 = threadIdx.x / TPR, t = threadIdx.x % TPR;
   float4 u[MAXV];
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
@@ -153,15 +155,15 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
   }
 }
 
-template <int TPR>
-__global__ __launch_bounds__(256) void scorer_loss_bwd_kernel(UrLossCfg c, const float4* __restrict__ user_emb,
+template <int TPR, int NT>
+__global__ __launch_bounds__(NT) void scorer_loss_bwd_kernel(UrLossCfg c, const float4* __restrict__ user_emb,
                                                               const float4* __restrict__ table, const long long* __restrict__ item_id,
                                                               const int* __restrict__ label, const float* __restrict__ scores,
                                                               const float* __restrict__ d_loss, const float* __restrict__ norm,
                                                               float* __restrict__ coef, float4* __restrict__ d_user,
                                                               float* __restrict__ d_user_bias_rows) {
-  extern __shared__ float sh[];  // [G] coef, then [groups][d] partial d_user, then 8 scratch
-  constexpr int groups = 256 / TPR;
+  extern __shared__ float sh[];  // [G] coef, then [groups][d] partial d_user, then 16 scratch
+  constexpr int groups = NT / TPR;
   const int b = blockIdx.x, G = c.G, d4 = c.d / 4, d = c.d;
   float* cf = sh;
   float* acc_lds = sh + G;
@@ -303,13 +305,15 @@ extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_em
   hipStream_t st = as_stream(stream);
   ProfScope ps(PC_LOSS, st, (double)cfg->B * cfg->G * cfg->d * 4.0);
   const int tpr = pick_tpr(cfg->d);
-  const size_t lds = (cfg->G + 8) * sizeof(float);
+  const size_t lds = (cfg->G + 16) * sizeof(float);
+  const bool wide = cfg->G >= 512 && cfg->B <= 512;   // few rows, many candidates: 1024-thread workgroups
   float* cnt_rows = loss_rows + cfg->B;  // loss_rows buffer is [2*B]: losses then counts
   static const int unr_env = getenv("UR_SCORER_UNR") ? atoi(getenv("UR_SCORER_UNR")) : 0;   // tuning aid
   const int unr = unr_env ? unr_env : 8;
-#define GO1(T, U) hipLaunchKernelGGL((scorer_loss_fwd_kernel<T, U>), dim3(cfg->B), dim3(256), lds, st, *cfg, (const float4*)user_emb, \
+#define GO2(T, U, NT) hipLaunchKernelGGL((scorer_loss_fwd_kernel<T, U, NT>), dim3(cfg->B), dim3(NT), lds, st, *cfg, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, user_bias, item_bias,            \
                                  (const long long*)user_id, scores, loss_rows, cnt_rows)
+#define GO1(T, U) do { if (wide) GO2(T, U, 1024); else GO2(T, U, 256); } while (0)
 #define GO(T) do { if (unr == 2) GO1(T, 2); else if (unr == 16) GO1(T, 16); else if (unr == 4) GO1(T, 4); else GO1(T, 8); } while (0)
   switch (tpr) {
     case 4: GO(4); break;
@@ -338,10 +342,13 @@ extern "C" int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_em
   hipStream_t st = as_stream(stream);
   ProfScope ps(PC_LOSS, st, (double)cfg->B * cfg->G * cfg->d * 4.0);
   const int tpr = pick_tpr(cfg->d);
-  const int groups = 256 / tpr;
-  const size_t lds = ((size_t)cfg->G + (size_t)groups * cfg->d + 8) * sizeof(float);
+  bool wide = cfg->G >= 512 && cfg->B <= 512;   // few rows, many candidates: 1024-thread workgroups
+  if (wide && ((size_t)cfg->G + (size_t)(1024 / tpr) * cfg->d + 16) * sizeof(float) > 64 * 1024) wide = false;
+  const int groups = (wide ? 1024 : 256) / tpr;
+  const size_t lds = ((size_t)cfg->G + (size_t)groups * cfg->d + 16) * sizeof(float);
   UR_REQUIRE(lds <= 64 * 1024, UR_ERR_UNSUPPORTED, "ur_gather_dot_loss_bwd: LDS need %zu bytes", lds);
-#define GO(T) hipLaunchKernelGGL((scorer_loss_bwd_kernel<T>), dim3(cfg->B), dim3(256), lds, st, *cfg, (const float4*)user_emb, \
+#define GO(T) do { if (wide) GOB(T, 1024); else GOB(T, 256); } while (0)
+#define GOB(T, NT) hipLaunchKernelGGL((scorer_loss_bwd_kernel<T, NT>), dim3(cfg->B), dim3(NT), lds, st, *cfg, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, scores, d_loss, loss_out, coef,  \
                                  (float4*)d_user, d_user_bias_rows)
   switch (tpr) {
