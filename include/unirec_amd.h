@@ -241,6 +241,11 @@ int64_t ur_rows_plan_workspace_bytes(int64_t n);
 int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
                  int32_t* uniq_idx, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws,
                  void* stream);
+/* The same plan for ids that arrive as n_runs concatenated runs, each ascending and unique (the owner side of the row-sharded
+ * step: one run per sending rank): a W-way merge by binary searches instead of a sort.  host_run_start[n_runs + 1] (HOST
+ * array, start[0] = 0, start[n_runs] = n).  Output identical to ur_rows_plan(ids, n, NULL, 0, ...).  ws: ur_rows_plan_workspace_bytes(n). */
+int ur_rows_plan_merge(const int32_t* ids, int64_t n, const int32_t* host_run_start, int32_t n_runs, int32_t* uniq_idx,
+                       int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws, void* stream);
 /* Row-sharded table (row i lives on rank i % world at local row i / world; SURVEY.md 8e -- not in the reference,
  * whose only strategy is DDP over a replicated dense table: unirec/facility/trainer.py:67).  Same as ur_rows_plan,
  * but the sort key is owner * ceil(n_rows/world) + local_row, so uniq_key[] is grouped by owner rank and

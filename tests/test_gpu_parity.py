@@ -427,3 +427,28 @@ def test_fullsoftmax_vs_oracle(model_name, B, N, bias):
     if bias:
         np.testing.assert_allclose(m.item_bias.grad.cpu().numpy(), G["item_bias"].numpy(), rtol=2e-4, atol=1e-7)
         assert float(m.user_bias.grad.abs().max()) == 0.0 and float(G["user_bias"].abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("W,n_per,n_rows", [(2, 1500, 4000), (8, 3500, 12_500_001), (5, 1, 10), (64, 300, 100000), (3, 40000, 90000)])
+def test_rows_plan_merge_equals_the_sorting_plan(W, n_per, n_rows):
+    """ur_rows_plan_merge (owner side of the row-sharded step: W ascending unique runs) == ur_rows_plan on the concatenation."""
+    from unirec_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(W * 1000 + n_per)
+    runs, counts = [], []
+    for r in range(W):
+        k = int(torch.randint(0, n_per + 1, (1,), generator=g)) if r % 3 else n_per       # some short / empty runs
+        ids = torch.unique(torch.randint(0, n_rows, (k,), generator=g)) if k else torch.zeros(0, dtype=torch.int64)
+        if r == 1 and ids.numel():
+            ids = torch.unique(torch.cat([ids, torch.zeros(1, dtype=torch.int64)]))     # the padding row, requested by one rank
+        runs.append(ids.to(torch.int32))
+        counts.append(int(ids.numel()))
+    cat = torch.cat(runs).to(dev)
+    if cat.numel() == 0:
+        pytest.skip("empty")
+    a = ops.rows_plan_merge(cat, counts)
+    b = ops.rows_plan(cat, None, n_rows)
+    nu = int(b.n_uniq.item())
+    assert int(a.n_uniq.item()) == nu
+    assert torch.equal(a.uniq_idx[:nu], b.uniq_idx[:nu]) and torch.equal(a.seg_start[:nu + 1], b.seg_start[:nu + 1])
+    assert torch.equal(a.sorted_pos[:cat.numel()], b.sorted_pos[:cat.numel()])

@@ -74,6 +74,7 @@ SIGNATURES = {
     "ur_gather_dot_loss_bwd": (C.c_int, [C.POINTER(UrLossCfg), P, P, I64, P, P, P, P, P, P, P, P, P]),
     "ur_rows_plan_workspace_bytes": (I64, [I64]),
     "ur_rows_plan": (C.c_int, [P, I64, P, I64, I64, P, P, P, P, P, P]),
+    "ur_rows_plan_merge": (C.c_int, [P, I64, P, I32, P, P, P, P, P, P]),
     "ur_rows_plan_sharded": (C.c_int, [P, I64, P, I64, I64, I32, P, P, P, P, P, P, P]),
     "ur_compact_index": (C.c_int, [P, P, P, I64, I64, P, P, P]),
     "ur_rows_reduce": (C.c_int, [P, P, P, P, I64, P, I64, P, P, I32, I32, P, P, P]),

@@ -611,6 +611,83 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const int* __rest
 
 using namespace ur;
 
+
+// ------------------------------------------------------------------------------------------------ plan of W sorted runs
+// The owner side of the row-sharded step receives, from every rank, a block of row ids that is already ascending and unique
+// (each sender's plan sorted them).  The plan of their concatenation -- what ur_rows_plan would compute with a full radix
+// sort (200 us in one workgroup at 28 K ids) -- is a W-way MERGE: the sorted position of an id is its offset in its own run
+// plus, for every other run, the number of smaller ids (ids of EARLIER runs that are equal also come first: the order a stable
+// sort gives).  One binary search per (id, run), all independent: one thread per id.
+struct RunStarts { int start[66]; int W; };   // start[W] = n
+
+__global__ __launch_bounds__(256) void plan_merge_rank_kernel(const int* __restrict__ ids, RunStarts rs, int n, int* __restrict__ sorted_pos,
+                                                              int* __restrict__ keys_sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int r = 0;
+  while (r + 1 < rs.W && i >= rs.start[r + 1]) ++r;
+  const int x = ids[i];
+  int pos = i - rs.start[r];
+  for (int q = 0; q < rs.W; ++q) {
+    if (q == r) continue;
+    int lo = rs.start[q], hi = rs.start[q + 1];
+    if (q < r) {   // upper bound: ids <= x
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (ids[mid] <= x) lo = mid + 1; else hi = mid; }
+    } else {       // lower bound: ids < x
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (ids[mid] < x) lo = mid + 1; else hi = mid; }
+    }
+    pos += lo - rs.start[q];
+  }
+  sorted_pos[pos] = i;
+  keys_sorted[pos] = x;
+}
+// heads of the runs of equal keys -> uniq_idx / seg_start / n_uniq   (one workgroup; thread t owns a contiguous slice)
+__global__ __launch_bounds__(1024) void plan_merge_heads_kernel(const int* __restrict__ keys_sorted, int n, int* __restrict__ uniq_idx,
+                                                               int* __restrict__ seg_start, int* __restrict__ n_uniq_dev) {
+  __shared__ int cnt[1024];
+  const int tid = threadIdx.x, per = (n + 1023) / 1024;
+  const int b = min(n, tid * per), e = min(n, b + per);
+  int c = 0;
+  for (int p = b; p < e; ++p) c += (p == 0 || keys_sorted[p] != keys_sorted[p - 1]) ? 1 : 0;
+  cnt[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+    const int v = tid >= off ? cnt[tid - off] : 0;
+    __syncthreads();
+    cnt[tid] += v;
+    __syncthreads();
+  }
+  int u = cnt[tid] - c;
+  for (int p = b; p < e; ++p)
+    if (p == 0 || keys_sorted[p] != keys_sorted[p - 1]) {
+      uniq_idx[u] = keys_sorted[p];
+      seg_start[u] = p;
+      ++u;
+    }
+  if (tid == 1023) {
+    n_uniq_dev[0] = cnt[1023];
+    seg_start[cnt[1023]] = n;
+  }
+}
+
+extern "C" int ur_rows_plan_merge(const int32_t* ids, int64_t n, const int32_t* host_run_start, int32_t n_runs, int32_t* uniq_idx,
+                                  int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws, void* stream) {
+  UR_REQUIRE(ids && host_run_start && uniq_idx && seg_start && sorted_pos && n_uniq_dev && ws, UR_ERR_ARG, "ur_rows_plan_merge: null pointer");
+  UR_REQUIRE(n > 0 && n < (1LL << 30) && n_runs >= 1 && n_runs <= 65, UR_ERR_ARG, "ur_rows_plan_merge: n=%lld runs=%d", (long long)n, n_runs);
+  RunStarts rs;
+  rs.W = n_runs;
+  for (int q = 0; q <= n_runs; ++q) rs.start[q] = host_run_start[q];
+  UR_REQUIRE(rs.start[0] == 0 && rs.start[n_runs] == n, UR_ERR_ARG, "ur_rows_plan_merge: run offsets must span [0, n]");
+  hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_SORT, st, (double)n * 4.0 * 4);
+  int* keys_sorted = (int*)ws;   // n ints (the plan workspace is far larger)
+  hipLaunchKernelGGL(plan_merge_rank_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids, rs, (int)n, sorted_pos, keys_sorted);
+  UR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(1), dim3(1024), 0, st, keys_sorted, (int)n, uniq_idx, seg_start, n_uniq_dev);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
 extern "C" int64_t ur_rows_plan_workspace_bytes(int64_t n) {
   if (n < 0) return UR_ERR_ARG;
   return carve_plan(n > 0 ? n : 1, nullptr).bytes;

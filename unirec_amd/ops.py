@@ -196,6 +196,23 @@ def rows_plan(ids_a, ids_b, n_rows, out=None) -> RowsPlan:
     return pl
 
 
+def rows_plan_merge(ids, run_counts) -> RowsPlan:
+    """plan of int32 `ids` that consist of len(run_counts) concatenated runs, each ascending and unique (one per sending rank):
+    same result as rows_plan(ids, None, ...), by a W-way merge instead of a sort (include/unirec_amd.h: ur_rows_plan_merge)."""
+    _chk(ids, torch.int32, "ids")
+    n = ids.numel()
+    starts = [0]
+    for c in run_counts:
+        starts.append(starts[-1] + int(c))
+    if starts[-1] != n:
+        raise _lib.UnirecAmdError("rows_plan_merge: run_counts do not sum to the number of ids")
+    pl, ws = rows_plan_alloc(n, n, ids.device)
+    arr = (C.c_int32 * len(starts))(*starts)
+    check(lib.ur_rows_plan_merge(_p(ids), n, arr, len(run_counts), _p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq),
+                                 _p(ws), _stream()), "ur_rows_plan_merge")
+    return pl
+
+
 def rows_plan_sharded(ids_a, ids_b, n_rows, world, out=None):
     """Like rows_plan, but keys are (owner = id % world, local row = id // world); returns (plan, owner_counts[world] int32 dev).
     plan.uniq_idx holds the sharded keys owner * ceil(n_rows/world) + local_row.

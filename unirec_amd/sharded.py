@@ -161,7 +161,9 @@ class ShardedSasrecStep:
         req_send = (keys % self.n_local).to(torch.int32) if W > 1 else keys
         # 2. all-to-all #1: row ids -> owners
         req = self.xchg.all_to_all_rows(req_send, send_counts, recv_counts)
-        own = ops.rows_plan(req.contiguous(), None, self.n_local)
+        # every sender's block is already ascending and unique (its plan sorted it): the owner-side plan is a W-way merge
+        own = (ops.rows_plan_merge(req.contiguous(), recv_counts) if 1 < W <= 64 and req.numel() > 0
+               else ops.rows_plan(req.contiguous(), None, self.n_local))
         if self.last is not None and self.t > 1:
             ops.lazy_adam_catchup(acfg, self.table, self.m, self.v, self.last, own)
         # 3. all-to-all #2: rows back -> compact table [n_uniq, d]
