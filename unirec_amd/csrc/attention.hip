@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(256) void attn_fwd_m16_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = jt * 16 + 4 * kq + r;
-        const bool ok = j < kend && kvalid[min(j, kend - 1)] != 0.f && (!causal || j <= i);
+        const bool ok = (j < kend) & (kvalid[min(j, kend - 1)] != 0.f) & (!causal | (j <= i));   // (no short-circuit: no divergent branches)
         e[r] = ok ? (literal ? (st[r] / p.sqrt_hd + -10000.0f) * LOG2E : st[r] * sc2) : -INFINITY;
         tmax = fmaxf(tmax, e[r]);
       }
@@ -1100,8 +1100,8 @@ __global__ __launch_bounds__(256) void attn_fwd_m16_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = min(jt * 16 + 4 * kq + r, kend - 1);
-        const float vv = c16 < HD ? vs[j * LDK + c16] : 0.f;
-        oa = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pr[r], oa, 0, 0, 0);
+        const float vraw = vs[j * LDK + c16];   // (c16 >= HD reads padding / the next row: discarded by the select)
+        oa = __builtin_amdgcn_mfma_f32_16x16x4f32(c16 < HD ? vraw : 0.f, pr[r], oa, 0, 0, 0);
       }
     }
     l += __shfl_xor(l, 16, 64);
@@ -1197,15 +1197,16 @@ __global__ __launch_bounds__(256) void attn_bwd_m16_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = jt * 16 + 4 * kq + r, jc = min(j, L - 1);
-        const bool ok = j < L && kvalid[jc] != 0.f && (!causal || j <= i);
+        const bool ok = (j < L) & (kvalid[jc] != 0.f) & (!causal | (j <= i));   // (no short-circuit: no divergent branches)
         const float e = literal ? (sT[r] / p.sqrt_hd + -10000.0f) * LOG2E : sT[r] * sc2;
-        const float pv = ok ? __builtin_amdgcn_exp2f(e - lse2) : 0.f;
+        const float pv = __builtin_amdgcn_exp2f(ok ? e - lse2 : -INFINITY);   // branch-free: exp2(-inf) = 0 for masked keys
         ds[r] = pv * (attn_keep<DROP>(p, rk, j) * dpT[r] - Di);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int jc = min(jt * 16 + 4 * kq + r, L - 1);
-        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(c16 < HD ? Ks[jc * LDK + c16] : 0.f, ds[r], dq, 0, 0, 0);
+        const float kk = Ks[jc * LDK + c16];   // (c16 >= HD reads the row's padding / the next row: discarded by the select)
+        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(c16 < HD ? kk : 0.f, ds[r], dq, 0, 0, 0);
       }
     }
     if (i < L && i >= pad && 4 * kq < HD)
@@ -1217,7 +1218,7 @@ __global__ __launch_bounds__(256) void attn_bwd_m16_kernel(const float* __restri
     float kf[KS], vf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) { kf[s] = Ks[jc * LDK + kq * KS + s]; vf[s] = Vs[jc * LDK + kq * KS + s]; }
-    const bool kv = j < L && kvalid[jc] != 0.f;
+    const bool kv = (j < L) & (kvalid[jc] != 0.f);
     floatx4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
     for (int it = causal ? jt : 0; it < nt; ++it) {
       const int ir = min(it * 16 + c16, L - 1);
@@ -1231,9 +1232,9 @@ __global__ __launch_bounds__(256) void attn_bwd_m16_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = it * 16 + 4 * kq + r, ic = min(i, L - 1);
-        const bool ok = kv && i < L && i >= pad && (!causal || j <= i);
+        const bool ok = kv & (i < L) & (i >= pad) & (!causal | (j <= i));
         const float e = literal ? (sM[r] / p.sqrt_hd + -10000.0f) * LOG2E : sM[r] * sc2;
-        const float pv = ok ? __builtin_amdgcn_exp2f(e - lse2s[ic]) : 0.f;
+        const float pv = __builtin_amdgcn_exp2f(ok ? e - lse2s[ic] : -INFINITY);
         const float mk = DROP ? drop_mul(attn_rowkey(p, b, h, ic), (unsigned)j, p.dthresh, p.dscale) : 1.0f;
         pd[r] = pv * mk;
         ds[r] = pv * (mk * dpM[r] - Ds[ic]);
@@ -1241,8 +1242,9 @@ __global__ __launch_bounds__(256) void attn_bwd_m16_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ic = min(it * 16 + 4 * kq + r, L - 1);
-        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(c16 < HD ? Gs[ic * LDK + c16] : 0.f, pd[r], dv, 0, 0, 0);
-        dk = __builtin_amdgcn_mfma_f32_16x16x4f32(c16 < HD ? Qs[ic * LDK + c16] : 0.f, ds[r], dk, 0, 0, 0);
+        const float gg = Gs[ic * LDK + c16], qq = Qs[ic * LDK + c16];
+        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(c16 < HD ? gg : 0.f, pd[r], dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_16x16x4f32(c16 < HD ? qq : 0.f, ds[r], dk, 0, 0, 0);
       }
     }
     if (j < L && j >= pad && 4 * kq < HD) {
