@@ -301,6 +301,10 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
   if (small_m(a)) return launch_nt<32, 128, PRO, EPI>(a, st);
   // compacted rows and a one-tile-wide output: the 64-row grid (M/64 workgroups, ~1.5 per CU) hides the rows that were
   // skipped behind wave quantisation; 32-row tiles let the saving through
+  // ... as 64 x 64 tiles (same workgroup count as 32 x 128, 16 KB instead of 20 KB of operands per K-step: measured 1 % of the
+  // step); UR_GEMM_C64=0 restores the 32-row tiles
+  static const int c64 = getenv("UR_GEMM_C64") ? atoi(getenv("UR_GEMM_C64")) : 1;   // tuning aid
+  if (a.m_dev && a.N <= 128 && a.N > 64 && c64 == 1) return launch_nt<64, 64, PRO, EPI>(a, st);
   if (a.m_dev && a.N <= 128) return launch_nt<32, 128, PRO, EPI>(a, st);
   // short K, wide N (QKV, FFN-1, d-act): the 16-deep K-step variant keeps 4 workgroups per CU resident and measured
   // 6-10 % faster at M = 25600; elsewhere the 32-deep step wins
