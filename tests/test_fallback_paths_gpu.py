@@ -1,0 +1,40 @@
+"""The kernels that are no longer the default for the benchmark shapes stay correct: the same parity tests, re-run in a subprocess
+with the tuning switch that routes through them (the switches are read once per process, hence the subprocess)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(env, args, expect_min_passed=1):
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x"] + args, env=e, capture_output=True, text=True, timeout=1500,
+                       cwd=os.path.dirname(HERE))
+    tail = r.stdout[-1500:] + r.stderr[-500:]
+    assert r.returncode == 0, tail
+    passed = [int(w) for line in r.stdout.splitlines() if " passed" in line for w in line.split() if w.isdigit()]
+    assert passed and passed[0] >= expect_min_passed, tail
+
+
+@pytest.mark.parametrize("env", [{"UR_ATTN_NO_M16": "1"},       # L > 64: register-broadcast kernels; L <= 64: 32x32 MFMA forward AND backward
+                                 {"UR_ATTN_BWD32": "1"},        # 32x32 single-block backward for L <= 64
+                                 {"UR_ATTN_NO_MFMA": "1"},      # no MFMA attention at all (VALU kernels, no compact rows)
+                                 {"UR_ATTN_M16": "1"}])         # 16x16-tile forward for L <= 64 as well
+def test_attention_kernel_families(env):
+    _run(env, [os.path.join(HERE, "test_dropout_gpu.py"), "-k", "sasrec"], expect_min_passed=40)
+    _run(env, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)
+
+
+def test_gru_per_step_path_and_sorting_owner_plan():
+    _run({"UR_GRU_NO_SEQ": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_edge_cases_gpu.py"),
+                                  os.path.join(HERE, "test_trainer_gpu.py"), "-k", "gru or GRU or g7"], expect_min_passed=8)
+
+
+def test_chunked_topk_and_32_row_gemm_tiles():
+    _run({"UR_TOPK_NO_PRUNE": "1"}, [os.path.join(HERE, "test_full_rank.py"), "-k", "topk and not overflow and not 3200003 and not 2200000"],
+         expect_min_passed=5)
+    _run({"UR_GEMM_C64": "0", "UR_SASREC_SIDE": "0"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden"], expect_min_passed=20)
