@@ -212,7 +212,7 @@ typedef struct UrLossCfg {
   float ccl_w, ccl_m;
 } UrLossCfg;
 /* user_bias / item_bias / user_id may be NULL (bias off). label (int32 [B,G]) is required for BCE and
- * SOFTMAX. Outputs: scores [B,G]; loss_out[2]: [0] = reduced loss (reduction=True), [1] = the mean's
+ * SOFTMAX. Outputs: scores [B,G]; loss_out[4] ([3] unused): [2] = update guard (1, or -1 when the loss is NaN), [0] = reduced loss (reduction=True), [1] = the mean's
  * denominator (rows, elements or positives); loss_rows [2*B]: per-row numerators (for BPR/CCL the
  * reduction=False row losses) followed by per-row denominators. */
 int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_emb, const float* item_table, int64_t n_items,
@@ -309,6 +309,11 @@ int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, float* v, i
 int ur_sumsq(const float* x, int64_t n, float* out, int accumulate, void* ws_2048_floats, void* stream);
 /* scale_out[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))   (torch clip_grad_norm_ coefficient) */
 int ur_clip_coef(const float* sumsq, float max_norm, float* scale_out, void* stream);
+/* NaN guard (Trainer.fit skips the update of a step whose loss is NaN: unirec/facility/trainer.py:164-168,343-350).  The loss
+ * kernels publish loss_out[2] = 1, or -1 when the loss is NaN; a grad_scale_dev value < 0 makes ur_dense_adam / ur_sparse_adam_rows
+ * return without touching anything (no host round trip).  This variant of ur_clip_coef passes the guard through:
+ * scale_out[0] = guard[0] < 0 ? -1 : clip coefficient. */
+int ur_clip_coef_guarded(const float* sumsq, float max_norm, const float* guard, float* scale_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Negative sampling and row construction (replaces the per-sample Python of
@@ -426,7 +431,7 @@ int ur_full_topk(const float* user_emb, const float* item_table, int64_t n_items
  * Replaces BaseRecommender.forward with loss_type 'fullsoftmax' (unirec/model/base/recommender.py:46-55) + _cal_loss
  * (unirec/model/base/reco_abc.py:266-270):  loss = mean_b( logsumexp_n s(b,n) - s(b,target_b) ) over ALL n in [0,n_items),
  * s(b,n) = (u_b . E_n + user_bias[user_b] + item_bias[n]) / tau, clamped to +-score_clip when score_clip > 0.
- *   fwd: target_score[B] = s(b,target_b) (from ur_gather_dot_loss_fwd with UR_LOSS_NONE); writes lse[B], loss_out[2].
+ *   fwd: target_score[B] = s(b,target_b) (from ur_gather_dot_loss_fwd with UR_LOSS_NONE); writes lse[B], loss_out[4] (as ur_gather_dot_loss_fwd).
  *   bwd: d_user_emb [B,d]; d_item_table [n_items,d] DENSE and overwritten (row 0 = 0: padding_idx); d_item_bias [n_items]
  *        (required iff item_bias); d user_bias is identically 0.  d_loss: device scalar (nullable = 1).
  * The [B, n_items] scores exist one 2^20-item chunk at a time (ws: ur_full_softmax_workspace_bytes). */

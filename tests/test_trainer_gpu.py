@@ -158,3 +158,42 @@ def test_fit_fullsoftmax_follows_the_oracle():
         if k.endswith("key.bias"):
             continue
         np.testing.assert_allclose(v.cpu().numpy(), P[k].numpy(), rtol=1e-3, atol=1e-4, err_msg=k)
+
+
+def test_a_step_with_nan_loss_is_skipped_without_a_host_sync():
+    """Trainer.fit's NaN check (unirec/facility/trainer.py:164-168,343-350): the update of a step whose loss is NaN is not applied.
+    Here the check is a device flag written by the loss kernel and read by the update kernels."""
+    from unirec_amd.facility.optimizer import SparseDenseAdam
+    from unirec_amd.model.sequential.sasrec import SASRec
+    dev = torch.device("cuda:0")
+    for clip in (None, 1.0):
+        cfg = dict(model="SASRec", n_users=10, n_items=500, device="cuda:0", loss_type="softmax", embedding_size=32, hidden_size=32,
+                   dropout_prob=0.0, init_method="normal", init_mean=0.0, init_std=0.05, has_user_emb=False, distance_type="dot", tau=1.0,
+                   train_file_format="user-item", exp_name="t", n_layers=2, n_heads=4, inner_size=64, hidden_dropout_prob=0.0,
+                   attn_dropout_prob=0.0, hidden_act="gelu", layer_norm_eps=1e-10, max_seq_len=8, use_position_emb=True)
+        torch.manual_seed(0)
+        m = SASRec(cfg)
+        opt = SparseDenseAdam(m, lr=1e-2, grad_clip=clip)
+        g = torch.Generator().manual_seed(1)
+        seq = torch.randint(1, 500, (16, 8), generator=g, dtype=torch.int32).to(dev)
+        ids = torch.randint(1, 500, (16, 5), generator=g).to(dev)
+        lab = torch.zeros(16, 5, dtype=torch.int32, device=dev)
+        lab[:, 0] = 1
+        m.train()
+
+        def step():
+            opt.zero_grad()
+            opt.plan_batch(item_seq=seq, item_id=ids)
+            loss = m.forward_backward(item_id=ids, label=lab, item_seq=seq)
+            opt.step()
+            return loss
+        step()                                                          # a normal step moves the weights
+        w1, t1 = m.dense_flat.data.clone(), m.item_embedding.weight.data.clone()
+        saved = m.item_embedding.weight.data[int(ids[0, 0])].clone()
+        m.item_embedding.weight.data[int(ids[0, 0])] = float("nan")     # poison one candidate row -> NaN loss
+        loss = step()
+        assert torch.isnan(loss)
+        m.item_embedding.weight.data[int(ids[0, 0])] = saved
+        assert torch.equal(m.dense_flat.data, w1) and torch.equal(m.item_embedding.weight.data, t1)   # nothing moved
+        loss = step()                                                   # and training goes on
+        assert torch.isfinite(loss) and not torch.equal(m.dense_flat.data, w1)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "ur_lazy_adam_flush": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, I64, I32, P]),
     "ur_sumsq": (C.c_int, [P, I64, P, C.c_int, P, P]),
     "ur_clip_coef": (C.c_int, [P, C.c_float, P, P]),
+    "ur_clip_coef_guarded": (C.c_int, [P, C.c_float, P, P, P]),
     "ur_host_sampler_create": (P, [C.c_uint64]),
     "ur_host_sampler_destroy": (None, [P]),
     "ur_host_sampler_getrandbits": (C.c_uint64, [P, C.c_int]),

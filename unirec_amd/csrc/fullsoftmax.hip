@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void fs_loss_kernel(const float* __restrict__ 
     for (int i = 0; i < 256; ++i) t += red[i];
     loss_out[0] = t / (float)B;
     loss_out[1] = (float)B;
+    loss_out[2] = t != t ? -1.0f : 1.0f;   // update guard (see ur_gather_dot_loss_fwd)
   }
 }
 

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
   if (threadIdx.x == 0) {
     out[0] = s / n;
     out[1] = n;
+    out[2] = (s / n) != (s / n) ? -1.0f : 1.0f;   // update guard: -1 when the loss is NaN (the optimizer kernels then skip the step)
   }
 }
 

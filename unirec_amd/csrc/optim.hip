@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void dense_adam_kernel(float* __restrict__ p, 
                                                          float* __restrict__ v, long long n, AdamK a, float bc1, float bc2s,
                                                          const float* __restrict__ scale_dev) {
   const float scale = scale_dev ? *scale_dev : 1.0f;
+  if (scale < 0.f) return;   // update guard: the step's loss was NaN (Trainer skips such a step, trainer.py:343-350)
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float w = p[i], mi = m[i], vi = v[i];
     opt_elem(w, mi, vi, g[i] * scale, a, bc1, bc2s);
@@ -60,9 +61,10 @@ __global__ __launch_bounds__(256) void sumsq_stage2(const float* __restrict__ pa
     out[0] = accumulate ? out[0] + t : t;
   }
 }
-__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ out) {
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ out,
+                                 const float* __restrict__ guard) {
   const float c = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
-  out[0] = c < 1.f ? c : 1.f;
+  out[0] = (guard && guard[0] < 0.f) ? -1.f : (c < 1.f ? c : 1.f);
 }
 
 }  // namespace ur
@@ -102,11 +104,17 @@ extern "C" int ur_sumsq(const float* x, int64_t n, float* out, int accumulate, v
   return UR_OK;
 }
 
-extern "C" int ur_clip_coef(const float* sumsq, float max_norm, float* scale_out, void* stream) {
+static int clip_coef_impl(const float* sumsq, float max_norm, float* scale_out, const float* guard, void* stream) {
   UR_REQUIRE(sumsq && scale_out && max_norm > 0.f, UR_ERR_ARG, "ur_clip_coef: bad argument");
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, as_stream(stream), sumsq, max_norm, scale_out);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, as_stream(stream), sumsq, max_norm, scale_out, guard);
   UR_LAUNCH_CHECK();
   return UR_OK;
+}
+extern "C" int ur_clip_coef(const float* sumsq, float max_norm, float* scale_out, void* stream) {
+  return clip_coef_impl(sumsq, max_norm, scale_out, nullptr, stream);
+}
+extern "C" int ur_clip_coef_guarded(const float* sumsq, float max_norm, const float* guard, float* scale_out, void* stream) {
+  return clip_coef_impl(sumsq, max_norm, scale_out, guard, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -494,6 +494,7 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int n_uniq = (int)min((long long)*n_uniq_dev, n_max);
   const float scale = scale_dev ? *scale_dev : 1.0f;
+  if (MODE == 0 && scale < 0.f) return;   // update guard: NaN loss, the whole step is skipped (see dense_adam_kernel)
   const float bc1 = 1.f - powf(a.b1, (float)a.step), bc2s = sqrtf(1.f - powf(a.b2, (float)a.step));
   for (int u = blockIdx.x * groups + g; u < n_uniq; u += gridDim.x * groups) {
     const long long row = uniq_idx[u];

@@ -177,7 +177,10 @@ class SparseDenseAdam:
             if name in reduced:
                 pl, ug = reduced.pop(name)
                 ops.rows_scatter_add(pl, ug, dg)
-        scale = None
+        # NaN guard (trainer.py:343-350: a step whose loss is NaN is not applied): the loss kernels left a device flag
+        # (1, or -1 for NaN) that the update kernels read as their gradient scale -- < 0 = return untouched; no host round trip
+        guard = getattr(model, "loss_guard", None)
+        scale = guard
         if self.grad_clip is not None:
             ss = self._scalars[0:1]
             ops.sumsq(model.dense_flat.grad, ss, accumulate=False, ws=self._sumsq_ws)
@@ -189,7 +192,7 @@ class SparseDenseAdam:
             for dg in dense_tables.values():
                 ops.sumsq(dg, ss, accumulate=True, ws=self._sumsq_ws)
             scale = self._scalars[1:2]
-            ops.clip_coef(ss, self.grad_clip, scale)
+            ops.clip_coef(ss, self.grad_clip, scale, guard=guard)
         if model.dense_flat.grad is not None:
             ops.dense_adam(cfg, model.dense_flat.data, model.dense_flat.grad, self.dense_m, self.dense_v, scale)
         for p, (m, v) in zip(self.extra, self.extra_state):
@@ -202,5 +205,7 @@ class SparseDenseAdam:
             st = self.tables[name]
             ops.dense_adam(cfg, st["w"], dg, st["m"], st["v"], scale)
         self._plans = {}
+        if guard is not None:
+            object.__setattr__(model, "loss_guard", None)
         model.sparse_grads.clear()
         model.dense_table_grads.clear()

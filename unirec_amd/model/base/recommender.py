@@ -32,6 +32,7 @@ class _ScoreLossFn(torch.autograd.Function):
         ctx.save_for_backward(user_emb, item_id, label if label is not None else item_id.new_empty(0), scores, loss_out,
                               user_id if user_id is not None else item_id.new_empty(0))
         ctx.mark_non_differentiable(scores, loss_rows)
+        object.__setattr__(model, "loss_guard", loss_out[2:3])   # device flag: -1 = this step's loss is NaN (optimizer skips the update)
         return loss_out[0], scores, loss_rows
 
     @staticmethod
@@ -67,6 +68,7 @@ class _FullSoftmaxFn(torch.autograd.Function):
                                                  ub, ib, model.tau, model.SCORE_CLIP)
         ctx.model, ctx.ws = model, ws
         ctx.save_for_backward(user_emb, target, lse, user_id if user_id is not None else target.new_empty(0))
+        object.__setattr__(model, "loss_guard", loss_out[2:3])
         return loss_out[0]
 
     @staticmethod
@@ -212,6 +214,7 @@ class BaseRecommender(AbstractRecommender):
             loss_out, lse, ws = ops.full_softmax_fwd(user_emb, self.item_embedding.weight.data, target, uid, ub, ib, self.tau, self.SCORE_CLIP)
             self._full_softmax_backward(user_emb, target, lse, ws, user_id, None)
             self._encode_backward(state, self._fs_d_user)
+            object.__setattr__(self, "loss_guard", loss_out[2:3])
             return loss_out[0]
         if self.group_size > 0:
             raise NotImplementedError("group_size > 0 (user-item-label rows) is not on the accelerated path")
@@ -241,6 +244,7 @@ class BaseRecommender(AbstractRecommender):
             g.index_add_(0, user_id, d_ub)
             self.user_bias.grad = g
         self._encode_backward(state, d_user)
+        object.__setattr__(self, "loss_guard", loss_out[2:3])   # device flag: -1 = this step's loss is NaN (optimizer skips the update)
         return loss_out[0]
 
     def _predict_layer(self, user_emb, items_emb, user_id, item_id):

@@ -142,7 +142,7 @@ def gather_dot_loss_fwd(cfg, user_emb, item_table, item_id, label=None, user_bia
     dev = user_emb.device
     scores = torch.empty(cfg.B, cfg.G, dtype=torch.float32, device=dev)
     loss_rows = torch.empty(2 * cfg.B, dtype=torch.float32, device=dev)
-    loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+    loss_out = torch.empty(4, dtype=torch.float32, device=dev)   # [loss, count, update guard, -]
     check(lib.ur_gather_dot_loss_fwd(C.byref(cfg), _p(user_emb), _p(item_table), item_table.shape[0], _p(item_id), _p(label),
                                      _p(user_bias), _p(item_bias), _p(user_id), _p(scores), _p(loss_rows), _p(loss_out),
                                      _stream()), "ur_gather_dot_loss_fwd")
@@ -300,8 +300,12 @@ def sumsq(x, out, accumulate=False, ws=None):
     check(lib.ur_sumsq(_p(x), x.numel(), _p(out), int(accumulate), _p(ws), _stream()), "ur_sumsq")
 
 
-def clip_coef(sumsq_t, max_norm, out):
-    check(lib.ur_clip_coef(_p(sumsq_t), float(max_norm), _p(out), _stream()), "ur_clip_coef")
+def clip_coef(sumsq_t, max_norm, out, guard=None):
+    """out[0] = min(1, max_norm / (sqrt(sumsq) + 1e-6)); with guard (device float: -1 = the step's loss was NaN) -> -1 passes through."""
+    if guard is None:
+        check(lib.ur_clip_coef(_p(sumsq_t), float(max_norm), _p(out), _stream()), "ur_clip_coef")
+    else:
+        check(lib.ur_clip_coef_guarded(_p(sumsq_t), float(max_norm), _p(guard), _p(out), _stream()), "ur_clip_coef_guarded")
 
 
 # --------------------------------------------------------------------------------------------- full-item ranking
@@ -417,7 +421,7 @@ def full_softmax_fwd(user_emb, item_table, target, user_id=None, user_bias=None,
     ts, _, _ = gather_dot_loss_fwd(cfg, user_emb, item_table, target.view(B, 1).contiguous(), None, user_bias, item_bias,
                                    user_id if user_bias is not None else None)
     lse = torch.empty(B, dtype=torch.float32, device=dev)
-    loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+    loss_out = torch.empty(4, dtype=torch.float32, device=dev)   # [loss, count, update guard, -]
     ws = torch.empty(check(lib.ur_full_softmax_workspace_bytes(B, d, N), "ur_full_softmax_workspace_bytes"), dtype=torch.uint8, device=dev)
     check(lib.ur_full_softmax_fwd(_p(user_emb), _p(item_table), N, B, d, _p(target), _p(user_id), _p(user_bias), _p(item_bias), float(tau),
                                   float(score_clip if score_clip else -1.0), _p(ts.view(-1)), _p(lse), _p(loss_out), _p(ws), _stream()),
