@@ -57,6 +57,21 @@ def test_scheduler_mirrors_match_torch(kind):
         assert math.isclose(mine.param_groups[0]["lr"], topt.param_groups[0]["lr"], rel_tol=1e-12, abs_tol=1e-18), (kind, s)
 
 
+def test_early_stopping_rule_is_the_references():
+    """Trainer.early_stopping: known answers worked out from unirec/facility/trainer.py:188-233 (stop when the number of
+    consecutive non-improving validations EXCEEDS early_stop for 'bigger' metrics; equality for 'smaller'; <= 0 disables)."""
+    from unirec_amd.facility.trainer import Trainer
+    es = Trainer.early_stopping
+    assert es(0.3, None, 1, 2, True) == (0.3, 0, False, True)
+    assert es(0.2, 0.3, 0, 2, True) == (0.3, 1, False, False)
+    assert es(0.2, 0.3, 1, 2, True) == (0.3, 2, False, False)          # == max_step: not yet
+    assert es(0.2, 0.3, 2, 2, True) == (0.3, 3, True, False)           # > max_step: stop
+    assert es(0.3, 0.3, 0, 2, True) == (0.3, 1, False, False)          # a tie is not an improvement
+    assert es(0.4, 0.3, 2, 2, True) == (0.4, 0, False, True)
+    assert es(0.5, 0.3, 1, 2, False) == (0.3, 2, True, False)          # 'smaller': stops at equality
+    assert es(0.1, 0.3, 5, 0, True) == (0.3, 5, False, True)           # disabled: always an update, nothing tracked
+
+
 # ----------------------------------------------------------------------------------------------------------- HIP kernels
 LR = 1e-3   # Adam-type rules move an element by ~lr whatever the size of its gradient, so rounding-noise gradients (analytically
             # zero entries) turn into +-lr differences: compared at atol = lr / 10 as in tests/test_trainer_gpu.py

@@ -197,6 +197,22 @@ class Trainer(object):
         opt.step()
         return loss.detach()
 
+    @staticmethod
+    def early_stopping(value, best, cur_step, max_step=4, bigger=True):
+        """Trainer.early_stopping (unirec/facility/trainer.py:188-233), value for value: -> (best, cur_step, stop_flag, update_flag).
+        Note the asymmetry the reference has: 'bigger' stops when cur_step > max_step, 'smaller' when cur_step >= max_step; with
+        max_step <= 0 early stopping is off and every validation counts as an update."""
+        stop_flag = update_flag = False
+        if max_step > 0:
+            if (best is None) or (value > best if bigger else value < best):
+                cur_step, best, update_flag = 0, value, True
+            else:
+                cur_step += 1
+                stop_flag = cur_step > max_step if bigger else cur_step >= max_step
+        else:
+            update_flag = True
+        return best, cur_step, stop_flag, update_flag
+
     def fit(self, train_data, valid_data=None, save_model=True, load_pretrained_model=False, model_file=None, verbose=2):
         if load_pretrained_model:
             if model_file is None:
@@ -206,15 +222,17 @@ class Trainer(object):
             if valid_data is not None:
                 res = self.evaluate(valid_data, load_best_model=False)
                 score = res[self.key_metric]
-                better = self.best_valid_score is None or score > self.best_valid_score
-                if better:
-                    self.best_valid_score, self.cur_step = score, 0
+                self.best_valid_score, self.cur_step, stop_flag, update_flag = Trainer.early_stopping(
+                    score, self.best_valid_score, self.cur_step, max_step=self.early_stop, bigger=True)
+                self.logger.info("epoch %d evaluating [%s: %f]", epoch_idx, self.key_metric, score)
+                if update_flag:
                     if save_model:
                         self.save_model(self.saved_model_file, self.optimizer, self.scheduler, epoch_idx, self.cur_step, res, self.config)
+                    self.best_valid_result = res
                 else:
-                    self.cur_step += 1
-                self.logger.info("epoch %d evaluating [%s: %f]", epoch_idx, self.key_metric, score)
-                if self.early_stop and self.cur_step >= self.early_stop:
+                    self.logger.info("No better score in the epoch. Patience: %d / %d", self.cur_step, self.early_stop)
+                if stop_flag:
+                    self.logger.info("Finished training, best eval result in epoch %d", epoch_idx - self.cur_step)
                     break
                 if self.scheduler and epoch_idx > 0:
                     self.scheduler.step(score)
