@@ -452,3 +452,35 @@ def test_rows_plan_merge_equals_the_sorting_plan(W, n_per, n_rows):
     assert int(a.n_uniq.item()) == nu
     assert torch.equal(a.uniq_idx[:nu], b.uniq_idx[:nu]) and torch.equal(a.seg_start[:nu + 1], b.seg_start[:nu + 1])
     assert torch.equal(a.sorted_pos[:cat.numel()], b.sorted_pos[:cat.numel()])
+
+
+@pytest.mark.parametrize("t0,gap", [(1, 1), (3, 7), (10, 100), (50, 192), (50, 193), (1000, 400), (20000, 5000)])
+def test_lazy_replay_of_long_gaps_equals_iterated_dense_adam(t0, gap):
+    """A row last updated at step t0 and looked up again `gap` steps later: ur_lazy_adam_flush must leave (w, m, v) where `gap`
+    zero-gradient steps of dense torch Adam leave them (fp64 iteration of the published update rule as the yardstick).  Gaps beyond
+    LAZY_EXACT_STEPS = 192 only decay the moments: the skipped weight updates are below fp32 resolution."""
+    from unirec_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(t0 + gap)
+    n, d, lr, b1, b2, eps = 64, 32, 1e-3, 0.9, 0.999, 1e-8
+    w = torch.randn(n, d, generator=g) * 0.05
+    m = torch.randn(n, d, generator=g) * 1e-3
+    v = m * m * (0.1 + 9.9 * torch.rand(n, d, generator=g))   # |m| / sqrt(v) in [0.3, 3], as Adam's moments are
+    m[::7] *= 1e-6                                          # some rows with tiny moments: eps matters there
+    v[::7] *= 1e-12
+    wd, md, vd = w.double().clone(), m.double().clone(), v.double().clone()
+    b1f, b2f = float(np.float32(b1)), float(np.float32(b2))   # torch multiplies fp32 tensors by the fp32-rounded betas ...
+    for t in range(t0 + 1, t0 + gap + 1):                   # torch.optim.Adam with a zero gradient
+        md *= b1f
+        vd *= b2f                                           # ... and evaluates the bias corrections below in Python floats
+        wd -= (lr / (1 - b1 ** t)) * md / (vd.sqrt() / (1 - b2 ** t) ** 0.5 + eps)
+    W, M, V = w.to(dev), m.to(dev), v.to(dev)
+    last = torch.full((n,), t0, dtype=torch.int32, device=dev)
+    last[0] = 0                                             # row 0: the padding row is never replayed
+    ops.lazy_adam_flush(ops.adam_cfg(lr, t0 + gap), W, M, V, last)
+    assert int(last[1:].min()) == t0 + gap
+    moved = (wd - w.double()).abs().max()
+    np.testing.assert_allclose(W[1:].cpu().double().numpy(), wd[1:].numpy(), rtol=0, atol=float(1e-5 * moved + 4e-9))   # fp32 sums + 1-ulp reciprocals
+    np.testing.assert_allclose(M[1:].cpu().double().numpy(), md[1:].numpy(), rtol=2e-5, atol=1e-30)
+    np.testing.assert_allclose(V[1:].cpu().double().numpy(), vd[1:].numpy(), rtol=2e-5, atol=1e-30)
+    assert torch.equal(W[0].cpu(), w[0])
