@@ -47,17 +47,31 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers -----------------------------------------------------------------------
-// xor-shuffle reduction across `width` consecutive lanes (width power of two <= 64).
+// Reduction across WIDTH consecutive lanes (WIDTH a power of two <= 64), result in EVERY lane of the group.  Inside a row of 16
+// lanes the exchange is DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: VALU-rate, no LDS crossbar); only the steps that
+// cross rows (16, 32) go through ds_bpermute.  A LayerNorm row needs two such reductions: 2 x 5 bpermutes -> 2 x 1.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if constexpr (WIDTH >= 2) v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (WIDTH >= 4) v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (WIDTH >= 8) v += dpp_move<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of its 8
+  if constexpr (WIDTH >= 16) v += dpp_move<0x140>(v);  // row_mirror:      lane i <-> 15 - i of its 16
+  if constexpr (WIDTH >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (WIDTH >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 template <int WIDTH>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-  for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if constexpr (WIDTH >= 2) v = fmaxf(v, dpp_move<0xB1>(v));
+  if constexpr (WIDTH >= 4) v = fmaxf(v, dpp_move<0x4E>(v));
+  if constexpr (WIDTH >= 8) v = fmaxf(v, dpp_move<0x141>(v));
+  if constexpr (WIDTH >= 16) v = fmaxf(v, dpp_move<0x140>(v));
+  if constexpr (WIDTH >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+  if constexpr (WIDTH >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
