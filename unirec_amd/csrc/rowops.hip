@@ -1,6 +1,8 @@
 // Row-wise HBM-bound kernels: embedding gather, fused gather+pos+LayerNorm, LayerNorm backward.
 // One row is owned by a group of TPR consecutive lanes (TPR | 64), each lane holding float4 column
 // chunks c = t, t+TPR, ...; row reductions are xor-shuffles inside the group (no LDS).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -305,22 +307,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ 
     }
   }
   // block-level reduction of dgamma/dbeta over the `groups` row groups (fixed order => deterministic)
-  __shared__ float red[groups][2][MAXV * TPR * 4 + 4];
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [groups][2][d + 4]: sized for the actual row width (occupancy)
+  const int d = d4 * 4, rs = d + 4;
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     const int c = t + k * TPR;
     if (c < d4) {
-      *(float4*)&red[g][0][c * 4] = dg[k];
-      *(float4*)&red[g][1][c * 4] = db[k];
+      *(float4*)&red[(g * 2 + 0) * rs + c * 4] = dg[k];
+      *(float4*)&red[(g * 2 + 1) * rs + c * 4] = db[k];
     }
   }
   __syncthreads();
-  const int d = d4 * 4;
   for (int i = threadIdx.x; i < 2 * d; i += 256) {
     const int which = i / d, col = i % d;
     float acc = 0.f;
 #pragma unroll
-    for (int gg = 0; gg < groups; ++gg) acc += red[gg][which][col];
+    for (int gg = 0; gg < groups; ++gg) acc += red[(gg * 2 + which) * rs + col];
     part[((long long)blockIdx.x * 2 + which) * d + col] = acc;
   }
 }
@@ -355,10 +357,12 @@ int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* g
   const DropSpec di = in_drop ? *in_drop : DropSpec{}, d_o = out_drop ? *out_drop : DropSpec{};
   if (d_o.thresh && (!dx_drop || out_rows)) return fail(UR_ERR_ARG, "ln_bwd: out_drop needs dx_drop and no out_rows");
   const int tpr = pick_tpr(d), groups = 256 / tpr;
-  int blocks = cdiv(M, groups * 4);
+  static const int rows_env = getenv("UR_LN_BWD_ROWS") ? atoi(getenv("UR_LN_BWD_ROWS")) : 4;   // tuning aid: rows per lane group
+  int blocks = cdiv(M, groups * rows_env);
   if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
+  const size_t lds = (size_t)groups * 2 * (d + 4) * sizeof(float);
   if (blocks < 1) blocks = 1;
-#define GO(T) hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float4*)dy, (const float4*)xhat, \
+#define GO(T) hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), lds, st, (const float4*)dy, (const float4*)xhat, \
                                  rstd, (const float4*)gamma, (const float4*)add_in, seq, M, d / 4, (float4*)dx, part_ws, m_dev, \
                                  out_rows, di, d_o, (float4*)dx_drop)
   switch (tpr) {
