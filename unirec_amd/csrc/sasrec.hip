@@ -169,11 +169,21 @@ __global__ __launch_bounds__(1024) void compact_plan_kernel(const int* __restric
   if (tid == 0) carry_s = 0;
   for (int c0 = 0; c0 < B; c0 += 1024) {
     const int nb = min(1024, B - c0);
+    // first item of each sequence: two lanes per sequence (1024 threads, <= 512 sequences per round ... a chunk is 1024
+    // sequences: two rounds), each scanning every other position with independent loads; min over the pair by shuffle
     s_pad[tid] = L;
     __syncthreads();
-    // one thread per token, all loads independent and coalesced; LDS atomicMin finds each sequence's first item
-    for (int idx = tid; idx < nb * L; idx += 1024)
-      if (seq[(long long)c0 * L + idx] > 0) atomicMin(&s_pad[idx / L], idx % L);
+    for (int half = 0; half < 2; ++half) {
+      const int sb = half * 512 + (tid >> 1), par = tid & 1;
+      int first = L;
+      if (sb < nb) {
+        const int* row = seq + ((long long)c0 + sb) * L;
+        for (int l = L - 1 - par; l >= 0; l -= 2)        // (independent loads; the compiler keeps several in flight)
+          if (row[l] > 0) first = l;
+      }
+      first = min(first, __shfl_xor(first, 1, 64));
+      if (sb < nb && par == 0) s_pad[sb] = first;
+    }
     __syncthreads();
     const int pad = tid < nb ? (s_pad[tid] == L ? 0 : s_pad[tid]) : 0;   // all padding: keep every position
     const int len = tid < nb ? L - pad : 0;
