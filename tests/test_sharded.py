@@ -188,19 +188,20 @@ def _gpu_worker(rank, world, port, q, kind="SASRec"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["SASRec", "GRU"])
-def test_two_ranks_equal_one_rank_with_the_concatenated_batch(kind):
-    """SURVEY.md 8e parity test: W ranks x batch B == 1 rank x batch W*B (losses and updated parameters); GRU = config C4."""
+@pytest.mark.parametrize("kind,world", [("SASRec", 2), ("GRU", 2), ("SASRec", 4)])
+def test_two_ranks_equal_one_rank_with_the_concatenated_batch(kind, world):
+    """SURVEY.md 8e parity test: W ranks x batch B == 1 rank x batch W*B (losses and updated parameters; full-item ranks over the
+    sharded table == over the gathered table); GRU = config C4; W = 4: more runs in the owner-side merge, unequal shard sizes."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q, kind)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = [q.get(timeout=400) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
 @pytest.mark.gpu
