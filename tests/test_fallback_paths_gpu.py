@@ -23,7 +23,7 @@ def _run(env, args, expect_min_passed=1):
 @pytest.mark.parametrize("env", [{"UR_ATTN_NO_M16": "1"},       # L > 64: register-broadcast kernels; L <= 64: 32x32 MFMA forward AND backward
                                  {"UR_ATTN_BWD32": "1"},        # 32x32 single-block backward for L <= 64
                                  {"UR_ATTN_NO_MFMA": "1"},      # no MFMA attention at all (VALU kernels, no compact rows)
-                                 {"UR_ATTN_M16": "1"}])         # 16x16-tile forward for L <= 64 as well
+                                 {"UR_ATTN_FWD32": "1"}])       # 32x32 single-block forward for L <= 64
 def test_attention_kernel_families(env):
     _run(env, [os.path.join(HERE, "test_dropout_gpu.py"), "-k", "sasrec"], expect_min_passed=40)
     _run(env, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)
