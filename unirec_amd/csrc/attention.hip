@@ -22,6 +22,8 @@
 //     s/sqrt(hd) + (-10000.0f) and the softmax runs over all L keys, exactly as torch evaluates it.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -62,6 +64,23 @@ __device__ __forceinline__ float dot_u(const float (&q)[HD], const float* __rest
 }
 
 #define UR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+
+// One (sequence, head) per workgroup, 1-D grid.  A head's slice of a qkv / ctx row is HD * 4 bytes, so 128 / (HD * 4) heads
+// share every 128-byte line; workgroup n runs on XCD n % 8 (each XCD has its own L2), so those heads are given CONSECUTIVE
+// slots of ONE XCD: the line is fetched into one L2 once instead of once per head, and the partial-line stores merge there.
+__host__ __device__ inline int attn_heads_per_line(int hd) { return hd >= 32 ? 1 : 32 / hd; }
+__host__ inline unsigned attn_bh_grid(int B, int H, int hd) {
+  const int hpl = attn_heads_per_line(hd), G = (H + hpl - 1) / hpl;
+  return 8u * hpl * (unsigned)(((long long)B * G + 7) / 8);
+}
+__device__ __forceinline__ bool attn_bh_of_block(const AttnDims& p, int hd, int& b, int& h) {
+  const int hpl = attn_heads_per_line(hd), G = (p.H + hpl - 1) / hpl;
+  const int n = blockIdx.x, t = n >> 3;
+  const int q = 8 * (t / hpl) + (n & 7);
+  b = q / G;
+  h = (q % G) * hpl + t % hpl;
+  return b < p.B && h < p.H;
+}
 
 // index of the first key with item_seq > 0, or L when the sequence is all padding (wave-uniform result)
 __device__ __forceinline__ int first_valid_key(const int* __restrict__ sq, int L, int lane) {
@@ -1028,8 +1047,9 @@ __global__ __launch_bounds__(256) void attn_fwd_m16_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float smem_m16[];
   // a workgroup = one (sequence, head): K / V are staged once, the four waves take the 16-query tiles round-robin
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int h = blockIdx.y;
-  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  int b, h;
+  if (!attn_bh_of_block(p, HD, b, h)) return;
+  const int L = p.L, ld = 3 * p.d;
   const int c16 = lane & 15, kq = lane >> 4;
   long long row0;
   int pad;
@@ -1128,7 +1148,9 @@ __global__ __launch_bounds__(256) void attn_bwd_m16_kernel(const float* __restri
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) float smem_m16[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int h = blockIdx.y, b = blockIdx.x, L = p.L, ld = 3 * p.d;
+  int b, h;
+  if (!attn_bh_of_block(p, HD, b, h)) return;
+  const int L = p.L, ld = 3 * p.d;
   const int c16 = lane & 15, kq = lane >> 4;
   long long row0;
   int pad;
@@ -1210,7 +1232,7 @@ __global__ __launch_bounds__(256) void attn_bwd_m16_kernel(const float* __restri
       *(float4*)(orow + (long long)i * ld + 4 * kq) = make_float4(dq[0] * f, dq[1] * f, dq[2] * f, dq[3] * f);
   }
   // =========================================================================== phase B: lane = key
-  for (int jt = 3 - w; jt < nt; jt += 4) {   // (3 - w: the waves that got the long query tiles get the short key tiles)
+  for (int jt = w; jt < nt; jt += 4) {   // key tile jt meets nt - jt query tiles, query tile it met it + 1 key tiles: same w balances the two phases
     const int j = jt * 16 + c16, jc = min(j, L - 1);
     float kf[KS], vf[KS];
 #pragma unroll
@@ -1250,6 +1272,185 @@ __global__ __launch_bounds__(256) void attn_bwd_m16_kernel(const float* __restri
       *(float4*)(out + 2 * p.d + 4 * kq) = make_float4(dv[0], dv[1], dv[2], dv[3]);
     }
   }
+}
+
+// Short-sequence variant of the backward above (same tiling, same arithmetic per element; used while its LDS footprint leaves
+// >= 4 workgroups per CU).  The backward at L = 50 is VALU-issue bound, not MFMA or HBM bound, so this one spends LDS to shed
+// instructions: the staged rows are padded to whole 16-row tiles (zero rows, validity 0 -> no index clamps and no j < L tests),
+// the per-row scalars (key / query validity, lse, D) are read four at a time, and K, Q, dO are also kept TRANSPOSED and
+// zero-padded to 16 feature rows, so the A operands of the dQ / dK / dV MFMAs are one ds_read_b128 instead of four reads and
+// four selects.  The all-padding ("literal") path is a compile-time copy of the tile loops instead of a branch per element.
+__host__ __device__ inline int attn_m16t_lds_floats(int L, int hd) {
+  const int Lp = (L + 15) & ~15;
+  return 4 * Lp * (hd + 4) + 3 * 16 * (Lp + 4) + 4 * Lp;
+}
+
+template <int KS>
+__device__ __forceinline__ void lds_frag(const float* __restrict__ src, float (&out)[KS]) {
+  if constexpr (KS == 1) out[0] = src[0];
+  else if constexpr (KS == 2) { const float2 v = *(const float2*)src; out[0] = v.x; out[1] = v.y; }
+  else { const float4 v = *(const float4*)src; out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
+}
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_m16t_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
+                                                            const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                            const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
+  constexpr int KS = HD / 4, LDK = HD + 4, PR = HD / 4;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) float smem_m16[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int b, h;
+  if (!attn_bh_of_block(p, HD, b, h)) return;
+  const int L = p.L, ld = 3 * p.d;
+  const int c16 = lane & 15, kq = lane >> 4;
+  long long row0;
+  int pad;
+  seq_rows(p, b, row0, pad);
+  const int* __restrict__ sq = seq + (long long)b * L;
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  const bool causal = p.causal && !literal;
+  const float f = literal ? 1.0f / p.sqrt_hd : p.scale;   // d(score) / d(q . k)
+  const int nt = (L + 15) >> 4, Lp = nt * 16, S = Lp + 4;
+  float* Qs = smem_m16;              // [Lp][LDK] rows (rows >= L zero)
+  float* Ks = Qs + Lp * LDK;
+  float* Vs = Ks + Lp * LDK;
+  float* Gs = Vs + Lp * LDK;
+  float* KT = Gs + Lp * LDK;         // [16][S] transposed (feature rows >= HD and columns >= L zero)
+  float* QT = KT + 16 * S;
+  float* GT = QT + 16 * S;
+  float* lse2s = GT + 16 * S;        // [Lp] lse * log2(e) per query
+  float* Ds = lse2s + Lp;            // [Lp] dO . O per query
+  float* kvalid = Ds + Lp;           // [Lp] 1 = key may be attended
+  float* qvalid = kvalid + Lp;       // [Lp] 1 = query row exists (pad <= i < L)
+  for (int x = threadIdx.x; x < Lp * PR; x += 256) {
+    const int j = x / PR, c = (x % PR) * 4;
+    const bool in = j < L;
+    const long long row = row0 + max(min(j, L - 1), pad);
+    const float* src = qkv + row * ld + h * HD + c;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, g4 = q4, o4 = q4;
+    if (in) {
+      q4 = *(const float4*)src; k4 = *(const float4*)(src + p.d); v4 = *(const float4*)(src + 2 * p.d);
+      g4 = *(const float4*)(dctx + row * p.d + h * HD + c); o4 = *(const float4*)(ctx + row * p.d + h * HD + c);
+    }
+    *(float4*)(Qs + j * LDK + c) = q4;
+    *(float4*)(Ks + j * LDK + c) = k4;
+    *(float4*)(Vs + j * LDK + c) = v4;
+    *(float4*)(Gs + j * LDK + c) = g4;
+    float* kt = KT + c * S + j; float* qt = QT + c * S + j; float* gt = GT + c * S + j;
+    kt[0] = k4.x; kt[S] = k4.y; kt[2 * S] = k4.z; kt[3 * S] = k4.w;
+    qt[0] = q4.x; qt[S] = q4.y; qt[2 * S] = q4.z; qt[3 * S] = q4.w;
+    gt[0] = g4.x; gt[S] = g4.y; gt[2 * S] = g4.z; gt[3 * S] = g4.w;
+    float D = (g4.x * o4.x + g4.y * o4.y) + (g4.z * o4.z + g4.w * o4.w);
+#pragma unroll
+    for (int o = 1; o < PR; o <<= 1) D += __shfl_xor(D, o, 64);   // the PR lanes of a row are adjacent and active together
+    if ((x % PR) == 0) {
+      lse2s[j] = in ? lse[((long long)b * p.H + h) * L + j] * LOG2E : 0.f;
+      Ds[j] = D;
+      kvalid[j] = (in && (literal || sq[j] > 0)) ? 1.f : 0.f;
+      qvalid[j] = (in && j >= pad) ? 1.f : 0.f;
+    }
+  }
+  if constexpr (HD < 16) {   // feature rows HD..15 of the transposed copies
+    const int n4 = (16 - HD) * S / 4;
+    for (int x = threadIdx.x; x < 3 * n4; x += 256) {
+      float* dst = (x < n4 ? KT : x < 2 * n4 ? QT : GT) + HD * S + (x % n4) * 4;
+      *(float4*)dst = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  const int jt0 = literal ? 0 : fv >> 4;
+  float* orow = dqkv + row0 * ld + h * HD;
+  const float sc2 = f * LOG2E, inv_sqrt_div = p.sqrt_hd;
+  auto tiles = [&](auto lit_tag) {
+    constexpr bool LIT = decltype(lit_tag)::value;
+    auto expo = [&](float sv) { return LIT ? (sv / inv_sqrt_div + -10000.0f) * LOG2E : sv * sc2; };
+    // ========================================================================= phase A: lane = query
+    for (int it = w; it < nt; it += 4) {
+      const int i = it * 16 + c16;
+      float qf[KS], gf[KS];
+      lds_frag<KS>(Qs + i * LDK + kq * KS, qf);
+      lds_frag<KS>(Gs + i * LDK + kq * KS, gf);
+      const float lse2 = lse2s[i], Di = Ds[i];
+      const unsigned rk = attn_rowkey(p, b, h, i);
+      floatx4 dq = {0.f, 0.f, 0.f, 0.f};
+      const int jt_end = (!LIT && causal) ? it + 1 : nt;
+      for (int jt = jt0; jt < jt_end; ++jt) {
+        float kf[KS], vf[KS];
+        lds_frag<KS>(Ks + (jt * 16 + c16) * LDK + kq * KS, kf);
+        lds_frag<KS>(Vs + (jt * 16 + c16) * LDK + kq * KS, vf);
+        const int j0 = jt * 16 + 4 * kq;
+        const float4 kv4 = *(const float4*)(kvalid + j0);
+        const float4 kt4 = *(const float4*)(KT + c16 * S + j0);
+        floatx4 sT = {0.f, 0.f, 0.f, 0.f}, dpT = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          sT = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[s], sT, 0, 0, 0);
+          dpT = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[s], gf[s], dpT, 0, 0, 0);
+        }
+        const float kvr[4] = {kv4.x, kv4.y, kv4.z, kv4.w}, ktr[4] = {kt4.x, kt4.y, kt4.z, kt4.w};
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = j0 + r;
+          const bool ok = (kvr[r] != 0.f) & ((LIT || !causal) | (j <= i));   // (no short-circuit: no divergent branches)
+          const float pv = __builtin_amdgcn_exp2f(ok ? expo(sT[r]) - lse2 : -INFINITY);   // exp2(-inf) = 0 for masked keys
+          ds[r] = pv * (attn_keep<DROP>(p, rk, j) * dpT[r] - Di);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq = __builtin_amdgcn_mfma_f32_16x16x4f32(ktr[r], ds[r], dq, 0, 0, 0);
+      }
+      if (i < L && i >= pad && 4 * kq < HD)
+        *(float4*)(orow + (long long)i * ld + 4 * kq) = make_float4(dq[0] * f, dq[1] * f, dq[2] * f, dq[3] * f);
+    }
+    // ========================================================================= phase B: lane = key
+    for (int jt = w; jt < nt; jt += 4) {   // key tile jt meets nt - jt query tiles, query tile it met it + 1 key tiles
+      const int j = jt * 16 + c16;
+      float kf[KS], vf[KS];
+      lds_frag<KS>(Ks + j * LDK + kq * KS, kf);
+      lds_frag<KS>(Vs + j * LDK + kq * KS, vf);
+      const bool kv = kvalid[j] != 0.f;
+      floatx4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+      for (int it = (!LIT && causal) ? jt : 0; it < nt; ++it) {
+        float qf[KS], gf[KS];
+        lds_frag<KS>(Qs + (it * 16 + c16) * LDK + kq * KS, qf);
+        lds_frag<KS>(Gs + (it * 16 + c16) * LDK + kq * KS, gf);
+        const int i0 = it * 16 + 4 * kq;
+        const float4 qv4 = *(const float4*)(qvalid + i0), l4 = *(const float4*)(lse2s + i0), d4 = *(const float4*)(Ds + i0);
+        const float4 gt4 = *(const float4*)(GT + c16 * S + i0), qt4 = *(const float4*)(QT + c16 * S + i0);
+        floatx4 sM = {0.f, 0.f, 0.f, 0.f}, dpM = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          sM = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], kf[s], sM, 0, 0, 0);
+          dpM = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[s], vf[s], dpM, 0, 0, 0);
+        }
+        const float qvr[4] = {qv4.x, qv4.y, qv4.z, qv4.w}, lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float gtr[4] = {gt4.x, gt4.y, gt4.z, gt4.w}, qtr[4] = {qt4.x, qt4.y, qt4.z, qt4.w};
+        float pd[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = i0 + r;
+          const bool ok = kv & (qvr[r] != 0.f) & ((LIT || !causal) | (j <= i));
+          const float pv = __builtin_amdgcn_exp2f(ok ? expo(sM[r]) - lr[r] : -INFINITY);
+          const float mk = DROP ? drop_mul(attn_rowkey(p, b, h, i), (unsigned)j, p.dthresh, p.dscale) : 1.0f;
+          pd[r] = pv * mk;
+          ds[r] = pv * (mk * dpM[r] - dr[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(gtr[r], pd[r], dv, 0, 0, 0);
+          dk = __builtin_amdgcn_mfma_f32_16x16x4f32(qtr[r], ds[r], dk, 0, 0, 0);
+        }
+      }
+      if (j < L && j >= pad && 4 * kq < HD) {
+        float* out = orow + (long long)j * ld;
+        *(float4*)(out + p.d + 4 * kq) = make_float4(dk[0] * f, dk[1] * f, dk[2] * f, dk[3] * f);
+        *(float4*)(out + 2 * p.d + 4 * kq) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+      }
+    }
+  };
+  if (literal) tiles(std::true_type{}); else tiles(std::false_type{});
 }
 
 // launches KERNEL<HD, true> when dropout is on (p.dthresh != 0), KERNEL<HD, false> otherwise
@@ -1307,7 +1508,7 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
   static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
   if (attn_m16_supported(L, p.hd) && !no_mfma && (L > 64 || attn_m16_short())) {
     const size_t lds = (size_t)attn_m16_lds_floats_per_wave(L, p.hd) * sizeof(float);
-    dim3 g3(B, H);
+    dim3 g3(attn_bh_grid(B, H, p.hd));
 #define GM(HD)                                                                                                                     \
     do {                                                                                                                             \
       static const hipError_t a0 = hipFuncSetAttribute((const void*)attn_fwd_m16_kernel<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -1361,8 +1562,17 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
   static const bool bwd32 = getenv("UR_ATTN_BWD32") != nullptr;   // tuning hook: the 32x32 single-block backward for L <= 64
   if (attn_m16_supported(L, p.hd) && (long long)attn_m16_bwd_lds_floats(L, p.hd) * 4 <= 80 * 1024 && !no_mfma && (L > 64 || !bwd32)) {
     // (also for L <= 64: measured 99 vs 112-122 us at B = 512, L = 50, 16 heads of 8 -- the 16-row tiles waste less of each MFMA)
+    dim3 g3(attn_bh_grid(B, H, p.hd));
+    static const bool no_t = getenv("UR_ATTN_NO_M16T") != nullptr;   // test / tuning hook: the un-transposed kernel for short L too
+    const size_t lds_t = (size_t)attn_m16t_lds_floats(L, p.hd) * sizeof(float);
+    if (!no_t && lds_t <= 40 * 1024) {   // >= 4 workgroups per CU
+#define GT_(HD) UR_ATTN_LAUNCH(attn_bwd_m16t_kernel, HD, g3, dim3(256), lds_t, st, qkv, seq, ctx, dctx, lse, p, dqkv)
+      if (p.hd == 4) GT_(4); else if (p.hd == 8) GT_(8); else GT_(16);
+#undef GT_
+      UR_LAUNCH_CHECK();
+      return UR_OK;
+    }
     const size_t lds = (size_t)attn_m16_bwd_lds_floats(L, p.hd) * sizeof(float);
-    dim3 g3(B, H);
 #define GM(HD)                                                                                                                     \
     do {                                                                                                                             \
       static const hipError_t a0 = hipFuncSetAttribute((const void*)attn_bwd_m16_kernel<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
