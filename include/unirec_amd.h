@@ -100,6 +100,17 @@ int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_ite
 int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                   const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
                   float* d_emb_rows, void* stream);
+/* the same pass with a DEFERRED join (no reference counterpart: loss.backward() is one call there).  On return `stream`
+ * holds everything but dense_grad: d_emb_rows is complete in stream order, while the weight-gradient GEMMs and the
+ * reductions into dense_grad may still be running on the library's side stream.  The caller does the work that does not
+ * need dense_grad (ur_rows_reduce, ur_sparse_adam_rows: the row-sparse half of the optimizer step) and then makes its
+ * stream wait with ur_sasrec_bwd_join before the first read of dense_grad.  dense_grad, ws must stay alive until then.
+ * Without a side stream (ur_sasrec_set_side_stream(0), > 2 layers) it behaves like ur_sasrec_bwd; ur_sasrec_bwd_join is
+ * then a no-op.  A pass nobody joined is joined by the next ur_sasrec_bwd* call. */
+int ur_sasrec_bwd_deferred(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
+                           const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
+                           float* d_emb_rows, void* stream);
+int ur_sasrec_bwd_join(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ConvFormer / FASTConvFormer user encoders (unirec/model/sequential/convformer.py:16-129,

@@ -197,3 +197,40 @@ def test_a_step_with_nan_loss_is_skipped_without_a_host_sync():
         assert torch.equal(m.dense_flat.data, w1) and torch.equal(m.item_embedding.weight.data, t1)   # nothing moved
         loss = step()                                                   # and training goes on
         assert torch.isfinite(loss) and not torch.equal(m.dense_flat.data, w1)
+
+
+def test_deferred_dense_join_gives_the_same_steps_as_the_eager_join():
+    """SparseDenseAdam (no clipping) lets the SASRec backward return while the dense-gradient reductions still run on the side
+    stream (ur_sasrec_bwd_deferred / ur_sasrec_bwd_join): same kernels, same order of every sum -> bit-identical weights; and the
+    dense gradient is not visible (None, not stale) before the join."""
+    from unirec_amd.facility.optimizer import SparseDenseAdam
+    from unirec_amd.facility.trainer import BatchLoader
+    from unirec_amd.utils.general import get_class_instance, init_seed
+    finals = []
+    for overlap in (True, False):
+        cfg, ds = _setup("SASRec", "bpr")
+        init_seed(cfg["seed"])
+        model = get_class_instance("SASRec", "unirec_amd/model")(cfg)
+        model.train()
+        opt = SparseDenseAdam(model, lr=1e-2, table_mode="rowwise", overlap_dense_join=overlap)
+        assert model.defer_dense_join == overlap
+        for i, b in enumerate(BatchLoader(ds, cfg["batch_size"], device="cuda:0")):
+            model.forward_backward(**b)
+            if overlap:
+                assert model.dense_flat.grad is None and model._deferred_dense_grad is not None
+                if i == 1:   # a reader that is not the optimizer joins explicitly
+                    model.finish_backward()
+                    assert model.dense_flat.grad is not None and bool(torch.isfinite(model.dense_flat.grad).all())
+            else:
+                assert model.dense_flat.grad is not None
+            opt.step()
+            opt.zero_grad()
+        torch.cuda.synchronize()
+        finals.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+    # clipping needs the global norm first: the optimizer then asks for complete gradients
+    cfg, ds = _setup("SASRec", "bpr")
+    model = get_class_instance("SASRec", "unirec_amd/model")(cfg)
+    SparseDenseAdam(model, lr=1e-2, table_mode="rowwise", grad_clip=1.0)
+    assert model.defer_dense_join is False

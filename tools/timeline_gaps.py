@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""GPU idle time inside the timed region of a bench.py run, from a rocprofv3 --kernel-trace CSV (tuning aid).
+usage: timeline_gaps.py <kernel_trace.csv>   -> busy union over all queues, per-queue busy time, largest gaps and what follows them"""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows), key=lambda e: e[0])
+# a window of steady-state steps: between two launches of the once-per-step plan kernel, well inside the timed region
+marks = [e[0] for e in ev if "plan_small_kernel" in e[2] or "rows_plan" in e[2]]
+n_steps = 100
+t0, t1 = marks[-(n_steps + 30)], marks[-30]
+ev = [e for e in ev if t0 <= e[0] < t1]
+print(f"{n_steps} steps: {(t1 - t0)/1e3/n_steps:.1f} us per step")
+wall = ev[-1][1] - ev[0][0]
+busy, cur_s, cur_e = 0, ev[0][0], ev[0][1]
+gaps = []
+for s, e, n, q in ev[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s
+        gaps.append((s - cur_e, n))
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+print(f"wall {wall/1e3:.0f} us, busy (union over queues) {busy/1e3:.0f} us = {100.0*busy/wall:.1f} %, kernels {len(ev)}")
+perq = collections.Counter()
+for s, e, n, q in ev: perq[q] += e - s
+for q, t in perq.most_common(): print(f"  queue {q}: {t/1e3:.0f} us of kernels = {100.0*t/wall:.1f} % of wall")
+after = collections.defaultdict(lambda: [0, 0])
+for g, n in gaps:
+    after[n[:60]][0] += g; after[n[:60]][1] += 1
+print("idle time by the kernel that FOLLOWS the gap:")
+for n, (g, c) in sorted(after.items(), key=lambda kv: -kv[1][0])[:12]: print(f"  {g/1e3:8.0f} us in {c:5d} gaps (avg {g/c/1e3:5.1f} us)  before {n}")
+print("per step, by queue and kernel:")
+agg = collections.defaultdict(lambda: [0, 0])
+for s, e, n, q in ev:
+    a = agg[(q, n[:72])]; a[0] += e - s; a[1] += 1
+for (q, n), (t, c) in sorted(agg.items(), key=lambda kv: (kv[0][0], -kv[1][0])):
+    print(f"  q{q} {t/1e3/n_steps:7.1f} us  x{c/n_steps:4.1f}  {n}")

@@ -268,7 +268,8 @@ namespace {
 struct SideCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[24];
-  hipEvent_t done = nullptr;
+  hipEvent_t done = nullptr, main_done = nullptr;
+  bool join_pending = false;   // ur_sasrec_bwd_deferred left reductions running: `done` marks their end
   bool ok = false;
 };
 int g_side_enabled = 1;   // runtime switch (ur_sasrec_set_side_stream)
@@ -282,6 +283,7 @@ SideCtx* side_ctx() {
     for (auto& ev : c->ev)
       if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c->main_done, hipEventDisableTiming) != hipSuccess) return nullptr;
     c->ok = true;
     return c;
   }();
@@ -379,15 +381,18 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
   return UR_OK;
 }
 
-extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
-                             const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
-                             float* d_emb_rows, void* stream) {
+extern "C" int ur_sasrec_bwd_join(void* stream);
+
+static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
+                           const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
+                           float* d_emb_rows, void* stream, bool defer_join) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   UR_REQUIRE(dense && item_seq && d_user_emb && ws && dense_grad && d_emb_rows, UR_ERR_ARG, "ur_sasrec_bwd: null pointer");
   (void)item_table; (void)n_items;
   const UrSasrecCfg& c = *cfg;
   hipStream_t st = as_stream(stream);
+  if ((rc = ur_sasrec_bwd_join(stream))) return rc;   // (a deferred pass nobody joined)
   const Layout lay = make_layout(c);
   Ws w = carve(c, (float*)ws);
   const int M = c.B * c.L, d = c.d, I = c.inner;
@@ -573,11 +578,43 @@ extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, in
   }
   UR_REQUIRE(tn_cur <= w.tn_ws + w.tn_floats && ln_cur <= w.ln_part + w.ln_floats, UR_ERR_ARG, "ur_sasrec_bwd: partial-sum workspace overrun");
   if ((rc = fork())) return rc;
+  if (n_fork > 0 && defer_join) {
+    // deferred join: the reductions into dense_grad run on the SIDE stream, behind the weight-gradient GEMMs there and behind
+    // the main stream's last producer of partial sums; the caller's stream goes on (row-gradient reduce, sparse update) and
+    // picks dense_grad up with ur_sasrec_bwd_join
+    UR_HIP(hipEventRecord(sc->main_done, st));
+    UR_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
+    if ((rc = reduce_batch(rb, sc->stream))) return rc;
+    UR_HIP(hipEventRecord(sc->done, sc->stream));
+    sc->join_pending = true;
+    return UR_OK;
+  }
   if (n_fork > 0) {   // join: the partial sums written on the side stream are read by the reduction below
     UR_HIP(hipEventRecord(sc->done, sc->stream));
     UR_HIP(hipStreamWaitEvent(st, sc->done, 0));
   }
   return reduce_batch(rb, st);
+}
+
+extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
+                             const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
+                             float* d_emb_rows, void* stream) {
+  return sasrec_bwd_impl(cfg, item_table, n_items, dense, item_seq, d_user_emb, ws, dense_grad, d_emb_rows, stream, false);
+}
+
+extern "C" int ur_sasrec_bwd_deferred(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
+                                      const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
+                                      float* d_emb_rows, void* stream) {
+  return sasrec_bwd_impl(cfg, item_table, n_items, dense, item_seq, d_user_emb, ws, dense_grad, d_emb_rows, stream, true);
+}
+
+extern "C" int ur_sasrec_bwd_join(void* stream) {
+  SideCtx* sc = side_ctx();
+  if (sc && sc->join_pending) {
+    UR_HIP(hipStreamWaitEvent(as_stream(stream), sc->done, 0));
+    sc->join_pending = false;
+  }
+  return UR_OK;
 }
 
 extern "C" int ur_sasrec_set_side_stream(int on) {

@@ -18,7 +18,7 @@ from .. import ops
 
 class SparseDenseAdam:
     def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=None, eps=None, grad_clip=None,
-                 table_mode="lazy_dense", algo="adam"):
+                 table_mode="lazy_dense", algo="adam", overlap_dense_join=True):
         """algo: the torch.optim rule the reference's Trainer._build_optimizer would construct (trainer.py:134-152):
         adam (default) / adamw / sgd / adagrad / rmsprop; betas / eps None = torch's defaults for that rule."""
         assert table_mode in ("lazy_dense", "rowwise")
@@ -31,6 +31,9 @@ class SparseDenseAdam:
         self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
         self.grad_clip = grad_clip if grad_clip and grad_clip > 0 else None
         self.table_mode = table_mode
+        # step() runs the row-sparse half first and joins the encoder's dense-gradient reductions itself: the model may leave
+        # them running on the side stream when its backward returns (dense_flat.grad is None until model.finish_backward())
+        model.defer_dense_join = bool(overlap_dense_join) and self.grad_clip is None
         self.t = 0
         dev = model.device
         self.dense_m = torch.zeros_like(model.dense_flat.data)
@@ -54,6 +57,7 @@ class SparseDenseAdam:
 
     # ------------------------------------------------------------------ torch.optim surface
     def zero_grad(self, set_to_none=True):
+        self.model.finish_backward()
         self.model.dense_flat.grad = None
         for p in self.extra:
             p.grad = None
@@ -181,6 +185,15 @@ class SparseDenseAdam:
         # (1, or -1 for NaN) that the update kernels read as their gradient scale -- < 0 = return untouched; no host round trip
         guard = getattr(model, "loss_guard", None)
         scale = guard
+        sparse_done = False
+        if self.grad_clip is None:
+            # no global norm to wait for: the row-sparse half goes first, under the encoder's dense-gradient reductions that
+            # may still be running on the side stream (model.defer_dense_join), then the join, then the dense half
+            for name, (pl, ug) in reduced.items():
+                st = self.tables[name]
+                ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
+            sparse_done = True
+        model.finish_backward()
         if self.grad_clip is not None:
             ss = self._scalars[0:1]
             ops.sumsq(model.dense_flat.grad, ss, accumulate=False, ws=self._sumsq_ws)
@@ -198,9 +211,10 @@ class SparseDenseAdam:
         for p, (m, v) in zip(self.extra, self.extra_state):
             if p.grad is not None:
                 ops.dense_adam(cfg, p.data, p.grad.contiguous(), m, v, scale)
-        for name, (pl, ug) in reduced.items():
-            st = self.tables[name]
-            ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
+        if not sparse_done:
+            for name, (pl, ug) in reduced.items():
+                st = self.tables[name]
+                ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
         for name, dg in dense_tables.items():
             st = self.tables[name]
             ops.dense_adam(cfg, st["w"], dg, st["m"], st["v"], scale)

@@ -196,6 +196,19 @@ class BaseRecommender(AbstractRecommender):
         self.sparse_grads.append(dict(table="user_embedding", ids_a=state.to(torch.int32).contiguous(),
                                       rows=d_user.view(-1, d_user.shape[-1])))
 
+    # An optimizer that runs the row-sparse half of its step first sets ``defer_dense_join``: the encoder backward may then
+    # return while its dense-gradient reductions are still running on a side stream (ur_sasrec_bwd_deferred);
+    # ``dense_flat.grad`` stays None until ``finish_backward()`` joins them.  Default off: backward leaves complete gradients.
+    defer_dense_join = False
+    _deferred_dense_grad = None
+
+    def finish_backward(self):
+        g = self._deferred_dense_grad
+        if g is not None:
+            ops.sasrec_bwd_join()
+            self.dense_flat.grad = g
+            object.__setattr__(self, "_deferred_dense_grad", None)
+
     def forward_backward(self, user_id=None, item_id=None, label=None, item_seq=None, item_seq_len=None, **_unused):
         """``loss = model(...); loss.backward()`` (unirec/facility/trainer.py:340-346) as one straight-line sequence of
         the same HIP launches, without building/walking an autograd graph: leaves ``dense_flat.grad``, the bias

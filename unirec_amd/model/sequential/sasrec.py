@@ -115,8 +115,14 @@ class SASRec(BaseRecommender):
 
     def _encode_backward(self, state, d_user):
         cfg, ws, item_seq = state
-        dense_grad, d_rows = ops.sasrec_bwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, d_user, ws)
-        self.dense_flat.grad = dense_grad
+        defer = bool(getattr(self, "defer_dense_join", False))
+        dense_grad, d_rows = ops.sasrec_bwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, d_user, ws,
+                                            defer_join=defer)
+        if defer:   # the reductions into dense_grad are still running on the side stream: finish_backward() publishes it
+            self.dense_flat.grad = None
+            object.__setattr__(self, "_deferred_dense_grad", dense_grad)
+        else:
+            self.dense_flat.grad = dense_grad
         self.sparse_grads.append(dict(table="item_embedding", ids_a=item_seq.reshape(-1), rows=d_rows))
 
     def forward_user_emb(self, user_id=None, item_seq=None, item_seq_len=None, item_seq_features=None, time_seq=None):

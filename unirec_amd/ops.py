@@ -83,13 +83,20 @@ def sasrec_fwd(cfg, item_table, dense, item_seq, ws):
     return user_emb
 
 
-def sasrec_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws):
+def sasrec_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws, defer_join=False):
+    """defer_join=True: dense_grad is NOT complete in stream order on return -- call sasrec_bwd_join() before reading it
+    (d_emb_rows is complete); see ur_sasrec_bwd_deferred."""
     _chk(d_user_emb, torch.float32, "d_user_emb")
     dense_grad = torch.empty_like(dense)
     d_emb_rows = torch.empty(cfg.B * cfg.L, cfg.d, dtype=torch.float32, device=dense.device)
-    check(lib.ur_sasrec_bwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(d_user_emb),
-                            _p(ws), _p(dense_grad), _p(d_emb_rows), _stream()), "ur_sasrec_bwd")
+    fn = lib.ur_sasrec_bwd_deferred if defer_join else lib.ur_sasrec_bwd
+    check(fn(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(d_user_emb),
+             _p(ws), _p(dense_grad), _p(d_emb_rows), _stream()), "ur_sasrec_bwd")
     return dense_grad, d_emb_rows
+
+
+def sasrec_bwd_join():
+    check(lib.ur_sasrec_bwd_join(_stream()), "ur_sasrec_bwd_join")
 
 
 # --------------------------------------------------------------------------------------------- GRU
