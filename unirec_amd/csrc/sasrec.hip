@@ -162,54 +162,73 @@ __global__ void put_last_kernel(const float* __restrict__ src, int B, int L, int
 __global__ __launch_bounds__(1024) void compact_plan_kernel(const int* __restrict__ seq, int B, int L, int* __restrict__ tok_full,
                                                             int* __restrict__ seq_base, int* __restrict__ seq_pad,
                                                             int* __restrict__ last_row, int* __restrict__ m_valid) {
-  __shared__ int sc[1024];      // scan scratch, then the first compact row of each sequence of the chunk
-  __shared__ int s_pad[1024];   // first non-zero position (L if none)
+  __shared__ int s_base[1024];  // first compact row of each sequence of the chunk
+  __shared__ int s_pad[1024];   // first non-zero position (0 if none: an all-padding sequence keeps every position)
+  __shared__ int wtot[16];
   __shared__ int carry_s;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) carry_s = 0;
+  __syncthreads();
   for (int c0 = 0; c0 < B; c0 += 1024) {
     const int nb = min(1024, B - c0);
-    // first item of each sequence: two lanes per sequence (1024 threads, <= 512 sequences per round ... a chunk is 1024
-    // sequences: two rounds), each scanning every other position with independent loads; min over the pair by shuffle
-    s_pad[tid] = L;
-    __syncthreads();
-    for (int half = 0; half < 2; ++half) {
-      const int sb = half * 512 + (tid >> 1), par = tid & 1;
-      int first = L;
-      if (sb < nb) {
-        const int* row = seq + ((long long)c0 + sb) * L;
-        for (int l = L - 1 - par; l >= 0; l -= 2)        // (independent loads; the compiler keeps several in flight)
-          if (row[l] > 0) first = l;
+    // first item of each sequence: a wave per sequence, lane = position (coalesced row reads, ballot + count-trailing-zeros);
+    // sixteen sequences per round: the kernel is one workgroup, so the row loads in flight per lane are all the memory
+    // parallelism there is
+    constexpr int U = 16;
+    for (int s0 = wv * U; s0 < nb; s0 += 16 * U) {
+      int first[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) first[u] = L;
+      for (int l0 = 0; l0 < L; l0 += 64) {
+        int v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          v[u] = seq[((long long)c0 + min(s0 + u, nb - 1)) * L + min(l0 + lane, L - 1)];   // clamped, unconditional: the U loads
+        const bool lin = l0 + lane < L;                                                    // issue back to back
+        bool all_found = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const unsigned long long m = __ballot(lin && v[u] > 0);
+          if (first[u] == L && m) first[u] = l0 + (int)__builtin_ctzll(m);
+          all_found &= first[u] < L;
+        }
+        if (all_found) break;
       }
-      first = min(first, __shfl_xor(first, 1, 64));
-      if (sb < nb && par == 0) s_pad[sb] = first;
+      int f = L;
+#pragma unroll
+      for (int u = 0; u < U; ++u) f = lane == u ? first[u] : f;
+      if (lane < U && s0 + lane < nb) s_pad[s0 + lane] = f == L ? 0 : f;
     }
     __syncthreads();
-    const int pad = tid < nb ? (s_pad[tid] == L ? 0 : s_pad[tid]) : 0;   // all padding: keep every position
+    const int pad = tid < nb ? s_pad[tid] : 0;
     const int len = tid < nb ? L - pad : 0;
-    __syncthreads();
-    s_pad[tid] = pad;
-    sc[tid] = len;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
-      const int v = tid >= off ? sc[tid - off] : 0;
-      __syncthreads();
-      sc[tid] += v;
-      __syncthreads();
+    // exclusive scan of the lengths: shuffles inside a wave, the 16 wave totals through LDS
+    int inc = len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += v;
     }
-    const int total = sc[1023];
-    const int base = carry_s + sc[tid] - len;    // first compact row of sequence c0 + tid
+    if (lane == 63) wtot[wv] = inc;
     __syncthreads();
-    sc[tid] = base;
+    int before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int t = wtot[k];
+      before += k < wv ? t : 0;
+      total += t;
+    }
+    const int base = carry_s + before + inc - len;    // first compact row of sequence c0 + tid
+    s_base[tid] = base;
     if (tid < nb) {
       seq_base[c0 + tid] = base - pad;
       seq_pad[c0 + tid] = pad;
       last_row[c0 + tid] = base + len - 1;
     }
     __syncthreads();
-    for (int idx = tid; idx < nb * L; idx += 1024) {   // token map, one thread per token
-      const int b = idx / L, l = idx % L;
-      if (l >= s_pad[b]) tok_full[sc[b] + l - s_pad[b]] = c0 * L + idx;
+    for (int sb = wv; sb < nb; sb += 16) {   // token map: a wave per sequence, coalesced stores
+      const int pd = s_pad[sb], bs = s_base[sb] - pd;
+      for (int l = pd + lane; l < L; l += 64) tok_full[bs + l] = (c0 + sb) * L + l;
     }
     __syncthreads();
     if (tid == 0) carry_s += total;
