@@ -500,7 +500,9 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long
 
 static int tn_splits(int T, int R, int Cc) {
   const int tiles = cdiv(R, TB) * cdiv(Cc, TB);
-  static const int target = getenv("UR_TN_BLOCKS") ? atoi(getenv("UR_TN_BLOCKS")) : 512;   // tuning aid
+  // one workgroup per CU: every further split is another R x Cc partial tile written and read back by the reduction, which
+  // shares HBM with the sparse optimizer step (measured at the C5 shapes: 256 -> 0.872 ms/step, 512 -> 0.882, 128 -> 0.94)
+  static const int target = getenv("UR_TN_BLOCKS") ? atoi(getenv("UR_TN_BLOCKS")) : 256;   // tuning aid
   int s = cdiv(target, tiles);
   const int smax = cdiv(T, T <= 4096 ? 64 : 128);   // >= 2 (small T) / 4 LDS stages of 32 tokens per split
   if (s > smax) s = smax;
