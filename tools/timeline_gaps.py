@@ -36,3 +36,8 @@ for s, e, n, q in ev:
     a = agg[(q, n[:72])]; a[0] += e - s; a[1] += 1
 for (q, n), (t, c) in sorted(agg.items(), key=lambda kv: (kv[0][0], -kv[1][0])):
     print(f"  q{q} {t/1e3/n_steps:7.1f} us  x{c/n_steps:4.1f}  {n}")
+import os
+if os.environ.get("SHOW"):
+    key = os.environ["SHOW"]
+    seqs = [(s, e - s, n) for s, e, n, q in ev if key in n]
+    print(f"durations of the first 15 launches of *{key}* in the window (us):", [round(d / 1e3, 1) for _, d, _ in seqs[:15]])
