@@ -54,6 +54,9 @@ def _worker(rank, world, port, N, d, q):
         x = RowExchange(world, rank)
         recv_counts = x.exchange_counts(send_counts)
         assert x.exchange_counts_dev(torch.tensor(send_counts, dtype=torch.int32)) == (send_counts, recv_counts)
+        assert x.exchange_counts_host(send_counts) == (send_counts, recv_counts)      # lookahead path: counts already on the host
+        x.cpu_group = None                                                             # no gloo group: falls back to the main group
+        assert x.exchange_counts_host(send_counts) == (send_counts, recv_counts)
         req = x.all_to_all_rows((uniq % n_local).to(torch.int32), send_counts, recv_counts)
         assert int(req.max()) < n_local and len(req) == sum(recv_counts)
         compact = x.all_to_all_rows(shard[req.long()], recv_counts, send_counts)      # rows come back in key order

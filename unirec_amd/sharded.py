@@ -17,6 +17,9 @@ the CPU; everything else is the HIP library.
 """
 from typing import List
 
+import os
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -28,6 +31,30 @@ class RowExchange:
 
     def __init__(self, world: int, rank: int, group=None):
         self.world, self.rank, self.group = world, rank, group
+        # host-side group for the tiny per-step counts exchange (2W integers that the HOST needs as split sizes): with
+        # an RCCL main group this is a second, gloo group, so the exchange neither queues behind device collectives nor
+        # forces the host to drain the compute stream (exchange_counts_host).  Created collectively by every rank.
+        self.cpu_group = None
+        if world > 1:
+            if dist.get_backend(group) == "gloo":
+                self.cpu_group = group
+            elif os.environ.get("UR_COUNTS_VIA_DEVICE") != "1":   # (switch: counts through the main group, as before)
+                try:
+                    self.cpu_group = dist.new_group(backend="gloo")
+                except Exception as e:   # no gloo transport on this host: every rank fails alike and takes the device path
+                    warnings.warn(f"row exchange: no gloo group for the counts ({e}); using the device group")
+
+    def exchange_counts_host(self, send_counts: List[int]):
+        """send_counts already on the HOST (read from a plan computed ahead on a side stream): all-to-all over the gloo group.
+        No device work, no stream synchronisation."""
+        if self.world == 1:
+            return list(send_counts), list(send_counts)
+        if self.cpu_group is None:
+            return [int(x) for x in send_counts], self.exchange_counts(send_counts)
+        src = torch.tensor(send_counts, dtype=torch.int64)
+        recv = torch.empty_like(src)
+        dist.all_to_all_single(recv, src, group=self.cpu_group)
+        return [int(x) for x in send_counts], [int(x) for x in recv.tolist()]
 
     def exchange_counts(self, send_counts: List[int]) -> List[int]:
         if self.world == 1:
@@ -139,7 +166,7 @@ class ShardedSasrecStep:
         self.zero_coef = torch.zeros(1, dtype=torch.float32, device=device)
         self.loss_type = model_cfg["loss_type"]
         self.tau = model_cfg.get("tau", 1.0)
-        self._side, self._prefetched = None, None
+        self._side, self._prefetched, self._counts_pinned = None, None, None
 
     # ---- the step ------------------------------------------------------------------------------------------
     def step(self, batch, next_batch=None):
@@ -152,10 +179,15 @@ class ShardedSasrecStep:
         # 1. plan: unique (owner, row) keys of this batch; a trailing lookup of id 0 pins compact row 0 = padding row.
         #    Local work that depends on the ids only: the plan of the NEXT batch is started on a side stream here (no
         #    collective runs there), so from the second step on this is just an event wait.
-        pl, counts_dev = self._take_plan(batch)
+        pl, counts_dev, counts_host = self._take_plan(batch)
         if next_batch is not None:
             self._prefetch_plan(next_batch)
-        send_counts, recv_counts = self.xchg.exchange_counts_dev(counts_dev)   # the one host sync of the step (2W ints)
+        if counts_host is not None:
+            # the plan came from the lookahead: its counts were copied to pinned host memory on the side stream, so the host
+            # only waited for THAT event -- the compute stream is never drained and the host keeps running ahead of the GPU
+            send_counts, recv_counts = self.xchg.exchange_counts_host(counts_host)
+        else:
+            send_counts, recv_counts = self.xchg.exchange_counts_dev(counts_dev)   # first step: one host sync (2W ints)
         n_uniq = sum(send_counts)
         keys = pl.uniq_idx[:n_uniq]
         req_send = (keys % self.n_local).to(torch.int32) if W > 1 else keys
@@ -181,16 +213,26 @@ class ShardedSasrecStep:
         lab = label.to(torch.int32).contiguous() if label is not None else None
         scores, _, loss_out = ops.gather_dot_loss_fwd(lcfg, user_emb, compact, item_c, lab)
         coef, d_user, _ = ops.gather_dot_loss_bwd(lcfg, user_emb, compact, item_c, lab, scores, loss_out)
-        dense_grad, d_rows = enc_bwd(cfg, compact, m.dense_flat.data, seq_c, d_user, ws)
+        # SASRec: the dense-gradient reductions stay on the library's side stream (ur_sasrec_bwd_deferred) under the row-gradient
+        # reduce and all-to-all #3 below; joined right before the first reader of dense_grad, the all-reduce
+        deferred = self.kind != "GRU"
+        if deferred:
+            dense_grad, d_rows = ops.sasrec_bwd(cfg, compact, m.dense_flat.data, seq_c, d_user, ws, defer_join=True)
+        else:
+            dense_grad, d_rows = enc_bwd(cfg, compact, m.dense_flat.data, seq_c, d_user, ws)
         # 5. row gradients of the unique keys, then all-to-all #3 to the owners
         coef_b = torch.cat([coef.reshape(-1), self.zero_coef])
         ug = ops.rows_reduce(pl, d_rows, coef_b, user_emb, G, d)[:n_uniq]
         grads_in = self.xchg.all_to_all_rows(ug, send_counts, recv_counts)
+        # 6. dense parameters: one flat all-reduce (sum), mean applied inside the Adam kernel.  Issued behind the last
+        #    all-to-all and waited for only before the dense update: it runs under the owner-side reduce + sparse update
+        if deferred:
+            ops.sasrec_bwd_join()
+        work = dist.all_reduce(dense_grad, async_op=True) if W > 1 else None
         own_ug = ops.rows_reduce(own, grads_in.contiguous(), None, None, 1, d)   # sums ranks in source-rank order
         ops.sparse_adam_rows(acfg, self.table, self.m, self.v, own, own_ug, self.last, self.inv_w)
-        # 6. dense parameters: one flat all-reduce (sum), mean applied inside the Adam kernel
-        if W > 1:
-            dist.all_reduce(dense_grad)
+        if work is not None:
+            work.wait()
         ops.dense_adam(acfg, m.dense_flat.data, dense_grad, self.dense_m, self.dense_v, self.inv_w)
         return loss_out[0]
 
@@ -208,20 +250,27 @@ class ShardedSasrecStep:
         n, n_a = ids_a.numel() + ids_b.numel(), ids_a.numel()
         bufs = (ops.rows_plan_alloc(n, n_a, self.device), torch.empty(self.world, dtype=torch.int32, device=self.device))
         self._side.wait_stream(main)
+        if self._counts_pinned is None:   # two slots: the host reads slot t while the side stream may already fill slot t+1
+            self._counts_pinned = [torch.empty(self.world, dtype=torch.int32).pin_memory() for _ in range(2)]
+        host = self._counts_pinned[self.t & 1]
         with torch.cuda.stream(self._side):
             pl, counts = ops.rows_plan_sharded(ids_a, ids_b, self.N, self.world, out=bufs)
+            host.copy_(counts, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._side)
-        self._prefetched = ((batch["item_seq"].data_ptr(), batch["item_id"].data_ptr()), pl, counts, ev, (ids_a, ids_b, bufs))
+        self._prefetched = ((batch["item_seq"].data_ptr(), batch["item_id"].data_ptr()), pl, counts, ev, (ids_a, ids_b, bufs), host)
 
     def _take_plan(self, batch):
+        """-> (plan, counts on the device, counts on the host or None)"""
         pre, self._prefetched = self._prefetched, None
         if pre is not None:
             torch.cuda.current_stream().wait_event(pre[3])
             if pre[0] == (batch["item_seq"].data_ptr(), batch["item_id"].data_ptr()):
-                return pre[1], pre[2]
+                pre[3].synchronize()           # the host waits for the side stream's plan only
+                return pre[1], pre[2], [int(x) for x in pre[5].tolist()]
         ids_a, ids_b = self._plan_ids(batch)
-        return ops.rows_plan_sharded(ids_a, ids_b, self.N, self.world)
+        pl, counts = ops.rows_plan_sharded(ids_a, ids_b, self.N, self.world)
+        return pl, counts, None
 
     # ---- evaluation over the sharded table (SURVEY.md 8e / f1) -------------------------------------------------
     @torch.no_grad()
