@@ -351,8 +351,10 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
 constexpr int TB = 128;  // output tile (rows of Out = columns of P) x (cols of Out = columns of Q)
 constexpr int BT = 32;   // tokens per LDS stage
 
-template <int PRO>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q,
+// NW = 4 waves (2 x 2, 64 x 64 per wave) or 8 waves (2 x 4, 64 x 32 per wave: with ONE workgroup per CU the second wave of
+// every SIMD issues MFMAs while the first waits on LDS / the barrier)
+template <int PRO, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_tn_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q,
                                                       int ldq, int T, int R, int Cc, int tok_per_split, int n_splits, int act,
                                                       float* __restrict__ part, float* __restrict__ bias_part,
                                                       const int* __restrict__ t_dev) {
@@ -364,7 +366,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   float* Ps = smem;                  // [2][BT*TB]
   float* Qs = smem + 2 * BT * TB;    // [2][BT*TB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  constexpr int WC = NW / 2, TN_ = 4 / WC;   // waves along the columns, 32-column MFMA tiles per wave
+  constexpr int NT_ = 64 * NW, RP = NT_ / 32, NP = BT / RP;   // threads, token rows per load pass, passes per stage
+  const int wr = wave / WC, wc = wave % WC;
   // XCD-aware mapping (see gemm_nt): the output tiles of one token split share an XCD, so the P / Q rows of that
   // split are fetched into one L2 only
   const int ntc = (Cc + TB - 1) / TB, ntiles = ntc * ((R + TB - 1) / TB);
@@ -375,13 +379,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   const bool first_ctile = (tile % ntc) == 0;
   const int t_begin = sp * tok_per_split;
   const int t_end = min(T, t_begin + tok_per_split);
-  const int c4 = tid & 31, trow = tid >> 5;  // 8 token rows per pass, 4 passes
+  const int c4 = tid & 31, trow = tid >> 5;  // RP token rows per pass, NP passes
 
-  floatx16 acc[2][2];
+  floatx16 acc[2][TN_];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN_; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum = 0.f;
@@ -389,11 +393,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   const bool rin = r0 + c4 * 4 < R, cin = c0 + c4 * 4 < Cc;
   const float* Pp = P + (rin ? r0 + c4 * 4 : 0);
   const float* Qp = Q + (cin ? c0 + c4 * 4 : 0);
-  float4 rp[4], rq[4];
+  float4 rp[NP], rq[NP];
   auto load_global = [&](int t0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = t0 + trow + 8 * i;
+    for (int i = 0; i < NP; ++i) {
+      const int t = t0 + trow + RP * i;
       const bool tin = t < t_end;
       const int tt = tin ? t : t_end - 1;
       float4 p = *(const float4*)(Pp + (long long)tt * ldp);
@@ -406,11 +410,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(float4*)(Ps + buf * BT * TB + (trow + 8 * i) * TB + c4 * 4) = rp[i];
+    for (int i = 0; i < NP; ++i) {
+      *(float4*)(Ps + buf * BT * TB + (trow + RP * i) * TB + c4 * 4) = rp[i];
       float4 v = rq[i];
       if (PRO == PRO_ACT) v = act4(v, act);
-      *(float4*)(Qs + buf * BT * TB + (trow + 8 * i) * TB + c4 * 4) = v;
+      *(float4*)(Qs + buf * BT * TB + (trow + RP * i) * TB + c4 * 4) = v;
     }
   };
 
@@ -425,15 +429,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     const int buf = it & 1;
     if (it + 1 < nt) load_global(t_begin + (it + 1) * BT);
     const float* Pb = Ps + buf * BT * TB + ft * TB + wr * 64 + fcol;
-    const float* Qb = Qs + buf * BT * TB + ft * TB + wc * 64 + fcol;
+    const float* Qb = Qs + buf * BT * TB + ft * TB + wc * (32 * TN_) + fcol;
 #pragma unroll
     for (int kk = 0; kk < BT; kk += 2) {
       const float a0 = Pb[kk * TB], a1 = Pb[kk * TB + 32];
-      const float b0 = Qb[kk * TB], b1 = Qb[kk * TB + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float b[TN_];
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) b[j] = Qb[kk * TB + 32 * j];
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[j], acc[1][j], 0, 0, 0);
+      }
     }
     if (bias_part != nullptr && first_ctile && tid < TB) {
 #pragma unroll 8
@@ -451,10 +458,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TN_; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          Cs[(wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4) * CS + wc * 64 + j * 32 + lcol] = acc[i][j][r];
+          Cs[(wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4) * CS + wc * (32 * TN_) + j * 32 + lcol] = acc[i][j][r];
   }
   __syncthreads();
   float* out = part + (long long)sp * R * Cc;
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     const int t = tid & 31, g = tid >> 5;
     const int c = c0 + t * 4;
     if (c < Cc)
-      for (int rl = g; rl < TB; rl += 8) {
+      for (int rl = g; rl < TB; rl += RP) {
         const int rr = r0 + rl;
         if (rr >= R) break;
         *(float4*)(out + (long long)rr * Cc + c) = *(const float4*)(Cs + rl * CS + t * 4);
@@ -572,16 +579,19 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
   float* bias_part = bias_out ? ws + (long long)S * R * Cc : nullptr;
   dim3 grid(8 * cdiv(S, 8) * cdiv(Cc, TB) * cdiv(R, TB));
   const size_t lds = (size_t)TB * (TB + 4) * sizeof(float);  // >= 4*BT*TB staging
+  static const int nw = getenv("UR_TN_WAVES") ? atoi(getenv("UR_TN_WAVES")) : 8;   // tuning aid: 4 or 8 waves per workgroup
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_ACT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_NONE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_ACT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_NONE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  if (pro_act_on_q)
-    hipLaunchKernelGGL((gemm_tn_kernel<PRO_ACT>), grid, dim3(256), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev);
-  else
-    hipLaunchKernelGGL((gemm_tn_kernel<PRO_NONE>), grid, dim3(256), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev);
+#define UR_TN_GO(PRO_, NW_) hipLaunchKernelGGL((gemm_tn_kernel<PRO_, NW_>), grid, dim3(64 * NW_), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev)
+  if (nw == 4) { if (pro_act_on_q) UR_TN_GO(PRO_ACT, 4); else UR_TN_GO(PRO_NONE, 4); }
+  else { if (pro_act_on_q) UR_TN_GO(PRO_ACT, 8); else UR_TN_GO(PRO_NONE, 8); }
+#undef UR_TN_GO
   UR_LAUNCH_CHECK();
   const long long n = (long long)R * Cc;
   if (defer) {
