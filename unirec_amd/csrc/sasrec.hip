@@ -292,8 +292,8 @@ struct SideCtx {
   bool ok = false;
 };
 int g_side_enabled = 1;   // runtime switch (ur_sasrec_set_side_stream)
-SideCtx* side_ctx() {
-  if (!g_side_enabled) return nullptr;
+SideCtx* side_ctx(bool even_if_disabled = false) {
+  if (!g_side_enabled && !even_if_disabled) return nullptr;
   static SideCtx* ctx = []() -> SideCtx* {
     const char* e = getenv("UR_SASREC_SIDE");
     if (e && atoi(e) == 0) return nullptr;
@@ -628,7 +628,7 @@ extern "C" int ur_sasrec_bwd_deferred(const UrSasrecCfg* cfg, const float* item_
 }
 
 extern "C" int ur_sasrec_bwd_join(void* stream) {
-  SideCtx* sc = side_ctx();
+  SideCtx* sc = side_ctx(true);   // (a pass deferred before ur_sasrec_set_side_stream(0) still has to be joined)
   if (sc && sc->join_pending) {
     UR_HIP(hipStreamWaitEvent(as_stream(stream), sc->done, 0));
     sc->join_pending = false;
