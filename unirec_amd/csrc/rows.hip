@@ -344,6 +344,59 @@ __device__ __forceinline__ void add_pos(float4 (&acc)[MAXV], long long p, long l
   }
 }
 
+// The walk of one lane group over its share of a LONG run (positions first, first + step, ...): four positions per trip with
+// every load of the trip issued before the first add -- position, coefficient and row loads are unconditional (clamped
+// indices, pointer selects), because a load behind a branch is waited for on the spot.  Same adds in the same order as add_pos
+// (acc + r == fma(1, r, acc) exactly), so results do not depend on which walk ran.  Hot items under Zipfian ids: ~1500
+// positions of one id per batch; one dependent position -> row round trip per add made this kernel 204 us of a 1.0 ms step.
+template <int TPR, int KV>
+__device__ __forceinline__ void long_walk(float4 (&acc)[MAXV], int first, int end, int step, const int* __restrict__ sorted_pos,
+                                          long long n_a, const float4* __restrict__ rows_a, const float* __restrict__ coef_b,
+                                          const float4* __restrict__ vec_b, int G, int d4, int t) {
+  constexpr int U = KV == 1 ? 8 : 4;   // positions per trip (KV float4 registers each)
+  const float* cb = coef_b ? coef_b : (const float*)rows_a;   // (never used when there are no b positions: every p < n_a)
+  const float4* vb = vec_b ? vec_b : rows_a;
+  long long pn[U];                     // positions of the NEXT trip: loaded one trip ahead, under the row loads of this one
+#pragma unroll
+  for (int u = 0; u < U; ++u) pn[u] = sorted_pos[min(first + u * step, end - 1)];
+  for (int q0 = first; q0 < end; q0 += U * step) {
+    bool ok[U];
+    long long pp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ok[u] = q0 + u * step < end;
+      pp[u] = pn[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) pn[u] = sorted_pos[min(q0 + (U + u) * step, end - 1)];
+    float w[U];
+    const float4* src[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool is_a = pp[u] < n_a;
+      const long long pb = is_a ? 0 : pp[u] - n_a;
+      const float cw = cb[pb];
+      w[u] = is_a ? 1.0f : cw;
+      src[u] = is_a ? rows_a + pp[u] * d4 : vb + (pb / G) * d4;
+    }
+    float4 r[U][KV];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < KV; ++k) r[u][k] = src[u][min(t + k * TPR, d4 - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (ok[u]) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k)
+          if (t + k * TPR < d4) {
+            acc[k].x = fmaf(w[u], r[u][k].x, acc[k].x); acc[k].y = fmaf(w[u], r[u][k].y, acc[k].y);
+            acc[k].z = fmaf(w[u], r[u][k].z, acc[k].z); acc[k].w = fmaf(w[u], r[u][k].w, acc[k].w);
+          }
+      }
+  }
+}
+
 // One lane group per unique id; positions are summed in sorted (= lookup) order.  Runs longer than LONG_SEG are
 // handled by all groups of the block together: group g takes positions s+g, s+g+groups, ..., the partial sums are
 // combined through LDS in group order -- still a fixed summation order, so results are bit-reproducible.
@@ -358,9 +411,13 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
   __shared__ int long_flag[groups];
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int n_uniq = *n_uniq_dev;
-  for (long long base = (long long)blockIdx.x * groups; base < n; base += (long long)gridDim.x * groups) {
-    if (base >= n_uniq && !zero_tail) break;   // block-uniform
-    const long long u = base + g;
+  // unique id u -> (workgroup u % gridDim, lane group (u / gridDim) % groups): NEIGHBOURING ids go to different workgroups.  Hot
+  // items sit next to each other in id order (Zipfian catalogues are numbered by popularity), and a workgroup walks its long
+  // runs one after the other -- with ids base..base+7 in one workgroup the first one carried the eight hottest items alone
+  const long long gstride = gridDim.x;
+  for (long long base = blockIdx.x; base < n; base += gstride * groups) {
+    if (base >= n_uniq && !zero_tail) break;   // block-uniform (base is the smallest id of the pass)
+    const long long u = base + gstride * g;
     int s = 0, e = 0;
     bool is_long = false;
     if (u < n) {
@@ -396,12 +453,17 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
     __syncthreads();
     for (int gi = 0; gi < groups; ++gi) {
       if (!long_flag[gi]) continue;            // block-uniform
-      const long long ul = base + gi;
+      const long long ul = base + gstride * gi;
       const int sl = seg_start[ul], el = seg_start[ul + 1];
       float4 acc[MAXV];
 #pragma unroll
       for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int q = sl + g; q < el; q += groups) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
+      switch ((d4 + TPR - 1) / TPR) {   // float4 chunks per lane (block-uniform)
+        case 1: long_walk<TPR, 1>(acc, sl + g, el, groups, sorted_pos, n_a, rows_a, coef_b, vec_b, G, d4, t); break;
+        case 2: long_walk<TPR, 2>(acc, sl + g, el, groups, sorted_pos, n_a, rows_a, coef_b, vec_b, G, d4, t); break;
+        case 3: long_walk<TPR, 3>(acc, sl + g, el, groups, sorted_pos, n_a, rows_a, coef_b, vec_b, G, d4, t); break;
+        default: long_walk<TPR, 4>(acc, sl + g, el, groups, sorted_pos, n_a, rows_a, coef_b, vec_b, G, d4, t); break;
+      }
 #pragma unroll
       for (int k = 0; k < MAXV; ++k) part[g][k * TPR + t] = acc[k];
       __syncthreads();
