@@ -437,8 +437,12 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
           s = seg_start[u];
           e = seg_start[u + 1];
           is_long = e - s > LONG_SEG;
-          if (!is_long)
-            for (int q = s; q < e; ++q) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
+          if (!is_long) {
+            if (e - s >= 8 && d4 <= TPR)   // a medium run: the same pipelined walk, this lane group alone (step 1)
+              long_walk<TPR, 1>(acc, s, e, 1, sorted_pos, n_a, rows_a, coef_b, vec_b, G, d4, t);
+            else
+              for (int q = s; q < e; ++q) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
+          }
         }
         if (!is_long) {
 #pragma unroll
