@@ -189,6 +189,8 @@ def test_rows_plan_and_reduce_vs_numpy():
     rng = np.random.default_rng(0)
     for (n_a, n_b, G, n_rows, d) in ((700, 330, 11, 97, 32), (5000, 4004, 1001, 60000, 64), (1, 0, 1, 10, 128),
                                      (3000, 1200, 3, 5, 64), (900, 0, 1, 3, 128),   # hot ids: runs >> 64 take the block-cooperative path
+                                     (4000, 1000, 5, 40, 256), (2000, 600, 3, 7, 512),   # ... with 2 and 4 float4 chunks per lane
+                                     (6000, 1500, 5, 300, 128),                            # medium runs (8..64): the pipelined walk inside a lane group
                                      (0, 2048, 4, 3_000_000, 128),
                                      (30000, 2768, 4, 100_000_000, 32),    # n = 32768: largest single-launch plan
                                      (80000, 20000, 5, 100_000_000, 32)):   # n > 65536: multi-launch plan
