@@ -5,7 +5,9 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows), key=lambda e: e[0])
 # a window of steady-state steps: between two launches of the once-per-step plan kernel, well inside the timed region
-marks = [e[0] for e in ev if "plan_small_kernel" in e[2] or "rows_plan" in e[2]]
+import os
+MARK = os.environ.get("MARK", "plan_small_kernel")   # a kernel launched exactly once per step
+marks = [e[0] for e in ev if MARK in e[2]]
 n_steps = min(100, len(marks) - 12)
 t0, t1 = marks[-(n_steps + 5)], marks[-5]
 ev = [e for e in ev if t0 <= e[0] < t1]

@@ -353,15 +353,15 @@ template <int TPR, int KV>
 __device__ __forceinline__ void long_walk(float4 (&acc)[MAXV], int first, int end, int step, const int* __restrict__ sorted_pos,
                                           long long n_a, const float4* __restrict__ rows_a, const float* __restrict__ coef_b,
                                           const float4* __restrict__ vec_b, int G, int d4, int t) {
-  constexpr int U = KV == 1 ? 8 : 4;   // positions per trip (KV float4 registers each)
+  constexpr int U = KV == 1 ? 4 : 1;   // positions per trip (KV float4 registers each; more costs the common short-run path its occupancy)
   const float* cb = coef_b ? coef_b : (const float*)rows_a;   // (never used when there are no b positions: every p < n_a)
   const float4* vb = vec_b ? vec_b : rows_a;
-  long long pn[U];                     // positions of the NEXT trip: loaded one trip ahead, under the row loads of this one
+  int pn[U];                           // positions of the NEXT trip: loaded one trip ahead, under the row loads of this one
 #pragma unroll
   for (int u = 0; u < U; ++u) pn[u] = sorted_pos[min(first + u * step, end - 1)];
   for (int q0 = first; q0 < end; q0 += U * step) {
     bool ok[U];
-    long long pp[U];
+    int pp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       ok[u] = q0 + u * step < end;
@@ -374,10 +374,10 @@ __device__ __forceinline__ void long_walk(float4 (&acc)[MAXV], int first, int en
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool is_a = pp[u] < n_a;
-      const long long pb = is_a ? 0 : pp[u] - n_a;
+      const int pb = is_a ? 0 : pp[u] - (int)n_a;
       const float cw = cb[pb];
       w[u] = is_a ? 1.0f : cw;
-      src[u] = is_a ? rows_a + pp[u] * d4 : vb + (pb / G) * d4;
+      src[u] = is_a ? rows_a + (long long)pp[u] * d4 : vb + (long long)(pb / G) * d4;
     }
     float4 r[U][KV];
 #pragma unroll
@@ -408,56 +408,60 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
                                                           int d4, float4* __restrict__ out, int zero_tail) {
   constexpr int groups = 256 / TPR;
   __shared__ float4 part[groups][MAXV * TPR];
-  __shared__ int long_flag[groups];
+  __shared__ int long_list[256];
+  __shared__ int long_cnt;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int n_uniq = *n_uniq_dev;
-  // unique id u -> (workgroup u % gridDim, lane group (u / gridDim) % groups): NEIGHBOURING ids go to different workgroups.  Hot
-  // items sit next to each other in id order (Zipfian catalogues are numbered by popularity), and a workgroup walks its long
-  // runs one after the other -- with ids base..base+7 in one workgroup the first one carried the eight hottest items alone
+  // (pass 2's first candidate test is issued here, so that its loads travel with pass 1's instead of after them)
   const long long gstride = gridDim.x;
-  for (long long base = blockIdx.x; base < n; base += gstride * groups) {
-    if (base >= n_uniq && !zero_tail) break;   // block-uniform (base is the smallest id of the pass)
-    const long long u = base + gstride * g;
-    int s = 0, e = 0;
-    bool is_long = false;
-    if (u < n) {
-      if (u >= n_uniq) {
-        if (zero_tail) {
+  const long long uc0 = blockIdx.x + gstride * threadIdx.x;
+  const bool cand0 = uc0 < n_uniq && uniq_idx[uc0] != 0 && seg_start[uc0 + 1] - seg_start[uc0] > LONG_SEG;
+  // ---- pass 1: one lane group per unique id, neighbouring ids in one workgroup (coalesced plan reads).  Long runs are left out.
+  for (long long base = (long long)blockIdx.x * groups; base < n; base += (long long)gridDim.x * groups) {
+    if (base >= n_uniq && !zero_tail) break;   // block-uniform
+    const long long u = base + g;
+    if (u >= n) continue;
+    if (u >= n_uniq) {
+      if (zero_tail) {
 #pragma unroll
-          for (int k = 0; k < MAXV; ++k) {
-            const int c = t + k * TPR;
-            if (c < d4) out[u * d4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-        }
-      } else {
-        float4 acc[MAXV];
-#pragma unroll
-        for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (uniq_idx[u] != 0) {
-          s = seg_start[u];
-          e = seg_start[u + 1];
-          is_long = e - s > LONG_SEG;
-          if (!is_long) {
-            if (e - s >= 8 && d4 <= TPR)   // a medium run: the same pipelined walk, this lane group alone (step 1)
-              long_walk<TPR, 1>(acc, s, e, 1, sorted_pos, n_a, rows_a, coef_b, vec_b, G, d4, t);
-            else
-              for (int q = s; q < e; ++q) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
-          }
-        }
-        if (!is_long) {
-#pragma unroll
-          for (int k = 0; k < MAXV; ++k) {
-            const int c = t + k * TPR;
-            if (c < d4) out[u * d4 + c] = acc[k];
-          }
+        for (int k = 0; k < MAXV; ++k) {
+          const int c = t + k * TPR;
+          if (c < d4) out[u * d4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
+      continue;
     }
-    if (t == 0) long_flag[g] = is_long ? 1 : 0;
+    float4 acc[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (uniq_idx[u] != 0) {
+      const int s = seg_start[u], e = seg_start[u + 1];
+      if (e - s > LONG_SEG) continue;                      // pass 2
+      if (e - s >= 8 && d4 <= TPR)   // a medium run: the pipelined walk, this lane group alone (step 1)
+        long_walk<TPR, 1>(acc, s, e, 1, sorted_pos, n_a, rows_a, coef_b, vec_b, G, d4, t);
+      else
+        for (int q = s; q < e; ++q) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int c = t + k * TPR;
+      if (c < d4) out[u * d4 + c] = acc[k];
+    }
+  }
+  // ---- pass 2: the long runs, each by a whole workgroup.  Candidates are dealt out INTERLEAVED (thread j of workgroup b looks at
+  // id b + gridDim * j): hot items sit next to each other in id order (Zipfian catalogues are numbered by popularity), and a
+  // workgroup walks its long runs one after the other -- with neighbouring ids in one workgroup the first one carried the eight
+  // hottest items alone.  The order of the list does not matter: every run's sum has its own fixed order.
+  for (long long j0 = 0; blockIdx.x + gstride * j0 < n_uniq; j0 += 256) {   // block-uniform
+    if (threadIdx.x == 0) long_cnt = 0;
     __syncthreads();
-    for (int gi = 0; gi < groups; ++gi) {
-      if (!long_flag[gi]) continue;            // block-uniform
-      const long long ul = base + gstride * gi;
+    const long long uc = blockIdx.x + gstride * (j0 + threadIdx.x);
+    const bool cand = j0 == 0 ? cand0 : (uc < n_uniq && uniq_idx[uc] != 0 && seg_start[uc + 1] - seg_start[uc] > LONG_SEG);
+    if (cand) long_list[atomicAdd(&long_cnt, 1)] = (int)uc;
+    __syncthreads();
+    const int cnt = long_cnt;
+    for (int li = 0; li < cnt; ++li) {
+      const long long ul = long_list[li];
       const int sl = seg_start[ul], el = seg_start[ul + 1];
       float4 acc[MAXV];
 #pragma unroll
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
       }
       __syncthreads();
     }
-    __syncthreads();   // long_flag is rewritten by the next iteration
+    __syncthreads();   // long_cnt / long_list are rewritten by the next round
   }
 }
 
