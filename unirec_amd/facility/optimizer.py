@@ -144,6 +144,13 @@ class SparseDenseAdam:
             if st["last"] is not None:
                 ops.lazy_adam_flush(cfg, st["w"], st["m"], st["v"], st["last"])
 
+    def mark_tables_current(self):
+        """The table rows were just replaced from outside (checkpoint load): they are up to date as of step ``t``, so no
+        zero-gradient replay is pending for any of them."""
+        for st in self.tables.values():
+            if st["last"] is not None:
+                st["last"].fill_(self.t)
+
     # ------------------------------------------------------------------ step
     def _collect(self, name):
         """-> (ids_a, rows_a, ids_b, coef, vec, G) for one table from model.sparse_grads."""

@@ -258,7 +258,7 @@ class Trainer(object):
     @staticmethod
     def _metrics_from_rank(r, n_scores):
         """hit/ndcg/mrr/group_auc from the 0-based rank of the positive (unirec/facility/evaluation/onepos.py:100-175)."""
-        r = np.asarray(r, dtype=np.float64)
+        r = np.maximum(np.asarray(r, dtype=np.float64), 0.0)   # a rank is a count: never below 0
         out = {"mrr": float(np.mean(1.0 / (r + 1))), "group_auc": float(np.mean((n_scores - 1 - r) / max(n_scores - 1, 1)))}
         for k in (1, 3, 5, 10, 20, 50, 100):
             out[f"hit@{k}"] = float(np.mean(r < k))
@@ -301,9 +301,11 @@ class Trainer(object):
 
     @torch.no_grad()
     def evaluate(self, eval_data, load_best_model=True, model_file=None, verbose=0, predict_only=False):
+        # pending lazy zero-gradient steps belong to the weights that are in memory NOW: apply them before a checkpoint
+        # replaces those weights (flushing afterwards would replay the old momentum on top of the loaded checkpoint)
+        self.optimizer.flush()
         if load_best_model and os.path.exists(model_file or self.saved_model_file):
             self.load_model(model_file or self.saved_model_file)
-        self.optimizer.flush()
         self.model.eval()
         if getattr(self, "eval_protocol", None) == "one_vs_all" and not predict_only:
             return self.evaluate_full_items(eval_data)
@@ -333,3 +335,6 @@ class Trainer(object):
         ck = torch.load(model_file, map_location="cpu", weights_only=False)
         self.model.load_state_dict(ck["state_dict"], strict=False)
         self.model.check_views()
+        # the loaded rows are current as of the optimizer's step counter: nothing is pending for them (the reference
+        # loads the state_dict only and keeps stepping its optimizer state, trainer.py:400-412)
+        self.optimizer.mark_tables_current()

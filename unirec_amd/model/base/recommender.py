@@ -196,6 +196,29 @@ class BaseRecommender(AbstractRecommender):
         self.sparse_grads.append(dict(table="user_embedding", ids_a=state.to(torch.int32).contiguous(),
                                       rows=d_user.view(-1, d_user.shape[-1])))
 
+    # ---- activation workspaces.  One per mode: evaluation forwards never touch the buffer a pending backward will read; every
+    # TRAINING forward bumps a generation counter, and an autograd backward whose saved activations were overwritten by a
+    # later training forward of the same model fails loudly instead of producing silently wrong gradients (the reference's
+    # autograd keeps activations per call; here they live in ONE caller-owned buffer per mode).
+    def _ws_slot(self, key, train, alloc):
+        slots = self.__dict__.get("_ws_slots")
+        if slots is None:
+            slots = {}
+            object.__setattr__(self, "_ws_slots", slots)
+        s = slots.get(bool(train))
+        if s is None or s[0] != key:
+            s = (key, alloc())
+            slots[bool(train)] = s
+        if train:
+            object.__setattr__(self, "_ws_gen", getattr(self, "_ws_gen", 0) + 1)
+        return s[1]
+
+    def _ws_check(self, gen):
+        if gen != getattr(self, "_ws_gen", 0):
+            raise RuntimeError("the activation workspace of this forward pass was overwritten by a later training forward of the same "
+                               "model before backward() ran: call backward() before the next training forward (evaluation forwards "
+                               "use their own workspace and are fine)")
+
     # An optimizer that runs the row-sparse half of its step first sets ``defer_dense_join``: the encoder backward may then
     # return while its dense-gradient reductions are still running on a side stream (ur_sasrec_bwd_deferred);
     # ``dense_flat.grad`` stays None until ``finish_backward()`` joins them.  Default off: backward leaves complete gradients.

@@ -12,9 +12,9 @@ class _AttHistFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, model, item_seq):
         cfg = model._cfg(item_seq.shape[0], item_seq.shape[1], train=True)
-        ws = model._workspace(cfg)
+        ws = model._workspace(cfg, train=True)
         out = ops.atthist_fwd(cfg, model.item_embedding.weight.data, dense.data, item_seq, ws)
-        ctx.model, ctx.cfg, ctx.ws = model, cfg, ws
+        ctx.model, ctx.cfg, ctx.ws, ctx.gen = model, cfg, ws, model._ws_gen
         ctx.save_for_backward(item_seq)
         return out
 
@@ -22,6 +22,7 @@ class _AttHistFn(torch.autograd.Function):
     def backward(ctx, d_user):
         (item_seq,) = ctx.saved_tensors
         model = ctx.model
+        model._ws_check(ctx.gen)
         dense_grad, d_rows = ops.atthist_bwd(ctx.cfg, model.item_embedding.weight.data, model.dense_flat.data, item_seq, d_user.contiguous(), ctx.ws)
         model.sparse_grads.append(dict(table="item_embedding", ids_a=item_seq.reshape(-1), rows=d_rows))
         return dense_grad, None, None
@@ -42,16 +43,10 @@ class AttHist(BaseRecommender):
                                drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0),
                                drop_step=getattr(self, "_drop_step", 0))
 
-    def _workspace(self, cfg):
-        key = (cfg.B, cfg.L)
-        ws = self._ws_cache.get(key)
-        if ws is None:
-            ws = ops.atthist_workspace(cfg, self.device)
-            self._ws_cache = {key: ws}
-        return ws
+    def _workspace(self, cfg, train=False):
+        return self._ws_slot((cfg.B, cfg.L), train, lambda: ops.atthist_workspace(cfg, self.device))
 
     def _define_model_layers(self):
-        object.__setattr__(self, "_ws_cache", {})
         d = self.embedding_size
         offs, total = ops.atthist_param_layout(self._cfg(1, 1))
         self._alloc_dense(total)
@@ -63,7 +58,7 @@ class AttHist(BaseRecommender):
     def _encode_train(self, user_id, item_seq, item_seq_len=None):
         item_seq = item_seq.to(torch.int32).contiguous()
         cfg = self._cfg(*item_seq.shape, train=True)
-        ws = self._workspace(cfg)
+        ws = self._workspace(cfg, train=True)
         return ops.atthist_fwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, ws), (cfg, ws, item_seq)
 
     def _encode_backward(self, state, d_user):

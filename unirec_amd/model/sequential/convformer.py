@@ -13,9 +13,9 @@ class _ConvFormerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, model, item_seq, item_seq_len):
         cfg = model._cfg(item_seq.shape[0], train=True)
-        ws = model._workspace(cfg)
+        ws = model._workspace(cfg, train=True)
         out = ops.convformer_fwd(cfg, model.item_embedding.weight.data, dense.data, item_seq, item_seq_len, ws)
-        ctx.model, ctx.cfg, ctx.ws = model, cfg, ws
+        ctx.model, ctx.cfg, ctx.ws, ctx.gen = model, cfg, ws, model._ws_gen
         ctx.save_for_backward(item_seq, item_seq_len if item_seq_len is not None else item_seq.new_empty(0, dtype=torch.int64))
         return out
 
@@ -23,6 +23,7 @@ class _ConvFormerFn(torch.autograd.Function):
     def backward(ctx, d_user):
         item_seq, item_seq_len = ctx.saved_tensors
         model = ctx.model
+        model._ws_check(ctx.gen)
         dense_grad, d_rows = ops.convformer_bwd(ctx.cfg, model.item_embedding.weight.data, model.dense_flat.data, item_seq,
                                                 item_seq_len if item_seq_len.numel() else None, d_user.contiguous(), ctx.ws)
         model.sparse_grads.append(dict(table="item_embedding", ids_a=item_seq.reshape(-1), rows=d_rows))
@@ -69,12 +70,9 @@ class ConvFormer(BaseRecommender):
                                   self._padding_mode(), self.FAST, self.seq_merge, self.layer_norm_eps, self.seq_decay, p_hidden=p,
                                   drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0), drop_step=self._drop_step)
 
-    def _workspace(self, cfg):
-        ws = self._ws_cache.get(cfg.B)
-        if ws is None:
-            ws = ops.convformer_workspace(self._cfg(cfg.B, p_hidden=self.hidden_dropout_prob), self.device)   # the training layout fits both
-            self._ws_cache = {cfg.B: ws}
-        return ws
+    def _workspace(self, cfg, train=False):
+        return self._ws_slot(cfg.B, train, lambda: ops.convformer_workspace(self._cfg(cfg.B, p_hidden=self.hidden_dropout_prob),
+                                                                            self.device))   # the training layout fits both
 
     def _mixer_holder(self, v, o, d, K):
         """parameters of one layer's mixer, named as in the reference"""
@@ -89,7 +87,6 @@ class ConvFormer(BaseRecommender):
     def _define_model_layers(self):
         if self.hidden_size != self.embedding_size:
             raise ValueError("ConvFormer adds position embeddings of hidden_size to item embeddings of embedding_size: they must be equal")
-        object.__setattr__(self, "_ws_cache", {})
         object.__setattr__(self, "_drop_step", 0)
         d, I, L, K = self.hidden_size, self.inner_size, self.max_seq_len, self.conv_size
         offs, total = ops.convformer_param_layout(self._cfg(1))
@@ -122,7 +119,7 @@ class ConvFormer(BaseRecommender):
     def _encode_train(self, user_id, item_seq, item_seq_len=None):
         item_seq, item_seq_len = self._prep(item_seq, item_seq_len)
         cfg = self._cfg(item_seq.shape[0], train=True)
-        ws = self._workspace(cfg)
+        ws = self._workspace(cfg, train=True)
         out = ops.convformer_fwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, item_seq_len, ws)
         return out, (cfg, ws, item_seq, item_seq_len)
 

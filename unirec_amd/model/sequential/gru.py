@@ -14,9 +14,9 @@ class _GruEncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, model, item_seq):
         cfg = model._cfg(item_seq.shape[0], train=True)
-        ws = model._workspace(cfg)
+        ws = model._workspace(cfg, train=True)
         out = ops.gru_fwd(cfg, model.item_embedding.weight.data, dense.data, item_seq, ws)
-        ctx.model, ctx.cfg, ctx.ws = model, cfg, ws
+        ctx.model, ctx.cfg, ctx.ws, ctx.gen = model, cfg, ws, model._ws_gen
         ctx.save_for_backward(item_seq)
         return out
 
@@ -24,6 +24,7 @@ class _GruEncoderFn(torch.autograd.Function):
     def backward(ctx, d_user):
         (item_seq,) = ctx.saved_tensors
         model = ctx.model
+        model._ws_check(ctx.gen)
         dense_grad, d_rows = ops.gru_bwd(ctx.cfg, model.item_embedding.weight.data, model.dense_flat.data, item_seq, d_user.contiguous(), ctx.ws)
         model.sparse_grads.append(dict(table="item_embedding", ids_a=item_seq.reshape(-1), rows=d_rows))
         return dense_grad, None, None
@@ -44,15 +45,14 @@ class GRU(BaseRecommender):
                            drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0),
                            drop_step=getattr(self, "_drop_step", 0))
 
-    def _workspace(self, cfg):
-        ws = self._ws_cache.get(cfg.B)
-        if ws is None:
-            ws = ops.gru_workspace(cfg, self.device)
-            self._ws_cache = {cfg.B: ws}
-        return ws
+    def _workspace(self, cfg, train=False):
+        return self._ws_slot(cfg.B, train, lambda: ops.gru_workspace(cfg, self.device))
+
+    def _check_seq(self, item_seq):
+        if item_seq.dim() != 2 or item_seq.shape[1] != self.config["max_seq_len"]:
+            raise ValueError(f"item_seq has shape {tuple(item_seq.shape)}, expected [B, max_seq_len={self.config['max_seq_len']}]")
 
     def _define_model_layers(self):
-        object.__setattr__(self, "_ws_cache", {})
         d, H = self.embedding_size, self.hidden_size
         offs, total = ops.gru_param_layout(self._cfg(1))
         self._alloc_dense(total)
@@ -67,8 +67,9 @@ class GRU(BaseRecommender):
 
     def _encode_train(self, user_id, item_seq, item_seq_len=None):
         item_seq = item_seq.to(torch.int32).contiguous()
+        self._check_seq(item_seq)
         cfg = self._cfg(item_seq.shape[0], train=True)
-        ws = self._workspace(cfg)
+        ws = self._workspace(cfg, train=True)
         return ops.gru_fwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, ws), (cfg, ws, item_seq)
 
     def _encode_backward(self, state, d_user):
@@ -79,6 +80,7 @@ class GRU(BaseRecommender):
 
     def forward_user_emb(self, user_id=None, item_seq=None, item_seq_len=None, item_seq_features=None, time_seq=None):
         item_seq = item_seq.to(torch.int32).contiguous()
+        self._check_seq(item_seq)
         if torch.is_grad_enabled() and self.training:
             return _GruEncoderFn.apply(self.dense_flat, self, item_seq)
         cfg = self._cfg(item_seq.shape[0])

@@ -18,9 +18,9 @@ class _SasrecEncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, model, item_seq):
         cfg = model._cfg(item_seq.shape[0], train=True)
-        ws = model._workspace(cfg)
+        ws = model._workspace(cfg, train=True)
         user_emb = ops.sasrec_fwd(cfg, model.item_embedding.weight.data, dense.data, item_seq, ws)
-        ctx.model, ctx.cfg, ctx.ws = model, cfg, ws
+        ctx.model, ctx.cfg, ctx.ws, ctx.gen = model, cfg, ws, model._ws_gen
         ctx.save_for_backward(item_seq)
         return user_emb
 
@@ -28,6 +28,7 @@ class _SasrecEncoderFn(torch.autograd.Function):
     def backward(ctx, d_user):
         (item_seq,) = ctx.saved_tensors
         model = ctx.model
+        model._ws_check(ctx.gen)
         dense_grad, d_rows = ops.sasrec_bwd(ctx.cfg, model.item_embedding.weight.data, model.dense_flat.data, item_seq,
                                             d_user.contiguous(), ctx.ws)
         model.sparse_grads.append(dict(table="item_embedding", ids_a=item_seq.reshape(-1), rows=d_rows))
@@ -63,21 +64,17 @@ class SASRec(BaseRecommender):
                               p_hidden=self.hidden_dropout_prob if drop else 0.0, p_attn=self.attn_dropout_prob if drop else 0.0,
                               drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0), drop_step=self._drop_step)
 
-    def _workspace(self, cfg):
-        key = cfg.B
-        ws = self._ws_cache.get(key)
-        if ws is None:
+    def _workspace(self, cfg, train=False):
+        def alloc():
             big = ops.sasrec_cfg(cfg.B, cfg.L, cfg.d, cfg.n_heads, cfg.inner, cfg.n_layers, self.hidden_act, cfg.use_pos, cfg.eps,
                                  p_hidden=self.hidden_dropout_prob)     # the training layout (dropout scratch included) fits both
-            ws = ops.sasrec_workspace(big, self.device)
-            self._ws_cache = {key: ws}  # keep one: batch size is fixed in training
-        return ws
+            return ops.sasrec_workspace(big, self.device)
+        return self._ws_slot(cfg.B, train, alloc)   # one buffer per mode (batch size is fixed in training)
 
     def _define_model_layers(self):
         if self.hidden_size != self.embedding_size:
             raise ValueError("SASRec adds position embeddings of hidden_size to item embeddings of embedding_size: "
                              "they must be equal (sasrec.py:25,60-66)")
-        object.__setattr__(self, "_ws_cache", {})
         object.__setattr__(self, "_drop_step", 0)
         d, I, L = self.hidden_size, self.inner_size, self.max_seq_len
         offs, total = ops.sasrec_param_layout(self._cfg(1))
@@ -110,7 +107,7 @@ class SASRec(BaseRecommender):
         if item_seq.shape[1] != self.max_seq_len:
             raise ValueError(f"item_seq has length {item_seq.shape[1]}, expected max_seq_len={self.max_seq_len}")
         cfg = self._cfg(item_seq.shape[0], train=True)
-        ws = self._workspace(cfg)
+        ws = self._workspace(cfg, train=True)
         return ops.sasrec_fwd(cfg, self.item_embedding.weight.data, self.dense_flat.data, item_seq, ws), (cfg, ws, item_seq)
 
     def _encode_backward(self, state, d_user):

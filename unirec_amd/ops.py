@@ -76,7 +76,8 @@ def sasrec_fwd(cfg, item_table, dense, item_seq, ws):
     _chk(item_table, torch.float32, "item_table")
     _chk(dense, torch.float32, "dense")
     _chk(item_seq, torch.int32, "item_seq")
-    assert item_seq.shape == (cfg.B, cfg.L), (item_seq.shape, cfg.B, cfg.L)
+    if tuple(item_seq.shape) != (cfg.B, cfg.L):
+        raise _lib.UnirecAmdError(f"sasrec_fwd: item_seq has shape {tuple(item_seq.shape)}, the configuration says [{cfg.B}, {cfg.L}]")
     user_emb = torch.empty(cfg.B, cfg.d, dtype=torch.float32, device=dense.device)
     check(lib.ur_sasrec_fwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(user_emb),
                             _p(ws), _stream()), "ur_sasrec_fwd")
@@ -118,6 +119,8 @@ def gru_fwd(cfg, item_table, dense, item_seq, ws):
     _chk(item_table, torch.float32, "item_table")
     _chk(dense, torch.float32, "dense")
     _chk(item_seq, torch.int32, "item_seq")
+    if tuple(item_seq.shape) != (cfg.B, cfg.L):   # the kernels index [B, L] ids: a shorter tensor would be read past its end
+        raise _lib.UnirecAmdError(f"gru_fwd: item_seq has shape {tuple(item_seq.shape)}, the configuration says [{cfg.B}, {cfg.L}]")
     user_emb = torch.empty(cfg.B, cfg.d, dtype=torch.float32, device=dense.device)
     check(lib.ur_gru_fwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(user_emb), _p(ws), _stream()),
           "ur_gru_fwd")
@@ -126,6 +129,9 @@ def gru_fwd(cfg, item_table, dense, item_seq, ws):
 
 def gru_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws):
     _chk(d_user_emb, torch.float32, "d_user_emb")
+    _chk(item_seq, torch.int32, "item_seq")
+    if tuple(item_seq.shape) != (cfg.B, cfg.L):
+        raise _lib.UnirecAmdError(f"gru_bwd: item_seq has shape {tuple(item_seq.shape)}, the configuration says [{cfg.B}, {cfg.L}]")
     dense_grad = torch.empty_like(dense)
     d_emb_rows = torch.empty(cfg.B * cfg.L, cfg.d, dtype=torch.float32, device=dense.device)
     check(lib.ur_gru_bwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(d_user_emb), _p(ws),
@@ -338,7 +344,9 @@ def full_rank(user_emb, item_table, target, user_id=None, hist_ptr=None, hist_so
     n_users = hist_ptr.numel() - 1 if hist_ptr is not None else 0
     check(lib.ur_full_rank(_p(user_emb), _p(item_table), n_items, B, d, _p(target), _p(user_id), _p(hist_ptr), _p(hist_sorted),
                            n_users, _p(user_bias), _p(item_bias), float(tau), _p(rank), _p(ts), _p(thr), _stream()), "ur_full_rank")
-    return rank, ts
+    # rank = (count over all items, MFMA summation order) - (count over history / non-items, row-dot summation order): a history
+    # item within one fp32 rounding of the target's score can be subtracted without having been counted -- a count is never < 0
+    return rank.clamp_(min=0), ts
 
 
 def full_rank_shard(phase, user_emb, shard_table, local_target, thr=None, user_id=None, hist_ptr=None, hist_sorted_local=None,

@@ -206,7 +206,7 @@ class ShardedSasrecStep:
         item_c = idx_b[: B * G].view(B, G).contiguous()
         # 4. forward / backward on the compact table (same kernels as the single-GPU path)
         cfg = m._cfg(B) if self.kind == "GRU" else m._cfg(B, train=True)   # SASRec: training-time dropout as configured
-        ws = m._workspace(cfg)
+        ws = m._workspace(cfg, train=True)
         enc_fwd, enc_bwd = (ops.gru_fwd, ops.gru_bwd) if self.kind == "GRU" else (ops.sasrec_fwd, ops.sasrec_bwd)
         user_emb = enc_fwd(cfg, compact, m.dense_flat.data, seq_c, ws)
         lcfg = ops.loss_cfg(B, G, d, self.loss_type, self.tau)
@@ -330,7 +330,7 @@ class ShardedSasrecStep:
         thr = self.xchg.all_reduce_sum(ops.full_rank_shard(1, ue_all, self.table, ltgt, n_rows=n_rows))
         part = ops.full_rank_shard(2, ue_all, self.table, ltgt, thr=thr, user_id=uid_all, hist_ptr=hp, hist_sorted_local=hs,
                                    n_rows=n_rows, excl_row=excl)
-        return self.xchg.all_reduce_sum(part)[r * B:(r + 1) * B]
+        return self.xchg.all_reduce_sum(part)[r * B:(r + 1) * B].clamp_(min=0)   # (see ops.full_rank: a count is never < 0)
 
     def flush(self):
         if self.last is not None and self.t > 0:
