@@ -344,11 +344,11 @@ def main():
     c = classes[dom] if dom is not None else {"ms": 0}
     if c["ms"] <= 0:
         roof = None   # --no-prof: kernels were not bracketed
-    elif dom in ("gemm_nt", "gemm_tn"):
+    elif dom in ("gemm_nt", "gemm_tn", "row_chain"):
         # the library counts 2*M*N*K with the PADDED row count M = B*L; with padding skipped (the default) only the rows
         # of real tokens are computed, so the algorithmic flops are scaled by the batches' real-token fraction
         achieved = c["work"] * valid_frac / (c["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": f"{dom}_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(achieved, 2),
+        roof = {"bound": "mfma", "kernel": f"{dom} kernels (v_mfma_f32_32x32x2_f32)", "achieved": round(achieved, 2),
                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "launches": c["launches"], "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2),
                 "real_token_fraction": round(valid_frac, 4)}

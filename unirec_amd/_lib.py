@@ -114,6 +114,7 @@ SIGNATURES = {
     "ur_pool_rows_fwd": (C.c_int, [P, I64, C.c_int32, P, P, P, C.c_float, C.c_int32, C.c_int32, P, P]),
     "ur_pool_rows_bwd": (C.c_int, [P, P, C.c_float, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "ur_sasrec_set_side_stream": (C.c_int, [C.c_int]),
+    "ur_sasrec_set_chain": (C.c_int, [C.c_int]),
     "ur_full_rank": (C.c_int, [P, P, I64, C.c_int32, C.c_int32, P, P, P, P, I64, P, P, C.c_float, P, P, P, P]),
     "ur_full_rank_shard": (C.c_int, [C.c_int32, P, P, I64, C.c_int32, C.c_int32, P, P, P, P, I64, P, I64, P, P, P]),
     "ur_full_topk_workspace_bytes": (I64, [C.c_int32, I64, C.c_int32]),

@@ -100,6 +100,48 @@ struct TransposeBatch {
 };
 int transpose_batch(TransposeBatch& tb, hipStream_t st);   // every queued transpose in one launch
 
+// ---- rowchain.hip: row-block chain kernels (a workgroup carries BM token rows through a sequence of GEMMs, tiles in LDS)
+bool chain_supported(int d, int inner);   // d in {32, 64, 128}, inner % d == 0, switched on (UR_SASREC_CHAIN=1 / ur_sasrec_set_chain)
+int chain_rows_per_block(int d);
+int chain_set_enabled(int on);            // on < 0: query only; returns the previous state
+struct ChainFwdArgs {
+  const float* ctx; int ldctx;          // attention output [M, d]
+  const float* res; int ldres;          // residual of the attention block = the layer input x
+  const float *wo, *bo, *g1, *b1ln;     // out-projection [d,d] + its LayerNorm
+  const float *w1, *b1, *w2, *b2;       // dense_1 [I,d], dense_2 [d,I]
+  const float *g2, *b2ln;
+  float *a, *ahat, *rstd1, *h1, *y, *yhat, *rstd2;
+  const float *wn, *bn; float* outn; int ldn, Nn;   // optional: next projection y Wn^T + bn, Wn [Nn, d], Nn % d == 0
+  int M; const int* m_dev;
+  int I, act; float eps;
+  DropSpec drop_out, drop_ffn;
+};
+struct ChainBwdArgs {
+  const float* gy;                      // d loss / d y  [M, d]
+  const float *yhat, *rstd2, *g2;       // feed-forward LayerNorm
+  const float* h1;                      // [M, I] pre-activation
+  const float* w2T;                     // [I, d]  (dense_2.weight transposed)
+  const float* w1T;                     // [d, I]  (dense_1.weight transposed)
+  const float *ahat, *rstd1, *g1;       // attention LayerNorm
+  const float* woT;                     // [d, d]
+  float *g_tf, *g_h1, *g_ta, *g_ctx;    // outputs (g_tf, g_h1, g_ta feed the weight-gradient GEMMs)
+  float* part;                          // [workgroups][4 d]: d gamma2 | d beta2 | d gamma1 | d beta1 partial sums
+  int M; const int* m_dev;
+  int I, act;
+};
+struct ChainProjBwdArgs {
+  const float* g; int ldg; int K;       // [M, K] gradient of the projection output; K % d == 0
+  const float* wT; int ldw;             // [d, ldw] transposed projection weight: out[m, n] = sum_k g[m, k] wT[n, k]
+  const float* res;                     // nullable addend [M, d]
+  const float *xhat, *rstd, *gamma;     // nullable: LayerNorm backward applied to the result (embedding LayerNorm)
+  float* out; const int* out_rows;      // row m of the result goes to row out_rows[m] (nullable: m) of out [., d]
+  float* part;                          // with LayerNorm: [workgroups][2 d] d gamma | d beta partial sums
+  int M; const int* m_dev;
+};
+int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st);
+int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st);     // workgroups = cdiv(M, chain_rows_per_block(d))
+int chain_proj_bwd(const ChainProjBwdArgs& a, int d, hipStream_t st);
+
 // ---- attention.hip
 long long attn_lse_floats(int B, int H, int L);
 // Compacted token rows (padding skipped): seq_base / seq_pad (nullable, int[B]): position l of sequence b lives in row

@@ -1,0 +1,604 @@
+// Row-block "chain" kernels of the SASRec layer: a workgroup owns BM token rows and carries them through a whole
+// SEQUENCE of dense contractions; the intermediate [BM, d] / [BM, d-chunk of inner] tiles never leave LDS.
+//
+//   chain_ffn_fwd  (unirec/model/modules.py:312-316 + 347-355, one launch instead of three GEMMs):
+//        a  = LN(drop(ctx Wo^T + bo) + x)                     -> a, ahat, rstd1
+//        h1 = a W1^T + b1                                     -> h1 (pre-activation, kept for the backward pass)
+//        y  = LN(drop(act(h1) W2^T + b2) + a)                 -> y, yhat, rstd2
+//        [next layer's projection  y Wn^T + bn                -> its qkv buffer]
+//   chain_ffn_bwd  (the mirror image: two LayerNorm backwards + three activation-gradient GEMMs in one launch):
+//        g_tf = LNbwd(g_y)   g_h1 = (g_tf W2) * act'(h1)   g_a = g_h1 W1 + g_tf   g_ta = LNbwd(g_a)   g_ctx = g_ta Wo
+//   chain_proj_bwd : g_x = g_qkv Wqkv + g_ta, followed (bottom layer) by the backward of the embedding LayerNorm, rows
+//        scattered straight into the padded [B*L, d] row-gradient buffer.
+//
+// Why: at M = 21 360 token rows the unfused layer is ~12 launches of 1-3 GFLOP each; every one pays a cold prologue, a
+// store burst that all of its workgroups issue together, and re-reads what the previous launch just wrote ([M, inner]
+// twice per direction).  Here the only HBM traffic is what the backward pass / the weight-gradient GEMMs need later.
+//
+// Geometry (D = d in {32, 64, 128}): BM = 4096 / D rows per workgroup, 4 waves, one 32 x 32 accumulator tile per wave and
+// GEMM (v_mfma_f32_32x32x2_f32: exact fp32), weights streamed through a double-buffered [D][32] LDS stage whose next slice
+// is in flight across GEMM boundaries (the stream of weight slices never drains inside a workgroup).  inner is walked in
+// D-wide chunks: h1 chunk -> LDS -> act -> second GEMM accumulates y over the chunks.  LDS: 70.7 KB at D = 128 (2 workgroups
+// per CU), 53 KB at D = 64.  The K order of every contraction equals gemm_nt's, so forward results are bit-identical to the
+// unfused path.
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ur {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float fx4 __attribute__((ext_vector_type(4)));   // plain LLVM vector: register arrays of it are always promoted (HIP's float4 class is not, in every context)
+
+constexpr int RC_BK = 32;          // K-slice of the streamed weight tile
+constexpr int RC_LS = RC_BK + 4;   // padded LDS row stride of the weight stage (conflict-free ds_read_b128)
+
+template <int D>
+struct RcGeom {
+  static constexpr int BM = 4096 / D;               // token rows per workgroup
+  static constexpr int WC = D / 32, WR = 4 / WC;    // wave grid: WR x WC accumulator tiles of 32 x 32 = BM x D
+  static constexpr int TS = D + 4;                  // LDS row stride of the activation tiles
+  static constexpr int TPR = D / 4;                 // lanes per row in the row-wise epilogues (one float4 each)
+  static constexpr int RPP = 256 / TPR;             // rows per epilogue pass; 4 passes cover the BM rows
+  static constexpr int WV = D / 32;                 // float4 loads per thread per weight slice
+  static constexpr int TILE = BM * TS;              // floats per activation tile
+  static constexpr int WST = D * RC_LS;             // floats per weight-stage buffer
+  static constexpr size_t LDS_BYTES = (size_t)(2 * TILE + 2 * WST) * sizeof(float);
+};
+
+// One thread's view of a weight segment (rows row0 .. row0+D-1, columns k0 .. of a row-major matrix with leading dimension
+// ldw): the address of ITS first float4 of the segment's first K-slice.  Thread tid stages row (tid >> 3) + 32 i, float4
+// column tid & 7 of every slice.  Everything is passed by value (a struct whose address is taken ends up in scratch memory).
+__device__ __forceinline__ const float* rc_wptr(const float* W, int ldw, int row0, int k0, int tid) {
+  return W + (long long)(row0 + (tid >> 3)) * ldw + k0 + (tid & 7) * 4;
+}
+template <int D>
+__device__ __forceinline__ void rc_wload(fx4 (&r)[RcGeom<D>::WV], const float* p, int ldw) {
+#pragma unroll
+  for (int i = 0; i < RcGeom<D>::WV; ++i) r[i] = *(const fx4*)(p + (long long)(32 * i) * ldw);
+}
+template <int D>
+__device__ __forceinline__ void rc_wstore(const fx4 (&r)[RcGeom<D>::WV], float* buf, int tid) {
+#pragma unroll
+  for (int i = 0; i < RcGeom<D>::WV; ++i) *(fx4*)(buf + ((tid >> 3) + 32 * i) * RC_LS + (tid & 7) * 4) = r[i];
+}
+
+// acc += As[BM, D] @ W[seg]^T, K = D in NK = D / 32 slices.  As: an LDS activation tile (row stride TS).
+// The weight-slice stream runs TWO slices ahead of the MFMAs (an L2 round trip is longer than one K-step of 16 MFMAs): on entry
+// slice 0 of the segment is in Wst[buf] and slice 1 is in flight into wreg[1] (for NK = 1: slice 0 of the NEXT segment);
+// step kt issues the loads of slice kt+2 into wreg[kt & 1], computes on Wst[buf], then stages slice kt+1 (issued one step
+// earlier) into the other buffer.  wp / wnp: rc_wptr of this / the next segment (wnp nullable: the stream then re-reads this
+// segment -- staged, never used).  The invariant holds again on exit, for the next segment.  Ends with a barrier: every wave is
+// done reading As and the stage.
+template <int D>
+__device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const float* wp, int ldw, const float* wnp, int ldwn,
+                                        float* Wst, int& buf, fx4 (&wreg)[2][RcGeom<D>::WV], int tid, int wr, int wc, int lane) {
+  using G = RcGeom<D>;
+  constexpr int NK = D / RC_BK;
+  const int frow = lane & 31, fk = 4 * (lane >> 5);
+  const float* Arow = As + (wr * 32 + frow) * G::TS + fk;
+  if (!wnp) { wnp = wp; ldwn = ldw; }
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    if constexpr (NK == 1) {
+      rc_wload<D>(wreg[0], wnp, ldwn);                            // one slice per segment: distance 1 (next segment's only slice)
+    } else {
+      if (kt + 2 < NK) rc_wload<D>(wreg[kt & 1], wp + (kt + 2) * RC_BK, ldw);
+      else rc_wload<D>(wreg[kt & 1], wnp + (kt + 2 - NK) * RC_BK, ldwn);
+    }
+    const float* Ab = Arow + kt * RC_BK;
+    const float* Wb = Wst + buf * G::WST + (wc * 32 + frow) * RC_LS + fk;
+#pragma unroll
+    for (int kk = 0; kk < RC_BK; kk += 8) {
+      const float4 af = *(const float4*)(Ab + kk);
+      const float4 bf = *(const float4*)(Wb + kk);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+    }
+    rc_wstore<D>(wreg[NK == 1 ? 0 : ((kt + 1) & 1)], Wst + (buf ^ 1) * G::WST, tid);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// start of the stream: slice 0 of the first segment -> Wst[0] (after the caller's barrier), slice 1 in flight
+template <int D>
+__device__ __forceinline__ void rc_prime_load(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw) {
+  rc_wload<D>(wreg[0], wp, ldw);
+}
+template <int D>
+__device__ __forceinline__ void rc_prime_store(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw, const float* wnp, int ldwn,
+                                               float* Wst, int tid) {
+  rc_wstore<D>(wreg[0], Wst, tid);
+  if constexpr (D / RC_BK > 1) rc_wload<D>(wreg[1], wp + RC_BK, ldw);
+  (void)wnp; (void)ldwn;
+}
+
+// accumulator tile -> LDS tile.  acc[r]: row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of the wave's 32 x 32 tile.
+template <int D>
+__device__ __forceinline__ void rc_acc_to_tile(const floatx16& acc, float* T, int wr, int wc, int lane) {
+  using G = RcGeom<D>;
+  const int nl = wc * 32 + (lane & 31), r4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) T[(wr * 32 + (r & 3) + 8 * (r >> 2) + r4) * G::TS + nl] = acc[r];
+}
+
+__device__ __forceinline__ floatx16 zero16() {
+  floatx16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+__device__ __forceinline__ float4 rc_act4(float4 v, int act) {
+  v.x = act_fwd(v.x, act); v.y = act_fwd(v.y, act); v.z = act_fwd(v.z, act); v.w = act_fwd(v.w, act);
+  return v;
+}
+
+// LayerNorm forward of one row held by TPR lanes (one float4 each): x -> (xhat, y); returns rstd.  Same arithmetic as the
+// EPI_BIAS_RES_LN epilogue of gemm_nt.
+template <int TPR>
+__device__ __forceinline__ float rc_ln_row(float4 x, float4 gm, float4 bt, float inv_n, float eps, float4& h, float4& o) {
+  const float mean = group_sum<TPR>((x.x + x.y) + (x.z + x.w)) * inv_n;
+  x.x -= mean; x.y -= mean; x.z -= mean; x.w -= mean;
+  const float q = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+  const float rstd = 1.0f / sqrtf(group_sum<TPR>(q) * inv_n + eps);
+  h.x = x.x * rstd; h.y = x.y * rstd; h.z = x.z * rstd; h.w = x.w * rstd;
+  o.x = h.x * gm.x + bt.x; o.y = h.y * gm.y + bt.y; o.z = h.z * gm.z + bt.z; o.w = h.w * gm.w + bt.w;
+  return rstd;
+}
+
+// LayerNorm backward of one row: y = d loss / d LN output, h = xhat, r = rstd -> d loss / d LN input; dg / db accumulate this
+// thread's share of d gamma / d beta.  Same arithmetic as ln_bwd_kernel.
+template <int TPR>
+__device__ __forceinline__ float4 rc_ln_bwd_row(float4 y, float4 h, float4 gm, float r, float inv_d, float4& dg, float4& db) {
+  dg.x += y.x * h.x; dg.y += y.y * h.y; dg.z += y.z * h.z; dg.w += y.w * h.w;
+  db.x += y.x; db.y += y.y; db.z += y.z; db.w += y.w;
+  float4 gy;
+  gy.x = y.x * gm.x; gy.y = y.y * gm.y; gy.z = y.z * gm.z; gy.w = y.w * gm.w;
+  const float s1 = (gy.x + gy.y) + (gy.z + gy.w);
+  const float s2 = (gy.x * h.x + gy.y * h.y) + (gy.z * h.z + gy.w * h.w);
+  const float m1 = group_sum<TPR>(s1) * inv_d;
+  const float m2 = group_sum<TPR>(s2) * inv_d;
+  float4 o;
+  o.x = r * (gy.x - m1 - h.x * m2);
+  o.y = r * (gy.y - m1 - h.y * m2);
+  o.z = r * (gy.z - m1 - h.z * m2);
+  o.w = r * (gy.w - m1 - h.w * m2);
+  return o;
+}
+
+// column sums of the per-thread (dg, db) over the workgroup's rows, in a fixed order -> part[0..D) = d gamma, part[D..2D) = d beta.
+// red: an LDS region of at least RPP * 2 * TS floats that nobody reads any more.  Ends with a barrier.
+template <int D>
+__device__ __forceinline__ void rc_block_colsum(float4 dg, float4 db, float* red, float* part, int eg, int et, int tid) {
+  using G = RcGeom<D>;
+  *(float4*)(red + (eg * 2 + 0) * G::TS + et * 4) = dg;
+  *(float4*)(red + (eg * 2 + 1) * G::TS + et * 4) = db;
+  __syncthreads();
+  for (int i = tid; i < 2 * D; i += 256) {
+    const int which = i / D, col = i % D;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int g = 0; g < G::RPP; ++g) acc += red[(g * 2 + which) * G::TS + col];
+    part[i] = acc;
+  }
+  __syncthreads();
+}
+
+// =============================================================================================== forward
+
+template <int D>
+__global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
+  using G = RcGeom<D>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* At = smem;                  // [BM][TS]: ctx, then a, then y
+  float* Ht = smem + G::TILE;        // [BM][TS]: accumulator staging / act(h1 chunk)
+  float* Wst = smem + 2 * G::TILE;   // [2][D][RC_LS]
+  int M = a.M;
+  if (a.m_dev) M = min(M, *a.m_dev);
+  const int m0 = blockIdx.x * G::BM;
+  if (m0 >= M) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / G::WC, wc = wave % G::WC;
+  const int et = tid % G::TPR, eg = tid / G::TPR;
+  const float inv_n = 1.0f / (float)D;
+  fx4 wreg[2][G::WV];
+  int buf = 0;
+  rc_prime_load<D>(wreg, rc_wptr(a.wo, D, 0, 0, tid), D);   // the first weight slice is in flight while the ctx tile is staged
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ml = eg + p * G::RPP, m = m0 + ml;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) v = *(const float4*)(a.ctx + (long long)m * a.ldctx + et * 4);
+    *(float4*)(At + ml * G::TS + et * 4) = v;
+  }
+  rc_prime_store<D>(wreg, rc_wptr(a.wo, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
+  __syncthreads();
+
+  // ---- 1. attention output projection + residual + LayerNorm
+  {
+    floatx16 acc = zero16();
+    rc_gemm<D>(acc, At, rc_wptr(a.wo, D, 0, 0, tid), D, rc_wptr(a.w1, D, 0, 0, tid), D, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
+  }
+  __syncthreads();
+  {
+    const float4 bs = *(const float4*)(a.bo + et * 4);
+    const float4 gm = *(const float4*)(a.g1 + et * 4), bt = *(const float4*)(a.b1ln + et * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        float4 x = *(const float4*)(Ht + ml * G::TS + et * 4);
+        const float4 rs = *(const float4*)(a.res + (long long)m * a.ldres + et * 4);
+        if (a.drop_out.thresh) {   // t = dropout(acc + bias) + res
+          x.x += bs.x; x.y += bs.y; x.z += bs.z; x.w += bs.w;
+          x = drop4(x, drop_rowkey(a.drop_out, m), (unsigned)(et * 4), a.drop_out);
+          x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w;
+        } else {
+          x.x += bs.x + rs.x; x.y += bs.y + rs.y; x.z += bs.z + rs.z; x.w += bs.w + rs.w;
+        }
+        float4 h;
+        const float rstd = rc_ln_row<G::TPR>(x, gm, bt, inv_n, a.eps, h, o);
+        *(float4*)(a.ahat + (long long)m * D + et * 4) = h;
+        *(float4*)(a.a + (long long)m * D + et * 4) = o;
+        if (et == 0) a.rstd1[m] = rstd;
+      }
+      *(float4*)(At + ml * G::TS + et * 4) = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. feed-forward: inner is walked in D-wide chunks; y accumulates over the chunks in registers
+  floatx16 accy = zero16();
+  const int nc = a.I / D;
+  for (int c = 0; c < nc; ++c) {
+    const float* w2p = rc_wptr(a.w2, a.I, 0, c * D, tid);
+    {
+      floatx16 acch = zero16();
+      rc_gemm<D>(acch, At, rc_wptr(a.w1, D, c * D, 0, tid), D, w2p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
+      rc_acc_to_tile<D>(acch, Ht, wr, wc, lane);
+    }
+    __syncthreads();
+    {
+      const float4 bs = *(const float4*)(a.b1 + c * D + et * 4);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int ml = eg + p * G::RPP, m = m0 + ml;
+        float4 v = *(const float4*)(Ht + ml * G::TS + et * 4);
+        v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+        if (m < M) *(float4*)(a.h1 + (long long)m * a.I + c * D + et * 4) = v;
+        *(float4*)(Ht + ml * G::TS + et * 4) = rc_act4(v, a.act);
+      }
+    }
+    __syncthreads();
+    const float* nxp = c + 1 < nc ? rc_wptr(a.w1, D, (c + 1) * D, 0, tid) : (a.wn ? rc_wptr(a.wn, D, 0, 0, tid) : nullptr);
+    rc_gemm<D>(accy, Ht, w2p, a.I, nxp, D, Wst, buf, wreg, tid, wr, wc, lane);
+  }
+
+  // ---- 3. y = LN(drop(acc + b2) + a)
+  rc_acc_to_tile<D>(accy, Ht, wr, wc, lane);
+  __syncthreads();
+  {
+    const float4 bs = *(const float4*)(a.b2 + et * 4);
+    const float4 gm = *(const float4*)(a.g2 + et * 4), bt = *(const float4*)(a.b2ln + et * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        float4 x = *(const float4*)(Ht + ml * G::TS + et * 4);
+        const float4 rs = *(const float4*)(At + ml * G::TS + et * 4);
+        if (a.drop_ffn.thresh) {
+          x.x += bs.x; x.y += bs.y; x.z += bs.z; x.w += bs.w;
+          x = drop4(x, drop_rowkey(a.drop_ffn, m), (unsigned)(et * 4), a.drop_ffn);
+          x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w;
+        } else {
+          x.x += bs.x + rs.x; x.y += bs.y + rs.y; x.z += bs.z + rs.z; x.w += bs.w + rs.w;
+        }
+        float4 h;
+        const float rstd = rc_ln_row<G::TPR>(x, gm, bt, inv_n, a.eps, h, o);
+        *(float4*)(a.yhat + (long long)m * D + et * 4) = h;
+        *(float4*)(a.y + (long long)m * D + et * 4) = o;
+        if (et == 0) a.rstd2[m] = rstd;
+      }
+      *(float4*)(At + ml * G::TS + et * 4) = o;
+    }
+  }
+  if (!a.wn) return;
+  __syncthreads();
+
+  // ---- 4. the next layer's input projection (its K / V -- or Q, K, V -- rows), straight from the y tile
+  const int nn = a.Nn / D;
+  for (int c = 0; c < nn; ++c) {
+    floatx16 acc = zero16();
+    rc_gemm<D>(acc, At, rc_wptr(a.wn, D, c * D, 0, tid), D, c + 1 < nn ? rc_wptr(a.wn, D, (c + 1) * D, 0, tid) : nullptr, D, Wst, buf,
+               wreg, tid, wr, wc, lane);
+    rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
+    __syncthreads();
+    const float4 bs = *(const float4*)(a.bn + c * D + et * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      if (m < M) {
+        float4 v = *(const float4*)(Ht + ml * G::TS + et * 4);
+        v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+        *(float4*)(a.outn + (long long)m * a.ldn + c * D + et * 4) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =============================================================================================== backward of the same block
+
+template <int D>
+__global__ __launch_bounds__(256) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
+  using G = RcGeom<D>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* At = smem;                  // [BM][TS]: g_tf, then g_ta
+  float* Ht = smem + G::TILE;        // [BM][TS]: accumulator staging / g_h1 chunk / reduction scratch
+  float* Wst = smem + 2 * G::TILE;
+  int M = a.M;
+  if (a.m_dev) M = min(M, *a.m_dev);
+  const int m0 = blockIdx.x * G::BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* part = a.part + (long long)blockIdx.x * 4 * D;
+  if (m0 >= M) {   // surplus workgroup (compacted rows): its partial sums are zeros
+    for (int i = tid; i < 4 * D; i += 256) part[i] = 0.f;
+    return;
+  }
+  const int wr = wave / G::WC, wc = wave % G::WC;
+  const int et = tid % G::TPR, eg = tid / G::TPR;
+  const float inv_d = 1.0f / (float)D;
+  fx4 wreg[2][G::WV];
+  int buf = 0;
+  rc_prime_load<D>(wreg, rc_wptr(a.w2T, D, 0, 0, tid), D);
+
+  // ---- 0. feed-forward LayerNorm backward: g_tf (also the residual branch of g_a)
+  {
+    const float4 gm = *(const float4*)(a.g2 + et * 4);
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        const float4 y = *(const float4*)(a.gy + (long long)m * D + et * 4);
+        const float4 h = *(const float4*)(a.yhat + (long long)m * D + et * 4);
+        o = rc_ln_bwd_row<G::TPR>(y, h, gm, a.rstd2[m], inv_d, dg, db);
+        *(float4*)(a.g_tf + (long long)m * D + et * 4) = o;
+      }
+      *(float4*)(At + ml * G::TS + et * 4) = o;
+    }
+    rc_block_colsum<D>(dg, db, Ht, part, eg, et, tid);
+  }
+  rc_prime_store<D>(wreg, rc_wptr(a.w2T, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
+  __syncthreads();
+
+  // ---- 1. g_h1 chunk = (g_tf W2[:, chunk]) * act'(h1 chunk);   g_a += g_h1 chunk W1[chunk, :]
+  floatx16 acca = zero16();
+  const int nc = a.I / D;
+  for (int c = 0; c < nc; ++c) {
+    const float* w1p = rc_wptr(a.w1T, a.I, 0, c * D, tid);
+    {
+      floatx16 accu = zero16();
+      rc_gemm<D>(accu, At, rc_wptr(a.w2T, D, c * D, 0, tid), D, w1p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
+      rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        v = *(const float4*)(Ht + ml * G::TS + et * 4);
+        const float4 h = *(const float4*)(a.h1 + (long long)m * a.I + c * D + et * 4);
+        v.x *= act_bwd(h.x, a.act); v.y *= act_bwd(h.y, a.act); v.z *= act_bwd(h.z, a.act); v.w *= act_bwd(h.w, a.act);
+        *(float4*)(a.g_h1 + (long long)m * a.I + c * D + et * 4) = v;
+      }
+      *(float4*)(Ht + ml * G::TS + et * 4) = v;
+    }
+    __syncthreads();
+    const float* nxp = c + 1 < nc ? rc_wptr(a.w2T, D, (c + 1) * D, 0, tid) : rc_wptr(a.woT, D, 0, 0, tid);
+    rc_gemm<D>(acca, Ht, w1p, a.I, nxp, D, Wst, buf, wreg, tid, wr, wc, lane);
+  }
+
+  // ---- 2. g_a = acc + g_tf;  attention LayerNorm backward -> g_ta
+  rc_acc_to_tile<D>(acca, Ht, wr, wc, lane);
+  __syncthreads();
+  {
+    const float4 gm = *(const float4*)(a.g1 + et * 4);
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        float4 y = *(const float4*)(Ht + ml * G::TS + et * 4);
+        const float4 rs = *(const float4*)(At + ml * G::TS + et * 4);
+        y.x += rs.x; y.y += rs.y; y.z += rs.z; y.w += rs.w;
+        const float4 h = *(const float4*)(a.ahat + (long long)m * D + et * 4);
+        o = rc_ln_bwd_row<G::TPR>(y, h, gm, a.rstd1[m], inv_d, dg, db);
+        *(float4*)(a.g_ta + (long long)m * D + et * 4) = o;
+      }
+      *(float4*)(At + ml * G::TS + et * 4) = o;
+    }
+    __syncthreads();   // every read of the staged accumulators is done: Ht becomes the reduction scratch
+    rc_block_colsum<D>(dg, db, Ht, part + 2 * D, eg, et, tid);
+  }
+
+  // ---- 3. g_ctx = g_ta Wo
+  {
+    floatx16 acc = zero16();
+    rc_gemm<D>(acc, At, rc_wptr(a.woT, D, 0, 0, tid), D, nullptr, 0, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ml = eg + p * G::RPP, m = m0 + ml;
+    if (m < M) *(float4*)(a.g_ctx + (long long)m * D + et * 4) = *(const float4*)(Ht + ml * G::TS + et * 4);
+  }
+}
+
+// =============================================================================================== g_x = g_qkv Wqkv (+ g_ta) (+ LN0 backward)
+
+template <int D>
+__global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a) {
+  using G = RcGeom<D>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* At = smem;
+  float* Ht = smem + G::TILE;
+  float* Wst = smem + 2 * G::TILE;
+  int M = a.M;
+  if (a.m_dev) M = min(M, *a.m_dev);
+  const int m0 = blockIdx.x * G::BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (m0 >= M) {
+    if (a.xhat)
+      for (int i = tid; i < 2 * D; i += 256) a.part[(long long)blockIdx.x * 2 * D + i] = 0.f;
+    return;
+  }
+  const int wr = wave / G::WC, wc = wave % G::WC;
+  const int et = tid % G::TPR, eg = tid / G::TPR;
+  fx4 wreg[2][G::WV];
+  int buf = 0;
+  const int nkc = a.K / D;
+  rc_prime_load<D>(wreg, rc_wptr(a.wT, a.ldw, 0, 0, tid), a.ldw);
+  float4 ra[4];
+  auto load_a = [&](int kc) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = m0 + eg + p * G::RPP;
+      ra[p] = m < M ? *(const float4*)(a.g + (long long)m * a.ldg + kc * D + et * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *(float4*)(At + (eg + p * G::RPP) * G::TS + et * 4) = ra[p];
+  };
+  load_a(0);
+  store_a();
+  rc_prime_store<D>(wreg, rc_wptr(a.wT, a.ldw, 0, 0, tid), a.ldw, nullptr, 0, Wst, tid);
+  __syncthreads();
+  floatx16 acc = zero16();
+  for (int kc = 0; kc < nkc; ++kc) {
+    const bool more = kc + 1 < nkc;
+    if (more) load_a(kc + 1);   // the next slice of g is in flight underneath this chunk's MFMAs
+    rc_gemm<D>(acc, At, rc_wptr(a.wT, a.ldw, 0, kc * D, tid), a.ldw, more ? rc_wptr(a.wT, a.ldw, 0, (kc + 1) * D, tid) : nullptr, a.ldw,
+               Wst, buf, wreg, tid, wr, wc, lane);
+    if (more) {
+      store_a();
+      __syncthreads();
+    }
+  }
+  rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
+  __syncthreads();
+  const float inv_d = 1.0f / (float)D;
+  float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.xhat) gm = *(const float4*)(a.gamma + et * 4);
+  float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ml = eg + p * G::RPP, m = m0 + ml;
+    if (m < M) {
+      float4 v = *(const float4*)(Ht + ml * G::TS + et * 4);
+      if (a.res) {
+        const float4 rs = *(const float4*)(a.res + (long long)m * D + et * 4);
+        v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+      }
+      if (a.xhat) {
+        const float4 h = *(const float4*)(a.xhat + (long long)m * D + et * 4);
+        v = rc_ln_bwd_row<G::TPR>(v, h, gm, a.rstd[m], inv_d, dg, db);
+      }
+      const long long orow = a.out_rows ? a.out_rows[m] : m;
+      *(float4*)(a.out + orow * D + et * 4) = v;
+    }
+  }
+  if (a.xhat) {
+    __syncthreads();
+    rc_block_colsum<D>(dg, db, Ht, a.part + (long long)blockIdx.x * 2 * D, eg, et, tid);
+  }
+}
+
+// =============================================================================================== launchers
+// Default OFF: measured on the C5 shapes (profiles/r02_a_chain_ab.txt) the chain kernels do not beat the launches they replace
+// (forward 126 us vs 120, backward 123 vs 121, projection 43 vs 46): one 32 x 32 accumulator per wave leaves 16 dependent MFMAs
+// between two barriers, and LDS-read latency + barrier skew cost as much as the MFMAs.  UR_SASREC_CHAIN=1 / ur_sasrec_set_chain(1)
+// switch them on (tests/test_rowchain_gpu.py keeps them covered).
+static int g_chain_on = -1;
+int chain_set_enabled(int on) {
+  if (g_chain_on < 0) g_chain_on = (getenv("UR_SASREC_CHAIN") && atoi(getenv("UR_SASREC_CHAIN"))) ? 1 : 0;
+  const int prev = g_chain_on;
+  if (on >= 0) g_chain_on = on ? 1 : 0;
+  return prev;
+}
+bool chain_supported(int d, int inner) {
+  if (!chain_set_enabled(-1)) return false;
+  return (d == 32 || d == 64 || d == 128) && inner % d == 0;
+}
+int chain_rows_per_block(int d) { return 4096 / d; }
+
+template <typename KernelT>
+static void set_lds(KernelT k, size_t bytes) {
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+#define UR_CHAIN_DISPATCH(D_, KERNEL, ARGS, GRID)                                                                   \
+  do {                                                                                                              \
+    static bool attr_##D_ = (set_lds(KERNEL<D_>, RcGeom<D_>::LDS_BYTES), true);                                     \
+    (void)attr_##D_;                                                                                                \
+    hipLaunchKernelGGL((KERNEL<D_>), dim3(GRID), dim3(256), RcGeom<D_>::LDS_BYTES, st, ARGS);                       \
+  } while (0)
+
+int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
+  if (a.M <= 0) return UR_OK;
+  if (!chain_supported(d, a.I) || (a.wn && a.Nn % d)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd: d=%d inner=%d", d, a.I);
+  ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * ((double)d + 2.0 * a.I + (a.wn ? a.Nn : 0)));
+  const int grid = cdiv(a.M, chain_rows_per_block(d));
+  switch (d) {
+    case 32: UR_CHAIN_DISPATCH(32, chain_ffn_fwd_kernel, a, grid); break;
+    case 64: UR_CHAIN_DISPATCH(64, chain_ffn_fwd_kernel, a, grid); break;
+    default: UR_CHAIN_DISPATCH(128, chain_ffn_fwd_kernel, a, grid); break;
+  }
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st) {
+  if (a.M <= 0) return UR_OK;
+  if (!chain_supported(d, a.I)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_bwd: d=%d inner=%d", d, a.I);
+  ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * ((double)d + 2.0 * a.I));
+  const int grid = cdiv(a.M, chain_rows_per_block(d));
+  switch (d) {
+    case 32: UR_CHAIN_DISPATCH(32, chain_ffn_bwd_kernel, a, grid); break;
+    case 64: UR_CHAIN_DISPATCH(64, chain_ffn_bwd_kernel, a, grid); break;
+    default: UR_CHAIN_DISPATCH(128, chain_ffn_bwd_kernel, a, grid); break;
+  }
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+int chain_proj_bwd(const ChainProjBwdArgs& a, int d, hipStream_t st) {
+  if (a.M <= 0) return UR_OK;
+  if (!(d == 32 || d == 64 || d == 128) || a.K % d) return fail(UR_ERR_UNSUPPORTED, "chain_proj_bwd: d=%d K=%d", d, a.K);
+  ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * (double)a.K);
+  const int grid = cdiv(a.M, chain_rows_per_block(d));
+  switch (d) {
+    case 32: UR_CHAIN_DISPATCH(32, chain_proj_bwd_kernel, a, grid); break;
+    case 64: UR_CHAIN_DISPATCH(64, chain_proj_bwd_kernel, a, grid); break;
+    default: UR_CHAIN_DISPATCH(128, chain_proj_bwd_kernel, a, grid); break;
+  }
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+}  // namespace ur
+
+extern "C" int ur_sasrec_set_chain(int on) { return ur::chain_set_enabled(on ? 1 : 0); }

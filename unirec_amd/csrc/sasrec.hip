@@ -64,6 +64,8 @@ struct Ws {
   float *x0, *x0hat, *rstd0;
   LayerWs layer[UR_MAX_LAYERS];
   float *g_y, *g_a, *g_ctx, *tn_ws, *ln_part, *attn_ws;
+  float* chain_part;                    // row-chain kernels: per-workgroup LayerNorm-affine partial sums (see chain_part_of)
+  long long chain_blocks;               // upper bound of their workgroup count: cdiv(B*L, 32)
   float *q_last, *dq_last, *lse_last;   // last-row specialisation of the final layer ([B,d] each)
   float *x_last, *t_last;               // compact mode: gathered last rows of the layer input / their gradient
   int *tok_full, *seq_base, *seq_pad, *last_row, *m_valid;   // compact mode: row maps (see compact_plan_kernel)
@@ -103,6 +105,8 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
   w.ln_floats = (2LL * c.n_layers + 1) * LN_BWD_MAX_BLOCKS * 2 * d;
   w.ln_part = take(w.ln_floats);
   w.attn_ws = take(attn_bwd_ws_floats(c.B, c.n_heads, c.L));
+  w.chain_blocks = (M + 31) / 32;
+  w.chain_part = take((4LL * c.n_layers + 2) * w.chain_blocks * d);
   w.q_last = take((long long)c.B * d); w.dq_last = take((long long)c.B * d);
   w.lse_last = take((long long)c.B * c.n_heads);
   w.x_last = take((long long)c.B * d); w.t_last = take((long long)c.B * d);
@@ -338,6 +342,8 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
                     tokmap, mv, &d_emb);
   if (rc) return rc;
   const float* x = w.x0;
+  const bool chain = chain_supported(d, I);   // out-projection + LN + feed-forward + LN (+ next projection) as ONE launch per layer
+  bool proj_done = false;                     // this layer's K,V (Q,K,V) rows were written by the previous layer's chain kernel
   for (int i = 0; i < c.n_layers; ++i) {
     const LayerP p = layer_ptrs(dense, lay, i);
     LayerWs& lw = w.layer[i];
@@ -356,7 +362,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       }
       g.A = x; g.lda = d; g.W = p.wqkv + (long long)d * d; g.ldw = d; g.C = lw.qkv + d; g.ldc = 3 * d; g.M = M; g.N = 2 * d; g.K = d;
       g.bias = p.bqkv + d; g.m_dev = mv;
-      if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
+      if (!proj_done && (rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
       g = GemmArgs{};
       g.A = x_last; g.lda = ld_last; g.W = p.wqkv; g.ldw = d; g.C = w.q_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bqkv;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
@@ -377,8 +383,29 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     }
     g.A = x; g.lda = d; g.W = p.wqkv; g.ldw = d; g.C = lw.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d; g.bias = p.bqkv;
     g.m_dev = mv;
-    if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
+    if (!proj_done && (rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
     if ((rc = attn_fwd(lw.qkv, item_seq, c.B, c.L, d, c.n_heads, c.use_pos, lw.ctx, lw.lse, 0, st, sbase, spad, &d_attn))) return rc;
+    proj_done = false;
+    if (chain) {
+      ChainFwdArgs ca{};
+      ca.ctx = lw.ctx; ca.ldctx = d; ca.res = x; ca.ldres = d;
+      ca.wo = p.wo; ca.bo = p.bo; ca.g1 = p.g1; ca.b1ln = p.b1ln; ca.w1 = p.w1; ca.b1 = p.b1; ca.w2 = p.w2; ca.b2 = p.b2;
+      ca.g2 = p.g2; ca.b2ln = p.b2ln;
+      ca.a = lw.a; ca.ahat = lw.ahat; ca.rstd1 = lw.rstd1; ca.h1 = lw.h1; ca.y = lw.y; ca.yhat = lw.yhat; ca.rstd2 = lw.rstd2;
+      ca.M = M; ca.m_dev = mv; ca.I = I; ca.act = c.act; ca.eps = c.eps;
+      ca.drop_out = site_spec(c, i, DROP_SITE_OUT, tokmap);
+      ca.drop_ffn = site_spec(c, i, DROP_SITE_FFN, tokmap);
+      if (i + 1 < c.n_layers) {   // the next layer's input projection rides along: K,V only when that layer is the last-row one
+        const LayerP pn = layer_ptrs(dense, lay, i + 1);
+        const int skip_q = (c.last_only && i + 1 == c.n_layers - 1) ? 1 : 0;
+        ca.wn = pn.wqkv + (long long)skip_q * d * d; ca.bn = pn.bqkv + skip_q * d;
+        ca.outn = w.layer[i + 1].qkv + skip_q * d; ca.ldn = 3 * d; ca.Nn = (3 - skip_q) * d;
+        proj_done = true;
+      }
+      if ((rc = chain_ffn_fwd(ca, d, st))) return rc;
+      x = lw.y;
+      continue;
+    }
     g = GemmArgs{};
     g.A = lw.ctx; g.lda = d; g.W = p.wo; g.ldw = d; g.C = lw.a; g.ldc = d; g.M = M; g.N = d; g.K = d; g.bias = p.bo;
     g.aux = x; g.ldaux = d; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1; g.m_dev = mv;
@@ -419,6 +446,10 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   const int* mv = compact ? w.m_valid : nullptr;
   const int* sbase = compact ? w.seq_base : nullptr;
   const int* spad = compact ? w.seq_pad : nullptr;
+  // row-chain kernels (rowchain.hip) for the full-sequence layers; hidden dropout keeps the unfused path (the chain backward
+  // does not carry the second, dropout-masked copy of the LayerNorm-backward outputs)
+  const bool chain_bwd = chain_supported(d, I) && c.p_hidden == 0.f;
+  bool ln0_done = false;                // the embedding LayerNorm backward ran inside the bottom layer's chain_proj_bwd
   ReduceBatch rb;                       // second stages of all split reductions: one launch at the end
   float* tn_cur = w.tn_ws;
   float* ln_cur = w.ln_part;
@@ -550,6 +581,46 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
       continue;
     }
+    if (chain_bwd) {
+      // ---- the whole block behind the attention as ONE launch: LN backward -> d act GEMM -> d FFN-1 GEMM + residual -> LN backward ->
+      // out-projection GEMM; g_tf, g_h1, g_ta are written for the weight-gradient GEMMs, everything else stays in LDS
+      float* part = w.chain_part + (long long)i * 4 * w.chain_blocks * d;
+      const int nblk = cdiv(M, chain_rows_per_block(d));
+      ChainBwdArgs cb{};
+      cb.gy = w.g_y; cb.yhat = lw.yhat; cb.rstd2 = lw.rstd2; cb.g2 = p.g2; cb.h1 = lw.h1; cb.w2T = lw.w2T; cb.w1T = lw.w1T;
+      cb.ahat = lw.ahat; cb.rstd1 = lw.rstd1; cb.g1 = p.g1; cb.woT = lw.woT;
+      cb.g_tf = lw.g_tf; cb.g_h1 = lw.g_h1; cb.g_ta = lw.g_ta; cb.g_ctx = w.g_ctx; cb.part = part;
+      cb.M = M; cb.m_dev = mv; cb.I = I; cb.act = c.act;
+      if ((rc = chain_ffn_bwd(cb, d, st))) return rc;
+      if (rb.full(4) && (rc = reduce_batch(rb, st))) return rc;
+      rb.add(part, 4 * d, nblk, d, d, G + o[14], d);
+      rb.add(part + d, 4 * d, nblk, d, d, G + o[15], d);
+      rb.add(part + 2 * d, 4 * d, nblk, d, d, G + o[8], d);
+      rb.add(part + 3 * d, 4 * d, nblk, d, d, G + o[9], d);
+      if ((rc = tn(lw.g_tf, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
+      if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
+      if ((rc = tn(lw.g_ta, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
+      if ((rc = fork())) return rc;
+      if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad, &d_attn))) return rc;
+      if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
+      if ((rc = fork())) return rc;
+      // g_x = g_qkv Wqkv + g_ta; for the bottom layer the backward of the embedding LayerNorm rides in the epilogue and the rows
+      // go straight to their (padded-layout) places in d_emb_rows
+      ChainProjBwdArgs cp{};
+      cp.g = lw.g_qkv; cp.ldg = 3 * d; cp.K = 3 * d; cp.wT = lw.wqkvT; cp.ldw = 3 * d; cp.res = lw.g_ta;
+      cp.out = w.g_y; cp.M = M; cp.m_dev = mv;
+      if (i == 0) {
+        float* part0 = w.chain_part + 4LL * c.n_layers * w.chain_blocks * d;
+        cp.xhat = w.x0hat; cp.rstd = w.rstd0; cp.gamma = dense + lay.off[1]; cp.out = d_emb_rows; cp.out_rows = compact ? w.tok_full : nullptr;
+        cp.part = part0;
+        if (rb.full(2) && (rc = reduce_batch(rb, st))) return rc;
+        rb.add(part0, 2 * d, nblk, d, d, dense_grad + lay.off[1], d);
+        rb.add(part0 + d, 2 * d, nblk, d, d, dense_grad + lay.off[2], d);
+        ln0_done = true;
+      }
+      if ((rc = chain_proj_bwd(cp, d, st))) return rc;
+      continue;
+    }
     // ---- feed-forward block
     if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb, mv,
                      nullptr, nullptr, &d_ffn, lw.g_tfd)))
@@ -586,7 +657,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   // ---- input block: LN0 backward -> row gradients of E[item_seq] and of the position table  (x0 = dropout(LN0(.)): g_y is
   // masked on read)
   DropSpec d_emb = site_spec(c, 0, DROP_SITE_EMBED, compact ? w.tok_full : nullptr);
-  if ((rc = ln_bwd(w.g_y, w.x0hat, w.rstd0, dense + lay.off[1], nullptr, nullptr, M, d, d_emb_rows, dense_grad + lay.off[1],
+  if (!ln0_done && (rc = ln_bwd(w.g_y, w.x0hat, w.rstd0, dense + lay.off[1], nullptr, nullptr, M, d, d_emb_rows, dense_grad + lay.off[1],
                    dense_grad + lay.off[2], ln_take(), st, &rb, mv, compact ? w.tok_full : nullptr, &d_emb)))
     return rc;
   // position-table gradient dP[l,:] = sum_b dx[b,l,:] (no padding index: sasrec.py:25): a split reduction over b with
