@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true", help="sort each batch's ids inside its own step (no side-stream lookahead)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--cpu-baseline-items", type=int, default=1_000_000)
+    ap.add_argument("--no-selfcheck", action="store_true", help="world > 1: skip the W-rank == 1-rank check that runs before the timed region")
+    ap.add_argument("--selfcheck-items", type=int, default=1_000_000)
     ap.add_argument("--dropout", type=float, default=0.0, help="hidden_dropout_prob = attn_dropout_prob (the reference's SASRec.yaml "
                     "default is 0.5; its example / benchmark scripts and the headline line use 0)")
     return ap.parse_args()
@@ -162,6 +164,66 @@ def cpu_baseline(a):
                       f"{cores} torch threads (fastest of the counts tried, {avail} cores available); torch {torch.__version__} CPU"}
 
 
+def multi_gpu_selfcheck(a, device, rank, world):
+    """world > 1, before anything is timed: 3 training steps of the SAME Trainer-level optimizer the benchmark uses
+    (facility/distributed.py: row-sharded table, 3 all-to-alls, one flat all-reduce -- over whatever backend the process group
+    runs, RCCL on the GPUs) must reproduce 1 rank stepping the concatenated batch: per-step loss (mean of the rank losses) and
+    every parameter.  A smaller catalogue (--selfcheck-items) keeps the 1-rank reference affordable; the code path is the same.
+    Raises on mismatch; returns a short report for the JSON line."""
+    import numpy as np
+    import torch.distributed as dist
+    from unirec_amd.facility.distributed import ShardedSparseDenseAdam
+    from unirec_amd.facility.optimizer import SparseDenseAdam
+    from unirec_amd.model.sequential.sasrec import SASRec
+    N = min(a.n_items, a.selfcheck_items)
+    cfg = model_config(a, str(device))
+    cfg["n_items"] = N
+    B, Wd = a.batch, world
+    torch.manual_seed(4242)
+    model = SASRec(cfg)
+    P0 = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    opt = ShardedSparseDenseAdam(model, rank, world, lr=1e-3, table_mode=a.table_mode)
+    model.train()
+    full = synth_batches(argparse.Namespace(**{**vars(a), "batch": B * Wd}), N, device, 99, n_batches=3)    # same seed: same batches on every rank
+    losses = []
+    for i, b in enumerate(full):
+        mine = {k: v[rank * B:(rank + 1) * B].contiguous() for k, v in b.items()}
+        nxt = {k: v[rank * B:(rank + 1) * B].contiguous() for k, v in full[i + 1].items()} if i + 1 < len(full) else None
+        losses.append(float(opt.train_step(mine, nxt)))
+    all_losses = [None] * world
+    dist.all_gather_object(all_losses, losses)
+    sd = opt.gather_state_dict()
+    report = None
+    if rank == 0:
+        m1 = SASRec(cfg)
+        m1.load_state_dict(P0)
+        m1.check_views()
+        o1 = SparseDenseAdam(m1, lr=1e-3, table_mode=a.table_mode)
+        m1.train()
+        ref = []
+        for b in full:
+            o1.zero_grad()
+            o1.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
+            ref.append(float(m1.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])))
+            o1.step()
+        o1.flush()
+        np.testing.assert_allclose(np.mean(all_losses, axis=0), ref, rtol=2e-5, err_msg="multi-GPU self-check: losses")
+        worst = 0.0
+        for k, v in m1.state_dict().items():
+            if k.endswith("key.bias"):
+                continue
+            got, want = sd[k].numpy(), v.detach().cpu().numpy()
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5, err_msg=f"multi-GPU self-check: {k}")
+            worst = max(worst, float(np.abs(got - want).max()))
+        report = {"ok": True, "steps": 3, "n_items": N, "ranks": world, "backend": dist.get_backend(),
+                  "max_abs_param_diff_vs_1_rank": worst, "losses": [round(float(x), 6) for x in np.mean(all_losses, axis=0)]}
+        del m1, o1
+    del model, opt, sd
+    torch.cuda.empty_cache()
+    dist.barrier()
+    return report
+
+
 def gather_microbench(table, device):
     """North-star gather target: 100M x 128 fp32 table, uniform random ids; HBM-read GB/s = n*(d*4+8)/t."""
     from unirec_amd import ops
@@ -234,9 +296,22 @@ def main():
 
     torch.manual_seed(2022 + rank)
     cfg = model_config(a, str(device))
+    selfcheck = None
     if world > 1:
-        from unirec_amd.sharded import build_sharded_trainer
-        step_fn, model, info = build_sharded_trainer(a, cfg, device, rank, world)
+        # the SAME optimizer Trainer(config, model) builds under torch.distributed (facility/trainer.py -> facility/distributed.py)
+        from unirec_amd.facility.distributed import ShardedSparseDenseAdam
+        from unirec_amd.sharded import shard_rows
+        if not a.no_selfcheck:
+            selfcheck = multi_gpu_selfcheck(a, device, rank, world)
+        torch.manual_seed(2022 + rank)
+        model = SASRec(dict(cfg, n_items=shard_rows(a.n_items, world)))     # the model's table IS this rank's shard: the 100 M-row
+        opt = ShardedSparseDenseAdam(model, rank, world, lr=1e-3, table_mode=a.table_mode,   # table never exists in one piece
+                                     full_rows={"item_embedding": a.n_items})
+        model.train()
+        info = {"parallelism": f"dp{world} + embedding rows sharded {world}-way (3 all-to-alls + 1 flat all-reduce per step)"}
+
+        def step_fn(batch, nxt=None):
+            return opt.train_step(batch, None if a.no_prefetch else nxt)
     else:
         model = SASRec(cfg)
         opt = SparseDenseAdam(model, lr=1e-3, table_mode=a.table_mode)
@@ -329,6 +404,15 @@ def main():
         _lib.lib.ur_sasrec_set_side_stream(prev)
         iso = prof_read()[dom]
     _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
+    collectives = None
+    if world > 1:   # per-collective device time and bytes to the peers, 10 extra steps after the timed region (all ranks take part)
+        opt.xchg.profile_start()
+        for i in range(10):
+            step_fn(batches[(a.warmup + i) % len(batches)], None)
+        barrier()
+        prof = opt.xchg.profile_stop()
+        collectives = {k: {"ms_per_step": round(v["ms"] / 10, 4), "MB_to_peers_per_step": round(v["MB_to_peers"] / 10, 3),
+                           "calls_per_step": v["calls"] / 10} for k, v in prof.items()}
     if rank != 0:
         return
 
@@ -386,6 +470,12 @@ def main():
         "roofline": roof,
         "kernel_time_ms_per_step_warmup": {k: round(v["ms"] / max(1, n_prof), 4) for k, v in warm.items() if v["launches"]},
     }
+    if world > 1:
+        import torch.distributed as dist
+        out["n_ranks"] = dist.get_world_size()
+        out["backend"] = dist.get_backend()
+        out["selfcheck"] = selfcheck if selfcheck is not None else "skipped (--no-selfcheck)"
+        out["collectives"] = collectives
     if world == 1 and not a.no_gather_bench:
         out["gather_roofline"] = gather_microbench(model.item_embedding.weight.data, device)
     if world == 1 and not a.no_cpu_baseline:

@@ -1,0 +1,185 @@
+"""a14: `Trainer(config, model)` under torch.distributed trains ONE model.
+
+W ranks x batch B must equal 1 rank x the concatenated batch of W*B rows (DDP's mean of equal-sized rank means == the mean over
+the concatenated batch): per-step losses, and every parameter after several steps with gradient clipping on -- for SASRec, GRU
+(BASELINE config C4's encoder) and MF (user + item table) -- plus the checkpoint round trip across world sizes: a checkpoint
+written by 1 rank loads into W ranks (`scatter_state_dict`), one written by W ranks (`gather_state_dict`, shards streamed to
+rank 0) loads into 1, and evaluation over the sharded tables (sampled and full-item protocol) gives the single-GPU metrics.
+The ranks share cuda:0 and talk over gloo (rows staged through the host): the routing, not RCCL, is under test here; the
+RCCL path has its own self-check (bench.py --gpus N).  BatchLoader's rank sharding is checked on the CPU."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_batch_loader_gives_every_rank_the_same_number_of_batches():
+    from unirec_amd.facility.trainer import BatchLoader
+
+    class DS:
+        def __len__(self):
+            return 23
+
+        def get_batch(self, idx):
+            return {"i": np.asarray(idx, dtype=np.int64)}
+
+    for W in (1, 2, 3, 4):
+        seen = []
+        for r in range(W):
+            ld = BatchLoader(DS(), 4, rank=r, world=W, device="cpu")
+            got = [b["i"].numpy() for b in ld]
+            assert len(got) == len(ld) == -(-6 // W)
+            seen.append(got)
+        order = [seen[r][k] for k in range(len(seen[0])) for r in range(W)]
+        flat = np.concatenate(order)
+        assert np.array_equal(flat[:23], np.arange(23))          # dataset order = (step, rank) order, nothing missing
+        assert set(flat[23:].tolist()) <= set(range(23))         # the wrap-around repeats the first batches
+
+
+N_ITEMS, N_USERS, L, G = 2003, 41, 12, 5
+
+
+def _cfg(kind, **kw):
+    from unirec_amd.utils.argument_parser import parse_arguments
+    base = dict(hidden_dropout_prob=0.0, attn_dropout_prob=0.0, dropout_prob=0.0, model=kind, n_users=N_USERS, n_items=N_ITEMS, device="cuda:0",
+                loss_type="softmax", embedding_size=32, hidden_size=32, inner_size=64, n_heads=4, n_layers=2, max_seq_len=L, epochs=1,
+                batch_size=16, seed=11, n_sample_neg_train=G - 1, grad_clip_value=0.05, learning_rate=2e-3, early_stop=0)
+    if kind == "MF":
+        base.update(has_user_emb=True, has_user_bias=True, has_item_bias=True, loss_type="bpr")
+    base.update(kw)
+    return parse_arguments(base)
+
+
+def _batches(n_steps, B, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for s in range(n_steps):
+        seq = torch.randint(1, N_ITEMS, (B, L), generator=g, dtype=torch.int32)
+        seq[::3, : 2 + s] = 0
+        seq[1] = 0                                   # an all-padding history
+        lab = torch.zeros(B, G, dtype=torch.int32)
+        lab[:, 0] = 1
+        ids = torch.randint(1, N_ITEMS, (B, G), generator=g)
+        ids[0, 1] = ids[0, 0]                        # duplicates inside a row and across ranks
+        ids[B - 1, 0] = ids[0, 0]
+        out.append(dict(item_seq=seq, item_id=ids, label=lab, user_id=torch.randint(1, N_USERS, (B,), generator=g)))
+    return out
+
+
+def _to(b, dev, lo=None, hi=None):
+    return {k: v[lo:hi].to(dev).contiguous() for k, v in b.items()}
+
+
+def _worker(rank, world, port, q, kind, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from unirec_amd.facility.trainer import Trainer
+        from unirec_amd.utils.general import get_class_instance, init_seed
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        cfg = _cfg(kind, output_path=tmp)
+        B = 16
+        full = _batches(4, B * world)
+        ev = _batches(2, B * world, seed=9)
+        single = types.SimpleNamespace(process_index=0, num_processes=1)      # forces the 1-GPU path although a group exists
+        ref = {}
+        if rank == 0:      # ---- the reference run: ONE rank on the concatenated batches
+            init_seed(cfg["seed"])
+            m1 = get_class_instance(kind, "unirec_amd/model")(cfg)
+            t1 = Trainer(cfg, m1, single)
+            assert t1.world == 1
+            t1.fit([_to(b, dev) for b in full[:2]], save_model=False)
+            t1.save_model(os.path.join(tmp, "w1.pth"))
+            ref["eval_k"] = t1.evaluate([_to(b, dev) for b in ev], load_best_model=False)
+            if kind != "MF":
+                t1.reset_evaluator("user-item", "one_vs_all")
+                ref["eval_all"] = t1.evaluate([_to(b, dev) for b in ev], load_best_model=False)
+                t1.reset_evaluator("user-item", None)
+            t1.fit([_to(b, dev) for b in full[2:]], save_model=False)
+            t1.optimizer.flush()
+            ref["losses"] = list(t1.step_losses)
+            ref["state"] = {k: v.detach().cpu().clone() for k, v in m1.state_dict().items()}
+        dist.barrier()
+        # ---- W ranks, each on its slice
+        init_seed(cfg["seed"])
+        m = get_class_instance(kind, "unirec_amd/model")(cfg)
+        tr = Trainer(cfg, m)
+        assert tr.world == world and type(tr.optimizer).__name__ == "ShardedSparseDenseAdam"
+        assert m.item_embedding.weight.shape[0] < N_ITEMS                       # the model holds a shard, not the table
+        mine = lambda bs: [_to(b, dev, rank * B, (rank + 1) * B) for b in bs]   # noqa: E731
+        tr.fit(mine(full[:2]), save_model=False)
+        tr.save_model(os.path.join(tmp, "ww.pth"))                              # collective: shards streamed to rank 0
+        got_k = tr.evaluate(mine(ev), load_best_model=False)
+        got_all = None
+        if kind != "MF":
+            tr.reset_evaluator("user-item", "one_vs_all")
+            got_all = tr.evaluate(mine(ev), load_best_model=False)
+            tr.reset_evaluator("user-item", None)
+        tr.load_model(os.path.join(tmp, "w1.pth"))                              # a 1-rank checkpoint dealt out to W ranks
+        tr.fit(mine(full[2:]), save_model=False)
+        losses = [None] * world
+        dist.all_gather_object(losses, list(tr.step_losses))
+        sd = tr.optimizer.gather_state_dict()
+        if rank == 0:
+            np.testing.assert_allclose(np.mean(losses, axis=0), ref["losses"], rtol=2e-5)
+            for k, v in ref["state"].items():
+                if k.endswith("key.bias"):
+                    continue
+                np.testing.assert_allclose(sd[k].numpy(), v.numpy(), rtol=1e-4, atol=2e-5, err_msg=k)   # atol = 1% of an lr-sized step
+            # the checkpoint written by W ranks holds FULL tables under the reference's names, equal to the 1-rank one
+            c1 = torch.load(os.path.join(tmp, "w1.pth"), map_location="cpu", weights_only=False)["state_dict"]
+            cw = torch.load(os.path.join(tmp, "ww.pth"), map_location="cpu", weights_only=False)["state_dict"]
+            assert set(c1) == set(cw)
+            for k in c1:
+                assert tuple(c1[k].shape) == tuple(cw[k].shape), k
+                if not k.endswith("key.bias"):
+                    np.testing.assert_allclose(cw[k].numpy(), c1[k].numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+            # ... and loads into ONE rank
+            init_seed(cfg["seed"] + 1)
+            m2 = get_class_instance(kind, "unirec_amd/model")(cfg)
+            t2 = Trainer(cfg, m2, single)
+            t2.load_model(os.path.join(tmp, "ww.pth"))
+            for k, v in m2.state_dict().items():
+                assert torch.equal(v.detach().cpu(), cw[k]), k
+            # evaluation over the sharded tables == over the full ones
+            for key in ("hit@1", "hit@5", "ndcg@10", "mrr", "group_auc"):
+                assert abs(got_k[key] - ref["eval_k"][key]) < 2e-3, (key, got_k[key], ref["eval_k"][key])
+                if got_all is not None:
+                    assert abs(got_all[key] - ref["eval_all"][key]) < 2e-3, (key, got_all[key], ref["eval_all"][key])
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world", [("SASRec", 2), ("GRU", 2), ("MF", 2), ("SASRec", 3)])
+def test_trainer_fit_on_w_ranks_equals_one_rank_on_the_concatenated_batches(kind, world, tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res

@@ -93,7 +93,9 @@ def test_chain_forward_with_hidden_dropout_is_bit_identical(d, inner):
 
 
 def test_unsupported_widths_take_the_unfused_path():
-    kw = dict(d=48, L=10, inner=96, heads=4, layers=2)
+    kw = dict(d=96, L=10, inner=96, heads=12, layers=2)
     ue1, dg1, dr1 = _run(kw, 9, 2, chain=True)
     ue0, dg0, dr0 = _run(kw, 9, 2, chain=False)
-    assert torch.equal(ue1, ue0) and torch.equal(dg1, dg0) and torch.equal(dr1, dr0)
+    assert torch.equal(ue1, ue0), float((ue1 - ue0).abs().max())
+    assert torch.equal(dr1, dr0), float((dr1 - dr0).abs().max())
+    assert torch.equal(dg1, dg0), (float((dg1 - dg0).abs().max()), torch.nonzero(dg1 != dg0).flatten()[:8].tolist())

@@ -234,3 +234,44 @@ def test_deferred_dense_join_gives_the_same_steps_as_the_eager_join():
     model = get_class_instance("SASRec", "unirec_amd/model")(cfg)
     SparseDenseAdam(model, lr=1e-2, table_mode="rowwise", grad_clip=1.0)
     assert model.defer_dense_join is False
+
+
+def test_fit_reproduces_the_references_own_trainer_run():
+    """per-step losses and final parameters of the reference's own Trainer.fit (unirec/facility/trainer.py:
+    234-357; 2 epochs over tests/golden/g12_dataset, Adam, grad_clip_value 0.5, negatives drawn by the reference's sampler stream),
+    captured by tools/capture_goldens.py.  Here: the same files -> SeqRecDataset -> BatchLoader -> Trainer.fit on the GPU, from the
+    reference's initial state_dict."""
+    import os
+    from conftest import GOLDEN, load_golden
+    from unirec_amd.data.dataset.seqrecdataset import SeqRecDataset
+    from unirec_amd.data.transform.addnegsamples import AddNegSamples
+    from unirec_amd.data.transform.adduserhistory import AddUserHistory
+    from unirec_amd.facility.trainer import BatchLoader, Trainer
+    from unirec_amd.utils.argument_parser import parse_arguments
+    from unirec_amd.utils.file_io import load_data_info
+    from unirec_amd.utils.general import get_class_instance, load_user_history
+    gcfg, groups = load_golden("g10_trainer_fit")
+    ddir = os.path.join(GOLDEN, "g12_dataset")
+    info = load_data_info(ddir)
+    u2h, _ = load_user_history(ddir, "user_history", n_users=info["n_users"], format=info["user_history_file_format"])
+    keys = ("n_heads", "n_layers", "inner_size", "embedding_size", "hidden_size", "max_seq_len", "hidden_act", "loss_type", "layer_norm_eps",
+            "use_position_emb", "init_std", "tau", "learning_rate", "grad_clip_value", "epochs", "batch_size", "weight_decay", "optimizer")
+    cfg = parse_arguments(dict({k: (gcfg[k].item() if hasattr(gcfg[k], "item") else gcfg[k]) for k in keys}, model="SASRec",
+                               n_users=info["n_users"], n_items=info["n_items"], device="cuda:0", hidden_dropout_prob=0.0, attn_dropout_prob=0.0,
+                               n_sample_neg_train=4, history_mask_mode="autoregressive", seed=21, early_stop=0))
+    model = get_class_instance("SASRec", "unirec_amd/model")(cfg)
+    missing = model.load_state_dict({k: torch.from_numpy(v) for k, v in groups["sd0"].items()}, strict=False)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.check_views()
+    ds = SeqRecDataset(cfg, path=ddir, filename="train", transform=AddNegSamples(info["n_users"], info["n_items"], 4, user2history=u2h, seed=21))
+    ds.add_user_history_transform(AddUserHistory(u2h, "autoregressive", seq_last=0))
+    tr = Trainer(cfg, model)
+    tr.fit(BatchLoader(ds, int(cfg["batch_size"]), device="cuda:0"), save_model=False)
+    want = groups["step_losses"][""] if "" in groups.get("step_losses", {}) else np.load(os.path.join(GOLDEN, "g10_trainer_fit.npz"))["step_losses"]
+    assert len(tr.step_losses) == len(want) == 10
+    np.testing.assert_allclose(tr.step_losses, want, rtol=1e-4)
+    tr.optimizer.flush()
+    for k, v in model.state_dict().items():
+        if k.endswith("key.bias"):
+            continue
+        np.testing.assert_allclose(v.cpu().numpy(), groups["sd1"][k], rtol=1e-3, atol=2e-5, err_msg=k)   # atol = 1 % of an lr-sized Adam step

@@ -545,3 +545,77 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def capture_g3_g10():
+    """G3: the first batches the reference's own DataLoader builds (unirec/main/main.py:121-204 get_data_loader ->
+    SeqRecDataset.__getitem__, seqrecdataset.py:38-57: AddNegSamples, AddUserHistory, _padding, default collate) from the committed
+    g12_dataset directory.  G10: per-step losses and final parameters of the reference's own Trainer.fit
+    (unirec/facility/trainer.py:234-357) over those batches, 2 epochs, Adam, gradient clipping on.  The per-step loss is read
+    through Trainer._check_nan (called with every step's loss, trainer.py:343); nothing of the reference is modified."""
+    sys.path.insert(0, REF)
+    _shims()
+    import json
+    import logging
+    import accelerate
+    from unirec.data.dataset.seqrecdataset import SeqRecDataset
+    from unirec.data.transform.adduserhistory import AddUserHistory
+    from unirec.facility.trainer import Trainer
+    from unirec.main import main as refmain
+    from unirec.model.sequential.sasrec import SASRec
+    from unirec.utils.general import load_user_history
+    ddir = os.path.join(OUT, "g12_dataset")
+    info = json.load(open(os.path.join(ddir, "data.info")))
+    u2h, _ = load_user_history(ddir, "user_history", n_users=info["n_users"], format="user-item")
+    cfg = base_cfg(model="SASRec", n_users=info["n_users"], n_items=info["n_items"], n_heads=4, loss_type="softmax", max_seq_len=8,
+                   dataset_path=ddir, train_file_format="user-item", num_workers=0, n_sample_neg_train=4, batch_size=64,
+                   history_mask_mode="autoregressive", seq_last=0, shuffle_train=0, pin_memory=False, persistent_workers=False,
+                   dataloader="SeqRecDataset", use_features=0, time_seq=0, output_path="/tmp/g10_out", checkpoint_dir="ck",
+                   optimizer="adam", scheduler="off", scheduler_factor=0.1, learning_rate=2e-3, weight_decay=0, grad_clip_value=0.5,
+                   use_tensorboard=0, use_wandb=0, freeze=0, epochs=2, early_stop=0, metrics="['hit@5']", key_metric="hit@5",
+                   verbose=0, seed=21, task="train")
+    logging.getLogger(cfg["exp_name"]).setLevel(logging.ERROR)
+
+    def loader():
+        return refmain.get_data_loader(cfg, "train", AddUserHistory, SeqRecDataset, ddir, "train", user2history=u2h)
+
+    # ---- G3: the batches, as the loop body sees them (trainer.py:328)
+    random.seed(21)
+    ld = loader()
+    keys = ld.dataset.return_key_2_index
+    g3 = {"n_batches": np.array(len(ld)), "batch_size": np.array(cfg["batch_size"]), "seed": np.array(21)}
+    for e in range(2):                      # two epochs: the sampler stream runs on across epochs
+        for i, b in enumerate(ld):
+            for k, v in keys.items():
+                g3[f"e{e}.b{i}.{k}"] = b[v].numpy().copy()
+    save("g3_dataloader_batches", **g3)
+
+    # ---- G10: Trainer.fit over the same stream
+    losses = []
+    orig = Trainer._check_nan
+
+    def rec(self, loss):
+        losses.append(float(loss.detach()))
+        return orig(self, loss)
+    Trainer._check_nan = rec
+    try:
+        torch.manual_seed(33)
+        m = SASRec(cfg)
+        sd0 = sd_np(m)
+        tr = Trainer(cfg, m, accelerate.Accelerator(cpu=True))
+        tr.evaluate = lambda *a, **k: {cfg["key_metric"]: 0.0}     # no validation set here: fit() evaluates before every epoch
+        random.seed(21)
+        tr.fit(loader(), valid_data=None, save_model=False, verbose=2)   # (verbose != 2 trips over len(enumerate) at trainer.py:330)
+    finally:
+        Trainer._check_nan = orig
+    keep = {k: (np.array(v) if not isinstance(v, (list, dict)) else np.array(str(v))) for k, v in cfg.items()}
+    arrs = pack("cfg.", keep)
+    arrs.update(pack("sd0.", sd0))
+    arrs.update(pack("sd1.", sd_np(m)))
+    arrs["step_losses"] = np.array(losses, dtype=np.float64)
+    save("g10_trainer_fit", **arrs)
+    print("G10: %d steps, first %.6f last %.6f" % (len(losses), losses[0], losses[-1]))
+
+
+if __name__ == "__main__" and (not ONLY or any(p in ("g3", "g10") for p in ONLY)):
+    capture_g3_g10()

@@ -33,7 +33,58 @@ __device__ __forceinline__ float4 act4(float4 v, int act) {
 template <int BM, int BN, int EPI>
 __device__ __forceinline__ void epilogue_from_lds(const float* Cs, int m0, int n0, int tid, const GemmArgs& a) {
   constexpr int CS = BN + 4;
-  if constexpr (EPI != EPI_BIAS_RES_LN) {
+  if constexpr (EPI == EPI_ADD_LNBWD) {
+    // t = acc (+ aux): gradient wrt the LayerNorm output.  One 32-lane group per row (N <= 128: one float4 per lane), same
+    // arithmetic as ln_bwd_kernel; the per-thread (d gamma, d beta) shares are summed over the tile's rows in a fixed order.
+    const int g = tid >> 5, t = tid & 31;
+    const int n4 = a.N >> 2;
+    const float inv_n = 1.0f / (float)a.N;
+    const bool cin = t < n4;
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), dg = gm, db = gm;
+    if (cin) gm = *(const float4*)(a.gamma + t * 4);
+    for (int ml = g; ml < BM; ml += 8) {
+      const int m = m0 + ml;
+      if (m >= a.M) break;
+      float4 y = make_float4(0.f, 0.f, 0.f, 0.f), h = y;
+      if (cin) {
+        y = *(const float4*)(Cs + ml * CS + t * 4);
+        if (a.aux) {
+          const float4 rs = *(const float4*)(a.aux + (long long)m * a.ldaux + t * 4);
+          y.x += rs.x; y.y += rs.y; y.z += rs.z; y.w += rs.w;
+        }
+        h = *(const float4*)(a.xhat + (long long)m * a.N + t * 4);
+      }
+      dg.x += y.x * h.x; dg.y += y.y * h.y; dg.z += y.z * h.z; dg.w += y.w * h.w;
+      db.x += y.x; db.y += y.y; db.z += y.z; db.w += y.w;
+      float4 gy;
+      gy.x = y.x * gm.x; gy.y = y.y * gm.y; gy.z = y.z * gm.z; gy.w = y.w * gm.w;
+      const float m1 = group_sum<32>((gy.x + gy.y) + (gy.z + gy.w)) * inv_n;
+      const float m2 = group_sum<32>((gy.x * h.x + gy.y * h.y) + (gy.z * h.z + gy.w * h.w)) * inv_n;
+      const float r = a.rstd[m];
+      if (cin) {
+        float4 o;
+        o.x = r * (gy.x - m1 - h.x * m2); o.y = r * (gy.y - m1 - h.y * m2);
+        o.z = r * (gy.z - m1 - h.z * m2); o.w = r * (gy.w - m1 - h.w * m2);
+        const long long orow = a.out_rows ? a.out_rows[m] : m;
+        *(float4*)(a.C + orow * a.ldc + t * 4) = o;
+      }
+    }
+    __syncthreads();   // every read of the staged accumulators is done: the buffer becomes the reduction scratch [8][2][CS]
+    float* red = const_cast<float*>(Cs);
+    if (cin) {
+      *(float4*)(red + (g * 2 + 0) * CS + t * 4) = dg;
+      *(float4*)(red + (g * 2 + 1) * CS + t * 4) = db;
+    }
+    __syncthreads();
+    float* part = a.ln_part + (long long)(m0 / BM) * 2 * a.N;
+    for (int i = tid; i < 2 * a.N; i += 256) {
+      const int which = i / a.N, col = i % a.N;
+      float acc = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) acc += red[(gg * 2 + which) * CS + col];
+      part[i] = acc;
+    }
+  } else if constexpr (EPI != EPI_BIAS_RES_LN) {
     constexpr int RT = BN / 4;         // threads per row (one float4 each)
     constexpr int RPP = 256 / RT;      // rows per pass
     const int t = tid % RT, g = tid / RT;
@@ -157,7 +208,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
   const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
   const int mt = (qid / ntn) * 8 + xcd, nt_ = qid % ntn;
-  if (mt >= ntm) return;
+  if (mt >= ntm) {
+    if constexpr (EPI == EPI_ADD_LNBWD) {   // a surplus M-tile (compacted rows: fewer rows than the grid was sized for): zero partial sums
+      if (mt < (a.M_host + BM - 1) / BM)
+        for (int i = threadIdx.x; i < 2 * a.N; i += 256) a.ln_part[(long long)mt * 2 * a.N + i] = 0.f;
+    }
+    return;
+  }
   const int m0 = mt * BM, n0 = nt_ * BN;
   const int c4 = tid % C4N, lrow = tid / C4N;
 
@@ -314,6 +371,9 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
   return launch_nt<64, 128, PRO, EPI>(a, st);
 }
 
+constexpr int LNBWD_BM = 32;   // rows per tile of the EPI_ADD_LNBWD launches (one tile row = one LayerNorm row: BN = 128)
+int gemm_nt_lnbwd_tiles(int M) { return cdiv(M, LNBWD_BM); }
+
 int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return UR_OK;
   ProfScope ps(PC_GEMM_NT, st, 2.0 * a.M * a.N * a.K);
@@ -330,6 +390,12 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
                                           : launch_nt<64, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
     return pro == PRO_ACT ? launch_nt<64, 256, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
                           : launch_nt<64, 256, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
+  }
+  if (epi == EPI_ADD_LNBWD) {
+    if (a.N > 128 || pro != PRO_NONE || !a.xhat || !a.rstd || !a.gamma || !a.ln_part)
+      return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm backward needs N <= 128 and xhat / rstd / gamma / ln_part (N=%d)", a.N);
+    const_cast<GemmArgs&>(a).M_host = a.M;
+    return launch_nt<LNBWD_BM, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
   }
   if (pro == PRO_ACT) {
     if (epi == EPI_BIAS) return dispatch_tile<PRO_ACT, EPI_BIAS>(a, st);

@@ -59,6 +59,8 @@ enum GemmEpi {
   EPI_MUL_DACT = 3,  // C = acc * act'(aux[m,n])
   EPI_ADD = 4,       // C = acc + aux[m,n]
   EPI_COUNT_GT = 5,  // nothing stored: ((int*)C)[m] += #{n != skip[m] : acc + bias[n] > aux[m]}   (full-item ranking)
+  EPI_ADD_LNBWD = 6, // t = acc (+ aux[m,n]): the gradient wrt a LayerNorm OUTPUT; C[out_rows[m]] = LayerNorm backward of t given the
+                     // saved xhat / rstd and gamma (N <= 128 = one tile row); per-M-tile (d gamma | d beta) partial sums -> ln_part
 };
 struct GemmArgs {
   const float* A; int lda;
@@ -75,7 +77,12 @@ struct GemmArgs {
   DropSpec drop;                 // EPI_BIAS_RES_LN: t = dropout(acc + bias) + res  (thresh == 0: off)
   const long long* skip; long long skip_base;   // EPI_COUNT_GT: column skip[m] - skip_base of row m is left out (nullable)
   int debug;                     // tuning aid (UR_GEMM_DEBUG): 1 = skip epilogue, 2 = skip K-loop global loads
+  // EPI_ADD_LNBWD: xhat / rstd are INPUTS here (saved by the forward pass); out_rows (nullable) scatters row m of the result to row
+  // out_rows[m] of C; ln_part [gemm_nt_lnbwd_tiles(M)][2 N] receives the partial sums (every slot is written); M_host = the M
+  // the grid was sized for (set by gemm_nt)
+  const int* out_rows; float* ln_part; int M_host;
 };
+int gemm_nt_lnbwd_tiles(int M);   // M-tiles (= partial-sum rows) of an EPI_ADD_LNBWD launch over M rows
 int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st);
 
 // Out[R,Cc] = P[T,R]^T @ pro(Q)[T,Cc];  bias_out[R] = colsum(P) (nullable). Deterministic split over T.

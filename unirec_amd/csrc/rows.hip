@@ -588,6 +588,47 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
   const float scale = scale_dev ? *scale_dev : 1.0f;
   if (MODE == 0 && scale < 0.f) return;   // update guard: NaN loss, the whole step is skipped (see dense_adam_kernel)
   const float bc1 = 1.f - powf(a.b1, (float)a.step), bc2s = sqrtf(1.f - powf(a.b2, (float)a.step));
+  if (MODE == 0 && d4 <= TPR) {
+    // One float4 per lane and row: FOUR rows per lane group in flight.  The rows are random 512-byte reads over tables of tens of
+    // GB (w, m, v: three TLB misses per row); with one row per group the kernel is a chain of dependent round trips (plan entry ->
+    // last_step -> row) at 1.4 TB/s.  Here every load of a trip is issued before the first use; indices are clamped and the loads
+    // unconditional (a load behind a branch is waited for on the spot).  Same arithmetic per element as the loop below.
+    constexpr int U = 4;
+    const int c = min(t, d4 - 1);
+    const bool cin = t < d4;
+    for (int u0 = (blockIdx.x * groups + g) * U; u0 < n_uniq; u0 += gridDim.x * groups * U) {
+      long long row[U];
+      int last[U];
+#pragma unroll
+      for (int i = 0; i < U; ++i) row[i] = uniq_idx[min(u0 + i, n_uniq - 1)];
+#pragma unroll
+      for (int i = 0; i < U; ++i) last[i] = last_step ? last_step[row[i]] : a.step - 1;
+      float4 w[U], m[U], v[U], gr[U];
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        w[i] = table[row[i] * d4 + c];
+        m[i] = mom[row[i] * d4 + c];
+        v[i] = var[row[i] * d4 + c];
+        gr[i] = grad[(long long)min(u0 + i, n_uniq - 1) * d4 + c];
+      }
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        if (u0 + i >= n_uniq || row[i] == 0) continue;   // group-uniform
+        if (last_step) lazy_replay4(w[i], m[i], v[i], last[i], a.step - 1, a);
+        opt_elem(w[i].x, m[i].x, v[i].x, gr[i].x * scale, a, bc1, bc2s);
+        opt_elem(w[i].y, m[i].y, v[i].y, gr[i].y * scale, a, bc1, bc2s);
+        opt_elem(w[i].z, m[i].z, v[i].z, gr[i].z * scale, a, bc1, bc2s);
+        opt_elem(w[i].w, m[i].w, v[i].w, gr[i].w * scale, a, bc1, bc2s);
+        if (cin) {
+          table[row[i] * d4 + c] = w[i];
+          mom[row[i] * d4 + c] = m[i];
+          var[row[i] * d4 + c] = v[i];
+        }
+        if (last_step && t == 0) last_step[row[i]] = a.step;
+      }
+    }
+    return;
+  }
   for (int u = blockIdx.x * groups + g; u < n_uniq; u += gridDim.x * groups) {
     const long long row = uniq_idx[u];
     if (row == 0) continue;

@@ -449,7 +449,13 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   // row-chain kernels (rowchain.hip) for the full-sequence layers; hidden dropout keeps the unfused path (the chain backward
   // does not carry the second, dropout-masked copy of the LayerNorm-backward outputs)
   const bool chain_bwd = chain_supported(d, I) && c.p_hidden == 0.f;
-  bool ln0_done = false;                // the embedding LayerNorm backward ran inside the bottom layer's chain_proj_bwd
+  bool ln0_done = false;                // the embedding LayerNorm backward already ran in the epilogue of the bottom layer's last GEMM
+  // LayerNorm backward in the epilogue of the GEMM that produces its input gradient (EPI_ADD_LNBWD): the attention block's
+  // LayerNorm behind the d FFN-1 GEMM, the embedding LayerNorm behind the bottom layer's projection-gradient GEMM.  Two launches and
+  // two [M, d] round trips less per full layer.  Not with hidden dropout (a second, masked copy of the result would be needed).
+  static const bool no_lnfuse = getenv("UR_SASREC_NO_LNFUSE") && atoi(getenv("UR_SASREC_NO_LNFUSE"));
+  const bool lnfuse = !no_lnfuse && c.p_hidden == 0.f && d <= 128;
+  auto lnfuse_part = [&](int slot) { return w.chain_part + (long long)slot * 4 * w.chain_blocks * d; };   // slot n_layers: LN0
   ReduceBatch rb;                       // second stages of all split reductions: one launch at the end
   float* tn_cur = w.tn_ws;
   float* ln_cur = w.ln_part;
@@ -634,11 +640,20 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     if ((rc = fork())) return rc;
     g = GemmArgs{};
     g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
-    if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
-    // ---- attention block
-    if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb, mv,
-                     nullptr, nullptr, &d_out, lw.g_tad)))
-      return rc;
+    if (lnfuse) {
+      // ---- d FFN-1 GEMM + residual + the attention block's LayerNorm backward in its epilogue: g_ta directly
+      g.C = lw.g_ta; g.xhat = lw.ahat; g.rstd = lw.rstd1; g.gamma = p.g1; g.ln_part = lnfuse_part(i);
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc;
+      if (rb.full(2) && (rc = reduce_batch(rb, st))) return rc;
+      rb.add(g.ln_part, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, G + o[8], d);
+      rb.add(g.ln_part + d, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, G + o[9], d);
+    } else {
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
+      // ---- attention block
+      if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, M, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb, mv,
+                       nullptr, nullptr, &d_out, lw.g_tad)))
+        return rc;
+    }
     if ((rc = tn(lw.g_tad, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
     g = GemmArgs{};
     g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = d;
@@ -652,7 +667,18 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     g = GemmArgs{};
     g.A = lw.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = 3 * d;
     g.aux = lw.g_ta; g.ldaux = d;
-    if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
+    if (lnfuse && i == 0) {
+      // bottom layer: the embedding LayerNorm's backward rides in the epilogue, rows go straight to their (padded-layout) places
+      g.C = d_emb_rows; g.xhat = w.x0hat; g.rstd = w.rstd0; g.gamma = dense + lay.off[1]; g.out_rows = compact ? w.tok_full : nullptr;
+      g.ln_part = lnfuse_part(c.n_layers);
+      if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc;
+      if (rb.full(2) && (rc = reduce_batch(rb, st))) return rc;
+      rb.add(g.ln_part, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, dense_grad + lay.off[1], d);
+      rb.add(g.ln_part + d, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, dense_grad + lay.off[2], d);
+      ln0_done = true;
+    } else if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) {
+      return rc;
+    }
   }
   // ---- input block: LN0 backward -> row gradients of E[item_seq] and of the position table  (x0 = dropout(LN0(.)): g_y is
   // masked on read)

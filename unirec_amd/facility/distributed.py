@@ -66,10 +66,14 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
     """SparseDenseAdam for world > 1 (see the module docstring).  The model keeps its SHARD under each table's ``weight``;
     ``train_step`` swaps the compact table of the batch's rows in for the duration of the model's forward_backward."""
 
-    def __init__(self, model, rank, world, group=None, sync_init=True, **kw):
+    def __init__(self, model, rank, world, group=None, sync_init=True, full_rows=None, **kw):
+        """full_rows (optional): {table: N} for tables the model ALREADY holds as this rank's shard (shard_rows(N, W) rows,
+        initialised per rank): nothing is broadcast or cut for them -- how a 100 M-row table is brought up without ever
+        existing in one piece (bench.py); by default the model's full tables are broadcast from rank 0 and cut here."""
         self.rank, self.world = rank, world
         self.xchg = RowExchange(world, rank, group)
         self.full_rows = {}
+        full_rows = dict(full_rows or {})
         dev = model.device
         if model.loss_type == "fullsoftmax":
             raise NotImplementedError("fullsoftmax scores every item against every user: not available over a row-sharded table")
@@ -82,6 +86,13 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             if not hasattr(model, name) or (name == "item_dst_embedding" and model.item_dst_embedding is model.item_embedding):
                 continue
             w = getattr(model, name).weight
+            if name in full_rows:
+                if w.shape[0] != shard_rows(full_rows[name], world):
+                    raise ValueError(f"{name}: a pre-sharded table of {full_rows[name]} rows has {shard_rows(full_rows[name], world)} "
+                                     f"rows per rank, the model holds {w.shape[0]}")
+                self.full_rows[name] = int(full_rows[name])
+                w.data[0].zero_()
+                continue
             self.full_rows[name] = w.shape[0]
             if sync_init and world > 1:
                 self._broadcast(w.data)
@@ -127,7 +138,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             out[name] = (ka if ta is not None else None, kb if tb is not None else None, a, b)
         return out
 
-    def _plans(self, batch):
+    def _sharded_plans(self, batch):
         return {name: (ka, kb, ops.rows_plan_sharded(a, b, self.full_rows[name], self.world))
                 for name, (ka, kb, a, b) in self._table_inputs(batch).items()}
 
@@ -178,9 +189,9 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                 look[3].synchronize()
                 plans, host_counts = look[1], {n: [int(x) for x in h.tolist()] for n, h in look[2].items()}
             else:
-                plans = self._plans(batch)
+                plans = self._sharded_plans(batch)
         else:
-            plans = self._plans(batch)
+            plans = self._sharded_plans(batch)
         if next_batch is not None:
             self.prefetch(next_batch)
         # ---- 2. per table: ids -> owners, rows back
@@ -196,12 +207,12 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             n_uniq = sum(send)
             keys = pl.uniq_idx[:n_uniq]
             req_send = (keys % n_local).to(torch.int32) if W > 1 else keys
-            req = xchg.all_to_all_rows(req_send, send, recv).contiguous()
+            req = xchg.all_to_all_rows(req_send, send, recv, label="a2a_ids").contiguous()
             # every sender's block is ascending and unique (its plan sorted it): the owner-side plan is a W-way merge
             own = ops.rows_plan_merge(req, recv) if 1 < W <= 64 and req.numel() > 0 else ops.rows_plan(req, None, n_local)
             if st["last"] is not None and self.t > 1:
                 ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], own)
-            compact = xchg.all_to_all_rows(ops.embedding_gather(st["w"], req), recv, send)
+            compact = xchg.all_to_all_rows(ops.embedding_gather(st["w"], req), recv, send, label="a2a_rows")
             idx_a, idx_b = ops.compact_index(pl)
             if ka is not None:
                 cbatch[ka] = idx_a.view(batch[ka].shape)
@@ -234,7 +245,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             else:
                 coef, vec, G = self._zero_coef, torch.zeros(1, d, dtype=torch.float32, device=c["compact"].device), 1
             ug = ops.rows_reduce(c["pl"], rows, coef, vec, G, d)[: c["n_uniq"]]
-            grads_in = xchg.all_to_all_rows(ug, c["send"], c["recv"]).contiguous()
+            grads_in = xchg.all_to_all_rows(ug, c["send"], c["recv"], label="a2a_row_grads").contiguous()
             owner_grads[name] = ops.rows_reduce(c["own"], grads_in, None, None, 1, d, zero_tail=self.grad_clip is not None)
         # ---- 5. dense gradients + bias gradients + flags: ONE flat all-reduce (sum)
         model.finish_backward()
@@ -332,7 +343,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         """For evaluation forwards: fetch the rows `batch` looks up.  -> (re-indexed batch, restore()); between the call and
         restore() the model's tables (and bias vectors) are the compact ones.  Call flush() first in lazy_dense mode."""
         model, xchg, W = self.model, self.xchg, self.world
-        plans = self._plans(batch)
+        plans = self._sharded_plans(batch)
         ctx, cbatch, swapped = {}, dict(batch), []
         for name, (ka, kb, (pl, counts)) in plans.items():
             st = self.tables[name]
@@ -359,6 +370,54 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             for p, data in reversed(swapped):
                 p.data = data
         return cbatch, restore
+
+    # ------------------------------------------------------------------ full-item ranking over the sharded catalogue
+    def local_history(self, hist_ptr, hist_sorted):
+        """CSR history (global ids, ascending per user) -> the same CSR restricted to this rank's items, in local row ids."""
+        if hist_ptr is None or self.world == 1:
+            return hist_ptr, hist_sorted
+        W, r = self.world, self.rank
+        own = (hist_sorted % W == r) & (hist_sorted > 0)
+        csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=own.device), own.to(torch.int64).cumsum(0)])
+        return csum[hist_ptr].contiguous(), (hist_sorted[own] // W + 1).to(torch.int32).contiguous()
+
+    @torch.no_grad()
+    def full_item_ranks(self, user_emb, target, user_id=None, local_hist=(None, None)):
+        """one_vs_all rank (Evaluator.evaluate_with_full_items semantics, as ops.full_rank) of this rank's rows over the row-SHARDED
+        catalogue: all-gather the user vectors, every rank counts on its own shard, two small all-reduces (thresholds, counts).
+        No score leaves a GPU, the table is never gathered.  Collective; ranks may bring different row counts.  -> int32[B]."""
+        W, r, xchg = self.world, self.rank, self.xchg
+        st = self.tables["item_embedding"]
+        N = self.full_rows["item_embedding"]
+        B = user_emb.shape[0]
+        Bmax = B
+        if W > 1:      # common row count (the last batch of an epoch may be short on one rank)
+            box = [None] * W
+            dist.all_gather_object(box, B, group=xchg.cpu_group or xchg.group)
+            Bmax = max(box)
+        target = target.reshape(B, -1)[:, 0].to(torch.int64)
+        if Bmax > B:
+            user_emb = torch.cat([user_emb, torch.zeros(Bmax - B, user_emb.shape[1], device=user_emb.device)])
+            target = torch.cat([target, torch.ones(Bmax - B, dtype=torch.int64, device=target.device)])
+            if user_id is not None:
+                user_id = torch.cat([user_id, torch.zeros(Bmax - B, dtype=user_id.dtype, device=user_id.device)])
+        ue_all, tgt_all = xchg.all_gather_cat(user_emb.contiguous()), xchg.all_gather_cat(target.contiguous())
+        uid_all = xchg.all_gather_cat(user_id.to(torch.int64).contiguous()) if user_id is not None else None
+        ltgt = tgt_all if W == 1 else torch.where(tgt_all % W == r, tgt_all // W + 1, torch.full_like(tgt_all, -1))
+        hp, hs = local_hist if uid_all is not None else (None, None)
+        if W == 1:
+            n_rows, excl = N, -1
+        elif r == 0:      # rank 0 holds ids W, 2W, .. at local rows 2.. (row 1 is the slot id 0 would take: never an item)
+            n_rows, excl = (N - 1) // W + 2, 1
+        else:
+            n_rows, excl = ((N - 1 - r) // W + 1 if N - 1 >= r else 0) + 1, -1
+        bias_local = None
+        if getattr(self.model, "has_item_bias", False):
+            bias_local = extract_shard(self.model.item_bias.data.view(-1, 1), r, W).view(-1).contiguous() if W > 1 else self.model.item_bias.data
+        thr = xchg.all_reduce_sum(ops.full_rank_shard(1, ue_all, st["w"], ltgt, item_bias_local=bias_local, n_rows=n_rows))
+        part = ops.full_rank_shard(2, ue_all, st["w"], ltgt, thr=thr, user_id=uid_all, hist_ptr=hp, hist_sorted_local=hs,
+                                   item_bias_local=bias_local, n_rows=n_rows, excl_row=excl)
+        return xchg.all_reduce_sum(part)[r * Bmax: r * Bmax + B].clamp_(min=0)
 
     # ------------------------------------------------------------------ checkpoints: full tables <-> shards
     def _send(self, t, dst):

@@ -13,6 +13,7 @@ import time
 import numpy as np
 import torch
 
+from .distributed import ShardedSparseDenseAdam, dist_info
 from .optimizer import SparseDenseAdam
 
 
@@ -26,14 +27,17 @@ class BatchLoader:
 
     def __len__(self):
         nb = (len(self.dataset) + self.batch_size - 1) // self.batch_size
-        return (nb - self.rank + self.world - 1) // self.world
+        return (nb + self.world - 1) // self.world
 
     def __iter__(self):
         n = len(self.dataset)
         order = np.random.default_rng(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
         self.epoch += 1
         nb = (n + self.batch_size - 1) // self.batch_size
-        for b in range(self.rank, nb, self.world):
+        # every rank takes the same number of steps (the step is collective): a rank whose share runs out wraps around to
+        # the first batches, as Accelerate's even_batches default does
+        for k in range((nb + self.world - 1) // self.world):
+            b = (k * self.world + self.rank) % nb
             rows = self.dataset.get_batch(order[b * self.batch_size:(b + 1) * self.batch_size])
             yield {k: torch.from_numpy(v).to(self.device, non_blocking=True) for k, v in rows.items()}
 
@@ -51,7 +55,7 @@ class DeviceBatchLoader:
 
     def __len__(self):
         nb = (len(self.pairs) + self.batch_size - 1) // self.batch_size
-        return (nb - self.rank + self.world - 1) // self.world
+        return (nb + self.world - 1) // self.world
 
     def __iter__(self):
         n, B = len(self.pairs), self.batch_size
@@ -64,7 +68,8 @@ class DeviceBatchLoader:
         nb = (n + B - 1) // B
         base = self.epoch * nb
         self.epoch += 1
-        for b in range(self.rank, nb, self.world):
+        for k in range((nb + self.world - 1) // self.world):   # equal step counts on every rank (see BatchLoader)
+            b = (k * self.world + self.rank) % nb
             sel = self.pairs[order[b * B:(b + 1) * B]]
             yield self.builder.build(sel[:, 0].contiguous(), sel[:, 1].contiguous(), with_seq=self.with_seq, step=base + b)
 
@@ -127,6 +132,10 @@ class ReduceLROnPlateauMax:
 class Trainer(object):
     def __init__(self, config, model, accelerator=None):
         self.config, self.model, self.accelerator = config, model, accelerator
+        # one process per GPU (unirec/facility/trainer.py:67,261: accelerator.prepare wraps model / optimizer / loaders): with
+        # world > 1 the optimizer built below trains ONE model -- tables row-sharded, dense parameters replicated and
+        # all-reduced (facility/distributed.py); world == 1 is the plain single-GPU path
+        self.rank, self.world = dist_info(accelerator)
         self.exp_name = config.get("exp_name", __name__)
         self.logger = logging.getLogger(self.exp_name)
         self.learning_rate = config.get("learning_rate", 1e-3)
@@ -156,6 +165,9 @@ class Trainer(object):
         elif opt_type not in ("adam", "sgd", "adagrad", "rmsprop", "adamw"):
             self.logger.warning("Received unrecognized optimizer, set default Adam optimizer")
             opt_type, wd = "adam", 0.0          # the reference's fall-back drops weight_decay too (trainer.py:151)
+        if self.world > 1:
+            return ShardedSparseDenseAdam(self.model, self.rank, self.world, lr=self.learning_rate, weight_decay=wd,
+                                          grad_clip=self.grad_clip_value, table_mode=table_mode, algo=opt_type)
         return SparseDenseAdam(self.model, lr=self.learning_rate, weight_decay=wd, grad_clip=self.grad_clip_value, table_mode=table_mode,
                                algo=opt_type)
 
@@ -184,6 +196,8 @@ class Trainer(object):
         stream underneath this step's forward/backward."""
         opt, model = self.optimizer, self.model
         model.train()
+        if self.world > 1:     # the collective step: plans, row exchange, forward / backward, gradient exchange, updates
+            return opt.train_step(batch, next_batch)
         opt.zero_grad()
         opt.plan_batch(**self._plan_ids(batch))
         if next_batch is not None:
@@ -284,8 +298,21 @@ class Trainer(object):
         from .. import ops
         model = self.model
         ranks = []
+        local_hist = None
         for batch in eval_data:
             kw = {k: batch[k] for k in ("user_id", "item_seq", "item_seq_len") if k in batch}
+            if self.world > 1:    # rows fetched through the row exchange, counts on every rank's own shard
+                opt = self.optimizer
+                target = batch["item_id"].reshape(batch["item_id"].shape[0], -1)[:, 0].contiguous()
+                cb, restore = opt.compact_batch({k: v for k, v in batch.items() if k != "item_id"})
+                try:
+                    user_emb = model.forward_user_emb(**{k: cb[k] for k in kw}).contiguous().clone()
+                finally:
+                    restore()
+                if local_hist is None:
+                    local_hist = opt.local_history(*self._history_csr(user_emb.device))
+                ranks.append(opt.full_item_ranks(user_emb, target, user_id=batch.get("user_id"), local_hist=local_hist))
+                continue
             user_emb = model.forward_user_emb(**kw).contiguous()
             target = batch["item_id"].reshape(user_emb.shape[0], -1)[:, 0].contiguous()
             hp, hs = self._history_csr(user_emb.device)
@@ -296,8 +323,27 @@ class Trainer(object):
                                     user_bias=model.user_bias.data if model.has_user_bias else None,
                                     item_bias=model.item_bias.data if model.has_item_bias else None, tau=model.tau)
             ranks.append(rank)
-        r = torch.cat(ranks).cpu().numpy()
+        r = self._gather_for_metrics([x.cpu().numpy() for x in ranks], eval_data)
         return self._metrics_from_rank(r, model.n_items)
+
+    def _gather_for_metrics(self, per_batch, eval_data):
+        """accelerator.gather_for_metrics (unirec/facility/evaluation/evaluator_abc.py): the per-batch results of all ranks in
+        dataset order (rank r holds batches r, r + W, ...), cut to the dataset length (ranks that wrapped around re-ran the first
+        batches)."""
+        if self.world == 1:
+            return np.concatenate(per_batch) if per_batch else np.zeros(0)
+        import torch.distributed as dist
+        box = [None] * self.world
+        dist.all_gather_object(box, per_batch, group=self.optimizer.xchg.cpu_group or self.optimizer.xchg.group)
+        out = [box[r][k] for k in range(len(per_batch)) for r in range(self.world) if k < len(box[r])]
+        flat = np.concatenate(out) if out else np.zeros(0)
+        n_total = None
+        ds = getattr(eval_data, "dataset", None)
+        if ds is not None:
+            n_total = len(ds)
+        elif hasattr(eval_data, "pairs"):
+            n_total = len(eval_data.pairs)
+        return flat[:n_total] if n_total is not None else flat
 
     @torch.no_grad()
     def evaluate(self, eval_data, load_best_model=True, model_file=None, verbose=0, predict_only=False):
@@ -312,26 +358,46 @@ class Trainer(object):
         ranks = []
         for batch in eval_data:   # one_vs_k: positive in column 0
             kw = {k: batch[k] for k in ("user_id", "item_id", "item_seq", "item_seq_len") if k in batch}
-            _, scores, _, _ = self.model(**kw)
+            if self.world > 1:    # the rows this batch looks up come through the row exchange (compact tables, ids re-indexed)
+                cb, restore = self.optimizer.compact_batch(batch)
+                try:
+                    _, scores, _, _ = self.model(**{k: cb[k] for k in kw})
+                    scores = scores.clone()
+                finally:
+                    restore()
+            else:
+                _, scores, _, _ = self.model(**kw)
             if predict_only:
                 ranks.append(scores.cpu().numpy())
                 continue
             ranks.append((scores[:, 1:] > scores[:, :1]).sum(1).cpu().numpy())   # 0-based rank of the positive
         if predict_only:
-            return np.concatenate(ranks)
-        return self._metrics_from_rank(np.concatenate(ranks), scores.shape[1])
+            return self._gather_for_metrics(ranks, eval_data)
+        return self._metrics_from_rank(self._gather_for_metrics(ranks, eval_data), scores.shape[1])
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:368-412)
     def save_model(self, filename, optimizer=None, scheduler=None, epoch=0, step=0, valid_result=None, config=None):
-        os.makedirs(os.path.dirname(filename), exist_ok=True)
         self.optimizer.flush()
+        if self.world > 1:
+            # unwrap_model(model).state_dict() on the main process (trainer.py:389-398): the FULL tables under the reference's
+            # names, streamed from the shards to rank 0 chunk by chunk; the other ranks only take part in the collective
+            state_dict = self.optimizer.gather_state_dict()
+            if self.rank != 0:
+                return
+        else:
+            state_dict = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
+        os.makedirs(os.path.dirname(filename), exist_ok=True)
         torch.save({"config": {k: v for k, v in (config or self.config).items() if k != "device"}, "cur_epoch": epoch,
                     "cur_step": step, "best_valid_score": self.best_valid_score,
-                    "state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                    "state_dict": state_dict,
                     "optimizer": {"t": self.optimizer.t, "algo": self.optimizer.algo, "param_groups": self.optimizer.param_groups},
                     "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None}, filename)
 
     def load_model(self, model_file):
+        if self.world > 1:     # rank 0 reads the file; tables are dealt out row by row, the rest is broadcast
+            ck = torch.load(model_file, map_location="cpu", weights_only=False) if self.rank == 0 else None
+            self.optimizer.scatter_state_dict(ck["state_dict"] if ck is not None else None)
+            return
         ck = torch.load(model_file, map_location="cpu", weights_only=False)
         self.model.load_state_dict(ck["state_dict"], strict=False)
         self.model.check_views()

@@ -31,6 +31,8 @@ class RowExchange:
 
     def __init__(self, world: int, rank: int, group=None):
         self.world, self.rank, self.group = world, rank, group
+        self.profile = None        # {label: [ms, bytes sent to peers, calls]} while profiling is on (bench.py: per-collective times)
+        self._pending = []
         # host-side group for the tiny per-step counts exchange (2W integers that the HOST needs as split sizes): with
         # an RCCL main group this is a second, gloo group, so the exchange neither queues behind device collectives nor
         # forces the host to drain the compute stream (exchange_counts_host).  Created collectively by every rank.
@@ -81,14 +83,43 @@ class RowExchange:
         both = torch.cat([src, recv]).tolist()
         return [int(x) for x in both[: self.world]], [int(x) for x in both[self.world:]]
 
-    def all_to_all_rows(self, send: torch.Tensor, send_counts: List[int], recv_counts: List[int]) -> torch.Tensor:
+    # ---- per-collective timing (off by default: two events per collective).  bytes = what this rank sends to its W - 1 peers.
+    def profile_start(self):
+        self.profile, self._pending = {}, []
+
+    def profile_stop(self):
+        """-> {label: {"ms": device time of the collective on the compute stream, "MB_to_peers": ..., "calls": ...}}"""
+        out = {}
+        for label, e0, e1, nbytes in self._pending:
+            e1.synchronize()
+            rec = out.setdefault(label, {"ms": 0.0, "MB_to_peers": 0.0, "calls": 0})
+            rec["ms"] += e0.elapsed_time(e1)
+            rec["MB_to_peers"] += nbytes / 1e6
+            rec["calls"] += 1
+        self.profile, self._pending = None, []
+        return out
+
+    def _timed(self, label, nbytes, fn, on_device):
+        if self.profile is None or not on_device:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self._pending.append((label, e0, e1, nbytes))
+        return r
+
+    def all_to_all_rows(self, send: torch.Tensor, send_counts: List[int], recv_counts: List[int], label="all_to_all") -> torch.Tensor:
         """send: [sum(send_counts), ...] blocks ordered by destination rank -> [sum(recv_counts), ...] ordered by source."""
         if self.world == 1:
             return send
         stage = send.is_cuda and dist.get_backend(self.group) != "nccl"   # gloo has no device all-to-all: stage via host
         src = send.contiguous().cpu() if stage else send.contiguous()
         out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=src.device)
-        dist.all_to_all_single(out, src, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
+        row_bytes = send.element_size() * (send[0].numel() if send.shape[0] else 1)
+        peers = (sum(send_counts) - send_counts[self.rank]) * row_bytes
+        self._timed(label, peers, lambda: dist.all_to_all_single(out, src, output_split_sizes=recv_counts,
+                                                                 input_split_sizes=send_counts, group=self.group), send.is_cuda)
         return out.to(send.device) if stage else out
 
 
@@ -100,9 +131,11 @@ class RowExchange:
             return t
         if self._staged(t):
             h = t.cpu()
-            dist.all_reduce(h, group=self.group)
+            self._timed("all_reduce", 2 * t.numel() * t.element_size() * (self.world - 1) // self.world,
+                        lambda: dist.all_reduce(h, group=self.group), t.is_cuda)
             return h.to(t.device)
-        dist.all_reduce(t, group=self.group)
+        self._timed("all_reduce", 2 * t.numel() * t.element_size() * (self.world - 1) // self.world,
+                    lambda: dist.all_reduce(t, group=self.group), t.is_cuda)
         return t
 
     def all_gather_cat(self, t: torch.Tensor) -> torch.Tensor:
