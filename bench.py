@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true", help="sort each batch's ids inside its own step (no side-stream lookahead)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--cpu-baseline-items", type=int, default=1_000_000)
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the steady_state and e2e legs that follow the timed region")
+    ap.add_argument("--all-configs", action="store_true", help="also measure BASELINE configs C2, C3 and C4's encoder (step time, "
+                    "dominant kernel class and its roofline fraction each) into the same JSON line")
     ap.add_argument("--no-selfcheck", action="store_true", help="world > 1: skip the W-rank == 1-rank check that runs before the timed region")
     ap.add_argument("--selfcheck-items", type=int, default=1_000_000)
     ap.add_argument("--dropout", type=float, default=0.0, help="hidden_dropout_prob = attn_dropout_prob (the reference's SASRec.yaml "
@@ -222,6 +225,172 @@ def multi_gpu_selfcheck(a, device, rank, world):
     torch.cuda.empty_cache()
     dist.barrier()
     return report
+
+
+MFMA_CLASSES = ("gemm_nt", "gemm_tn", "row_chain", "attn_fwd", "attn_bwd", "gru")   # classes whose `work` is flops; the rest count bytes
+
+
+def steady_state_leg(a, opt, step_fn, batches, steps, barrier):
+    """The headline steps meet rows that were never updated (N = 100 M, ~27 K rows per step), so the lazily-evaluated dense Adam
+    has nothing to replay.  In a long run every looked-up row HAS history -- a row comes back every ~N / 27 K steps -- and the
+    replay of its missed zero-gradient steps is part of every step.  This leg ages the whole table (every row: moments set,
+    last update `gap` steps ago) and times the same step again; `embedding_optimizer: rowwise` has no replay at all."""
+    st = opt.tables["item_embedding"]
+    if st["last"] is None:
+        return {"note": "rowwise table optimizer: no replay, steady state == headline"}
+    gap = max(200, min(4000, a.n_items // 27_000))
+    st["m"].fill_(1e-5)
+    st["v"].fill_(1e-10)
+    st["m"][0].zero_()
+    st["v"][0].zero_()
+    opt.t += gap
+    st["last"].fill_(opt.t - gap)
+    for i in range(3):
+        step_fn(batches[i % len(batches)], batches[(i + 1) % len(batches)])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(batches[(3 + i) % len(batches)], batches[(4 + i) % len(batches)])
+    barrier()
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": round(dt / steps * 1e3, 4), "examples_per_s": round(a.batch * steps / dt, 1), "steps": steps,
+            "replayed_gap_steps": gap, "note": "every looked-up row replays the zero-gradient Adam steps it missed (capped at 192 terms)"}
+
+
+def e2e_leg(a, model, opt, device, steps):
+    """The input pipeline INSIDE the timed loop (north_star: the uniform negative sampler is part of the path): interaction pairs
+    and the CSR history live in HBM; per step ur_sample_negatives + ur_device_build_seq (DeviceRowBuilder: negatives rejected
+    against the user's history, history cut at the target, left padding) build the batch, then the same training step runs."""
+    import numpy as np
+    from unirec_amd.data.rows import DeviceRowBuilder, HistoryCSR
+    n_users = 100_000
+    rng = np.random.default_rng(0)
+    lens = np.clip(np.exp(rng.normal(4.25, 1.0, n_users)).astype(np.int64), 5, 1000)
+    ptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    items = rng.integers(1, a.n_items, int(ptr[-1])).astype(np.int32)
+    csr = HistoryCSR.__new__(HistoryCSR)
+    csr.ptr, csr.items, csr.n_users, csr._dev = ptr, items, n_users, None
+    order = np.lexsort((items, np.repeat(np.arange(n_users), lens)))
+    csr.sorted = items[order]
+    n_pairs = a.batch * (steps + 6)
+    users = rng.integers(0, n_users, n_pairs)
+    pos = items[ptr[users] + (rng.random(n_pairs) * lens[users]).astype(np.int64)]
+    pairs = torch.from_numpy(np.stack([users, pos.astype(np.int64)], 1)).to(device)
+    bld = DeviceRowBuilder(n_users, a.n_items, a.negatives, a.seq_len, csr, reject_history=True, mask_mode="autoregressive", seq_last=0, seed=1,
+                           device=str(device))
+
+    def build(k):
+        sel = pairs[k * a.batch:(k + 1) * a.batch]
+        return bld.build(sel[:, 0].contiguous(), sel[:, 1].contiguous(), with_seq=True, step=k)
+
+    def step(b, nxt):
+        opt.zero_grad()
+        opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
+        opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
+        model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
+        opt.step()
+
+    cur = build(0)
+    for k in range(5):
+        nxt = build(k + 1)
+        step(cur, nxt)
+        cur = nxt
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(5, 5 + steps):
+        nxt = build(k + 1)          # the NEXT batch is built (sampler + history cut) while this step's launches are queued
+        step(cur, nxt)
+        cur = nxt
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": round(dt / steps * 1e3, 4), "examples_per_s": round(a.batch * steps / dt, 1), "steps": steps,
+            "pipeline": "device-resident: ur_sample_negatives (uniform, history-rejecting) + ur_device_build_seq per step, inside the clock"}
+
+
+def other_config(name, device):
+    """One BASELINE configuration other than the headline one: step time + the dominant kernel class with its roofline fraction
+    (same method as the headline: HIP events around every launch of the class, algorithmic work / device time)."""
+    import ctypes as C
+    from unirec_amd import _lib
+    from unirec_amd.facility.optimizer import SparseDenseAdam
+    from unirec_amd.model.sequential.gru import GRU
+    from unirec_amd.model.sequential.sasrec import SASRec
+    argv = {"C2": ["--n-items", "60000", "--d", "64"],
+            "C3": ["--n-items", "2000000", "--seq-len", "200", "--negatives", "1000", "--loss", "softmax", "--batch", "128"],
+            "C4_encoder": ["--n-items", "10000000", "--loss", "softmax"]}[name]
+    old = sys.argv
+    sys.argv = [old[0]] + argv
+    try:
+        a = parse()
+    finally:
+        sys.argv = old
+    cfg = model_config(a, str(device))
+    if name == "C4_encoder":
+        cfg.update(model="GRU", hidden_size=128)
+    torch.manual_seed(2022)
+    model = (GRU if name == "C4_encoder" else SASRec)(cfg)
+    opt = SparseDenseAdam(model, lr=1e-3, table_mode="lazy_dense")
+    model.train()
+    steps, warm = 30, 8
+    batches = synth_batches(a, a.n_items, device, 5, n_batches=steps + warm + 2)
+
+    def step(b, nxt):
+        opt.zero_grad()
+        opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
+        opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
+        model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
+        opt.step()
+
+    ncls = _lib.lib.ur_prof_num_classes()
+    names = [_lib.lib.ur_prof_class_name(i).decode() for i in range(ncls)]
+
+    def read():
+        ms, cnt, work = (C.c_double * ncls)(), (C.c_int64 * ncls)(), (C.c_double * ncls)()
+        _lib.check(_lib.lib.ur_prof_read(ms, cnt, work), "ur_prof_read")
+        return {names[i]: dict(ms=ms[i], launches=int(cnt[i]), work=work[i]) for i in range(ncls)}
+
+    for i in range(warm // 2):
+        step(batches[i], batches[i + 1])
+    _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
+    _lib.lib.ur_prof_reset()
+    _lib.lib.ur_prof_enable(1)
+    for i in range(warm // 2, warm):
+        step(batches[i], batches[i + 1])
+    torch.cuda.synchronize()
+    _lib.lib.ur_prof_enable(0)
+    per = read()
+    dom = max((k for k in per if k != "rows_sort"), key=lambda k: per[k]["ms"])    # (the id sort runs on a side stream under the previous step)
+    _lib.lib.ur_prof_reset()
+    _lib.lib.ur_prof_set_mask(1 << names.index(dom))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        _lib.lib.ur_prof_enable(1 if i % PROF_EVERY == 0 else 0)
+        step(batches[warm + i], batches[warm + i + 1])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.lib.ur_prof_enable(0)
+    c = read()[dom]
+    _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
+    L, d = a.seq_len, a.d
+    seqs = torch.stack([b["item_seq"] for b in batches[warm:warm + steps]])
+    first = (seqs > 0).int().argmax(-1)
+    lens = torch.where((seqs > 0).any(-1), L - first, torch.full_like(first, L))
+    frac = float(lens.float().mean() / L) if (name != "C4_encoder" and (d // a.heads) in (4, 8, 16)) else 1.0
+    mfma = dom in MFMA_CLASSES
+    scale = frac if dom in ("gemm_nt", "gemm_tn", "row_chain") else 1.0     # GEMM work is counted on the padded row count
+    ach = c["work"] * scale / max(c["ms"] * 1e-3, 1e-12) / (1e12 if mfma else 1e9)
+    peak = MFMA_F32_PEAK_TFLOPS if mfma else HBM_PEAK_GBPS
+    out = {"workload": f"{cfg['model']} n_items={a.n_items} d={d} L={L} B={a.batch} K={a.negatives} {a.loss}",
+           "ms_per_step": round(dt / steps * 1e3, 4), "examples_per_s": round(a.batch * steps / dt, 1),
+           "roofline": {"bound": "mfma" if mfma else "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": peak,
+                        "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "launches": c["launches"],
+                        "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2)},
+           "kernel_time_ms_per_step": {k: round(v["ms"] / (warm - warm // 2), 4) for k, v in per.items() if v["launches"]}}
+    del model, opt, batches
+    torch.cuda.empty_cache()
+    return out
 
 
 def gather_microbench(table, device):
@@ -476,11 +645,20 @@ def main():
         out["backend"] = dist.get_backend()
         out["selfcheck"] = selfcheck if selfcheck is not None else "skipped (--no-selfcheck)"
         out["collectives"] = collectives
+    if world == 1 and not a.no_extra_legs and not a.autograd:
+        n_leg = max(10, min(a.steps, 50))
+        out["e2e"] = e2e_leg(a, model, opt, device, n_leg)
+        out["steady_state"] = steady_state_leg(a, opt, step_fn, batches, n_leg, barrier)      # (last: it ages the optimizer state)
     if world == 1 and not a.no_gather_bench:
         out["gather_roofline"] = gather_microbench(model.item_embedding.weight.data, device)
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and (a.all_configs or not a.no_cpu_baseline):
         del model
+        if world == 1:
+            del opt
         torch.cuda.empty_cache()
+    if world == 1 and a.all_configs:
+        out["other_configs"] = {n: other_config(n, device) for n in ("C2", "C3", "C4_encoder")}
+    if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)
     print(json.dumps(out))
 

@@ -109,3 +109,50 @@ def test_nothing_reads_the_reference_tree_at_run_time():
                 for node in ast.walk(tree):
                     if isinstance(node, ast.Constant) and isinstance(node.value, str) and id(node) not in doc:
                         assert "/root/reference" not in node.value, f"{fn} uses /root/reference at run time"
+
+
+def test_torch_ops_cover_the_header():
+    """north_star: "exposed as torch ops".  Every symbol of include/unirec_amd.h is either registered as torch.ops.unirec_amd.<op>
+    (unirec_amd/torch_ops.py: torch.library.custom_op over the ctypes call) or listed there with the reason it is not a
+    dispatcher op; every registered op carries a fake (shape-inference) implementation, exercised here on FakeTensors without a GPU."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import unirec_amd.torch_ops as T
+    names = set(_declared())
+    ops_, not_ops = set(T.HEADER_TO_OP), set(T.NOT_OPS)
+    assert not (ops_ & not_ops), ops_ & not_ops
+    assert ops_ | not_ops == names, (names - (ops_ | not_ops), (ops_ | not_ops) - names)
+    assert len(ops_) >= 15 and all(isinstance(r, str) and len(r) > 20 for r in T.NOT_OPS.values())
+    for sym, op in T.HEADER_TO_OP.items():
+        assert hasattr(torch.ops.unirec_amd, op), (sym, op)
+        assert getattr(torch.ops.unirec_amd, op).default._schema.name == f"unirec_amd::{op}"
+    with FakeTensorMode():
+        B, L, G, d, N, I = 6, 10, 5, 32, 100, 64
+        table = torch.empty(N, d)
+        dense = torch.empty(5000)
+        seq = torch.empty(B, L, dtype=torch.int32)
+        ids = torch.empty(B, G, dtype=torch.int64)
+        ws = torch.empty(1 << 16, dtype=torch.uint8)
+        assert torch.ops.unirec_amd.embedding_gather(table, ids).shape == (B, G, d)
+        ue = torch.ops.unirec_amd.sasrec_fwd(table, dense, seq, ws, 4, I, 2, "swish", True, 1e-10)
+        assert ue.shape == (B, d) and ue.dtype == torch.float32
+        dg, dr = torch.ops.unirec_amd.sasrec_bwd(table, dense, seq, ue, ws, 4, I, 2, "swish", True, 1e-10)
+        assert dg.shape == dense.shape and dr.shape == (B * L, d)
+        assert torch.ops.unirec_amd.gru_fwd(table, dense, seq, ws, 32).shape == (B, d)
+        sc, lr_, lo = torch.ops.unirec_amd.gather_dot_loss_fwd(ue, table, ids, None, None, None, None, "bpr")
+        assert sc.shape == (B, G) and lo.shape == (4,)
+        coef, du, dub = torch.ops.unirec_amd.gather_dot_loss_bwd(ue, table, ids, None, sc, lo, None, "bpr")
+        assert coef.shape == (B, G) and du.shape == (B, d)
+        it, lab = torch.ops.unirec_amd.sample_negatives(torch.empty(B, dtype=torch.int64), torch.empty(B, dtype=torch.int64), 4, N, None, None, 1, 0)
+        assert it.shape == (B, 5) and lab.dtype == torch.int32
+        u, s, p, n = torch.ops.unirec_amd.rows_plan(seq.reshape(-1), ids.reshape(-1), N)
+        assert u.shape == (B * L + B * G,) and s.shape == (B * L + B * G + 1,) and n.shape == (1,)
+        ug = torch.ops.unirec_amd.rows_reduce(u, s, p, n, dr, coef.reshape(-1), ue, B * L, G, d)
+        assert ug.shape == (B * L + B * G, d)
+        m, v = torch.empty_like(table), torch.empty_like(table)
+        assert torch.ops.unirec_amd.sparse_adam_rows(table, m, v, None, u, n, ug, None, 1e-3, 1) is None
+        assert torch.ops.unirec_amd.dense_adam(dense, dg, torch.empty_like(dense), torch.empty_like(dense), None, 1e-3, 1) is None
+        r, ts = torch.ops.unirec_amd.full_rank(ue, table, ids[:, 0], None, None, None, None, None)
+        assert r.dtype == torch.int32 and r.shape == (B,)
+        sc2, id2 = torch.ops.unirec_amd.full_topk(ue, table, 7, None, None, None, None, None)
+        assert sc2.shape == (B, 7) and id2.dtype == torch.int64

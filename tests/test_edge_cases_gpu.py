@@ -86,3 +86,34 @@ def test_gru_small_shapes_both_recurrence_paths(B, L, H):
 def test_mf_single_row_and_two_item_catalogue():
     _run("MF", {}, 1, 1, 2, 2, loss="bpr")
     _run("MF", dict(has_user_bias=True, has_item_bias=True, tau=0.5), 6, 1, 5, 11, loss="bpr")
+
+
+def test_torch_ops_dispatch_to_the_same_kernels():
+    """torch.ops.unirec_amd.* (unirec_amd/torch_ops.py) are the ctypes calls behind a dispatcher schema: same results, bit for bit,
+    and they survive torch.compile's tracing (fullgraph: no graph break at the custom ops)."""
+    import unirec_amd.torch_ops  # noqa: F401
+    from unirec_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    N, d, B, L, G, I = 500, 64, 9, 12, 5, 128
+    table = torch.randn(N, d, device=dev, generator=g) * 0.1
+    table[0] = 0
+    ids = torch.randint(1, N, (B, G), device=dev, generator=g)
+    assert torch.equal(torch.ops.unirec_amd.embedding_gather(table, ids), table[ids])
+    cfg = ops.sasrec_cfg(B, L, d, 4, I, 2, "swish", True, 1e-10)
+    offs, total = ops.sasrec_param_layout(cfg)
+    dense = torch.randn(total, device=dev, generator=g) * 0.05
+    seq = torch.randint(1, N, (B, L), device=dev, generator=g, dtype=torch.int32)
+    seq[:, :3] = 0
+    ws = torch.ops.unirec_amd.sasrec_workspace(seq, d, 4, I, 2, 0.0)
+    ue = torch.ops.unirec_amd.sasrec_fwd(table, dense, seq, ws, 4, I, 2, "swish", True, 1e-10)
+    want = ops.sasrec_fwd(cfg, table, dense, seq, ops.sasrec_workspace(cfg, dev))
+    assert torch.equal(ue, want)
+    sc, _, lo = torch.ops.unirec_amd.gather_dot_loss_fwd(ue, table, ids, None, None, None, None, "bpr")
+    sc2, _, lo2 = ops.gather_dot_loss_fwd(ops.loss_cfg(B, G, d, "bpr"), ue, table, ids)
+    assert torch.equal(sc, sc2) and torch.equal(lo[:1], lo2[:1])
+
+    @torch.compile(fullgraph=True, backend="eager")
+    def f(t, i):
+        return torch.ops.unirec_amd.embedding_gather(t, i) * 2.0
+    assert torch.equal(f(table, ids), table[ids] * 2.0)

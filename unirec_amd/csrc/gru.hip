@@ -321,7 +321,7 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
   UR_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * H, st));
   if (gru_seq_supported(H)) {   // the whole recurrence in one launch
-    ProfScope ps(PC_GRU, st, 0);
+    ProfScope ps(PC_GRU, st, 2.0 * B * L * 3.0 * H * H);   // h_{t-1} W_hh^T of every step
     const dim3 grid(cdiv(B, GRU_SEQ_ROWS));
 #define GO(HH) hipLaunchKernelGGL((gru_seq_fwd_kernel<HH>), grid, dim3(HH * 4), 0, st, w.gi, dense + lay.w_hh, dense + lay.b_hh, B, L, w.h_all, \
                                   w.r, w.z, w.n, w.hn)
@@ -368,7 +368,7 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   g.A = d_user_emb; g.lda = d; g.W = w.w_dT; g.ldw = d; g.C = w.dh; g.ldc = H; g.M = B; g.N = H; g.K = d;
   if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
   if (gru_seq_supported(H)) {   // the whole backward sweep in one launch
-    ProfScope ps(PC_GRU, st, 0);
+    ProfScope ps(PC_GRU, st, 2.0 * B * L * 3.0 * H * H);   // dgh_t W_hh of every step
     const dim3 grid(cdiv(B, GRU_SEQ_ROWS));
 #define GO(HH) hipLaunchKernelGGL((gru_seq_bwd_kernel<HH>), grid, dim3(HH * 4), 0, st, w.dh, dense + lay.w_hh, w.r, w.z, w.n, w.hn, w.h_all, B, L, \
                                   w.dgi, w.dgh)

@@ -249,7 +249,8 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             owner_grads[name] = ops.rows_reduce(c["own"], grads_in, None, None, 1, d, zero_tail=self.grad_clip is not None)
         # ---- 5. dense gradients + bias gradients + flags: ONE flat all-reduce (sum)
         model.finish_backward()
-        pieces = [model.dense_flat.grad.reshape(-1)]
+        dgrad = model.dense_flat.grad if model.dense_flat.grad is not None else torch.zeros_like(model.dense_flat.data)   # (MF: no dense parameters)
+        pieces = [dgrad.reshape(-1)]
         bias_full = []
         for p, gid in bias_ctx:       # compact bias gradient -> the bias vector's own index space
             g = torch.zeros_like(p.data)

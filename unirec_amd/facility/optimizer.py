@@ -203,7 +203,9 @@ class SparseDenseAdam:
         model.finish_backward()
         if self.grad_clip is not None:
             ss = self._scalars[0:1]
-            ops.sumsq(model.dense_flat.grad, ss, accumulate=False, ws=self._sumsq_ws)
+            ss.zero_()
+            if model.dense_flat.grad is not None and model.dense_flat.grad.numel():    # (MF: no dense encoder parameters)
+                ops.sumsq(model.dense_flat.grad, ss, accumulate=True, ws=self._sumsq_ws)
             for p in self.extra:
                 if p.grad is not None:
                     ops.sumsq(p.grad, ss, accumulate=True, ws=self._sumsq_ws)
