@@ -401,21 +401,37 @@ def gather_microbench(table, device):
     idx = torch.randint(1, N, (n,), device=device)
     ops.embedding_gather(table, idx[:1024])
     torch.cuda.synchronize()
-    best = None
+    times = []
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = ops.embedding_gather(table, idx)
         e1.record()
         e1.synchronize()
-        ms = e0.elapsed_time(e1)
-        best = ms if best is None else min(best, ms)
+        times.append(e0.elapsed_time(e1))
         del out
+    best, med = min(times), sorted(times)[len(times) // 2]
     read = n * (d * 4 + 8) / (best * 1e-3) / 1e9
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of the same two launches (tools/gather_pmc.sh: FETCH_SIZE x 2 per
+    # the gfx950 note, + WRITE_SIZE; separate passes, kernel trace only): counters cannot be read from inside this process
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_b_gather_pmc.json")
+    pmc = json.load(open(pmc_path)).get("per_kernel", {}) if os.path.exists(pmc_path) else {}
+
+    def traffic(tag):
+        for k, v in pmc.items():
+            if tag in k and "FETCH_SIZE" in v:
+                tot = v["TCC_HIT_sum"] + v["TCC_MISS_sum"] if "TCC_HIT_sum" in v else 0
+                tlb = v.get("TCP_UTCL1_TRANSLATION_MISS_sum", 0) + v.get("TCP_UTCL1_TRANSLATION_HIT_sum", 0)
+                return {"hbm_read_bytes": int(2 * v["FETCH_SIZE"] * 1024), "hbm_write_bytes": int(v.get("WRITE_SIZE", 0) * 1024),
+                        "l2_hit_rate": round(v["TCC_HIT_sum"] / tot, 3) if tot else None,
+                        "l1_tlb_miss_rate": round(v.get("TCP_UTCL1_TRANSLATION_MISS_sum", 0) / tlb, 3) if tlb else None,
+                        "source": "profiles/r02_b_gather_pmc.json (same launch shape)"}
+        return None
     copy = {"bound": "hbm", "kernel": "gather_kernel<int64,32,4> (gather that WRITES the rows back: n*d*4 B of stores compete for HBM; non-temporal loads and stores)",
             "achieved": round(read, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(read / HBM_PEAK_GBPS, 4),
             "read_plus_write_GBps": round(n * (2 * d * 4 + 8) / (best * 1e-3) / 1e9, 1), "n_lookups": n, "table_rows": N,
-            "ms": round(best, 4), "traffic": None}
+            "ms": round(best, 4), "ms_median": round(med, 4), "median_GBps": round(n * (d * 4 + 8) / (med * 1e-3) / 1e9, 1),
+            "algorithmic_read_bytes": n * (d * 4 + 8), "traffic": traffic("gather_kernel") if (N == 100_000_000 and d == 128) else None}
     # the gather the training path actually uses for candidates: fused gather-dot scorer (rows are consumed in
     # registers, one float written per row) -- C3-shaped: G = 1001 candidates per row
     B, G = 4096, 1001
@@ -425,20 +441,24 @@ def gather_microbench(table, device):
     ids = torch.randint(1, N, (B, G), device=device)
     ops.gather_dot_loss_fwd(cfg, user, table, ids)
     torch.cuda.synchronize()
-    best2 = None
+    times2 = []
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         ops.gather_dot_loss_fwd(cfg, user, table, ids)
         e1.record()
         e1.synchronize()
-        ms = e0.elapsed_time(e1)
-        best2 = ms if best2 is None else min(best2, ms)
+        times2.append(e0.elapsed_time(e1))
+    best2, med2 = min(times2), sorted(times2)[len(times2) // 2]
     n2 = B * G
     read2 = n2 * (d * 4 + 8) / (best2 * 1e-3) / 1e9
     copy["fused_gather_dot"] = {"bound": "hbm", "kernel": "scorer_loss_fwd_kernel<32,8> (gather + dot, scores only; 8 rows in flight per lane group, non-temporal row loads)",
                                 "achieved": round(read2, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": round(read2 / HBM_PEAK_GBPS, 4), "n_lookups": n2, "table_rows": N, "ms": round(best2, 4)}
+                                "frac": round(read2 / HBM_PEAK_GBPS, 4), "n_lookups": n2, "table_rows": N, "ms": round(best2, 4),
+                                "ms_median": round(med2, 4), "median_GBps": round(n2 * (d * 4 + 8) / (med2 * 1e-3) / 1e9, 1),
+                                "frac_median": round(n2 * (d * 4 + 8) / (med2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                "algorithmic_read_bytes": n2 * (d * 4 + 8),
+                                "traffic": traffic("scorer_loss_fwd") if (N == 100_000_000 and d == 128) else None}
     return copy
 
 

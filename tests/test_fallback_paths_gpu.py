@@ -38,3 +38,14 @@ def test_chunked_topk_and_32_row_gemm_tiles():
     _run({"UR_TOPK_NO_PRUNE": "1"}, [os.path.join(HERE, "test_full_rank.py"), "-k", "topk and not overflow and not 3200003 and not 2200000"],
          expect_min_passed=5)
     _run({"UR_GEMM_C64": "0", "UR_SASREC_SIDE": "0"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden"], expect_min_passed=20)
+
+
+def test_round2_schedules_keep_reference_parity():
+    """Round-2 alternatives of the default schedule: the one-workgroup id sort (the chunk-sort path is the default), the stand-alone
+    LayerNorm-backward launches (the fused GEMM epilogue is the default), and the opt-in row-chain kernels -- each must pass the
+    reference goldens and the oracle comparisons."""
+    _run({"UR_PLAN_ONEWG": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_sharded.py"), "-k", "rows_plan or golden or world1"],
+         expect_min_passed=20)
+    _run({"UR_SASREC_NO_LNFUSE": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)
+    _run({"UR_SASREC_CHAIN": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_trainer_gpu.py"),
+                                    "-k", "golden or larger_random or skip_padding or sasrec or SASRec"], expect_min_passed=20)

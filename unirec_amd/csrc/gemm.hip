@@ -371,8 +371,15 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
   return launch_nt<64, 128, PRO, EPI>(a, st);
 }
 
-constexpr int LNBWD_BM = 32;   // rows per tile of the EPI_ADD_LNBWD launches (one tile row = one LayerNorm row: BN = 128)
-int gemm_nt_lnbwd_tiles(int M) { return cdiv(M, LNBWD_BM); }
+// Rows per tile of the launches whose epilogue needs whole rows (LayerNorm forward / backward: BN = 128 = one row).  UR_GEMM_LNTILE
+// = 32 / 64 / 128 (tuning aid).  One 32 x 32 accumulator per wave (32-row tiles) leaves 16 dependent MFMAs between two barriers and
+// twice the LDS bytes per MFMA of the 64 x 64 register block of the 128-row tile.
+static int ln_tile_rows() {
+  static const int v = getenv("UR_GEMM_LNTILE") ? atoi(getenv("UR_GEMM_LNTILE")) : 32;
+  return v;
+}
+static int lnbwd_bm(int M) { return (M > 1024 && ln_tile_rows() != 32) ? ln_tile_rows() : 32; }
+int gemm_nt_lnbwd_tiles(int M) { return cdiv(M, lnbwd_bm(M)); }
 
 int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return UR_OK;
@@ -383,6 +390,12 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
     return fail(UR_ERR_ARG, "gemm_nt: N, K and all leading dimensions must be multiples of 4 (N=%d K=%d)", a.N, a.K);
   if (epi == EPI_BIAS_RES_LN) {
     if (a.N > 256 || a.ldc != a.N) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm needs N<=256 (N=%d)", a.N);
+    if (a.N <= 128 && !small_m(a) && ln_tile_rows() == 128)
+      return pro == PRO_ACT ? launch_nt<128, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
+                            : launch_nt<128, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
+    if (a.N <= 128 && !small_m(a) && ln_tile_rows() == 64)
+      return pro == PRO_ACT ? launch_nt<64, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
+                            : launch_nt<64, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
     if (a.N <= 128 && (small_m(a) || a.m_dev))
       return pro == PRO_ACT ? launch_nt<32, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
                             : launch_nt<32, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
@@ -395,7 +408,11 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
     if (a.N > 128 || pro != PRO_NONE || !a.xhat || !a.rstd || !a.gamma || !a.ln_part)
       return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm backward needs N <= 128 and xhat / rstd / gamma / ln_part (N=%d)", a.N);
     const_cast<GemmArgs&>(a).M_host = a.M;
-    return launch_nt<LNBWD_BM, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
+    switch (lnbwd_bm(a.M)) {
+      case 128: return launch_nt<128, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
+      case 64: return launch_nt<64, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
+      default: return launch_nt<32, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
+    }
   }
   if (pro == PRO_ACT) {
     if (epi == EPI_BIAS) return dispatch_tile<PRO_ACT, EPI_BIAS>(a, st);

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void heads_write_kernel(const unsigned* __rest
 // ---- the whole plan in ONE launch for small batches (n <= SMALL_N): one workgroup of 16 waves runs the same
 // wave-granular stable LSD sort with its histograms in LDS and the key / value ping-pong in (L2-resident) global
 // scratch.  16 launches (~120 us of launch floors at n = 28 K) become one (~25 us).
+constexpr int SMALL_N_MID = 32768;            // (= SMALL_N; named apart because the chunk-sort kernels are defined further up)
 constexpr int SMALL_IT = 32;                  // 64-key groups per wave
 constexpr int SMALL_N = 16 * SMALL_IT * 64;   // = 32768
 constexpr int SW = 16;   // waves in the single workgroup
@@ -701,6 +702,93 @@ static inline int bits_for(long long n_rows) {
   return b;
 }
 
+// ---- small batches (n <= SMALL_N = 32 768 ids: every training batch of the benchmark shapes), three launches on many CUs:
+//   1. plan_chunk_sort_kernel : a workgroup per 2048-id chunk builds the keys and sorts (key, position) pairs in LDS (bitonic network
+//      on the packed 64-bit value key << 11 | local position: all values distinct, so the order of equal keys IS the lookup order);
+//   2. plan_chunk_rank_kernel : a thread per id; its final position = its place in its own chunk + for every OTHER chunk the number of
+//      ids that precede it there (upper bound in earlier chunks, lower bound in later ones: stable) -- <= 15 independent branch-free
+//      bisections over L2-resident 8 KB chunks, all in flight together; the id and its key are scattered to that position;
+//   3. plan_heads_kernel : run heads -> uniq_idx / seg_start / n_uniq (/ per-owner counts).
+// Replaces the one-workgroup LSD radix sort (plan_small_kernel: 4 passes of global round trips on ONE CU, 205 us at n = 28 161;
+// UR_PLAN_ONEWG=1 restores it) wherever the sort is not hidden under the previous step: first step, no lookahead, evaluation,
+// the row-sharded step.  Same output, bit for bit.
+constexpr int MID_CHUNK = 2048;
+
+__global__ __launch_bounds__(1024) void plan_chunk_sort_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
+                                                               long long n_b, int W, long long n_local, unsigned* __restrict__ ckeys,
+                                                               int* __restrict__ cpos, int* __restrict__ owner_counts) {
+  __shared__ unsigned long long s[MID_CHUNK];
+  const int tid = threadIdx.x;
+  const long long n = n_a + n_b, base = (long long)blockIdx.x * MID_CHUNK;
+  if (owner_counts && blockIdx.x == 0)
+    for (int i = tid; i < W; i += 1024) owner_counts[i] = 0;
+#pragma unroll
+  for (int q = 0; q < MID_CHUNK / 1024; ++q) {
+    const int i = tid + q * 1024;
+    const long long g = base + i;
+    unsigned key = 0xFFFFFFFFu;   // padding of the last chunk: sorts behind every real key
+    if (g < n) {
+      const long long id = (g < n_a) ? (long long)ids_a[g] : ids_b[g - n_a];
+      key = (W > 1) ? (id ? (unsigned)((id % W) * n_local + id / W + 1) : 0u) : (unsigned)id;
+    }
+    s[i] = ((unsigned long long)key << 11) | (unsigned)i;
+  }
+  __syncthreads();
+  for (int k = 2; k <= MID_CHUNK; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1)), p = i | j;   // the tid-th compare-exchange pair of this stage
+      const bool up = (i & k) == 0;
+      const unsigned long long a = s[i], b = s[p];
+      if ((a > b) == up) {
+        s[i] = b;
+        s[p] = a;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+  for (int q = 0; q < MID_CHUNK / 1024; ++q) {
+    const int i = tid + q * 1024;
+    ckeys[base + i] = (unsigned)(s[i] >> 11);
+    cpos[base + i] = (int)(base + (long long)(s[i] & 2047u));
+  }
+}
+
+// 16 lanes per id, lane q bisects chunk q: the 12 dependent loads of a bisection are the whole latency chain of the kernel (a thread per
+// id with 15 chains in flight ran 120 workgroups for 38 us; this runs 1920 for the same number of loads).
+__global__ __launch_bounds__(256) void plan_chunk_rank_kernel(const unsigned* __restrict__ ckeys, const int* __restrict__ cpos, int n,
+                                                              int nchunks, int* __restrict__ sorted_pos, int* __restrict__ keys_sorted) {
+  constexpr int MAXC = SMALL_N_MID / MID_CHUNK;   // 16 lanes per id
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int g = t / MAXC, cc = t % MAXC;          // id (chunk-sorted order), the chunk this lane searches
+  const bool live = g < nchunks * MID_CHUNK;
+  const int gg = live ? g : 0;
+  const int orig = cpos[gg];
+  const unsigned key = ckeys[gg];
+  const int c = gg / MID_CHUNK;
+  int cnt = 0;
+  if (live && orig < n && cc < nchunks && cc != c) {
+    const unsigned* a = ckeys + cc * MID_CHUNK;
+    const bool le = cc < c;                       // earlier chunk: equal keys precede (stable); later chunk: they follow
+    int pos = 0;
+#pragma unroll
+    for (int step = MID_CHUNK / 2; step >= 1; step >>= 1) {
+      const unsigned v = a[pos + step - 1];
+      pos += (le ? v <= key : v < key) ? step : 0;
+    }
+    const unsigned v = a[pos];                    // the 2048th key
+    cnt = pos + ((le ? v <= key : v < key) ? 1 : 0);
+  }
+  cnt += __shfl_xor(cnt, 1, 64);
+  cnt += __shfl_xor(cnt, 2, 64);
+  cnt += __shfl_xor(cnt, 4, 64);
+  cnt += __shfl_xor(cnt, 8, 64);
+  if (live && orig < n && cc == 0) {
+    const int rank = (gg - c * MID_CHUNK) + cnt;
+    sorted_pos[rank] = orig;
+    keys_sorted[rank] = (int)key;
+  }
+}
+
 struct PlanWs {
   unsigned *keys0, *keys1;
   int *vals_tmp, *hist, *counts;
@@ -715,9 +803,10 @@ static PlanWs carve_plan(long long n, char* base) {
     return p;
   };
   const long long nwaves = (n + CH - 1) / CH;
-  w.keys0 = (unsigned*)take(n * 4);
-  w.keys1 = (unsigned*)take(n * 4);
-  w.vals_tmp = (int*)take(n * 4);
+  const long long np = n + MID_CHUNK;   // (the chunk-sort path pads the last chunk with sentinel keys)
+  w.keys0 = (unsigned*)take(np * 4);
+  w.keys1 = (unsigned*)take(np * 4);
+  w.vals_tmp = (int*)take(np * 4);
   w.hist = (int*)take(nwaves * RADIX * 4);
   w.counts = (int*)take((nwaves + 1) * 4);
   w.bytes = o;
@@ -777,7 +866,8 @@ __global__ __launch_bounds__(256) void plan_merge_rank_kernel(const int* __restr
 }
 // heads of the runs of equal keys -> uniq_idx / seg_start / n_uniq   (one workgroup; thread t owns a contiguous slice)
 __global__ __launch_bounds__(1024) void plan_merge_heads_kernel(const int* __restrict__ keys_sorted, int n, int* __restrict__ uniq_idx,
-                                                               int* __restrict__ seg_start, int* __restrict__ n_uniq_dev) {
+                                                               int* __restrict__ seg_start, int* __restrict__ n_uniq_dev,
+                                                               int* __restrict__ owner_counts = nullptr, long long n_local = 1) {
   __shared__ int cnt[1024];
   const int tid = threadIdx.x, per = (n + 1023) / 1024;
   const int b = min(n, tid * per), e = min(n, b + per);
@@ -796,6 +886,7 @@ __global__ __launch_bounds__(1024) void plan_merge_heads_kernel(const int* __res
     if (p == 0 || keys_sorted[p] != keys_sorted[p - 1]) {
       uniq_idx[u] = keys_sorted[p];
       seg_start[u] = p;
+      if (owner_counts) atomicAdd(&owner_counts[(unsigned)keys_sorted[p] / n_local], 1);
       ++u;
     }
   if (tid == 1023) {
@@ -849,6 +940,20 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
   vbuf[passes & 1] = sorted_pos;       // after `passes` swaps the result sits in index (passes & 1)
   vbuf[(passes & 1) ^ 1] = w.vals_tmp;
   static const bool no_small = getenv("UR_PLAN_MULTI") != nullptr;   // test hook: force the multi-launch path
+  static const bool one_wg = getenv("UR_PLAN_ONEWG") != nullptr;     // the one-workgroup radix sort instead of the chunk-sort path
+  if (n <= SMALL_N && !no_small && !one_wg) {
+    const int nch = cdiv(n, MID_CHUNK);
+    hipLaunchKernelGGL(plan_chunk_sort_kernel, dim3(nch), dim3(1024), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b, W,
+                       n_local, w.keys0, w.vals_tmp, owner_counts_dev);
+    UR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(plan_chunk_rank_kernel, dim3(cdiv((long long)nch * MID_CHUNK * (SMALL_N / MID_CHUNK), 256)), dim3(256), 0, st, w.keys0, w.vals_tmp, (int)n, nch,
+                       sorted_pos, (int*)w.keys1);
+    UR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(1), dim3(1024), 0, st, (const int*)w.keys1, (int)n, uniq_idx, seg_start, n_uniq_dev,
+                       owner_counts_dev, n_local);
+    UR_LAUNCH_CHECK();
+    return UR_OK;
+  }
   if (n <= SMALL_N && !no_small) {
     hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(1024), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b, W,
                        n_local, passes, kbuf[0], kbuf[1], vbuf[0], vbuf[1], uniq_idx, seg_start, n_uniq_dev, owner_counts_dev);
