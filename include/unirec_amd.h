@@ -285,6 +285,14 @@ int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_pos, const 
 int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
                    const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
                    const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, void* stream);
+/* ur_rows_reduce followed by ur_sparse_adam_rows (below) in ONE launch: every unique row's gradient is summed (same order) and the
+ * optimizer rule applied to the row on the spot -- uniq_grad is never written.  For the step without gradient clipping (the norm
+ * needs every gradient first): embedding_dense_backward + optimizer.step on the touched rows, unirec/facility/trainer.py:346-349.
+ * Arguments as the two calls it replaces; grad_scale_dev as in ur_sparse_adam_rows (< 0: the step is skipped). */
+int ur_rows_reduce_adam(const struct UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, const int32_t* uniq_idx,
+                        const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n, const float* rows_a,
+                        int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d, const float* grad_scale_dev,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam as built at unirec/facility/trainer.py:134-136 and stepped at :349;

@@ -80,6 +80,7 @@ SIGNATURES = {
     "ur_rows_plan_sharded": (C.c_int, [P, I64, P, I64, I64, I32, P, P, P, P, P, P, P]),
     "ur_compact_index": (C.c_int, [P, P, P, I64, I64, P, P, P]),
     "ur_rows_reduce": (C.c_int, [P, P, P, P, I64, P, I64, P, P, I32, I32, P, P, P]),
+    "ur_rows_reduce_adam": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, P, P, I64, P, I64, P, P, I32, I32, P, P]),
     "ur_dense_adam": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, P, P]),
     "ur_sparse_adam_rows": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, P, I32, P, P]),
     "ur_lazy_adam_catchup": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, I32, P]),

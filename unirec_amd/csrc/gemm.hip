@@ -187,7 +187,13 @@ __device__ __forceinline__ void epilogue_from_lds(const float* Cs, int m0, int n
 // PF = global-load prefetch distance in K-steps (register slots).  1: the next tile is in flight during the current
 // one (enough when several workgroups share a CU); 4: for launches with few workgroups (M <= 1024 rows), where nothing
 // else hides the L2/HBM round trip of every K-step.
-template <int BM, int BN, int PRO, int EPI, int BK = 32, int PF = 1>
+// PIPE = 1: software-pipelined K loop.  With one or two 32 x 32 accumulators per wave a K-step is 16-32 dependent MFMAs between two
+// barriers, and the schedule above exposes, per step, the LDS round trip of the fragment reads, the global -> LDS hand-over and the
+// HBM latency of operands that are not cache resident (one slice of loads in flight per workgroup).  Here the three are taken off
+// the MFMA chain: a ring of THREE LDS stages (tile t is stored during step t-2, its fragments are read into a second register set
+// during step t-1 -- underneath that step's MFMAs -- and multiplied during step t), and two register sets for the global loads, issued
+// FOUR steps ahead.  Same K order, same results.
+template <int BM, int BN, int PRO, int EPI, int BK = 32, int PF = 1, int PIPE = 0>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   constexpr int LS = BK + 4;            // padded LDS row stride (floats): conflict-free ds_read_b128 for BK = 16 and 32
   constexpr int C4N = BK / 4;           // float4 columns per tile row
@@ -262,12 +268,87 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 
   const int nk = (a.K + BK - 1) / BK;
   const int dbg = a.debug;
+  const int frow = lane & 31, fk = 4 * (lane >> 5);
+  if constexpr (PIPE) {
+    constexpr int NKK = BK / 8;
+    float* As3 = smem;                  // [3][BM*LS]
+    float* Ws3 = smem + 3 * BM * LS;    // [3][BN*LS]
+    float4 ga[2][AV], gw[2][WV];        // global-load register sets
+    float4 fa[2][NKK][TM], fb[2][NKK][TN];
+    auto load_g = [&](int kt, int set) {
+      const int k = kt * BK;
+      if (k + c4 * 4 < a.K) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) ga[set][i] = *(const float4*)(Ap[i] + k);
+#pragma unroll
+        for (int i = 0; i < WV; ++i) gw[set][i] = *(const float4*)(Wp[i] + k);
+      } else {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) ga[set][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < WV; ++i) gw[set][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto store_r = [&](int ring, int set) {
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        float4 v = ga[set][i];
+        if (PRO == PRO_ACT) v = act4(v, a.act);
+        *(float4*)(As3 + ring * BM * LS + (lrow + RPT * i) * LS + c4 * 4) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < WV; ++i) *(float4*)(Ws3 + ring * BN * LS + (lrow + RPT * i) * LS + c4 * 4) = gw[set][i];
+    };
+    auto read_f = [&](int ring, int fs) {
+      const float* Ab = As3 + ring * BM * LS + (wr * (BM / WM) + frow) * LS + fk;
+      const float* Wb = Ws3 + ring * BN * LS + (wc * (BN / WN) + frow) * LS + fk;
+#pragma unroll
+      for (int q = 0; q < NKK; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[fs][q][i] = *(const float4*)(Ab + i * 32 * LS + q * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[fs][q][j] = *(const float4*)(Wb + j * 32 * LS + q * 8);
+      }
+    };
+    load_g(0, 0);
+    if (nk > 1) load_g(1, 1);
+    store_r(0, 0);
+    if (nk > 1) store_r(1, 1);
+    if (nk > 2) load_g(2, 0);
+    if (nk > 3) load_g(3, 1);
+    __syncthreads();
+    read_f(0, 0);
+    int ring = 0;   // ring slot of tile kt
+    for (int kt0 = 0; kt0 < nk; kt0 += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kt = kt0 + u;
+        if (kt >= nk) break;
+        const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
+        if (kt + 1 < nk) read_f(r1, u ^ 1);   // next step's fragments: in flight underneath this step's MFMAs
+#pragma unroll
+        for (int q = 0; q < NKK; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][q][i].x, fb[u][q][j].x, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][q][i].y, fb[u][q][j].y, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][q][i].z, fb[u][q][j].z, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][q][i].w, fb[u][q][j].w, acc[i][j], 0, 0, 0);
+            }
+        if (kt + 2 < nk) store_r(r2, u);        // tile kt+2 (loaded two steps ago into set u)
+        if (kt + 4 < nk) load_g(kt + 4, u);     // four steps ahead, into the set just stored
+        __syncthreads();
+        ring = r1;
+      }
+    }
+  } else {
 #pragma unroll
   for (int u = 0; u < PF; ++u)
     if (u < nk) load_global(u, u);
   store_lds(0, 0);
   __syncthreads();
-  const int frow = lane & 31, fk = 4 * (lane >> 5);
   for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {   // tile kt lives in register slot kt % PF == u (kt0 is a multiple of PF)
@@ -298,6 +379,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
       __syncthreads();
     }
   }
+  }
 
   if (dbg & 1) {   // tuning aid: no epilogue at all (keeps the accumulators alive through one dummy store)
     if (acc[0][0][0] == 123456.789f) a.C[0] = acc[0][0][1];
@@ -324,25 +406,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   epilogue_from_lds<BM, BN, EPI>(Cs, m0, n0, tid, a);
 }
 
-template <int BM, int BN, int PRO, int EPI, int BK = 32, int PF = 1>
+template <int BM, int BN, int PRO, int EPI, int BK = 32, int PF = 1, int PIPE = 0>
 static int launch_nt(const GemmArgs& a, hipStream_t st) {
   constexpr int LS = BK + 4;
   const long long nblk = 8LL * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN);
   if (nblk * 256 >= (1LL << 32)) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: %lld workgroups exceed HIP's 2^32-thread grid limit", nblk);
   dim3 grid((unsigned)nblk);
-  size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
+  size_t lds = (size_t)(PIPE ? 3 : 2) * (BM + BN) * LS * sizeof(float);
   const size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
   if (cs > lds) lds = cs;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI, BK, PF>,
+  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI, BK, PF, PIPE>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, PRO, EPI, BK, PF>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, PRO, EPI, BK, PF, PIPE>), grid, dim3(256), lds, st, a);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }
 
 // Few rows (the last-row layer, the GRU's per-step GEMM): 64-row tiles leave most CUs idle and each workgroup MFMA-bound
 // on its own K loop (M = 512, N = 128, K = 512: 8 workgroups x 13.7 us of MFMA).  32-row tiles double the workgroups.
+// software-pipelined K loop (gemm_nt_kernel PIPE = 1) for the many-row launches: UR_GEMM_PIPE=0 / 1
+static bool pipe_on(const GemmArgs& a) {
+  static const int v = getenv("UR_GEMM_PIPE") ? atoi(getenv("UR_GEMM_PIPE")) : 0;
+  return v != 0 && a.M > 1024;
+}
+
 static bool small_m(const GemmArgs& a) {
   static const int force = getenv("UR_GEMM_SMALLM") ? atoi(getenv("UR_GEMM_SMALLM")) : -1;   // tuning aid: 0 = never, 1 = always
   if (force >= 0) return force == 1;
@@ -361,11 +449,13 @@ static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
   // ... as 64 x 64 tiles (same workgroup count as 32 x 128, 16 KB instead of 20 KB of operands per K-step: measured 1 % of the
   // step); UR_GEMM_C64=0 restores the 32-row tiles
   static const int c64 = getenv("UR_GEMM_C64") ? atoi(getenv("UR_GEMM_C64")) : 1;   // tuning aid
-  if (a.m_dev && a.N <= 128 && a.N > 64 && c64 == 1) return launch_nt<64, 64, PRO, EPI>(a, st);
+  if (a.m_dev && a.N <= 128 && a.N > 64 && c64 == 1)
+    return pipe_on(a) ? launch_nt<64, 64, PRO, EPI, 32, 1, 1>(a, st) : launch_nt<64, 64, PRO, EPI>(a, st);
   if (a.m_dev && a.N <= 128) return launch_nt<32, 128, PRO, EPI>(a, st);
   // short K, wide N (QKV, FFN-1, d-act): the 16-deep K-step variant keeps 4 workgroups per CU resident and measured
   // 6-10 % faster at M = 25600; elsewhere the 32-deep step wins
-  if (force == 16 || (force == 0 && a.K <= 128 && a.N >= 256)) return launch_nt<64, 128, PRO, EPI, 16>(a, st);
+  if (force == 16 || (force == 0 && a.K <= 128 && a.N >= 256))
+    return pipe_on(a) ? launch_nt<64, 128, PRO, EPI, 16, 1, 1>(a, st) : launch_nt<64, 128, PRO, EPI, 16>(a, st);
   if (force == 1616) return launch_nt<128, 128, PRO, EPI, 16>(a, st);
   if (force == 128 || (force == 0 && big >= 512)) return launch_nt<128, 128, PRO, EPI>(a, st);
   return launch_nt<64, 128, PRO, EPI>(a, st);
@@ -396,6 +486,9 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
     if (a.N <= 128 && !small_m(a) && ln_tile_rows() == 64)
       return pro == PRO_ACT ? launch_nt<64, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
                             : launch_nt<64, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
+    if (a.N <= 128 && a.m_dev && pipe_on(a))
+      return pro == PRO_ACT ? launch_nt<32, 128, PRO_ACT, EPI_BIAS_RES_LN, 32, 1, 1>(a, st)
+                            : launch_nt<32, 128, PRO_NONE, EPI_BIAS_RES_LN, 32, 1, 1>(a, st);
     if (a.N <= 128 && (small_m(a) || a.m_dev))
       return pro == PRO_ACT ? launch_nt<32, 128, PRO_ACT, EPI_BIAS_RES_LN>(a, st)
                             : launch_nt<32, 128, PRO_NONE, EPI_BIAS_RES_LN>(a, st);
@@ -411,7 +504,8 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
     switch (lnbwd_bm(a.M)) {
       case 128: return launch_nt<128, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
       case 64: return launch_nt<64, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
-      default: return launch_nt<32, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
+      default: return pipe_on(a) ? launch_nt<32, 128, PRO_NONE, EPI_ADD_LNBWD, 32, 1, 1>(a, st)
+                                 : launch_nt<32, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
     }
   }
   if (pro == PRO_ACT) {

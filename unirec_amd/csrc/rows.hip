@@ -398,16 +398,53 @@ __device__ __forceinline__ void long_walk(float4 (&acc)[MAXV], int first, int en
   }
 }
 
+// FUSE: the optimizer update of the row rides behind its segment sum (ur_rows_reduce_adam): uniq_grad never exists in memory, one
+// launch instead of two, and the row's (w, m, v) loads are issued BEFORE the walk over its lookups, so the two dependent chains
+// (plan entry -> position -> gradient row; plan entry -> table row) run side by side.
+struct RowsFuse {
+  AdamK a;
+  float4 *table, *mom, *var;
+  int* last_step;
+  const float* scale_dev;
+};
+__device__ __forceinline__ void lazy_replay4(float4& w, float4& m, float4& v, int from, int to, const AdamK& a);
+template <int TPR>
+__device__ __forceinline__ void fuse_update(const RowsFuse& f, long long row, int last, float4 (&w)[MAXV], float4 (&m)[MAXV], float4 (&v)[MAXV],
+                                            const float4 (&gr)[MAXV], float scale, float bc1, float bc2s, int d4, int t) {
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = t + k * TPR;
+    if (c < d4) {
+      if (f.last_step) lazy_replay4(w[k], m[k], v[k], last, f.a.step - 1, f.a);
+      opt_elem(w[k].x, m[k].x, v[k].x, gr[k].x * scale, f.a, bc1, bc2s);
+      opt_elem(w[k].y, m[k].y, v[k].y, gr[k].y * scale, f.a, bc1, bc2s);
+      opt_elem(w[k].z, m[k].z, v[k].z, gr[k].z * scale, f.a, bc1, bc2s);
+      opt_elem(w[k].w, m[k].w, v[k].w, gr[k].w * scale, f.a, bc1, bc2s);
+      f.table[row * d4 + c] = w[k];
+      f.mom[row * d4 + c] = m[k];
+      f.var[row * d4 + c] = v[k];
+    }
+  }
+  if (f.last_step && t == 0) f.last_step[row] = f.a.step;
+}
+
 // One lane group per unique id; positions are summed in sorted (= lookup) order.  Runs longer than LONG_SEG are
 // handled by all groups of the block together: group g takes positions s+g, s+g+groups, ..., the partial sums are
 // combined through LDS in group order -- still a fixed summation order, so results are bit-reproducible.
-template <int TPR>
+template <int TPR, bool FUSE = false>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict__ uniq_idx, const int* __restrict__ seg_start,
                                                           const int* __restrict__ sorted_pos, const int* __restrict__ n_uniq_dev,
                                                           long long n, const float4* __restrict__ rows_a, long long n_a,
                                                           const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G,
-                                                          int d4, float4* __restrict__ out, int zero_tail) {
+                                                          int d4, float4* __restrict__ out, int zero_tail, RowsFuse fz = RowsFuse{}) {
   constexpr int groups = 256 / TPR;
+  float fscale = 1.f, bc1 = 1.f, bc2s = 1.f;
+  if constexpr (FUSE) {
+    fscale = fz.scale_dev ? *fz.scale_dev : 1.0f;
+    if (fscale < 0.f) return;   // update guard: NaN loss, the whole step is skipped (see dense_adam_kernel)
+    bc1 = 1.f - powf(fz.a.b1, (float)fz.a.step);
+    bc2s = sqrtf(1.f - powf(fz.a.b2, (float)fz.a.step));
+  }
   __shared__ float4 part[groups][MAXV * TPR];
   __shared__ int long_list[256];
   __shared__ int long_cnt;
@@ -435,13 +472,28 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
     float4 acc[MAXV];
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (uniq_idx[u] != 0) {
+    const long long frow = uniq_idx[u];
+    float4 fw[MAXV], fm[MAXV], fv[MAXV];
+    int flast = 0;
+    if constexpr (FUSE) {      // the row's state: in flight during the walk below
+      flast = fz.last_step ? fz.last_step[frow] : fz.a.step - 1;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int c = min(t + k * TPR, d4 - 1);
+        fw[k] = fz.table[frow * d4 + c]; fm[k] = fz.mom[frow * d4 + c]; fv[k] = fz.var[frow * d4 + c];
+      }
+    }
+    if (frow != 0) {
       const int s = seg_start[u], e = seg_start[u + 1];
       if (e - s > LONG_SEG) continue;                      // pass 2
       if (e - s >= 8 && d4 <= TPR)   // a medium run: the pipelined walk, this lane group alone (step 1)
         long_walk<TPR, 1>(acc, s, e, 1, sorted_pos, n_a, rows_a, coef_b, vec_b, G, d4, t);
       else
         for (int q = s; q < e; ++q) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
+    }
+    if constexpr (FUSE) {
+      if (frow != 0) fuse_update<TPR>(fz, frow, flast, fw, fm, fv, acc, fscale, bc1, bc2s, d4, t);
+      continue;
     }
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
@@ -477,17 +529,31 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
       for (int k = 0; k < MAXV; ++k) part[g][k * TPR + t] = acc[k];
       __syncthreads();
       if (g == 0) {
+        float4 rs[MAXV];
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
           const int c = t + k * TPR;
+          rs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (c < d4) {
             float4 r = part[0][k * TPR + t];
             for (int gg = 1; gg < groups; ++gg) {
               const float4 x = part[gg][k * TPR + t];
               r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
             }
-            out[ul * d4 + c] = r;
+            rs[k] = r;
+            if constexpr (!FUSE) out[ul * d4 + c] = r;
           }
+        }
+        if constexpr (FUSE) {
+          const long long lrow = uniq_idx[ul];
+          const int ll = fz.last_step ? fz.last_step[lrow] : fz.a.step - 1;
+          float4 lw[MAXV], lm[MAXV], lv[MAXV];
+#pragma unroll
+          for (int k = 0; k < MAXV; ++k) {
+            const int c = min(t + k * TPR, d4 - 1);
+            lw[k] = fz.table[lrow * d4 + c]; lm[k] = fz.mom[lrow * d4 + c]; lv[k] = fz.var[lrow * d4 + c];
+          }
+          fuse_update<TPR>(fz, lrow, ll, lw, lm, lv, rs, fscale, bc1, bc2s, d4, t);
         }
       }
       __syncthreads();
@@ -1048,6 +1114,36 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
 #define GO(T) hipLaunchKernelGGL((rows_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
                                  (long long)n, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,          \
                                  (float4*)uniq_grad, zero_tail)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_rows_reduce_adam(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, const int32_t* uniq_idx,
+                                   const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n,
+                                   const float* rows_a, int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d,
+                                   const float* grad_scale_dev, void* stream) {
+  UR_REQUIRE(cfg != nullptr && cfg->step >= 1, UR_ERR_ARG, "ur_rows_reduce_adam: cfg");
+  UR_REQUIRE(table && m && v && uniq_idx && seg_start && sorted_pos && n_uniq_dev, UR_ERR_ARG, "ur_rows_reduce_adam: null pointer");
+  UR_REQUIRE(n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_rows_reduce_adam: n=%lld n_a=%lld", (long long)n, (long long)n_a);
+  UR_REQUIRE((rows_a || n_a == 0) && ((coef_b && vec_b && G > 0) || n_a == n), UR_ERR_ARG, "ur_rows_reduce_adam: missing source");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512, UR_ERR_ARG, "ur_rows_reduce_adam: d=%d", d);
+  hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_ADAM, st, (double)n * d * 4.0 * 2 + (double)n * d * 4.0 * 6);
+  RowsFuse fz{AdamK{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo}, (float4*)table, (float4*)m,
+              (float4*)v, last_step, grad_scale_dev};
+  const int tpr = pick_tpr(d), groups = 256 / tpr;
+  int blocks = cdiv(n, groups);
+  if (blocks > 8192) blocks = 8192;
+#define GO(T) hipLaunchKernelGGL((rows_reduce_kernel<T, true>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
+                                 (long long)n, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,                \
+                                 (float4*)nullptr, 0, fz)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

@@ -50,6 +50,8 @@ class SparseDenseAdam:
                     st["last"] = None      # fullsoftmax: a dense [N,d] gradient every step -> plain dense Adam on this table
                 self.tables[name] = st
         self._plans = {}
+        import os
+        self._fuse = os.environ.get("UR_ROWS_FUSE") == "1"
         self._prefetched, self._side = None, None
         self._scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [0] sumsq, [1] clip coef
         self._sumsq_ws = torch.empty(2048, dtype=torch.float32, device=dev)
@@ -171,6 +173,11 @@ class SparseDenseAdam:
         self.t += 1
         cfg = self._cfg(self.t)
         reduced = {}
+        guard = getattr(model, "loss_guard", None)
+        # without clipping nothing needs the row gradients but the row update itself: segment sum + optimizer rule can be ONE launch per
+        # table (ur_rows_reduce_adam, UR_ROWS_FUSE=1).  Off by default: measured at C5 the fused launch takes what the two take together
+        # (37.3 us vs 11.2 + 26.3: the update is bound by the random 512-byte rows of w, m, v, not by the launch or the gradient round trip)
+        fuse = self.grad_clip is None and self._fuse
         for name, st in self.tables.items():
             ids_a, rows, ids_b, coef, vec, G = self._collect(name)
             if ids_a is None and ids_b is None:
@@ -181,6 +188,9 @@ class SparseDenseAdam:
                     raise RuntimeError("lazy_dense mode: call optimizer.plan_batch(...) before the forward pass")
                 pl = ops.rows_plan(ids_a.contiguous() if ids_a is not None else None, ids_b, st["w"].shape[0])
             d = st["w"].shape[1]
+            if fuse and name not in model.dense_table_grads:
+                ops.rows_reduce_adam(cfg, st["w"], st["m"], st["v"], pl, rows, coef, vec, G, st["last"], guard)
+                continue
             reduced[name] = (pl, ops.rows_reduce(pl, rows, coef, vec, G, d, zero_tail=self.grad_clip is not None))
         # fullsoftmax: the table's gradient is dense; the encoder's row-sparse part is folded into it
         dense_tables = dict(model.dense_table_grads)
@@ -190,7 +200,6 @@ class SparseDenseAdam:
                 ops.rows_scatter_add(pl, ug, dg)
         # NaN guard (trainer.py:343-350: a step whose loss is NaN is not applied): the loss kernels left a device flag
         # (1, or -1 for NaN) that the update kernels read as their gradient scale -- < 0 = return untouched; no host round trip
-        guard = getattr(model, "loss_guard", None)
         scale = guard
         sparse_done = False
         if self.grad_clip is None:

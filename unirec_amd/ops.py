@@ -268,6 +268,18 @@ def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False) -> t
     return out
 
 
+def rows_reduce_adam(cfg, table, m, v, pl: RowsPlan, rows_a, coef_b, vec_b, G, last_step=None, grad_scale=None):
+    """rows_reduce + sparse_adam_rows in one launch (no uniq_grad tensor): include/unirec_amd.h: ur_rows_reduce_adam."""
+    _chk(table, torch.float32, "table")
+    _chk(rows_a, torch.float32, "rows_a", allow_none=True)
+    _chk(coef_b, torch.float32, "coef_b", allow_none=True)
+    _chk(vec_b, torch.float32, "vec_b", allow_none=True)
+    _chk(last_step, torch.int32, "last_step", allow_none=True)
+    check(lib.ur_rows_reduce_adam(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos),
+                                  _p(pl.n_uniq), pl.n, _p(rows_a), pl.n_a, _p(coef_b), _p(vec_b), int(G), table.shape[1], _p(grad_scale),
+                                  _stream()), "ur_rows_reduce_adam")
+
+
 # --------------------------------------------------------------------------------------------- optimizer
 OPT_ALGOS = {"adam": 0, "adamw": 1, "sgd": 2, "adagrad": 3, "rmsprop": 4}
 # torch's defaults for what the reference does not pass (trainer.py:134-152): (beta1, beta2 | alpha, eps)
