@@ -109,6 +109,13 @@ __device__ __forceinline__ void epilogue_from_lds(const float* Cs, int m0, int n
             const float4 h2 = *(const float4*)(a.aux2 + (long long)m * a.ldaux2 + n);
             v.x += h2.x; v.y += h2.y; v.z += h2.z; v.w += h2.w;
           }
+          if (a.out_rows) {   // scatter-accumulate: row m is ADDED onto row out_rows[m] of C (distinct rows; replaces a scatter-add launch)
+            float* dst = a.C + (long long)a.out_rows[m] * a.ldc + n;
+            const float4 old = *(const float4*)dst;
+            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+            *(float4*)dst = v;
+            continue;
+          }
         }
         if (EPI == EPI_COUNT_GT) {
           // full-item ranking: nothing is stored; count the columns of this tile whose score (acc + bias[n]) beats the

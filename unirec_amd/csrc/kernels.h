@@ -77,6 +77,7 @@ struct GemmArgs {
   DropSpec drop;                 // EPI_BIAS_RES_LN: t = dropout(acc + bias) + res  (thresh == 0: off)
   const long long* skip; long long skip_base;   // EPI_COUNT_GT: column skip[m] - skip_base of row m is left out (nullable)
   int debug;                     // tuning aid (UR_GEMM_DEBUG): 1 = skip epilogue, 2 = skip K-loop global loads
+  // EPI_ADD with out_rows: C[out_rows[m], :] += acc + aux[m, :] (rows of out_rows distinct).
   // EPI_ADD_LNBWD: xhat / rstd are INPUTS here (saved by the forward pass); out_rows (nullable) scatters row m of the result to row
   // out_rows[m] of C; ln_part [gemm_nt_lnbwd_tiles(M)][2 N] receives the partial sums (every slot is written); M_host = the M
   // the grid was sized for (set by gemm_nt)

@@ -556,10 +556,18 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       if ((rc = tn(lw.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
       g = GemmArgs{};   // (the small weight-gradient GEMMs of this layer are forked together, once, below)
       g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = B; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
-      if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
-      if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, B, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb,
-                       nullptr, nullptr, nullptr, &d_out, lw.g_tad)))
-        return rc;
+      if (lnfuse) {   // the attention block's LayerNorm backward in this GEMM's epilogue (as in the full layers below)
+        g.C = lw.g_ta; g.xhat = lw.ahat; g.rstd = lw.rstd1; g.gamma = p.g1; g.ln_part = lnfuse_part(i);
+        if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc;
+        if (rb.full(2) && (rc = reduce_batch(rb, st))) return rc;
+        rb.add(g.ln_part, 2 * d, gemm_nt_lnbwd_tiles(B), d, d, G + o[8], d);
+        rb.add(g.ln_part + d, 2 * d, gemm_nt_lnbwd_tiles(B), d, d, G + o[9], d);
+      } else {
+        if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
+        if ((rc = ln_bwd(w.g_a, lw.ahat, lw.rstd1, p.g1, nullptr, nullptr, B, d, lw.g_ta, G + o[8], G + o[9], ln_take(), st, &rb,
+                         nullptr, nullptr, nullptr, &d_out, lw.g_tad)))
+          return rc;
+      }
       if ((rc = tn(lw.g_tad, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
       g = GemmArgs{};
       g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
@@ -573,12 +581,10 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       g.A = lw.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = 2 * d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
       g = GemmArgs{};   // rows L-1 additionally get dq Wq + the residual branch of the attention LayerNorm
-      if (compact) {   // last rows are irregularly spaced: dq Wq + g_ta into a [B,d] buffer, then add it onto those rows
-        g.A = w.dq_last; g.lda = d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.t_last; g.ldc = d; g.M = B; g.N = d; g.K = d;
-        g.aux = lw.g_ta; g.ldaux = d;
+      if (compact) {   // last rows are irregularly spaced: dq Wq + g_ta is scatter-accumulated onto them by the epilogue
+        g.A = w.dq_last; g.lda = d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = B; g.N = d; g.K = d;
+        g.aux = lw.g_ta; g.ldaux = d; g.out_rows = w.last_row;
         if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
-        hipLaunchKernelGGL(scatter_add_rows_idx_kernel, dim3(cdiv((long long)B * d, 256)), dim3(256), 0, st, w.t_last, w.last_row, B, d, w.g_y);
-        UR_LAUNCH_CHECK();
         continue;
       }
       float* gy_last = w.g_y + (long long)(c.L - 1) * d;   // in place on the strided last rows (each element: one thread reads then writes it)
