@@ -183,15 +183,14 @@ int ur_pool_rows_bwd(const float* d_user_emb, const int64_t* seq_len, float alph
  * debugging); returns the previous setting.  Default 1 (also: environment UR_SASREC_SIDE=0). */
 int ur_sasrec_set_side_stream(int on);
 
-/* Row-chain kernels (csrc/rowchain.hip), an OPTIONAL schedule: for d in {32, 64, 128} with inner_size % d == 0, ur_sasrec_fwd can run everything
- * behind the attention of a full-sequence layer -- out-projection + residual + LayerNorm (unirec/model/modules.py:312-316),
- * dense_1, activation, dense_2 + residual + LayerNorm (:347-355) and the NEXT layer's Q/K/V projection (:285-287) -- as one
- * launch with the intermediate tiles in LDS, and ur_sasrec_bwd the mirror image (two LayerNorm backwards + three
- * activation-gradient GEMMs in one launch; the input-gradient GEMM of the projection with the embedding LayerNorm's backward
- * in its epilogue).  Same K order as the stand-alone GEMMs.  1 switches them on, 0 restores the one-GEMM-per-launch path;
- * returns the previous setting.  Default 0 -- on the benchmark shapes they do not beat the launches they replace (DESIGN.md
- * section 6d has the measurements) -- also: environment UR_SASREC_CHAIN=1. */
-int ur_sasrec_set_chain(int on);
+/* Row-chain kernels (csrc/rowchain.hip), alternative schedules of the same arithmetic for d in {32, 64, 128} with inner_size % d == 0.
+ * `mask` bit 1: ur_sasrec_fwd runs everything behind the attention of a full-sequence layer -- out-projection + residual + LayerNorm
+ * (unirec/model/modules.py:312-316), dense_1, activation, dense_2 + residual + LayerNorm (:347-355) and the NEXT layer's Q/K/V projection
+ * (:285-287) -- as one launch with the intermediate tiles in LDS; bit 2: ur_sasrec_bwd runs the mirror image (two LayerNorm backwards +
+ * three activation-gradient GEMMs) as one launch; bit 4: the input-gradient GEMM of the projection with the embedding LayerNorm's backward
+ * in its epilogue as a chain launch.  Same K order as the stand-alone GEMMs.  Returns the previous mask.  The default mask and the
+ * measurements behind it: DESIGN.md section 6d; environment UR_SASREC_CHAIN=<mask>. */
+int ur_sasrec_set_chain(int mask);
 
 /* ---------------------------------------------------------------------------------------------
  * GRU user encoder (unirec/model/sequential/gru.py:13-35; arithmetic of torch.nn.GRU, 1 layer, batch_first,

@@ -42,10 +42,11 @@ def test_chunked_topk_and_32_row_gemm_tiles():
 
 def test_round2_schedules_keep_reference_parity():
     """Round-2 alternatives of the default schedule: the one-workgroup id sort (the chunk-sort path is the default), the stand-alone
-    LayerNorm-backward launches (the fused GEMM epilogue is the default), and the opt-in row-chain kernels -- each must pass the
+    LayerNorm-backward launches (the fused GEMM epilogue is the default), and the row-chain kernels switched all off / all on (forward only is the default) -- each must pass the
     reference goldens and the oracle comparisons."""
     _run({"UR_PLAN_ONEWG": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_sharded.py"), "-k", "rows_plan or golden or world1"],
          expect_min_passed=20)
     _run({"UR_SASREC_NO_LNFUSE": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)
-    _run({"UR_SASREC_CHAIN": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_trainer_gpu.py"),
-                                    "-k", "golden or larger_random or skip_padding or sasrec or SASRec"], expect_min_passed=20)
+    for mask in ("0", "7"):     # no chain kernels at all / forward + backward + projection chains (default: forward only)
+        _run({"UR_SASREC_CHAIN": mask}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_trainer_gpu.py"),
+                                         "-k", "golden or larger_random or skip_padding or sasrec or SASRec"], expect_min_passed=20)

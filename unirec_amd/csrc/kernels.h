@@ -109,9 +109,11 @@ struct TransposeBatch {
 int transpose_batch(TransposeBatch& tb, hipStream_t st);   // every queued transpose in one launch
 
 // ---- rowchain.hip: row-block chain kernels (a workgroup carries BM token rows through a sequence of GEMMs, tiles in LDS)
-bool chain_supported(int d, int inner);   // d in {32, 64, 128}, inner % d == 0, switched on (UR_SASREC_CHAIN=1 / ur_sasrec_set_chain)
+constexpr int CHAIN_FWD = 1, CHAIN_BWD = 2, CHAIN_PROJ = 4;
+constexpr int CHAIN_DEFAULT = CHAIN_FWD;  // which chain kernels run by default (UR_SASREC_CHAIN / ur_sasrec_set_chain: bit mask); DESIGN.md 6d
+bool chain_supported(int d, int inner, int which);   // d in {32, 64, 128}, inner % d == 0, and the bit(s) `which` switched on
 int chain_rows_per_block(int d);
-int chain_set_enabled(int on);            // on < 0: query only; returns the previous state
+int chain_set_enabled(int mask);          // mask < 0: query only; returns the previous mask
 struct ChainFwdArgs {
   const float* ctx; int ldctx;          // attention output [M, d]
   const float* res; int ldres;          // residual of the attention block = the layer input x
@@ -119,6 +121,7 @@ struct ChainFwdArgs {
   const float *w1, *b1, *w2, *b2;       // dense_1 [I,d], dense_2 [d,I]
   const float *g2, *b2ln;
   float *a, *ahat, *rstd1, *h1, *y, *yhat, *rstd2;
+  float* u;                             // nullable: act(h1) [M, I], saved for the dense_2 weight-gradient GEMM (no activation recompute there)
   const float *wn, *bn; float* outn; int ldn, Nn;   // optional: next projection y Wn^T + bn, Wn [Nn, d], Nn % d == 0
   int M; const int* m_dev;
   int I, act; float eps;

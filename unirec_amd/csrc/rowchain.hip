@@ -18,8 +18,9 @@
 // Geometry (D = d in {32, 64, 128}): BM = 4096 / D rows per workgroup, 4 waves, one 32 x 32 accumulator tile per wave and
 // GEMM (v_mfma_f32_32x32x2_f32: exact fp32), weights streamed through a double-buffered [D][32] LDS stage whose next slice
 // is in flight across GEMM boundaries (the stream of weight slices never drains inside a workgroup).  inner is walked in
-// D-wide chunks: h1 chunk -> LDS -> act -> second GEMM accumulates y over the chunks.  LDS: 70.7 KB at D = 128 (2 workgroups
-// per CU), 53 KB at D = 64.  The K order of every contraction equals gemm_nt's, so forward results are bit-identical to the
+// D-wide chunks: h1 chunk -> LDS -> act -> second GEMM accumulates y over the chunks.  LDS: 52 KB at D = 128 (unpadded, XOR-swizzled
+// activation tiles + a 16-deep weight stage: THREE workgroups per CU; the first version, 70.7 KB = two per CU, paid 2.6 us per K = 32
+// step where the stand-alone 32-row GEMM kernels, three per CU, pay 1.7), 42 KB at D = 64.  The K order of every contraction equals gemm_nt's, so forward results are bit-identical to the
 // unfused path.
 #include <stdlib.h>
 
@@ -31,37 +32,48 @@ namespace ur {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float fx4 __attribute__((ext_vector_type(4)));   // plain LLVM vector: register arrays of it are always promoted (HIP's float4 class is not, in every context)
 
-constexpr int RC_BK = 32;          // K-slice of the streamed weight tile
+constexpr int RC_BK = 16;          // K-slice of the streamed weight tile
 constexpr int RC_LS = RC_BK + 4;   // padded LDS row stride of the weight stage (conflict-free ds_read_b128)
 
 template <int D>
 struct RcGeom {
   static constexpr int BM = 4096 / D;               // token rows per workgroup
   static constexpr int WC = D / 32, WR = 4 / WC;    // wave grid: WR x WC accumulator tiles of 32 x 32 = BM x D
-  static constexpr int TS = D + 4;                  // LDS row stride of the activation tiles
+  static constexpr int TS = D;                      // LDS row stride of the activation tiles: UNPADDED, 16-byte chunks XOR-swizzled by row
+  static constexpr int SWZ = (D / 4 - 1) < 15 ? (D / 4 - 1) : 15;   // (rc_toff) -- 52 KB of LDS at D = 128: three workgroups per CU
+  static constexpr int RS = D + 4;                  // row stride of the reduction scratch laid over a dead tile
   static constexpr int TPR = D / 4;                 // lanes per row in the row-wise epilogues (one float4 each)
   static constexpr int RPP = 256 / TPR;             // rows per epilogue pass; 4 passes cover the BM rows
-  static constexpr int WV = D / 32;                 // float4 loads per thread per weight slice
+  static constexpr int WV = D >= 64 ? D / 64 : 1;   // float4 loads per thread per weight slice (D rows x 4 float4; D = 32: half the threads)
   static constexpr int TILE = BM * TS;              // floats per activation tile
   static constexpr int WST = D * RC_LS;             // floats per weight-stage buffer
   static constexpr size_t LDS_BYTES = (size_t)(2 * TILE + 2 * WST) * sizeof(float);
 };
 
+// offset (floats) of 16-byte chunk c4 of row r in a swizzled activation tile: rows are D floats apart (a multiple of the 64 banks), so the
+// chunk index is XORed with the row -- the 16 rows a ds_read_b128 lane group touches land on 16 distinct bank quads
+template <int D>
+__device__ __forceinline__ int rc_toff(int r, int c4) {
+  return r * D + ((c4 ^ (r & RcGeom<D>::SWZ)) << 2);
+}
+
 // One thread's view of a weight segment (rows row0 .. row0+D-1, columns k0 .. of a row-major matrix with leading dimension
-// ldw): the address of ITS first float4 of the segment's first K-slice.  Thread tid stages row (tid >> 3) + 32 i, float4
-// column tid & 7 of every slice.  Everything is passed by value (a struct whose address is taken ends up in scratch memory).
+// ldw): the address of ITS first float4 of the segment's first K-slice.  Thread tid stages row (tid >> 2) + 64 i, float4
+// column tid & 3 of every slice.  Everything is passed by value (a struct whose address is taken ends up in scratch memory).
+template <int D>
 __device__ __forceinline__ const float* rc_wptr(const float* W, int ldw, int row0, int k0, int tid) {
-  return W + (long long)(row0 + (tid >> 3)) * ldw + k0 + (tid & 7) * 4;
+  return W + (long long)(row0 + min(tid >> 2, D - 1)) * ldw + k0 + (tid & 3) * 4;
 }
 template <int D>
 __device__ __forceinline__ void rc_wload(fx4 (&r)[RcGeom<D>::WV], const float* p, int ldw) {
 #pragma unroll
-  for (int i = 0; i < RcGeom<D>::WV; ++i) r[i] = *(const fx4*)(p + (long long)(32 * i) * ldw);
+  for (int i = 0; i < RcGeom<D>::WV; ++i) r[i] = *(const fx4*)(p + (long long)(64 * i) * ldw);
 }
 template <int D>
 __device__ __forceinline__ void rc_wstore(const fx4 (&r)[RcGeom<D>::WV], float* buf, int tid) {
 #pragma unroll
-  for (int i = 0; i < RcGeom<D>::WV; ++i) *(fx4*)(buf + ((tid >> 3) + 32 * i) * RC_LS + (tid & 7) * 4) = r[i];
+  for (int i = 0; i < RcGeom<D>::WV; ++i)
+    if ((tid >> 2) + 64 * i < D) *(fx4*)(buf + ((tid >> 2) + 64 * i) * RC_LS + (tid & 3) * 4) = r[i];
 }
 
 // acc += As[BM, D] @ W[seg]^T, K = D in NK = D / 32 slices.  As: an LDS activation tile (row stride TS).
@@ -77,7 +89,7 @@ __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const fl
   using G = RcGeom<D>;
   constexpr int NK = D / RC_BK;
   const int frow = lane & 31, fk = 4 * (lane >> 5);
-  const float* Arow = As + (wr * 32 + frow) * G::TS + fk;
+  const int arow = wr * 32 + frow, ac0 = fk >> 2;   // this lane's tile row and the chunk offset of its K half
   if (!wnp) { wnp = wp; ldwn = ldw; }
 #pragma unroll
   for (int kt = 0; kt < NK; ++kt) {
@@ -87,11 +99,10 @@ __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const fl
       if (kt + 2 < NK) rc_wload<D>(wreg[kt & 1], wp + (kt + 2) * RC_BK, ldw);
       else rc_wload<D>(wreg[kt & 1], wnp + (kt + 2 - NK) * RC_BK, ldwn);
     }
-    const float* Ab = Arow + kt * RC_BK;
     const float* Wb = Wst + buf * G::WST + (wc * 32 + frow) * RC_LS + fk;
 #pragma unroll
     for (int kk = 0; kk < RC_BK; kk += 8) {
-      const float4 af = *(const float4*)(Ab + kk);
+      const float4 af = *(const float4*)(As + rc_toff<D>(arow, kt * (RC_BK / 4) + (kk >> 2) + ac0));
       const float4 bf = *(const float4*)(Wb + kk);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
@@ -123,7 +134,7 @@ __device__ __forceinline__ void rc_acc_to_tile(const floatx16& acc, float* T, in
   using G = RcGeom<D>;
   const int nl = wc * 32 + (lane & 31), r4 = 4 * (lane >> 5);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) T[(wr * 32 + (r & 3) + 8 * (r >> 2) + r4) * G::TS + nl] = acc[r];
+  for (int r = 0; r < 16; ++r) T[rc_toff<D>(wr * 32 + (r & 3) + 8 * (r >> 2) + r4, nl >> 2) + (nl & 3)] = acc[r];
 }
 
 __device__ __forceinline__ floatx16 zero16() {
@@ -172,18 +183,18 @@ __device__ __forceinline__ float4 rc_ln_bwd_row(float4 y, float4 h, float4 gm, f
 }
 
 // column sums of the per-thread (dg, db) over the workgroup's rows, in a fixed order -> part[0..D) = d gamma, part[D..2D) = d beta.
-// red: an LDS region of at least RPP * 2 * TS floats that nobody reads any more.  Ends with a barrier.
+// red: an LDS region of at least RPP * 2 * RS floats that nobody reads any more.  Ends with a barrier.
 template <int D>
 __device__ __forceinline__ void rc_block_colsum(float4 dg, float4 db, float* red, float* part, int eg, int et, int tid) {
   using G = RcGeom<D>;
-  *(float4*)(red + (eg * 2 + 0) * G::TS + et * 4) = dg;
-  *(float4*)(red + (eg * 2 + 1) * G::TS + et * 4) = db;
+  *(float4*)(red + (eg * 2 + 0) * G::RS + et * 4) = dg;
+  *(float4*)(red + (eg * 2 + 1) * G::RS + et * 4) = db;
   __syncthreads();
   for (int i = tid; i < 2 * D; i += 256) {
     const int which = i / D, col = i % D;
     float acc = 0.f;
 #pragma unroll 8
-    for (int g = 0; g < G::RPP; ++g) acc += red[(g * 2 + which) * G::TS + col];
+    for (int g = 0; g < G::RPP; ++g) acc += red[(g * 2 + which) * G::RS + col];
     part[i] = acc;
   }
   __syncthreads();
@@ -208,21 +219,21 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   const float inv_n = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
   int buf = 0;
-  rc_prime_load<D>(wreg, rc_wptr(a.wo, D, 0, 0, tid), D);   // the first weight slice is in flight while the ctx tile is staged
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);   // the first weight slice is in flight while the ctx tile is staged
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int ml = eg + p * G::RPP, m = m0 + ml;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (m < M) v = *(const float4*)(a.ctx + (long long)m * a.ldctx + et * 4);
-    *(float4*)(At + ml * G::TS + et * 4) = v;
+    *(float4*)(At + rc_toff<D>(ml, et)) = v;
   }
-  rc_prime_store<D>(wreg, rc_wptr(a.wo, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
+  rc_prime_store<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
   __syncthreads();
 
   // ---- 1. attention output projection + residual + LayerNorm
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr(a.wo, D, 0, 0, tid), D, rc_wptr(a.w1, D, 0, 0, tid), D, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0, tid), D, rc_wptr<D>(a.w1, D, 0, 0, tid), D, Wst, buf, wreg, tid, wr, wc, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
       const int ml = eg + p * G::RPP, m = m0 + ml;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M) {
-        float4 x = *(const float4*)(Ht + ml * G::TS + et * 4);
+        float4 x = *(const float4*)(Ht + rc_toff<D>(ml, et));
         const float4 rs = *(const float4*)(a.res + (long long)m * a.ldres + et * 4);
         if (a.drop_out.thresh) {   // t = dropout(acc + bias) + res
           x.x += bs.x; x.y += bs.y; x.z += bs.z; x.w += bs.w;
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
         *(float4*)(a.a + (long long)m * D + et * 4) = o;
         if (et == 0) a.rstd1[m] = rstd;
       }
-      *(float4*)(At + ml * G::TS + et * 4) = o;
+      *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
   }
   __syncthreads();
@@ -258,10 +269,10 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   floatx16 accy = zero16();
   const int nc = a.I / D;
   for (int c = 0; c < nc; ++c) {
-    const float* w2p = rc_wptr(a.w2, a.I, 0, c * D, tid);
+    const float* w2p = rc_wptr<D>(a.w2, a.I, 0, c * D, tid);
     {
       floatx16 acch = zero16();
-      rc_gemm<D>(acch, At, rc_wptr(a.w1, D, c * D, 0, tid), D, w2p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
+      rc_gemm<D>(acch, At, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, w2p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
       rc_acc_to_tile<D>(acch, Ht, wr, wc, lane);
     }
     __syncthreads();
@@ -270,14 +281,16 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int ml = eg + p * G::RPP, m = m0 + ml;
-        float4 v = *(const float4*)(Ht + ml * G::TS + et * 4);
+        float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
         v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
         if (m < M) *(float4*)(a.h1 + (long long)m * a.I + c * D + et * 4) = v;
-        *(float4*)(Ht + ml * G::TS + et * 4) = rc_act4(v, a.act);
+        v = rc_act4(v, a.act);
+        if (a.u && m < M) *(float4*)(a.u + (long long)m * a.I + c * D + et * 4) = v;
+        *(float4*)(Ht + rc_toff<D>(ml, et)) = v;
       }
     }
     __syncthreads();
-    const float* nxp = c + 1 < nc ? rc_wptr(a.w1, D, (c + 1) * D, 0, tid) : (a.wn ? rc_wptr(a.wn, D, 0, 0, tid) : nullptr);
+    const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w1, D, (c + 1) * D, 0, tid) : (a.wn ? rc_wptr<D>(a.wn, D, 0, 0, tid) : nullptr);
     rc_gemm<D>(accy, Ht, w2p, a.I, nxp, D, Wst, buf, wreg, tid, wr, wc, lane);
   }
 
@@ -292,8 +305,8 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
       const int ml = eg + p * G::RPP, m = m0 + ml;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M) {
-        float4 x = *(const float4*)(Ht + ml * G::TS + et * 4);
-        const float4 rs = *(const float4*)(At + ml * G::TS + et * 4);
+        float4 x = *(const float4*)(Ht + rc_toff<D>(ml, et));
+        const float4 rs = *(const float4*)(At + rc_toff<D>(ml, et));
         if (a.drop_ffn.thresh) {
           x.x += bs.x; x.y += bs.y; x.z += bs.z; x.w += bs.w;
           x = drop4(x, drop_rowkey(a.drop_ffn, m), (unsigned)(et * 4), a.drop_ffn);
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
         *(float4*)(a.y + (long long)m * D + et * 4) = o;
         if (et == 0) a.rstd2[m] = rstd;
       }
-      *(float4*)(At + ml * G::TS + et * 4) = o;
+      *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
   }
   if (!a.wn) return;
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   const int nn = a.Nn / D;
   for (int c = 0; c < nn; ++c) {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr(a.wn, D, c * D, 0, tid), D, c + 1 < nn ? rc_wptr(a.wn, D, (c + 1) * D, 0, tid) : nullptr, D, Wst, buf,
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wn, D, c * D, 0, tid), D, c + 1 < nn ? rc_wptr<D>(a.wn, D, (c + 1) * D, 0, tid) : nullptr, D, Wst, buf,
                wreg, tid, wr, wc, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
     __syncthreads();
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
     for (int p = 0; p < 4; ++p) {
       const int ml = eg + p * G::RPP, m = m0 + ml;
       if (m < M) {
-        float4 v = *(const float4*)(Ht + ml * G::TS + et * 4);
+        float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
         v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
         *(float4*)(a.outn + (long long)m * a.ldn + c * D + et * 4) = v;
       }
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   const float inv_d = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
   int buf = 0;
-  rc_prime_load<D>(wreg, rc_wptr(a.w2T, D, 0, 0, tid), D);
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.w2T, D, 0, 0, tid), D);
 
   // ---- 0. feed-forward LayerNorm backward: g_tf (also the residual branch of g_a)
   {
@@ -374,21 +387,21 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
         o = rc_ln_bwd_row<G::TPR>(y, h, gm, a.rstd2[m], inv_d, dg, db);
         *(float4*)(a.g_tf + (long long)m * D + et * 4) = o;
       }
-      *(float4*)(At + ml * G::TS + et * 4) = o;
+      *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
     rc_block_colsum<D>(dg, db, Ht, part, eg, et, tid);
   }
-  rc_prime_store<D>(wreg, rc_wptr(a.w2T, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
+  rc_prime_store<D>(wreg, rc_wptr<D>(a.w2T, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
   __syncthreads();
 
   // ---- 1. g_h1 chunk = (g_tf W2[:, chunk]) * act'(h1 chunk);   g_a += g_h1 chunk W1[chunk, :]
   floatx16 acca = zero16();
   const int nc = a.I / D;
   for (int c = 0; c < nc; ++c) {
-    const float* w1p = rc_wptr(a.w1T, a.I, 0, c * D, tid);
+    const float* w1p = rc_wptr<D>(a.w1T, a.I, 0, c * D, tid);
     {
       floatx16 accu = zero16();
-      rc_gemm<D>(accu, At, rc_wptr(a.w2T, D, c * D, 0, tid), D, w1p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
+      rc_gemm<D>(accu, At, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D, w1p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
       rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
     }
     __syncthreads();
@@ -397,15 +410,15 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
       const int ml = eg + p * G::RPP, m = m0 + ml;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M) {
-        v = *(const float4*)(Ht + ml * G::TS + et * 4);
+        v = *(const float4*)(Ht + rc_toff<D>(ml, et));
         const float4 h = *(const float4*)(a.h1 + (long long)m * a.I + c * D + et * 4);
         v.x *= act_bwd(h.x, a.act); v.y *= act_bwd(h.y, a.act); v.z *= act_bwd(h.z, a.act); v.w *= act_bwd(h.w, a.act);
         *(float4*)(a.g_h1 + (long long)m * a.I + c * D + et * 4) = v;
       }
-      *(float4*)(Ht + ml * G::TS + et * 4) = v;
+      *(float4*)(Ht + rc_toff<D>(ml, et)) = v;
     }
     __syncthreads();
-    const float* nxp = c + 1 < nc ? rc_wptr(a.w2T, D, (c + 1) * D, 0, tid) : rc_wptr(a.woT, D, 0, 0, tid);
+    const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w2T, D, (c + 1) * D, 0, tid) : rc_wptr<D>(a.woT, D, 0, 0, tid);
     rc_gemm<D>(acca, Ht, w1p, a.I, nxp, D, Wst, buf, wreg, tid, wr, wc, lane);
   }
 
@@ -420,14 +433,14 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
       const int ml = eg + p * G::RPP, m = m0 + ml;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M) {
-        float4 y = *(const float4*)(Ht + ml * G::TS + et * 4);
-        const float4 rs = *(const float4*)(At + ml * G::TS + et * 4);
+        float4 y = *(const float4*)(Ht + rc_toff<D>(ml, et));
+        const float4 rs = *(const float4*)(At + rc_toff<D>(ml, et));
         y.x += rs.x; y.y += rs.y; y.z += rs.z; y.w += rs.w;
         const float4 h = *(const float4*)(a.ahat + (long long)m * D + et * 4);
         o = rc_ln_bwd_row<G::TPR>(y, h, gm, a.rstd1[m], inv_d, dg, db);
         *(float4*)(a.g_ta + (long long)m * D + et * 4) = o;
       }
-      *(float4*)(At + ml * G::TS + et * 4) = o;
+      *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
     __syncthreads();   // every read of the staged accumulators is done: Ht becomes the reduction scratch
     rc_block_colsum<D>(dg, db, Ht, part + 2 * D, eg, et, tid);
@@ -436,14 +449,14 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   // ---- 3. g_ctx = g_ta Wo
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr(a.woT, D, 0, 0, tid), D, nullptr, 0, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0, tid), D, nullptr, 0, Wst, buf, wreg, tid, wr, wc, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int ml = eg + p * G::RPP, m = m0 + ml;
-    if (m < M) *(float4*)(a.g_ctx + (long long)m * D + et * 4) = *(const float4*)(Ht + ml * G::TS + et * 4);
+    if (m < M) *(float4*)(a.g_ctx + (long long)m * D + et * 4) = *(const float4*)(Ht + rc_toff<D>(ml, et));
   }
 }
 
@@ -470,7 +483,7 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   fx4 wreg[2][G::WV];
   int buf = 0;
   const int nkc = a.K / D;
-  rc_prime_load<D>(wreg, rc_wptr(a.wT, a.ldw, 0, 0, tid), a.ldw);
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.wT, a.ldw, 0, 0, tid), a.ldw);
   float4 ra[4];
   auto load_a = [&](int kc) {
 #pragma unroll
@@ -481,17 +494,17 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   };
   auto store_a = [&]() {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *(float4*)(At + (eg + p * G::RPP) * G::TS + et * 4) = ra[p];
+    for (int p = 0; p < 4; ++p) *(float4*)(At + rc_toff<D>(eg + p * G::RPP, et)) = ra[p];
   };
   load_a(0);
   store_a();
-  rc_prime_store<D>(wreg, rc_wptr(a.wT, a.ldw, 0, 0, tid), a.ldw, nullptr, 0, Wst, tid);
+  rc_prime_store<D>(wreg, rc_wptr<D>(a.wT, a.ldw, 0, 0, tid), a.ldw, nullptr, 0, Wst, tid);
   __syncthreads();
   floatx16 acc = zero16();
   for (int kc = 0; kc < nkc; ++kc) {
     const bool more = kc + 1 < nkc;
     if (more) load_a(kc + 1);   // the next slice of g is in flight underneath this chunk's MFMAs
-    rc_gemm<D>(acc, At, rc_wptr(a.wT, a.ldw, 0, kc * D, tid), a.ldw, more ? rc_wptr(a.wT, a.ldw, 0, (kc + 1) * D, tid) : nullptr, a.ldw,
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wT, a.ldw, 0, kc * D, tid), a.ldw, more ? rc_wptr<D>(a.wT, a.ldw, 0, (kc + 1) * D, tid) : nullptr, a.ldw,
                Wst, buf, wreg, tid, wr, wc, lane);
     if (more) {
       store_a();
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   for (int p = 0; p < 4; ++p) {
     const int ml = eg + p * G::RPP, m = m0 + ml;
     if (m < M) {
-      float4 v = *(const float4*)(Ht + ml * G::TS + et * 4);
+      float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
       if (a.res) {
         const float4 rs = *(const float4*)(a.res + (long long)m * D + et * 4);
         v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
@@ -528,19 +541,19 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
 }
 
 // =============================================================================================== launchers
-// Default OFF: measured on the C5 shapes (profiles/r02_a_chain_ab.txt) the chain kernels do not beat the launches they replace
-// (forward 126 us vs 120, backward 123 vs 121, projection 43 vs 46): one 32 x 32 accumulator per wave leaves 16 dependent MFMAs
-// between two barriers, and LDS-read latency + barrier skew cost as much as the MFMAs.  UR_SASREC_CHAIN=1 / ur_sasrec_set_chain(1)
-// switch them on (tests/test_rowchain_gpu.py keeps them covered).
-static int g_chain_on = -1;
+// Defaults (kernels.h: CHAIN_DEFAULT = forward chain only), measured in situ on C5 (profiles/r02_g_chain_masks.txt): forward chain
+// 0.834 -> 0.812 ms/step (isolated: 99 us against 138 for the four launches it replaces); with the backward chains as well the step is
+// SLOWER (0.858): three chain workgroups fill a CU's LDS, so the weight-gradient GEMMs of the side stream (67 KB each) cannot share
+// the CUs with them any more -- in the forward pass the side stream is idle and nothing is lost.
+static int g_chain_on = -1;   // bit mask: 1 forward chain, 2 backward chain, 4 projection-gradient chain
 int chain_set_enabled(int on) {
-  if (g_chain_on < 0) g_chain_on = (getenv("UR_SASREC_CHAIN") && atoi(getenv("UR_SASREC_CHAIN"))) ? 1 : 0;
+  if (g_chain_on < 0) g_chain_on = getenv("UR_SASREC_CHAIN") ? (atoi(getenv("UR_SASREC_CHAIN")) & 7) : CHAIN_DEFAULT;
   const int prev = g_chain_on;
-  if (on >= 0) g_chain_on = on ? 1 : 0;
+  if (on >= 0) g_chain_on = on & 7;
   return prev;
 }
-bool chain_supported(int d, int inner) {
-  if (!chain_set_enabled(-1)) return false;
+bool chain_supported(int d, int inner, int which) {
+  if (!(chain_set_enabled(-1) & which)) return false;
   return (d == 32 || d == 64 || d == 128) && inner % d == 0;
 }
 int chain_rows_per_block(int d) { return 4096 / d; }
@@ -559,7 +572,7 @@ static void set_lds(KernelT k, size_t bytes) {
 
 int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
   if (a.M <= 0) return UR_OK;
-  if (!chain_supported(d, a.I) || (a.wn && a.Nn % d)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd: d=%d inner=%d", d, a.I);
+  if (!chain_supported(d, a.I, 7) || (a.wn && a.Nn % d)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd: d=%d inner=%d", d, a.I);
   ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * ((double)d + 2.0 * a.I + (a.wn ? a.Nn : 0)));
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
@@ -573,7 +586,7 @@ int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
 
 int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st) {
   if (a.M <= 0) return UR_OK;
-  if (!chain_supported(d, a.I)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_bwd: d=%d inner=%d", d, a.I);
+  if (!chain_supported(d, a.I, 7)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_bwd: d=%d inner=%d", d, a.I);
   ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * ((double)d + 2.0 * a.I));
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
@@ -601,4 +614,4 @@ int chain_proj_bwd(const ChainProjBwdArgs& a, int d, hipStream_t st) {
 
 }  // namespace ur
 
-extern "C" int ur_sasrec_set_chain(int on) { return ur::chain_set_enabled(on ? 1 : 0); }
+extern "C" int ur_sasrec_set_chain(int mask) { return ur::chain_set_enabled(mask < 0 ? 0 : (mask & 7)); }

@@ -56,6 +56,7 @@ static LayerP layer_ptrs(const float* base, const Layout& l, int i) {
 // ---- workspace carving (float units, every region 64-float aligned)
 struct LayerWs {
   float *qkv, *lse, *ctx, *a, *ahat, *rstd1, *h1, *y, *yhat, *rstd2;
+  float* u;                            // act(h1), written by the forward chain kernel (the dense_2 weight-gradient GEMM reads it)
   float *wqkvT, *woT, *w1T, *w2T;
   float *g_tf, *g_ta, *g_h1, *g_qkv;   // backward: LN-backward outputs (FFN / attention block), d h1, d qkv
   float *g_tfd, *g_tad;                // hidden dropout on: dropout-masked g_tf / g_ta (what the block's GEMMs consume)
@@ -85,7 +86,7 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
   for (int i = 0; i < c.n_layers; ++i) {
     LayerWs& lw = w.layer[i];
     lw.qkv = take(M * 3 * d); lw.lse = take(attn_lse_floats(c.B, c.n_heads, c.L)); lw.ctx = take(M * d);
-    lw.a = take(M * d); lw.ahat = take(M * d); lw.rstd1 = take(M); lw.h1 = take(M * I);
+    lw.a = take(M * d); lw.ahat = take(M * d); lw.rstd1 = take(M); lw.h1 = take(M * I); lw.u = take(M * I);
     lw.y = take(M * d); lw.yhat = take(M * d); lw.rstd2 = take(M);
     lw.wqkvT = take(3 * d * d); lw.woT = take(d * d); lw.w1T = take(I * d); lw.w2T = take(I * d);
     // backward scratch that the weight-gradient GEMMs read: per layer, written once per backward pass, so those GEMMs
@@ -342,7 +343,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
                     tokmap, mv, &d_emb);
   if (rc) return rc;
   const float* x = w.x0;
-  const bool chain = chain_supported(d, I);   // out-projection + LN + feed-forward + LN (+ next projection) as ONE launch per layer
+  const bool chain = chain_supported(d, I, CHAIN_FWD);   // out-projection + LN + feed-forward + LN (+ next projection) as ONE launch per layer
   bool proj_done = false;                     // this layer's K,V (Q,K,V) rows were written by the previous layer's chain kernel
   for (int i = 0; i < c.n_layers; ++i) {
     const LayerP p = layer_ptrs(dense, lay, i);
@@ -392,6 +393,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       ca.wo = p.wo; ca.bo = p.bo; ca.g1 = p.g1; ca.b1ln = p.b1ln; ca.w1 = p.w1; ca.b1 = p.b1; ca.w2 = p.w2; ca.b2 = p.b2;
       ca.g2 = p.g2; ca.b2ln = p.b2ln;
       ca.a = lw.a; ca.ahat = lw.ahat; ca.rstd1 = lw.rstd1; ca.h1 = lw.h1; ca.y = lw.y; ca.yhat = lw.yhat; ca.rstd2 = lw.rstd2;
+      ca.u = lw.u;
       ca.M = M; ca.m_dev = mv; ca.I = I; ca.act = c.act; ca.eps = c.eps;
       ca.drop_out = site_spec(c, i, DROP_SITE_OUT, tokmap);
       ca.drop_ffn = site_spec(c, i, DROP_SITE_FFN, tokmap);
@@ -448,7 +450,9 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   const int* spad = compact ? w.seq_pad : nullptr;
   // row-chain kernels (rowchain.hip) for the full-sequence layers; hidden dropout keeps the unfused path (the chain backward
   // does not carry the second, dropout-masked copy of the LayerNorm-backward outputs)
-  const bool chain_bwd = chain_supported(d, I) && c.p_hidden == 0.f;
+  const bool chain_bwd = chain_supported(d, I, CHAIN_BWD) && c.p_hidden == 0.f;
+  const bool chain_proj = chain_supported(d, I, CHAIN_PROJ) && c.p_hidden == 0.f;
+  const bool have_u = chain_supported(d, I, CHAIN_FWD);   // the forward pass of the full layers went through chain_ffn_fwd: lw.u is valid
   bool ln0_done = false;                // the embedding LayerNorm backward already ran in the epilogue of the bottom layer's last GEMM
   // LayerNorm backward in the epilogue of the GEMM that produces its input gradient (EPI_ADD_LNBWD): the attention block's
   // LayerNorm behind the d FFN-1 GEMM, the embedding LayerNorm behind the bottom layer's projection-gradient GEMM.  Two launches and
@@ -532,6 +536,47 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     }
     if ((rc = transpose_batch(tb, st))) return rc;
   }
+  // g_x = g_qkv Wqkv + g_ta as a row-chain launch (CHAIN_PROJ); for the bottom layer the backward of the embedding LayerNorm rides in
+  // the epilogue and the rows go straight to their (padded-layout) places in d_emb_rows
+  auto proj_chain = [&](int i, LayerWs& lw) -> int {
+    const int nblk = cdiv(M, chain_rows_per_block(d));
+    ChainProjBwdArgs cp{};
+    cp.g = lw.g_qkv; cp.ldg = 3 * d; cp.K = 3 * d; cp.wT = lw.wqkvT; cp.ldw = 3 * d; cp.res = lw.g_ta;
+    cp.out = w.g_y; cp.M = M; cp.m_dev = mv;
+    if (i == 0) {
+      float* part0 = w.chain_part + 4LL * c.n_layers * w.chain_blocks * d;
+      cp.xhat = w.x0hat; cp.rstd = w.rstd0; cp.gamma = dense + lay.off[1]; cp.out = d_emb_rows; cp.out_rows = compact ? w.tok_full : nullptr;
+      cp.part = part0;
+      if (rb.full(2)) {
+        int rc2 = reduce_batch(rb, st);
+        if (rc2) return rc2;
+      }
+      rb.add(part0, 2 * d, nblk, d, d, dense_grad + lay.off[1], d);
+      rb.add(part0 + d, 2 * d, nblk, d, d, dense_grad + lay.off[2], d);
+      ln0_done = true;
+    }
+    return chain_proj_bwd(cp, d, st);
+  };
+  // the projection-gradient step of a full layer: chain launch or GEMM (+ LN0 backward in its epilogue for the bottom layer)
+  auto proj_step = [&](int i, LayerWs& lw) -> int {
+    if (chain_proj) return proj_chain(i, lw);
+    int rc2;
+    GemmArgs g{};
+    g.A = lw.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = 3 * d;
+    g.aux = lw.g_ta; g.ldaux = d;
+    if (lnfuse && i == 0) {
+      // bottom layer: the embedding LayerNorm's backward rides in the epilogue, rows go straight to their (padded-layout) places
+      g.C = d_emb_rows; g.xhat = w.x0hat; g.rstd = w.rstd0; g.gamma = dense + lay.off[1]; g.out_rows = compact ? w.tok_full : nullptr;
+      g.ln_part = lnfuse_part(c.n_layers);
+      if ((rc2 = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc2;
+      if (rb.full(2) && (rc2 = reduce_batch(rb, st))) return rc2;
+      rb.add(g.ln_part, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, dense_grad + lay.off[1], d);
+      rb.add(g.ln_part + d, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, dense_grad + lay.off[2], d);
+      ln0_done = true;
+      return UR_OK;
+    }
+    return gemm_nt(g, PRO_NONE, EPI_ADD, st);
+  };
   for (int i = c.n_layers - 1; i >= 0; --i) {
     const LayerP p = layer_ptrs(dense, lay, i);
     const long long* o = lay.off + UR_SASREC_N_GLOBAL + i * UR_SASREC_N_PER_LAYER;
@@ -609,35 +654,26 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       rb.add(part + d, 4 * d, nblk, d, d, G + o[15], d);
       rb.add(part + 2 * d, 4 * d, nblk, d, d, G + o[8], d);
       rb.add(part + 3 * d, 4 * d, nblk, d, d, G + o[9], d);
-      if ((rc = tn(lw.g_tf, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
+      if ((rc = have_u ? tn(lw.g_tf, d, lw.u, I, M, d, I, 0, 0, G + o[12], I, G + o[13])
+                       : tn(lw.g_tf, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13])))
+        return rc;
       if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
       if ((rc = tn(lw.g_ta, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
       if ((rc = fork())) return rc;
       if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad, &d_attn))) return rc;
       if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
       if ((rc = fork())) return rc;
-      // g_x = g_qkv Wqkv + g_ta; for the bottom layer the backward of the embedding LayerNorm rides in the epilogue and the rows
-      // go straight to their (padded-layout) places in d_emb_rows
-      ChainProjBwdArgs cp{};
-      cp.g = lw.g_qkv; cp.ldg = 3 * d; cp.K = 3 * d; cp.wT = lw.wqkvT; cp.ldw = 3 * d; cp.res = lw.g_ta;
-      cp.out = w.g_y; cp.M = M; cp.m_dev = mv;
-      if (i == 0) {
-        float* part0 = w.chain_part + 4LL * c.n_layers * w.chain_blocks * d;
-        cp.xhat = w.x0hat; cp.rstd = w.rstd0; cp.gamma = dense + lay.off[1]; cp.out = d_emb_rows; cp.out_rows = compact ? w.tok_full : nullptr;
-        cp.part = part0;
-        if (rb.full(2) && (rc = reduce_batch(rb, st))) return rc;
-        rb.add(part0, 2 * d, nblk, d, d, dense_grad + lay.off[1], d);
-        rb.add(part0 + d, 2 * d, nblk, d, d, dense_grad + lay.off[2], d);
-        ln0_done = true;
-      }
-      if ((rc = chain_proj_bwd(cp, d, st))) return rc;
+      if ((rc = proj_step(i, lw))) return rc;
       continue;
     }
     // ---- feed-forward block
     if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb, mv,
                      nullptr, nullptr, &d_ffn, lw.g_tfd)))
       return rc;
-    if ((rc = tn(lw.g_tfd, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
+    // (the forward chain kernel saved act(h1): no activation recompute on the operand)
+    if ((rc = have_u ? tn(lw.g_tfd, d, lw.u, I, M, d, I, 0, 0, G + o[12], I, G + o[13])
+                     : tn(lw.g_tfd, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13])))
+      return rc;
     GemmArgs g{};
     g.A = lw.g_tfd; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = M; g.m_dev = mv; g.N = I; g.K = d;
     g.aux = lw.h1; g.ldaux = I; g.act = c.act;
@@ -670,21 +706,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad, &d_attn))) return rc;
     if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
     if ((rc = fork())) return rc;
-    g = GemmArgs{};
-    g.A = lw.g_qkv; g.lda = 3 * d; g.W = lw.wqkvT; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = 3 * d;
-    g.aux = lw.g_ta; g.ldaux = d;
-    if (lnfuse && i == 0) {
-      // bottom layer: the embedding LayerNorm's backward rides in the epilogue, rows go straight to their (padded-layout) places
-      g.C = d_emb_rows; g.xhat = w.x0hat; g.rstd = w.rstd0; g.gamma = dense + lay.off[1]; g.out_rows = compact ? w.tok_full : nullptr;
-      g.ln_part = lnfuse_part(c.n_layers);
-      if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc;
-      if (rb.full(2) && (rc = reduce_batch(rb, st))) return rc;
-      rb.add(g.ln_part, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, dense_grad + lay.off[1], d);
-      rb.add(g.ln_part + d, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, dense_grad + lay.off[2], d);
-      ln0_done = true;
-    } else if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) {
-      return rc;
-    }
+    if ((rc = proj_step(i, lw))) return rc;
   }
   // ---- input block: LN0 backward -> row gradients of E[item_seq] and of the position table  (x0 = dropout(LN0(.)): g_y is
   // masked on read)
