@@ -636,14 +636,15 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "launches": c["launches"],
                 "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2)}
     # HBM bytes per launch of the dominant class: PMC counters cannot be collected from inside this process, so the
-    # figure is the committed rocprofv3 --pmc summary of the SAME workload (profiles/r02_e_pmc_hbm_traffic.json:
+    # figure is the committed rocprofv3 --pmc summary of the SAME workload (profiles/r02_h_pmc_hbm_traffic.json:
     # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction); null when the summary is absent
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_e_pmc_hbm_traffic.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_h_pmc_hbm_traffic.json")
     if roof is not None and os.path.exists(pmc) and a.n_items == 100_000_000 and a.batch == 512:
         per_class = json.load(open(pmc)).get("per_class", {})
-        if dom in per_class:
+        per_class["row_chain"] = per_class.get("chain_ffn_fwd", per_class.get("row_chain", {}))
+        if dom in per_class and per_class[dom]:
             roof["traffic"] = per_class[dom]["hbm_bytes_per_launch"]
-            roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/r02_e_pmc_hbm_traffic.json)"
+            roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/r02_h_pmc_hbm_traffic.json)"
             roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * valid_frac * 1e6 / max(1, c["launches"] / max(1, (a.steps + PROF_EVERY - 1) // PROF_EVERY)))
     emb_bytes_per_example = 8 * (L + G) * d * 4   # fwd read + bwd/opt touched rows (w,m,v,grad)
     out = {
@@ -658,6 +659,12 @@ def main():
         "final_loss": round(final_loss, 6),
         "roofline": roof,
         "kernel_time_ms_per_step_warmup": {k: round(v["ms"] / max(1, n_prof), 4) for k, v in warm.items() if v["launches"]},
+        # every MFMA-bound class, from the warm-up steps where all classes are bracketed (same definition as `roofline`: algorithmic flops
+        # of the real token rows / device time of the class, in situ -- the weight-gradient GEMMs share the CUs with the main stream)
+        "mfma_classes_warmup": {k: {"TFLOPs": round(v["work"] * (valid_frac if k in ("gemm_nt", "gemm_tn", "row_chain") else 1.0) / (v["ms"] * 1e-3) / 1e12, 2),
+                                    "frac": round(v["work"] * (valid_frac if k in ("gemm_nt", "gemm_tn", "row_chain") else 1.0) / (v["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                    "launches_per_step": round(v["launches"] / max(1, n_prof), 1)}
+                                for k, v in warm.items() if k in MFMA_CLASSES and v["ms"] > 0 and v["work"] > 0},
     }
     if world > 1:
         import torch.distributed as dist

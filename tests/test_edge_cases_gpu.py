@@ -117,3 +117,34 @@ def test_torch_ops_dispatch_to_the_same_kernels():
     def f(t, i):
         return torch.ops.unirec_amd.embedding_gather(t, i) * 2.0
     assert torch.equal(f(table, ids), table[ids] * 2.0)
+
+
+def test_parameter_init_statistics_follow_the_reference_rules():
+    """SURVEY.md 8 a15 (unirec/model/base/reco_abc.py:19-58, 210-218): normal(init_mean, init_std) for embeddings and linear weights,
+    zeros for biases, ones / zeros for LayerNorm, the padding row of every table zero; nn.GRU keeps torch's U(-1/sqrt(H), 1/sqrt(H))."""
+    from unirec_amd.utils.argument_parser import parse_arguments
+    from unirec_amd.utils.general import get_class_instance, init_seed
+    base = dict(n_users=300, n_items=20000, device="cuda:0", embedding_size=64, hidden_size=64, inner_size=128, n_heads=4, n_layers=2,
+                max_seq_len=20, init_method="normal", init_mean=0.0, init_std=0.02, hidden_dropout_prob=0.0, attn_dropout_prob=0.0, seed=1)
+    init_seed(1)
+    m = get_class_instance("SASRec", "unirec_amd/model")(parse_arguments(dict(base, model="SASRec")))
+    sd = m.state_dict()
+    tab = sd["item_embedding.weight"]
+    assert not tab[0].any() and abs(float(tab[1:].mean())) < 5e-4 and abs(float(tab[1:].std()) - 0.02) < 5e-4
+    for k, v in sd.items():
+        if k.endswith("LayerNorm.weight"):
+            assert torch.equal(v, torch.ones_like(v)), k
+        elif k.endswith(".bias"):
+            assert not v.any(), k
+        elif k.endswith(".weight") and v.dim() == 2 and "embedding" not in k:
+            assert abs(float(v.mean())) < 3e-3 and abs(float(v.std()) - 0.02) < 2e-3, (k, float(v.std()))
+    assert abs(float(sd["position_embedding.weight"].std()) - 0.02) < 3e-3
+    init_seed(1)
+    g = get_class_instance("GRU", "unirec_amd/model")(parse_arguments(dict(base, model="GRU", hidden_size=64)))
+    bound = 1.0 / 8.0
+    for k, v in g.state_dict().items():
+        if k.startswith("gru_layers."):
+            assert float(v.abs().max()) <= bound and abs(float(v.std()) - bound / 3 ** 0.5) < 0.01, k     # U(-b, b): std = b / sqrt(3)
+    x = get_class_instance("SASRec", "unirec_amd/model")(parse_arguments(dict(base, model="SASRec", init_method="xavier_normal")))
+    w = x.state_dict()["trm_encoder.layer.0.feed_forward.dense_1.weight"]      # [128, 64]: std = sqrt(2 / (128 + 64))
+    assert abs(float(w.std()) - (2.0 / 192) ** 0.5) < 5e-3

@@ -178,7 +178,7 @@ def test_sasrec_larger_random_vs_oracle():
                 assert np.abs(got).max() < 1e-6 and np.abs(ref.numpy()).max() < 1e-6, k
                 continue
             scale = max(1e-8, float(np.abs(ref.numpy()).max()))
-            np.testing.assert_allclose(got / scale, ref.numpy() / scale, rtol=2e-4, atol=2e-5, err_msg=f"d={d} H={H} {k}")
+            np.testing.assert_allclose(got / scale, ref.numpy() / scale, rtol=1e-4, atol=1e-5, err_msg=f"d={d} H={H} {k}")   # the contract's 1e-4, absolute floor 1e-5 of the tensor's largest gradient
         m.sparse_grads.clear()
 
 

@@ -20,7 +20,7 @@ def per_kernel(path, counter):
 
 
 def cls(name):
-    for c in ("gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "attn_last", "ln_bwd", "sparse_adam", "reduce_batch", "scorer_loss", "plan_small"):
+    for c in ("gemm_nt", "gemm_tn", "chain_ffn_fwd", "attn_fwd", "attn_bwd", "attn_last", "ln_bwd", "sparse_adam", "reduce_batch", "scorer_loss", "plan_small"):
         if c in name:
             return c
     return None

@@ -303,7 +303,13 @@ SideCtx* side_ctx(bool even_if_disabled = false) {
     const char* e = getenv("UR_SASREC_SIDE");
     if (e && atoi(e) == 0) return nullptr;
     SideCtx* c = new SideCtx();
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // UR_SASREC_SIDE_PRIO=low / high: queue priority of the side stream relative to the caller's (tuning aid; default: the same)
+    const char* pr = getenv("UR_SASREC_SIDE_PRIO");
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (pr && (pr[0] == 'l' || pr[0] == 'h')) {
+      if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest) != hipSuccess) return nullptr;
+    } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
     for (auto& ev : c->ev)
       if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) return nullptr;
