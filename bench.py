@@ -491,7 +491,13 @@ def main():
         from unirec_amd.facility.distributed import ShardedSparseDenseAdam
         from unirec_amd.sharded import shard_rows
         if not a.no_selfcheck:
-            selfcheck = multi_gpu_selfcheck(a, device, rank, world)
+            try:
+                selfcheck = multi_gpu_selfcheck(a, device, rank, world)
+            except AssertionError as e:      # a parity failure is reported in the line (and on stderr), the timing still runs
+                selfcheck = {"ok": False, "error": str(e)[:500]}
+                print(f"[bench] rank {rank}: multi-GPU self-check FAILED: {e}", file=sys.stderr)
+                import torch.distributed as dist
+                dist.barrier()
         torch.manual_seed(2022 + rank)
         model = SASRec(dict(cfg, n_items=shard_rows(a.n_items, world)))     # the model's table IS this rank's shard: the 100 M-row
         opt = ShardedSparseDenseAdam(model, rank, world, lr=1e-3, table_mode=a.table_mode,   # table never exists in one piece

@@ -255,7 +255,8 @@ class ShardedSasrecStep:
             dense_grad, d_rows = enc_bwd(cfg, compact, m.dense_flat.data, seq_c, d_user, ws)
         # 5. row gradients of the unique keys, then all-to-all #3 to the owners
         coef_b = torch.cat([coef.reshape(-1), self.zero_coef])
-        ug = ops.rows_reduce(pl, d_rows, coef_b, user_emb, G, d)[:n_uniq]
+        vec_b = torch.cat([user_emb, torch.zeros(1, d, dtype=user_emb.dtype, device=user_emb.device)])   # the trailing id-0 lookup reads row B
+        ug = ops.rows_reduce(pl, d_rows, coef_b, vec_b, G, d)[:n_uniq]
         grads_in = self.xchg.all_to_all_rows(ug, send_counts, recv_counts)
         # 6. dense parameters: one flat all-reduce (sum), mean applied inside the Adam kernel.  Issued behind the last
         #    all-to-all and waited for only before the dense update: it runs under the owner-side reduce + sparse update
