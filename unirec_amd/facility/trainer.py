@@ -253,19 +253,31 @@ class Trainer(object):
                     self.logger.info("epoch: %d, learning rate: %s", epoch_idx, self.optimizer.param_groups[0]["lr"])
             t0 = time.time()
             losses, it = [], iter(train_data)
+            epoch_sum, n_nan = 0.0, 0
+
+            def drain():      # device scalars -> host: one sync per 4096 steps (and one per epoch), not one per step
+                nonlocal epoch_sum, n_nan
+                if not losses:
+                    return
+                stacked = torch.stack(losses)
+                losses.clear()
+                nan = torch.isnan(stacked)
+                n_nan += int(nan.sum())
+                epoch_sum += float(stacked[~nan].sum())
+                self.step_losses.extend(stacked.tolist())
+
             cur = next(it, None)
             while cur is not None:          # one batch of lookahead: the next batch's plan overlaps this step
                 nxt = next(it, None)
                 losses.append(self.train_step(cur, nxt))
+                if len(losses) >= 4096:
+                    drain()
                 cur = nxt
-            stacked = torch.stack(losses)
-            nan = torch.isnan(stacked)
-            if bool(nan.any()):
-                self.logger.error("Training loss is nan in %d steps of epoch %d", int(nan.sum()), epoch_idx + 1)
-            self.step_losses.extend(stacked.tolist())   # one host sync per epoch
+            drain()
+            if n_nan:
+                self.logger.error("Training loss is nan in %d steps of epoch %d", n_nan, epoch_idx + 1)
             # reported train loss = SUM over batches of the batch loss (trainer.py:354-355)
-            self.logger.info("epoch %d training [time: %.2fs, train loss: %.4f]", epoch_idx + 1, time.time() - t0,
-                             float(stacked[~nan].sum()))
+            self.logger.info("epoch %d training [time: %.2fs, train loss: %.4f]", epoch_idx + 1, time.time() - t0, epoch_sum)
         return self.best_valid_score
 
     # ------------------------------------------------------------------ evaluation
