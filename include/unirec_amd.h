@@ -329,6 +329,15 @@ int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m, float* v, 
 int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                          const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
                          void* stream);
+/* the same catch-up issued AHEAD of a step that is still in flight (on another stream): rows in busy_idx[0..*busy_n_dev) -- the
+ * ascending unique row list of the in-flight step's plan, i.e. the rows that step reads and will update -- are left alone (the
+ * step's own update replays them); every other row of uniq_idx is brought to "after step (cfg->step - 1)", where cfg->step - 1 is
+ * the in-flight step itself.  Rows already at or past that state are skipped.  Bit-identical to running ur_lazy_adam_catchup
+ * after the step: a zero-gradient step depends on the step index only.  (Reference semantics: torch's dense Adam moves every
+ * row every step, unirec/facility/trainer.py:349.) */
+int ur_lazy_adam_catchup_ahead(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
+                               const int32_t* busy_idx, const int32_t* busy_n_dev, int64_t busy_max, void* stream);
 /* same for a contiguous block of rows [row0, row0+n): flush before evaluation / checkpoint */
 int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, int64_t row0,
                        int64_t n, int32_t d, void* stream);

@@ -1,0 +1,115 @@
+"""Lazy-Adam catch-up of the NEXT batch's rows issued ahead of time, under the step in flight (ur_lazy_adam_catchup_ahead).
+
+The reference's dense torch.optim.Adam moves every embedding row every step (unirec/facility/trainer.py:349).  The lazy table replays a
+row's missed zero-gradient steps when the row is next looked up; `SparseDenseAdam.prefetch_plan` now does that replay on the side stream
+while the current step runs, leaving the rows the current step touches to that step's own update.  A zero-gradient step depends on the
+step index only, so the trajectory must be BIT-identical to catching up at the head of the next step -- that is what is asserted here,
+on a small table (every row comes back every few steps), for Adam and AdamW-with-decay, with a prefetched batch that is then not the one
+trained on, and with steps whose loss guard skips the update.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(**kw):
+    from unirec_amd.utils.argument_parser import parse_arguments
+    return parse_arguments(dict(dict(hidden_dropout_prob=0.0, attn_dropout_prob=0.0, model="SASRec", n_users=50, n_items=300, device="cuda:0",
+                                     loss_type="bpr", embedding_size=32, hidden_size=32, inner_size=64, n_heads=4, max_seq_len=10, epochs=1,
+                                     batch_size=16, seed=4, n_sample_neg_train=4), **kw))
+
+
+def _batches(n, B=16, L=10, N=300, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for s in range(n):
+        seq = torch.randint(1, N, (B, L), generator=g, dtype=torch.int32)
+        seq[::3, : 2 + s % 4] = 0
+        out.append(dict(item_seq=seq.cuda(), item_id=torch.randint(1, N, (B, 5), generator=g).cuda()))
+    return out
+
+
+def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14):
+    """ahead: False = catch-up at the head of the next step, "side" = on the side stream under the step in flight, "tail" = on the main
+    stream between the row update and the join of the dense-gradient stream (the default)"""
+    from unirec_amd.facility.optimizer import SparseDenseAdam
+    from unirec_amd.utils.general import get_class_instance, init_seed
+    init_seed(4)
+    model = get_class_instance("SASRec", "unirec_amd/model")(_cfg())
+    opt = SparseDenseAdam(model, lr=5e-3, weight_decay=wd, algo=algo)
+    opt._ahead = ahead or ""
+    model.train()
+    bs = _batches(n_steps + 2)
+    other = _batches(3, seed=99)
+    lab = torch.zeros(16, 5, dtype=torch.int32, device="cuda:0")
+    lab[:, 0] = 1
+    losses = []
+    for s in range(n_steps):
+        b = bs[s]
+        opt.zero_grad()
+        opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
+        nxt = other[0] if swap_at == s else bs[s + 1]       # swap_at: the batch planned ahead is NOT the one trained on next
+        opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
+        loss = model.forward_backward(item_id=b["item_id"], label=lab, item_seq=b["item_seq"])
+        opt.step()
+        losses.append(float(loss))
+    opt.flush()
+    torch.cuda.synchronize()
+    st = opt.tables["item_embedding"]
+    return losses, st["w"].clone(), st["m"].clone(), st["v"].clone(), model.dense_flat.data.clone()
+
+
+@pytest.mark.parametrize("algo,wd", [("adam", 0.0), ("adamw", 0.01), ("adam", 0.001), ("rmsprop", 0.0)])
+def test_catchup_ahead_is_bit_identical(algo, wd):
+    b = _train(False, algo, wd)
+    for mode in ("side", "tail"):
+        a = _train(mode, algo, wd)
+        assert a[0] == b[0]
+        for x, y, what in zip(a[1:], b[1:], ("w", "m", "v", "dense")):
+            assert torch.equal(x, y), (mode, what, float((x - y).abs().max()))
+
+
+def test_a_prefetched_batch_that_is_not_trained_on_changes_nothing():
+    """rows caught up for a batch that is then not trained on are simply up to date earlier: the same zero-gradient steps, summed in
+    two pieces instead of one (fp32 re-association of the replay sum: a few ulp of an lr-sized term, not bit-equal)"""
+    c = _train(False)
+    for mode in ("side", "tail"):
+        a = _train(mode, swap_at=5)
+        for x, z, what in zip(a[1:4], c[1:4], ("w", "m", "v")):
+            assert torch.allclose(x, z, rtol=1e-4, atol=1e-6), (mode, what, float((x - z).abs().max()))
+
+
+def test_catchup_ahead_leaves_the_busy_rows_alone():
+    from unirec_amd import ops
+    dev = torch.device("cuda:0")
+    N, d = 2000, 32
+    g = torch.Generator(device=dev).manual_seed(0)
+    w = torch.randn(N, d, device=dev, generator=g)
+    m = torch.randn(N, d, device=dev, generator=g) * 0.01
+    v = torch.rand(N, d, device=dev, generator=g) * 1e-4
+    last = torch.full((N,), 3, dtype=torch.int32, device=dev)
+    nxt = torch.arange(100, 700, dtype=torch.int32, device=dev)
+    busy = torch.arange(400, 1000, 3, dtype=torch.int32, device=dev)
+    pl_n = ops.rows_plan(nxt, None, N)
+    pl_b = ops.rows_plan(busy, None, N)
+    w0, m0, v0 = w.clone(), m.clone(), v.clone()
+    cfg = ops.adam_cfg(1e-2, 8)                                   # in-flight step = 7: rows go to "after step 7"
+    ops.lazy_adam_catchup_ahead(cfg, w, m, v, last, pl_n, pl_b)
+    torch.cuda.synchronize()
+    is_busy = torch.zeros(N, dtype=torch.bool, device=dev)
+    is_busy[busy.long()] = True
+    moved = torch.zeros(N, dtype=torch.bool, device=dev)
+    moved[nxt.long()] = True
+    moved &= ~is_busy
+    assert torch.equal(last[moved], torch.full_like(last[moved], 7)) and torch.equal(last[~moved], torch.full_like(last[~moved], 3))
+    assert torch.equal(w[~moved], w0[~moved]) and torch.equal(m[~moved], m0[~moved]) and torch.equal(v[~moved], v0[~moved])
+    # the moved rows are what the plain catch-up gives
+    w1, m1, v1, l1 = w0.clone(), m0.clone(), v0.clone(), torch.full((N,), 3, dtype=torch.int32, device=dev)
+    ops.lazy_adam_catchup(cfg, w1, m1, v1, l1, pl_n)
+    assert torch.equal(w[moved], w1[moved]) and torch.equal(m[moved], m1[moved]) and torch.equal(v[moved], v1[moved])
+    assert not torch.equal(w[moved], w0[moved])
+    # a second call is a no-op (rows already there), and the plain catch-up never moves a row backwards
+    ops.lazy_adam_catchup_ahead(cfg, w, m, v, last, pl_n, pl_b)
+    ops.lazy_adam_catchup(ops.adam_cfg(1e-2, 5), w, m, v, last, pl_n)
+    assert torch.equal(w[moved], w1[moved]) and torch.equal(last[moved], torch.full_like(last[moved], 7))

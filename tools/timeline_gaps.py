@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows), key=lambda e: e[0])
 # a window of steady-state steps: between two launches of the once-per-step plan kernel, well inside the timed region
 import os
-MARK = os.environ.get("MARK", "plan_small_kernel")   # a kernel launched exactly once per step
+MARK = os.environ.get("MARK", "plan_chunk_sort_kernel")   # a kernel launched exactly once per step
 marks = [e[0] for e in ev if MARK in e[2]]
 n_steps = min(100, len(marks) - 12)
 t0, t1 = marks[-(n_steps + 5)], marks[-5]
@@ -43,3 +43,11 @@ if os.environ.get("SHOW"):
     key = os.environ["SHOW"]
     seqs = [(s, e - s, n) for s, e, n, q in ev if key in n]
     print(f"durations of the first 15 launches of *{key}* in the window (us):", [round(d / 1e3, 1) for _, d, _ in seqs[:15]])
+
+if os.environ.get("DUMP"):   # one steady-state step, launch by launch: start offset, duration, queue, kernel (the critical path by eye)
+    k = int(os.environ["DUMP"])
+    a, b = marks[-(k + 6)], marks[-(k + 5)]
+    print(f"one step ({(b - a)/1e3:.1f} us):")
+    for s, e, n, q in ev:
+        if a <= s < b:
+            print(f"  {(s - a)/1e3:7.1f} +{(e - s)/1e3:6.1f}  q{q}  {n[:100]}")

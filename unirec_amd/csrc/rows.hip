@@ -648,7 +648,8 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
                                                           float4* __restrict__ var, int* __restrict__ last_step,
                                                           const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
                                                           long long n_max, const float4* __restrict__ grad, int d4,
-                                                          const float* __restrict__ scale_dev) {
+                                                          const float* __restrict__ scale_dev, const int* __restrict__ busy_idx = nullptr,
+                                                          const int* __restrict__ busy_n_dev = nullptr, int busy_max = 0) {
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int n_uniq = (int)min((long long)*n_uniq_dev, n_max);
@@ -700,6 +701,21 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
     const long long row = uniq_idx[u];
     if (row == 0) continue;
     const int last = last_step ? last_step[row] : a.step - 1;
+    if (MODE == 1 && last >= a.step - 1) continue;   // already there (updated by the step in between, or caught up ahead of time)
+    if (MODE == 1 && busy_idx != nullptr) {
+      // catch-up AHEAD of the step in flight: rows that step reads and updates (the sorted unique list of its plan) are its own
+      // business -- its update replays them first; everything else can take its zero-gradient steps now.  Branch-free lower bound,
+      // every lane of the group walks the same addresses (one broadcast load per probe, the list sits in L2).
+      const int nb = min(*busy_n_dev, busy_max);
+      int lo = 0;
+      for (int len = nb; len > 0;) {
+        const int half = len >> 1;
+        const bool right = busy_idx[lo + half] < (int)row;
+        lo = right ? lo + half + 1 : lo;
+        len = right ? len - half - 1 : half;
+      }
+      if (lo < nb && busy_idx[lo] == (int)row) continue;
+    }
     if (MODE == 1 && last == 0 && a.wd == 0.f) {   // never updated: m = v = 0, every zero-gradient step is a no-op
       if (t == 0) last_step[row] = a.step - 1;
       continue;
@@ -930,36 +946,84 @@ __global__ __launch_bounds__(256) void plan_merge_rank_kernel(const int* __restr
   sorted_pos[pos] = i;
   keys_sorted[pos] = x;
 }
-// heads of the runs of equal keys -> uniq_idx / seg_start / n_uniq   (one workgroup; thread t owns a contiguous slice)
+// heads of the runs of equal keys -> uniq_idx / seg_start / n_uniq.  Workgroup b owns positions [b * HEADS_SPAN, (b + 1) * HEADS_SPAN):
+// it first COUNTS the heads in front of its span itself (coalesced loads, eight independent ones per thread in flight; the keys are a
+// few hundred KB and sit in L2), then ranks its own heads with wave ballots -- one launch, no carried state between workgroups, every
+// load independent of every other.  (The first version gave thread t a contiguous slice of n / 1024 positions in ONE workgroup: 2 x 28
+// dependent, uncoalesced loads per thread = 69 us at C5's 28 K ids.)
+constexpr int HEADS_U = 4, HEADS_SPAN = 1024 * HEADS_U;
+
+__device__ __forceinline__ int heads_block_sum(int v, int* red, int tid) {   // sum over the 1024 threads; red: 16 ints of LDS
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  int s = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) s += red[w];
+  return s;
+}
+
 __global__ __launch_bounds__(1024) void plan_merge_heads_kernel(const int* __restrict__ keys_sorted, int n, int* __restrict__ uniq_idx,
                                                                int* __restrict__ seg_start, int* __restrict__ n_uniq_dev,
                                                                int* __restrict__ owner_counts = nullptr, long long n_local = 1) {
-  __shared__ int cnt[1024];
-  const int tid = threadIdx.x, per = (n + 1023) / 1024;
-  const int b = min(n, tid * per), e = min(n, b + per);
+  __shared__ int red[16];
+  __shared__ int wcnt[HEADS_U][16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int span0 = blockIdx.x * HEADS_SPAN;
+  auto is_head = [&](int p) { return p < n && (p == 0 || keys_sorted[p] != keys_sorted[p - 1]); };
+  // heads in [0, span0)
   int c = 0;
-  for (int p = b; p < e; ++p) c += (p == 0 || keys_sorted[p] != keys_sorted[p - 1]) ? 1 : 0;
-  cnt[tid] = c;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
-    const int v = tid >= off ? cnt[tid - off] : 0;
-    __syncthreads();
-    cnt[tid] += v;
-    __syncthreads();
-  }
-  int u = cnt[tid] - c;
-  for (int p = b; p < e; ++p)
-    if (p == 0 || keys_sorted[p] != keys_sorted[p - 1]) {
-      uniq_idx[u] = keys_sorted[p];
-      seg_start[u] = p;
-      if (owner_counts) atomicAdd(&owner_counts[(unsigned)keys_sorted[p] / n_local], 1);
-      ++u;
+  for (int p0 = 0; p0 < span0; p0 += 8 * 1024) {
+    bool h[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int p = p0 + u * 1024 + tid;
+      h[u] = p < span0 && is_head(p);
     }
-  if (tid == 1023) {
-    n_uniq_dev[0] = cnt[1023];
-    seg_start[cnt[1023]] = n;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c += h[u] ? 1 : 0;
+  }
+  const int before = heads_block_sum(c, red, tid);
+  // this span
+  int key[HEADS_U], rank[HEADS_U];
+  bool h[HEADS_U];
+#pragma unroll
+  for (int u = 0; u < HEADS_U; ++u) {
+    const int p = span0 + u * 1024 + tid;
+    key[u] = p < n ? keys_sorted[p] : 0;
+    h[u] = is_head(p);
+  }
+#pragma unroll
+  for (int u = 0; u < HEADS_U; ++u) {
+    const unsigned long long m = __ballot(h[u]);
+    rank[u] = __popcll(m & ((1ULL << lane) - 1ULL));
+    if (lane == 0) wcnt[u][wv] = __popcll(m);
+  }
+  __syncthreads();
+  int total = before;
+#pragma unroll
+  for (int u = 0; u < HEADS_U; ++u) {
+    int o = total;                       // heads of every earlier position group of the span ...
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int v = wcnt[u][w];
+      o += w < wv ? v : 0;               // ... and of the earlier waves of this one
+      total += v;
+    }
+    if (h[u]) {
+      const int slot = o + rank[u];
+      uniq_idx[slot] = key[u];
+      seg_start[slot] = span0 + u * 1024 + tid;
+      if (owner_counts) atomicAdd(&owner_counts[(unsigned)key[u] / n_local], 1);
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    n_uniq_dev[0] = total;
+    seg_start[total] = n;
   }
 }
+static inline int heads_grid(long long n) { return (int)((n + HEADS_SPAN - 1) / HEADS_SPAN); }
 
 extern "C" int ur_rows_plan_merge(const int32_t* ids, int64_t n, const int32_t* host_run_start, int32_t n_runs, int32_t* uniq_idx,
                                   int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws, void* stream) {
@@ -974,7 +1038,7 @@ extern "C" int ur_rows_plan_merge(const int32_t* ids, int64_t n, const int32_t* 
   int* keys_sorted = (int*)ws;   // n ints (the plan workspace is far larger)
   hipLaunchKernelGGL(plan_merge_rank_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids, rs, (int)n, sorted_pos, keys_sorted);
   UR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(1), dim3(1024), 0, st, keys_sorted, (int)n, uniq_idx, seg_start, n_uniq_dev);
+  hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(heads_grid(n)), dim3(1024), 0, st, keys_sorted, (int)n, uniq_idx, seg_start, n_uniq_dev);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }
@@ -1015,7 +1079,7 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
     hipLaunchKernelGGL(plan_chunk_rank_kernel, dim3(cdiv((long long)nch * MID_CHUNK * (SMALL_N / MID_CHUNK), 256)), dim3(256), 0, st, w.keys0, w.vals_tmp, (int)n, nch,
                        sorted_pos, (int*)w.keys1);
     UR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(1), dim3(1024), 0, st, (const int*)w.keys1, (int)n, uniq_idx, seg_start, n_uniq_dev,
+    hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(heads_grid(n)), dim3(1024), 0, st, (const int*)w.keys1, (int)n, uniq_idx, seg_start, n_uniq_dev,
                        owner_counts_dev, n_local);
     UR_LAUNCH_CHECK();
     return UR_OK;
@@ -1157,7 +1221,8 @@ extern "C" int ur_rows_reduce_adam(const UrAdamCfg* cfg, float* table, float* m,
 
 static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* grad, int d,
-                              const float* scale, hipStream_t st) {
+                              const float* scale, hipStream_t st, const int32_t* busy_idx = nullptr,
+                              const int32_t* busy_n_dev = nullptr, int busy_max = 0) {
   ProfScope ps(PC_ADAM, st, (double)n_max * d * 4.0 * 7);
   AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
   const int tpr = pick_tpr(d), groups = 256 / tpr;
@@ -1165,7 +1230,8 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
 #define GO(T, MD) hipLaunchKernelGGL((sparse_adam_kernel<T, MD>), dim3(blocks), dim3(256), 0, st, a, (float4*)table, (float4*)m, \
-                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale)
+                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale, \
+                                     busy_idx, busy_n_dev, busy_max)
 #define SW(MD)            \
   switch (tpr) {          \
     case 4: GO(4, MD); break;   \
@@ -1204,6 +1270,18 @@ extern "C" int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m
   UR_REQUIRE(table && m && v && last_step && uniq_idx && n_uniq_dev, UR_ERR_ARG, "ur_lazy_adam_catchup: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_lazy_adam_catchup: d=%d", d);
   return launch_sparse_adam(1, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, nullptr, d, nullptr, as_stream(stream));
+}
+
+extern "C" int ur_lazy_adam_catchup_ahead(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                                          const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
+                                          const int32_t* busy_idx, const int32_t* busy_n_dev, int64_t busy_max, void* stream) {
+  int rc = check_adam(cfg, "ur_lazy_adam_catchup_ahead");
+  if (rc) return rc;
+  UR_REQUIRE(table && m && v && last_step && uniq_idx && n_uniq_dev && busy_idx && busy_n_dev, UR_ERR_ARG, "ur_lazy_adam_catchup_ahead: null pointer");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0 && busy_max > 0 && busy_max < (1LL << 31), UR_ERR_ARG,
+             "ur_lazy_adam_catchup_ahead: d=%d n_max=%lld busy_max=%lld", d, (long long)n_max, (long long)busy_max);
+  return launch_sparse_adam(1, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, nullptr, d, nullptr, as_stream(stream), busy_idx,
+                            busy_n_dev, (int)busy_max);
 }
 
 extern "C" int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, int64_t row0,

@@ -52,6 +52,11 @@ class SparseDenseAdam:
         self._plans = {}
         import os
         self._fuse = os.environ.get("UR_ROWS_FUSE") == "1"
+        # where the next batch's rows take their missed zero-gradient steps (lazy_dense): "tail" (default) = on the main stream right
+        # after this step's row update, under the tail of the dense-gradient stream the main stream would otherwise wait for idle;
+        # "side" = on the plan's side stream under the whole step in flight (measured slower: its VALU work lands on the forward
+        # pass); "" / "0" = at the head of the next step (round 1)
+        self._ahead = {"0": "", "1": "tail"}.get(os.environ.get("UR_CATCHUP_AHEAD", "tail"), os.environ.get("UR_CATCHUP_AHEAD", "tail"))
         self._prefetched, self._side = None, None
         self._scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [0] sumsq, [1] clip coef
         self._sumsq_ws = torch.empty(2048, dtype=torch.float32, device=dev)
@@ -113,12 +118,31 @@ class SparseDenseAdam:
         bufs = {name: ops.rows_plan_alloc((a.numel() if a is not None else 0) + (b.numel() if b is not None else 0),
                                           a.numel() if a is not None else 0, self.model.device) for name, (a, b) in req.items()}
         self._side.wait_stream(main)   # the ids may still be in flight (H2D copy) on the main stream
+        ahead = None
         with torch.cuda.stream(self._side):
             plans = {name: ops.rows_plan(a, b, self.tables[name]["w"].shape[0], out=bufs[name]) for name, (a, b) in req.items()}
+            if self.table_mode == "lazy_dense" and self._ahead == "side" and self.t > 0:
+                # the next batch's rows take their missed zero-gradient steps HERE, under the current step, instead of at the head
+                # of the next one (where the forward waits for them: 15-130 us of VALU work per step, growing with the revisit gap).
+                # With a step in flight (plan_batch called, step() not yet) the target state is "after that step" and the rows the
+                # step itself touches are left to its update; a zero-gradient step depends on the step index only, so the result
+                # is bit-identical to catching up afterwards.
+                in_flight = bool(self._plans)
+                ahead = self.t + (1 if in_flight else 0)
+                cfg = self._cfg(ahead + 1)
+                for name, pl in plans.items():
+                    st = self.tables[name]
+                    if st["last"] is None:
+                        continue
+                    if in_flight and name in self._plans:
+                        ops.lazy_adam_catchup_ahead(cfg, st["w"], st["m"], st["v"], st["last"], pl, self._plans[name])
+                    else:
+                        ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
             ev = torch.cuda.Event()
             ev.record(self._side)
         # keep ids + workspaces alive until the plan is adopted (the side stream reads / writes them asynchronously)
-        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev, (req, bufs))
+        # (and the in-flight step's plans: the catch-up reads their row lists after step() has dropped them)
+        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev, (req, bufs, dict(self._plans)), ahead)
 
     def plan_batch(self, item_seq=None, item_id=None, user_id=None):
         """Sort/unique the ids this batch will look up (or adopt the plan `prefetch_plan` made for the same tensors);
@@ -126,16 +150,34 @@ class SparseDenseAdam:
         pre, self._prefetched = self._prefetched, None
         if pre is not None:   # always order the main stream after the side stream's use of the prefetch buffers
             torch.cuda.current_stream().wait_event(pre[2])
+        caught_up = False
         if pre is not None and pre[0] == self._ids_key(item_seq, item_id, user_id):
             self._plans = pre[1]
+            caught_up = pre[4] == self.t      # the side stream already brought these rows to the state after step t
         else:
             self._plans = self._make_plans(item_seq, item_id, user_id)
-        if self.table_mode == "lazy_dense" and self.t > 0:
+        if self.table_mode == "lazy_dense" and self.t > 0 and not caught_up:
             cfg = self._cfg(self.t + 1)
             for name, pl in self._plans.items():
                 st = self.tables[name]
                 if st["last"] is not None:
                     ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
+
+    def _catchup_prefetched(self):
+        """step(), after the row update: the NEXT batch's rows (plan already made by `prefetch_plan`) take their zero-gradient steps
+        up to and including this one now, on the main stream, while the dense-gradient reductions are still running on the side
+        stream -- the same launch `plan_batch` would make at the head of the next step, moved into a slot where the main stream
+        has nothing else to do."""
+        pre = self._prefetched
+        if pre is None or self._ahead != "tail" or self.table_mode != "lazy_dense" or pre[4] is not None:
+            return
+        torch.cuda.current_stream().wait_event(pre[2])
+        cfg = self._cfg(self.t + 1)
+        for name, pl in pre[1].items():
+            st = self.tables[name]
+            if st["last"] is not None:
+                ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
+        self._prefetched = pre[:4] + (self.t,)
 
     def flush(self):
         """lazy_dense: apply all pending zero-gradient steps to every row (before eval / checkpoint)."""
@@ -209,6 +251,7 @@ class SparseDenseAdam:
                 st = self.tables[name]
                 ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
             sparse_done = True
+            self._catchup_prefetched()
         model.finish_backward()
         if self.grad_clip is not None:
             ss = self._scalars[0:1]

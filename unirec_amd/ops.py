@@ -314,6 +314,14 @@ def lazy_adam_catchup(cfg, table, m, v, last_step, pl: RowsPlan):
                                    table.shape[1], _stream()), "ur_lazy_adam_catchup")
 
 
+def lazy_adam_catchup_ahead(cfg, table, m, v, last_step, pl: RowsPlan, busy: RowsPlan):
+    """catch-up of `pl`'s rows to "after step cfg.step - 1" while step cfg.step - 1 is still in flight on another stream: the rows of
+    `busy` (that step's plan) are left to the step's own update (ur_lazy_adam_catchup_ahead)."""
+    _chk(last_step, torch.int32, "last_step")
+    check(lib.ur_lazy_adam_catchup_ahead(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
+                                         table.shape[1], _p(busy.uniq_idx), _p(busy.n_uniq), busy.n, _stream()), "ur_lazy_adam_catchup_ahead")
+
+
 def lazy_adam_flush(cfg, table, m, v, last_step, row0=0, n=None):
     n = table.shape[0] - row0 if n is None else n
     check(lib.ur_lazy_adam_flush(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), row0, n, table.shape[1], _stream()),
