@@ -47,6 +47,10 @@ def test_round2_schedules_keep_reference_parity():
     _run({"UR_PLAN_ONEWG": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_sharded.py"), "-k", "rows_plan or golden or world1"],
          expect_min_passed=20)
     _run({"UR_SASREC_NO_LNFUSE": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)
-    for mask in ("0", "7"):     # no chain kernels at all / forward + backward + projection chains (default: forward only)
+    # no chain kernels at all / every chain kernel (default: forward chain + both chains of the last-row layer) / round 2a's default /
+    # the gemm_tn variants (LDS-staged is the default; the no-LDS kernel with an 8- or 16-deep register ring)
+    _run({"UR_TN_DIRECT": "8"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_gemm_gpu.py"), "-k", "golden or larger_random or tn"], expect_min_passed=20)
+    _run({"UR_TN_DIRECT": "16"}, [os.path.join(HERE, "test_gemm_gpu.py"), "-k", "tn"], expect_min_passed=10)
+    for mask in ("0", "31", "1"):
         _run({"UR_SASREC_CHAIN": mask}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_trainer_gpu.py"),
                                          "-k", "golden or larger_random or skip_padding or sasrec or SASRec"], expect_min_passed=20)

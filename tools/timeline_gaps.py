@@ -32,6 +32,17 @@ for g, n in gaps:
     after[n[:60]][0] += g; after[n[:60]][1] += 1
 print("idle time by the kernel that FOLLOWS the gap:")
 for n, (g, c) in sorted(after.items(), key=lambda kv: -kv[1][0])[:12]: print(f"  {g/1e3:8.0f} us in {c:5d} gaps (avg {g/c/1e3:5.1f} us)  before {n}")
+# gaps INSIDE the busiest queue (the main stream): time between the end of one of its kernels and the start of the next
+mainq = perq.most_common(1)[0][0]
+mq = [e for e in ev if e[3] == mainq]
+qg = collections.defaultdict(lambda: [0, 0])
+tot = 0
+for (s0, e0, n0, _), (s1, e1, n1, _) in zip(mq, mq[1:]):
+    g = max(0, s1 - e0)
+    tot += g
+    qg[(n0[:44], n1[:44])][0] += g; qg[(n0[:44], n1[:44])][1] += 1
+print(f"main queue {mainq}: {tot/1e3/n_steps:.1f} us of gaps per step between its own kernels; largest, by (previous -> next):")
+for (a, b), (g, c) in sorted(qg.items(), key=lambda kv: -kv[1][0])[:16]: print(f"  {g/1e3/n_steps:6.1f} us/step  avg {g/c/1e3:5.1f} us x{c/n_steps:4.1f}  {a}  ->  {b}")
 print("per step, by queue and kernel:")
 agg = collections.defaultdict(lambda: [0, 0])
 for s, e, n, q in ev:

@@ -662,6 +662,115 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_kernel(const float* __restric
   if (bias_part != nullptr && first_ctile && tid < TB && r0 + tid < R) bias_part[(long long)sp * R + r0 + tid] = bsum;
 }
 
+// ---- the same product with NO LDS: operand fragments straight from global memory.
+// For Out = P^T Q both operands are walked along the REDUCTION dimension row by row, and a 32x32x2 MFMA fragment is exactly that: lane
+// (i, k) of the A operand holds P[t + k][r + i] -- 32 consecutive floats of one token row per half-wave, a full 128-byte line.  So a
+// wave loads its fragments with plain coalesced global loads and the workgroup shares nothing: no staging stores, no barriers, no LDS
+// allocation (the staged kernel's 67.6 KB decide on which CUs it can run next to the main stream's kernels), and the waves of a CU
+// drift freely.  float2 loads take TWO adjacent columns per lane (columns 2i, 2i+1 of a 64-column block -> two MFMAs; the output
+// tile comes out with its rows / columns interleaved the same way, undone by the addressing of the epilogue), so an iteration (two
+// tokens, four MFMAs = 256 MFMA cycles per wave) costs two load instructions.  Latency is covered by a register ring: the loads of
+// iteration it + DEPTH are issued when iteration it is consumed (DEPTH = 16: 2 x 16 float2 = 64 VGPRs, ~4 000 MFMA cycles ahead).
+// Redundant fetches (each P element is wanted by the two waves of a row pair, each Q element by two waves of a column pair, and by
+// the other column / row tiles of the split) are served by L1 / the XCD's L2: the split -> XCD mapping is the staged kernel's.
+// Workgroup = 4 waves (2 x 2), 128 x 128 output tile, 64 x 64 per wave (four accumulators: consecutive MFMAs never depend).
+template <int PRO, int DEPTH>
+__global__ __launch_bounds__(256) void gemm_tn_direct_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q, int ldq,
+                                                             int T, int R, int Cc, int tok_per_split, int n_splits, int act,
+                                                             float* __restrict__ part, float* __restrict__ bias_part,
+                                                             const int* __restrict__ t_dev, const float* __restrict__ tn_zero) {
+  if (t_dev) {
+    T = min(T, *t_dev);
+    tok_per_split = (((T + n_splits - 1) / n_splits + BT - 1) / BT) * BT;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kk = lane >> 5;
+  const int ntc = (Cc + TB - 1) / TB, ntiles = ntc * ((R + TB - 1) / TB);
+  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
+  const int sp = (qid / ntiles) * 8 + xcd, tile = qid % ntiles;
+  if (sp >= n_splits) return;
+  const int c0 = (tile % ntc) * TB, r0 = (tile / ntc) * TB;
+  const bool first_ctile = (tile % ntc) == 0;
+  const int t_begin = sp * tok_per_split;
+  const int t_end = min(T, t_begin + tok_per_split);
+  const int ra = r0 + wr * 64 + 2 * li, cb = c0 + wc * 64 + 2 * li;   // this lane's two P columns (= output rows) / Q columns
+  const bool rin = ra < R, cin = cb < Cc;
+  const float* Pp = P + (rin ? ra : 0);
+  const float* Qp = Q + (cin ? cb : 0);
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float2 bsum = make_float2(0.f, 0.f);
+
+  const int n_it = (max(t_end - t_begin, 0) + 1) >> 1;
+  // TWO rings in ping-pong: a round consumes one and refills the other (DEPTH iterations ahead).  With a single ring refilled in place
+  // the old value of a slot is still wanted by its MFMAs when the new load is issued, the register allocator gives the load another
+  // register and rotates the whole ring at the back-edge (32 v_movs behind an s_waitcnt vmcnt(0): a full drain every round); here
+  // every slot has one definition per round trip and no copy.  sched_barrier: the loads stay where they are written (the scheduler
+  // would sink them to just ahead of their use).
+  typedef float fx2 __attribute__((ext_vector_type(2)));
+  fx2 fa[DEPTH], fb[DEPTH], ga[DEPTH], gb[DEPTH];
+  // out-of-range tokens (and the lanes of a column pair past R) read a ZERO instead of being zeroed after the load: a select on the
+  // loaded value lets the optimizer sink the load into the branch that uses it (a dependent round trip per iteration)
+  auto issue = [&](int it, fx2& a, fx2& b) {
+    const int t = t_begin + 2 * it + kk;
+    const bool in = rin && t < t_end;
+    const float* pa = in ? Pp + (long long)t * ldp : tn_zero;
+    a = *(const fx2*)pa;
+    b = *(const fx2*)(Qp + (long long)min(t, T - 1) * ldq);
+  };
+  auto consume = [&](int it, fx2 a, fx2 b) {
+    if (PRO == PRO_ACT) b = fx2{act_fwd(b.x, act), act_fwd(b.y, act)};
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+    bsum.x += a.x;
+    bsum.y += a.y;
+  };
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) issue(u, fa[u], fb[u]);
+  for (int base = 0; base < n_it; base += 2 * DEPTH) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      issue(base + DEPTH + u, ga[u], gb[u]);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(base + u, fa[u], fb[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      issue(base + 2 * DEPTH + u, fa[u], fb[u]);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(base + DEPTH + u, ga[u], gb[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // accumulator element r of lane (li, kk): fragment row (r & 3) + 8 (r >> 2) + 4 kk, fragment column li; fragment row / column f of
+  // accumulator [i][j] is output row 2 f + i / output column 2 f + j of the wave's 64 x 64 block
+  float* out = part + (long long)sp * R * Cc;
+  if (cin) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = r0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kk) + i;
+        if (rr < R) *(float2*)(out + (long long)rr * Cc + cb) = make_float2(acc[i][0][r], acc[i][1][r]);
+      }
+  }
+  if (bias_part != nullptr && first_ctile && wc == 0) {
+    bsum.x += __shfl_xor(bsum.x, 32, 64);
+    bsum.y += __shfl_xor(bsum.y, 32, 64);
+    if (kk == 0 && rin) *(float2*)(bias_part + (long long)sp * R + ra) = bsum;
+  }
+}
+
 // out[i] = sum_s part[s*n + i] (fixed order; 4 consecutive elements per thread); the same launch also reduces the
 // bias partials bias_part[s*R + r] -> bias_out[r] (threads past n/4)
 __global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long long n, int cols, float* __restrict__ out,
@@ -689,12 +798,30 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long
   }
 }
 
+// a few zero floats in device memory (per device, allocated once): what the direct kernel's out-of-range lanes load
+static const float* tn_zero_buf() {
+  static float* z[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!z[dev]) {
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    z[dev] = p;
+  }
+  return z[dev];
+}
+
 static int tn_splits(int T, int R, int Cc) {
   const int tiles = cdiv(R, TB) * cdiv(Cc, TB);
   // one workgroup per CU: every further split is another R x Cc partial tile written and read back by the reduction, which
   // shares HBM with the sparse optimizer step (measured at the C5 shapes: 256 -> 0.872 ms/step, 512 -> 0.882, 128 -> 0.94)
   static const int target = getenv("UR_TN_BLOCKS") ? atoi(getenv("UR_TN_BLOCKS")) : 256;   // tuning aid
-  int s = cdiv(target, tiles);
+  // Never more workgroups on an XCD than it has CUs: workgroup number 33 of an XCD shares a CU with another one, both run at half
+  // speed and the launch takes twice as long.  Split sp runs on XCD sp % 8 (all its tiles together), so the bound is
+  // ceil(S / 8) * tiles <= target / 8:  3 tiles x 86 splits (11 splits = 33 workgroups on five of the XCDs) took 45 us, 3 x 80 takes 27.
+  int s = (target / 8) / tiles * 8;
+  if (s < 8) s = target / tiles;
   const int smax = cdiv(T, T <= 4096 ? 64 : 128);   // >= 2 (small T) / 4 LDS stages of 32 tokens per split
   if (s > smax) s = smax;
   if (s < 1) s = 1;
@@ -772,6 +899,15 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_NONE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  static const int direct = getenv("UR_TN_DIRECT") ? atoi(getenv("UR_TN_DIRECT")) : 0;   // 0 (default): the LDS-staged kernel; 8 / 16: the no-LDS kernel, ring depth
+  if (direct) {
+    const float* zeros = tn_zero_buf();
+    if (!zeros) return fail(UR_ERR_HIP, "gemm_tn: no device memory for the zero row");
+#define UR_TND_GO(PRO_, DP_) hipLaunchKernelGGL((gemm_tn_direct_kernel<PRO_, DP_>), grid, dim3(256), 0, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev, zeros)
+    if (direct == 16) { if (pro_act_on_q) UR_TND_GO(PRO_ACT, 16); else UR_TND_GO(PRO_NONE, 16); }
+    else { if (pro_act_on_q) UR_TND_GO(PRO_ACT, 8); else UR_TND_GO(PRO_NONE, 8); }
+#undef UR_TND_GO
+  } else
 #define UR_TN_GO(PRO_, NW_) hipLaunchKernelGGL((gemm_tn_kernel<PRO_, NW_>), grid, dim3(64 * NW_), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev)
   if (nw == 4) { if (pro_act_on_q) UR_TN_GO(PRO_ACT, 4); else UR_TN_GO(PRO_NONE, 4); }
   else { if (pro_act_on_q) UR_TN_GO(PRO_ACT, 8); else UR_TN_GO(PRO_NONE, 8); }

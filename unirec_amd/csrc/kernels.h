@@ -109,9 +109,10 @@ struct TransposeBatch {
 int transpose_batch(TransposeBatch& tb, hipStream_t st);   // every queued transpose in one launch
 
 // ---- rowchain.hip: row-block chain kernels (a workgroup carries BM token rows through a sequence of GEMMs, tiles in LDS)
-constexpr int CHAIN_FWD = 1, CHAIN_BWD = 2, CHAIN_PROJ = 4;
-constexpr int CHAIN_DEFAULT = CHAIN_FWD;  // which chain kernels run by default (UR_SASREC_CHAIN / ur_sasrec_set_chain: bit mask); DESIGN.md 6d
-bool chain_supported(int d, int inner, int which);   // d in {32, 64, 128}, inner % d == 0, and the bit(s) `which` switched on
+constexpr int CHAIN_FWD = 1, CHAIN_BWD = 2, CHAIN_PROJ = 4, CHAIN_LAST = 8, CHAIN_LAST_BWD = 16, CHAIN_ALL = 31;   // LAST*: the B last rows of the last-row layer
+constexpr int CHAIN_DEFAULT = CHAIN_FWD | CHAIN_LAST | CHAIN_LAST_BWD;  // which chain kernels run by default (UR_SASREC_CHAIN / ur_sasrec_set_chain: bit mask); DESIGN.md 6d
+bool chain_supported(int d, int inner, int which);
+bool chain_shape_ok(int d, int inner);              // the kernels exist for this shape (whatever the switch says)   // d in {32, 64, 128}, inner % d == 0, and the bit(s) `which` switched on
 int chain_rows_per_block(int d);
 int chain_set_enabled(int mask);          // mask < 0: query only; returns the previous mask
 struct ChainFwdArgs {

@@ -545,17 +545,15 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
 // 0.834 -> 0.812 ms/step (isolated: 99 us against 138 for the four launches it replaces); with the backward chains as well the step is
 // SLOWER (0.858): three chain workgroups fill a CU's LDS, so the weight-gradient GEMMs of the side stream (67 KB each) cannot share
 // the CUs with them any more -- in the forward pass the side stream is idle and nothing is lost.
-static int g_chain_on = -1;   // bit mask: 1 forward chain, 2 backward chain, 4 projection-gradient chain
+static int g_chain_on = -1;   // bit mask: 1 forward chain, 2 backward chain, 4 projection-gradient chain, 8 / 16 forward / backward chain of the last-row layer
 int chain_set_enabled(int on) {
-  if (g_chain_on < 0) g_chain_on = getenv("UR_SASREC_CHAIN") ? (atoi(getenv("UR_SASREC_CHAIN")) & 7) : CHAIN_DEFAULT;
+  if (g_chain_on < 0) g_chain_on = getenv("UR_SASREC_CHAIN") ? (atoi(getenv("UR_SASREC_CHAIN")) & CHAIN_ALL) : CHAIN_DEFAULT;
   const int prev = g_chain_on;
-  if (on >= 0) g_chain_on = on & 7;
+  if (on >= 0) g_chain_on = on & CHAIN_ALL;
   return prev;
 }
-bool chain_supported(int d, int inner, int which) {
-  if (!(chain_set_enabled(-1) & which)) return false;
-  return (d == 32 || d == 64 || d == 128) && inner % d == 0;
-}
+bool chain_shape_ok(int d, int inner) { return (d == 32 || d == 64 || d == 128) && inner % d == 0; }
+bool chain_supported(int d, int inner, int which) { return (chain_set_enabled(-1) & which) && chain_shape_ok(d, inner); }
 int chain_rows_per_block(int d) { return 4096 / d; }
 
 template <typename KernelT>
@@ -572,7 +570,7 @@ static void set_lds(KernelT k, size_t bytes) {
 
 int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
   if (a.M <= 0) return UR_OK;
-  if (!chain_supported(d, a.I, 7) || (a.wn && a.Nn % d)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd: d=%d inner=%d", d, a.I);
+  if (!chain_shape_ok(d, a.I) || (a.wn && a.Nn % d)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd: d=%d inner=%d", d, a.I);
   ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * ((double)d + 2.0 * a.I + (a.wn ? a.Nn : 0)));
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
@@ -586,7 +584,7 @@ int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
 
 int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st) {
   if (a.M <= 0) return UR_OK;
-  if (!chain_supported(d, a.I, 7)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_bwd: d=%d inner=%d", d, a.I);
+  if (!chain_shape_ok(d, a.I)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_bwd: d=%d inner=%d", d, a.I);
   ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * ((double)d + 2.0 * a.I));
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {

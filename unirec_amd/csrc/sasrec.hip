@@ -310,10 +310,15 @@ SideCtx* side_ctx(bool even_if_disabled = false) {
     if (pr && (pr[0] == 'l' || pr[0] == 'h')) {
       if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest) != hipSuccess) return nullptr;
     } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // Events that order two streams of ONE device need no system-scope fence: a plain event makes the recording stream write back
+    // and invalidate its caches for the host and for other devices, a 6-7 us bubble in front of the next kernel of the main stream at
+    // every fork (measured: five per backward pass).  UR_SASREC_EVENT_FENCE=1 restores the default events.
+    const char* fe = getenv("UR_SASREC_EVENT_FENCE");
+    const unsigned evf = hipEventDisableTiming | ((fe && atoi(fe) == 1) ? 0u : (unsigned)hipEventDisableSystemFence);
     for (auto& ev : c->ev)
-      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c->main_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&ev, evf) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c->done, evf) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c->main_done, evf) != hipSuccess) return nullptr;
     c->ok = true;
     return c;
   }();
@@ -350,6 +355,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
   if (rc) return rc;
   const float* x = w.x0;
   const bool chain = chain_supported(d, I, CHAIN_FWD);   // out-projection + LN + feed-forward + LN (+ next projection) as ONE launch per layer
+  const bool chain_last = chain_supported(d, I, CHAIN_LAST);   // ... and for the B last rows of the last-row layer
   bool proj_done = false;                     // this layer's K,V (Q,K,V) rows were written by the previous layer's chain kernel
   for (int i = 0; i < c.n_layers; ++i) {
     const LayerP p = layer_ptrs(dense, lay, i);
@@ -374,6 +380,19 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       g.A = x_last; g.lda = ld_last; g.W = p.wqkv; g.ldw = d; g.C = w.q_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bqkv;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
       if ((rc = attn_last_fwd(w.q_last, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st, sbase, spad, &d_attn))) return rc;
+      if (chain_last) {
+        // the B last rows through the same row-chain kernel as the full layers: out-projection + LN + feed-forward + LN in one launch
+        // (16 workgroups at B = 512: three latency-bound launches of 10 + 7 + 25 us become one)
+        ChainFwdArgs ca{};
+        ca.ctx = lw.ctx; ca.ldctx = d; ca.res = x_last; ca.ldres = ld_last;
+        ca.wo = p.wo; ca.bo = p.bo; ca.g1 = p.g1; ca.b1ln = p.b1ln; ca.w1 = p.w1; ca.b1 = p.b1; ca.w2 = p.w2; ca.b2 = p.b2;
+        ca.g2 = p.g2; ca.b2ln = p.b2ln;
+        ca.a = lw.a; ca.ahat = lw.ahat; ca.rstd1 = lw.rstd1; ca.h1 = lw.h1; ca.y = user_emb; ca.yhat = lw.yhat; ca.rstd2 = lw.rstd2;
+        ca.M = B; ca.I = I; ca.act = c.act; ca.eps = c.eps;
+        ca.drop_out = site_spec(c, i, DROP_SITE_OUT, nullptr, c.L, c.L - 1);   // row b of these [B, .] tiles is token (b, L-1)
+        ca.drop_ffn = site_spec(c, i, DROP_SITE_FFN, nullptr, c.L, c.L - 1);
+        return chain_ffn_fwd(ca, d, st);
+      }
       g = GemmArgs{};
       g.A = lw.ctx; g.lda = d; g.W = p.wo; g.ldw = d; g.C = lw.a; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bo;
       g.aux = x_last; g.ldaux = ld_last; g.gamma = p.g1; g.beta = p.b1ln; g.eps = c.eps; g.xhat = lw.ahat; g.rstd = lw.rstd1;
@@ -458,6 +477,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   // does not carry the second, dropout-masked copy of the LayerNorm-backward outputs)
   const bool chain_bwd = chain_supported(d, I, CHAIN_BWD) && c.p_hidden == 0.f;
   const bool chain_proj = chain_supported(d, I, CHAIN_PROJ) && c.p_hidden == 0.f;
+  const bool chain_last_bwd = chain_supported(d, I, CHAIN_LAST_BWD) && c.p_hidden == 0.f;
   const bool have_u = chain_supported(d, I, CHAIN_FWD);   // the forward pass of the full layers went through chain_ffn_fwd: lw.u is valid
   bool ln0_done = false;                // the embedding LayerNorm backward already ran in the epilogue of the bottom layer's last GEMM
   // LayerNorm backward in the epilogue of the GEMM that produces its input gradient (EPI_ADD_LNBWD): the attention block's
@@ -598,6 +618,26 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       // final layer: only row L-1 carries gradient (d_user_emb); K,V gradients still cover every position
       const int B = c.B;
       GemmArgs g{};
+      if (chain_last_bwd) {
+        // LN backward -> d act GEMM -> d FFN-1 GEMM + residual -> LN backward -> out-projection GEMM of the B last rows as ONE row-chain
+        // launch (the full layers' chain_ffn_bwd; four latency-bound launches of 8 + 13 + 19 + 7 us become one)
+        float* part = w.chain_part + (long long)i * 4 * w.chain_blocks * d;
+        const int nblk = cdiv(B, chain_rows_per_block(d));
+        ChainBwdArgs cb{};
+        cb.gy = d_user_emb; cb.yhat = lw.yhat; cb.rstd2 = lw.rstd2; cb.g2 = p.g2; cb.h1 = lw.h1; cb.w2T = lw.w2T; cb.w1T = lw.w1T;
+        cb.ahat = lw.ahat; cb.rstd1 = lw.rstd1; cb.g1 = p.g1; cb.woT = lw.woT;
+        cb.g_tf = lw.g_tf; cb.g_h1 = lw.g_h1; cb.g_ta = lw.g_ta; cb.g_ctx = w.g_ctx; cb.part = part;
+        cb.M = B; cb.I = I; cb.act = c.act;
+        if ((rc = chain_ffn_bwd(cb, d, st))) return rc;
+        if (rb.full(4) && (rc = reduce_batch(rb, st))) return rc;
+        rb.add(part, 4 * d, nblk, d, d, G + o[14], d);
+        rb.add(part + d, 4 * d, nblk, d, d, G + o[15], d);
+        rb.add(part + 2 * d, 4 * d, nblk, d, d, G + o[8], d);
+        rb.add(part + 3 * d, 4 * d, nblk, d, d, G + o[9], d);
+        if ((rc = tn(lw.g_tf, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
+        if ((rc = tn(lw.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
+        if ((rc = tn(lw.g_ta, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
+      } else {
       if ((rc = ln_bwd(d_user_emb, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, B, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb,
                        nullptr, nullptr, nullptr, &d_ffn, lw.g_tfd)))
         return rc;
@@ -623,6 +663,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       g = GemmArgs{};
       g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
+      }
       if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, lw.g_qkv, st, sbase, spad, &d_attn))) return rc;
       // dWq from the B last rows, dWk/dWv from all rows
       if ((rc = tn(w.dq_last, d, compact ? w.x_last : x_in + (long long)(c.L - 1) * d, compact ? d : c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
@@ -685,7 +726,8 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     g.aux = lw.h1; g.ldaux = I; g.act = c.act;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
     if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
-    if ((rc = fork())) return rc;
+    static const bool early_fork = getenv("UR_SASREC_EARLY_FORK") != nullptr;
+    if (early_fork && (rc = fork())) return rc;
     g = GemmArgs{};
     g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
     if (lnfuse) {
@@ -703,6 +745,9 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
         return rc;
     }
     if ((rc = tn(lw.g_tad, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
+    // every fork is an event record on the main stream = a ~5 us bubble in front of its next kernel: dW2, dW1 and dWo go together, here
+    // (the side stream is still busy with the top layer's batch when the first two become ready; UR_SASREC_EARLY_FORK=1: round-2a order)
+    if (!early_fork && (rc = fork())) return rc;
     g = GemmArgs{};
     g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = d;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
