@@ -88,6 +88,7 @@ __device__ __forceinline__ float group_sum_rt(float v, int width) {
 struct AdamK {
   float lr, b1, b2, eps, wd;
   int step, algo;
+  float lb1 = 0.f, lb2 = 0.f;   // log2(b1), log2(b2) (host, double precision): b^j = exp2(j * lb) in the lazy-replay series (rows.hip)
 };
 // one element, gradient gr (already scaled / clipped); bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t)
 __device__ __forceinline__ void opt_elem(float& w, float& m, float& v, float gr, const AdamK& a, float bc1, float bc2s) {

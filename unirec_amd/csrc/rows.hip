@@ -642,6 +642,96 @@ __device__ __forceinline__ void lazy_replay4(float4& w, float4& m, float4& v, in
   }
 }
 
+// ---- the same replay without the per-element loop (Adam / AdamW, weight_decay == 0, the case above).
+// The replayed weight is w_0 - m_0 S with S = sum_j c_j / (x_j + eps), x_j = sqrt(v_0) d_j: J = min(k, 192) reciprocals per ELEMENT --
+// the VALU bill of a long run (a table of 100 M rows sees a row again every ~3 600 steps: every looked-up row replays the full 192
+// steps, 28 K rows x 128 elements x 192 quarter-rate reciprocals = 0.17 ms per step).  Written as a series in r_j = eps / x_j,
+//     1 / (x_j + eps) = (1 / x_j) (1 - r_j + r_j^2 - ...)      =>      S = (1 / sv) sum_n (-e)^n G_{n+1},
+//     e = eps / sv,   sv = sqrt(v_0),   G_p = sum_j c_j d_j^-p,
+// the sums G_p depend on (from, k) only -- the same for every element of the row -- so the TPR lanes of the row's group compute
+// them TOGETHER (lane l takes j = l + 1, l + 1 + TPR, ...; b^j = exp2(j log2 b), no running products) and an element pays two
+// reciprocals and a Horner chain.  LAZY_NT = 6 terms, used while r_j < 0.1 for every step (truncation < 1e-6 of an update that is
+// itself <= lr * 10: far below the weight's fp32 resolution); elements with a smaller second moment (sqrt(v) < ~1e-7: next to no
+// gradient history) take the exact loop, as do short gaps (k < LAZY_SERIES_MIN, where the loop is cheaper than the cooperative sums).
+constexpr int LAZY_NT = 6;
+constexpr int LAZY_SERIES_MIN = 6;
+constexpr float LAZY_SERIES_R = 0.1f;
+struct LazyRow {
+  float G[LAZY_NT];
+  float invd_max, f1, f2;
+  int from, to;
+  bool series;    // group-uniform: the sums are valid
+};
+// every lane of the row's TPR-lane group calls this with the same (from, to); t = lane index within the group
+template <int TPR>
+__device__ __forceinline__ LazyRow lazy_row_prepare(int from, int to, const AdamK& a, int t) {
+  LazyRow r;
+  r.from = from; r.to = to;
+  const int k = to - from;
+  // from == 0: the row was never updated (m = v = 0: nothing to replay, lazy_replay4 returns at once)
+  r.series = a.algo < UR_OPT_SGD && a.wd == 0.f && k >= LAZY_SERIES_MIN && from > 0;
+  if (!r.series) return r;
+  const int J = min(k, LAZY_EXACT_STEPS);
+  float g[LAZY_NT];
+#pragma unroll
+  for (int p = 0; p < LAZY_NT; ++p) g[p] = 0.f;
+  float mx = 0.f;
+  for (int j = t + 1; j <= J; j += TPR) {
+    const float fj = (float)j, ft = (float)(from + j);
+    const float p1 = __builtin_amdgcn_exp2f(fj * a.lb1), p2 = __builtin_amdgcn_exp2f(fj * a.lb2);
+    const float b1t = __builtin_amdgcn_exp2f(ft * a.lb1), b2t = __builtin_amdgcn_exp2f(ft * a.lb2);
+    const float c = a.lr * p1 * __builtin_amdgcn_rcpf(1.f - b1t);
+    const float invd = __builtin_amdgcn_sqrtf((1.f - b2t) * __builtin_amdgcn_rcpf(p2));
+    mx = fmaxf(mx, invd);
+    float q = c;
+#pragma unroll
+    for (int p = 0; p < LAZY_NT; ++p) {
+      q *= invd;
+      g[p] += q;
+    }
+  }
+#pragma unroll
+  for (int off = TPR / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int p = 0; p < LAZY_NT; ++p) g[p] += __shfl_xor(g[p], off, TPR);
+    mx = fmaxf(mx, __shfl_xor(mx, off, TPR));
+  }
+#pragma unroll
+  for (int p = 0; p < LAZY_NT; ++p) r.G[p] = g[p];
+  r.invd_max = mx;
+  r.f1 = __builtin_amdgcn_exp2f((float)k * a.lb1);
+  r.f2 = __builtin_amdgcn_exp2f((float)k * a.lb2);
+  return r;
+}
+__device__ __forceinline__ bool lazy_series_elem(float m, float v, const LazyRow& r, float eps, float& S) {
+  S = 0.f;
+  if (m == 0.f) return true;                       // contributes nothing, whatever v is
+  const float isv = __builtin_amdgcn_rsqf(v);      // v == 0 -> inf -> e = inf -> not < R: exact loop
+  const float e = eps * isv;
+  if (!(e * r.invd_max < LAZY_SERIES_R)) return false;
+  float h = r.G[LAZY_NT - 1];
+#pragma unroll
+  for (int p = LAZY_NT - 2; p >= 0; --p) h = fmaf(-e, h, r.G[p]);
+  S = isv * h;
+  return true;
+}
+// one float4 of a row whose group prepared `r` (per lane; lanes without data simply do not call it)
+__device__ __forceinline__ void lazy_row_apply(const LazyRow& r, float4& w, float4& m, float4& v, const AdamK& a) {
+  if (r.to - r.from <= 0) return;
+  if (r.series) {
+    float sx, sy, sz, sw;
+    const bool ok = lazy_series_elem(m.x, v.x, r, a.eps, sx) & lazy_series_elem(m.y, v.y, r, a.eps, sy) &
+                    lazy_series_elem(m.z, v.z, r, a.eps, sz) & lazy_series_elem(m.w, v.w, r, a.eps, sw);
+    if (ok) {
+      w.x = fmaf(-m.x, sx, w.x); w.y = fmaf(-m.y, sy, w.y); w.z = fmaf(-m.z, sz, w.z); w.w = fmaf(-m.w, sw, w.w);
+      m.x *= r.f1; m.y *= r.f1; m.z *= r.f1; m.w *= r.f1;
+      v.x *= r.f2; v.y *= r.f2; v.z *= r.f2; v.w *= r.f2;
+      return;
+    }
+  }
+  lazy_replay4(w, m, v, r.from, r.to, a);
+}
+
 // MODE 0: update with gradient (catch-up first when last_step != null); MODE 1: catch-up only (to step-1)
 template <int TPR, int MODE>
 __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
@@ -682,7 +772,10 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
 #pragma unroll
       for (int i = 0; i < U; ++i) {
         if (u0 + i >= n_uniq || row[i] == 0) continue;   // group-uniform
-        if (last_step) lazy_replay4(w[i], m[i], v[i], last[i], a.step - 1, a);
+        if (last_step) {
+          const LazyRow lr = lazy_row_prepare<TPR>(last[i], a.step - 1, a, t);
+          lazy_row_apply(lr, w[i], m[i], v[i], a);
+        }
         opt_elem(w[i].x, m[i].x, v[i].x, gr[i].x * scale, a, bc1, bc2s);
         opt_elem(w[i].y, m[i].y, v[i].y, gr[i].y * scale, a, bc1, bc2s);
         opt_elem(w[i].z, m[i].z, v[i].z, gr[i].z * scale, a, bc1, bc2s);
@@ -720,14 +813,14 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
       if (t == 0) last_step[row] = a.step - 1;
       continue;
     }
+    LazyRow lr;
+    if (last_step) lr = lazy_row_prepare<TPR>(last, a.step - 1, a, t);   // (every lane of the group: the sums are a group effort)
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int c = t + k * TPR;
       if (c < d4) {
         float4 w = table[row * d4 + c], m = mom[row * d4 + c], v = var[row * d4 + c];
-        if (last_step) {
-          lazy_replay4(w, m, v, last, a.step - 1, a);
-        }
+        if (last_step) lazy_row_apply(lr, w, m, v, a);
         if (MODE == 0) {
           const float4 gr = grad[(long long)u * d4 + c];
           opt_elem(w.x, m.x, v.x, gr.x * scale, a, bc1, bc2s);
@@ -757,12 +850,13 @@ __global__ __launch_bounds__(256) void lazy_flush_kernel(AdamK a, float4* __rest
     if (row == 0) continue;
     const int last = last_step[row];
     if (last >= a.step) continue;
+    const LazyRow lr = lazy_row_prepare<TPR>(last, a.step, a, t);
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int c = t + k * TPR;
       if (c < d4) {
         float4 w = table[row * d4 + c], m = mom[row * d4 + c], v = var[row * d4 + c];
-        lazy_replay4(w, m, v, last, a.step, a);
+        lazy_row_apply(lr, w, m, v, a);
         table[row * d4 + c] = w;
         mom[row * d4 + c] = m;
         var[row * d4 + c] = v;
@@ -1225,6 +1319,8 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
                               const int32_t* busy_n_dev = nullptr, int busy_max = 0) {
   ProfScope ps(PC_ADAM, st, (double)n_max * d * 4.0 * 7);
   AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
+  a.lb1 = cfg->beta1 > 0.f ? (float)log2((double)cfg->beta1) : -1e30f;
+  a.lb2 = cfg->beta2 > 0.f ? (float)log2((double)cfg->beta2) : -1e30f;
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(n_max, groups);
   if (blocks > 8192) blocks = 8192;
@@ -1291,6 +1387,8 @@ extern "C" int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, 
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n >= 0 && row0 >= 0, UR_ERR_ARG, "ur_lazy_adam_flush: d=%d", d);
   if (n == 0) return UR_OK;
   AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
+  a.lb1 = cfg->beta1 > 0.f ? (float)log2((double)cfg->beta1) : -1e30f;
+  a.lb2 = cfg->beta2 > 0.f ? (float)log2((double)cfg->beta2) : -1e30f;
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   long long blocks = (n + groups - 1) / groups;
   if (blocks > 16384) blocks = 16384;
