@@ -1453,6 +1453,193 @@ __global__ __launch_bounds__(256) void attn_bwd_m16t_kernel(const float* __restr
   if (literal) tiles(std::true_type{}); else tiles(std::false_type{});
 }
 
+// ---- L <= 64, a WAVE per head: four heads per workgroup, every (query tile, key tile) pair evaluated once.
+// What the kernel above pays for, measured at C5 (B = 512, L = 50, 16 heads of 8; 63 us): 31 us are the STAGING alone -- a head's
+// rows of Q, K, V, dO, O are 32-byte pieces of 128-byte lines, so each workgroup pulls whole lines into its L1 for a quarter of
+// their bytes (262 MB through the L1s for 67 MB of operands: the XCD placement makes the four heads of a line share an L2, not an
+// L1) -- 13 us the query-oriented pass, 19 us the key-oriented pass, which re-evaluates every score, exp2, mask and dP.  Here
+//   * a workgroup stages FOUR adjacent heads: 8 threads read one row's 128-byte line of each tensor, nothing is fetched twice;
+//   * wave w owns head h0 + w entirely: all its tile pairs (balanced: every wave has the same pairs), dQ, dK and dV accumulate in
+//     ITS registers (dK / dV: one accumulator pair per key tile, <= 4 tiles) -- no cross-wave reduction, one barrier in the kernel;
+//   * a pair is evaluated ONCE, in the query orientation (lane = query): P and dS, 16 x 16 as they sit in the accumulators, go through
+//     a per-wave LDS scratch (2 x 16 x 20 floats: one ds_write_b128 each, four conflict-free ds_read_b32 back) and are then the
+//     B operands of the dK / dV MFMAs in the key orientation.  2 KS + 12 MFMAs per pair instead of 4 KS + 12; 4 exp2 / mask /
+//     dropout evaluations per lane instead of 8;
+//   * no transposed copies of K, Q, dO: the A operands of the dQ / dK / dV MFMAs are read from the row-major tiles (conflict-free:
+//     rows 48 bytes apart) with a select for the feature rows >= HD.
+// Same arithmetic per element as the kernels above; results differ from theirs only by the summation order inside dK / dV.
+constexpr int M16W_TS = 20, M16W_HEADS = 4;
+__host__ __device__ inline int attn_m16w_head_floats(int L, int hd) {
+  const int Lp = (L + 15) & ~15;
+  return 4 * Lp * (hd + 4) + 2 * Lp;
+}
+__host__ __device__ inline int attn_m16w_lds_floats(int L, int hd) {
+  const int Lp = (L + 15) & ~15;
+  return M16W_HEADS * attn_m16w_head_floats(L, hd) + 2 * Lp + M16W_HEADS * 2 * 16 * M16W_TS;
+}
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_m16w_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
+                                                            const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                            const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
+  constexpr int KS = HD / 4, LDK = HD + 4, PR = HD / 4, NTM = 4, TS = M16W_TS, SL = M16W_HEADS * PR;   // SL: float4 slots per row
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) float smem_m16[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int hg = (p.H + M16W_HEADS - 1) / M16W_HEADS;
+  const int b = blockIdx.x / hg, h0 = (blockIdx.x % hg) * M16W_HEADS;
+  const int L = p.L, ld = 3 * p.d;
+  const int c16 = lane & 15, kq = lane >> 4;
+  long long row0;
+  int pad;
+  seq_rows(p, b, row0, pad);
+  const int* __restrict__ sq = seq + (long long)b * L;
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  const bool causal = p.causal && !literal;
+  const float f = literal ? 1.0f / p.sqrt_hd : p.scale;   // d(score) / d(q . k)
+  const int nt = (L + 15) >> 4, Lp = nt * 16;
+  const int HF = 4 * Lp * LDK + 2 * Lp;              // floats per head: Q, K, V, dO tiles [Lp][LDK] (rows >= L zero), lse2, D
+  float* kvalid = smem_m16 + M16W_HEADS * HF;        // [Lp] 1 = key may be attended
+  float* qvalid = kvalid + Lp;                       // [Lp] 1 = query row exists (pad <= i < L)
+  float* TP = qvalid + Lp + w * (2 * 16 * TS);       // this wave's transpose scratch: P tile, dS tile
+  float* TD = TP + 16 * TS;
+  for (int x = threadIdx.x; x < Lp * SL; x += 256) {
+    const int j = x / SL, q = x % SL, hh = q / PR, c = (q % PR) * 4, h = h0 + hh;
+    const bool in = j < L && h < p.H;
+    const long long row = row0 + max(min(j, L - 1), pad);
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, g4 = q4, o4 = q4;
+    if (in) {
+      const float* src = qkv + row * ld + h * HD + c;
+      q4 = *(const float4*)src; k4 = *(const float4*)(src + p.d); v4 = *(const float4*)(src + 2 * p.d);
+      g4 = *(const float4*)(dctx + row * p.d + h * HD + c); o4 = *(const float4*)(ctx + row * p.d + h * HD + c);
+    }
+    float* base = smem_m16 + hh * HF;
+    *(float4*)(base + j * LDK + c) = q4;
+    *(float4*)(base + (Lp + j) * LDK + c) = k4;
+    *(float4*)(base + (2 * Lp + j) * LDK + c) = v4;
+    *(float4*)(base + (3 * Lp + j) * LDK + c) = g4;
+    float D = (g4.x * o4.x + g4.y * o4.y) + (g4.z * o4.z + g4.w * o4.w);
+#pragma unroll
+    for (int o = 1; o < PR; o <<= 1) D += __shfl_xor(D, o, 64);   // the PR lanes of a (row, head) are adjacent and active together
+    if ((q % PR) == 0) {
+      base[4 * Lp * LDK + j] = in ? lse[((long long)b * p.H + h) * L + j] * LOG2E : 0.f;
+      base[4 * Lp * LDK + Lp + j] = D;
+    }
+    if (q == 0) {
+      kvalid[j] = (j < L && (literal || sq[j] > 0)) ? 1.f : 0.f;
+      qvalid[j] = (j < L && j >= pad) ? 1.f : 0.f;
+    }
+  }
+  __syncthreads();
+  const int h = h0 + w;
+  if (h >= p.H) return;
+  const float* Qs = smem_m16 + w * HF;
+  const float* Ks = Qs + Lp * LDK;
+  const float* Vs = Ks + Lp * LDK;
+  const float* Gs = Vs + Lp * LDK;
+  const float* lse2s = Gs + Lp * LDK;
+  const float* Ds = lse2s + Lp;
+  const int jt0 = literal ? 0 : fv >> 4;
+  float* orow = dqkv + row0 * ld + h * HD;
+  const float sc2 = f * LOG2E, inv_sqrt_div = p.sqrt_hd;
+  const bool frow = c16 < HD;                       // this lane's feature row of an A operand exists
+  const int cA = frow ? c16 : 0;
+  floatx4 dkA[NTM], dvA[NTM];
+#pragma unroll
+  for (int q = 0; q < NTM; ++q) {
+    dkA[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+    dvA[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto tiles = [&](auto lit_tag) {
+    constexpr bool LIT = decltype(lit_tag)::value;
+    auto expo = [&](float sv) { return LIT ? (sv / inv_sqrt_div + -10000.0f) * LOG2E : sv * sc2; };
+    for (int it = 0; it < nt; ++it) {
+      const int i = it * 16 + c16;
+      float qf[KS], gf[KS];
+      lds_frag<KS>(Qs + i * LDK + kq * KS, qf);
+      lds_frag<KS>(Gs + i * LDK + kq * KS, gf);
+      const float lse2 = lse2s[i], Di = Ds[i];
+      const bool qv = qvalid[i] != 0.f;
+      const unsigned rk = attn_rowkey(p, b, h, i);
+      const int i0 = it * 16 + 4 * kq;
+      float gtr[4], qtr[4];                          // A operands of the dV / dK MFMAs: dO / Q feature c16 of queries i0 .. i0 + 3
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gg = Gs[(i0 + r) * LDK + cA], qq = Qs[(i0 + r) * LDK + cA];
+        gtr[r] = frow ? gg : 0.f;
+        qtr[r] = frow ? qq : 0.f;
+      }
+      floatx4 dq = {0.f, 0.f, 0.f, 0.f};
+      const int jt_end = (!LIT && causal) ? it + 1 : nt;
+#pragma unroll
+      for (int jt = 0; jt < NTM; ++jt) {
+        if (jt < jt0 || jt >= jt_end) continue;     // (wave-uniform)
+        float kf[KS], vf[KS];
+        lds_frag<KS>(Ks + (jt * 16 + c16) * LDK + kq * KS, kf);
+        lds_frag<KS>(Vs + (jt * 16 + c16) * LDK + kq * KS, vf);
+        const int j0 = jt * 16 + 4 * kq;
+        const float4 kv4 = *(const float4*)(kvalid + j0);
+        float ktr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float kk = Ks[(j0 + r) * LDK + cA];
+          ktr[r] = frow ? kk : 0.f;
+        }
+        floatx4 sT = {0.f, 0.f, 0.f, 0.f}, dpT = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+          sT = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s2], qf[s2], sT, 0, 0, 0);
+          dpT = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[s2], gf[s2], dpT, 0, 0, 0);
+        }
+        const float kvr[4] = {kv4.x, kv4.y, kv4.z, kv4.w};
+        float pd[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = j0 + r;
+          const bool ok = qv & (kvr[r] != 0.f) & ((LIT || !causal) | (j <= i));   // (no short-circuit: no divergent branches)
+          const float pv = __builtin_amdgcn_exp2f(ok ? expo(sT[r]) - lse2 : -INFINITY);   // exp2(-inf) = 0 for masked pairs
+          const float mk = attn_keep<DROP>(p, rk, j);
+          pd[r] = pv * mk;
+          ds[r] = pv * (mk * dpT[r] - Di);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq = __builtin_amdgcn_mfma_f32_16x16x4f32(ktr[r], ds[r], dq, 0, 0, 0);
+        // query orientation -> key orientation: lane (query c16, keys 4 kq + r) writes a row chunk, lane (key c16, queries 4 kq + r) reads a column
+        *(float4*)(TP + c16 * TS + 4 * kq) = make_float4(pd[0], pd[1], pd[2], pd[3]);
+        *(float4*)(TD + c16 * TS + 4 * kq) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+        __builtin_amdgcn_wave_barrier();
+        float pk[4], dsk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pk[r] = TP[(4 * kq + r) * TS + c16];
+          dsk[r] = TD[(4 * kq + r) * TS + c16];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dvA[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gtr[r], pk[r], dvA[jt], 0, 0, 0);
+          dkA[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qtr[r], dsk[r], dkA[jt], 0, 0, 0);
+        }
+      }
+      if (i < L && i >= pad && 4 * kq < HD)
+        *(float4*)(orow + (long long)i * ld + 4 * kq) = make_float4(dq[0] * f, dq[1] * f, dq[2] * f, dq[3] * f);
+    }
+  };
+  if (literal) tiles(std::true_type{}); else tiles(std::false_type{});
+  if (4 * kq < HD) {
+#pragma unroll
+    for (int jt = 0; jt < NTM; ++jt) {
+      const int j = jt * 16 + c16;
+      if (jt < nt && j < L && j >= pad) {
+        float* out = orow + (long long)j * ld;
+        *(float4*)(out + p.d + 4 * kq) = make_float4(dkA[jt][0] * f, dkA[jt][1] * f, dkA[jt][2] * f, dkA[jt][3] * f);
+        *(float4*)(out + 2 * p.d + 4 * kq) = make_float4(dvA[jt][0], dvA[jt][1], dvA[jt][2], dvA[jt][3]);
+      }
+    }
+  }
+}
+
 // launches KERNEL<HD, true> when dropout is on (p.dthresh != 0), KERNEL<HD, false> otherwise
 #define UR_ATTN_LAUNCH(KERNEL, HD, ...)                                   \
   do {                                                                    \
@@ -1565,6 +1752,16 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
     dim3 g3(attn_bh_grid(B, H, p.hd));
     static const bool no_t = getenv("UR_ATTN_NO_M16T") != nullptr;   // test / tuning hook: the un-transposed kernel for short L too
     const size_t lds_t = (size_t)attn_m16t_lds_floats(L, p.hd) * sizeof(float);
+    static const bool no_w = getenv("UR_ATTN_NO_M16W") != nullptr;   // test / tuning hook: the workgroup-per-head kernels for L <= 64 as well
+    const size_t lds_w = (size_t)attn_m16w_lds_floats(L, p.hd) * sizeof(float);
+    if (!no_t && !no_w && L <= 64 && lds_w <= 64 * 1024) {   // four heads per workgroup, a wave per head, one pass over the tile pairs
+      dim3 gw(B * cdiv(H, M16W_HEADS));
+#define GW_(HD) UR_ATTN_LAUNCH(attn_bwd_m16w_kernel, HD, gw, dim3(256), lds_w, st, qkv, seq, ctx, dctx, lse, p, dqkv)
+      if (p.hd == 4) GW_(4); else if (p.hd == 8) GW_(8); else GW_(16);
+#undef GW_
+      UR_LAUNCH_CHECK();
+      return UR_OK;
+    }
     if (!no_t && lds_t <= 40 * 1024) {   // >= 4 workgroups per CU
 #define GT_(HD) UR_ATTN_LAUNCH(attn_bwd_m16t_kernel, HD, g3, dim3(256), lds_t, st, qkv, seq, ctx, dctx, lse, p, dqkv)
       if (p.hd == 4) GT_(4); else if (p.hd == 8) GT_(8); else GT_(16);
