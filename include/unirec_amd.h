@@ -189,7 +189,8 @@ int ur_sasrec_set_side_stream(int on);
  * (:285-287) -- as one launch with the intermediate tiles in LDS; bit 2: ur_sasrec_bwd runs the mirror image (two LayerNorm backwards +
  * three activation-gradient GEMMs) as one launch; bit 4: the input-gradient GEMM of the projection with the embedding LayerNorm's backward
  * in its epilogue as a chain launch; bits 8 / 16: the B last rows of the last-row layer (last_only) go through the same forward /
- * backward chain kernels instead of three / four small GEMM launches.  Same K order as the stand-alone GEMMs.  Returns the previous mask.  The default mask and the
+ * backward chain kernels instead of three / four small GEMM launches; bit 32: the embedding lookup + position + LayerNorm
+ * (unirec/model/sequential/sasrec.py:60-69) and the first layer's Q/K/V projection as one launch.  Same K order as the stand-alone GEMMs.  Returns the previous mask.  The default mask and the
  * measurements behind it: DESIGN.md section 6d; environment UR_SASREC_CHAIN=<mask>. */
 int ur_sasrec_set_chain(int mask);
 

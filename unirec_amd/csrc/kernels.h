@@ -109,8 +109,8 @@ struct TransposeBatch {
 int transpose_batch(TransposeBatch& tb, hipStream_t st);   // every queued transpose in one launch
 
 // ---- rowchain.hip: row-block chain kernels (a workgroup carries BM token rows through a sequence of GEMMs, tiles in LDS)
-constexpr int CHAIN_FWD = 1, CHAIN_BWD = 2, CHAIN_PROJ = 4, CHAIN_LAST = 8, CHAIN_LAST_BWD = 16, CHAIN_ALL = 31;   // LAST*: the B last rows of the last-row layer
-constexpr int CHAIN_DEFAULT = CHAIN_FWD | CHAIN_LAST | CHAIN_LAST_BWD;  // which chain kernels run by default (UR_SASREC_CHAIN / ur_sasrec_set_chain: bit mask); DESIGN.md 6d
+constexpr int CHAIN_FWD = 1, CHAIN_BWD = 2, CHAIN_PROJ = 4, CHAIN_LAST = 8, CHAIN_LAST_BWD = 16, CHAIN_EMBED = 32, CHAIN_ALL = 63;   // LAST*: the B last rows of the last-row layer; EMBED: lookup + LN + first projection
+constexpr int CHAIN_DEFAULT = CHAIN_FWD | CHAIN_LAST | CHAIN_LAST_BWD | CHAIN_EMBED;  // which chain kernels run by default (UR_SASREC_CHAIN / ur_sasrec_set_chain: bit mask); DESIGN.md 6d
 bool chain_supported(int d, int inner, int which);
 bool chain_shape_ok(int d, int inner);              // the kernels exist for this shape (whatever the switch says)   // d in {32, 64, 128}, inner % d == 0, and the bit(s) `which` switched on
 int chain_rows_per_block(int d);
@@ -150,6 +150,17 @@ struct ChainProjBwdArgs {
   float* part;                          // with LayerNorm: [workgroups][2 d] d gamma | d beta partial sums
   int M; const int* m_dev;
 };
+struct ChainEmbedArgs {
+  const int* seq;                       // [B*L] item ids of the padded token grid
+  const float *table, *pos;             // item table [N, d]; position table [L, d] (nullable)
+  const float *g0, *b0ln; float eps;    // the embedding LayerNorm
+  int L; const int* tok;                // tok (nullable): buffer row -> token of the padded grid (compacted rows)
+  DropSpec drop;                        // embedding dropout (keyed by the token)
+  float *x0, *x0hat, *rstd0;            // outputs: the layer input [M, d], its normalised copy and 1/std (for the backward)
+  const float *wn, *bn; float* outn; int ldn, Nn;   // first projection: x0 Wn^T + bn, Wn [Nn, d], Nn % d == 0
+  int M; const int* m_dev;
+};
+int chain_embed_proj(const ChainEmbedArgs& a, int d, hipStream_t st);   // lookup + position + LayerNorm + the first layer's Q/K/V projection
 int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st);
 int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st);     // workgroups = cdiv(M, chain_rows_per_block(d))
 int chain_proj_bwd(const ChainProjBwdArgs& a, int d, hipStream_t st);

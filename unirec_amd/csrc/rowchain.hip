@@ -540,6 +540,86 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   }
 }
 
+// =============================================================================================== input block
+// x0 = dropout(LN(E[item_seq] + P)) and the FIRST layer's Q / K / V projection in one launch: the 32 gathered rows of a workgroup go
+// through the LayerNorm into the LDS tile (and out to x0 / x0hat / rstd0 for the backward) and are the A operand of the projection
+// straight away -- the stand-alone lookup kernel (10-13 us) and the x0 round trip disappear.  Same arithmetic as embed_ln_fwd_kernel
+// (rowops.hip) + the stand-alone projection GEMM (same K order).
+template <int D>
+__global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a) {
+  using G = RcGeom<D>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* At = smem;                  // [BM][TS]: x0
+  float* Ht = smem + G::TILE;        // [BM][TS]: accumulator staging
+  float* Wst = smem + 2 * G::TILE;   // [2][D][RC_LS]
+  int M = a.M;
+  if (a.m_dev) M = min(M, *a.m_dev);
+  const int m0 = blockIdx.x * G::BM;
+  if (m0 >= M) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / G::WC, wc = wave % G::WC;
+  const int et = tid % G::TPR, eg = tid / G::TPR;
+  const float inv_n = 1.0f / (float)D;
+  fx4 wreg[2][G::WV];
+  int buf = 0;
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.wn, D, 0, 0, tid), D);   // the first weight slice is in flight while the rows are gathered
+  {
+    const float4 gm = *(const float4*)(a.g0 + et * 4), bt = *(const float4*)(a.b0ln + et * 4);
+    int full[4];
+    float4 x[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {          // the four rows of this lane group: ids first, then all four row loads in flight
+      const int m = min(m0 + eg + p * G::RPP, M - 1);
+      full[p] = a.tok ? a.tok[m] : m;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const long long id = a.seq[full[p]];
+      x[p] = *(const float4*)(a.table + id * D + et * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        float4 v = x[p];
+        if (a.pos) {
+          const float4 ps = *(const float4*)(a.pos + (long long)(full[p] % a.L) * D + et * 4);
+          v.x += ps.x; v.y += ps.y; v.z += ps.z; v.w += ps.w;
+        }
+        float4 h;
+        const float rstd = rc_ln_row<G::TPR>(v, gm, bt, inv_n, a.eps, h, o);
+        *(float4*)(a.x0hat + (long long)m * D + et * 4) = h;
+        if (a.drop.thresh) o = drop4(o, mix32((unsigned)full[p] ^ a.drop.key), (unsigned)(et * 4), a.drop);
+        *(float4*)(a.x0 + (long long)m * D + et * 4) = o;
+        if (et == 0) a.rstd0[m] = rstd;
+      }
+      *(float4*)(At + rc_toff<D>(ml, et)) = o;
+    }
+  }
+  rc_prime_store<D>(wreg, rc_wptr<D>(a.wn, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
+  __syncthreads();
+  const int nn = a.Nn / D;
+  for (int c = 0; c < nn; ++c) {
+    floatx16 acc = zero16();
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wn, D, c * D, 0, tid), D, c + 1 < nn ? rc_wptr<D>(a.wn, D, (c + 1) * D, 0, tid) : nullptr, D, Wst, buf,
+               wreg, tid, wr, wc, lane);
+    rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
+    __syncthreads();
+    const float4 bs = *(const float4*)(a.bn + c * D + et * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      if (m < M) {
+        float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
+        v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+        *(float4*)(a.outn + (long long)m * a.ldn + c * D + et * 4) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // =============================================================================================== launchers
 // Defaults (kernels.h: CHAIN_DEFAULT = forward chain only), measured in situ on C5 (profiles/r02_g_chain_masks.txt): forward chain
 // 0.834 -> 0.812 ms/step (isolated: 99 us against 138 for the four launches it replaces); with the backward chains as well the step is
@@ -577,6 +657,20 @@ int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
     case 32: UR_CHAIN_DISPATCH(32, chain_ffn_fwd_kernel, a, grid); break;
     case 64: UR_CHAIN_DISPATCH(64, chain_ffn_fwd_kernel, a, grid); break;
     default: UR_CHAIN_DISPATCH(128, chain_ffn_fwd_kernel, a, grid); break;
+  }
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+int chain_embed_proj(const ChainEmbedArgs& a, int d, hipStream_t st) {
+  if (a.M <= 0) return UR_OK;
+  if (!(d == 32 || d == 64 || d == 128) || a.Nn <= 0 || a.Nn % d) return fail(UR_ERR_UNSUPPORTED, "chain_embed_proj: d=%d Nn=%d", d, a.Nn);
+  ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * (double)a.Nn);
+  const int grid = cdiv(a.M, chain_rows_per_block(d));
+  switch (d) {
+    case 32: UR_CHAIN_DISPATCH(32, chain_embed_proj_kernel, a, grid); break;
+    case 64: UR_CHAIN_DISPATCH(64, chain_embed_proj_kernel, a, grid); break;
+    default: UR_CHAIN_DISPATCH(128, chain_embed_proj_kernel, a, grid); break;
   }
   UR_LAUNCH_CHECK();
   return UR_OK;

@@ -350,13 +350,27 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
   }
   const int* tokmap = compact ? w.tok_full : nullptr;   // buffer row -> token id (identity when not compact)
   const DropSpec d_emb = site_spec(c, 0, DROP_SITE_EMBED, nullptr);
-  rc = embed_ln_fwd(item_seq, item_table, pos, dense + lay.off[1], dense + lay.off[2], c.eps, M, c.L, d, w.x0, w.x0hat, w.rstd0, st,
-                    tokmap, mv, &d_emb);
-  if (rc) return rc;
-  const float* x = w.x0;
   const bool chain = chain_supported(d, I, CHAIN_FWD);   // out-projection + LN + feed-forward + LN (+ next projection) as ONE launch per layer
   const bool chain_last = chain_supported(d, I, CHAIN_LAST);   // ... and for the B last rows of the last-row layer
-  bool proj_done = false;                     // this layer's K,V (Q,K,V) rows were written by the previous layer's chain kernel
+  bool proj_done = false;                     // this layer's K,V (Q,K,V) rows were written by the previous layer's chain kernel (or the input block's)
+  if (chain_supported(d, I, CHAIN_EMBED)) {   // lookup + position + LayerNorm + the first layer's projection as one launch
+    const LayerP p0 = layer_ptrs(dense, lay, 0);
+    const int skip_q = (c.last_only && c.n_layers == 1) ? 1 : 0;   // a last-row first layer projects K, V only here
+    ChainEmbedArgs ce{};
+    ce.seq = item_seq; ce.table = item_table; ce.pos = pos; ce.g0 = dense + lay.off[1]; ce.b0ln = dense + lay.off[2]; ce.eps = c.eps;
+    ce.L = c.L; ce.tok = tokmap; ce.drop = d_emb;
+    ce.x0 = w.x0; ce.x0hat = w.x0hat; ce.rstd0 = w.rstd0;
+    ce.wn = p0.wqkv + (long long)skip_q * d * d; ce.bn = p0.bqkv + skip_q * d;
+    ce.outn = w.layer[0].qkv + skip_q * d; ce.ldn = 3 * d; ce.Nn = (3 - skip_q) * d;
+    ce.M = M; ce.m_dev = mv;
+    if ((rc = chain_embed_proj(ce, d, st))) return rc;
+    proj_done = true;
+  } else {
+    rc = embed_ln_fwd(item_seq, item_table, pos, dense + lay.off[1], dense + lay.off[2], c.eps, M, c.L, d, w.x0, w.x0hat, w.rstd0, st,
+                      tokmap, mv, &d_emb);
+    if (rc) return rc;
+  }
+  const float* x = w.x0;
   for (int i = 0; i < c.n_layers; ++i) {
     const LayerP p = layer_ptrs(dense, lay, i);
     LayerWs& lw = w.layer[i];
