@@ -249,6 +249,17 @@ int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_emb, const fl
                            const int64_t* item_id, const int32_t* label, const float* scores,
                            const float* loss_out, const float* d_loss, float* coef, float* d_user,
                            float* d_user_bias_rows, void* stream);
+/* The training step's loss section as ONE launch: scores, per-row loss, d loss / d score (coef), d_user and the batch loss +
+ * update guard (loss_out, as ur_gather_dot_loss_fwd leaves it) -- what ur_gather_dot_loss_fwd followed by
+ * ur_gather_dot_loss_bwd (d_loss = NULL) compute in three launches.  Available for bpr / bce / ccl (the mean's denominator is
+ * B or B * G, known before the scores are) with G * d * 4 <= 32 KB: ask ur_gather_dot_loss_fused_supported, otherwise call the
+ * two entry points above.  Reference: unirec/model/base/recommender.py:199-241 (scorer + loss) under loss.backward().
+ * Launches on one device must not overlap each other (a per-device completion counter). */
+int ur_gather_dot_loss_fused_supported(const UrLossCfg* cfg);
+int ur_gather_dot_loss_fwd_bwd(const UrLossCfg* cfg, const float* user_emb, const float* item_table, int64_t n_items,
+                               const int64_t* item_id, const int32_t* label, const float* user_bias,
+                               const float* item_bias, const int64_t* user_id, float* scores, float* loss_rows,
+                               float* loss_out, float* coef, float* d_user, float* d_user_bias_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row-sparse gradient of an embedding table (replaces embedding_dense_backward + the dense [N,d]

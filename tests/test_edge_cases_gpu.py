@@ -148,3 +148,50 @@ def test_parameter_init_statistics_follow_the_reference_rules():
     x = get_class_instance("SASRec", "unirec_amd/model")(parse_arguments(dict(base, model="SASRec", init_method="xavier_normal")))
     w = x.state_dict()["trm_encoder.layer.0.feed_forward.dense_1.weight"]      # [128, 64]: std = sqrt(2 / (128 + 64))
     assert abs(float(w.std()) - (2.0 / 192) ** 0.5) < 5e-3
+
+
+@pytest.mark.parametrize("loss,G,biases", [("bpr", 5, False), ("bpr", 2, True), ("bce", 7, True), ("ccl", 5, False), ("bpr", 60, False)])
+def test_fused_loss_step_equals_forward_plus_backward(loss, G, biases):
+    """ur_gather_dot_loss_fwd_bwd (the training step's scorer + loss + gradient as one launch, batch loss finished by the last
+    workgroup) against ur_gather_dot_loss_fwd followed by ur_gather_dot_loss_bwd: scores, loss and coefficients to fp32 rounding
+    (same arithmetic per element), d_user to re-association of the sum over the candidates; twice in a row (the completion counter resets itself); softmax is not fusable and must take the two-launch path."""
+    from unirec_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    B, d, N = 300, 64, 5000
+    g = torch.Generator(device=dev).manual_seed(G)
+    ue = torch.randn(B, d, device=dev, generator=g) * 0.3
+    table = torch.randn(N, d, device=dev, generator=g) * 0.3
+    ids = torch.randint(1, N, (B, G), device=dev, generator=g)
+    lab = torch.zeros(B, G, dtype=torch.int32, device=dev)
+    lab[:, 0] = 1
+    ub = torch.randn(50, device=dev, generator=g) * 0.1 if biases else None
+    ib = torch.randn(N, device=dev, generator=g) * 0.1 if biases else None
+    uid = torch.randint(1, 50, (B,), device=dev, generator=g) if biases else None
+    cfg = ops.loss_cfg(B, G, d, loss, 0.7, 3.0 if loss == "bce" else -1.0, 0.5, 0.2)
+    assert _lib.lib.ur_gather_dot_loss_fused_supported(cfg)
+    s0, _, lo0 = ops.gather_dot_loss_fwd(cfg, ue, table, ids, lab, ub, ib, uid)
+    c0, du0, dub0 = ops.gather_dot_loss_bwd(cfg, ue, table, ids, lab, s0, lo0, None, want_user_bias=biases)
+    for _ in range(2):
+        s1, lo1, c1, du1, dub1 = ops.gather_dot_loss_fwd_bwd(cfg, ue, table, ids, lab, ub, ib, uid, want_user_bias=biases)
+        torch.cuda.synchronize()
+        assert torch.allclose(s0, s1, rtol=2e-6, atol=1e-6)      # (the compiler contracts the dot products of the two kernels differently)
+        assert torch.allclose(lo0[:3], lo1[:3], rtol=2e-6, atol=0), (lo0, lo1)
+        assert torch.allclose(c0, c1, rtol=1e-5, atol=1e-9)
+        assert torch.allclose(du0, du1, rtol=1e-5, atol=1e-8)
+        if biases:
+            assert torch.allclose(dub0, dub1, rtol=1e-5, atol=1e-9)
+    cfg_s = ops.loss_cfg(B, G, d, "softmax", 0.7, -1.0)
+    assert not _lib.lib.ur_gather_dot_loss_fused_supported(cfg_s)
+    s2, lo2, c2, du2, _ = ops.gather_dot_loss_fwd_bwd(cfg_s, ue, table, ids, lab, None, None, None)
+    s3, _, lo3 = ops.gather_dot_loss_fwd(cfg_s, ue, table, ids, lab)
+    assert torch.equal(s2, s3) and torch.equal(lo2[:3], lo3[:3])
+    big = ops.loss_cfg(8, 1001, 128, "bpr", 1.0, -1.0)          # 1001 candidates of 512 bytes do not fit the LDS budget
+    assert not _lib.lib.ur_gather_dot_loss_fused_supported(big)
+    # a NaN score reaches the update guard through the fused path as well
+    ue_bad = ue.clone()
+    ue_bad[3, 0] = float("nan")
+    _, lo4, _, _, _ = ops.gather_dot_loss_fwd_bwd(cfg, ue_bad, table, ids, lab, ub, ib, uid, want_user_bias=biases)
+    if loss != "bce":                                           # (bce runs with score_clip here: fmin / fmax clip the NaN away, in both paths)
+        assert float(lo4[2]) == -1.0
+    _, lo5, _, _, _ = ops.gather_dot_loss_fwd_bwd(cfg, ue, table, ids, lab, ub, ib, uid, want_user_bias=biases)
+    assert float(lo5[2]) == 1.0 and torch.allclose(lo5[:3], lo0[:3], rtol=2e-6, atol=0)

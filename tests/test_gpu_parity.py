@@ -288,8 +288,10 @@ def test_rowwise_mode_only_touches_looked_up_rows():
 # ------------------------------------------------------------------------------------------ fused step == autograd step
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
 def test_forward_backward_equals_autograd_path(name):
-    """model.forward_backward (the trainer's default) issues the same launches as model(...) + loss.backward():
-    loss, dense gradient, bias gradients and the row-sparse gradient pieces must be bit-identical."""
+    """model.forward_backward (the trainer's default) issues the same launches as model(...) + loss.backward() -- except for the
+    scorer + loss section, which it runs as ONE fused launch (ur_gather_dot_loss_fwd_bwd) where the loss allows it: loss, dense
+    gradient, bias gradients and the row-sparse gradient pieces agree to fp32 rounding of that section (2e-6 of each tensor's
+    scale; bit-identical wherever the two-launch path is taken)."""
     cfg, g = load_golden(name)
     dev = _dev()
     batch = {k: v.to(dev) for k, v in _t(g["in"]).items()}
@@ -310,16 +312,28 @@ def test_forward_backward_equals_autograd_path(name):
         out.append((loss.detach().clone(), None if m.dense_flat.grad is None else m.dense_flat.grad.clone(),
                     [None if p.grad is None else p.grad.clone() for n, p in m.named_parameters() if n in ("user_bias", "item_bias")],
                     pieces))
+    def same(x, y, what):
+        if x.dtype.is_floating_point:
+            scale = max(float(x.abs().max()), 1e-30) if x.numel() else 1.0
+            err = float((x.reshape(-1) - y.reshape(-1)).abs().max()) / scale if x.numel() else 0.0
+            assert err <= 2e-6, (what, err)
+        else:
+            assert torch.equal(x.reshape(-1), y.reshape(-1)), what
+
     (l0, d0, b0, s0), (l1, d1, b1, s1) = out
-    assert torch.equal(l0, l1)
-    assert (d0 is None) == (d1 is None) and (d0 is None or torch.equal(d0, d1))
-    assert len(b0) == len(b1) and all(torch.equal(x, y) for x, y in zip(b0, b1))
+    same(l0, l1, "loss")
+    assert (d0 is None) == (d1 is None)
+    if d0 is not None:
+        same(d0, d1, "dense gradient")
+    assert len(b0) == len(b1)
+    for x, y in zip(b0, b1):
+        same(x, y, "bias gradient")
     assert len(s0) == len(s1)
     for x, y in zip(s0, s1):
         assert x.keys() == y.keys() and x["table"] == y["table"]
         for k in x:
             if torch.is_tensor(x[k]):
-                assert torch.equal(x[k].reshape(-1), y[k].reshape(-1)), k
+                same(x[k], y[k], k)
 
 
 @pytest.mark.parametrize("B,L,d,heads,layers", [(37, 50, 64, 8, 2), (1100, 20, 32, 8, 1), (3, 64, 64, 4, 3), (5, 33, 16, 4, 2),

@@ -74,6 +74,8 @@ SIGNATURES = {
     "ur_gru_bwd": (C.c_int, [C.POINTER(UrGruCfg), P, I64, P, P, P, P, P, P, P]),
     "ur_gather_dot_loss_fwd": (C.c_int, [C.POINTER(UrLossCfg), P, P, I64, P, P, P, P, P, P, P, P, P]),
     "ur_gather_dot_loss_bwd": (C.c_int, [C.POINTER(UrLossCfg), P, P, I64, P, P, P, P, P, P, P, P, P]),
+    "ur_gather_dot_loss_fused_supported": (C.c_int, [C.POINTER(UrLossCfg)]),
+    "ur_gather_dot_loss_fwd_bwd": (C.c_int, [C.POINTER(UrLossCfg), P, P, I64, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ur_rows_plan_workspace_bytes": (I64, [I64]),
     "ur_rows_plan": (C.c_int, [P, I64, P, I64, I64, P, P, P, P, P, P]),
     "ur_rows_plan_merge": (C.c_int, [P, I64, P, I32, P, P, P, P, P, P]),

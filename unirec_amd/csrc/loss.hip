@@ -270,6 +270,169 @@ __global__ __launch_bounds__(NT) void scorer_loss_bwd_kernel(UrLossCfg c, const 
   }
 }
 
+// ---- training step in ONE launch: scores + per-row loss + d loss / d score + d_user, and the batch loss finished by the LAST
+// workgroup.  ur_gather_dot_loss_fwd + ur_gather_dot_loss_bwd are three launches (scores / loss rows, the one-workgroup mean, the
+// gradient) of 5-8 us each with nothing to hide their latency behind: at a few candidates per row (BPR with 4 negatives) the whole
+// loss section of a step is launch latency.  The backward needs the denominator of the mean before it can scale a single
+// coefficient -- for bpr / bce / ccl that is B or B * G, known on the host -- so one workgroup can carry a row from the gather to
+// d_user: the candidate rows it gathered for the scores stay in LDS ([G][d], G * d * 4 <= 32 KB) and are the operand of
+// d_user = sum_g coef_g E_g (no second gather).  The mean over the batch (and the NaN guard the optimizer kernels read) is summed by
+// the workgroup that finishes last, in row order (fixed order: bit-reproducible), behind a device-scope fence and a counter that
+// resets itself.  Same arithmetic per element as the two kernels above (softmax, whose denominator is data-dependent, keeps them).
+template <int TPR>
+__global__ __launch_bounds__(256) void scorer_loss_fused_kernel(UrLossCfg c, float total, const float4* __restrict__ user_emb,
+                                                                const float4* __restrict__ table, const long long* __restrict__ item_id,
+                                                                const int* __restrict__ label, const float* __restrict__ user_bias,
+                                                                const float* __restrict__ item_bias, const long long* __restrict__ user_id,
+                                                                float* __restrict__ scores, float* __restrict__ loss_rows,
+                                                                float* __restrict__ cnt_rows, float* __restrict__ coef,
+                                                                float* __restrict__ d_user, float* __restrict__ d_user_bias_rows,
+                                                                float* __restrict__ loss_out, unsigned* __restrict__ done_counter) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];   // [G][d] rows, [G] scores, [G] coefficients, 16 floats of scratch
+  const int b = blockIdx.x, G = c.G, d4 = c.d / 4, d = c.d;
+  float* rows = sh;
+  float* sc = rows + (long long)G * d;
+  float* cf = sc + G;
+  float* red = cf + G;
+  __shared__ int is_last;
+  constexpr int groups = 256 / TPR, UNR = 4;
+  const int g0 = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  float4 u[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int col = t + k * TPR;
+    u[k] = col < d4 ? user_emb[(long long)b * d4 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float ub = user_bias ? user_bias[user_id[b]] : 0.f;
+  for (int gb = g0 * UNR; gb < G; gb += groups * UNR) {
+    long long id[UNR];
+    float s[UNR];
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      id[q] = (gb + q < G) ? item_id[(long long)b * G + gb + q] : 0;
+      s[q] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int col = t + k * TPR;
+      if (col < d4) {
+        float4 e[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+          typedef float vf4_t __attribute__((ext_vector_type(4)));
+          const vf4_t t4 = __builtin_nontemporal_load((const vf4_t*)&table[id[q] * d4 + col]);   // rows are read once: do not keep them in L2
+          e[q] = make_float4(t4.x, t4.y, t4.z, t4.w);
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+          s[q] += (e[q].x * u[k].x + e[q].y * u[k].y) + (e[q].z * u[k].z + e[q].w * u[k].w);
+          if (gb + q < G) *(float4*)(rows + (long long)(gb + q) * d + col * 4) = e[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) s[q] = group_sum<TPR>(s[q]);
+    if (t == 0) {
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) {
+        const int g = gb + q;
+        if (g < G) {
+          float v = s[q] + ub;
+          if (item_bias) v += item_bias[id[q]];
+          v = v / c.tau;
+          if (c.score_clip > 0.f) v = fminf(fmaxf(v, -c.score_clip), c.score_clip);
+          sc[g] = v;
+          scores[(long long)b * G + g] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- per-row loss and d loss / d score (the arithmetic of scorer_loss_fwd_kernel / scorer_loss_bwd_kernel)
+  float part = 0.f, cnt = 1.f;
+  if (c.loss_type == UR_LOSS_BPR) {
+    const float s0 = sc[0];
+    float a0 = 0.f;
+    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) {
+      const float sg = 1.0f / (1.0f + expf(-(s0 - sc[g])));
+      part += -logf(kEps + sg);
+      const float w = sg * (1.f - sg) / (kEps + sg) / ((float)(G - 1) * total);
+      cf[g] = w;
+      a0 -= w;
+    }
+    part = block_sum(part, red) / (float)(G - 1);
+    a0 = block_sum(a0, red);
+    if (threadIdx.x == 0) cf[0] = a0;
+  } else if (c.loss_type == UR_LOSS_BCE) {
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+      const float p = 1.0f / (1.0f + expf(-sc[g]));  // clamp(sigmoid, -EPS, 1-EPS) is the identity in fp32
+      const float y = (float)label[(long long)b * G + g];
+      part += -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+      const float gp = (logf(p) > -100.f ? y * (1.f - p) : 0.f) - (logf(1.f - p) > -100.f ? (1.f - y) * p : 0.f);
+      cf[g] = -gp / total;
+    }
+    part = block_sum(part, red);
+    cnt = (float)G;
+  } else {  // CCL
+    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) part += fmaxf(sc[g] - c.ccl_m, 0.f);
+    part = 1.f - sc[0] + c.ccl_w * block_sum(part, red) / (float)(G - 1);
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+      cf[g] = (g == 0) ? -1.f / total : ((sc[g] - c.ccl_m > 0.f) ? c.ccl_w / ((float)(G - 1) * total) : 0.f);
+  }
+  if (threadIdx.x == 0) {
+    // device-scope atomic stores: written through to the coherence point, so the workgroup that finishes last (maybe on another XCD,
+    // behind another L2) can read them with device-scope loads -- WITHOUT a device-scope fence, which on this part writes back the
+    // whole L2 of the XCD (the forward pass's activations are sitting there dirty: 512 such fences cost the step 20 us)
+    __hip_atomic_store(loss_rows + b, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cnt_rows + b, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  float bsum = 0.f;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float v = cf[g] / c.tau;
+    if (c.score_clip > 0.f && fabsf(sc[g]) >= c.score_clip) v = 0.f;
+    cf[g] = v;
+    coef[(long long)b * G + g] = v;
+    bsum += v;
+  }
+  if (d_user_bias_rows) {
+    bsum = block_sum(bsum, red);
+    if (threadIdx.x == 0) d_user_bias_rows[b] = bsum;
+  }
+  __syncthreads();
+  // ---- d_user[b,:] = sum_g coef[g] * E[item_id[b,g],:]   (rows from LDS, candidates in order)
+  for (int col = threadIdx.x; col < d4; col += blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < G; ++g) {
+      const float w = cf[g];
+      const float4 e = *(const float4*)(rows + (long long)g * d + col * 4);
+      acc.x = fmaf(w, e.x, acc.x); acc.y = fmaf(w, e.y, acc.y); acc.z = fmaf(w, e.z, acc.z); acc.w = fmaf(w, e.w, acc.w);
+    }
+    *(float4*)(d_user + (long long)b * d + col * 4) = acc;
+  }
+  // ---- the batch loss, by whichever workgroup finishes last
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (waits for this thread's two stores above to be acknowledged; no cache flush)
+    const unsigned prev = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = prev == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  float s = 0.f, n = 0.f;
+  for (int i = threadIdx.x; i < c.B; i += blockDim.x) {
+    s += __hip_atomic_load(loss_rows + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    n += __hip_atomic_load(cnt_rows + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  s = block_sum(s, red);
+  n = block_sum(n, red);
+  if (threadIdx.x == 0) {
+    loss_out[0] = s / n;
+    loss_out[1] = n;
+    loss_out[2] = (s / n) != (s / n) ? -1.0f : 1.0f;   // update guard (see loss_finish_kernel)
+    __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  }
+}
+
 static inline int pick_tpr(int d) {
   int d4 = d / 4, t = 4;
   while (t < d4 && t < 32) t <<= 1;
@@ -352,6 +515,63 @@ extern "C" int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_em
 #define GOB(T, NT) hipLaunchKernelGGL((scorer_loss_bwd_kernel<T, NT>), dim3(cfg->B), dim3(NT), lds, st, *cfg, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, scores, d_loss, loss_out, coef,  \
                                  (float4*)d_user, d_user_bias_rows)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+// One counter per device for the "last workgroup finishes the loss" step of the fused kernel (zeroed once; the kernel resets it).
+// Launches of the fused kernel on ONE device must not overlap each other (one training stream per process: they do not).
+static unsigned* fused_counter() {
+  static unsigned* z[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!z[dev]) {
+    unsigned* p = nullptr;
+    if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    z[dev] = p;
+  }
+  return z[dev];
+}
+
+extern "C" int ur_gather_dot_loss_fused_supported(const UrLossCfg* cfg) {
+  if (!cfg || getenv("UR_LOSS_NO_FUSE")) return 0;
+  if (!(cfg->loss_type == UR_LOSS_BPR || cfg->loss_type == UR_LOSS_BCE || cfg->loss_type == UR_LOSS_CCL)) return 0;
+  return ((size_t)cfg->G * cfg->d + 2 * (size_t)cfg->G + 16) * sizeof(float) <= 32 * 1024 && cfg->d % 4 == 0 && cfg->d <= 512;
+}
+
+extern "C" int ur_gather_dot_loss_fwd_bwd(const UrLossCfg* cfg, const float* user_emb, const float* item_table, int64_t n_items,
+                                          const int64_t* item_id, const int32_t* label, const float* user_bias,
+                                          const float* item_bias, const int64_t* user_id, float* scores, float* loss_rows,
+                                          float* loss_out, float* coef, float* d_user, float* d_user_bias_rows, void* stream) {
+  int rc = check_loss_cfg(cfg, "ur_gather_dot_loss_fwd_bwd");
+  if (rc) return rc;
+  UR_REQUIRE(user_emb && item_table && item_id && scores && loss_rows && loss_out && coef && d_user, UR_ERR_ARG,
+             "ur_gather_dot_loss_fwd_bwd: null pointer");
+  UR_REQUIRE(n_items > 0, UR_ERR_ARG, "ur_gather_dot_loss_fwd_bwd: n_items");
+  UR_REQUIRE(label || cfg->loss_type != UR_LOSS_BCE, UR_ERR_ARG, "ur_gather_dot_loss_fwd_bwd: label is required for bce");
+  UR_REQUIRE(!user_bias || user_id, UR_ERR_ARG, "ur_gather_dot_loss_fwd_bwd: user_bias needs user_id");
+  UR_REQUIRE(ur_gather_dot_loss_fused_supported(cfg), UR_ERR_UNSUPPORTED,
+             "ur_gather_dot_loss_fwd_bwd: loss_type=%d G=%d d=%d (bpr / bce / ccl with G * d * 4 <= 32 KB; otherwise call _fwd and _bwd)",
+             cfg->loss_type, cfg->G, cfg->d);
+  hipStream_t st = as_stream(stream);
+  unsigned* counter = fused_counter();
+  UR_REQUIRE(counter != nullptr, UR_ERR_HIP, "ur_gather_dot_loss_fwd_bwd: no device memory for the completion counter");
+  ProfScope ps(PC_LOSS, st, (double)cfg->B * cfg->G * cfg->d * 4.0);
+  const int tpr = pick_tpr(cfg->d);
+  const size_t lds = ((size_t)cfg->G * cfg->d + 2 * (size_t)cfg->G + 16) * sizeof(float);
+  const float total = cfg->loss_type == UR_LOSS_BCE ? (float)cfg->B * (float)cfg->G : (float)cfg->B;
+  float* cnt_rows = loss_rows + cfg->B;
+#define GO(T) hipLaunchKernelGGL((scorer_loss_fused_kernel<T>), dim3(cfg->B), dim3(256), lds, st, *cfg, total, (const float4*)user_emb, \
+                                 (const float4*)item_table, (const long long*)item_id, label, user_bias, item_bias,                 \
+                                 (const long long*)user_id, scores, loss_rows, cnt_rows, coef, d_user, d_user_bias_rows, loss_out, counter)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

@@ -267,9 +267,9 @@ class BaseRecommender(AbstractRecommender):
         ub = self.user_bias.data if self.has_user_bias else None
         ib = self.item_bias.data if self.has_item_bias else None
         table = self.item_embedding.weight.data
-        scores, _, loss_out = ops.gather_dot_loss_fwd(cfg, user_emb, table, item_id, lab, ub, ib, user_id if ub is not None else None)
-        coef, d_user, d_ub = ops.gather_dot_loss_bwd(cfg, user_emb, table, item_id, lab, scores, loss_out, None,
-                                                     want_user_bias=self.has_user_bias)
+        scores, loss_out, coef, d_user, d_ub = ops.gather_dot_loss_fwd_bwd(cfg, user_emb, table, item_id, lab, ub, ib,
+                                                                           user_id if ub is not None else None,
+                                                                           want_user_bias=self.has_user_bias)
         self.sparse_grads.append(dict(table="item_embedding", ids_b=item_id, coef=coef, vec=user_emb, G=G))
         if self.has_item_bias:
             g = torch.zeros_like(self.item_bias)

@@ -174,6 +174,34 @@ def gather_dot_loss_bwd(cfg, user_emb, item_table, item_id, label, scores, loss_
     return coef, d_user, d_ub
 
 
+def gather_dot_loss_fwd_bwd(cfg, user_emb, item_table, item_id, label=None, user_bias=None, item_bias=None, user_id=None,
+                            want_user_bias=False):
+    """scorer + loss + its backward for one training step -> (scores, loss_out, coef, d_user, d_user_bias_rows).  ONE launch
+    (ur_gather_dot_loss_fwd_bwd) where the loss allows it (bpr / bce / ccl, G * d * 4 <= 32 KB), else the two entry points."""
+    if not lib.ur_gather_dot_loss_fused_supported(C.byref(cfg)):
+        scores, _, loss_out = gather_dot_loss_fwd(cfg, user_emb, item_table, item_id, label, user_bias, item_bias, user_id)
+        coef, d_user, d_ub = gather_dot_loss_bwd(cfg, user_emb, item_table, item_id, label, scores, loss_out, None, want_user_bias)
+        return scores, loss_out, coef, d_user, d_ub
+    _chk(user_emb, torch.float32, "user_emb")
+    _chk(item_table, torch.float32, "item_table")
+    _chk(item_id, torch.int64, "item_id")
+    _chk(label, torch.int32, "label", allow_none=True)
+    _chk(user_bias, torch.float32, "user_bias", allow_none=True)
+    _chk(item_bias, torch.float32, "item_bias", allow_none=True)
+    _chk(user_id, torch.int64, "user_id", allow_none=True)
+    dev = user_emb.device
+    scores = torch.empty(cfg.B, cfg.G, dtype=torch.float32, device=dev)
+    loss_rows = torch.empty(2 * cfg.B, dtype=torch.float32, device=dev)
+    loss_out = torch.empty(4, dtype=torch.float32, device=dev)   # [loss, count, update guard, -]
+    coef = torch.empty(cfg.B, cfg.G, dtype=torch.float32, device=dev)
+    d_user = torch.empty(cfg.B, cfg.d, dtype=torch.float32, device=dev)
+    d_ub = torch.empty(cfg.B, dtype=torch.float32, device=dev) if want_user_bias else None
+    check(lib.ur_gather_dot_loss_fwd_bwd(C.byref(cfg), _p(user_emb), _p(item_table), item_table.shape[0], _p(item_id), _p(label),
+                                         _p(user_bias), _p(item_bias), _p(user_id), _p(scores), _p(loss_rows), _p(loss_out), _p(coef),
+                                         _p(d_user), _p(d_ub), _stream()), "ur_gather_dot_loss_fwd_bwd")
+    return scores, loss_out, coef, d_user, d_ub
+
+
 # --------------------------------------------------------------------------------------------- sparse rows
 class RowsPlan:
     """Result of ur_rows_plan (all device tensors; n_uniq stays on the device)."""

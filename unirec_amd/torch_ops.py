@@ -310,5 +310,7 @@ NOT_OPS = {
     "ur_convformer_fwd": _FAMILY, "ur_convformer_bwd": _FAMILY, "ur_atthist_fwd": _FAMILY, "ur_atthist_bwd": _FAMILY,
     "ur_pool_rows_fwd": _FAMILY, "ur_pool_rows_bwd": _FAMILY, "ur_full_softmax_fwd": _FAMILY, "ur_full_softmax_bwd": _FAMILY,
     "ur_rows_scatter_add": _FAMILY,
+    "ur_gather_dot_loss_fused_supported": _QUERY,
+    "ur_gather_dot_loss_fwd_bwd": "fusion of the two ops gather_dot_loss_fwd + gather_dot_loss_bwd (both registered) for the graph-free training step: a scheduling choice, not a new op",
     "ur_rows_reduce_adam": "fusion of the two ops rows_reduce + sparse_adam_rows (both registered): a scheduling choice of the optimizer, not a new op",
 }
