@@ -163,83 +163,84 @@ __global__ void put_last_kernel(const float* __restrict__ src, int B, int L, int
 // stack then runs over M' = sum_b (L - pad_b) compact rows instead of B*L:
 //   tok_full[r]  = b*L + l of compact row r          seq_base[b] = (first compact row of b) - pad_b  (row of (b,l) = seq_base[b] + l)
 //   seq_pad[b]   = pad_b                             last_row[b] = compact row of (b, L-1)          m_valid[0] = M'
-// M' stays on the device: grids are sized for B*L and surplus workgroups exit.  One workgroup of 1024 threads.
+// M' stays on the device: grids are sized for B*L and surplus workgroups exit.
+// Workgroup k writes the maps of sequences [k * CP_SEQS, (k + 1) * CP_SEQS); the compact row of its first sequence is the sum of the
+// lengths of every sequence before it, which it computes ITSELF from their rows (the whole id matrix is ~100 KB and sits in L2:
+// reading it eight times costs less than a second launch or a spin on another workgroup's result).  First item of a sequence: a
+// wave per sequence, lane = position (coalesced row reads, ballot + count-trailing-zeros), sixteen sequences in flight per wave.
+// (Round 1-2a: ONE workgroup walked all B sequences and then wrote the token map, 32 sequences per wave in turn: 14 us at the
+// head of every step.)
+constexpr int CP_SEQS = 64;
 __global__ __launch_bounds__(1024) void compact_plan_kernel(const int* __restrict__ seq, int B, int L, int* __restrict__ tok_full,
                                                             int* __restrict__ seq_base, int* __restrict__ seq_pad,
                                                             int* __restrict__ last_row, int* __restrict__ m_valid) {
-  __shared__ int s_base[1024];  // first compact row of each sequence of the chunk
-  __shared__ int s_pad[1024];   // first non-zero position (0 if none: an all-padding sequence keeps every position)
-  __shared__ int wtot[16];
-  __shared__ int carry_s;
+  __shared__ int s_pad[CP_SEQS];   // first non-zero position of this workgroup's sequences (0 if none: an all-padding sequence keeps every position)
+  __shared__ int s_len[CP_SEQS];
+  __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int c0 = 0; c0 < B; c0 += 1024) {
-    const int nb = min(1024, B - c0);
-    // first item of each sequence: a wave per sequence, lane = position (coalesced row reads, ballot + count-trailing-zeros);
-    // sixteen sequences per round: the kernel is one workgroup, so the row loads in flight per lane are all the memory
-    // parallelism there is
-    constexpr int U = 16;
-    for (int s0 = wv * U; s0 < nb; s0 += 16 * U) {
-      int first[U];
+  const int b0 = blockIdx.x * CP_SEQS, b1 = min(B, b0 + CP_SEQS);
+  const bool tail = b1 == B;       // the last workgroup also knows the total
+  // ---- lengths of the sequences [0, b1): summed for b < b0 (per wave, then over the waves), kept for b0 <= b < b1
+  int before = 0;
+  constexpr int U = 16;
+  for (int s0 = wv * U; s0 < b1; s0 += 16 * U) {
+    int first[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) first[u] = L;
-      for (int l0 = 0; l0 < L; l0 += 64) {
-        int v[U];
+    for (int u = 0; u < U; ++u) first[u] = L;
+    for (int l0 = 0; l0 < L; l0 += 64) {
+      int v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          v[u] = seq[((long long)c0 + min(s0 + u, nb - 1)) * L + min(l0 + lane, L - 1)];   // clamped, unconditional: the U loads
-        const bool lin = l0 + lane < L;                                                    // issue back to back
-        bool all_found = true;
+      for (int u = 0; u < U; ++u)
+        v[u] = seq[(long long)min(s0 + u, b1 - 1) * L + min(l0 + lane, L - 1)];   // clamped, unconditional: the U loads issue back to back
+      const bool lin = l0 + lane < L;
+      bool all_found = true;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const unsigned long long m = __ballot(lin && v[u] > 0);
-          if (first[u] == L && m) first[u] = l0 + (int)__builtin_ctzll(m);
-          all_found &= first[u] < L;
-        }
-        if (all_found) break;
+      for (int u = 0; u < U; ++u) {
+        const unsigned long long m = __ballot(lin && v[u] > 0);
+        if (first[u] == L && m) first[u] = l0 + (int)__builtin_ctzll(m);
+        all_found &= first[u] < L;
       }
-      int f = L;
-#pragma unroll
-      for (int u = 0; u < U; ++u) f = lane == u ? first[u] : f;
-      if (lane < U && s0 + lane < nb) s_pad[s0 + lane] = f == L ? 0 : f;
+      if (all_found) break;
     }
-    __syncthreads();
-    const int pad = tid < nb ? s_pad[tid] : 0;
-    const int len = tid < nb ? L - pad : 0;
-    // exclusive scan of the lengths: shuffles inside a wave, the 16 wave totals through LDS
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int sb = s0 + u;
+      const int pad = first[u] == L ? 0 : first[u];
+      if (sb < b0) before += L - pad;                                   // (wave-uniform values: every lane holds the same sum)
+      else if (sb < b1 && lane == 0) { s_pad[sb - b0] = pad; s_len[sb - b0] = L - pad; }
+    }
+  }
+  if (lane == 0) wsum[wv] = before;
+  __syncthreads();
+  int base0 = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) base0 += wsum[k];
+  // ---- this workgroup's sequences: exclusive scan of their lengths (wave 0), then the maps
+  const int nb = b1 - b0;
+  __shared__ int s_base[CP_SEQS];
+  if (wv == 0) {
+    const int len = lane < nb ? s_len[lane] : 0;
     int inc = len;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const int v = __shfl_up(inc, off, 64);
       if (lane >= off) inc += v;
     }
-    if (lane == 63) wtot[wv] = inc;
-    __syncthreads();
-    int before = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int t = wtot[k];
-      before += k < wv ? t : 0;
-      total += t;
+    const int base = base0 + inc - len;
+    s_base[lane] = base;
+    if (lane < nb) {
+      const int pad = s_pad[lane];
+      seq_base[b0 + lane] = base - pad;
+      seq_pad[b0 + lane] = pad;
+      last_row[b0 + lane] = base + len - 1;
     }
-    const int base = carry_s + before + inc - len;    // first compact row of sequence c0 + tid
-    s_base[tid] = base;
-    if (tid < nb) {
-      seq_base[c0 + tid] = base - pad;
-      seq_pad[c0 + tid] = pad;
-      last_row[c0 + tid] = base + len - 1;
-    }
-    __syncthreads();
-    for (int sb = wv; sb < nb; sb += 16) {   // token map: a wave per sequence, coalesced stores
-      const int pd = s_pad[sb], bs = s_base[sb] - pd;
-      for (int l = pd + lane; l < L; l += 64) tok_full[bs + l] = (c0 + sb) * L + l;
-    }
-    __syncthreads();
-    if (tid == 0) carry_s += total;
-    __syncthreads();
+    if (tail && lane == 63) m_valid[0] = base0 + inc;
   }
-  if (tid == 0) m_valid[0] = carry_s;
+  __syncthreads();
+  for (int sb = wv; sb < nb; sb += 16) {   // token map: a wave per sequence, coalesced stores
+    const int pd = s_pad[sb], bs = s_base[sb] - pd;
+    for (int l = pd + lane; l < L; l += 64) tok_full[bs + l] = (b0 + sb) * L + l;
+  }
 }
 // dst[b,:] = src[idx[b],:]
 __global__ void gather_rows_idx_kernel(const float* __restrict__ src, const int* __restrict__ idx, int B, int d, float* __restrict__ dst) {
@@ -344,8 +345,8 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
   const int* sbase = compact ? w.seq_base : nullptr;
   const int* spad = compact ? w.seq_pad : nullptr;
   if (compact) {
-    hipLaunchKernelGGL(compact_plan_kernel, dim3(1), dim3(1024), 0, st, item_seq, c.B, c.L, w.tok_full, w.seq_base, w.seq_pad, w.last_row,
-                       w.m_valid);
+    hipLaunchKernelGGL(compact_plan_kernel, dim3(cdiv(c.B, CP_SEQS)), dim3(1024), 0, st, item_seq, c.B, c.L, w.tok_full, w.seq_base, w.seq_pad,
+                       w.last_row, w.m_valid);
     UR_LAUNCH_CHECK();
   }
   const int* tokmap = compact ? w.tok_full : nullptr;   // buffer row -> token id (identity when not compact)
