@@ -1469,9 +1469,14 @@ __global__ __launch_bounds__(256) void attn_bwd_m16t_kernel(const float* __restr
 //     rows 48 bytes apart) with a select for the feature rows >= HD.
 // Same arithmetic per element as the kernels above; results differ from theirs only by the summation order inside dK / dV.
 constexpr int M16W_TS = 20, M16W_HEADS = 4;
+// row stride of the staged tiles: head dim 8 needs no padding -- rows 8 .. 15 of every 16 keep their two 16-byte halves swapped
+// (column c of row r sits at r * 8 + (c ^ ((r & 8) >> 1))), which makes the b64 fragment reads of a 16-row tile conflict-free; the
+// 8 floats per row this saves (12 -> 8) are what lets TWO of these workgroups share a CU with a weight-gradient GEMM of the side
+// stream (2 x 45 + 67 KB <= 160 KB) instead of one
+__host__ __device__ inline int attn_m16w_ldk(int hd) { return hd == 8 ? 8 : hd + 4; }
 __host__ __device__ inline int attn_m16w_head_floats(int L, int hd) {
   const int Lp = (L + 15) & ~15;
-  return 4 * Lp * (hd + 4) + 2 * Lp;
+  return 4 * Lp * attn_m16w_ldk(hd) + 2 * Lp;
 }
 __host__ __device__ inline int attn_m16w_lds_floats(int L, int hd) {
   const int Lp = (L + 15) & ~15;
@@ -1482,7 +1487,8 @@ template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_m16w_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
                                                             const float* __restrict__ ctx, const float* __restrict__ dctx,
                                                             const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
-  constexpr int KS = HD / 4, LDK = HD + 4, PR = HD / 4, NTM = 4, TS = M16W_TS, SL = M16W_HEADS * PR;   // SL: float4 slots per row
+  constexpr int KS = HD / 4, LDK = HD == 8 ? 8 : HD + 4, PR = HD / 4, NTM = 4, TS = M16W_TS, SL = M16W_HEADS * PR;   // SL: float4 slots per row
+  auto at = [](int row, int c) { return row * LDK + (HD == 8 ? (c ^ ((row & 8) >> 1)) : c); };   // element (row, c) of a staged tile
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) float smem_m16[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1515,10 +1521,10 @@ __global__ __launch_bounds__(256) void attn_bwd_m16w_kernel(const float* __restr
       g4 = *(const float4*)(dctx + row * p.d + h * HD + c); o4 = *(const float4*)(ctx + row * p.d + h * HD + c);
     }
     float* base = smem_m16 + hh * HF;
-    *(float4*)(base + j * LDK + c) = q4;
-    *(float4*)(base + (Lp + j) * LDK + c) = k4;
-    *(float4*)(base + (2 * Lp + j) * LDK + c) = v4;
-    *(float4*)(base + (3 * Lp + j) * LDK + c) = g4;
+    *(float4*)(base + at(j, c)) = q4;
+    *(float4*)(base + Lp * LDK + at(j, c)) = k4;
+    *(float4*)(base + 2 * Lp * LDK + at(j, c)) = v4;
+    *(float4*)(base + 3 * Lp * LDK + at(j, c)) = g4;
     float D = (g4.x * o4.x + g4.y * o4.y) + (g4.z * o4.z + g4.w * o4.w);
 #pragma unroll
     for (int o = 1; o < PR; o <<= 1) D += __shfl_xor(D, o, 64);   // the PR lanes of a (row, head) are adjacent and active together
@@ -1557,8 +1563,8 @@ __global__ __launch_bounds__(256) void attn_bwd_m16w_kernel(const float* __restr
     for (int it = 0; it < nt; ++it) {
       const int i = it * 16 + c16;
       float qf[KS], gf[KS];
-      lds_frag<KS>(Qs + i * LDK + kq * KS, qf);
-      lds_frag<KS>(Gs + i * LDK + kq * KS, gf);
+      lds_frag<KS>(Qs + at(i, kq * KS), qf);
+      lds_frag<KS>(Gs + at(i, kq * KS), gf);
       const float lse2 = lse2s[i], Di = Ds[i];
       const bool qv = qvalid[i] != 0.f;
       const unsigned rk = attn_rowkey(p, b, h, i);
@@ -1566,7 +1572,7 @@ __global__ __launch_bounds__(256) void attn_bwd_m16w_kernel(const float* __restr
       float gtr[4], qtr[4];                          // A operands of the dV / dK MFMAs: dO / Q feature c16 of queries i0 .. i0 + 3
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float gg = Gs[(i0 + r) * LDK + cA], qq = Qs[(i0 + r) * LDK + cA];
+        const float gg = Gs[at(i0 + r, cA)], qq = Qs[at(i0 + r, cA)];
         gtr[r] = frow ? gg : 0.f;
         qtr[r] = frow ? qq : 0.f;
       }
@@ -1576,14 +1582,14 @@ __global__ __launch_bounds__(256) void attn_bwd_m16w_kernel(const float* __restr
       for (int jt = 0; jt < NTM; ++jt) {
         if (jt < jt0 || jt >= jt_end) continue;     // (wave-uniform)
         float kf[KS], vf[KS];
-        lds_frag<KS>(Ks + (jt * 16 + c16) * LDK + kq * KS, kf);
-        lds_frag<KS>(Vs + (jt * 16 + c16) * LDK + kq * KS, vf);
+        lds_frag<KS>(Ks + at(jt * 16 + c16, kq * KS), kf);
+        lds_frag<KS>(Vs + at(jt * 16 + c16, kq * KS), vf);
         const int j0 = jt * 16 + 4 * kq;
         const float4 kv4 = *(const float4*)(kvalid + j0);
         float ktr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float kk = Ks[(j0 + r) * LDK + cA];
+          const float kk = Ks[at(j0 + r, cA)];
           ktr[r] = frow ? kk : 0.f;
         }
         floatx4 sT = {0.f, 0.f, 0.f, 0.f}, dpT = {0.f, 0.f, 0.f, 0.f};
