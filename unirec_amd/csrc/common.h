@@ -36,7 +36,7 @@ int fail(int code, const char* fmt, ...);
 
 // ---- live kernel-class profiler (HIP events recorded on the launch stream; see ur_prof_* in the header)
 enum ProfClass { PC_GEMM_NT = 0, PC_GEMM_TN, PC_ATTN_FWD, PC_ATTN_BWD, PC_ROWOPS, PC_LOSS, PC_SORT, PC_REDUCE, PC_ADAM, PC_GATHER,
-                 PC_GRU, PC_CHAIN, PC_MISC, PC_COUNT };
+                 PC_GRU, PC_CHAIN, PC_CHAIN_SMALL, PC_MISC, PC_COUNT };
 struct ProfScope {
   int cls; hipStream_t st; int slot;
   ProfScope(int cls_, hipStream_t st_, double work = 0.0);

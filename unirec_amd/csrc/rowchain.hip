@@ -635,6 +635,8 @@ int chain_set_enabled(int on) {
 bool chain_shape_ok(int d, int inner) { return (d == 32 || d == 64 || d == 128) && inner % d == 0; }
 bool chain_supported(int d, int inner, int which) { return (chain_set_enabled(-1) & which) && chain_shape_ok(d, inner); }
 int chain_rows_per_block(int d) { return 4096 / d; }
+// profiler class: the chain launches of the B last rows (a few dozen workgroups: latency-bound, not a throughput figure) are kept apart
+static inline ProfClass chain_class(int M, int d) { return cdiv(M, 4096 / d) <= 64 ? PC_CHAIN_SMALL : PC_CHAIN; }
 
 template <typename KernelT>
 static void set_lds(KernelT k, size_t bytes) {
@@ -651,7 +653,7 @@ static void set_lds(KernelT k, size_t bytes) {
 int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
   if (a.M <= 0) return UR_OK;
   if (!chain_shape_ok(d, a.I) || (a.wn && a.Nn % d)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd: d=%d inner=%d", d, a.I);
-  ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * ((double)d + 2.0 * a.I + (a.wn ? a.Nn : 0)));
+  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I + (a.wn ? a.Nn : 0)));
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
     case 32: UR_CHAIN_DISPATCH(32, chain_ffn_fwd_kernel, a, grid); break;
@@ -679,7 +681,7 @@ int chain_embed_proj(const ChainEmbedArgs& a, int d, hipStream_t st) {
 int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st) {
   if (a.M <= 0) return UR_OK;
   if (!chain_shape_ok(d, a.I)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_bwd: d=%d inner=%d", d, a.I);
-  ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * ((double)d + 2.0 * a.I));
+  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I));
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
     case 32: UR_CHAIN_DISPATCH(32, chain_ffn_bwd_kernel, a, grid); break;
