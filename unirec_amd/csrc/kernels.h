@@ -127,6 +127,8 @@ struct ChainFwdArgs {
   int M; const int* m_dev;
   int I, act; float eps;
   DropSpec drop_out, drop_ffn;
+  float* split_part = nullptr;          // chain_ffn_fwd_split: [row blocks][I/d][rows per block][d] partial dense_2 outputs
+  unsigned* split_cnt = nullptr;        //   and one completion counter per row block (zero on entry, reset by the kernel)
 };
 struct ChainBwdArgs {
   const float* gy;                      // d loss / d y  [M, d]
@@ -162,6 +164,11 @@ struct ChainEmbedArgs {
 };
 int chain_embed_proj(const ChainEmbedArgs& a, int d, hipStream_t st);   // lookup + position + LayerNorm + the first layer's Q/K/V projection
 int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st);
+// the same block for FEW rows (the B last rows): the inner dimension is split over I/d workgroups per row block, the LayerNorm behind
+// dense_2 is done by the workgroup of a row block that finishes last.  Needs cdiv(M, rows per block) <= CHAIN_SPLIT_MAX_BLOCKS.
+constexpr int CHAIN_SPLIT_MAX_BLOCKS = 64;
+int chain_ffn_fwd_split(const ChainFwdArgs& a, int d, hipStream_t st);
+long long chain_split_part_floats(int M, int d, int inner);
 int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st);     // workgroups = cdiv(M, chain_rows_per_block(d))
 int chain_proj_bwd(const ChainProjBwdArgs& a, int d, hipStream_t st);
 

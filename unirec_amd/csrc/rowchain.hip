@@ -348,6 +348,162 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   }
 }
 
+// 16-byte store / load at DEVICE scope (sc1: written through to / read from the point every XCD's L2 agrees on) -- what a
+// device-scope atomic store / load of a float compiles to, four floats wide.  For data handed from one workgroup to another inside a
+// kernel; ordering against the completion counter is the caller's (s_waitcnt vmcnt(0) before the counter moves).
+__device__ __forceinline__ void rc_store_dev4(float* p, fx4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ fx4 rc_load_dev4(const float* p) {
+  fx4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// =============================================================================================== forward, few rows
+// The B last rows of the last-row layer are 16 row blocks at B = 512: as ONE workgroup per block the chain above is 72 dependent
+// K slices on 16 CUs (42 us: latency, not throughput).  Here the inner dimension is split: workgroup (block rb, chunk c) computes the
+// attention-output projection + LayerNorm itself (all I/d workgroups of a block do: 1/9 of the work, cheaper than passing the tile
+// around), dense_1 + activation for ITS d-wide chunk of inner, and its partial of dense_2; the partials go to memory with device-scope
+// stores and the workgroup of the block that finishes LAST (a counter per block, self-resetting) sums them in chunk order -- fixed
+// order: bit-reproducible -- and does the bias / residual / LayerNorm epilogue.  24 slices on the critical path instead of 72, 64
+// workgroups instead of 16.  (No device-scope FENCE anywhere: on this part it writes back the XCD's whole L2.)
+template <int D>
+__global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a) {
+  using G = RcGeom<D>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* At = smem;                  // [BM][TS]: ctx, then a
+  float* Ht = smem + G::TILE;        // [BM][TS]: accumulator staging / act(h1 chunk)
+  float* Wst = smem + 2 * G::TILE;   // [2][D][RC_LS]
+  __shared__ int is_last;
+  const int M = a.M;
+  const int nc = a.I / D;
+  const int rb = blockIdx.x / nc, c = blockIdx.x % nc;
+  const int m0 = rb * G::BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / G::WC, wc = wave % G::WC;
+  const int et = tid % G::TPR, eg = tid / G::TPR;
+  const float inv_n = 1.0f / (float)D;
+  fx4 wreg[2][G::WV];
+  int buf = 0;
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ml = eg + p * G::RPP, m = m0 + ml;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) v = *(const float4*)(a.ctx + (long long)m * a.ldctx + et * 4);
+    *(float4*)(At + rc_toff<D>(ml, et)) = v;
+  }
+  rc_prime_store<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
+  __syncthreads();
+  // ---- 1. attention output projection + residual + LayerNorm (every chunk's workgroup; chunk 0 writes a / ahat / rstd1)
+  {
+    floatx16 acc = zero16();
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0, tid), D, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
+  }
+  __syncthreads();
+  {
+    const float4 bs = *(const float4*)(a.bo + et * 4);
+    const float4 gm = *(const float4*)(a.g1 + et * 4), bt = *(const float4*)(a.b1ln + et * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        float4 x = *(const float4*)(Ht + rc_toff<D>(ml, et));
+        const float4 rs = *(const float4*)(a.res + (long long)m * a.ldres + et * 4);
+        if (a.drop_out.thresh) {   // t = dropout(acc + bias) + res
+          x.x += bs.x; x.y += bs.y; x.z += bs.z; x.w += bs.w;
+          x = drop4(x, drop_rowkey(a.drop_out, m), (unsigned)(et * 4), a.drop_out);
+          x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w;
+        } else {
+          x.x += bs.x + rs.x; x.y += bs.y + rs.y; x.z += bs.z + rs.z; x.w += bs.w + rs.w;
+        }
+        float4 h;
+        const float rstd = rc_ln_row<G::TPR>(x, gm, bt, inv_n, a.eps, h, o);
+        if (c == 0) {
+          *(float4*)(a.ahat + (long long)m * D + et * 4) = h;
+          *(float4*)(a.a + (long long)m * D + et * 4) = o;
+          if (et == 0) a.rstd1[m] = rstd;
+        }
+      }
+      *(float4*)(At + rc_toff<D>(ml, et)) = o;
+    }
+  }
+  __syncthreads();
+  // ---- 2. dense_1 + activation for chunk c, then this chunk's partial of dense_2
+  const float* w2p = rc_wptr<D>(a.w2, a.I, 0, c * D, tid);
+  {
+    floatx16 acch = zero16();
+    rc_gemm<D>(acch, At, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, w2p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_acc_to_tile<D>(acch, Ht, wr, wc, lane);
+  }
+  __syncthreads();
+  {
+    const float4 bs = *(const float4*)(a.b1 + c * D + et * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
+      v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+      if (m < M) *(float4*)(a.h1 + (long long)m * a.I + c * D + et * 4) = v;
+      v = rc_act4(v, a.act);
+      if (a.u && m < M) *(float4*)(a.u + (long long)m * a.I + c * D + et * 4) = v;
+      *(float4*)(Ht + rc_toff<D>(ml, et)) = v;
+    }
+  }
+  __syncthreads();
+  floatx16 accy = zero16();
+  rc_gemm<D>(accy, Ht, w2p, a.I, nullptr, D, Wst, buf, wreg, tid, wr, wc, lane);
+  rc_acc_to_tile<D>(accy, Ht, wr, wc, lane);
+  __syncthreads();
+  // ---- 3. the partial -> memory (device scope), count, and the last workgroup of the row block finishes
+  float* mine = a.split_part + ((long long)(rb * nc + c) * G::BM) * D;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ml = eg + p * G::RPP;
+    const float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
+    rc_store_dev4(mine + (long long)ml * D + et * 4, fx4{v.x, v.y, v.z, v.w});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's stores are acknowledged (no cache flush) ...
+  __syncthreads();                                         // ... and so are every other thread's
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(a.split_cnt + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = prev == (unsigned)nc - 1u;
+    if (is_last) __hip_atomic_store(a.split_cnt + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  }
+  __syncthreads();
+  if (!is_last) return;
+  {
+    const float4 bs = *(const float4*)(a.b2 + et * 4);
+    const float4 gm = *(const float4*)(a.g2 + et * 4), bt = *(const float4*)(a.b2ln + et * 4);
+    const float* blk = a.split_part + ((long long)rb * nc * G::BM) * D;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      if (m < M) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int cc = 0; cc < nc; ++cc) {   // chunk order: the order the one-workgroup chain accumulates in
+          const fx4 t = rc_load_dev4(blk + ((long long)cc * G::BM + ml) * D + et * 4);
+          x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
+        }
+        const float4 rs = *(const float4*)(At + rc_toff<D>(ml, et));
+        if (a.drop_ffn.thresh) {
+          x.x += bs.x; x.y += bs.y; x.z += bs.z; x.w += bs.w;
+          x = drop4(x, drop_rowkey(a.drop_ffn, m), (unsigned)(et * 4), a.drop_ffn);
+          x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w;
+        } else {
+          x.x += bs.x + rs.x; x.y += bs.y + rs.y; x.z += bs.z + rs.z; x.w += bs.w + rs.w;
+        }
+        float4 h, o;
+        const float rstd = rc_ln_row<G::TPR>(x, gm, bt, inv_n, a.eps, h, o);
+        *(float4*)(a.yhat + (long long)m * D + et * 4) = h;
+        *(float4*)(a.y + (long long)m * D + et * 4) = o;
+        if (et == 0) a.rstd2[m] = rstd;
+      }
+    }
+  }
+}
+
 // =============================================================================================== backward of the same block
 
 template <int D>
@@ -673,6 +829,43 @@ int chain_embed_proj(const ChainEmbedArgs& a, int d, hipStream_t st) {
     case 32: UR_CHAIN_DISPATCH(32, chain_embed_proj_kernel, a, grid); break;
     case 64: UR_CHAIN_DISPATCH(64, chain_embed_proj_kernel, a, grid); break;
     default: UR_CHAIN_DISPATCH(128, chain_embed_proj_kernel, a, grid); break;
+  }
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+long long chain_split_part_floats(int M, int d, int inner) {
+  const int bm = chain_rows_per_block(d);
+  return (long long)cdiv(M, bm) * (inner / d) * bm * d;
+}
+// counters of the split kernels: one per row block, zeroed once per device, reset by the kernel that used them
+static unsigned* chain_split_counters() {
+  static unsigned* z[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!z[dev]) {
+    unsigned* p = nullptr;
+    if (hipMalloc((void**)&p, 2 * CHAIN_SPLIT_MAX_BLOCKS * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 2 * CHAIN_SPLIT_MAX_BLOCKS * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    z[dev] = p;
+  }
+  return z[dev];
+}
+
+int chain_ffn_fwd_split(const ChainFwdArgs& a0, int d, hipStream_t st) {
+  if (a0.M <= 0) return UR_OK;
+  ChainFwdArgs a = a0;
+  const int nblk = cdiv(a.M, chain_rows_per_block(d));
+  if (!chain_shape_ok(d, a.I) || a.wn || a.m_dev || nblk > CHAIN_SPLIT_MAX_BLOCKS || !a.split_part)
+    return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd_split: d=%d inner=%d M=%d", d, a.I, a.M);
+  a.split_cnt = chain_split_counters();
+  if (!a.split_cnt) return fail(UR_ERR_HIP, "chain_ffn_fwd_split: no device memory for the completion counters");
+  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I));
+  const int grid = nblk * (a.I / d);
+  switch (d) {
+    case 32: UR_CHAIN_DISPATCH(32, chain_ffn_fwd_split_kernel, a, grid); break;
+    case 64: UR_CHAIN_DISPATCH(64, chain_ffn_fwd_split_kernel, a, grid); break;
+    default: UR_CHAIN_DISPATCH(128, chain_ffn_fwd_split_kernel, a, grid); break;
   }
   UR_LAUNCH_CHECK();
   return UR_OK;

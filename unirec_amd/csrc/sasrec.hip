@@ -65,6 +65,7 @@ struct Ws {
   float *x0, *x0hat, *rstd0;
   LayerWs layer[UR_MAX_LAYERS];
   float *g_y, *g_a, *g_ctx, *tn_ws, *ln_part, *attn_ws;
+  float* split_part;                    // chain_ffn_fwd_split / _bwd_split: per-(row block, inner chunk) partial tiles
   float* chain_part;                    // row-chain kernels: per-workgroup LayerNorm-affine partial sums (see chain_part_of)
   long long chain_blocks;               // upper bound of their workgroup count: cdiv(B*L, 32)
   float *q_last, *dq_last, *lse_last;   // last-row specialisation of the final layer ([B,d] each)
@@ -108,6 +109,7 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
   w.attn_ws = take(attn_bwd_ws_floats(c.B, c.n_heads, c.L));
   w.chain_blocks = (M + 31) / 32;
   w.chain_part = take((4LL * c.n_layers + 2) * w.chain_blocks * d);
+  w.split_part = take(2 * chain_split_part_floats(c.B, d, c.inner));   // last-row chain, inner split over workgroups: forward + backward partials
   w.q_last = take((long long)c.B * d); w.dq_last = take((long long)c.B * d);
   w.lse_last = take((long long)c.B * c.n_heads);
   w.x_last = take((long long)c.B * d); w.t_last = take((long long)c.B * d);
@@ -406,6 +408,11 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
         ca.M = B; ca.I = I; ca.act = c.act; ca.eps = c.eps;
         ca.drop_out = site_spec(c, i, DROP_SITE_OUT, nullptr, c.L, c.L - 1);   // row b of these [B, .] tiles is token (b, L-1)
         ca.drop_ffn = site_spec(c, i, DROP_SITE_FFN, nullptr, c.L, c.L - 1);
+        static const bool no_split = getenv("UR_SASREC_NO_SPLIT") != nullptr;   // the one-workgroup-per-row-block chain for the last rows too
+        if (!no_split && I / d >= 2 && cdiv(B, chain_rows_per_block(d)) <= CHAIN_SPLIT_MAX_BLOCKS) {
+          ca.split_part = w.split_part;
+          return chain_ffn_fwd_split(ca, d, st);
+        }
         return chain_ffn_fwd(ca, d, st);
       }
       g = GemmArgs{};
