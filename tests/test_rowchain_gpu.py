@@ -110,3 +110,42 @@ def test_unsupported_widths_take_the_unfused_path():
     assert torch.equal(ue1, ue0), float((ue1 - ue0).abs().max())
     assert torch.equal(dr1, dr0), float((dr1 - dr0).abs().max())
     assert torch.equal(dg1, dg0), (float((dg1 - dg0).abs().max()), torch.nonzero(dg1 != dg0).flatten()[:8].tolist())
+
+
+def test_last_row_split_kernels_are_race_free_over_repeated_steps():
+    """The last-row layer's chain kernels split the inner dimension over workgroups and hand partial tiles to the workgroup of the row
+    block that finishes last (device-scope atomics + a counter per block, no device-scope fence).  A hand-off that is merely USUALLY in
+    order shows up only when the partial buffers carry the previous step's values: 30 steps with fresh inputs on ONE workspace, twice
+    -- the two runs must agree bit for bit (fixed summation order), and with the unsplit launches to fp32 rounding.  (The first version
+    used device-scope stores: 6 of 40 backward passes summed a stale partial.)"""
+    from unirec_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    B, L, d, I, H, nl, N = 512, 50, 128, 512, 16, 2, 20000
+    cfg = ops.sasrec_cfg(B, L, d, H, I, nl, "swish", True, 1e-10, last_only=1, skip_padding=1, p_hidden=0.0, p_attn=0.0, drop_seed=7, drop_step=3)
+    _, total = ops.sasrec_param_layout(cfg)
+
+    def run(mask):
+        prev = _lib.lib.ur_sasrec_set_chain(mask)
+        try:
+            g = torch.Generator(device=dev).manual_seed(0)
+            ws = ops.sasrec_workspace(cfg, dev)
+            ws.zero_()
+            outs = []
+            for _ in range(30):
+                dense = torch.randn(total, device=dev, generator=g) * 0.08
+                table = torch.randn(N, d, device=dev, generator=g) * 0.1
+                seq = torch.randint(1, N, (B, L), device=dev, generator=g, dtype=torch.int32)
+                du = torch.randn(B, d, device=dev, generator=g)
+                ue = ops.sasrec_fwd(cfg, table, dense, seq, ws).clone()
+                dg, dr = ops.sasrec_bwd(cfg, table, dense, seq, du, ws)
+                outs.append((ue, dg.clone(), dr.clone()))
+            torch.cuda.synchronize()
+            return outs
+        finally:
+            _lib.lib.ur_sasrec_set_chain(prev)
+
+    a, b, ref = run(57), run(57), run(33)        # 33: forward chain + input block, the last-row layer through the stand-alone GEMMs
+    for step, (x, y, z) in enumerate(zip(a, b, ref)):
+        for k, tol in ((0, 5e-6), (1, 3e-4), (2, 5e-6)):
+            assert torch.equal(x[k], y[k]), (step, k)
+            _close(x[k], z[k], tol, (step, k))

@@ -142,6 +142,8 @@ struct ChainBwdArgs {
   float* part;                          // [workgroups][4 d]: d gamma2 | d beta2 | d gamma1 | d beta1 partial sums
   int M; const int* m_dev;
   int I, act;
+  float* split_part = nullptr;          // chain_ffn_bwd_split: [row blocks][I/d][rows per block][d] partial d a tiles
+  unsigned* split_cnt = nullptr;        //   and one completion counter per row block (zero on entry, reset by the kernel)
 };
 struct ChainProjBwdArgs {
   const float* g; int ldg; int K;       // [M, K] gradient of the projection output; K % d == 0
@@ -168,6 +170,7 @@ int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st);
 // dense_2 is done by the workgroup of a row block that finishes last.  Needs cdiv(M, rows per block) <= CHAIN_SPLIT_MAX_BLOCKS.
 constexpr int CHAIN_SPLIT_MAX_BLOCKS = 64;
 int chain_ffn_fwd_split(const ChainFwdArgs& a, int d, hipStream_t st);
+int chain_ffn_bwd_split(const ChainBwdArgs& a, int d, hipStream_t st);   // part: [cdiv(M, rows per block)][4 d]
 long long chain_split_part_floats(int M, int d, int inner);
 int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st);     // workgroups = cdiv(M, chain_rows_per_block(d))
 int chain_proj_bwd(const ChainProjBwdArgs& a, int d, hipStream_t st);

@@ -380,11 +380,14 @@ __global__ __launch_bounds__(256) void scorer_loss_fused_kernel(UrLossCfg c, flo
       cf[g] = (g == 0) ? -1.f / total : ((sc[g] - c.ccl_m > 0.f) ? c.ccl_w / ((float)(G - 1) * total) : 0.f);
   }
   if (threadIdx.x == 0) {
-    // device-scope atomic stores: written through to the coherence point, so the workgroup that finishes last (maybe on another XCD,
-    // behind another L2) can read them with device-scope loads -- WITHOUT a device-scope fence, which on this part writes back the
-    // whole L2 of the XCD (the forward pass's activations are sitting there dirty: 512 such fences cost the step 20 us)
-    __hip_atomic_store(loss_rows + b, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(cnt_rows + b, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // device-scope atomics carry the two numbers to the workgroup that finishes last (maybe on another XCD, behind another L2) --
+    // WITHOUT a device-scope fence, which on this part writes back the whole L2 of the XCD (the forward pass's activations are sitting
+    // there dirty: 512 such fences cost the step 20 us)
+    // (exchanges, not stores: a read-modify-write is performed at the point all XCDs agree on, and once its old value is back it HAS
+    // been performed -- a store's acknowledgement does not say that its write-through has landed, and the counter could overtake it)
+    const float o0 = __hip_atomic_exchange(loss_rows + b, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float o1 = __hip_atomic_exchange(cnt_rows + b, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(o0), "v"(o1));
   }
   __syncthreads();
   float bsum = 0.f;
@@ -412,7 +415,6 @@ __global__ __launch_bounds__(256) void scorer_loss_fused_kernel(UrLossCfg c, flo
   }
   // ---- the batch loss, by whichever workgroup finishes last
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (waits for this thread's two stores above to be acknowledged; no cache flush)
     const unsigned prev = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = prev == gridDim.x - 1;
   }
@@ -420,8 +422,8 @@ __global__ __launch_bounds__(256) void scorer_loss_fused_kernel(UrLossCfg c, flo
   if (!is_last) return;
   float s = 0.f, n = 0.f;
   for (int i = threadIdx.x; i < c.B; i += blockDim.x) {
-    s += __hip_atomic_load(loss_rows + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    n += __hip_atomic_load(cnt_rows + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s += __uint_as_float(__hip_atomic_fetch_or((unsigned*)loss_rows + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    n += __uint_as_float(__hip_atomic_fetch_or((unsigned*)cnt_rows + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   }
   s = block_sum(s, red);
   n = block_sum(n, red);

@@ -348,14 +348,26 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   }
 }
 
-// 16-byte store / load at DEVICE scope (sc1: written through to / read from the point every XCD's L2 agrees on) -- what a
-// device-scope atomic store / load of a float compiles to, four floats wide.  For data handed from one workgroup to another inside a
-// kernel; ordering against the completion counter is the caller's (s_waitcnt vmcnt(0) before the counter moves).
-__device__ __forceinline__ void rc_store_dev4(float* p, fx4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ fx4 rc_load_dev4(const float* p) {
-  fx4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
+// Handing a tile from one workgroup to another INSIDE a kernel, without a device-scope fence (which on this part writes back the whole
+// L2 of the XCD): the data moves by device-scope atomic READ-MODIFY-WRITE instructions, which are performed at the point all XCDs
+// agree on and -- returning their old value -- are known to be performed once the value is back.  (sc1 stores are not enough: their
+// acknowledgement does not say that the write-through has landed, and the completion counter can overtake them: measured, 6 of 40
+// backward passes summed a stale partial.)  8 bytes per instruction: 8 exchanges per thread and tile, 8 fetch-ors per thread and tile
+// on the reading side.
+__device__ __forceinline__ void rc_dev_put4(float* p, float4 v) {
+  unsigned long long* q = (unsigned long long*)p;
+  const unsigned long long lo = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+  const unsigned long long hi = (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32);
+  const unsigned long long o0 = __hip_atomic_exchange(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long o1 = __hip_atomic_exchange(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::"v"(o0), "v"(o1));   // the old values are waited for: both exchanges have been performed
+}
+__device__ __forceinline__ float4 rc_dev_get4(const float* p) {
+  unsigned long long* q = (unsigned long long*)p;
+  const unsigned long long lo = __hip_atomic_fetch_or(q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_fetch_or(q + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
+                     __uint_as_float((unsigned)(hi >> 32)));
 }
 
 // =============================================================================================== forward, few rows
@@ -462,10 +474,9 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   for (int p = 0; p < 4; ++p) {
     const int ml = eg + p * G::RPP;
     const float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
-    rc_store_dev4(mine + (long long)ml * D + et * 4, fx4{v.x, v.y, v.z, v.w});
+    rc_dev_put4(mine + (long long)ml * D + et * 4, v);     // (returns once performed)
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's stores are acknowledged (no cache flush) ...
-  __syncthreads();                                         // ... and so are every other thread's
+  __syncthreads();                                         // every thread's part of the tile is out
   if (tid == 0) {
     const unsigned prev = __hip_atomic_fetch_add(a.split_cnt + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = prev == (unsigned)nc - 1u;
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
       if (m < M) {
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int cc = 0; cc < nc; ++cc) {   // chunk order: the order the one-workgroup chain accumulates in
-          const fx4 t = rc_load_dev4(blk + ((long long)cc * G::BM + ml) * D + et * 4);
+          const float4 t = rc_dev_get4(blk + ((long long)cc * G::BM + ml) * D + et * 4);
           x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
         }
         const float4 rs = *(const float4*)(At + rc_toff<D>(ml, et));
@@ -696,6 +707,132 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   }
 }
 
+// =============================================================================================== backward, few rows
+// The mirror image of chain_ffn_fwd_split_kernel: workgroup (row block rb, chunk c) does the feed-forward LayerNorm backward itself
+// (chunk 0 writes g_tf and the d gamma / d beta partials), the d act GEMM of ITS chunk of inner (g_h1 chunk out) and its partial of
+// the d dense_1 GEMM; the workgroup of the block that finishes last sums the partials in chunk order, adds the residual branch, does
+// the attention LayerNorm backward (g_ta, the other two partial sums) and the out-projection gradient GEMM (g_ctx).
+template <int D>
+__global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a) {
+  using G = RcGeom<D>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* At = smem;                  // [BM][TS]: g_tf, then g_ta
+  float* Ht = smem + G::TILE;        // [BM][TS]: accumulator staging / g_h1 chunk / reduction scratch
+  float* Wst = smem + 2 * G::TILE;
+  __shared__ int is_last;
+  const int M = a.M;
+  const int nc = a.I / D;
+  const int rb = blockIdx.x / nc, c = blockIdx.x % nc;
+  const int m0 = rb * G::BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* part = a.part + (long long)rb * 4 * D;
+  const int wr = wave / G::WC, wc = wave % G::WC;
+  const int et = tid % G::TPR, eg = tid / G::TPR;
+  const float inv_d = 1.0f / (float)D;
+  fx4 wreg[2][G::WV];
+  int buf = 0;
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D);
+  // ---- 0. feed-forward LayerNorm backward (every chunk's workgroup; chunk 0 writes)
+  {
+    const float4 gm = *(const float4*)(a.g2 + et * 4);
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        const float4 y = *(const float4*)(a.gy + (long long)m * D + et * 4);
+        const float4 h = *(const float4*)(a.yhat + (long long)m * D + et * 4);
+        o = rc_ln_bwd_row<G::TPR>(y, h, gm, a.rstd2[m], inv_d, dg, db);
+        if (c == 0) *(float4*)(a.g_tf + (long long)m * D + et * 4) = o;
+      }
+      *(float4*)(At + rc_toff<D>(ml, et)) = o;
+    }
+    if (c == 0) rc_block_colsum<D>(dg, db, Ht, part, eg, et, tid);   // (workgroup-uniform branch: the barriers inside are fine)
+  }
+  rc_prime_store<D>(wreg, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D, nullptr, 0, Wst, tid);
+  __syncthreads();
+  // ---- 1. g_h1 chunk = (g_tf W2[:, chunk]) * act'(h1 chunk);   partial of g_a = g_h1 chunk W1[chunk, :]
+  const float* w1p = rc_wptr<D>(a.w1T, a.I, 0, c * D, tid);
+  {
+    floatx16 accu = zero16();
+    rc_gemm<D>(accu, At, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D, w1p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ml = eg + p * G::RPP, m = m0 + ml;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) {
+      v = *(const float4*)(Ht + rc_toff<D>(ml, et));
+      const float4 h = *(const float4*)(a.h1 + (long long)m * a.I + c * D + et * 4);
+      v.x *= act_bwd(h.x, a.act); v.y *= act_bwd(h.y, a.act); v.z *= act_bwd(h.z, a.act); v.w *= act_bwd(h.w, a.act);
+      *(float4*)(a.g_h1 + (long long)m * a.I + c * D + et * 4) = v;
+    }
+    *(float4*)(Ht + rc_toff<D>(ml, et)) = v;
+  }
+  __syncthreads();
+  floatx16 acca = zero16();
+  rc_gemm<D>(acca, Ht, w1p, a.I, rc_wptr<D>(a.woT, D, 0, 0, tid), D, Wst, buf, wreg, tid, wr, wc, lane);
+  rc_acc_to_tile<D>(acca, Ht, wr, wc, lane);
+  __syncthreads();
+  // ---- 2. the partial -> memory (device scope), count; the last workgroup of the row block goes on
+  float* mine = a.split_part + ((long long)(rb * nc + c) * G::BM) * D;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ml = eg + p * G::RPP;
+    const float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
+    rc_dev_put4(mine + (long long)ml * D + et * 4, v);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(a.split_cnt + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = prev == (unsigned)nc - 1u;
+    if (is_last) __hip_atomic_store(a.split_cnt + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  // ---- 3. g_a = sum of the partials (chunk order) + g_tf;  attention LayerNorm backward -> g_ta
+  {
+    const float4 gm = *(const float4*)(a.g1 + et * 4);
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+    const float* blk = a.split_part + ((long long)rb * nc * G::BM) * D;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int cc = 0; cc < nc; ++cc) {
+          const float4 t = rc_dev_get4(blk + ((long long)cc * G::BM + ml) * D + et * 4);
+          y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        }
+        const float4 rs = *(const float4*)(At + rc_toff<D>(ml, et));
+        y.x += rs.x; y.y += rs.y; y.z += rs.z; y.w += rs.w;
+        const float4 h = *(const float4*)(a.ahat + (long long)m * D + et * 4);
+        o = rc_ln_bwd_row<G::TPR>(y, h, gm, a.rstd1[m], inv_d, dg, db);
+        *(float4*)(a.g_ta + (long long)m * D + et * 4) = o;
+      }
+      *(float4*)(At + rc_toff<D>(ml, et)) = o;
+    }
+    __syncthreads();   // (Ht is free: it becomes the reduction scratch)
+    rc_block_colsum<D>(dg, db, Ht, part + 2 * D, eg, et, tid);
+  }
+  // ---- 4. g_ctx = g_ta Wo
+  {
+    floatx16 acc = zero16();
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0, tid), D, nullptr, 0, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ml = eg + p * G::RPP, m = m0 + ml;
+    if (m < M) *(float4*)(a.g_ctx + (long long)m * D + et * 4) = *(const float4*)(Ht + rc_toff<D>(ml, et));
+  }
+}
+
 // =============================================================================================== input block
 // x0 = dropout(LN(E[item_seq] + P)) and the FIRST layer's Q / K / V projection in one launch: the 32 gathered rows of a workgroup go
 // through the LayerNorm into the LDS tile (and out to x0 / x0hat / rstd0 for the backward) and are the A operand of the projection
@@ -866,6 +1003,26 @@ int chain_ffn_fwd_split(const ChainFwdArgs& a0, int d, hipStream_t st) {
     case 32: UR_CHAIN_DISPATCH(32, chain_ffn_fwd_split_kernel, a, grid); break;
     case 64: UR_CHAIN_DISPATCH(64, chain_ffn_fwd_split_kernel, a, grid); break;
     default: UR_CHAIN_DISPATCH(128, chain_ffn_fwd_split_kernel, a, grid); break;
+  }
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+int chain_ffn_bwd_split(const ChainBwdArgs& a0, int d, hipStream_t st) {
+  if (a0.M <= 0) return UR_OK;
+  ChainBwdArgs a = a0;
+  const int nblk = cdiv(a.M, chain_rows_per_block(d));
+  if (!chain_shape_ok(d, a.I) || a.m_dev || nblk > CHAIN_SPLIT_MAX_BLOCKS || !a.split_part)
+    return fail(UR_ERR_UNSUPPORTED, "chain_ffn_bwd_split: d=%d inner=%d M=%d", d, a.I, a.M);
+  unsigned* cnt = chain_split_counters();
+  if (!cnt) return fail(UR_ERR_HIP, "chain_ffn_bwd_split: no device memory for the completion counters");
+  a.split_cnt = cnt + CHAIN_SPLIT_MAX_BLOCKS;   // (the forward kernel's counters are the first half)
+  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I));
+  const int grid = nblk * (a.I / d);
+  switch (d) {
+    case 32: UR_CHAIN_DISPATCH(32, chain_ffn_bwd_split_kernel, a, grid); break;
+    case 64: UR_CHAIN_DISPATCH(64, chain_ffn_bwd_split_kernel, a, grid); break;
+    default: UR_CHAIN_DISPATCH(128, chain_ffn_bwd_split_kernel, a, grid); break;
   }
   UR_LAUNCH_CHECK();
   return UR_OK;

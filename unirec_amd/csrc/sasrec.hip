@@ -650,7 +650,11 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
         cb.ahat = lw.ahat; cb.rstd1 = lw.rstd1; cb.g1 = p.g1; cb.woT = lw.woT;
         cb.g_tf = lw.g_tf; cb.g_h1 = lw.g_h1; cb.g_ta = lw.g_ta; cb.g_ctx = w.g_ctx; cb.part = part;
         cb.M = B; cb.I = I; cb.act = c.act;
-        if ((rc = chain_ffn_bwd(cb, d, st))) return rc;
+        static const bool no_split = getenv("UR_SASREC_NO_SPLIT") != nullptr;
+        if (!no_split && I / d >= 2 && nblk <= CHAIN_SPLIT_MAX_BLOCKS) {   // inner split over workgroups (see chain_ffn_fwd_split)
+          cb.split_part = w.split_part + chain_split_part_floats(B, d, I);
+          if ((rc = chain_ffn_bwd_split(cb, d, st))) return rc;
+        } else if ((rc = chain_ffn_bwd(cb, d, st))) return rc;
         if (rb.full(4) && (rc = reduce_batch(rb, st))) return rc;
         rb.add(part, 4 * d, nblk, d, d, G + o[14], d);
         rb.add(part + d, 4 * d, nblk, d, d, G + o[15], d);
