@@ -342,6 +342,14 @@ int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m, float* v, 
 int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                          const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
                          void* stream);
+/* ur_sparse_adam_rows (lazy-dense semantics, last_step != NULL) for THIS step's rows and ur_lazy_adam_catchup for the NEXT batch's
+ * rows (next_uniq_idx: its plan's row list) in ONE launch: the next batch's rows -- minus the ones updated here -- are brought to
+ * the state after this step (cfg->step).  Same results as the two calls in sequence; the two halves are latency-bound chains of random
+ * accesses and overlap instead of queueing up at the tail of the step. */
+int ur_sparse_adam_rows_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                                const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad,
+                                int32_t d, const float* grad_scale_dev, const int32_t* next_uniq_idx,
+                                const int32_t* next_n_uniq_dev, int64_t next_n_max, void* stream);
 /* the same catch-up issued AHEAD of a step that is still in flight (on another stream): rows in busy_idx[0..*busy_n_dev) -- the
  * ascending unique row list of the in-flight step's plan, i.e. the rows that step reads and will update -- are left alone (the
  * step's own update replays them); every other row of uniq_idx is brought to "after step (cfg->step - 1)", where cfg->step - 1 is

@@ -38,7 +38,8 @@ def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14):
     init_seed(4)
     model = get_class_instance("SASRec", "unirec_amd/model")(_cfg())
     opt = SparseDenseAdam(model, lr=5e-3, weight_decay=wd, algo=algo)
-    opt._ahead = ahead or ""
+    opt._ahead = "tail" if ahead == "merged" else (ahead or "")
+    opt._merge = ahead == "merged"          # row update + the next batch's catch-up as one launch (ur_sparse_adam_rows_catchup)
     model.train()
     bs = _batches(n_steps + 2)
     other = _batches(3, seed=99)
@@ -63,7 +64,7 @@ def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14):
 @pytest.mark.parametrize("algo,wd", [("adam", 0.0), ("adamw", 0.01), ("adam", 0.001), ("rmsprop", 0.0)])
 def test_catchup_ahead_is_bit_identical(algo, wd):
     b = _train(False, algo, wd)
-    for mode in ("side", "tail"):
+    for mode in ("side", "tail", "merged"):
         a = _train(mode, algo, wd)
         assert a[0] == b[0]
         for x, y, what in zip(a[1:], b[1:], ("w", "m", "v", "dense")):

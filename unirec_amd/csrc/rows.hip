@@ -733,13 +733,14 @@ __device__ __forceinline__ void lazy_row_apply(const LazyRow& r, float4& w, floa
 }
 
 // MODE 0: update with gradient (catch-up first when last_step != null); MODE 1: catch-up only (to step-1)
+// (a device function so that one launch can run both modes: `bid` / `nblk` are the workgroup's index and the number of workgroups of its mode)
 template <int TPR, int MODE>
-__global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
-                                                          float4* __restrict__ var, int* __restrict__ last_step,
-                                                          const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
-                                                          long long n_max, const float4* __restrict__ grad, int d4,
-                                                          const float* __restrict__ scale_dev, const int* __restrict__ busy_idx = nullptr,
-                                                          const int* __restrict__ busy_n_dev = nullptr, int busy_max = 0) {
+__device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restrict__ table, float4* __restrict__ mom,
+                                                 float4* __restrict__ var, int* __restrict__ last_step,
+                                                 const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev, long long n_max,
+                                                 const float4* __restrict__ grad, int d4, const float* __restrict__ scale_dev,
+                                                 const int* __restrict__ busy_idx, const int* __restrict__ busy_n_dev, int busy_max,
+                                                 int bid, int nblk) {
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int n_uniq = (int)min((long long)*n_uniq_dev, n_max);
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
     constexpr int U = 4;
     const int c = min(t, d4 - 1);
     const bool cin = t < d4;
-    for (int u0 = (blockIdx.x * groups + g) * U; u0 < n_uniq; u0 += gridDim.x * groups * U) {
+    for (int u0 = (bid * groups + g) * U; u0 < n_uniq; u0 += nblk * groups * U) {
       long long row[U];
       int last[U];
 #pragma unroll
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
     }
     return;
   }
-  for (int u = blockIdx.x * groups + g; u < n_uniq; u += gridDim.x * groups) {
+  for (int u = bid * groups + g; u < n_uniq; u += nblk * groups) {
     const long long row = uniq_idx[u];
     if (row == 0) continue;
     const int last = last_step ? last_step[row] : a.step - 1;
@@ -835,6 +836,39 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
     }
     __builtin_amdgcn_wave_barrier();
     if (last_step && t == 0) last_step[row] = (MODE == 0) ? a.step : a.step - 1;
+  }
+}
+
+template <int TPR, int MODE>
+__global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
+                                                          float4* __restrict__ var, int* __restrict__ last_step,
+                                                          const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
+                                                          long long n_max, const float4* __restrict__ grad, int d4,
+                                                          const float* __restrict__ scale_dev, const int* __restrict__ busy_idx = nullptr,
+                                                          const int* __restrict__ busy_n_dev = nullptr, int busy_max = 0) {
+  sparse_adam_body<TPR, MODE>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, busy_idx, busy_n_dev, busy_max,
+                              (int)blockIdx.x, (int)gridDim.x);
+}
+// The update of THIS step's rows and the catch-up of the NEXT batch's rows in one launch: workgroups [0, nb_update) run the update,
+// the rest bring the next batch's rows -- minus the ones being updated here (binary search in this step's sorted row list) -- to the
+// state after this step.  Both halves are chains of dependent random accesses (plan entry -> last_step -> row); as two launches they
+// queue up behind each other at the tail of every step (44 + 45 us in situ), as one they overlap.
+template <int TPR>
+__global__ __launch_bounds__(256) void sparse_adam_dual_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
+                                                               float4* __restrict__ var, int* __restrict__ last_step,
+                                                               const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
+                                                               long long n_max, const float4* __restrict__ grad, int d4,
+                                                               const float* __restrict__ scale_dev, int nb_update,
+                                                               const int* __restrict__ next_idx, const int* __restrict__ next_n_dev,
+                                                               long long next_max) {
+  if ((int)blockIdx.x < nb_update) {
+    sparse_adam_body<TPR, 0>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, nullptr, nullptr, 0,
+                             (int)blockIdx.x, nb_update);
+  } else {
+    AdamK an = a;
+    an.step = a.step + 1;   // MODE 1 brings a row to "after step an.step - 1" = after THIS step
+    sparse_adam_body<TPR, 1>(an, table, mom, var, last_step, next_idx, next_n_dev, next_max, nullptr, d4, nullptr, uniq_idx, n_uniq_dev,
+                             (int)n_max, (int)blockIdx.x - nb_update, (int)gridDim.x - nb_update);
   }
 }
 
@@ -1357,6 +1391,40 @@ extern "C" int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m,
   UR_REQUIRE(table && m && v && uniq_idx && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_sparse_adam_rows: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_sparse_adam_rows: d=%d n_max=%lld", d, (long long)n_max);
   return launch_sparse_adam(0, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, uniq_grad, d, grad_scale_dev, as_stream(stream));
+}
+
+extern "C" int ur_sparse_adam_rows_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                                           const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad,
+                                           int32_t d, const float* grad_scale_dev, const int32_t* next_uniq_idx,
+                                           const int32_t* next_n_uniq_dev, int64_t next_n_max, void* stream) {
+  int rc = check_adam(cfg, "ur_sparse_adam_rows_catchup");
+  if (rc) return rc;
+  UR_REQUIRE(table && m && v && last_step && uniq_idx && n_uniq_dev && uniq_grad && next_uniq_idx && next_n_uniq_dev, UR_ERR_ARG,
+             "ur_sparse_adam_rows_catchup: null pointer");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0 && next_n_max > 0 && n_max < (1LL << 31), UR_ERR_ARG,
+             "ur_sparse_adam_rows_catchup: d=%d n_max=%lld next_n_max=%lld", d, (long long)n_max, (long long)next_n_max);
+  hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_ADAM, st, (double)n_max * d * 4.0 * 7);
+  AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
+  a.lb1 = cfg->beta1 > 0.f ? (float)log2((double)cfg->beta1) : -1e30f;
+  a.lb2 = cfg->beta2 > 0.f ? (float)log2((double)cfg->beta2) : -1e30f;
+  const int tpr = pick_tpr(d), groups = 256 / tpr;
+  int nb0 = cdiv(n_max, groups * ((d / 4 <= tpr) ? 4 : 1));   // the update's fast path takes four rows per lane group
+  int nb1 = cdiv(next_n_max, groups);
+  if (nb0 > 8192) nb0 = 8192;
+  if (nb1 > 8192) nb1 = 8192;
+#define GO(T) hipLaunchKernelGGL((sparse_adam_dual_kernel<T>), dim3(nb0 + nb1), dim3(256), 0, st, a, (float4*)table, (float4*)m, (float4*)v, \
+                                 last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)uniq_grad, d / 4, grad_scale_dev, nb0,     \
+                                 next_uniq_idx, next_n_uniq_dev, (long long)next_n_max)
+  switch (tpr) {
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    case 16: GO(16); break;
+    default: GO(32); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
 }
 
 extern "C" int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,

@@ -52,6 +52,9 @@ class SparseDenseAdam:
         self._plans = {}
         import os
         self._fuse = os.environ.get("UR_ROWS_FUSE") == "1"
+        # row update + next batch's catch-up as ONE launch (ur_sparse_adam_rows_catchup).  Off by default: measured at C5 the merged launch
+        # takes what the two take together (both halves are bound by the same random-row traffic) and the step is 8 us slower
+        self._merge = os.environ.get("UR_ADAM_MERGE", "0") == "1"
         # where the next batch's rows take their missed zero-gradient steps (lazy_dense): "tail" (default) = on the main stream right
         # after this step's row update, under the tail of the dense-gradient stream the main stream would otherwise wait for idle;
         # "side" = on the plan's side stream under the whole step in flight (measured slower: its VALU work lands on the forward
@@ -163,7 +166,7 @@ class SparseDenseAdam:
                 if st["last"] is not None:
                     ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
 
-    def _catchup_prefetched(self):
+    def _catchup_prefetched(self, skip=()):
         """step(), after the row update: the NEXT batch's rows (plan already made by `prefetch_plan`) take their zero-gradient steps
         up to and including this one now, on the main stream, while the dense-gradient reductions are still running on the side
         stream -- the same launch `plan_batch` would make at the head of the next step, moved into a slot where the main stream
@@ -175,7 +178,7 @@ class SparseDenseAdam:
         cfg = self._cfg(self.t + 1)
         for name, pl in pre[1].items():
             st = self.tables[name]
-            if st["last"] is not None:
+            if st["last"] is not None and name not in skip:
                 ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
         self._prefetched = pre[:4] + (self.t,)
 
@@ -247,11 +250,21 @@ class SparseDenseAdam:
         if self.grad_clip is None:
             # no global norm to wait for: the row-sparse half goes first, under the encoder's dense-gradient reductions that
             # may still be running on the side stream (model.defer_dense_join), then the join, then the dense half
+            # (lazy_dense, next batch's plan already made: its rows' catch-up rides in the same launch as this step's row update)
+            pre = self._prefetched
+            merge = (pre is not None and self._ahead == "tail" and self.table_mode == "lazy_dense" and pre[4] is None and self._merge)
+            if merge:
+                torch.cuda.current_stream().wait_event(pre[2])
+            merged = set()
             for name, (pl, ug) in reduced.items():
                 st = self.tables[name]
-                ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
+                if merge and st["last"] is not None and name in pre[1]:
+                    ops.sparse_adam_rows_catchup(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale, pre[1][name])
+                    merged.add(name)
+                else:
+                    ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
             sparse_done = True
-            self._catchup_prefetched()
+            self._catchup_prefetched(skip=merged)
         model.finish_backward()
         if self.grad_clip is not None:
             ss = self._scalars[0:1]

@@ -336,6 +336,14 @@ def sparse_adam_rows(cfg, table, m, v, pl: RowsPlan, uniq_grad, last_step=None, 
                                   _p(uniq_grad), table.shape[1], _p(grad_scale), _stream()), "ur_sparse_adam_rows")
 
 
+def sparse_adam_rows_catchup(cfg, table, m, v, pl: RowsPlan, uniq_grad, last_step, grad_scale, next_pl: RowsPlan):
+    """sparse_adam_rows for this step's rows + lazy_adam_catchup of the next batch's rows (to the state after this step), one launch"""
+    _chk(last_step, torch.int32, "last_step")
+    check(lib.ur_sparse_adam_rows_catchup(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
+                                          _p(uniq_grad), table.shape[1], _p(grad_scale), _p(next_pl.uniq_idx), _p(next_pl.n_uniq),
+                                          next_pl.n, _stream()), "ur_sparse_adam_rows_catchup")
+
+
 def lazy_adam_catchup(cfg, table, m, v, last_step, pl: RowsPlan):
     _chk(last_step, torch.int32, "last_step")
     check(lib.ur_lazy_adam_catchup(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
