@@ -342,6 +342,11 @@ int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m, float* v, 
 int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                          const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
                          void* stream);
+/* out_idx[0 .. *out_n_dev) = the rows of uniq_idx[0 .. *n_uniq_dev) that were ever updated (last_step != 0), in arbitrary order: with
+ * weight_decay == 0 the only rows ur_lazy_adam_catchup has work for.  Made next to the plan (side stream), it keeps the catch-up of a
+ * batch of never-seen rows -- a chain of random last_step reads and nothing else -- off the main stream.  out_idx: n_max ints. */
+int ur_rows_filter_touched(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const int32_t* last_step,
+                           int32_t* out_idx, int32_t* out_n_dev, void* stream);
 /* ur_sparse_adam_rows (lazy-dense semantics, last_step != NULL) for THIS step's rows and ur_lazy_adam_catchup for the NEXT batch's
  * rows (next_uniq_idx: its plan's row list) in ONE launch: the next batch's rows -- minus the ones updated here -- are brought to
  * the state after this step (cfg->step).  Same results as the two calls in sequence; the two halves are latency-bound chains of random

@@ -1436,6 +1436,34 @@ extern "C" int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m
   return launch_sparse_adam(1, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, nullptr, d, nullptr, as_stream(stream));
 }
 
+// rows of a plan that have EVER been updated (last_step != 0): the only ones a catch-up has anything to do for when weight_decay == 0.
+// Run next to the plan on its side stream, it takes the random last_step reads of a batch of new rows (every row of a 100 M-row table in
+// a short run) off the main stream's tail.  Order of the output is arbitrary (one atomic per wave), which the catch-up does not mind.
+__global__ __launch_bounds__(256) void rows_filter_touched_kernel(const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
+                                                                  long long n_max, const int* __restrict__ last_step,
+                                                                  int* __restrict__ out_idx, int* __restrict__ out_n) {
+  const int n = (int)min((long long)*n_uniq_dev, n_max);
+  const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const int row = i < n ? uniq_idx[i] : 0;
+  const bool keep = i < n && row != 0 && last_step[row] != 0;
+  const unsigned long long m = __ballot(keep);
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(out_n, __popcll(m));
+  base = __shfl(base, 0, 64);
+  if (keep) out_idx[base + __popcll(m & ((1ULL << lane) - 1ULL))] = row;
+}
+extern "C" int ur_rows_filter_touched(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const int32_t* last_step,
+                                      int32_t* out_idx, int32_t* out_n_dev, void* stream) {
+  UR_REQUIRE(uniq_idx && n_uniq_dev && last_step && out_idx && out_n_dev && n_max > 0 && n_max < (1LL << 31), UR_ERR_ARG,
+             "ur_rows_filter_touched: null pointer or n_max=%lld", (long long)n_max);
+  hipStream_t st = as_stream(stream);
+  UR_HIP(hipMemsetAsync(out_n_dev, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(rows_filter_touched_kernel, dim3(cdiv(n_max, 256)), dim3(256), 0, st, uniq_idx, n_uniq_dev, (long long)n_max, last_step,
+                     out_idx, out_n_dev);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
 extern "C" int ur_lazy_adam_catchup_ahead(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                                           const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
                                           const int32_t* busy_idx, const int32_t* busy_n_dev, int64_t busy_max, void* stream) {

@@ -55,6 +55,7 @@ class SparseDenseAdam:
         # row update + next batch's catch-up as ONE launch (ur_sparse_adam_rows_catchup).  Off by default: measured at C5 the merged launch
         # takes what the two take together (both halves are bound by the same random-row traffic) and the step is 8 us slower
         self._merge = os.environ.get("UR_ADAM_MERGE", "0") == "1"
+        self._filter = os.environ.get("UR_CATCHUP_FILTER", "1") != "0"   # tail catch-up over the next batch's rows WITH history only
         # where the next batch's rows take their missed zero-gradient steps (lazy_dense): "tail" (default) = on the main stream right
         # after this step's row update, under the tail of the dense-gradient stream the main stream would otherwise wait for idle;
         # "side" = on the plan's side stream under the whole step in flight (measured slower: its VALU work lands on the forward
@@ -141,11 +142,17 @@ class SparseDenseAdam:
                         ops.lazy_adam_catchup_ahead(cfg, st["w"], st["m"], st["v"], st["last"], pl, self._plans[name])
                     else:
                         ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
+            filtered = None
+            if self.table_mode == "lazy_dense" and self._ahead == "tail" and self.wd == 0.0 and self._filter:
+                # rows of the next batch that have any optimizer history at all: the catch-up at the tail of this step only walks those
+                # (a row first touched by the step in flight is missed here and needs no catch-up: its update leaves it current)
+                filtered = {name: ops.rows_filter_touched(pl, self.tables[name]["last"]) for name, pl in plans.items()
+                            if self.tables[name]["last"] is not None}
             ev = torch.cuda.Event()
             ev.record(self._side)
         # keep ids + workspaces alive until the plan is adopted (the side stream reads / writes them asynchronously)
         # (and the in-flight step's plans: the catch-up reads their row lists after step() has dropped them)
-        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev, (req, bufs, dict(self._plans)), ahead)
+        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev, (req, bufs, dict(self._plans)), ahead, filtered)
 
     def plan_batch(self, item_seq=None, item_id=None, user_id=None):
         """Sort/unique the ids this batch will look up (or adopt the plan `prefetch_plan` made for the same tensors);
@@ -179,8 +186,10 @@ class SparseDenseAdam:
         for name, pl in pre[1].items():
             st = self.tables[name]
             if st["last"] is not None and name not in skip:
+                if pre[5] is not None and name in pre[5]:
+                    pl = pre[5][name]
                 ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
-        self._prefetched = pre[:4] + (self.t,)
+        self._prefetched = pre[:4] + (self.t,) + pre[5:]
 
     def flush(self):
         """lazy_dense: apply all pending zero-gradient steps to every row (before eval / checkpoint)."""

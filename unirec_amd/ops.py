@@ -336,6 +336,19 @@ def sparse_adam_rows(cfg, table, m, v, pl: RowsPlan, uniq_grad, last_step=None, 
                                   _p(uniq_grad), table.shape[1], _p(grad_scale), _stream()), "ur_sparse_adam_rows")
 
 
+def rows_filter_touched(pl: RowsPlan, last_step) -> RowsPlan:
+    """-> a plan-like list (uniq_idx / n_uniq only, arbitrary order) of pl's rows that were ever updated (ur_rows_filter_touched)"""
+    _chk(last_step, torch.int32, "last_step")
+    out = RowsPlan()
+    out.n, out.n_a = pl.n, 0
+    out.uniq_idx = torch.empty(pl.n, dtype=torch.int32, device=last_step.device)
+    out.n_uniq = torch.empty(1, dtype=torch.int32, device=last_step.device)
+    out.seg_start = out.sorted_pos = None
+    check(lib.ur_rows_filter_touched(_p(pl.uniq_idx), _p(pl.n_uniq), pl.n, _p(last_step), _p(out.uniq_idx), _p(out.n_uniq), _stream()),
+          "ur_rows_filter_touched")
+    return out
+
+
 def sparse_adam_rows_catchup(cfg, table, m, v, pl: RowsPlan, uniq_grad, last_step, grad_scale, next_pl: RowsPlan):
     """sparse_adam_rows for this step's rows + lazy_adam_catchup of the next batch's rows (to the state after this step), one launch"""
     _chk(last_step, torch.int32, "last_step")

@@ -312,6 +312,7 @@ NOT_OPS = {
     "ur_rows_scatter_add": _FAMILY,
     "ur_gather_dot_loss_fused_supported": _QUERY,
     "ur_gather_dot_loss_fwd_bwd": "fusion of the two ops gather_dot_loss_fwd + gather_dot_loss_bwd (both registered) for the graph-free training step: a scheduling choice, not a new op",
+    "ur_rows_filter_touched": "index bookkeeping of the lazy optimizer schedule (which rows of the next plan have any history): no arithmetic, a scheduling aid",
     "ur_sparse_adam_rows_catchup": "fusion of the two ops sparse_adam_rows + lazy_adam_catchup (both registered) into one launch: a scheduling choice of the optimizer, not a new op",
     "ur_rows_reduce_adam": "fusion of the two ops rows_reduce + sparse_adam_rows (both registered): a scheduling choice of the optimizer, not a new op",
 }
