@@ -55,6 +55,7 @@ def test_round2_schedules_keep_reference_parity():
     _run({"UR_ATTN_NO_M16W": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_dropout_gpu.py"), "-k", "golden or larger_random or skip_padding or attn or dropout"],
          expect_min_passed=20)
     # the last-row layer as ONE workgroup per row block (default: the inner dimension split over workgroups)
+    _run({"UR_SASREC_NO_QFUSE": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)   # gather + query GEMM launches in front of the one-query attention
     _run({"UR_SASREC_NO_SPLIT": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)
     for mask in ("0", "63", "1"):
         _run({"UR_SASREC_CHAIN": mask}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_trainer_gpu.py"),

@@ -317,7 +317,7 @@ __device__ __forceinline__ void store_vec(float* __restrict__ dst, const float (
 template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restrict__ q_last, const float* __restrict__ qkv,
                                                             const int* __restrict__ seq, AttnDims p, float* __restrict__ ctx_last,
-                                                            float* __restrict__ lse_last) {
+                                                            float* __restrict__ lse_last, AttnQProj qp) {
   const int lane = threadIdx.x & 63;
   const int h = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
   if (h >= p.H) return;
@@ -327,7 +327,28 @@ __global__ __launch_bounds__(256) void attn_last_fwd_kernel(const float* __restr
   seq_rows(p, b, row0, pad);
   const float* __restrict__ base = qkv + row0 * ld;
   const int* __restrict__ sq = seq + (long long)b * L;
-  const float* __restrict__ qr = q_last + (long long)b * p.d + h * HD;   // wave-uniform row
+  float qr[HD];
+  if (qp.wq != nullptr) {   // project this head's query: lane = input feature(s), one wave reduction per output
+    const long long xr = qp.xrow ? (long long)qp.xrow[b] : (long long)b * qp.xstride + qp.xoff;
+    const float* __restrict__ xrow = qp.x + xr * p.d;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) qr[c] = 0.f;
+    for (int k = lane; k < p.d; k += 64) {
+      const float xv = xrow[k];
+#pragma unroll
+      for (int c = 0; c < HD; ++c) qr[c] = fmaf(xv, qp.wq[(long long)(h * HD + c) * p.d + k], qr[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < HD; ++c) qr[c] = wave_sum(qr[c]) + qp.bq[h * HD + c];
+#pragma unroll
+    for (int c = 0; c < HD; ++c)
+      if (lane == c) qp.q_out[(long long)b * p.d + h * HD + c] = qr[c];
+    if (qp.x_out != nullptr && lane < HD) qp.x_out[(long long)b * p.d + h * HD + lane] = xrow[h * HD + lane];
+  } else {
+    const float* __restrict__ qsrc = q_last + (long long)b * p.d + h * HD;   // wave-uniform row
+#pragma unroll
+    for (int c = 0; c < HD; ++c) qr[c] = qsrc[c];
+  }
   const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
   const bool literal = fv >= L;
   const unsigned rk = attn_rowkey(p, b, h, L - 1);
@@ -1819,7 +1840,8 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
 }
 
 int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, int L, int d, int H, float* ctx_last,
-                  float* lse_last, hipStream_t st, const int* seq_base, const int* seq_pad, const DropSpec* drop) {
+                  float* lse_last, hipStream_t st, const int* seq_base, const int* seq_pad, const DropSpec* drop, const AttnQProj* qp) {
+  const AttnQProj qpv = qp ? *qp : AttnQProj{};
   ProfScope ps(PC_ATTN_FWD, st, 4.0 * B * (double)L * d);
   AttnDims p;
   int rc = make_dims(B, L, d, H, 1, &p);
@@ -1828,7 +1850,7 @@ int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, 
   p.seq_pad = seq_pad;
   if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   dim3 grid(B, cdiv(H, 4));
-#define GO(HD) UR_ATTN_LAUNCH(attn_last_fwd_kernel, HD, grid, dim3(256), 0, st, q_last, qkv, seq, p, ctx_last, lse_last)
+#define GO(HD) UR_ATTN_LAUNCH(attn_last_fwd_kernel, HD, grid, dim3(256), 0, st, q_last, qkv, seq, p, ctx_last, lse_last, qpv)
   switch (p.hd) {
     case 2: GO(2); break;
     case 4: GO(4); break;

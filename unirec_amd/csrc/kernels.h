@@ -190,9 +190,18 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
              int d, int H, int causal, float* dqkv, float* ws, int q_last_only, hipStream_t st,
              const int* seq_base = nullptr, const int* seq_pad = nullptr, const DropSpec* drop = nullptr);
 
+// QProj (optional): the query rows are not given but PROJECTED by the kernel -- q[b] = x[xrow ? xrow[b] : b * xstride + xoff] Wq^T + bq,
+// each wave its head's HD outputs -- and written to q_out (= the q_last the backward reads): the row gather and the B x d x d
+// projection GEMM in front of the one-query attention (5 + 8 us at their launch floors) disappear
+struct AttnQProj {
+  const float* x; const int* xrow; long long xstride, xoff;   // layer input rows [., d]
+  const float *wq, *bq;                                        // query.weight [d, d] (row = output feature), query.bias
+  float* q_out;                                                // [B, d]
+  float* x_out;                                                // nullable [B, d]: the gathered rows (each wave copies its head's slice)
+};
 int attn_last_fwd(const float* q_last, const float* qkv, const int* seq, int B, int L, int d, int H, float* ctx_last,
                   float* lse_last, hipStream_t st, const int* seq_base = nullptr, const int* seq_pad = nullptr,
-                  const DropSpec* drop = nullptr);
+                  const DropSpec* drop = nullptr, const AttnQProj* qp = nullptr);
 int attn_last_bwd(const float* q_last, const float* qkv, const int* seq, const float* ctx_last, const float* dctx_last,
                   const float* lse_last, int B, int L, int d, int H, float* dq_last, float* dqkv, hipStream_t st,
                   const int* seq_base = nullptr, const int* seq_pad = nullptr, const DropSpec* drop = nullptr);

@@ -384,19 +384,31 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       const int B = c.B;
       const float* x_last = x + (long long)(c.L - 1) * d;   // rows (b, L-1): a strided view, leading dimension L*d
       int ld_last = c.L * d;
+      // the one-query attention projects its own queries (and, compact rows, gathers the last rows on the way): no gather launch, no
+      // B x d x d GEMM launch in front of it.  UR_SASREC_NO_QFUSE=1: the stand-alone launches
+      static const bool qfuse = getenv("UR_SASREC_NO_QFUSE") == nullptr;
       if (compact) {   // the last rows are not equally spaced any more: gather them
-        hipLaunchKernelGGL(gather_rows_idx_kernel, dim3(cdiv((long long)B * d, 256)), dim3(256), 0, st, x, w.last_row, B, d, w.x_last);
-        UR_LAUNCH_CHECK();
+        if (!qfuse) {
+          hipLaunchKernelGGL(gather_rows_idx_kernel, dim3(cdiv((long long)B * d, 256)), dim3(256), 0, st, x, w.last_row, B, d, w.x_last);
+          UR_LAUNCH_CHECK();
+        }
         x_last = w.x_last;
         ld_last = d;
       }
       g.A = x; g.lda = d; g.W = p.wqkv + (long long)d * d; g.ldw = d; g.C = lw.qkv + d; g.ldc = 3 * d; g.M = M; g.N = 2 * d; g.K = d;
       g.bias = p.bqkv + d; g.m_dev = mv;
       if (!proj_done && (rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
-      g = GemmArgs{};
-      g.A = x_last; g.lda = ld_last; g.W = p.wqkv; g.ldw = d; g.C = w.q_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bqkv;
-      if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
-      if ((rc = attn_last_fwd(w.q_last, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st, sbase, spad, &d_attn))) return rc;
+      if (qfuse) {
+        AttnQProj qp{};
+        qp.x = x; qp.xrow = compact ? w.last_row : nullptr; qp.xstride = c.L; qp.xoff = c.L - 1;
+        qp.wq = p.wqkv; qp.bq = p.bqkv; qp.q_out = w.q_last; qp.x_out = compact ? w.x_last : nullptr;
+        if ((rc = attn_last_fwd(nullptr, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st, sbase, spad, &d_attn, &qp))) return rc;
+      } else {
+        g = GemmArgs{};
+        g.A = x_last; g.lda = ld_last; g.W = p.wqkv; g.ldw = d; g.C = w.q_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bqkv;
+        if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
+        if ((rc = attn_last_fwd(w.q_last, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st, sbase, spad, &d_attn))) return rc;
+      }
       if (chain_last) {
         // the B last rows through the same row-chain kernel as the full layers: out-projection + LN + feed-forward + LN in one launch
         // (16 workgroups at B = 512: three latency-bound launches of 10 + 7 + 25 us become one)
