@@ -746,6 +746,8 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
   const int n_uniq = (int)min((long long)*n_uniq_dev, n_max);
   const float scale = scale_dev ? *scale_dev : 1.0f;
   if (MODE == 0 && scale < 0.f) return;   // update guard: NaN loss, the whole step is skipped (see dense_adam_kernel)
+  if (bid * groups >= n_uniq) return;     // nothing for this workgroup (the grid is sized for the plan's capacity; a filtered catch-up
+                                          // list is often EMPTY: 3 520 workgroups evaluating two powf for nothing were 20 us)
   const float bc1 = 1.f - powf(a.b1, (float)a.step), bc2s = sqrtf(1.f - powf(a.b2, (float)a.step));
   if (MODE == 0 && d4 <= TPR) {
     // One float4 per lane and row: FOUR rows per lane group in flight.  The rows are random 512-byte reads over tables of tens of
