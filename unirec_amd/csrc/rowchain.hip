@@ -32,6 +32,13 @@ namespace ur {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float fx4 __attribute__((ext_vector_type(4)));   // plain LLVM vector: register arrays of it are always promoted (HIP's float4 class is not, in every context)
 
+// UR_RC_DIRECT = 1: the weight slices are NOT staged through LDS.  A wave owns 32 output columns of every GEMM of the chain (WC = D / 32
+// waves side by side), so at D = 128 no two waves of a workgroup want the same weight rows: each wave loads ITS fragment of a slice
+// straight from global memory (the weights are L2-resident) into registers, two slices ahead -- no staging stores, and ONE barrier per
+// GEMM segment (when the activation tile changes hands) instead of one per K slice.  LDS = the two activation tiles (32 KB at D = 128).
+#ifndef UR_RC_DIRECT
+#define UR_RC_DIRECT 1
+#endif
 constexpr int RC_BK = 16;          // K-slice of the streamed weight tile
 constexpr int RC_LS = RC_BK + 4;   // padded LDS row stride of the weight stage (conflict-free ds_read_b128)
 
@@ -44,9 +51,15 @@ struct RcGeom {
   static constexpr int RS = D + 4;                  // row stride of the reduction scratch laid over a dead tile
   static constexpr int TPR = D / 4;                 // lanes per row in the row-wise epilogues (one float4 each)
   static constexpr int RPP = 256 / TPR;             // rows per epilogue pass; 4 passes cover the BM rows
+#if UR_RC_DIRECT
+  static constexpr int WV = 2;                      // float4 loads per lane per weight slice: k offsets fk .. fk+3 and 8 + fk .. of ITS row
+  static constexpr int TILE = BM * TS;              // floats per activation tile
+  static constexpr int WST = 0;                     // (no weight stage)
+#else
   static constexpr int WV = D >= 64 ? D / 64 : 1;   // float4 loads per thread per weight slice (D rows x 4 float4; D = 32: half the threads)
   static constexpr int TILE = BM * TS;              // floats per activation tile
   static constexpr int WST = D * RC_LS;             // floats per weight-stage buffer
+#endif
   static constexpr size_t LDS_BYTES = (size_t)(2 * TILE + 2 * WST) * sizeof(float);
 };
 
@@ -60,6 +73,24 @@ __device__ __forceinline__ int rc_toff(int r, int c4) {
 // One thread's view of a weight segment (rows row0 .. row0+D-1, columns k0 .. of a row-major matrix with leading dimension
 // ldw): the address of ITS first float4 of the segment's first K-slice.  Thread tid stages row (tid >> 2) + 64 i, float4
 // column tid & 3 of every slice.  Everything is passed by value (a struct whose address is taken ends up in scratch memory).
+#if UR_RC_DIRECT
+// One LANE's view of a weight segment (rows row0 .. row0+D-1 = output features, columns k0 .. of a row-major matrix with leading
+// dimension ldw): the address of the first float4 of ITS B-operand fragment of the first K-slice -- row = the wave's 32-column block +
+// lane & 31, k offset 4 (lane >> 5) (the fragment layout of rc_gemm).
+template <int D>
+__device__ __forceinline__ const float* rc_wptr(const float* W, int ldw, int row0, int k0, int tid) {
+  const int lane = tid & 63, wc = (tid >> 6) % RcGeom<D>::WC;
+  return W + (long long)(row0 + wc * 32 + (lane & 31)) * ldw + k0 + 4 * (lane >> 5);
+}
+template <int D>
+__device__ __forceinline__ void rc_wload(fx4 (&r)[RcGeom<D>::WV], const float* p, int ldw) {
+  (void)ldw;
+  r[0] = *(const fx4*)p;
+  r[1] = *(const fx4*)(p + 8);
+}
+template <int D>
+__device__ __forceinline__ void rc_wstore(const fx4 (&r)[RcGeom<D>::WV], float* buf, int tid) { (void)r; (void)buf; (void)tid; }
+#else
 template <int D>
 __device__ __forceinline__ const float* rc_wptr(const float* W, int ldw, int row0, int k0, int tid) {
   return W + (long long)(row0 + min(tid >> 2, D - 1)) * ldw + k0 + (tid & 3) * 4;
@@ -76,6 +107,8 @@ __device__ __forceinline__ void rc_wstore(const fx4 (&r)[RcGeom<D>::WV], float* 
     if ((tid >> 2) + 64 * i < D) *(fx4*)(buf + ((tid >> 2) + 64 * i) * RC_LS + (tid & 3) * 4) = r[i];
 }
 
+#endif
+
 // acc += As[BM, D] @ W[seg]^T, K = D in NK = D / 32 slices.  As: an LDS activation tile (row stride TS).
 // The weight-slice stream runs TWO slices ahead of the MFMAs (an L2 round trip is longer than one K-step of 16 MFMAs): on entry
 // slice 0 of the segment is in Wst[buf] and slice 1 is in flight into wreg[1] (for NK = 1: slice 0 of the NEXT segment);
@@ -83,6 +116,38 @@ __device__ __forceinline__ void rc_wstore(const fx4 (&r)[RcGeom<D>::WV], float* 
 // earlier) into the other buffer.  wp / wnp: rc_wptr of this / the next segment (wnp nullable: the stream then re-reads this
 // segment -- staged, never used).  The invariant holds again on exit, for the next segment.  Ends with a barrier: every wave is
 // done reading As and the stage.
+#if UR_RC_DIRECT
+template <int D>
+__device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const float* wp, int ldw, const float* wnp, int ldwn,
+                                        float* Wst, int& buf, fx4 (&wreg)[2][RcGeom<D>::WV], int tid, int wr, int wc, int lane) {
+  (void)Wst; (void)buf; (void)tid; (void)wc;
+  constexpr int NK = D / RC_BK;
+  static_assert(NK % 2 == 0, "the two-slot ring assumes an even number of slices per segment");
+  const int frow = lane & 31, fk = 4 * (lane >> 5);
+  const int arow = wr * 32 + frow, ac0 = fk >> 2;   // this lane's tile row and the chunk offset of its K half
+  if (!wnp) { wnp = wp; ldwn = ldw; }
+  // on entry wreg[0] / wreg[1] hold this lane's fragments of slices 0 / 1 of the segment (in flight or landed); step kt consumes
+  // slice kt and refills its slot with slice kt + 2 (of this segment or the next): the invariant holds again on exit
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    const fx4 b0 = wreg[kt & 1][0], b1 = wreg[kt & 1][1];
+    if (kt + 2 < NK) rc_wload<D>(wreg[kt & 1], wp + (kt + 2) * RC_BK, ldw);
+    else rc_wload<D>(wreg[kt & 1], wnp + (kt + 2 - NK) * RC_BK, ldwn);
+    __builtin_amdgcn_sched_barrier(0);   // (the loads stay here: the scheduler would sink them to just ahead of their use)
+    const float4 a0 = *(const float4*)(As + rc_toff<D>(arow, kt * (RC_BK / 4) + 0 + ac0));
+    const float4 a1 = *(const float4*)(As + rc_toff<D>(arow, kt * (RC_BK / 4) + 2 + ac0));
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
+  }
+  __syncthreads();   // every wave is done reading As: the caller may overwrite it
+}
+#else
 template <int D>
 __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const float* wp, int ldw, const float* wnp, int ldwn,
                                         float* Wst, int& buf, fx4 (&wreg)[2][RcGeom<D>::WV], int tid, int wr, int wc, int lane) {
@@ -115,7 +180,21 @@ __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const fl
   }
 }
 
+#endif
+
 // start of the stream: slice 0 of the first segment -> Wst[0] (after the caller's barrier), slice 1 in flight
+#if UR_RC_DIRECT
+template <int D>
+__device__ __forceinline__ void rc_prime_load(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw) {
+  rc_wload<D>(wreg[0], wp, ldw);
+}
+template <int D>
+__device__ __forceinline__ void rc_prime_store(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw, const float* wnp, int ldwn,
+                                               float* Wst, int tid) {
+  (void)wnp; (void)ldwn; (void)Wst; (void)tid;
+  rc_wload<D>(wreg[1], wp + RC_BK, ldw);
+}
+#else
 template <int D>
 __device__ __forceinline__ void rc_prime_load(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw) {
   rc_wload<D>(wreg[0], wp, ldw);
@@ -127,6 +206,8 @@ __device__ __forceinline__ void rc_prime_store(fx4 (&wreg)[2][RcGeom<D>::WV], co
   if constexpr (D / RC_BK > 1) rc_wload<D>(wreg[1], wp + RC_BK, ldw);
   (void)wnp; (void)ldwn;
 }
+
+#endif
 
 // accumulator tile -> LDS tile.  acc[r]: row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of the wave's 32 x 32 tile.
 template <int D>
