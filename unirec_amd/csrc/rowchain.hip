@@ -16,8 +16,9 @@
 // twice per direction).  Here the only HBM traffic is what the backward pass / the weight-gradient GEMMs need later.
 //
 // Geometry (D = d in {32, 64, 128}): BM = 4096 / D rows per workgroup, 4 waves, one 32 x 32 accumulator tile per wave and
-// GEMM (v_mfma_f32_32x32x2_f32: exact fp32), weights streamed through a double-buffered [D][32] LDS stage whose next slice
-// is in flight across GEMM boundaries (the stream of weight slices never drains inside a workgroup).  inner is walked in
+// GEMM (v_mfma_f32_32x32x2_f32: exact fp32), weight slices streamed two ahead across GEMM boundaries (the stream never drains inside a
+// workgroup) -- since round 2b straight from global memory into the owning wave's registers (UR_RC_DIRECT, below); before that through
+// a double-buffered [D][16] LDS stage (the numbers that follow are that version's).  inner is walked in
 // D-wide chunks: h1 chunk -> LDS -> act -> second GEMM accumulates y over the chunks.  LDS: 52 KB at D = 128 (unpadded, XOR-swizzled
 // activation tiles + a 16-deep weight stage: THREE workgroups per CU; the first version, 70.7 KB = two per CU, paid 2.6 us per K = 32
 // step where the stand-alone 32-row GEMM kernels, three per CU, pay 1.7), 42 KB at D = 64.  The K order of every contraction equals gemm_nt's, so forward results are bit-identical to the
