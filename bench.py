@@ -569,6 +569,12 @@ def main():
     _lib.lib.ur_prof_reset()
     if dom is not None:
         _lib.lib.ur_prof_set_mask(1 << names.index(dom))
+    # Python's cyclic garbage collector is kept out of the timed region, as `timeit` does: a generation-2 collection of a process that
+    # has imported torch takes ~35 ms of HOST time, lands on an arbitrary step (measured: step 22 of one run, 37 of another, none in a
+    # third) and, in a 20-step region whose host runs only ~8 ms ahead of the device, shows up as +1.5 ms/step
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -577,6 +583,7 @@ def main():
         loss = step_fn(batches[(a.warmup + i) % len(batches)], batches[(a.warmup + i + 1) % len(batches)])
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     _lib.lib.ur_prof_enable(0)
     if world > 1:
         import torch.distributed as dist

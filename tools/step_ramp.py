@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Per-step device time of the first steps after a synchronisation (what a short timed region pays that a long one amortises)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from unirec_amd.facility.optimizer import SparseDenseAdam
+from unirec_amd.model.sequential.sasrec import SASRec
+
+a = bench.parse()
+dev = torch.device("cuda:0")
+model = SASRec(bench.model_config(a, "cuda:0"))
+opt = SparseDenseAdam(model, lr=1e-3, table_mode=a.table_mode)
+model.train()
+batches = bench.synth_batches(a, a.n_items, dev, 1, n_batches=80)
+
+def step(b, nxt):
+    opt.zero_grad()
+    opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
+    opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
+    model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
+    opt.step()
+
+for i in range(10):
+    step(batches[i], batches[i + 1])
+torch.cuda.synchronize()
+for rep in range(2):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(31)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(30):
+        step(batches[10 + i], batches[11 + i])
+        ev[i + 1].record()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    d = [ev[i].elapsed_time(ev[i + 1]) for i in range(30)]
+    print("per-step device ms:", " ".join(f"{x:.3f}" for x in d))
+    print(f"host enqueue {1e3*(t1-t0)/30:.3f} ms/step, wall incl. sync {1e3*(t2-t0)/30:.3f} ms/step, first 20 wall-equivalent {sum(d[:20])/20:.3f}")
