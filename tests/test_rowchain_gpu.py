@@ -60,6 +60,8 @@ def _close(a, b, tol, what):
     dict(d=32, L=10, inner=96, heads=4, layers=3, last_only=0, act="gelu"),
     dict(d=128, L=50, inner=512, heads=16, layers=2, skip_padding=0),       # padded rows: host-side row count
     dict(d=128, L=200, inner=256, heads=16, layers=2),                      # C3 sequence length
+    dict(d=128, L=30, inner=256, heads=16, layers=1),                       # ONE layer that is the last-row layer: the input block projects K, V only
+    dict(d=64, L=20, inner=128, heads=8, layers=1, act="gelu"),
 ])
 @pytest.mark.parametrize("B", [1, 37, 512])
 def test_chain_equals_unfused(kw, B):
