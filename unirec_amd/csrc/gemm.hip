@@ -541,7 +541,7 @@ template <int PRO, int NW>
 __global__ __launch_bounds__(64 * NW) void gemm_tn_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q,
                                                       int ldq, int T, int R, int Cc, int tok_per_split, int n_splits, int act,
                                                       float* __restrict__ part, float* __restrict__ bias_part,
-                                                      const int* __restrict__ t_dev) {
+                                                      const int* __restrict__ t_dev, const float* __restrict__ zero_row) {
   if (t_dev) {   // compacted token rows: spread the ACTUAL tokens over the splits (the host sized the split for the maximum)
     T = min(T, *t_dev);
     tok_per_split = (((T + n_splits - 1) / n_splits + BT - 1) / BT) * BT;
@@ -577,26 +577,27 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_kernel(const float* __restric
   const bool rin = r0 + c4 * 4 < R, cin = c0 + c4 * 4 < Cc;
   const float* Pp = P + (rin ? r0 + c4 * 4 : 0);
   const float* Qp = Q + (cin ? c0 + c4 * 4 : 0);
-  float4 rp[NP], rq[NP];
+  typedef float tfx4 __attribute__((ext_vector_type(4)));   // (plain LLVM vectors: arrays of HIP's float4 class are not always kept in registers)
+  tfx4 rp[NP], rq[NP];
   auto load_global = [&](int t0) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
+      // rows past the range (and the column groups past R) load ZEROS from a spare row instead of being zeroed after the load: a select
+      // on the loaded value makes the compiler branch around it and wait for the load on the spot (s_waitcnt vmcnt(0) at the TOP of the
+      // stage: the prefetch of the next stage was not overlapping the MFMAs at all).  P = 0 makes the product 0 whatever Q holds.
       const int t = t0 + trow + RP * i;
       const bool tin = t < t_end;
-      const int tt = tin ? t : t_end - 1;
-      float4 p = *(const float4*)(Pp + (long long)tt * ldp);
-      float4 q = *(const float4*)(Qp + (long long)tt * ldq);
-      if (!(tin && rin)) p = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!(tin && cin)) q = make_float4(0.f, 0.f, 0.f, 0.f);
-      rp[i] = p;
-      rq[i] = q;
+      const int tt = min(t, T - 1);
+      const float* pp = (tin && rin) ? Pp + (long long)t * ldp : zero_row;
+      rp[i] = *(const tfx4*)pp;
+      rq[i] = *(const tfx4*)(Qp + (long long)tt * ldq);
     }
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      *(float4*)(Ps + buf * BT * TB + (trow + RP * i) * TB + c4 * 4) = rp[i];
-      float4 v = rq[i];
+      *(tfx4*)(Ps + buf * BT * TB + (trow + RP * i) * TB + c4 * 4) = rp[i];
+      float4 v = make_float4(rq[i].x, rq[i].y, rq[i].z, rq[i].w);
       if (PRO == PRO_ACT) v = act4(v, act);
       *(float4*)(Qs + buf * BT * TB + (trow + RP * i) * TB + c4 * 4) = v;
     }
@@ -614,17 +615,37 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_kernel(const float* __restric
     if (it + 1 < nt) load_global(t_begin + (it + 1) * BT);
     const float* Pb = Ps + buf * BT * TB + ft * TB + wr * 64 + fcol;
     const float* Qb = Qs + buf * BT * TB + ft * TB + wc * (32 * TN_) + fcol;
+    // fragments of step kk + FD are read while step kk's MFMAs run (written out: left to itself the compiler waits for each step's
+    // reads right in front of that step's MFMAs, lgkmcnt(0) sixteen times per stage)
+    constexpr int FD = 4;                      // steps of read-ahead
+    float fa0[FD], fa1[FD], fbq[FD][TN_];
+#pragma unroll
+    for (int u = 0; u < FD; ++u) {
+      fa0[u] = Pb[2 * u * TB];
+      fa1[u] = Pb[2 * u * TB + 32];
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) fbq[u][j] = Qb[2 * u * TB + 32 * j];
+    }
 #pragma unroll
     for (int kk = 0; kk < BT; kk += 2) {
-      const float a0 = Pb[kk * TB], a1 = Pb[kk * TB + 32];
+      const int u = (kk >> 1) % FD;
+      const float a0 = fa0[u], a1 = fa1[u];
       float b[TN_];
 #pragma unroll
-      for (int j = 0; j < TN_; ++j) b[j] = Qb[kk * TB + 32 * j];
+      for (int j = 0; j < TN_; ++j) b[j] = fbq[u][j];
+      if (kk + 2 * FD < BT) {
+        fa0[u] = Pb[(kk + 2 * FD) * TB];
+        fa1[u] = Pb[(kk + 2 * FD) * TB + 32];
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) fbq[u][j] = Qb[(kk + 2 * FD) * TB + 32 * j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < TN_; ++j) {
         acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[j], acc[0][j], 0, 0, 0);
         acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[j], acc[1][j], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (bias_part != nullptr && first_ctile && tid < TB) {
 #pragma unroll 8
@@ -899,6 +920,8 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_NONE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  const float* zeros_staged = tn_zero_buf();
+  if (!zeros_staged) return fail(UR_ERR_HIP, "gemm_tn: no device memory for the zero row");
   static const int direct = getenv("UR_TN_DIRECT") ? atoi(getenv("UR_TN_DIRECT")) : 0;   // 0 (default): the LDS-staged kernel; 8 / 16: the no-LDS kernel, ring depth
   if (direct) {
     const float* zeros = tn_zero_buf();
@@ -908,7 +931,7 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
     else { if (pro_act_on_q) UR_TND_GO(PRO_ACT, 8); else UR_TND_GO(PRO_NONE, 8); }
 #undef UR_TND_GO
   } else
-#define UR_TN_GO(PRO_, NW_) hipLaunchKernelGGL((gemm_tn_kernel<PRO_, NW_>), grid, dim3(64 * NW_), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev)
+#define UR_TN_GO(PRO_, NW_) hipLaunchKernelGGL((gemm_tn_kernel<PRO_, NW_>), grid, dim3(64 * NW_), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev, zeros_staged)
   if (nw == 4) { if (pro_act_on_q) UR_TN_GO(PRO_ACT, 4); else UR_TN_GO(PRO_NONE, 4); }
   else { if (pro_act_on_q) UR_TN_GO(PRO_ACT, 8); else UR_TN_GO(PRO_NONE, 8); }
 #undef UR_TN_GO
