@@ -15,6 +15,8 @@
 // and made the store tail as long as the K loop.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -541,12 +543,15 @@ template <int PRO, int NW>
 __global__ __launch_bounds__(64 * NW) void gemm_tn_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ Q,
                                                       int ldq, int T, int R, int Cc, int tok_per_split, int n_splits, int act,
                                                       float* __restrict__ part, float* __restrict__ bias_part,
-                                                      const int* __restrict__ t_dev, const float* __restrict__ zero_row) {
+                                                      const int* __restrict__ t_dev, const float* __restrict__ zero_row, int swz) {
   if (t_dev) {   // compacted token rows: spread the ACTUAL tokens over the splits (the host sized the split for the maximum)
     T = min(T, *t_dev);
     tok_per_split = (((T + n_splits - 1) / n_splits + BT - 1) / BT) * BT;
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // a fragment read takes 32 consecutive floats of token t (lanes 0-31) and of token t + 1 (lanes 32-63): with the rows 128 floats apart the
+  // two halves would hit the same 32 banks (2-way conflict on every read), so the rows of ODD tokens are stored with column bit 5 flipped
+  // (c ^ 32): the halves then sit in different banks, and no LDS is added
   float* Ps = smem;                  // [2][BT*TB]
   float* Qs = smem + 2 * BT * TB;    // [2][BT*TB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -596,10 +601,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_kernel(const float* __restric
   auto store_lds = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      *(tfx4*)(Ps + buf * BT * TB + (trow + RP * i) * TB + c4 * 4) = rp[i];
+      *(tfx4*)(Ps + buf * BT * TB + (trow + RP * i) * TB + ((c4 * 4) ^ (((trow + RP * i) & swz) << 5))) = rp[i];
       float4 v = make_float4(rq[i].x, rq[i].y, rq[i].z, rq[i].w);
       if (PRO == PRO_ACT) v = act4(v, act);
-      *(float4*)(Qs + buf * BT * TB + (trow + RP * i) * TB + c4 * 4) = v;
+      *(float4*)(Qs + buf * BT * TB + (trow + RP * i) * TB + ((c4 * 4) ^ (((trow + RP * i) & swz) << 5))) = v;
     }
   };
 
@@ -610,21 +615,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_kernel(const float* __restric
   }
   __syncthreads();
   const int fcol = lane & 31, ft = lane >> 5;
+  const int sw = (ft & swz) << 5;   // column swizzle of this lane's (odd/even) token rows
+  int qc[TN_];              // swizzled column offsets of this wave's Q fragments
+#pragma unroll
+  for (int j = 0; j < TN_; ++j) qc[j] = (wc * (32 * TN_) + 32 * j) ^ sw;
   for (int it = 0; it < nt; ++it) {
     const int buf = it & 1;
     if (it + 1 < nt) load_global(t_begin + (it + 1) * BT);
     const float* Pb = Ps + buf * BT * TB + ft * TB + wr * 64 + fcol;
-    const float* Qb = Qs + buf * BT * TB + ft * TB + wc * (32 * TN_) + fcol;
+    const float* Qb = Qs + buf * BT * TB + ft * TB + fcol;
     // fragments of step kk + FD are read while step kk's MFMAs run (written out: left to itself the compiler waits for each step's
     // reads right in front of that step's MFMAs, lgkmcnt(0) sixteen times per stage)
     constexpr int FD = 4;                      // steps of read-ahead
     float fa0[FD], fa1[FD], fbq[FD][TN_];
 #pragma unroll
     for (int u = 0; u < FD; ++u) {
-      fa0[u] = Pb[2 * u * TB];
-      fa1[u] = Pb[2 * u * TB + 32];
+      fa0[u] = Pb[2 * u * TB + sw];
+      fa1[u] = Pb[2 * u * TB + (sw ^ 32)];
 #pragma unroll
-      for (int j = 0; j < TN_; ++j) fbq[u][j] = Qb[2 * u * TB + 32 * j];
+      for (int j = 0; j < TN_; ++j) fbq[u][j] = Qb[2 * u * TB + qc[j]];
     }
 #pragma unroll
     for (int kk = 0; kk < BT; kk += 2) {
@@ -634,10 +643,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < TN_; ++j) b[j] = fbq[u][j];
       if (kk + 2 * FD < BT) {
-        fa0[u] = Pb[(kk + 2 * FD) * TB];
-        fa1[u] = Pb[(kk + 2 * FD) * TB + 32];
+        fa0[u] = Pb[(kk + 2 * FD) * TB + sw];
+        fa1[u] = Pb[(kk + 2 * FD) * TB + (sw ^ 32)];
 #pragma unroll
-        for (int j = 0; j < TN_; ++j) fbq[u][j] = Qb[(kk + 2 * FD) * TB + 32 * j];
+        for (int j = 0; j < TN_; ++j) fbq[u][j] = Qb[(kk + 2 * FD) * TB + qc[j]];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -649,7 +658,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_kernel(const float* __restric
     }
     if (bias_part != nullptr && first_ctile && tid < TB) {
 #pragma unroll 8
-      for (int t = 0; t < BT; ++t) bsum += Ps[buf * BT * TB + t * TB + tid];
+      for (int t = 0; t < BT; ++t) bsum += Ps[buf * BT * TB + t * TB + (tid ^ ((t & swz) << 5))];
     }
     if (it + 1 < nt) store_lds(buf ^ 1);
     __syncthreads();
@@ -920,6 +929,7 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<PRO_NONE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  static const int swz = (getenv("UR_TN_NO_SWIZZLE") && atoi(getenv("UR_TN_NO_SWIZZLE"))) ? 0 : 1;   // 1: odd token rows stored with column bit 5 flipped (no bank conflicts)
   const float* zeros_staged = tn_zero_buf();
   if (!zeros_staged) return fail(UR_ERR_HIP, "gemm_tn: no device memory for the zero row");
   static const int direct = getenv("UR_TN_DIRECT") ? atoi(getenv("UR_TN_DIRECT")) : 0;   // 0 (default): the LDS-staged kernel; 8 / 16: the no-LDS kernel, ring depth
@@ -931,7 +941,7 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
     else { if (pro_act_on_q) UR_TND_GO(PRO_ACT, 8); else UR_TND_GO(PRO_NONE, 8); }
 #undef UR_TND_GO
   } else
-#define UR_TN_GO(PRO_, NW_) hipLaunchKernelGGL((gemm_tn_kernel<PRO_, NW_>), grid, dim3(64 * NW_), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev, zeros_staged)
+#define UR_TN_GO(PRO_, NW_) hipLaunchKernelGGL((gemm_tn_kernel<PRO_, NW_>), grid, dim3(64 * NW_), lds, st, P, ldp, Q, ldq, T, R, Cc, tps, S, act, part, bias_part, t_dev, zeros_staged, swz)
   if (nw == 4) { if (pro_act_on_q) UR_TN_GO(PRO_ACT, 4); else UR_TN_GO(PRO_NONE, 4); }
   else { if (pro_act_on_q) UR_TN_GO(PRO_ACT, 8); else UR_TN_GO(PRO_NONE, 8); }
 #undef UR_TN_GO
