@@ -549,6 +549,14 @@ def main():
 
     # ---- warm-up: W untimed steps.  Every kernel class is bracketed with HIP events here; the per-class breakdown
     # tells which class dominates.  (Bracketing every launch costs ~0.4 ms/step, so it is NOT left on for `value`.)
+    # Python's cyclic garbage collector is kept out of the timed region, as `timeit` does: a generation-2 collection of a process that
+    # has imported torch takes ~35 ms of HOST time, lands on an arbitrary step (measured: step 22 of one run, 37 of another, none in a
+    # third) and, in a 20-step region whose host runs only ~8 ms ahead of the device, shows up as +1.5 ms/step.  The collection is done
+    # HERE, in front of the warm-up steps, not between them and the timed region: 35 ms of idle device right before the clock starts
+    # cost the first 20 steps +0.04 ms each (tools/warm_probe.py: 0.746 vs 0.725 for the first 20-step region, 0.705 from the second on)
+    import gc
+    gc.collect()
+    gc.disable()
     _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
     _lib.lib.ur_prof_reset()
     n_first = a.warmup // 2            # the first warm-up steps carry one-time costs (code-object loads, workspace allocation):
@@ -569,12 +577,6 @@ def main():
     _lib.lib.ur_prof_reset()
     if dom is not None:
         _lib.lib.ur_prof_set_mask(1 << names.index(dom))
-    # Python's cyclic garbage collector is kept out of the timed region, as `timeit` does: a generation-2 collection of a process that
-    # has imported torch takes ~35 ms of HOST time, lands on an arbitrary step (measured: step 22 of one run, 37 of another, none in a
-    # third) and, in a 20-step region whose host runs only ~8 ms ahead of the device, shows up as +1.5 ms/step
-    import gc
-    gc.collect()
-    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
