@@ -111,6 +111,13 @@ int ur_sasrec_bwd_deferred(const UrSasrecCfg* cfg, const float* item_table, int6
                            const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
                            float* d_emb_rows, void* stream);
 int ur_sasrec_bwd_join(void* stream);
+/* The side stream (a hipStream_t) while a deferred pass is pending, else NULL: work enqueued there runs behind the pass's
+ * dense-gradient reductions without a cross-stream wait (the dense half of the optimizer step).  ur_sasrec_side_publish marks the
+ * end of that work (`done` is recorded again); late != 0: the next ur_sasrec_fwd joins it on its own stream after its first launch
+ * (which reads ids only), late == 0 / ur_sasrec_bwd_join: the caller joins explicitly.  Until the join nothing else may read or
+ * write what the side-stream work touches. */
+void* ur_sasrec_side_stream(void);
+int ur_sasrec_side_publish(int late);
 
 /* ---------------------------------------------------------------------------------------------
  * ConvFormer / FASTConvFormer user encoders (unirec/model/sequential/convformer.py:16-129,

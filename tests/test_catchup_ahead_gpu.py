@@ -114,3 +114,56 @@ def test_catchup_ahead_leaves_the_busy_rows_alone():
     ops.lazy_adam_catchup_ahead(cfg, w, m, v, last, pl_n, pl_b)
     ops.lazy_adam_catchup(ops.adam_cfg(1e-2, 5), w, m, v, last, pl_n)
     assert torch.equal(w[moved], w1[moved]) and torch.equal(last[moved], torch.full_like(last[moved], 7))
+
+
+@pytest.mark.gpu
+def test_dense_half_on_the_side_stream_is_bit_identical(monkeypatch):
+    """UR_DENSE_ADAM_SIDE: the dense half of the optimizer step runs on the encoder's side stream behind the dense-gradient reductions
+    (ur_sasrec_side_stream / ur_sasrec_side_publish) and the NEXT forward pass joins it after its first launch ("late", default), or step()
+    joins it ("join"), or the main stream waits and runs it itself ("0", round 2a).  Same kernels, same inputs: bit-identical parameters,
+    optimizer state and losses after every step; a state_dict() taken right after step() must already see the update (the model joins)."""
+    import copy
+    import torch
+    from unirec_amd import ops
+    from unirec_amd.facility.optimizer import SparseDenseAdam
+    from unirec_amd.model.sequential.sasrec import SASRec
+
+    def run(mode):
+        monkeypatch.setenv("UR_DENSE_ADAM_SIDE", mode)
+        torch.manual_seed(7)
+        model = SASRec(_cfg(n_items=5000, embedding_size=128, hidden_size=128, inner_size=512, n_heads=16, max_seq_len=50, batch_size=64))
+        opt = SparseDenseAdam(model, lr=1e-3, table_mode="lazy_dense")
+        model.train()
+        g = torch.Generator(device="cpu").manual_seed(11)
+        batches = []
+        for _ in range(13):
+            seq = torch.randint(1, 5000, (64, 50), generator=g, dtype=torch.int32)
+            pad = torch.randint(0, 40, (64,), generator=g)
+            for b in range(64):
+                seq[b, :pad[b]] = 0
+            batches.append(dict(item_seq=seq.cuda(), item_id=torch.randint(1, 5000, (64, 5), generator=g).cuda(),
+                                label=torch.tensor([1, 0, 0, 0, 0], dtype=torch.int32).repeat(64, 1).cuda()))
+        losses, snaps = [], []
+        for k in range(12):
+            b, nxt = batches[k], batches[k + 1]
+            opt.zero_grad()
+            opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
+            opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
+            losses.append(model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"]))
+            opt.step()
+            if k in (0, 5):   # read through the public surface right after step(): must be the UPDATED parameters
+                snaps.append(copy.deepcopy({n: t.clone() for n, t in model.state_dict().items()}))
+        torch.cuda.synchronize()
+        assert not ops._side_hold or mode == "late"
+        return ([float(x) for x in losses], model.dense_flat.data.clone(), opt.dense_m.clone(), opt.dense_v.clone(),
+                model.item_embedding.weight.data.clone(), snaps)
+
+    ref = run("0")
+    for mode in ("join", "late"):
+        got = run(mode)
+        assert got[0] == ref[0], mode
+        for a, b in zip(got[1:5], ref[1:5]):
+            assert torch.equal(a, b), mode
+        for sa, sb in zip(got[5], ref[5]):
+            for n in sb:
+                assert torch.equal(sa[n], sb[n]), (mode, n)

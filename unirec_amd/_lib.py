@@ -68,6 +68,8 @@ SIGNATURES = {
     "ur_sasrec_bwd": (C.c_int, [C.POINTER(UrSasrecCfg), P, I64, P, P, P, P, P, P, P]),
     "ur_sasrec_bwd_deferred": (C.c_int, [C.POINTER(UrSasrecCfg), P, I64, P, P, P, P, P, P, P]),
     "ur_sasrec_bwd_join": (C.c_int, [P]),
+    "ur_sasrec_side_stream": (P, []),
+    "ur_sasrec_side_publish": (C.c_int, [C.c_int]),
     "ur_gru_param_layout": (I64, [C.POINTER(UrGruCfg), C.POINTER(I64)]),
     "ur_gru_workspace_bytes": (I64, [C.POINTER(UrGruCfg)]),
     "ur_gru_fwd": (C.c_int, [C.POINTER(UrGruCfg), P, I64, P, P, P, P, P]),

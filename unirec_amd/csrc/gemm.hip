@@ -985,6 +985,7 @@ int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st) 
 // several transposes in ONE launch (all weight matrices of the encoder before its backward pass: 8 launches -> 1)
 __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb) {
   __shared__ float tile[32][33];
+  if (tb.copy_src && blockIdx.x == 0 && threadIdx.x == 0) *tb.copy_dst = *tb.copy_src;
   if (tb.zero2_ptr && (int)blockIdx.x >= tb.zero2_first_block) {   // riders: zero-fill (the backward's gradient buffers)
     const long long i0 = ((long long)(blockIdx.x - tb.zero2_first_block) * 256 + threadIdx.x) * 16;
 #pragma unroll

@@ -297,6 +297,7 @@ struct SideCtx {
   hipEvent_t ev[24];
   hipEvent_t done = nullptr, main_done = nullptr;
   bool join_pending = false;   // ur_sasrec_bwd_deferred left reductions running: `done` marks their end
+  bool late_join = false;      // ur_sasrec_side_publish: the next ur_sasrec_fwd joins `done` itself, after its first launch
   bool ok = false;
 };
 int g_side_enabled = 1;   // runtime switch (ur_sasrec_set_side_stream)
@@ -346,10 +347,22 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
   const int* mv = compact ? w.m_valid : nullptr;
   const int* sbase = compact ? w.seq_base : nullptr;
   const int* spad = compact ? w.seq_pad : nullptr;
+  static const bool join_top = getenv("UR_SIDE_JOIN_TOP") && atoi(getenv("UR_SIDE_JOIN_TOP"));   // a late join in FRONT of the first launch (tuning aid)
+  if (join_top)
+    if (SideCtx* sc = side_ctx(true); sc && sc->join_pending && sc->late_join) {
+      UR_HIP(hipStreamWaitEvent(st, sc->done, 0));
+      sc->join_pending = false;
+      sc->late_join = false;
+    }
   if (compact) {
     hipLaunchKernelGGL(compact_plan_kernel, dim3(cdiv(c.B, CP_SEQS)), dim3(1024), 0, st, item_seq, c.B, c.L, w.tok_full, w.seq_base, w.seq_pad,
                        w.last_row, w.m_valid);
     UR_LAUNCH_CHECK();
+  }
+  if (SideCtx* sc = side_ctx(true); sc && sc->join_pending && sc->late_join) {   // (ur_sasrec_side_publish: the weights below are being updated on the side stream)
+    UR_HIP(hipStreamWaitEvent(st, sc->done, 0));
+    sc->join_pending = false;
+    sc->late_join = false;
   }
   const int* tokmap = compact ? w.tok_full : nullptr;   // buffer row -> token id (identity when not compact)
   const DropSpec d_emb = site_spec(c, 0, DROP_SITE_EMBED, nullptr);
@@ -533,6 +546,10 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     ln_cur += (long long)LN_BWD_MAX_BLOCKS * 2 * d;
     return p;
   };
+  // The side stream's GEMMs read the valid-row count from the backward's OWN copy (made by the transpose launch below): with a late join
+  // (ur_sasrec_side_publish) the next forward pass's row-compaction plan rewrites m_valid[0] while the side stream may not have started
+  // this pass's last GEMM yet -- seen as a loss that differed in the 6th digit in 3 of 14 runs.
+  const int* mv_side = mv ? w.m_valid + 16 : nullptr;
   // weight-gradient GEMM, forked onto the side stream (its inputs are complete at this point of the main stream)
   SideCtx* sc = (c.n_layers <= 2) ? side_ctx() : nullptr;   // the queue of deferred reductions must not flush mid-pass
   int n_fork = 0;
@@ -564,7 +581,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       int rc2 = fork();
       if (rc2) return rc2;
     }
-    pend[n_pend++] = PendingTn{P, Q, ldp, ldq, T_, R_, C_, pro_act, act, ldo, out, bias_out, tn_take(T_, R_, C_), T_ == M ? mv : nullptr};
+    pend[n_pend++] = PendingTn{P, Q, ldp, ldq, T_, R_, C_, pro_act, act, ldo, out, bias_out, tn_take(T_, R_, C_), T_ == M ? mv_side : nullptr};
     return sc ? UR_OK : fork();
   };
   if (!c.last_only) {
@@ -583,6 +600,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     if (lay.total % 4 == 0) { tb.zero_ptr = dense_grad; tb.zero_n = lay.total; }
     else UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
     if (compact) { tb.zero2_ptr = d_emb_rows; tb.zero2_n = (long long)M * d; }   // padded positions: zero gradient rows
+    if (mv) { tb.copy_src = mv; tb.copy_dst = w.m_valid + 16; }
     for (int i = 0; i < c.n_layers; ++i) {
       const LayerP p = layer_ptrs(dense, lay, i);
       LayerWs& lw = w.layer[i];
@@ -764,7 +782,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     g.aux = lw.h1; g.ldaux = I; g.act = c.act;
     if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
     if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
-    static const bool early_fork = getenv("UR_SASREC_EARLY_FORK") != nullptr;
+    static const bool early_fork = getenv("UR_SASREC_EARLY_FORK") && atoi(getenv("UR_SASREC_EARLY_FORK"));
     if (early_fork && (rc = fork())) return rc;
     g = GemmArgs{};
     g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
@@ -846,7 +864,27 @@ extern "C" int ur_sasrec_bwd_join(void* stream) {
   if (sc && sc->join_pending) {
     UR_HIP(hipStreamWaitEvent(as_stream(stream), sc->done, 0));
     sc->join_pending = false;
+    sc->late_join = false;
   }
+  return UR_OK;
+}
+
+// The side stream while a deferred pass is pending (else NULL): what the caller enqueues there runs behind the pass's dense-gradient
+// reductions with no cross-stream wait in between (the dense half of the optimizer step: the main stream's wait for `done` + the launch
+// + the wait's latency were ~30 us at the end of every step during which the main stream did 5 us of work).
+extern "C" void* ur_sasrec_side_stream(void) {
+  SideCtx* sc = side_ctx(true);
+  return (sc && sc->join_pending) ? (void*)sc->stream : nullptr;
+}
+
+// Marks the end of what the caller added to the side stream: `done` is recorded again.  late != 0: the next ur_sasrec_fwd of this
+// process joins it on ITS stream right after its first launch (the row-compaction plan reads ids only, no weights), so the join's
+// latency hides under that launch; ur_sasrec_bwd_join(stream) joins at once, as before, whichever was asked for.
+extern "C" int ur_sasrec_side_publish(int late) {
+  SideCtx* sc = side_ctx(true);
+  if (!sc || !sc->join_pending) return UR_OK;
+  UR_HIP(hipEventRecord(sc->done, sc->stream));
+  sc->late_join = late != 0;
   return UR_OK;
 }
 

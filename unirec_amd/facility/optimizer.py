@@ -55,6 +55,10 @@ class SparseDenseAdam:
         # row update + next batch's catch-up as ONE launch (ur_sparse_adam_rows_catchup).  Off by default: measured at C5 the merged launch
         # takes what the two take together (both halves are bound by the same random-row traffic) and the step is 8 us slower
         self._merge = os.environ.get("UR_ADAM_MERGE", "0") == "1"
+        # the dense half of the step on the encoder's side stream, right behind the dense-gradient reductions it waits for (no cross-stream
+        # wait in front of it), joined by the next forward pass after its first launch: "late" (default) / "join" (joined at the end of
+        # step()) / "0" (round 2a: the main stream waits for the reductions, then runs the dense half itself)
+        self._dense_side = os.environ.get("UR_DENSE_ADAM_SIDE", "late")
         self._filter = os.environ.get("UR_CATCHUP_FILTER", "1") != "0"   # tail catch-up over the next batch's rows WITH history only
         # where the next batch's rows take their missed zero-gradient steps (lazy_dense): "tail" (default) = on the main stream right
         # after this step's row update, under the tail of the dense-gradient stream the main stream would otherwise wait for idle;
@@ -76,6 +80,7 @@ class SparseDenseAdam:
         self.model.dense_table_grads.clear()
 
     def state_dict(self):
+        self.model.join_side_updates()
         return dict(t=self.t, dense_m=self.dense_m, dense_v=self.dense_v, param_groups=self.param_groups,
                     tables={k: {kk: vv for kk, vv in v.items() if kk != "w"} for k, v in self.tables.items()})
 
@@ -274,6 +279,19 @@ class SparseDenseAdam:
                     ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
             sparse_done = True
             self._catchup_prefetched(skip=merged)
+        side = None
+        if (self.grad_clip is None and self._dense_side in ("late", "join") and getattr(model, "_deferred_dense_grad", None) is not None
+                and model._deferred_dense_grad.numel()):
+            side = ops.sasrec_side_stream()
+        if side is not None:
+            g = model._deferred_dense_grad
+            with torch.cuda.stream(side):
+                ops.dense_adam(cfg, model.dense_flat.data, g, self.dense_m, self.dense_v, scale)
+            # (held until the main stream joins: the gradient buffer, and the row gradients the side stream's reductions read -- zero_grad()
+            # drops both before the next forward pass, and the plan stream's buffers could land on their memory)
+            ops.sasrec_side_publish(late=self._dense_side == "late", hold=(g,) + tuple(getattr(model, "_deferred_reads", ())))
+            model.dense_flat.grad = g
+            object.__setattr__(model, "_deferred_dense_grad", None)
         model.finish_backward()
         if self.grad_clip is not None:
             ss = self._scalars[0:1]
@@ -289,7 +307,7 @@ class SparseDenseAdam:
                 ops.sumsq(dg, ss, accumulate=True, ws=self._sumsq_ws)
             scale = self._scalars[1:2]
             ops.clip_coef(ss, self.grad_clip, scale, guard=guard)
-        if model.dense_flat.grad is not None:
+        if model.dense_flat.grad is not None and side is None:
             ops.dense_adam(cfg, model.dense_flat.data, model.dense_flat.grad, self.dense_m, self.dense_v, scale)
         for p, (m, v) in zip(self.extra, self.extra_state):
             if p.grad is not None:

@@ -224,6 +224,21 @@ class BaseRecommender(AbstractRecommender):
     # ``dense_flat.grad`` stays None until ``finish_backward()`` joins them.  Default off: backward leaves complete gradients.
     defer_dense_join = False
     _deferred_dense_grad = None
+    _deferred_reads = ()
+
+    @staticmethod
+    def join_side_updates():
+        """The optimizer may leave the dense half of its step running on the encoder's side stream (joined by the next encoder forward
+        pass): anything else that reads the dense parameters or their optimizer state on the current stream calls this first."""
+        ops.sasrec_side_join()
+
+    def state_dict(self, *args, **kwargs):
+        self.join_side_updates()
+        return super().state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        self.join_side_updates()
+        return super().train(mode)
 
     def finish_backward(self):
         g = self._deferred_dense_grad

@@ -118,6 +118,7 @@ class SASRec(BaseRecommender):
         if defer:   # the reductions into dense_grad are still running on the side stream: finish_backward() publishes it
             self.dense_flat.grad = None
             object.__setattr__(self, "_deferred_dense_grad", dense_grad)
+            object.__setattr__(self, "_deferred_reads", (d_rows,))   # what the side stream's reductions read besides the workspace (position-table gradient)
         else:
             self.dense_flat.grad = dense_grad
         self.sparse_grads.append(dict(table="item_embedding", ids_a=item_seq.reshape(-1), rows=d_rows))

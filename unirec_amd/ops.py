@@ -81,6 +81,8 @@ def sasrec_fwd(cfg, item_table, dense, item_seq, ws):
     user_emb = torch.empty(cfg.B, cfg.d, dtype=torch.float32, device=dense.device)
     check(lib.ur_sasrec_fwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(user_emb),
                             _p(ws), _stream()), "ur_sasrec_fwd")
+    _side_hold.clear()   # (a late join of side-stream work, if one was pending, is now enqueued on this stream)
+    _side_late[0] = False
     return user_emb
 
 
@@ -98,6 +100,36 @@ def sasrec_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws, defer_join=Fals
 
 def sasrec_bwd_join():
     check(lib.ur_sasrec_bwd_join(_stream()), "ur_sasrec_bwd_join")
+    _side_hold.clear()
+    _side_late[0] = False
+
+
+def sasrec_side_stream():
+    """The encoder's side stream as a torch stream while a deferred backward is pending (else None): see ur_sasrec_side_stream."""
+    p = lib.ur_sasrec_side_stream()
+    return torch.cuda.ExternalStream(p) if p else None
+
+
+_side_late = [False]   # a late join is armed (sasrec_side_publish(late=True)) and no forward pass / explicit join has taken it yet
+_side_hold = []   # tensors the side-stream work reads (allocated under the main stream): kept alive until the main stream has joined
+
+
+def sasrec_side_publish(late=True, hold=()):
+    """End of the work the caller put on the encoder's side stream.  late=True: the next sasrec_fwd joins it after its first launch;
+    `hold`: tensors that work reads -- kept referenced until that join is enqueued (their memory belongs to the main stream's allocator)."""
+    check(lib.ur_sasrec_side_publish(1 if late else 0), "ur_sasrec_side_publish")
+    if late:
+        _side_hold.extend(hold)
+        _side_late[0] = True
+    else:
+        sasrec_bwd_join()
+
+
+def sasrec_side_join():
+    """Joins a late side-stream update now, on the current stream (no-op when none is pending): for readers of the dense parameters
+    other than the encoder's forward pass."""
+    if _side_late[0]:
+        sasrec_bwd_join()
 
 
 # --------------------------------------------------------------------------------------------- GRU
