@@ -59,7 +59,8 @@ def test_round2_schedules_keep_reference_parity():
     _run({"UR_SASREC_NO_SPLIT": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)
     # the dense half of the optimizer step on the main stream (round 2a) / on the side stream but joined by step() itself; a late join in
     # front of the next forward pass's first launch
-    for env in ({"UR_DENSE_ADAM_SIDE": "0"}, {"UR_DENSE_ADAM_SIDE": "join"}, {"UR_SIDE_JOIN_TOP": "1"}):
+    # ({"UR_SASREC_STOP_EVENTS": "0"}: every fork of the backward pass by hipEventRecord instead of an event carried by the producing launch)
+    for env in ({"UR_DENSE_ADAM_SIDE": "0"}, {"UR_DENSE_ADAM_SIDE": "join"}, {"UR_SIDE_JOIN_TOP": "1"}, {"UR_SASREC_STOP_EVENTS": "0"}):
         _run(env, [os.path.join(HERE, "test_trainer_gpu.py"), os.path.join(HERE, "test_catchup_ahead_gpu.py")], expect_min_passed=10)
     for mask in ("0", "63", "1"):
         _run({"UR_SASREC_CHAIN": mask}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_trainer_gpu.py"),

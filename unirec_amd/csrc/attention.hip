@@ -1670,8 +1670,8 @@ __global__ __launch_bounds__(256) void attn_bwd_m16w_kernel(const float* __restr
 // launches KERNEL<HD, true> when dropout is on (p.dthresh != 0), KERNEL<HD, false> otherwise
 #define UR_ATTN_LAUNCH(KERNEL, HD, ...)                                   \
   do {                                                                    \
-    if (p.dthresh) hipLaunchKernelGGL((KERNEL<HD, true>), __VA_ARGS__);   \
-    else hipLaunchKernelGGL((KERNEL<HD, false>), __VA_ARGS__);            \
+    if (p.dthresh) UR_LAUNCH_EV((KERNEL<HD, true>), __VA_ARGS__);         \
+    else UR_LAUNCH_EV((KERNEL<HD, false>), __VA_ARGS__);                  \
   } while (0)
 
 static int make_dims(int B, int L, int d, int H, int causal, AttnDims* p) {

@@ -1,6 +1,7 @@
 // Shared device/host helpers for the unirec_amd HIP library (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -32,6 +33,22 @@ int fail(int code, const char* fmt, ...);
     hipError_t _e = hipGetLastError();                                                       \
     if (_e != hipSuccess)                                                                    \
       return ::ur::fail(UR_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+// ---- a launch that carries its own completion event.  hipEventRecord puts a marker packet behind the kernel and the NEXT kernel of the
+// stream waits for that packet: ~5 us of idle stream at every fork of the backward pass.  hipExtLaunchKernelGGL binds the event to the
+// kernel's own completion signal instead: nothing is inserted.  A caller arms `g_stop_event` right before calling a helper whose LAST
+// launch goes through UR_LAUNCH_EV; that launch consumes it (other launches of the helper leave it alone).
+extern thread_local hipEvent_t g_stop_event;
+#define UR_LAUNCH_EV(kernel, grid, block, lds, st, ...)                                        \
+  do {                                                                                       \
+    if (::ur::g_stop_event) {                                                                \
+      hipEvent_t ev_ = ::ur::g_stop_event;                                                   \
+      ::ur::g_stop_event = nullptr;                                                          \
+      hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), st, nullptr, ev_, 0, __VA_ARGS__); \
+    } else {                                                                                 \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                         \
+    }                                                                                        \
   } while (0)
 
 // ---- live kernel-class profiler (HIP events recorded on the launch stream; see ur_prof_* in the header)

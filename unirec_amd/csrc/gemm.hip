@@ -427,7 +427,7 @@ static int launch_nt(const GemmArgs& a, hipStream_t st) {
   static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI, BK, PF, PIPE>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, PRO, EPI, BK, PF, PIPE>), grid, dim3(256), lds, st, a);
+  UR_LAUNCH_EV((gemm_nt_kernel<BM, BN, PRO, EPI, BK, PF, PIPE>), grid, dim3(256), lds, st, a);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

@@ -5,6 +5,9 @@
 #include "kernels.h"
 
 namespace ur {
+thread_local hipEvent_t g_stop_event = nullptr;   // common.h: UR_LAUNCH_EV
+}
+namespace ur {
 
 static thread_local char g_err[512] = "";
 

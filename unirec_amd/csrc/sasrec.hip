@@ -558,11 +558,25 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   int n_pend = 0;
   // launch the queued weight-gradient GEMMs: on the side stream behind ONE event of the main stream (every queued GEMM's
   // inputs are complete at the point of the main stream where fork() is called), or in line when there is no side stream
+  // arm(): the next gemm_nt / attention launch of the main stream carries the next fork's event as its own completion event
+  // (UR_LAUNCH_EV) -- the fork behind it then needs no hipEventRecord (a marker packet = ~5 us of idle main stream).  Only in front of a
+  // launch that is followed by fork() with queued GEMMs and nothing else on the main stream in between.
+  static const bool stop_events = !(getenv("UR_SASREC_STOP_EVENTS") && atoi(getenv("UR_SASREC_STOP_EVENTS")) == 0);
+  hipEvent_t armed = nullptr;
+  auto arm = [&]() {
+    if (stop_events && sc && n_fork < 24) { armed = sc->ev[n_fork]; g_stop_event = armed; }
+  };
+  bool main_done_armed = false, main_done_carried = false;
   auto fork = [&]() -> int {
-    if (n_pend == 0) return UR_OK;
+    const bool carried = armed != nullptr && g_stop_event == nullptr;   // the armed launch took the event
+    if (armed) { armed = nullptr; g_stop_event = nullptr; }
+    if (n_pend == 0) {
+      if (carried) ++n_fork;   // (the event is in flight: its slot is used up)
+      return UR_OK;
+    }
     hipStream_t s2 = st;
     if (sc && n_fork < 24) {
-      UR_HIP(hipEventRecord(sc->ev[n_fork], st));
+      if (!carried) UR_HIP(hipEventRecord(sc->ev[n_fork], st));
       UR_HIP(hipStreamWaitEvent(sc->stream, sc->ev[n_fork], 0));
       ++n_fork;
       s2 = sc->stream;
@@ -646,7 +660,11 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       // bottom layer: the embedding LayerNorm's backward rides in the epilogue, rows go straight to their (padded-layout) places
       g.C = d_emb_rows; g.xhat = w.x0hat; g.rstd = w.rstd0; g.gamma = dense + lay.off[1]; g.out_rows = compact ? w.tok_full : nullptr;
       g.ln_part = lnfuse_part(c.n_layers);
+      // the LAST launch of the pass on the main stream: it carries `main_done` (what the side stream's reductions wait for) itself
+      if (stop_events && sc && defer_join && n_fork > 0) { g_stop_event = sc->main_done; main_done_armed = true; }
       if ((rc2 = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc2;
+      main_done_carried = main_done_armed && g_stop_event == nullptr;
+      g_stop_event = nullptr;
       if (rb.full(2) && (rc2 = reduce_batch(rb, st))) return rc2;
       rb.add(g.ln_part, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, dense_grad + lay.off[1], d);
       rb.add(g.ln_part + d, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, dense_grad + lay.off[2], d);
@@ -720,6 +738,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
       }
+      arm();
       if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, lw.g_qkv, st, sbase, spad, &d_attn))) return rc;
       // dWq from the B last rows, dWk/dWv from all rows
       if ((rc = tn(w.dq_last, d, compact ? w.x_last : x_in + (long long)(c.L - 1) * d, compact ? d : c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
@@ -789,6 +808,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     if (lnfuse) {
       // ---- d FFN-1 GEMM + residual + the attention block's LayerNorm backward in its epilogue: g_ta directly
       g.C = lw.g_ta; g.xhat = lw.ahat; g.rstd = lw.rstd1; g.gamma = p.g1; g.ln_part = lnfuse_part(i);
+      if (!early_fork) arm();
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc;
       if (rb.full(2) && (rc = reduce_batch(rb, st))) return rc;
       rb.add(g.ln_part, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, G + o[8], d);
@@ -806,10 +826,12 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     if (!early_fork && (rc = fork())) return rc;
     g = GemmArgs{};
     g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = d;
+    if (n_pend > 0) arm();
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
     // fork dWo now: it then runs underneath the attention backward instead of queueing up behind it at the very end of
     // the pass, where the side stream would finish after the main one (one more event, ~30 us off the tail)
     if ((rc = fork())) return rc;
+    arm();
     if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad, &d_attn))) return rc;
     if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
     if ((rc = fork())) return rc;
@@ -833,7 +855,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     // deferred join: the reductions into dense_grad run on the SIDE stream, behind the weight-gradient GEMMs there and behind
     // the main stream's last producer of partial sums; the caller's stream goes on (row-gradient reduce, sparse update) and
     // picks dense_grad up with ur_sasrec_bwd_join
-    UR_HIP(hipEventRecord(sc->main_done, st));
+    if (!main_done_carried) UR_HIP(hipEventRecord(sc->main_done, st));
     UR_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
     if ((rc = reduce_batch(rb, sc->stream))) return rc;
     UR_HIP(hipEventRecord(sc->done, sc->stream));

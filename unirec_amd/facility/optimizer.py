@@ -59,6 +59,7 @@ class SparseDenseAdam:
         # wait in front of it), joined by the next forward pass after its first launch: "late" (default) / "join" (joined at the end of
         # step()) / "0" (round 2a: the main stream waits for the reductions, then runs the dense half itself)
         self._dense_side = os.environ.get("UR_DENSE_ADAM_SIDE", "late")
+        self._rewait = os.environ.get("UR_PLAN_REWAIT") == "1"   # tuning aid: plan_batch waits for the plan's event even if this stream already has
         self._filter = os.environ.get("UR_CATCHUP_FILTER", "1") != "0"   # tail catch-up over the next batch's rows WITH history only
         # where the next batch's rows take their missed zero-gradient steps (lazy_dense): "tail" (default) = on the main stream right
         # after this step's row update, under the tail of the dense-gradient stream the main stream would otherwise wait for idle;
@@ -164,7 +165,12 @@ class SparseDenseAdam:
         in lazy_dense mode bring those rows up to date."""
         pre, self._prefetched = self._prefetched, None
         if pre is not None:   # always order the main stream after the side stream's use of the prefetch buffers
-            torch.cuda.current_stream().wait_event(pre[2])
+            cur = torch.cuda.current_stream()
+            # (the tail catch-up of the previous step() already made THIS stream wait for THIS event: a second wait is one more barrier
+            # packet in front of the forward pass, ~5 us of idle main stream at every step boundary)
+            if self._rewait or getattr(self, "_pre_waited", None) != (id(pre[2]), cur.cuda_stream):
+                cur.wait_event(pre[2])
+            self._pre_waited = None
         caught_up = False
         if pre is not None and pre[0] == self._ids_key(item_seq, item_id, user_id):
             self._plans = pre[1]
@@ -186,7 +192,9 @@ class SparseDenseAdam:
         pre = self._prefetched
         if pre is None or self._ahead != "tail" or self.table_mode != "lazy_dense" or pre[4] is not None:
             return
-        torch.cuda.current_stream().wait_event(pre[2])
+        cur = torch.cuda.current_stream()
+        cur.wait_event(pre[2])
+        self._pre_waited = (id(pre[2]), cur.cuda_stream)
         cfg = self._cfg(self.t + 1)
         for name, pl in pre[1].items():
             st = self.tables[name]
