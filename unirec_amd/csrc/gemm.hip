@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   constexpr int LS = BK + 4;            // padded LDS row stride (floats): conflict-free ds_read_b128 for BK = 16 and 32
   constexpr int C4N = BK / 4;           // float4 columns per tile row
   constexpr int RPT = 256 / C4N;        // tile rows covered per pass of the 256 threads
-  constexpr int WM = BM >= 64 ? 2 : 1, WN = 4 / WM;    // wave grid (BM = 32: all four waves side by side along N)
+  constexpr int WM = (BM >= 64 && BM % 64 == 0) ? 2 : 1, WN = 4 / WM;    // wave grid (BM = 32 / 96: all four waves side by side along N)
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int AV = BM / RPT, WV = BN / RPT;  // float4 loads per thread per K-step
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -513,6 +513,7 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
     switch (lnbwd_bm(a.M)) {
       case 128: return launch_nt<128, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
       case 64: return launch_nt<64, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
+      case 96: return launch_nt<96, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
       default: return pipe_on(a) ? launch_nt<32, 128, PRO_NONE, EPI_ADD_LNBWD, 32, 1, 1>(a, st)
                                  : launch_nt<32, 128, PRO_NONE, EPI_ADD_LNBWD>(a, st);
     }

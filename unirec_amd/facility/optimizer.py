@@ -208,6 +208,7 @@ class SparseDenseAdam:
         """lazy_dense: apply all pending zero-gradient steps to every row (before eval / checkpoint)."""
         if self.table_mode != "lazy_dense" or self.t == 0:
             return
+        self.model.join_side_updates()
         cfg = self._cfg(self.t)
         for st in self.tables.values():
             if st["last"] is not None:
