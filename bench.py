@@ -483,6 +483,17 @@ def main():
     from unirec_amd.facility.optimizer import SparseDenseAdam
     from unirec_amd.model.sequential.sasrec import SASRec
 
+    # one distinct batch per step (+1 for the lookahead): cycling a few batches would make every looked-up row "touched
+    # 8 steps ago", which is not what uniform ids over n_items rows look like (and costs a 7-step lazy-Adam replay per row)
+    def make_batches():
+        return synth_batches(a, a.n_items, device, 2022 + 7919 * rank, n_batches=min(a.warmup + a.steps + 1, 1024))
+
+    # The batches (their own generator: the order does not change a value) are made BEFORE the model and the optimizer state: those are
+    # ~150 GB of device fills, and the warm-up steps then start on a device that has just been busy.  A device left idle for tens of
+    # milliseconds runs the next 20-60 steps 2-5 % slower (tools/warm_probe.py: IDLE_MS = 5 / 50 / 500 in front of a 20-step region:
+    # +0.01 / +0.035 / +0.07 ms per step); ~30 batches of a dozen tiny launches each are such a gap.  UR_BENCH_ORDER=old: round-2a order.
+    old_order = os.environ.get("UR_BENCH_ORDER") == "old"
+    batches = None if old_order else make_batches()
     torch.manual_seed(2022 + rank)
     cfg = model_config(a, str(device))
     selfcheck = None
@@ -528,9 +539,8 @@ def main():
             opt.step()
             return loss
 
-    # one distinct batch per step (+1 for the lookahead): cycling a few batches would make every looked-up row "touched
-    # 8 steps ago", which is not what uniform ids over n_items rows look like (and costs a 7-step lazy-Adam replay per row)
-    batches = synth_batches(a, a.n_items, device, 2022 + 7919 * rank, n_batches=min(a.warmup + a.steps + 1, 1024))
+    if batches is None:
+        batches = make_batches()
 
     def barrier():
         if world > 1:
@@ -551,11 +561,14 @@ def main():
     # tells which class dominates.  (Bracketing every launch costs ~0.4 ms/step, so it is NOT left on for `value`.)
     # Python's cyclic garbage collector is kept out of the timed region, as `timeit` does: a generation-2 collection of a process that
     # has imported torch takes ~35 ms of HOST time, lands on an arbitrary step (measured: step 22 of one run, 37 of another, none in a
-    # third) and, in a 20-step region whose host runs only ~8 ms ahead of the device, shows up as +1.5 ms/step.  The collection is done
-    # HERE, in front of the warm-up steps, not between them and the timed region: 35 ms of idle device right before the clock starts
-    # cost the first 20 steps +0.04 ms each (tools/warm_probe.py: 0.746 vs 0.725 for the first 20-step region, 0.705 from the second on)
+    # third) and, in a 20-step region whose host runs only ~8 ms ahead of the device, shows up as +1.5 ms/step.  The collector is
+    # switched off HERE, in front of the warm-up steps, and nothing is collected: 35 ms of idle device between the warm-up steps and the
+    # clock cost the first 20 steps +0.04 ms each (tools/warm_probe.py: 0.746 vs 0.725 for the first 20-step region, 0.705 from the second on)
     import gc
-    gc.collect()
+    if old_order:
+        gc.collect()
+    else:
+        gc.freeze()     # (no collection here either: it would be 35 ms of idle device right in front of the warm-up steps)
     gc.disable()
     _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
     _lib.lib.ur_prof_reset()

@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 model = SASRec(bench.model_config(a, "cuda:0"))
 opt = SparseDenseAdam(model, lr=1e-3, table_mode=a.table_mode)
 model.train()
-batches = bench.synth_batches(a, a.n_items, dev, 1, n_batches=120)
+batches = bench.synth_batches(a, a.n_items, dev, 1, n_batches=320)
 def step(b, nxt):
     opt.zero_grad()
     opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
@@ -64,8 +64,21 @@ elif mode == "sleep":
     time.sleep(0.03)
 if not mode.startswith("gcfirst"):
     gc.collect(); gc.disable()
+if os.environ.get("IDLE_MS"):     # idle device right in front of the first region (after W warm-up steps)
+    torch.cuda.synchronize(); time.sleep(float(os.environ["IDLE_MS"]) * 1e-3)
+if os.environ.get("EMPTY_CACHE"):   # give every cached block back: the allocator starts over (new addresses, unsettled reuse pattern)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    step(batches[k], batches[k + 1]); k += 1     # (one untimed step pays the hipMallocs)
+    torch.cuda.synchronize()
+if os.environ.get("POST_BUSY_MS"):   # unrelated device work between the idle period and the first region
+    ms = float(os.environ["POST_BUSY_MS"])
+    A = torch.randn(4096, 4096, device=dev); Bm = torch.randn(4096, 4096, device=dev); x = torch.empty(64 << 20, device=dev)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    while time.perf_counter() - t0 < ms * 1e-3:
+        for _ in range(4): A @ Bm; x.add_(1.0)
+        torch.cuda.synchronize()
 out = []
-for rep in range(4):
+for rep in range(int(os.environ.get("REGIONS", "4"))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(20):
         step(batches[k], batches[k + 1]); k += 1
