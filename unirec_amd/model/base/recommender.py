@@ -236,6 +236,10 @@ class BaseRecommender(AbstractRecommender):
         self.join_side_updates()
         return super().state_dict(*args, **kwargs)
 
+    def load_state_dict(self, *args, **kwargs):
+        self.join_side_updates()
+        return super().load_state_dict(*args, **kwargs)
+
     def train(self, mode=True):
         self.join_side_updates()
         return super().train(mode)
