@@ -587,6 +587,16 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       if (rc2) return rc2;
     }
     n_pend = 0;
+    // everything queued for the final reduction so far is complete in the side stream's order once these GEMMs are (their own partials;
+    // partial sums written by main-stream launches in front of this fork's event): reduced HERE, behind the first fork's GEMMs, it runs
+    // in the gap the side stream has before the next fork instead of at the tail of the pass (UR_SASREC_EARLY_REDUCE=0: all at the end)
+    static const bool early_reduce = !(getenv("UR_SASREC_EARLY_REDUCE") && atoi(getenv("UR_SASREC_EARLY_REDUCE")) == 0);
+    // (behind EVERY fork, UR_SASREC_EARLY_REDUCE_ALL=1: +25 us -- the second flush, 45 MB, runs beside the attention backward)
+    static const int early_from = getenv("UR_SASREC_EARLY_REDUCE_ALL") && atoi(getenv("UR_SASREC_EARLY_REDUCE_ALL")) == 1 ? 24 : 1;
+    if (early_reduce && s2 != st && n_fork >= 1 && n_fork <= early_from && defer_join) {
+      int rc2 = reduce_batch(rb, s2);
+      if (rc2) return rc2;
+    }
     return UR_OK;
   };
   auto tn = [&](const float* P, int ldp, const float* Q, int ldq, int T_, int R_, int C_, int pro_act, int act, float* out, int ldo,
