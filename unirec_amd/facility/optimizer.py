@@ -20,7 +20,14 @@ class SparseDenseAdam:
     def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=None, eps=None, grad_clip=None,
                  table_mode="lazy_dense", algo="adam", overlap_dense_join=True):
         """algo: the torch.optim rule the reference's Trainer._build_optimizer would construct (trainer.py:134-152):
-        adam (default) / adamw / sgd / adagrad / rmsprop; betas / eps None = torch's defaults for that rule."""
+        adam (default) / adamw / sgd / adagrad / rmsprop; betas / eps None = torch's defaults for that rule.
+
+        Stream contract (SASRec encoder, no gradient clipping): ``step()`` may return with the dense half of the update still running on
+        the encoder's side stream; the model's next forward pass joins it.  Everything else that reads the dense parameters or this
+        optimizer's dense state through the public surface joins first (``model.state_dict() / load_state_dict() / train() / eval()``,
+        ``optimizer.state_dict() / flush()``); code that reads ``model.dense_flat.data`` or ``dense_m / dense_v`` DIRECTLY right after
+        ``step()`` calls ``model.join_side_updates()`` (or synchronises the device) first.  ``UR_DENSE_ADAM_SIDE=join`` / ``0`` make
+        ``step()`` itself join."""
         assert table_mode in ("lazy_dense", "rowwise")
         if algo not in ops.OPT_ALGOS:
             raise ValueError(f"unknown optimizer rule {algo!r}")
