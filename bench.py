@@ -580,10 +580,16 @@ def main():
             _lib.lib.ur_prof_enable(0 if a.no_prof else 1)
         loss = step_fn(batches[i % len(batches)], batches[(i + 1) % len(batches)])
     barrier()
+    t_gap0 = time.perf_counter()
     _lib.lib.ur_prof_enable(0)
     warm = prof_read()
-    if loss is not None and not torch.isfinite(loss.detach()).item():
+    t_gap1 = time.perf_counter()
+    # (a host-side check of the copied scalar: torch.isfinite() here was the first use of four elementwise kernels -- 20-100 ms of
+    # code-object loading with the device idle, right in front of the timed region, and an idle device runs its next steps slower)
+    import math
+    if loss is not None and not math.isfinite(float(loss.detach().item())):
         raise SystemExit("non-finite loss in warm-up")
+    t_gap2 = time.perf_counter()
     dom = max(warm, key=lambda k: warm[k]["ms"]) if (not a.no_prof and any(v["launches"] for v in warm.values())) else None
     # ---- timed region: exactly --steps steps.  Only the dominant kernel class is bracketed (HIP events on the launch
     # stream), and only on every PROF_EVERY-th step, so the measurement perturbs `value` by ~1 %.
@@ -592,6 +598,8 @@ def main():
         _lib.lib.ur_prof_set_mask(1 << names.index(dom))
     barrier()
     t0 = time.perf_counter()
+    if os.environ.get("UR_BENCH_GAP"):
+        print(f"[bench] idle device between warm-up and the timed region: {1e3*(t0-t_gap0):.2f} ms (prof_read {1e3*(t_gap1-t_gap0):.2f}, isfinite {1e3*(t_gap2-t_gap1):.2f})", file=sys.stderr)
     for i in range(a.steps):
         if dom is not None:
             _lib.lib.ur_prof_enable(1 if i % PROF_EVERY == 0 else 0)

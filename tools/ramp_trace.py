@@ -39,3 +39,23 @@ A, B = agg(0, 3), agg(N - 5, N - 2)
 print("kernel time per step, first 3 steps vs late steps (us), sorted by difference:")
 for k in sorted(set(A) | set(B), key=lambda k: -(A.get(k, 0) - B.get(k, 0)))[:14]:
     print(f"  {A.get(k,0)/1e3:7.1f} {B.get(k,0)/1e3:7.1f}  {(A.get(k,0)-B.get(k,0))/1e3:+6.1f}  q{k[0]} {k[1]}")
+# idle device between the last warm-up step and the first timed step
+allm = [e[0] for e in ev if MARK in e[2]]
+i0 = len(allm) - N
+if i0 >= 1:
+    prev_end = max(e[1] for e in ev if e[0] < allm[i0])
+    print(f"idle between the last kernel before the timed region and its first kernel: {(allm[i0] - prev_end)/1e3:.1f} us")
+    starts = [allm[k + 1] - allm[k] for k in range(max(0, i0 - 5), i0)]
+    print("warm-up steps (start to start, us):", [round(x / 1e3, 1) for x in starts])
+if i0 >= 1:
+    a_, b_ = allm[i0 - 1], allm[i0]
+    win = [e for e in ev if a_ <= e[0] < b_]
+    t_end_step = a_ + 800_000
+    late = [e for e in win if e[0] > t_end_step]
+    agg2 = collections.Counter(); dur2 = collections.Counter()
+    for s_, e_, n_, q_ in late: agg2[n_[:70]] += 1; dur2[n_[:70]] += e_ - s_
+    print(f"between the last warm-up step and the timed region: {len(late)} launches, {sum(dur2.values())/1e3:.0f} us of kernels in {(b_ - t_end_step)/1e3:.0f} us")
+    for n_, c_ in agg2.most_common(8): print(f"   x{c_:4d} {dur2[n_]/1e3:9.1f} us  {n_}")
+    if late:
+        gaps_ = sorted(((y[0] - x[1]) / 1e3 for x, y in zip(late, late[1:])), reverse=True)[:5]
+        print("   largest idle gaps in that window (us):", [round(g, 1) for g in gaps_], " first launch", round((late[0][0] - t_end_step) / 1e3, 1), "us after the step")
