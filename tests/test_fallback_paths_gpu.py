@@ -60,7 +60,10 @@ def test_round2_schedules_keep_reference_parity():
     # the dense half of the optimizer step on the main stream (round 2a) / on the side stream but joined by step() itself; a late join in
     # front of the next forward pass's first launch
     # ({"UR_SASREC_STOP_EVENTS": "0"}: every fork of the backward pass by hipEventRecord instead of an event carried by the producing launch)
-    for env in ({"UR_DENSE_ADAM_SIDE": "0"}, {"UR_DENSE_ADAM_SIDE": "join"}, {"UR_SIDE_JOIN_TOP": "1"}, {"UR_SASREC_STOP_EVENTS": "0"}):
+    # ({"UR_SASREC_SAVE_U": "1"}: the forward chain keeps act(h1) for the FFN-2 weight gradient instead of recomputing it there;
+    #  {"UR_SASREC_EARLY_REDUCE": "0"}: every deferred reduction at the end of the pass)
+    for env in ({"UR_DENSE_ADAM_SIDE": "0"}, {"UR_DENSE_ADAM_SIDE": "join"}, {"UR_SIDE_JOIN_TOP": "1"}, {"UR_SASREC_STOP_EVENTS": "0"},
+                {"UR_SASREC_SAVE_U": "1"}, {"UR_SASREC_EARLY_REDUCE": "0"}):
         _run(env, [os.path.join(HERE, "test_trainer_gpu.py"), os.path.join(HERE, "test_catchup_ahead_gpu.py")], expect_min_passed=10)
     for mask in ("0", "63", "1"):
         _run({"UR_SASREC_CHAIN": mask}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_trainer_gpu.py"),

@@ -300,6 +300,13 @@ struct SideCtx {
   bool late_join = false;      // ur_sasrec_side_publish: the next ur_sasrec_fwd joins `done` itself, after its first launch
   bool ok = false;
 };
+// Does the forward chain keep act(h1) ([M, inner]: 44 MB of stores per full layer at C5) for the FFN-2 weight gradient, or does that GEMM
+// (side stream) apply the activation to h1 on the fly?  Default: on the fly -- the stores sat on the forward pass, i.e. on the critical
+// path, the recomputation sits on the side stream (bit-identical; step -2 us).  UR_SASREC_SAVE_U=1: keep it (rounds 1-2a).
+static bool save_u() {
+  static const bool v = getenv("UR_SASREC_SAVE_U") && atoi(getenv("UR_SASREC_SAVE_U")) == 1;
+  return v;
+}
 int g_side_enabled = 1;   // runtime switch (ur_sasrec_set_side_stream)
 SideCtx* side_ctx(bool even_if_disabled = false) {
   if (!g_side_enabled && !even_if_disabled) return nullptr;
@@ -465,7 +472,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       ca.wo = p.wo; ca.bo = p.bo; ca.g1 = p.g1; ca.b1ln = p.b1ln; ca.w1 = p.w1; ca.b1 = p.b1; ca.w2 = p.w2; ca.b2 = p.b2;
       ca.g2 = p.g2; ca.b2ln = p.b2ln;
       ca.a = lw.a; ca.ahat = lw.ahat; ca.rstd1 = lw.rstd1; ca.h1 = lw.h1; ca.y = lw.y; ca.yhat = lw.yhat; ca.rstd2 = lw.rstd2;
-      ca.u = lw.u;
+      ca.u = save_u() ? lw.u : nullptr;
       ca.M = M; ca.m_dev = mv; ca.I = I; ca.act = c.act; ca.eps = c.eps;
       ca.drop_out = site_spec(c, i, DROP_SITE_OUT, tokmap);
       ca.drop_ffn = site_spec(c, i, DROP_SITE_FFN, tokmap);
@@ -525,7 +532,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   const bool chain_bwd = chain_supported(d, I, CHAIN_BWD) && c.p_hidden == 0.f;
   const bool chain_proj = chain_supported(d, I, CHAIN_PROJ) && c.p_hidden == 0.f;
   const bool chain_last_bwd = chain_supported(d, I, CHAIN_LAST_BWD) && c.p_hidden == 0.f;
-  const bool have_u = chain_supported(d, I, CHAIN_FWD);   // the forward pass of the full layers went through chain_ffn_fwd: lw.u is valid
+  const bool have_u = chain_supported(d, I, CHAIN_FWD) && save_u();   // the forward pass of the full layers went through chain_ffn_fwd and kept act(h1): lw.u is valid
   bool ln0_done = false;                // the embedding LayerNorm backward already ran in the epilogue of the bottom layer's last GEMM
   // LayerNorm backward in the epilogue of the GEMM that produces its input gradient (EPI_ADD_LNBWD): the attention block's
   // LayerNorm behind the d FFN-1 GEMM, the embedding LayerNorm behind the bottom layer's projection-gradient GEMM.  Two launches and
