@@ -145,6 +145,9 @@ ProfScope::ProfScope(int cls_, hipStream_t st_, double work) : cls(cls_), st(st_
 ProfScope::~ProfScope() {
   if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
 }
+// is a launch of class `cls` being bracketed right now?  (A launch that carries a fork's completion event, UR_LAUNCH_EV, would have the
+// event's ~5 us inside the bracket: the forks fall back to hipEventRecord while their producers are being timed.)
+bool prof_brackets(int cls) { return g_prof_on && ((g_prof_mask >> cls) & 1u); }
 }  // namespace ur
 
 extern "C" int ur_prof_enable(int on) {

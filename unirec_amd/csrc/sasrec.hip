@@ -570,8 +570,9 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   // launch that is followed by fork() with queued GEMMs and nothing else on the main stream in between.
   static const bool stop_events = !(getenv("UR_SASREC_STOP_EVENTS") && atoi(getenv("UR_SASREC_STOP_EVENTS")) == 0);
   hipEvent_t armed = nullptr;
+  const bool timing_producers = prof_brackets(PC_GEMM_NT) || prof_brackets(PC_ATTN_BWD);   // (their brackets would include the event: see prof_brackets)
   auto arm = [&]() {
-    if (stop_events && sc && n_fork < 24) { armed = sc->ev[n_fork]; g_stop_event = armed; }
+    if (stop_events && !timing_producers && sc && n_fork < 24) { armed = sc->ev[n_fork]; g_stop_event = armed; }
   };
   bool main_done_armed = false, main_done_carried = false;
   auto fork = [&]() -> int {
@@ -678,7 +679,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       g.C = d_emb_rows; g.xhat = w.x0hat; g.rstd = w.rstd0; g.gamma = dense + lay.off[1]; g.out_rows = compact ? w.tok_full : nullptr;
       g.ln_part = lnfuse_part(c.n_layers);
       // the LAST launch of the pass on the main stream: it carries `main_done` (what the side stream's reductions wait for) itself
-      if (stop_events && sc && defer_join && n_fork > 0) { g_stop_event = sc->main_done; main_done_armed = true; }
+      if (stop_events && !timing_producers && sc && defer_join && n_fork > 0) { g_stop_event = sc->main_done; main_done_armed = true; }
       if ((rc2 = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc2;
       main_done_carried = main_done_armed && g_stop_event == nullptr;
       g_stop_event = nullptr;
