@@ -289,7 +289,7 @@ def e2e_leg(a, model, opt, device, steps):
         opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
         opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
         model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
-        opt.step()
+        opt.step(late_join=True)
 
     cur = build(0)
     for k in range(5):
@@ -340,7 +340,7 @@ def other_config(name, device):
         opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
         opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
         model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
-        opt.step()
+        opt.step(late_join=True)
 
     ncls = _lib.lib.ur_prof_num_classes()
     names = [_lib.lib.ur_prof_class_name(i).decode() for i in range(ncls)]
@@ -536,7 +536,7 @@ def main():
                 loss.backward()
             else:   # the trainer's default: the same launches in a straight line, no autograd graph (facility/trainer.py)
                 loss = model.forward_backward(item_id=batch["item_id"], label=batch["label"], item_seq=batch["item_seq"])
-            opt.step()
+            opt.step(late_join=nxt is not None)   # as Trainer.train_step does: the next step's forward pass joins the side-stream half
             return loss
 
     if batches is None:

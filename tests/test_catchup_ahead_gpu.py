@@ -129,7 +129,10 @@ def test_dense_half_on_the_side_stream_is_bit_identical(monkeypatch):
     from unirec_amd.model.sequential.sasrec import SASRec
 
     def run(mode):
-        monkeypatch.setenv("UR_DENSE_ADAM_SIDE", mode)
+        if mode == "per-call":      # no override: step(late_join=True) while another step follows, step() for the last one
+            monkeypatch.delenv("UR_DENSE_ADAM_SIDE", raising=False)
+        else:
+            monkeypatch.setenv("UR_DENSE_ADAM_SIDE", mode)
         torch.manual_seed(7)
         model = SASRec(_cfg(n_items=5000, embedding_size=128, hidden_size=128, inner_size=512, n_heads=16, max_seq_len=50, batch_size=64))
         opt = SparseDenseAdam(model, lr=1e-3, table_mode="lazy_dense")
@@ -150,16 +153,16 @@ def test_dense_half_on_the_side_stream_is_bit_identical(monkeypatch):
             opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
             opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
             losses.append(model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"]))
-            opt.step()
+            opt.step(late_join=k < 11)
             if k in (0, 5):   # read through the public surface right after step(): must be the UPDATED parameters
                 snaps.append(copy.deepcopy({n: t.clone() for n, t in model.state_dict().items()}))
         torch.cuda.synchronize()
-        assert not ops._side_hold or mode == "late"
+        assert not ops._side_hold or mode == "late"       # ("per-call": the last step() joined itself)
         return ([float(x) for x in losses], model.dense_flat.data.clone(), opt.dense_m.clone(), opt.dense_v.clone(),
                 model.item_embedding.weight.data.clone(), snaps)
 
     ref = run("0")
-    for mode in ("join", "late"):
+    for mode in ("join", "late", "per-call"):
         got = run(mode)
         assert got[0] == ref[0], mode
         for a, b in zip(got[1:5], ref[1:5]):

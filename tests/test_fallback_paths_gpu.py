@@ -63,7 +63,12 @@ def test_round2_schedules_keep_reference_parity():
     # ({"UR_SASREC_SAVE_U": "1"}: the forward chain keeps act(h1) for the FFN-2 weight gradient instead of recomputing it there;
     #  {"UR_SASREC_EARLY_REDUCE": "0"}: every deferred reduction at the end of the pass)
     for env in ({"UR_DENSE_ADAM_SIDE": "0"}, {"UR_DENSE_ADAM_SIDE": "join"}, {"UR_SIDE_JOIN_TOP": "1"}, {"UR_SASREC_STOP_EVENTS": "0"},
-                {"UR_SASREC_SAVE_U": "1"}, {"UR_SASREC_EARLY_REDUCE": "0"}):
+                {"UR_SASREC_SAVE_U": "1"}, {"UR_SASREC_EARLY_REDUCE": "0"},
+                # a spin kernel in front of the dense half on the side stream: every window in which the main stream could touch what
+                # the side stream has not finished with is 400 us wide (direct readers of the parameters after step() included)
+                # (not together with UR_DENSE_ADAM_SIDE=late: that override leaves the join to the next forward pass even for the last
+                # step, and these tests read the parameters right after it -- the case step(late_join=False) exists for)
+                {"UR_SIDE_TEST_DELAY_US": "400"}):
         _run(env, [os.path.join(HERE, "test_trainer_gpu.py"), os.path.join(HERE, "test_catchup_ahead_gpu.py")], expect_min_passed=10)
     for mask in ("0", "63", "1"):
         _run({"UR_SASREC_CHAIN": mask}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_trainer_gpu.py"),

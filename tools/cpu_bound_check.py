@@ -32,7 +32,7 @@ def main():
             loss.backward()
         else:
             model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
-        opt.step()
+        opt.step(late_join=True)
 
     for i in range(10):
         step(batches[i % 64], batches[(i + 1) % 64])

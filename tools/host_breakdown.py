@@ -27,7 +27,7 @@ def step(b, nxt, rec):
     opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"]); t.append(time.perf_counter())
     opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"]); t.append(time.perf_counter())
     model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"]); t.append(time.perf_counter())
-    opt.step(); t.append(time.perf_counter())
+    opt.step(late_join=True); t.append(time.perf_counter())
     if rec:
         for i in range(5): acc[i] += t[i + 1] - t[i]
 

@@ -19,7 +19,7 @@ def step(b, nxt):
     opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
     opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
     model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
-    opt.step()
+    opt.step(late_join=True)
 k = 0
 W = int(os.environ.get("W", "5"))
 if mode.startswith("gcfirst"):

@@ -990,8 +990,15 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb)
   if (tb.zero2_ptr && (int)blockIdx.x >= tb.zero2_first_block) {   // riders: zero-fill (the backward's gradient buffers)
     const long long i0 = ((long long)(blockIdx.x - tb.zero2_first_block) * 256 + threadIdx.x) * 16;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (i0 + q * 4 < tb.zero2_n) *(float4*)(tb.zero2_ptr + i0 + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 4; ++q) {
+      const long long e = i0 + q * 4;
+      if (e >= tb.zero2_n) continue;
+      if (tb.zero2_pad) {   // only the padded positions of every sequence: the valid rows are written whole by their producer
+        const long long row = e / tb.zero2_d;
+        if ((int)(row % tb.zero2_L) >= tb.zero2_pad[row / tb.zero2_L]) continue;
+      }
+      *(float4*)(tb.zero2_ptr + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     return;
   }
   if (tb.zero_ptr && (int)blockIdx.x >= tb.zero_first_block) {

@@ -100,6 +100,7 @@ struct TransposeBatch {
   TransposeItem item[MAX]; int n = 0;
   float* zero_ptr = nullptr; long long zero_n = 0; int zero_first_block = 0;   // optional: also zero-fill a buffer (n % 4 == 0)
   float* zero2_ptr = nullptr; long long zero2_n = 0; int zero2_first_block = 0; // ... and a second one
+  const int* zero2_pad = nullptr; int zero2_L = 0, zero2_d = 0;                  // ... of [B, L, d] rows: only rows (b, l < zero2_pad[b]) are zeroed (nullptr: all)
   const int* copy_src = nullptr; int* copy_dst = nullptr;                        // optional rider: one int copied (the backward's own copy of the valid-row count)
   bool add(const float* src, int rows, int cols, float* dst) {
     if (n >= MAX) return false;

@@ -631,7 +631,11 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     TransposeBatch tb;
     if (lay.total % 4 == 0) { tb.zero_ptr = dense_grad; tb.zero_n = lay.total; }
     else UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
-    if (compact) { tb.zero2_ptr = d_emb_rows; tb.zero2_n = (long long)M * d; }   // padded positions: zero gradient rows
+    if (compact) {   // padded positions: zero gradient rows (the valid rows are written whole by the bottom layer's projection-gradient launch)
+      tb.zero2_ptr = d_emb_rows; tb.zero2_n = (long long)M * d;
+      static const bool pad_only = !(getenv("UR_SASREC_ZERO_ALL") && atoi(getenv("UR_SASREC_ZERO_ALL")) == 1);
+      if (pad_only) { tb.zero2_pad = w.seq_pad; tb.zero2_L = c.L; tb.zero2_d = d; }
+    }
     if (mv) { tb.copy_src = mv; tb.copy_dst = w.m_valid + 16; }
     for (int i = 0; i < c.n_layers; ++i) {
       const LayerP p = layer_ptrs(dense, lay, i);
@@ -912,9 +916,18 @@ extern "C" int ur_sasrec_bwd_join(void* stream) {
 // The side stream while a deferred pass is pending (else NULL): what the caller enqueues there runs behind the pass's dense-gradient
 // reductions with no cross-stream wait in between (the dense half of the optimizer step: the main stream's wait for `done` + the launch
 // + the wait's latency were ~30 us at the end of every step during which the main stream did 5 us of work).
+// test aid (UR_SIDE_TEST_DELAY_US): a kernel that spins for that long, put on the side stream in front of whatever the caller enqueues there
+// -- it widens every window in which the main stream could touch what the side stream has not finished with (tools/race_runs.sh)
+__global__ void side_delay_kernel(long long cycles) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+}
 extern "C" void* ur_sasrec_side_stream(void) {
   SideCtx* sc = side_ctx(true);
-  return (sc && sc->join_pending) ? (void*)sc->stream : nullptr;
+  if (!(sc && sc->join_pending)) return nullptr;
+  static const int delay_us = getenv("UR_SIDE_TEST_DELAY_US") ? atoi(getenv("UR_SIDE_TEST_DELAY_US")) : 0;
+  if (delay_us > 0) hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(64), 0, sc->stream, (long long)delay_us * 100);   // wall_clock64: 100 MHz
+  return (void*)sc->stream;
 }
 
 // Marks the end of what the caller added to the side stream: `done` is recorded again.  late != 0: the next ur_sasrec_fwd of this

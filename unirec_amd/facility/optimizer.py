@@ -22,12 +22,12 @@ class SparseDenseAdam:
         """algo: the torch.optim rule the reference's Trainer._build_optimizer would construct (trainer.py:134-152):
         adam (default) / adamw / sgd / adagrad / rmsprop; betas / eps None = torch's defaults for that rule.
 
-        Stream contract (SASRec encoder, no gradient clipping): ``step()`` may return with the dense half of the update still running on
-        the encoder's side stream; the model's next forward pass joins it.  Everything else that reads the dense parameters or this
-        optimizer's dense state through the public surface joins first (``model.state_dict() / load_state_dict() / train() / eval()``,
-        ``optimizer.state_dict() / flush()``); code that reads ``model.dense_flat.data`` or ``dense_m / dense_v`` DIRECTLY right after
-        ``step()`` calls ``model.join_side_updates()`` (or synchronises the device) first.  ``UR_DENSE_ADAM_SIDE=join`` / ``0`` make
-        ``step()`` itself join."""
+        Stream contract (SASRec encoder, no gradient clipping): the dense half of the update runs on the encoder's side stream.
+        ``step()`` makes the current stream wait for it before returning; ``step(late_join=True)`` -- what the training loop passes when
+        another step follows at once -- leaves that to the model's next forward pass.  In that window everything that reads the dense
+        parameters or this optimizer's dense state through the public surface joins first (``model.state_dict() / load_state_dict() /
+        train() / eval()``, ``optimizer.state_dict() / flush()``); code that reads ``model.dense_flat.data`` or ``dense_m / dense_v``
+        directly calls ``model.join_side_updates()`` first.  ``UR_DENSE_ADAM_SIDE=late / join / 0`` overrides the per-call choice."""
         assert table_mode in ("lazy_dense", "rowwise")
         if algo not in ops.OPT_ALGOS:
             raise ValueError(f"unknown optimizer rule {algo!r}")
@@ -65,7 +65,7 @@ class SparseDenseAdam:
         # the dense half of the step on the encoder's side stream, right behind the dense-gradient reductions it waits for (no cross-stream
         # wait in front of it), joined by the next forward pass after its first launch: "late" (default) / "join" (joined at the end of
         # step()) / "0" (round 2a: the main stream waits for the reductions, then runs the dense half itself)
-        self._dense_side = os.environ.get("UR_DENSE_ADAM_SIDE", "late")
+        self._dense_side = os.environ.get("UR_DENSE_ADAM_SIDE", "")      # "" = per call: step(late_join=...) -> "late" / "join"
         self._rewait = os.environ.get("UR_PLAN_REWAIT") == "1"   # tuning aid: plan_batch waits for the plan's event even if this stream already has
         self._filter = os.environ.get("UR_CATCHUP_FILTER", "1") != "0"   # tail catch-up over the next batch's rows WITH history only
         # where the next batch's rows take their missed zero-gradient steps (lazy_dense): "tail" (default) = on the main stream right
@@ -243,8 +243,12 @@ class SparseDenseAdam:
             return ids_a, rows, b[0]["ids_b"].reshape(-1), b[0]["coef"], b[0]["vec"], b[0]["G"]
         return ids_a, rows, None, None, None, 1
 
-    def step(self):
+    def step(self, late_join=False):
+        """late_join=True: the caller enqueues the model's next training forward pass right after this call (the training loop does): the
+        dense half of the update, running on the encoder's side stream, is then joined by that forward pass instead of here.  With the
+        default the current stream has joined when step() returns, and anything enqueued on it afterwards sees the updated parameters."""
         model = self.model
+        dense_side = self._dense_side or ("late" if late_join else "join")
         self.t += 1
         cfg = self._cfg(self.t)
         reduced = {}
@@ -296,7 +300,7 @@ class SparseDenseAdam:
             sparse_done = True
             self._catchup_prefetched(skip=merged)
         side = None
-        if (self.grad_clip is None and self._dense_side in ("late", "join") and getattr(model, "_deferred_dense_grad", None) is not None
+        if (self.grad_clip is None and dense_side in ("late", "join") and getattr(model, "_deferred_dense_grad", None) is not None
                 and model._deferred_dense_grad.numel()):
             side = ops.sasrec_side_stream()
         if side is not None:
@@ -305,7 +309,7 @@ class SparseDenseAdam:
                 ops.dense_adam(cfg, model.dense_flat.data, g, self.dense_m, self.dense_v, scale)
             # (held until the main stream joins: the gradient buffer, and the row gradients the side stream's reductions read -- zero_grad()
             # drops both before the next forward pass, and the plan stream's buffers could land on their memory)
-            ops.sasrec_side_publish(late=self._dense_side == "late", hold=(g,) + tuple(getattr(model, "_deferred_reads", ())))
+            ops.sasrec_side_publish(late=dense_side == "late", hold=(g,) + tuple(getattr(model, "_deferred_reads", ())))
             model.dense_flat.grad = g
             object.__setattr__(model, "_deferred_dense_grad", None)
         model.finish_backward()

@@ -208,7 +208,7 @@ class Trainer(object):
         else:
             loss, _, _, _ = model(**kw)
             loss.backward()
-        opt.step()
+        opt.step(late_join=next_batch is not None)   # (another step follows at once: its forward pass joins the side-stream half of this update)
         return loss.detach()
 
     @staticmethod
