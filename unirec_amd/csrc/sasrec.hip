@@ -307,6 +307,7 @@ static bool save_u() {
   static const bool v = getenv("UR_SASREC_SAVE_U") && atoi(getenv("UR_SASREC_SAVE_U")) == 1;
   return v;
 }
+__global__ void side_delay_kernel(long long cycles);   // test aid, defined next to ur_sasrec_side_stream
 int g_side_enabled = 1;   // runtime switch (ur_sasrec_set_side_stream)
 SideCtx* side_ctx(bool even_if_disabled = false) {
   if (!g_side_enabled && !even_if_disabled) return nullptr;
@@ -588,6 +589,10 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       UR_HIP(hipStreamWaitEvent(sc->stream, sc->ev[n_fork], 0));
       ++n_fork;
       s2 = sc->stream;
+      // test aid (UR_SIDE_TEST_DELAY_US, see ur_sasrec_side_stream): the side stream starts this pass's work that much late, i.e. the
+      // main stream runs that far ahead of everything the side stream still has to read
+      static const int delay_us = getenv("UR_SIDE_TEST_DELAY_US") ? atoi(getenv("UR_SIDE_TEST_DELAY_US")) : 0;
+      if (delay_us > 0 && n_fork == 1) hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(64), 0, s2, (long long)delay_us * 100);
     }
     for (int i = 0; i < n_pend; ++i) {
       const PendingTn& t = pend[i];
