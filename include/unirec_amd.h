@@ -116,6 +116,9 @@ int ur_sasrec_bwd_join(void* stream);
  * end of that work (`done` is recorded again); late != 0: the next ur_sasrec_fwd joins it on its own stream after its first launch
  * (which reads ids only), late == 0 / ur_sasrec_bwd_join: the caller joins explicitly.  Until the join nothing else may read or
  * write what the side-stream work touches. */
+/* Stream `waiter` waits for what has been enqueued on stream `waited` so far (same device); the event in between carries no system-scope
+ * fence.  Plumbing for callers that fork their own side streams (the optimizer's id-plan stream). */
+int ur_stream_wait_stream(void* waiter, void* waited);
 void* ur_sasrec_side_stream(void);
 int ur_sasrec_side_publish(int late);
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     "ur_sasrec_bwd": (C.c_int, [C.POINTER(UrSasrecCfg), P, I64, P, P, P, P, P, P, P]),
     "ur_sasrec_bwd_deferred": (C.c_int, [C.POINTER(UrSasrecCfg), P, I64, P, P, P, P, P, P, P]),
     "ur_sasrec_bwd_join": (C.c_int, [P]),
+    "ur_stream_wait_stream": (C.c_int, [P, P]),
     "ur_sasrec_side_stream": (P, []),
     "ur_sasrec_side_publish": (C.c_int, [C.c_int]),
     "ur_gru_param_layout": (I64, [C.POINTER(UrGruCfg), C.POINTER(I64)]),

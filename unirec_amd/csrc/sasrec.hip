@@ -307,7 +307,12 @@ static bool save_u() {
   static const bool v = getenv("UR_SASREC_SAVE_U") && atoi(getenv("UR_SASREC_SAVE_U")) == 1;
   return v;
 }
-__global__ void side_delay_kernel(long long cycles);   // test aid, defined next to ur_sasrec_side_stream
+// test aid (UR_SIDE_TEST_DELAY_US): a kernel that spins for that long on the side stream -- it widens every window in which the main stream
+// could touch what the side stream has not finished with (tools/race_runs.sh, tests/test_fallback_paths_gpu.py)
+__global__ void side_delay_kernel(long long cycles) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+}
 int g_side_enabled = 1;   // runtime switch (ur_sasrec_set_side_stream)
 SideCtx* side_ctx(bool even_if_disabled = false) {
   if (!g_side_enabled && !even_if_disabled) return nullptr;
@@ -921,12 +926,7 @@ extern "C" int ur_sasrec_bwd_join(void* stream) {
 // The side stream while a deferred pass is pending (else NULL): what the caller enqueues there runs behind the pass's dense-gradient
 // reductions with no cross-stream wait in between (the dense half of the optimizer step: the main stream's wait for `done` + the launch
 // + the wait's latency were ~30 us at the end of every step during which the main stream did 5 us of work).
-// test aid (UR_SIDE_TEST_DELAY_US): a kernel that spins for that long, put on the side stream in front of whatever the caller enqueues there
-// -- it widens every window in which the main stream could touch what the side stream has not finished with (tools/race_runs.sh)
-__global__ void side_delay_kernel(long long cycles) {
-  const long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
-}
+// (UR_SIDE_TEST_DELAY_US: the spin kernel goes in front of whatever the caller enqueues on the side stream)
 extern "C" void* ur_sasrec_side_stream(void) {
   SideCtx* sc = side_ctx(true);
   if (!(sc && sc->join_pending)) return nullptr;
@@ -943,6 +943,21 @@ extern "C" int ur_sasrec_side_publish(int late) {
   if (!sc || !sc->join_pending) return UR_OK;
   UR_HIP(hipEventRecord(sc->done, sc->stream));
   sc->late_join = late != 0;
+  return UR_OK;
+}
+
+// `waiter` waits for everything enqueued on `waited` so far (both streams of the current device), through an event WITHOUT the
+// system-scope fence (see side_ctx): what torch's Stream.wait_stream does with a default event, ~1.5 us cheaper on the recording stream.
+extern "C" int ur_stream_wait_stream(void* waiter, void* waited) {
+  static hipEvent_t ring[16];
+  static int made = 0, next = 0;
+  if (!made) {
+    for (auto& e : ring) UR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    made = 1;
+  }
+  hipEvent_t e = ring[next++ & 15];
+  UR_HIP(hipEventRecord(e, as_stream(waited)));
+  UR_HIP(hipStreamWaitEvent(as_stream(waiter), e, 0));
   return UR_OK;
 }
 

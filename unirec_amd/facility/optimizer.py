@@ -66,6 +66,7 @@ class SparseDenseAdam:
         # wait in front of it), joined by the next forward pass after its first launch: "late" (default) / "join" (joined at the end of
         # step()) / "0" (round 2a: the main stream waits for the reductions, then runs the dense half itself)
         self._dense_side = os.environ.get("UR_DENSE_ADAM_SIDE", "")      # "" = per call: step(late_join=...) -> "late" / "join"
+        self._nofence = os.environ.get("UR_PLAN_FORK_FENCE") != "1"   # the main -> plan-stream fork through an event without the system-scope fence
         self._rewait = os.environ.get("UR_PLAN_REWAIT") == "1"   # tuning aid: plan_batch waits for the plan's event even if this stream already has
         self._filter = os.environ.get("UR_CATCHUP_FILTER", "1") != "0"   # tail catch-up over the next batch's rows WITH history only
         # where the next batch's rows take their missed zero-gradient steps (lazy_dense): "tail" (default) = on the main stream right
@@ -134,7 +135,10 @@ class SparseDenseAdam:
         req = self._plan_inputs(item_seq, item_id, user_id)
         bufs = {name: ops.rows_plan_alloc((a.numel() if a is not None else 0) + (b.numel() if b is not None else 0),
                                           a.numel() if a is not None else 0, self.model.device) for name, (a, b) in req.items()}
-        self._side.wait_stream(main)   # the ids may still be in flight (H2D copy) on the main stream
+        if self._nofence:
+            ops.stream_wait_stream(self._side, main)   # the ids may still be in flight (H2D copy) on the main stream; `last` is being updated there
+        else:
+            self._side.wait_stream(main)
         ahead = None
         with torch.cuda.stream(self._side):
             plans = {name: ops.rows_plan(a, b, self.tables[name]["w"].shape[0], out=bufs[name]) for name, (a, b) in req.items()}

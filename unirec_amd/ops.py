@@ -104,6 +104,11 @@ def sasrec_bwd_join():
     _side_late[0] = False
 
 
+def stream_wait_stream(waiter, waited):
+    """torch's ``waiter.wait_stream(waited)`` through an event without the system-scope fence (ur_stream_wait_stream)."""
+    check(lib.ur_stream_wait_stream(C.c_void_p(waiter.cuda_stream), C.c_void_p(waited.cuda_stream)), "ur_stream_wait_stream")
+
+
 def sasrec_side_stream():
     """The encoder's side stream as a torch stream while a deferred backward is pending (else None): see ur_sasrec_side_stream."""
     p = lib.ur_sasrec_side_stream()

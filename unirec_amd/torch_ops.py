@@ -302,7 +302,7 @@ NOT_OPS = {
     "ur_sasrec_set_side_stream": _SWITCH, "ur_sasrec_set_chain": _SWITCH, "ur_prof_enable": _SWITCH, "ur_prof_set_mask": _SWITCH,
     "ur_prof_reset": _SWITCH, "ur_prof_num_classes": _SWITCH, "ur_prof_class_name": _SWITCH, "ur_prof_read": _SWITCH,
     "ur_gemm_nt": _HOOK, "ur_gemm_tn": _HOOK,
-    "ur_sasrec_bwd_deferred": _PLUMB, "ur_sasrec_bwd_join": _PLUMB, "ur_sasrec_side_stream": _PLUMB, "ur_sasrec_side_publish": _PLUMB,
+    "ur_sasrec_bwd_deferred": _PLUMB, "ur_sasrec_bwd_join": _PLUMB, "ur_stream_wait_stream": _PLUMB, "ur_sasrec_side_stream": _PLUMB, "ur_sasrec_side_publish": _PLUMB,
     "ur_rows_plan_merge": _SHARD, "ur_rows_plan_sharded": _SHARD, "ur_compact_index": _SHARD, "ur_full_rank_shard": _SHARD,
     "ur_sumsq": _FAMILY + " (gradient-clipping helpers of the optimizer)", "ur_clip_coef": _FAMILY + " (gradient-clipping helpers)",
     "ur_clip_coef_guarded": _FAMILY + " (gradient-clipping helpers)",
