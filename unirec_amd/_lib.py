@@ -10,7 +10,8 @@ import torch  # noqa: F401  -- FIRST: the process must use torch's bundled HIP r
 #                              before torch's would put two runtimes in one process ("no ROCm-capable device")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunirec_amd.so")
+_VARIANT = os.environ.get("UR_LIB_VARIANT", "")   # tuning aid: a library built with UR_BUILD_VARIANT (unirec_amd/build.py)
+LIB_PATH = os.path.join(_HERE, f"libunirec_amd{'_' + _VARIANT if _VARIANT not in ('', 'base') else ''}.so")
 
 UR_MAX_LAYERS = 8
 UR_SASREC_N_GLOBAL = 3

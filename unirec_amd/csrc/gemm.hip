@@ -204,6 +204,7 @@ __device__ __forceinline__ void epilogue_from_lds(const float* Cs, int m0, int n
 // FOUR steps ahead.  Same K order, same results.
 template <int BM, int BN, int PRO, int EPI, int BK = 32, int PF = 1, int PIPE = 0>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+  UR_PRIO_MAIN();
   constexpr int LS = BK + 4;            // padded LDS row stride (floats): conflict-free ds_read_b128 for BK = 16 and 32
   constexpr int C4N = BK / 4;           // float4 columns per tile row
   constexpr int RPT = 256 / C4N;        // tile rows covered per pass of the 256 threads
@@ -859,9 +860,15 @@ static int tn_splits(int T, int R, int Cc) {
   return s;
 }
 
+long long gemm_tn_group_ws_floats(int R, int Cc);
+static bool tn_use_group() {   // UR_TN_GROUP=0: the single-product kernel (round 1-2) for every weight-gradient GEMM
+  static const bool v = !(getenv("UR_TN_GROUP") && atoi(getenv("UR_TN_GROUP")) == 0);
+  return v;
+}
+bool gemm_tn_grouped() { return tn_use_group(); }
 long long gemm_tn_ws_floats(int T, int R, int Cc) {
   const int s = tn_splits(T, R, Cc);
-  return (long long)s * R * Cc + (long long)s * R + 64;
+  return std::max((long long)s * R * Cc + (long long)s * R + 64, gemm_tn_group_ws_floats(R, Cc));
 }
 
 // ---- all queued split reductions in one launch.  Block = 16 float4 columns x 16 slices: slice k sums the partials
@@ -913,6 +920,10 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
             int ldo, float* bias_out, float* ws, hipStream_t st, ReduceBatch* defer, const int* t_dev) {
   if ((R & 3) || (Cc & 3) || (ldp & 3) || (ldq & 3) || (ldo & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
   if (T <= 0) return fail(UR_ERR_ARG, "gemm_tn: T=%d", T);
+  if (tn_use_group()) {
+    const TnReq q{P, ldp, Q, ldq, T, R, Cc, pro_act_on_q, act, out, ldo, bias_out, ws, t_dev};
+    return gemm_tn_group(&q, 1, st, defer);
+  }
   ProfScope ps(PC_GEMM_TN, st, 2.0 * T * R * Cc);
   const int S = tn_splits(T, R, Cc);
   int tps = cdiv(T, S);
@@ -960,6 +971,219 @@ int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int 
   hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n / 4 + (bias_out ? R / 4 : 0), 256)), dim3(256), 0, st, part, S, n, Cc, out, ldo,
                      bias_part, R, bias_out);
   UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+// ======================================================================================== gemm_tn_group
+// Several weight-gradient products Out_i[R_i, C_i] = P_i[T_i, R_i]^T pro(Q_i)[T_i, C_i] in ONE launch (round 3).  The single-product
+// kernel above gives every GEMM its own launch and fills the chip by splitting the token dimension ~86 ways: 9-11 launches per backward
+// pass, each workgroup runs 8 LDS stages between a cold prologue and a 64 KB partial-tile store, and the deferred reduction then reads
+// 85-100 MB of partial tiles back (1.77 x the algorithmic HBM bytes; 0.17 of the fp32-MFMA roof in situ).  Here the chip is filled
+// ACROSS products: every (product, 64 x 64 output tile, token split) is one workgroup of a single grid, so a layer's dW_2, dW_1, dW_o
+// (36 tiles) need only 8 token splits -- one per XCD -- for 288 workgroups, each walking ~2 700 tokens (83 stages) per prologue /
+// epilogue; the partial tiles shrink to S x R x C = a few MB per launch, and a product whose T is small (the B last rows) takes S = 1
+// and writes its result (and bias gradient) directly.  The second stage of the split is the deferred ReduceBatch as before (fixed
+// order: bit-reproducible).
+//   workgroup = 4 waves (2 x 2), wave = one 32 x 32 accumulator; stage = 32 tokens x (64 + 64) columns, double buffered (32 KB);
+//   odd token rows are stored with column bit 5 flipped (the two half-waves of a fragment read hit different banks);
+//   out-of-range token rows load a zero row (pointer select, see gemm_tn_kernel); the bias gradient colsum(P) is accumulated from the
+//   staging registers (no LDS reads) by the workgroups of tile column 0.
+constexpr int GT = 64;    // output tile edge
+constexpr int GBT = 32;   // tokens per stage
+struct TnItem {
+  const float *P, *Q; int ldp, ldq;
+  int T; const int* t_dev;       // t_dev (nullable): device-side token count, T = min(T, *t_dev)
+  int R, Cc, pro_act, act;
+  float *part, *bias_part;       // S > 1: [S][R * Cc] and [S][R] (nullable) partial results
+  float *out, *bias_out; int ldo;   // S == 1: the result itself
+  int S, ntr, ntc, first_block;
+};
+struct TnGroup { static constexpr int MAX = 8; TnItem item[MAX]; int n; };
+
+__global__ __launch_bounds__(256) void gemm_tn_group_kernel(TnGroup g, const float* __restrict__ zero_row) {
+  int j = 0;
+  while (j + 1 < g.n && (int)blockIdx.x >= g.item[j + 1].first_block) ++j;
+  const TnItem& it = g.item[j];
+  const int local = blockIdx.x - it.first_block, ntiles = it.ntr * it.ntc, S = it.S;
+  int sp, tile;
+  if ((S & 7) == 0) {   // all tiles of a split on one XCD (first_block % 8 == 0): its token rows enter one L2 only
+    const int xcd = local & 7, qid = local >> 3;
+    sp = (qid / ntiles) * 8 + xcd; tile = qid % ntiles;
+  } else { sp = local % S; tile = local / S; }
+  if (sp >= S || tile >= ntiles) return;
+  int T = it.T;
+  if (it.t_dev) T = min(T, *it.t_dev);
+  const int tps = (((T + S - 1) / S + GBT - 1) / GBT) * GBT;
+  const int t_begin = sp * tps, t_end = min(T, t_begin + tps);
+  const int R = it.R, Cc = it.Cc, ldp = it.ldp, ldq = it.ldq, act = it.act;
+  const bool pro = it.pro_act != 0;
+  const int r0 = (tile / it.ntc) * GT, c0 = (tile % it.ntc) * GT;
+  const bool want_bias = (it.bias_part != nullptr || (S == 1 && it.bias_out != nullptr)) && (tile % it.ntc) == 0;
+
+  __shared__ __attribute__((aligned(16))) float smem[4 * GBT * GT];   // Ps[2][32*64] | Qs[2][32*64]; epilogue: Cs[64][68]
+  float* Ps = smem;
+  float* Qs = smem + 2 * GBT * GT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int c4 = tid & 15, trow = tid >> 4;   // 16 token rows per pass, 2 passes per stage
+  const bool rin = r0 + c4 * 4 < R, cin = c0 + c4 * 4 < Cc;
+  const float* Pp = it.P + (rin ? r0 + c4 * 4 : 0);
+  const float* Qp = it.Q + (cin ? c0 + c4 * 4 : 0);
+  typedef float tfx4 __attribute__((ext_vector_type(4)));
+  tfx4 rp[2], rq[2];
+  tfx4 bs = {0.f, 0.f, 0.f, 0.f};
+  auto load_global = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = t0 + trow + 16 * i;
+      const bool tin = t < t_end;
+      const int tt = max(0, min(t, T - 1));
+      const float* pp = (tin && rin) ? Pp + (long long)t * ldp : zero_row;
+      rp[i] = *(const tfx4*)pp;
+      rq[i] = *(const tfx4*)(cin ? Qp + (long long)tt * ldq : zero_row);
+    }
+  };
+  auto store_lds = [&](int buf) {
+    if (pro) {   // (one wave-uniform switch per stage, not one per element)
+#define UR_ACT8(A_)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int e = 0; e < 4; ++e) rq[i][e] = act_fwd(rq[i][e], A_)
+      switch (act) {
+        case UR_ACT_GELU: UR_ACT8(UR_ACT_GELU); break;
+        case UR_ACT_RELU: UR_ACT8(UR_ACT_RELU); break;
+        case UR_ACT_SWISH: UR_ACT8(UR_ACT_SWISH); break;
+        case UR_ACT_TANH: UR_ACT8(UR_ACT_TANH); break;
+        case UR_ACT_SIGMOID: UR_ACT8(UR_ACT_SIGMOID); break;
+        default: break;
+      }
+#undef UR_ACT8
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = trow + 16 * i;
+      const int col = (c4 * 4) ^ ((row & 1) << 5);
+      *(tfx4*)(Ps + buf * GBT * GT + row * GT + col) = rp[i];
+      bs += rp[i];
+      *(tfx4*)(Qs + buf * GBT * GT + row * GT + col) = rq[i];
+    }
+  };
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nt = (t_end - t_begin + GBT - 1) / GBT;
+  if (nt > 0) {
+    load_global(t_begin);
+    store_lds(0);
+  }
+  __syncthreads();
+  const int fcol = lane & 31, ft = lane >> 5;
+  const int sw = ft << 5;
+  const int pa = ft * GT + ((wr * 32 + fcol) ^ sw), qa = ft * GT + ((wc * 32 + fcol) ^ sw);
+  for (int s_ = 0; s_ < nt; ++s_) {
+    const int buf = s_ & 1;
+    if (s_ + 1 < nt) load_global(t_begin + (s_ + 1) * GBT);
+    const float* Pb = Ps + buf * GBT * GT + pa;
+    const float* Qb = Qs + buf * GBT * GT + qa;
+    constexpr int FD = 4;   // fragments read FD steps ahead of their MFMA
+    float fa[FD], fb[FD];
+#pragma unroll
+    for (int u = 0; u < FD; ++u) { fa[u] = Pb[2 * u * GT]; fb[u] = Qb[2 * u * GT]; }
+#pragma unroll
+    for (int kk = 0; kk < GBT; kk += 2) {
+      const int u = (kk >> 1) % FD;
+      const float a = fa[u], b = fb[u];
+      if (kk + 2 * FD < GBT) { fa[u] = Pb[(kk + 2 * FD) * GT]; fb[u] = Qb[(kk + 2 * FD) * GT]; }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (s_ + 1 < nt) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+  // ---- epilogue through LDS: coalesced float4 row stores of the (partial) tile
+  constexpr int CS = GT + 4;
+  float* Cs = smem;
+  {
+    const int lrow4 = 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Cs[(wr * 32 + (r & 3) + 8 * (r >> 2) + lrow4) * CS + wc * 32 + fcol] = acc[r];
+  }
+  float* Bs = smem + GT * CS;   // [16][64] bias partial sums of the 16 row groups
+  if (want_bias) *(tfx4*)(Bs + trow * GT + c4 * 4) = bs;
+  __syncthreads();
+  const bool direct = S == 1;
+  float* out = direct ? it.out : it.part + (long long)sp * R * Cc;
+  const int ldo = direct ? it.ldo : Cc;
+  {
+    const int c = c0 + c4 * 4;
+    if (c < Cc)
+      for (int rl = trow; rl < GT; rl += 16) {
+        const int rr = r0 + rl;
+        if (rr >= R) break;
+        *(float4*)(out + (long long)rr * ldo + c) = *(const float4*)(Cs + rl * CS + c4 * 4);
+      }
+  }
+  if (want_bias && tid < GT && r0 + tid < R) {
+    float b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) b += Bs[k * GT + tid];
+    if (direct) it.bias_out[r0 + tid] = b;
+    else it.bias_part[(long long)sp * R + r0 + tid] = b;
+  }
+}
+
+constexpr int TN_GROUP_SMAX = 32;
+long long gemm_tn_group_ws_floats(int R, int Cc) { return (long long)TN_GROUP_SMAX * ((long long)R * Cc + R) + 64; }
+
+// req[i].ws: gemm_tn_group_ws_floats(R, Cc) floats each (untouched until the deferred reduction has run).  defer == nullptr: the
+// reduction of the split products runs right behind the launch.
+int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
+  if (n <= 0) return UR_OK;
+  if (n > TnGroup::MAX) return fail(UR_ERR_ARG, "gemm_tn_group: %d products (max %d)", n, TnGroup::MAX);
+  const float* zeros = tn_zero_buf();
+  if (!zeros) return fail(UR_ERR_HIP, "gemm_tn: no device memory for the zero row");
+  static const int target = getenv("UR_TN_BLOCKS") ? atoi(getenv("UR_TN_BLOCKS")) : 288;   // tuning aid: workgroups per launch
+  TnGroup g{};
+  g.n = n;
+  double work = 0.0, flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const TnReq& q = req[i];
+    if ((q.R & 3) || (q.Cc & 3) || (q.ldp & 3) || (q.ldq & 3) || (q.ldo & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
+    if (q.T <= 0) return fail(UR_ERR_ARG, "gemm_tn: T=%d", q.T);
+    work += (double)cdiv(q.R, GT) * cdiv(q.Cc, GT) * q.T;
+    flops += 2.0 * q.T * q.R * q.Cc;
+  }
+  const double rows_per = std::max(128.0, work / target);   // token rows one workgroup walks
+  ProfScope ps(PC_GEMM_TN, st, flops);
+  int blocks = 0;
+  ReduceBatch local;
+  ReduceBatch* rb = defer ? defer : &local;
+  for (int i = 0; i < n; ++i) {
+    const TnReq& q = req[i];
+    TnItem& it = g.item[i];
+    int S = (int)(q.T / rows_per + 0.5);
+    if (S > q.T / (2 * GBT)) S = q.T / (2 * GBT);
+    if (S >= 6) S = std::min(TN_GROUP_SMAX, (S + 4) / 8 * 8);
+    if (S < 1) S = 1;
+    it.P = q.P; it.Q = q.Q; it.ldp = q.ldp; it.ldq = q.ldq; it.T = q.T; it.t_dev = q.t_dev; it.R = q.R; it.Cc = q.Cc;
+    it.pro_act = q.pro_act; it.act = q.act; it.S = S; it.ntr = cdiv(q.R, GT); it.ntc = cdiv(q.Cc, GT);
+    it.out = q.out; it.bias_out = q.bias_out; it.ldo = q.ldo;
+    it.part = q.ws; it.bias_part = q.bias_out ? q.ws + (long long)S * q.R * q.Cc : nullptr;
+    it.first_block = blocks;
+    blocks += (S & 7) == 0 ? S * it.ntr * it.ntc : 8 * cdiv(S * it.ntr * it.ntc, 8);   // (every product starts on XCD 0)
+  }
+  hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g, zeros);
+  UR_LAUNCH_CHECK();
+  for (int i = 0; i < n; ++i) {
+    const TnItem& it = g.item[i];
+    if (it.S == 1) continue;
+    const long long ne = (long long)it.R * it.Cc;
+    if (rb->full(2)) {
+      int rc = reduce_batch(*rb, st);
+      if (rc) return rc;
+    }
+    rb->add(it.part, ne, it.S, ne, it.Cc, it.out, it.ldo);
+    if (it.bias_out) rb->add(it.bias_part, it.R, it.S, it.R, it.R, it.bias_out, it.R);
+  }
+  if (!defer) return reduce_batch(local, st);
   return UR_OK;
 }
 

@@ -92,6 +92,14 @@ long long gemm_tn_ws_floats(int T, int R, int Cc);
 int gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act,
             float* out, int ldo, float* bias_out, float* ws, hipStream_t st, ReduceBatch* defer = nullptr,
             const int* t_dev = nullptr);   // t_dev (nullable): device-side token count, T = min(T, *t_dev)
+// Several such products in ONE launch (gemm_tn_group_kernel): the chip is filled across products, so each needs few token splits.
+struct TnReq {
+  const float* P; int ldp; const float* Q; int ldq; int T, R, Cc, pro_act, act;
+  float* out; int ldo; float* bias_out; float* ws; const int* t_dev;   // ws: gemm_tn_group_ws_floats(R, Cc) floats
+};
+long long gemm_tn_group_ws_floats(int R, int Cc);
+int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer = nullptr);
+bool gemm_tn_grouped();   // the grouped kernel is the weight-gradient path (UR_TN_GROUP=0: the single-product kernel)
 // dst[c,r] = src[r,c]
 int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
 struct TransposeItem { const float* src; float* dst; int rows, cols, first_block; };

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ 
                                                      float4* dx_out, float* __restrict__ part, const int* __restrict__ m_dev,
                                                      const int* __restrict__ out_rows, DropSpec in_drop, DropSpec out_drop,
                                                      float4* __restrict__ dx_drop) {
+  UR_PRIO_MAIN();
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const float inv_d = 1.0f / (float)(d4 * 4);

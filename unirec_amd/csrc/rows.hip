@@ -437,6 +437,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
                                                           long long n, const float4* __restrict__ rows_a, long long n_a,
                                                           const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G,
                                                           int d4, float4* __restrict__ out, int zero_tail, RowsFuse fz = RowsFuse{}) {
+  UR_PRIO_MAIN();
   constexpr int groups = 256 / TPR;
   float fscale = 1.f, bc1 = 1.f, bc2s = 1.f;
   if constexpr (FUSE) {
@@ -848,6 +849,7 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
                                                           long long n_max, const float4* __restrict__ grad, int d4,
                                                           const float* __restrict__ scale_dev, const int* __restrict__ busy_idx = nullptr,
                                                           const int* __restrict__ busy_n_dev = nullptr, int busy_max = 0) {
+  UR_PRIO_MAIN();
   sparse_adam_body<TPR, MODE>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, busy_idx, busy_n_dev, busy_max,
                               (int)blockIdx.x, (int)gridDim.x);
 }

@@ -599,6 +599,15 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       static const int delay_us = getenv("UR_SIDE_TEST_DELAY_US") ? atoi(getenv("UR_SIDE_TEST_DELAY_US")) : 0;
       if (delay_us > 0 && n_fork == 1) hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(64), 0, s2, (long long)delay_us * 100);
     }
+    if (gemm_tn_grouped()) {   // every queued product in ONE launch (gemm_tn_group_kernel): few token splits each, small partial tiles
+      TnReq rq[8];
+      for (int i = 0; i < n_pend; ++i) {
+        const PendingTn& t = pend[i];
+        rq[i] = TnReq{t.P, t.ldp, t.Q, t.ldq, t.T, t.R, t.C, t.pro_act, t.act, t.out, t.ldo, t.bias_out, t.ws, t.t_dev};
+      }
+      int rc2 = gemm_tn_group(rq, n_pend, s2, &rb);
+      if (rc2) return rc2;
+    } else
     for (int i = 0; i < n_pend; ++i) {
       const PendingTn& t = pend[i];
       int rc2 = gemm_tn(t.P, t.ldp, t.Q, t.ldq, t.T, t.R, t.C, t.pro_act, t.act, t.out, t.ldo, t.bias_out, t.ws, s2, &rb, t.t_dev);

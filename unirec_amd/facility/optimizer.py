@@ -128,6 +128,7 @@ class SparseDenseAdam:
         """Sort/unique the ids of the NEXT batch on a side stream, so that the (latency-bound, ~0.15 ms) plan overlaps
         with the current step's forward/backward.  The plan depends on the ids only, never on the model state."""
         main = torch.cuda.current_stream()
+        self._pre_waited = None
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.model.device)
         # every buffer is allocated (and later released) under the MAIN stream; the side stream only fills them.  No
@@ -179,7 +180,8 @@ class SparseDenseAdam:
             cur = torch.cuda.current_stream()
             # (the tail catch-up of the previous step() already made THIS stream wait for THIS event: a second wait is one more barrier
             # packet in front of the forward pass, ~5 us of idle main stream at every step boundary)
-            if self._rewait or getattr(self, "_pre_waited", None) != (id(pre[2]), cur.cuda_stream):
+            pw = getattr(self, "_pre_waited", None)
+            if self._rewait or pw is None or pw[0] is not pre[2] or pw[1] != cur.cuda_stream:
                 cur.wait_event(pre[2])
             self._pre_waited = None
         caught_up = False
@@ -205,7 +207,7 @@ class SparseDenseAdam:
             return
         cur = torch.cuda.current_stream()
         cur.wait_event(pre[2])
-        self._pre_waited = (id(pre[2]), cur.cuda_stream)
+        self._pre_waited = (pre[2], cur.cuda_stream)   # (the event object itself: an id() could be re-used by the next plan's event)
         cfg = self._cfg(self.t + 1)
         for name, pl in pre[1].items():
             st = self.tables[name]
@@ -313,7 +315,10 @@ class SparseDenseAdam:
                 ops.dense_adam(cfg, model.dense_flat.data, g, self.dense_m, self.dense_v, scale)
             # (held until the main stream joins: the gradient buffer, and the row gradients the side stream's reductions read -- zero_grad()
             # drops both before the next forward pass, and the plan stream's buffers could land on their memory)
-            ops.sasrec_side_publish(late=dense_side == "late", hold=(g,) + tuple(getattr(model, "_deferred_reads", ())))
+            # the guard / gradient scale is a view of the step's loss buffer: the side stream reads it too, so it is held as well (a
+            # caller that drops the returned loss would otherwise hand that block back to the main stream's allocator under the read)
+            ops.sasrec_side_publish(late=dense_side == "late",
+                                    hold=(g,) + ((scale,) if scale is not None else ()) + tuple(getattr(model, "_deferred_reads", ())))
             model.dense_flat.grad = g
             object.__setattr__(model, "_deferred_dense_grad", None)
         model.finish_backward()

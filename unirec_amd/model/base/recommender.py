@@ -241,7 +241,10 @@ class BaseRecommender(AbstractRecommender):
         return super().load_state_dict(*args, **kwargs)
 
     def train(self, mode=True):
-        self.join_side_updates()
+        # (train() reads no parameter: a call that leaves the mode as it is -- the training loop's, at the head of every step -- must not
+        # take the late join away from the forward pass that hides it)
+        if bool(mode) != self.training:
+            self.join_side_updates()
         return super().train(mode)
 
     def finish_backward(self):
