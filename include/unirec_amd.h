@@ -296,10 +296,38 @@ int ur_rows_plan_merge(const int32_t* ids, int64_t n, const int32_t* host_run_st
 int ur_rows_plan_sharded(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
                          int32_t world, int32_t* uniq_key, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev,
                          int32_t* owner_counts_dev, void* ws, void* stream);
+/* ---- row exchange of the row-sharded tables: SURVEY.md 8b `a2a_embedding_exchange(...)` / 8e.  Replaces what DDP does for the embedding
+ * table in the reference (unirec/facility/trainer.py:67,261: accelerator.prepare -> DDP; :346 accelerator.backward all-reduces the dense
+ * [N, d] gradient): rows travel instead of tables.  FIXED CAPACITY: every (source, owner) pair carries exactly `cap` slots in all three
+ * exchanges of a step, so no count exchange and no host synchronisation exist; slot q = owner * cap + p of a rank's block holds its
+ * requests for that owner right-aligned behind padding slots that ask for local row 0.  transport != 0: the packed block is moved by
+ * the library's RCCL communicator (ur_comm_init) on `stream`; transport == 0: pack / unpack only, the caller moves the block itself
+ * (torch.distributed over gloo in the CPU-staged tests).
+ *   ur_shard_exchange_ids : plan keys (ur_rows_plan_sharded: uniq_key, n_uniq_dev, owner counts) -> send_ids[world*cap] (+ the maps
+ *                           slot_of_uniq[u] / u_of_slot[q], -1 for padding) -> recv_ids[world*cap]; flags_dev[0] |= 1 if a count > cap
+ *   ur_shard_exchange_rows: rows_ws[q,:] = table[req_ids[q],:] (this rank's shard) -> compact[world*cap, d] on the requesters
+ *   ur_shard_exchange_grads: uniq_grad[n_uniq,d] -> slot layout (padding: zeros) in send_ws -> grads_in[world*cap, d] on the owners */
+int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_uniq_dev, const int32_t* counts_dev, int64_t n_local,
+                          int32_t world, int32_t cap, int32_t* send_ids, int32_t* slot_of_uniq, int32_t* u_of_slot,
+                          int32_t* flags_dev, int32_t* recv_ids, int32_t transport, void* stream);
+int ur_shard_exchange_rows(const float* table, const int32_t* req_ids, int32_t world, int32_t cap, int32_t d, float* rows_ws,
+                           float* compact, int32_t transport, void* stream);
+int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_of_slot, int32_t world, int32_t cap, int32_t d,
+                            float* send_ws, float* grads_in, int32_t transport, void* stream);
+/* The library's RCCL communicator (one per process, one process per GPU; RCCL is resolved at run time from the librccl.so.1 the process has
+ * loaded).  ur_comm_world: -1 no RCCL library, 0 not initialised, else the communicator's size.  ur_comm_unique_id: 128 bytes made on
+ * rank 0 and handed to every rank's ur_comm_init by the host (a broadcast over its process group).  ur_comm_all_reduce_sum: in place,
+ * fp32 -- the flat dense-gradient all-reduce of the step (what DDP's bucketed all-reduce does, trainer.py:346), on `stream`. */
+int ur_comm_world(void);
+int ur_comm_unique_id(void* id_out128);
+int ur_comm_init(const void* id128, int32_t rank, int32_t world);
+int ur_comm_destroy(void);
+int ur_comm_all_reduce_sum(float* buf, int64_t n, void* stream);
 /* idx_a[p] (p < n_a) / idx_b[p - n_a] = u for every lookup position p in the run of unique key u: the batch's
- * lookups re-expressed as indices into the compact [n_uniq, d] table of fetched rows. */
+ * lookups re-expressed as indices into the compact [n_uniq, d] table of fetched rows; slot_of_uniq (nullable, from
+ * ur_shard_exchange_ids): the index is slot_of_uniq[u] instead -- the row of the fixed-capacity [world * cap, d] table. */
 int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n, int64_t n_a,
-                     int32_t* idx_a, int64_t* idx_b, void* stream);
+                     const int32_t* slot_of_uniq, int32_t* idx_a, int64_t* idx_b, void* stream);
 /* uniq_grad[u,:] = sum over the run of uniq_idx[u] (in sorted, i.e. position, order) of
  *   rows_a[p,:]                      for p <  n_a
  *   coef_b[p-n_a] * vec_b[(p-n_a)/G,:] for p >= n_a     (the scorer's implicit candidate-row gradient)

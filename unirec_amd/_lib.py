@@ -84,7 +84,15 @@ SIGNATURES = {
     "ur_rows_plan": (C.c_int, [P, I64, P, I64, I64, P, P, P, P, P, P]),
     "ur_rows_plan_merge": (C.c_int, [P, I64, P, I32, P, P, P, P, P, P]),
     "ur_rows_plan_sharded": (C.c_int, [P, I64, P, I64, I64, I32, P, P, P, P, P, P, P]),
-    "ur_compact_index": (C.c_int, [P, P, P, I64, I64, P, P, P]),
+    "ur_compact_index": (C.c_int, [P, P, P, I64, I64, P, P, P, P]),
+    "ur_shard_exchange_ids": (C.c_int, [P, P, P, I64, I32, I32, P, P, P, P, P, I32, P]),
+    "ur_shard_exchange_rows": (C.c_int, [P, P, I32, I32, I32, P, P, I32, P]),
+    "ur_shard_exchange_grads": (C.c_int, [P, P, I32, I32, I32, P, P, I32, P]),
+    "ur_comm_world": (C.c_int, []),
+    "ur_comm_unique_id": (C.c_int, [P]),
+    "ur_comm_init": (C.c_int, [P, I32, I32]),
+    "ur_comm_destroy": (C.c_int, []),
+    "ur_comm_all_reduce_sum": (C.c_int, [P, I64, P]),
     "ur_rows_reduce": (C.c_int, [P, P, P, P, I64, P, I64, P, P, I32, I32, P, P, P]),
     "ur_rows_reduce_adam": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, P, P, I64, P, I64, P, P, I32, I32, P, P]),
     "ur_dense_adam": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, P, P]),

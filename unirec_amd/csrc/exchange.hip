@@ -1,0 +1,222 @@
+// Row exchange of the row-sharded embedding tables (SURVEY.md 8b `a2a_embedding_exchange`, 8e): fixed-capacity pack / unpack kernels and
+// the RCCL transport on the caller's stream.
+//
+// Not in the reference (its only multi-GPU strategy is DDP over a replicated table, unirec/facility/trainer.py:67,261,346-349).  Here row i
+// lives on rank i % W; a step moves (1) the batch's unique row ids to their owners, (2) the rows back, (3) the row gradients to the owners.
+// Every (source, destination) pair carries EXACTLY `cap` slots in all three exchanges, so the split sizes are compile-time constants of
+// the step: no per-step count exchange, no host synchronisation, every buffer preallocated.  A rank's block for owner o holds its
+// count[o] requests right-aligned -- slots [o * cap + cap - count[o], (o + 1) * cap) -- behind padding slots that ask for local row 0 (the
+// padding row of every shard: gathers zeros, never updated), so each block stays ascending (what the owner's W-way merge plan needs).
+// A count above `cap` raises a device flag that rides in the step's flat all-reduce: every rank then skips the update (as for a NaN loss)
+// and the host, which reads the flag a step later, doubles the capacity and trains the batch again.
+//
+// Transport: the library owns one RCCL communicator per process (ur_comm_init; the unique id travels through the host's process group
+// once) and issues ncclSend / ncclRecv groups on the stream it is given.  RCCL is resolved at run time from the librccl.so.1 the process
+// has already loaded (torch's): nothing is linked, and a host without RCCL still loads the library (the gloo route of the tests).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ur {
+
+// slot q = o * cap + p of the send block:  pad = cap - min(cap, count[o]);  p < pad: padding (local row 0), else the (p - pad)-th key of owner o
+__global__ __launch_bounds__(256) void shard_pack_kernel(const int* __restrict__ uniq_key, const int* __restrict__ n_uniq_dev,
+                                                         const int* __restrict__ counts, long long n_local, int W, int cap,
+                                                         int* __restrict__ send_ids, int* __restrict__ slot_of_uniq,
+                                                         int* __restrict__ u_of_slot, int* __restrict__ flags) {
+  __shared__ int pre[65];
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int o = 0; o < W; ++o) { pre[o] = s; s += counts[o]; }
+    pre[W] = s;
+  }
+  __syncthreads();
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= W * cap) return;
+  const int o = q / cap, p = q % cap;
+  const int cnt = pre[o + 1] - pre[o];
+  if (p == 0 && cnt > cap) atomicOr(flags, 1);   // overflow: the rows beyond the capacity are cut (the step is skipped, see the header)
+  const int pad = cap - min(cap, cnt);
+  if (p < pad) {
+    send_ids[q] = 0;
+    u_of_slot[q] = -1;
+    return;
+  }
+  const int u = pre[o] + (p - pad);
+  const unsigned key = (unsigned)uniq_key[u];
+  const int local = W > 1 ? (int)(key % (unsigned long long)n_local) : (int)key;
+  send_ids[q] = local;
+  // key 0 (the padding id) reads compact row 0 whatever its slot: slot 0 belongs to owner 0 and asks for local row 0 either as padding
+  // or as this very key (count[0] == cap)
+  const bool is_pad_id = key == 0u;
+  slot_of_uniq[u] = is_pad_id ? 0 : q;
+  u_of_slot[q] = is_pad_id ? -1 : u;
+}
+
+// out[q, :] = u_of_slot[q] >= 0 ? rows[u_of_slot[q], :] : 0      (unique-order rows -> the fixed-capacity slot layout)
+__global__ __launch_bounds__(256) void shard_scatter_rows_kernel(const float4* __restrict__ rows, const int* __restrict__ u_of_slot,
+                                                                 long long n_slots, int d4, float4* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_slots * d4) return;
+  const long long q = i / d4;
+  const int c = (int)(i % d4);
+  const int u = u_of_slot[q];
+  out[i] = u >= 0 ? rows[(long long)u * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---- RCCL, resolved from the already-loaded library
+namespace {
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+Rccl* rccl() {
+  static Rccl* r = []() -> Rccl* {
+    Rccl* x = new Rccl();
+    x->h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!x->h) x->h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!x->h) return x;
+#define UR_SYM(field, name) x->field = reinterpret_cast<decltype(x->field)>(dlsym(x->h, name))
+    UR_SYM(GetUniqueId, "ncclGetUniqueId"); UR_SYM(CommInitRank, "ncclCommInitRank"); UR_SYM(CommDestroy, "ncclCommDestroy");
+    UR_SYM(GroupStart, "ncclGroupStart"); UR_SYM(GroupEnd, "ncclGroupEnd"); UR_SYM(Send, "ncclSend"); UR_SYM(Recv, "ncclRecv");
+    UR_SYM(AllReduce, "ncclAllReduce"); UR_SYM(GetErrorString, "ncclGetErrorString");
+#undef UR_SYM
+    x->ok = x->GetUniqueId && x->CommInitRank && x->CommDestroy && x->GroupStart && x->GroupEnd && x->Send && x->Recv && x->AllReduce &&
+            x->GetErrorString;
+    return x;
+  }();
+  return r;
+}
+struct Comm { ncclComm_t comm = nullptr; int rank = 0, world = 0; };
+Comm g_comm;
+}  // namespace
+
+#define UR_NCCL(expr)                                                                                            \
+  do {                                                                                                           \
+    ncclResult_t _r = (expr);                                                                                    \
+    if (_r != ncclSuccess) return ::ur::fail(UR_ERR_HIP, "%s failed: %s", #expr, rccl()->GetErrorString(_r));    \
+  } while (0)
+
+// equal-split all-to-all: `bytes` per peer, block p of `send` -> rank p, block p of `recv` <- rank p
+static int a2a_bytes(const void* send, void* recv, size_t bytes, hipStream_t st) {
+  Rccl* r = rccl();
+  const int W = g_comm.world;
+  UR_NCCL(r->GroupStart());
+  for (int p = 0; p < W; ++p) {
+    UR_NCCL(r->Send((const char*)send + (size_t)p * bytes, bytes, ncclInt8, p, g_comm.comm, st));
+    UR_NCCL(r->Recv((char*)recv + (size_t)p * bytes, bytes, ncclInt8, p, g_comm.comm, st));
+  }
+  UR_NCCL(r->GroupEnd());
+  return UR_OK;
+}
+
+}  // namespace ur
+
+using namespace ur;
+
+extern "C" int ur_comm_unique_id(void* id_out) {
+  UR_REQUIRE(id_out, UR_ERR_ARG, "ur_comm_unique_id: null pointer");
+  UR_REQUIRE(rccl()->ok, UR_ERR_UNSUPPORTED, "ur_comm_unique_id: no RCCL library in this process");
+  ncclUniqueId id;
+  UR_NCCL(rccl()->GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return UR_OK;
+}
+
+extern "C" int ur_comm_init(const void* id, int32_t rank, int32_t world) {
+  UR_REQUIRE(id && world >= 1 && rank >= 0 && rank < world, UR_ERR_ARG, "ur_comm_init: rank %d of %d", rank, world);
+  UR_REQUIRE(rccl()->ok, UR_ERR_UNSUPPORTED, "ur_comm_init: no RCCL library in this process");
+  if (g_comm.comm) {
+    UR_REQUIRE(g_comm.rank == rank && g_comm.world == world, UR_ERR_ARG, "ur_comm_init: already initialised as rank %d of %d",
+               g_comm.rank, g_comm.world);
+    return UR_OK;
+  }
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  UR_NCCL(rccl()->CommInitRank(&g_comm.comm, world, uid, rank));
+  g_comm.rank = rank;
+  g_comm.world = world;
+  return UR_OK;
+}
+
+extern "C" int ur_comm_world(void) { return !rccl()->ok ? -1 : (g_comm.comm ? g_comm.world : 0); }
+
+extern "C" int ur_comm_destroy(void) {
+  if (g_comm.comm) {
+    UR_NCCL(rccl()->CommDestroy(g_comm.comm));
+    g_comm = Comm{};
+  }
+  return UR_OK;
+}
+
+extern "C" int ur_comm_all_reduce_sum(float* buf, int64_t n, void* stream) {
+  UR_REQUIRE(buf && n > 0, UR_ERR_ARG, "ur_comm_all_reduce_sum: bad argument");
+  UR_REQUIRE(g_comm.comm, UR_ERR_ARG, "ur_comm_all_reduce_sum: no communicator (ur_comm_init)");
+  UR_NCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, g_comm.comm, as_stream(stream)));
+  return UR_OK;
+}
+
+// (1) ids: pack the plan's unique keys into the fixed-capacity send block, then (communicator up) all-to-all into recv_ids.
+// transport == 0: pack only -- the caller moves send_ids itself (the gloo route of the CPU-staged tests).
+extern "C" int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_uniq_dev, const int32_t* counts_dev, int64_t n_local,
+                                     int32_t world, int32_t cap, int32_t* send_ids, int32_t* slot_of_uniq, int32_t* u_of_slot,
+                                     int32_t* flags_dev, int32_t* recv_ids, int32_t transport, void* stream) {
+  UR_REQUIRE(uniq_key && n_uniq_dev && counts_dev && send_ids && slot_of_uniq && u_of_slot && flags_dev, UR_ERR_ARG,
+             "ur_shard_exchange_ids: null pointer");
+  UR_REQUIRE(world >= 1 && world <= 64 && cap > 0 && (long long)world * cap < (1LL << 31), UR_ERR_ARG,
+             "ur_shard_exchange_ids: world=%d cap=%d", world, cap);
+  hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_SORT, st, (double)world * cap * 12.0);
+  hipLaunchKernelGGL(shard_pack_kernel, dim3(cdiv((long long)world * cap, 256)), dim3(256), 0, st, uniq_key, n_uniq_dev, counts_dev,
+                     (long long)n_local, world, cap, send_ids, slot_of_uniq, u_of_slot, flags_dev);
+  UR_LAUNCH_CHECK();
+  if (!transport) return UR_OK;
+  UR_REQUIRE(recv_ids, UR_ERR_ARG, "ur_shard_exchange_ids: null receive buffer");
+  UR_REQUIRE(g_comm.comm && g_comm.world == world, UR_ERR_ARG, "ur_shard_exchange_ids: communicator of %d ranks, world=%d", g_comm.world, world);
+  return a2a_bytes(send_ids, recv_ids, (size_t)cap * sizeof(int32_t), st);
+}
+
+// (2) rows: gather the requested rows of this rank's shard (req_ids: world * cap local rows, as received) into rows_ws, then
+// all-to-all into compact [world * cap, d]: row q of `compact` is the row slot q of ur_shard_exchange_ids asked for.
+extern "C" int ur_shard_exchange_rows(const float* table, const int32_t* req_ids, int32_t world, int32_t cap, int32_t d, float* rows_ws,
+                                      float* compact, int32_t transport, void* stream) {
+  UR_REQUIRE(table && req_ids && rows_ws, UR_ERR_ARG, "ur_shard_exchange_rows: null pointer");
+  UR_REQUIRE(world >= 1 && cap > 0 && d > 0 && d % 4 == 0, UR_ERR_ARG, "ur_shard_exchange_rows: world=%d cap=%d d=%d", world, cap, d);
+  hipStream_t st = as_stream(stream);
+  int rc = gather_rows(table, req_ids, 4, (long long)world * cap, d, rows_ws, st);
+  if (rc || !transport) return rc;
+  UR_REQUIRE(compact, UR_ERR_ARG, "ur_shard_exchange_rows: null receive buffer");
+  UR_REQUIRE(g_comm.comm && g_comm.world == world, UR_ERR_ARG, "ur_shard_exchange_rows: communicator of %d ranks, world=%d", g_comm.world, world);
+  return a2a_bytes(rows_ws, compact, (size_t)cap * d * sizeof(float), st);
+}
+
+// (3) row gradients: uniq_grad [n_uniq, d] (unique order, from ur_rows_reduce) -> slot layout (padding slots: zeros) in send_ws, then
+// all-to-all into grads_in [world * cap, d] on the owners (block s = what rank s sends: summed in source-rank order by the owner's plan).
+extern "C" int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_of_slot, int32_t world, int32_t cap, int32_t d,
+                                       float* send_ws, float* grads_in, int32_t transport, void* stream) {
+  UR_REQUIRE(uniq_grad && u_of_slot && send_ws, UR_ERR_ARG, "ur_shard_exchange_grads: null pointer");
+  UR_REQUIRE(world >= 1 && cap > 0 && d > 0 && d % 4 == 0, UR_ERR_ARG, "ur_shard_exchange_grads: world=%d cap=%d d=%d", world, cap, d);
+  hipStream_t st = as_stream(stream);
+  const long long n_slots = (long long)world * cap;
+  {
+    ProfScope ps(PC_REDUCE, st, (double)n_slots * d * 8.0);
+    hipLaunchKernelGGL(shard_scatter_rows_kernel, dim3(cdiv(n_slots * (d / 4), 256)), dim3(256), 0, st, (const float4*)uniq_grad, u_of_slot,
+                       n_slots, d / 4, (float4*)send_ws);
+    UR_LAUNCH_CHECK();
+  }
+  if (!transport) return UR_OK;
+  UR_REQUIRE(grads_in, UR_ERR_ARG, "ur_shard_exchange_grads: null receive buffer");
+  UR_REQUIRE(g_comm.comm && g_comm.world == world, UR_ERR_ARG, "ur_shard_exchange_grads: communicator of %d ranks, world=%d", g_comm.world, world);
+  return a2a_bytes(send_ws, grads_in, (size_t)cap * d * sizeof(float), st);
+}

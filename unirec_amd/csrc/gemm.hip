@@ -998,7 +998,7 @@ struct TnItem {
   float *out, *bias_out; int ldo;   // S == 1: the result itself
   int S, ntr, ntc, first_block;
 };
-struct TnGroup { static constexpr int MAX = 8; TnItem item[MAX]; int n; };
+struct TnGroup { static constexpr int MAX = 12; TnItem item[MAX]; int n; };
 
 __global__ __launch_bounds__(256) void gemm_tn_group_kernel(TnGroup g, const float* __restrict__ zero_row) {
   int j = 0;
@@ -1140,7 +1140,7 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
   if (n > TnGroup::MAX) return fail(UR_ERR_ARG, "gemm_tn_group: %d products (max %d)", n, TnGroup::MAX);
   const float* zeros = tn_zero_buf();
   if (!zeros) return fail(UR_ERR_HIP, "gemm_tn: no device memory for the zero row");
-  static const int target = getenv("UR_TN_BLOCKS") ? atoi(getenv("UR_TN_BLOCKS")) : 288;   // tuning aid: workgroups per launch
+  static const int target = getenv("UR_TN_BLOCKS") ? atoi(getenv("UR_TN_BLOCKS")) : 864;   // tuning aid: workgroups per launch
   TnGroup g{};
   g.n = n;
   double work = 0.0, flops = 0.0;
@@ -1170,7 +1170,16 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
     it.first_block = blocks;
     blocks += (S & 7) == 0 ? S * it.ntr * it.ntc : 8 * cdiv(S * it.ntr * it.ntc, 8);   // (every product starts on XCD 0)
   }
-  hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g, zeros);
+  // (tuning aid, UR_TN_LDS_KB: workgroup LDS footprint in KB -- reserved, unused bytes beyond the kernel's own 32 KB decide how many of
+  // its workgroups fit on a CU next to the main stream's kernels)
+  static const int lds_kb = getenv("UR_TN_LDS_KB") ? atoi(getenv("UR_TN_LDS_KB")) : 0;
+  const size_t extra = lds_kb > 32 ? (size_t)(lds_kb - 32) * 1024 : 0;
+  static bool attr_set = false;
+  if (extra && !attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)extra);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), extra, st, g, zeros);
   UR_LAUNCH_CHECK();
   for (int i = 0; i < n; ++i) {
     const TnItem& it = g.item[i];

@@ -1268,7 +1268,8 @@ extern "C" int ur_rows_plan_sharded(const int32_t* ids_a, int64_t n_a, const int
 // segment -- 17 % of all positions at ML-25M-shaped data -- to one lane group, a 100-us serial walk)
 __global__ __launch_bounds__(256) void compact_index_kernel(const int* __restrict__ seg_start, const int* __restrict__ sorted_pos,
                                                             const int* __restrict__ n_uniq_dev, long long n, long long n_a,
-                                                            int* __restrict__ idx_a, long long* __restrict__ idx_b) {
+                                                            const int* __restrict__ slot, int* __restrict__ idx_a,
+                                                            long long* __restrict__ idx_b) {
   const int n_uniq = *n_uniq_dev;
   const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
   if (q >= n || n_uniq <= 0 || q >= seg_start[n_uniq]) return;
@@ -1278,18 +1279,19 @@ __global__ __launch_bounds__(256) void compact_index_kernel(const int* __restric
     if (seg_start[mid] <= q) lo = mid; else hi = mid;
   }
   const long long p = sorted_pos[q];
+  if (slot) lo = slot[lo];   // (fixed-capacity exchange: the row of the [world * cap, d] table, see ur_shard_exchange_ids)
   if (p < n_a) idx_a[p] = lo;
   else idx_b[p - n_a] = lo;
 }
 
 extern "C" int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n,
-                                int64_t n_a, int32_t* idx_a, int64_t* idx_b, void* stream) {
+                                int64_t n_a, const int32_t* slot_of_uniq, int32_t* idx_a, int64_t* idx_b, void* stream) {
   UR_REQUIRE(seg_start && sorted_pos && n_uniq_dev && n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_compact_index: bad argument");
   UR_REQUIRE((idx_a || n_a == 0) && (idx_b || n_a == n), UR_ERR_ARG, "ur_compact_index: null output");
   UR_REQUIRE(n < (1LL << 31), UR_ERR_UNSUPPORTED, "ur_compact_index: n=%lld", (long long)n);
   const int blocks = cdiv(n, 256);
   hipLaunchKernelGGL(compact_index_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), seg_start, sorted_pos, n_uniq_dev,
-                     (long long)n, (long long)n_a, idx_a, (long long*)idx_b);
+                     (long long)n, (long long)n_a, slot_of_uniq, idx_a, (long long*)idx_b);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

@@ -567,13 +567,16 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   SideCtx* sc = (c.n_layers <= 2) ? side_ctx() : nullptr;   // the queue of deferred reductions must not flush mid-pass
   int n_fork = 0;
   struct PendingTn { const float *P, *Q; int ldp, ldq, T, R, C, pro_act, act, ldo; float *out, *bias_out, *ws; const int* t_dev; };
-  PendingTn pend[8];
+  PendingTn pend[12];
   int n_pend = 0;
   // launch the queued weight-gradient GEMMs: on the side stream behind ONE event of the main stream (every queued GEMM's
   // inputs are complete at the point of the main stream where fork() is called), or in line when there is no side stream
   // arm(): the next gemm_nt / attention launch of the main stream carries the next fork's event as its own completion event
   // (UR_LAUNCH_EV) -- the fork behind it then needs no hipEventRecord (a marker packet = ~5 us of idle main stream).  Only in front of a
   // launch that is followed by fork() with queued GEMMs and nothing else on the main stream in between.
+  // which forks are held back (tuning aid, UR_SASREC_HOLD bit mask): 1 = the top (last-row) layer's products wait for the next fork,
+  // 2 = a full layer's dW_2 / dW_1 / dW_o wait for its dW_qkv (one launch behind the attention backward instead of one beside it)
+  static const int hold = getenv("UR_SASREC_HOLD") ? atoi(getenv("UR_SASREC_HOLD")) : 2;
   static const bool stop_events = !(getenv("UR_SASREC_STOP_EVENTS") && atoi(getenv("UR_SASREC_STOP_EVENTS")) == 0);
   hipEvent_t armed = nullptr;
   const bool timing_producers = prof_brackets(PC_GEMM_NT) || prof_brackets(PC_ATTN_BWD);   // (their brackets would include the event: see prof_brackets)
@@ -600,7 +603,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       if (delay_us > 0 && n_fork == 1) hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(64), 0, s2, (long long)delay_us * 100);
     }
     if (gemm_tn_grouped()) {   // every queued product in ONE launch (gemm_tn_group_kernel): few token splits each, small partial tiles
-      TnReq rq[8];
+      TnReq rq[12];
       for (int i = 0; i < n_pend; ++i) {
         const PendingTn& t = pend[i];
         rq[i] = TnReq{t.P, t.ldp, t.Q, t.ldq, t.T, t.R, t.C, t.pro_act, t.act, t.out, t.ldo, t.bias_out, t.ws, t.t_dev};
@@ -628,7 +631,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   };
   auto tn = [&](const float* P, int ldp, const float* Q, int ldq, int T_, int R_, int C_, int pro_act, int act, float* out, int ldo,
                 float* bias_out) -> int {
-    if (n_pend == 8) {
+    if (n_pend == 12) {
       int rc2 = fork();
       if (rc2) return rc2;
     }
@@ -779,12 +782,12 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
       }
-      arm();
+      if (!(hold & 1)) arm();
       if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, lw.g_qkv, st, sbase, spad, &d_attn))) return rc;
       // dWq from the B last rows, dWk/dWv from all rows
       if ((rc = tn(w.dq_last, d, compact ? w.x_last : x_in + (long long)(c.L - 1) * d, compact ? d : c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
       if ((rc = tn(lw.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4]))) return rc;
-      if ((rc = fork())) return rc;
+      if (!(hold & 1) && (rc = fork())) return rc;
       g = GemmArgs{};   // g_x = [dK dV] Wkv  for every row
       g.A = lw.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = 2 * d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
@@ -822,7 +825,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
         return rc;
       if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
       if ((rc = tn(lw.g_ta, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
-      if ((rc = fork())) return rc;
+      if (!(hold & 2) && (rc = fork())) return rc;
       if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad, &d_attn))) return rc;
       if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
       if ((rc = fork())) return rc;
@@ -840,16 +843,20 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     GemmArgs g{};
     g.A = lw.g_tfd; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = M; g.m_dev = mv; g.N = I; g.K = d;
     g.aux = lw.h1; g.ldaux = I; g.act = c.act;
+    // dW_2 and dW_1 are forked right behind this GEMM (round 3): they run beside the d FFN-1 and out-projection GEMMs and are done before
+    // the attention backward starts; dW_o waits for dW_qkv (`hold`): the attention backward, which loses most beside a weight-gradient
+    // launch (116 us against 49 alone), has the chip to itself.  UR_SASREC_EARLY_FORK=0: dW_2, dW_1, dW_o together behind the next GEMM
+    static const bool early_fork = !(getenv("UR_SASREC_EARLY_FORK") && atoi(getenv("UR_SASREC_EARLY_FORK")) == 0);
+    if (early_fork) arm();
     if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
     if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
-    static const bool early_fork = getenv("UR_SASREC_EARLY_FORK") && atoi(getenv("UR_SASREC_EARLY_FORK"));
     if (early_fork && (rc = fork())) return rc;
     g = GemmArgs{};
     g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
     if (lnfuse) {
       // ---- d FFN-1 GEMM + residual + the attention block's LayerNorm backward in its epilogue: g_ta directly
       g.C = lw.g_ta; g.xhat = lw.ahat; g.rstd = lw.rstd1; g.gamma = p.g1; g.ln_part = lnfuse_part(i);
-      if (!early_fork) arm();
+      if (!early_fork && !(hold & 2)) arm();
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc;
       if (rb.full(2) && (rc = reduce_batch(rb, st))) return rc;
       rb.add(g.ln_part, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, G + o[8], d);
@@ -864,14 +871,14 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     if ((rc = tn(lw.g_tad, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
     // every fork is an event record on the main stream = a ~5 us bubble in front of its next kernel: dW2, dW1 and dWo go together, here
     // (the side stream is still busy with the top layer's batch when the first two become ready; UR_SASREC_EARLY_FORK=1: round-2a order)
-    if (!early_fork && (rc = fork())) return rc;
+    if (!early_fork && !(hold & 2) && (rc = fork())) return rc;
     g = GemmArgs{};
     g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = d;
-    if (n_pend > 0) arm();
+    if (n_pend > 0 && !(hold & 2)) arm();
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
     // fork dWo now: it then runs underneath the attention backward instead of queueing up behind it at the very end of
     // the pass, where the side stream would finish after the main one (one more event, ~30 us off the tail)
-    if ((rc = fork())) return rc;
+    if (!(hold & 2) && (rc = fork())) return rc;
     arm();
     if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad, &d_attn))) return rc;
     if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;

@@ -312,14 +312,76 @@ def rows_plan_sharded(ids_a, ids_b, n_rows, world, out=None):
     return pl, counts
 
 
-def compact_index(pl: RowsPlan):
-    """-> (idx_a int32[n_a], idx_b int64[n - n_a]): every lookup as an index into the compact table of unique rows."""
+def compact_index(pl: RowsPlan, slot_of_uniq=None, out=None):
+    """-> (idx_a int32[n_a], idx_b int64[n - n_a]): every lookup as an index into the compact table of unique rows (slot_of_uniq, from
+    shard_exchange_ids: into the fixed-capacity [world * cap, d] table instead).  out: preallocated (idx_a, idx_b)."""
     dev = pl.uniq_idx.device
-    idx_a = torch.empty(pl.n_a, dtype=torch.int32, device=dev) if pl.n_a else None
-    idx_b = torch.empty(pl.n - pl.n_a, dtype=torch.int64, device=dev) if pl.n > pl.n_a else None
-    check(lib.ur_compact_index(_p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, pl.n_a, _p(idx_a), _p(idx_b), _stream()),
-          "ur_compact_index")
+    if out is not None:
+        idx_a, idx_b = out
+    else:
+        idx_a = torch.empty(pl.n_a, dtype=torch.int32, device=dev) if pl.n_a else None
+        idx_b = torch.empty(pl.n - pl.n_a, dtype=torch.int64, device=dev) if pl.n > pl.n_a else None
+    _chk(slot_of_uniq, torch.int32, "slot_of_uniq", allow_none=True)
+    check(lib.ur_compact_index(_p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, pl.n_a, _p(slot_of_uniq), _p(idx_a), _p(idx_b),
+                               _stream()), "ur_compact_index")
     return idx_a, idx_b
+
+
+# ---- fixed-capacity row exchange of the row-sharded tables (include/unirec_amd.h: ur_shard_exchange_*, ur_comm_*)
+def comm_world():
+    """-1: no RCCL library in the process, 0: the library's communicator is not initialised, else its size."""
+    return int(lib.ur_comm_world())
+
+
+def comm_init(rank, world, group=None):
+    """The library's own RCCL communicator, one per process: rank 0 makes the unique id, torch.distributed (any backend) carries it."""
+    import torch.distributed as dist
+    buf = (C.c_char * 128)()
+    if rank == 0:
+        check(lib.ur_comm_unique_id(buf), "ur_comm_unique_id")
+    if world > 1:
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        buf = (C.c_char * 128).from_buffer_copy(box[0])
+    check(lib.ur_comm_init(buf, int(rank), int(world)), "ur_comm_init")
+
+
+def comm_destroy():
+    check(lib.ur_comm_destroy(), "ur_comm_destroy")
+
+
+def comm_all_reduce_sum(t):
+    _chk(t, torch.float32, "t")
+    check(lib.ur_comm_all_reduce_sum(_p(t), t.numel(), _stream()), "ur_comm_all_reduce_sum")
+    return t
+
+
+def shard_exchange_ids(pl: RowsPlan, counts, n_local, world, cap, send_ids, slot_of_uniq, u_of_slot, flags, recv_ids=None, transport=False):
+    """pack (+ RCCL all-to-all when transport): see ur_shard_exchange_ids.  Buffers are the caller's (preallocated once)."""
+    for t, nm in ((counts, "counts"), (send_ids, "send_ids"), (slot_of_uniq, "slot_of_uniq"), (u_of_slot, "u_of_slot"), (flags, "flags")):
+        _chk(t, torch.int32, nm)
+    assert send_ids.numel() == world * cap and u_of_slot.numel() == world * cap and slot_of_uniq.numel() >= pl.n
+    check(lib.ur_shard_exchange_ids(_p(pl.uniq_idx), _p(pl.n_uniq), _p(counts), int(n_local), int(world), int(cap), _p(send_ids),
+                                    _p(slot_of_uniq), _p(u_of_slot), _p(flags), _p(recv_ids), 1 if transport else 0, _stream()),
+          "ur_shard_exchange_ids")
+    return recv_ids if transport else send_ids
+
+
+def shard_exchange_rows(table, req_ids, world, cap, rows_ws, compact=None, transport=False):
+    _chk(table, torch.float32, "table"); _chk(req_ids, torch.int32, "req_ids"); _chk(rows_ws, torch.float32, "rows_ws")
+    assert req_ids.numel() == world * cap and rows_ws.numel() == world * cap * table.shape[1]
+    check(lib.ur_shard_exchange_rows(_p(table), _p(req_ids), int(world), int(cap), table.shape[1], _p(rows_ws), _p(compact),
+                                     1 if transport else 0, _stream()), "ur_shard_exchange_rows")
+    return compact if transport else rows_ws
+
+
+def shard_exchange_grads(uniq_grad, u_of_slot, world, cap, send_ws, grads_in=None, transport=False):
+    _chk(uniq_grad, torch.float32, "uniq_grad"); _chk(u_of_slot, torch.int32, "u_of_slot"); _chk(send_ws, torch.float32, "send_ws")
+    d = uniq_grad.shape[1]
+    assert u_of_slot.numel() == world * cap and send_ws.numel() == world * cap * d
+    check(lib.ur_shard_exchange_grads(_p(uniq_grad), _p(u_of_slot), int(world), int(cap), d, _p(send_ws), _p(grads_in),
+                                      1 if transport else 0, _stream()), "ur_shard_exchange_grads")
+    return grads_in if transport else send_ws
 
 
 def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False) -> torch.Tensor:

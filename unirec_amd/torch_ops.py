@@ -185,6 +185,61 @@ def _(ids_a, ids_b, n_rows):
     return ref.new_empty((n,), **i32), ref.new_empty((n + 1,), **i32), ref.new_empty((n,), **i32), ref.new_empty((1,), **i32)
 
 
+# ------------------------------------------------------------------------------------------------ row exchange (row-sharded tables)
+# a2a_embedding_exchange.  The three legs of a step's exchange over the library's RCCL communicator (ops.comm_init); the
+# fixed capacity `cap` per (source, owner) pair makes every shape static.
+@custom_op(f"{NS}::a2a_embedding_ids", mutates_args=())
+def a2a_embedding_ids(uniq_key: torch.Tensor, n_uniq: torch.Tensor, counts: torch.Tensor, n_local: int, world: int,
+                      cap: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (recv_ids [world*cap] on the owners, slot_of_uniq, u_of_slot, flags)"""
+    dev, i32 = uniq_key.device, torch.int32
+    pl = _plan(uniq_key, None, None, n_uniq, uniq_key.numel(), 0)
+    send = torch.empty(world * cap, dtype=i32, device=dev)
+    recv = torch.empty(world * cap, dtype=i32, device=dev)
+    slot = torch.zeros(uniq_key.numel(), dtype=i32, device=dev)
+    uos = torch.empty(world * cap, dtype=i32, device=dev)
+    flags = torch.zeros(4, dtype=i32, device=dev)
+    ops.shard_exchange_ids(pl, counts, n_local, world, cap, send, slot, uos, flags, recv_ids=recv, transport=True)
+    return recv, slot, uos, flags
+
+
+@a2a_embedding_ids.register_fake
+def _(uniq_key, n_uniq, counts, n_local, world, cap):
+    i32 = dict(dtype=torch.int32)
+    return (uniq_key.new_empty((world * cap,), **i32), uniq_key.new_empty((uniq_key.numel(),), **i32),
+            uniq_key.new_empty((world * cap,), **i32), uniq_key.new_empty((4,), **i32))
+
+
+@custom_op(f"{NS}::a2a_embedding_exchange", mutates_args=())
+def a2a_embedding_exchange(table_shard: torch.Tensor, req_ids: torch.Tensor, world: int, cap: int) -> torch.Tensor:
+    """owner side gathers the requested rows of its shard, all-to-all -> the requesters' compact [world*cap, d] tables"""
+    d = table_shard.shape[1]
+    ws = torch.empty(world * cap, d, dtype=torch.float32, device=table_shard.device)
+    out = torch.empty(world * cap, d, dtype=torch.float32, device=table_shard.device)
+    ops.shard_exchange_rows(table_shard, req_ids, world, cap, ws, compact=out, transport=True)
+    return out
+
+
+@a2a_embedding_exchange.register_fake
+def _(table_shard, req_ids, world, cap):
+    return table_shard.new_empty((world * cap, table_shard.shape[1]))
+
+
+@custom_op(f"{NS}::a2a_embedding_grads", mutates_args=())
+def a2a_embedding_grads(uniq_grad: torch.Tensor, u_of_slot: torch.Tensor, world: int, cap: int) -> torch.Tensor:
+    """row gradients in unique order -> slot layout, all-to-all -> [world*cap, d] on the owners (block s = from rank s)"""
+    d = uniq_grad.shape[1]
+    ws = torch.empty(world * cap, d, dtype=torch.float32, device=uniq_grad.device)
+    out = torch.empty(world * cap, d, dtype=torch.float32, device=uniq_grad.device)
+    ops.shard_exchange_grads(uniq_grad, u_of_slot, world, cap, ws, grads_in=out, transport=True)
+    return out
+
+
+@a2a_embedding_grads.register_fake
+def _(uniq_grad, u_of_slot, world, cap):
+    return uniq_grad.new_empty((world * cap, uniq_grad.shape[1]))
+
+
 @custom_op(f"{NS}::rows_reduce", mutates_args=())
 def rows_reduce(uniq_idx: torch.Tensor, seg_start: torch.Tensor, sorted_pos: torch.Tensor, n_uniq: torch.Tensor, rows_a: Optional[torch.Tensor],
                 coef_b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], n_a: int, G: int, d: int) -> torch.Tensor:
@@ -275,6 +330,9 @@ HEADER_TO_OP = {
     "ur_gather_dot_loss_bwd": "gather_dot_loss_bwd",
     "ur_sample_negatives": "sample_negatives",
     "ur_rows_plan": "rows_plan",
+    "ur_shard_exchange_ids": "a2a_embedding_ids",
+    "ur_shard_exchange_rows": "a2a_embedding_exchange",
+    "ur_shard_exchange_grads": "a2a_embedding_grads",
     "ur_rows_reduce": "rows_reduce",
     "ur_sparse_adam_rows": "sparse_adam_rows",
     "ur_lazy_adam_catchup": "lazy_adam_catchup",
@@ -291,6 +349,7 @@ _SWITCH = "process-wide switch / profiler control"
 _HOOK = "raw kernel hook for unit tests and micro-benchmarks (the encoder ops call these kernels internally)"
 _PLUMB = "stream plumbing of the deferred-join backward: ordering between HIP streams, not a tensor computation"
 _SHARD = "row-sharded (multi-GPU) variant driven by facility/distributed.py around torch.distributed collectives"
+_COMM = "the library's RCCL communicator (process-wide state behind the a2a_embedding_exchange ops): set-up / tear-down / the flat all-reduce, no tensor dispatch"
 _FAMILY = "sibling model family / loss outside the north_star's named ops (SURVEY.md 8 f4): reached through unirec_amd.ops"
 NOT_OPS = {
     "ur_last_error": _QUERY, "ur_version": _QUERY, "ur_sasrec_param_layout": _QUERY, "ur_gru_param_layout": _QUERY,
@@ -304,6 +363,7 @@ NOT_OPS = {
     "ur_gemm_nt": _HOOK, "ur_gemm_tn": _HOOK,
     "ur_sasrec_bwd_deferred": _PLUMB, "ur_sasrec_bwd_join": _PLUMB, "ur_stream_wait_stream": _PLUMB, "ur_sasrec_side_stream": _PLUMB, "ur_sasrec_side_publish": _PLUMB,
     "ur_rows_plan_merge": _SHARD, "ur_rows_plan_sharded": _SHARD, "ur_compact_index": _SHARD, "ur_full_rank_shard": _SHARD,
+    "ur_comm_world": _COMM, "ur_comm_unique_id": _COMM, "ur_comm_init": _COMM, "ur_comm_destroy": _COMM, "ur_comm_all_reduce_sum": _COMM,
     "ur_sumsq": _FAMILY + " (gradient-clipping helpers of the optimizer)", "ur_clip_coef": _FAMILY + " (gradient-clipping helpers)",
     "ur_clip_coef_guarded": _FAMILY + " (gradient-clipping helpers)",
     "ur_sample_negatives_pop": _FAMILY + " (popularity-biased sampler)", "ur_device_build_seq": _FAMILY + " (device row builder)",
