@@ -335,14 +335,6 @@ int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_pos, const 
 int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
                    const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
                    const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, void* stream);
-/* ur_rows_reduce followed by ur_sparse_adam_rows (below) in ONE launch: every unique row's gradient is summed (same order) and the
- * optimizer rule applied to the row on the spot -- uniq_grad is never written.  For the step without gradient clipping (the norm
- * needs every gradient first): embedding_dense_backward + optimizer.step on the touched rows, unirec/facility/trainer.py:346-349.
- * Arguments as the two calls it replaces; grad_scale_dev as in ur_sparse_adam_rows (< 0: the step is skipped). */
-int ur_rows_reduce_adam(const struct UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, const int32_t* uniq_idx,
-                        const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n, const float* rows_a,
-                        int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d, const float* grad_scale_dev,
-                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam as built at unirec/facility/trainer.py:134-136 and stepped at :349;
@@ -389,19 +381,7 @@ int ur_rows_filter_touched(const int32_t* uniq_idx, const int32_t* n_uniq_dev, i
  * rows (next_uniq_idx: its plan's row list) in ONE launch: the next batch's rows -- minus the ones updated here -- are brought to
  * the state after this step (cfg->step).  Same results as the two calls in sequence; the two halves are latency-bound chains of random
  * accesses and overlap instead of queueing up at the tail of the step. */
-int ur_sparse_adam_rows_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
-                                const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad,
-                                int32_t d, const float* grad_scale_dev, const int32_t* next_uniq_idx,
-                                const int32_t* next_n_uniq_dev, int64_t next_n_max, void* stream);
-/* the same catch-up issued AHEAD of a step that is still in flight (on another stream): rows in busy_idx[0..*busy_n_dev) -- the
- * ascending unique row list of the in-flight step's plan, i.e. the rows that step reads and will update -- are left alone (the
- * step's own update replays them); every other row of uniq_idx is brought to "after step (cfg->step - 1)", where cfg->step - 1 is
- * the in-flight step itself.  Rows already at or past that state are skipped.  Bit-identical to running ur_lazy_adam_catchup
- * after the step: a zero-gradient step depends on the step index only.  (Reference semantics: torch's dense Adam moves every
- * row every step, unirec/facility/trainer.py:349.) */
-int ur_lazy_adam_catchup_ahead(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
-                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
-                               const int32_t* busy_idx, const int32_t* busy_n_dev, int64_t busy_max, void* stream);
+
 /* same for a contiguous block of rows [row0, row0+n): flush before evaluation / checkpoint */
 int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, int64_t row0,
                        int64_t n, int32_t d, void* stream);

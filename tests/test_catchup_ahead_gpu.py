@@ -1,9 +1,9 @@
-"""Lazy-Adam catch-up of the NEXT batch's rows issued ahead of time, under the step in flight (ur_lazy_adam_catchup_ahead).
+"""Lazy-Adam catch-up of the NEXT batch's rows issued ahead of time, at the tail of the step in flight.
 
 The reference's dense torch.optim.Adam moves every embedding row every step (unirec/facility/trainer.py:349).  The lazy table replays a
-row's missed zero-gradient steps when the row is next looked up; `SparseDenseAdam.prefetch_plan` now does that replay on the side stream
-while the current step runs, leaving the rows the current step touches to that step's own update.  A zero-gradient step depends on the
-step index only, so the trajectory must be BIT-identical to catching up at the head of the next step -- that is what is asserted here,
+row's missed zero-gradient steps when the row is next looked up; with a plan prefetched for the next batch `SparseDenseAdam.step()` does
+that replay right after its own row update (main stream, under the tail of the dense-gradient stream).  A zero-gradient step depends on
+the step index only, so the trajectory must be BIT-identical to catching up at the head of the next step -- that is what is asserted here,
 on a small table (every row comes back every few steps), for Adam and AdamW-with-decay, with a prefetched batch that is then not the one
 trained on, and with steps whose loss guard skips the update.
 """
@@ -31,15 +31,13 @@ def _batches(n, B=16, L=10, N=300, seed=0):
 
 
 def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14):
-    """ahead: False = catch-up at the head of the next step, "side" = on the side stream under the step in flight, "tail" = on the main
-    stream between the row update and the join of the dense-gradient stream (the default)"""
+    """ahead: False = catch-up at the head of the next step (no plan lookahead), "tail" = on the main stream between the row update and
+    the join of the dense-gradient stream (what a prefetched plan gives)"""
     from unirec_amd.facility.optimizer import SparseDenseAdam
     from unirec_amd.utils.general import get_class_instance, init_seed
     init_seed(4)
     model = get_class_instance("SASRec", "unirec_amd/model")(_cfg())
     opt = SparseDenseAdam(model, lr=5e-3, weight_decay=wd, algo=algo)
-    opt._ahead = "tail" if ahead == "merged" else (ahead or "")
-    opt._merge = ahead == "merged"          # row update + the next batch's catch-up as one launch (ur_sparse_adam_rows_catchup)
     model.train()
     bs = _batches(n_steps + 2)
     other = _batches(3, seed=99)
@@ -51,7 +49,8 @@ def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14):
         opt.zero_grad()
         opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
         nxt = other[0] if swap_at == s else bs[s + 1]       # swap_at: the batch planned ahead is NOT the one trained on next
-        opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
+        if ahead:
+            opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
         loss = model.forward_backward(item_id=b["item_id"], label=lab, item_seq=b["item_seq"])
         opt.step()
         losses.append(float(loss))
@@ -64,7 +63,7 @@ def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14):
 @pytest.mark.parametrize("algo,wd", [("adam", 0.0), ("adamw", 0.01), ("adam", 0.001), ("rmsprop", 0.0)])
 def test_catchup_ahead_is_bit_identical(algo, wd):
     b = _train(False, algo, wd)
-    for mode in ("side", "tail", "merged"):
+    for mode in ("tail",):
         a = _train(mode, algo, wd)
         assert a[0] == b[0]
         for x, y, what in zip(a[1:], b[1:], ("w", "m", "v", "dense")):
@@ -75,50 +74,15 @@ def test_a_prefetched_batch_that_is_not_trained_on_changes_nothing():
     """rows caught up for a batch that is then not trained on are simply up to date earlier: the same zero-gradient steps, summed in
     two pieces instead of one (fp32 re-association of the replay sum: a few ulp of an lr-sized term, not bit-equal)"""
     c = _train(False)
-    for mode in ("side", "tail"):
+    for mode in ("tail",):
         a = _train(mode, swap_at=5)
         for x, z, what in zip(a[1:4], c[1:4], ("w", "m", "v")):
             assert torch.allclose(x, z, rtol=1e-4, atol=1e-6), (mode, what, float((x - z).abs().max()))
 
 
-def test_catchup_ahead_leaves_the_busy_rows_alone():
-    from unirec_amd import ops
-    dev = torch.device("cuda:0")
-    N, d = 2000, 32
-    g = torch.Generator(device=dev).manual_seed(0)
-    w = torch.randn(N, d, device=dev, generator=g)
-    m = torch.randn(N, d, device=dev, generator=g) * 0.01
-    v = torch.rand(N, d, device=dev, generator=g) * 1e-4
-    last = torch.full((N,), 3, dtype=torch.int32, device=dev)
-    nxt = torch.arange(100, 700, dtype=torch.int32, device=dev)
-    busy = torch.arange(400, 1000, 3, dtype=torch.int32, device=dev)
-    pl_n = ops.rows_plan(nxt, None, N)
-    pl_b = ops.rows_plan(busy, None, N)
-    w0, m0, v0 = w.clone(), m.clone(), v.clone()
-    cfg = ops.adam_cfg(1e-2, 8)                                   # in-flight step = 7: rows go to "after step 7"
-    ops.lazy_adam_catchup_ahead(cfg, w, m, v, last, pl_n, pl_b)
-    torch.cuda.synchronize()
-    is_busy = torch.zeros(N, dtype=torch.bool, device=dev)
-    is_busy[busy.long()] = True
-    moved = torch.zeros(N, dtype=torch.bool, device=dev)
-    moved[nxt.long()] = True
-    moved &= ~is_busy
-    assert torch.equal(last[moved], torch.full_like(last[moved], 7)) and torch.equal(last[~moved], torch.full_like(last[~moved], 3))
-    assert torch.equal(w[~moved], w0[~moved]) and torch.equal(m[~moved], m0[~moved]) and torch.equal(v[~moved], v0[~moved])
-    # the moved rows are what the plain catch-up gives
-    w1, m1, v1, l1 = w0.clone(), m0.clone(), v0.clone(), torch.full((N,), 3, dtype=torch.int32, device=dev)
-    ops.lazy_adam_catchup(cfg, w1, m1, v1, l1, pl_n)
-    assert torch.equal(w[moved], w1[moved]) and torch.equal(m[moved], m1[moved]) and torch.equal(v[moved], v1[moved])
-    assert not torch.equal(w[moved], w0[moved])
-    # a second call is a no-op (rows already there), and the plain catch-up never moves a row backwards
-    ops.lazy_adam_catchup_ahead(cfg, w, m, v, last, pl_n, pl_b)
-    ops.lazy_adam_catchup(ops.adam_cfg(1e-2, 5), w, m, v, last, pl_n)
-    assert torch.equal(w[moved], w1[moved]) and torch.equal(last[moved], torch.full_like(last[moved], 7))
-
-
 @pytest.mark.gpu
-def test_dense_half_on_the_side_stream_is_bit_identical(monkeypatch):
-    """UR_DENSE_ADAM_SIDE: the dense half of the optimizer step runs on the encoder's side stream behind the dense-gradient reductions
+def test_dense_half_on_the_side_stream_is_bit_identical():
+    """SparseDenseAdam(dense_side=...): the dense half of the optimizer step runs on the encoder's side stream behind the dense-gradient reductions
     (ur_sasrec_side_stream / ur_sasrec_side_publish) and the NEXT forward pass joins it after its first launch ("late", default), or step()
     joins it ("join"), or the main stream waits and runs it itself ("0", round 2a).  Same kernels, same inputs: bit-identical parameters,
     optimizer state and losses after every step; a state_dict() taken right after step() must already see the update (the model joins)."""
@@ -129,13 +93,10 @@ def test_dense_half_on_the_side_stream_is_bit_identical(monkeypatch):
     from unirec_amd.model.sequential.sasrec import SASRec
 
     def run(mode):
-        if mode == "per-call":      # no override: step(late_join=True) while another step follows, step() for the last one
-            monkeypatch.delenv("UR_DENSE_ADAM_SIDE", raising=False)
-        else:
-            monkeypatch.setenv("UR_DENSE_ADAM_SIDE", mode)
+        # "per-call": no override -- step(late_join=True) while another step follows, step() for the last one
         torch.manual_seed(7)
         model = SASRec(_cfg(n_items=5000, embedding_size=128, hidden_size=128, inner_size=512, n_heads=16, max_seq_len=50, batch_size=64))
-        opt = SparseDenseAdam(model, lr=1e-3, table_mode="lazy_dense")
+        opt = SparseDenseAdam(model, lr=1e-3, table_mode="lazy_dense", dense_side=None if mode == "per-call" else mode)
         model.train()
         g = torch.Generator(device="cpu").manual_seed(11)
         batches = []

@@ -34,42 +34,26 @@ def test_gru_per_step_path_and_sorting_owner_plan():
                                   os.path.join(HERE, "test_trainer_gpu.py"), "-k", "gru or GRU or g7"], expect_min_passed=8)
 
 
-def test_chunked_topk_and_32_row_gemm_tiles():
-    _run({"UR_TOPK_NO_PRUNE": "1"}, [os.path.join(HERE, "test_full_rank.py"), "-k", "topk and not overflow and not 3200003 and not 2200000"],
-         expect_min_passed=5)
-    _run({"UR_GEMM_C64": "0", "UR_SASREC_SIDE": "0"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden"], expect_min_passed=20)
+def test_inline_weight_gradients():
+    """UR_SASREC_SIDE=0: no side stream -- the weight-gradient launches run in line on the caller's stream (what > 2 layers do anyway)"""
+    _run({"UR_SASREC_SIDE": "0"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden"], expect_min_passed=20)
 
 
-def test_round2_schedules_keep_reference_parity():
-    """Round-2 alternatives of the default schedule: the one-workgroup id sort (the chunk-sort path is the default), the stand-alone
-    LayerNorm-backward launches (the fused GEMM epilogue is the default), and the row-chain kernels switched all off / all on (forward only is the default) -- each must pass the
-    reference goldens and the oracle comparisons."""
-    _run({"UR_PLAN_ONEWG": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_sharded.py"), "-k", "rows_plan or golden or world1"],
+def test_multi_launch_id_sort():
+    """UR_PLAN_MULTI=1: the multi-launch radix sort (the path of batches with more than 32 768 ids) at the small test shapes"""
+    _run({"UR_PLAN_MULTI": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_sharded.py"), "-k", "rows_plan or golden or world1"],
          expect_min_passed=20)
-    _run({"UR_SASREC_NO_LNFUSE": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)
-    # no chain kernels at all / every chain kernel (default: forward chain + both chains of the last-row layer) / round 2a's default /
-    # the gemm_tn variants (LDS-staged is the default; the no-LDS kernel with an 8- or 16-deep register ring)
-    _run({"UR_TN_DIRECT": "8"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_gemm_gpu.py"), "-k", "golden or larger_random or tn"], expect_min_passed=20)
-    _run({"UR_TN_DIRECT": "16"}, [os.path.join(HERE, "test_gemm_gpu.py"), "-k", "tn"], expect_min_passed=10)
-    # the two-pass, workgroup-per-head attention backward (the wave-per-head single-pass kernel is the default for L <= 64)
+
+
+def test_alternative_schedules_keep_reference_parity():
+    """The two-pass attention backward (default for L > 64) at L <= 64, the row-chain kernels switched all off / forward only (all on is
+    the default), and a spin kernel on the side stream that widens every window in which the main stream could touch what the side stream
+    has not finished with (400 us: direct readers of the parameters after step() included) -- each must pass the reference goldens and
+    the oracle comparisons."""
     _run({"UR_ATTN_NO_M16W": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_dropout_gpu.py"), "-k", "golden or larger_random or skip_padding or attn or dropout"],
          expect_min_passed=20)
-    # the last-row layer as ONE workgroup per row block (default: the inner dimension split over workgroups)
-    _run({"UR_SASREC_NO_QFUSE": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)   # gather + query GEMM launches in front of the one-query attention
-    _run({"UR_SASREC_NO_SPLIT": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)
-    # the dense half of the optimizer step on the main stream (round 2a) / on the side stream but joined by step() itself; a late join in
-    # front of the next forward pass's first launch
-    # ({"UR_SASREC_STOP_EVENTS": "0"}: every fork of the backward pass by hipEventRecord instead of an event carried by the producing launch)
-    # ({"UR_SASREC_SAVE_U": "1"}: the forward chain keeps act(h1) for the FFN-2 weight gradient instead of recomputing it there;
-    #  {"UR_SASREC_EARLY_REDUCE": "0"}: every deferred reduction at the end of the pass)
-    for env in ({"UR_DENSE_ADAM_SIDE": "0"}, {"UR_DENSE_ADAM_SIDE": "join"}, {"UR_SIDE_JOIN_TOP": "1"}, {"UR_SASREC_STOP_EVENTS": "0"},
-                {"UR_SASREC_SAVE_U": "1"}, {"UR_SASREC_EARLY_REDUCE": "0"},
-                # a spin kernel in front of the dense half on the side stream: every window in which the main stream could touch what
-                # the side stream has not finished with is 400 us wide (direct readers of the parameters after step() included)
-                # (not together with UR_DENSE_ADAM_SIDE=late: that override leaves the join to the next forward pass even for the last
-                # step, and these tests read the parameters right after it -- the case step(late_join=False) exists for)
-                {"UR_SIDE_TEST_DELAY_US": "400"}):
-        _run(env, [os.path.join(HERE, "test_trainer_gpu.py"), os.path.join(HERE, "test_catchup_ahead_gpu.py")], expect_min_passed=10)
-    for mask in ("0", "63", "1"):
+    _run({"UR_ATTN_NO_M16T": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden or larger_random or skip_padding"], expect_min_passed=20)
+    _run({"UR_SIDE_TEST_DELAY_US": "400"}, [os.path.join(HERE, "test_trainer_gpu.py"), os.path.join(HERE, "test_catchup_ahead_gpu.py")], expect_min_passed=10)
+    for mask in ("0", "1", "57"):
         _run({"UR_SASREC_CHAIN": mask}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_trainer_gpu.py"),
                                          "-k", "golden or larger_random or skip_padding or sasrec or SASRec"], expect_min_passed=20)

@@ -10,8 +10,7 @@ import torch  # noqa: F401  -- FIRST: the process must use torch's bundled HIP r
 #                              before torch's would put two runtimes in one process ("no ROCm-capable device")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_VARIANT = os.environ.get("UR_LIB_VARIANT", "")   # tuning aid: a library built with UR_BUILD_VARIANT (unirec_amd/build.py)
-LIB_PATH = os.path.join(_HERE, f"libunirec_amd{'_' + _VARIANT if _VARIANT not in ('', 'base') else ''}.so")
+LIB_PATH = os.path.join(_HERE, "libunirec_amd.so")
 
 UR_MAX_LAYERS = 8
 UR_SASREC_N_GLOBAL = 3
@@ -94,13 +93,10 @@ SIGNATURES = {
     "ur_comm_destroy": (C.c_int, []),
     "ur_comm_all_reduce_sum": (C.c_int, [P, I64, P]),
     "ur_rows_reduce": (C.c_int, [P, P, P, P, I64, P, I64, P, P, I32, I32, P, P, P]),
-    "ur_rows_reduce_adam": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, P, P, I64, P, I64, P, P, I32, I32, P, P]),
     "ur_dense_adam": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, P, P]),
     "ur_sparse_adam_rows": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, P, I32, P, P]),
     "ur_lazy_adam_catchup": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, I32, P]),
     "ur_rows_filter_touched": (C.c_int, [P, P, I64, P, P, P, P]),
-    "ur_sparse_adam_rows_catchup": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, P, I32, P, P, P, I64, P]),
-    "ur_lazy_adam_catchup_ahead": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, I32, P, P, I64, P]),
     "ur_lazy_adam_flush": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, I64, I32, P]),
     "ur_sumsq": (C.c_int, [P, I64, P, C.c_int, P, P]),
     "ur_clip_coef": (C.c_int, [P, C.c_float, P, P]),

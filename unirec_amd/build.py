@@ -12,11 +12,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
-# (tuning aid: UR_BUILD_VARIANT=name UR_BUILD_FLAGS="-D..." builds libunirec_amd_<name>.so next to the product library; UR_LIB_VARIANT=name loads it)
-VARIANT = os.environ.get("UR_BUILD_VARIANT", "")
-LIB = os.path.join(HERE, f"libunirec_amd{'_' + VARIANT if VARIANT else ''}.so")
+LIB = os.path.join(HERE, "libunirec_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("UR_BUILD_FLAGS", "").split()
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def _digest(paths):
@@ -36,11 +34,11 @@ def build(verbose=True, force=False):
     for s in srcs:
         src = os.path.join(CSRC, s)
         tag = _digest([src] + hdrs)
-        obj = os.path.join(OBJ, f"{os.path.splitext(s)[0]}{'@' + VARIANT if VARIANT else ''}.{tag}.o")
+        obj = os.path.join(OBJ, f"{os.path.splitext(s)[0]}.{tag}.o")
         objs.append(obj)
         if force or not os.path.exists(obj):
             for old in os.listdir(OBJ):
-                if old.startswith(os.path.splitext(s)[0] + ('@' + VARIANT if VARIANT else '') + "."):
+                if old.startswith(os.path.splitext(s)[0] + "."):
                     os.remove(os.path.join(OBJ, old))
             lang = ["-x", "hip"] if s.endswith(".hip") else []
             jobs.append((s, [HIPCC] + FLAGS + lang + ["-c", src, "-o", obj]))

@@ -390,7 +390,6 @@ __global__ __launch_bounds__(256) void attn_last_bwd_kernel(const float* __restr
                                                             const int* __restrict__ seq, const float* __restrict__ ctx_last,
                                                             const float* __restrict__ dctx_last, const float* __restrict__ lse_last,
                                                             AttnDims p, float* __restrict__ dq_last, float* __restrict__ dqkv) {
-  UR_PRIO_MAIN();
   const int lane = threadIdx.x & 63;
   const int h = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
   if (h >= p.H) return;
@@ -1509,7 +1508,6 @@ template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_m16w_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
                                                             const float* __restrict__ ctx, const float* __restrict__ dctx,
                                                             const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
-  UR_PRIO_MAIN();
   constexpr int KS = HD / 4, LDK = HD == 8 ? 8 : HD + 4, PR = HD / 4, NTM = 4, TS = M16W_TS, SL = M16W_HEADS * PR;   // SL: float4 slots per row
   auto at = [](int row, int c) { return row * LDK + (HD == 8 ? (c ^ ((row & 8) >> 1)) : c); };   // element (row, c) of a staged tile
   constexpr float LOG2E = 1.4426950408889634f;

@@ -61,17 +61,6 @@ struct ProfScope {
   ~ProfScope();
 };
 
-// Wave priority of the kernels on the critical path (the caller's stream): the weight-gradient GEMMs of the side stream share the CUs
-// with them and run at the default priority 0, so a raised priority lets the critical path win the SIMD's issue arbitration.
-#ifndef UR_MAIN_PRIO
-#define UR_MAIN_PRIO 0
-#endif
-#if UR_MAIN_PRIO > 0
-#define UR_PRIO_MAIN() __builtin_amdgcn_s_setprio(UR_MAIN_PRIO)
-#else
-#define UR_PRIO_MAIN() ((void)0)
-#endif
-
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -657,14 +657,13 @@ extern "C" int ur_full_topk(const float* user_emb, const float* item_table, int6
   // k-th best score; then ALL items are streamed once by the ranking kernel in EMIT mode -- scores stay in the MFMA accumulators,
   // only the few that beat the bound are written -- and the k best of those candidates are the answer.  No [B, N] score ever
   // reaches HBM.  Falls back to the chunked path when a row's candidate list overflows (k * N / chunk too large).
-  static const bool no_prune = getenv("UR_TOPK_NO_PRUNE") != nullptr;   // test / tuning hook
   static const long long cap_env = getenv("UR_TOPK_CAP") ? atoll(getenv("UR_TOPK_CAP")) : 0;   // test hook: force list overflows
   // size of the first range: large enough that few items beat its k-th best (expected survivors per row: k * N / first),
   // small enough that the score-matrix pipeline over it is a fraction of the streaming pass
   const long long first = std::min<long long>(chunk, std::max<long long>(65536, (n_items / 16) & ~3LL));
   const long long cap = cap_env > 0 ? cap_env
                                     : std::min<long long>(chunk / 4, std::max<long long>(4096, 8LL * k * ((n_items + first - 1) / first)));
-  const bool prune = !no_prune && d <= 128 && n_items >= 262144 && B <= 4096 && (long long)k * 64 <= first;
+  const bool prune = d <= 128 && n_items >= 262144 && B <= 4096 && (long long)k * 64 <= first;
   int* cnt = (int*)(((uintptr_t)(cand_i + (long long)B * nchunks * k) + 15) & ~(uintptr_t)15);   // [B] list lengths
   float* thr = (float*)(cnt + B);                                                                  // [B]
   // k best of items [c0, c0 + cn) -> slot `slot` of the per-chunk winners (or the final output when direct)

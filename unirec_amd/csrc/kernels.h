@@ -76,7 +76,6 @@ struct GemmArgs {
   const int* m_dev;              // nullable: device-side row count, M = min(M, *m_dev) (compacted token rows)
   DropSpec drop;                 // EPI_BIAS_RES_LN: t = dropout(acc + bias) + res  (thresh == 0: off)
   const long long* skip; long long skip_base;   // EPI_COUNT_GT: column skip[m] - skip_base of row m is left out (nullable)
-  int debug;                     // tuning aid (UR_GEMM_DEBUG): 1 = skip epilogue, 2 = skip K-loop global loads
   // EPI_ADD with out_rows: C[out_rows[m], :] += acc + aux[m, :] (rows of out_rows distinct).
   // EPI_ADD_LNBWD: xhat / rstd are INPUTS here (saved by the forward pass); out_rows (nullable) scatters row m of the result to row
   // out_rows[m] of C; ln_part [gemm_nt_lnbwd_tiles(M)][2 N] receives the partial sums (every slot is written); M_host = the M
@@ -99,7 +98,6 @@ struct TnReq {
 };
 long long gemm_tn_group_ws_floats(int R, int Cc);
 int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer = nullptr);
-bool gemm_tn_grouped();   // the grouped kernel is the weight-gradient path (UR_TN_GROUP=0: the single-product kernel)
 // dst[c,r] = src[r,c]
 int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
 struct TransposeItem { const float* src; float* dst; int rows, cols, first_block; };
@@ -120,7 +118,7 @@ int transpose_batch(TransposeBatch& tb, hipStream_t st);   // every queued trans
 
 // ---- rowchain.hip: row-block chain kernels (a workgroup carries BM token rows through a sequence of GEMMs, tiles in LDS)
 constexpr int CHAIN_FWD = 1, CHAIN_BWD = 2, CHAIN_PROJ = 4, CHAIN_LAST = 8, CHAIN_LAST_BWD = 16, CHAIN_EMBED = 32, CHAIN_ALL = 63;   // LAST*: the B last rows of the last-row layer; EMBED: lookup + LN + first projection
-constexpr int CHAIN_DEFAULT = CHAIN_FWD | CHAIN_LAST | CHAIN_LAST_BWD | CHAIN_EMBED;  // which chain kernels run by default (UR_SASREC_CHAIN / ur_sasrec_set_chain: bit mask); DESIGN.md 6d
+constexpr int CHAIN_DEFAULT = CHAIN_ALL;  // which chain kernels run by default (UR_SASREC_CHAIN / ur_sasrec_set_chain: bit mask); DESIGN.md 6d
 bool chain_supported(int d, int inner, int which);
 bool chain_shape_ok(int d, int inner);              // the kernels exist for this shape (whatever the switch says)   // d in {32, 64, 128}, inner % d == 0, and the bit(s) `which` switched on
 int chain_rows_per_block(int d);

@@ -474,13 +474,11 @@ extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_em
   const size_t lds = (cfg->G + 16) * sizeof(float);
   const bool wide = cfg->G >= 512 && cfg->B <= 512;   // few rows, many candidates: 1024-thread workgroups
   float* cnt_rows = loss_rows + cfg->B;  // loss_rows buffer is [2*B]: losses then counts
-  static const int unr_env = getenv("UR_SCORER_UNR") ? atoi(getenv("UR_SCORER_UNR")) : 0;   // tuning aid
-  const int unr = unr_env ? unr_env : 8;
 #define GO2(T, U, NT) hipLaunchKernelGGL((scorer_loss_fwd_kernel<T, U, NT>), dim3(cfg->B), dim3(NT), lds, st, *cfg, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, user_bias, item_bias,            \
                                  (const long long*)user_id, scores, loss_rows, cnt_rows)
 #define GO1(T, U) do { if (wide) GO2(T, U, 1024); else GO2(T, U, 256); } while (0)
-#define GO(T) do { if (unr == 2) GO1(T, 2); else if (unr == 16) GO1(T, 16); else if (unr == 4) GO1(T, 4); else GO1(T, 8); } while (0)
+#define GO(T) GO1(T, 8)   /* 8 candidate rows in flight per lane group (2 / 4 / 16 measured slower: round 1) */
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;
@@ -544,7 +542,7 @@ static unsigned* fused_counter() {
 }
 
 extern "C" int ur_gather_dot_loss_fused_supported(const UrLossCfg* cfg) {
-  if (!cfg || getenv("UR_LOSS_NO_FUSE")) return 0;
+  if (!cfg) return 0;
   if (!(cfg->loss_type == UR_LOSS_BPR || cfg->loss_type == UR_LOSS_BCE || cfg->loss_type == UR_LOSS_CCL)) return 0;
   return ((size_t)cfg->G * cfg->d + 2 * (size_t)cfg->G + 16) * sizeof(float) <= 32 * 1024 && cfg->d % 4 == 0 && cfg->d <= 512;
 }

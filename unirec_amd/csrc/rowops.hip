@@ -256,7 +256,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float4* __restrict__ 
                                                      float4* dx_out, float* __restrict__ part, const int* __restrict__ m_dev,
                                                      const int* __restrict__ out_rows, DropSpec in_drop, DropSpec out_drop,
                                                      float4* __restrict__ dx_drop) {
-  UR_PRIO_MAIN();
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const float inv_d = 1.0f / (float)(d4 * 4);
@@ -358,8 +357,7 @@ int ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* g
   const DropSpec di = in_drop ? *in_drop : DropSpec{}, d_o = out_drop ? *out_drop : DropSpec{};
   if (d_o.thresh && (!dx_drop || out_rows)) return fail(UR_ERR_ARG, "ln_bwd: out_drop needs dx_drop and no out_rows");
   const int tpr = pick_tpr(d), groups = 256 / tpr;
-  static const int rows_env = getenv("UR_LN_BWD_ROWS") ? atoi(getenv("UR_LN_BWD_ROWS")) : 4;   // tuning aid: rows per lane group
-  int blocks = cdiv(M, groups * rows_env);
+  int blocks = cdiv(M, groups * 4);   // 4 rows per lane group
   if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
   const size_t lds = (size_t)groups * 2 * (d + 4) * sizeof(float);
   if (blocks < 1) blocks = 1;

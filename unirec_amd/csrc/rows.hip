@@ -163,154 +163,9 @@ __global__ __launch_bounds__(256) void heads_write_kernel(const unsigned* __rest
 }
 
 
-// ---- the whole plan in ONE launch for small batches (n <= SMALL_N): one workgroup of 16 waves runs the same
-// wave-granular stable LSD sort with its histograms in LDS and the key / value ping-pong in (L2-resident) global
-// scratch.  16 launches (~120 us of launch floors at n = 28 K) become one (~25 us).
-constexpr int SMALL_N_MID = 32768;            // (= SMALL_N; named apart because the chunk-sort kernels are defined further up)
-constexpr int SMALL_IT = 32;                  // 64-key groups per wave
-constexpr int SMALL_N = 16 * SMALL_IT * 64;   // = 32768
-constexpr int SW = 16;   // waves in the single workgroup
-
-// exclusive prefix of v over the 1024 threads of the block (scratch: 16 ints of LDS); returns the prefix, total in *tot
-__device__ __forceinline__ int block_excl_scan_1024(int v, int* scratch, int* tot) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int u = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += u;
-  }
-  if (lane == 63) scratch[w] = inc;
-  __syncthreads();
-  int base = 0, total = 0;
-#pragma unroll
-  for (int i = 0; i < SW; ++i) {
-    const int x = scratch[i];
-    base += i < w ? x : 0;
-    total += x;
-  }
-  __syncthreads();
-  if (tot) *tot = total;
-  return base + inc - v;
-}
-
-__global__ __launch_bounds__(1024) void plan_small_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
-                                                          long long n_b, int W, long long n_local, int passes, unsigned* keys0,
-                                                          unsigned* keys1, int* vals0, int* vals1, int* __restrict__ uniq_idx,
-                                                          int* __restrict__ seg_start, int* __restrict__ n_uniq_dev,
-                                                          int* __restrict__ owner_counts) {
-  __shared__ int cnt[SW][RADIX];
-  __shared__ int scratch[SW];
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  const int n = (int)(n_a + n_b);
-  const int cw = (((n + SW - 1) / SW + 63) / 64) * 64;   // keys per wave (multiple of 64)
-  const int base = w * cw, iters = cw / 64;
-  for (int i = tid; i < n; i += 1024) {
-    const long long id = (i < n_a) ? (long long)ids_a[i] : ids_b[i - n_a];
-    keys0[i] = (W > 1) ? (id ? (unsigned)((id % W) * n_local + id / W + 1) : 0u) : (unsigned)id;
-    vals0[i] = i;
-  }
-  if (owner_counts) for (int i = tid; i < W; i += 1024) owner_counts[i] = 0;
-  __syncthreads();
-  unsigned* kin = keys0; unsigned* kout = keys1;
-  int* vin = vals0; int* vout = vals1;
-  const unsigned long long lt = lanemask_lt();
-  for (int p = 0; p < passes; ++p) {
-    const int shift = 8 * p;
-    // the wave's whole chunk goes to registers first: SMALL_IT independent loads in flight instead of one
-    // L2 round trip per 64 keys (a single workgroup has no other waves to hide that latency behind)
-    unsigned rk[SMALL_IT];
-    int rv[SMALL_IT];
-#pragma unroll
-    for (int it = 0; it < SMALL_IT; ++it) {
-      const int i = base + it * 64 + lane;
-      const bool active = it < iters && i < n;
-      rk[it] = active ? kin[i] : 0u;
-      rv[it] = active ? vin[i] : 0;
-    }
-    for (int i = lane; i < RADIX; i += 64) cnt[w][i] = 0;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < SMALL_IT; ++it) {
-      const int i = base + it * 64 + lane;
-      if (it < iters && i < n) atomicAdd(&cnt[w][(rk[it] >> shift) & 0xFF], 1);
-    }
-    __syncthreads();
-    {   // exclusive scan in (digit, wave) order: thread t owns entries 4t .. 4t+3 of the [RADIX][SW] ordering
-      int v[4], s = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = tid * 4 + k;
-        v[k] = cnt[e % SW][e / SW];
-        s += v[k];
-      }
-      int run = block_excl_scan_1024(s, scratch, nullptr);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = tid * 4 + k;
-        cnt[e % SW][e / SW] = run;
-        run += v[k];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < SMALL_IT; ++it) {
-      if (it < iters) {   // wave-uniform
-        const int i = base + it * 64 + lane;
-        const bool active = i < n;
-        const unsigned key = rk[it];
-        const unsigned dgt = (key >> shift) & 0xFF;
-        const unsigned long long m = match_digit(dgt, active);
-        const int rank = __popcll(m & lt);
-        int pos = 0;
-        if (active) pos = cnt[w][dgt] + rank;
-        __builtin_amdgcn_wave_barrier();
-        if (active && rank == 0) cnt[w][dgt] += __popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        if (active) {
-          kout[pos] = key;
-          vout[pos] = rv[it];
-        }
-      }
-    }
-    __syncthreads();   // workgroup-scope release/acquire: the 16 waves share one CU and its vector L1
-    unsigned* tk = kin; kin = kout; kout = tk;
-    int* tv = vin; vin = vout; vout = tv;
-  }
-  // ---- segment heads (keys and their left neighbours preloaded, same reason as above)
-  unsigned hk[SMALL_IT];
-  unsigned hbits = 0;   // bit `it`: this lane's key of group `it` starts a run
-  int c = 0;
-#pragma unroll
-  for (int it = 0; it < SMALL_IT; ++it) {
-    const int i = base + it * 64 + lane;
-    const bool active = it < iters && i < n;
-    hk[it] = active ? kin[i] : 0u;
-    const unsigned prev = (active && i > 0) ? kin[i - 1] : 0u;
-    const bool head = active && (i == 0 || hk[it] != prev);
-    hbits |= head ? (1u << it) : 0u;
-    c += __popcll(__ballot(head));
-  }
-  int total = 0;
-  const int mine = block_excl_scan_1024(lane == 0 ? c : 0, scratch, &total);
-  int run = __shfl(mine, 0, 64);   // lane 0 holds the wave's exclusive prefix
-#pragma unroll
-  for (int it = 0; it < SMALL_IT; ++it) {
-    const bool head = (hbits >> it) & 1u;
-    const unsigned long long m = __ballot(head);
-    if (head) {
-      const int seg = run + __popcll(m & lt);
-      uniq_idx[seg] = (int)hk[it];
-      seg_start[seg] = base + it * 64 + lane;
-      if (owner_counts) atomicAdd(&owner_counts[hk[it] / n_local], 1);
-    }
-    run += __popcll(m);
-  }
-  if (tid == 0) {
-    *n_uniq_dev = total;
-    seg_start[total] = n;
-  }
-}
+// small batches (n <= SMALL_N ids: every training batch of the C2 / C4 / C5 shapes) take the chunk-sort path further down
+constexpr int SMALL_N = 32768;
+constexpr int SMALL_N_MID = SMALL_N;          // (named apart because the chunk-sort kernels are defined further up)
 
 // ------------------------------------------------------------------------------- segment reduce
 constexpr int MAXV = 4;
@@ -398,54 +253,16 @@ __device__ __forceinline__ void long_walk(float4 (&acc)[MAXV], int first, int en
   }
 }
 
-// FUSE: the optimizer update of the row rides behind its segment sum (ur_rows_reduce_adam): uniq_grad never exists in memory, one
-// launch instead of two, and the row's (w, m, v) loads are issued BEFORE the walk over its lookups, so the two dependent chains
-// (plan entry -> position -> gradient row; plan entry -> table row) run side by side.
-struct RowsFuse {
-  AdamK a;
-  float4 *table, *mom, *var;
-  int* last_step;
-  const float* scale_dev;
-};
-__device__ __forceinline__ void lazy_replay4(float4& w, float4& m, float4& v, int from, int to, const AdamK& a);
-template <int TPR>
-__device__ __forceinline__ void fuse_update(const RowsFuse& f, long long row, int last, float4 (&w)[MAXV], float4 (&m)[MAXV], float4 (&v)[MAXV],
-                                            const float4 (&gr)[MAXV], float scale, float bc1, float bc2s, int d4, int t) {
-#pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
-    const int c = t + k * TPR;
-    if (c < d4) {
-      if (f.last_step) lazy_replay4(w[k], m[k], v[k], last, f.a.step - 1, f.a);
-      opt_elem(w[k].x, m[k].x, v[k].x, gr[k].x * scale, f.a, bc1, bc2s);
-      opt_elem(w[k].y, m[k].y, v[k].y, gr[k].y * scale, f.a, bc1, bc2s);
-      opt_elem(w[k].z, m[k].z, v[k].z, gr[k].z * scale, f.a, bc1, bc2s);
-      opt_elem(w[k].w, m[k].w, v[k].w, gr[k].w * scale, f.a, bc1, bc2s);
-      f.table[row * d4 + c] = w[k];
-      f.mom[row * d4 + c] = m[k];
-      f.var[row * d4 + c] = v[k];
-    }
-  }
-  if (f.last_step && t == 0) f.last_step[row] = f.a.step;
-}
-
 // One lane group per unique id; positions are summed in sorted (= lookup) order.  Runs longer than LONG_SEG are
 // handled by all groups of the block together: group g takes positions s+g, s+g+groups, ..., the partial sums are
 // combined through LDS in group order -- still a fixed summation order, so results are bit-reproducible.
-template <int TPR, bool FUSE = false>
+template <int TPR>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict__ uniq_idx, const int* __restrict__ seg_start,
                                                           const int* __restrict__ sorted_pos, const int* __restrict__ n_uniq_dev,
                                                           long long n, const float4* __restrict__ rows_a, long long n_a,
                                                           const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G,
-                                                          int d4, float4* __restrict__ out, int zero_tail, RowsFuse fz = RowsFuse{}) {
-  UR_PRIO_MAIN();
+                                                          int d4, float4* __restrict__ out, int zero_tail) {
   constexpr int groups = 256 / TPR;
-  float fscale = 1.f, bc1 = 1.f, bc2s = 1.f;
-  if constexpr (FUSE) {
-    fscale = fz.scale_dev ? *fz.scale_dev : 1.0f;
-    if (fscale < 0.f) return;   // update guard: NaN loss, the whole step is skipped (see dense_adam_kernel)
-    bc1 = 1.f - powf(fz.a.b1, (float)fz.a.step);
-    bc2s = sqrtf(1.f - powf(fz.a.b2, (float)fz.a.step));
-  }
   __shared__ float4 part[groups][MAXV * TPR];
   __shared__ int long_list[256];
   __shared__ int long_cnt;
@@ -474,16 +291,6 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long frow = uniq_idx[u];
-    float4 fw[MAXV], fm[MAXV], fv[MAXV];
-    int flast = 0;
-    if constexpr (FUSE) {      // the row's state: in flight during the walk below
-      flast = fz.last_step ? fz.last_step[frow] : fz.a.step - 1;
-#pragma unroll
-      for (int k = 0; k < MAXV; ++k) {
-        const int c = min(t + k * TPR, d4 - 1);
-        fw[k] = fz.table[frow * d4 + c]; fm[k] = fz.mom[frow * d4 + c]; fv[k] = fz.var[frow * d4 + c];
-      }
-    }
     if (frow != 0) {
       const int s = seg_start[u], e = seg_start[u + 1];
       if (e - s > LONG_SEG) continue;                      // pass 2
@@ -491,10 +298,6 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
         long_walk<TPR, 1>(acc, s, e, 1, sorted_pos, n_a, rows_a, coef_b, vec_b, G, d4, t);
       else
         for (int q = s; q < e; ++q) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
-    }
-    if constexpr (FUSE) {
-      if (frow != 0) fuse_update<TPR>(fz, frow, flast, fw, fm, fv, acc, fscale, bc1, bc2s, d4, t);
-      continue;
     }
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
@@ -530,31 +333,17 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
       for (int k = 0; k < MAXV; ++k) part[g][k * TPR + t] = acc[k];
       __syncthreads();
       if (g == 0) {
-        float4 rs[MAXV];
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
           const int c = t + k * TPR;
-          rs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (c < d4) {
             float4 r = part[0][k * TPR + t];
             for (int gg = 1; gg < groups; ++gg) {
               const float4 x = part[gg][k * TPR + t];
               r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
             }
-            rs[k] = r;
-            if constexpr (!FUSE) out[ul * d4 + c] = r;
+            out[ul * d4 + c] = r;
           }
-        }
-        if constexpr (FUSE) {
-          const long long lrow = uniq_idx[ul];
-          const int ll = fz.last_step ? fz.last_step[lrow] : fz.a.step - 1;
-          float4 lw[MAXV], lm[MAXV], lv[MAXV];
-#pragma unroll
-          for (int k = 0; k < MAXV; ++k) {
-            const int c = min(t + k * TPR, d4 - 1);
-            lw[k] = fz.table[lrow * d4 + c]; lm[k] = fz.mom[lrow * d4 + c]; lv[k] = fz.var[lrow * d4 + c];
-          }
-          fuse_update<TPR>(fz, lrow, ll, lw, lm, lv, rs, fscale, bc1, bc2s, d4, t);
         }
       }
       __syncthreads();
@@ -734,13 +523,11 @@ __device__ __forceinline__ void lazy_row_apply(const LazyRow& r, float4& w, floa
 }
 
 // MODE 0: update with gradient (catch-up first when last_step != null); MODE 1: catch-up only (to step-1)
-// (a device function so that one launch can run both modes: `bid` / `nblk` are the workgroup's index and the number of workgroups of its mode)
 template <int TPR, int MODE>
 __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restrict__ table, float4* __restrict__ mom,
                                                  float4* __restrict__ var, int* __restrict__ last_step,
                                                  const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev, long long n_max,
                                                  const float4* __restrict__ grad, int d4, const float* __restrict__ scale_dev,
-                                                 const int* __restrict__ busy_idx, const int* __restrict__ busy_n_dev, int busy_max,
                                                  int bid, int nblk) {
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
@@ -799,20 +586,6 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
     if (row == 0) continue;
     const int last = last_step ? last_step[row] : a.step - 1;
     if (MODE == 1 && last >= a.step - 1) continue;   // already there (updated by the step in between, or caught up ahead of time)
-    if (MODE == 1 && busy_idx != nullptr) {
-      // catch-up AHEAD of the step in flight: rows that step reads and updates (the sorted unique list of its plan) are its own
-      // business -- its update replays them first; everything else can take its zero-gradient steps now.  Branch-free lower bound,
-      // every lane of the group walks the same addresses (one broadcast load per probe, the list sits in L2).
-      const int nb = min(*busy_n_dev, busy_max);
-      int lo = 0;
-      for (int len = nb; len > 0;) {
-        const int half = len >> 1;
-        const bool right = busy_idx[lo + half] < (int)row;
-        lo = right ? lo + half + 1 : lo;
-        len = right ? len - half - 1 : half;
-      }
-      if (lo < nb && busy_idx[lo] == (int)row) continue;
-    }
     if (MODE == 1 && last == 0 && a.wd == 0.f) {   // never updated: m = v = 0, every zero-gradient step is a no-op
       if (t == 0) last_step[row] = a.step - 1;
       continue;
@@ -847,36 +620,9 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
                                                           float4* __restrict__ var, int* __restrict__ last_step,
                                                           const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
                                                           long long n_max, const float4* __restrict__ grad, int d4,
-                                                          const float* __restrict__ scale_dev, const int* __restrict__ busy_idx = nullptr,
-                                                          const int* __restrict__ busy_n_dev = nullptr, int busy_max = 0) {
-  UR_PRIO_MAIN();
-  sparse_adam_body<TPR, MODE>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, busy_idx, busy_n_dev, busy_max,
-                              (int)blockIdx.x, (int)gridDim.x);
+                                                          const float* __restrict__ scale_dev) {
+  sparse_adam_body<TPR, MODE>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, (int)blockIdx.x, (int)gridDim.x);
 }
-// The update of THIS step's rows and the catch-up of the NEXT batch's rows in one launch: workgroups [0, nb_update) run the update,
-// the rest bring the next batch's rows -- minus the ones being updated here (binary search in this step's sorted row list) -- to the
-// state after this step.  Both halves are chains of dependent random accesses (plan entry -> last_step -> row); as two launches they
-// queue up behind each other at the tail of every step (44 + 45 us in situ), as one they overlap.
-template <int TPR>
-__global__ __launch_bounds__(256) void sparse_adam_dual_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
-                                                               float4* __restrict__ var, int* __restrict__ last_step,
-                                                               const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
-                                                               long long n_max, const float4* __restrict__ grad, int d4,
-                                                               const float* __restrict__ scale_dev, int nb_update,
-                                                               const int* __restrict__ next_idx, const int* __restrict__ next_n_dev,
-                                                               long long next_max) {
-  if ((int)blockIdx.x < nb_update) {
-    sparse_adam_body<TPR, 0>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, nullptr, nullptr, 0,
-                             (int)blockIdx.x, nb_update);
-  } else {
-    AdamK an = a;
-    an.step = a.step + 1;   // MODE 1 brings a row to "after step an.step - 1" = after THIS step
-    sparse_adam_body<TPR, 1>(an, table, mom, var, last_step, next_idx, next_n_dev, next_max, nullptr, d4, nullptr, uniq_idx, n_uniq_dev,
-                             (int)n_max, (int)blockIdx.x - nb_update, (int)gridDim.x - nb_update);
-  }
-}
-
-// catch-up of a contiguous block of rows to `step` (flush before evaluation / checkpoint)
 template <int TPR>
 __global__ __launch_bounds__(256) void lazy_flush_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
                                                          float4* __restrict__ var, int* __restrict__ last_step, long long row0,
@@ -1202,8 +948,7 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
   vbuf[passes & 1] = sorted_pos;       // after `passes` swaps the result sits in index (passes & 1)
   vbuf[(passes & 1) ^ 1] = w.vals_tmp;
   static const bool no_small = getenv("UR_PLAN_MULTI") != nullptr;   // test hook: force the multi-launch path
-  static const bool one_wg = getenv("UR_PLAN_ONEWG") != nullptr;     // the one-workgroup radix sort instead of the chunk-sort path
-  if (n <= SMALL_N && !no_small && !one_wg) {
+  if (n <= SMALL_N && !no_small) {
     const int nch = cdiv(n, MID_CHUNK);
     hipLaunchKernelGGL(plan_chunk_sort_kernel, dim3(nch), dim3(1024), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b, W,
                        n_local, w.keys0, w.vals_tmp, owner_counts_dev);
@@ -1213,12 +958,6 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
     UR_LAUNCH_CHECK();
     hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(heads_grid(n)), dim3(1024), 0, st, (const int*)w.keys1, (int)n, uniq_idx, seg_start, n_uniq_dev,
                        owner_counts_dev, n_local);
-    UR_LAUNCH_CHECK();
-    return UR_OK;
-  }
-  if (n <= SMALL_N && !no_small) {
-    hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(1024), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b, W,
-                       n_local, passes, kbuf[0], kbuf[1], vbuf[0], vbuf[1], uniq_idx, seg_start, n_uniq_dev, owner_counts_dev);
     UR_LAUNCH_CHECK();
     return UR_OK;
   }
@@ -1323,40 +1062,9 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
   return UR_OK;
 }
 
-extern "C" int ur_rows_reduce_adam(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, const int32_t* uniq_idx,
-                                   const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n,
-                                   const float* rows_a, int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d,
-                                   const float* grad_scale_dev, void* stream) {
-  UR_REQUIRE(cfg != nullptr && cfg->step >= 1, UR_ERR_ARG, "ur_rows_reduce_adam: cfg");
-  UR_REQUIRE(table && m && v && uniq_idx && seg_start && sorted_pos && n_uniq_dev, UR_ERR_ARG, "ur_rows_reduce_adam: null pointer");
-  UR_REQUIRE(n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_rows_reduce_adam: n=%lld n_a=%lld", (long long)n, (long long)n_a);
-  UR_REQUIRE((rows_a || n_a == 0) && ((coef_b && vec_b && G > 0) || n_a == n), UR_ERR_ARG, "ur_rows_reduce_adam: missing source");
-  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512, UR_ERR_ARG, "ur_rows_reduce_adam: d=%d", d);
-  hipStream_t st = as_stream(stream);
-  ProfScope ps(PC_ADAM, st, (double)n * d * 4.0 * 2 + (double)n * d * 4.0 * 6);
-  RowsFuse fz{AdamK{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo}, (float4*)table, (float4*)m,
-              (float4*)v, last_step, grad_scale_dev};
-  const int tpr = pick_tpr(d), groups = 256 / tpr;
-  int blocks = cdiv(n, groups);
-  if (blocks > 8192) blocks = 8192;
-#define GO(T) hipLaunchKernelGGL((rows_reduce_kernel<T, true>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
-                                 (long long)n, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,                \
-                                 (float4*)nullptr, 0, fz)
-  switch (tpr) {
-    case 4: GO(4); break;
-    case 8: GO(8); break;
-    case 16: GO(16); break;
-    default: GO(32); break;
-  }
-#undef GO
-  UR_LAUNCH_CHECK();
-  return UR_OK;
-}
-
 static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* grad, int d,
-                              const float* scale, hipStream_t st, const int32_t* busy_idx = nullptr,
-                              const int32_t* busy_n_dev = nullptr, int busy_max = 0) {
+                              const float* scale, hipStream_t st) {
   ProfScope ps(PC_ADAM, st, (double)n_max * d * 4.0 * 7);
   AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
   a.lb1 = cfg->beta1 > 0.f ? (float)log2((double)cfg->beta1) : -1e30f;
@@ -1366,8 +1074,7 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
 #define GO(T, MD) hipLaunchKernelGGL((sparse_adam_kernel<T, MD>), dim3(blocks), dim3(256), 0, st, a, (float4*)table, (float4*)m, \
-                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale, \
-                                     busy_idx, busy_n_dev, busy_max)
+                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale)
 #define SW(MD)            \
   switch (tpr) {          \
     case 4: GO(4, MD); break;   \
@@ -1397,40 +1104,6 @@ extern "C" int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m,
   UR_REQUIRE(table && m && v && uniq_idx && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_sparse_adam_rows: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_sparse_adam_rows: d=%d n_max=%lld", d, (long long)n_max);
   return launch_sparse_adam(0, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, uniq_grad, d, grad_scale_dev, as_stream(stream));
-}
-
-extern "C" int ur_sparse_adam_rows_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
-                                           const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad,
-                                           int32_t d, const float* grad_scale_dev, const int32_t* next_uniq_idx,
-                                           const int32_t* next_n_uniq_dev, int64_t next_n_max, void* stream) {
-  int rc = check_adam(cfg, "ur_sparse_adam_rows_catchup");
-  if (rc) return rc;
-  UR_REQUIRE(table && m && v && last_step && uniq_idx && n_uniq_dev && uniq_grad && next_uniq_idx && next_n_uniq_dev, UR_ERR_ARG,
-             "ur_sparse_adam_rows_catchup: null pointer");
-  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0 && next_n_max > 0 && n_max < (1LL << 31), UR_ERR_ARG,
-             "ur_sparse_adam_rows_catchup: d=%d n_max=%lld next_n_max=%lld", d, (long long)n_max, (long long)next_n_max);
-  hipStream_t st = as_stream(stream);
-  ProfScope ps(PC_ADAM, st, (double)n_max * d * 4.0 * 7);
-  AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
-  a.lb1 = cfg->beta1 > 0.f ? (float)log2((double)cfg->beta1) : -1e30f;
-  a.lb2 = cfg->beta2 > 0.f ? (float)log2((double)cfg->beta2) : -1e30f;
-  const int tpr = pick_tpr(d), groups = 256 / tpr;
-  int nb0 = cdiv(n_max, groups * ((d / 4 <= tpr) ? 4 : 1));   // the update's fast path takes four rows per lane group
-  int nb1 = cdiv(next_n_max, groups);
-  if (nb0 > 8192) nb0 = 8192;
-  if (nb1 > 8192) nb1 = 8192;
-#define GO(T) hipLaunchKernelGGL((sparse_adam_dual_kernel<T>), dim3(nb0 + nb1), dim3(256), 0, st, a, (float4*)table, (float4*)m, (float4*)v, \
-                                 last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)uniq_grad, d / 4, grad_scale_dev, nb0,     \
-                                 next_uniq_idx, next_n_uniq_dev, (long long)next_n_max)
-  switch (tpr) {
-    case 4: GO(4); break;
-    case 8: GO(8); break;
-    case 16: GO(16); break;
-    default: GO(32); break;
-  }
-#undef GO
-  UR_LAUNCH_CHECK();
-  return UR_OK;
 }
 
 extern "C" int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
@@ -1468,18 +1141,6 @@ extern "C" int ur_rows_filter_touched(const int32_t* uniq_idx, const int32_t* n_
                      out_idx, out_n_dev);
   UR_LAUNCH_CHECK();
   return UR_OK;
-}
-
-extern "C" int ur_lazy_adam_catchup_ahead(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
-                                          const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
-                                          const int32_t* busy_idx, const int32_t* busy_n_dev, int64_t busy_max, void* stream) {
-  int rc = check_adam(cfg, "ur_lazy_adam_catchup_ahead");
-  if (rc) return rc;
-  UR_REQUIRE(table && m && v && last_step && uniq_idx && n_uniq_dev && busy_idx && busy_n_dev, UR_ERR_ARG, "ur_lazy_adam_catchup_ahead: null pointer");
-  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0 && busy_max > 0 && busy_max < (1LL << 31), UR_ERR_ARG,
-             "ur_lazy_adam_catchup_ahead: d=%d n_max=%lld busy_max=%lld", d, (long long)n_max, (long long)busy_max);
-  return launch_sparse_adam(1, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, nullptr, d, nullptr, as_stream(stream), busy_idx,
-                            busy_n_dev, (int)busy_max);
 }
 
 extern "C" int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, int64_t row0,

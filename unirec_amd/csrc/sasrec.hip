@@ -56,7 +56,6 @@ static LayerP layer_ptrs(const float* base, const Layout& l, int i) {
 // ---- workspace carving (float units, every region 64-float aligned)
 struct LayerWs {
   float *qkv, *lse, *ctx, *a, *ahat, *rstd1, *h1, *y, *yhat, *rstd2;
-  float* u;                            // act(h1), written by the forward chain kernel (the dense_2 weight-gradient GEMM reads it)
   float *wqkvT, *woT, *w1T, *w2T;
   float *g_tf, *g_ta, *g_h1, *g_qkv;   // backward: LN-backward outputs (FFN / attention block), d h1, d qkv
   float *g_tfd, *g_tad;                // hidden dropout on: dropout-masked g_tf / g_ta (what the block's GEMMs consume)
@@ -87,7 +86,7 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
   for (int i = 0; i < c.n_layers; ++i) {
     LayerWs& lw = w.layer[i];
     lw.qkv = take(M * 3 * d); lw.lse = take(attn_lse_floats(c.B, c.n_heads, c.L)); lw.ctx = take(M * d);
-    lw.a = take(M * d); lw.ahat = take(M * d); lw.rstd1 = take(M); lw.h1 = take(M * I); lw.u = take(M * I);
+    lw.a = take(M * d); lw.ahat = take(M * d); lw.rstd1 = take(M); lw.h1 = take(M * I);
     lw.y = take(M * d); lw.yhat = take(M * d); lw.rstd2 = take(M);
     lw.wqkvT = take(3 * d * d); lw.woT = take(d * d); lw.w1T = take(I * d); lw.w2T = take(I * d);
     // backward scratch that the weight-gradient GEMMs read: per layer, written once per backward pass, so those GEMMs
@@ -300,13 +299,6 @@ struct SideCtx {
   bool late_join = false;      // ur_sasrec_side_publish: the next ur_sasrec_fwd joins `done` itself, after its first launch
   bool ok = false;
 };
-// Does the forward chain keep act(h1) ([M, inner]: 44 MB of stores per full layer at C5) for the FFN-2 weight gradient, or does that GEMM
-// (side stream) apply the activation to h1 on the fly?  Default: on the fly -- the stores sat on the forward pass, i.e. on the critical
-// path, the recomputation sits on the side stream (bit-identical; step -2 us).  UR_SASREC_SAVE_U=1: keep it (rounds 1-2a).
-static bool save_u() {
-  static const bool v = getenv("UR_SASREC_SAVE_U") && atoi(getenv("UR_SASREC_SAVE_U")) == 1;
-  return v;
-}
 // test aid (UR_SIDE_TEST_DELAY_US): a kernel that spins for that long on the side stream -- it widens every window in which the main stream
 // could touch what the side stream has not finished with (tools/race_runs.sh, tests/test_fallback_paths_gpu.py)
 __global__ void side_delay_kernel(long long cycles) {
@@ -320,18 +312,11 @@ SideCtx* side_ctx(bool even_if_disabled = false) {
     const char* e = getenv("UR_SASREC_SIDE");
     if (e && atoi(e) == 0) return nullptr;
     SideCtx* c = new SideCtx();
-    // UR_SASREC_SIDE_PRIO=low / high: queue priority of the side stream relative to the caller's (tuning aid; default: the same)
-    const char* pr = getenv("UR_SASREC_SIDE_PRIO");
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (pr && (pr[0] == 'l' || pr[0] == 'h')) {
-      if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest) != hipSuccess) return nullptr;
-    } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
     // Events that order two streams of ONE device need no system-scope fence: a plain event makes the recording stream write back
     // and invalidate its caches for the host and for other devices, a 6-7 us bubble in front of the next kernel of the main stream at
-    // every fork (measured: five per backward pass).  UR_SASREC_EVENT_FENCE=1 restores the default events.
-    const char* fe = getenv("UR_SASREC_EVENT_FENCE");
-    const unsigned evf = hipEventDisableTiming | ((fe && atoi(fe) == 1) ? 0u : (unsigned)hipEventDisableSystemFence);
+    // every fork (measured: five per backward pass).
+    const unsigned evf = hipEventDisableTiming | (unsigned)hipEventDisableSystemFence;
     for (auto& ev : c->ev)
       if (hipEventCreateWithFlags(&ev, evf) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c->done, evf) != hipSuccess) return nullptr;
@@ -360,13 +345,6 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
   const int* mv = compact ? w.m_valid : nullptr;
   const int* sbase = compact ? w.seq_base : nullptr;
   const int* spad = compact ? w.seq_pad : nullptr;
-  static const bool join_top = getenv("UR_SIDE_JOIN_TOP") && atoi(getenv("UR_SIDE_JOIN_TOP"));   // a late join in FRONT of the first launch (tuning aid)
-  if (join_top)
-    if (SideCtx* sc = side_ctx(true); sc && sc->join_pending && sc->late_join) {
-      UR_HIP(hipStreamWaitEvent(st, sc->done, 0));
-      sc->join_pending = false;
-      sc->late_join = false;
-    }
   if (compact) {
     hipLaunchKernelGGL(compact_plan_kernel, dim3(cdiv(c.B, CP_SEQS)), dim3(1024), 0, st, item_seq, c.B, c.L, w.tok_full, w.seq_base, w.seq_pad,
                        w.last_row, w.m_valid);
@@ -411,29 +389,19 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       const float* x_last = x + (long long)(c.L - 1) * d;   // rows (b, L-1): a strided view, leading dimension L*d
       int ld_last = c.L * d;
       // the one-query attention projects its own queries (and, compact rows, gathers the last rows on the way): no gather launch, no
-      // B x d x d GEMM launch in front of it.  UR_SASREC_NO_QFUSE=1: the stand-alone launches
-      static const bool qfuse = getenv("UR_SASREC_NO_QFUSE") == nullptr;
-      if (compact) {   // the last rows are not equally spaced any more: gather them
-        if (!qfuse) {
-          hipLaunchKernelGGL(gather_rows_idx_kernel, dim3(cdiv((long long)B * d, 256)), dim3(256), 0, st, x, w.last_row, B, d, w.x_last);
-          UR_LAUNCH_CHECK();
-        }
+      // B x d x d GEMM launch in front of it
+      if (compact) {   // the last rows are not equally spaced any more: the attention kernel gathers them into x_last
         x_last = w.x_last;
         ld_last = d;
       }
       g.A = x; g.lda = d; g.W = p.wqkv + (long long)d * d; g.ldw = d; g.C = lw.qkv + d; g.ldc = 3 * d; g.M = M; g.N = 2 * d; g.K = d;
       g.bias = p.bqkv + d; g.m_dev = mv;
       if (!proj_done && (rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
-      if (qfuse) {
+      {
         AttnQProj qp{};
         qp.x = x; qp.xrow = compact ? w.last_row : nullptr; qp.xstride = c.L; qp.xoff = c.L - 1;
         qp.wq = p.wqkv; qp.bq = p.bqkv; qp.q_out = w.q_last; qp.x_out = compact ? w.x_last : nullptr;
         if ((rc = attn_last_fwd(nullptr, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st, sbase, spad, &d_attn, &qp))) return rc;
-      } else {
-        g = GemmArgs{};
-        g.A = x_last; g.lda = ld_last; g.W = p.wqkv; g.ldw = d; g.C = w.q_last; g.ldc = d; g.M = B; g.N = d; g.K = d; g.bias = p.bqkv;
-        if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
-        if ((rc = attn_last_fwd(w.q_last, lw.qkv, item_seq, B, c.L, d, c.n_heads, lw.ctx, w.lse_last, st, sbase, spad, &d_attn))) return rc;
       }
       if (chain_last) {
         // the B last rows through the same row-chain kernel as the full layers: out-projection + LN + feed-forward + LN in one launch
@@ -446,8 +414,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
         ca.M = B; ca.I = I; ca.act = c.act; ca.eps = c.eps;
         ca.drop_out = site_spec(c, i, DROP_SITE_OUT, nullptr, c.L, c.L - 1);   // row b of these [B, .] tiles is token (b, L-1)
         ca.drop_ffn = site_spec(c, i, DROP_SITE_FFN, nullptr, c.L, c.L - 1);
-        static const bool no_split = getenv("UR_SASREC_NO_SPLIT") != nullptr;   // the one-workgroup-per-row-block chain for the last rows too
-        if (!no_split && I / d >= 2 && cdiv(B, chain_rows_per_block(d)) <= CHAIN_SPLIT_MAX_BLOCKS) {
+        if (I / d >= 2 && cdiv(B, chain_rows_per_block(d)) <= CHAIN_SPLIT_MAX_BLOCKS) {
           ca.split_part = w.split_part;
           return chain_ffn_fwd_split(ca, d, st);
         }
@@ -478,7 +445,6 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       ca.wo = p.wo; ca.bo = p.bo; ca.g1 = p.g1; ca.b1ln = p.b1ln; ca.w1 = p.w1; ca.b1 = p.b1; ca.w2 = p.w2; ca.b2 = p.b2;
       ca.g2 = p.g2; ca.b2ln = p.b2ln;
       ca.a = lw.a; ca.ahat = lw.ahat; ca.rstd1 = lw.rstd1; ca.h1 = lw.h1; ca.y = lw.y; ca.yhat = lw.yhat; ca.rstd2 = lw.rstd2;
-      ca.u = save_u() ? lw.u : nullptr;
       ca.M = M; ca.m_dev = mv; ca.I = I; ca.act = c.act; ca.eps = c.eps;
       ca.drop_out = site_spec(c, i, DROP_SITE_OUT, tokmap);
       ca.drop_ffn = site_spec(c, i, DROP_SITE_FFN, tokmap);
@@ -538,13 +504,11 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   const bool chain_bwd = chain_supported(d, I, CHAIN_BWD) && c.p_hidden == 0.f;
   const bool chain_proj = chain_supported(d, I, CHAIN_PROJ) && c.p_hidden == 0.f;
   const bool chain_last_bwd = chain_supported(d, I, CHAIN_LAST_BWD) && c.p_hidden == 0.f;
-  const bool have_u = chain_supported(d, I, CHAIN_FWD) && save_u();   // the forward pass of the full layers went through chain_ffn_fwd and kept act(h1): lw.u is valid
   bool ln0_done = false;                // the embedding LayerNorm backward already ran in the epilogue of the bottom layer's last GEMM
   // LayerNorm backward in the epilogue of the GEMM that produces its input gradient (EPI_ADD_LNBWD): the attention block's
   // LayerNorm behind the d FFN-1 GEMM, the embedding LayerNorm behind the bottom layer's projection-gradient GEMM.  Two launches and
   // two [M, d] round trips less per full layer.  Not with hidden dropout (a second, masked copy of the result would be needed).
-  static const bool no_lnfuse = getenv("UR_SASREC_NO_LNFUSE") && atoi(getenv("UR_SASREC_NO_LNFUSE"));
-  const bool lnfuse = !no_lnfuse && c.p_hidden == 0.f && d <= 128;
+  const bool lnfuse = c.p_hidden == 0.f && d <= 128;
   auto lnfuse_part = [&](int slot) { return w.chain_part + (long long)slot * 4 * w.chain_blocks * d; };   // slot n_layers: LN0
   ReduceBatch rb;                       // second stages of all split reductions: one launch at the end
   float* tn_cur = w.tn_ws;
@@ -574,14 +538,10 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   // arm(): the next gemm_nt / attention launch of the main stream carries the next fork's event as its own completion event
   // (UR_LAUNCH_EV) -- the fork behind it then needs no hipEventRecord (a marker packet = ~5 us of idle main stream).  Only in front of a
   // launch that is followed by fork() with queued GEMMs and nothing else on the main stream in between.
-  // which forks are held back (tuning aid, UR_SASREC_HOLD bit mask): 1 = the top (last-row) layer's products wait for the next fork,
-  // 2 = a full layer's dW_2 / dW_1 / dW_o wait for its dW_qkv (one launch behind the attention backward instead of one beside it)
-  static const int hold = getenv("UR_SASREC_HOLD") ? atoi(getenv("UR_SASREC_HOLD")) : 2;
-  static const bool stop_events = !(getenv("UR_SASREC_STOP_EVENTS") && atoi(getenv("UR_SASREC_STOP_EVENTS")) == 0);
   hipEvent_t armed = nullptr;
   const bool timing_producers = prof_brackets(PC_GEMM_NT) || prof_brackets(PC_ATTN_BWD);   // (their brackets would include the event: see prof_brackets)
   auto arm = [&]() {
-    if (stop_events && !timing_producers && sc && n_fork < 24) { armed = sc->ev[n_fork]; g_stop_event = armed; }
+    if (!timing_producers && sc && n_fork < 24) { armed = sc->ev[n_fork]; g_stop_event = armed; }
   };
   bool main_done_armed = false, main_done_carried = false;
   auto fork = [&]() -> int {
@@ -602,7 +562,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       static const int delay_us = getenv("UR_SIDE_TEST_DELAY_US") ? atoi(getenv("UR_SIDE_TEST_DELAY_US")) : 0;
       if (delay_us > 0 && n_fork == 1) hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(64), 0, s2, (long long)delay_us * 100);
     }
-    if (gemm_tn_grouped()) {   // every queued product in ONE launch (gemm_tn_group_kernel): few token splits each, small partial tiles
+    {   // every queued product in ONE launch (gemm_tn_group_kernel): few token splits each, small partial tiles
       TnReq rq[12];
       for (int i = 0; i < n_pend; ++i) {
         const PendingTn& t = pend[i];
@@ -610,20 +570,12 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       }
       int rc2 = gemm_tn_group(rq, n_pend, s2, &rb);
       if (rc2) return rc2;
-    } else
-    for (int i = 0; i < n_pend; ++i) {
-      const PendingTn& t = pend[i];
-      int rc2 = gemm_tn(t.P, t.ldp, t.Q, t.ldq, t.T, t.R, t.C, t.pro_act, t.act, t.out, t.ldo, t.bias_out, t.ws, s2, &rb, t.t_dev);
-      if (rc2) return rc2;
     }
     n_pend = 0;
     // everything queued for the final reduction so far is complete in the side stream's order once these GEMMs are (their own partials;
     // partial sums written by main-stream launches in front of this fork's event): reduced HERE, behind the first fork's GEMMs, it runs
     // in the gap the side stream has before the next fork instead of at the tail of the pass (UR_SASREC_EARLY_REDUCE=0: all at the end)
-    static const bool early_reduce = !(getenv("UR_SASREC_EARLY_REDUCE") && atoi(getenv("UR_SASREC_EARLY_REDUCE")) == 0);
-    // (behind EVERY fork, UR_SASREC_EARLY_REDUCE_ALL=1: +25 us -- the second flush, 45 MB, runs beside the attention backward)
-    static const int early_from = getenv("UR_SASREC_EARLY_REDUCE_ALL") && atoi(getenv("UR_SASREC_EARLY_REDUCE_ALL")) == 1 ? 24 : 1;
-    if (early_reduce && s2 != st && n_fork >= 1 && n_fork <= early_from && defer_join) {
+    if (s2 != st && n_fork == 1 && defer_join) {   // (behind EVERY fork: +25 us -- the later flushes run beside the attention backward)
       int rc2 = reduce_batch(rb, s2);
       if (rc2) return rc2;
     }
@@ -655,8 +607,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     else UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
     if (compact) {   // padded positions: zero gradient rows (the valid rows are written whole by the bottom layer's projection-gradient launch)
       tb.zero2_ptr = d_emb_rows; tb.zero2_n = (long long)M * d;
-      static const bool pad_only = !(getenv("UR_SASREC_ZERO_ALL") && atoi(getenv("UR_SASREC_ZERO_ALL")) == 1);
-      if (pad_only) { tb.zero2_pad = w.seq_pad; tb.zero2_L = c.L; tb.zero2_d = d; }
+      tb.zero2_pad = w.seq_pad; tb.zero2_L = c.L; tb.zero2_d = d;
     }
     if (mv) { tb.copy_src = mv; tb.copy_dst = w.m_valid + 16; }
     for (int i = 0; i < c.n_layers; ++i) {
@@ -705,7 +656,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       g.C = d_emb_rows; g.xhat = w.x0hat; g.rstd = w.rstd0; g.gamma = dense + lay.off[1]; g.out_rows = compact ? w.tok_full : nullptr;
       g.ln_part = lnfuse_part(c.n_layers);
       // the LAST launch of the pass on the main stream: it carries `main_done` (what the side stream's reductions wait for) itself
-      if (stop_events && !timing_producers && sc && defer_join && n_fork > 0) { g_stop_event = sc->main_done; main_done_armed = true; }
+      if (!timing_producers && sc && defer_join && n_fork > 0) { g_stop_event = sc->main_done; main_done_armed = true; }
       if ((rc2 = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc2;
       main_done_carried = main_done_armed && g_stop_event == nullptr;
       g_stop_event = nullptr;
@@ -742,8 +693,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
         cb.ahat = lw.ahat; cb.rstd1 = lw.rstd1; cb.g1 = p.g1; cb.woT = lw.woT;
         cb.g_tf = lw.g_tf; cb.g_h1 = lw.g_h1; cb.g_ta = lw.g_ta; cb.g_ctx = w.g_ctx; cb.part = part;
         cb.M = B; cb.I = I; cb.act = c.act;
-        static const bool no_split = getenv("UR_SASREC_NO_SPLIT") != nullptr;
-        if (!no_split && I / d >= 2 && nblk <= CHAIN_SPLIT_MAX_BLOCKS) {   // inner split over workgroups (see chain_ffn_fwd_split)
+        if (I / d >= 2 && nblk <= CHAIN_SPLIT_MAX_BLOCKS) {   // inner split over workgroups (see chain_ffn_fwd_split)
           cb.split_part = w.split_part + chain_split_part_floats(B, d, I);
           if ((rc = chain_ffn_bwd_split(cb, d, st))) return rc;
         } else if ((rc = chain_ffn_bwd(cb, d, st))) return rc;
@@ -782,12 +732,12 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = B; g.N = d; g.K = d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
       }
-      if (!(hold & 1)) arm();
+      arm();
       if ((rc = attn_last_bwd(w.q_last, lw.qkv, item_seq, lw.ctx, w.g_ctx, w.lse_last, B, c.L, d, c.n_heads, w.dq_last, lw.g_qkv, st, sbase, spad, &d_attn))) return rc;
       // dWq from the B last rows, dWk/dWv from all rows
       if ((rc = tn(w.dq_last, d, compact ? w.x_last : x_in + (long long)(c.L - 1) * d, compact ? d : c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
       if ((rc = tn(lw.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4]))) return rc;
-      if (!(hold & 1) && (rc = fork())) return rc;
+      if ((rc = fork())) return rc;
       g = GemmArgs{};   // g_x = [dK dV] Wkv  for every row
       g.A = lw.g_qkv + d; g.lda = 3 * d; g.W = lw.wqkvT + d; g.ldw = 3 * d; g.C = w.g_y; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = 2 * d;
       if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
@@ -820,12 +770,10 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       rb.add(part + d, 4 * d, nblk, d, d, G + o[15], d);
       rb.add(part + 2 * d, 4 * d, nblk, d, d, G + o[8], d);
       rb.add(part + 3 * d, 4 * d, nblk, d, d, G + o[9], d);
-      if ((rc = have_u ? tn(lw.g_tf, d, lw.u, I, M, d, I, 0, 0, G + o[12], I, G + o[13])
-                       : tn(lw.g_tf, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13])))
-        return rc;
+      if ((rc = tn(lw.g_tf, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;   // (the activation is applied to h1 on the operand)
       if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
       if ((rc = tn(lw.g_ta, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
-      if (!(hold & 2) && (rc = fork())) return rc;
+      // (dW_2, dW_1, dW_o wait for dW_qkv: one launch BEHIND the attention backward, see the unfused path below)
       if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad, &d_attn))) return rc;
       if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
       if ((rc = fork())) return rc;
@@ -836,27 +784,22 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     if ((rc = ln_bwd(w.g_y, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, M, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb, mv,
                      nullptr, nullptr, &d_ffn, lw.g_tfd)))
       return rc;
-    // (the forward chain kernel saved act(h1): no activation recompute on the operand)
-    if ((rc = have_u ? tn(lw.g_tfd, d, lw.u, I, M, d, I, 0, 0, G + o[12], I, G + o[13])
-                     : tn(lw.g_tfd, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13])))
-      return rc;
+    if ((rc = tn(lw.g_tfd, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
     GemmArgs g{};
     g.A = lw.g_tfd; g.lda = d; g.W = lw.w2T; g.ldw = d; g.C = lw.g_h1; g.ldc = I; g.M = M; g.m_dev = mv; g.N = I; g.K = d;
     g.aux = lw.h1; g.ldaux = I; g.act = c.act;
     // dW_2 and dW_1 are forked right behind this GEMM (round 3): they run beside the d FFN-1 and out-projection GEMMs and are done before
-    // the attention backward starts; dW_o waits for dW_qkv (`hold`): the attention backward, which loses most beside a weight-gradient
-    // launch (116 us against 49 alone), has the chip to itself.  UR_SASREC_EARLY_FORK=0: dW_2, dW_1, dW_o together behind the next GEMM
-    static const bool early_fork = !(getenv("UR_SASREC_EARLY_FORK") && atoi(getenv("UR_SASREC_EARLY_FORK")) == 0);
-    if (early_fork) arm();
+    // the attention backward starts; dW_o waits for dW_qkv: the attention backward, which loses most beside a weight-gradient launch
+    // (116 us against 49 alone), has the chip to itself (profiles/r03_a_dw_schedule.txt)
+    arm();
     if ((rc = gemm_nt(g, PRO_NONE, EPI_MUL_DACT, st))) return rc;
     if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
-    if (early_fork && (rc = fork())) return rc;
+    if ((rc = fork())) return rc;
     g = GemmArgs{};
     g.A = lw.g_h1; g.lda = I; g.W = lw.w1T; g.ldw = I; g.C = w.g_a; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = I; g.aux = lw.g_tf; g.ldaux = d;
     if (lnfuse) {
       // ---- d FFN-1 GEMM + residual + the attention block's LayerNorm backward in its epilogue: g_ta directly
       g.C = lw.g_ta; g.xhat = lw.ahat; g.rstd = lw.rstd1; g.gamma = p.g1; g.ln_part = lnfuse_part(i);
-      if (!early_fork && !(hold & 2)) arm();
       if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD_LNBWD, st))) return rc;
       if (rb.full(2) && (rc = reduce_batch(rb, st))) return rc;
       rb.add(g.ln_part, 2 * d, gemm_nt_lnbwd_tiles(M), d, d, G + o[8], d);
@@ -868,17 +811,10 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
                        nullptr, nullptr, &d_out, lw.g_tad)))
         return rc;
     }
-    if ((rc = tn(lw.g_tad, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
-    // every fork is an event record on the main stream = a ~5 us bubble in front of its next kernel: dW2, dW1 and dWo go together, here
-    // (the side stream is still busy with the top layer's batch when the first two become ready; UR_SASREC_EARLY_FORK=1: round-2a order)
-    if (!early_fork && !(hold & 2) && (rc = fork())) return rc;
+    if ((rc = tn(lw.g_tad, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;   // (queued: launched with dW_qkv)
     g = GemmArgs{};
     g.A = lw.g_tad; g.lda = d; g.W = lw.woT; g.ldw = d; g.C = w.g_ctx; g.ldc = d; g.M = M; g.m_dev = mv; g.N = d; g.K = d;
-    if (n_pend > 0 && !(hold & 2)) arm();
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
-    // fork dWo now: it then runs underneath the attention backward instead of queueing up behind it at the very end of
-    // the pass, where the side stream would finish after the main one (one more event, ~30 us off the tail)
-    if (!(hold & 2) && (rc = fork())) return rc;
     arm();
     if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad, &d_attn))) return rc;
     if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;

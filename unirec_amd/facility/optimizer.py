@@ -18,7 +18,7 @@ from .. import ops
 
 class SparseDenseAdam:
     def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=None, eps=None, grad_clip=None,
-                 table_mode="lazy_dense", algo="adam", overlap_dense_join=True):
+                 table_mode="lazy_dense", algo="adam", overlap_dense_join=True, dense_side=None):
         """algo: the torch.optim rule the reference's Trainer._build_optimizer would construct (trainer.py:134-152):
         adam (default) / adamw / sgd / adagrad / rmsprop; betas / eps None = torch's defaults for that rule.
 
@@ -27,7 +27,7 @@ class SparseDenseAdam:
         another step follows at once -- leaves that to the model's next forward pass.  In that window everything that reads the dense
         parameters or this optimizer's dense state through the public surface joins first (``model.state_dict() / load_state_dict() /
         train() / eval()``, ``optimizer.state_dict() / flush()``); code that reads ``model.dense_flat.data`` or ``dense_m / dense_v``
-        directly calls ``model.join_side_updates()`` first.  ``UR_DENSE_ADAM_SIDE=late / join / 0`` overrides the per-call choice."""
+        directly calls ``model.join_side_updates()`` first.  ``dense_side="late" / "join" / "0"`` overrides the per-call choice."""
         assert table_mode in ("lazy_dense", "rowwise")
         if algo not in ops.OPT_ALGOS:
             raise ValueError(f"unknown optimizer rule {algo!r}")
@@ -57,23 +57,12 @@ class SparseDenseAdam:
                     st["last"] = None      # fullsoftmax: a dense [N,d] gradient every step -> plain dense Adam on this table
                 self.tables[name] = st
         self._plans = {}
-        import os
-        self._fuse = os.environ.get("UR_ROWS_FUSE") == "1"
-        # row update + next batch's catch-up as ONE launch (ur_sparse_adam_rows_catchup).  Off by default: measured at C5 the merged launch
-        # takes what the two take together (both halves are bound by the same random-row traffic) and the step is 8 us slower
-        self._merge = os.environ.get("UR_ADAM_MERGE", "0") == "1"
-        # the dense half of the step on the encoder's side stream, right behind the dense-gradient reductions it waits for (no cross-stream
-        # wait in front of it), joined by the next forward pass after its first launch: "late" (default) / "join" (joined at the end of
-        # step()) / "0" (round 2a: the main stream waits for the reductions, then runs the dense half itself)
-        self._dense_side = os.environ.get("UR_DENSE_ADAM_SIDE", "")      # "" = per call: step(late_join=...) -> "late" / "join"
-        self._nofence = os.environ.get("UR_PLAN_FORK_FENCE") != "1"   # the main -> plan-stream fork through an event without the system-scope fence
-        self._rewait = os.environ.get("UR_PLAN_REWAIT") == "1"   # tuning aid: plan_batch waits for the plan's event even if this stream already has
-        self._filter = os.environ.get("UR_CATCHUP_FILTER", "1") != "0"   # tail catch-up over the next batch's rows WITH history only
-        # where the next batch's rows take their missed zero-gradient steps (lazy_dense): "tail" (default) = on the main stream right
-        # after this step's row update, under the tail of the dense-gradient stream the main stream would otherwise wait for idle;
-        # "side" = on the plan's side stream under the whole step in flight (measured slower: its VALU work lands on the forward
-        # pass); "" / "0" = at the head of the next step (round 1)
-        self._ahead = {"0": "", "1": "tail"}.get(os.environ.get("UR_CATCHUP_AHEAD", "tail"), os.environ.get("UR_CATCHUP_AHEAD", "tail"))
+        # dense_side: "" = per call (step(late_join=...) -> "late" / "join"); "late" / "join" / "0" force one mode ("0": the dense half on
+        # the main stream after it has waited for the reductions).  The next batch's rows take their missed zero-gradient steps
+        # (lazy_dense) on the main stream right after this step's row update -- under the tail of the dense-gradient stream, and only the
+        # rows WITH optimizer history (filtered next to the plan, on its stream) -- or, without a prefetched plan, at the head of the
+        # next step (`plan_batch`)
+        self._dense_side = dense_side or ""
         self._prefetched, self._side = None, None
         self._scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [0] sumsq, [1] clip coef
         self._sumsq_ws = torch.empty(2048, dtype=torch.float32, device=dev)
@@ -136,32 +125,13 @@ class SparseDenseAdam:
         req = self._plan_inputs(item_seq, item_id, user_id)
         bufs = {name: ops.rows_plan_alloc((a.numel() if a is not None else 0) + (b.numel() if b is not None else 0),
                                           a.numel() if a is not None else 0, self.model.device) for name, (a, b) in req.items()}
-        if self._nofence:
-            ops.stream_wait_stream(self._side, main)   # the ids may still be in flight (H2D copy) on the main stream; `last` is being updated there
-        else:
-            self._side.wait_stream(main)
+        # (through an event without the system-scope fence: ~2 us cheaper on the recording stream than Stream.wait_stream)
+        ops.stream_wait_stream(self._side, main)   # the ids may still be in flight (H2D copy) on the main stream; `last` is being updated there
         ahead = None
         with torch.cuda.stream(self._side):
             plans = {name: ops.rows_plan(a, b, self.tables[name]["w"].shape[0], out=bufs[name]) for name, (a, b) in req.items()}
-            if self.table_mode == "lazy_dense" and self._ahead == "side" and self.t > 0:
-                # the next batch's rows take their missed zero-gradient steps HERE, under the current step, instead of at the head
-                # of the next one (where the forward waits for them: 15-130 us of VALU work per step, growing with the revisit gap).
-                # With a step in flight (plan_batch called, step() not yet) the target state is "after that step" and the rows the
-                # step itself touches are left to its update; a zero-gradient step depends on the step index only, so the result
-                # is bit-identical to catching up afterwards.
-                in_flight = bool(self._plans)
-                ahead = self.t + (1 if in_flight else 0)
-                cfg = self._cfg(ahead + 1)
-                for name, pl in plans.items():
-                    st = self.tables[name]
-                    if st["last"] is None:
-                        continue
-                    if in_flight and name in self._plans:
-                        ops.lazy_adam_catchup_ahead(cfg, st["w"], st["m"], st["v"], st["last"], pl, self._plans[name])
-                    else:
-                        ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
             filtered = None
-            if self.table_mode == "lazy_dense" and self._ahead == "tail" and self.wd == 0.0 and self._filter:
+            if self.table_mode == "lazy_dense" and self.wd == 0.0:
                 # rows of the next batch that have any optimizer history at all: the catch-up at the tail of this step only walks those
                 # (a row first touched by the step in flight is missed here and needs no catch-up: its update leaves it current)
                 filtered = {name: ops.rows_filter_touched(pl, self.tables[name]["last"]) for name, pl in plans.items()
@@ -181,7 +151,7 @@ class SparseDenseAdam:
             # (the tail catch-up of the previous step() already made THIS stream wait for THIS event: a second wait is one more barrier
             # packet in front of the forward pass, ~5 us of idle main stream at every step boundary)
             pw = getattr(self, "_pre_waited", None)
-            if self._rewait or pw is None or pw[0] is not pre[2] or pw[1] != cur.cuda_stream:
+            if pw is None or pw[0] is not pre[2] or pw[1] != cur.cuda_stream:
                 cur.wait_event(pre[2])
             self._pre_waited = None
         caught_up = False
@@ -197,13 +167,13 @@ class SparseDenseAdam:
                 if st["last"] is not None:
                     ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
 
-    def _catchup_prefetched(self, skip=()):
+    def _catchup_prefetched(self):
         """step(), after the row update: the NEXT batch's rows (plan already made by `prefetch_plan`) take their zero-gradient steps
         up to and including this one now, on the main stream, while the dense-gradient reductions are still running on the side
         stream -- the same launch `plan_batch` would make at the head of the next step, moved into a slot where the main stream
         has nothing else to do."""
         pre = self._prefetched
-        if pre is None or self._ahead != "tail" or self.table_mode != "lazy_dense" or pre[4] is not None:
+        if pre is None or self.table_mode != "lazy_dense" or pre[4] is not None:
             return
         cur = torch.cuda.current_stream()
         cur.wait_event(pre[2])
@@ -211,7 +181,7 @@ class SparseDenseAdam:
         cfg = self._cfg(self.t + 1)
         for name, pl in pre[1].items():
             st = self.tables[name]
-            if st["last"] is not None and name not in skip:
+            if st["last"] is not None:
                 if pre[5] is not None and name in pre[5]:
                     pl = pre[5][name]
                 ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
@@ -259,10 +229,6 @@ class SparseDenseAdam:
         cfg = self._cfg(self.t)
         reduced = {}
         guard = getattr(model, "loss_guard", None)
-        # without clipping nothing needs the row gradients but the row update itself: segment sum + optimizer rule can be ONE launch per
-        # table (ur_rows_reduce_adam, UR_ROWS_FUSE=1).  Off by default: measured at C5 the fused launch takes what the two take together
-        # (37.3 us vs 11.2 + 26.3: the update is bound by the random 512-byte rows of w, m, v, not by the launch or the gradient round trip)
-        fuse = self.grad_clip is None and self._fuse
         for name, st in self.tables.items():
             ids_a, rows, ids_b, coef, vec, G = self._collect(name)
             if ids_a is None and ids_b is None:
@@ -273,9 +239,6 @@ class SparseDenseAdam:
                     raise RuntimeError("lazy_dense mode: call optimizer.plan_batch(...) before the forward pass")
                 pl = ops.rows_plan(ids_a.contiguous() if ids_a is not None else None, ids_b, st["w"].shape[0])
             d = st["w"].shape[1]
-            if fuse and name not in model.dense_table_grads:
-                ops.rows_reduce_adam(cfg, st["w"], st["m"], st["v"], pl, rows, coef, vec, G, st["last"], guard)
-                continue
             reduced[name] = (pl, ops.rows_reduce(pl, rows, coef, vec, G, d, zero_tail=self.grad_clip is not None))
         # fullsoftmax: the table's gradient is dense; the encoder's row-sparse part is folded into it
         dense_tables = dict(model.dense_table_grads)
@@ -290,21 +253,11 @@ class SparseDenseAdam:
         if self.grad_clip is None:
             # no global norm to wait for: the row-sparse half goes first, under the encoder's dense-gradient reductions that
             # may still be running on the side stream (model.defer_dense_join), then the join, then the dense half
-            # (lazy_dense, next batch's plan already made: its rows' catch-up rides in the same launch as this step's row update)
-            pre = self._prefetched
-            merge = (pre is not None and self._ahead == "tail" and self.table_mode == "lazy_dense" and pre[4] is None and self._merge)
-            if merge:
-                torch.cuda.current_stream().wait_event(pre[2])
-            merged = set()
             for name, (pl, ug) in reduced.items():
                 st = self.tables[name]
-                if merge and st["last"] is not None and name in pre[1]:
-                    ops.sparse_adam_rows_catchup(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale, pre[1][name])
-                    merged.add(name)
-                else:
-                    ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
+                ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
             sparse_done = True
-            self._catchup_prefetched(skip=merged)
+            self._catchup_prefetched()
         side = None
         if (self.grad_clip is None and dense_side in ("late", "join") and getattr(model, "_deferred_dense_grad", None) is not None
                 and model._deferred_dense_grad.numel()):

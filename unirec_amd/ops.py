@@ -395,25 +395,6 @@ def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False) -> t
     return out
 
 
-def rows_reduce_adam(cfg, table, m, v, pl: RowsPlan, rows_a, coef_b, vec_b, G, last_step=None, grad_scale=None):
-    """rows_reduce + sparse_adam_rows in one launch (no uniq_grad tensor): include/unirec_amd.h: ur_rows_reduce_adam."""
-    _chk(table, torch.float32, "table")
-    _chk(rows_a, torch.float32, "rows_a", allow_none=True)
-    _chk(coef_b, torch.float32, "coef_b", allow_none=True)
-    _chk(vec_b, torch.float32, "vec_b", allow_none=True)
-    _chk(last_step, torch.int32, "last_step", allow_none=True)
-    check(lib.ur_rows_reduce_adam(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos),
-                                  _p(pl.n_uniq), pl.n, _p(rows_a), pl.n_a, _p(coef_b), _p(vec_b), int(G), table.shape[1], _p(grad_scale),
-                                  _stream()), "ur_rows_reduce_adam")
-
-
-# --------------------------------------------------------------------------------------------- optimizer
-OPT_ALGOS = {"adam": 0, "adamw": 1, "sgd": 2, "adagrad": 3, "rmsprop": 4}
-# torch's defaults for what the reference does not pass (trainer.py:134-152): (beta1, beta2 | alpha, eps)
-OPT_DEFAULTS = {"adam": (0.9, 0.999, 1e-8), "adamw": (0.9, 0.999, 1e-8), "sgd": (0.0, 0.0, 0.0), "adagrad": (0.0, 0.0, 1e-10),
-                "rmsprop": (0.0, 0.99, 1e-8)}
-
-
 def adam_cfg(lr, step, wd=0.0, b1=None, b2=None, eps=None, algo="adam") -> UrAdamCfg:
     """optimizer-step configuration (`algo`: adam / adamw / sgd / adagrad / rmsprop, torch.optim semantics)"""
     d1, d2, de = OPT_DEFAULTS[algo]
@@ -448,26 +429,10 @@ def rows_filter_touched(pl: RowsPlan, last_step) -> RowsPlan:
     return out
 
 
-def sparse_adam_rows_catchup(cfg, table, m, v, pl: RowsPlan, uniq_grad, last_step, grad_scale, next_pl: RowsPlan):
-    """sparse_adam_rows for this step's rows + lazy_adam_catchup of the next batch's rows (to the state after this step), one launch"""
-    _chk(last_step, torch.int32, "last_step")
-    check(lib.ur_sparse_adam_rows_catchup(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
-                                          _p(uniq_grad), table.shape[1], _p(grad_scale), _p(next_pl.uniq_idx), _p(next_pl.n_uniq),
-                                          next_pl.n, _stream()), "ur_sparse_adam_rows_catchup")
-
-
 def lazy_adam_catchup(cfg, table, m, v, last_step, pl: RowsPlan):
     _chk(last_step, torch.int32, "last_step")
     check(lib.ur_lazy_adam_catchup(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
                                    table.shape[1], _stream()), "ur_lazy_adam_catchup")
-
-
-def lazy_adam_catchup_ahead(cfg, table, m, v, last_step, pl: RowsPlan, busy: RowsPlan):
-    """catch-up of `pl`'s rows to "after step cfg.step - 1" while step cfg.step - 1 is still in flight on another stream: the rows of
-    `busy` (that step's plan) are left to the step's own update (ur_lazy_adam_catchup_ahead)."""
-    _chk(last_step, torch.int32, "last_step")
-    check(lib.ur_lazy_adam_catchup_ahead(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
-                                         table.shape[1], _p(busy.uniq_idx), _p(busy.n_uniq), busy.n, _stream()), "ur_lazy_adam_catchup_ahead")
 
 
 def lazy_adam_flush(cfg, table, m, v, last_step, row0=0, n=None):

@@ -266,15 +266,6 @@ def lazy_adam_catchup(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, las
     ops.lazy_adam_catchup(ops.adam_cfg(lr, step, weight_decay, algo=algo), table, m, v, last_step, pl)
 
 
-@custom_op(f"{NS}::lazy_adam_catchup_ahead", mutates_args=("table", "m", "v", "last_step"))
-def lazy_adam_catchup_ahead(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, last_step: torch.Tensor, uniq_idx: torch.Tensor,
-                            n_uniq: torch.Tensor, busy_idx: torch.Tensor, busy_n: torch.Tensor, lr: float, step: int,
-                            weight_decay: float = 0.0, algo: str = "adam") -> None:
-    pl = _plan(uniq_idx, None, None, n_uniq, uniq_idx.numel(), 0)
-    busy = _plan(busy_idx, None, None, busy_n, busy_idx.numel(), 0)
-    ops.lazy_adam_catchup_ahead(ops.adam_cfg(lr, step, weight_decay, algo=algo), table, m, v, last_step, pl, busy)
-
-
 @custom_op(f"{NS}::lazy_adam_flush", mutates_args=("table", "m", "v", "last_step"))
 def lazy_adam_flush(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, last_step: torch.Tensor, lr: float, step: int,
                     weight_decay: float = 0.0, algo: str = "adam") -> None:
@@ -287,7 +278,7 @@ def dense_adam(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torc
     ops.dense_adam(ops.adam_cfg(lr, step, weight_decay, algo=algo), param, grad, m, v, grad_scale)
 
 
-for _op in (sparse_adam_rows, lazy_adam_catchup, lazy_adam_catchup_ahead, lazy_adam_flush, dense_adam):
+for _op in (sparse_adam_rows, lazy_adam_catchup, lazy_adam_flush, dense_adam):
     _op.register_fake(lambda *a, **k: None)
 
 
@@ -336,7 +327,6 @@ HEADER_TO_OP = {
     "ur_rows_reduce": "rows_reduce",
     "ur_sparse_adam_rows": "sparse_adam_rows",
     "ur_lazy_adam_catchup": "lazy_adam_catchup",
-    "ur_lazy_adam_catchup_ahead": "lazy_adam_catchup_ahead",
     "ur_lazy_adam_flush": "lazy_adam_flush",
     "ur_dense_adam": "dense_adam",
     "ur_full_rank": "full_rank",
@@ -373,6 +363,4 @@ NOT_OPS = {
     "ur_gather_dot_loss_fused_supported": _QUERY,
     "ur_gather_dot_loss_fwd_bwd": "fusion of the two ops gather_dot_loss_fwd + gather_dot_loss_bwd (both registered) for the graph-free training step: a scheduling choice, not a new op",
     "ur_rows_filter_touched": "index bookkeeping of the lazy optimizer schedule (which rows of the next plan have any history): no arithmetic, a scheduling aid",
-    "ur_sparse_adam_rows_catchup": "fusion of the two ops sparse_adam_rows + lazy_adam_catchup (both registered) into one launch: a scheduling choice of the optimizer, not a new op",
-    "ur_rows_reduce_adam": "fusion of the two ops rows_reduce + sparse_adam_rows (both registered): a scheduling choice of the optimizer, not a new op",
 }
