@@ -395,6 +395,13 @@ def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False) -> t
     return out
 
 
+# --------------------------------------------------------------------------------------------- optimizer
+OPT_ALGOS = {"adam": 0, "adamw": 1, "sgd": 2, "adagrad": 3, "rmsprop": 4}
+# torch's defaults for what the reference does not pass (trainer.py:134-152): (beta1, beta2 | alpha, eps)
+OPT_DEFAULTS = {"adam": (0.9, 0.999, 1e-8), "adamw": (0.9, 0.999, 1e-8), "sgd": (0.0, 0.0, 0.0), "adagrad": (0.0, 0.0, 1e-10),
+                "rmsprop": (0.0, 0.99, 1e-8)}
+
+
 def adam_cfg(lr, step, wd=0.0, b1=None, b2=None, eps=None, algo="adam") -> UrAdamCfg:
     """optimizer-step configuration (`algo`: adam / adamw / sgd / adagrad / rmsprop, torch.optim semantics)"""
     d1, d2, de = OPT_DEFAULTS[algo]
