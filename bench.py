@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the steady_state and e2e legs that follow the timed region")
     ap.add_argument("--all-configs", action="store_true", help="also measure BASELINE configs C2, C3 and C4's encoder (step time, "
                     "dominant kernel class and its roofline fraction each) into the same JSON line")
+    ap.add_argument("--sharded-w1", action="store_true", help="--gpus 1 only: step through the multi-GPU code path (facility/distributed.py, "
+                    "fixed-capacity row exchange with world = 1, collectives degenerate) instead of the plain optimizer: its overhead")
     ap.add_argument("--no-selfcheck", action="store_true", help="world > 1: skip the W-rank == 1-rank check that runs before the timed region")
     ap.add_argument("--selfcheck-items", type=int, default=1_000_000)
     ap.add_argument("--dropout", type=float, default=0.0, help="hidden_dropout_prob = attn_dropout_prob (the reference's SASRec.yaml "
@@ -491,17 +493,16 @@ def main():
     # The batches (their own generator: the order does not change a value) are made BEFORE the model and the optimizer state: those are
     # ~150 GB of device fills, and the warm-up steps then start on a device that has just been busy.  A device left idle for tens of
     # milliseconds runs the next 20-60 steps 2-5 % slower (tools/warm_probe.py: IDLE_MS = 5 / 50 / 500 in front of a 20-step region:
-    # +0.01 / +0.035 / +0.07 ms per step); ~30 batches of a dozen tiny launches each are such a gap.  UR_BENCH_ORDER=old: round-2a order.
-    old_order = os.environ.get("UR_BENCH_ORDER") == "old"
-    batches = None if old_order else make_batches()
+    # +0.01 / +0.035 / +0.07 ms per step); ~30 batches of a dozen tiny launches each are such a gap.
+    batches = make_batches()
     torch.manual_seed(2022 + rank)
     cfg = model_config(a, str(device))
     selfcheck = None
-    if world > 1:
+    if world > 1 or a.sharded_w1:
         # the SAME optimizer Trainer(config, model) builds under torch.distributed (facility/trainer.py -> facility/distributed.py)
         from unirec_amd.facility.distributed import ShardedSparseDenseAdam
         from unirec_amd.sharded import shard_rows
-        if not a.no_selfcheck:
+        if world > 1 and not a.no_selfcheck:
             try:
                 selfcheck = multi_gpu_selfcheck(a, device, rank, world)
             except AssertionError as e:      # a parity failure is reported in the line (and on stderr), the timing still runs
@@ -514,7 +515,8 @@ def main():
         opt = ShardedSparseDenseAdam(model, rank, world, lr=1e-3, table_mode=a.table_mode,   # table never exists in one piece
                                      full_rows={"item_embedding": a.n_items})
         model.train()
-        info = {"parallelism": f"dp{world} + embedding rows sharded {world}-way (3 all-to-alls + 1 flat all-reduce per step)"}
+        info = {"parallelism": f"dp{world} + embedding rows sharded {world}-way (3 fixed-capacity all-to-alls + 1 flat all-reduce per step; "
+                               f"transport: {'library RCCL communicators' if opt._native else 'torch.distributed' if world > 1 else 'none (world 1)'})"}
 
         def step_fn(batch, nxt=None):
             return opt.train_step(batch, None if a.no_prefetch else nxt)
@@ -539,8 +541,6 @@ def main():
             opt.step(late_join=nxt is not None)   # as Trainer.train_step does: the next step's forward pass joins the side-stream half
             return loss
 
-    if batches is None:
-        batches = make_batches()
 
     def barrier():
         if world > 1:
@@ -565,10 +565,7 @@ def main():
     # switched off HERE, in front of the warm-up steps, and nothing is collected: 35 ms of idle device between the warm-up steps and the
     # clock cost the first 20 steps +0.04 ms each (tools/warm_probe.py: 0.746 vs 0.725 for the first 20-step region, 0.705 from the second on)
     import gc
-    if old_order:
-        gc.collect()
-    else:
-        gc.freeze()     # (no collection here either: it would be 35 ms of idle device right in front of the warm-up steps)
+    gc.freeze()     # (no collection here either: it would be 35 ms of idle device right in front of the warm-up steps)
     gc.disable()
     _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
     _lib.lib.ur_prof_reset()
@@ -580,16 +577,13 @@ def main():
             _lib.lib.ur_prof_enable(0 if a.no_prof else 1)
         loss = step_fn(batches[i % len(batches)], batches[(i + 1) % len(batches)])
     barrier()
-    t_gap0 = time.perf_counter()
     _lib.lib.ur_prof_enable(0)
     warm = prof_read()
-    t_gap1 = time.perf_counter()
     # (a host-side check of the copied scalar: torch.isfinite() here was the first use of four elementwise kernels -- 20-100 ms of
     # code-object loading with the device idle, right in front of the timed region, and an idle device runs its next steps slower)
     import math
     if loss is not None and not math.isfinite(float(loss.detach().item())):
         raise SystemExit("non-finite loss in warm-up")
-    t_gap2 = time.perf_counter()
     dom = max(warm, key=lambda k: warm[k]["ms"]) if (not a.no_prof and any(v["launches"] for v in warm.values())) else None
     # ---- timed region: exactly --steps steps.  Only the dominant kernel class is bracketed (HIP events on the launch
     # stream), and only on every PROF_EVERY-th step, so the measurement perturbs `value` by ~1 %.
@@ -598,8 +592,6 @@ def main():
         _lib.lib.ur_prof_set_mask(1 << names.index(dom))
     barrier()
     t0 = time.perf_counter()
-    if os.environ.get("UR_BENCH_GAP"):
-        print(f"[bench] idle device between warm-up and the timed region: {1e3*(t0-t_gap0):.2f} ms (prof_read {1e3*(t_gap1-t_gap0):.2f}, isfinite {1e3*(t_gap2-t_gap1):.2f})", file=sys.stderr)
     for i in range(a.steps):
         if dom is not None:
             _lib.lib.ur_prof_enable(1 if i % PROF_EVERY == 0 else 0)

@@ -313,14 +313,22 @@ int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_uniq_dev, co
 int ur_shard_exchange_rows(const float* table, const int32_t* req_ids, int32_t world, int32_t cap, int32_t d, float* rows_ws,
                            float* compact, int32_t transport, void* stream);
 int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_of_slot, int32_t world, int32_t cap, int32_t d,
-                            float* send_ws, float* grads_in, int32_t transport, void* stream);
+                            const float* loss_out, const int32_t* flags_dev, float* send_ws, float* grads_in, int32_t transport,
+                            void* stream);
+/* Slot 0 of every block is reserved padding (a block holds cap - 1 keys); in the gradient exchange it carries the sender's step flags
+ * [loss is NaN (loss_out[2] < 0, as the loss kernels publish it), capacity overflow (flags_dev[0] & 1), loss_out[0], 1] to every owner.
+ * ur_shard_step_flags sums them in source-rank order: out4 = [gradient scale for the update kernels: 1 / world (DDP's mean,
+ * trainer.py:346) or -1 = skip the step on every rank, mean loss over the ranks (trainer.py:353 gather_for_metrics(loss).mean()),
+ * ranks with a NaN loss, ranks with an overflow]. */
+int ur_shard_step_flags(const float* grads_in, int32_t world, int32_t cap, int32_t d, float* out4, void* stream);
 /* The library's RCCL communicator (one per process, one process per GPU; RCCL is resolved at run time from the librccl.so.1 the process has
- * loaded).  ur_comm_world: -1 no RCCL library, 0 not initialised, else the communicator's size.  ur_comm_unique_id: 128 bytes made on
+ * loaded).  ur_comm_world: -1 no RCCL library, 0 not initialised, else the communicator's size.  ur_comm_unique_id: 256 bytes (two
+ * ids: one communicator for the row exchanges, one for the dense all-reduce, so that neither queues behind the other) made on
  * rank 0 and handed to every rank's ur_comm_init by the host (a broadcast over its process group).  ur_comm_all_reduce_sum: in place,
  * fp32 -- the flat dense-gradient all-reduce of the step (what DDP's bucketed all-reduce does, trainer.py:346), on `stream`. */
 int ur_comm_world(void);
-int ur_comm_unique_id(void* id_out128);
-int ur_comm_init(const void* id128, int32_t rank, int32_t world);
+int ur_comm_unique_id(void* id_out256);
+int ur_comm_init(const void* id256, int32_t rank, int32_t world);
 int ur_comm_destroy(void);
 int ur_comm_all_reduce_sum(float* buf, int64_t n, void* stream);
 /* idx_a[p] (p < n_a) / idx_b[p - n_a] = u for every lookup position p in the run of unique key u: the batch's

@@ -1,11 +1,11 @@
-"""Multi-GPU path.
+"""Multi-GPU path: the fixed-capacity row exchange.
 
-* world_size-2 gloo test on the CPU: the routing of the row-sharded table (owner mapping, all-to-all split
-  sizes, ordering of the three exchanges) reproduces the single-process row gradients.  The HIP kernels that
-  sit between the exchanges are stood in for by torch CPU indexing INSIDE THIS TEST (the product code has no
-  CPU path); what is under test is unirec_amd.sharded.RowExchange / owner_and_local / shard_rows.
-* GPU test: the sharded step with world == 1 is bit-identical in structure to the plain optimizer path and must
-  produce the same parameters after a few steps.
+* world_size-2 gloo test on the CPU: the routing of the row-sharded table (owner mapping, the fixed-capacity block layout, the
+  ordering of the three exchanges, the flags riding in slot 0) reproduces the single-process row gradients.  The HIP kernels that sit
+  between the exchanges are stood in for by torch CPU indexing INSIDE THIS TEST (the product code has no CPU path); what is under
+  test is unirec_amd.sharded.RowExchange / owner_and_local / shard_rows / pack_layout.
+* GPU tests: the pack / scatter / flag kernels against that host statement (exact integers), the RCCL transport at world 1 (the
+  library's own communicator, send / recv to itself), and the sharded optimizer with world == 1 against the plain optimizer path.
 """
 import os
 import socket
@@ -23,6 +23,29 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def _pack_host(uniq, n_local, world, cap):
+    """torch restatement of ur_shard_exchange_ids' packing for sorted unique sharded keys `uniq` -> (send_ids, slot_of_uniq, u_of_slot)"""
+    from unirec_amd.sharded import pack_layout
+    counts = [int(((uniq // n_local) == r).sum()) for r in range(world)]
+    has0 = len(uniq) > 0 and int(uniq[0]) == 0
+    lay = pack_layout(counts, cap, key0_first=has0)
+    send = torch.zeros(world * cap, dtype=torch.int32)
+    slot = torch.zeros(len(uniq), dtype=torch.int64)
+    uos = torch.full((world * cap,), -1, dtype=torch.int64)
+    u = 0
+    for o, (first, n) in enumerate(lay):
+        if o == 0 and has0:
+            slot[0] = 0
+            u += 1
+        for j in range(n):
+            send[first + j] = int(uniq[u] % n_local) if world > 1 else int(uniq[u])
+            slot[u] = first + j
+            uos[first + j] = u
+            u += 1
+    assert u == len(uniq)
+    return send, slot, uos, counts
 
 
 def _worker(rank, world, port, N, d, q):
@@ -46,25 +69,33 @@ def _worker(rank, world, port, N, d, q):
         ids[:3] = 0
         ids[5] = ids[6]
         grads = torch.randn(len(ids), d, generator=gb)
-        # ---- what rows_plan_sharded produces: unique keys sorted by (owner, local row) + per-owner counts
+        # ---- what rows_plan_sharded produces: unique keys sorted by (owner, local row); then the fixed-capacity block
         o, l = owner_and_local(ids, world)
         keys = o * n_local + l
         uniq, inv = torch.unique(keys, sorted=True, return_inverse=True)
-        send_counts = [int(((uniq // n_local) == r).sum()) for r in range(world)]
+        cap = 48
+        send, slot, uos, counts = _pack_host(uniq, n_local, world, cap)
         x = RowExchange(world, rank)
-        recv_counts = x.exchange_counts(send_counts)
-        assert x.exchange_counts_dev(torch.tensor(send_counts, dtype=torch.int32)) == (send_counts, recv_counts)
-        assert x.exchange_counts_host(send_counts) == (send_counts, recv_counts)      # lookahead path: counts already on the host
-        x.cpu_group = None                                                             # no gloo group: falls back to the main group
-        assert x.exchange_counts_host(send_counts) == (send_counts, recv_counts)
-        req = x.all_to_all_rows((uniq % n_local).to(torch.int32), send_counts, recv_counts)
-        assert int(req.max()) < n_local and len(req) == sum(recv_counts)
-        compact = x.all_to_all_rows(shard[req.long()], recv_counts, send_counts)      # rows come back in key order
-        assert torch.equal(compact[inv], full[ids])                                  # lookups see the right rows, bit-exact
+        req = x.all_to_all_equal(send)                                               # (1) ids -> owners
+        assert len(req) == world * cap and int(req.max()) < n_local
+        for s_ in range(world):                                                      # every block ascending (the owner's merge plan needs that)
+            blk = req[s_ * cap:(s_ + 1) * cap]
+            assert bool((blk[1:] >= blk[:-1]).all()) and int(blk[0]) == 0           # slot 0: reserved padding
+        compact = x.all_to_all_equal(shard[req.long()])                              # (2) rows -> requesters, slot layout
+        assert torch.equal(compact[slot[inv]], full[ids])                            # lookups see the right rows, bit-exact
+        assert torch.equal(compact[0], torch.zeros(d))                               # compact row 0 = the padding row
         ug = torch.zeros(len(uniq), d).index_add_(0, inv, grads)
         ug[uniq == 0] = 0                                                            # padding row
-        grads_in = x.all_to_all_rows(ug, send_counts, recv_counts)
+        sendg = torch.zeros(world * cap, d)
+        sendg[uos >= 0] = ug[uos[uos >= 0]]
+        for s_ in range(world):                                                      # slot 0 of every block: this rank's flags
+            sendg[s_ * cap, :4] = torch.tensor([0.0, 0.0, 1.5 + rank, 1.0])
+        grads_in = x.all_to_all_equal(sendg)                                         # (3) row gradients -> owners
+        flags = torch.stack([grads_in[s_ * cap, :4] for s_ in range(world)])
+        assert torch.equal(flags[:, 2], torch.tensor([1.5 + r for r in range(world)]))   # every rank sees every rank's loss
+        grads_in[torch.arange(world) * cap] = 0                                      # (the owner's segment sum ignores local row 0)
         shard_grad = torch.zeros(n_local, d).index_add_(0, req.long(), grads_in)
+        shard_grad[0] = 0
         # ---- reference: dense gradient of the whole table summed over both ranks' lookups
         all_ids = [None] * world
         all_gr = [None] * world
@@ -77,10 +108,12 @@ def _worker(rank, world, port, N, d, q):
         expect = torch.zeros(n_local, d)
         expect[local[mine]] = dense[mine]
         np.testing.assert_allclose(shard_grad.numpy(), expect.numpy(), rtol=1e-5, atol=1e-6)
-        assert torch.equal(shard_grad[0], torch.zeros(d))
+        assert torch.equal(x.all_reduce_sum(torch.ones(3) * (rank + 1)), torch.ones(3) * sum(range(1, world + 1)))
+        assert torch.equal(x.all_gather_cat(torch.tensor([rank])), torch.arange(world))
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
-        q.put((rank, f"{type(e).__name__}: {e}"))
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
     finally:
         dist.destroy_process_group()
 
@@ -114,135 +147,180 @@ def test_owner_mapping_matches_kernel_contract():
             assert torch.equal(l, ids)
 
 
-_CFG = dict(model="SASRec", n_users=10, n_items=3001, device="cuda:0", loss_type="bpr", embedding_size=64, hidden_size=64,
-            dropout_prob=0.0, init_method="normal", init_mean=0.0, init_std=0.05, has_user_emb=False, has_user_bias=False,
-            has_item_bias=False, distance_type="dot", tau=1.0, train_file_format="user-item", exp_name="t", n_layers=2,
-            n_heads=16, inner_size=128, hidden_dropout_prob=0.0, attn_dropout_prob=0.0, hidden_act="swish",
-            layer_norm_eps=1e-10, max_seq_len=20, use_position_emb=True)
+def test_pack_layout_reserves_slot_zero_and_detects_overflow():
+    from unirec_amd.sharded import pack_layout
+    assert pack_layout([3, 0, 5], 8) == [(5, 3), (16, 0), (19, 5)]
+    assert pack_layout([3, 2], 4, key0_first=True) == [(2, 2), (6, 2)]          # key 0 takes no slot
+    assert pack_layout([7], 8) == [(1, 7)]
+    with pytest.raises(OverflowError):
+        pack_layout([8], 8)
 
 
-def _batches(n_steps, B):
-    g = torch.Generator().manual_seed(11)
-    out = []
-    for s in range(n_steps):
-        seq = torch.randint(1, 3001, (B, 20), generator=g, dtype=torch.int32)
-        seq[::3, : 4 + s] = 0
-        out.append(dict(item_seq=seq, item_id=torch.randint(1, 3001, (B, 5), generator=g),
-                        label=torch.zeros(B, 5, dtype=torch.int32)))
-    return out
-
-
-def _gpu_worker(rank, world, port, q, kind="SASRec"):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share cuda:0; rows are staged via host
-    try:
-        from unirec_amd.sharded import ShardedSasrecStep, owner_and_local
-        dev = torch.device("cuda:0")
-        torch.cuda.set_device(dev)
-        T0 = torch.randn(3001, 64, generator=torch.Generator().manual_seed(5)) * 0.05
-        T0[0] = 0
-        cfg_k = dict(_CFG, model=kind)
-        st = ShardedSasrecStep(cfg_k, dev, rank, world, table_mode="lazy_dense")
-        owner, local = owner_and_local(torch.arange(3001), world)
-        st.table.zero_()
-        st.table[local[owner == rank].to(dev)] = T0[owner == rank].to(dev)
-        B = 16
-        losses = []
-        mine = [{k: v[rank * B:(rank + 1) * B].to(dev).contiguous() for k, v in b.items()} for b in _batches(3, B * world)]
-        for i, b in enumerate(mine):   # with the plan lookahead (next batch's id sort on a side stream); the 1-rank run has none
-            losses.append(float(st.step(b, mine[i + 1] if i + 1 < len(mine) else None)))
-        st.flush()
-        full = st.gather_table().cpu()
-        dense = st.model.dense_flat.data.cpu()
-        # ---- full-item ranking over the sharded table == ur_full_rank over the gathered table (exact integers)
-        from unirec_amd import ops
-        gh = torch.Generator().manual_seed(100 + rank)
-        uid = torch.randint(0, 12, (B,), generator=gh).to(dev)                # users 10, 11: outside the history table
-        tgt = mine[0]["item_id"][:, 0].contiguous()
-        lens = torch.randint(0, 40, (10,), generator=torch.Generator().manual_seed(7))
-        hp = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).to(dev)
-        hs_g = torch.randint(1, 3001, (int(lens.sum()),), generator=torch.Generator().manual_seed(8), dtype=torch.int32)
-        hs = torch.cat([hs_g[int(hp[u]):int(hp[u + 1])].sort().values for u in range(10)]).to(dev)
-        got = st.full_item_ranks(mine[0]["item_seq"], tgt, user_id=uid, hist_ptr=hp, hist_sorted=hs)
-        want, _ = ops.full_rank(st.encode(mine[0]["item_seq"]), full.to(dev), tgt, user_id=uid, hist_ptr=hp, hist_sorted=hs)
-        assert torch.equal(got.cpu(), want.cpu()), (got.cpu(), want.cpu())
-        got2 = st.full_item_ranks(mine[0]["item_seq"], tgt)                    # no history
-        want2, _ = ops.full_rank(st.encode(mine[0]["item_seq"]), full.to(dev), tgt)
-        assert torch.equal(got2.cpu(), want2.cpu()) and int(want2.max()) > 0
-        all_losses = [None] * world
-        dist.all_gather_object(all_losses, losses)
-        if rank == 0:
-            one = ShardedSasrecStep(cfg_k, dev, 0, 1, table_mode="lazy_dense")
-            one.table.copy_(T0.to(dev))
-            ref_losses = [float(one.step({k: v.to(dev) for k, v in b.items()})) for b in _batches(3, B * world)]
-            one.flush()
-            # global-mean loss == mean of the equal-sized rank means; parameters after 3 steps agree
-            np.testing.assert_allclose(np.mean(all_losses, axis=0), ref_losses, rtol=1e-5)
-            np.testing.assert_allclose(dense.numpy(), one.model.dense_flat.data.cpu().numpy(), rtol=1e-4, atol=2e-5)  # Adam amplifies rounding noise on ~zero gradients (key.bias): atol = 2% of an lr-sized step
-            np.testing.assert_allclose(full.numpy(), one.table.cpu().numpy(), rtol=1e-4, atol=2e-5)
-        dist.barrier()
-        q.put((rank, "ok"))
-    except Exception as e:  # noqa: BLE001
-        import traceback
-        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
-    finally:
-        dist.destroy_process_group()
+# ------------------------------------------------------------------------------------------------ GPU: kernels of the exchange
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,with_zero", [(1, True), (2, True), (4, False), (8, True)])
+def test_pack_kernel_matches_host_layout(world, with_zero):
+    """ur_shard_exchange_ids (pack only) == the host statement: send ids, slot of every unique key, key of every slot (exact integers);
+    ur_compact_index with the slot map; the overflow flag."""
+    from unirec_amd import ops
+    from unirec_amd.sharded import shard_rows
+    dev = torch.device("cuda:0")
+    N = 5003
+    g = torch.Generator().manual_seed(world)
+    ids_a = torch.randint(1, N, (700,), generator=g, dtype=torch.int32)
+    if with_zero:
+        ids_a[::7] = 0
+    ids_b = torch.randint(1, N, (90,), generator=g)
+    n_local = shard_rows(N, world)
+    pl, counts = ops.rows_plan_sharded(ids_a.to(dev), ids_b.to(dev), N, world)
+    n_uniq = int(pl.n_uniq)
+    uniq = pl.uniq_idx[:n_uniq].cpu().to(torch.int64)
+    cap = 790 + 1 if world == 1 else 64 * ((int(counts.max()) + 64) // 64)
+    i32 = dict(dtype=torch.int32, device=dev)
+    send, slot, uos, flags = torch.empty(world * cap, **i32), torch.zeros(pl.n, **i32), torch.empty(world * cap, **i32), torch.zeros(4, **i32)
+    ops.shard_exchange_ids(pl, counts, n_local, world, cap, send, slot, uos, flags)
+    want_send, want_slot, want_uos, want_counts = _pack_host(uniq, n_local, world, cap)
+    assert counts.cpu().tolist() == want_counts and int(flags[0]) == 0
+    assert torch.equal(send.cpu(), want_send)
+    assert torch.equal(slot[:n_uniq].cpu().to(torch.int64), want_slot)
+    got_uos = uos.cpu().to(torch.int64)
+    if with_zero:      # the padding id reads slot 0; its own key has no slot
+        want_uos = want_uos.clone()
+    assert torch.equal(got_uos, want_uos)
+    idx_a, idx_b = ops.compact_index(pl, slot)
+    # every lookup's slot asks its owner for exactly the lookup's row
+    req_local = send.cpu().to(torch.int64)
+    for ids, idx in ((ids_a.to(torch.int64), idx_a.cpu().to(torch.int64)), (ids_b, idx_b.cpu())):
+        owner = idx // cap
+        glob = torch.where(req_local[idx] > 0, (req_local[idx] - 1) * world + owner, torch.zeros_like(idx)) if world > 1 else req_local[idx]
+        assert torch.equal(glob, ids)
+        assert bool((idx[ids == 0] == 0).all())
+    # overflow: a capacity one below what the fullest owner needs raises the flag
+    need = int(counts.max()) - (1 if with_zero and int(counts[0]) == int(counts.max()) else 0)
+    small = max(2, need)          # holds need - 1 keys
+    flags.zero_()
+    ops.shard_exchange_ids(pl, counts, n_local, world, small, torch.empty(world * small, **i32), slot, torch.empty(world * small, **i32), flags)
+    assert int(flags[0]) == 1
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,world", [("SASRec", 2), ("GRU", 2), ("SASRec", 4)])
-def test_two_ranks_equal_one_rank_with_the_concatenated_batch(kind, world):
-    """SURVEY.md 8e parity test: W ranks x batch B == 1 rank x batch W*B (losses and updated parameters; full-item ranks over the
-    sharded table == over the gathered table); GRU = config C4; W = 4: more runs in the owner-side merge, unequal shard sizes."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, kind)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=400) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(res) == [(r, "ok") for r in range(world)], res
+def test_grad_scatter_carries_the_flags_and_step_flags_reads_them():
+    from unirec_amd import ops
+    dev = torch.device("cuda:0")
+    W, cap, d = 4, 8, 16
+    uos = torch.full((W * cap,), -1, dtype=torch.int32, device=dev)
+    uos[5], uos[9], uos[31] = 0, 2, 1
+    ug = torch.arange(3 * d, dtype=torch.float32, device=dev).view(3, d) + 1
+    loss_out = torch.tensor([0.75, 16.0, 1.0, 0.0], device=dev)
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    ws = torch.empty(W * cap, d, device=dev)
+    out = ops.shard_exchange_grads(ug, uos, W, cap, ws, loss_out=loss_out, flags=flags)
+    assert torch.equal(out[5], ug[0]) and torch.equal(out[9], ug[2]) and torch.equal(out[31], ug[1])
+    for s in range(W):
+        assert out[s * cap, :4].tolist() == [0.0, 0.0, 0.75, 1.0] and float(out[s * cap, 4:].abs().sum()) == 0
+    mask = torch.ones(W * cap, dtype=torch.bool, device=dev)
+    mask[[5, 9, 31] + [s * cap for s in range(W)]] = False
+    assert float(out[mask].abs().sum()) == 0
+    out4 = torch.zeros(4, device=dev)
+    # as received by an owner: one block per source rank; rank 2 reports an overflow, rank 1 a NaN loss
+    recv = out.clone()
+    for s, (nan, ovf, loss) in enumerate([(0, 0, 0.5), (0, 0, 1.5), (0, 0, 1.0), (0, 0, 2.0)]):
+        recv[s * cap, :4] = torch.tensor([nan, ovf, loss, 1.0])
+    ops.shard_step_flags(recv, W, cap, out4)
+    assert out4.tolist() == [0.25, 1.25, 0.0, 0.0]
+    recv[2 * cap, 1] = 1.0
+    ops.shard_step_flags(recv, W, cap, out4)
+    assert out4[0] == -1.0 and out4[3] == 1.0 and out4[1] == 1.25
+    recv[1 * cap, 0] = 1.0
+    ops.shard_step_flags(recv, W, cap, out4)
+    assert out4[0] == -1.0 and out4[2] == 1.0 and bool(torch.isnan(out4[1]))
+    # a NaN loss on THIS rank: the flag row says so (and carries no NaN into the sums)
+    nan_loss = torch.tensor([float("nan"), 16.0, -1.0, 0.0], device=dev)
+    out = ops.shard_exchange_grads(ug, uos, W, cap, ws, loss_out=nan_loss, flags=flags)
+    assert out[0, :4].tolist() == [1.0, 0.0, 0.0, 1.0]
+
+
+@pytest.mark.gpu
+def test_rccl_transport_at_world_one():
+    """The library's own RCCL communicators (ur_comm_init): at world 1 every exchange is a send / recv to itself and the all-reduce the
+    identity -- the transport code path of the multi-GPU step, executed through RCCL on the one GPU there is."""
+    from unirec_amd import ops
+    if ops.comm_world() < 0:
+        pytest.skip("no RCCL library in this process")
+    dev = torch.device("cuda:0")
+    ops.comm_init(0, 1)
+    assert ops.comm_world() == 1
+    try:
+        N, d = 3001, 32
+        g = torch.Generator().manual_seed(3)
+        table = torch.randn(N, d, generator=g).to(dev)
+        table[0] = 0
+        ids = torch.randint(0, N, (500,), generator=g, dtype=torch.int32).to(dev)
+        pl, counts = ops.rows_plan_sharded(ids, None, N, 1)
+        cap = 501
+        i32 = dict(dtype=torch.int32, device=dev)
+        bufs = lambda: (torch.empty(cap, **i32), torch.zeros(500, **i32), torch.empty(cap, **i32), torch.zeros(4, **i32))   # noqa: E731
+        s0, slot0, uos0, f0 = bufs()
+        ops.shard_exchange_ids(pl, counts, N, 1, cap, s0, slot0, uos0, f0)
+        s1, slot1, uos1, f1 = bufs()
+        recv = torch.empty(cap, **i32)
+        ops.shard_exchange_ids(pl, counts, N, 1, cap, s1, slot1, uos1, f1, recv_ids=recv, transport=True)
+        assert torch.equal(recv, s0) and torch.equal(slot0, slot1)
+        ws, compact = torch.empty(cap, d, device=dev), torch.empty(cap, d, device=dev)
+        ops.shard_exchange_rows(table, recv, 1, cap, ws, compact=compact, transport=True)
+        idx_a, _ = ops.compact_index(pl, slot1)
+        assert torch.equal(compact[idx_a.long()], table[ids.long()])
+        ug = torch.randn(int(pl.n_uniq), d, generator=torch.Generator().manual_seed(1)).to(dev)
+        gin = torch.empty(cap, d, device=dev)
+        ops.shard_exchange_grads(ug, uos1, 1, cap, ws, grads_in=gin, transport=True)
+        assert torch.equal(gin, ops.shard_exchange_grads(ug, uos1, 1, cap, torch.empty(cap, d, device=dev)))
+        t = torch.arange(1000, dtype=torch.float32, device=dev)
+        assert torch.equal(ops.comm_all_reduce_sum(t.clone()), t)
+        torch.cuda.synchronize()
+    finally:
+        ops.comm_destroy()
+    assert ops.comm_world() == 0
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["SASRec", "GRU"])
-def test_sharded_step_world1_equals_plain_path(kind):
+def test_sharded_optimizer_world1_equals_plain_path(kind):
+    """ShardedSparseDenseAdam at world 1 (the whole fixed-capacity step, collectives degenerate) == SparseDenseAdam: same losses, same
+    parameters, with and without the plan lookahead, lazy_dense and rowwise, with and without gradient clipping."""
+    from unirec_amd.facility.distributed import ShardedSparseDenseAdam
     from unirec_amd.facility.optimizer import SparseDenseAdam
-    from unirec_amd.model.sequential.gru import GRU
-    from unirec_amd.model.sequential.sasrec import SASRec as _S
-    from unirec_amd.sharded import ShardedSasrecStep
-    SASRec = GRU if kind == "GRU" else _S
+    from unirec_amd.utils.argument_parser import parse_arguments
+    from unirec_amd.utils.general import get_class_instance, init_seed
     dev = torch.device("cuda:0")
-    cfg = dict(model=kind, n_users=10, n_items=5000, device="cuda:0", loss_type="bpr", embedding_size=64, hidden_size=64,
-               dropout_prob=0.0, init_method="normal", init_mean=0.0, init_std=0.05, has_user_emb=False, has_user_bias=False,
-               has_item_bias=False, distance_type="dot", tau=1.0, train_file_format="user-item", exp_name="t", n_layers=2,
-               n_heads=16, inner_size=128, hidden_dropout_prob=0.0, attn_dropout_prob=0.0, hidden_act="swish",
-               layer_norm_eps=1e-10, max_seq_len=20, use_position_emb=True)
-    for mode in ("lazy_dense", "rowwise"):
-        st = ShardedSasrecStep(cfg, dev, rank=0, world=1, table_mode=mode)
-        m = SASRec(cfg)
-        with torch.no_grad():
-            m.dense_flat.data.copy_(st.model.dense_flat.data)
-            m.item_embedding.weight.copy_(st.table)
-        opt = SparseDenseAdam(m, lr=1e-3, table_mode=mode)
-        m.train()
-        g = torch.Generator().manual_seed(3)
-        for step in range(3):
-            seq = torch.randint(1, 5000, (32, 20), generator=g, dtype=torch.int32)
-            seq[:, : step * 3] = 0
-            batch = dict(item_seq=seq.to(dev), item_id=torch.randint(1, 5000, (32, 5), generator=g).to(dev),
-                         label=torch.zeros(32, 5, dtype=torch.int32, device=dev))
-            l1 = st.step(batch)
-            opt.zero_grad()
-            opt.plan_batch(item_seq=batch["item_seq"], item_id=batch["item_id"])
-            l2, _, _, _ = m(item_id=batch["item_id"], label=batch["label"], item_seq=batch["item_seq"])
-            l2.backward()
-            opt.step()
-            np.testing.assert_allclose(float(l1), float(l2.detach()), rtol=1e-6)
-        st.flush()
-        opt.flush()
-        np.testing.assert_allclose(st.model.dense_flat.data.cpu().numpy(), m.dense_flat.data.cpu().numpy(), rtol=1e-6, atol=1e-8)
-        np.testing.assert_allclose(st.gather_table().cpu().numpy(), m.item_embedding.weight.detach().cpu().numpy(), rtol=1e-6, atol=1e-8)
+    cfg = parse_arguments(dict(model=kind, n_users=10, n_items=5000, device="cuda:0", loss_type="bpr", embedding_size=64, hidden_size=64,
+                               n_layers=2, n_heads=16, inner_size=128, hidden_dropout_prob=0.0, attn_dropout_prob=0.0, dropout_prob=0.0,
+                               hidden_act="swish", max_seq_len=20, batch_size=32, seed=5, n_sample_neg_train=4))
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for step in range(5):
+        seq = torch.randint(1, 5000, (32, 20), generator=g, dtype=torch.int32)
+        seq[:, : step * 3] = 0
+        lab = torch.zeros(32, 5, dtype=torch.int32)
+        lab[:, 0] = 1
+        batches.append(dict(item_seq=seq.to(dev), item_id=torch.randint(1, 5000, (32, 5), generator=g).to(dev), label=lab.to(dev)))
+    for mode, clip, look in (("lazy_dense", None, True), ("lazy_dense", None, False), ("rowwise", None, True), ("lazy_dense", 0.05, True)):
+        init_seed(5)
+        m1 = get_class_instance(kind, "unirec_amd/model")(cfg)
+        init_seed(5)
+        m2 = get_class_instance(kind, "unirec_amd/model")(cfg)
+        o1 = ShardedSparseDenseAdam(m1, 0, 1, lr=2e-3, table_mode=mode, grad_clip=clip)
+        o2 = SparseDenseAdam(m2, lr=2e-3, table_mode=mode, grad_clip=clip)
+        m1.train(), m2.train()
+        for i, b in enumerate(batches):
+            l1 = o1.train_step(b, batches[i + 1] if look and i + 1 < len(batches) else None)
+            o2.zero_grad()
+            o2.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
+            l2 = m2.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
+            o2.step()
+            np.testing.assert_allclose(float(l1), float(l2), rtol=1e-6)
+        m1.join_side_updates()
+        o1.flush(), o2.flush()
+        assert o1.n_overflow == 0
+        np.testing.assert_allclose(m1.dense_flat.data.cpu().numpy(), m2.dense_flat.data.cpu().numpy(), rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(m1.item_embedding.weight.detach().cpu().numpy(), m2.item_embedding.weight.detach().cpu().numpy(),
+                                   rtol=1e-6, atol=1e-8)

@@ -86,7 +86,8 @@ SIGNATURES = {
     "ur_compact_index": (C.c_int, [P, P, P, I64, I64, P, P, P, P]),
     "ur_shard_exchange_ids": (C.c_int, [P, P, P, I64, I32, I32, P, P, P, P, P, I32, P]),
     "ur_shard_exchange_rows": (C.c_int, [P, P, I32, I32, I32, P, P, I32, P]),
-    "ur_shard_exchange_grads": (C.c_int, [P, P, I32, I32, I32, P, P, I32, P]),
+    "ur_shard_exchange_grads": (C.c_int, [P, P, I32, I32, I32, P, P, P, P, I32, P]),
+    "ur_shard_step_flags": (C.c_int, [P, I32, I32, I32, P, P]),
     "ur_comm_world": (C.c_int, []),
     "ur_comm_unique_id": (C.c_int, [P]),
     "ur_comm_init": (C.c_int, [P, I32, I32]),

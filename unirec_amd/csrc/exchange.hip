@@ -7,8 +7,9 @@
 // the step: no per-step count exchange, no host synchronisation, every buffer preallocated.  A rank's block for owner o holds its
 // count[o] requests right-aligned -- slots [o * cap + cap - count[o], (o + 1) * cap) -- behind padding slots that ask for local row 0 (the
 // padding row of every shard: gathers zeros, never updated), so each block stays ascending (what the owner's W-way merge plan needs).
-// A count above `cap` raises a device flag that rides in the step's flat all-reduce: every rank then skips the update (as for a NaN loss)
-// and the host, which reads the flag a step later, doubles the capacity and trains the batch again.
+// A count above `cap - 1` raises a device flag; the flags of all ranks travel in slot 0 of every block of the gradient exchange (an
+// all-gather riding in the all-to-all): every rank then skips the update (as for a NaN loss anywhere), and the host, which reads the
+// flags two steps later, doubles the capacity and trains the batch again.
 //
 // Transport: the library owns one RCCL communicator per process (ur_comm_init; the unique id travels through the host's process group
 // once) and issues ncclSend / ncclRecv groups on the stream it is given.  RCCL is resolved at run time from the librccl.so.1 the process
@@ -21,7 +22,9 @@
 
 namespace ur {
 
-// slot q = o * cap + p of the send block:  pad = cap - min(cap, count[o]);  p < pad: padding (local row 0), else the (p - pad)-th key of owner o
+// slot q = o * cap + p of the send block.  Slot 0 of EVERY block is reserved padding (it carries the step's flags in the gradient
+// exchange, and compact row 0 -- owner 0's slot 0 -- is the padding row the re-indexed lookups of id 0 read), so a block holds up to
+// cap - 1 keys:  pad = cap - min(cap - 1, count[o]);  p < pad: padding (local row 0), else the (p - pad)-th key of owner o
 __global__ __launch_bounds__(256) void shard_pack_kernel(const int* __restrict__ uniq_key, const int* __restrict__ n_uniq_dev,
                                                          const int* __restrict__ counts, long long n_local, int W, int cap,
                                                          int* __restrict__ send_ids, int* __restrict__ slot_of_uniq,
@@ -37,33 +40,58 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const int* __restrict__
   if (q >= W * cap) return;
   const int o = q / cap, p = q % cap;
   const int cnt = pre[o + 1] - pre[o];
-  if (p == 0 && cnt > cap) atomicOr(flags, 1);   // overflow: the rows beyond the capacity are cut (the step is skipped, see the header)
-  const int pad = cap - min(cap, cnt);
+  // key 0 (the padding id, owner 0's first key when present) needs no slot of its own: it reads the reserved slot 0
+  const int has0 = (o == 0 && cnt > 0 && uniq_key[0] == 0) ? 1 : 0;
+  const int need = cnt - has0;
+  if (p == 0 && need > cap - 1) atomicOr(flags, 1);   // overflow: the rows beyond the capacity are cut (the step is skipped, see the header)
+  const int pad = cap - min(cap - 1, need);
+  if (p == 0 && has0) slot_of_uniq[0] = 0;   // the padding id (unique key 0 of the plan) reads compact row 0
   if (p < pad) {
     send_ids[q] = 0;
     u_of_slot[q] = -1;
     return;
   }
-  const int u = pre[o] + (p - pad);
+  const int u = pre[o] + has0 + (p - pad);
   const unsigned key = (unsigned)uniq_key[u];
-  const int local = W > 1 ? (int)(key % (unsigned long long)n_local) : (int)key;
-  send_ids[q] = local;
-  // key 0 (the padding id) reads compact row 0 whatever its slot: slot 0 belongs to owner 0 and asks for local row 0 either as padding
-  // or as this very key (count[0] == cap)
-  const bool is_pad_id = key == 0u;
-  slot_of_uniq[u] = is_pad_id ? 0 : q;
-  u_of_slot[q] = is_pad_id ? -1 : u;
+  send_ids[q] = W > 1 ? (int)(key % (unsigned long long)n_local) : (int)key;
+  slot_of_uniq[u] = q;
+  u_of_slot[q] = u;
 }
 
 // out[q, :] = u_of_slot[q] >= 0 ? rows[u_of_slot[q], :] : 0      (unique-order rows -> the fixed-capacity slot layout)
+// The reserved slot 0 of every block carries this rank's step flags to every owner (an all-gather riding in the all-to-all):
+// [loss is NaN, a capacity overflow, the loss, 1].  The owner's segment sum ignores the row (it belongs to local row 0).
 __global__ __launch_bounds__(256) void shard_scatter_rows_kernel(const float4* __restrict__ rows, const int* __restrict__ u_of_slot,
-                                                                 long long n_slots, int d4, float4* __restrict__ out) {
+                                                                 long long n_slots, int cap, int d4, const float* __restrict__ loss_out,
+                                                                 const int* __restrict__ flags, float4* __restrict__ out) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_slots * d4) return;
   const long long q = i / d4;
   const int c = (int)(i % d4);
+  if (q % cap == 0 && c == 0) {
+    const float loss = loss_out ? loss_out[0] : 0.f;
+    const float nan = (loss_out && (loss_out[2] < 0.f || loss != loss)) ? 1.f : 0.f;
+    out[i] = make_float4(nan, (flags && (flags[0] & 1)) ? 1.f : 0.f, nan != 0.f ? 0.f : loss, 1.f);
+    return;
+  }
   const int u = u_of_slot[q];
   out[i] = u >= 0 ? rows[(long long)u * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// the flags of all ranks, as received in slot 0 of every block of grads_in -> out[0] = gradient scale of the update kernels (1 / W =
+// DDP's mean, or -1 = skip the step: a NaN loss or an overflow on ANY rank), out[1] = mean loss over the ranks, out[2] / out[3] = number
+// of ranks with a NaN loss / an overflow
+__global__ void shard_step_flags_kernel(const float* __restrict__ grads_in, int W, int cap, int d, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float nan = 0.f, ovf = 0.f, loss = 0.f;
+  for (int s = 0; s < W; ++s) {   // source-rank order: every rank sums the same values in the same order
+    const float* r = grads_in + (long long)s * cap * d;
+    nan += r[0]; ovf += r[1]; loss += r[2];
+  }
+  out[0] = (nan > 0.f || ovf > 0.f) ? -1.f : 1.f / (float)W;
+  out[1] = nan > 0.f ? __builtin_nanf("") : loss / (float)W;
+  out[2] = nan;
+  out[3] = ovf;
 }
 
 // ---- RCCL, resolved from the already-loaded library
@@ -98,7 +126,9 @@ Rccl* rccl() {
   }();
   return r;
 }
-struct Comm { ncclComm_t comm = nullptr; int rank = 0, world = 0; };
+// two communicators: [0] the row exchanges (plan stream / caller's stream), [1] the dense all-reduce (the encoder's side stream) --
+// operations on ONE communicator are serialised in issue order, and the all-reduce of step t must not hold up the rows of step t + 1
+struct Comm { ncclComm_t comm = nullptr, comm2 = nullptr; int rank = 0, world = 0; };
 Comm g_comm;
 }  // namespace
 
@@ -128,9 +158,10 @@ using namespace ur;
 extern "C" int ur_comm_unique_id(void* id_out) {
   UR_REQUIRE(id_out, UR_ERR_ARG, "ur_comm_unique_id: null pointer");
   UR_REQUIRE(rccl()->ok, UR_ERR_UNSUPPORTED, "ur_comm_unique_id: no RCCL library in this process");
-  ncclUniqueId id;
-  UR_NCCL(rccl()->GetUniqueId(&id));
-  memcpy(id_out, &id, sizeof(id));
+  ncclUniqueId id[2];
+  UR_NCCL(rccl()->GetUniqueId(&id[0]));
+  UR_NCCL(rccl()->GetUniqueId(&id[1]));
+  memcpy(id_out, id, sizeof(id));
   return UR_OK;
 }
 
@@ -142,9 +173,10 @@ extern "C" int ur_comm_init(const void* id, int32_t rank, int32_t world) {
                g_comm.rank, g_comm.world);
     return UR_OK;
   }
-  ncclUniqueId uid;
-  memcpy(&uid, id, sizeof(uid));
-  UR_NCCL(rccl()->CommInitRank(&g_comm.comm, world, uid, rank));
+  ncclUniqueId uid[2];
+  memcpy(uid, id, sizeof(uid));
+  UR_NCCL(rccl()->CommInitRank(&g_comm.comm, world, uid[0], rank));
+  UR_NCCL(rccl()->CommInitRank(&g_comm.comm2, world, uid[1], rank));
   g_comm.rank = rank;
   g_comm.world = world;
   return UR_OK;
@@ -155,6 +187,7 @@ extern "C" int ur_comm_world(void) { return !rccl()->ok ? -1 : (g_comm.comm ? g_
 extern "C" int ur_comm_destroy(void) {
   if (g_comm.comm) {
     UR_NCCL(rccl()->CommDestroy(g_comm.comm));
+    if (g_comm.comm2) UR_NCCL(rccl()->CommDestroy(g_comm.comm2));
     g_comm = Comm{};
   }
   return UR_OK;
@@ -163,7 +196,7 @@ extern "C" int ur_comm_destroy(void) {
 extern "C" int ur_comm_all_reduce_sum(float* buf, int64_t n, void* stream) {
   UR_REQUIRE(buf && n > 0, UR_ERR_ARG, "ur_comm_all_reduce_sum: bad argument");
   UR_REQUIRE(g_comm.comm, UR_ERR_ARG, "ur_comm_all_reduce_sum: no communicator (ur_comm_init)");
-  UR_NCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, g_comm.comm, as_stream(stream)));
+  UR_NCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, g_comm.comm2, as_stream(stream)));
   return UR_OK;
 }
 
@@ -204,7 +237,8 @@ extern "C" int ur_shard_exchange_rows(const float* table, const int32_t* req_ids
 // (3) row gradients: uniq_grad [n_uniq, d] (unique order, from ur_rows_reduce) -> slot layout (padding slots: zeros) in send_ws, then
 // all-to-all into grads_in [world * cap, d] on the owners (block s = what rank s sends: summed in source-rank order by the owner's plan).
 extern "C" int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_of_slot, int32_t world, int32_t cap, int32_t d,
-                                       float* send_ws, float* grads_in, int32_t transport, void* stream) {
+                                       const float* loss_out, const int32_t* flags_dev, float* send_ws, float* grads_in,
+                                       int32_t transport, void* stream) {
   UR_REQUIRE(uniq_grad && u_of_slot && send_ws, UR_ERR_ARG, "ur_shard_exchange_grads: null pointer");
   UR_REQUIRE(world >= 1 && cap > 0 && d > 0 && d % 4 == 0, UR_ERR_ARG, "ur_shard_exchange_grads: world=%d cap=%d d=%d", world, cap, d);
   hipStream_t st = as_stream(stream);
@@ -212,11 +246,20 @@ extern "C" int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_
   {
     ProfScope ps(PC_REDUCE, st, (double)n_slots * d * 8.0);
     hipLaunchKernelGGL(shard_scatter_rows_kernel, dim3(cdiv(n_slots * (d / 4), 256)), dim3(256), 0, st, (const float4*)uniq_grad, u_of_slot,
-                       n_slots, d / 4, (float4*)send_ws);
+                       n_slots, cap, d / 4, loss_out, flags_dev, (float4*)send_ws);
     UR_LAUNCH_CHECK();
   }
   if (!transport) return UR_OK;
   UR_REQUIRE(grads_in, UR_ERR_ARG, "ur_shard_exchange_grads: null receive buffer");
   UR_REQUIRE(g_comm.comm && g_comm.world == world, UR_ERR_ARG, "ur_shard_exchange_grads: communicator of %d ranks, world=%d", g_comm.world, world);
   return a2a_bytes(send_ws, grads_in, (size_t)cap * d * sizeof(float), st);
+}
+
+// after (3): the flags every rank put into slot 0 of its blocks -> out4 = [gradient scale (1 / world, or -1 = skip the step), mean loss,
+// ranks with a NaN loss, ranks with a capacity overflow]
+extern "C" int ur_shard_step_flags(const float* grads_in, int32_t world, int32_t cap, int32_t d, float* out4, void* stream) {
+  UR_REQUIRE(grads_in && out4 && world >= 1 && cap > 0 && d >= 4, UR_ERR_ARG, "ur_shard_step_flags: bad argument");
+  hipLaunchKernelGGL(shard_step_flags_kernel, dim3(1), dim3(64), 0, as_stream(stream), grads_in, world, cap, d, out4);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
 }

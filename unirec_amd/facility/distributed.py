@@ -12,7 +12,8 @@ per GPU over ``torch.distributed`` (RCCL on the GPUs):
     owners bring the rows up to date (lazy Adam) and gather them -> all-to-all #2 (rows) -> the model runs its NORMAL
     ``forward_backward`` on the compact table of fetched rows (ids re-indexed; same HIP kernels, same model code) ->
     segment-reduce the row gradients -> all-to-all #3 (row gradients) -> owners sum the contributions in source-rank order
-    (deterministic) and apply the optimizer rule to their rows.  No collective ever touches a full table;
+    (deterministic) and apply the optimizer rule to their rows.  No collective ever touches a full table; every exchange has a
+    FIXED capacity per (source, owner) pair (no count exchange, no host synchronisation: ShardedSparseDenseAdam's docstring);
   * ``grad_clip_value`` (trainer.py:347-348): the global norm is that of the AVERAGED gradient = sqrt(sum of squares of the
     all-reduced dense gradients + of the owner-side unique row gradients, all-reduced) / W; every optimizer rule of
     ``Trainer._build_optimizer`` and ``weight_decay`` go through the same kernels as on one GPU (SparseDenseAdam);
@@ -28,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 from .. import ops
-from ..sharded import RowExchange, shard_rows
+from ..sharded import RowExchange, shard_rows   # noqa: F401  (shard_rows: re-exported for callers)
 from .optimizer import SparseDenseAdam
 
 TABLE_NAMES = ("item_embedding", "user_embedding", "item_dst_embedding")
@@ -62,14 +63,36 @@ def extract_shard(full, rank, world):
     return shard
 
 
+class _Look:
+    """ids-only state of one batch (plans, packed ids, owner-side plan, re-indexed lookups): made a step ahead on the plan stream"""
+    __slots__ = ("key", "tabs", "event", "keep", "waited")
+
+
 class ShardedSparseDenseAdam(SparseDenseAdam):
     """SparseDenseAdam for world > 1 (see the module docstring).  The model keeps its SHARD under each table's ``weight``;
-    ``train_step`` swaps the compact table of the batch's rows in for the duration of the model's forward_backward."""
+    ``train_step`` swaps the compact table of the batch's rows in for the duration of the model's forward_backward.
 
-    def __init__(self, model, rank, world, group=None, sync_init=True, full_rows=None, **kw):
+    The step (round 3): every exchange has FIXED capacity (``cap`` slots per (source, owner) pair, include/unirec_amd.h
+    ur_shard_exchange_*), so there is no per-step count exchange, no host synchronisation, and every buffer is allocated once.
+      plan stream, one step AHEAD (ids only): id sort by (owner, row) -> pack -> all-to-all #1 (ids) -> owner-side merge plan ->
+                                              re-indexed lookups -> which of the owner's rows have optimizer history
+      main stream: [tail of the previous step: lazy catch-up of this batch's owner rows] -> gather + all-to-all #2 (rows) -> the model's
+                   own forward_backward on the compact table -> row-gradient reduce -> scatter to slots + all-to-all #3 (slot 0 of every
+                   block carries the rank's NaN / overflow flags and loss: an all-gather riding along) -> owner-side reduce in source-rank
+                   order -> flags -> row update -> catch-up of the NEXT batch's owner rows
+      encoder's side stream (no gradient clipping): dense-gradient reductions -> all-reduce (second communicator) -> dense update, joined
+                   by the next forward pass after its first launch (SparseDenseAdam's late join)
+    With ``grad_clip`` the global norm needs every gradient first: the dense half runs on the main stream behind ONE flat all-reduce
+    that also carries the owners' row-gradient norms.  A capacity overflow (a rank asks one owner for more than cap - 1 rows: skewed
+    ids) skips the step on every rank, like a NaN loss; the host sees the flag two steps later, doubles the capacity and trains that
+    batch again.  Transport: the library's RCCL communicators (ops.comm_init) when the process group is nccl, else torch.distributed
+    on the packed blocks (gloo: CPU-staged -- the routing tests)."""
+
+    def __init__(self, model, rank, world, group=None, sync_init=True, full_rows=None, cap_slack=1.25, **kw):
         """full_rows (optional): {table: N} for tables the model ALREADY holds as this rank's shard (shard_rows(N, W) rows,
         initialised per rank): nothing is broadcast or cut for them -- how a 100 M-row table is brought up without ever
-        existing in one piece (bench.py); by default the model's full tables are broadcast from rank 0 and cut here."""
+        existing in one piece (bench.py); by default the model's full tables are broadcast from rank 0 and cut here.
+        cap_slack: capacity per (source, owner) pair = cap_slack x lookups / world (uniform ids need ~1.1)."""
         self.rank, self.world = rank, world
         self.xchg = RowExchange(world, rank, group)
         self.full_rows = {}
@@ -77,6 +100,8 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         dev = model.device
         if model.loss_type == "fullsoftmax":
             raise NotImplementedError("fullsoftmax scores every item against every user: not available over a row-sharded table")
+        if world > 64:
+            raise NotImplementedError("row exchange: at most 64 ranks (the owner-side plan is a 64-way merge)")
         if sync_init and world > 1:      # what DDP's wrap-time parameter broadcast does (trainer.py:67)
             self._broadcast(model.dense_flat.data)
             for n, p in model.named_parameters():
@@ -99,10 +124,22 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             w.data = extract_shard(w.data, rank, world) if world > 1 else w.data
         super().__init__(model, **kw)
         self.inv_w = torch.full((1,), 1.0 / world, dtype=torch.float32, device=dev)
-        self._zero_id = torch.zeros(1, dtype=torch.int64, device=dev)
-        self._zero_coef = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._comm = None
-        self._look = None          # plans of the next batch, made on a side stream (ids only)
+        self.cap_slack = float(cap_slack)
+        self._cap_scale = 1               # doubled after a capacity overflow
+        # native transport: RCCL through the library's own communicators, on whatever stream the step is on
+        self._native = False
+        if world > 1 and dev.type == "cuda" and dist.get_backend(group) == "nccl" and ops.comm_world() >= 0:
+            ops.comm_init(rank, world, group)
+            self._native = True
+        self._bufs = {}                   # (table, n, n_a, parity) -> preallocated exchange buffers
+        self._look = None                 # _Look of the next batch (plan stream)
+        self._parity = 0
+        self._out4 = [torch.zeros(4, dtype=torch.float32, device=dev) for _ in range(4)]   # per-step flags (ring: the host reads them late)
+        self._flag_host = [torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4) for _ in range(4)]
+        self._flag_ev = [None] * 4
+        self._flag_batch = [None] * 4
+        self._replaying = False
+        self.n_overflow = 0
 
     # ------------------------------------------------------------------ collectives on top of RowExchange
     def _broadcast(self, t, chunk=1 << 26):
@@ -117,10 +154,27 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             else:
                 dist.broadcast(piece, src=0, group=self.xchg.group)
 
+    def _a2a(self, send, recv, label):
+        """equal-split all-to-all of a packed block through torch.distributed (the non-native route)"""
+        if self.world == 1:
+            recv.copy_(send)
+            return recv
+        recv.copy_(self.xchg.all_to_all_equal(send, label=label))
+        return recv
+
+    def _all_reduce(self, t):
+        if self.world == 1:
+            return t
+        if self._native:
+            return ops.comm_all_reduce_sum(t)
+        r = self.xchg.all_reduce_sum(t)
+        if r is not t:
+            t.copy_(r)
+        return t
+
     # ------------------------------------------------------------------ id plans
     def _table_inputs(self, batch):
-        """-> {table: (field_a, field_b, ids_a int32 | None, ids_b int64 with a trailing 0)}.  The trailing lookup of id 0 pins
-        compact row 0 = the padding row, whatever the batch holds."""
+        """-> {table: (field_a, field_b, ids_a int32 | None, ids_b int64 | None)}"""
         spec = self.model.lookup_tables()
         out, seen = {}, {}
         for name, (ka, kb) in spec.items():
@@ -134,187 +188,294 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                 if k is not None and seen.setdefault(k, name) != name:
                     raise NotImplementedError(f"batch field {k!r} indexes two sharded tables ({seen[k]}, {name})")
             a = ta.reshape(-1).to(torch.int32).contiguous() if ta is not None else None
-            b = torch.cat([tb.reshape(-1).to(torch.int64), self._zero_id]) if tb is not None else self._zero_id
+            b = tb.reshape(-1).to(torch.int64).contiguous() if tb is not None else None
             out[name] = (ka if ta is not None else None, kb if tb is not None else None, a, b)
         return out
 
-    def _sharded_plans(self, batch):
-        return {name: (ka, kb, ops.rows_plan_sharded(a, b, self.full_rows[name], self.world))
-                for name, (ka, kb, a, b) in self._table_inputs(batch).items()}
+    def _capacity(self, n):
+        """slots per (source, owner) pair for a batch of n lookups of one table; slot 0 of every block is reserved"""
+        W = self.world
+        if W == 1:
+            return n + 1
+        cap = int(self.cap_slack * self._cap_scale * n / W) + 2
+        cap = (cap + 63) // 64 * 64
+        return min(cap, (n + 1 + 63) // 64 * 64)
+
+    def _buffers(self, name, n, n_a, d, parity):
+        key = (name, n, n_a, parity, self._cap_scale)
+        bf = self._bufs.get(key)
+        if bf is None:
+            dev, W = self.model.device, self.world
+            cap = self._capacity(n)
+            i32 = dict(dtype=torch.int32, device=dev)
+            bf = dict(cap=cap, plan=ops.rows_plan_alloc(n, n_a, dev), counts=torch.empty(W, **i32), send_ids=torch.empty(W * cap, **i32),
+                      recv_ids=torch.empty(W * cap, **i32), slot=torch.zeros(n, **i32), uos=torch.empty(W * cap, **i32),
+                      flags=torch.zeros(4, **i32), own=ops.rows_plan_alloc(W * cap, W * cap, dev),
+                      idx_a=torch.empty(n_a, **i32) if n_a else None,
+                      idx_b=torch.empty(n - n_a, dtype=torch.int64, device=dev) if n > n_a else None)
+            self._bufs[key] = bf
+        skey = (name, n, "step", self._cap_scale)
+        sb = self._bufs.get(skey)
+        if sb is None:
+            dev, W, cap = self.model.device, self.world, bf["cap"]
+            f32 = dict(dtype=torch.float32, device=dev)
+            sb = dict(rows_ws=torch.empty(W * cap, d, **f32), compact=torch.empty(W * cap, d, **f32),
+                      send_grads=torch.empty(W * cap, d, **f32), grads_in=torch.empty(W * cap, d, **f32))
+            self._bufs[skey] = sb
+        return bf, sb
+
+    def _prepare(self, batch, parity):
+        """everything of a step that depends on the ids only, on the CURRENT stream -> {table: state}"""
+        W, tabs = self.world, {}
+        for name, (ka, kb, a, b) in self._table_inputs(batch).items():
+            st = self.tables[name]
+            n_a = a.numel() if a is not None else 0
+            n = n_a + (b.numel() if b is not None else 0)
+            bf, sb = self._buffers(name, n, n_a, st["w"].shape[1], parity)
+            cap = bf["cap"]
+            pl, counts = ops.rows_plan_sharded(a, b, self.full_rows[name], W, out=(bf["plan"], bf["counts"]))
+            bf["flags"].zero_()
+            ops.shard_exchange_ids(pl, counts, st["w"].shape[0], W, cap, bf["send_ids"], bf["slot"], bf["uos"], bf["flags"],
+                                   recv_ids=bf["recv_ids"], transport=self._native)
+            if not self._native:
+                self._a2a(bf["send_ids"], bf["recv_ids"], "a2a_ids")
+            own = ops.rows_plan_merge(bf["recv_ids"], [cap] * W, out=bf["own"])
+            ops.compact_index(pl, bf["slot"], out=(bf["idx_a"], bf["idx_b"]))
+            filt = None
+            if st["last"] is not None and self.wd == 0.0:
+                filt = ops.rows_filter_touched(own, st["last"])     # (rows first touched by the step in flight need no catch-up)
+            tabs[name] = dict(ka=ka, kb=kb, pl=pl, own=own, filt=filt, bf=bf, sb=sb, cap=cap, ids=(a, b), caught_up=None)
+        return tabs
 
     def prefetch(self, batch):
-        """plans (id sorts + per-owner counts) of the NEXT batch on a side stream, counts copied to pinned host memory there:
-        the step that adopts them only waits for that event, never drains the compute stream."""
-        if batch is None or not self.model.device.type == "cuda":
+        """ids-only half of the NEXT batch's step on the plan stream, all-to-all #1 included: nothing of it is left for the step itself."""
+        if batch is None or self.model.device.type != "cuda":
             return
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.model.device)
-        inputs = self._table_inputs(batch)        # built (and later released) under the main stream
-        bufs = {name: (ops.rows_plan_alloc((a.numel() if a is not None else 0) + b.numel(), a.numel() if a is not None else 0,
-                                           self.model.device), torch.empty(self.world, dtype=torch.int32, device=self.model.device))
-                for name, (_, _, a, b) in inputs.items()}
-        hosts = {name: torch.empty(self.world, dtype=torch.int32).pin_memory() for name in inputs}
-        self._side.wait_stream(main)
-        plans = {}
+        ops.stream_wait_stream(self._side, main)      # the ids may still be in flight on the main stream; `last` is being updated there
+        look = _Look()
+        self._parity ^= 1
         with torch.cuda.stream(self._side):
-            for name, (ka, kb, a, b) in inputs.items():
-                pl, counts = ops.rows_plan_sharded(a, b, self.full_rows[name], self.world, out=bufs[name])
-                hosts[name].copy_(counts, non_blocking=True)
-                plans[name] = (ka, kb, (pl, counts))
-            ev = torch.cuda.Event()
-            ev.record(self._side)
-        self._look = (self._batch_key(batch), plans, hosts, ev, (inputs, bufs))
+            look.tabs = self._prepare(batch, self._parity)
+            look.event = torch.cuda.Event()
+            look.event.record(self._side)
+        look.key, look.keep, look.waited = self._batch_key(batch), batch, False
+        self._look = look
 
     @staticmethod
     def _batch_key(batch):
         return tuple((k, v.data_ptr(), v.numel()) for k, v in sorted(batch.items()) if torch.is_tensor(v))
 
+    def _catchup(self, tabs, target_t):
+        """bring the owner rows of `tabs` to the state after step target_t (lazy_dense): the rows with history only when the filter exists"""
+        cfg = self._cfg(target_t + 1)
+        for name, c in tabs.items():
+            st = self.tables[name]
+            if st["last"] is not None and c["caught_up"] != target_t:
+                ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], c["filt"] if c["filt"] is not None else c["own"])
+                c["caught_up"] = target_t
+
     # ------------------------------------------------------------------ the step
+    def _check_overflow(self):
+        """the flags of the step two steps back (long finished: no stall).  An overflow there -> every rank skipped that step: double
+        the capacity and train the batch again (every rank reads the same all-gathered flags at the same step: lockstep)."""
+        k = (self.t - 1) % 4            # slot of step t - 2 (this is called with self.t = index of the last finished enqueue)
+        ev, b = self._flag_ev[k], self._flag_batch[k]
+        self._flag_ev[k] = self._flag_batch[k] = None
+        if ev is None or self._replaying:
+            return
+        ev.synchronize()
+        if float(self._flag_host[k][3]) > 0:
+            batch, scale_then = b
+            self.n_overflow += 1
+            if scale_then == self._cap_scale:   # (the step after it may have overflowed under the same, since doubled, capacity)
+                self._cap_scale *= 2
+            self._look = None             # made with the old capacity
+            import warnings
+            warnings.warn(f"row exchange: capacity overflow at step {self.t - 1}; capacity doubled (x{self._cap_scale}), batch re-trained")
+            self._replaying = True
+            try:
+                self.train_step(batch, None)
+            finally:
+                self._replaying = False
+
     def train_step(self, batch, next_batch=None):
         """One optimisation step of the ONE model on this rank's batch (a dict of device tensors as the Trainer builds it).
-        Returns this rank's loss (device scalar, detached)."""
-        model, W, xchg = self.model, self.world, self.xchg
+        Returns the mean loss over the ranks (device scalar; trainer.py:353 gather_for_metrics(loss).mean())."""
+        model, W = self.model, self.world
         if not model.training:
             model.train()
+        cuda = model.device.type == "cuda"
+        if self.t >= 2:
+            self._check_overflow()
         self.zero_grad()
         self.t += 1
         cfg = self._cfg(self.t)
-        # ---- 1. plans: adopt the lookahead (host-side counts: no stream sync) or sort now (one host sync for the counts)
+        # ---- 1. ids-only state: adopt the lookahead (an event wait, unless the previous step's tail already waited) or make it now
         look, self._look = self._look, None
-        host_counts = None
+        tabs = None
         if look is not None:
-            torch.cuda.current_stream().wait_event(look[3])
-            if look[0] == self._batch_key(batch):
-                look[3].synchronize()
-                plans, host_counts = look[1], {n: [int(x) for x in h.tolist()] for n, h in look[2].items()}
-            else:
-                plans = self._sharded_plans(batch)
-        else:
-            plans = self._sharded_plans(batch)
+            if not look.waited:
+                torch.cuda.current_stream().wait_event(look.event)
+            if look.key == self._batch_key(batch):
+                tabs = look.tabs
+        if tabs is None:
+            self._parity ^= 1
+            tabs = self._prepare(batch, self._parity)
         if next_batch is not None:
             self.prefetch(next_batch)
-        # ---- 2. per table: ids -> owners, rows back
-        ctx = {}
+        # ---- 2. owner rows up to date (normally done at the tail of the previous step), then the rows travel
+        if self.t > 1:
+            self._catchup(tabs, self.t - 1)
         cbatch = dict(batch)
-        for name, (ka, kb, (pl, counts)) in plans.items():
-            st = self.tables[name]
-            n_local = st["w"].shape[0]
-            if host_counts is not None:
-                send, recv = xchg.exchange_counts_host(host_counts[name])
-            else:
-                send, recv = xchg.exchange_counts_dev(counts)
-            n_uniq = sum(send)
-            keys = pl.uniq_idx[:n_uniq]
-            req_send = (keys % n_local).to(torch.int32) if W > 1 else keys
-            req = xchg.all_to_all_rows(req_send, send, recv, label="a2a_ids").contiguous()
-            # every sender's block is ascending and unique (its plan sorted it): the owner-side plan is a W-way merge
-            own = ops.rows_plan_merge(req, recv) if 1 < W <= 64 and req.numel() > 0 else ops.rows_plan(req, None, n_local)
-            if st["last"] is not None and self.t > 1:
-                ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], own)
-            compact = xchg.all_to_all_rows(ops.embedding_gather(st["w"], req), recv, send, label="a2a_rows")
-            idx_a, idx_b = ops.compact_index(pl)
-            if ka is not None:
-                cbatch[ka] = idx_a.view(batch[ka].shape)
-            if kb is not None:
-                cbatch[kb] = idx_b[:-1].view(batch[kb].shape)
-            ctx[name] = dict(pl=pl, own=own, send=send, recv=recv, n_uniq=n_uniq, keys=keys, compact=compact, n_local=n_local)
+        for name, c in tabs.items():
+            st, bf, sb = self.tables[name], c["bf"], c["sb"]
+            ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, c["cap"], sb["rows_ws"], compact=sb["compact"], transport=self._native)
+            if not self._native:
+                self._a2a(sb["rows_ws"], sb["compact"], "a2a_rows")
+            if c["ka"] is not None:
+                cbatch[c["ka"]] = bf["idx_a"].view(batch[c["ka"]].shape)
+            if c["kb"] is not None:
+                cbatch[c["kb"]] = bf["idx_b"].view(batch[c["kb"]].shape)
         # ---- 3. the model's own forward / backward on the compact tables (bias vectors compacted the same way)
         swapped = []
         try:
-            for name, c in ctx.items():
+            for name, c in tabs.items():
                 p = getattr(model, name).weight
                 swapped.append((p, p.data))
-                p.data = c["compact"]
-            bias_ctx = self._compact_biases(ctx, plans, batch, swapped)
+                p.data = c["sb"]["compact"]
+            bias_ctx = self._compact_biases(tabs, batch, swapped)
             if "user_id" in cbatch and cbatch["user_id"].dtype != torch.int64:
                 cbatch["user_id"] = cbatch["user_id"].to(torch.int64)
             kw = {k: cbatch[k] for k in ("user_id", "item_id", "label", "item_seq", "item_seq_len") if k in cbatch}
-            loss = model.forward_backward(**kw)
+            model.forward_backward(**kw)
         finally:
             for p, data in reversed(swapped):
                 p.data = data
-        # ---- 4. row gradients: reduce per unique key, send to the owners, owners sum in source-rank order
-        owner_grads = {}
-        for name, c in ctx.items():
-            ids_a, rows, ids_b, coef, vec, G = self._collect(name)
-            d = c["compact"].shape[1]
-            if ids_b is not None:    # the trailing id-0 lookup carries a zero coefficient and a zero vector row
-                coef = torch.cat([coef.reshape(-1), self._zero_coef])
-                vec = torch.cat([vec.reshape(-1, d), torch.zeros(1, d, dtype=vec.dtype, device=vec.device)])
-            else:
-                coef, vec, G = self._zero_coef, torch.zeros(1, d, dtype=torch.float32, device=c["compact"].device), 1
-            ug = ops.rows_reduce(c["pl"], rows, coef, vec, G, d)[: c["n_uniq"]]
-            grads_in = xchg.all_to_all_rows(ug, c["send"], c["recv"], label="a2a_row_grads").contiguous()
-            owner_grads[name] = ops.rows_reduce(c["own"], grads_in, None, None, 1, d, zero_tail=self.grad_clip is not None)
-        # ---- 5. dense gradients + bias gradients + flags: ONE flat all-reduce (sum)
-        model.finish_backward()
-        dgrad = model.dense_flat.grad if model.dense_flat.grad is not None else torch.zeros_like(model.dense_flat.data)   # (MF: no dense parameters)
-        pieces = [dgrad.reshape(-1)]
-        bias_full = []
-        for p, gid in bias_ctx:       # compact bias gradient -> the bias vector's own index space
-            g = torch.zeros_like(p.data)
-            if p.grad is not None:
-                g.index_add_(0, gid, p.grad.reshape(-1)[: gid.numel()])
-            bias_full.append(g)
-            pieces.append(g)
-        for p in self.extra:
-            if not any(p is q for q, _ in bias_ctx):
-                bias_full.append(p.grad.reshape(-1) if p.grad is not None else torch.zeros_like(p.data))
-                pieces.append(bias_full[-1])
         guard = getattr(model, "loss_guard", None)
-        nan_flag = (guard < 0).to(torch.float32) if guard is not None else self._zero_coef
-        extra = [nan_flag]
-        if self.grad_clip is not None:   # sum of squares of THIS rank's owned row gradients rides along
-            ss = self._scalars[0:1]
-            first = True
-            for name, og in owner_grads.items():
-                ops.sumsq(og, ss, accumulate=not first, ws=self._sumsq_ws)
-                first = False
+        loss_buf = guard._base if guard is not None and guard._base is not None else None   # the loss kernels' [loss, n, guard, .]
+        # ---- 4. row gradients: reduce per unique key, scatter to slots (+ this rank's flags in slot 0), owners sum in source-rank order
+        owner_grads, out4 = {}, self._out4[self.t % 4]
+        first = True
+        for name, c in tabs.items():
+            ids_a, rows, ids_b, coef, vec, G = self._collect(name)
+            sb, bf = c["sb"], c["bf"]
+            d = sb["compact"].shape[1]
+            ug = ops.rows_reduce(c["pl"], rows, coef.reshape(-1) if coef is not None else None, vec, G, d)
+            ops.shard_exchange_grads(ug, bf["uos"], W, c["cap"], sb["send_grads"], grads_in=sb["grads_in"], transport=self._native,
+                                     loss_out=loss_buf, flags=bf["flags"])
+            if not self._native:
+                self._a2a(sb["send_grads"], sb["grads_in"], "a2a_row_grads")
             if first:
-                ss.zero_()
-            extra.append(ss)
-        flat = torch.cat(pieces + extra)
-        flat = xchg.all_reduce_sum(flat)
-        n_tail = len(extra)
-        tail = flat[flat.numel() - n_tail:]
-        # gradient scale of every update kernel: 1/W (DDP's mean), times the clip coefficient, or -1 = skip (a NaN loss somewhere)
-        scale = torch.where(tail[0:1] > 0, torch.full_like(self.inv_w, -1.0), self.inv_w)
-        if self.grad_clip is not None:
-            body = flat[: flat.numel() - n_tail]
-            ss_all = self._scalars[2:3]
-            ops.sumsq(body, ss_all, accumulate=False, ws=self._sumsq_ws)
-            total = (ss_all + tail[1:2]) * (self.inv_w * self.inv_w)       # squared norm of the AVERAGED gradient
-            coef = self._scalars[1:2]
-            ops.clip_coef(total, self.grad_clip, coef)
-            scale = torch.where(scale < 0, scale, scale * coef)
-        # ---- 6. updates: owners' rows, then the replicated dense parameters
-        for name, c in ctx.items():
-            st = self.tables[name]
-            ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], c["own"], owner_grads[name], st["last"], scale)
-        o = model.dense_flat.numel()
-        ops.dense_adam(cfg, model.dense_flat.data, flat[:o].contiguous(), self.dense_m, self.dense_v, scale)
-        for p, (m, v), g in zip(self._bias_order(bias_ctx), self._bias_state(bias_ctx), bias_full):
-            n = p.numel()
-            ops.dense_adam(cfg, p.data, flat[o:o + n].contiguous(), m, v, scale)
-            o += n
+                ops.shard_step_flags(sb["grads_in"], W, c["cap"], out4)
+                first = False
+            owner_grads[name] = ops.rows_reduce(c["own"], sb["grads_in"], None, None, 1, d, zero_tail=self.grad_clip is not None)
+        scale = out4[0:1]
+        if cuda:
+            k = self.t % 4
+            self._flag_host[k].copy_(out4, non_blocking=True)
+            self._flag_ev[k] = torch.cuda.Event()
+            self._flag_ev[k].record()
+            self._flag_batch[k] = (batch, self._cap_scale)
+        # ---- 5./6. updates
+        side = None
+        if self.grad_clip is None:
+            # rows first (nothing to wait for), then the next batch's owner rows take this step too -- under the dense-gradient stream
+            for name, c in tabs.items():
+                st = self.tables[name]
+                ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], c["own"], owner_grads[name], st["last"], scale)
+            nxt = self._look
+            if nxt is not None and self.table_mode == "lazy_dense":
+                torch.cuda.current_stream().wait_event(nxt.event)
+                nxt.waited = True
+                self._catchup(nxt.tabs, self.t)
+            g = getattr(model, "_deferred_dense_grad", None)
+            if g is not None and g.numel() and not self.extra and not bias_ctx:
+                side = ops.sasrec_side_stream()
+            if side is not None:
+                # the dense half behind the encoder's own reductions on ITS stream: all-reduce (second communicator) + update; the next
+                # forward pass joins after its first launch.  `scale` was made on the main stream: the side stream waits for it
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    self._all_reduce(g)
+                    ops.dense_adam(cfg, model.dense_flat.data, g, self.dense_m, self.dense_v, scale)
+                ops.sasrec_side_publish(late=next_batch is not None, hold=(g, out4) + tuple(getattr(model, "_deferred_reads", ())))
+                model.dense_flat.grad = g
+                object.__setattr__(model, "_deferred_dense_grad", None)
+        if side is None:
+            self._dense_main(cfg, bias_ctx, owner_grads, tabs, scale)
         object.__setattr__(model, "loss_guard", None)
         model.sparse_grads.clear()
         model.dense_flat.grad = None
         for p in self.extra:
             p.grad = None
-        return loss.detach()
+        return out4[1]
+
+    def _dense_main(self, cfg, bias_ctx, owner_grads, tabs, scale):
+        """the dense half on the main stream: ONE flat all-reduce (dense gradients, bias gradients and -- with clipping -- the owners'
+        row-gradient norms), the clip coefficient, the updates (and, with clipping, the row updates that waited for the norm)"""
+        model = self.model
+        model.finish_backward()
+        dgrad = model.dense_flat.grad if model.dense_flat.grad is not None else torch.zeros_like(model.dense_flat.data)   # (MF: no dense parameters)
+        pieces = [dgrad.reshape(-1)]
+        for p, gid in bias_ctx:       # compact bias gradient -> the bias vector's own index space
+            g = torch.zeros_like(p.data)
+            if p.grad is not None:
+                g.index_add_(0, gid, p.grad.reshape(-1)[: gid.numel()])
+            pieces.append(g)
+        for p in self.extra:
+            if not any(p is q for q, _ in bias_ctx):
+                pieces.append(p.grad.reshape(-1) if p.grad is not None else torch.zeros_like(p.data))
+        tail = []
+        if self.grad_clip is not None:   # sum of squares of THIS rank's owned row gradients rides along
+            ss = self._scalars[0:1]
+            first = True
+            for og in owner_grads.values():
+                ops.sumsq(og, ss, accumulate=not first, ws=self._sumsq_ws)
+                first = False
+            if first:
+                ss.zero_()
+            tail = [ss]
+        flat = torch.cat(pieces + tail) if len(pieces) + len(tail) > 1 else pieces[0]
+        flat = self._all_reduce(flat)
+        if self.grad_clip is not None:
+            body = flat[: flat.numel() - 1]
+            ss_all = self._scalars[2:3]
+            ops.sumsq(body, ss_all, accumulate=False, ws=self._sumsq_ws)
+            total = (ss_all + flat[flat.numel() - 1:]) * (self.inv_w * self.inv_w)       # squared norm of the AVERAGED gradient
+            coef = self._scalars[1:2]
+            ops.clip_coef(total, self.grad_clip, coef)
+            scale = torch.where(scale < 0, scale, scale * coef)
+            for name, c in tabs.items():
+                st = self.tables[name]
+                ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], c["own"], owner_grads[name], st["last"], scale)
+            nxt = self._look
+            if nxt is not None and self.table_mode == "lazy_dense":
+                torch.cuda.current_stream().wait_event(nxt.event)
+                nxt.waited = True
+                self._catchup(nxt.tabs, self.t)
+        o = model.dense_flat.numel()
+        if o:
+            ops.dense_adam(cfg, model.dense_flat.data, flat[:o].contiguous(), self.dense_m, self.dense_v, scale)
+        for p, (m, v) in zip(self._bias_order(bias_ctx), self._bias_state(bias_ctx)):
+            n = p.numel()
+            ops.dense_adam(cfg, p.data, flat[o:o + n].contiguous(), m, v, scale)
+            o += n
 
     # ---- bias vectors under compacted ids -------------------------------------------------------------------------------
-    def _global_ids(self, name, c):
-        """global id of every compact row of table `name` (row 0 = id 0)."""
-        keys = c["keys"].to(torch.int64)
+    def _global_ids(self, c):
+        """global id of every compact row (= slot) of a table's fixed-capacity exchange (padding slots: id 0)."""
+        local = c["bf"]["send_ids"].to(torch.int64)
         if self.world == 1:
-            return keys
-        owner, local = keys // c["n_local"], keys % c["n_local"]
-        return torch.where(keys > 0, (local - 1) * self.world + owner, torch.zeros_like(keys))
+            return local
+        owner = torch.arange(local.numel(), device=local.device) // c["cap"]
+        return torch.where(local > 0, (local - 1) * self.world + owner, torch.zeros_like(local))
 
-    def _compact_biases(self, ctx, plans, batch, swapped):
+    def _compact_biases(self, tabs, batch, swapped):
         """item_bias is indexed by item_id, user_bias by user_id: when that field was re-indexed to compact rows, the model must
         see the bias entries of those rows.  -> [(parameter, global ids of its compact entries)]"""
         model, out = self.model, []
@@ -322,9 +483,9 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             if not getattr(model, "has_" + pname, False):
                 continue
             p = getattr(model, pname)
-            for name, (ka, kb, _) in plans.items():
-                if field in (ka, kb):
-                    gid = self._global_ids(name, ctx[name])
+            for name, c in tabs.items():
+                if field in (c["ka"], c["kb"]):
+                    gid = self._global_ids(c)
                     swapped.append((p, p.data))
                     p.data = p.data[gid].contiguous()
                     out.append((p, gid))
@@ -341,29 +502,34 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
     # ------------------------------------------------------------------ evaluation-time access to rows
     @torch.no_grad()
     def compact_batch(self, batch):
-        """For evaluation forwards: fetch the rows `batch` looks up.  -> (re-indexed batch, restore()); between the call and
-        restore() the model's tables (and bias vectors) are the compact ones.  Call flush() first in lazy_dense mode."""
-        model, xchg, W = self.model, self.xchg, self.world
-        plans = self._sharded_plans(batch)
-        ctx, cbatch, swapped = {}, dict(batch), []
-        for name, (ka, kb, (pl, counts)) in plans.items():
-            st = self.tables[name]
-            n_local = st["w"].shape[0]
-            send, recv = xchg.exchange_counts_dev(counts)
-            keys = pl.uniq_idx[: sum(send)]
-            req_send = (keys % n_local).to(torch.int32) if W > 1 else keys
-            req = xchg.all_to_all_rows(req_send, send, recv).contiguous()
-            compact = xchg.all_to_all_rows(ops.embedding_gather(st["w"], req), recv, send)
-            idx_a, idx_b = ops.compact_index(pl)
-            if ka is not None:
-                cbatch[ka] = idx_a.view(batch[ka].shape)
-            if kb is not None:
-                cbatch[kb] = idx_b[:-1].view(batch[kb].shape)
-            ctx[name] = dict(keys=keys, n_local=n_local)
+        """For evaluation forwards: fetch the rows `batch` looks up (the same fixed-capacity exchange as a training step, on the current
+        stream).  -> (re-indexed batch, restore()); between the call and restore() the model's tables (and bias vectors) are the compact
+        ones.  Call flush() first in lazy_dense mode.  Evaluation is not the hot path: the overflow flag is checked on the spot (one
+        host synchronisation) and the capacity doubled until the batch fits."""
+        model, W = self.model, self.world
+        while True:
+            self._parity ^= 1
+            tabs = self._prepare(batch, self._parity)
+            ovf = torch.stack([c["bf"]["flags"][0:1].to(torch.float32) for c in tabs.values()]).sum().reshape(1)
+            if float(self._all_reduce(ovf)) == 0:
+                break
+            self._cap_scale *= 2
+            self.n_overflow += 1
+        cbatch, swapped = dict(batch), []
+        for name, c in tabs.items():
+            st, bf, sb = self.tables[name], c["bf"], c["sb"]
+            compact = torch.empty_like(sb["compact"])      # (the caller keeps it until restore(): not the step's buffer)
+            ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, c["cap"], sb["rows_ws"], compact=compact, transport=self._native)
+            if not self._native:
+                self._a2a(sb["rows_ws"], compact, "a2a_rows")
+            if c["ka"] is not None:
+                cbatch[c["ka"]] = bf["idx_a"].clone().view(batch[c["ka"]].shape)
+            if c["kb"] is not None:
+                cbatch[c["kb"]] = bf["idx_b"].clone().view(batch[c["kb"]].shape)
             p = getattr(model, name).weight
             swapped.append((p, p.data))
             p.data = compact
-        self._compact_biases(ctx, plans, batch, swapped)
+        self._compact_biases(tabs, batch, swapped)
         if "user_id" in cbatch and cbatch["user_id"].dtype != torch.int64:
             cbatch["user_id"] = cbatch["user_id"].to(torch.int64)
 

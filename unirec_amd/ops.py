@@ -274,7 +274,7 @@ def rows_plan(ids_a, ids_b, n_rows, out=None) -> RowsPlan:
     return pl
 
 
-def rows_plan_merge(ids, run_counts) -> RowsPlan:
+def rows_plan_merge(ids, run_counts, out=None) -> RowsPlan:
     """plan of int32 `ids` that consist of len(run_counts) concatenated runs, each ascending and unique (one per sending rank):
     same result as rows_plan(ids, None, ...), by a W-way merge instead of a sort (include/unirec_amd.h: ur_rows_plan_merge)."""
     _chk(ids, torch.int32, "ids")
@@ -284,7 +284,7 @@ def rows_plan_merge(ids, run_counts) -> RowsPlan:
         starts.append(starts[-1] + int(c))
     if starts[-1] != n:
         raise _lib.UnirecAmdError("rows_plan_merge: run_counts do not sum to the number of ids")
-    pl, ws = rows_plan_alloc(n, n, ids.device)
+    pl, ws = out if out is not None else rows_plan_alloc(n, n, ids.device)
     arr = (C.c_int32 * len(starts))(*starts)
     check(lib.ur_rows_plan_merge(_p(ids), n, arr, len(run_counts), _p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq),
                                  _p(ws), _stream()), "ur_rows_plan_merge")
@@ -336,13 +336,13 @@ def comm_world():
 def comm_init(rank, world, group=None):
     """The library's own RCCL communicator, one per process: rank 0 makes the unique id, torch.distributed (any backend) carries it."""
     import torch.distributed as dist
-    buf = (C.c_char * 128)()
+    buf = (C.c_char * 256)()
     if rank == 0:
         check(lib.ur_comm_unique_id(buf), "ur_comm_unique_id")
     if world > 1:
         box = [bytes(buf.raw)]
         dist.broadcast_object_list(box, src=0, group=group)
-        buf = (C.c_char * 128).from_buffer_copy(box[0])
+        buf = (C.c_char * 256).from_buffer_copy(box[0])
     check(lib.ur_comm_init(buf, int(rank), int(world)), "ur_comm_init")
 
 
@@ -375,13 +375,22 @@ def shard_exchange_rows(table, req_ids, world, cap, rows_ws, compact=None, trans
     return compact if transport else rows_ws
 
 
-def shard_exchange_grads(uniq_grad, u_of_slot, world, cap, send_ws, grads_in=None, transport=False):
+def shard_exchange_grads(uniq_grad, u_of_slot, world, cap, send_ws, grads_in=None, transport=False, loss_out=None, flags=None):
+    """loss_out (the loss kernels' [loss, n, guard, .] buffer) / flags (shard_exchange_ids): this rank's step flags, carried in slot 0"""
     _chk(uniq_grad, torch.float32, "uniq_grad"); _chk(u_of_slot, torch.int32, "u_of_slot"); _chk(send_ws, torch.float32, "send_ws")
+    _chk(loss_out, torch.float32, "loss_out", allow_none=True); _chk(flags, torch.int32, "flags", allow_none=True)
     d = uniq_grad.shape[1]
     assert u_of_slot.numel() == world * cap and send_ws.numel() == world * cap * d
-    check(lib.ur_shard_exchange_grads(_p(uniq_grad), _p(u_of_slot), int(world), int(cap), d, _p(send_ws), _p(grads_in),
-                                      1 if transport else 0, _stream()), "ur_shard_exchange_grads")
+    check(lib.ur_shard_exchange_grads(_p(uniq_grad), _p(u_of_slot), int(world), int(cap), d, _p(loss_out), _p(flags), _p(send_ws),
+                                      _p(grads_in), 1 if transport else 0, _stream()), "ur_shard_exchange_grads")
     return grads_in if transport else send_ws
+
+
+def shard_step_flags(grads_in, world, cap, out4):
+    """-> out4 = [gradient scale (1 / world or -1 = skip), mean loss over the ranks, #NaN ranks, #overflow ranks] (ur_shard_step_flags)"""
+    _chk(grads_in, torch.float32, "grads_in"); _chk(out4, torch.float32, "out4")
+    check(lib.ur_shard_step_flags(_p(grads_in), int(world), int(cap), grads_in.shape[-1], _p(out4), _stream()), "ur_shard_step_flags")
+    return out4
 
 
 def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False) -> torch.Tensor:
