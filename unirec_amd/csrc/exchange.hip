@@ -25,17 +25,29 @@ namespace ur {
 // slot q = o * cap + p of the send block.  Slot 0 of EVERY block is reserved padding (it carries the step's flags in the gradient
 // exchange, and compact row 0 -- owner 0's slot 0 -- is the padding row the re-indexed lookups of id 0 read), so a block holds up to
 // cap - 1 keys:  pad = cap - min(cap - 1, count[o]);  p < pad: padding (local row 0), else the (p - pad)-th key of owner o
+// The keys are sorted by (owner, local row), so owner o's keys are the range [lower_bound(o * n_local), lower_bound((o + 1) * n_local)) of
+// the unique list: W + 1 binary searches per workgroup (the list sits in L2), no counting pass -- counting the owners with one atomic per
+// unique key in the plan's head kernel was 27 K atomics on W addresses: 300 us at W = 1, and it slowed every kernel running beside it.
 __global__ __launch_bounds__(256) void shard_pack_kernel(const int* __restrict__ uniq_key, const int* __restrict__ n_uniq_dev,
-                                                         const int* __restrict__ counts, long long n_local, int W, int cap,
+                                                         int* __restrict__ counts_out, long long n_local, int W, int cap,
                                                          int* __restrict__ send_ids, int* __restrict__ slot_of_uniq,
                                                          int* __restrict__ u_of_slot, int* __restrict__ flags) {
   __shared__ int pre[65];
-  if (threadIdx.x == 0) {
-    int s = 0;
-    for (int o = 0; o < W; ++o) { pre[o] = s; s += counts[o]; }
-    pre[W] = s;
+  if ((int)threadIdx.x <= W) {
+    const int n_uniq = *n_uniq_dev;
+    const unsigned long long bound = (unsigned long long)threadIdx.x * (unsigned long long)n_local;   // first key of owner threadIdx.x
+    int lo = 0, hi = n_uniq;
+    if ((int)threadIdx.x == W) lo = n_uniq;
+    else if (W > 1)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((unsigned long long)(unsigned)uniq_key[mid] < bound) lo = mid + 1; else hi = mid;
+      }
+    else lo = 0;
+    pre[threadIdx.x] = lo;
   }
   __syncthreads();
+  if (counts_out && blockIdx.x == 0 && (int)threadIdx.x < W) counts_out[threadIdx.x] = pre[threadIdx.x + 1] - pre[threadIdx.x];
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= W * cap) return;
   const int o = q / cap, p = q % cap;
@@ -202,10 +214,10 @@ extern "C" int ur_comm_all_reduce_sum(float* buf, int64_t n, void* stream) {
 
 // (1) ids: pack the plan's unique keys into the fixed-capacity send block, then (communicator up) all-to-all into recv_ids.
 // transport == 0: pack only -- the caller moves send_ids itself (the gloo route of the CPU-staged tests).
-extern "C" int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_uniq_dev, const int32_t* counts_dev, int64_t n_local,
+extern "C" int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_uniq_dev, int32_t* counts_dev, int64_t n_local,
                                      int32_t world, int32_t cap, int32_t* send_ids, int32_t* slot_of_uniq, int32_t* u_of_slot,
                                      int32_t* flags_dev, int32_t* recv_ids, int32_t transport, void* stream) {
-  UR_REQUIRE(uniq_key && n_uniq_dev && counts_dev && send_ids && slot_of_uniq && u_of_slot && flags_dev, UR_ERR_ARG,
+  UR_REQUIRE(uniq_key && n_uniq_dev && send_ids && slot_of_uniq && u_of_slot && flags_dev, UR_ERR_ARG,
              "ur_shard_exchange_ids: null pointer");
   UR_REQUIRE(world >= 1 && world <= 64 && cap > 0 && (long long)world * cap < (1LL << 31), UR_ERR_ARG,
              "ur_shard_exchange_ids: world=%d cap=%d", world, cap);

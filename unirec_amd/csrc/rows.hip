@@ -996,7 +996,7 @@ extern "C" int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* id
 extern "C" int ur_rows_plan_sharded(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
                                     int32_t world, int32_t* uniq_key, int32_t* seg_start, int32_t* sorted_pos,
                                     int32_t* n_uniq_dev, int32_t* owner_counts_dev, void* ws, void* stream) {
-  UR_REQUIRE(world >= 1 && world <= 1024 && owner_counts_dev, UR_ERR_ARG, "ur_rows_plan_sharded: world=%d", world);
+  UR_REQUIRE(world >= 1 && world <= 1024, UR_ERR_ARG, "ur_rows_plan_sharded: world=%d", world);
   return rows_plan_impl(ids_a, n_a, ids_b, n_b, n_rows, world, uniq_key, seg_start, sorted_pos, n_uniq_dev, owner_counts_dev, ws,
                         stream);
 }

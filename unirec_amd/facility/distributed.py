@@ -157,7 +157,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
     def _a2a(self, send, recv, label):
         """equal-split all-to-all of a packed block through torch.distributed (the non-native route)"""
         if self.world == 1:
-            recv.copy_(send)
+            assert recv.data_ptr() == send.data_ptr()     # (aliased at world 1: see _buffers)
             return recv
         recv.copy_(self.xchg.all_to_all_equal(send, label=label))
         return recv
@@ -208,8 +208,10 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             dev, W = self.model.device, self.world
             cap = self._capacity(n)
             i32 = dict(dtype=torch.int32, device=dev)
-            bf = dict(cap=cap, plan=ops.rows_plan_alloc(n, n_a, dev), counts=torch.empty(W, **i32), send_ids=torch.empty(W * cap, **i32),
-                      recv_ids=torch.empty(W * cap, **i32), slot=torch.zeros(n, **i32), uos=torch.empty(W * cap, **i32),
+            send_ids = torch.empty(W * cap, **i32)
+            bf = dict(cap=cap, plan=ops.rows_plan_alloc(n, n_a, dev), counts=torch.empty(W, **i32), send_ids=send_ids,
+                      # (world 1: every exchange is the identity -- the receive buffers ARE the send buffers, nothing is copied)
+                      recv_ids=torch.empty(W * cap, **i32) if W > 1 else send_ids, slot=torch.zeros(n, **i32), uos=torch.empty(W * cap, **i32),
                       flags=torch.zeros(4, **i32), own=ops.rows_plan_alloc(W * cap, W * cap, dev),
                       idx_a=torch.empty(n_a, **i32) if n_a else None,
                       idx_b=torch.empty(n - n_a, dtype=torch.int64, device=dev) if n > n_a else None)
@@ -219,8 +221,9 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         if sb is None:
             dev, W, cap = self.model.device, self.world, bf["cap"]
             f32 = dict(dtype=torch.float32, device=dev)
-            sb = dict(rows_ws=torch.empty(W * cap, d, **f32), compact=torch.empty(W * cap, d, **f32),
-                      send_grads=torch.empty(W * cap, d, **f32), grads_in=torch.empty(W * cap, d, **f32))
+            rows_ws, send_grads = torch.empty(W * cap, d, **f32), torch.empty(W * cap, d, **f32)
+            sb = dict(rows_ws=rows_ws, compact=torch.empty(W * cap, d, **f32) if W > 1 else rows_ws,
+                      send_grads=send_grads, grads_in=torch.empty(W * cap, d, **f32) if W > 1 else send_grads)
             self._bufs[skey] = sb
         return bf, sb
 
@@ -233,7 +236,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             n = n_a + (b.numel() if b is not None else 0)
             bf, sb = self._buffers(name, n, n_a, st["w"].shape[1], parity)
             cap = bf["cap"]
-            pl, counts = ops.rows_plan_sharded(a, b, self.full_rows[name], W, out=(bf["plan"], bf["counts"]))
+            pl, counts = ops.rows_plan_sharded(a, b, self.full_rows[name], W, out=(bf["plan"], bf["counts"]), want_counts=False)
             bf["flags"].zero_()
             ops.shard_exchange_ids(pl, counts, st["w"].shape[0], W, cap, bf["send_ids"], bf["slot"], bf["uos"], bf["flags"],
                                    recv_ids=bf["recv_ids"], transport=self._native)
@@ -519,8 +522,9 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         for name, c in tabs.items():
             st, bf, sb = self.tables[name], c["bf"], c["sb"]
             compact = torch.empty_like(sb["compact"])      # (the caller keeps it until restore(): not the step's buffer)
-            ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, c["cap"], sb["rows_ws"], compact=compact, transport=self._native)
-            if not self._native:
+            ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, c["cap"], sb["rows_ws"] if W > 1 else compact, compact=compact,
+                                    transport=self._native)
+            if not self._native and W > 1:
                 self._a2a(sb["rows_ws"], compact, "a2a_rows")
             if c["ka"] is not None:
                 cbatch[c["ka"]] = bf["idx_a"].clone().view(batch[c["ka"]].shape)

@@ -291,10 +291,11 @@ def rows_plan_merge(ids, run_counts, out=None) -> RowsPlan:
     return pl
 
 
-def rows_plan_sharded(ids_a, ids_b, n_rows, world, out=None):
+def rows_plan_sharded(ids_a, ids_b, n_rows, world, out=None, want_counts=True):
     """Like rows_plan, but keys are (owner = id % world, local row = id // world); returns (plan, owner_counts[world] int32 dev).
     plan.uniq_idx holds the sharded keys owner * ceil(n_rows/world) + local_row.
-    out: ((RowsPlan, workspace), counts) preallocated by the caller (rows_plan_alloc + an int32[world] tensor)."""
+    out: ((RowsPlan, workspace), counts) preallocated by the caller (rows_plan_alloc + an int32[world] tensor).
+    want_counts=False: no counting pass (one atomic per unique key) -- shard_exchange_ids finds the owner ranges by bisection."""
     dev = (ids_a if ids_a is not None else ids_b).device
     n_a = ids_a.numel() if ids_a is not None else 0
     n_b = ids_b.numel() if ids_b is not None else 0
@@ -308,7 +309,8 @@ def rows_plan_sharded(ids_a, ids_b, n_rows, world, out=None):
         pl, ws = rows_plan_alloc(n, n_a, dev)
         counts = torch.empty(world, dtype=torch.int32, device=dev)
     check(lib.ur_rows_plan_sharded(_p(ids_a), n_a, _p(ids_b), n_b, int(n_rows), int(world), _p(pl.uniq_idx), _p(pl.seg_start),
-                                   _p(pl.sorted_pos), _p(pl.n_uniq), _p(counts), _p(ws), _stream()), "ur_rows_plan_sharded")
+                                   _p(pl.sorted_pos), _p(pl.n_uniq), _p(counts if want_counts else None), _p(ws), _stream()),
+          "ur_rows_plan_sharded")
     return pl, counts
 
 
@@ -358,8 +360,9 @@ def comm_all_reduce_sum(t):
 
 def shard_exchange_ids(pl: RowsPlan, counts, n_local, world, cap, send_ids, slot_of_uniq, u_of_slot, flags, recv_ids=None, transport=False):
     """pack (+ RCCL all-to-all when transport): see ur_shard_exchange_ids.  Buffers are the caller's (preallocated once)."""
-    for t, nm in ((counts, "counts"), (send_ids, "send_ids"), (slot_of_uniq, "slot_of_uniq"), (u_of_slot, "u_of_slot"), (flags, "flags")):
+    for t, nm in ((send_ids, "send_ids"), (slot_of_uniq, "slot_of_uniq"), (u_of_slot, "u_of_slot"), (flags, "flags")):
         _chk(t, torch.int32, nm)
+    _chk(counts, torch.int32, "counts", allow_none=True)   # (output: per-owner unique counts, optional)
     assert send_ids.numel() == world * cap and u_of_slot.numel() == world * cap and slot_of_uniq.numel() >= pl.n
     check(lib.ur_shard_exchange_ids(_p(pl.uniq_idx), _p(pl.n_uniq), _p(counts), int(n_local), int(world), int(cap), _p(send_ids),
                                     _p(slot_of_uniq), _p(u_of_slot), _p(flags), _p(recv_ids), 1 if transport else 0, _stream()),
