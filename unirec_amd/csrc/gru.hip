@@ -32,7 +32,7 @@ static GruLayout gru_layout(const UrGruCfg& c) {
 struct GruWs {
   int* seq_tm;
   float *x, *gi, *gh, *h_all, *r, *z, *n, *hn;          // saved by forward
-  float *dh, *dh_carry, *dgi, *dgh, *dx_tm, *w_ihT, *w_hhT, *w_dT, *tn_ws;
+  float *dh, *dh_carry, *dgi, *dgh, *dx_tm, *w_ihT, *w_hhT, *w_dT, *tn_ws, *tn_ws2;
   long long total_floats;
 };
 static GruWs gru_carve(const UrGruCfg& c, float* base) {
@@ -53,6 +53,7 @@ static GruWs gru_carve(const UrGruCfg& c, float* base) {
   if (gemm_tn_ws_floats((int)M, (int)(3 * H), (int)d) > tn) tn = gemm_tn_ws_floats((int)M, (int)(3 * H), (int)d);
   if (gemm_tn_ws_floats((int)B, (int)d, (int)H) > tn) tn = gemm_tn_ws_floats((int)B, (int)d, (int)H);
   w.tn_ws = take(tn);
+  w.tn_ws2 = take(gemm_tn_ws_floats((int)M, (int)(3 * H), (int)d));
   w.total_floats = o;
   return w;
 }
@@ -273,9 +274,180 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(const float* __restr
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Round 3: FOUR sequences per workgroup on v_mfma_f32_4x4x1_16b_f32 (H = 64, 128).  The 16-row kernels above put B / 16 = 32
+// workgroups on a 256-CU chip at B = 512, and a step's 16 x 3H x H product is 2.6 us of one CU's fp32 MFMA rate (H = 128): the
+// sweep is bound by how few CUs it runs on (gru class 0.064 of the roof in round 2).  The 4x4x1 form multiplies sixteen independent
+// 4 x 4 blocks per instruction at the same 64 flop / clk / SIMD, and its A operand is only 4 rows tall: with the four rows = four
+// sequences and the 64 B-operand lanes = 64 different gate columns (lane l of block b = l / 4: A from lane 4 b + i = row i,
+// B / D column = l, D register r = row r; tools/probe/mfma4x4_probe.hip), a workgroup needs 4 sequences, not 16 -- B / 4 = 128
+// workgroups, each step 0.64 us of MFMA.
+//   forward : 3H columns = 3H / 64 column groups x K splits = 24 units, three per wave (8 waves); a unit's W_hh slice (64 columns x
+//             H / splits k) is resident in VGPRs for the whole sweep; the per-unit partial pre-activations go through LDS and thread
+//             (row i, hidden unit j) sums them in split order, applies the gate math and writes h_t (LDS for the next step, HBM for
+//             the backward) -- gi_t is prefetched under the MFMAs.  Two barriers per step.
+//   backward: dh_{t-1} = dgh_t W_hh + dh_t z: H columns x 3H deep = 8 units, one per wave (three interleaved accumulator chains);
+//             thread (i, j) keeps dh[i][j] in a register across the sweep.
+constexpr int GRU4_ROWS = 4;
+
+template <int H>
+__global__ __launch_bounds__(512) void gru_seq4_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                           const float* __restrict__ b_hh, int B, int L, float* __restrict__ h_all,
+                                                           float* __restrict__ r_s, float* __restrict__ z_s, float* __restrict__ n_s,
+                                                           float* __restrict__ hn_s) {
+  constexpr int C = 3 * H, NCG = C / 64, KSPL = 24 / NCG, KU = H / KSPL;   // column groups, K splits, k per unit
+  constexpr int LDH = H + 4;
+  __shared__ __attribute__((aligned(16))) float hs[2][GRU4_ROWS][LDH];
+  __shared__ __attribute__((aligned(16))) float part[KSPL][GRU4_ROWS][C];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b0 = blockIdx.x * GRU4_ROWS;
+  int uc[3], uk[3], us[3];   // this wave's units: gate column of this lane, first k, split index
+  float wf[3][KU];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int u = w + 8 * q;
+    us[q] = u / NCG;
+    uc[q] = 64 * (u % NCG) + lane;
+    uk[q] = us[q] * KU;
+#pragma unroll
+    for (int k = 0; k < KU; k += 4) {
+      const float4 v = *(const float4*)(w_hh + (long long)uc[q] * H + uk[q] + k);
+      wf[q][k] = v.x; wf[q][k + 1] = v.y; wf[q][k + 2] = v.z; wf[q][k + 3] = v.w;
+    }
+  }
+  const bool gact = tid < GRU4_ROWS * H;       // gate thread (row gi_i, hidden unit gj)
+  const int gi_i = tid / H, gj = tid % H;
+  const int gb = min(b0 + gi_i, B - 1);
+  const float bh_r = b_hh[gj], bh_z = b_hh[H + gj], bh_n = b_hh[2 * H + gj];
+  for (int i = tid; i < GRU4_ROWS * LDH; i += 512) (&hs[0][0][0])[i] = 0.f;   // h_0 = 0
+  __syncthreads();
+  const int ai = lane & 3;   // row of the A operand this lane supplies
+  for (int t = 0; t < L; ++t) {
+    const int cur = t & 1;
+    float g_r = 0.f, g_z = 0.f, g_n = 0.f;
+    if (gact) {   // issued before the MFMAs, consumed after
+      const float* gp = gi + ((long long)t * B + gb) * C;
+      g_r = gp[gj]; g_z = gp[H + gj]; g_n = gp[2 * H + gj];
+    }
+    floatx4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KU; k += 4) {
+      float4 a4[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a4[q] = *(const float4*)&hs[cur][ai][uk[q] + k];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].x, wf[q][k], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].y, wf[q][k + 1], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].z, wf[q][k + 2], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].w, wf[q][k + 3], acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < GRU4_ROWS; ++r) part[us[q]][r][uc[q]] = acc[q][r];
+    __syncthreads();
+    if (gact) {
+      float pr = 0.f, pz = 0.f, pn = 0.f;
+#pragma unroll
+      for (int s_ = 0; s_ < KSPL; ++s_) { pr += part[s_][gi_i][gj]; pz += part[s_][gi_i][H + gj]; pn += part[s_][gi_i][2 * H + gj]; }
+      const float rr = 1.0f / (1.0f + expf(-(g_r + (pr + bh_r))));
+      const float zz = 1.0f / (1.0f + expf(-(g_z + (pz + bh_z))));
+      const float hn = pn + bh_n;
+      const float nn = tanhf(g_n + rr * hn);
+      const float hnew = (1.0f - zz) * nn + zz * hs[cur][gi_i][gj];
+      hs[cur ^ 1][gi_i][gj] = hnew;
+      if (b0 + gi_i < B) {
+        const long long o = ((long long)t * B + gb) * H + gj;
+        h_all[o + (long long)B * H] = hnew;
+        r_s[o] = rr; z_s[o] = zz; n_s[o] = nn; hn_s[o] = hn;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(512) void gru_seq4_bwd_kernel(const float* __restrict__ dh_in, const float* __restrict__ w_hh,
+                                                           const float* __restrict__ r_s, const float* __restrict__ z_s,
+                                                           const float* __restrict__ n_s, const float* __restrict__ hn_s,
+                                                           const float* __restrict__ h_all, int B, int L, float* __restrict__ dgi,
+                                                           float* __restrict__ dgh) {
+  constexpr int C = 3 * H, NCG = H / 64, KSPL = 8 / NCG, KU = C / KSPL;   // H = 128: 2 column groups x 4 splits of 96; H = 64: 1 x 8 of 24
+  constexpr int LDG = C + 4;
+  __shared__ __attribute__((aligned(16))) float dg[GRU4_ROWS][LDG];
+  __shared__ __attribute__((aligned(16))) float part[KSPL][GRU4_ROWS][H];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b0 = blockIdx.x * GRU4_ROWS;
+  const int ks = w / NCG, col = 64 * (w % NCG) + lane, k0 = ks * KU;
+  float wf[KU];   // W_hh[k0 + k][col]: the B operand of dh_{t-1}[i, col] = sum_c dgh[i, c] W_hh[c, col]
+#pragma unroll
+  for (int k = 0; k < KU; ++k) wf[k] = w_hh[(long long)(k0 + k) * H + col];
+  const bool gact = tid < GRU4_ROWS * H;
+  const int gi_i = tid / H, gj = tid % H;
+  const int gb = min(b0 + gi_i, B - 1);
+  float dh = gact ? dh_in[(long long)gb * H + gj] : 0.f;
+  const int ai = lane & 3;
+  for (int t = L - 1; t >= 0; --t) {
+    float carry = 0.f;
+    if (gact) {
+      const long long o = ((long long)t * B + gb) * H + gj;
+      const float g = dh, rr = r_s[o], zz = z_s[o], nn = n_s[o], hn = hn_s[o], hp = h_all[o];
+      const float dn = g * (1.0f - zz);
+      const float dz = g * (hp - nn);
+      const float dan = dn * (1.0f - nn * nn);
+      const float daz = dz * zz * (1.0f - zz);
+      const float dar = dan * hn * rr * (1.0f - rr);
+      const float dhn = dan * rr;
+      dg[gi_i][gj] = dar; dg[gi_i][H + gj] = daz; dg[gi_i][2 * H + gj] = dhn;
+      carry = g * zz;
+      if (b0 + gi_i < B) {
+        float* gio = dgi + ((long long)t * B + gb) * C;
+        float* gho = dgh + ((long long)t * B + gb) * C;
+        gio[gj] = dar; gio[H + gj] = daz; gio[2 * H + gj] = dan;
+        gho[gj] = dar; gho[H + gj] = daz; gho[2 * H + gj] = dhn;
+      }
+    }
+    __syncthreads();
+    floatx4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KU; k += 12) {   // three interleaved accumulator chains (KU is a multiple of 12 for H = 64, 128)
+      float4 a4[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a4[q] = *(const float4*)&dg[ai][k0 + k + 4 * q];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].x, wf[k + 4 * q], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].y, wf[k + 4 * q + 1], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].z, wf[k + 4 * q + 2], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].w, wf[k + 4 * q + 3], acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < GRU4_ROWS; ++r) part[ks][r][col] = (acc[0][r] + acc[1][r]) + acc[2][r];
+    __syncthreads();
+    if (gact) {
+      float sum = 0.f;
+#pragma unroll
+      for (int s_ = 0; s_ < KSPL; ++s_) sum += part[s_][gi_i][gj];
+      dh = sum + carry;
+    }
+  }
+}
+
+static bool gru_seq4_supported(int H) { return H == 64 || H == 128; }
+
 static bool gru_seq_supported(int H) {
   static const bool off = getenv("UR_GRU_NO_SEQ") != nullptr;   // test / tuning hook
-  return !off && (H == 32 || H == 64 || H == 128);
+  return !off && (H == 32 || H == 64 || H == 128);   // (H = 64 / 128: the four-sequence kernels, H = 32: the 16-sequence ones)
 }
 
 }  // namespace ur
@@ -322,11 +494,18 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   UR_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * H, st));
   if (gru_seq_supported(H)) {   // the whole recurrence in one launch
     ProfScope ps(PC_GRU, st, 2.0 * B * L * 3.0 * H * H);   // h_{t-1} W_hh^T of every step
-    const dim3 grid(cdiv(B, GRU_SEQ_ROWS));
+    if (gru_seq4_supported(H)) {   // four sequences per workgroup (4x4x1 MFMA): B / 4 workgroups
+#define GO4(HH) hipLaunchKernelGGL((gru_seq4_fwd_kernel<HH>), dim3(cdiv(B, GRU4_ROWS)), dim3(512), 0, st, w.gi, dense + lay.w_hh, dense + lay.b_hh, \
+                                   B, L, w.h_all, w.r, w.z, w.n, w.hn)
+      if (H == 64) GO4(64); else GO4(128);
+#undef GO4
+    } else {
+      const dim3 grid(cdiv(B, GRU_SEQ_ROWS));
 #define GO(HH) hipLaunchKernelGGL((gru_seq_fwd_kernel<HH>), grid, dim3(HH * 4), 0, st, w.gi, dense + lay.w_hh, dense + lay.b_hh, B, L, w.h_all, \
                                   w.r, w.z, w.n, w.hn)
-    if (H == 32) GO(32); else if (H == 64) GO(64); else GO(128);
+      GO(32);
 #undef GO
+    }
     UR_LAUNCH_CHECK();
   } else
   for (int t = 0; t < L; ++t) {
@@ -369,11 +548,18 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
   if (gru_seq_supported(H)) {   // the whole backward sweep in one launch
     ProfScope ps(PC_GRU, st, 2.0 * B * L * 3.0 * H * H);   // dgh_t W_hh of every step
-    const dim3 grid(cdiv(B, GRU_SEQ_ROWS));
+    if (gru_seq4_supported(H)) {
+#define GO4(HH) hipLaunchKernelGGL((gru_seq4_bwd_kernel<HH>), dim3(cdiv(B, GRU4_ROWS)), dim3(512), 0, st, w.dh, dense + lay.w_hh, w.r, w.z, w.n, w.hn, \
+                                   w.h_all, B, L, w.dgi, w.dgh)
+      if (H == 64) GO4(64); else GO4(128);
+#undef GO4
+    } else {
+      const dim3 grid(cdiv(B, GRU_SEQ_ROWS));
 #define GO(HH) hipLaunchKernelGGL((gru_seq_bwd_kernel<HH>), grid, dim3(HH * 4), 0, st, w.dh, dense + lay.w_hh, w.r, w.z, w.n, w.hn, w.h_all, B, L, \
                                   w.dgi, w.dgh)
-    if (H == 32) GO(32); else if (H == 64) GO(64); else GO(128);
+      GO(32);
 #undef GO
+    }
     UR_LAUNCH_CHECK();
   } else
   for (int t = L - 1; t >= 0; --t) {
@@ -390,8 +576,11 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
     if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
   }
   // weight gradients over all (t, b) tokens at once (time-major rows on both operands)
-  if ((rc = gemm_tn(w.dgh, 3 * H, w.h_all, H, M, 3 * H, H, 0, 0, dense_grad + lay.w_hh, H, dense_grad + lay.b_hh, w.tn_ws, st))) return rc;
-  if ((rc = gemm_tn(w.dgi, 3 * H, w.x, d, M, 3 * H, d, 0, 0, dense_grad + lay.w_ih, d, dense_grad + lay.b_ih, w.tn_ws, st))) return rc;
+  {   // (one grouped launch: dW_hh and dW_ih share the token dimension)
+    const TnReq rq[2] = {{w.dgh, 3 * H, w.h_all, H, M, 3 * H, H, 0, 0, dense_grad + lay.w_hh, H, dense_grad + lay.b_hh, w.tn_ws, nullptr},
+                         {w.dgi, 3 * H, w.x, d, M, 3 * H, d, 0, 0, dense_grad + lay.w_ih, d, dense_grad + lay.b_ih, w.tn_ws2, nullptr}};
+    if ((rc = gemm_tn_group(rq, 2, st))) return rc;
+  }
   g = GemmArgs{};   // dx = dgi W_ih
   g.A = w.dgi; g.lda = 3 * H; g.W = w.w_ihT; g.ldw = 3 * H; g.C = w.dx_tm; g.ldc = d; g.M = M; g.N = d; g.K = 3 * H;
   if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
