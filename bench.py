@@ -30,7 +30,11 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 
 # algorithmic activation traffic of the GEMM classes per step at the default workload, MB
 PROF_EVERY = 10   # the dominant kernel class is bracketed with HIP events on every PROF_EVERY-th timed step
-ALGO_BYTES_PER_STEP = {"gemm_nt": 598.0, "gemm_tn": 247.0}
+# algorithmic HBM MB per step of a kernel class at the FULL row count M = B * L (scaled by the real-token fraction where used):
+# row_chain = the four full-sequence chain launches: input block 3 072 B / row (item row in; x0, x0hat, q, k, v out), forward chain 6 144
+# (ctx, x in; a, ahat, h1, y, yhat, next k, v out), backward chain 7 168 (gy, yhat, h1, ahat in; g_tf, g_h1, g_ta, g_ctx out), projection
+# gradient 3 072 (g_qkv, g_ta, x0hat in; row gradient out) = 19 456 B / row x 25 600 rows
+ALGO_BYTES_PER_STEP = {"gemm_nt": 598.0, "gemm_tn": 247.0, "row_chain": 498.0}
 
 
 def parse():
@@ -731,15 +735,14 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "launches": c["launches"],
                 "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2)}
     # HBM bytes per launch of the dominant class: PMC counters cannot be collected from inside this process, so the
-    # figure is the committed rocprofv3 --pmc summary of the SAME workload (profiles/r02_s_pmc_hbm_traffic.json:
+    # figure is the committed rocprofv3 --pmc summary of the SAME workload (profiles/r03_a_pmc_hbm_traffic.json:
     # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction); null when the summary is absent
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_s_pmc_hbm_traffic.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_a_pmc_hbm_traffic.json")
     if roof is not None and os.path.exists(pmc) and a.n_items == 100_000_000 and a.batch == 512:
         per_class = json.load(open(pmc)).get("per_class", {})
-        per_class["row_chain"] = per_class.get("chain_ffn_fwd", per_class.get("row_chain", {}))
         if dom in per_class and per_class[dom]:
             roof["traffic"] = per_class[dom]["hbm_bytes_per_launch"]
-            roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/r02_s_pmc_hbm_traffic.json)"
+            roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/r03_a_pmc_hbm_traffic.json)"
             roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * valid_frac * 1e6 / max(1, c["launches"] / max(1, (a.steps + PROF_EVERY - 1) // PROF_EVERY)))
     emb_bytes_per_example = 8 * (L + G) * d * 4   # fwd read + bwd/opt touched rows (w,m,v,grad)
     out = {

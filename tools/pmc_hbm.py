@@ -20,7 +20,12 @@ def per_kernel(path, counter):
 
 
 def cls(name):
-    for c in ("gemm_nt", "gemm_tn", "chain_ffn_fwd", "attn_fwd", "attn_bwd", "attn_last", "ln_bwd", "sparse_adam", "reduce_batch", "scorer_loss", "plan_small"):
+    if "_split_kernel" in name:
+        return "row_chain_last"
+    for c in ("chain_ffn_fwd_kernel", "chain_ffn_bwd_kernel", "chain_proj_bwd_kernel", "chain_embed_proj_kernel"):
+        if c in name:
+            return "row_chain"      # bench.py's class of the same name (PC_CHAIN): the four full-sequence row-chain launches of a step
+    for c in ("gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "attn_last", "ln_bwd", "sparse_adam", "rows_reduce", "reduce_batch", "scorer_loss", "gru_seq4"):
         if c in name:
             return c
     return None

@@ -1062,6 +1062,7 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
   return UR_OK;
 }
 
+constexpr int UR_CATCHUP_BLOCKS = 1024;
 static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* grad, int d,
                               const float* scale, hipStream_t st) {
@@ -1072,6 +1073,9 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(n_max, groups);
   if (blocks > 8192) blocks = 8192;
+  // the catch-up walks a (usually short, often empty) filtered list with a grid-stride loop: a grid sized for the plan's capacity was
+  // 3 520 workgroups that start, read the count and leave -- 20 us of dispatch at the tail of every step beside the dW launch
+  if (mode == 1 && blocks > UR_CATCHUP_BLOCKS) blocks = UR_CATCHUP_BLOCKS;
   if (blocks < 1) blocks = 1;
 #define GO(T, MD) hipLaunchKernelGGL((sparse_adam_kernel<T, MD>), dim3(blocks), dim3(256), 0, st, a, (float4*)table, (float4*)m, \
                                      (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale)
