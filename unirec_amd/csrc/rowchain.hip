@@ -17,12 +17,14 @@
 //
 // Geometry (D = d in {32, 64, 128}): BM = 4096 / D rows per workgroup, 4 waves, one 32 x 32 accumulator tile per wave and
 // GEMM (v_mfma_f32_32x32x2_f32: exact fp32), weight slices streamed two ahead across GEMM boundaries (the stream never drains inside a
-// workgroup) -- since round 2b straight from global memory into the owning wave's registers (UR_RC_DIRECT, below); before that through
-// a double-buffered [D][16] LDS stage (the numbers that follow are that version's).  inner is walked in
-// D-wide chunks: h1 chunk -> LDS -> act -> second GEMM accumulates y over the chunks.  LDS: 52 KB at D = 128 (unpadded, XOR-swizzled
-// activation tiles + a 16-deep weight stage: THREE workgroups per CU; the first version, 70.7 KB = two per CU, paid 2.6 us per K = 32
-// step where the stand-alone 32-row GEMM kernels, three per CU, pay 1.7), 42 KB at D = 64.  The K order of every contraction equals gemm_nt's, so forward results are bit-identical to the
-// unfused path.
+// workgroup) straight from global memory into the owning wave's registers (below).  inner is walked in D-wide chunks: h1 chunk -> LDS ->
+// act -> second GEMM accumulates y over the chunks.  LDS: the two activation tiles, 32 KB at D = 128 (unpadded, XOR-swizzled).
+// REGISTERS decide the residency: <= 168 per lane = three workgroups per CU = 768 slots for the 668 row blocks of the headline batch
+// (tools/occupancy.sh).  The backward kernel at 196 registers ran them in two rounds, the second 30 % full: 103 us; bounded to 168
+// (__launch_bounds__(256, 3)): 88 us, the whole step - 12 us.  (Element-wise epilogues done on the accumulator registers where they are
+// -- no LDS round trip, one barrier less per chunk -- were measured and dropped: the 16 dword stores per lane they need are slower than
+// the transposed float4 stores, + 4 us per kernel.)  The K order of every contraction equals gemm_nt's, so forward results are
+// bit-identical to the unfused path.
 #include <stdlib.h>
 
 #include "common.h"
@@ -33,13 +35,10 @@ namespace ur {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float fx4 __attribute__((ext_vector_type(4)));   // plain LLVM vector: register arrays of it are always promoted (HIP's float4 class is not, in every context)
 
-// UR_RC_DIRECT = 1: the weight slices are NOT staged through LDS.  A wave owns 32 output columns of every GEMM of the chain (WC = D / 32
+// The weight slices are NOT staged through LDS.  A wave owns 32 output columns of every GEMM of the chain (WC = D / 32
 // waves side by side), so at D = 128 no two waves of a workgroup want the same weight rows: each wave loads ITS fragment of a slice
 // straight from global memory (the weights are L2-resident) into registers, two slices ahead -- no staging stores, and ONE barrier per
 // GEMM segment (when the activation tile changes hands) instead of one per K slice.  LDS = the two activation tiles (32 KB at D = 128).
-#ifndef UR_RC_DIRECT
-#define UR_RC_DIRECT 1
-#endif
 constexpr int RC_BK = 16;          // K-slice of the streamed weight tile
 constexpr int RC_LS = RC_BK + 4;   // padded LDS row stride of the weight stage (conflict-free ds_read_b128)
 
@@ -52,15 +51,9 @@ struct RcGeom {
   static constexpr int RS = D + 4;                  // row stride of the reduction scratch laid over a dead tile
   static constexpr int TPR = D / 4;                 // lanes per row in the row-wise epilogues (one float4 each)
   static constexpr int RPP = 256 / TPR;             // rows per epilogue pass; 4 passes cover the BM rows
-#if UR_RC_DIRECT
   static constexpr int WV = 2;                      // float4 loads per lane per weight slice: k offsets fk .. fk+3 and 8 + fk .. of ITS row
   static constexpr int TILE = BM * TS;              // floats per activation tile
   static constexpr int WST = 0;                     // (no weight stage)
-#else
-  static constexpr int WV = D >= 64 ? D / 64 : 1;   // float4 loads per thread per weight slice (D rows x 4 float4; D = 32: half the threads)
-  static constexpr int TILE = BM * TS;              // floats per activation tile
-  static constexpr int WST = D * RC_LS;             // floats per weight-stage buffer
-#endif
   static constexpr size_t LDS_BYTES = (size_t)(2 * TILE + 2 * WST) * sizeof(float);
 };
 
@@ -74,7 +67,6 @@ __device__ __forceinline__ int rc_toff(int r, int c4) {
 // One thread's view of a weight segment (rows row0 .. row0+D-1, columns k0 .. of a row-major matrix with leading dimension
 // ldw): the address of ITS first float4 of the segment's first K-slice.  Thread tid stages row (tid >> 2) + 64 i, float4
 // column tid & 3 of every slice.  Everything is passed by value (a struct whose address is taken ends up in scratch memory).
-#if UR_RC_DIRECT
 // One LANE's view of a weight segment (rows row0 .. row0+D-1 = output features, columns k0 .. of a row-major matrix with leading
 // dimension ldw): the address of the first float4 of ITS B-operand fragment of the first K-slice -- row = the wave's 32-column block +
 // lane & 31, k offset 4 (lane >> 5) (the fragment layout of rc_gemm).
@@ -91,24 +83,6 @@ __device__ __forceinline__ void rc_wload(fx4 (&r)[RcGeom<D>::WV], const float* p
 }
 template <int D>
 __device__ __forceinline__ void rc_wstore(const fx4 (&r)[RcGeom<D>::WV], float* buf, int tid) { (void)r; (void)buf; (void)tid; }
-#else
-template <int D>
-__device__ __forceinline__ const float* rc_wptr(const float* W, int ldw, int row0, int k0, int tid) {
-  return W + (long long)(row0 + min(tid >> 2, D - 1)) * ldw + k0 + (tid & 3) * 4;
-}
-template <int D>
-__device__ __forceinline__ void rc_wload(fx4 (&r)[RcGeom<D>::WV], const float* p, int ldw) {
-#pragma unroll
-  for (int i = 0; i < RcGeom<D>::WV; ++i) r[i] = *(const fx4*)(p + (long long)(64 * i) * ldw);
-}
-template <int D>
-__device__ __forceinline__ void rc_wstore(const fx4 (&r)[RcGeom<D>::WV], float* buf, int tid) {
-#pragma unroll
-  for (int i = 0; i < RcGeom<D>::WV; ++i)
-    if ((tid >> 2) + 64 * i < D) *(fx4*)(buf + ((tid >> 2) + 64 * i) * RC_LS + (tid & 3) * 4) = r[i];
-}
-
-#endif
 
 // acc += As[BM, D] @ W[seg]^T, K = D in NK = D / 32 slices.  As: an LDS activation tile (row stride TS).
 // The weight-slice stream runs TWO slices ahead of the MFMAs (an L2 round trip is longer than one K-step of 16 MFMAs): on entry
@@ -117,7 +91,6 @@ __device__ __forceinline__ void rc_wstore(const fx4 (&r)[RcGeom<D>::WV], float* 
 // earlier) into the other buffer.  wp / wnp: rc_wptr of this / the next segment (wnp nullable: the stream then re-reads this
 // segment -- staged, never used).  The invariant holds again on exit, for the next segment.  Ends with a barrier: every wave is
 // done reading As and the stage.
-#if UR_RC_DIRECT
 template <int D>
 __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const float* wp, int ldw, const float* wnp, int ldwn,
                                         float* Wst, int& buf, fx4 (&wreg)[2][RcGeom<D>::WV], int tid, int wr, int wc, int lane) {
@@ -148,43 +121,8 @@ __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const fl
   }
   __syncthreads();   // every wave is done reading As: the caller may overwrite it
 }
-#else
-template <int D>
-__device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const float* wp, int ldw, const float* wnp, int ldwn,
-                                        float* Wst, int& buf, fx4 (&wreg)[2][RcGeom<D>::WV], int tid, int wr, int wc, int lane) {
-  using G = RcGeom<D>;
-  constexpr int NK = D / RC_BK;
-  const int frow = lane & 31, fk = 4 * (lane >> 5);
-  const int arow = wr * 32 + frow, ac0 = fk >> 2;   // this lane's tile row and the chunk offset of its K half
-  if (!wnp) { wnp = wp; ldwn = ldw; }
-#pragma unroll
-  for (int kt = 0; kt < NK; ++kt) {
-    if constexpr (NK == 1) {
-      rc_wload<D>(wreg[0], wnp, ldwn);                            // one slice per segment: distance 1 (next segment's only slice)
-    } else {
-      if (kt + 2 < NK) rc_wload<D>(wreg[kt & 1], wp + (kt + 2) * RC_BK, ldw);
-      else rc_wload<D>(wreg[kt & 1], wnp + (kt + 2 - NK) * RC_BK, ldwn);
-    }
-    const float* Wb = Wst + buf * G::WST + (wc * 32 + frow) * RC_LS + fk;
-#pragma unroll
-    for (int kk = 0; kk < RC_BK; kk += 8) {
-      const float4 af = *(const float4*)(As + rc_toff<D>(arow, kt * (RC_BK / 4) + (kk >> 2) + ac0));
-      const float4 bf = *(const float4*)(Wb + kk);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
-    }
-    rc_wstore<D>(wreg[NK == 1 ? 0 : ((kt + 1) & 1)], Wst + (buf ^ 1) * G::WST, tid);
-    __syncthreads();
-    buf ^= 1;
-  }
-}
-
-#endif
 
 // start of the stream: slice 0 of the first segment -> Wst[0] (after the caller's barrier), slice 1 in flight
-#if UR_RC_DIRECT
 template <int D>
 __device__ __forceinline__ void rc_prime_load(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw) {
   rc_wload<D>(wreg[0], wp, ldw);
@@ -195,20 +133,6 @@ __device__ __forceinline__ void rc_prime_store(fx4 (&wreg)[2][RcGeom<D>::WV], co
   (void)wnp; (void)ldwn; (void)Wst; (void)tid;
   rc_wload<D>(wreg[1], wp + RC_BK, ldw);
 }
-#else
-template <int D>
-__device__ __forceinline__ void rc_prime_load(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw) {
-  rc_wload<D>(wreg[0], wp, ldw);
-}
-template <int D>
-__device__ __forceinline__ void rc_prime_store(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw, const float* wnp, int ldwn,
-                                               float* Wst, int tid) {
-  rc_wstore<D>(wreg[0], Wst, tid);
-  if constexpr (D / RC_BK > 1) rc_wload<D>(wreg[1], wp + RC_BK, ldw);
-  (void)wnp; (void)ldwn;
-}
-
-#endif
 
 // accumulator tile -> LDS tile.  acc[r]: row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of the wave's 32 x 32 tile.
 template <int D>
@@ -600,7 +524,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
 // =============================================================================================== backward of the same block
 
 template <int D>
-__global__ __launch_bounds__(256) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
+__global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   using G = RcGeom<D>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* At = smem;                  // [BM][TS]: g_tf, then g_ta
