@@ -288,9 +288,10 @@ def e2e_leg(a, model, opt, device, steps):
     bld = DeviceRowBuilder(n_users, a.n_items, a.negatives, a.seq_len, csr, reject_history=True, mask_mode="autoregressive", seq_last=0, seed=1,
                            device=str(device))
 
-    def build(k):
-        sel = pairs[k * a.batch:(k + 1) * a.batch]
-        return bld.build(sel[:, 0].contiguous(), sel[:, 1].contiguous(), with_seq=True, step=k)
+    # the product loader (facility/trainer.py): builds run on its own stream, two batches ahead of the step that consumes them
+    from unirec_amd.facility.trainer import DeviceBatchLoader
+    loader = DeviceBatchLoader(pairs, bld, a.batch, shuffle=False)
+    it = iter(loader)
 
     def step(b, nxt):
         opt.zero_grad()
@@ -299,26 +300,28 @@ def e2e_leg(a, model, opt, device, steps):
         model.forward_backward(item_id=b["item_id"], label=b["label"], item_seq=b["item_seq"])
         opt.step(late_join=True)
 
-    cur = build(0)
+    cur = next(it)
     for k in range(5):
-        nxt = build(k + 1)
+        nxt = next(it)
         step(cur, nxt)
         cur = nxt
     torch.cuda.synchronize()
     real = torch.zeros(1, device=device)
     t0 = time.perf_counter()
     for k in range(5, 5 + steps):
-        nxt = build(k + 1)          # the NEXT batch is built (sampler + history cut) while this step's launches are queued
+        nxt = next(it)              # handed out behind an event recorded a step ago; the loader queues the build of batch k + 3
         step(cur, nxt)
         cur = nxt
+    t_host = time.perf_counter() - t0   # the host has queued everything: if this is close to dt, the leg is bound by the host's launch rate
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    del it
     for k in range(5, 8):           # (outside the clock) what fraction of the B * L token slots these batches fill
-        real += (build(k)["item_seq"] > 0).float().mean() / 3
+        real += (loader._build(torch.arange(len(pairs), device=device), k, 0)["item_seq"] > 0).float().mean() / 3
     return {"ms_per_step": round(dt / steps * 1e3, 4), "examples_per_s": round(a.batch * steps / dt, 1), "steps": steps,
-            "real_token_fraction": round(float(real), 4), "negatives": a.negatives,
-            "pipeline": "device-resident: ur_sample_negatives (uniform, history-rejecting) + ur_device_build_seq per step, inside the clock; "
-                        "history lengths as the headline's"}
+            "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 4), "real_token_fraction": round(float(real), 4), "negatives": a.negatives,
+            "pipeline": "device-resident: ur_sample_negatives (uniform, history-rejecting) + ur_device_build_seq per step, inside the clock "
+                        "(DeviceBatchLoader: built on the loader's stream two batches ahead); history lengths as the headline's"}
 
 
 def variant_leg(a, model, opt, step_fn, device, steps, dropout=None, ids=None):

@@ -6,6 +6,7 @@ Same constructor / method names (``Trainer(config, model, accelerator)``, ``fit`
 The loop body (trainer.py:327-357) becomes: plan ids -> forward -> backward -> clip -> step, with the loss kept on
 the device and read back once per epoch instead of two host syncs per step."""
 import logging
+import collections
 import math
 import os
 import time
@@ -45,17 +46,29 @@ class BatchLoader:
 class DeviceBatchLoader:
     """Device-resident input pipeline: the (user, item) interaction pairs live in HBM and every batch
     is built there by ``DeviceRowBuilder`` (negatives, history cut, left padding: two launches, no host work, no H2D
-    copy).  Sharding and last-partial-batch behaviour as ``BatchLoader``."""
+    copy).  Sharding and last-partial-batch behaviour as ``BatchLoader``.
 
-    def __init__(self, pairs, builder, batch_size, shuffle=False, seed=2022, rank=0, world=1, with_seq=True):
+    The builds run on the loader's OWN stream, ``lookahead`` batches ahead of the consumer: a batch is handed out behind a wait for an
+    event that completed a step ago, so the half-dozen small launches of a build (index, two column copies, sampler, history cut) sit
+    beside the training step's kernels instead of in front of them (bench.py `e2e`; at the headline shape the builds are ~1 % of the step
+    either way -- what separates `e2e` from the headline line is the lazy-Adam replay of rows seen before and 1 % more real tokens)."""
+
+    def __init__(self, pairs, builder, batch_size, shuffle=False, seed=2022, rank=0, world=1, with_seq=True, lookahead=2):
         dev = builder.device
         self.pairs = (pairs if torch.is_tensor(pairs) else torch.from_numpy(np.asarray(pairs).astype(np.int64))).to(dev).contiguous()
         self.builder, self.batch_size, self.shuffle, self.seed = builder, batch_size, shuffle, seed
         self.rank, self.world, self.with_seq, self.epoch = rank, world, with_seq, 0
+        self.lookahead = max(1, int(lookahead))
+        self.stream = torch.cuda.Stream(device=self.pairs.device) if self.pairs.is_cuda else None
 
     def __len__(self):
         nb = (len(self.pairs) + self.batch_size - 1) // self.batch_size
         return (nb + self.world - 1) // self.world
+
+    def _build(self, order, b, base):
+        B = self.batch_size
+        sel = self.pairs[order[b * B:(b + 1) * B]]
+        return self.builder.build(sel[:, 0].contiguous(), sel[:, 1].contiguous(), with_seq=self.with_seq, step=base + b)
 
     def __iter__(self):
         n, B = len(self.pairs), self.batch_size
@@ -68,10 +81,35 @@ class DeviceBatchLoader:
         nb = (n + B - 1) // B
         base = self.epoch * nb
         self.epoch += 1
-        for k in range((nb + self.world - 1) // self.world):   # equal step counts on every rank (see BatchLoader)
-            b = (k * self.world + self.rank) % nb
-            sel = self.pairs[order[b * B:(b + 1) * B]]
-            yield self.builder.build(sel[:, 0].contiguous(), sel[:, 1].contiguous(), with_seq=self.with_seq, step=base + b)
+        ks = iter(range((nb + self.world - 1) // self.world))   # equal step counts on every rank (see BatchLoader)
+        if self.stream is None:
+            for k in ks:
+                yield self._build(order, (k * self.world + self.rank) % nb, base)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream(dev))   # (`order` was made on the caller's stream)
+        pending = collections.deque()
+
+        def issue():
+            k = next(ks, None)
+            if k is None:
+                return
+            with torch.cuda.stream(self.stream):
+                batch = self._build(order, (k * self.world + self.rank) % nb, base)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            pending.append((batch, ev))
+
+        for _ in range(self.lookahead):
+            issue()
+        while pending:
+            batch, ev = pending.popleft()
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ev)
+            for t in batch.values():      # made on the loader's stream, used on the caller's: the allocator must not recycle them early
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+            issue()
+            yield batch
 
 
 class StepLRByScore:
