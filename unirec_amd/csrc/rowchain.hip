@@ -150,10 +150,37 @@ __device__ __forceinline__ floatx16 zero16() {
   return z;
 }
 
-__device__ __forceinline__ float4 rc_act4(float4 v, int act) {
-  v.x = act_fwd(v.x, act); v.y = act_fwd(v.y, act); v.z = act_fwd(v.z, act); v.w = act_fwd(v.w, act);
-  return v;
-}
+// The activation of a thread's 4 x float4 of an epilogue with ONE switch around the sixteen evaluations (each case a straight run of
+// code).  With the switch inside the per-element call the unrolled epilogue was 3 000 instructions of which a launch executes a few
+// hundred, jumping over the erff / tanhf expansions of the other cases sixteen times: 12 000 cycles per epilogue on a cold instruction
+// cache (measured with s_memtime stamps; the few-row kernels run one workgroup per CU, every launch cold), ~2 000 of them arithmetic.
+#define RC_ACT_CASES(FN)                                                                       \
+  switch (act) {                                                                               \
+    case UR_ACT_GELU: RC_ACT_LOOP_SERIAL(FN, UR_ACT_GELU); break;                              \
+    case UR_ACT_RELU: RC_ACT_LOOP(FN, UR_ACT_RELU); break;                                     \
+    case UR_ACT_SWISH: RC_ACT_LOOP(FN, UR_ACT_SWISH); break;                                   \
+    case UR_ACT_TANH: RC_ACT_LOOP_SERIAL(FN, UR_ACT_TANH); break;                              \
+    case UR_ACT_SIGMOID: RC_ACT_LOOP(FN, UR_ACT_SIGMOID); break;                               \
+    default: RC_ACT_LOOP(FN, -1); break;                                                       \
+  }
+#define RC_ACT_LOOP(FN, A)                                                                                              \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                       \
+    v[p].x = FN(v[p].x, A); v[p].y = FN(v[p].y, A); v[p].z = FN(v[p].z, A); v[p].w = FN(v[p].w, A);                     \
+  }
+// (erff / tanhf are ~60 instructions each: evaluated one after the other -- a scheduling barrier between them -- or the scheduler
+// interleaves all sixteen and the kernel's register allocation, which is static over every case, loses a workgroup per CU)
+#define RC_ACT_LOOP_SERIAL(FN, A)                                                                                       \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                       \
+    v[p].x = FN(v[p].x, A); __builtin_amdgcn_sched_barrier(0);                                                          \
+    v[p].y = FN(v[p].y, A); __builtin_amdgcn_sched_barrier(0);                                                          \
+    v[p].z = FN(v[p].z, A); __builtin_amdgcn_sched_barrier(0);                                                          \
+    v[p].w = FN(v[p].w, A); __builtin_amdgcn_sched_barrier(0);                                                          \
+  }
+__device__ __forceinline__ void rc_act_fwd16(float4 (&v)[4], int act) { RC_ACT_CASES(act_fwd) }   // v := act(v)
+__device__ __forceinline__ void rc_act_bwd16(float4 (&v)[4], int act) { RC_ACT_CASES(act_bwd) }   // v := act'(v)
+#undef RC_ACT_LOOP
+#undef RC_ACT_LOOP_SERIAL
+#undef RC_ACT_CASES
 
 // LayerNorm forward of one row held by TPR lanes (one float4 each): x -> (xhat, y); returns rstd.  Same arithmetic as the
 // EPI_BIAS_RES_LN epilogue of gemm_nt.
@@ -209,7 +236,7 @@ __device__ __forceinline__ void rc_block_colsum(float4 dg, float4 db, float* red
 // =============================================================================================== forward
 
 template <int D>
-__global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
+__global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   using G = RcGeom<D>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* At = smem;                  // [BM][TS]: ctx, then a, then y
@@ -284,15 +311,20 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
     __syncthreads();
     {
       const float4 bs = *(const float4*)(a.b1 + c * D + et * 4);
+      float4 v[4];
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int ml = eg + p * G::RPP, m = m0 + ml;
-        float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
-        v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
-        if (m < M) *(float4*)(a.h1 + (long long)m * a.I + c * D + et * 4) = v;
-        v = rc_act4(v, a.act);
-        if (a.u && m < M) *(float4*)(a.u + (long long)m * a.I + c * D + et * 4) = v;
-        *(float4*)(Ht + rc_toff<D>(ml, et)) = v;
+        v[p] = *(const float4*)(Ht + rc_toff<D>(ml, et));
+        v[p].x += bs.x; v[p].y += bs.y; v[p].z += bs.z; v[p].w += bs.w;
+        if (m < M) *(float4*)(a.h1 + (long long)m * a.I + c * D + et * 4) = v[p];
+      }
+      rc_act_fwd16(v, a.act);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int ml = eg + p * G::RPP, m = m0 + ml;
+        if (a.u && m < M) *(float4*)(a.u + (long long)m * a.I + c * D + et * 4) = v[p];
+        *(float4*)(Ht + rc_toff<D>(ml, et)) = v[p];
       }
     }
     __syncthreads();
@@ -458,15 +490,20 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   __syncthreads();
   {
     const float4 bs = *(const float4*)(a.b1 + c * D + et * 4);
+    float4 v[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int ml = eg + p * G::RPP, m = m0 + ml;
-      float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
-      v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
-      if (m < M) *(float4*)(a.h1 + (long long)m * a.I + c * D + et * 4) = v;
-      v = rc_act4(v, a.act);
-      if (a.u && m < M) *(float4*)(a.u + (long long)m * a.I + c * D + et * 4) = v;
-      *(float4*)(Ht + rc_toff<D>(ml, et)) = v;
+      v[p] = *(const float4*)(Ht + rc_toff<D>(ml, et));
+      v[p].x += bs.x; v[p].y += bs.y; v[p].z += bs.z; v[p].w += bs.w;
+      if (m < M) *(float4*)(a.h1 + (long long)m * a.I + c * D + et * 4) = v[p];
+    }
+    rc_act_fwd16(v, a.act);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      if (a.u && m < M) *(float4*)(a.u + (long long)m * a.I + c * D + et * 4) = v[p];
+      *(float4*)(Ht + rc_toff<D>(ml, et)) = v[p];
     }
   }
   __syncthreads();
@@ -578,17 +615,25 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
       rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
     }
     __syncthreads();
+    {
+      float4 v[4];   // h1 -> act'(h1)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int ml = eg + p * G::RPP, m = m0 + ml;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M) {
-        v = *(const float4*)(Ht + rc_toff<D>(ml, et));
-        const float4 h = *(const float4*)(a.h1 + (long long)m * a.I + c * D + et * 4);
-        v.x *= act_bwd(h.x, a.act); v.y *= act_bwd(h.y, a.act); v.z *= act_bwd(h.z, a.act); v.w *= act_bwd(h.w, a.act);
-        *(float4*)(a.g_h1 + (long long)m * a.I + c * D + et * 4) = v;
+      for (int p = 0; p < 4; ++p) {
+        const int m = min(m0 + eg + p * G::RPP, M - 1);
+        v[p] = *(const float4*)(a.h1 + (long long)m * a.I + c * D + et * 4);
       }
-      *(float4*)(Ht + rc_toff<D>(ml, et)) = v;
+      rc_act_bwd16(v, a.act);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int ml = eg + p * G::RPP, m = m0 + ml;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M) {
+          g = *(const float4*)(Ht + rc_toff<D>(ml, et));
+          g.x *= v[p].x; g.y *= v[p].y; g.z *= v[p].z; g.w *= v[p].w;
+          *(float4*)(a.g_h1 + (long long)m * a.I + c * D + et * 4) = g;
+        }
+        *(float4*)(Ht + rc_toff<D>(ml, et)) = g;
+      }
     }
     __syncthreads();
     const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w2T, D, (c + 1) * D, 0, tid) : rc_wptr<D>(a.woT, D, 0, 0, tid);
@@ -766,17 +811,25 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
     rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
   }
   __syncthreads();
+  {
+    float4 v[4];   // h1 -> act'(h1)
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int ml = eg + p * G::RPP, m = m0 + ml;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m < M) {
-      v = *(const float4*)(Ht + rc_toff<D>(ml, et));
-      const float4 h = *(const float4*)(a.h1 + (long long)m * a.I + c * D + et * 4);
-      v.x *= act_bwd(h.x, a.act); v.y *= act_bwd(h.y, a.act); v.z *= act_bwd(h.z, a.act); v.w *= act_bwd(h.w, a.act);
-      *(float4*)(a.g_h1 + (long long)m * a.I + c * D + et * 4) = v;
+    for (int p = 0; p < 4; ++p) {
+      const int m = min(m0 + eg + p * G::RPP, M - 1);
+      v[p] = *(const float4*)(a.h1 + (long long)m * a.I + c * D + et * 4);
     }
-    *(float4*)(Ht + rc_toff<D>(ml, et)) = v;
+    rc_act_bwd16(v, a.act);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP, m = m0 + ml;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        g = *(const float4*)(Ht + rc_toff<D>(ml, et));
+        g.x *= v[p].x; g.y *= v[p].y; g.z *= v[p].z; g.w *= v[p].w;
+        *(float4*)(a.g_h1 + (long long)m * a.I + c * D + et * 4) = g;
+      }
+      *(float4*)(Ht + rc_toff<D>(ml, et)) = g;
+    }
   }
   __syncthreads();
   floatx16 acca = zero16();
