@@ -392,13 +392,20 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
 // acknowledgement does not say that the write-through has landed, and the completion counter can overtake them: measured, 6 of 40
 // backward passes summed a stale partial.)  8 bytes per instruction: 8 exchanges per thread and tile, 8 fetch-ors per thread and tile
 // on the reading side.
-__device__ __forceinline__ void rc_dev_put4(float* p, float4 v) {
+// rc_dev_put4 ISSUES the two exchanges of a float4 and returns their old values; the caller hands all of them to rc_dev_wait once every
+// exchange of the thread is in flight (one round trip to the coherence point -- ~1 us -- per thread and tile instead of four).
+struct RcPut { unsigned long long o0, o1; };
+__device__ __forceinline__ RcPut rc_dev_put4(float* p, float4 v) {
   unsigned long long* q = (unsigned long long*)p;
   const unsigned long long lo = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
   const unsigned long long hi = (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32);
-  const unsigned long long o0 = __hip_atomic_exchange(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long o1 = __hip_atomic_exchange(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("" ::"v"(o0), "v"(o1));   // the old values are waited for: both exchanges have been performed
+  RcPut r;
+  r.o0 = __hip_atomic_exchange(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  r.o1 = __hip_atomic_exchange(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return r;
+}
+__device__ __forceinline__ void rc_dev_wait(const RcPut (&r)[4]) {   // the old values are waited for: the exchanges have been performed
+  asm volatile("" ::"v"(r[0].o0), "v"(r[0].o1), "v"(r[1].o0), "v"(r[1].o1), "v"(r[2].o0), "v"(r[2].o1), "v"(r[3].o0), "v"(r[3].o1));
 }
 __device__ __forceinline__ float4 rc_dev_get4(const float* p) {
   unsigned long long* q = (unsigned long long*)p;
@@ -406,6 +413,25 @@ __device__ __forceinline__ float4 rc_dev_get4(const float* p) {
   const unsigned long long hi = __hip_atomic_fetch_or(q + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
                      __uint_as_float((unsigned)(hi >> 32)));
+}
+
+// x[p] = sum over the nc chunk partials (chunk order: the order the one-workgroup chain accumulates in) of this thread's float4 of its
+// four rows; per chunk the eight fetch-ors of the thread are issued together (one round trip per chunk instead of four)
+template <int D>
+__device__ __forceinline__ void rc_dev_sum4(float4 (&x)[4], const float* blk, int nc, int m0, int M, int eg, int et) {
+  using G = RcGeom<D>;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) x[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int cc = 0; cc < nc; ++cc) {
+    float4 t[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP;
+      t[p] = m0 + ml < M ? rc_dev_get4(blk + ((long long)cc * G::BM + ml) * D + et * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { x[p].x += t[p].x; x[p].y += t[p].y; x[p].z += t[p].z; x[p].w += t[p].w; }
+  }
 }
 
 // =============================================================================================== forward, few rows
@@ -435,6 +461,14 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   fx4 wreg[2][G::WV];
   int buf = 0;
   rc_prime_load<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);
+  // every small operand of the epilogues is requested HERE (one workgroup per CU, parameters rewritten by the optimizer a moment ago:
+  // each of these is a miss all the way to HBM, ~2 us when it is asked for where it is used, behind a barrier)
+  const float4 q_bo = *(const float4*)(a.bo + et * 4), q_g1 = *(const float4*)(a.g1 + et * 4), q_b1ln = *(const float4*)(a.b1ln + et * 4);
+  const float4 q_b1 = *(const float4*)(a.b1 + c * D + et * 4);
+  const float4 q_b2 = *(const float4*)(a.b2 + et * 4), q_g2 = *(const float4*)(a.g2 + et * 4), q_b2ln = *(const float4*)(a.b2ln + et * 4);
+  float4 q_res[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) q_res[p] = *(const float4*)(a.res + (long long)min(m0 + eg + p * G::RPP, M - 1) * a.ldres + et * 4);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int ml = eg + p * G::RPP, m = m0 + ml;
@@ -452,15 +486,14 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   }
   __syncthreads();
   {
-    const float4 bs = *(const float4*)(a.bo + et * 4);
-    const float4 gm = *(const float4*)(a.g1 + et * 4), bt = *(const float4*)(a.b1ln + et * 4);
+    const float4 bs = q_bo, gm = q_g1, bt = q_b1ln;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int ml = eg + p * G::RPP, m = m0 + ml;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M) {
         float4 x = *(const float4*)(Ht + rc_toff<D>(ml, et));
-        const float4 rs = *(const float4*)(a.res + (long long)m * a.ldres + et * 4);
+        const float4 rs = q_res[p];
         if (a.drop_out.thresh) {   // t = dropout(acc + bias) + res
           x.x += bs.x; x.y += bs.y; x.z += bs.z; x.w += bs.w;
           x = drop4(x, drop_rowkey(a.drop_out, m), (unsigned)(et * 4), a.drop_out);
@@ -489,7 +522,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   }
   __syncthreads();
   {
-    const float4 bs = *(const float4*)(a.b1 + c * D + et * 4);
+    const float4 bs = q_b1;
     float4 v[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -513,11 +546,15 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   __syncthreads();
   // ---- 3. the partial -> memory (device scope), count, and the last workgroup of the row block finishes
   float* mine = a.split_part + ((long long)(rb * nc + c) * G::BM) * D;
+  {
+    RcPut puts[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int ml = eg + p * G::RPP;
-    const float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
-    rc_dev_put4(mine + (long long)ml * D + et * 4, v);     // (returns once performed)
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP;
+      const float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
+      puts[p] = rc_dev_put4(mine + (long long)ml * D + et * 4, v);
+    }
+    rc_dev_wait(puts);                                     // (returns once all eight have been performed)
   }
   __syncthreads();                                         // every thread's part of the tile is out
   if (tid == 0) {
@@ -528,18 +565,15 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   __syncthreads();
   if (!is_last) return;
   {
-    const float4 bs = *(const float4*)(a.b2 + et * 4);
-    const float4 gm = *(const float4*)(a.g2 + et * 4), bt = *(const float4*)(a.b2ln + et * 4);
+    const float4 bs = q_b2, gm = q_g2, bt = q_b2ln;
     const float* blk = a.split_part + ((long long)rb * nc * G::BM) * D;
+    float4 xs[4];
+    rc_dev_sum4<D>(xs, blk, nc, m0, M, eg, et);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int ml = eg + p * G::RPP, m = m0 + ml;
       if (m < M) {
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int cc = 0; cc < nc; ++cc) {   // chunk order: the order the one-workgroup chain accumulates in
-          const float4 t = rc_dev_get4(blk + ((long long)cc * G::BM + ml) * D + et * 4);
-          x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
-        }
+        float4 x = xs[p];
         const float4 rs = *(const float4*)(At + rc_toff<D>(ml, et));
         if (a.drop_ffn.thresh) {
           x.x += bs.x; x.y += bs.y; x.z += bs.z; x.w += bs.w;
@@ -783,6 +817,17 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   fx4 wreg[2][G::WV];
   int buf = 0;
   rc_prime_load<D>(wreg, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D);
+  // (what the later epilogues read from memory is requested here: see chain_ffn_fwd_split_kernel)
+  const float4 q_g1 = *(const float4*)(a.g1 + et * 4);
+  float4 q_h1[4], q_ahat[4];
+  float q_rstd1[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int m = min(m0 + eg + p * G::RPP, M - 1);
+    q_h1[p] = *(const float4*)(a.h1 + (long long)m * a.I + c * D + et * 4);
+    q_ahat[p] = *(const float4*)(a.ahat + (long long)m * D + et * 4);
+    q_rstd1[p] = a.rstd1[m];
+  }
   // ---- 0. feed-forward LayerNorm backward (every chunk's workgroup; chunk 0 writes)
   {
     const float4 gm = *(const float4*)(a.g2 + et * 4);
@@ -815,8 +860,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
     float4 v[4];   // h1 -> act'(h1)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int m = min(m0 + eg + p * G::RPP, M - 1);
-      v[p] = *(const float4*)(a.h1 + (long long)m * a.I + c * D + et * 4);
+      v[p] = q_h1[p];
     }
     rc_act_bwd16(v, a.act);
 #pragma unroll
@@ -838,11 +882,15 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   __syncthreads();
   // ---- 2. the partial -> memory (device scope), count; the last workgroup of the row block goes on
   float* mine = a.split_part + ((long long)(rb * nc + c) * G::BM) * D;
+  {
+    RcPut puts[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int ml = eg + p * G::RPP;
-    const float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
-    rc_dev_put4(mine + (long long)ml * D + et * 4, v);
+    for (int p = 0; p < 4; ++p) {
+      const int ml = eg + p * G::RPP;
+      const float4 v = *(const float4*)(Ht + rc_toff<D>(ml, et));
+      puts[p] = rc_dev_put4(mine + (long long)ml * D + et * 4, v);
+    }
+    rc_dev_wait(puts);                                     // (returns once all eight have been performed)
   }
   __syncthreads();
   if (tid == 0) {
@@ -854,23 +902,21 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   if (!is_last) return;
   // ---- 3. g_a = sum of the partials (chunk order) + g_tf;  attention LayerNorm backward -> g_ta
   {
-    const float4 gm = *(const float4*)(a.g1 + et * 4);
+    const float4 gm = q_g1;
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
     const float* blk = a.split_part + ((long long)rb * nc * G::BM) * D;
+    float4 ys[4];
+    rc_dev_sum4<D>(ys, blk, nc, m0, M, eg, et);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int ml = eg + p * G::RPP, m = m0 + ml;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M) {
-        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int cc = 0; cc < nc; ++cc) {
-          const float4 t = rc_dev_get4(blk + ((long long)cc * G::BM + ml) * D + et * 4);
-          y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
-        }
+        float4 y = ys[p];
         const float4 rs = *(const float4*)(At + rc_toff<D>(ml, et));
         y.x += rs.x; y.y += rs.y; y.z += rs.z; y.w += rs.w;
-        const float4 h = *(const float4*)(a.ahat + (long long)m * D + et * 4);
-        o = rc_ln_bwd_row<G::TPR>(y, h, gm, a.rstd1[m], inv_d, dg, db);
+        const float4 h = q_ahat[p];
+        o = rc_ln_bwd_row<G::TPR>(y, h, gm, q_rstd1[p], inv_d, dg, db);
         *(float4*)(a.g_ta + (long long)m * D + et * 4) = o;
       }
       *(float4*)(At + rc_toff<D>(ml, et)) = o;
