@@ -738,14 +738,16 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "launches": c["launches"],
                 "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2)}
     # HBM bytes per launch of the dominant class: PMC counters cannot be collected from inside this process, so the
-    # figure is the committed rocprofv3 --pmc summary of the SAME workload (profiles/r03_a_pmc_hbm_traffic.json:
+    # figure is the committed rocprofv3 --pmc summary of the SAME workload (profiles/r*_pmc_hbm_traffic.json, the latest:
     # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction); null when the summary is absent
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_a_pmc_hbm_traffic.json")
-    if roof is not None and os.path.exists(pmc) and a.n_items == 100_000_000 and a.batch == 512:
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic.json")))   # the latest one
+    pmc = pmcs[-1] if pmcs else ""
+    if roof is not None and pmc and a.n_items == 100_000_000 and a.batch == 512:
         per_class = json.load(open(pmc)).get("per_class", {})
         if dom in per_class and per_class[dom]:
             roof["traffic"] = per_class[dom]["hbm_bytes_per_launch"]
-            roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/r03_a_pmc_hbm_traffic.json)"
+            roof["traffic_unit"] = f"HBM bytes per launch (rocprofv3 PMC, profiles/{os.path.basename(pmc)})"
             roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * valid_frac * 1e6 / max(1, c["launches"] / max(1, (a.steps + PROF_EVERY - 1) // PROF_EVERY)))
     emb_bytes_per_example = 8 * (L + G) * d * 4   # fwd read + bwd/opt touched rows (w,m,v,grad)
     out = {
