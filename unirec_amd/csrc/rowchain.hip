@@ -102,14 +102,24 @@ __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const fl
   if (!wnp) { wnp = wp; ldwn = ldw; }
   // on entry wreg[0] / wreg[1] hold this lane's fragments of slices 0 / 1 of the segment (in flight or landed); step kt consumes
   // slice kt and refills its slot with slice kt + 2 (of this segment or the next): the invariant holds again on exit
+  // The swizzle XORs the chunk index with row & 15: chunk = 4 kt + q (q = ac0, 2 + ac0) has its bits above 15 untouched, so the lane's
+  // address of (kt, q) is the address of (kt & 3, q) plus the CONSTANT 64 floats x (kt >> 2) -- eight lane addresses for the sixteen
+  // fragments of a segment (spelled out: the compiler kept sixteen in registers for the whole kernel).
+  constexpr int NA = NK < 4 ? NK : 4;
+  int aoff[NA][2];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    aoff[j][0] = rc_toff<D>(arow, j * (RC_BK / 4) + 0 + ac0);
+    aoff[j][1] = rc_toff<D>(arow, j * (RC_BK / 4) + 2 + ac0);
+  }
 #pragma unroll
   for (int kt = 0; kt < NK; ++kt) {
     const fx4 b0 = wreg[kt & 1][0], b1 = wreg[kt & 1][1];
     if (kt + 2 < NK) rc_wload<D>(wreg[kt & 1], wp + (kt + 2) * RC_BK, ldw);
     else rc_wload<D>(wreg[kt & 1], wnp + (kt + 2 - NK) * RC_BK, ldwn);
     __builtin_amdgcn_sched_barrier(0);   // (the loads stay here: the scheduler would sink them to just ahead of their use)
-    const float4 a0 = *(const float4*)(As + rc_toff<D>(arow, kt * (RC_BK / 4) + 0 + ac0));
-    const float4 a1 = *(const float4*)(As + rc_toff<D>(arow, kt * (RC_BK / 4) + 2 + ac0));
+    const float4 a0 = *(const float4*)(As + aoff[kt % NA][0] + (kt / NA) * 64);
+    const float4 a1 = *(const float4*)(As + aoff[kt % NA][1] + (kt / NA) * 64);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
@@ -141,6 +151,14 @@ __device__ __forceinline__ void rc_acc_to_tile(const floatx16& acc, float* T, in
   const int nl = wc * 32 + (lane & 31), r4 = 4 * (lane >> 5);
 #pragma unroll
   for (int r = 0; r < 16; ++r) T[rc_toff<D>(wr * 32 + (r & 3) + 8 * (r >> 2) + r4, nl >> 2) + (nl & 3)] = acc[r];
+}
+
+// A lane-dependent index as a value the optimiser cannot see through: what an epilogue derives from it (row pointers, swizzled LDS
+// addresses) is then recomputed where it is used -- a few VALU operations -- instead of being hoisted out of the chunk loops and held
+// in registers (or spilled) across the whole kernel: the many-row kernels sit at the 168-register edge of three workgroups per CU.
+__device__ __forceinline__ int rc_fresh(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
 }
 
 __device__ __forceinline__ floatx16 zero16() {
@@ -248,17 +266,19 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   if (m0 >= M) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / G::WC, wc = wave % G::WC;
-  const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_n = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
   int buf = 0;
   rc_prime_load<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);   // the first weight slice is in flight while the ctx tile is staged
+  {
+  const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int ml = eg + p * G::RPP, m = m0 + ml;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (m < M) v = *(const float4*)(a.ctx + (long long)m * a.ldctx + et * 4);
     *(float4*)(At + rc_toff<D>(ml, et)) = v;
+  }
   }
   rc_prime_store<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
   __syncthreads();
@@ -271,6 +291,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   }
   __syncthreads();
   {
+    const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
     const float4 bs = *(const float4*)(a.bo + et * 4);
     const float4 gm = *(const float4*)(a.g1 + et * 4), bt = *(const float4*)(a.b1ln + et * 4);
 #pragma unroll
@@ -310,6 +331,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
     }
     __syncthreads();
     {
+      const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
       const float4 bs = *(const float4*)(a.b1 + c * D + et * 4);
       float4 v[4];
 #pragma unroll
@@ -336,6 +358,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   rc_acc_to_tile<D>(accy, Ht, wr, wc, lane);
   __syncthreads();
   {
+    const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
     const float4 bs = *(const float4*)(a.b2 + et * 4);
     const float4 gm = *(const float4*)(a.g2 + et * 4), bt = *(const float4*)(a.b2ln + et * 4);
 #pragma unroll
@@ -372,6 +395,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
                wreg, tid, wr, wc, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
     __syncthreads();
+    const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
     const float4 bs = *(const float4*)(a.bn + c * D + et * 4);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -611,7 +635,6 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
     return;
   }
   const int wr = wave / G::WC, wc = wave % G::WC;
-  const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_d = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
   int buf = 0;
@@ -619,6 +642,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
 
   // ---- 0. feed-forward LayerNorm backward: g_tf (also the residual branch of g_a)
   {
+    const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
     const float4 gm = *(const float4*)(a.g2 + et * 4);
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
 #pragma unroll
@@ -650,6 +674,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
     }
     __syncthreads();
     {
+      const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);   // (shadow the kernel-wide ones: nothing derived from them outlives the block)
       float4 v[4];   // h1 -> act'(h1)
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -678,6 +703,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   rc_acc_to_tile<D>(acca, Ht, wr, wc, lane);
   __syncthreads();
   {
+    const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
     const float4 gm = *(const float4*)(a.g1 + et * 4);
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
 #pragma unroll
@@ -705,6 +731,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
+  const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int ml = eg + p * G::RPP, m = m0 + ml;
