@@ -307,7 +307,10 @@ int ur_rows_plan_sharded(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b
  *                           sorted keys and written to counts_dev when non-NULL) -> send_ids[world*cap] (+ the maps
  *                           slot_of_uniq[u] / u_of_slot[q], -1 for padding) -> recv_ids[world*cap]; flags_dev[0] |= 1 if a count > cap
  *   ur_shard_exchange_rows: rows_ws[q,:] = table[req_ids[q],:] (this rank's shard) -> compact[world*cap, d] on the requesters
- *   ur_shard_exchange_grads: uniq_grad[n_uniq,d] -> slot layout (padding: zeros) in send_ws -> grads_in[world*cap, d] on the owners */
+ *   ur_shard_exchange_grads: uniq_grad[n_uniq,d] -> slot layout (padding: zeros) in send_ws -> grads_in[world*cap, d] on the owners;
+ *                           uniq_grad NULL: the rows are in their slots of send_ws already (ur_rows_reduce with out_rows = slot_of_uniq;
+ *                           the padding slots then hold stale bytes, which no owner reads: they ask for the padding row) and only the
+ *                           flag rows are written */
 int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_uniq_dev, int32_t* counts_dev, int64_t n_local,
                           int32_t world, int32_t cap, int32_t* send_ids, int32_t* slot_of_uniq, int32_t* u_of_slot,
                           int32_t* flags_dev, int32_t* recv_ids, int32_t transport, void* stream);
@@ -340,10 +343,13 @@ int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_pos, const 
 /* uniq_grad[u,:] = sum over the run of uniq_idx[u] (in sorted, i.e. position, order) of
  *   rows_a[p,:]                      for p <  n_a
  *   coef_b[p-n_a] * vec_b[(p-n_a)/G,:] for p >= n_a     (the scorer's implicit candidate-row gradient)
- * rows of id 0 are written as zeros. Also accumulates sum(uniq_grad^2) into sumsq_dev[0] when non-NULL. */
+ * rows of id 0 are written as zeros. sumsq_dev non-NULL: the rows n_uniq .. n-1 of uniq_grad are zeroed as well (a caller that
+ * sums squares over all n rows).  out_rows (nullable, not with sumsq_dev): row u is written to uniq_grad[out_rows[u],:] instead of
+ * uniq_grad[u,:] -- e.g. slot_of_uniq of ur_shard_exchange_ids: the sums land in their exchange slots, no scatter pass. */
 int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
                    const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
-                   const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, void* stream);
+                   const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
+                   void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam as built at unirec/facility/trainer.py:134-136 and stepped at :349;

@@ -90,6 +90,16 @@ __global__ __launch_bounds__(256) void shard_scatter_rows_kernel(const float4* _
   out[i] = u >= 0 ? rows[(long long)u * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// the flag rows alone (the gradient rows were written into their slots by the reduction itself)
+__global__ void shard_flag_rows_kernel(int world, int cap, int d4, const float* __restrict__ loss_out, const int* __restrict__ flags,
+                                       float4* __restrict__ out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= world) return;
+  const float loss = loss_out ? loss_out[0] : 0.f;
+  const float nan = (loss_out && (loss_out[2] < 0.f || loss != loss)) ? 1.f : 0.f;
+  out[(long long)s * cap * d4] = make_float4(nan, (flags && (flags[0] & 1)) ? 1.f : 0.f, nan != 0.f ? 0.f : loss, 1.f);
+}
+
 // the flags of all ranks, as received in slot 0 of every block of grads_in -> out[0] = gradient scale of the update kernels (1 / W =
 // DDP's mean, or -1 = skip the step: a NaN loss or an overflow on ANY rank), out[1] = mean loss over the ranks, out[2] / out[3] = number
 // of ranks with a NaN loss / an overflow
@@ -251,11 +261,14 @@ extern "C" int ur_shard_exchange_rows(const float* table, const int32_t* req_ids
 extern "C" int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_of_slot, int32_t world, int32_t cap, int32_t d,
                                        const float* loss_out, const int32_t* flags_dev, float* send_ws, float* grads_in,
                                        int32_t transport, void* stream) {
-  UR_REQUIRE(uniq_grad && u_of_slot && send_ws, UR_ERR_ARG, "ur_shard_exchange_grads: null pointer");
+  UR_REQUIRE((uniq_grad == nullptr || u_of_slot) && send_ws, UR_ERR_ARG, "ur_shard_exchange_grads: null pointer");
   UR_REQUIRE(world >= 1 && cap > 0 && d > 0 && d % 4 == 0, UR_ERR_ARG, "ur_shard_exchange_grads: world=%d cap=%d d=%d", world, cap, d);
   hipStream_t st = as_stream(stream);
   const long long n_slots = (long long)world * cap;
-  {
+  if (!uniq_grad) {
+    hipLaunchKernelGGL(shard_flag_rows_kernel, dim3(cdiv(world, 64)), dim3(64), 0, st, world, cap, d / 4, loss_out, flags_dev, (float4*)send_ws);
+    UR_LAUNCH_CHECK();
+  } else {
     ProfScope ps(PC_REDUCE, st, (double)n_slots * d * 8.0);
     hipLaunchKernelGGL(shard_scatter_rows_kernel, dim3(cdiv(n_slots * (d / 4), 256)), dim3(256), 0, st, (const float4*)uniq_grad, u_of_slot,
                        n_slots, cap, d / 4, loss_out, flags_dev, (float4*)send_ws);

@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
                                                           const int* __restrict__ sorted_pos, const int* __restrict__ n_uniq_dev,
                                                           long long n, const float4* __restrict__ rows_a, long long n_a,
                                                           const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G,
-                                                          int d4, float4* __restrict__ out, int zero_tail) {
+                                                          int d4, float4* __restrict__ out, int zero_tail,
+                                                          const int* __restrict__ out_rows) {
   constexpr int groups = 256 / TPR;
   __shared__ float4 part[groups][MAXV * TPR];
   __shared__ int long_list[256];
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long frow = uniq_idx[u];
+    const long long orow = out_rows ? out_rows[u] : u;   // (out_rows: the row of unique id u in the caller's layout, e.g. its exchange slot)
     if (frow != 0) {
       const int s = seg_start[u], e = seg_start[u + 1];
       if (e - s > LONG_SEG) continue;                      // pass 2
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int c = t + k * TPR;
-      if (c < d4) out[u * d4 + c] = acc[k];
+      if (c < d4) out[orow * d4 + c] = acc[k];
     }
   }
   // ---- pass 2: the long runs, each by a whole workgroup.  Candidates are dealt out INTERLEAVED (thread j of workgroup b looks at
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
               const float4 x = part[gg][k * TPR + t];
               r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
             }
-            out[ul * d4 + c] = r;
+            out[(out_rows ? (long long)out_rows[ul] : ul) * d4 + c] = r;
           }
         }
       }
@@ -1037,8 +1039,10 @@ extern "C" int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_
 
 extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
                               const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
-                              const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, void* stream) {
+                              const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
+                              void* stream) {
   UR_REQUIRE(uniq_idx && seg_start && sorted_pos && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_rows_reduce: null pointer");
+  UR_REQUIRE(!(out_rows && sumsq_dev), UR_ERR_ARG, "ur_rows_reduce: out_rows with the zeroed tail");
   UR_REQUIRE(n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_rows_reduce: n=%lld n_a=%lld", (long long)n, (long long)n_a);
   UR_REQUIRE((rows_a || n_a == 0) && ((coef_b && vec_b && G > 0) || n_a == n), UR_ERR_ARG, "ur_rows_reduce: missing source");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512, UR_ERR_ARG, "ur_rows_reduce: d=%d", d);
@@ -1050,7 +1054,7 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
   const int zero_tail = sumsq_dev != nullptr;
 #define GO(T) hipLaunchKernelGGL((rows_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
                                  (long long)n, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,          \
-                                 (float4*)uniq_grad, zero_tail)
+                                 (float4*)uniq_grad, zero_tail, out_rows)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

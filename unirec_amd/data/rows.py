@@ -8,6 +8,7 @@ import ctypes as C
 import numpy as np
 import torch
 
+from .. import ops
 from .._lib import check, lib
 
 MASK_MODES = {"unorder": 0, "autoregressive": 1}
@@ -143,11 +144,11 @@ def sample_negatives_device(pos_item, K, n_items, user_id=None, history: History
         assert odds.is_cuda and odds.dtype == torch.float64 and idx.dtype == torch.int64 and odds.numel() == n_items == idx.numel()
         check(lib.ur_sample_negatives_pop(p(user_id), p(pos_item.contiguous()), B, K, n_items, history.n_users if history else 0, p(ptr),
                                           p(srt), p(odds), p(idx), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step) & 0xFFFFFFFF, p(item_id),
-                                          p(label), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ur_sample_negatives_pop")
+                                          p(label), ops._stream()), "ur_sample_negatives_pop")
         return item_id, label
     check(lib.ur_sample_negatives(p(user_id), p(pos_item.contiguous()), B, K, n_items, history.n_users if history else 0, p(ptr), p(srt),
                                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(step) & 0xFFFFFFFF, p(item_id), p(label),
-                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ur_sample_negatives")
+                                  ops._stream()), "ur_sample_negatives")
     return item_id, label
 
 
@@ -190,7 +191,7 @@ class DeviceRowBuilder:
             p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
             check(lib.ur_device_build_seq(p(user_id.contiguous()), p(item_id), B, G, self.history.n_users, p(ptr), p(items), self.mask_mode,
                                           self.seq_last, 0 if self.reject else 1, self.L, self.seed & 0xFFFFFFFFFFFFFFFF,
-                                          step & 0xFFFFFFFF, p(seq), p(slen), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                          step & 0xFFFFFFFF, p(seq), p(slen), ops._stream()),
                   "ur_device_build_seq")
             out["item_seq"], out["item_seq_len"] = seq, slen
         return out

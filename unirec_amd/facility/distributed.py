@@ -366,8 +366,9 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             ids_a, rows, ids_b, coef, vec, G = self._collect(name)
             sb, bf = c["sb"], c["bf"]
             d = sb["compact"].shape[1]
-            ug = ops.rows_reduce(c["pl"], rows, coef.reshape(-1) if coef is not None else None, vec, G, d)
-            ops.shard_exchange_grads(ug, bf["uos"], W, c["cap"], sb["send_grads"], grads_in=sb["grads_in"], transport=self._native,
+            # (the sums land in their exchange slots: no scatter pass; padding slots keep stale bytes that no owner reads)
+            ops.rows_reduce(c["pl"], rows, coef.reshape(-1) if coef is not None else None, vec, G, d, out=sb["send_grads"], out_rows=bf["slot"])
+            ops.shard_exchange_grads(None, bf["uos"], W, c["cap"], sb["send_grads"], grads_in=sb["grads_in"], transport=self._native,
                                      loss_out=loss_buf, flags=bf["flags"])
             if not self._native:
                 self._a2a(sb["send_grads"], sb["grads_in"], "a2a_row_grads")
@@ -376,8 +377,10 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                 first = False
             owner_grads[name] = ops.rows_reduce(c["own"], sb["grads_in"], None, None, 1, d, zero_tail=self.grad_clip is not None)
         scale = out4[0:1]
-        if cuda:
-            k = self.t % 4
+        flags_copied = False
+
+        def copy_flags():   # the step's flags -> pinned host memory (read two steps later); on the side stream when there is one:
+            k = self.t % 4  # a device-to-host copy in the main queue is 4 us of copy and 8 us of idle queue behind it
             self._flag_host[k].copy_(out4, non_blocking=True)
             self._flag_ev[k] = torch.cuda.Event()
             self._flag_ev[k].record()
@@ -404,11 +407,16 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                 ev.record()
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
+                    if cuda:
+                        copy_flags()
+                        flags_copied = True
                     self._all_reduce(g)
                     ops.dense_adam(cfg, model.dense_flat.data, g, self.dense_m, self.dense_v, scale)
                 ops.sasrec_side_publish(late=next_batch is not None, hold=(g, out4) + tuple(getattr(model, "_deferred_reads", ())))
                 model.dense_flat.grad = g
                 object.__setattr__(model, "_deferred_dense_grad", None)
+        if cuda and not flags_copied:
+            copy_flags()
         if side is None:
             self._dense_main(cfg, bias_ctx, owner_grads, tabs, scale)
         object.__setattr__(model, "loss_guard", None)

@@ -9,7 +9,15 @@ from . import _lib
 from ._lib import ACT_IDS, LOSS_IDS, UrAdamCfg, UrLossCfg, UrSasrecCfg, check, lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream as a raw pointer.  torch.cuda.current_stream() builds a Stream object through three layers of Python
+    (~8 us); a step makes 20-40 ctypes calls, which made the multi-GPU step host-bound (0.65 ms of enqueue per 0.60 ms of device
+    work).  The raw accessor is one C call."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -380,10 +388,10 @@ def shard_exchange_rows(table, req_ids, world, cap, rows_ws, compact=None, trans
 
 def shard_exchange_grads(uniq_grad, u_of_slot, world, cap, send_ws, grads_in=None, transport=False, loss_out=None, flags=None):
     """loss_out (the loss kernels' [loss, n, guard, .] buffer) / flags (shard_exchange_ids): this rank's step flags, carried in slot 0"""
-    _chk(uniq_grad, torch.float32, "uniq_grad"); _chk(u_of_slot, torch.int32, "u_of_slot"); _chk(send_ws, torch.float32, "send_ws")
+    _chk(uniq_grad, torch.float32, "uniq_grad", allow_none=True); _chk(u_of_slot, torch.int32, "u_of_slot"); _chk(send_ws, torch.float32, "send_ws")
     _chk(loss_out, torch.float32, "loss_out", allow_none=True); _chk(flags, torch.int32, "flags", allow_none=True)
-    d = uniq_grad.shape[1]
-    assert u_of_slot.numel() == world * cap and send_ws.numel() == world * cap * d
+    d = send_ws.shape[-1]   # (uniq_grad None: the rows are in their slots already -- rows_reduce(out=send_ws, out_rows=slot_of_uniq))
+    assert (uniq_grad is None or u_of_slot.numel() == world * cap) and send_ws.numel() == world * cap * d
     check(lib.ur_shard_exchange_grads(_p(uniq_grad), _p(u_of_slot), int(world), int(cap), d, _p(loss_out), _p(flags), _p(send_ws),
                                       _p(grads_in), 1 if transport else 0, _stream()), "ur_shard_exchange_grads")
     return grads_in if transport else send_ws
@@ -396,14 +404,20 @@ def shard_step_flags(grads_in, world, cap, out4):
     return out4
 
 
-def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False) -> torch.Tensor:
+def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False, out=None, out_rows=None) -> torch.Tensor:
+    """out / out_rows: write the sum of unique id u to out[out_rows[u], :] (a preallocated buffer in the caller's layout, e.g. the
+    exchange slots of the multi-GPU step) instead of a fresh [n, d] tensor"""
     _chk(rows_a, torch.float32, "rows_a", allow_none=True)
     _chk(coef_b, torch.float32, "coef_b", allow_none=True)
     _chk(vec_b, torch.float32, "vec_b", allow_none=True)
-    out = torch.empty(pl.n, d, dtype=torch.float32, device=pl.uniq_idx.device)
+    _chk(out, torch.float32, "out", allow_none=True); _chk(out_rows, torch.int32, "out_rows", allow_none=True)
+    if out_rows is not None and (out is None or zero_tail or out_rows.numel() < pl.n or out.shape[-1] != d):
+        raise _lib.UnirecAmdError("rows_reduce: out_rows needs a preallocated `out` of row width d, a map of >= n entries and no zeroed tail")
+    if out is None:
+        out = torch.empty(pl.n, d, dtype=torch.float32, device=pl.uniq_idx.device)
     flag = out if zero_tail else None  # non-null sumsq pointer = "zero the rows beyond n_uniq"
     check(lib.ur_rows_reduce(_p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, _p(rows_a), pl.n_a,
-                             _p(coef_b), _p(vec_b), int(G), int(d), _p(out), _p(flag), _stream()), "ur_rows_reduce")
+                             _p(coef_b), _p(vec_b), int(G), int(d), _p(out), _p(flag), _p(out_rows), _stream()), "ur_rows_reduce")
     return out
 
 

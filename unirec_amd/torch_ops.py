@@ -160,7 +160,7 @@ def sample_negatives(user_id: torch.Tensor, pos_item: torch.Tensor, n_neg: int, 
     n_users = hist_ptr.numel() - 1 if hist_ptr is not None else 0
     check(lib.ur_sample_negatives(p(user_id), p(pos_item.contiguous()), B, n_neg, n_items, n_users, p(hist_ptr), p(hist_sorted),
                                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(step) & 0xFFFFFFFF, p(item_id), p(label),
-                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ur_sample_negatives")
+                                  ops._stream()), "ur_sample_negatives")
     return item_id, label
 
 
