@@ -325,3 +325,27 @@ def test_sharded_optimizer_world1_equals_plain_path(kind):
         # (the lazy replay of a row's missed steps is summed in two pieces when the tail catch-up ran: a few ulp of an lr-sized term)
         np.testing.assert_allclose(m1.item_embedding.weight.detach().cpu().numpy(), m2.item_embedding.weight.detach().cpu().numpy(),
                                    rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_rows_reduce_into_caller_rows():
+    """ur_rows_reduce(out_rows): the per-id sums written to rows of the caller's choice == the default output scattered by the same map
+    (bit-exact), rows outside the map untouched"""
+    import torch
+    from unirec_amd import ops
+    torch.manual_seed(5)
+    dev, d, n_a, n_b, G = "cuda", 64, 900, 30, 5
+    ids_a = torch.randint(0, 200, (n_a,), device=dev, dtype=torch.int32)
+    ids_b = torch.randint(0, 200, (n_b * G,), device=dev, dtype=torch.int64)
+    rows = torch.randn(n_a, d, device=dev)
+    coef, vec = torch.randn(n_b * G, device=dev), torch.randn(n_b, d, device=dev)
+    pl = ops.rows_plan(ids_a, ids_b, 200)
+    want = ops.rows_reduce(pl, rows, coef, vec, G, d)
+    n_uniq = int(pl.n_uniq.item())
+    perm = torch.randperm(pl.n + 17, device=dev)[: pl.n].to(torch.int32)
+    out = torch.full((pl.n + 17, d), 7.0, device=dev)
+    got = ops.rows_reduce(pl, rows, coef, vec, G, d, out=out, out_rows=perm)
+    assert got is out
+    ref = torch.full_like(out, 7.0)
+    ref[perm[:n_uniq].long()] = want[:n_uniq]
+    assert torch.equal(out, ref)

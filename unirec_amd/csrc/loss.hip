@@ -526,19 +526,27 @@ extern "C" int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_em
   return UR_OK;
 }
 
-// One counter per device for the "last workgroup finishes the loss" step of the fused kernel (zeroed once; the kernel resets it).
-// Launches of the fused kernel on ONE device must not overlap each other (one training stream per process: they do not).
-static unsigned* fused_counter() {
-  static unsigned* z[64] = {};
+// One counter per (device, stream) for the "last workgroup finishes the loss" step of the fused kernel (zeroed once; the kernel resets
+// it): launches on different streams never share one, launches on one stream are ordered.  (The hand-off itself uses relaxed
+// device-scope read-modify-writes, not release / acquire: a device-scope release on this part writes back the XCD's whole L2 -- 512
+// of them cost the step 20 us -- and an RMW is performed at the point all XCDs agree on; see scorer_loss_fused_kernel.)
+static unsigned* fused_counter(hipStream_t st) {
+  struct Slot { hipStream_t st; unsigned* p; };
+  static Slot z[64][16] = {};
+  static int used[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!z[dev]) {
-    unsigned* p = nullptr;
-    if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-    z[dev] = p;
+  for (int i = 0; i < used[dev]; ++i)
+    if (z[dev][i].st == st) return z[dev][i].p;
+  if (used[dev] == 16) {   // more than 16 training streams on a device: the last counter changes hands (it is zero between launches)
+    z[dev][15].st = st;
+    return z[dev][15].p;
   }
-  return z[dev];
+  unsigned* p = nullptr;
+  if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
+  if (hipMemset(p, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+  z[dev][used[dev]++] = Slot{st, p};
+  return p;
 }
 
 extern "C" int ur_gather_dot_loss_fused_supported(const UrLossCfg* cfg) {
@@ -562,7 +570,7 @@ extern "C" int ur_gather_dot_loss_fwd_bwd(const UrLossCfg* cfg, const float* use
              "ur_gather_dot_loss_fwd_bwd: loss_type=%d G=%d d=%d (bpr / bce / ccl with G * d * 4 <= 32 KB; otherwise call _fwd and _bwd)",
              cfg->loss_type, cfg->G, cfg->d);
   hipStream_t st = as_stream(stream);
-  unsigned* counter = fused_counter();
+  unsigned* counter = fused_counter(st);
   UR_REQUIRE(counter != nullptr, UR_ERR_HIP, "ur_gather_dot_loss_fwd_bwd: no device memory for the completion counter");
   ProfScope ps(PC_LOSS, st, (double)cfg->B * cfg->G * cfg->d * 4.0);
   const int tpr = pick_tpr(cfg->d);
