@@ -349,3 +349,28 @@ def test_rows_reduce_into_caller_rows():
     ref = torch.full_like(out, 7.0)
     ref[perm[:n_uniq].long()] = want[:n_uniq]
     assert torch.equal(out, ref)
+
+
+@pytest.mark.gpu
+def test_native_transport_selftest_world_one():
+    """What ShardedSparseDenseAdam runs once before it trusts the library's communicators (world > 1 on the nccl backend), executed at
+    world 1 on a one-rank nccl group: library all-to-all / all-reduce == torch.distributed's."""
+    from unirec_amd import ops
+    from unirec_amd.facility.distributed import native_transport_selftest
+    if ops.comm_world() < 0:
+        pytest.skip("no RCCL library in this process")
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda:0")
+        assert ops.comm_init(0, 1) is True
+        try:
+            assert native_transport_selftest(0, 1, None, dev) is True
+        finally:
+            if ops.comm_world() >= 1:
+                ops.comm_destroy()
+    finally:
+        if own_group:
+            dist.destroy_process_group()

@@ -68,6 +68,29 @@ class _Look:
     __slots__ = ("key", "tabs", "event", "keep", "waited")
 
 
+def native_transport_selftest(rank, world, group, dev):
+    """One tiny all-to-all and all-reduce through the library's communicators (ops.comm_init) against torch.distributed's: the first RCCL
+    traffic of the process goes through a check, not through the first training step.  Every rank gets the same verdict (a MIN
+    all-reduce); on a mismatch the library's communicators are destroyed and the step uses the torch.distributed transport."""
+    W, cap, d = world, 4, 8
+    send = (torch.arange(W * cap * d, device=dev, dtype=torch.float32) + 1000.0 * rank).reshape(W * cap, d)
+    got = torch.empty_like(send)
+    ops.shard_exchange_grads(send.clone(), torch.arange(W * cap, device=dev, dtype=torch.int32), W, cap, send.clone(), grads_in=got, transport=True)
+    want = torch.empty_like(send)
+    dist.all_to_all_single(want, send.clone(), group=group)
+    got[::cap] = want[::cap]          # (slot 0 of every block carries the flag row: not part of the comparison)
+    s = torch.full((16,), float(rank + 1), device=dev)
+    ops.comm_all_reduce_sum(s)
+    ok = torch.tensor([1.0 if torch.equal(got, want) and float(s[0]) == W * (W + 1) / 2 else 0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if float(ok) != 1.0:
+        import warnings
+        warnings.warn("unirec_amd: the library's RCCL transport failed its self-test; using torch.distributed for the row exchange")
+        ops.comm_destroy()
+        return False
+    return True
+
+
 class ShardedSparseDenseAdam(SparseDenseAdam):
     """SparseDenseAdam for world > 1 (see the module docstring).  The model keeps its SHARD under each table's ``weight``;
     ``train_step`` swaps the compact table of the batch's rows in for the duration of the model's forward_backward.
@@ -129,8 +152,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         # native transport: RCCL through the library's own communicators, on whatever stream the step is on
         self._native = False
         if world > 1 and dev.type == "cuda" and dist.get_backend(group) == "nccl" and ops.comm_world() >= 0:
-            ops.comm_init(rank, world, group)
-            self._native = True
+            self._native = bool(ops.comm_init(rank, world, group)) and self._native_selftest(dev)
         self._bufs = {}                   # (table, n, n_a, parity) -> preallocated exchange buffers
         self._look = None                 # _Look of the next batch (plan stream)
         self._parity = 0
@@ -140,6 +162,9 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         self._flag_batch = [None] * 4
         self._replaying = False
         self.n_overflow = 0
+
+    def _native_selftest(self, dev):
+        return native_transport_selftest(self.rank, self.world, self.xchg.group, dev)
 
     # ------------------------------------------------------------------ collectives on top of RowExchange
     def _broadcast(self, t, chunk=1 << 26):

@@ -344,16 +344,24 @@ def comm_world():
 
 
 def comm_init(rank, world, group=None):
-    """The library's own RCCL communicator, one per process: rank 0 makes the unique id, torch.distributed (any backend) carries it."""
+    """The library's own RCCL communicator, one per process: rank 0 makes the unique id, torch.distributed (any backend) carries it.
+    Returns False -- on EVERY rank alike -- when rank 0 could not make the id (no RCCL in the process): the caller then moves the packed
+    blocks with torch.distributed instead.  A failure of the collective initialisation itself raises (the other ranks are inside it)."""
     import torch.distributed as dist
     buf = (C.c_char * 256)()
+    ok = True
     if rank == 0:
-        check(lib.ur_comm_unique_id(buf), "ur_comm_unique_id")
+        ok = lib.ur_comm_unique_id(buf) >= 0
     if world > 1:
-        box = [bytes(buf.raw)]
+        box = [bytes(buf.raw) if ok else None]
         dist.broadcast_object_list(box, src=0, group=group)
+        if box[0] is None:
+            return False
         buf = (C.c_char * 256).from_buffer_copy(box[0])
+    elif not ok:
+        return False
     check(lib.ur_comm_init(buf, int(rank), int(world)), "ur_comm_init")
+    return True
 
 
 def comm_destroy():
