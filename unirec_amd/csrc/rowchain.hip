@@ -40,7 +40,6 @@ typedef float fx4 __attribute__((ext_vector_type(4)));   // plain LLVM vector: r
 // straight from global memory (the weights are L2-resident) into registers, two slices ahead -- no staging stores, and ONE barrier per
 // GEMM segment (when the activation tile changes hands) instead of one per K slice.  LDS = the two activation tiles (32 KB at D = 128).
 constexpr int RC_BK = 16;          // K-slice of the streamed weight tile
-constexpr int RC_LS = RC_BK + 4;   // padded LDS row stride of the weight stage (conflict-free ds_read_b128)
 
 template <int D>
 struct RcGeom {
@@ -53,8 +52,7 @@ struct RcGeom {
   static constexpr int RPP = 256 / TPR;             // rows per epilogue pass; 4 passes cover the BM rows
   static constexpr int WV = 2;                      // float4 loads per lane per weight slice: k offsets fk .. fk+3 and 8 + fk .. of ITS row
   static constexpr int TILE = BM * TS;              // floats per activation tile
-  static constexpr int WST = 0;                     // (no weight stage)
-  static constexpr size_t LDS_BYTES = (size_t)(2 * TILE + 2 * WST) * sizeof(float);
+  static constexpr size_t LDS_BYTES = (size_t)(2 * TILE) * sizeof(float);
 };
 
 // offset (floats) of 16-byte chunk c4 of row r in a swizzled activation tile: rows are D floats apart (a multiple of the 64 banks), so the
@@ -64,9 +62,6 @@ __device__ __forceinline__ int rc_toff(int r, int c4) {
   return r * D + ((c4 ^ (r & RcGeom<D>::SWZ)) << 2);
 }
 
-// One thread's view of a weight segment (rows row0 .. row0+D-1, columns k0 .. of a row-major matrix with leading dimension
-// ldw): the address of ITS first float4 of the segment's first K-slice.  Thread tid stages row (tid >> 2) + 64 i, float4
-// column tid & 3 of every slice.  Everything is passed by value (a struct whose address is taken ends up in scratch memory).
 // One LANE's view of a weight segment (rows row0 .. row0+D-1 = output features, columns k0 .. of a row-major matrix with leading
 // dimension ldw): the address of the first float4 of ITS B-operand fragment of the first K-slice -- row = the wave's 32-column block +
 // lane & 31, k offset 4 (lane >> 5) (the fragment layout of rc_gemm).
@@ -81,20 +76,14 @@ __device__ __forceinline__ void rc_wload(fx4 (&r)[RcGeom<D>::WV], const float* p
   r[0] = *(const fx4*)p;
   r[1] = *(const fx4*)(p + 8);
 }
-template <int D>
-__device__ __forceinline__ void rc_wstore(const fx4 (&r)[RcGeom<D>::WV], float* buf, int tid) { (void)r; (void)buf; (void)tid; }
 
-// acc += As[BM, D] @ W[seg]^T, K = D in NK = D / 32 slices.  As: an LDS activation tile (row stride TS).
-// The weight-slice stream runs TWO slices ahead of the MFMAs (an L2 round trip is longer than one K-step of 16 MFMAs): on entry
-// slice 0 of the segment is in Wst[buf] and slice 1 is in flight into wreg[1] (for NK = 1: slice 0 of the NEXT segment);
-// step kt issues the loads of slice kt+2 into wreg[kt & 1], computes on Wst[buf], then stages slice kt+1 (issued one step
-// earlier) into the other buffer.  wp / wnp: rc_wptr of this / the next segment (wnp nullable: the stream then re-reads this
-// segment -- staged, never used).  The invariant holds again on exit, for the next segment.  Ends with a barrier: every wave is
-// done reading As and the stage.
+// acc += As[BM, D] @ W[seg]^T, K = D in NK = D / 16 slices.  As: an LDS activation tile (row stride TS).
+// The weight-slice stream runs TWO slices ahead of the MFMAs (an L2 round trip is longer than one K-step of 8 MFMAs) and never drains
+// inside a workgroup: wp / wnp are rc_wptr of this / the next segment (wnp nullable: the stream then re-reads this segment, unused).
+// Ends with a barrier: every wave is done reading As.
 template <int D>
 __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const float* wp, int ldw, const float* wnp, int ldwn,
-                                        float* Wst, int& buf, fx4 (&wreg)[2][RcGeom<D>::WV], int tid, int wr, int wc, int lane) {
-  (void)Wst; (void)buf; (void)tid; (void)wc;
+                                        fx4 (&wreg)[2][RcGeom<D>::WV], int wr, int lane) {
   constexpr int NK = D / RC_BK;
   static_assert(NK % 2 == 0, "the two-slot ring assumes an even number of slices per segment");
   const int frow = lane & 31, fk = 4 * (lane >> 5);
@@ -132,22 +121,19 @@ __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const fl
   __syncthreads();   // every wave is done reading As: the caller may overwrite it
 }
 
-// start of the stream: slice 0 of the first segment -> Wst[0] (after the caller's barrier), slice 1 in flight
+// start of the stream: slice 0 of the first segment at kernel entry, slice 1 behind the tile staging loads
 template <int D>
 __device__ __forceinline__ void rc_prime_load(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw) {
   rc_wload<D>(wreg[0], wp, ldw);
 }
 template <int D>
-__device__ __forceinline__ void rc_prime_store(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw, const float* wnp, int ldwn,
-                                               float* Wst, int tid) {
-  (void)wnp; (void)ldwn; (void)Wst; (void)tid;
+__device__ __forceinline__ void rc_prime_next(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw) {   // slice 1, once the tile staging loads are out
   rc_wload<D>(wreg[1], wp + RC_BK, ldw);
 }
 
 // accumulator tile -> LDS tile.  acc[r]: row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of the wave's 32 x 32 tile.
 template <int D>
 __device__ __forceinline__ void rc_acc_to_tile(const floatx16& acc, float* T, int wr, int wc, int lane) {
-  using G = RcGeom<D>;
   const int nl = wc * 32 + (lane & 31), r4 = 4 * (lane >> 5);
 #pragma unroll
   for (int r = 0; r < 16; ++r) T[rc_toff<D>(wr * 32 + (r & 3) + 8 * (r >> 2) + r4, nl >> 2) + (nl & 3)] = acc[r];
@@ -259,7 +245,6 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* At = smem;                  // [BM][TS]: ctx, then a, then y
   float* Ht = smem + G::TILE;        // [BM][TS]: accumulator staging / act(h1 chunk)
-  float* Wst = smem + 2 * G::TILE;   // [2][D][RC_LS]
   int M = a.M;
   if (a.m_dev) M = min(M, *a.m_dev);
   const int m0 = blockIdx.x * G::BM;
@@ -268,7 +253,6 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   const int wr = wave / G::WC, wc = wave % G::WC;
   const float inv_n = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
-  int buf = 0;
   rc_prime_load<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);   // the first weight slice is in flight while the ctx tile is staged
   {
   const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
@@ -280,13 +264,13 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
     *(float4*)(At + rc_toff<D>(ml, et)) = v;
   }
   }
-  rc_prime_store<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);
   __syncthreads();
 
   // ---- 1. attention output projection + residual + LayerNorm
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0, tid), D, rc_wptr<D>(a.w1, D, 0, 0, tid), D, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0, tid), D, rc_wptr<D>(a.w1, D, 0, 0, tid), D, wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -326,7 +310,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
     const float* w2p = rc_wptr<D>(a.w2, a.I, 0, c * D, tid);
     {
       floatx16 acch = zero16();
-      rc_gemm<D>(acch, At, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, w2p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
+      rc_gemm<D>(acch, At, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, w2p, a.I, wreg, wr, lane);
       rc_acc_to_tile<D>(acch, Ht, wr, wc, lane);
     }
     __syncthreads();
@@ -351,7 +335,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
     }
     __syncthreads();
     const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w1, D, (c + 1) * D, 0, tid) : (a.wn ? rc_wptr<D>(a.wn, D, 0, 0, tid) : nullptr);
-    rc_gemm<D>(accy, Ht, w2p, a.I, nxp, D, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_gemm<D>(accy, Ht, w2p, a.I, nxp, D, wreg, wr, lane);
   }
 
   // ---- 3. y = LN(drop(acc + b2) + a)
@@ -391,8 +375,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   const int nn = a.Nn / D;
   for (int c = 0; c < nn; ++c) {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wn, D, c * D, 0, tid), D, c + 1 < nn ? rc_wptr<D>(a.wn, D, (c + 1) * D, 0, tid) : nullptr, D, Wst, buf,
-               wreg, tid, wr, wc, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wn, D, c * D, 0, tid), D, c + 1 < nn ? rc_wptr<D>(a.wn, D, (c + 1) * D, 0, tid) : nullptr, D, wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
     __syncthreads();
     const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
@@ -472,7 +455,6 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* At = smem;                  // [BM][TS]: ctx, then a
   float* Ht = smem + G::TILE;        // [BM][TS]: accumulator staging / act(h1 chunk)
-  float* Wst = smem + 2 * G::TILE;   // [2][D][RC_LS]
   __shared__ int is_last;
   const int M = a.M;
   const int nc = a.I / D;
@@ -483,7 +465,6 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_n = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
-  int buf = 0;
   rc_prime_load<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);
   // every small operand of the epilogues is requested HERE (one workgroup per CU, parameters rewritten by the optimizer a moment ago:
   // each of these is a miss all the way to HBM, ~2 us when it is asked for where it is used, behind a barrier)
@@ -500,12 +481,12 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
     if (m < M) v = *(const float4*)(a.ctx + (long long)m * a.ldctx + et * 4);
     *(float4*)(At + rc_toff<D>(ml, et)) = v;
   }
-  rc_prime_store<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);
   __syncthreads();
   // ---- 1. attention output projection + residual + LayerNorm (every chunk's workgroup; chunk 0 writes a / ahat / rstd1)
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0, tid), D, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0, tid), D, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -541,7 +522,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   const float* w2p = rc_wptr<D>(a.w2, a.I, 0, c * D, tid);
   {
     floatx16 acch = zero16();
-    rc_gemm<D>(acch, At, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, w2p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_gemm<D>(acch, At, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, w2p, a.I, wreg, wr, lane);
     rc_acc_to_tile<D>(acch, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -565,7 +546,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   }
   __syncthreads();
   floatx16 accy = zero16();
-  rc_gemm<D>(accy, Ht, w2p, a.I, nullptr, D, Wst, buf, wreg, tid, wr, wc, lane);
+  rc_gemm<D>(accy, Ht, w2p, a.I, nullptr, D, wreg, wr, lane);
   rc_acc_to_tile<D>(accy, Ht, wr, wc, lane);
   __syncthreads();
   // ---- 3. the partial -> memory (device scope), count, and the last workgroup of the row block finishes
@@ -624,7 +605,6 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* At = smem;                  // [BM][TS]: g_tf, then g_ta
   float* Ht = smem + G::TILE;        // [BM][TS]: accumulator staging / g_h1 chunk / reduction scratch
-  float* Wst = smem + 2 * G::TILE;
   int M = a.M;
   if (a.m_dev) M = min(M, *a.m_dev);
   const int m0 = blockIdx.x * G::BM;
@@ -637,7 +617,6 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   const int wr = wave / G::WC, wc = wave % G::WC;
   const float inv_d = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
-  int buf = 0;
   rc_prime_load<D>(wreg, rc_wptr<D>(a.w2T, D, 0, 0, tid), D);
 
   // ---- 0. feed-forward LayerNorm backward: g_tf (also the residual branch of g_a)
@@ -659,7 +638,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
     }
     rc_block_colsum<D>(dg, db, Ht, part, eg, et, tid);
   }
-  rc_prime_store<D>(wreg, rc_wptr<D>(a.w2T, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.w2T, D, 0, 0, tid), D);
   __syncthreads();
 
   // ---- 1. g_h1 chunk = (g_tf W2[:, chunk]) * act'(h1 chunk);   g_a += g_h1 chunk W1[chunk, :]
@@ -669,7 +648,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
     const float* w1p = rc_wptr<D>(a.w1T, a.I, 0, c * D, tid);
     {
       floatx16 accu = zero16();
-      rc_gemm<D>(accu, At, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D, w1p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
+      rc_gemm<D>(accu, At, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D, w1p, a.I, wreg, wr, lane);
       rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
     }
     __syncthreads();
@@ -696,7 +675,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
     }
     __syncthreads();
     const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w2T, D, (c + 1) * D, 0, tid) : rc_wptr<D>(a.woT, D, 0, 0, tid);
-    rc_gemm<D>(acca, Ht, w1p, a.I, nxp, D, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_gemm<D>(acca, Ht, w1p, a.I, nxp, D, wreg, wr, lane);
   }
 
   // ---- 2. g_a = acc + g_tf;  attention LayerNorm backward -> g_ta
@@ -727,7 +706,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   // ---- 3. g_ctx = g_ta Wo
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0, tid), D, nullptr, 0, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0, tid), D, nullptr, 0, wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -747,7 +726,6 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* At = smem;
   float* Ht = smem + G::TILE;
-  float* Wst = smem + 2 * G::TILE;
   int M = a.M;
   if (a.m_dev) M = min(M, *a.m_dev);
   const int m0 = blockIdx.x * G::BM;
@@ -760,7 +738,6 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   const int wr = wave / G::WC, wc = wave % G::WC;
   const int et = tid % G::TPR, eg = tid / G::TPR;
   fx4 wreg[2][G::WV];
-  int buf = 0;
   const int nkc = a.K / D;
   rc_prime_load<D>(wreg, rc_wptr<D>(a.wT, a.ldw, 0, 0, tid), a.ldw);
   float4 ra[4];
@@ -777,14 +754,14 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   };
   load_a(0);
   store_a();
-  rc_prime_store<D>(wreg, rc_wptr<D>(a.wT, a.ldw, 0, 0, tid), a.ldw, nullptr, 0, Wst, tid);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.wT, a.ldw, 0, 0, tid), a.ldw);
   __syncthreads();
   floatx16 acc = zero16();
   for (int kc = 0; kc < nkc; ++kc) {
     const bool more = kc + 1 < nkc;
     if (more) load_a(kc + 1);   // the next slice of g is in flight underneath this chunk's MFMAs
     rc_gemm<D>(acc, At, rc_wptr<D>(a.wT, a.ldw, 0, kc * D, tid), a.ldw, more ? rc_wptr<D>(a.wT, a.ldw, 0, (kc + 1) * D, tid) : nullptr, a.ldw,
-               Wst, buf, wreg, tid, wr, wc, lane);
+               wreg, wr, lane);
     if (more) {
       store_a();
       __syncthreads();
@@ -830,7 +807,6 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* At = smem;                  // [BM][TS]: g_tf, then g_ta
   float* Ht = smem + G::TILE;        // [BM][TS]: accumulator staging / g_h1 chunk / reduction scratch
-  float* Wst = smem + 2 * G::TILE;
   __shared__ int is_last;
   const int M = a.M;
   const int nc = a.I / D;
@@ -842,7 +818,6 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_d = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
-  int buf = 0;
   rc_prime_load<D>(wreg, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D);
   // (what the later epilogues read from memory is requested here: see chain_ffn_fwd_split_kernel)
   const float4 q_g1 = *(const float4*)(a.g1 + et * 4);
@@ -873,13 +848,13 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
     }
     if (c == 0) rc_block_colsum<D>(dg, db, Ht, part, eg, et, tid);   // (workgroup-uniform branch: the barriers inside are fine)
   }
-  rc_prime_store<D>(wreg, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D, nullptr, 0, Wst, tid);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D);
   __syncthreads();
   // ---- 1. g_h1 chunk = (g_tf W2[:, chunk]) * act'(h1 chunk);   partial of g_a = g_h1 chunk W1[chunk, :]
   const float* w1p = rc_wptr<D>(a.w1T, a.I, 0, c * D, tid);
   {
     floatx16 accu = zero16();
-    rc_gemm<D>(accu, At, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D, w1p, a.I, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_gemm<D>(accu, At, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D, w1p, a.I, wreg, wr, lane);
     rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -904,7 +879,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   }
   __syncthreads();
   floatx16 acca = zero16();
-  rc_gemm<D>(acca, Ht, w1p, a.I, rc_wptr<D>(a.woT, D, 0, 0, tid), D, Wst, buf, wreg, tid, wr, wc, lane);
+  rc_gemm<D>(acca, Ht, w1p, a.I, rc_wptr<D>(a.woT, D, 0, 0, tid), D, wreg, wr, lane);
   rc_acc_to_tile<D>(acca, Ht, wr, wc, lane);
   __syncthreads();
   // ---- 2. the partial -> memory (device scope), count; the last workgroup of the row block goes on
@@ -954,7 +929,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   // ---- 4. g_ctx = g_ta Wo
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0, tid), D, nullptr, 0, Wst, buf, wreg, tid, wr, wc, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0, tid), D, nullptr, 0, wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -976,7 +951,6 @@ __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* At = smem;                  // [BM][TS]: x0
   float* Ht = smem + G::TILE;        // [BM][TS]: accumulator staging
-  float* Wst = smem + 2 * G::TILE;   // [2][D][RC_LS]
   int M = a.M;
   if (a.m_dev) M = min(M, *a.m_dev);
   const int m0 = blockIdx.x * G::BM;
@@ -986,7 +960,6 @@ __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a)
   const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_n = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
-  int buf = 0;
   rc_prime_load<D>(wreg, rc_wptr<D>(a.wn, D, 0, 0, tid), D);   // the first weight slice is in flight while the rows are gathered
   {
     const float4 gm = *(const float4*)(a.g0 + et * 4), bt = *(const float4*)(a.b0ln + et * 4);
@@ -1022,13 +995,12 @@ __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a)
       *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
   }
-  rc_prime_store<D>(wreg, rc_wptr<D>(a.wn, D, 0, 0, tid), D, nullptr, 0, Wst, tid);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.wn, D, 0, 0, tid), D);
   __syncthreads();
   const int nn = a.Nn / D;
   for (int c = 0; c < nn; ++c) {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wn, D, c * D, 0, tid), D, c + 1 < nn ? rc_wptr<D>(a.wn, D, (c + 1) * D, 0, tid) : nullptr, D, Wst, buf,
-               wreg, tid, wr, wc, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wn, D, c * D, 0, tid), D, c + 1 < nn ? rc_wptr<D>(a.wn, D, (c + 1) * D, 0, tid) : nullptr, D, wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
     __syncthreads();
     const float4 bs = *(const float4*)(a.bn + c * D + et * 4);
