@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of two builds on one box: the tree's library against unirec_amd/libunirec_amd.so.base (copied before the change)   usage: r3_ab2.sh [reps]
+# A/B of two builds on one box: the tree's library against unirec_amd/libunirec_amd.so.base (copied before the change)   usage: ab_build.sh [reps]
 reps=${1:-3}
 cp unirec_amd/libunirec_amd.so /tmp/new.so
 for rep in $(seq $reps); do
