@@ -643,10 +643,18 @@ def main():
     gc.disable()
     _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
     _lib.lib.ur_prof_reset()
-    n_first = a.warmup // 2            # the first warm-up steps carry one-time costs (code-object loads, workspace allocation):
-    n_prof = a.warmup - n_first        # the per-class breakdown is taken over the remaining ones
+    # The W warm-up steps: the first ones carry one-time costs (code-object loads, workspace allocation), the middle ones are bracketed
+    # class by class (HIP events around every launch: the per-class breakdown, and which class gets bracketed in the timed region),
+    # and the LAST ones run exactly as the timed steps do, right in front of the clock -- reading some hundred event pairs back is
+    # milliseconds of idle device right where the clock would start.  (What a short region still pays, and a long one amortises: one
+    # pipeline fill and drain -- the side stream's tail of the last step has no next step to hide under -- ~0.15 ms per region, and a
+    # slow ramp over the first ~20 steps after any synchronisation: 20 steps after 5 warm-ups 0.615-0.62 ms, after 50 warm-ups 0.60-0.61,
+    # 200 steps 0.596.)
+    n_tail = min(2, a.warmup // 2)
+    n_first = (a.warmup - n_tail) // 2
+    n_prof = a.warmup - n_tail - n_first
     loss = None
-    for i in range(a.warmup):
+    for i in range(n_first + n_prof):
         if i == n_first:
             _lib.lib.ur_prof_enable(0 if a.no_prof else 1)
         loss = step_fn(batches[i % len(batches)], batches[(i + 1) % len(batches)])
@@ -664,6 +672,8 @@ def main():
     _lib.lib.ur_prof_reset()
     if dom is not None:
         _lib.lib.ur_prof_set_mask(1 << names.index(dom))
+    for i in range(n_first + n_prof, a.warmup):     # the last warm-up steps: plain, no read-back behind them
+        loss = step_fn(batches[i % len(batches)], batches[(i + 1) % len(batches)])
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
