@@ -78,7 +78,7 @@ def test_sasrec_eight_layers_and_every_sequence_empty():
     _run("SASRec", dict(use_position_emb=False), 4, 6, 3, 30, seq_fn=lambda s: torch.cat([torch.zeros_like(s[:, :4]), s[:, 4:]], 1))
 
 
-@pytest.mark.parametrize("B,L,H", [(1, 1, 16), (2, 3, 32), (17, 5, 64), (3, 2, 128), (4, 4, 24)])
+@pytest.mark.parametrize("B,L,H", [(1, 1, 16), (2, 3, 32), (17, 5, 64), (3, 2, 128), (4, 4, 24), (5, 4, 384)])   # 384: the per-step path with its K dimension split (2 pieces forward, 6 backward)
 def test_gru_small_shapes_both_recurrence_paths(B, L, H):
     _run("GRU", dict(hidden_size=H, embedding_size=16), B, L, 3, 40)
 

@@ -206,6 +206,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   float* Ws = smem + 2 * BM * LS;   // [2][BN*LS]
 
   if (a.m_dev) a.M = min(a.M, *a.m_dev);   // compacted token rows: the row count lives on the device
+  if (a.ksplit > 1) {   // this grid row's piece of K: [kb, kb + ks), a multiple of BK long; its partial product goes to its own copy of C
+    const int ks = ((a.K + a.ksplit - 1) / a.ksplit + BK - 1) / BK * BK, kb = (int)blockIdx.y * ks;
+    a.A += kb; a.W += kb;
+    a.K = max(0, min(a.K - kb, ks));
+    a.C += (long long)blockIdx.y * a.split_stride;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
   // XCD-aware tile mapping: workgroup id b runs on XCD b % 8 (each XCD has its own L2).  All N-tiles of one M-tile are
@@ -325,7 +331,7 @@ static int launch_nt(const GemmArgs& a, hipStream_t st) {
   constexpr int LS = BK + 4;
   const long long nblk = 8LL * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN);
   if (nblk * 256 >= (1LL << 32)) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: %lld workgroups exceed HIP's 2^32-thread grid limit", nblk);
-  dim3 grid((unsigned)nblk);
+  dim3 grid((unsigned)nblk, (unsigned)(a.ksplit > 1 ? a.ksplit : 1));
   size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
   const size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
   if (cs > lds) lds = cs;
@@ -368,6 +374,8 @@ int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
   ProfScope ps(PC_GEMM_NT, st, 2.0 * a.M * a.N * a.K);
   if ((a.K & 3) || (a.N & 3) || (a.lda & 3) || (a.ldw & 3) || (epi != EPI_COUNT_GT && ((a.ldc & 3) || (a.aux && (a.ldaux & 3)) || (a.aux2 && (a.ldaux2 & 3)))))
     return fail(UR_ERR_ARG, "gemm_nt: N, K and all leading dimensions must be multiples of 4 (N=%d K=%d)", a.N, a.K);
+  if (a.ksplit > 1 && (epi != EPI_NONE || pro != PRO_NONE || a.m_dev || a.ksplit > 64))
+    return fail(UR_ERR_UNSUPPORTED, "gemm_nt: a split K dimension needs the plain epilogue (epi=%d pro=%d ksplit=%d)", epi, pro, a.ksplit);
   if (epi == EPI_BIAS_RES_LN) {
     if (a.N > 256 || a.ldc != a.N) return fail(UR_ERR_UNSUPPORTED, "gemm_nt: fused LayerNorm needs N<=256 (N=%d)", a.N);
     if (a.N <= 128 && (small_m(a) || a.m_dev))

@@ -32,9 +32,13 @@ static GruLayout gru_layout(const UrGruCfg& c) {
 struct GruWs {
   int* seq_tm;
   float *x, *gi, *gh, *h_all, *r, *z, *n, *hn;          // saved by forward
-  float *dh, *dh_carry, *dgi, *dgh, *dx_tm, *w_ihT, *w_hhT, *w_dT, *tn_ws, *tn_ws2;
+  float *dh, *dh_carry, *dh_parts, *dgi, *dgh, *dx_tm, *w_ihT, *w_hhT, *w_dT, *tn_ws, *tn_ws2;
   long long total_floats;
 };
+// pieces of the K dimension of a per-step GEMM (few rows, K = H forward / 3H backward): ~192 columns each, so that B / 32 x N / 128 x pieces
+// workgroups are several per CU (H = 768: 288 x 4 forward, 96 x 12 backward) instead of one walking the whole K loop alone
+static int gru_ksplit(long long K) { return (int)std::max(1LL, std::min(16LL, K / 192)); }
+
 static GruWs gru_carve(const UrGruCfg& c, float* base) {
   GruWs w;
   long long o = 0;
@@ -45,9 +49,9 @@ static GruWs gru_carve(const UrGruCfg& c, float* base) {
   };
   const long long B = c.B, L = c.L, d = c.d, H = c.H, M = B * L;
   w.seq_tm = (int*)take(M);
-  w.x = take(M * d); w.gi = take(M * 3 * H); w.gh = take(B * 3 * H); w.h_all = take((L + 1) * B * H);
+  w.x = take(M * d); w.gi = take(M * 3 * H); w.gh = take(gru_ksplit(H) * B * 3 * H); w.h_all = take((L + 1) * B * H);
   w.r = take(M * H); w.z = take(M * H); w.n = take(M * H); w.hn = take(M * H);
-  w.dh = take(B * H); w.dh_carry = take(B * H); w.dgi = take(M * 3 * H); w.dgh = take(M * 3 * H); w.dx_tm = take(M * d);
+  w.dh = take(B * H); w.dh_carry = take(B * H); w.dh_parts = take(gru_ksplit(3 * H) * B * H); w.dgi = take(M * 3 * H); w.dgh = take(M * 3 * H); w.dx_tm = take(M * d);
   w.w_ihT = take(3 * H * d); w.w_hhT = take(3 * H * H); w.w_dT = take(d * H);
   long long tn = gemm_tn_ws_floats((int)M, (int)(3 * H), (int)H);
   if (gemm_tn_ws_floats((int)M, (int)(3 * H), (int)d) > tn) tn = gemm_tn_ws_floats((int)M, (int)(3 * H), (int)d);
@@ -84,7 +88,9 @@ __global__ void rows_batch_major_kernel(const float4* __restrict__ src, int B, i
   dst[i] = src[(t * B + b) * d4 + c];
 }
 
-__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+// gh: S partial products [S][B][3H] of h_{t-1} W_hh^T (S = 1: the product itself), summed here in piece order, + b_hh
+__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh, int S,
+                                                           const float* __restrict__ b_hh,
                                                            const float* __restrict__ h_prev, int B, int H, float* __restrict__ h_out,
                                                            float* __restrict__ r_s, float* __restrict__ z_s, float* __restrict__ n_s,
                                                            float* __restrict__ hn_s) {
@@ -93,15 +99,21 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const float* __restri
   const int b = i / H, j = i % H;
   const float* gib = gi + (long long)b * 3 * H;
   const float* ghb = gh + (long long)b * 3 * H;
-  const float r = 1.0f / (1.0f + expf(-(gib[j] + ghb[j])));
-  const float z = 1.0f / (1.0f + expf(-(gib[H + j] + ghb[H + j])));
-  const float hn = ghb[2 * H + j];
+  const long long ps = (long long)B * 3 * H;
+  float ghr = ghb[j], ghz = ghb[H + j], ghn = ghb[2 * H + j];
+  for (int s = 1; s < S; ++s) { ghr += ghb[s * ps + j]; ghz += ghb[s * ps + H + j]; ghn += ghb[s * ps + 2 * H + j]; }
+  ghr += b_hh[j]; ghz += b_hh[H + j]; ghn += b_hh[2 * H + j];
+  const float r = 1.0f / (1.0f + expf(-(gib[j] + ghr)));
+  const float z = 1.0f / (1.0f + expf(-(gib[H + j] + ghz)));
+  const float hn = ghn;
   const float n = tanhf(gib[2 * H + j] + r * hn);
   h_out[i] = (1.0f - z) * n + z * h_prev[i];
   r_s[i] = r; z_s[i] = z; n_s[i] = n; hn_s[i] = hn;
 }
 
-__global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ r_s,
+// dh_t: dh (S = 0: the gradient that enters the sweep) or the S partial products [S][B][H] of dgh_{t+1} W_hh summed in piece order + the
+// carry dh_{t+1} z that the previous call left in dh_carry (read, then overwritten with this step's, by the same thread)
+__global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restrict__ dh, int S, const float* __restrict__ r_s,
                                                            const float* __restrict__ z_s, const float* __restrict__ n_s,
                                                            const float* __restrict__ hn_s, const float* __restrict__ h_prev, int B,
                                                            int H, float* __restrict__ dgi, float* __restrict__ dgh,
@@ -109,7 +121,12 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restri
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * H) return;
   const int b = i / H, j = i % H;
-  const float g = dh[i], r = r_s[i], z = z_s[i], n = n_s[i], hn = hn_s[i];
+  float g = dh[i];
+  if (S > 0) {
+    for (int s = 1; s < S; ++s) g += dh[(long long)s * B * H + i];
+    g += dh_carry[i];
+  }
+  const float r = r_s[i], z = z_s[i], n = n_s[i], hn = hn_s[i];
   const float dn = g * (1.0f - z);
   const float dz = g * (h_prev[i] - n);
   const float dan = dn * (1.0f - n * n);
@@ -512,11 +529,11 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
     const long long o = (long long)t * B * H;
     g = GemmArgs{};
     g.A = w.h_all + o; g.lda = H; g.W = dense + lay.w_hh; g.ldw = H; g.C = w.gh; g.ldc = 3 * H; g.M = B; g.N = 3 * H; g.K = H;
-    g.bias = dense + lay.b_hh;
-    if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
+    g.ksplit = gru_ksplit(H); g.split_stride = (long long)B * 3 * H;   // (the cell kernel sums the pieces and adds b_hh)
+    if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
     ProfScope ps(PC_GRU, st, 0);
     hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, st, w.gi + (long long)t * B * 3 * H, w.gh,
-                       w.h_all + o, B, H, w.h_all + o + (long long)B * H, w.r + o, w.z + o, w.n + o, w.hn + o);
+                       g.ksplit, dense + lay.b_hh, w.h_all + o, B, H, w.h_all + o + (long long)B * H, w.r + o, w.z + o, w.n + o, w.hn + o);
     UR_LAUNCH_CHECK();
   }
   g = GemmArgs{};
@@ -566,14 +583,16 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
     const long long o = (long long)t * B * H, o3 = (long long)t * B * 3 * H;
     {
       ProfScope ps(PC_GRU, st, 0);
-      hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, st, w.dh, w.r + o, w.z + o, w.n + o,
-                         w.hn + o, w.h_all + o, B, H, w.dgi + o3, w.dgh + o3, w.dh_carry);
+      const bool first = t == L - 1;   // (the first step of the sweep reads the head's gradient; the others the pieces of the step before)
+      hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, st, first ? w.dh : w.dh_parts,
+                         first ? 0 : gru_ksplit(3 * H), w.r + o, w.z + o, w.n + o, w.hn + o, w.h_all + o, B, H, w.dgi + o3, w.dgh + o3, w.dh_carry);
       UR_LAUNCH_CHECK();
     }
-    g = GemmArgs{};   // dh_{t-1} = dgh_t W_hh + dh_t * z
-    g.A = w.dgh + o3; g.lda = 3 * H; g.W = w.w_hhT; g.ldw = 3 * H; g.C = w.dh; g.ldc = H; g.M = B; g.N = H; g.K = 3 * H;
-    g.aux = w.dh_carry; g.ldaux = H;
-    if ((rc = gemm_nt(g, PRO_NONE, EPI_ADD, st))) return rc;
+    if (t == 0) break;   // (dh_{-1} has no reader: h_0 = 0)
+    g = GemmArgs{};   // the pieces of dgh_t W_hh; dh_{t-1} = their sum + dh_t * z is formed by the next cell kernel
+    g.A = w.dgh + o3; g.lda = 3 * H; g.W = w.w_hhT; g.ldw = 3 * H; g.C = w.dh_parts; g.ldc = H; g.M = B; g.N = H; g.K = 3 * H;
+    g.ksplit = gru_ksplit(3 * H); g.split_stride = (long long)B * H;
+    if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
   }
   // weight gradients over all (t, b) tokens at once (time-major rows on both operands)
   {   // (one grouped launch: dW_hh and dW_ih share the token dimension)

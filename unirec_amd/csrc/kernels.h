@@ -81,6 +81,10 @@ struct GemmArgs {
   // out_rows[m] of C; ln_part [gemm_nt_lnbwd_tiles(M)][2 N] receives the partial sums (every slot is written); M_host = the M
   // the grid was sized for (set by gemm_nt)
   const int* out_rows; float* ln_part; int M_host;
+  // ksplit > 1 (EPI_NONE only): the K dimension is cut into ksplit pieces, piece s is one grid row and writes ITS partial product to
+  // C + s * split_stride; the consumer sums the pieces in order.  For few-row, long-K products (the GRU's per-step GEMMs at H = 768:
+  // one workgroup per CU walking 24-72 dependent K-steps) this is what puts several workgroups on a CU.
+  int ksplit; long long split_stride;
 };
 int gemm_nt_lnbwd_tiles(int M);   // M-tiles (= partial-sum rows) of an EPI_ADD_LNBWD launch over M rows
 int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st);
