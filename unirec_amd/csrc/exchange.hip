@@ -161,13 +161,18 @@ Comm g_comm;
   } while (0)
 
 // equal-split all-to-all: `bytes` per peer, block p of `send` -> rank p, block p of `recv` <- rank p
-static int a2a_bytes(const void* send, void* recv, size_t bytes, hipStream_t st) {
+// RCCL runs the operations of ONE communicator in the order they were issued, whatever streams they are on (every launch waits for the
+// communicator's previous one).  The id exchange of the NEXT batch is issued first in a step, on the plan stream, behind that batch's id
+// sort: on the row communicator it would hold this step's row exchange -- issued later, on the main stream -- until the sort is done.
+// It therefore goes through the SECOND communicator (the dense all-reduce's: that one is issued at the end of the step and waits for an
+// id exchange that finished long before); rows and row gradients keep the first to themselves.
+static int a2a_bytes(const void* send, void* recv, size_t bytes, hipStream_t st, ncclComm_t comm) {
   Rccl* r = rccl();
   const int W = g_comm.world;
   UR_NCCL(r->GroupStart());
   for (int p = 0; p < W; ++p) {
-    UR_NCCL(r->Send((const char*)send + (size_t)p * bytes, bytes, ncclInt8, p, g_comm.comm, st));
-    UR_NCCL(r->Recv((char*)recv + (size_t)p * bytes, bytes, ncclInt8, p, g_comm.comm, st));
+    UR_NCCL(r->Send((const char*)send + (size_t)p * bytes, bytes, ncclInt8, p, comm, st));
+    UR_NCCL(r->Recv((char*)recv + (size_t)p * bytes, bytes, ncclInt8, p, comm, st));
   }
   UR_NCCL(r->GroupEnd());
   return UR_OK;
@@ -239,7 +244,7 @@ extern "C" int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_u
   if (!transport) return UR_OK;
   UR_REQUIRE(recv_ids, UR_ERR_ARG, "ur_shard_exchange_ids: null receive buffer");
   UR_REQUIRE(g_comm.comm && g_comm.world == world, UR_ERR_ARG, "ur_shard_exchange_ids: communicator of %d ranks, world=%d", g_comm.world, world);
-  return a2a_bytes(send_ids, recv_ids, (size_t)cap * sizeof(int32_t), st);
+  return a2a_bytes(send_ids, recv_ids, (size_t)cap * sizeof(int32_t), st, g_comm.comm2);
 }
 
 // (2) rows: gather the requested rows of this rank's shard (req_ids: world * cap local rows, as received) into rows_ws, then
@@ -253,7 +258,7 @@ extern "C" int ur_shard_exchange_rows(const float* table, const int32_t* req_ids
   if (rc || !transport) return rc;
   UR_REQUIRE(compact, UR_ERR_ARG, "ur_shard_exchange_rows: null receive buffer");
   UR_REQUIRE(g_comm.comm && g_comm.world == world, UR_ERR_ARG, "ur_shard_exchange_rows: communicator of %d ranks, world=%d", g_comm.world, world);
-  return a2a_bytes(rows_ws, compact, (size_t)cap * d * sizeof(float), st);
+  return a2a_bytes(rows_ws, compact, (size_t)cap * d * sizeof(float), st, g_comm.comm);
 }
 
 // (3) row gradients: uniq_grad [n_uniq, d] (unique order, from ur_rows_reduce) -> slot layout (padding slots: zeros) in send_ws, then
@@ -277,7 +282,7 @@ extern "C" int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_
   if (!transport) return UR_OK;
   UR_REQUIRE(grads_in, UR_ERR_ARG, "ur_shard_exchange_grads: null receive buffer");
   UR_REQUIRE(g_comm.comm && g_comm.world == world, UR_ERR_ARG, "ur_shard_exchange_grads: communicator of %d ranks, world=%d", g_comm.world, world);
-  return a2a_bytes(send_ws, grads_in, (size_t)cap * d * sizeof(float), st);
+  return a2a_bytes(send_ws, grads_in, (size_t)cap * d * sizeof(float), st, g_comm.comm);
 }
 
 // after (3): the flags every rank put into slot 0 of its blocks -> out4 = [gradient scale (1 / world, or -1 = skip the step), mean loss,
