@@ -156,6 +156,10 @@ struct ChainBwdArgs {
   int I, act;
   float* split_part = nullptr;          // chain_ffn_bwd_split: [row blocks][I/d][rows per block][d] partial d a tiles
   unsigned* split_cnt = nullptr;        //   and one completion counter per row block (zero on entry, reset by the kernel)
+  // hidden dropout (chain_ffn_bwd only; thresh == 0: off): the masks of the forward pass's two sites.  The residual branches take the
+  // unmasked g_tf / g_ta; the GEMMs (and the weight-gradient products) take the masked copies, written to g_tfd / g_tad
+  DropSpec drop_ffn = {}, drop_out = {};
+  float *g_tfd = nullptr, *g_tad = nullptr;
 };
 struct ChainProjBwdArgs {
   const float* g; int ldg; int K;       // [M, K] gradient of the projection output; K % d == 0
@@ -165,6 +169,7 @@ struct ChainProjBwdArgs {
   float* out; const int* out_rows;      // row m of the result goes to row out_rows[m] (nullable: m) of out [., d]
   float* part;                          // with LayerNorm: [workgroups][2 d] d gamma | d beta partial sums
   int M; const int* m_dev;
+  DropSpec drop = {};                   // with LayerNorm: x0 = dropout(LN0(.)) -- the result is masked before the LayerNorm backward (thresh 0: off)
 };
 struct ChainEmbedArgs {
   const int* seq;                       // [B*L] item ids of the padded token grid

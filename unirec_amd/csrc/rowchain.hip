@@ -633,6 +633,10 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
         const float4 h = *(const float4*)(a.yhat + (long long)m * D + et * 4);
         o = rc_ln_bwd_row<G::TPR>(y, h, gm, a.rstd2[m], inv_d, dg, db);
         *(float4*)(a.g_tf + (long long)m * D + et * 4) = o;
+        if (a.drop_ffn.thresh) {   // the feed-forward branch sees the masked gradient (the residual branch, below, the one just stored)
+          o = drop4(o, drop_rowkey(a.drop_ffn, m), (unsigned)(et * 4), a.drop_ffn);
+          *(float4*)(a.g_tfd + (long long)m * D + et * 4) = o;
+        }
       }
       *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
@@ -691,11 +695,16 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M) {
         float4 y = *(const float4*)(Ht + rc_toff<D>(ml, et));
-        const float4 rs = *(const float4*)(At + rc_toff<D>(ml, et));
+        // (hidden dropout: the tile holds the MASKED g_tf; the unmasked one is what this thread stored in phase 0)
+        const float4 rs = a.drop_ffn.thresh ? *(const float4*)(a.g_tf + (long long)m * D + et * 4) : *(const float4*)(At + rc_toff<D>(ml, et));
         y.x += rs.x; y.y += rs.y; y.z += rs.z; y.w += rs.w;
         const float4 h = *(const float4*)(a.ahat + (long long)m * D + et * 4);
         o = rc_ln_bwd_row<G::TPR>(y, h, gm, a.rstd1[m], inv_d, dg, db);
         *(float4*)(a.g_ta + (long long)m * D + et * 4) = o;
+        if (a.drop_out.thresh) {
+          o = drop4(o, drop_rowkey(a.drop_out, m), (unsigned)(et * 4), a.drop_out);
+          *(float4*)(a.g_tad + (long long)m * D + et * 4) = o;
+        }
       }
       *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
@@ -783,6 +792,7 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
         v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
       }
       if (a.xhat) {
+        if (a.drop.thresh) v = drop4(v, drop_rowkey(a.drop, m), (unsigned)(et * 4), a.drop);   // (the embedding dropout's mask)
         const float4 h = *(const float4*)(a.xhat + (long long)m * D + et * 4);
         v = rc_ln_bwd_row<G::TPR>(v, h, gm, a.rstd[m], inv_d, dg, db);
       }
@@ -831,6 +841,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
     q_rstd1[p] = a.rstd1[m];
   }
   // ---- 0. feed-forward LayerNorm backward (every chunk's workgroup; chunk 0 writes)
+  float4 gtf_keep[4];   // hidden dropout: the UNMASKED g_tf of this thread's rows (the residual branch of phase 3; the tile holds the masked one)
   {
     const float4 gm = *(const float4*)(a.g2 + et * 4);
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
@@ -843,6 +854,11 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
         const float4 h = *(const float4*)(a.yhat + (long long)m * D + et * 4);
         o = rc_ln_bwd_row<G::TPR>(y, h, gm, a.rstd2[m], inv_d, dg, db);
         if (c == 0) *(float4*)(a.g_tf + (long long)m * D + et * 4) = o;
+      }
+      gtf_keep[p] = o;
+      if (a.drop_ffn.thresh && m < M) {
+        o = drop4(o, drop_rowkey(a.drop_ffn, m), (unsigned)(et * 4), a.drop_ffn);
+        if (c == 0) *(float4*)(a.g_tfd + (long long)m * D + et * 4) = o;
       }
       *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
@@ -915,11 +931,15 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M) {
         float4 y = ys[p];
-        const float4 rs = *(const float4*)(At + rc_toff<D>(ml, et));
+        const float4 rs = gtf_keep[p];
         y.x += rs.x; y.y += rs.y; y.z += rs.z; y.w += rs.w;
         const float4 h = q_ahat[p];
         o = rc_ln_bwd_row<G::TPR>(y, h, gm, q_rstd1[p], inv_d, dg, db);
         *(float4*)(a.g_ta + (long long)m * D + et * 4) = o;
+        if (a.drop_out.thresh) {
+          o = drop4(o, drop_rowkey(a.drop_out, m), (unsigned)(et * 4), a.drop_out);
+          *(float4*)(a.g_tad + (long long)m * D + et * 4) = o;
+        }
       }
       *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }

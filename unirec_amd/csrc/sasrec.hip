@@ -501,9 +501,9 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   const int* spad = compact ? w.seq_pad : nullptr;
   // row-chain kernels (rowchain.hip) for the full-sequence layers; hidden dropout keeps the unfused path (the chain backward
   // does not carry the second, dropout-masked copy of the LayerNorm-backward outputs)
-  const bool chain_bwd = chain_supported(d, I, CHAIN_BWD) && c.p_hidden == 0.f;
-  const bool chain_proj = chain_supported(d, I, CHAIN_PROJ) && c.p_hidden == 0.f;
-  const bool chain_last_bwd = chain_supported(d, I, CHAIN_LAST_BWD) && c.p_hidden == 0.f;
+  const bool chain_bwd = chain_supported(d, I, CHAIN_BWD);   // (hidden dropout: the masks are re-evaluated in the kernel)
+  const bool chain_proj = chain_supported(d, I, CHAIN_PROJ);
+  const bool chain_last_bwd = chain_supported(d, I, CHAIN_LAST_BWD);
   bool ln0_done = false;                // the embedding LayerNorm backward already ran in the epilogue of the bottom layer's last GEMM
   // LayerNorm backward in the epilogue of the GEMM that produces its input gradient (EPI_ADD_LNBWD): the attention block's
   // LayerNorm behind the d FFN-1 GEMM, the embedding LayerNorm behind the bottom layer's projection-gradient GEMM.  Two launches and
@@ -634,6 +634,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       float* part0 = w.chain_part + 4LL * c.n_layers * w.chain_blocks * d;
       cp.xhat = w.x0hat; cp.rstd = w.rstd0; cp.gamma = dense + lay.off[1]; cp.out = d_emb_rows; cp.out_rows = compact ? w.tok_full : nullptr;
       cp.part = part0;
+      cp.drop = site_spec(c, 0, DROP_SITE_EMBED, compact ? w.tok_full : nullptr);   // (x0 = dropout(LN0(.)): masked before the LayerNorm backward)
       if (rb.full(2)) {
         int rc2 = reduce_batch(rb, st);
         if (rc2) return rc2;
@@ -693,6 +694,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
         cb.ahat = lw.ahat; cb.rstd1 = lw.rstd1; cb.g1 = p.g1; cb.woT = lw.woT;
         cb.g_tf = lw.g_tf; cb.g_h1 = lw.g_h1; cb.g_ta = lw.g_ta; cb.g_ctx = w.g_ctx; cb.part = part;
         cb.M = B; cb.I = I; cb.act = c.act;
+        cb.drop_ffn = d_ffn; cb.drop_out = d_out; cb.g_tfd = lw.g_tfd; cb.g_tad = lw.g_tad;
         if (I / d >= 2 && nblk <= CHAIN_SPLIT_MAX_BLOCKS) {   // inner split over workgroups (see chain_ffn_fwd_split)
           cb.split_part = w.split_part + chain_split_part_floats(B, d, I);
           if ((rc = chain_ffn_bwd_split(cb, d, st))) return rc;
@@ -702,9 +704,9 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
         rb.add(part + d, 4 * d, nblk, d, d, G + o[15], d);
         rb.add(part + 2 * d, 4 * d, nblk, d, d, G + o[8], d);
         rb.add(part + 3 * d, 4 * d, nblk, d, d, G + o[9], d);
-        if ((rc = tn(lw.g_tf, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
+        if ((rc = tn(lw.g_tfd, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
         if ((rc = tn(lw.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
-        if ((rc = tn(lw.g_ta, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
+        if ((rc = tn(lw.g_tad, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
       } else {
       if ((rc = ln_bwd(d_user_emb, lw.yhat, lw.rstd2, p.g2, nullptr, nullptr, B, d, lw.g_tf, G + o[14], G + o[15], ln_take(), st, &rb,
                        nullptr, nullptr, nullptr, &d_ffn, lw.g_tfd)))
@@ -764,15 +766,16 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       cb.ahat = lw.ahat; cb.rstd1 = lw.rstd1; cb.g1 = p.g1; cb.woT = lw.woT;
       cb.g_tf = lw.g_tf; cb.g_h1 = lw.g_h1; cb.g_ta = lw.g_ta; cb.g_ctx = w.g_ctx; cb.part = part;
       cb.M = M; cb.m_dev = mv; cb.I = I; cb.act = c.act;
+      cb.drop_ffn = d_ffn; cb.drop_out = d_out; cb.g_tfd = lw.g_tfd; cb.g_tad = lw.g_tad;
       if ((rc = chain_ffn_bwd(cb, d, st))) return rc;
       if (rb.full(4) && (rc = reduce_batch(rb, st))) return rc;
       rb.add(part, 4 * d, nblk, d, d, G + o[14], d);
       rb.add(part + d, 4 * d, nblk, d, d, G + o[15], d);
       rb.add(part + 2 * d, 4 * d, nblk, d, d, G + o[8], d);
       rb.add(part + 3 * d, 4 * d, nblk, d, d, G + o[9], d);
-      if ((rc = tn(lw.g_tf, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;   // (the activation is applied to h1 on the operand)
+      if ((rc = tn(lw.g_tfd, d, lw.h1, I, M, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;   // (the activation is applied to h1 on the operand)
       if ((rc = tn(lw.g_h1, I, lw.a, d, M, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
-      if ((rc = tn(lw.g_ta, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
+      if ((rc = tn(lw.g_tad, d, lw.ctx, d, M, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
       // (dW_2, dW_1, dW_o wait for dW_qkv: one launch BEHIND the attention backward, see the unfused path below)
       if ((rc = attn_bwd(lw.qkv, item_seq, lw.ctx, w.g_ctx, lw.lse, c.B, c.L, d, c.n_heads, c.use_pos, lw.g_qkv, w.attn_ws, 0, st, sbase, spad, &d_attn))) return rc;
       if ((rc = tn(lw.g_qkv, 3 * d, x_in, d, M, 3 * d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
