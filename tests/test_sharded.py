@@ -321,7 +321,10 @@ def test_sharded_optimizer_world1_equals_plain_path(kind):
         m1.join_side_updates()
         o1.flush(), o2.flush()
         assert o1.n_overflow == 0
-        np.testing.assert_allclose(m1.dense_flat.data.cpu().numpy(), m2.dense_flat.data.cpu().numpy(), rtol=1e-6, atol=1e-8)
+        # (bit-identical without clipping; WITH it the two paths sum the squared gradient norm in different orders -- owners' rows + one
+        # flat all-reduce against one pass -- so the clip coefficient, and with it every update, differs by an ulp: 1e-7 relative, and
+        # on an element that is ~0, 1e-8 absolute)
+        np.testing.assert_allclose(m1.dense_flat.data.cpu().numpy(), m2.dense_flat.data.cpu().numpy(), rtol=1e-6, atol=3e-8)
         # (the lazy replay of a row's missed steps is summed in two pieces when the tail catch-up ran: a few ulp of an lr-sized term)
         np.testing.assert_allclose(m1.item_embedding.weight.detach().cpu().numpy(), m2.item_embedding.weight.detach().cpu().numpy(),
                                    rtol=1e-5, atol=1e-7)
