@@ -131,6 +131,16 @@ def test_fit_with_the_device_resident_input_pipeline():
         assert not (set(ids[b, 1:].tolist()) - {0}) & set(u2h[uid[b]].tolist())      # negatives avoid the history
         nz = np.flatnonzero(seq[b])
         assert len(nz) == 0 or (nz == np.arange(L - len(nz), L)).all()               # left padded
+    # the builds run two batches ahead on the loader's own stream: every batch == what an in-line build of the same (epoch, index) gives
+    loader.epoch = 0
+    ahead = [{k: v.clone() for k, v in b.items()} for b in loader]
+    torch.cuda.synchronize()
+    g = torch.Generator(device="cuda:0").manual_seed(6 + 0)
+    order = torch.randperm(len(pairs), generator=g, device="cuda:0")
+    assert len(ahead) == len(loader) == (len(pairs) + 127) // 128
+    for k, b in enumerate(ahead):
+        ref = loader._build(order, k, 0)
+        assert all(torch.equal(b[key], ref[key]) for key in ref), k
     loader.epoch = 0
     tr = Trainer(cfg, model)
     tr.fit(loader, save_model=False)
