@@ -35,7 +35,7 @@ def test_gru_per_step_path_and_sorting_owner_plan():
 
 
 def test_inline_weight_gradients():
-    """UR_SASREC_SIDE=0: no side stream -- the weight-gradient launches run in line on the caller's stream (what > 2 layers do anyway)"""
+    """UR_SASREC_SIDE=0: no side stream -- the weight-gradient launches run in line on the caller's stream (what more than 6 layers do anyway)"""
     _run({"UR_SASREC_SIDE": "0"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden"], expect_min_passed=20)
 
 

@@ -670,17 +670,20 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceBatch rb) {
   }
 }
 
-int reduce_batch(ReduceBatch& rb, hipStream_t st) {
-  if (rb.n <= 0) return UR_OK;
-  ProfScope ps(PC_GEMM_TN, st, 0.0);
-  int blocks = 0;
-  for (int i = 0; i < rb.n; ++i) {
-    rb.item[i].first_block = blocks;
-    blocks += cdiv(rb.item[i].n / 4, 16);
+int reduce_batch(ReduceBatch& rb0, hipStream_t st) {
+  for (ReduceBatch* b = &rb0; b; b = b->next) {
+    ReduceBatch& rb = *b;
+    if (rb.n <= 0) continue;
+    ProfScope ps(PC_GEMM_TN, st, 0.0);
+    int blocks = 0;
+    for (int i = 0; i < rb.n; ++i) {
+      rb.item[i].first_block = blocks;
+      blocks += cdiv(rb.item[i].n / 4, 16);
+    }
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, rb);
+    UR_LAUNCH_CHECK();
+    rb.n = 0;
   }
-  hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, rb);
-  UR_LAUNCH_CHECK();
-  rb.n = 0;
   return UR_OK;
 }
 

@@ -31,12 +31,21 @@ struct ReduceItem {
 struct ReduceBatch {
   static constexpr int MAX = 48;
   ReduceItem item[MAX]; int n = 0;
-  bool full(int need) const { return n + need > MAX; }
+  // host side only: a batch that is full goes on in `next` (one launch per link at the end).  A backward pass whose reductions are
+  // deferred to the side stream must not flush in the middle of the pass -- deeper models (> 2 layers: > 48 items) chain batches.
+  ReduceBatch* next = nullptr;
+  bool full(int need) const {
+    int room = 0;
+    for (const ReduceBatch* b = this; b; b = b->next) room += MAX - b->n;
+    return room < need;
+  }
   void add(const float* part, long long stride, int S, long long n_el, int cols, float* out, int ldo) {
-    item[n++] = ReduceItem{part, out, stride, n_el, S, cols, ldo, 0};
+    ReduceBatch* b = this;
+    while (b->n >= MAX && b->next) b = b->next;
+    b->item[b->n++] = ReduceItem{part, out, stride, n_el, S, cols, ldo, 0};
   }
 };
-int reduce_batch(ReduceBatch& rb, hipStream_t st);   // runs and empties the queue
+int reduce_batch(ReduceBatch& rb, hipStream_t st);   // runs and empties the queue (every link of the chain)
 
 // defer != nullptr: part_ws must stay untouched until reduce_batch(*defer) has run
 // m_dev (nullable): device-side row count (M is then the maximum); out_rows (nullable): dx row r is written to row

@@ -510,7 +510,8 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   // two [M, d] round trips less per full layer.  Not with hidden dropout (a second, masked copy of the result would be needed).
   const bool lnfuse = c.p_hidden == 0.f && d <= 128;
   auto lnfuse_part = [&](int slot) { return w.chain_part + (long long)slot * 4 * w.chain_blocks * d; };   // slot n_layers: LN0
-  ReduceBatch rb;                       // second stages of all split reductions: one launch at the end
+  ReduceBatch rb, rb_more[3];           // second stages of all split reductions: launched at the end (4 x 48 items: ~10 layers)
+  rb.next = &rb_more[0]; rb_more[0].next = &rb_more[1]; rb_more[1].next = &rb_more[2];
   float* tn_cur = w.tn_ws;
   float* ln_cur = w.ln_part;
   auto tn_take = [&](int T_, int R_, int C_) {
@@ -528,7 +529,8 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   // this pass's last GEMM yet -- seen as a loss that differed in the 6th digit in 3 of 14 runs.
   const int* mv_side = mv ? w.m_valid + 16 : nullptr;
   // weight-gradient GEMM, forked onto the side stream (its inputs are complete at this point of the main stream)
-  SideCtx* sc = (c.n_layers <= 2) ? side_ctx() : nullptr;   // the queue of deferred reductions must not flush mid-pass
+  // (the queue of deferred reductions must not flush mid-pass: it chains batches instead; up to 24 forks have an event of their own)
+  SideCtx* sc = (c.n_layers <= 6) ? side_ctx() : nullptr;
   int n_fork = 0;
   struct PendingTn { const float *P, *Q; int ldp, ldq, T, R, C, pro_act, act, ldo; float *out, *bias_out, *ws; const int* t_dev; };
   PendingTn pend[12];
