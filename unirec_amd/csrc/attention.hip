@@ -1077,15 +1077,44 @@ __global__ __launch_bounds__(256) void attn_fwd_m16_kernel(const float* __restri
   seq_rows(p, b, row0, pad);
   const float* __restrict__ base = qkv + row0 * ld + h * HD;
   const int* __restrict__ sq = seq + (long long)b * L;
-  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
-  const bool literal = fv >= L;
-  const bool causal = p.causal && !literal;
   const int kend = L, kstage = L;
   float* ks = smem_m16;                                      // [L][LDK]
   float* vs = ks + L * LDK;                                  // [L][LDK]
   float* kvalid = vs + L * LDK;                              // [L] 1 = key may be attended
+  // A workgroup lives for a few microseconds, most of them round trips to memory: ids -> first valid key -> K / V rows -> barrier ->
+  // query fragment were FOUR dependent trips.  Everything the workgroup reads is requested here, before the first wait: the query
+  // fragment of the wave's first tile, the first 256 K / V rows (thread = row), their ids, and the ids first_valid_key looks at.
+  float qf0[KS];
+  {
+    const int irow = max(min(w * 16 + c16, L - 1), pad);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf0[s] = base[(long long)irow * ld + kq * KS + s];
+  }
+  float4 k0[HD / 4], v0[HD / 4];
+  const int j_first = min((int)threadIdx.x, kstage - 1);
+  {
+    const float* src = base + (long long)max(j_first, pad) * ld;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      k0[c / 4] = *(const float4*)(src + p.d + c);
+      v0[c / 4] = *(const float4*)(src + 2 * p.d + c);
+    }
+  }
+  const int sq0 = sq[j_first];
+  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
+  const bool literal = fv >= L;
+  const bool causal = p.causal && !literal;
   // ---- stage K, V rows [0, kstage) and the key mask (thread = row, 16-byte copies)
-  for (int j = threadIdx.x; j < kstage; j += 256) {
+  if ((int)threadIdx.x < kstage) {
+    const int j = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      *(float4*)(ks + j * LDK + c) = k0[c / 4];
+      *(float4*)(vs + j * LDK + c) = v0[c / 4];
+    }
+    kvalid[j] = (literal || sq0 > 0) ? 1.f : 0.f;
+  }
+  for (int j = threadIdx.x + 256; j < kstage; j += 256) {
     const float* src = base + (long long)max(j, pad) * ld;
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
@@ -1103,7 +1132,11 @@ __global__ __launch_bounds__(256) void attn_fwd_m16_kernel(const float* __restri
     const int irow = max(min(i, L - 1), pad);
     float qf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = base[(long long)irow * ld + kq * KS + s];
+    for (int s = 0; s < KS; ++s) qf[s] = qf0[s];
+    if (it != w) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) qf[s] = base[(long long)irow * ld + kq * KS + s];
+    }
     const unsigned rk = attn_rowkey(p, b, h, min(i, L - 1));
     float m = -INFINITY, l = 0.f;
     floatx4 oa = {0.f, 0.f, 0.f, 0.f};
