@@ -55,11 +55,22 @@ def build(verbose=True, force=False):
                     print(f"[{name}]\n{out}")
                 if rc != 0:
                     raise RuntimeError(f"hipcc failed on {name}:\n{out}")
-    if jobs or force or not os.path.exists(LIB):
+    # relink whenever the library on disk was not linked from exactly these objects (e.g. a .so copied in from another build)
+    stamp = os.path.join(OBJ, "link.stamp")
+    want = hashlib.sha256(" ".join(os.path.basename(o) for o in objs).encode()).hexdigest()
+    have = None
+    if os.path.exists(stamp) and os.path.exists(LIB):
+        with open(stamp) as f:
+            tag, _, mtime = f.read().partition(" ")
+        if mtime == repr(os.path.getmtime(LIB)):
+            have = tag
+    if jobs or force or have != want:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        with open(stamp, "w") as f:
+            f.write(want + " " + repr(os.path.getmtime(LIB)))
     if verbose:
         print(f"built {LIB} ({len(jobs)} objects recompiled)")
     return LIB
