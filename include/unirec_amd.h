@@ -200,7 +200,10 @@ int ur_sasrec_set_side_stream(int on);
  * three activation-gradient GEMMs) as one launch; bit 4: the input-gradient GEMM of the projection with the embedding LayerNorm's backward
  * in its epilogue as a chain launch; bits 8 / 16: the B last rows of the last-row layer (last_only) go through the same forward /
  * backward chain kernels instead of three / four small GEMM launches; bit 32: the embedding lookup + position + LayerNorm
- * (unirec/model/sequential/sasrec.py:60-69) and the first layer's Q/K/V projection as one launch.  Same K order as the stand-alone GEMMs.  Returns the previous mask.  The default mask and the
+ * (unirec/model/sequential/sasrec.py:60-69) and the first layer's Q/K/V projection as one launch; bit 64 (csrc/lastrow.hip; wins over
+ * bits 8 / 16; d in {64, 128}, head dim 4 / 8 / 16, 8 <= L <= 64, inner_size 256 / 512): the WHOLE last-row layer as two launches --
+ * query projection, one-query attention, out-projection, feed-forward for the B last rows (unirec/model/modules.py:284-316, 347-355,
+ * row L-1 only: unirec/model/sequential/sasrec.py:75), and their mirror image including the layer's full input gradient.  Returns the previous mask.  The default mask and the
  * measurements behind it: DESIGN.md section 6d; environment UR_SASREC_CHAIN=<mask>. */
 int ur_sasrec_set_chain(int mask);
 

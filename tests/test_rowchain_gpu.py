@@ -18,7 +18,7 @@ def _run(cfg_kw, B, seed, chain, train_drop=0.0):
     dev = torch.device("cuda:0")
     d, L, I, H, nl = cfg_kw["d"], cfg_kw["L"], cfg_kw["inner"], cfg_kw["heads"], cfg_kw["layers"]
     N = 5000
-    prev = _lib.lib.ur_sasrec_set_chain(int(chain) if not isinstance(chain, bool) else (63 if chain else 0))   # bit mask: 1 fwd, 2 bwd, 4 projection, 8 / 16 fwd / bwd of the last-row layer, 32 input block
+    prev = _lib.lib.ur_sasrec_set_chain(int(chain) if not isinstance(chain, bool) else (127 if chain else 0))   # bit mask: 1 fwd, 2 bwd, 4 projection, 8 / 16 fwd / bwd of the last-row layer (row-chain kernels), 32 input block, 64 the last-row layer as two launches (lastrow.hip)
     try:
         cfg = ops.sasrec_cfg(B, L, d, H, I, nl, cfg_kw.get("act", "swish"), True, 1e-10, last_only=cfg_kw.get("last_only", 1),
                              skip_padding=cfg_kw.get("skip_padding", 1), p_hidden=train_drop, p_attn=0.0, drop_seed=7, drop_step=3)
@@ -84,7 +84,7 @@ def test_chain_equals_unfused(kw, B):
             _close(a, b, 3e-4, f"param {j}")   # B = 1: a few dozen rows, rounding differences of the activations are not averaged out
 
 
-@pytest.mark.parametrize("mask", [1, 2, 4, 5, 8, 16, 24, 25, 32, 57])
+@pytest.mark.parametrize("mask", [1, 2, 4, 5, 8, 16, 24, 25, 32, 57, 64, 65, 103, 63])
 def test_chain_phases_are_independent_switches(mask):
     """forward / backward / projection-gradient chains and the last-row layer's two can be switched on one by one (ur_sasrec_set_chain bit mask)"""
     kw = dict(d=128, L=50, inner=512, heads=16, layers=2)

@@ -40,9 +40,18 @@ int fail(int code, const char* fmt, ...);
 // kernel's own completion signal instead: nothing is inserted.  A caller arms `g_stop_event` right before calling a helper whose LAST
 // launch goes through UR_LAUNCH_EV; that launch consumes it (other launches of the helper leave it alone).
 extern thread_local hipEvent_t g_stop_event;
+// The profiler's kernel-bound brackets (ProfScope with kernel_events): the next UR_LAUNCH_EV launch carries the scope's two events as ITS
+// start / completion timestamps -- the dispatch's own begin and end, not the stream's: an event RECORDED in front of a kernel is stamped
+// when the stream gets there, so a cross-stream wait queued between the record and the kernel (the forward pass's late join of the side
+// stream, a fork's wait) was counted as kernel time (round 3: the row-chain class read 361 us / step where the kernel trace said 259).
+extern thread_local hipEvent_t g_prof_start, g_prof_stop;
 #define UR_LAUNCH_EV(kernel, grid, block, lds, st, ...)                                        \
   do {                                                                                       \
-    if (::ur::g_stop_event) {                                                                \
+    if (::ur::g_prof_start) {                                                                \
+      hipEvent_t ea_ = ::ur::g_prof_start, eb_ = ::ur::g_prof_stop;                          \
+      ::ur::g_prof_start = nullptr; ::ur::g_prof_stop = nullptr;                             \
+      hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), st, ea_, eb_, 0, __VA_ARGS__); \
+    } else if (::ur::g_stop_event) {                                                         \
       hipEvent_t ev_ = ::ur::g_stop_event;                                                   \
       ::ur::g_stop_event = nullptr;                                                          \
       hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), st, nullptr, ev_, 0, __VA_ARGS__); \
@@ -56,8 +65,9 @@ enum ProfClass { PC_GEMM_NT = 0, PC_GEMM_TN, PC_ATTN_FWD, PC_ATTN_BWD, PC_ROWOPS
                  PC_GRU, PC_CHAIN, PC_CHAIN_SMALL, PC_MISC, PC_COUNT };
 bool prof_brackets(int cls);   // launches of this class are being bracketed with events right now
 struct ProfScope {
-  int cls; hipStream_t st; int slot;
-  ProfScope(int cls_, hipStream_t st_, double work = 0.0);
+  int cls; hipStream_t st; int slot; bool kernel_events;
+  // kernel_events: the scope holds exactly ONE launch and that launch goes through UR_LAUNCH_EV -- its own start / end timestamps are the bracket
+  ProfScope(int cls_, hipStream_t st_, double work = 0.0, bool kernel_events_ = false);
   ~ProfScope();
 };
 

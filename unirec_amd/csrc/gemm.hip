@@ -371,7 +371,7 @@ int gemm_nt_lnbwd_tiles(int M) { return cdiv(M, 32); }
 
 int gemm_nt(const GemmArgs& a, int pro, int epi, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return UR_OK;
-  ProfScope ps(PC_GEMM_NT, st, 2.0 * a.M * a.N * a.K);
+  ProfScope ps(PC_GEMM_NT, st, 2.0 * a.M * a.N * a.K, true);   // (one launch, through UR_LAUNCH_EV: the kernel's own timestamps)
   if ((a.K & 3) || (a.N & 3) || (a.lda & 3) || (a.ldw & 3) || (epi != EPI_COUNT_GT && ((a.ldc & 3) || (a.aux && (a.ldaux & 3)) || (a.aux2 && (a.ldaux2 & 3)))))
     return fail(UR_ERR_ARG, "gemm_nt: N, K and all leading dimensions must be multiples of 4 (N=%d K=%d)", a.N, a.K);
   if (a.ksplit > 1 && (epi != EPI_NONE || pro != PRO_NONE || a.m_dev || a.ksplit > 64))
@@ -739,6 +739,7 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb)
       if (i0 + q * 4 < tb.zero_n) *(float4*)(tb.zero_ptr + i0 + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
+  if (tb.n <= 0) return;   // (riders only)
   int j = 0;
   while (j + 1 < tb.n && (int)blockIdx.x >= tb.item[j + 1].first_block) ++j;
   const TransposeItem it = tb.item[j];
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb)
 }
 
 int transpose_batch(TransposeBatch& tb, hipStream_t st) {
-  if (tb.n <= 0) return UR_OK;
+  if (tb.n <= 0 && !tb.zero_ptr && !tb.zero2_ptr && !tb.copy_src) return UR_OK;
   ProfScope ps(PC_MISC, st, 0.0);
   int blocks = 0;
   for (int i = 0; i < tb.n; ++i) {
@@ -768,6 +769,7 @@ int transpose_batch(TransposeBatch& tb, hipStream_t st) {
     tb.zero2_first_block = blocks;
     blocks += cdiv(tb.zero2_n, 4096);
   }
+  if (blocks == 0) blocks = 1;   // (only the one-int copy rides)
   hipLaunchKernelGGL(transpose_batch_kernel, dim3(blocks), dim3(256), 0, st, tb);
   UR_LAUNCH_CHECK();
   return UR_OK;

@@ -37,7 +37,13 @@ struct GruWs {
 };
 // pieces of the K dimension of a per-step GEMM (few rows, K = H forward / 3H backward): ~192 columns each, so that B / 32 x N / 128 x pieces
 // workgroups are several per CU (H = 768: 288 x 4 forward, 96 x 12 backward) instead of one walking the whole K loop alone
-static int gru_ksplit(long long K) { return (int)std::max(1LL, std::min(16LL, K / 192)); }
+static int gru_ksplit(long long K) {
+  long long s = std::max(1LL, std::min(16LL, K / 192));
+  // gemm_nt gives every piece ceil(K / s) rounded up to its 32-wide K step: with K > 3072 the last of 16 such pieces would start
+  // behind K (an empty piece, whose partial product nobody writes) -- as many pieces as are non-empty
+  const long long ks = ((K + s - 1) / s + 31) / 32 * 32;
+  return (int)((K + ks - 1) / ks);
+}
 
 static GruWs gru_carve(const UrGruCfg& c, float* base) {
   GruWs w;

@@ -130,7 +130,7 @@ struct TransposeBatch {
 int transpose_batch(TransposeBatch& tb, hipStream_t st);   // every queued transpose in one launch
 
 // ---- rowchain.hip: row-block chain kernels (a workgroup carries BM token rows through a sequence of GEMMs, tiles in LDS)
-constexpr int CHAIN_FWD = 1, CHAIN_BWD = 2, CHAIN_PROJ = 4, CHAIN_LAST = 8, CHAIN_LAST_BWD = 16, CHAIN_EMBED = 32, CHAIN_ALL = 63;   // LAST*: the B last rows of the last-row layer; EMBED: lookup + LN + first projection
+constexpr int CHAIN_FWD = 1, CHAIN_BWD = 2, CHAIN_PROJ = 4, CHAIN_LAST = 8, CHAIN_LAST_BWD = 16, CHAIN_EMBED = 32, CHAIN_LASTROW = 64, CHAIN_ALL = 127;   // LAST*: the B last rows of the last-row layer through the row-chain kernels; EMBED: lookup + LN + first projection; LASTROW: the last-row layer as two launches (lastrow.hip; wins over LAST*)
 constexpr int CHAIN_DEFAULT = CHAIN_ALL;  // which chain kernels run by default (UR_SASREC_CHAIN / ur_sasrec_set_chain: bit mask); DESIGN.md 6d
 bool chain_supported(int d, int inner, int which);
 bool chain_shape_ok(int d, int inner);              // the kernels exist for this shape (whatever the switch says)   // d in {32, 64, 128}, inner % d == 0, and the bit(s) `which` switched on
@@ -139,12 +139,15 @@ int chain_set_enabled(int mask);          // mask < 0: query only; returns the p
 struct ChainFwdArgs {
   const float* ctx; int ldctx;          // attention output [M, d]
   const float* res; int ldres;          // residual of the attention block = the layer input x
-  const float *wo, *bo, *g1, *b1ln;     // out-projection [d,d] + its LayerNorm
-  const float *w1, *b1, *w2, *b2;       // dense_1 [I,d], dense_2 [d,I]
+  // Weights come TRANSPOSED ([in, out]: the copies ur_sasrec_fwd makes at its head): a lane of the B operand owns an output column, so
+  // the 32 lanes of a half-wave read 128 contiguous bytes of one k-row (lane = row of the nn.Linear layout, 16 B each, was 64 separate
+  // 16-byte accesses per wave instruction: 35 GB/s per workgroup against 80-115 coalesced, tools/probe/wstream_probe.hip)
+  const float *woT, *bo, *g1, *b1ln;    // out-projection^T [d,d] + its LayerNorm
+  const float *w1T, *b1, *w2T, *b2;     // dense_1^T [d,I], dense_2^T [I,d]
   const float *g2, *b2ln;
   float *a, *ahat, *rstd1, *h1, *y, *yhat, *rstd2;
   float* u;                             // nullable: act(h1) [M, I], saved for the dense_2 weight-gradient GEMM (no activation recompute there)
-  const float *wn, *bn; float* outn; int ldn, Nn;   // optional: next projection y Wn^T + bn, Wn [Nn, d], Nn % d == 0
+  const float *wnT, *bn; float* outn; int ldn, Nn, ldwn;   // optional: next projection y Wn^T + bn; WnT [d, ldwn] (columns = outputs), Nn % d == 0
   int M; const int* m_dev;
   int I, act; float eps;
   DropSpec drop_out, drop_ffn;
@@ -155,10 +158,10 @@ struct ChainBwdArgs {
   const float* gy;                      // d loss / d y  [M, d]
   const float *yhat, *rstd2, *g2;       // feed-forward LayerNorm
   const float* h1;                      // [M, I] pre-activation
-  const float* w2T;                     // [I, d]  (dense_2.weight transposed)
-  const float* w1T;                     // [d, I]  (dense_1.weight transposed)
+  const float* w2;                      // [d, I]  dense_2.weight as stored: g_u = g_tf W2 contracts over its rows (coalesced B operand, see ChainFwdArgs)
+  const float* w1;                      // [I, d]  dense_1.weight as stored
   const float *ahat, *rstd1, *g1;       // attention LayerNorm
-  const float* woT;                     // [d, d]
+  const float* wo;                      // [d, d]  dense.weight as stored
   float *g_tf, *g_h1, *g_ta, *g_ctx;    // outputs (g_tf, g_h1, g_ta feed the weight-gradient GEMMs)
   float* part;                          // [workgroups][4 d]: d gamma2 | d beta2 | d gamma1 | d beta1 partial sums
   int M; const int* m_dev;
@@ -172,7 +175,7 @@ struct ChainBwdArgs {
 };
 struct ChainProjBwdArgs {
   const float* g; int ldg; int K;       // [M, K] gradient of the projection output; K % d == 0
-  const float* wT; int ldw;             // [d, ldw] transposed projection weight: out[m, n] = sum_k g[m, k] wT[n, k]
+  const float* w; int ldw;              // [K, ldw] projection weight as stored: out[m, n] = sum_k g[m, k] w[k, n]
   const float* res;                     // nullable addend [M, d]
   const float *xhat, *rstd, *gamma;     // nullable: LayerNorm backward applied to the result (embedding LayerNorm)
   float* out; const int* out_rows;      // row m of the result goes to row out_rows[m] (nullable: m) of out [., d]
@@ -187,7 +190,7 @@ struct ChainEmbedArgs {
   int L; const int* tok;                // tok (nullable): buffer row -> token of the padded grid (compacted rows)
   DropSpec drop;                        // embedding dropout (keyed by the token)
   float *x0, *x0hat, *rstd0;            // outputs: the layer input [M, d], its normalised copy and 1/std (for the backward)
-  const float *wn, *bn; float* outn; int ldn, Nn;   // first projection: x0 Wn^T + bn, Wn [Nn, d], Nn % d == 0
+  const float *wnT, *bn; float* outn; int ldn, Nn, ldwn;   // first projection: x0 Wn^T + bn; WnT [d, ldwn] (columns = outputs), Nn % d == 0
   int M; const int* m_dev;
 };
 int chain_embed_proj(const ChainEmbedArgs& a, int d, hipStream_t st);   // lookup + position + LayerNorm + the first layer's Q/K/V projection
@@ -200,6 +203,43 @@ int chain_ffn_bwd_split(const ChainBwdArgs& a, int d, hipStream_t st);   // part
 long long chain_split_part_floats(int M, int d, int inner);
 int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st);     // workgroups = cdiv(M, chain_rows_per_block(d))
 int chain_proj_bwd(const ChainProjBwdArgs& a, int d, hipStream_t st);
+
+// ---- lastrow.hip: the last-row layer (last_only: only position L-1 of the top layer reaches the loss) as two launches
+struct LastRowFwdArgs {
+  const float* x; const int* xrow; long long xstride, xoff;   // layer input [., d]: the row of sequence b is xrow ? xrow[b] : b * xstride + xoff
+  const float* qkv;                     // [M, 3d]: this layer's K | V rows in columns d .. 3d (written by the layer below's chain kernel)
+  const int* seq;                       // [B, L] item ids (the key mask)
+  const int *seq_base, *seq_pad;        // compacted rows (nullable): position l of sequence b is row seq_base[b] + l, l >= seq_pad[b]
+  const float* wqT; int ldq;            // K-major query weight: [d][ldq], columns 0 .. d-1 (= the layer's wqkvT)
+  const float *bq, *woT, *bo, *g1, *b1ln, *w1T, *b1, *w2T, *b2, *g2, *b2ln;   // K-major copies (kernels.h: ChainFwdArgs) and the vectors
+  float *q_out, *x_out;                 // [B, d] queries (the backward reads them); x_out (nullable): the gathered input rows
+  float *ctx, *lse;                     // [B, d] attention output, [B, H] log-sum-exp
+  float *a, *ahat, *rstd1, *h1, *y, *yhat, *rstd2;
+  int B, L, I, act; float eps, scale, sqrt_hd;
+  DropSpec drop_out, drop_ffn;          // hidden dropout sites (row id of row b per the spec)
+  unsigned dkey, dthresh; float dscale; // dropout on the attention probabilities (dthresh == 0: off): row id (b * H + h) * L + L - 1, column j
+  int part_floats;                      // (set by the launcher)
+};
+struct LastRowBwdArgs {
+  const float* gy;                      // [B, d] d loss / d y
+  const float *yhat, *rstd2, *g2, *h1;  // saved by the forward
+  const float *w2, *w1, *wo, *wqkv;     // weights AS STORED: [d, I], [I, d], [d, d], [3d, d] (K-major for the gradient products)
+  const float *ahat, *rstd1, *g1;
+  const float *q, *ctx, *lse;           // [B, d], [B, d], [B, H]
+  const float* qkv; const int* seq; const int *seq_base, *seq_pad;
+  float *g_tf, *g_tfd, *g_h1, *g_ta, *g_tad, *dq;   // [B, .] operands of the weight-gradient products (g_tfd / g_tad: dropout-masked copies, = g_tf / g_ta without)
+  float* g_qkv;                         // [M, 3d]: dK | dV of every row into columns d .. 3d
+  float* g_x;                           // [M, d]: the layer's input gradient, EVERY row of every sequence written
+  float* part;                          // [workgroups][4 d]: d gamma2 | d beta2 | d gamma1 | d beta1 partial sums
+  int B, L, I, act; float scale, sqrt_hd;
+  DropSpec drop_ffn, drop_out; unsigned dkey, dthresh; float dscale;
+  int part_floats;
+};
+bool lastrow_shape_ok(int B, int L, int d, int H, int inner);
+bool lastrow_supported(int B, int L, int d, int H, int inner);   // shape ok and switched on (CHAIN_LASTROW of the chain mask)
+int lastrow_rows_per_block();
+int lastrow_fwd(const LastRowFwdArgs& a, int d, int H, hipStream_t st);
+int lastrow_bwd(const LastRowBwdArgs& a, int d, int H, hipStream_t st);
 
 // ---- attention.hip
 long long attn_lse_floats(int B, int H, int L);

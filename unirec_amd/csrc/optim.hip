@@ -6,6 +6,7 @@
 
 namespace ur {
 thread_local hipEvent_t g_stop_event = nullptr;   // common.h: UR_LAUNCH_EV
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;   // common.h: ProfScope with kernel_events
 }
 namespace ur {
 
@@ -132,18 +133,28 @@ static unsigned g_prof_mask = 0xffffffffu;   // bit c set = kernel class c is br
 static std::vector<ProfRec> g_prof;      // recorded pairs since the last reset
 static std::vector<ProfRec> g_prof_pool; // reusable events
 
-ProfScope::ProfScope(int cls_, hipStream_t st_, double work) : cls(cls_), st(st_), slot(-1) {
+ProfScope::ProfScope(int cls_, hipStream_t st_, double work, bool kernel_events_) : cls(cls_), st(st_), slot(-1), kernel_events(kernel_events_) {
   if (!g_prof_on || !((g_prof_mask >> cls_) & 1u)) return;
   ProfRec r;
   if (!g_prof_pool.empty()) { r = g_prof_pool.back(); g_prof_pool.pop_back(); }
   else { if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return; }
   r.cls = cls; r.work = work;
-  (void)hipEventRecord(r.a, st);
+  if (kernel_events) { g_prof_start = r.a; g_prof_stop = r.b; }   // bound to the scope's launch (UR_LAUNCH_EV)
+  else (void)hipEventRecord(r.a, st);
   slot = (int)g_prof.size();
   g_prof.push_back(r);
 }
 ProfScope::~ProfScope() {
-  if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+  if (slot < 0) return;
+  if (kernel_events) {
+    if (g_prof_start == g_prof[slot].a) {   // no launch took them (an early return): an empty bracket
+      g_prof_start = nullptr; g_prof_stop = nullptr;
+      (void)hipEventRecord(g_prof[slot].a, st);
+      (void)hipEventRecord(g_prof[slot].b, st);
+    }
+    return;
+  }
+  (void)hipEventRecord(g_prof[slot].b, st);
 }
 // is a launch of class `cls` being bracketed right now?  (A launch that carries a fork's completion event, UR_LAUNCH_EV, would have the
 // event's ~5 us inside the bracket: the forks fall back to hipEventRecord while their producers are being timed.)

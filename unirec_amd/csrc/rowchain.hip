@@ -36,9 +36,17 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float fx4 __attribute__((ext_vector_type(4)));   // plain LLVM vector: register arrays of it are always promoted (HIP's float4 class is not, in every context)
 
 // The weight slices are NOT staged through LDS.  A wave owns 32 output columns of every GEMM of the chain (WC = D / 32
-// waves side by side), so at D = 128 no two waves of a workgroup want the same weight rows: each wave loads ITS fragment of a slice
+// waves side by side), so at D = 128 no two waves of a workgroup want the same weight columns: each wave loads ITS fragment of a slice
 // straight from global memory (the weights are L2-resident) into registers, two slices ahead -- no staging stores, and ONE barrier per
 // GEMM segment (when the activation tile changes hands) instead of one per K slice.  LDS = the two activation tiles (32 KB at D = 128).
+//
+// The weight operand is K-MAJOR: Wt [K, ldt], element (k, n) = weight of output column n (round 4).  A lane of the B fragment owns
+// column n = its wave's block + lane & 31 and k offset 4 (lane >> 5): one dword per k, so the 32 lanes of a half-wave read 128
+// CONTIGUOUS bytes of k-row.  Rounds 2-3 read the nn.Linear layout (row = output column, a float4 along k per lane): 64 separate 16-byte
+// accesses per wave instruction, which the texture path serves at ~1 lane per clock -- 35 GB/s per workgroup whatever the number of
+// workgroups, against 80 (dword) to 115 (float4) GB/s for coalesced accesses (tools/probe/wstream_probe.hip, profiles/r04_a_wstream.txt):
+// a 32-row workgroup streams 640 KB of weights, 2.6 workgroups per CU = 47 us of a 89 us kernel with the load path busy.
+// Forward chains get the transposed copies of the nn.Linear weights (made at the head of ur_sasrec_fwd), backward chains the weights as stored.
 constexpr int RC_BK = 16;          // K-slice of the streamed weight tile
 
 template <int D>
@@ -50,7 +58,7 @@ struct RcGeom {
   static constexpr int RS = D + 4;                  // row stride of the reduction scratch laid over a dead tile
   static constexpr int TPR = D / 4;                 // lanes per row in the row-wise epilogues (one float4 each)
   static constexpr int RPP = 256 / TPR;             // rows per epilogue pass; 4 passes cover the BM rows
-  static constexpr int WV = 2;                      // float4 loads per lane per weight slice: k offsets fk .. fk+3 and 8 + fk .. of ITS row
+  static constexpr int WV = 2;                      // fx4 registers per lane per weight slice: k offsets fk .. fk+3 and 8 + fk .. of ITS column
   static constexpr int TILE = BM * TS;              // floats per activation tile
   static constexpr size_t LDS_BYTES = (size_t)(2 * TILE) * sizeof(float);
 };
@@ -62,33 +70,46 @@ __device__ __forceinline__ int rc_toff(int r, int c4) {
   return r * D + ((c4 ^ (r & RcGeom<D>::SWZ)) << 2);
 }
 
-// One LANE's view of a weight segment (rows row0 .. row0+D-1 = output features, columns k0 .. of a row-major matrix with leading
-// dimension ldw): the address of the first float4 of ITS B-operand fragment of the first K-slice -- row = the wave's 32-column block +
-// lane & 31, k offset 4 (lane >> 5) (the fragment layout of rc_gemm).
+// A weight segment (output columns col0 .. col0+D-1, k from k0 of a K-major matrix Wt with row stride ldt) is addressed as a
+// WAVE-UNIFORM pointer (rc_wptr: its first element; advanced per K-slice with scalar arithmetic) plus ONE per-lane element offset
+// (rc_woff, a function of the row stride only): column = the wave's 32-column block + lane & 31, k offset 4 (lane >> 5) (the
+// fragment layout of rc_gemm).  Eight dword loads per slice off one 32-bit lane offset -- with a per-lane 64-bit pointer the eight row
+// addresses of a slice cost 16 registers per stream and the forward chain spilled.
 template <int D>
-__device__ __forceinline__ const float* rc_wptr(const float* W, int ldw, int row0, int k0, int tid) {
-  const int lane = tid & 63, wc = (tid >> 6) % RcGeom<D>::WC;
-  return W + (long long)(row0 + wc * 32 + (lane & 31)) * ldw + k0 + 4 * (lane >> 5);
+__device__ __forceinline__ const float* rc_wptr(const float* Wt, int ldt, int col0, int k0) {
+  return Wt + (long long)k0 * ldt + col0;
 }
 template <int D>
-__device__ __forceinline__ void rc_wload(fx4 (&r)[RcGeom<D>::WV], const float* p, int ldw) {
-  (void)ldw;
-  r[0] = *(const fx4*)p;
-  r[1] = *(const fx4*)(p + 8);
+__device__ __forceinline__ unsigned rc_woff(int ldt, int tid) {   // BYTE offset, unsigned: base + zext(offset) is the scalar-base addressing mode
+  const int lane = tid & 63, wc = (tid >> 6) % RcGeom<D>::WC;
+  return 4u * (unsigned)(4 * (lane >> 5) * ldt + wc * 32 + (lane & 31));
+}
+// (buffer loads: the wave-uniform part of an address -- segment base in the resource, k-row offset in the scalar offset -- stays in
+// SGPRs by construction; with global loads the compiler turned most of the eight row addresses of a slice into per-lane 64-bit
+// pointers, hoisted them out of the chunk loops and spilled)
+__device__ __forceinline__ float rc_ld(__amdgpu_buffer_rsrc_t rs, unsigned boff, int sbyte) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)boff, sbyte, 0));
+}
+template <int D>
+__device__ __forceinline__ void rc_wload(fx4 (&r)[RcGeom<D>::WV], const float* p, int ldt, unsigned off) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000);
+  const int lb = ldt * 4;
+  r[0][0] = rc_ld(rs, off, 0); r[0][1] = rc_ld(rs, off, lb); r[0][2] = rc_ld(rs, off, 2 * lb); r[0][3] = rc_ld(rs, off, 3 * lb);
+  r[1][0] = rc_ld(rs, off, 8 * lb); r[1][1] = rc_ld(rs, off, 9 * lb); r[1][2] = rc_ld(rs, off, 10 * lb); r[1][3] = rc_ld(rs, off, 11 * lb);
 }
 
-// acc += As[BM, D] @ W[seg]^T, K = D in NK = D / 16 slices.  As: an LDS activation tile (row stride TS).
+// acc += As[BM, D] @ Wt[seg], K = D in NK = D / 16 slices (ldw / ldwn: the k-row strides of this / the next segment's matrix).  As: an LDS activation tile (row stride TS).
 // The weight-slice stream runs TWO slices ahead of the MFMAs (an L2 round trip is longer than one K-step of 8 MFMAs) and never drains
 // inside a workgroup: wp / wnp are rc_wptr of this / the next segment (wnp nullable: the stream then re-reads this segment, unused).
 // Ends with a barrier: every wave is done reading As.
 template <int D>
-__device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const float* wp, int ldw, const float* wnp, int ldwn,
-                                        fx4 (&wreg)[2][RcGeom<D>::WV], int wr, int lane) {
+__device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const float* wp, int ldw, unsigned woff, const float* wnp, int ldwn,
+                                        unsigned wnoff, fx4 (&wreg)[2][RcGeom<D>::WV], int wr, int lane) {
   constexpr int NK = D / RC_BK;
   static_assert(NK % 2 == 0, "the two-slot ring assumes an even number of slices per segment");
   const int frow = lane & 31, fk = 4 * (lane >> 5);
   const int arow = wr * 32 + frow, ac0 = fk >> 2;   // this lane's tile row and the chunk offset of its K half
-  if (!wnp) { wnp = wp; ldwn = ldw; }
+  if (!wnp) { wnp = wp; ldwn = ldw; wnoff = woff; }
   // on entry wreg[0] / wreg[1] hold this lane's fragments of slices 0 / 1 of the segment (in flight or landed); step kt consumes
   // slice kt and refills its slot with slice kt + 2 (of this segment or the next): the invariant holds again on exit
   // The swizzle XORs the chunk index with row & 15: chunk = 4 kt + q (q = ac0, 2 + ac0) has its bits above 15 untouched, so the lane's
@@ -104,8 +125,8 @@ __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const fl
 #pragma unroll
   for (int kt = 0; kt < NK; ++kt) {
     const fx4 b0 = wreg[kt & 1][0], b1 = wreg[kt & 1][1];
-    if (kt + 2 < NK) rc_wload<D>(wreg[kt & 1], wp + (kt + 2) * RC_BK, ldw);
-    else rc_wload<D>(wreg[kt & 1], wnp + (kt + 2 - NK) * RC_BK, ldwn);
+    if (kt + 2 < NK) rc_wload<D>(wreg[kt & 1], wp + (long long)(kt + 2) * RC_BK * ldw, ldw, woff);
+    else rc_wload<D>(wreg[kt & 1], wnp + (long long)(kt + 2 - NK) * RC_BK * ldwn, ldwn, wnoff);
     __builtin_amdgcn_sched_barrier(0);   // (the loads stay here: the scheduler would sink them to just ahead of their use)
     const float4 a0 = *(const float4*)(As + aoff[kt % NA][0] + (kt / NA) * 64);
     const float4 a1 = *(const float4*)(As + aoff[kt % NA][1] + (kt / NA) * 64);
@@ -123,12 +144,12 @@ __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const fl
 
 // start of the stream: slice 0 of the first segment at kernel entry, slice 1 behind the tile staging loads
 template <int D>
-__device__ __forceinline__ void rc_prime_load(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw) {
-  rc_wload<D>(wreg[0], wp, ldw);
+__device__ __forceinline__ void rc_prime_load(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw, unsigned woff) {
+  rc_wload<D>(wreg[0], wp, ldw, woff);
 }
 template <int D>
-__device__ __forceinline__ void rc_prime_next(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw) {   // slice 1, once the tile staging loads are out
-  rc_wload<D>(wreg[1], wp + RC_BK, ldw);
+__device__ __forceinline__ void rc_prime_next(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw, unsigned woff) {   // slice 1, once the tile staging loads are out
+  rc_wload<D>(wreg[1], wp + (long long)RC_BK * ldw, ldw, woff);
 }
 
 // accumulator tile -> LDS tile.  acc[r]: row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of the wave's 32 x 32 tile.
@@ -253,7 +274,9 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   const int wr = wave / G::WC, wc = wave % G::WC;
   const float inv_n = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);   // the first weight slice is in flight while the ctx tile is staged
+  const unsigned woff_d = rc_woff<D>(D, tid), woff_i = rc_woff<D>(a.I, tid), woff_n = a.wnT ? rc_woff<D>(a.ldwn, tid) : 0;
+  auto WOFF = [&](int ld) { return ld == D ? woff_d : (ld == a.I ? woff_i : woff_n); };   // this lane's element offset in a K-major matrix of row stride ld
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D));   // the first weight slice is in flight while the ctx tile is staged
   {
   const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
 #pragma unroll
@@ -264,13 +287,13 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
     *(float4*)(At + rc_toff<D>(ml, et)) = v;
   }
   }
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D));
   __syncthreads();
 
   // ---- 1. attention output projection + residual + LayerNorm
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0, tid), D, rc_wptr<D>(a.w1, D, 0, 0, tid), D, wreg, wr, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D), rc_wptr<D>(a.w1T, a.I, 0, 0), a.I, WOFF(a.I), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -307,10 +330,10 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   floatx16 accy = zero16();
   const int nc = a.I / D;
   for (int c = 0; c < nc; ++c) {
-    const float* w2p = rc_wptr<D>(a.w2, a.I, 0, c * D, tid);
+    const float* w2p = rc_wptr<D>(a.w2T, D, 0, c * D);
     {
       floatx16 acch = zero16();
-      rc_gemm<D>(acch, At, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, w2p, a.I, wreg, wr, lane);
+      rc_gemm<D>(acch, At, rc_wptr<D>(a.w1T, a.I, c * D, 0), a.I, WOFF(a.I), w2p, D, WOFF(D), wreg, wr, lane);
       rc_acc_to_tile<D>(acch, Ht, wr, wc, lane);
     }
     __syncthreads();
@@ -334,8 +357,8 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
       }
     }
     __syncthreads();
-    const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w1, D, (c + 1) * D, 0, tid) : (a.wn ? rc_wptr<D>(a.wn, D, 0, 0, tid) : nullptr);
-    rc_gemm<D>(accy, Ht, w2p, a.I, nxp, D, wreg, wr, lane);
+    const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w1T, a.I, (c + 1) * D, 0) : (a.wnT ? rc_wptr<D>(a.wnT, a.ldwn, 0, 0) : nullptr);
+    rc_gemm<D>(accy, Ht, w2p, D, WOFF(D), nxp, c + 1 < nc ? a.I : a.ldwn, WOFF(c + 1 < nc ? a.I : a.ldwn), wreg, wr, lane);
   }
 
   // ---- 3. y = LN(drop(acc + b2) + a)
@@ -368,14 +391,14 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
       *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
   }
-  if (!a.wn) return;
+  if (!a.wnT) return;
   __syncthreads();
 
   // ---- 4. the next layer's input projection (its K / V -- or Q, K, V -- rows), straight from the y tile
   const int nn = a.Nn / D;
   for (int c = 0; c < nn; ++c) {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wn, D, c * D, 0, tid), D, c + 1 < nn ? rc_wptr<D>(a.wn, D, (c + 1) * D, 0, tid) : nullptr, D, wreg, wr, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wnT, a.ldwn, c * D, 0), a.ldwn, WOFF(a.ldwn), c + 1 < nn ? rc_wptr<D>(a.wnT, a.ldwn, (c + 1) * D, 0) : nullptr, a.ldwn, WOFF(a.ldwn), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
     __syncthreads();
     const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
@@ -465,7 +488,9 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_n = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);
+  const unsigned woff_d = rc_woff<D>(D, tid), woff_i = rc_woff<D>(a.I, tid);
+  auto WOFF = [&](int ld) { return ld == D ? woff_d : woff_i; };
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D));
   // every small operand of the epilogues is requested HERE (one workgroup per CU, parameters rewritten by the optimizer a moment ago:
   // each of these is a miss all the way to HBM, ~2 us when it is asked for where it is used, behind a barrier)
   const float4 q_bo = *(const float4*)(a.bo + et * 4), q_g1 = *(const float4*)(a.g1 + et * 4), q_b1ln = *(const float4*)(a.b1ln + et * 4);
@@ -481,12 +506,12 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
     if (m < M) v = *(const float4*)(a.ctx + (long long)m * a.ldctx + et * 4);
     *(float4*)(At + rc_toff<D>(ml, et)) = v;
   }
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.wo, D, 0, 0, tid), D);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D));
   __syncthreads();
   // ---- 1. attention output projection + residual + LayerNorm (every chunk's workgroup; chunk 0 writes a / ahat / rstd1)
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0, tid), D, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, wreg, wr, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D), rc_wptr<D>(a.w1T, a.I, c * D, 0), a.I, WOFF(a.I), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -519,10 +544,10 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   }
   __syncthreads();
   // ---- 2. dense_1 + activation for chunk c, then this chunk's partial of dense_2
-  const float* w2p = rc_wptr<D>(a.w2, a.I, 0, c * D, tid);
+  const float* w2p = rc_wptr<D>(a.w2T, D, 0, c * D);
   {
     floatx16 acch = zero16();
-    rc_gemm<D>(acch, At, rc_wptr<D>(a.w1, D, c * D, 0, tid), D, w2p, a.I, wreg, wr, lane);
+    rc_gemm<D>(acch, At, rc_wptr<D>(a.w1T, a.I, c * D, 0), a.I, WOFF(a.I), w2p, D, WOFF(D), wreg, wr, lane);
     rc_acc_to_tile<D>(acch, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -546,7 +571,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   }
   __syncthreads();
   floatx16 accy = zero16();
-  rc_gemm<D>(accy, Ht, w2p, a.I, nullptr, D, wreg, wr, lane);
+  rc_gemm<D>(accy, Ht, w2p, D, WOFF(D), nullptr, D, WOFF(D), wreg, wr, lane);
   rc_acc_to_tile<D>(accy, Ht, wr, wc, lane);
   __syncthreads();
   // ---- 3. the partial -> memory (device scope), count, and the last workgroup of the row block finishes
@@ -617,7 +642,9 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   const int wr = wave / G::WC, wc = wave % G::WC;
   const float inv_d = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.w2T, D, 0, 0, tid), D);
+  const unsigned woff_d = rc_woff<D>(D, tid), woff_i = rc_woff<D>(a.I, tid);
+  auto WOFF = [&](int ld) { return ld == D ? woff_d : woff_i; };
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.w2, a.I, 0, 0), a.I, WOFF(a.I));
 
   // ---- 0. feed-forward LayerNorm backward: g_tf (also the residual branch of g_a)
   {
@@ -642,17 +669,17 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
     }
     rc_block_colsum<D>(dg, db, Ht, part, eg, et, tid);
   }
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.w2T, D, 0, 0, tid), D);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.w2, a.I, 0, 0), a.I, WOFF(a.I));
   __syncthreads();
 
   // ---- 1. g_h1 chunk = (g_tf W2[:, chunk]) * act'(h1 chunk);   g_a += g_h1 chunk W1[chunk, :]
   floatx16 acca = zero16();
   const int nc = a.I / D;
   for (int c = 0; c < nc; ++c) {
-    const float* w1p = rc_wptr<D>(a.w1T, a.I, 0, c * D, tid);
+    const float* w1p = rc_wptr<D>(a.w1, D, 0, c * D);
     {
       floatx16 accu = zero16();
-      rc_gemm<D>(accu, At, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D, w1p, a.I, wreg, wr, lane);
+      rc_gemm<D>(accu, At, rc_wptr<D>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I), w1p, D, WOFF(D), wreg, wr, lane);
       rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
     }
     __syncthreads();
@@ -678,8 +705,8 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
       }
     }
     __syncthreads();
-    const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w2T, D, (c + 1) * D, 0, tid) : rc_wptr<D>(a.woT, D, 0, 0, tid);
-    rc_gemm<D>(acca, Ht, w1p, a.I, nxp, D, wreg, wr, lane);
+    const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w2, a.I, (c + 1) * D, 0) : rc_wptr<D>(a.wo, D, 0, 0);
+    rc_gemm<D>(acca, Ht, w1p, D, WOFF(D), nxp, c + 1 < nc ? a.I : D, WOFF(c + 1 < nc ? a.I : D), wreg, wr, lane);
   }
 
   // ---- 2. g_a = acc + g_tf;  attention LayerNorm backward -> g_ta
@@ -715,7 +742,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   // ---- 3. g_ctx = g_ta Wo
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0, tid), D, nullptr, 0, wreg, wr, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0), D, WOFF(D), nullptr, 0, WOFF(0), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -747,8 +774,10 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   const int wr = wave / G::WC, wc = wave % G::WC;
   const int et = tid % G::TPR, eg = tid / G::TPR;
   fx4 wreg[2][G::WV];
+  const unsigned woff_w = rc_woff<D>(a.ldw, tid);
+  auto WOFF = [&](int) { return woff_w; };
   const int nkc = a.K / D;
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.wT, a.ldw, 0, 0, tid), a.ldw);
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.w, a.ldw, 0, 0), a.ldw, WOFF(a.ldw));
   float4 ra[4];
   auto load_a = [&](int kc) {
 #pragma unroll
@@ -763,14 +792,13 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   };
   load_a(0);
   store_a();
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.wT, a.ldw, 0, 0, tid), a.ldw);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.w, a.ldw, 0, 0), a.ldw, WOFF(a.ldw));
   __syncthreads();
   floatx16 acc = zero16();
   for (int kc = 0; kc < nkc; ++kc) {
     const bool more = kc + 1 < nkc;
     if (more) load_a(kc + 1);   // the next slice of g is in flight underneath this chunk's MFMAs
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wT, a.ldw, 0, kc * D, tid), a.ldw, more ? rc_wptr<D>(a.wT, a.ldw, 0, (kc + 1) * D, tid) : nullptr, a.ldw,
-               wreg, wr, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.w, a.ldw, 0, kc * D), a.ldw, WOFF(a.ldw), more ? rc_wptr<D>(a.w, a.ldw, 0, (kc + 1) * D) : nullptr, a.ldw, WOFF(a.ldw), wreg, wr, lane);
     if (more) {
       store_a();
       __syncthreads();
@@ -828,7 +856,9 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_d = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D);
+  const unsigned woff_d = rc_woff<D>(D, tid), woff_i = rc_woff<D>(a.I, tid);
+  auto WOFF = [&](int ld) { return ld == D ? woff_d : woff_i; };
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I));
   // (what the later epilogues read from memory is requested here: see chain_ffn_fwd_split_kernel)
   const float4 q_g1 = *(const float4*)(a.g1 + et * 4);
   float4 q_h1[4], q_ahat[4];
@@ -864,13 +894,13 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
     }
     if (c == 0) rc_block_colsum<D>(dg, db, Ht, part, eg, et, tid);   // (workgroup-uniform branch: the barriers inside are fine)
   }
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I));
   __syncthreads();
   // ---- 1. g_h1 chunk = (g_tf W2[:, chunk]) * act'(h1 chunk);   partial of g_a = g_h1 chunk W1[chunk, :]
-  const float* w1p = rc_wptr<D>(a.w1T, a.I, 0, c * D, tid);
+  const float* w1p = rc_wptr<D>(a.w1, D, 0, c * D);
   {
     floatx16 accu = zero16();
-    rc_gemm<D>(accu, At, rc_wptr<D>(a.w2T, D, c * D, 0, tid), D, w1p, a.I, wreg, wr, lane);
+    rc_gemm<D>(accu, At, rc_wptr<D>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I), w1p, D, WOFF(D), wreg, wr, lane);
     rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -895,7 +925,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   }
   __syncthreads();
   floatx16 acca = zero16();
-  rc_gemm<D>(acca, Ht, w1p, a.I, rc_wptr<D>(a.woT, D, 0, 0, tid), D, wreg, wr, lane);
+  rc_gemm<D>(acca, Ht, w1p, D, WOFF(D), rc_wptr<D>(a.wo, D, 0, 0), D, WOFF(D), wreg, wr, lane);
   rc_acc_to_tile<D>(acca, Ht, wr, wc, lane);
   __syncthreads();
   // ---- 2. the partial -> memory (device scope), count; the last workgroup of the row block goes on
@@ -949,7 +979,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   // ---- 4. g_ctx = g_ta Wo
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0, tid), D, nullptr, 0, wreg, wr, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0), D, WOFF(D), nullptr, 0, WOFF(0), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -980,7 +1010,9 @@ __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a)
   const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_n = 1.0f / (float)D;
   fx4 wreg[2][G::WV];
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.wn, D, 0, 0, tid), D);   // the first weight slice is in flight while the rows are gathered
+  const unsigned woff_n = rc_woff<D>(a.ldwn, tid);
+  auto WOFF = [&](int) { return woff_n; };
+  rc_prime_load<D>(wreg, rc_wptr<D>(a.wnT, a.ldwn, 0, 0), a.ldwn, WOFF(a.ldwn));   // the first weight slice is in flight while the rows are gathered
   {
     const float4 gm = *(const float4*)(a.g0 + et * 4), bt = *(const float4*)(a.b0ln + et * 4);
     int full[4];
@@ -1015,12 +1047,12 @@ __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a)
       *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
   }
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.wn, D, 0, 0, tid), D);
+  rc_prime_next<D>(wreg, rc_wptr<D>(a.wnT, a.ldwn, 0, 0), a.ldwn, WOFF(a.ldwn));
   __syncthreads();
   const int nn = a.Nn / D;
   for (int c = 0; c < nn; ++c) {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wn, D, c * D, 0, tid), D, c + 1 < nn ? rc_wptr<D>(a.wn, D, (c + 1) * D, 0, tid) : nullptr, D, wreg, wr, lane);
+    rc_gemm<D>(acc, At, rc_wptr<D>(a.wnT, a.ldwn, c * D, 0), a.ldwn, WOFF(a.ldwn), c + 1 < nn ? rc_wptr<D>(a.wnT, a.ldwn, (c + 1) * D, 0) : nullptr, a.ldwn, WOFF(a.ldwn), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
     __syncthreads();
     const float4 bs = *(const float4*)(a.bn + c * D + et * 4);
@@ -1042,7 +1074,7 @@ __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a)
 // 0.834 -> 0.812 ms/step (isolated: 99 us against 138 for the four launches it replaces); with the backward chains as well the step is
 // SLOWER (0.858): three chain workgroups fill a CU's LDS, so the weight-gradient GEMMs of the side stream (67 KB each) cannot share
 // the CUs with them any more -- in the forward pass the side stream is idle and nothing is lost.
-static int g_chain_on = -1;   // bit mask: 1 forward chain, 2 backward chain, 4 projection-gradient chain, 8 / 16 forward / backward chain of the last-row layer
+static int g_chain_on = -1;   // bit mask: 1 forward chain, 2 backward chain, 4 projection-gradient chain, 8 / 16 forward / backward chain of the last-row layer, 32 input block, 64 the last-row layer as two launches
 int chain_set_enabled(int on) {
   if (g_chain_on < 0) g_chain_on = getenv("UR_SASREC_CHAIN") ? (atoi(getenv("UR_SASREC_CHAIN")) & CHAIN_ALL) : CHAIN_DEFAULT;
   const int prev = g_chain_on;
@@ -1064,13 +1096,13 @@ static void set_lds(KernelT k, size_t bytes) {
   do {                                                                                                              \
     static bool attr_##D_ = (set_lds(KERNEL<D_>, RcGeom<D_>::LDS_BYTES), true);                                     \
     (void)attr_##D_;                                                                                                \
-    hipLaunchKernelGGL((KERNEL<D_>), dim3(GRID), dim3(256), RcGeom<D_>::LDS_BYTES, st, ARGS);                       \
+    UR_LAUNCH_EV((KERNEL<D_>), dim3(GRID), dim3(256), RcGeom<D_>::LDS_BYTES, st, ARGS);                             \
   } while (0)
 
 int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
   if (a.M <= 0) return UR_OK;
-  if (!chain_shape_ok(d, a.I) || (a.wn && a.Nn % d)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd: d=%d inner=%d", d, a.I);
-  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I + (a.wn ? a.Nn : 0)));
+  if (!chain_shape_ok(d, a.I) || (a.wnT && a.Nn % d)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd: d=%d inner=%d", d, a.I);
+  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I + (a.wnT ? a.Nn : 0)), true);
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
     case 32: UR_CHAIN_DISPATCH(32, chain_ffn_fwd_kernel, a, grid); break;
@@ -1084,7 +1116,7 @@ int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
 int chain_embed_proj(const ChainEmbedArgs& a, int d, hipStream_t st) {
   if (a.M <= 0) return UR_OK;
   if (!(d == 32 || d == 64 || d == 128) || a.Nn <= 0 || a.Nn % d) return fail(UR_ERR_UNSUPPORTED, "chain_embed_proj: d=%d Nn=%d", d, a.Nn);
-  ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * (double)a.Nn);
+  ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * (double)a.Nn, true);
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
     case 32: UR_CHAIN_DISPATCH(32, chain_embed_proj_kernel, a, grid); break;
@@ -1117,11 +1149,11 @@ int chain_ffn_fwd_split(const ChainFwdArgs& a0, int d, hipStream_t st) {
   if (a0.M <= 0) return UR_OK;
   ChainFwdArgs a = a0;
   const int nblk = cdiv(a.M, chain_rows_per_block(d));
-  if (!chain_shape_ok(d, a.I) || a.wn || a.m_dev || nblk > CHAIN_SPLIT_MAX_BLOCKS || !a.split_part)
+  if (!chain_shape_ok(d, a.I) || a.wnT || a.m_dev || nblk > CHAIN_SPLIT_MAX_BLOCKS || !a.split_part)
     return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd_split: d=%d inner=%d M=%d", d, a.I, a.M);
   a.split_cnt = chain_split_counters();
   if (!a.split_cnt) return fail(UR_ERR_HIP, "chain_ffn_fwd_split: no device memory for the completion counters");
-  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I));
+  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I), true);
   const int grid = nblk * (a.I / d);
   switch (d) {
     case 32: UR_CHAIN_DISPATCH(32, chain_ffn_fwd_split_kernel, a, grid); break;
@@ -1141,7 +1173,7 @@ int chain_ffn_bwd_split(const ChainBwdArgs& a0, int d, hipStream_t st) {
   unsigned* cnt = chain_split_counters();
   if (!cnt) return fail(UR_ERR_HIP, "chain_ffn_bwd_split: no device memory for the completion counters");
   a.split_cnt = cnt + CHAIN_SPLIT_MAX_BLOCKS;   // (the forward kernel's counters are the first half)
-  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I));
+  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I), true);
   const int grid = nblk * (a.I / d);
   switch (d) {
     case 32: UR_CHAIN_DISPATCH(32, chain_ffn_bwd_split_kernel, a, grid); break;
@@ -1155,7 +1187,7 @@ int chain_ffn_bwd_split(const ChainBwdArgs& a0, int d, hipStream_t st) {
 int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st) {
   if (a.M <= 0) return UR_OK;
   if (!chain_shape_ok(d, a.I)) return fail(UR_ERR_UNSUPPORTED, "chain_ffn_bwd: d=%d inner=%d", d, a.I);
-  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I));
+  ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I), true);
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
     case 32: UR_CHAIN_DISPATCH(32, chain_ffn_bwd_kernel, a, grid); break;
@@ -1169,7 +1201,7 @@ int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st) {
 int chain_proj_bwd(const ChainProjBwdArgs& a, int d, hipStream_t st) {
   if (a.M <= 0) return UR_OK;
   if (!(d == 32 || d == 64 || d == 128) || a.K % d) return fail(UR_ERR_UNSUPPORTED, "chain_proj_bwd: d=%d K=%d", d, a.K);
-  ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * (double)a.K);
+  ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * (double)a.K, true);
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
     case 32: UR_CHAIN_DISPATCH(32, chain_proj_bwd_kernel, a, grid); break;
@@ -1182,4 +1214,4 @@ int chain_proj_bwd(const ChainProjBwdArgs& a, int d, hipStream_t st) {
 
 }  // namespace ur
 
-extern "C" int ur_sasrec_set_chain(int mask) { return ur::chain_set_enabled(mask < 0 ? 0 : (mask & 7)); }
+extern "C" int ur_sasrec_set_chain(int mask) { return ur::chain_set_enabled(mask < 0 ? 0 : (mask & ur::CHAIN_ALL)); }

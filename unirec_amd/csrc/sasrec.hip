@@ -7,6 +7,7 @@
 //   a   = LN(ctx Wo^T + bo + x)                gemm_nt  EPI_BIAS_RES_LN
 //   h1  = a W1^T + b1                          gemm_nt  EPI_BIAS            (pre-activation kept for backward)
 //   y   = LN(act(h1) W2^T + b2 + a)            gemm_nt  PRO_ACT + EPI_BIAS_RES_LN
+#include <math.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -355,6 +356,20 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     sc->join_pending = false;
     sc->late_join = false;
   }
+  {   // K-major copies of every layer's weights, one launch: the forward chain kernels stream THEM (coalesced B operand, rowchain.hip);
+      // the backward's unfused GEMMs (gemm_nt: C = A W^T) read the same copies -- the weights do not change between the two passes
+    TransposeBatch tb;
+    for (int i = 0; i < c.n_layers; ++i) {
+      const LayerP p = layer_ptrs(dense, lay, i);
+      LayerWs& lw = w.layer[i];
+      if (tb.n + 4 > TransposeBatch::MAX) {
+        if ((rc = transpose_batch(tb, st))) return rc;
+        tb.n = 0;
+      }
+      tb.add(p.wqkv, 3 * d, d, lw.wqkvT); tb.add(p.wo, d, d, lw.woT); tb.add(p.w1, I, d, lw.w1T); tb.add(p.w2, d, I, lw.w2T);
+    }
+    if ((rc = transpose_batch(tb, st))) return rc;
+  }
   const int* tokmap = compact ? w.tok_full : nullptr;   // buffer row -> token id (identity when not compact)
   const DropSpec d_emb = site_spec(c, 0, DROP_SITE_EMBED, nullptr);
   const bool chain = chain_supported(d, I, CHAIN_FWD);   // out-projection + LN + feed-forward + LN (+ next projection) as ONE launch per layer
@@ -367,7 +382,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     ce.seq = item_seq; ce.table = item_table; ce.pos = pos; ce.g0 = dense + lay.off[1]; ce.b0ln = dense + lay.off[2]; ce.eps = c.eps;
     ce.L = c.L; ce.tok = tokmap; ce.drop = d_emb;
     ce.x0 = w.x0; ce.x0hat = w.x0hat; ce.rstd0 = w.rstd0;
-    ce.wn = p0.wqkv + (long long)skip_q * d * d; ce.bn = p0.bqkv + skip_q * d;
+    ce.wnT = w.layer[0].wqkvT + skip_q * d; ce.ldwn = 3 * d; ce.bn = p0.bqkv + skip_q * d;
     ce.outn = w.layer[0].qkv + skip_q * d; ce.ldn = 3 * d; ce.Nn = (3 - skip_q) * d;
     ce.M = M; ce.m_dev = mv;
     if ((rc = chain_embed_proj(ce, d, st))) return rc;
@@ -397,6 +412,22 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       g.A = x; g.lda = d; g.W = p.wqkv + (long long)d * d; g.ldw = d; g.C = lw.qkv + d; g.ldc = 3 * d; g.M = M; g.N = 2 * d; g.K = d;
       g.bias = p.bqkv + d; g.m_dev = mv;
       if (!proj_done && (rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;
+      if (lastrow_supported(B, c.L, d, c.n_heads, I)) {
+        // ONE launch: query projection -> one-query attention -> out-projection + LN -> feed-forward + LN for the B last rows (lastrow.hip)
+        LastRowFwdArgs la{};
+        la.x = x; la.xrow = compact ? w.last_row : nullptr; la.xstride = c.L; la.xoff = c.L - 1;
+        la.qkv = lw.qkv; la.seq = item_seq; la.seq_base = sbase; la.seq_pad = spad;
+        la.wqT = lw.wqkvT; la.ldq = 3 * d; la.bq = p.bqkv; la.woT = lw.woT; la.bo = p.bo; la.g1 = p.g1; la.b1ln = p.b1ln;
+        la.w1T = lw.w1T; la.b1 = p.b1; la.w2T = lw.w2T; la.b2 = p.b2; la.g2 = p.g2; la.b2ln = p.b2ln;
+        la.q_out = w.q_last; la.x_out = compact ? w.x_last : nullptr; la.ctx = lw.ctx; la.lse = w.lse_last;
+        la.a = lw.a; la.ahat = lw.ahat; la.rstd1 = lw.rstd1; la.h1 = lw.h1; la.y = user_emb; la.yhat = lw.yhat; la.rstd2 = lw.rstd2;
+        la.B = B; la.L = c.L; la.I = I; la.act = c.act; la.eps = c.eps;
+        la.sqrt_hd = sqrtf((float)(d / c.n_heads)); la.scale = 1.0f / la.sqrt_hd;
+        la.drop_out = site_spec(c, i, DROP_SITE_OUT, nullptr, c.L, c.L - 1);   // row b of these [B, .] tiles is token (b, L-1)
+        la.drop_ffn = site_spec(c, i, DROP_SITE_FFN, nullptr, c.L, c.L - 1);
+        la.dkey = d_attn.key; la.dthresh = d_attn.thresh; la.dscale = d_attn.scale;
+        return lastrow_fwd(la, d, c.n_heads, st);
+      }
       {
         AttnQProj qp{};
         qp.x = x; qp.xrow = compact ? w.last_row : nullptr; qp.xstride = c.L; qp.xoff = c.L - 1;
@@ -408,7 +439,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
         // (16 workgroups at B = 512: three latency-bound launches of 10 + 7 + 25 us become one)
         ChainFwdArgs ca{};
         ca.ctx = lw.ctx; ca.ldctx = d; ca.res = x_last; ca.ldres = ld_last;
-        ca.wo = p.wo; ca.bo = p.bo; ca.g1 = p.g1; ca.b1ln = p.b1ln; ca.w1 = p.w1; ca.b1 = p.b1; ca.w2 = p.w2; ca.b2 = p.b2;
+        ca.woT = lw.woT; ca.bo = p.bo; ca.g1 = p.g1; ca.b1ln = p.b1ln; ca.w1T = lw.w1T; ca.b1 = p.b1; ca.w2T = lw.w2T; ca.b2 = p.b2;
         ca.g2 = p.g2; ca.b2ln = p.b2ln;
         ca.a = lw.a; ca.ahat = lw.ahat; ca.rstd1 = lw.rstd1; ca.h1 = lw.h1; ca.y = user_emb; ca.yhat = lw.yhat; ca.rstd2 = lw.rstd2;
         ca.M = B; ca.I = I; ca.act = c.act; ca.eps = c.eps;
@@ -442,7 +473,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     if (chain) {
       ChainFwdArgs ca{};
       ca.ctx = lw.ctx; ca.ldctx = d; ca.res = x; ca.ldres = d;
-      ca.wo = p.wo; ca.bo = p.bo; ca.g1 = p.g1; ca.b1ln = p.b1ln; ca.w1 = p.w1; ca.b1 = p.b1; ca.w2 = p.w2; ca.b2 = p.b2;
+      ca.woT = lw.woT; ca.bo = p.bo; ca.g1 = p.g1; ca.b1ln = p.b1ln; ca.w1T = lw.w1T; ca.b1 = p.b1; ca.w2T = lw.w2T; ca.b2 = p.b2;
       ca.g2 = p.g2; ca.b2ln = p.b2ln;
       ca.a = lw.a; ca.ahat = lw.ahat; ca.rstd1 = lw.rstd1; ca.h1 = lw.h1; ca.y = lw.y; ca.yhat = lw.yhat; ca.rstd2 = lw.rstd2;
       ca.M = M; ca.m_dev = mv; ca.I = I; ca.act = c.act; ca.eps = c.eps;
@@ -451,7 +482,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       if (i + 1 < c.n_layers) {   // the next layer's input projection rides along: K,V only when that layer is the last-row one
         const LayerP pn = layer_ptrs(dense, lay, i + 1);
         const int skip_q = (c.last_only && i + 1 == c.n_layers - 1) ? 1 : 0;
-        ca.wn = pn.wqkv + (long long)skip_q * d * d; ca.bn = pn.bqkv + skip_q * d;
+        ca.wnT = w.layer[i + 1].wqkvT + skip_q * d; ca.ldwn = 3 * d; ca.bn = pn.bqkv + skip_q * d;
         ca.outn = w.layer[i + 1].qkv + skip_q * d; ca.ldn = 3 * d; ca.Nn = (3 - skip_q) * d;
         proj_done = true;
       }
@@ -541,7 +572,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   // (UR_LAUNCH_EV) -- the fork behind it then needs no hipEventRecord (a marker packet = ~5 us of idle main stream).  Only in front of a
   // launch that is followed by fork() with queued GEMMs and nothing else on the main stream in between.
   hipEvent_t armed = nullptr;
-  const bool timing_producers = prof_brackets(PC_GEMM_NT) || prof_brackets(PC_ATTN_BWD);   // (their brackets would include the event: see prof_brackets)
+  const bool timing_producers = prof_brackets(PC_GEMM_NT) || prof_brackets(PC_ATTN_BWD) || prof_brackets(PC_CHAIN_SMALL);   // (their brackets would include the event: see prof_brackets)
   auto arm = [&]() {
     if (!timing_producers && sc && n_fork < 24) { armed = sc->ev[n_fork]; g_stop_event = armed; }
   };
@@ -602,8 +633,8 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     UR_LAUNCH_CHECK();
   }
 
-  {   // weight transposes for the activation-gradient GEMMs of every layer, one launch (up to 8 layers per launch);
-      // the same launch zero-fills dense_grad (slots nobody writes: unused position rows, absent parameters)
+  {   // one launch zero-fills dense_grad (slots nobody writes: unused position rows, absent parameters) and the padded positions'
+      // gradient rows (the K-major weight copies the activation-gradient GEMMs read were made by ur_sasrec_fwd)
     TransposeBatch tb;
     if (lay.total % 4 == 0) { tb.zero_ptr = dense_grad; tb.zero_n = lay.total; }
     else UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
@@ -612,17 +643,6 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       tb.zero2_pad = w.seq_pad; tb.zero2_L = c.L; tb.zero2_d = d;
     }
     if (mv) { tb.copy_src = mv; tb.copy_dst = w.m_valid + 16; }
-    for (int i = 0; i < c.n_layers; ++i) {
-      const LayerP p = layer_ptrs(dense, lay, i);
-      LayerWs& lw = w.layer[i];
-      if (tb.n + 4 > TransposeBatch::MAX) {
-        if ((rc = transpose_batch(tb, st))) return rc;
-        tb.n = 0;
-        tb.zero_ptr = nullptr;
-        tb.zero2_ptr = nullptr;
-      }
-      tb.add(p.wqkv, 3 * d, d, lw.wqkvT); tb.add(p.wo, d, d, lw.woT); tb.add(p.w1, I, d, lw.w1T); tb.add(p.w2, d, I, lw.w2T);
-    }
     if ((rc = transpose_batch(tb, st))) return rc;
   }
   // g_x = g_qkv Wqkv + g_ta as a row-chain launch (CHAIN_PROJ); for the bottom layer the backward of the embedding LayerNorm rides in
@@ -630,7 +650,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   auto proj_chain = [&](int i, LayerWs& lw) -> int {
     const int nblk = cdiv(M, chain_rows_per_block(d));
     ChainProjBwdArgs cp{};
-    cp.g = lw.g_qkv; cp.ldg = 3 * d; cp.K = 3 * d; cp.wT = lw.wqkvT; cp.ldw = 3 * d; cp.res = lw.g_ta;
+    cp.g = lw.g_qkv; cp.ldg = 3 * d; cp.K = 3 * d; cp.w = layer_ptrs(dense, lay, i).wqkv; cp.ldw = d; cp.res = lw.g_ta;
     cp.out = w.g_y; cp.M = M; cp.m_dev = mv;
     if (i == 0) {
       float* part0 = w.chain_part + 4LL * c.n_layers * w.chain_blocks * d;
@@ -686,14 +706,42 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       // final layer: only row L-1 carries gradient (d_user_emb); K,V gradients still cover every position
       const int B = c.B;
       GemmArgs g{};
+      if (lastrow_supported(B, c.L, d, c.n_heads, I)) {
+        // ONE launch for the B last rows' chain, the one-query attention backward AND the layer's whole input gradient (lastrow.hip)
+        float* part = w.chain_part + (long long)i * 4 * w.chain_blocks * d;
+        const int nblk = cdiv(B, lastrow_rows_per_block());
+        LastRowBwdArgs lb{};
+        lb.gy = d_user_emb; lb.yhat = lw.yhat; lb.rstd2 = lw.rstd2; lb.g2 = p.g2; lb.h1 = lw.h1;
+        lb.w2 = p.w2; lb.w1 = p.w1; lb.wo = p.wo; lb.wqkv = p.wqkv; lb.ahat = lw.ahat; lb.rstd1 = lw.rstd1; lb.g1 = p.g1;
+        lb.q = w.q_last; lb.ctx = lw.ctx; lb.lse = w.lse_last; lb.qkv = lw.qkv; lb.seq = item_seq; lb.seq_base = sbase; lb.seq_pad = spad;
+        lb.g_tf = lw.g_tf; lb.g_tfd = lw.g_tfd; lb.g_h1 = lw.g_h1; lb.g_ta = lw.g_ta; lb.g_tad = lw.g_tad; lb.dq = w.dq_last;
+        lb.g_qkv = lw.g_qkv; lb.g_x = w.g_y; lb.part = part;
+        lb.B = B; lb.L = c.L; lb.I = I; lb.act = c.act;
+        lb.sqrt_hd = sqrtf((float)(d / c.n_heads)); lb.scale = 1.0f / lb.sqrt_hd;
+        lb.drop_ffn = d_ffn; lb.drop_out = d_out; lb.dkey = d_attn.key; lb.dthresh = d_attn.thresh; lb.dscale = d_attn.scale;
+        arm();
+        if ((rc = lastrow_bwd(lb, d, c.n_heads, st))) return rc;
+        if (rb.full(4) && (rc = reduce_batch(rb, st))) return rc;
+        rb.add(part, 4 * d, nblk, d, d, G + o[14], d);
+        rb.add(part + d, 4 * d, nblk, d, d, G + o[15], d);
+        rb.add(part + 2 * d, 4 * d, nblk, d, d, G + o[8], d);
+        rb.add(part + 3 * d, 4 * d, nblk, d, d, G + o[9], d);
+        if ((rc = tn(lw.g_tfd, d, lw.h1, I, B, d, I, 1, c.act, G + o[12], I, G + o[13]))) return rc;
+        if ((rc = tn(lw.g_h1, I, lw.a, d, B, I, d, 0, 0, G + o[10], d, G + o[11]))) return rc;
+        if ((rc = tn(lw.g_tad, d, lw.ctx, d, B, d, d, 0, 0, G + o[6], d, G + o[7]))) return rc;
+        if ((rc = tn(w.dq_last, d, compact ? w.x_last : x_in + (long long)(c.L - 1) * d, compact ? d : c.L * d, B, d, d, 0, 0, G + o[0], d, G + o[3]))) return rc;
+        if ((rc = tn(lw.g_qkv + d, 3 * d, x_in, d, M, 2 * d, d, 0, 0, G + o[1], d, G + o[4]))) return rc;
+        if ((rc = fork())) return rc;
+        continue;
+      }
       if (chain_last_bwd) {
         // LN backward -> d act GEMM -> d FFN-1 GEMM + residual -> LN backward -> out-projection GEMM of the B last rows as ONE row-chain
         // launch (the full layers' chain_ffn_bwd; four latency-bound launches of 8 + 13 + 19 + 7 us become one)
         float* part = w.chain_part + (long long)i * 4 * w.chain_blocks * d;
         const int nblk = cdiv(B, chain_rows_per_block(d));
         ChainBwdArgs cb{};
-        cb.gy = d_user_emb; cb.yhat = lw.yhat; cb.rstd2 = lw.rstd2; cb.g2 = p.g2; cb.h1 = lw.h1; cb.w2T = lw.w2T; cb.w1T = lw.w1T;
-        cb.ahat = lw.ahat; cb.rstd1 = lw.rstd1; cb.g1 = p.g1; cb.woT = lw.woT;
+        cb.gy = d_user_emb; cb.yhat = lw.yhat; cb.rstd2 = lw.rstd2; cb.g2 = p.g2; cb.h1 = lw.h1; cb.w2 = p.w2; cb.w1 = p.w1;
+        cb.ahat = lw.ahat; cb.rstd1 = lw.rstd1; cb.g1 = p.g1; cb.wo = p.wo;
         cb.g_tf = lw.g_tf; cb.g_h1 = lw.g_h1; cb.g_ta = lw.g_ta; cb.g_ctx = w.g_ctx; cb.part = part;
         cb.M = B; cb.I = I; cb.act = c.act;
         cb.drop_ffn = d_ffn; cb.drop_out = d_out; cb.g_tfd = lw.g_tfd; cb.g_tad = lw.g_tad;
@@ -764,8 +812,8 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       float* part = w.chain_part + (long long)i * 4 * w.chain_blocks * d;
       const int nblk = cdiv(M, chain_rows_per_block(d));
       ChainBwdArgs cb{};
-      cb.gy = w.g_y; cb.yhat = lw.yhat; cb.rstd2 = lw.rstd2; cb.g2 = p.g2; cb.h1 = lw.h1; cb.w2T = lw.w2T; cb.w1T = lw.w1T;
-      cb.ahat = lw.ahat; cb.rstd1 = lw.rstd1; cb.g1 = p.g1; cb.woT = lw.woT;
+      cb.gy = w.g_y; cb.yhat = lw.yhat; cb.rstd2 = lw.rstd2; cb.g2 = p.g2; cb.h1 = lw.h1; cb.w2 = p.w2; cb.w1 = p.w1;
+      cb.ahat = lw.ahat; cb.rstd1 = lw.rstd1; cb.g1 = p.g1; cb.wo = p.wo;
       cb.g_tf = lw.g_tf; cb.g_h1 = lw.g_h1; cb.g_ta = lw.g_ta; cb.g_ctx = w.g_ctx; cb.part = part;
       cb.M = M; cb.m_dev = mv; cb.I = I; cb.act = c.act;
       cb.drop_ffn = d_ffn; cb.drop_out = d_out; cb.g_tfd = lw.g_tfd; cb.g_tad = lw.g_tad;

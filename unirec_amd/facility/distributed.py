@@ -25,6 +25,10 @@ per GPU over ``torch.distributed`` (RCCL on the GPUs):
 
 Parity: W ranks x batch B == 1 rank x the concatenated batch (tests/test_distributed_trainer.py; gloo, CPU-staged on one GPU).
 """
+import collections
+import os
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -71,7 +75,9 @@ class _Look:
 def native_transport_selftest(rank, world, group, dev):
     """One tiny all-to-all and all-reduce through the library's communicators (ops.comm_init) against torch.distributed's: the first RCCL
     traffic of the process goes through a check, not through the first training step.  Every rank gets the same verdict (a MIN
-    all-reduce); on a mismatch the library's communicators are destroyed and the step uses the torch.distributed transport."""
+    all-reduce).  A mismatch RAISES on every rank: the torch.distributed route is several times slower and nothing but
+    ``config.parallelism`` would say so.  UR_ALLOW_TD_FALLBACK=1: warn, destroy the library's communicators and go on over
+    torch.distributed instead."""
     W, cap, d = world, 4, 8
     send = (torch.arange(W * cap * d, device=dev, dtype=torch.float32) + 1000.0 * rank).reshape(W * cap, d)
     got = torch.empty_like(send)
@@ -84,10 +90,14 @@ def native_transport_selftest(rank, world, group, dev):
     ok = torch.tensor([1.0 if torch.equal(got, want) and float(s[0]) == W * (W + 1) / 2 else 0.0], device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if float(ok) != 1.0:
-        import warnings
-        warnings.warn("unirec_amd: the library's RCCL transport failed its self-test; using torch.distributed for the row exchange")
         ops.comm_destroy()
-        return False
+        if os.environ.get("UR_ALLOW_TD_FALLBACK", "0") not in ("", "0"):
+            warnings.warn("unirec_amd: the library's RCCL transport failed its self-test; using torch.distributed for the row exchange "
+                          "(UR_ALLOW_TD_FALLBACK is set)")
+            return False
+        raise RuntimeError("unirec_amd: the library's RCCL transport failed its self-test (all-to-all / all-reduce through ur_comm_* != "
+                           "torch.distributed's).  Set UR_ALLOW_TD_FALLBACK=1 to train over torch.distributed collectives instead "
+                           "(slower), or UR_NATIVE_TRANSPORT=0 to skip the library's communicators altogether.")
     return True
 
 
@@ -151,15 +161,15 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         self._cap_scale = 1               # doubled after a capacity overflow
         # native transport: RCCL through the library's own communicators, on whatever stream the step is on
         self._native = False
-        if world > 1 and dev.type == "cuda" and dist.get_backend(group) == "nccl" and ops.comm_world() >= 0:
+        if (world > 1 and dev.type == "cuda" and dist.get_backend(group) == "nccl" and ops.comm_world() >= 0
+                and os.environ.get("UR_NATIVE_TRANSPORT", "1") not in ("", "0")):
             self._native = bool(ops.comm_init(rank, world, group)) and self._native_selftest(dev)
         self._bufs = {}                   # (table, n, n_a, parity) -> preallocated exchange buffers
         self._look = None                 # _Look of the next batch (plan stream)
         self._parity = 0
         self._out4 = [torch.zeros(4, dtype=torch.float32, device=dev) for _ in range(4)]   # per-step flags (ring: the host reads them late)
-        self._flag_host = [torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4) for _ in range(4)]
-        self._flag_ev = [None] * 4
-        self._flag_batch = [None] * 4
+        self._flag_pool = []              # pinned host copies of a step's flags, recycled
+        self._pending = collections.deque()   # (step, event, host flags, batch, capacity scale of the step): read by _check_overflow
         self._replaying = False
         self.n_overflow = 0
 
@@ -306,28 +316,36 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                 c["caught_up"] = target_t
 
     # ------------------------------------------------------------------ the step
-    def _check_overflow(self):
-        """the flags of the step two steps back (long finished: no stall).  An overflow there -> every rank skipped that step: double
-        the capacity and train the batch again (every rank reads the same all-gathered flags at the same step: lockstep)."""
-        k = (self.t - 1) % 4            # slot of step t - 2 (this is called with self.t = index of the last finished enqueue)
-        ev, b = self._flag_ev[k], self._flag_batch[k]
-        self._flag_ev[k] = self._flag_batch[k] = None
-        if ev is None or self._replaying:
+    def _check_overflow(self, drain=False):
+        """The flags of the steps that finished at least two enqueues ago (long done: no stall), in step order; drain=True: of every
+        step enqueued so far (flush / end of an epoch).  An overflow -> every rank skipped that step: double the capacity and train the
+        batch again (every rank reads the same all-gathered flags at the same point of its loop: lockstep).  The step RIGHT AFTER an
+        overflowed one ran under the same, too small capacity: its entry is next in the queue and is looked at in the same call -- the
+        replay has advanced the step count past it."""
+        if self._replaying:
             return
-        ev.synchronize()
-        if float(self._flag_host[k][3]) > 0:
-            batch, scale_then = b
+        while self._pending and (drain or self._pending[0][0] <= self.t - 1):
+            step, ev, host, batch, scale_then = self._pending.popleft()
+            if ev is not None:
+                ev.synchronize()
+            overflow = float(host[3]) > 0
+            self._flag_pool.append(host)
+            if not overflow:
+                continue
             self.n_overflow += 1
-            if scale_then == self._cap_scale:   # (the step after it may have overflowed under the same, since doubled, capacity)
+            if scale_then == self._cap_scale:   # (not doubled yet by an earlier entry of the same capacity)
                 self._cap_scale *= 2
             self._look = None             # made with the old capacity
-            import warnings
-            warnings.warn(f"row exchange: capacity overflow at step {self.t - 1}; capacity doubled (x{self._cap_scale}), batch re-trained")
+            warnings.warn(f"row exchange: capacity overflow at step {step}; capacity x{self._cap_scale}, batch re-trained")
             self._replaying = True
             try:
                 self.train_step(batch, None)
             finally:
                 self._replaying = False
+
+    def flush(self):
+        self._check_overflow(drain=True)
+        return super().flush()
 
     def train_step(self, batch, next_batch=None):
         """One optimisation step of the ONE model on this rank's batch (a dict of device tensors as the Trainer builds it).
@@ -336,8 +354,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         if not model.training:
             model.train()
         cuda = model.device.type == "cuda"
-        if self.t >= 2:
-            self._check_overflow()
+        self._check_overflow()
         self.zero_grad()
         self.t += 1
         cfg = self._cfg(self.t)
@@ -387,6 +404,10 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         # ---- 4. row gradients: reduce per unique key, scatter to slots (+ this rank's flags in slot 0), owners sum in source-rank order
         owner_grads, out4 = {}, self._out4[self.t % 4]
         first = True
+        if len(tabs) > 1:     # ONE flag row per step rides in the first table's exchange: it must say "overflow" for every table
+            f0 = next(iter(tabs.values()))["bf"]["flags"]
+            for c in list(tabs.values())[1:]:
+                f0.add_(c["bf"]["flags"])
         for name, c in tabs.items():
             ids_a, rows, ids_b, coef, vec, G = self._collect(name)
             sb, bf = c["sb"], c["bf"]
@@ -405,11 +426,14 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         flags_copied = False
 
         def copy_flags():   # the step's flags -> pinned host memory (read two steps later); on the side stream when there is one:
-            k = self.t % 4  # a device-to-host copy in the main queue is 4 us of copy and 8 us of idle queue behind it
-            self._flag_host[k].copy_(out4, non_blocking=True)
-            self._flag_ev[k] = torch.cuda.Event()
-            self._flag_ev[k].record()
-            self._flag_batch[k] = (batch, self._cap_scale)
+            # a device-to-host copy in the main queue is 4 us of copy and 8 us of idle queue behind it
+            host = self._flag_pool.pop() if self._flag_pool else (torch.zeros(4, dtype=torch.float32).pin_memory() if cuda else torch.zeros(4))
+            host.copy_(out4, non_blocking=True)
+            ev = None
+            if cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+            self._pending.append((self.t, ev, host, batch, self._cap_scale))
         # ---- 5./6. updates
         side = None
         if self.grad_clip is None:
@@ -440,7 +464,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                 ops.sasrec_side_publish(late=next_batch is not None, hold=(g, out4) + tuple(getattr(model, "_deferred_reads", ())))
                 model.dense_flat.grad = g
                 object.__setattr__(model, "_deferred_dense_grad", None)
-        if cuda and not flags_copied:
+        if not flags_copied:
             copy_flags()
         if side is None:
             self._dense_main(cfg, bias_ctx, owner_grads, tabs, scale)
@@ -449,7 +473,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         model.dense_flat.grad = None
         for p in self.extra:
             p.grad = None
-        return out4[1]
+        return out4[1].clone()        # (out4 is a slot of a four-step ring: callers keep the loss for a whole epoch)
 
     def _dense_main(self, cfg, bias_ctx, owner_grads, tabs, scale):
         """the dense half on the main stream: ONE flat all-reduce (dense gradients, bias gradients and -- with clipping -- the owners'
@@ -543,9 +567,11 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         ones.  Call flush() first in lazy_dense mode.  Evaluation is not the hot path: the overflow flag is checked on the spot (one
         host synchronisation) and the capacity doubled until the batch fits."""
         model, W = self.model, self.world
+        if self._look is not None and not self._look.waited:   # (a prefetched training batch: its plan-stream work reads `last` and the tables)
+            torch.cuda.current_stream().wait_event(self._look.event)
+            self._look.waited = True
         while True:
-            self._parity ^= 1
-            tabs = self._prepare(batch, self._parity)
+            tabs = self._prepare(batch, 2)          # evaluation has buffers of its own (key 2): a pending lookahead keeps parity 0 / 1
             ovf = torch.stack([c["bf"]["flags"][0:1].to(torch.float32) for c in tabs.values()]).sum().reshape(1)
             if float(self._all_reduce(ovf)) == 0:
                 break
