@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_COPY_GBPS = 6290.0        # MI355X_MICROARCH.md: what a streaming float4 copy reaches (79 % of the spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 
 
@@ -35,6 +36,19 @@ PROF_EVERY = 10   # the dominant kernel class is bracketed with HIP events on ev
 # (ctx, x in; a, ahat, h1, y, yhat, next k, v out), backward chain 7 168 (gy, yhat, h1, ahat in; g_tf, g_h1, g_ta, g_ctx out), projection
 # gradient 3 072 (g_qkv, g_ta, x0hat in; row gradient out) = 19 456 B / row x 25 600 rows
 ALGO_BYTES_PER_STEP = {"gemm_nt": 598.0, "gemm_tn": 247.0, "row_chain": 498.0}
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: a committed PMC summary (tools/pmc_hbm.py writes the digest it was measured on) is only quoted
+    in the line when it was taken on THIS tree's kernels"""
+    import hashlib
+    root = os.path.join(ROOT, "unirec_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -322,6 +336,57 @@ def e2e_leg(a, model, opt, device, steps):
             "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 4), "real_token_fraction": round(float(real), 4), "negatives": a.negatives,
             "pipeline": "device-resident: ur_sample_negatives (uniform, history-rejecting) + ur_device_build_seq per step, inside the clock "
                         "(DeviceBatchLoader: built on the loader's stream two batches ahead); history lengths as the headline's"}
+
+
+def trainer_fit_leg(a, device, steps=200):
+    """The drop-in surface itself: ``Trainer(config, model).fit(loader)`` (unirec/facility/trainer.py:255-357) on a fresh model of the
+    headline shape, fed by the DeviceBatchLoader -- fit()'s own loop (model.train() per step, the loss list, drain(), the epoch's
+    bookkeeping), one epoch of `steps` batches after a short warm-up epoch, wall clock around the whole call."""
+    import logging
+    import numpy as np
+    from unirec_amd.data.rows import DeviceRowBuilder, HistoryCSR
+    from unirec_amd.facility.trainer import DeviceBatchLoader, Trainer
+    from unirec_amd.model.sequential.sasrec import SASRec
+    n_users = 100_000
+    rng = np.random.default_rng(1)
+    lens = np.clip(np.exp(rng.normal(4.25, 1.0, n_users)).astype(np.int64), 5, 1000) + 1
+    ptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    items = rng.integers(1, a.n_items, int(ptr[-1])).astype(np.int32)
+    csr = HistoryCSR.__new__(HistoryCSR)
+    csr.ptr, csr.items, csr.n_users, csr._dev = ptr, items, n_users, None
+    order = np.lexsort((items, np.repeat(np.arange(n_users), lens)))
+    csr.sorted = items[order]
+
+    def loader(n_batches, seed):
+        users = np.random.default_rng(seed).integers(0, n_users, a.batch * n_batches)
+        pos = items[ptr[users] + lens[users] - 1]
+        pairs = torch.from_numpy(np.stack([users, pos.astype(np.int64)], 1)).to(device)
+        bld = DeviceRowBuilder(n_users, a.n_items, a.negatives, a.seq_len, csr, reject_history=True, mask_mode="autoregressive", seq_last=0,
+                               seed=seed, device=str(device))
+        return DeviceBatchLoader(pairs, bld, a.batch, shuffle=False)
+
+    cfg = dict(model_config(a, str(device)), learning_rate=1e-3, epochs=1, optimizer="adam", scheduler="off", early_stop=0,
+               embedding_optimizer=a.table_mode, output_path="/tmp/unirec_amd_bench")
+    logging.getLogger(cfg.get("exp_name", "bench")).setLevel(logging.WARNING)
+    torch.manual_seed(7)
+    model = SASRec(cfg)
+    tr = Trainer(cfg, model)
+    tr.fit(loader(12, 3), valid_data=None, save_model=False)      # warm-up epoch (code objects, workspaces, the collector's freeze)
+    torch.cuda.synchronize()
+    data = loader(steps, 4)
+    t0 = time.perf_counter()
+    tr.fit(data, valid_data=None, save_model=False)
+    tr.optimizer.flush() if hasattr(tr.optimizer, "flush") else None
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    losses = tr.step_losses[-steps:]
+    out = {"ms_per_step": round(dt / steps * 1e3, 4), "examples_per_s": round(a.batch * steps / dt, 1), "steps": steps,
+           "final_loss": round(float(losses[-1]), 6) if losses else None,
+           "what": "Trainer(config, model).fit(DeviceBatchLoader) -- one epoch, wall clock around fit() (its drain() and the lazy rows' flush included)"}
+    del tr, model
+    torch.cuda.empty_cache()
+    return out
 
 
 def variant_leg(a, model, opt, step_fn, device, steps, dropout=None, ids=None):
@@ -708,13 +773,26 @@ def main():
     _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
     collectives = None
     if world > 1:   # per-collective device time and bytes to the peers, 10 extra steps after the timed region (all ranks take part)
-        opt.xchg.profile_start()
+        coll_names = ("a2a_ids", "a2a_rows", "a2a_row_grads", "allreduce")
+        if opt._native:   # the library's RCCL route: its own profiler classes (events on the stream each group runs on)
+            _lib.lib.ur_prof_reset()
+            _lib.lib.ur_prof_set_mask(sum(1 << names.index(n) for n in coll_names))
+            _lib.lib.ur_prof_enable(1)
+        else:
+            opt.xchg.profile_start()
         for i in range(10):
             step_fn(batches[(a.warmup + i) % len(batches)], None)
         barrier()
-        prof = opt.xchg.profile_stop()
-        collectives = {k: {"ms_per_step": round(v["ms"] / 10, 4), "MB_to_peers_per_step": round(v["MB_to_peers"] / 10, 3),
-                           "calls_per_step": v["calls"] / 10} for k, v in prof.items()}
+        if opt._native:
+            _lib.lib.ur_prof_enable(0)
+            pr = prof_read()
+            _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
+            collectives = {n: {"ms_per_step": round(pr[n]["ms"] / 10, 4), "MB_to_peers_per_step": round(pr[n]["work"] / 10 / 1e6, 3),
+                               "calls_per_step": pr[n]["launches"] / 10, "route": "library RCCL communicators"} for n in coll_names}
+        else:
+            prof = opt.xchg.profile_stop()
+            collectives = {k: {"ms_per_step": round(v["ms"] / 10, 4), "MB_to_peers_per_step": round(v["MB_to_peers"] / 10, 3),
+                               "calls_per_step": v["calls"] / 10, "route": "torch.distributed"} for k, v in prof.items()}
     if rank != 0:
         return
 
@@ -752,14 +830,42 @@ def main():
     # figure is the committed rocprofv3 --pmc summary of the SAME workload (profiles/r*_pmc_hbm_traffic.json, the latest:
     # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction); null when the summary is absent
     import glob
-    pmcs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic.json")))   # the latest one
-    pmc = pmcs[-1] if pmcs else ""
+    digest = csrc_digest()
+    pmc, pmc_json, stale = "", None, []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):   # newest first
+        try:
+            js = json.load(open(f))
+        except Exception:    # noqa: BLE001
+            continue
+        if js.get("csrc_digest") == digest:
+            pmc, pmc_json = f, js
+            break
+        stale.append(os.path.basename(f))
+    if roof is not None:
+        roof["traffic_source"] = (f"profiles/{os.path.basename(pmc)} (kernel sources digest {digest}: taken on this tree)" if pmc else
+                                  f"none: no committed PMC summary was taken on this tree's kernels (digest {digest}); newest other: {stale[:1]}")
     if roof is not None and pmc and a.n_items == 100_000_000 and a.batch == 512:
-        per_class = json.load(open(pmc)).get("per_class", {})
+        per_class = pmc_json.get("per_class", {})
         if dom in per_class and per_class[dom]:
             roof["traffic"] = per_class[dom]["hbm_bytes_per_launch"]
             roof["traffic_unit"] = f"HBM bytes per launch (rocprofv3 PMC, profiles/{os.path.basename(pmc)})"
             roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * valid_frac * 1e6 / max(1, c["launches"] / max(1, (a.steps + PROF_EVERY - 1) // PROF_EVERY)))
+    # the whole step against its two floors: algorithmic flops of the MFMA classes (the launchers' own counts from the bracketed warm-up
+    # steps, padded-row counts scaled to the real token rows) at the fp32 MFMA peak, and every kernel's PMC bytes at the rate a
+    # streaming copy reaches on this part
+    n_prof_steps = max(1, n_prof)
+    useful = sum(v["work"] * (valid_frac if k in ("gemm_nt", "gemm_tn", "row_chain") else 1.0) for k, v in warm.items() if k in MFMA_CLASSES) / n_prof_steps / 1e9
+    pmc_bytes = pmc_json.get("hbm_bytes_per_step_all_kernels") if (pmc_json and a.n_items == 100_000_000 and a.batch == 512) else None
+    step_floor = None
+    if useful > 0:
+        mfma_floor_ms = useful / (MFMA_F32_PEAK_TFLOPS * 1e3) * 1e3
+        step_floor = {"useful_gflop": round(useful, 2), "mfma_floor_ms": round(mfma_floor_ms, 4), "frac_of_mfma_floor": round(mfma_floor_ms / ms_per_step, 4),
+                      "pmc_bytes": pmc_bytes,
+                      "hbm_floor_ms": round(pmc_bytes / (HBM_COPY_GBPS * 1e9) * 1e3, 4) if pmc_bytes else None,
+                      "frac_of_hbm_floor": round(pmc_bytes / (HBM_COPY_GBPS * 1e9) * 1e3 / ms_per_step, 4) if pmc_bytes else None,
+                      "note": f"useful_gflop = algorithmic flops of the MFMA classes per step (launcher counts, real token rows); floors at {MFMA_F32_PEAK_TFLOPS} "
+                              f"TFLOP/s fp32 MFMA and {HBM_COPY_GBPS / 1e3:.2f} TB/s (streaming-copy rate of this part); pmc_bytes = all kernels of a step, "
+                              f"from the same summary as roofline.traffic (null when none was taken on this tree)"}
     emb_bytes_per_example = 8 * (L + G) * d * 4   # fwd read + bwd/opt touched rows (w,m,v,grad)
     out = {
         "metric": "training_examples_per_sec", "value": round(ex_per_s, 1), "unit": "examples/s", "n_gpus": world,
@@ -772,6 +878,7 @@ def main():
         "hbm_embedding_GBps_algorithmic": round(ex_per_s * emb_bytes_per_example / 1e9, 2),
         "final_loss": round(final_loss, 6),
         "roofline": roof,
+        "step_floor": step_floor,
         "kernel_time_ms_per_step_warmup": {k: round(v["ms"] / max(1, n_prof), 4) for k, v in warm.items() if v["launches"]},
         # every MFMA-bound class, from the warm-up steps where all classes are bracketed (same definition as `roofline`: algorithmic flops
         # of the real token rows / device time of the class, in situ -- the weight-gradient GEMMs share the CUs with the main stream)
@@ -797,11 +904,11 @@ def main():
         out["steady_state"] = steady_state_leg(a, opt, step_fn, batches, n_leg, barrier)      # (last: it ages the optimizer state)
     if world == 1 and not a.no_gather_bench:
         out["gather_roofline"] = gather_microbench(model.item_embedding.weight.data, device)
-    if world == 1 and (a.all_configs or not a.no_cpu_baseline):
-        del model
-        if world == 1:
-            del opt
+    if world == 1:      # (the legs below build models of their own: the headline's 100 M-row table and its optimizer state go first)
+        del model, opt
         torch.cuda.empty_cache()
+    if world == 1 and not a.no_extra_legs and not a.autograd and not a.sharded_w1 and a.dropout == 0.0:
+        out["trainer_fit"] = trainer_fit_leg(a, device)      # (after the headline's model is gone: a second 100 M-row table + state)
     if world == 1 and a.all_configs:
         out["other_configs"] = {n: other_config(n, device) for n in ("C2", "C3", "C4_encoder", "C4_encoder_h768")}
         out["other_configs"]["C3"]["e2e"] = c3_e2e_leg(device)

@@ -193,7 +193,8 @@ def test_rows_plan_and_reduce_vs_numpy():
                                      (6000, 1500, 5, 300, 128),                            # medium runs (8..64): the pipelined walk inside a lane group
                                      (0, 2048, 4, 3_000_000, 128),
                                      (30000, 2768, 4, 100_000_000, 32),    # n = 32768: largest single-launch plan
-                                     (80000, 20000, 5, 100_000_000, 32)):   # n > 65536: multi-launch plan
+                                     (80000, 20000, 5, 100_000_000, 32),    # n > 65536: multi-launch plan, 4 passes of 8 bits
+                                     (25600, 128128, 1001, 2_000_000, 32)):  # C3's batch: 153 728 ids over 2 M rows, 3 passes
         ids_a = rng.integers(0, n_rows, n_a).astype(np.int32)
         ids_b = rng.integers(0, n_rows, n_b).astype(np.int64)
         rows_a = rng.standard_normal((n_a, d)).astype(np.float32)

@@ -37,9 +37,25 @@ __global__ __launch_bounds__(512) void stream_kernel(const float* __restrict__ W
   } else if constexpr (MODE == 3) {
 #pragma unroll 8
     for (int i = tid; i < NF / 2; i += 512) { const fx2 v = *(const fx2*)(W + 2LL * i); acc.x += v.x; acc.y += v.y; }
-  } else {
+  } else if constexpr (MODE == 4) {
 #pragma unroll 8
     for (int i = tid; i < NF; i += 512) acc.x += W[i];
+  } else {
+    // MODE 5 / 6: lastrow.hip's pattern -- buffer loads of 1 KB k-rows, row stride 2 KB (a [K][512] matrix, this wave's 256-column tile),
+    // 32 rows requested back to back, then consumed; mode 6: 8 rows at a time
+    constexpr int DEPTH = MODE == 5 ? 32 : 8;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
+    const int t1 = wave & 1, k1 = wave >> 1;            // 2 column tiles x 4 K-parts of 32 rows = one [128][512] matrix = 256 KB
+    for (int m = 0; m < NF / (128 * 512); ++m) {        // (NF = 2.5 such matrices: two full ones)
+      for (int r0 = 0; r0 < 32; r0 += DEPTH) {
+        fx4 w[DEPTH];
+#pragma unroll
+        for (int r = 0; r < DEPTH; ++r)
+          w[r] = __builtin_bit_cast(fx4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, ((m * 128 + k1 * 32 + r0 + r) * 512 + t1 * 256) * 4, 0));
+#pragma unroll
+        for (int r = 0; r < DEPTH; ++r) acc += w[r];
+      }
+    }
   }
   const float s = (acc.x + acc.y) + (acc.z + acc.w);
   if (s == 123.456f) out[blockIdx.x * 512 + tid] = s;
@@ -74,6 +90,8 @@ int main() {
     if (run<2>(W, out, G, "contiguous float4")) return 1;
     if (run<3>(W, out, G, "contiguous float2")) return 1;
     if (run<4>(W, out, G, "contiguous dword")) return 1;
+    if (run<5>(W, out, G, "buffer 1 KB rows x32 (512 KB)")) return 1;
+    if (run<6>(W, out, G, "buffer 1 KB rows x8 (512 KB)")) return 1;
   }
   return 0;
 }

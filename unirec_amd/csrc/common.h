@@ -62,7 +62,9 @@ extern thread_local hipEvent_t g_prof_start, g_prof_stop;
 
 // ---- live kernel-class profiler (HIP events recorded on the launch stream; see ur_prof_* in the header)
 enum ProfClass { PC_GEMM_NT = 0, PC_GEMM_TN, PC_ATTN_FWD, PC_ATTN_BWD, PC_ROWOPS, PC_LOSS, PC_SORT, PC_REDUCE, PC_ADAM, PC_GATHER,
-                 PC_GRU, PC_CHAIN, PC_CHAIN_SMALL, PC_MISC, PC_COUNT };
+                 PC_GRU, PC_CHAIN, PC_CHAIN_SMALL, PC_MISC,
+                 PC_A2A_IDS, PC_A2A_ROWS, PC_A2A_GRADS, PC_ALLREDUCE,   // the library's RCCL collectives (exchange.hip): stream time of the group, work = bytes sent to peers
+                 PC_COUNT };
 bool prof_brackets(int cls);   // launches of this class are being bracketed with events right now
 struct ProfScope {
   int cls; hipStream_t st; int slot; bool kernel_events;

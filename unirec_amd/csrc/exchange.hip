@@ -166,9 +166,10 @@ Comm g_comm;
 // sort: on the row communicator it would hold this step's row exchange -- issued later, on the main stream -- until the sort is done.
 // It therefore goes through the SECOND communicator (the dense all-reduce's: that one is issued at the end of the step and waits for an
 // id exchange that finished long before); rows and row gradients keep the first to themselves.
-static int a2a_bytes(const void* send, void* recv, size_t bytes, hipStream_t st, ncclComm_t comm) {
+static int a2a_bytes(const void* send, void* recv, size_t bytes, hipStream_t st, ncclComm_t comm, int prof_class) {
   Rccl* r = rccl();
   const int W = g_comm.world;
+  ProfScope ps(prof_class, st, (double)bytes * (W - 1));   // (events on the caller's stream around the group: what the stream spends in it)
   UR_NCCL(r->GroupStart());
   for (int p = 0; p < W; ++p) {
     UR_NCCL(r->Send((const char*)send + (size_t)p * bytes, bytes, ncclInt8, p, comm, st));
@@ -223,6 +224,7 @@ extern "C" int ur_comm_destroy(void) {
 extern "C" int ur_comm_all_reduce_sum(float* buf, int64_t n, void* stream) {
   UR_REQUIRE(buf && n > 0, UR_ERR_ARG, "ur_comm_all_reduce_sum: bad argument");
   UR_REQUIRE(g_comm.comm, UR_ERR_ARG, "ur_comm_all_reduce_sum: no communicator (ur_comm_init)");
+  ProfScope ps(PC_ALLREDUCE, as_stream(stream), (double)n * 4.0 * 2.0 * (g_comm.world - 1) / g_comm.world);   // (ring all-reduce: 2 (W - 1) / W of the buffer leaves the rank)
   UR_NCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, g_comm.comm2, as_stream(stream)));
   return UR_OK;
 }
@@ -244,7 +246,7 @@ extern "C" int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_u
   if (!transport) return UR_OK;
   UR_REQUIRE(recv_ids, UR_ERR_ARG, "ur_shard_exchange_ids: null receive buffer");
   UR_REQUIRE(g_comm.comm && g_comm.world == world, UR_ERR_ARG, "ur_shard_exchange_ids: communicator of %d ranks, world=%d", g_comm.world, world);
-  return a2a_bytes(send_ids, recv_ids, (size_t)cap * sizeof(int32_t), st, g_comm.comm2);
+  return a2a_bytes(send_ids, recv_ids, (size_t)cap * sizeof(int32_t), st, g_comm.comm2, PC_A2A_IDS);
 }
 
 // (2) rows: gather the requested rows of this rank's shard (req_ids: world * cap local rows, as received) into rows_ws, then
@@ -258,7 +260,7 @@ extern "C" int ur_shard_exchange_rows(const float* table, const int32_t* req_ids
   if (rc || !transport) return rc;
   UR_REQUIRE(compact, UR_ERR_ARG, "ur_shard_exchange_rows: null receive buffer");
   UR_REQUIRE(g_comm.comm && g_comm.world == world, UR_ERR_ARG, "ur_shard_exchange_rows: communicator of %d ranks, world=%d", g_comm.world, world);
-  return a2a_bytes(rows_ws, compact, (size_t)cap * d * sizeof(float), st, g_comm.comm);
+  return a2a_bytes(rows_ws, compact, (size_t)cap * d * sizeof(float), st, g_comm.comm, PC_A2A_ROWS);
 }
 
 // (3) row gradients: uniq_grad [n_uniq, d] (unique order, from ur_rows_reduce) -> slot layout (padding slots: zeros) in send_ws, then
@@ -282,7 +284,7 @@ extern "C" int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_
   if (!transport) return UR_OK;
   UR_REQUIRE(grads_in, UR_ERR_ARG, "ur_shard_exchange_grads: null receive buffer");
   UR_REQUIRE(g_comm.comm && g_comm.world == world, UR_ERR_ARG, "ur_shard_exchange_grads: communicator of %d ranks, world=%d", g_comm.world, world);
-  return a2a_bytes(send_ws, grads_in, (size_t)cap * d * sizeof(float), st, g_comm.comm);
+  return a2a_bytes(send_ws, grads_in, (size_t)cap * d * sizeof(float), st, g_comm.comm, PC_A2A_GRADS);
 }
 
 // after (3): the flags every rank put into slot 0 of its blocks -> out4 = [gradient scale (1 / world, or -1 = skip the step), mean loss,

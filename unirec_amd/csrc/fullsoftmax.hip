@@ -215,10 +215,14 @@ extern "C" int ur_full_softmax_fwd(const float* user_emb, const float* item_tabl
   return UR_OK;
 }
 
-extern "C" int ur_full_softmax_bwd(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d,
-                                   const int64_t* target, const int64_t* user_id, const float* user_bias, const float* item_bias,
-                                   float tau, float score_clip, const float* lse, const float* d_loss, float* d_user_emb,
-                                   float* d_item_table, float* d_item_bias, void* ws, void* stream) {
+// The same over a SHARD of the catalogue (facility/distributed.py: fullsoftmax over a row-sharded table): `item_table` / `item_bias` /
+// `d_item_table` / `d_item_bias` are the n_items rows this rank scores, `target[b]` the row of column b's positive INSIDE them (-1: another
+// rank's), `lse` the log-sum-exp over the WHOLE catalogue (all ranks' partials combined), B every rank's columns.  zero_row0 = 0: row 0
+// of the shard is an item like any other (only global row 0 is the padding row).
+static int fs_bwd_impl(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d,
+                       const int64_t* target, const int64_t* user_id, const float* user_bias, const float* item_bias,
+                       float tau, float score_clip, const float* lse, const float* d_loss, float* d_user_emb,
+                       float* d_item_table, float* d_item_bias, void* ws, void* stream, int zero_row0) {
   int rc = fs_check(user_emb, item_table, n_items, B, d, target, user_id, user_bias, tau, "ur_full_softmax_bwd");
   if (rc) return rc;
   UR_REQUIRE(lse && d_user_emb && d_item_table && ws, UR_ERR_ARG, "ur_full_softmax_bwd: null pointer");
@@ -246,6 +250,22 @@ extern "C" int ur_full_softmax_bwd(const float* user_emb, const float* item_tabl
                        c0 == 0 ? 0 : 1);
     UR_LAUNCH_CHECK();
   }
-  UR_HIP(hipMemsetAsync(d_item_table, 0, sizeof(float) * d, st));   // padding_idx = 0 (reco_abc.py:168)
+  if (zero_row0) UR_HIP(hipMemsetAsync(d_item_table, 0, sizeof(float) * d, st));   // padding_idx = 0 (reco_abc.py:168)
   return UR_OK;
+}
+
+extern "C" int ur_full_softmax_bwd(const float* user_emb, const float* item_table, int64_t n_items, int32_t B, int32_t d,
+                                   const int64_t* target, const int64_t* user_id, const float* user_bias, const float* item_bias,
+                                   float tau, float score_clip, const float* lse, const float* d_loss, float* d_user_emb,
+                                   float* d_item_table, float* d_item_bias, void* ws, void* stream) {
+  return fs_bwd_impl(user_emb, item_table, n_items, B, d, target, user_id, user_bias, item_bias, tau, score_clip, lse, d_loss, d_user_emb,
+                     d_item_table, d_item_bias, ws, stream, 1);
+}
+
+extern "C" int ur_full_softmax_bwd_shard(const float* user_emb, const float* shard_rows, int64_t n_rows, int32_t B, int32_t d,
+                                         const int64_t* target_row, const int64_t* user_id, const float* user_bias, const float* item_bias_rows,
+                                         float tau, float score_clip, const float* lse, const float* d_loss, float* d_user_emb,
+                                         float* d_shard_rows, float* d_item_bias_rows, int32_t zero_row0, void* ws, void* stream) {
+  return fs_bwd_impl(user_emb, shard_rows, n_rows, B, d, target_row, user_id, user_bias, item_bias_rows, tau, score_clip, lse, d_loss,
+                     d_user_emb, d_shard_rows, d_item_bias_rows, ws, stream, zero_row0 ? 1 : 0);
 }

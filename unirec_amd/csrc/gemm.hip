@@ -602,7 +602,6 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
     flops += 2.0 * q.T * q.R * q.Cc;
   }
   const double rows_per = std::max(128.0, work / target);   // token rows one workgroup walks
-  ProfScope ps(PC_GEMM_TN, st, flops);
   int blocks = 0;
   ReduceBatch local;
   ReduceBatch* rb = defer ? defer : &local;
@@ -620,7 +619,10 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
     it.first_block = blocks;
     blocks += (S & 7) == 0 ? S * it.ntr * it.ntc : 8 * cdiv(S * it.ntr * it.ntc, 8);   // (every product starts on XCD 0)
   }
-  hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g, zeros);
+  {
+    ProfScope ps(PC_GEMM_TN, st, flops, true);   // (the launch's own timestamps: on the side stream a recorded bracket would hold the waits of every fork)
+    UR_LAUNCH_EV(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g, zeros);
+  }
   UR_LAUNCH_CHECK();
   for (int i = 0; i < n; ++i) {
     const TnItem& it = g.item[i];

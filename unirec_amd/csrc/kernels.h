@@ -219,6 +219,7 @@ struct LastRowFwdArgs {
   DropSpec drop_out, drop_ffn;          // hidden dropout sites (row id of row b per the spec)
   unsigned dkey, dthresh; float dscale; // dropout on the attention probabilities (dthresh == 0: off): row id (b * H + h) * L + L - 1, column j
   int part_floats;                      // (set by the launcher)
+  unsigned long long* trace;            // (set by the launcher: phase stamps, ur_debug_lr_trace)
 };
 struct LastRowBwdArgs {
   const float* gy;                      // [B, d] d loss / d y
@@ -233,7 +234,14 @@ struct LastRowBwdArgs {
   float* part;                          // [workgroups][4 d]: d gamma2 | d beta2 | d gamma1 | d beta1 partial sums
   int B, L, I, act; float scale, sqrt_hd;
   DropSpec drop_ffn, drop_out; unsigned dkey, dthresh; float dscale;
-  int part_floats;
+  // riders (extra workgroups behind the B / 4 that do the work; all optional): what the backward pass zero-fills before anything else --
+  // zero_ptr[0 .. zero_n) (the dense-gradient buffer), the rows (b, l < zero2_pad[b]) of zero2_ptr [., zero2_L, zero2_d] (zero2_pad
+  // null: all zero2_n floats; counts multiples of 4) -- and one int copied
+  float* zero_ptr; long long zero_n;
+  float* zero2_ptr; long long zero2_n; const int* zero2_pad; int zero2_L, zero2_d;
+  const int* copy_src; int* copy_dst;
+  int part_floats, scr_floats, n_main;  // (set by the launcher)
+  unsigned long long* trace;
 };
 bool lastrow_shape_ok(int B, int L, int d, int H, int inner);
 bool lastrow_supported(int B, int L, int d, int H, int inner);   // shape ok and switched on (CHAIN_LASTROW of the chain mask)

@@ -153,6 +153,95 @@ __device__ __forceinline__ void lr_put(const fx4 (&acc)[RG][VW], float* out, int
     }
 }
 
+// ---- N = D products with 16-byte loads.  D / 4 lanes span a k-row of a K-major [K][D] matrix, so ONE wave instruction covers Q = 256 / D
+// k-rows (D = 128: the two half-waves; D = 64: four quarter-waves): 1 KB per instruction, the texture path's full rate -- with one
+// 8-byte load per lane (a 64-lane row of 128 columns) the same stream ran at 65 GB/s per workgroup against 115 (wstream_probe).
+// Sub-row q = lane / (D / 4) walks ITS contiguous share of the wave's K range, k0 + q * (kn / Q) + s, and is a K-part of its own:
+// LR_NW * Q partial tiles, part index wave * Q + q (the A operand of a 4x4x1 block comes from the block's own four lanes, which share q).
+template <int D> struct LrH { static constexpr int LPR = D / 4, Q = 64 / LPR, NP = LR_NW * Q; };
+template <int D, int SMAX>
+__device__ __forceinline__ void lr_fetch_h(fx4 (&w)[SMAX], const float* Wt, int ldt, int k0, int kn, int lane) {
+  const __amdgpu_buffer_rsrc_t rs = lr_rsrc(Wt);
+  const int ks = kn / LrH<D>::Q;
+  const unsigned voff = (unsigned)((lane / LrH<D>::LPR) * ks * ldt + 4 * (lane % LrH<D>::LPR)) * 4u;
+  const int s0 = k0 * ldt * 4, sl = ldt * 4;
+#pragma unroll
+  for (int k = 0; k < SMAX; ++k)
+    if (k < ks) w[k] = lr_bload<4>(rs, voff, s0 + k * sl);
+}
+template <int D, int SMAX, int RG>
+__device__ __forceinline__ void lr_mma_h(fx4 (&acc)[RG][4], const fx4 (&w)[SMAX], const float* A, int AS, int k0, int kn, int lane) {
+  const int ks = kn / LrH<D>::Q;
+  const float* ap = A + (lane & 3) * AS + k0 + (lane / LrH<D>::LPR) * ks;
+  if constexpr (SMAX % 4 == 0) {
+    if ((ks & 3) == 0) {   // (wave-uniform) the A operand four k at a time
+#pragma unroll
+      for (int k = 0; k < SMAX; k += 4) {
+        if (k < ks) {
+          float4 a4[RG];
+#pragma unroll
+          for (int g = 0; g < RG; ++g) a4[g] = *(const float4*)(ap + 4 * g * AS + k);
+#pragma unroll
+          for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[g][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[g].x, w[k][c], acc[g][c], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[g][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[g].y, w[k + 1][c], acc[g][c], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[g][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[g].z, w[k + 2][c], acc[g][c], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[g][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[g].w, w[k + 3][c], acc[g][c], 0, 0, 0);
+        }
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SMAX; ++k) {
+    if (k < ks) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        const float av = ap[4 * g * AS + k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[g][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, w[k][c], acc[g][c], 0, 0, 0);
+      }
+    }
+  }
+}
+// partial tiles -> out[((wave * Q + q) * R + 4 g + v) * D + 4 * (lane % LPR) + c];  FOLD: the Q sub-rows of the wave are summed with
+// shuffles first and sub-row 0 writes part `wave` (LR_NW parts)
+template <int D, int RG, bool FOLD>
+__device__ __forceinline__ void lr_put_h(fx4 (&acc)[RG][4], float* out, int wave, int lane) {
+  constexpr int R = 4 * RG, LPR = LrH<D>::LPR, Q = LrH<D>::Q;
+  const int q = lane / LPR, c4 = lane % LPR;
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float x = acc[g][c][v];
+#pragma unroll
+          for (int m = LPR; m < 64; m <<= 1) x += __shfl_xor(x, m, 64);
+          acc[g][c][v] = x;
+        }
+    if (q != 0) return;
+  }
+  const int p = FOLD ? wave : wave * Q + q;
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      *(float4*)(out + (long long)(p * R + 4 * g + v) * D + 4 * c4) = make_float4(acc[g][0][v], acc[g][1][v], acc[g][2][v], acc[g][3][v]);
+}
+
 __device__ __forceinline__ float4 lr_act_fwd4(float4 v, int act) {
   switch (act) {   // ONE switch around the four evaluations (rowchain.hip: rc_act_fwd16)
     case UR_ACT_GELU: v.x = act_fwd(v.x, UR_ACT_GELU); v.y = act_fwd(v.y, UR_ACT_GELU); v.z = act_fwd(v.z, UR_ACT_GELU); v.w = act_fwd(v.w, UR_ACT_GELU); break;
@@ -207,7 +296,10 @@ struct LrGeom {
   static constexpr int VWD = D / 64;            // columns per lane of an N = D product (one 64-lane tile spans D)
   static constexpr int XS = D + 4;              // row stride of the [R][D] LDS tiles (rows 4 floats apart in bank space: the four A rows of a block do not collide)
   static constexpr int TPR = D / 4;             // lanes per row in the row-wise epilogues
-  static constexpr int KND = D / LR_NW;         // k-rows per wave of a K = D, N = D product (8 K-parts)
+  static constexpr int KND = D / LR_NW;         // k-rows per wave of a K = D, N = D product
+  static constexpr int SD = KND / LrH<D>::Q;    // ... = load instructions per wave of such a product
+  static constexpr int SI = LR_K2MAX / LrH<D>::Q;   // ... of a K = inner, N = D product (inner <= 512)
+  static constexpr int NP = LrH<D>::NP;         // K-part partial tiles of an N = D product
   static constexpr int WPS = LR_NW / R;         // waves per sequence in the attention phases
   static constexpr int LPH = 64 / H;            // lanes per head in a wave
   static constexpr int KQ = WPS * LPH;          // key parts per sequence: lane (h, q) of wave s walks keys pad + s * LPH + q, + KQ, ...
@@ -218,13 +310,31 @@ struct LrGeom {
   static_assert(T * 2 * HD <= 160, "lastrow: the K / V rows of a lane's keys live in registers");
 };
 
+// L2 warm-up.  The weights of a layer were rewritten a moment ago (the K-major copies by the transpose launch, the weights themselves by
+// the optimizer), so no XCD's L2 holds them, and the workgroups of a launch walk them in lockstep: every line is a miss to memory for all
+// sixteen workgroups of an XCD at the same time, and a CU's 32 KB of L1 lines in flight per ~2 000-cycle miss is 16-19 B / clk -- a 256 KB
+// fragment set took 13 000 cycles to arrive (phase stamps, profiles/r04_b_lastrow_stamps.txt) against 4 000 from a warm L2 (wstream_probe).
+// Each workgroup therefore first TOUCHES its own 1 / nsl share of every matrix (nsl = workgroups per XCD, workgroup g sits on XCD g % 8):
+// together they request every line once, all misses in flight at the same time, and the fragment loads that follow find the lines in L2.
+__device__ __forceinline__ void lr_touch(const float* W, int rows, int rowlen, int ld, int slice, int nsl, int tid, float& sink) {
+  const int total4 = rows * (rowlen / 4), per = (total4 + nsl - 1) / nsl, lo = slice * per, hi = min(total4, lo + per);
+  const int r4 = rowlen / 4;
+  for (int i = lo + tid; i < hi; i += LR_THREADS) {
+    const float4 v = *(const float4*)(W + (long long)(i / r4) * ld + (i % r4) * 4);
+    sink += v.x;
+  }
+}
+
+// phase stamps (ur_debug_lr_trace: a device buffer of [2][1024][32] shader-clock readings, forward then backward; thread 0 of a workgroup)
+#define LR_STAMP(i) do { if (a.trace && tid == 0) a.trace[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
 __device__ __forceinline__ float lr_exp_or0(float m, float M) { return m == -INFINITY ? 0.f : __expf(m - M); }
 
 // ===================================================================================================================== forward
 template <int D, int HD, int RG>
 __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs a) {
   using G = LrGeom<D, HD, RG>;
-  constexpr int R = G::R, H = G::H, XS = G::XS, VWD = G::VWD, KND = G::KND, T = G::T, TPR = G::TPR;
+  constexpr int R = G::R, H = G::H, XS = G::XS, KND = G::KND, T = G::T, TPR = G::TPR, SD = G::SD, SI = G::SI, NP = G::NP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int IS = a.I + 4;
   float* xs = smem;                       // [R][XS] layer input rows (residual of the attention block)
@@ -234,18 +344,51 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
   float* us = as_ + R * XS;               // [R][IS] act(h1)
   float* part = us + R * IS;              // K-part partial tiles: max(8 * R * D, KP1 * R * I)
   float* mrg = part + a.part_floats;      // attention: per (sequence, wave, head) softmax state
+  float* vec = mrg + R * G::WPS * H * (HD + 2);   // bq | bo | g1 | b1ln | b2 | g2 | b2ln (D each) | b1 (I): requested at entry -- read where
+                                          // they are used, behind a barrier, each is a round trip to memory of its own on the critical path
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: it goes into buffer-load scalar offsets)
   const int b0 = blockIdx.x * R;
   const float inv_n = 1.0f / (float)D;
-  // ---- weight fragments of the query projection (K-part = wave) and this lane's keys are requested first
-  typename LrVec<VWD>::T wq[KND];
-  lr_fetch<VWD, KND>(wq, a.wqT, a.ldq, 0, wave * KND, lane);
+  LR_STAMP(0);
+  float sink = 0.f;
+  {
+    const int nsl = min(16, ((int)gridDim.x + 7) / 8), slice = ((int)blockIdx.x / 8) % nsl;
+    lr_touch(a.wqT, D, D, a.ldq, slice, nsl, tid, sink);
+    lr_touch(a.woT, D, D, D, slice, nsl, tid, sink);
+    lr_touch(a.w1T, D, a.I, a.I, slice, nsl, tid, sink);
+    lr_touch(a.w2T, a.I, D, D, slice, nsl, tid, sink);
+  }
+  // ---- requests in the order they are needed: the query projection's fragments (K-part = wave), the input rows (staged at once: the
+  // memory counter is in-order, whatever is requested in front of them is waited for with them), then this lane's K / V rows, which
+  // have the whole query projection to arrive
+  fx4 wq[SD];
+  lr_fetch_h<D, SD>(wq, a.wqT, a.ldq, wave * KND, KND, lane);
   // attention roles
   const int ar = wave / G::WPS, ah = lane % H, akq = (wave % G::WPS) * G::LPH + lane / H;
   const int ab = min(b0 + ar, a.B - 1);
   const long long arow0 = a.seq_base ? (long long)a.seq_base[ab] : (long long)ab * a.L;
   const int apad = a.seq_pad ? a.seq_pad[ab] : 0;
   const int* asq = a.seq + (long long)ab * a.L;
+  float4 vreg = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nvec4 = 7 * TPR + a.I / 4;         // <= LR_THREADS (D <= 128, inner <= 512)
+  if (tid < nvec4) {
+    const int w = tid / TPR;
+    const float* p = w == 0 ? a.bq : w == 1 ? a.bo : w == 2 ? a.g1 : w == 3 ? a.b1ln : w == 4 ? a.b2 : w == 5 ? a.g2 : w == 6 ? a.b2ln : a.b1 - 7 * D;
+    vreg = *(const float4*)(p + (w < 7 ? (tid % TPR) * 4 : tid * 4));
+  }
+  for (int i = tid; i < R * TPR; i += LR_THREADS) {
+    const int r = i / TPR, et = i % TPR, b = b0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < a.B) {
+      const long long xr = a.xrow ? (long long)a.xrow[b] : (long long)b * a.xstride + a.xoff;
+      v = *(const float4*)(a.x + xr * D + et * 4);
+      if (a.x_out) *(float4*)(a.x_out + (long long)b * D + et * 4) = v;
+    }
+    *(float4*)(xs + r * XS + et * 4) = v;
+  }
+  if (tid < nvec4) *(float4*)(vec + tid * 4) = vreg;
+  asm volatile("" ::"v"(sink));     // (the touched values are waited for here, with the input rows: the counter is in-order anyway)
+  __builtin_amdgcn_sched_barrier(0);
   float kr[T][HD], vr[T][HD];
   int sid[T];
   {
@@ -264,35 +407,27 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
     }
   }
   const int any_id = lane < a.L ? asq[lane] : 0;
-  // ---- stage the rows
-  for (int i = tid; i < R * TPR; i += LR_THREADS) {
-    const int r = i / TPR, et = i % TPR, b = b0 + r;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b < a.B) {
-      const long long xr = a.xrow ? (long long)a.xrow[b] : (long long)b * a.xstride + a.xoff;
-      v = *(const float4*)(a.x + xr * D + et * 4);
-      if (a.x_out) *(float4*)(a.x_out + (long long)b * D + et * 4) = v;
-    }
-    *(float4*)(xs + r * XS + et * 4) = v;
-  }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  LR_STAMP(1);
   // ---- 1. q = x Wq^T + bq
   {
-    fx4 acc[RG][VWD];
-    lr_zero<VWD, RG>(acc);
-    lr_mma<VWD, KND, RG>(acc, wq, xs, XS, wave * KND, lane);
-    lr_put<VWD, RG>(acc, part, D, wave * R, 0, lane);
+    fx4 acc[RG][4];
+    lr_zero<4, RG>(acc);
+    lr_mma_h<D, SD, RG>(acc, wq, xs, XS, wave * KND, KND, lane);
+    lr_put_h<D, RG, false>(acc, part, wave, lane);
   }
-  typename LrVec<VWD>::T wo[KND];
-  lr_fetch<VWD, KND>(wo, a.woT, D, 0, wave * KND, lane);
+  fx4 wo[SD];
+  lr_fetch_h<D, SD>(wo, a.woT, D, wave * KND, KND, lane);
   __builtin_amdgcn_sched_barrier(0);
+  LR_STAMP(2);
   __syncthreads();
+  LR_STAMP(3);
   for (int i = tid; i < R * TPR; i += LR_THREADS) {
     const int r = i / TPR, et = i % TPR, b = b0 + r;
-    float4 s = *(const float4*)(a.bq + et * 4);
+    float4 s = *(const float4*)(vec + et * 4);
 #pragma unroll
-    for (int kp = 0; kp < LR_NW; ++kp) {
+    for (int kp = 0; kp < NP; ++kp) {
       const float4 p = *(const float4*)(part + (kp * R + r) * D + et * 4);
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
@@ -300,6 +435,7 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
     if (b < a.B) *(float4*)(a.q_out + (long long)b * D + et * 4) = s;
   }
   __syncthreads();
+  LR_STAMP(4);
   // ---- 2. one-query attention: lane (head h, key part q) walks its keys with a private running softmax; the parts of a head are
   // merged across the lanes of the wave (shuffles) and the waves of the sequence (LDS)
   {
@@ -315,14 +451,20 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
     float m = -INFINITY;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const int j = apad + akq + t * G::KQ;
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < HD; ++c) s = fmaf(q[c], kr[t][c], s);
-      const bool allowed = j < a.L && (literal || sid[t] > 0);
-      sv[t] = allowed ? (literal ? s / a.sqrt_hd + -10000.0f : s * a.scale) : -INFINITY;
-      m = fmaxf(m, sv[t]);
+      sv[t] = s;
     }
+    if (literal) {   // (wave-uniform; the division of the reference's literal path stays out of the common one)
+#pragma unroll
+      for (int t = 0; t < T; ++t) sv[t] = apad + akq + t * G::KQ < a.L ? sv[t] / a.sqrt_hd + -10000.0f : -INFINITY;
+    } else {
+#pragma unroll
+      for (int t = 0; t < T; ++t) sv[t] = (apad + akq + t * G::KQ < a.L && sid[t] > 0) ? sv[t] * a.scale : -INFINITY;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) m = fmaxf(m, sv[t]);
     float l = 0.f, o[HD];
 #pragma unroll
     for (int c = 0; c < HD; ++c) o[c] = 0.f;
@@ -352,6 +494,7 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  LR_STAMP(5);
   // feed-forward 1 fragments: N = I in 256-column tiles (4 columns per lane), the waves left over split K
   const int nt1 = a.I / 256, kp1n = LR_NW / nt1, kn1 = D / kp1n;   // host: nt1 in {1, 2, 4, 8}
   const int t1 = wave % nt1, k1 = wave / nt1;
@@ -359,6 +502,7 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
   lr_fetch_rt<4, D / 4>(w1, a.w1T, a.I, t1 * 256, k1 * kn1, kn1, lane);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  LR_STAMP(6);
   for (int i = tid; i < R * H; i += LR_THREADS) {   // merge the waves of a sequence; ctx and the log-sum-exp
     const int r = i / H, h = i % H, b = b0 + r;
     const float* src = mrg + (r * G::WPS * H + h) * (HD + 2);
@@ -384,19 +528,21 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
     if (b < a.B) a.lse[(long long)b * H + h] = m + __logf(l);
   }
   __syncthreads();
+  LR_STAMP(7);
   // ---- 3. a = LN(drop(ctx Wo^T + bo) + x)
   {
-    fx4 acc[RG][VWD];
-    lr_zero<VWD, RG>(acc);
-    lr_mma<VWD, KND, RG>(acc, wo, cs, XS, wave * KND, lane);
-    lr_put<VWD, RG>(acc, part, D, wave * R, 0, lane);
+    fx4 acc[RG][4];
+    lr_zero<4, RG>(acc);
+    lr_mma_h<D, SD, RG>(acc, wo, cs, XS, wave * KND, KND, lane);
+    lr_put_h<D, RG, false>(acc, part, wave, lane);
   }
   __syncthreads();
+  LR_STAMP(8);
   for (int i = tid; i < R * TPR; i += LR_THREADS) {
     const int r = i / TPR, et = i % TPR, b = b0 + r;
-    float4 x = *(const float4*)(a.bo + et * 4);
+    float4 x = *(const float4*)(vec + D + et * 4);
 #pragma unroll
-    for (int kp = 0; kp < LR_NW; ++kp) {
+    for (int kp = 0; kp < NP; ++kp) {
       const float4 p = *(const float4*)(part + (kp * R + r) * D + et * 4);
       x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
     }
@@ -404,7 +550,7 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
     const float4 rs = *(const float4*)(xs + r * XS + et * 4);
     x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w;
     float4 h, o;
-    const float rstd = lr_ln_row<TPR>(x, *(const float4*)(a.g1 + et * 4), *(const float4*)(a.b1ln + et * 4), inv_n, a.eps, h, o);
+    const float rstd = lr_ln_row<TPR>(x, *(const float4*)(vec + 2 * D + et * 4), *(const float4*)(vec + 3 * D + et * 4), inv_n, a.eps, h, o);
     *(float4*)(as_ + r * XS + et * 4) = o;
     if (b < a.B) {
       *(float4*)(a.ahat + (long long)b * D + et * 4) = h;
@@ -413,6 +559,7 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
     }
   }
   __syncthreads();
+  LR_STAMP(9);
   // ---- 4. h1 = a W1^T + b1, u = act(h1)
   {
     fx4 acc[RG][4];
@@ -421,15 +568,17 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
     lr_put<4, RG>(acc, part, a.I, k1 * R, t1 * 256, lane);
   }
   __builtin_amdgcn_sched_barrier(0);
+  LR_STAMP(10);
   // feed-forward 2 fragments: N = D, K = I over the 8 waves
   const int kn2 = a.I / LR_NW;                                       // host: I % 32 == 0, I <= 8 * LR_K2MAX
-  typename LrVec<VWD>::T w2[LR_K2MAX];
-  lr_fetch_rt<VWD, LR_K2MAX>(w2, a.w2T, D, 0, wave * kn2, kn2, lane);
+  fx4 w2[SI];
+  lr_fetch_h<D, SI>(w2, a.w2T, D, wave * kn2, kn2, lane);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  LR_STAMP(11);
   for (int i = tid; i < R * (a.I / 4); i += LR_THREADS) {
     const int r = i / (a.I / 4), e4 = i % (a.I / 4), b = b0 + r;
-    float4 s = *(const float4*)(a.b1 + e4 * 4);
+    float4 s = *(const float4*)(vec + 7 * D + e4 * 4);
     for (int kp = 0; kp < kp1n; ++kp) {
       const float4 p = *(const float4*)(part + (long long)(kp * R + r) * a.I + e4 * 4);
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
@@ -438,19 +587,21 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
     *(float4*)(us + r * IS + e4 * 4) = lr_act_fwd4(s, a.act);
   }
   __syncthreads();
+  LR_STAMP(12);
   // ---- 5. y = LN(drop(u W2^T + b2) + a)
   {
-    fx4 acc[RG][VWD];
-    lr_zero<VWD, RG>(acc);
-    lr_mma_rt<VWD, LR_K2MAX, RG>(acc, w2, us, IS, wave * kn2, kn2, lane);
-    lr_put<VWD, RG>(acc, part, D, wave * R, 0, lane);
+    fx4 acc[RG][4];
+    lr_zero<4, RG>(acc);
+    lr_mma_h<D, SI, RG>(acc, w2, us, IS, wave * kn2, kn2, lane);
+    lr_put_h<D, RG, false>(acc, part, wave, lane);
   }
   __syncthreads();
+  LR_STAMP(13);
   for (int i = tid; i < R * TPR; i += LR_THREADS) {
     const int r = i / TPR, et = i % TPR, b = b0 + r;
-    float4 x = *(const float4*)(a.b2 + et * 4);
+    float4 x = *(const float4*)(vec + 4 * D + et * 4);
 #pragma unroll
-    for (int kp = 0; kp < LR_NW; ++kp) {
+    for (int kp = 0; kp < NP; ++kp) {
       const float4 p = *(const float4*)(part + (kp * R + r) * D + et * 4);
       x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
     }
@@ -458,13 +609,14 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
     const float4 rs = *(const float4*)(as_ + r * XS + et * 4);
     x.x += rs.x; x.y += rs.y; x.z += rs.z; x.w += rs.w;
     float4 h, o;
-    const float rstd = lr_ln_row<TPR>(x, *(const float4*)(a.g2 + et * 4), *(const float4*)(a.b2ln + et * 4), inv_n, a.eps, h, o);
+    const float rstd = lr_ln_row<TPR>(x, *(const float4*)(vec + 5 * D + et * 4), *(const float4*)(vec + 6 * D + et * 4), inv_n, a.eps, h, o);
     if (b < a.B) {
       *(float4*)(a.yhat + (long long)b * D + et * 4) = h;
       *(float4*)(a.y + (long long)b * D + et * 4) = o;
       if (et == 0) a.rstd2[b] = rstd;
     }
   }
+  LR_STAMP(14);
 }
 
 // ===================================================================================================================== backward
@@ -481,7 +633,7 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_fwd_kernel(LastRowFwdArgs 
 template <int D, int HD, int RG>
 __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs a) {
   using G = LrGeom<D, HD, RG>;
-  constexpr int R = G::R, H = G::H, XS = G::XS, VWD = G::VWD, KND = G::KND, T = G::T, TPR = G::TPR;
+  constexpr int R = G::R, H = G::H, XS = G::XS, VWD = G::VWD, KND = G::KND, T = G::T, TPR = G::TPR, SD = G::SD, SI = G::SI, NP = G::NP;
   constexpr int SS = 2 * H + 4;           // row stride of the S tiles: four consecutive rows on four different bank quads
   constexpr int UPW = 2 * H / LR_NW;      // (q, head) / (g_ctx, head) units per wave in phase 5
   static_assert(2 * H % LR_NW == 0, "lastrow: 2 * heads must be a multiple of the wave count");
@@ -502,10 +654,40 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
   float* gh = scr + a.part_floats;
   float* red = gh + R * IS;               // [R][2][D] column-sum scratch
   float* V = scr;
+  float* aht = scr + a.scr_floats;        // [R][XS] ahat rows | [D] g1 | [R] rstd1: operands of the phase-2 epilogue, requested at entry
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x >= a.n_main) {   // riders: the zero-fills the backward pass starts with (its gradient buffers), 16 floats per thread
+    const long long blk = (long long)blockIdx.x - a.n_main;
+    if (blk == 0 && tid == 0 && a.copy_src) *a.copy_dst = *a.copy_src;
+    const long long z1 = (a.zero_n + 8191) / 8192;
+    const long long i0 = ((blk < z1 ? blk : blk - z1) * LR_THREADS + tid) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long e = i0 + q * 4;
+      if (blk < z1) {
+        if (e < a.zero_n) *(float4*)(a.zero_ptr + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (e < a.zero2_n) {
+        if (a.zero2_pad) {   // only the padded positions of every sequence: the valid rows are written whole by their producer
+          const long long row = e / a.zero2_d;
+          if ((int)(row % a.zero2_L) >= a.zero2_pad[row / a.zero2_L]) continue;
+        }
+        *(float4*)(a.zero2_ptr + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    return;
+  }
   const int b0 = blockIdx.x * R;
   const float inv_d = 1.0f / (float)D;
   float* gpart = a.part + (long long)blockIdx.x * 4 * D;
+  LR_STAMP(0);
+  float sink = 0.f;
+  {
+    const int nsl = min(16, (a.n_main + 7) / 8), slice = ((int)blockIdx.x / 8) % nsl;
+    lr_touch(a.w2, D, a.I, a.I, slice, nsl, tid, sink);
+    lr_touch(a.w1, a.I, D, D, slice, nsl, tid, sink);
+    lr_touch(a.wo, D, D, D, slice, nsl, tid, sink);
+    lr_touch(a.wqkv, 3 * D, D, D, slice, nsl, tid, sink);
+  }
   // ---- fragments of phase 1: N = I in 256-column tiles, the waves left over split K = D
   const int nt1 = a.I / 256, kp1n = LR_NW / nt1, kn1 = D / kp1n;
   const int t1 = wave % nt1, k1 = wave / nt1;
@@ -517,6 +699,14 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
   const bool evalid = erow && eb < a.B;
   const int ebc = min(eb, a.B - 1);
   float4 gtf_keep = make_float4(0.f, 0.f, 0.f, 0.f), gta_keep = gtf_keep;
+  // (operands of the LATER epilogues, requested now: asked for where they are used they are a memory round trip each, behind a barrier)
+  float4 q_ahat = make_float4(0.f, 0.f, 0.f, 0.f), q_g1 = q_ahat;
+  float q_rstd1 = 0.f;
+  if (erow) {
+    q_ahat = *(const float4*)(a.ahat + (long long)ebc * D + ee * 4);
+    q_g1 = *(const float4*)(a.g1 + ee * 4);
+    q_rstd1 = a.rstd1[ebc];
+  }
   // ---- 0. feed-forward LayerNorm backward
   {
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
@@ -539,10 +729,15 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
       *(float4*)(gtf + er * XS + ee * 4) = o;
       *(float4*)(red + (er * 2 + 0) * D + ee * 4) = dg;
       *(float4*)(red + (er * 2 + 1) * D + ee * 4) = db;
+      *(float4*)(aht + er * XS + ee * 4) = q_ahat;      // (parked in LDS: read back by this same thread in phase 2)
+      if (er == 0) *(float4*)(aht + R * XS + ee * 4) = q_g1;
+      if (ee == 0) aht[R * XS + D + er] = q_rstd1;
     }
   }
+  asm volatile("" ::"v"(sink));     // (lr_touch: waited for with the loads of phase 0)
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  LR_STAMP(1);
   for (int i = tid; i < 2 * D; i += LR_THREADS) {   // d gamma2 | d beta2 of this workgroup's rows, fixed order
     float s = 0.f;
 #pragma unroll
@@ -557,34 +752,42 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
     lr_put<4, RG>(acc, part, a.I, k1 * R, t1 * 256, lane);
   }
   __builtin_amdgcn_sched_barrier(0);
+  LR_STAMP(2);
   const int kn2 = a.I / LR_NW;
-  typename LrVec<VWD>::T w1f[LR_K2MAX];
-  lr_fetch_rt<VWD, LR_K2MAX>(w1f, a.w1, D, 0, wave * kn2, kn2, lane);
+  fx4 w1f[SI];
+  lr_fetch_h<D, SI>(w1f, a.w1, D, wave * kn2, kn2, lane);
+  static_assert(R * 512 / 4 <= LR_THREADS, "the g_h1 epilogue is one float4 per thread (inner <= 512)");
+  const bool hrow = tid < R * (a.I / 4);
+  float4 q_h1 = make_float4(0.f, 0.f, 0.f, 0.f);   // this thread's h1 values of the epilogue below, requested ahead of the barrier
+  if (hrow) q_h1 = *(const float4*)(a.h1 + (long long)min(b0 + tid / (a.I / 4), a.B - 1) * a.I + (tid % (a.I / 4)) * 4);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
-  for (int i = tid; i < R * (a.I / 4); i += LR_THREADS) {
-    const int r = i / (a.I / 4), e4 = i % (a.I / 4), b = b0 + r;
+  LR_STAMP(3);
+  if (hrow) {
+    const int r = tid / (a.I / 4), e4 = tid % (a.I / 4), b = b0 + r;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int kp = 0; kp < kp1n; ++kp) {
       const float4 p = *(const float4*)(part + (long long)(kp * R + r) * a.I + e4 * 4);
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
-    const float4 da = lr_act_bwd4(*(const float4*)(a.h1 + (long long)min(b, a.B - 1) * a.I + e4 * 4), a.act);
+    const float4 da = lr_act_bwd4(q_h1, a.act);
     s.x *= da.x; s.y *= da.y; s.z *= da.z; s.w *= da.w;
     if (b < a.B) *(float4*)(a.g_h1 + (long long)b * a.I + e4 * 4) = s;
     *(float4*)(gh + r * IS + e4 * 4) = s;
   }
   __syncthreads();
+  LR_STAMP(4);
   // ---- 2. g_a = g_h1 W1 + g_tf;  g_ta = LNbwd(g_a)
   {
-    fx4 acc[RG][VWD];
-    lr_zero<VWD, RG>(acc);
-    lr_mma_rt<VWD, LR_K2MAX, RG>(acc, w1f, gh, IS, wave * kn2, kn2, lane);
-    lr_put<VWD, RG>(acc, part, D, wave * R, 0, lane);
+    fx4 acc[RG][4];
+    lr_zero<4, RG>(acc);
+    lr_mma_h<D, SI, RG>(acc, w1f, gh, IS, wave * kn2, kn2, lane);
+    lr_put_h<D, RG, false>(acc, part, wave, lane);
   }
   __builtin_amdgcn_sched_barrier(0);   // (the requests below stay behind the MFMAs above: hoisted, their registers overlap the fragments')
-  typename LrVec<VWD>::T wof[KND];
-  lr_fetch<VWD, KND>(wof, a.wo, D, 0, wave * KND, lane);
+  LR_STAMP(5);
+  fx4 wof[SD];
+  lr_fetch_h<D, SD>(wof, a.wo, D, wave * KND, KND, lane);
   // attention roles; this lane's K / V rows and the staging of q / ctx are requested here
   const int ar = wave / G::WPS, ah = lane % H, akq = (wave % G::WPS) * G::LPH + lane / H;
   const int ab = min(b0 + ar, a.B - 1);
@@ -616,17 +819,17 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  LR_STAMP(6);
   {
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
     if (erow) {
       float4 y = gtf_keep;
 #pragma unroll
-      for (int kp = 0; kp < LR_NW; ++kp) {
+      for (int kp = 0; kp < NP; ++kp) {
         const float4 p = *(const float4*)(part + (kp * R + er) * D + ee * 4);
         y.x += p.x; y.y += p.y; y.z += p.z; y.w += p.w;
       }
-      const float4 h = *(const float4*)(a.ahat + (long long)ebc * D + ee * 4);
-      float4 o = lr_ln_bwd_row<TPR>(y, h, *(const float4*)(a.g1 + ee * 4), a.rstd1[ebc], inv_d, dg, db);
+      float4 o = lr_ln_bwd_row<TPR>(y, *(const float4*)(aht + er * XS + ee * 4), *(const float4*)(aht + R * XS + ee * 4), aht[R * XS + D + er], inv_d, dg, db);
       if (!evalid) { o = make_float4(0.f, 0.f, 0.f, 0.f); dg = o; db = o; }
       gta_keep = o;
       if (evalid) *(float4*)(a.g_ta + (long long)eb * D + ee * 4) = o;
@@ -646,25 +849,28 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
     for (int r = 0; r < R; ++r) s += red[(r * 2 + i / D) * D + i % D];
     gpart[2 * D + i] = s;
   }
+  LR_STAMP(7);
   // ---- 3. g_ctx = g_ta Wo
   {
-    fx4 acc[RG][VWD];
-    lr_zero<VWD, RG>(acc);
-    lr_mma<VWD, KND, RG>(acc, wof, gta, XS, wave * KND, lane);
-    lr_put<VWD, RG>(acc, part, D, wave * R, 0, lane);
+    fx4 acc[RG][4];
+    lr_zero<4, RG>(acc);
+    lr_mma_h<D, SD, RG>(acc, wof, gta, XS, wave * KND, KND, lane);
+    lr_put_h<D, RG, false>(acc, part, wave, lane);
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  LR_STAMP(8);
   if (erow) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int kp = 0; kp < LR_NW; ++kp) {
+    for (int kp = 0; kp < NP; ++kp) {
       const float4 p = *(const float4*)(part + (kp * R + er) * D + ee * 4);
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
     *(float4*)(gc + er * XS + ee * 4) = s;
   }
   __syncthreads();
+  LR_STAMP(9);
   // ---- 4. attention backward of the one query: p recomputed from q, K and the saved log-sum-exp
   {
     const bool literal = __ballot(any_id > 0) == 0ull;
@@ -695,9 +901,9 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
           s = fmaf(q[c], kr[t][c], s);
           dp = fmaf(g[c], vr[t][c], dp);
         }
-        const bool allowed = literal || sid[t] > 0;
-        const float sv = literal ? s / a.sqrt_hd + -10000.0f : s * a.scale;
-        const float pj = allowed ? __expf(sv - alse) : 0.f;
+        float pj;
+        if (literal) pj = __expf(s / a.sqrt_hd + -10000.0f - alse);   // (wave-uniform branch)
+        else pj = sid[t] > 0 ? __expf(s * a.scale - alse) : 0.f;
         const float mk = a.dthresh ? drop_mul(rk, (unsigned)j, a.dthresh, a.dscale) : 1.0f;
         const float ds = pj * (mk * dp - Dh) * f, pm = pj * mk;
         srow[t * G::KQ * SS + ah] = ds;
@@ -725,9 +931,10 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
     }
   }
   __builtin_amdgcn_sched_barrier(0);   // (behind the attention phase: its K / V rows are dead, the registers are free)
+  LR_STAMP(10);
   // fragments of phase 5: Wq K-part of this wave; the Wk / Wv rows of this wave's (operand, head) units
-  typename LrVec<VWD>::T wqf[KND];
-  lr_fetch<VWD, KND>(wqf, a.wqkv, D, 0, wave * KND, lane);
+  fx4 wqf[SD];
+  lr_fetch_h<D, SD>(wqf, a.wqkv, D, wave * KND, KND, lane);
   typename LrVec<VWD>::T wuf[UPW][HD];
 #pragma unroll
   for (int q = 0; q < UPW; ++q) {
@@ -737,6 +944,7 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
   }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  LR_STAMP(11);
   if (erow) {
     float4 s = *(const float4*)(dqp + (er * G::WPS) * D + ee * 4);
 #pragma unroll
@@ -748,12 +956,13 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
     if (evalid) *(float4*)(a.dq + (long long)eb * D + ee * 4) = s;
   }
   __syncthreads();
+  LR_STAMP(12);
   // ---- 5. dq Wq (K-parts -> part2) and the per-head row vectors V[r][u][:] (one unit = one head's HD k-rows: already "a K-part")
   {
-    fx4 acc[RG][VWD];
-    lr_zero<VWD, RG>(acc);
-    lr_mma<VWD, KND, RG>(acc, wqf, dqs, XS, wave * KND, lane);
-    lr_put<VWD, RG>(acc, part2, D, wave * R, 0, lane);
+    fx4 acc[RG][4];
+    lr_zero<4, RG>(acc);
+    lr_mma_h<D, SD, RG>(acc, wqf, dqs, XS, wave * KND, KND, lane);
+    lr_put_h<D, RG, true>(acc, part2, wave, lane);      // (sub-rows folded: LR_NW parts -- the LDS budget of this kernel is tight)
   }
 #pragma unroll
   for (int q = 0; q < UPW; ++q) {
@@ -764,6 +973,7 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
     lr_put<VWD, RG>(acc, V + u * D, 2 * H * D, 0, 0, lane);       // V[(4 g + v) * 2H * D + u * D + col]
   }
   __syncthreads();
+  LR_STAMP(13);
   if (erow) {
     float4 s = gta_keep;
 #pragma unroll
@@ -774,6 +984,7 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
     *(float4*)(xl + er * XS + ee * 4) = s;
   }
   __syncthreads();
+  LR_STAMP(14);
   // ---- 6. the sequence's input-gradient rows: [len][2H] x [2H][D], four rows per MFMA; the waves of a sequence alternate row groups
   {
     const bool bvalid = b0 + ar < a.B;
@@ -782,44 +993,60 @@ __global__ __launch_bounds__(LR_THREADS) void lastrow_bwd_kernel(LastRowBwdArgs 
 #pragma unroll
     for (int u = 0; u < 2 * H; ++u) vf[u] = *(const typename LrVec<VWD>::T*)(V + (ar * 2 * H + u) * D + VWD * lane);
     typename LrVec<VWD>::T xlast = *(const typename LrVec<VWD>::T*)(xl + ar * XS + VWD * lane);
-    for (int jg = wave % G::WPS; 4 * jg < len; jg += G::WPS) {
-      fx4 acc[VWD];
+    constexpr int JB = 4;   // row groups in flight per wave: JB * VWD independent accumulator chains (a 4x4x1 MFMA result is ~60 cycles away)
+    for (int jg0 = wave % G::WPS; 4 * jg0 < len; jg0 += JB * G::WPS) {
+      fx4 acc[JB][VWD];
 #pragma unroll
-      for (int c = 0; c < VWD; ++c) acc[c] = fx4{0.f, 0.f, 0.f, 0.f};
-      const float* sp = St + (ar * LR_MAXL + 4 * jg + (lane & 3)) * SS;
+      for (int e = 0; e < JB; ++e)
+#pragma unroll
+        for (int c = 0; c < VWD; ++c) acc[e][c] = fx4{0.f, 0.f, 0.f, 0.f};
+      const float* sp = St + (ar * LR_MAXL + 4 * jg0 + (lane & 3)) * SS;
 #pragma unroll
       for (int u = 0; u < 2 * H; u += 4) {
-        const float4 s4 = *(const float4*)(sp + u);
+        float4 s4[JB];
 #pragma unroll
-        for (int c = 0; c < VWD; ++c) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(s4.x, lr_comp<VWD>(vf[u], c), acc[c], 0, 0, 0);
+        for (int e = 0; e < JB; ++e) s4[e] = *(const float4*)(sp + min(4 * e * G::WPS, LR_MAXL - 4 - 4 * jg0) * SS + u);   // (clamped: rows beyond the tile are not stored below)
 #pragma unroll
-        for (int c = 0; c < VWD; ++c) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(s4.y, lr_comp<VWD>(vf[u + 1], c), acc[c], 0, 0, 0);
+        for (int e = 0; e < JB; ++e)
 #pragma unroll
-        for (int c = 0; c < VWD; ++c) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(s4.z, lr_comp<VWD>(vf[u + 2], c), acc[c], 0, 0, 0);
+          for (int c = 0; c < VWD; ++c) acc[e][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(s4[e].x, lr_comp<VWD>(vf[u], c), acc[e][c], 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < VWD; ++c) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(s4.w, lr_comp<VWD>(vf[u + 3], c), acc[c], 0, 0, 0);
+        for (int e = 0; e < JB; ++e)
+#pragma unroll
+          for (int c = 0; c < VWD; ++c) acc[e][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(s4[e].y, lr_comp<VWD>(vf[u + 1], c), acc[e][c], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < JB; ++e)
+#pragma unroll
+          for (int c = 0; c < VWD; ++c) acc[e][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(s4[e].z, lr_comp<VWD>(vf[u + 2], c), acc[e][c], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < JB; ++e)
+#pragma unroll
+          for (int c = 0; c < VWD; ++c) acc[e][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(s4[e].w, lr_comp<VWD>(vf[u + 3], c), acc[e][c], 0, 0, 0);
       }
       if (bvalid) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int jl = 4 * jg + v;
-          if (jl < len) {
-            float* out = a.g_x + (arow0 + apad + jl) * D + VWD * lane;
-            const bool last = jl == len - 1;
-            if constexpr (VWD == 2) {
-              float2 o = make_float2(acc[0][v], acc[1][v]);
-              if (last) { o.x += xlast[0]; o.y += xlast[1]; }
-              *(float2*)out = o;
-            } else {
-              float o = acc[0][v];
-              if (last) o += xlast;
-              *out = o;
+        for (int e = 0; e < JB; ++e)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int jl = 4 * (jg0 + e * G::WPS) + v;
+            if (jl < len) {
+              float* out = a.g_x + (arow0 + apad + jl) * D + VWD * lane;
+              const bool last = jl == len - 1;
+              if constexpr (VWD == 2) {
+                float2 o = make_float2(acc[e][0][v], acc[e][1][v]);
+                if (last) { o.x += xlast[0]; o.y += xlast[1]; }
+                *(float2*)out = o;
+              } else {
+                float o = acc[e][0][v];
+                if (last) o += xlast;
+                *out = o;
+              }
             }
           }
-        }
       }
     }
   }
+  LR_STAMP(15);
 }
 
 // ===================================================================================================================== launchers
@@ -840,7 +1067,7 @@ static void lr_set_lds(KernelT k, size_t bytes) {
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 static int lr_part_floats(int d, int inner) {   // K-part partial tiles: N = d products (8 parts) and the N = inner product (8 / (inner / 256) parts)
-  const int R = 4, a1 = LR_NW * R * d, a2 = (LR_NW / (inner / 256)) * R * inner;
+  const int R = 4, a1 = LR_NW * (256 / d) * R * d, a2 = (LR_NW / (inner / 256)) * R * inner;   // (N = d products: LR_NW * Q parts, LrH)
   return a1 > a2 ? a1 : a2;
 }
 
@@ -861,13 +1088,16 @@ static int lr_part_floats(int d, int inner) {   // K-part partial tiles: N = d p
     UR_LAUNCH_EV((KERNEL<D_, HD_, 1>), dim3(GRID), dim3(LR_THREADS), (LDS), st, ARGS);               \
   } while (0)
 
+static unsigned long long* g_lr_trace = nullptr;   // [2][1024][32] (ur_debug_lr_trace)
+
 int lastrow_fwd(const LastRowFwdArgs& a0, int d, int H, hipStream_t st) {
   if (a0.B <= 0) return UR_OK;
   if (!lastrow_shape_ok(a0.B, a0.L, d, H, a0.I)) return fail(UR_ERR_UNSUPPORTED, "lastrow_fwd: B=%d L=%d d=%d H=%d inner=%d", a0.B, a0.L, d, H, a0.I);
   LastRowFwdArgs a = a0;
   const int R = 4, hd = d / H;
   a.part_floats = lr_part_floats(d, a.I);
-  const size_t lds = sizeof(float) * ((size_t)4 * R * (d + 4) + (size_t)R * (a.I + 4) + a.part_floats + (size_t)R * (LR_NW / R) * H * (hd + 2));
+  a.trace = (g_lr_trace && cdiv(a.B, R) <= 1024) ? g_lr_trace : nullptr;
+  const size_t lds = sizeof(float) * ((size_t)4 * R * (d + 4) + (size_t)R * (a.I + 4) + a.part_floats + (size_t)R * (LR_NW / R) * H * (hd + 2) + 7 * d + a.I);
   ProfScope ps(PC_CHAIN_SMALL, st, 2.0 * a.B * d * (2.0 * d + 2.0 * a.I) + 4.0 * a.B * a.L * d, true);
   LR_DISPATCH(lastrow_fwd_kernel, a, cdiv(a.B, R), lds);
   UR_LAUNCH_CHECK();
@@ -880,15 +1110,40 @@ int lastrow_bwd(const LastRowBwdArgs& a0, int d, int H, hipStream_t st) {
   LastRowBwdArgs a = a0;
   const int R = 4;
   a.part_floats = lr_part_floats(d, a.I);
+  a.trace = (g_lr_trace && cdiv(a.B, R) <= 1024) ? g_lr_trace + 1024 * 32 : nullptr;
   size_t scr = (size_t)a.part_floats + (size_t)R * (a.I + 4) + (size_t)R * 2 * d;
   const size_t vfl = (size_t)R * 2 * H * d;
   if (vfl > scr) scr = vfl;
+  a.scr_floats = (int)scr;
   const size_t lds = sizeof(float) * ((size_t)7 * R * (d + 4) + (size_t)R * (LR_NW / R) * d + (size_t)LR_NW * R * d +
-                                      (size_t)R * LR_MAXL * (2 * H + 4) + scr);
+                                      (size_t)R * LR_MAXL * (2 * H + 4) + scr + (size_t)R * (d + 4) + d + R);
   ProfScope ps(PC_CHAIN_SMALL, st, 2.0 * a.B * d * (3.0 * d + 2.0 * a.I) + 8.0 * a.B * a.L * d + 4.0 * a.B * a.L * H * d, true);
-  LR_DISPATCH(lastrow_bwd_kernel, a, cdiv(a.B, R), lds);
+  a.n_main = cdiv(a.B, R);
+  const int riders = (a.zero_ptr ? cdiv(a.zero_n, 8192) : 0) + (a.zero2_ptr ? cdiv(a.zero2_n, 8192) : 0);
+  if (!a.zero_ptr) a.zero_n = 0;
+  if (!a.zero2_ptr) a.zero2_n = 0;
+  LR_DISPATCH(lastrow_bwd_kernel, a, a.n_main + (riders > 0 || a.copy_src ? (riders > 0 ? riders : 1) : 0), lds);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }
 
 }  // namespace ur
+
+// debug (not part of the ABI): on = 1 allocates the stamp buffer, every later lastrow launch of the process writes its phase stamps;
+// on = 0 copies [2][1024][32] uint64 (forward, backward; shader clock) to host_out and frees it
+extern "C" int ur_debug_lr_trace(int on, unsigned long long* host_out) {
+  const size_t bytes = (size_t)2 * 1024 * 32 * sizeof(unsigned long long);
+  if (on) {
+    if (!ur::g_lr_trace) {
+      UR_HIP(hipMalloc((void**)&ur::g_lr_trace, bytes));
+      UR_HIP(hipMemset(ur::g_lr_trace, 0, bytes));
+    }
+    return UR_OK;
+  }
+  if (!ur::g_lr_trace) return UR_OK;
+  UR_HIP(hipDeviceSynchronize());
+  if (host_out) UR_HIP(hipMemcpy(host_out, ur::g_lr_trace, bytes, hipMemcpyDeviceToHost));
+  UR_HIP(hipFree(ur::g_lr_trace));
+  ur::g_lr_trace = nullptr;
+  return UR_OK;
+}

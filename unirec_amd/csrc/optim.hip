@@ -177,7 +177,7 @@ extern "C" int ur_prof_reset(void) {
 extern "C" int ur_prof_num_classes(void) { return ur::PC_COUNT; }
 extern "C" const char* ur_prof_class_name(int cls) {
   static const char* names[] = {"gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops", "scorer_loss", "rows_sort", "rows_reduce",
-                                "adam", "gather", "gru", "row_chain", "row_chain_last", "misc"};
+                                "adam", "gather", "gru", "row_chain", "row_chain_last", "misc", "a2a_ids", "a2a_rows", "a2a_row_grads", "allreduce"};
   return (cls >= 0 && cls < ur::PC_COUNT) ? names[cls] : "?";
 }
 extern "C" int ur_prof_read(double* host_ms, int64_t* host_count, double* host_work) {

@@ -121,6 +121,127 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __re
   }
 }
 
+// ---- round 4: the multi-launch sort (n > SMALL_N: C3's 154 K ids per batch) as passes + 2 launches.  Rounds 1-3 ran three launches per
+// 8-bit pass (per-wave histogram, a ONE-workgroup scan of the [digit][wave] table, scatter) + build + three for the heads: 13 launches,
+// 0.34 ms at n = 153 728.  Now:
+//   radix_first_kernel : keys / positions built, the per-wave histogram of pass 0 counted, the tables of the later passes zeroed;
+//   radix_pass_kernel  : a workgroup derives the bases of ITS four waves from the whole (L2-resident, [wave][digit]) table itself --
+//                        digit totals + the prefix over the earlier waves, one coalesced sweep of 256 threads, then a 256-entry scan in
+//                        LDS: no scan launch -- scatters as before (wave-level, stable) and COUNTS the next pass's histogram where the
+//                        keys land (integer atomics on [wave of the destination][next digit]: order-independent totals);
+//   plan_merge_heads_kernel: run heads in one launch (as the small-batch path).
+constexpr int RCH = 1024;    // keys per workgroup of the radix_first / radix_pass kernels: thread t of wave w owns keys w * 256 + it * 64 + lane, it < 4
+
+__global__ __launch_bounds__(256) void radix_first_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
+                                                          long long n_b, unsigned* __restrict__ keys, int* __restrict__ vals, int W,
+                                                          long long n_local, int nchunks, int* __restrict__ hist, int n_later) {
+  __shared__ int cnt[RADIX];
+  const int chunk = blockIdx.x;
+  const long long n = n_a + n_b, base = (long long)chunk * RCH;
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < RCH / 256; ++it) {
+    const long long i = base + it * 256 + threadIdx.x;
+    if (i < n) {
+      const long long id = (i < n_a) ? (long long)ids_a[i] : ids_b[i - n_a];
+      const unsigned key = (W > 1) ? (id ? (unsigned)((id % W) * n_local + id / W + 1) : 0u) : (unsigned)id;   // (build_keys_kernel)
+      keys[i] = key;
+      vals[i] = (int)i;
+      atomicAdd(&cnt[key & 0xFF], 1);
+    }
+  }
+  __syncthreads();
+  hist[(long long)chunk * RADIX + threadIdx.x] = cnt[threadIdx.x];
+  for (int p = 1; p <= n_later; ++p) hist[((long long)p * nchunks + chunk) * RADIX + threadIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(256) void radix_pass_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, long long n,
+                                                         int shift, int nchunks, const int* __restrict__ hist, unsigned* __restrict__ keys_out,
+                                                         int* __restrict__ vals_out, int* __restrict__ hist_next) {
+  __shared__ int cntw[4][RADIX];   // per wave: keys of every digit seen so far (phase A), then the global position of the wave's first such key
+  __shared__ int tot[RADIX];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, chunk = blockIdx.x;
+  const long long base = (long long)chunk * RCH + w * 256;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cntw[q][threadIdx.x] = 0;
+  // ---- phase A (a wave's 256 keys, in order): digit, rank among the equal digits of the 64-key group, keys of that digit before the group
+  unsigned key[4];
+  int val[4], off[4];
+  bool act[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {     // (all four loads first)
+    const long long i = base + it * 64 + lane;
+    act[it] = i < n;
+    key[it] = act[it] ? keys_in[i] : 0u;
+    val[it] = act[it] ? vals_in[i] : 0;
+  }
+  __syncthreads();
+  const unsigned long long lt = lanemask_lt();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const unsigned dgt = (key[it] >> shift) & 0xFF;
+    const unsigned long long m = match_digit(dgt, act[it]);
+    const int rank = __popcll(m & lt);
+    off[it] = act[it] ? cntw[w][dgt] + rank : 0;
+    __builtin_amdgcn_wave_barrier();
+    if (act[it] && rank == 0) cntw[w][dgt] += __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- bases: thread d sums digit d over every chunk (one coalesced sweep of the [chunk][digit] table, eight loads in flight) and notes
+  // the running sum in front of THIS chunk; then an exclusive scan of the 256 totals
+  int pre = 0;
+  {
+    const int dgt = threadIdx.x;
+    int run = 0;
+    for (int c0 = 0; c0 < nchunks; c0 += 8) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = c0 + u < nchunks ? hist[(long long)(c0 + u) * RADIX + dgt] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (c0 + u == chunk) pre = run;
+        run += v[u];
+      }
+    }
+    tot[dgt] = run;
+  }
+  __syncthreads();
+  if (w == 0) {
+    const int a0 = tot[4 * lane], a1 = tot[4 * lane + 1], a2 = tot[4 * lane + 2], a3 = tot[4 * lane + 3];
+    const int sum = a0 + a1 + a2 + a3;
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    const int ex = inc - sum;
+    tot[4 * lane] = ex; tot[4 * lane + 1] = ex + a0; tot[4 * lane + 2] = ex + a0 + a1; tot[4 * lane + 3] = ex + a0 + a1 + a2;
+  }
+  __syncthreads();
+  {   // ---- phase B: thread d turns the four waves' counts of digit d into their starting positions
+    int sum = tot[threadIdx.x] + pre;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = cntw[q][threadIdx.x];
+      cntw[q][threadIdx.x] = sum;
+      sum += t;
+    }
+  }
+  __syncthreads();
+  // ---- phase C: scatter (and count the NEXT pass's histogram where the keys land)
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    if (act[it]) {
+      const int pos = cntw[w][(key[it] >> shift) & 0xFF] + off[it];
+      keys_out[pos] = key[it];
+      vals_out[pos] = val[it];
+      if (hist_next) atomicAdd(&hist_next[(long long)(pos / RCH) * RADIX + ((key[it] >> (shift + 8)) & 0xFF)], 1);
+    }
+  }
+}
+
 // ---- segment heads: count per wave -> scan -> write (uniq_idx, seg_start)
 __global__ __launch_bounds__(256) void heads_count_kernel(const unsigned* __restrict__ keys, long long n, int nwaves,
                                                           int* __restrict__ counts) {
@@ -772,7 +893,7 @@ static PlanWs carve_plan(long long n, char* base) {
   w.keys0 = (unsigned*)take(np * 4);
   w.keys1 = (unsigned*)take(np * 4);
   w.vals_tmp = (int*)take(np * 4);
-  w.hist = (int*)take(nwaves * RADIX * 4);
+  w.hist = (int*)take(4 * nwaves * RADIX * 4);   // one [wave][digit] table per pass (<= 4 passes of 8 bits)
   w.counts = (int*)take((nwaves + 1) * 4);
   w.bytes = o;
   return w;
@@ -967,6 +1088,25 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
     return UR_OK;
   }
   if (owner_counts_dev) UR_HIP(hipMemsetAsync(owner_counts_dev, 0, sizeof(int) * W, st));
+  static const bool old_multi = getenv("UR_PLAN_MULTI_OLD") != nullptr;   // test hook: the three-launches-per-pass sort of rounds 1-3
+  if (!old_multi) {
+    const int nchunks = cdiv(n, RCH);
+    hipLaunchKernelGGL(radix_first_kernel, dim3(nchunks), dim3(256), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b,
+                       kbuf[0], vbuf[0], W, n_local, nchunks, w.hist, passes - 1);
+    UR_LAUNCH_CHECK();
+    int cur = 0;
+    for (int p = 0; p < passes; ++p) {
+      hipLaunchKernelGGL(radix_pass_kernel, dim3(nchunks), dim3(256), 0, st, kbuf[cur], vbuf[cur], n, 8 * p, nchunks,
+                         w.hist + (long long)p * nchunks * RADIX, kbuf[cur ^ 1], vbuf[cur ^ 1],
+                         p + 1 < passes ? w.hist + (long long)(p + 1) * nchunks * RADIX : (int*)nullptr);
+      UR_LAUNCH_CHECK();
+      cur ^= 1;
+    }
+    hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(heads_grid(n)), dim3(1024), 0, st, (const int*)kbuf[cur], (int)n, uniq_idx, seg_start, n_uniq_dev,
+                       owner_counts_dev, n_local);
+    UR_LAUNCH_CHECK();
+    return UR_OK;
+  }
   hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids_a, (long long)n_a, (const long long*)ids_b,
                      (long long)n_b, kbuf[0], vbuf[0], W, n_local);
   UR_LAUNCH_CHECK();

@@ -633,18 +633,19 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     UR_LAUNCH_CHECK();
   }
 
-  {   // one launch zero-fills dense_grad (slots nobody writes: unused position rows, absent parameters) and the padded positions'
-      // gradient rows (the K-major weight copies the activation-gradient GEMMs read were made by ur_sasrec_fwd)
-    TransposeBatch tb;
-    if (lay.total % 4 == 0) { tb.zero_ptr = dense_grad; tb.zero_n = lay.total; }
-    else UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
-    if (compact) {   // padded positions: zero gradient rows (the valid rows are written whole by the bottom layer's projection-gradient launch)
-      tb.zero2_ptr = d_emb_rows; tb.zero2_n = (long long)M * d;
-      tb.zero2_pad = w.seq_pad; tb.zero2_L = c.L; tb.zero2_d = d;
-    }
-    if (mv) { tb.copy_src = mv; tb.copy_dst = w.m_valid + 16; }
-    if ((rc = transpose_batch(tb, st))) return rc;
+  // zero-fills of the pass (dense_grad: slots nobody writes -- unused position rows, absent parameters; the padded positions' gradient
+  // rows) + the backward's own copy of the valid-row count: riders of the last-row layer's launch when that kernel runs (it is the first
+  // launch of the pass and nothing reads any of this before it is done), else a launch of their own
+  TransposeBatch riders;
+  if (lay.total % 4 == 0) { riders.zero_ptr = dense_grad; riders.zero_n = lay.total; }
+  else UR_HIP(hipMemsetAsync(dense_grad, 0, lay.total * sizeof(float), st));
+  if (compact) {   // padded positions: zero gradient rows (the valid rows are written whole by the bottom layer's projection-gradient launch)
+    riders.zero2_ptr = d_emb_rows; riders.zero2_n = (long long)M * d;
+    riders.zero2_pad = w.seq_pad; riders.zero2_L = c.L; riders.zero2_d = d;
   }
+  if (mv) { riders.copy_src = mv; riders.copy_dst = w.m_valid + 16; }
+  const bool riders_ride = c.last_only && lastrow_supported(c.B, c.L, d, c.n_heads, I);
+  if (!riders_ride && (rc = transpose_batch(riders, st))) return rc;
   // g_x = g_qkv Wqkv + g_ta as a row-chain launch (CHAIN_PROJ); for the bottom layer the backward of the embedding LayerNorm rides in
   // the epilogue and the rows go straight to their (padded-layout) places in d_emb_rows
   auto proj_chain = [&](int i, LayerWs& lw) -> int {
@@ -719,6 +720,9 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
         lb.B = B; lb.L = c.L; lb.I = I; lb.act = c.act;
         lb.sqrt_hd = sqrtf((float)(d / c.n_heads)); lb.scale = 1.0f / lb.sqrt_hd;
         lb.drop_ffn = d_ffn; lb.drop_out = d_out; lb.dkey = d_attn.key; lb.dthresh = d_attn.thresh; lb.dscale = d_attn.scale;
+        lb.zero_ptr = riders.zero_ptr; lb.zero_n = riders.zero_n; lb.zero2_ptr = riders.zero2_ptr; lb.zero2_n = riders.zero2_n;
+        lb.zero2_pad = riders.zero2_pad; lb.zero2_L = riders.zero2_L; lb.zero2_d = riders.zero2_d;
+        lb.copy_src = riders.copy_src; lb.copy_dst = riders.copy_dst;
         arm();
         if ((rc = lastrow_bwd(lb, d, c.n_heads, st))) return rc;
         if (rb.full(4) && (rc = reduce_batch(rb, st))) return rc;
