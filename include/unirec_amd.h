@@ -543,6 +543,25 @@ int ur_full_softmax_bwd(const float* user_emb, const float* item_table, int64_t 
                         const int64_t* target, const int64_t* user_id, const float* user_bias, const float* item_bias,
                         float tau, float score_clip, const float* lse, const float* d_loss, float* d_user_emb,
                         float* d_item_table, float* d_item_bias, void* ws, void* stream);
+/* fullsoftmax over a ROW-SHARDED catalogue (the loss of the reference's own multi-GPU test,
+ * tests/test_model/run_ddp_test.sh:28 loss_type='fullsoftmax' under accelerate/DDP: unirec/facility/trainer.py:67,346).  Every rank
+ * holds the user vectors of ALL ranks (all-gather, B = all columns) and scores them against the n_rows rows it owns:
+ *   fwd_shard      : part3[3][B] = per column (running max, sum-exp, score of the positive if target_row[b] >= 0 else 0) over those rows;
+ *   combine_shards : the all-gathered parts[world][3][B_all] folded in rank order -> lse[B_all] (identical on every rank) and
+ *                    loss_out[4] = [mean over this rank's columns col0 .. col0 + B_own of lse - s_target, B_own, update guard, -];
+ *   bwd_shard      : as ur_full_softmax_bwd on the shard's rows with the GLOBAL lse: d_shard_rows [n_rows,d] is this rank's slice of the
+ *                    table gradient summed over every rank's columns (no exchange needed), d_user_emb [B,d] the partial sum over this
+ *                    rank's items (all-reduce / reduce-scatter it); scale 1 / (B tau) times *d_loss; zero_row0: row 0 of shard_rows is
+ *                    global row 0 (padding_idx) and gets a zero gradient. */
+int ur_full_softmax_fwd_shard(const float* user_emb, const float* shard_rows, int64_t n_rows, int32_t B, int32_t d,
+                              const int64_t* target_row, const int64_t* user_id, const float* user_bias,
+                              const float* item_bias_rows, float tau, float score_clip, float* part3, void* ws, void* stream);
+int ur_full_softmax_combine_shards(const float* parts, int32_t world, int32_t B_all, int32_t col0, int32_t B_own, float* lse,
+                                   float* loss_out, void* stream);
+int ur_full_softmax_bwd_shard(const float* user_emb, const float* shard_rows, int64_t n_rows, int32_t B, int32_t d,
+                              const int64_t* target_row, const int64_t* user_id, const float* user_bias, const float* item_bias_rows,
+                              float tau, float score_clip, const float* lse, const float* d_loss, float* d_user_emb,
+                              float* d_shard_rows, float* d_item_bias_rows, int32_t zero_row0, void* ws, void* stream);
 /* dense[uniq_idx[u], :] += rows[u, :] for u < *n_uniq_dev (unique rows: no conflicts) -- folds the encoder's row-sparse
  * gradient into the dense table gradient of a fullsoftmax step. */
 int ur_rows_scatter_add(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* rows, int32_t d,

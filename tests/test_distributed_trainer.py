@@ -88,7 +88,7 @@ def _to(b, dev, lo=None, hi=None):
     return {k: v[lo:hi].to(dev).contiguous() for k, v in b.items()}
 
 
-def _worker(rank, world, port, q, kind, tmp, clip=0.05):
+def _worker(rank, world, port, q, kind, tmp, clip=0.05, loss=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -97,7 +97,7 @@ def _worker(rank, world, port, q, kind, tmp, clip=0.05):
         from unirec_amd.utils.general import get_class_instance, init_seed
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        cfg = _cfg(kind, output_path=tmp, grad_clip_value=clip)
+        cfg = _cfg(kind, output_path=tmp, grad_clip_value=clip, **({"loss_type": loss} if loss else {}))
         B = 16
         full = _batches(4, B * world)
         ev = _batches(2, B * world, seed=9)
@@ -179,13 +179,17 @@ def _worker(rank, world, port, q, kind, tmp, clip=0.05):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,world,clip", [("SASRec", 2, 0.05), ("GRU", 2, 0.05), ("MF", 2, 0.05), ("SASRec", 3, 0.05),
-                                             ("SASRec", 2, 0.0), ("GRU", 2, 0.0)])   # clip 0: the dense half on the encoder's side stream
-def test_trainer_fit_on_w_ranks_equals_one_rank_on_the_concatenated_batches(kind, world, clip, tmp_path):
+@pytest.mark.parametrize("kind,world,clip,loss", [
+    ("SASRec", 2, 0.05, None), ("GRU", 2, 0.05, None), ("MF", 2, 0.05, None), ("SASRec", 3, 0.05, None),
+    ("SASRec", 2, 0.0, None), ("GRU", 2, 0.0, None),     # clip 0: the dense half on the encoder's side stream
+    # the reference's own DDP test trains exactly this loss (tests/test_model/run_ddp_test.sh:28): every item a candidate, the catalogue
+    # row-sharded -- per-shard logsumexp partials, the shard's table gradient final on its owner
+    ("SASRec", 2, 0.05, "fullsoftmax"), ("SASRec", 3, 0.0, "fullsoftmax"), ("MF", 2, 0.05, "fullsoftmax")])
+def test_trainer_fit_on_w_ranks_equals_one_rank_on_the_concatenated_batches(kind, world, clip, loss, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, str(tmp_path), clip)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, str(tmp_path), clip, loss)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

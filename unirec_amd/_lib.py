@@ -137,6 +137,9 @@ SIGNATURES = {
     "ur_full_softmax_workspace_bytes": (I64, [C.c_int32, C.c_int32, I64]),
     "ur_full_softmax_fwd": (C.c_int, [P, P, I64, C.c_int32, C.c_int32, P, P, P, P, C.c_float, C.c_float, P, P, P, P, P]),
     "ur_full_softmax_bwd": (C.c_int, [P, P, I64, C.c_int32, C.c_int32, P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P]),
+    "ur_full_softmax_fwd_shard": (C.c_int, [P, P, I64, C.c_int32, C.c_int32, P, P, P, P, C.c_float, C.c_float, P, P, P]),
+    "ur_full_softmax_combine_shards": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P]),
+    "ur_full_softmax_bwd_shard": (C.c_int, [P, P, I64, C.c_int32, C.c_int32, P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, C.c_int32, P, P]),
     "ur_rows_scatter_add": (C.c_int, [P, P, I64, P, C.c_int32, P, P]),
     "ur_prof_enable": (C.c_int, [C.c_int]),
     "ur_prof_set_mask": (C.c_int, [C.c_uint32]),

@@ -1,5 +1,6 @@
 // Shared device/host helpers for the unirec_amd HIP library (gfx950 / CDNA4 only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -103,6 +104,31 @@ __device__ __forceinline__ float group_max(float v) {
   if constexpr (WIDTH >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
   if constexpr (WIDTH >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
+}
+// ---- arrival at a cross-workgroup hand-off ("whoever arrives last finishes the job").  mode bit 0 (default ON; UR_STRICT_ORDER=0
+// clears it): the counter increment is release-acquire at agent scope, the form the HIP memory model recognises -- buffer_wbl2 sc1 in
+// front of the RMW (the XCD's L2 written back, dirty lines of every other kernel included), buffer_inv sc1 behind it.  One thread per
+// workgroup arrives: measured +2 us on the 0.55 ms step (three interleaved pairs, profiles/r04_c_strict_order.txt) -- rounds 2-3 had
+// priced a __threadfence() by all 256 threads (+20 us) and kept a relaxed counter instead, resting on the ISA-level behaviour that
+// device-scope RMWs are performed at the one point all XCDs agree on and have been performed once their old value has returned.  The
+// DATA still travels in such RMWs (no reader can hit a stale L2 line whatever the order of the arrivals); the counter now carries the
+// ordering the model asks for.  mode >> 1 (UR_ARRIVAL_SKEW_US, test hook): the arriving thread first waits (hash of the workgroup) %
+// skew microseconds, so the last arriver moves over all XCDs (tests/test_handoff_order_gpu.py).
+static inline int ur_arrive_mode() {   // read once per process
+  static const int mode = (getenv("UR_STRICT_ORDER") && !atoi(getenv("UR_STRICT_ORDER")) ? 0 : 1) |
+                          ((getenv("UR_ARRIVAL_SKEW_US") ? atoi(getenv("UR_ARRIVAL_SKEW_US")) : 0) << 1);
+  return mode;
+}
+__device__ __forceinline__ unsigned ur_arrive(unsigned* cnt, int mode) {
+  const int skew = mode >> 1;
+  if (skew > 0) {
+    unsigned h = (blockIdx.x + 1u) * 2654435761u;
+    h ^= h >> 15;
+    const long long t0 = wall_clock64(), wait = (long long)(h % (unsigned)skew) * 100;   // wall_clock64: 100 MHz
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
+  return (mode & 1) ? __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                    : __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 

@@ -132,6 +132,59 @@ __global__ __launch_bounds__(256) void fs_grad_kernel(float* __restrict__ ST, in
   if (lane == 0 && d_item_bias) d_item_bias[c0 + r] = rs;
 }
 
+// s_t[b] = s(b, row trow[b]) of the rows this rank scores (0 where trow[b] < 0: another rank's).  One wave per column.
+__global__ __launch_bounds__(256) void fs_target_score_kernel(const float* __restrict__ U, const float* __restrict__ rows,
+                                                              const long long* __restrict__ trow, int B, int d,
+                                                              const float* __restrict__ item_bias, const long long* __restrict__ user_id,
+                                                              const float* __restrict__ user_bias, float inv_tau, float clip,
+                                                              float* __restrict__ s_t) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const long long t = trow[b];
+  if (t < 0) {
+    if (lane == 0) s_t[b] = 0.f;
+    return;
+  }
+  float acc = 0.f;
+  for (int c = lane; c < d; c += 64) acc = fmaf(U[(long long)b * d + c], rows[t * d + c], acc);
+  acc = wave_sum(acc);
+  bool cl;
+  if (lane == 0) s_t[b] = fs_score(acc, item_bias ? item_bias[t] : 0.f, user_bias ? user_bias[user_id[b]] : 0.f, inv_tau, clip, &cl);
+}
+
+// The W ranks' partials [W][3][BA] = (running max, sum-exp, target score) of every column over that rank's rows, folded in RANK order
+// (the same order on every rank: identical lse everywhere) -> lse[BA]; loss_out = [mean over THIS rank's columns col0 .. col0 + Bown of
+// lse - s_target, Bown, update guard].  Single block.
+__global__ __launch_bounds__(256) void fs_combine_shards_kernel(const float* __restrict__ parts, int W, int BA, int col0, int Bown,
+                                                                float* __restrict__ lse, float* __restrict__ loss_out) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < BA; b += 256) {
+    float m = -INFINITY, l = 0.f, st = 0.f;
+    for (int r = 0; r < W; ++r) {
+      const float* p = parts + (long long)r * 3 * BA;
+      const float pm = p[b], pl = p[BA + b];
+      st += p[2 * BA + b];
+      const float nm = fmaxf(m, pm);
+      if (nm == -INFINITY) continue;
+      l = l * __expf(m - nm) + pl * __expf(pm - nm);
+      m = nm;
+    }
+    const float v = m + logf(l);
+    lse[b] = v;
+    if (b >= col0 && b < col0 + Bown) acc += v - st;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 256; ++i) t += red[i];
+    loss_out[0] = t / (float)Bown;
+    loss_out[1] = (float)Bown;
+    loss_out[2] = t != t ? -1.0f : 1.0f;
+  }
+}
+
 __global__ void fs_axpy_kernel(const float* __restrict__ x, long long n, float* __restrict__ y, int accumulate) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = accumulate ? y[i] + x[i] : x[i];
@@ -211,6 +264,49 @@ extern "C" int ur_full_softmax_fwd(const float* user_emb, const float* item_tabl
     UR_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(fs_loss_kernel, dim3(1), dim3(256), 0, st, w.run_m, w.run_l, target_score, B, lse, loss_out);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+// Forward over a SHARD of the catalogue: part3[3][B] = (max, sum-exp, target score) of every column over the n_rows rows this rank
+// scores (target_row[b] = row of column b's positive inside them, -1: another rank's).  ur_full_softmax_combine_shards folds the
+// all-gathered partials of the W ranks.
+extern "C" int ur_full_softmax_fwd_shard(const float* user_emb, const float* shard_rows, int64_t n_rows, int32_t B, int32_t d,
+                                         const int64_t* target_row, const int64_t* user_id, const float* user_bias,
+                                         const float* item_bias_rows, float tau, float score_clip, float* part3, void* ws, void* stream) {
+  int rc = fs_check(user_emb, shard_rows, n_rows, B, d, target_row, user_id, user_bias, tau, "ur_full_softmax_fwd_shard");
+  if (rc) return rc;
+  UR_REQUIRE(part3 && ws, UR_ERR_ARG, "ur_full_softmax_fwd_shard: null pointer");
+  hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_LOSS, st, 2.0 * B * (double)n_rows * d);
+  FsWs w = fs_carve(B, d, n_rows, (float*)ws);
+  const int B4 = (B + 3) & ~3;
+  hipLaunchKernelGGL(fs_pad_transpose_kernel, dim3(cdiv((long long)B4 * d, 256)), dim3(256), 0, st, user_emb, B, B4, d, w.Upad, w.UT);
+  UR_LAUNCH_CHECK();
+  const long long chunk = std::min<long long>(n_rows, UR_FS_CHUNK);
+  for (long long c0 = 0; c0 < n_rows; c0 += chunk) {
+    const long long C = std::min(chunk, n_rows - c0);
+    if ((rc = fs_scores(w, shard_rows, c0, C, B4, d, st))) return rc;
+    const int nsp = cdiv(C, FS_SPLIT_ROWS);
+    hipLaunchKernelGGL(fs_lse_partial_kernel, dim3(cdiv(B, 256), nsp), dim3(256), 0, st, w.ST, (int)C, B, B4, item_bias_rows, c0,
+                       (const long long*)user_id, user_bias, 1.0f / tau, score_clip, w.part_m, w.part_l);
+    UR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fs_lse_combine_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, w.part_m, w.part_l, nsp, B, part3, part3 + B,
+                       c0 == 0 ? 1 : 0);
+    UR_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(fs_target_score_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, user_emb, shard_rows, (const long long*)target_row, B, d,
+                     item_bias_rows, (const long long*)user_id, user_bias, 1.0f / tau, score_clip, part3 + 2 * (long long)B);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_full_softmax_combine_shards(const float* parts, int32_t world, int32_t B_all, int32_t col0, int32_t B_own, float* lse,
+                                              float* loss_out, void* stream) {
+  UR_REQUIRE(parts && lse && loss_out, UR_ERR_ARG, "ur_full_softmax_combine_shards: null pointer");
+  UR_REQUIRE(world > 0 && B_all > 0 && B_own > 0 && col0 >= 0 && col0 + B_own <= B_all, UR_ERR_ARG, "ur_full_softmax_combine_shards: shape");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(fs_combine_shards_kernel, dim3(1), dim3(256), 0, st, parts, world, B_all, col0, B_own, lse, loss_out);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

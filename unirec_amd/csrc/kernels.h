@@ -153,6 +153,7 @@ struct ChainFwdArgs {
   DropSpec drop_out, drop_ffn;
   float* split_part = nullptr;          // chain_ffn_fwd_split: [row blocks][I/d][rows per block][d] partial dense_2 outputs
   unsigned* split_cnt = nullptr;        //   and one completion counter per row block (zero on entry, reset by the kernel)
+  int arrive_mode = 0;                  //   ur_arrive_mode(): memory order of the arrival / test skew (common.h)
 };
 struct ChainBwdArgs {
   const float* gy;                      // d loss / d y  [M, d]
@@ -168,6 +169,7 @@ struct ChainBwdArgs {
   int I, act;
   float* split_part = nullptr;          // chain_ffn_bwd_split: [row blocks][I/d][rows per block][d] partial d a tiles
   unsigned* split_cnt = nullptr;        //   and one completion counter per row block (zero on entry, reset by the kernel)
+  int arrive_mode = 0;                  //   ur_arrive_mode(): memory order of the arrival / test skew (common.h)
   // hidden dropout (chain_ffn_bwd only; thresh == 0: off): the masks of the forward pass's two sites.  The residual branches take the
   // unmasked g_tf / g_ta; the GEMMs (and the weight-gradient products) take the masked copies, written to g_tfd / g_tad
   DropSpec drop_ffn = {}, drop_out = {};

@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256) void scorer_loss_fused_kernel(UrLossCfg c, flo
                                                                 float* __restrict__ scores, float* __restrict__ loss_rows,
                                                                 float* __restrict__ cnt_rows, float* __restrict__ coef,
                                                                 float* __restrict__ d_user, float* __restrict__ d_user_bias_rows,
-                                                                float* __restrict__ loss_out, unsigned* __restrict__ done_counter) {
+                                                                float* __restrict__ loss_out, unsigned* __restrict__ done_counter,
+                                                                int arrive_mode) {
   extern __shared__ __attribute__((aligned(16))) float sh[];   // [G][d] rows, [G] scores, [G] coefficients, 16 floats of scratch
   const int b = blockIdx.x, G = c.G, d4 = c.d / 4, d = c.d;
   float* rows = sh;
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) void scorer_loss_fused_kernel(UrLossCfg c, flo
   }
   // ---- the batch loss, by whichever workgroup finishes last
   if (threadIdx.x == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = ur_arrive(done_counter, arrive_mode);
     is_last = prev == gridDim.x - 1;
   }
   __syncthreads();
@@ -579,7 +580,7 @@ extern "C" int ur_gather_dot_loss_fwd_bwd(const UrLossCfg* cfg, const float* use
   float* cnt_rows = loss_rows + cfg->B;
 #define GO(T) hipLaunchKernelGGL((scorer_loss_fused_kernel<T>), dim3(cfg->B), dim3(256), lds, st, *cfg, total, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, user_bias, item_bias,                 \
-                                 (const long long*)user_id, scores, loss_rows, cnt_rows, coef, d_user, d_user_bias_rows, loss_out, counter)
+                                 (const long long*)user_id, scores, loss_rows, cnt_rows, coef, d_user, d_user_bias_rows, loss_out, counter, ur_arrive_mode())
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

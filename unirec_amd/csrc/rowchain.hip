@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   }
   __syncthreads();                                         // every thread's part of the tile is out
   if (tid == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(a.split_cnt + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = ur_arrive(a.split_cnt + rb, a.arrive_mode);
     is_last = prev == (unsigned)nc - 1u;
     if (is_last) __hip_atomic_store(a.split_cnt + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   }
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   }
   __syncthreads();
   if (tid == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(a.split_cnt + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = ur_arrive(a.split_cnt + rb, a.arrive_mode);
     is_last = prev == (unsigned)nc - 1u;
     if (is_last) __hip_atomic_store(a.split_cnt + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1152,6 +1152,7 @@ int chain_ffn_fwd_split(const ChainFwdArgs& a0, int d, hipStream_t st) {
   if (!chain_shape_ok(d, a.I) || a.wnT || a.m_dev || nblk > CHAIN_SPLIT_MAX_BLOCKS || !a.split_part)
     return fail(UR_ERR_UNSUPPORTED, "chain_ffn_fwd_split: d=%d inner=%d M=%d", d, a.I, a.M);
   a.split_cnt = chain_split_counters();
+  a.arrive_mode = ur_arrive_mode();
   if (!a.split_cnt) return fail(UR_ERR_HIP, "chain_ffn_fwd_split: no device memory for the completion counters");
   ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I), true);
   const int grid = nblk * (a.I / d);
@@ -1173,6 +1174,7 @@ int chain_ffn_bwd_split(const ChainBwdArgs& a0, int d, hipStream_t st) {
   unsigned* cnt = chain_split_counters();
   if (!cnt) return fail(UR_ERR_HIP, "chain_ffn_bwd_split: no device memory for the completion counters");
   a.split_cnt = cnt + CHAIN_SPLIT_MAX_BLOCKS;   // (the forward kernel's counters are the first half)
+  a.arrive_mode = ur_arrive_mode();
   ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I), true);
   const int grid = nblk * (a.I / d);
   switch (d) {

@@ -134,7 +134,8 @@ constexpr int RCH = 1024;    // keys per workgroup of the radix_first / radix_pa
 
 __global__ __launch_bounds__(256) void radix_first_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
                                                           long long n_b, unsigned* __restrict__ keys, int* __restrict__ vals, int W,
-                                                          long long n_local, int nchunks, int* __restrict__ hist, int n_later) {
+                                                          long long n_local, int nchunks, int* __restrict__ hist, int n_later,
+                                                          unsigned* __restrict__ status, int n_status) {
   __shared__ int cnt[RADIX];
   const int chunk = blockIdx.x;
   const long long n = n_a + n_b, base = (long long)chunk * RCH;
@@ -154,6 +155,8 @@ __global__ __launch_bounds__(256) void radix_first_kernel(const int* __restrict_
   __syncthreads();
   hist[(long long)chunk * RADIX + threadIdx.x] = cnt[threadIdx.x];
   for (int p = 1; p <= n_later; ++p) hist[((long long)p * nchunks + chunk) * RADIX + threadIdx.x] = 0;
+  if (chunk == 0)   // the heads kernel's look-back words (plan_merge_heads_kernel)
+    for (int i = threadIdx.x; i < n_status; i += 256) status[i] = 0u;
 }
 
 __global__ __launch_bounds__(256) void radix_pass_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, long long n,
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(256) void radix_pass_kernel(const unsigned* __restr
                                                          int* __restrict__ vals_out, int* __restrict__ hist_next) {
   __shared__ int cntw[4][RADIX];   // per wave: keys of every digit seen so far (phase A), then the global position of the wave's first such key
   __shared__ int tot[RADIX];
+  __shared__ __attribute__((aligned(16))) int tot4[4][RADIX], pre4[4][RADIX];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, chunk = blockIdx.x;
   const long long base = (long long)chunk * RCH + w * 256;
 #pragma unroll
@@ -176,6 +180,26 @@ __global__ __launch_bounds__(256) void radix_pass_kernel(const unsigned* __restr
     key[it] = act[it] ? keys_in[i] : 0u;
     val[it] = act[it] ? vals_in[i] : 0;
   }
+  // ---- bases: digit totals over every chunk and the running sum in front of THIS chunk.  Wave w sweeps the chunks c = w, w + 4, ...
+  // of the [chunk][digit] table, a lane four digits at a time (one 16-byte load per chunk, a wave reads the chunk's 1 KB row), eight
+  // chunks in flight; the four waves' integer partial sums meet in LDS (19 dependent batches of 4-byte loads per thread before:
+  // the sweep was most of a pass)
+  {
+    int4 run = make_int4(0, 0, 0, 0), prw = make_int4(0, 0, 0, 0);
+    const int4* h4 = (const int4*)hist + lane;
+    for (int c0 = w; c0 < nchunks; c0 += 32) {
+      int4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = c0 + 4 * u < nchunks ? h4[(long long)(c0 + 4 * u) * (RADIX / 4)] : make_int4(0, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        run.x += v[u].x; run.y += v[u].y; run.z += v[u].z; run.w += v[u].w;
+        if (c0 + 4 * u < chunk) { prw.x += v[u].x; prw.y += v[u].y; prw.z += v[u].z; prw.w += v[u].w; }
+      }
+    }
+    *(int4*)&tot4[w][4 * lane] = run;
+    *(int4*)&pre4[w][4 * lane] = prw;
+  }
   __syncthreads();
   const unsigned long long lt = lanemask_lt();
 #pragma unroll
@@ -188,24 +212,9 @@ __global__ __launch_bounds__(256) void radix_pass_kernel(const unsigned* __restr
     if (act[it] && rank == 0) cntw[w][dgt] += __popcll(m);
     __builtin_amdgcn_wave_barrier();
   }
-  // ---- bases: thread d sums digit d over every chunk (one coalesced sweep of the [chunk][digit] table, eight loads in flight) and notes
-  // the running sum in front of THIS chunk; then an exclusive scan of the 256 totals
-  int pre = 0;
-  {
-    const int dgt = threadIdx.x;
-    int run = 0;
-    for (int c0 = 0; c0 < nchunks; c0 += 8) {
-      int v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = c0 + u < nchunks ? hist[(long long)(c0 + u) * RADIX + dgt] : 0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (c0 + u == chunk) pre = run;
-        run += v[u];
-      }
-    }
-    tot[dgt] = run;
-  }
+  __syncthreads();
+  const int pre = pre4[0][threadIdx.x] + pre4[1][threadIdx.x] + pre4[2][threadIdx.x] + pre4[3][threadIdx.x];
+  tot[threadIdx.x] = tot4[0][threadIdx.x] + tot4[1][threadIdx.x] + tot4[2][threadIdx.x] + tot4[3][threadIdx.x];
   __syncthreads();
   if (w == 0) {
     const int a0 = tot[4 * lane], a1 = tot[4 * lane + 1], a2 = tot[4 * lane + 2], a3 = tot[4 * lane + 3];
@@ -970,25 +979,13 @@ __device__ __forceinline__ int heads_block_sum(int v, int* red, int tid) {   // 
 
 __global__ __launch_bounds__(1024) void plan_merge_heads_kernel(const int* __restrict__ keys_sorted, int n, int* __restrict__ uniq_idx,
                                                                int* __restrict__ seg_start, int* __restrict__ n_uniq_dev,
-                                                               int* __restrict__ owner_counts = nullptr, long long n_local = 1) {
+                                                               int* __restrict__ owner_counts = nullptr, long long n_local = 1,
+                                                               unsigned* __restrict__ status = nullptr) {
   __shared__ int red[16];
   __shared__ int wcnt[HEADS_U][16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int span0 = blockIdx.x * HEADS_SPAN;
   auto is_head = [&](int p) { return p < n && (p == 0 || keys_sorted[p] != keys_sorted[p - 1]); };
-  // heads in [0, span0)
-  int c = 0;
-  for (int p0 = 0; p0 < span0; p0 += 8 * 1024) {
-    bool h[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int p = p0 + u * 1024 + tid;
-      h[u] = p < span0 && is_head(p);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) c += h[u] ? 1 : 0;
-  }
-  const int before = heads_block_sum(c, red, tid);
   // this span
   int key[HEADS_U], rank[HEADS_U];
   bool h[HEADS_U];
@@ -998,6 +995,40 @@ __global__ __launch_bounds__(1024) void plan_merge_heads_kernel(const int* __res
     key[u] = p < n ? keys_sorted[p] : 0;
     h[u] = is_head(p);
   }
+  // heads in [0, span0)
+  int c = 0;
+  if (status) {
+    // (the large-batch path, gridDim.x <= 1024: every workgroup publishes the head count of ITS span -- one word, count | ready bit, zeroed by
+    // the sort's first launch -- and thread t waits for workgroup t < blockIdx.x.  The word IS the message, nothing else is ordered by it;
+    // workgroups are dispatched in index order, so a predecessor is running or done.  Counting [0, span0) again in every workgroup, below,
+    // is quadratic in n: 23 us at n = 153 728.)
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < HEADS_U; ++u) mine += h[u] ? 1 : 0;
+    mine = heads_block_sum(mine, red, tid);
+    if (tid == 0) __hip_atomic_store(status + blockIdx.x, 0x80000000u | (unsigned)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < (int)blockIdx.x) {
+      unsigned v;
+      do {
+        v = __hip_atomic_load(status + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(v & 0x80000000u)) __builtin_amdgcn_s_sleep(2);
+      } while (!(v & 0x80000000u));
+      c = (int)(v & 0x7fffffffu);
+    }
+    __syncthreads();   // (red is reused)
+  } else {
+    for (int p0 = 0; p0 < span0; p0 += 8 * 1024) {
+      bool hh[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + u * 1024 + tid;
+        hh[u] = p < span0 && is_head(p);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c += hh[u] ? 1 : 0;
+    }
+  }
+  const int before = heads_block_sum(c, red, tid);
 #pragma unroll
   for (int u = 0; u < HEADS_U; ++u) {
     const unsigned long long m = __ballot(h[u]);
@@ -1074,7 +1105,9 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
   vbuf[passes & 1] = sorted_pos;       // after `passes` swaps the result sits in index (passes & 1)
   vbuf[(passes & 1) ^ 1] = w.vals_tmp;
   static const bool no_small = getenv("UR_PLAN_MULTI") != nullptr;   // test hook: force the multi-launch path
-  if (n <= SMALL_N && !no_small) {
+  // (two 8-bit passes -- tables of up to 65 536 rows, BASELINE config C2 -- are 5 short launches of the radix path: 23 us at n = 28 160 against
+  // 35 for the chunk-sort + bisection path, whose cost does not depend on the key width; 4 passes: 40 against 35)
+  if (n <= SMALL_N && !no_small && passes > 2) {
     const int nch = cdiv(n, MID_CHUNK);
     hipLaunchKernelGGL(plan_chunk_sort_kernel, dim3(nch), dim3(1024), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b, W,
                        n_local, w.keys0, w.vals_tmp, owner_counts_dev);
@@ -1090,9 +1123,9 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
   if (owner_counts_dev) UR_HIP(hipMemsetAsync(owner_counts_dev, 0, sizeof(int) * W, st));
   static const bool old_multi = getenv("UR_PLAN_MULTI_OLD") != nullptr;   // test hook: the three-launches-per-pass sort of rounds 1-3
   if (!old_multi) {
-    const int nchunks = cdiv(n, RCH);
+    const int nchunks = cdiv(n, RCH), hgrid = heads_grid(n);
     hipLaunchKernelGGL(radix_first_kernel, dim3(nchunks), dim3(256), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b,
-                       kbuf[0], vbuf[0], W, n_local, nchunks, w.hist, passes - 1);
+                       kbuf[0], vbuf[0], W, n_local, nchunks, w.hist, passes - 1, (unsigned*)w.counts, hgrid <= 1024 ? hgrid : 0);
     UR_LAUNCH_CHECK();
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
@@ -1102,8 +1135,8 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
       UR_LAUNCH_CHECK();
       cur ^= 1;
     }
-    hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(heads_grid(n)), dim3(1024), 0, st, (const int*)kbuf[cur], (int)n, uniq_idx, seg_start, n_uniq_dev,
-                       owner_counts_dev, n_local);
+    hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(hgrid), dim3(1024), 0, st, (const int*)kbuf[cur], (int)n, uniq_idx, seg_start, n_uniq_dev,
+                       owner_counts_dev, n_local, hgrid <= 1024 ? (unsigned*)w.counts : (unsigned*)nullptr);
     UR_LAUNCH_CHECK();
     return UR_OK;
   }

@@ -131,8 +131,6 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         self.full_rows = {}
         full_rows = dict(full_rows or {})
         dev = model.device
-        if model.loss_type == "fullsoftmax":
-            raise NotImplementedError("fullsoftmax scores every item against every user: not available over a row-sharded table")
         if world > 64:
             raise NotImplementedError("row exchange: at most 64 ranks (the owner-side plan is a 64-way merge)")
         if sync_init and world > 1:      # what DDP's wrap-time parameter broadcast does (trainer.py:67)
@@ -172,6 +170,15 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         self._pending = collections.deque()   # (step, event, host flags, batch, capacity scale of the step): read by _check_overflow
         self._replaying = False
         self.n_overflow = 0
+        # fullsoftmax (the loss of the reference's own DDP test, tests/test_model/run_ddp_test.sh:28): every rank scores ALL ranks' users
+        # against the rows it owns; the table gradient of a shard is complete on its owner (dense over the shard, no exchange)
+        self._fs_dgrad = None
+        if model.loss_type == "fullsoftmax":
+            if "item_embedding" not in self.tables or self.full_rows["item_embedding"] < world:
+                raise NotImplementedError("fullsoftmax under row-sharding needs an item table of at least `world` rows")
+            self._fs_dgrad = torch.zeros_like(self.tables["item_embedding"]["w"])
+            self._fs_w = torch.full((1,), float(world), dtype=torch.float32, device=dev)
+            object.__setattr__(model, "_fs_shard_step", self._fs_shard_step)
 
     def _native_selftest(self, dev):
         return native_transport_selftest(self.rank, self.world, self.xchg.group, dev)
@@ -315,6 +322,64 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                 ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], c["filt"] if c["filt"] is not None else c["own"])
                 c["caught_up"] = target_t
 
+    # ------------------------------------------------------------------ fullsoftmax over the sharded catalogue
+    def _fs_rows(self):
+        """(first local row, count) of the rows this rank scores: every global id it owns INCLUDING id 0 (rank 0's local row 1: the
+        reference's logsumexp runs over all n in [0, n_items), recommender.py:47-50), never the shard's own padding row 0.  Row j of
+        that range is global id j * W + rank."""
+        N, W, r = self.full_rows["item_embedding"], self.world, self.rank
+        if W == 1:
+            return 0, N
+        return 1, ((N - 1 - r) // W + 1 if N - 1 >= r else 0)
+
+    def _fs_shard_step(self, user_emb, target, user_id):
+        """model.forward_backward's fullsoftmax half (reco_abc.py:266-270 under DDP): all-gather the user vectors, per-shard
+        (max, sum-exp, target score) partials, ONE small all-gather of those, the global logsumexp, then the backward over this rank's
+        rows with it: the shard's table gradient is final here (summed over every rank's users), d_user is summed over the ranks.
+        -> (loss_out [loss of THIS rank's users, B, guard, -], d_user [B, d]).  Gradients carry 1 / (B tau): the optimizer's 1 / W
+        (DDP's mean) applies to them like to every other gradient of the step."""
+        model, W, r, x = self.model, self.world, self.rank, self.xchg
+        st = self.tables["item_embedding"]
+        B = user_emb.shape[0]
+        lo, cnt = self._fs_rows()
+        rows = st["w"][lo:lo + cnt]
+        gather = (lambda t: t) if W == 1 else x.all_gather_cat
+        ue_all = gather(user_emb.contiguous())
+        tgt_all = gather(target.to(torch.int64).contiguous())
+        ltgt = tgt_all if W == 1 else torch.where(tgt_all % W == r, tgt_all // W, torch.full_like(tgt_all, -1))
+        uid_all = ub_all = ib_rows = None
+        if model.has_user_bias:      # the value per column travels (user_id may be a compact index on this rank)
+            ub_all = gather(model.user_bias.data.reshape(-1)[user_id.to(torch.int64)].contiguous())
+            uid_all = torch.arange(ub_all.numel(), dtype=torch.int64, device=ub_all.device)
+        if model.has_item_bias:
+            ib = model.item_bias.data.reshape(-1)
+            ib_rows = ib if W == 1 else ib[r::W][:cnt].contiguous()
+        part3, ws = ops.full_softmax_fwd_shard(ue_all, rows, ltgt, uid_all, ub_all, ib_rows, model.tau, model.SCORE_CLIP)
+        parts = part3.view(1, 3, -1) if W == 1 else x.all_gather_cat(part3.view(1, 3, -1))
+        lse, loss_out = ops.full_softmax_combine_shards(parts.contiguous(), r * B, B)
+        d_user_all, d_ib = ops.full_softmax_bwd_shard(ue_all, rows, ltgt, lse, ws, self._fs_dgrad[lo:lo + cnt], uid_all, ub_all, ib_rows,
+                                                      model.tau, model.SCORE_CLIP, d_loss=self._fs_w, zero_row0=(r == 0))
+        d_user_all = self._all_reduce(d_user_all)
+        if model.has_item_bias:
+            g = torch.zeros_like(model.item_bias.data)
+            if W == 1:
+                g.view(-1).copy_(d_ib)
+            else:
+                g.view(-1)[r::W][:cnt] = d_ib
+            model.item_bias.grad = g
+        if model.has_user_bias:
+            model.user_bias.grad = torch.zeros_like(model.user_bias.data)      # softmax is shift invariant along n: exactly 0
+        return loss_out, d_user_all[r * B:(r + 1) * B].contiguous()
+
+    def _update_rows(self, cfg, tabs, owner_grads, dense_shard, scale):
+        for name, c in tabs.items():
+            if name not in dense_shard:
+                st = self.tables[name]
+                ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], c["own"], owner_grads[name], st["last"], scale)
+        for name, dg in dense_shard.items():      # fullsoftmax: every row of the shard moves -> plain dense rule on the shard
+            st = self.tables[name]
+            ops.dense_adam(cfg, st["w"], dg, st["m"], st["v"], scale)
+
     # ------------------------------------------------------------------ the step
     def _check_overflow(self, drain=False):
         """The flags of the steps that finished at least two enqueues ago (long done: no stall), in step order; drain=True: of every
@@ -422,6 +487,12 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                 ops.shard_step_flags(sb["grads_in"], W, c["cap"], out4)
                 first = False
             owner_grads[name] = ops.rows_reduce(c["own"], sb["grads_in"], None, None, 1, d, zero_tail=self.grad_clip is not None)
+        dense_shard = {}
+        if self._fs_dgrad is not None:      # fullsoftmax: the encoder's row-sparse part of the item table's gradient folds into the dense one
+            dense_shard["item_embedding"] = self._fs_dgrad
+            if "item_embedding" in owner_grads:
+                ops.rows_scatter_add(tabs["item_embedding"]["own"], owner_grads["item_embedding"], self._fs_dgrad)
+                self._fs_dgrad[0].zero_()   # (the shard's padding row: requests for id 0 land there)
         scale = out4[0:1]
         flags_copied = False
 
@@ -438,9 +509,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         side = None
         if self.grad_clip is None:
             # rows first (nothing to wait for), then the next batch's owner rows take this step too -- under the dense-gradient stream
-            for name, c in tabs.items():
-                st = self.tables[name]
-                ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], c["own"], owner_grads[name], st["last"], scale)
+            self._update_rows(cfg, tabs, owner_grads, dense_shard, scale)
             nxt = self._look
             if nxt is not None and self.table_mode == "lazy_dense":
                 torch.cuda.current_stream().wait_event(nxt.event)
@@ -467,7 +536,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         if not flags_copied:
             copy_flags()
         if side is None:
-            self._dense_main(cfg, bias_ctx, owner_grads, tabs, scale)
+            self._dense_main(cfg, bias_ctx, owner_grads, tabs, scale, dense_shard)
         object.__setattr__(model, "loss_guard", None)
         model.sparse_grads.clear()
         model.dense_flat.grad = None
@@ -475,7 +544,8 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             p.grad = None
         return out4[1].clone()        # (out4 is a slot of a four-step ring: callers keep the loss for a whole epoch)
 
-    def _dense_main(self, cfg, bias_ctx, owner_grads, tabs, scale):
+    def _dense_main(self, cfg, bias_ctx, owner_grads, tabs, scale, dense_shard=None):
+        dense_shard = dense_shard or {}
         """the dense half on the main stream: ONE flat all-reduce (dense gradients, bias gradients and -- with clipping -- the owners'
         row-gradient norms), the clip coefficient, the updates (and, with clipping, the row updates that waited for the norm)"""
         model = self.model
@@ -494,7 +564,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         if self.grad_clip is not None:   # sum of squares of THIS rank's owned row gradients rides along
             ss = self._scalars[0:1]
             first = True
-            for og in owner_grads.values():
+            for og in [g for n, g in owner_grads.items() if n not in dense_shard] + [dense_shard[n] for n in dense_shard]:
                 ops.sumsq(og, ss, accumulate=not first, ws=self._sumsq_ws)
                 first = False
             if first:
@@ -510,9 +580,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             coef = self._scalars[1:2]
             ops.clip_coef(total, self.grad_clip, coef)
             scale = torch.where(scale < 0, scale, scale * coef)
-            for name, c in tabs.items():
-                st = self.tables[name]
-                ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], c["own"], owner_grads[name], st["last"], scale)
+            self._update_rows(cfg, tabs, owner_grads, dense_shard, scale)
             nxt = self._look
             if nxt is not None and self.table_mode == "lazy_dense":
                 torch.cuda.current_stream().wait_event(nxt.event)

@@ -135,6 +135,8 @@ class BaseRecommender(AbstractRecommender):
                 item_seq_features=None, time_seq=None, session_id=None, reduction=True, return_loss_only=True, max_len=None):
         if self.loss_type == "fullsoftmax" and self.training:
             # label = item_id, candidates = every item (recommender.py:47-50)
+            if getattr(self, "_fs_shard_step", None) is not None:
+                raise NotImplementedError("fullsoftmax over a row-sharded table runs through forward_backward (the Trainer's fused step)")
             if not (reduction and return_loss_only):
                 raise NotImplementedError("fullsoftmax: the [B, n_items] score matrix is never materialised (reduction / return_loss_only)")
             user_emb = self.forward_user_emb(user_id, item_seq, item_seq_len, item_seq_features, time_seq)
@@ -181,7 +183,8 @@ class BaseRecommender(AbstractRecommender):
         """Which batch field indexes which row-sparse table: {table: (explicit-row ids, scorer candidate ids)}; the optimizer
         plans the batch's id sort from it.  Default: MF-style (user table <- user_id, item table <- scorer candidates);
         sequence models add item_seq to the item table."""
-        cand = None if self.loss_type == "fullsoftmax" else "item_id"   # fullsoftmax: the candidates' gradient is dense
+        # fullsoftmax TRAINING: every item is a candidate, their gradient is dense; evaluation scores item_id like every other loss
+        cand = None if (self.loss_type == "fullsoftmax" and self.training) else "item_id"
         spec = {"item_embedding": ("item_seq" if "SeqRecBase" in self.annotations else None, cand)}
         if hasattr(self, "user_embedding"):
             spec["user_embedding"] = ("user_id", None)
@@ -269,8 +272,13 @@ class BaseRecommender(AbstractRecommender):
             ub = self.user_bias.data if self.has_user_bias else None
             ib = self.item_bias.data if self.has_item_bias else None
             uid = user_id if ub is not None else None
-            loss_out, lse, ws = ops.full_softmax_fwd(user_emb, self.item_embedding.weight.data, target, uid, ub, ib, self.tau, self.SCORE_CLIP)
-            self._full_softmax_backward(user_emb, target, lse, ws, user_id, None)
+            shard_step = getattr(self, "_fs_shard_step", None)
+            if shard_step is not None:    # row-sharded catalogue (facility/distributed.py): every rank scores all users against ITS rows
+                loss_out, d_user = shard_step(user_emb, target, user_id)
+                object.__setattr__(self, "_fs_d_user", d_user)
+            else:
+                loss_out, lse, ws = ops.full_softmax_fwd(user_emb, self.item_embedding.weight.data, target, uid, ub, ib, self.tau, self.SCORE_CLIP)
+                self._full_softmax_backward(user_emb, target, lse, ws, user_id, None)
             self._encode_backward(state, self._fs_d_user)
             object.__setattr__(self, "loss_guard", loss_out[2:3])
             return loss_out[0]

@@ -633,6 +633,51 @@ def full_softmax_bwd(user_emb, item_table, target, lse, ws, user_id=None, user_b
     return d_user, d_table, d_ib
 
 
+def full_softmax_fwd_shard(user_emb_all, shard_rows, target_row, user_id=None, user_bias=None, item_bias_rows=None, tau=1.0, score_clip=-1.0):
+    """this rank's partials over the rows it scores -> (part3 float32[3, B_all] = (max, sum-exp, target score), workspace)
+    -- include/unirec_amd.h: ur_full_softmax_fwd_shard."""
+    _chk(user_emb_all, torch.float32, "user_emb_all")
+    _chk(shard_rows, torch.float32, "shard_rows")
+    _chk(target_row, torch.int64, "target_row")
+    B, d = user_emb_all.shape
+    n = shard_rows.shape[0]
+    dev = user_emb_all.device
+    part3 = torch.empty(3, B, dtype=torch.float32, device=dev)
+    ws = torch.empty(check(lib.ur_full_softmax_workspace_bytes(B, d, n), "ur_full_softmax_workspace_bytes"), dtype=torch.uint8, device=dev)
+    check(lib.ur_full_softmax_fwd_shard(_p(user_emb_all), _p(shard_rows), n, B, d, _p(target_row), _p(user_id), _p(user_bias),
+                                        _p(item_bias_rows), float(tau), float(score_clip if score_clip else -1.0), _p(part3), _p(ws),
+                                        _stream()), "ur_full_softmax_fwd_shard")
+    return part3, ws
+
+
+def full_softmax_combine_shards(parts, col0, B_own):
+    """parts float32[W, 3, B_all] (the all-gathered part3 of every rank) -> (lse float32[B_all], loss_out float32[4])."""
+    _chk(parts, torch.float32, "parts")
+    W, _, BA = parts.shape
+    lse = torch.empty(BA, dtype=torch.float32, device=parts.device)
+    loss_out = torch.empty(4, dtype=torch.float32, device=parts.device)
+    check(lib.ur_full_softmax_combine_shards(_p(parts), W, BA, int(col0), int(B_own), _p(lse), _p(loss_out), _stream()),
+          "ur_full_softmax_combine_shards")
+    return lse, loss_out
+
+
+def full_softmax_bwd_shard(user_emb_all, shard_rows, target_row, lse, ws, d_shard_rows, user_id=None, user_bias=None, item_bias_rows=None,
+                           tau=1.0, score_clip=-1.0, d_loss=None, zero_row0=False):
+    """-> (d_user_all [B_all, d] partial over this rank's items, d_item_bias_rows [n] | None); d_shard_rows [n, d] is overwritten."""
+    B, d = user_emb_all.shape
+    n = shard_rows.shape[0]
+    dev = user_emb_all.device
+    _chk(d_shard_rows, torch.float32, "d_shard_rows")
+    assert tuple(d_shard_rows.shape) == (n, d)
+    d_user = torch.empty(B, d, dtype=torch.float32, device=dev)
+    d_ib = torch.empty(n, dtype=torch.float32, device=dev) if item_bias_rows is not None else None
+    check(lib.ur_full_softmax_bwd_shard(_p(user_emb_all), _p(shard_rows), n, B, d, _p(target_row), _p(user_id), _p(user_bias),
+                                        _p(item_bias_rows), float(tau), float(score_clip if score_clip else -1.0), _p(lse), _p(d_loss),
+                                        _p(d_user), _p(d_shard_rows), _p(d_ib), 1 if zero_row0 else 0, _p(ws), _stream()),
+          "ur_full_softmax_bwd_shard")
+    return d_user, d_ib
+
+
 def rows_scatter_add(pl: RowsPlan, rows, dense):
     check(lib.ur_rows_scatter_add(_p(pl.uniq_idx), _p(pl.n_uniq), pl.n, _p(rows), rows.shape[1], _p(dense), _stream()), "ur_rows_scatter_add")
 

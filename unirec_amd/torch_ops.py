@@ -359,6 +359,7 @@ NOT_OPS = {
     "ur_sample_negatives_pop": _FAMILY + " (popularity-biased sampler)", "ur_device_build_seq": _FAMILY + " (device row builder)",
     "ur_convformer_fwd": _FAMILY, "ur_convformer_bwd": _FAMILY, "ur_atthist_fwd": _FAMILY, "ur_atthist_bwd": _FAMILY,
     "ur_pool_rows_fwd": _FAMILY, "ur_pool_rows_bwd": _FAMILY, "ur_full_softmax_fwd": _FAMILY, "ur_full_softmax_bwd": _FAMILY,
+    "ur_full_softmax_fwd_shard": _SHARD, "ur_full_softmax_combine_shards": _SHARD, "ur_full_softmax_bwd_shard": _SHARD,
     "ur_rows_scatter_add": _FAMILY,
     "ur_gather_dot_loss_fused_supported": _QUERY,
     "ur_gather_dot_loss_fwd_bwd": "fusion of the two ops gather_dot_loss_fwd + gather_dot_loss_bwd (both registered) for the graph-free training step: a scheduling choice, not a new op",
