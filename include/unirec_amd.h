@@ -322,6 +322,26 @@ int ur_shard_exchange_rows(const float* table, const int32_t* req_ids, int32_t w
 int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_of_slot, int32_t world, int32_t cap, int32_t d,
                             const float* loss_out, const int32_t* flags_dev, float* send_ws, float* grads_in, int32_t transport,
                             void* stream);
+/* The row exchange of batch t + 1 made a step AHEAD ("rows travel"; no reference counterpart: DDP replicates the table).
+ * ur_shard_exchange_rows for the next batch runs on the plan stream under step t's forward / backward (ur_comm_all_to_all with ahead = 1:
+ * the second communicator); the rows step t's own update still changes -- the owner-side unique rows of step t, `prev_uniq` -- are re-sent
+ * behind that update in a small exchange of cap2 <= cap slots per (owner, requester) pair:
+ *   ur_shard_fixup_plan : (ids only) for every source block of the NEXT batch's request list recv_ids[world*cap]: req2[s*cap2 + i] = the
+ *                         rows it asks for that are in prev_uniq (ascending unique int32, *prev_n_uniq_dev of them; NULL = none), in
+ *                         arbitrary order, slot2[..] = the slot of each inside the block; padding (row 0, slot -1) behind them;
+ *                         flags_dev[0] |= 1 when a block has more than cap2
+ *   ur_shard_fixup_apply: compact[(q / cap2) * cap + slot2[q], :] = rows2[q, :] for the received slots with slot2[q] >= 0
+ * ur_rows_split_hot splits a plan's unique rows against prev_uniq: hot = in both, cold = the others that have optimizer history
+ * (last_step[row] != 0; last_step NULL: all others) -- the rows a lazy catch-up made a step ahead may touch. */
+int ur_comm_all_to_all(const void* send, void* recv, int64_t bytes_per_peer, int32_t ahead, void* stream);
+int ur_shard_fixup_plan(const int32_t* recv_ids, int32_t world, int32_t cap, const int32_t* prev_uniq, const int32_t* prev_n_uniq_dev,
+                        int64_t prev_n_max, int32_t cap2, int32_t* req2, int32_t* slot2, int32_t* counts_ws /* world ints */,
+                        int32_t* flags_dev, void* stream);
+int ur_shard_fixup_apply(float* compact, const float* rows2, const int32_t* slot2, int32_t world, int32_t cap, int32_t cap2, int32_t d,
+                         void* stream);
+int ur_rows_split_hot(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const int32_t* last_step,
+                      const int32_t* excl_sorted, const int32_t* excl_n_dev, int64_t excl_max, int32_t* cold_idx, int32_t* cold_n_dev,
+                      int32_t* hot_idx, int32_t* hot_n_dev, void* stream);
 /* Slot 0 of every block is reserved padding (a block holds cap - 1 keys); in the gradient exchange it carries the sender's step flags
  * [loss is NaN (loss_out[2] < 0, as the loss kernels publish it), capacity overflow (flags_dev[0] & 1), loss_out[0], 1] to every owner.
  * ur_shard_step_flags sums them in source-rank order: out4 = [gradient scale for the update kernels: 1 / world (DDP's mean,

@@ -89,6 +89,9 @@ def _to(b, dev, lo=None, hi=None):
 
 
 def _worker(rank, world, port, q, kind, tmp, clip=0.05, loss=None):
+    if loss == "serial-rows":       # the row exchange inside the step (rounds 1-3) instead of a step ahead + fix-up
+        os.environ["UR_PREFETCH_ROWS"] = "0"
+        loss = None
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -184,7 +187,8 @@ def _worker(rank, world, port, q, kind, tmp, clip=0.05, loss=None):
     ("SASRec", 2, 0.0, None), ("GRU", 2, 0.0, None),     # clip 0: the dense half on the encoder's side stream
     # the reference's own DDP test trains exactly this loss (tests/test_model/run_ddp_test.sh:28): every item a candidate, the catalogue
     # row-sharded -- per-shard logsumexp partials, the shard's table gradient final on its owner
-    ("SASRec", 2, 0.05, "fullsoftmax"), ("SASRec", 3, 0.0, "fullsoftmax"), ("MF", 2, 0.05, "fullsoftmax")])
+    ("SASRec", 2, 0.05, "fullsoftmax"), ("SASRec", 3, 0.0, "fullsoftmax"), ("MF", 2, 0.05, "fullsoftmax"),
+    ("SASRec", 2, 0.0, "serial-rows")])
 def test_trainer_fit_on_w_ranks_equals_one_rank_on_the_concatenated_batches(kind, world, clip, loss, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

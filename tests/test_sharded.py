@@ -377,3 +377,81 @@ def test_native_transport_selftest_world_one():
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cap,cap2,n_prev", [(1, 300, 64, 120), (4, 192, 64, 400), (8, 128, 64, 0), (3, 257, 64, 2000)])
+def test_fixup_plan_split_and_apply_match_a_host_statement(world, cap, cap2, n_prev):
+    """Row prefetch (facility/distributed.py _prefetch_rows): the ids-only kernels of the fix-up exchange against numpy -- which slots of
+    the next batch's request list ask for rows the step in flight updates (in slot order, padding behind, overflow flag), the hot / cold
+    split of the next owner-side plan, and the scatter of the received rows into the compact table."""
+    from unirec_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(world * 1000 + cap)
+    n_local = 5000
+    prev_rows = np.sort(rng.choice(np.arange(1, n_local), size=n_prev, replace=False)).astype(np.int32) if n_prev else np.zeros(0, np.int32)
+    recv = np.zeros((world, cap), np.int32)
+    for s in range(world):                       # every block: slot 0 reserved, keys right-aligned and ascending behind padding
+        cnt = int(rng.integers(0, cap))
+        keys = np.sort(rng.choice(np.arange(1, n_local), size=cnt, replace=False))
+        if n_prev and cnt:                       # make sure some are hot
+            k = min(cnt, n_prev, 40 if s != 1 else cap - 1)
+            keys[:k] = rng.choice(prev_rows, size=k, replace=False)
+            keys = np.sort(np.unique(keys))
+            cnt = len(keys)
+        recv[s, cap - cnt:] = keys
+    prev = None
+    if n_prev:
+        prev = ops.RowsPlan()
+        prev.n, prev.n_a = max(n_prev, 1) + 7, 0
+        buf = np.zeros(prev.n, np.int32)
+        buf[:n_prev] = prev_rows
+        prev.uniq_idx = torch.from_numpy(buf).to(dev)
+        prev.n_uniq = torch.tensor([n_prev], dtype=torch.int32, device=dev)
+    req2 = torch.full((world * cap2,), 77, dtype=torch.int32, device=dev)
+    slot2 = torch.full((world * cap2,), 77, dtype=torch.int32, device=dev)
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    ops.shard_fixup_plan(torch.from_numpy(recv.reshape(-1)).to(dev), world, cap, prev, cap2, req2, slot2, flags,
+                         torch.zeros(world, dtype=torch.int32, device=dev))
+    req2, slot2 = req2.cpu().numpy().reshape(world, cap2), slot2.cpu().numpy().reshape(world, cap2)
+    hotset = set(prev_rows.tolist())
+    overflow = False
+    for s in range(world):
+        want = [(int(r), p) for p, r in enumerate(recv[s]) if p > 0 and int(r) in hotset]
+        got = [(int(r), int(p)) for r, p in zip(req2[s], slot2[s]) if p >= 0]      # (order inside a list is arbitrary)
+        if len(want) > cap2:
+            overflow = True
+            assert len(got) == cap2 and set(got) <= set(want)
+        else:
+            assert sorted(got) == sorted(want)
+        k = len(got)
+        assert all(p >= 0 for p in slot2[s, :k]) and (req2[s, k:] == 0).all() and (slot2[s, k:] == -1).all()
+    assert bool(int(flags[0]) & 1) == overflow
+    # ---- hot / cold split of an owner-side plan against the previous one
+    own_rows = np.unique(recv.reshape(-1))
+    own = ops.RowsPlan()
+    own.n, own.n_a = len(own_rows) + 5, 0
+    buf = np.zeros(own.n, np.int32)
+    buf[:len(own_rows)] = own_rows
+    own.uniq_idx = torch.from_numpy(buf).to(dev)
+    own.n_uniq = torch.tensor([len(own_rows)], dtype=torch.int32, device=dev)
+    last = torch.zeros(n_local, dtype=torch.int32, device=dev)
+    touched = rng.random(n_local) < 0.5
+    last[torch.from_numpy(np.nonzero(touched)[0]).to(dev)] = 3
+    for use_last in (True, False):
+        cold, hot = ops.rows_split_hot(own, last if use_last else None, prev)
+        got_c = sorted(cold.uniq_idx[: int(cold.n_uniq)].cpu().tolist())
+        got_h = sorted(hot.uniq_idx[: int(hot.n_uniq)].cpu().tolist())
+        assert got_h == sorted(int(r) for r in own_rows if r != 0 and int(r) in hotset)
+        assert got_c == sorted(int(r) for r in own_rows if r != 0 and int(r) not in hotset and (touched[r] or not use_last))
+    # ---- apply
+    d = 8
+    compact = torch.zeros(world * cap, d, device=dev)
+    rows2 = torch.arange(world * cap2 * d, device=dev, dtype=torch.float32).reshape(world * cap2, d) + 1
+    ops.shard_fixup_apply(compact, rows2, torch.from_numpy(slot2.reshape(-1)).to(dev), world, cap, cap2)
+    exp = np.zeros((world * cap, d), np.float32)
+    r2 = rows2.cpu().numpy()
+    for q in range(world * cap2):
+        if slot2.reshape(-1)[q] >= 0:
+            exp[(q // cap2) * cap + slot2.reshape(-1)[q]] = r2[q]
+    assert np.array_equal(compact.cpu().numpy(), exp)

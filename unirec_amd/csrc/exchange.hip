@@ -100,6 +100,67 @@ __global__ void shard_flag_rows_kernel(int world, int cap, int d4, const float* 
   out[(long long)s * cap * d4] = make_float4(nan, (flags && (flags[0] & 1)) ? 1.f : 0.f, nan != 0.f ? 0.f : loss, 1.f);
 }
 
+// ---- round 4: the row exchange of batch t + 1 made a step AHEAD (plan stream, under step t's forward / backward); what the step in
+// flight still changes -- the rows its owner-side plan updates -- is re-sent afterwards in a SMALL fixed-capacity exchange.
+// shard_fixup_plan (ids only, next to the plan): a thread per slot of the NEXT batch's request list; a slot whose row is in `prev_uniq`
+// (the sorted unique rows of THIS step's owner-side plan) takes the next free entry of its source block's list (one atomic per wave and
+// block: the order inside a list is arbitrary, every entry carries its slot): req2[s * cap2 + i] = the row, slot2[..] = its slot inside
+// the block (the requester adds owner * cap); the lists are pre-filled with padding (row 0, slot -1).  More than cap2 hot rows for one
+// source: flags |= 1 -- the step is skipped everywhere and re-trained with doubled capacities, as for the main exchange.
+// (One workgroup per source block walking its cap slots was 490 us at world 1 -- 28 K slots, 110 trips of three barriers.)
+__global__ __launch_bounds__(256) void shard_fixup_plan_kernel(const int* __restrict__ recv_ids, int W, int cap, const int* __restrict__ prev_uniq,
+                                                               const int* __restrict__ prev_n_dev, int prev_max, int cap2,
+                                                               int* __restrict__ req2, int* __restrict__ slot2, int* __restrict__ counts,
+                                                               int* __restrict__ flags) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int n_prev = min(*prev_n_dev, prev_max);
+  const bool in = q < (long long)W * cap;
+  const int s = in ? (int)(q / cap) : -1, p = in ? (int)(q % cap) : 0;
+  const int row = (in && p > 0) ? recv_ids[q] : 0;
+  bool hot = false;
+  if (row != 0 && n_prev > 0) {
+    int lo = 0, hi = n_prev;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (prev_uniq[mid] < row) lo = mid + 1; else hi = mid;
+    }
+    hot = lo < n_prev && prev_uniq[lo] == row;
+  }
+  // a wave spans at most two source blocks (cap >= 64 whenever world > 1)
+  const int s0 = __shfl(s, 0, 64);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool mine = hot && (pass == 0 ? s == s0 : s != s0);
+    const unsigned long long m = __ballot(mine);
+    if (!m) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    const int sb = __shfl(s, leader, 64);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counts[sb], __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (mine) {
+      const int i = base + __popcll(m & ((1ULL << lane) - 1ULL));
+      if (i < cap2) {
+        req2[(long long)s * cap2 + i] = row;
+        slot2[(long long)s * cap2 + i] = p;
+      } else {
+        atomicOr(flags, 1);
+      }
+    }
+  }
+}
+
+// compact[(q / cap2) * cap + slot2[q], :] = rows2[q, :] for the received fix-up slots (slot2 >= 0)
+__global__ __launch_bounds__(256) void shard_fixup_apply_kernel(float4* __restrict__ compact, const float4* __restrict__ rows2,
+                                                                const int* __restrict__ slot2, long long n2, int cap, int cap2, int d4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n2 * d4) return;
+  const long long q = i / d4;
+  const int c = (int)(i % d4), sl = slot2[q];
+  if (sl >= 0) compact[((q / cap2) * cap + sl) * d4 + c] = rows2[i];
+}
+
 // the flags of all ranks, as received in slot 0 of every block of grads_in -> out[0] = gradient scale of the update kernels (1 / W =
 // DDP's mean, or -1 = skip the step: a NaN loss or an overflow on ANY rank), out[1] = mean loss over the ranks, out[2] / out[3] = number
 // of ranks with a NaN loss / an overflow
@@ -226,6 +287,44 @@ extern "C" int ur_comm_all_reduce_sum(float* buf, int64_t n, void* stream) {
   UR_REQUIRE(g_comm.comm, UR_ERR_ARG, "ur_comm_all_reduce_sum: no communicator (ur_comm_init)");
   ProfScope ps(PC_ALLREDUCE, as_stream(stream), (double)n * 4.0 * 2.0 * (g_comm.world - 1) / g_comm.world);   // (ring all-reduce: 2 (W - 1) / W of the buffer leaves the rank)
   UR_NCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, g_comm.comm2, as_stream(stream)));
+  return UR_OK;
+}
+
+// equal-split all-to-all of a packed buffer through the library's communicators: ahead != 0 = the second one (the dense all-reduce's and
+// the id exchange's: work issued a step ahead on the plan stream), else the row communicator of the step's own exchanges.
+extern "C" int ur_comm_all_to_all(const void* send, void* recv, int64_t bytes_per_peer, int32_t ahead, void* stream) {
+  UR_REQUIRE(send && recv && bytes_per_peer > 0, UR_ERR_ARG, "ur_comm_all_to_all: bad argument");
+  UR_REQUIRE(g_comm.comm, UR_ERR_ARG, "ur_comm_all_to_all: no communicator (ur_comm_init)");
+  return a2a_bytes(send, recv, (size_t)bytes_per_peer, as_stream(stream), ahead ? g_comm.comm2 : g_comm.comm, PC_A2A_ROWS);
+}
+
+extern "C" int ur_shard_fixup_plan(const int32_t* recv_ids, int32_t world, int32_t cap, const int32_t* prev_uniq,
+                                   const int32_t* prev_n_uniq_dev, int64_t prev_n_max, int32_t cap2, int32_t* req2, int32_t* slot2,
+                                   int32_t* counts_ws, int32_t* flags_dev, void* stream) {
+  UR_REQUIRE(recv_ids && req2 && slot2 && counts_ws && flags_dev, UR_ERR_ARG, "ur_shard_fixup_plan: null pointer");
+  UR_REQUIRE(world >= 1 && cap > 0 && cap2 > 0 && cap2 <= cap && (world == 1 || cap >= 64) &&
+                 (prev_uniq == nullptr || (prev_n_uniq_dev && prev_n_max > 0 && prev_n_max < (1LL << 31))),
+             UR_ERR_ARG, "ur_shard_fixup_plan: world=%d cap=%d cap2=%d", world, cap, cap2);
+  hipStream_t st = as_stream(stream);
+  const size_t n2 = (size_t)world * cap2;
+  UR_HIP(hipMemsetAsync(req2, 0, n2 * sizeof(int32_t), st));
+  UR_HIP(hipMemsetAsync(slot2, 0xFF, n2 * sizeof(int32_t), st));   // -1
+  if (!prev_uniq) return UR_OK;                                     // (nothing in flight: every list is padding)
+  UR_HIP(hipMemsetAsync(counts_ws, 0, (size_t)world * sizeof(int32_t), st));
+  hipLaunchKernelGGL(shard_fixup_plan_kernel, dim3(cdiv((long long)world * cap, 256)), dim3(256), 0, st, recv_ids, world, cap, prev_uniq,
+                     prev_n_uniq_dev, (int)prev_n_max, cap2, req2, slot2, counts_ws, flags_dev);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+extern "C" int ur_shard_fixup_apply(float* compact, const float* rows2, const int32_t* slot2, int32_t world, int32_t cap, int32_t cap2,
+                                    int32_t d, void* stream) {
+  UR_REQUIRE(compact && rows2 && slot2, UR_ERR_ARG, "ur_shard_fixup_apply: null pointer");
+  UR_REQUIRE(world >= 1 && cap > 0 && cap2 > 0 && d > 0 && d % 4 == 0, UR_ERR_ARG, "ur_shard_fixup_apply: world=%d cap=%d cap2=%d d=%d", world, cap, cap2, d);
+  const long long n2 = (long long)world * cap2;
+  hipLaunchKernelGGL(shard_fixup_apply_kernel, dim3(cdiv(n2 * (d / 4), 256)), dim3(256), 0, as_stream(stream), (float4*)compact,
+                     (const float4*)rows2, slot2, n2, cap, cap2, d / 4);
+  UR_LAUNCH_CHECK();
   return UR_OK;
 }
 

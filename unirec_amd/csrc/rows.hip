@@ -1327,6 +1327,55 @@ extern "C" int ur_rows_filter_touched(const int32_t* uniq_idx, const int32_t* n_
   return UR_OK;
 }
 
+// The rows of a plan split against the (sorted, unique) rows of ANOTHER plan -- the step in flight's: `hot` = in both (that step updates
+// them: they are current afterwards), `cold` = only in this one and, when last_step is given, ever updated before (what a catch-up
+// made a step AHEAD has work for: the step in flight gives them a zero gradient).  Output order arbitrary.
+__global__ __launch_bounds__(256) void rows_split_hot_kernel(const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
+                                                             long long n_max, const int* __restrict__ last_step,
+                                                             const int* __restrict__ excl, const int* __restrict__ excl_n_dev, int excl_max,
+                                                             int* __restrict__ cold, int* __restrict__ cold_n, int* __restrict__ hot,
+                                                             int* __restrict__ hot_n) {
+  const int n = (int)min((long long)*n_uniq_dev, n_max);
+  const int ne = excl ? min(*excl_n_dev, excl_max) : 0;
+  const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const int row = i < n ? uniq_idx[i] : 0;
+  bool is_hot = false;
+  if (row != 0 && ne > 0) {
+    int lo = 0, hi = ne;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (excl[mid] < row) lo = mid + 1; else hi = mid;
+    }
+    is_hot = lo < ne && excl[lo] == row;
+  }
+  const bool is_cold = row != 0 && !is_hot && (!last_step || last_step[row] != 0);
+  const unsigned long long lt = (1ULL << lane) - 1ULL;
+  unsigned long long m = __ballot(is_cold);
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(cold_n, __popcll(m));
+  base = __shfl(base, 0, 64);
+  if (is_cold) cold[base + __popcll(m & lt)] = row;
+  m = __ballot(is_hot);
+  base = 0;
+  if (lane == 0 && m) base = atomicAdd(hot_n, __popcll(m));
+  base = __shfl(base, 0, 64);
+  if (is_hot) hot[base + __popcll(m & lt)] = row;
+}
+extern "C" int ur_rows_split_hot(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const int32_t* last_step,
+                                 const int32_t* excl_sorted, const int32_t* excl_n_dev, int64_t excl_max, int32_t* cold_idx,
+                                 int32_t* cold_n_dev, int32_t* hot_idx, int32_t* hot_n_dev, void* stream) {
+  UR_REQUIRE(uniq_idx && n_uniq_dev && cold_idx && cold_n_dev && hot_idx && hot_n_dev && n_max > 0 && n_max < (1LL << 31), UR_ERR_ARG,
+             "ur_rows_split_hot: null pointer or n_max=%lld", (long long)n_max);
+  UR_REQUIRE(!excl_sorted || (excl_n_dev && excl_max > 0 && excl_max < (1LL << 31)), UR_ERR_ARG, "ur_rows_split_hot: exclusion list");
+  hipStream_t st = as_stream(stream);
+  UR_HIP(hipMemsetAsync(cold_n_dev, 0, sizeof(int32_t), st));
+  UR_HIP(hipMemsetAsync(hot_n_dev, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(rows_split_hot_kernel, dim3(cdiv(n_max, 256)), dim3(256), 0, st, uniq_idx, n_uniq_dev, (long long)n_max, last_step,
+                     excl_sorted, excl_n_dev, (int)excl_max, cold_idx, cold_n_dev, hot_idx, hot_n_dev);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
 extern "C" int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, int64_t row0,
                                   int64_t n, int32_t d, void* stream) {
   UR_REQUIRE(cfg != nullptr && cfg->step >= 0, UR_ERR_ARG, "ur_lazy_adam_flush: cfg");

@@ -172,6 +172,9 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         self.n_overflow = 0
         # fullsoftmax (the loss of the reference's own DDP test, tests/test_model/run_ddp_test.sh:28): every rank scores ALL ranks' users
         # against the rows it owns; the table gradient of a shard is complete on its owner (dense over the shard, no exchange)
+        # rows of the next batch fetched a step ahead (_prefetch_rows); UR_PREFETCH_ROWS=0: in the step itself (rounds 1-3).  Not with
+        # fullsoftmax: its dense update moves every row of the item shard in every step
+        self.prefetch_rows = os.environ.get("UR_PREFETCH_ROWS", "1") not in ("", "0") and model.loss_type != "fullsoftmax"
         self._fs_dgrad = None
         if model.loss_type == "fullsoftmax":
             if "item_embedding" not in self.tables or self.full_rows["item_embedding"] < world:
@@ -243,35 +246,55 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         cap = (cap + 63) // 64 * 64
         return min(cap, (n + 1 + 63) // 64 * 64)
 
+    def _capacity2(self, n, cap):
+        """slots per (owner, requester) pair of the FIX-UP exchange (rows of the next batch that the step in flight updates): an eighth
+        of the unclamped main capacity -- uniform ids over a large table need a handful -- growing with it after an overflow, up to cap."""
+        W = self.world
+        if W == 1:
+            return min(cap, max(64, (n // 8 + 63) // 64 * 64 * self._cap_scale))
+        want = int(self.cap_slack * self._cap_scale * n / W / 8)
+        return min(cap, max(64, (want + 63) // 64 * 64))
+
     def _buffers(self, name, n, n_a, d, parity):
         key = (name, n, n_a, parity, self._cap_scale)
         bf = self._bufs.get(key)
         if bf is None:
             dev, W = self.model.device, self.world
             cap = self._capacity(n)
+            cap2 = self._capacity2(n, cap)
             i32 = dict(dtype=torch.int32, device=dev)
+            f32 = dict(dtype=torch.float32, device=dev)
             send_ids = torch.empty(W * cap, **i32)
+            rows_ws = torch.empty(W * cap, d, **f32)
+            slot2, rows2 = torch.empty(W * cap2, **i32), torch.empty(W * cap2, d, **f32)
             bf = dict(cap=cap, plan=ops.rows_plan_alloc(n, n_a, dev), counts=torch.empty(W, **i32), send_ids=send_ids,
                       # (world 1: every exchange is the identity -- the receive buffers ARE the send buffers, nothing is copied)
                       recv_ids=torch.empty(W * cap, **i32) if W > 1 else send_ids, slot=torch.zeros(n, **i32), uos=torch.empty(W * cap, **i32),
                       flags=torch.zeros(4, **i32), own=ops.rows_plan_alloc(W * cap, W * cap, dev),
                       idx_a=torch.empty(n_a, **i32) if n_a else None,
-                      idx_b=torch.empty(n - n_a, dtype=torch.int64, device=dev) if n > n_a else None)
+                      idx_b=torch.empty(n - n_a, dtype=torch.int64, device=dev) if n > n_a else None,
+                      # the rows themselves, per parity: batch t + 1's are fetched on the plan stream while step t computes on batch t's
+                      rows_ws=rows_ws, compact=torch.empty(W * cap, d, **f32) if W > 1 else rows_ws,
+                      # fix-up exchange (rows of this batch that the previous step's update changed after they were fetched)
+                      cap2=cap2, req2=torch.zeros(W * cap2, **i32), slot2=slot2, slot2_recv=torch.empty(W * cap2, **i32) if W > 1 else slot2,
+                      rows2=rows2, rows2_recv=torch.empty(W * cap2, d, **f32) if W > 1 else rows2, split=None,
+                      fix_cnt=torch.zeros(W, **i32))
             self._bufs[key] = bf
         skey = (name, n, "step", self._cap_scale)
         sb = self._bufs.get(skey)
         if sb is None:
             dev, W, cap = self.model.device, self.world, bf["cap"]
             f32 = dict(dtype=torch.float32, device=dev)
-            rows_ws, send_grads = torch.empty(W * cap, d, **f32), torch.empty(W * cap, d, **f32)
-            sb = dict(rows_ws=rows_ws, compact=torch.empty(W * cap, d, **f32) if W > 1 else rows_ws,
-                      send_grads=send_grads, grads_in=torch.empty(W * cap, d, **f32) if W > 1 else send_grads)
+            send_grads = torch.empty(W * cap, d, **f32)
+            sb = dict(send_grads=send_grads, grads_in=torch.empty(W * cap, d, **f32) if W > 1 else send_grads)
             self._bufs[skey] = sb
         return bf, sb
 
-    def _prepare(self, batch, parity):
-        """everything of a step that depends on the ids only, on the CURRENT stream -> {table: state}"""
+    def _prepare(self, batch, parity, prev=None):
+        """everything of a step that depends on the ids only, on the CURRENT stream -> {table: state}.  prev (the tabs of the step in
+        flight; lookahead only): the ROWS are fetched here as well, a step ahead (_prefetch_rows)."""
         W, tabs = self.world, {}
+        ahead = prev is not None
         for name, (ka, kb, a, b) in self._table_inputs(batch).items():
             st = self.tables[name]
             n_a = a.numel() if a is not None else 0
@@ -287,13 +310,52 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             own = ops.rows_plan_merge(bf["recv_ids"], [cap] * W, out=bf["own"])
             ops.compact_index(pl, bf["slot"], out=(bf["idx_a"], bf["idx_b"]))
             filt = None
-            if st["last"] is not None and self.wd == 0.0:
+            if st["last"] is not None and self.wd == 0.0 and not ahead:
                 filt = ops.rows_filter_touched(own, st["last"])     # (rows first touched by the step in flight need no catch-up)
-            tabs[name] = dict(ka=ka, kb=kb, pl=pl, own=own, filt=filt, bf=bf, sb=sb, cap=cap, ids=(a, b), caught_up=None)
+            tabs[name] = dict(ka=ka, kb=kb, pl=pl, own=own, filt=filt, bf=bf, sb=sb, cap=cap, ids=(a, b), caught_up=None,
+                              rows_ready=False, hot=None)
+        if ahead:
+            self._prefetch_rows(tabs, prev)
         return tabs
 
-    def prefetch(self, batch):
-        """ids-only half of the NEXT batch's step on the plan stream, all-to-all #1 included: nothing of it is left for the step itself."""
+    def _prefetch_rows(self, tabs, prev):
+        """The row exchange (all-to-all #2) of the NEXT batch, on the plan stream under the step in flight (step self.t, owner-side plans
+        `prev`).  What that step still changes are the rows ITS update writes -- prev's owner-side unique rows; everything else the next
+        batch asks for can travel now:
+          * (lazy_dense) the requested rows the step in flight does NOT touch take their zero-gradient steps up to and including it
+            here (it gives them a zero gradient by construction): `cold`; the others, `hot`, are current once that step's update ran;
+          * all requested rows are gathered and exchanged (second communicator: work issued a step ahead never queues in front of the
+            step's own exchanges); the copies of hot rows are stale and are replaced at the head of the next step by a FIX-UP exchange
+            of cap2 << cap slots per pair, planned here from the ids alone (ur_shard_fixup_plan; its slot list travels now too).
+        A pair with more than cap2 hot rows raises the batch's overflow flag: skipped everywhere, capacities doubled, re-trained."""
+        W = self.world
+        lazy = self.table_mode == "lazy_dense"
+        cfg = self._cfg(self.t + 1)
+        for name, c in tabs.items():
+            st, bf, cap, cap2 = self.tables[name], c["bf"], c["cap"], c["bf"]["cap2"]
+            pown = prev[name]["own"] if name in prev else None
+            ops.shard_fixup_plan(bf["recv_ids"], W, cap, pown, cap2, bf["req2"], bf["slot2"], bf["flags"], bf["fix_cnt"])
+            if W > 1:
+                if self._native:
+                    ops.comm_all_to_all(bf["slot2"], bf["slot2_recv"], W, ahead=True)
+                else:
+                    self._a2a(bf["slot2"], bf["slot2_recv"], "a2a_fix_slots")
+            if lazy and st["last"] is not None:
+                bf["split"] = ops.rows_split_hot(c["own"], st["last"] if self.wd == 0.0 else None, pown, out=bf["split"])
+                cold, c["hot"] = bf["split"]
+                ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], cold)
+                c["caught_up"] = self.t
+            ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, cap, bf["rows_ws"], compact=bf["compact"], transport=False)
+            if W > 1:
+                if self._native:
+                    ops.comm_all_to_all(bf["rows_ws"], bf["compact"], W, ahead=True)
+                else:
+                    self._a2a(bf["rows_ws"], bf["compact"], "a2a_rows")
+            c["rows_ready"] = True
+
+    def prefetch(self, batch, cur_tabs=None):
+        """ids-only half of the NEXT batch's step on the plan stream, all-to-all #1 included: nothing of it is left for the step itself.
+        cur_tabs (the step in flight's state): its ROWS travel now as well (_prefetch_rows), unless switched off."""
         if batch is None or self.model.device.type != "cuda":
             return
         main = torch.cuda.current_stream()
@@ -303,7 +365,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         look = _Look()
         self._parity ^= 1
         with torch.cuda.stream(self._side):
-            look.tabs = self._prepare(batch, self._parity)
+            look.tabs = self._prepare(batch, self._parity, prev=cur_tabs if self.prefetch_rows else None)
             look.event = torch.cuda.Event()
             look.event.record(self._side)
         look.key, look.keep, look.waited = self._batch_key(batch), batch, False
@@ -380,6 +442,16 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             st = self.tables[name]
             ops.dense_adam(cfg, st["w"], dg, st["m"], st["v"], scale)
 
+    def _catchup_next(self):
+        """tail of a step: the NEXT batch's owner rows take this step too (lazy_dense) -- unless the plan stream has done that already for
+        the rows this step does not touch (_prefetch_rows): then there is nothing to do here, and nothing to wait for yet"""
+        nxt = self._look
+        if nxt is None or self.table_mode != "lazy_dense" or all(c["rows_ready"] for c in nxt.tabs.values()):
+            return
+        torch.cuda.current_stream().wait_event(nxt.event)
+        nxt.waited = True
+        self._catchup(nxt.tabs, self.t)
+
     # ------------------------------------------------------------------ the step
     def _check_overflow(self, drain=False):
         """The flags of the steps that finished at least two enqueues ago (long done: no stall), in step order; drain=True: of every
@@ -435,16 +507,25 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             self._parity ^= 1
             tabs = self._prepare(batch, self._parity)
         if next_batch is not None:
-            self.prefetch(next_batch)
-        # ---- 2. owner rows up to date (normally done at the tail of the previous step), then the rows travel
+            self.prefetch(next_batch, tabs)
+        # ---- 2. the rows.  Fetched a step ahead (lookahead): only the rows the previous step's update changed after that are re-sent
+        # (fix-up exchange, cap2 slots per pair).  Otherwise: owner rows up to date, then the full exchange
         if self.t > 1:
-            self._catchup(tabs, self.t - 1)
+            self._catchup({n: c for n, c in tabs.items() if not c["rows_ready"]}, self.t - 1)
         cbatch = dict(batch)
         for name, c in tabs.items():
             st, bf, sb = self.tables[name], c["bf"], c["sb"]
-            ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, c["cap"], sb["rows_ws"], compact=sb["compact"], transport=self._native)
-            if not self._native:
-                self._a2a(sb["rows_ws"], sb["compact"], "a2a_rows")
+            if c["rows_ready"]:
+                if c["hot"] is not None:   # current after the previous step's update -- or, had that step been skipped everywhere, after this
+                    ops.lazy_adam_catchup(self._cfg(self.t), st["w"], st["m"], st["v"], st["last"], c["hot"])
+                ops.shard_exchange_rows(st["w"], bf["req2"], W, bf["cap2"], bf["rows2"], compact=bf["rows2_recv"], transport=self._native)
+                if not self._native:
+                    self._a2a(bf["rows2"], bf["rows2_recv"], "a2a_fix_rows")
+                ops.shard_fixup_apply(bf["compact"], bf["rows2_recv"], bf["slot2_recv"], W, c["cap"], bf["cap2"])
+            else:
+                ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, c["cap"], bf["rows_ws"], compact=bf["compact"], transport=self._native)
+                if not self._native:
+                    self._a2a(bf["rows_ws"], bf["compact"], "a2a_rows")
             if c["ka"] is not None:
                 cbatch[c["ka"]] = bf["idx_a"].view(batch[c["ka"]].shape)
             if c["kb"] is not None:
@@ -455,7 +536,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             for name, c in tabs.items():
                 p = getattr(model, name).weight
                 swapped.append((p, p.data))
-                p.data = c["sb"]["compact"]
+                p.data = c["bf"]["compact"]
             bias_ctx = self._compact_biases(tabs, batch, swapped)
             if "user_id" in cbatch and cbatch["user_id"].dtype != torch.int64:
                 cbatch["user_id"] = cbatch["user_id"].to(torch.int64)
@@ -476,7 +557,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         for name, c in tabs.items():
             ids_a, rows, ids_b, coef, vec, G = self._collect(name)
             sb, bf = c["sb"], c["bf"]
-            d = sb["compact"].shape[1]
+            d = bf["compact"].shape[1]
             # (the sums land in their exchange slots: no scatter pass; padding slots keep stale bytes that no owner reads)
             ops.rows_reduce(c["pl"], rows, coef.reshape(-1) if coef is not None else None, vec, G, d, out=sb["send_grads"], out_rows=bf["slot"])
             ops.shard_exchange_grads(None, bf["uos"], W, c["cap"], sb["send_grads"], grads_in=sb["grads_in"], transport=self._native,
@@ -510,11 +591,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         if self.grad_clip is None:
             # rows first (nothing to wait for), then the next batch's owner rows take this step too -- under the dense-gradient stream
             self._update_rows(cfg, tabs, owner_grads, dense_shard, scale)
-            nxt = self._look
-            if nxt is not None and self.table_mode == "lazy_dense":
-                torch.cuda.current_stream().wait_event(nxt.event)
-                nxt.waited = True
-                self._catchup(nxt.tabs, self.t)
+            self._catchup_next()
             g = getattr(model, "_deferred_dense_grad", None)
             if g is not None and g.numel() and not self.extra and not bias_ctx:
                 side = ops.sasrec_side_stream()
@@ -581,11 +658,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             ops.clip_coef(total, self.grad_clip, coef)
             scale = torch.where(scale < 0, scale, scale * coef)
             self._update_rows(cfg, tabs, owner_grads, dense_shard, scale)
-            nxt = self._look
-            if nxt is not None and self.table_mode == "lazy_dense":
-                torch.cuda.current_stream().wait_event(nxt.event)
-                nxt.waited = True
-                self._catchup(nxt.tabs, self.t)
+            self._catchup_next()
         o = model.dense_flat.numel()
         if o:
             ops.dense_adam(cfg, model.dense_flat.data, flat[:o].contiguous(), self.dense_m, self.dense_v, scale)
@@ -648,11 +721,11 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         cbatch, swapped = dict(batch), []
         for name, c in tabs.items():
             st, bf, sb = self.tables[name], c["bf"], c["sb"]
-            compact = torch.empty_like(sb["compact"])      # (the caller keeps it until restore(): not the step's buffer)
-            ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, c["cap"], sb["rows_ws"] if W > 1 else compact, compact=compact,
+            compact = torch.empty_like(bf["compact"])      # (the caller keeps it until restore(): not the step's buffer)
+            ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, c["cap"], bf["rows_ws"] if W > 1 else compact, compact=compact,
                                     transport=self._native)
             if not self._native and W > 1:
-                self._a2a(sb["rows_ws"], compact, "a2a_rows")
+                self._a2a(bf["rows_ws"], compact, "a2a_rows")
             if c["ka"] is not None:
                 cbatch[c["ka"]] = bf["idx_a"].clone().view(batch[c["ka"]].shape)
             if c["kb"] is not None:

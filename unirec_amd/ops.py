@@ -374,6 +374,53 @@ def comm_all_reduce_sum(t):
     return t
 
 
+def comm_all_to_all(send, recv, world, ahead=False):
+    """equal-split all-to-all of a packed buffer through the library's communicators (ahead: the second one, for work issued a step ahead)"""
+    assert send.numel() == recv.numel() and send.dtype == recv.dtype and send.numel() % world == 0
+    check(lib.ur_comm_all_to_all(_p(send), _p(recv), send.numel() * send.element_size() // world, 1 if ahead else 0, _stream()),
+          "ur_comm_all_to_all")
+    return recv
+
+
+def shard_fixup_plan(recv_ids, world, cap, prev_own, cap2, req2, slot2, flags, counts_ws):
+    """(ids only) the slots of the NEXT batch's request list whose row `prev_own` (this step's owner-side plan, or None) updates"""
+    _chk(recv_ids, torch.int32, "recv_ids"); _chk(req2, torch.int32, "req2"); _chk(slot2, torch.int32, "slot2"); _chk(flags, torch.int32, "flags")
+    assert recv_ids.numel() == world * cap and req2.numel() == world * cap2 == slot2.numel()
+    pu, pn, pm = (prev_own.uniq_idx, prev_own.n_uniq, prev_own.n) if prev_own is not None else (None, None, 0)
+    _chk(counts_ws, torch.int32, "counts_ws")
+    assert counts_ws.numel() >= world
+    check(lib.ur_shard_fixup_plan(_p(recv_ids), int(world), int(cap), _p(pu), _p(pn), int(pm), int(cap2), _p(req2), _p(slot2), _p(counts_ws),
+                                  _p(flags), _stream()), "ur_shard_fixup_plan")
+
+
+def shard_fixup_apply(compact, rows2, slot2, world, cap, cap2):
+    _chk(compact, torch.float32, "compact"); _chk(rows2, torch.float32, "rows2"); _chk(slot2, torch.int32, "slot2")
+    d = compact.shape[-1]
+    assert compact.numel() == world * cap * d and rows2.numel() == world * cap2 * d and slot2.numel() == world * cap2
+    check(lib.ur_shard_fixup_apply(_p(compact), _p(rows2), _p(slot2), int(world), int(cap), int(cap2), d, _stream()), "ur_shard_fixup_apply")
+
+
+def rows_split_hot(pl: RowsPlan, last_step, excl: RowsPlan, out=None):
+    """pl's unique rows split against excl's (sorted unique): -> (cold, hot) plan-like lists (uniq_idx / n_uniq only, arbitrary order);
+    cold = not in excl and (last_step is None or last_step[row] != 0), hot = in both.  out: (cold, hot) of an earlier call, reused."""
+    _chk(last_step, torch.int32, "last_step", allow_none=True)
+    dev = pl.uniq_idx.device
+    if out is None:
+        out = []
+        for _ in range(2):
+            o = RowsPlan()
+            o.n, o.n_a = pl.n, 0
+            o.uniq_idx = torch.empty(pl.n, dtype=torch.int32, device=dev)
+            o.n_uniq = torch.empty(1, dtype=torch.int32, device=dev)
+            o.seg_start = o.sorted_pos = None
+            out.append(o)
+    cold, hot = out
+    eu, en, em = (excl.uniq_idx, excl.n_uniq, excl.n) if excl is not None else (None, None, 0)
+    check(lib.ur_rows_split_hot(_p(pl.uniq_idx), _p(pl.n_uniq), pl.n, _p(last_step), _p(eu), _p(en), int(em), _p(cold.uniq_idx),
+                                _p(cold.n_uniq), _p(hot.uniq_idx), _p(hot.n_uniq), _stream()), "ur_rows_split_hot")
+    return cold, hot
+
+
 def shard_exchange_ids(pl: RowsPlan, counts, n_local, world, cap, send_ids, slot_of_uniq, u_of_slot, flags, recv_ids=None, transport=False):
     """pack (+ RCCL all-to-all when transport): see ur_shard_exchange_ids.  Buffers are the caller's (preallocated once)."""
     for t, nm in ((send_ids, "send_ids"), (slot_of_uniq, "slot_of_uniq"), (u_of_slot, "u_of_slot"), (flags, "flags")):

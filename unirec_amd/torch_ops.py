@@ -354,6 +354,7 @@ NOT_OPS = {
     "ur_sasrec_bwd_deferred": _PLUMB, "ur_sasrec_bwd_join": _PLUMB, "ur_stream_wait_stream": _PLUMB, "ur_sasrec_side_stream": _PLUMB, "ur_sasrec_side_publish": _PLUMB,
     "ur_rows_plan_merge": _SHARD, "ur_rows_plan_sharded": _SHARD, "ur_compact_index": _SHARD, "ur_full_rank_shard": _SHARD,
     "ur_shard_step_flags": _SHARD, "ur_comm_world": _COMM, "ur_comm_unique_id": _COMM, "ur_comm_init": _COMM, "ur_comm_destroy": _COMM, "ur_comm_all_reduce_sum": _COMM,
+    "ur_comm_all_to_all": _COMM, "ur_shard_fixup_plan": _SHARD, "ur_shard_fixup_apply": _SHARD, "ur_rows_split_hot": _SHARD,
     "ur_sumsq": _FAMILY + " (gradient-clipping helpers of the optimizer)", "ur_clip_coef": _FAMILY + " (gradient-clipping helpers)",
     "ur_clip_coef_guarded": _FAMILY + " (gradient-clipping helpers)",
     "ur_sample_negatives_pop": _FAMILY + " (popularity-biased sampler)", "ur_device_build_seq": _FAMILY + " (device row builder)",
