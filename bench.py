@@ -80,6 +80,8 @@ def parse():
                     "fixed-capacity row exchange with world = 1, collectives degenerate) instead of the plain optimizer: its overhead")
     ap.add_argument("--no-selfcheck", action="store_true", help="world > 1: skip the W-rank == 1-rank check that runs before the timed region")
     ap.add_argument("--selfcheck-items", type=int, default=1_000_000)
+    ap.add_argument("--skip-padding", type=int, default=1, help="0: the encoder carries the padded [B * L] rows (per-sequence layout) instead of "
+                    "the compact real-token rows: a probe for profiles/, not a configuration of the line")
     ap.add_argument("--dropout", type=float, default=0.0, help="hidden_dropout_prob = attn_dropout_prob (the reference's SASRec.yaml "
                     "default is 0.5; its example / benchmark scripts and the headline line use 0)")
     return ap.parse_args()
@@ -90,7 +92,8 @@ def model_config(a, device):
                 hidden_size=a.d, dropout_prob=0.0, init_method="normal", init_mean=0.0, init_std=0.02, has_user_emb=False,
                 has_user_bias=False, has_item_bias=False, distance_type="dot", tau=1.0, train_file_format="user-item",
                 exp_name="bench", n_layers=a.layers, n_heads=a.heads, inner_size=a.inner, hidden_dropout_prob=a.dropout,
-                attn_dropout_prob=a.dropout, seed=2022, hidden_act="swish", layer_norm_eps=1e-10, max_seq_len=a.seq_len, use_position_emb=True)
+                attn_dropout_prob=a.dropout, seed=2022, hidden_act="swish", layer_norm_eps=1e-10, max_seq_len=a.seq_len, use_position_emb=True,
+                skip_padding=getattr(a, "skip_padding", 1))
 
 
 def synth_batches(a, n_items, device, seed, n_batches=8):

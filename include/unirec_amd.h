@@ -341,7 +341,8 @@ int ur_shard_fixup_apply(float* compact, const float* rows2, const int32_t* slot
                          void* stream);
 int ur_rows_split_hot(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const int32_t* last_step,
                       const int32_t* excl_sorted, const int32_t* excl_n_dev, int64_t excl_max, int32_t* cold_idx, int32_t* cold_n_dev,
-                      int32_t* hot_idx, int32_t* hot_n_dev, void* stream);
+                      int32_t* hot_idx, int32_t* hot_n_dev, int32_t* hot_u /* nullable: index of each hot row in excl_sorted */,
+                      int32_t* excl_mark /* nullable, excl_max ints: 1 for the entries of excl_sorted that are hot */, void* stream);
 /* Slot 0 of every block is reserved padding (a block holds cap - 1 keys); in the gradient exchange it carries the sender's step flags
  * [loss is NaN (loss_out[2] < 0, as the loss kernels publish it), capacity overflow (flags_dev[0] & 1), loss_out[0], 1] to every owner.
  * ur_shard_step_flags sums them in source-rank order: out4 = [gradient scale for the update kernels: 1 / world (DDP's mean,
@@ -410,6 +411,18 @@ int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m, float* v, 
 int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                          const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
                          void* stream);
+/* The row update of a step in two launches, so that most of it can run beside the NEXT forward pass (facility/optimizer.py; no
+ * reference counterpart: torch.optim steps every parameter before the next forward, unirec/facility/trainer.py:349):
+ *   ur_rows_reduce_subset    : ur_rows_reduce for the unique ids u_list[0 .. *n_list_dev) only, entry i -> out[i, :] (same sums, same order)
+ *   ur_sparse_adam_rows_split: hot != 0: ur_sparse_adam_rows over a short row list (the rows the next batch reads as well); a skipped step
+ *                              (grad_scale_dev < 0) is applied to them as a zero-gradient step.  hot == 0: over the whole plan except
+ *                              the unique ids with skip_mark[u] != 0. */
+int ur_rows_reduce_subset(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev,
+                          int64_t n, const float* rows_a, int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d,
+                          const int32_t* u_list, const int32_t* n_list_dev, int64_t n_list_max, float* out, void* stream);
+int ur_sparse_adam_rows_split(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, const int32_t* uniq_idx,
+                              const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad, int32_t d, const float* grad_scale_dev,
+                              int32_t hot, const int32_t* skip_mark, void* stream);
 /* out_idx[0 .. *out_n_dev) = the rows of uniq_idx[0 .. *n_uniq_dev) that were ever updated (last_step != 0), in arbitrary order: with
  * weight_decay == 0 the only rows ur_lazy_adam_catchup has work for.  Made next to the plan (side stream), it keeps the catch-up of a
  * batch of never-seen rows -- a chain of random last_step reads and nothing else -- off the main stream.  out_idx: n_max ints. */

@@ -30,14 +30,19 @@ def _batches(n, B=16, L=10, N=300, seed=0):
     return out
 
 
-def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14):
+@pytest.fixture(autouse=True)
+def _tail_overlap_on(monkeypatch):
+    monkeypatch.setenv("UR_TAIL_OVERLAP", "1")      # (read by SparseDenseAdam.__init__; the "defer" runs need it, the others ignore it)
+
+
+def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14, nan_at=None, table_mode="lazy_dense"):
     """ahead: False = catch-up at the head of the next step (no plan lookahead), "tail" = on the main stream between the row update and
     the join of the dense-gradient stream (what a prefetched plan gives)"""
     from unirec_amd.facility.optimizer import SparseDenseAdam
     from unirec_amd.utils.general import get_class_instance, init_seed
     init_seed(4)
     model = get_class_instance("SASRec", "unirec_amd/model")(_cfg())
-    opt = SparseDenseAdam(model, lr=5e-3, weight_decay=wd, algo=algo)
+    opt = SparseDenseAdam(model, lr=5e-3, weight_decay=wd, algo=algo, table_mode=table_mode)
     model.train()
     bs = _batches(n_steps + 2)
     other = _batches(3, seed=99)
@@ -52,7 +57,11 @@ def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14):
         if ahead:
             opt.prefetch_plan(item_seq=nxt["item_seq"], item_id=nxt["item_id"])
         loss = model.forward_backward(item_id=b["item_id"], label=lab, item_seq=b["item_seq"])
-        opt.step()
+        if nan_at == s:                       # a NaN loss: the update kernels read the guard and skip the step
+            model.loss_guard.fill_(-1.0)
+        # "defer": the loop says another step follows (as Trainer.fit / bench.py do): the rows the next batch does not read are reduced
+        # and updated on the optimizer's tail stream, beside the next forward pass; the others at once, on the main stream
+        opt.step(late_join=(ahead == "defer" and s + 1 < n_steps))
         losses.append(float(loss))
     opt.flush()
     torch.cuda.synchronize()
@@ -63,7 +72,7 @@ def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14):
 @pytest.mark.parametrize("algo,wd", [("adam", 0.0), ("adamw", 0.01), ("adam", 0.001), ("rmsprop", 0.0)])
 def test_catchup_ahead_is_bit_identical(algo, wd):
     b = _train(False, algo, wd)
-    for mode in ("tail",):
+    for mode in ("tail", "defer"):
         a = _train(mode, algo, wd)
         assert a[0] == b[0]
         for x, y, what in zip(a[1:], b[1:], ("w", "m", "v", "dense")):
@@ -74,7 +83,7 @@ def test_a_prefetched_batch_that_is_not_trained_on_changes_nothing():
     """rows caught up for a batch that is then not trained on are simply up to date earlier: the same zero-gradient steps, summed in
     two pieces instead of one (fp32 re-association of the replay sum: a few ulp of an lr-sized term, not bit-equal)"""
     c = _train(False)
-    for mode in ("tail",):
+    for mode in ("tail", "defer"):
         a = _train(mode, swap_at=5)
         for x, z, what in zip(a[1:4], c[1:4], ("w", "m", "v")):
             assert torch.allclose(x, z, rtol=1e-4, atol=1e-6), (mode, what, float((x - z).abs().max()))
@@ -131,3 +140,16 @@ def test_dense_half_on_the_side_stream_is_bit_identical():
         for sa, sb in zip(got[5], ref[5]):
             for n in sb:
                 assert torch.equal(sa[n], sb[n]), (mode, n)
+
+
+@pytest.mark.parametrize("table_mode", ["lazy_dense", "rowwise"])
+def test_deferred_row_update_with_a_skipped_step_is_bit_identical(table_mode):
+    """The row update split over the main stream (rows the next batch reads as well) and the tail stream (the rest, beside the next
+    forward pass), with a step whose NaN guard skips the update in the middle: the rows two batches share take the skipped step as a
+    zero-gradient step (as every row the step does not touch), the others are left alone -- the trajectory of catching up at the head
+    of the next step, bit for bit.  300 rows, 16 x 15 lookups per batch: about half of a batch's rows are the next one's too."""
+    b = _train(False, nan_at=6, table_mode=table_mode)
+    a = _train("defer", nan_at=6, table_mode=table_mode)
+    assert a[0] == b[0]
+    for x, y, what in zip(a[1:], b[1:], ("w", "m", "v", "dense")):
+        assert torch.equal(x, y), (what, float((x - y).abs().max()))

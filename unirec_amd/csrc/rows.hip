@@ -392,7 +392,8 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
                                                           long long n, const float4* __restrict__ rows_a, long long n_a,
                                                           const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G,
                                                           int d4, float4* __restrict__ out, int zero_tail,
-                                                          const int* __restrict__ out_rows) {
+                                                          const int* __restrict__ out_rows, const int* __restrict__ u_list = nullptr,
+                                                          const int* __restrict__ n_list_dev = nullptr) {
   // (these two kernels run beside the bottom layer's weight-gradient launch: their few memory instructions go first -- 0.601 -> 0.596 ms/step)
   __builtin_amdgcn_s_setprio(3);
   constexpr int groups = 256 / TPR;
@@ -400,31 +401,39 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
   __shared__ int long_list[256];
   __shared__ int long_cnt;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
-  const int n_uniq = *n_uniq_dev;
+  // u_list (nullable): only the unique ids u_list[0 .. *n_list_dev) are reduced, entry i into out row i (ur_rows_reduce_subset);
+  // below, an ENTRY is a position of that list, or the unique id itself without one
+  const int n_uniq = u_list ? min(*n_list_dev, *n_uniq_dev) : *n_uniq_dev;
+  auto uid = [&](long long i) -> long long { return u_list ? (long long)u_list[i] : i; };
   // (pass 2's first candidate test is issued here, so that its loads travel with pass 1's instead of after them)
   const long long gstride = gridDim.x;
   const long long uc0 = blockIdx.x + gstride * threadIdx.x;
-  const bool cand0 = uc0 < n_uniq && uniq_idx[uc0] != 0 && seg_start[uc0 + 1] - seg_start[uc0] > LONG_SEG;
+  bool cand0 = false;
+  if (uc0 < n_uniq) {
+    const long long u0 = uid(uc0);
+    cand0 = uniq_idx[u0] != 0 && seg_start[u0 + 1] - seg_start[u0] > LONG_SEG;
+  }
   // ---- pass 1: one lane group per unique id, neighbouring ids in one workgroup (coalesced plan reads).  Long runs are left out.
   for (long long base = (long long)blockIdx.x * groups; base < n; base += (long long)gridDim.x * groups) {
     if (base >= n_uniq && !zero_tail) break;   // block-uniform
-    const long long u = base + g;
-    if (u >= n) continue;
-    if (u >= n_uniq) {
+    const long long ent = base + g;
+    if (ent >= n) continue;
+    if (ent >= n_uniq) {
       if (zero_tail) {
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
           const int c = t + k * TPR;
-          if (c < d4) out[u * d4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c < d4) out[ent * d4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
       continue;
     }
+    const long long u = uid(ent);
     float4 acc[MAXV];
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long frow = uniq_idx[u];
-    const long long orow = out_rows ? out_rows[u] : u;   // (out_rows: the row of unique id u in the caller's layout, e.g. its exchange slot)
+    const long long orow = out_rows ? out_rows[u] : ent;   // (out_rows: the row of unique id u in the caller's layout, e.g. its exchange slot)
     if (frow != 0) {
       const int s = seg_start[u], e = seg_start[u + 1];
       if (e - s > LONG_SEG) continue;                      // pass 2
@@ -447,12 +456,19 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
     if (threadIdx.x == 0) long_cnt = 0;
     __syncthreads();
     const long long uc = blockIdx.x + gstride * (j0 + threadIdx.x);
-    const bool cand = j0 == 0 ? cand0 : (uc < n_uniq && uniq_idx[uc] != 0 && seg_start[uc + 1] - seg_start[uc] > LONG_SEG);
+    bool cand = cand0;
+    if (j0 != 0) {
+      cand = false;
+      if (uc < n_uniq) {
+        const long long uu = uid(uc);
+        cand = uniq_idx[uu] != 0 && seg_start[uu + 1] - seg_start[uu] > LONG_SEG;
+      }
+    }
     if (cand) long_list[atomicAdd(&long_cnt, 1)] = (int)uc;
     __syncthreads();
     const int cnt = long_cnt;
     for (int li = 0; li < cnt; ++li) {
-      const long long ul = long_list[li];
+      const long long el_ = long_list[li], ul = uid(el_);
       const int sl = seg_start[ul], el = seg_start[ul + 1];
       float4 acc[MAXV];
 #pragma unroll
@@ -476,7 +492,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
               const float4 x = part[gg][k * TPR + t];
               r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
             }
-            out[(out_rows ? (long long)out_rows[ul] : ul) * d4 + c] = r;
+            out[(out_rows ? (long long)out_rows[ul] : el_) * d4 + c] = r;
           }
         }
       }
@@ -662,16 +678,20 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
                                                  float4* __restrict__ var, int* __restrict__ last_step,
                                                  const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev, long long n_max,
                                                  const float4* __restrict__ grad, int d4, const float* __restrict__ scale_dev,
-                                                 int bid, int nblk) {
+                                                 int bid, int nblk, const int* __restrict__ skip_mark = nullptr) {
+  // MODE 2 = MODE 0 for rows the NEXT batch reads as well (the "hot" rows of a step whose other updates run beside the next forward
+  // pass): when the step is skipped (scale < 0) they still take it as a zero-gradient step, as every row the step does not touch does --
+  // the catch-up the next batch's rows would otherwise get behind the update.  skip_mark (MODE 0; per unique id): rows somebody else updates.
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int n_uniq = (int)min((long long)*n_uniq_dev, n_max);
   const float scale = scale_dev ? *scale_dev : 1.0f;
   if (MODE == 0 && scale < 0.f) return;   // update guard: NaN loss, the whole step is skipped (see dense_adam_kernel)
+  const bool skipped = MODE == 2 && scale < 0.f;
   if (bid * groups >= n_uniq) return;     // nothing for this workgroup (the grid is sized for the plan's capacity; a filtered catch-up
                                           // list is often EMPTY: 3 520 workgroups evaluating two powf for nothing were 20 us)
   const float bc1 = 1.f - powf(a.b1, (float)a.step), bc2s = sqrtf(1.f - powf(a.b2, (float)a.step));
-  if (MODE == 0 && d4 <= TPR) {
+  if (MODE != 1 && d4 <= TPR && !skipped) {   // (MODE 2 too: the rows two batches share go through the SAME instruction sequence as the rest)
     // One float4 per lane and row: FOUR rows per lane group in flight.  The rows are random 512-byte reads over tables of tens of
     // GB (w, m, v: three TLB misses per row); with one row per group the kernel is a chain of dependent round trips (plan entry ->
     // last_step -> row) at 1.4 TB/s.  Here every load of a trip is issued before the first use; indices are clamped and the loads
@@ -696,7 +716,7 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
       }
 #pragma unroll
       for (int i = 0; i < U; ++i) {
-        if (u0 + i >= n_uniq || row[i] == 0) continue;   // group-uniform
+        if (u0 + i >= n_uniq || row[i] == 0 || (skip_mark && skip_mark[u0 + i])) continue;   // group-uniform
         if (last_step) {
           const LazyRow lr = lazy_row_prepare<TPR>(last[i], a.step - 1, a, t);
           lazy_row_apply(lr, w[i], m[i], v[i], a);
@@ -717,8 +737,26 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
   }
   for (int u = bid * groups + g; u < n_uniq; u += nblk * groups) {
     const long long row = uniq_idx[u];
-    if (row == 0) continue;
+    if (row == 0 || (MODE == 0 && skip_mark && skip_mark[u])) continue;
     const int last = last_step ? last_step[row] : a.step - 1;
+    if (skipped) {   // (MODE 2, the step is skipped: the zero-gradient steps up to and including this one)
+      if (!last_step || last >= a.step) continue;
+      const LazyRow lz = lazy_row_prepare<TPR>(last, a.step, a, t);
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int c = t + k * TPR;
+        if (c < d4) {
+          float4 w = table[row * d4 + c], m = mom[row * d4 + c], v = var[row * d4 + c];
+          lazy_row_apply(lz, w, m, v, a);
+          table[row * d4 + c] = w;
+          mom[row * d4 + c] = m;
+          var[row * d4 + c] = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (t == 0) last_step[row] = a.step;
+      continue;
+    }
     if (MODE == 1 && last >= a.step - 1) continue;   // already there (updated by the step in between, or caught up ahead of time)
     if (MODE == 1 && last == 0 && a.wd == 0.f) {   // never updated: m = v = 0, every zero-gradient step is a no-op
       if (t == 0) last_step[row] = a.step - 1;
@@ -732,7 +770,7 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
       if (c < d4) {
         float4 w = table[row * d4 + c], m = mom[row * d4 + c], v = var[row * d4 + c];
         if (last_step) lazy_row_apply(lr, w, m, v, a);
-        if (MODE == 0) {
+        if (MODE != 1) {
           const float4 gr = grad[(long long)u * d4 + c];
           opt_elem(w.x, m.x, v.x, gr.x * scale, a, bc1, bc2s);
           opt_elem(w.y, m.y, v.y, gr.y * scale, a, bc1, bc2s);
@@ -745,7 +783,7 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (last_step && t == 0) last_step[row] = (MODE == 0) ? a.step : a.step - 1;
+    if (last_step && t == 0) last_step[row] = (MODE != 1) ? a.step : a.step - 1;
   }
 }
 
@@ -754,9 +792,10 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
                                                           float4* __restrict__ var, int* __restrict__ last_step,
                                                           const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
                                                           long long n_max, const float4* __restrict__ grad, int d4,
-                                                          const float* __restrict__ scale_dev) {
+                                                          const float* __restrict__ scale_dev, const int* __restrict__ skip_mark) {
   __builtin_amdgcn_s_setprio(3);   // (see rows_reduce_kernel)
-  sparse_adam_body<TPR, MODE>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, (int)blockIdx.x, (int)gridDim.x);
+  sparse_adam_body<TPR, MODE>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, (int)blockIdx.x, (int)gridDim.x,
+                              skip_mark);
 }
 template <int TPR>
 __global__ __launch_bounds__(256) void lazy_flush_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
@@ -1213,10 +1252,10 @@ extern "C" int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_
   return UR_OK;
 }
 
-extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
-                              const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
-                              const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
-                              void* stream) {
+static int rows_reduce_impl(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
+                            const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
+                            const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
+                            const int32_t* u_list, const int32_t* n_list_dev, int64_t n_entries, void* stream) {
   UR_REQUIRE(uniq_idx && seg_start && sorted_pos && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_rows_reduce: null pointer");
   UR_REQUIRE(!(out_rows && sumsq_dev), UR_ERR_ARG, "ur_rows_reduce: out_rows with the zeroed tail");
   UR_REQUIRE(n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_rows_reduce: n=%lld n_a=%lld", (long long)n, (long long)n_a);
@@ -1225,12 +1264,13 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
   hipStream_t st = as_stream(stream);
   ProfScope ps(PC_REDUCE, st, (double)n * d * 4.0 * 2);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
-  int blocks = cdiv(n, groups);
+  int blocks = cdiv(n_entries, groups);   // (entries = the plan's capacity, or the subset list's)
   if (blocks > 8192) blocks = 8192;
+  if (u_list && blocks > 512) blocks = 512;   // (a subset list is sized for the worst case and usually short: grid-stride over it)
   const int zero_tail = sumsq_dev != nullptr;
 #define GO(T) hipLaunchKernelGGL((rows_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
-                                 (long long)n, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,          \
-                                 (float4*)uniq_grad, zero_tail, out_rows)
+                                 (long long)n_entries, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,          \
+                                 (float4*)uniq_grad, zero_tail, out_rows, u_list, n_list_dev)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;
@@ -1242,10 +1282,29 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
   return UR_OK;
 }
 
+extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
+                              const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
+                              const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
+                              void* stream) {
+  return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, uniq_grad, sumsq_dev, out_rows,
+                          nullptr, nullptr, n, stream);
+}
+
+// the same for a SUBSET of the plan's unique ids: entry i of u_list (indices into uniq_idx, *n_list_dev of them, at most n_list_max)
+// -> row i of out [n_list_max, d].  Same sums in the same order as ur_rows_reduce gives those ids.
+extern "C" int ur_rows_reduce_subset(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
+                                     const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
+                                     const float* vec_b, int32_t G, int32_t d, const int32_t* u_list, const int32_t* n_list_dev,
+                                     int64_t n_list_max, float* out, void* stream) {
+  UR_REQUIRE(u_list && n_list_dev && n_list_max > 0, UR_ERR_ARG, "ur_rows_reduce_subset: list");
+  return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, out, nullptr, nullptr, u_list,
+                          n_list_dev, n_list_max, stream);
+}
+
 constexpr int UR_CATCHUP_BLOCKS = 1024;
 static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* grad, int d,
-                              const float* scale, hipStream_t st) {
+                              const float* scale, hipStream_t st, const int32_t* skip_mark = nullptr) {
   ProfScope ps(PC_ADAM, st, (double)n_max * d * 4.0 * 7);
   AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
   a.lb1 = cfg->beta1 > 0.f ? (float)log2((double)cfg->beta1) : -1e30f;
@@ -1255,10 +1314,10 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
   if (blocks > 8192) blocks = 8192;
   // the catch-up walks a (usually short, often empty) filtered list with a grid-stride loop: a grid sized for the plan's capacity was
   // 3 520 workgroups that start, read the count and leave -- 20 us of dispatch at the tail of every step beside the dW launch
-  if (mode == 1 && blocks > UR_CATCHUP_BLOCKS) blocks = UR_CATCHUP_BLOCKS;
+  if (mode != 0 && blocks > UR_CATCHUP_BLOCKS) blocks = UR_CATCHUP_BLOCKS;   // (mode 2: the short list of rows two consecutive batches share)
   if (blocks < 1) blocks = 1;
 #define GO(T, MD) hipLaunchKernelGGL((sparse_adam_kernel<T, MD>), dim3(blocks), dim3(256), 0, st, a, (float4*)table, (float4*)m, \
-                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale)
+                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale, skip_mark)
 #define SW(MD)            \
   switch (tpr) {          \
     case 4: GO(4, MD); break;   \
@@ -1266,7 +1325,7 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
     case 16: GO(16, MD); break; \
     default: GO(32, MD); break; \
   }
-  if (mode == 0) { SW(0) } else { SW(1) }
+  if (mode == 0) { SW(0) } else if (mode == 1) { SW(1) } else { SW(2) }
 #undef SW
 #undef GO
   UR_LAUNCH_CHECK();
@@ -1288,6 +1347,21 @@ extern "C" int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m,
   UR_REQUIRE(table && m && v && uniq_idx && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_sparse_adam_rows: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_sparse_adam_rows: d=%d n_max=%lld", d, (long long)n_max);
   return launch_sparse_adam(0, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, uniq_grad, d, grad_scale_dev, as_stream(stream));
+}
+
+// ur_sparse_adam_rows split over two launches (the update of a step running beside the NEXT forward pass, facility/optimizer.py):
+// hot != 0: the rows the next batch reads too, a short list with its own gradients (ur_rows_reduce_subset) -- and when the step is
+// skipped (grad_scale_dev < 0) they take it as a zero-gradient step; hot == 0: the whole plan minus the ids with skip_mark[u] != 0.
+extern "C" int ur_sparse_adam_rows_split(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                                         const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad,
+                                         int32_t d, const float* grad_scale_dev, int32_t hot, const int32_t* skip_mark, void* stream) {
+  int rc = check_adam(cfg, "ur_sparse_adam_rows_split");
+  if (rc) return rc;
+  UR_REQUIRE(table && m && v && uniq_idx && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_sparse_adam_rows_split: null pointer");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_sparse_adam_rows_split: d=%d n_max=%lld", d, (long long)n_max);
+  UR_REQUIRE(hot ? skip_mark == nullptr : skip_mark != nullptr, UR_ERR_ARG, "ur_sparse_adam_rows_split: hot list XOR skip marks");
+  return launch_sparse_adam(hot ? 2 : 0, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, uniq_grad, d, grad_scale_dev,
+                            as_stream(stream), skip_mark);
 }
 
 extern "C" int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
@@ -1334,14 +1408,15 @@ __global__ __launch_bounds__(256) void rows_split_hot_kernel(const int* __restri
                                                              long long n_max, const int* __restrict__ last_step,
                                                              const int* __restrict__ excl, const int* __restrict__ excl_n_dev, int excl_max,
                                                              int* __restrict__ cold, int* __restrict__ cold_n, int* __restrict__ hot,
-                                                             int* __restrict__ hot_n) {
+                                                             int* __restrict__ hot_n, int* __restrict__ hot_u, int* __restrict__ excl_mark) {
   const int n = (int)min((long long)*n_uniq_dev, n_max);
   const int ne = excl ? min(*excl_n_dev, excl_max) : 0;
   const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
   const int row = i < n ? uniq_idx[i] : 0;
   bool is_hot = false;
+  int lo = 0;
   if (row != 0 && ne > 0) {
-    int lo = 0, hi = ne;
+    int hi = ne;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       if (excl[mid] < row) lo = mid + 1; else hi = mid;
@@ -1359,19 +1434,26 @@ __global__ __launch_bounds__(256) void rows_split_hot_kernel(const int* __restri
   base = 0;
   if (lane == 0 && m) base = atomicAdd(hot_n, __popcll(m));
   base = __shfl(base, 0, 64);
-  if (is_hot) hot[base + __popcll(m & lt)] = row;
+  if (is_hot) {
+    const int o = base + __popcll(m & lt);
+    hot[o] = row;
+    if (hot_u) hot_u[o] = lo;          // its index in the other plan's unique list
+    if (excl_mark) excl_mark[lo] = 1;
+  }
 }
 extern "C" int ur_rows_split_hot(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const int32_t* last_step,
                                  const int32_t* excl_sorted, const int32_t* excl_n_dev, int64_t excl_max, int32_t* cold_idx,
-                                 int32_t* cold_n_dev, int32_t* hot_idx, int32_t* hot_n_dev, void* stream) {
+                                 int32_t* cold_n_dev, int32_t* hot_idx, int32_t* hot_n_dev, int32_t* hot_u, int32_t* excl_mark,
+                                 void* stream) {
   UR_REQUIRE(uniq_idx && n_uniq_dev && cold_idx && cold_n_dev && hot_idx && hot_n_dev && n_max > 0 && n_max < (1LL << 31), UR_ERR_ARG,
              "ur_rows_split_hot: null pointer or n_max=%lld", (long long)n_max);
   UR_REQUIRE(!excl_sorted || (excl_n_dev && excl_max > 0 && excl_max < (1LL << 31)), UR_ERR_ARG, "ur_rows_split_hot: exclusion list");
   hipStream_t st = as_stream(stream);
   UR_HIP(hipMemsetAsync(cold_n_dev, 0, sizeof(int32_t), st));
   UR_HIP(hipMemsetAsync(hot_n_dev, 0, sizeof(int32_t), st));
+  if (excl_mark && excl_sorted) UR_HIP(hipMemsetAsync(excl_mark, 0, sizeof(int32_t) * (size_t)excl_max, st));
   hipLaunchKernelGGL(rows_split_hot_kernel, dim3(cdiv(n_max, 256)), dim3(256), 0, st, uniq_idx, n_uniq_dev, (long long)n_max, last_step,
-                     excl_sorted, excl_n_dev, (int)excl_max, cold_idx, cold_n_dev, hot_idx, hot_n_dev);
+                     excl_sorted, excl_n_dev, (int)excl_max, cold_idx, cold_n_dev, hot_idx, hot_n_dev, hot_u, excl_mark);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

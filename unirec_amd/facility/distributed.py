@@ -342,7 +342,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                     self._a2a(bf["slot2"], bf["slot2_recv"], "a2a_fix_slots")
             if lazy and st["last"] is not None:
                 bf["split"] = ops.rows_split_hot(c["own"], st["last"] if self.wd == 0.0 else None, pown, out=bf["split"])
-                cold, c["hot"] = bf["split"]
+                cold, c["hot"] = bf["split"][0], bf["split"][1]
                 ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], cold)
                 c["caught_up"] = self.t
             ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, cap, bf["rows_ws"], compact=bf["compact"], transport=False)
