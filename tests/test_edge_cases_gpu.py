@@ -78,7 +78,10 @@ def test_sasrec_eight_layers_and_every_sequence_empty():
     _run("SASRec", dict(use_position_emb=False), 4, 6, 3, 30, seq_fn=lambda s: torch.cat([torch.zeros_like(s[:, :4]), s[:, 4:]], 1))
 
 
-@pytest.mark.parametrize("B,L,H", [(1, 1, 16), (2, 3, 32), (17, 5, 64), (3, 2, 128), (4, 4, 24), (5, 4, 384)])   # 384: the per-step path with its K dimension split (2 pieces forward, 6 backward)
+# 24: gemm_nt + cell kernels per step; 384 / 192 / 768 / 512: the fused step kernels (H % 64 == 0 beyond the persistent kernels' range) with
+# 16, 32 and 48 units per workgroup (the wider tiles need >= 200 workgroups: B >= 416), B not a multiple of the 32-row tile
+@pytest.mark.parametrize("B,L,H", [(1, 1, 16), (2, 3, 32), (17, 5, 64), (3, 2, 128), (4, 4, 24), (5, 4, 384), (37, 3, 192), (420, 3, 768),
+                                   (421, 2, 512), (33, 2, 768)])
 def test_gru_small_shapes_both_recurrence_paths(B, L, H):
     _run("GRU", dict(hidden_size=H, embedding_size=16), B, L, 3, 40)
 

@@ -30,8 +30,11 @@ def test_attention_kernel_families(env):
 
 
 def test_gru_per_step_path_and_sorting_owner_plan():
-    _run({"UR_GRU_NO_SEQ": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_edge_cases_gpu.py"),
-                                  os.path.join(HERE, "test_trainer_gpu.py"), "-k", "gru or GRU or g7"], expect_min_passed=8)
+    # UR_GRU_NO_SEQ: no persistent recurrence kernel -- H % 64 == 0 then takes the fused step kernels (one launch per step: product + gates /
+    # product + carry, round 4), other widths gemm_nt + the cell kernels; UR_GRU_NO_STEP on top: gemm_nt + cell kernels for every width
+    for env in ({"UR_GRU_NO_SEQ": "1"}, {"UR_GRU_NO_SEQ": "1", "UR_GRU_NO_STEP": "1"}):
+        _run(env, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_edge_cases_gpu.py"),
+                   os.path.join(HERE, "test_trainer_gpu.py"), "-k", "gru or GRU or g7"], expect_min_passed=8)
 
 
 def test_inline_weight_gradients():

@@ -20,12 +20,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n-items", type=int, default=10_000_000)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--hidden", type=int, default=128, help="768 = the reference yaml's default width")
     x = ap.parse_args()
     sys.argv = [sys.argv[0], "--n-items", str(x.n_items)]
     a = bench.parse()
     dev = torch.device("cuda:0")
     cfg = bench.model_config(a, "cuda:0")
-    cfg.update(model="GRU", hidden_size=128, loss_type="softmax")
+    cfg.update(model="GRU", hidden_size=x.hidden, loss_type="softmax")
     model = GRU(cfg)
     opt = SparseDenseAdam(model, lr=1e-3, table_mode="lazy_dense")
     model.train()
@@ -57,7 +58,7 @@ def main():
         step(batches[i], batches[i + 1])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (x.steps - 1)
-    print(json.dumps({"workload": f"GRU n_items={x.n_items} d=H=128 L=50 B=512 K=4 softmax", "ms_per_step": round(dt * 1e3, 4),
+    print(json.dumps({"workload": f"GRU n_items={x.n_items} d=128 H={x.hidden} L=50 B=512 K=4 softmax", "ms_per_step": round(dt * 1e3, 4),
                       "examples_per_s": round(a.batch / dt, 1), "kernel_ms_and_launches_per_step": classes}))
 
 

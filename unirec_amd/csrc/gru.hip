@@ -466,6 +466,209 @@ __global__ __launch_bounds__(512) void gru_seq4_bwd_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Round 4: the recurrence of a WIDE hidden state (H = 768: unirec/config/model/GRU.yaml:4, the reference's default; any H % 64 == 0
+// outside the persistent kernels' range) as ONE launch per time step and direction.  W_hh is 7 MB at H = 768: it does not live in one
+// CU, and a step's product is 1.8 GFLOP -- 11.5 us of the chip's fp32 MFMA rate -- so a launch per step is not the bound; what was:
+// the per-step path of rounds 1-3 ran gemm_nt with its K dimension split into 4 (forward) / 12 (backward) pieces, wrote the partial
+// products to HBM (19 MB a step) and summed them in a separate cell kernel: 29 + 10 us a step, 309 launches a pass, 4.85 ms.  Here:
+//   * a workgroup owns 32 rows x NU hidden units (48 at H = 768: 16 x 16 = 256 workgroups) and ALL THREE gates of those units (forward: 9
+//     column tiles of 16 = r, z, n of the same units), so the gate arithmetic is the epilogue of the product and h_t, r, z, n, hn are
+//     the only things written;
+//   * its four waves split K (no two waves read the same operand bytes: fragments go straight from L2 into registers, a ring of NS
+//     16-wide k blocks deep), v_mfma_f32_16x16x4_f32, 2 x NT accumulator tiles per wave; the four partial tiles meet in LDS and are summed
+//     in wave order (fixed order: bit-reproducible);
+//   * blockIdx -> (unit block, row block) keeps the workgroups of one XCD on 1 / 8 of the unit blocks: 0.9 MB of W_hh + the 1.5 MB of
+//     h_{t-1} per XCD stay in its 4 MB L2 (PMC: 88 % L2 hits, 13 MB from HBM a step = the operands once);
+//   * backward: dh_{t-1} = dgh_t W_hh + dh_t z with the carry added in the epilogue (the cell kernel in front of it no longer sums pieces).
+// Measured (B = 512, L = 50, one MI355X, tools/probe/gru_host.py): forward sweep 1.83 -> 1.43 ms, backward 2.89 -> 2.40 ms; a step's
+// launch 24 / 20 us = 0.47 / 0.57 of the MFMA rate (PMC 0.34-0.38 busy incl. the ramps), the rest ~7 us of fixed cost per launch.
+constexpr int GS_ROWS = 32;
+struct __attribute__((packed, aligned(4))) GsF3 { float a, b, c; };
+struct __attribute__((packed, aligned(4))) GsF2 { float a, b; };
+struct GruStepArgs {
+  const float* A; int lda;            // [B][K]: h_{t-1} (forward) / dgh_t (backward)
+  const float* W; int ldw;            // [K][cols], K-major: W_hh^T [H][3H] (forward: column g * H + unit) / W_hh [3H][H] (backward)
+  int B, K, H, unit_blocks;
+  const float *gi, *b_hh, *hprev;     // forward: gi_t [B][3H], b_hh [3H], h_{t-1} [B][H]
+  float *h_out, *r_s, *z_s, *n_s, *hn_s;
+  const float* carry; float* dh_out;  // backward: dh_t z_t [B][H] -> dh_{t-1} [B][H]
+};
+
+template <int NUT, bool FWD>
+__global__ __launch_bounds__(256) void gru_step_kernel(GruStepArgs a) {
+  constexpr int NU = 16 * NUT;                  // hidden units (forward) / dh columns (backward) per workgroup
+  constexpr int NT = FWD ? 3 * NUT : NUT;       // column tiles of 16
+  constexpr int NG = FWD ? 3 : 1;               // gates (column groups of NU)
+  constexpr int LDP = 16 * NT + 4;              // LDS row stride of a partial tile
+  extern __shared__ __attribute__((aligned(16))) float part[];   // [4 waves][32 rows][LDP]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+  // XCD-aware tile order (workgroup b runs on XCD b % 8)
+  int ub, rb;
+  const int bid = blockIdx.x;
+  if (a.unit_blocks % 8 == 0) {
+    const int per = a.unit_blocks / 8, xcd = bid & 7, loc = bid >> 3;
+    ub = xcd * per + loc % per;
+    rb = loc / per;
+  } else {
+    ub = bid % a.unit_blocks;
+    rb = bid / a.unit_blocks;
+  }
+  const int m0 = rb * GS_ROWS, u0 = ub * NU;
+  const int KQ = a.K / 4, k0 = w * KQ + 4 * kq;
+  const float* ap[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) ap[rt] = a.A + (long long)min(m0 + 16 * rt + c16, a.B - 1) * a.lda + k0;
+  // W is K-MAJOR ([K][cols]) and a lane reads NUT CONSECUTIVE columns of a k row in one load: the 16 lanes of a k row cover the
+  // workgroup's 16 NUT columns of a gate contiguously (192 B at NUT = 3), four k rows per wave instruction.  Column tile t of a gate then
+  // holds the columns u0 + NUT c16 + t (a permutation undone where the partial tiles are written); MFMA i of a 16-wide k block
+  // multiplies k = 4 kq + i on both operands.  ([cols][K] with one 16-byte load per lane -- 16 rows x 64 B per wave instruction -- ran
+  // at 26 us a step; one dword per (column, k) is 38 loads a block, and three blocks of those overflow the 6-bit count of loads in flight.)
+  const float* wp[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) wp[g] = a.W + (long long)k0 * a.ldw + (FWD ? g * a.H : 0) + u0 + NUT * c16;
+  const int ldw = a.ldw;
+  struct WFrag { float v[4][NUT]; };            // [k step i][column tile t]
+  auto wload = [&](const float* p, int kb) -> WFrag {   // k block kb (multiple of 16) of this lane's NUT columns
+    WFrag f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* q = p + (long long)(kb + i) * ldw;
+      if constexpr (NUT == 3) { const GsF3 x = *(const GsF3*)q; f.v[i][0] = x.a; f.v[i][1] = x.b; f.v[i][2] = x.c; }   // global_load_dwordx3 (dword-aligned)
+      else if constexpr (NUT == 2) { const GsF2 x = *(const GsF2*)q; f.v[i][0] = x.a; f.v[i][1] = x.b; }
+      else f.v[i][0] = q[0];
+    }
+    return f;
+  };
+  // the epilogue's operands (thread -> EPT (row, unit) pairs) are requested HERE, in front of the product they do not depend on: behind it
+  // they were EPT dependent round trips of a lone wave per SIMD
+  constexpr int EPT = GS_ROWS * NU / 256;
+  float e_gi[FWD ? EPT : 1][3], e_bh[FWD ? EPT : 1][3], e_x[EPT];     // forward: gi_t, b_hh (r, z, n), h_{t-1}; backward: the carry
+#pragma unroll
+  for (int it = 0; it < EPT; ++it) {
+    const int e = tid + 256 * it, m = e / NU, u = e % NU, b = min(m0 + m, a.B - 1), j = u0 + u;
+    if constexpr (FWD) {
+      const float* gp = a.gi + (long long)b * 3 * a.H;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) { e_gi[it][g] = gp[g * a.H + j]; e_bh[it][g] = a.b_hh[g * a.H + j]; }
+      e_x[it] = a.hprev[(long long)b * a.H + j];
+    } else {
+      e_x[it] = a.carry[(long long)b * a.H + j];
+    }
+  }
+  floatx4 acc[2][NT];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[rt][ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+  // fragments of NS 16-wide k blocks in a ring: a block is requested NS - 1 blocks before it is consumed -- ONE wave per SIMD lives here
+  // (72 accumulator + 44 fragment registers per stage at NT = 9), so nothing else hides an L2 round trip
+  constexpr int NS = FWD ? 4 : 6;
+  float4 af[NS][2];
+  WFrag wf[NS][NG];
+  const int ns = KQ / 16;
+#pragma unroll
+  for (int p = 0; p < NS - 1; ++p) {
+    const int sp = min(p, ns - 1) * 16;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) af[p][rt] = *(const float4*)(ap[rt] + sp);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wf[p][g] = wload(wp[g], sp);
+  }
+  for (int s = 0; s < ns; s += NS) {
+#pragma unroll
+    for (int ph = 0; ph < NS; ++ph) {
+      const int cur = ph, nxt = (ph + NS - 1) % NS;
+      const int sn = min(s + ph + NS - 1, ns - 1) * 16;     // (beyond the end: re-reads the last block, no branch around a load)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) af[nxt][rt] = *(const float4*)(ap[rt] + sn);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) wf[nxt][g] = wload(wp[g], sn);
+      if (s + ph < ns) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+              const float av = i == 0 ? af[cur][rt].x : i == 1 ? af[cur][rt].y : i == 2 ? af[cur][rt].z : af[cur][rt].w;
+              acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[cur][ct / NUT].v[i][ct % NUT], acc[rt][ct], 0, 0, 0);
+            }
+      }
+    }
+  }
+  // partial tiles -> LDS (accumulator register r: row 4 kq + r, column c16)
+  float* mine = part + (long long)w * GS_ROWS * LDP;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)   // tile ct = (gate, t): its column c16 is column NUT c16 + t of the gate
+        mine[(16 * rt + 4 * kq + r) * LDP + (ct / NUT) * NU + NUT * c16 + ct % NUT] = acc[rt][ct][r];
+  __syncthreads();
+  // epilogue: thread -> (row, unit); the four waves' partials in wave order
+#pragma unroll
+  for (int it = 0; it < EPT; ++it) {
+    const int e = tid + 256 * it, m = e / NU, u = e % NU, b = m0 + m;
+    if (b >= a.B) continue;
+    if constexpr (FWD) {
+      float pr = 0.f, pz = 0.f, pn = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* p = part + ((long long)q * GS_ROWS + m) * LDP;
+        pr += p[u]; pz += p[NU + u]; pn += p[2 * NU + u];
+      }
+      const float rr = 1.0f / (1.0f + expf(-(e_gi[it][0] + (pr + e_bh[it][0]))));
+      const float zz = 1.0f / (1.0f + expf(-(e_gi[it][1] + (pz + e_bh[it][1]))));
+      const float hn = pn + e_bh[it][2];
+      const float nn = tanhf(e_gi[it][2] + rr * hn);
+      const long long o = (long long)b * a.H + u0 + u;
+      a.h_out[o] = (1.0f - zz) * nn + zz * e_x[it];
+      a.r_s[o] = rr; a.z_s[o] = zz; a.n_s[o] = nn; a.hn_s[o] = hn;
+    } else {
+      float sacc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sacc += part[((long long)q * GS_ROWS + m) * LDP + u];
+      a.dh_out[(long long)b * a.H + u0 + u] = sacc + e_x[it];
+    }
+  }
+}
+
+// units per workgroup (in 16s) of the step kernels, 0 = not applicable: the widest tile that still gives ~a workgroup per CU
+static int gru_step_nut(int B, int H) {
+  static const bool off = getenv("UR_GRU_NO_STEP") != nullptr;   // test / tuning hook: the gemm_nt + cell-kernel path of rounds 1-3
+  if (off || H % 64 != 0) return 0;
+  const int rbs = cdiv(B, GS_ROWS);
+  for (int nut = 3; nut >= 1; --nut)
+    if (H % (16 * nut) == 0 && (nut == 1 || (long long)rbs * (H / (16 * nut)) >= 200)) return nut;
+  return 0;
+}
+template <bool FWD>
+static int gru_step_launch(int nut, GruStepArgs a, hipStream_t st) {
+  a.unit_blocks = a.H / (16 * nut);
+  const int grid = cdiv(a.B, GS_ROWS) * a.unit_blocks;
+  const int nt = FWD ? 3 * nut : nut;
+  const size_t lds = (size_t)4 * GS_ROWS * (16 * nt + 4) * sizeof(float);
+  ProfScope ps(PC_GRU, st, 2.0 * a.B * (double)a.K * (FWD ? 3.0 * a.H : (double)a.H));
+#define GO(N_) do {                                                                                                                   \
+    static bool big_lds_set = false;   /* (76 KB at 48 units forward: above the 64 KB a kernel gets without asking) */                 \
+    if (lds > 64 * 1024 && !big_lds_set) {                                                                                            \
+      UR_HIP(hipFuncSetAttribute((const void*)gru_step_kernel<N_, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));        \
+      big_lds_set = true;                                                                                                             \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((gru_step_kernel<N_, FWD>), dim3(grid), dim3(256), lds, st, a);                                                \
+  } while (0)
+  switch (nut) {
+    case 3: GO(3); break;
+    case 2: GO(2); break;
+    default: GO(1); break;
+  }
+#undef GO
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
 static bool gru_seq4_supported(int H) { return H == 64 || H == 128; }
 
 static bool gru_seq_supported(int H) {
@@ -530,6 +733,16 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
 #undef GO
     }
     UR_LAUNCH_CHECK();
+  } else if (const int nut = gru_step_nut(B, H)) {   // wide hidden state: one fused launch per step (product + gates)
+    if ((rc = transpose(dense + lay.w_hh, 3 * H, H, w.w_hhT, st))) return rc;   // [H, 3H]: the K-major operand of the step kernel
+    for (int t = 0; t < L; ++t) {
+      const long long o = (long long)t * B * H;
+      GruStepArgs sa{};
+      sa.A = w.h_all + o; sa.lda = H; sa.W = w.w_hhT; sa.ldw = 3 * H; sa.B = B; sa.K = H; sa.H = H;
+      sa.gi = w.gi + (long long)t * B * 3 * H; sa.b_hh = dense + lay.b_hh; sa.hprev = w.h_all + o;
+      sa.h_out = w.h_all + o + (long long)B * H; sa.r_s = w.r + o; sa.z_s = w.z + o; sa.n_s = w.n + o; sa.hn_s = w.hn + o;
+      if ((rc = gru_step_launch<true>(nut, sa, st))) return rc;
+    }
   } else
   for (int t = 0; t < L; ++t) {
     const long long o = (long long)t * B * H;
@@ -584,6 +797,23 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
 #undef GO
     }
     UR_LAUNCH_CHECK();
+  } else if (const int nut = gru_step_nut(B, H)) {   // wide hidden state: cell backward + one fused launch (product + carry) per step
+    const float* dh_cur = w.dh;
+    for (int t = L - 1; t >= 0; --t) {
+      const long long o = (long long)t * B * H, o3 = (long long)t * B * 3 * H;
+      {
+        ProfScope ps(PC_GRU, st, 0);
+        hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, st, dh_cur, 0, w.r + o, w.z + o, w.n + o,
+                           w.hn + o, w.h_all + o, B, H, w.dgi + o3, w.dgh + o3, w.dh_carry);
+        UR_LAUNCH_CHECK();
+      }
+      if (t == 0) break;   // (dh_{-1} has no reader: h_0 = 0)
+      GruStepArgs sa{};
+      sa.A = w.dgh + o3; sa.lda = 3 * H; sa.W = dense + lay.w_hh; sa.ldw = H; sa.B = B; sa.K = 3 * H; sa.H = H;
+      sa.carry = w.dh_carry; sa.dh_out = w.dh_parts;
+      if ((rc = gru_step_launch<false>(nut, sa, st))) return rc;
+      dh_cur = w.dh_parts;
+    }
   } else
   for (int t = L - 1; t >= 0; --t) {
     const long long o = (long long)t * B * H, o3 = (long long)t * B * 3 * H;
