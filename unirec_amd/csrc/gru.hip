@@ -650,14 +650,14 @@ static int gru_step_launch(int nut, GruStepArgs a, hipStream_t st) {
   const int grid = cdiv(a.B, GS_ROWS) * a.unit_blocks;
   const int nt = FWD ? 3 * nut : nut;
   const size_t lds = (size_t)4 * GS_ROWS * (16 * nt + 4) * sizeof(float);
-  ProfScope ps(PC_GRU, st, 2.0 * a.B * (double)a.K * (FWD ? 3.0 * a.H : (double)a.H));
+  ProfScope ps(PC_GRU, st, 2.0 * a.B * (double)a.K * (FWD ? 3.0 * a.H : (double)a.H), true);   // (the launch's own start / end: 100 launches a pass)
 #define GO(N_) do {                                                                                                                   \
     static bool big_lds_set = false;   /* (76 KB at 48 units forward: above the 64 KB a kernel gets without asking) */                 \
     if (lds > 64 * 1024 && !big_lds_set) {                                                                                            \
       UR_HIP(hipFuncSetAttribute((const void*)gru_step_kernel<N_, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));        \
       big_lds_set = true;                                                                                                             \
     }                                                                                                                                 \
-    hipLaunchKernelGGL((gru_step_kernel<N_, FWD>), dim3(grid), dim3(256), lds, st, a);                                                \
+    UR_LAUNCH_EV((gru_step_kernel<N_, FWD>), dim3(grid), dim3(256), lds, st, a);                                                      \
   } while (0)
   switch (nut) {
     case 3: GO(3); break;
@@ -802,9 +802,9 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
     for (int t = L - 1; t >= 0; --t) {
       const long long o = (long long)t * B * H, o3 = (long long)t * B * 3 * H;
       {
-        ProfScope ps(PC_GRU, st, 0);
-        hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, st, dh_cur, 0, w.r + o, w.z + o, w.n + o,
-                           w.hn + o, w.h_all + o, B, H, w.dgi + o3, w.dgh + o3, w.dh_carry);
+        ProfScope ps(PC_GRU, st, 0, true);
+        UR_LAUNCH_EV(gru_cell_bwd_kernel, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, st, dh_cur, 0, w.r + o, w.z + o, w.n + o,
+                     w.hn + o, w.h_all + o, B, H, w.dgi + o3, w.dgh + o3, w.dh_carry);
         UR_LAUNCH_CHECK();
       }
       if (t == 0) break;   // (dh_{-1} has no reader: h_0 = 0)
