@@ -248,6 +248,72 @@ def _overflow_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _fixup_overflow_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from unirec_amd.facility.distributed import ShardedSparseDenseAdam
+        from unirec_amd.utils.general import get_class_instance, init_seed
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        cfg = _cfg("SASRec", grad_clip_value=0.0)
+        B = 16
+        full = _batches(5, B * world)
+        full = [b for b in full for _ in range(2)]          # every batch twice in a row: the second time ALL of its rows are hot
+        mine = [_to(b, dev, rank * B, (rank + 1) * B) for b in full]
+
+        def run(prefetch_rows):
+            init_seed(cfg["seed"])
+            m = get_class_instance("SASRec", "unirec_amd/model")(cfg)
+            opt = ShardedSparseDenseAdam(m, rank, world, lr=2e-3, cap_slack=1.5, fix_cap_min=4)
+            opt.prefetch_rows = prefetch_rows
+            m.train()
+            losses = [opt.train_step(b, mine[i + 1] if i + 1 < len(mine) else None) for i, b in enumerate(mine)]
+            opt.flush()
+            m.join_side_updates()
+            torch.cuda.synchronize()
+            return opt, m, [float(x) for x in losses]
+
+        opt, m, losses = run(True)
+        assert opt.n_overflow >= 1 and opt._cap_scale >= 2, (opt.n_overflow, opt._cap_scale)      # the fix-up lists overflowed (the main capacity never does at slack 1.5)
+        scales = [None] * world
+        dist.all_gather_object(scales, (opt._cap_scale, opt.n_overflow, opt.t))
+        assert len(set(scales)) == 1, scales
+        assert opt.t == len(mine) + opt.n_overflow
+        dense = [None] * world
+        dist.all_gather_object(dense, m.dense_flat.data.cpu())
+        assert all(torch.equal(dense[0], x) for x in dense[1:])
+        ref_opt, ref_m, ref_losses = run(False)              # rows inside the step: no fix-up exchange, no overflow
+        assert ref_opt.n_overflow == 0
+        # once the capacity has settled the two runs train the same batches on almost the same parameters
+        assert abs(losses[-1] - ref_losses[-1]) < 0.05 * abs(ref_losses[-1]), (losses, ref_losses)
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_fixup_exchange_overflow_is_an_overflow_like_any_other():
+    """Row prefetch: the rows of the next batch that the step in flight updates come in a small second exchange (cap2 slots per pair).
+    Batches repeated back to back make EVERY row hot: more than cap2 per pair raises the batch's overflow flag on the owner, the flag
+    travels with the gradients, every rank skips, the capacities double, the batch is trained again -- and the replicas stay identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fixup_overflow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(2)], res
+
+
 @pytest.mark.gpu
 def test_capacity_overflow_skips_the_step_everywhere_doubles_and_retrains():
     """A (source, owner) pair that needs more than cap - 1 slots: the flag travels with the row gradients, EVERY rank skips that step's

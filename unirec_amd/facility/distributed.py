@@ -121,7 +121,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
     batch again.  Transport: the library's RCCL communicators (ops.comm_init) when the process group is nccl, else torch.distributed
     on the packed blocks (gloo: CPU-staged -- the routing tests)."""
 
-    def __init__(self, model, rank, world, group=None, sync_init=True, full_rows=None, cap_slack=1.25, **kw):
+    def __init__(self, model, rank, world, group=None, sync_init=True, full_rows=None, cap_slack=1.25, fix_cap_min=64, **kw):
         """full_rows (optional): {table: N} for tables the model ALREADY holds as this rank's shard (shard_rows(N, W) rows,
         initialised per rank): nothing is broadcast or cut for them -- how a 100 M-row table is brought up without ever
         existing in one piece (bench.py); by default the model's full tables are broadcast from rank 0 and cut here.
@@ -156,6 +156,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         super().__init__(model, **kw)
         self.inv_w = torch.full((1,), 1.0 / world, dtype=torch.float32, device=dev)
         self.cap_slack = float(cap_slack)
+        self.fix_cap_min = int(fix_cap_min)
         self._cap_scale = 1               # doubled after a capacity overflow
         # native transport: RCCL through the library's own communicators, on whatever stream the step is on
         self._native = False
@@ -248,12 +249,11 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
 
     def _capacity2(self, n, cap):
         """slots per (owner, requester) pair of the FIX-UP exchange (rows of the next batch that the step in flight updates): an eighth
-        of the unclamped main capacity -- uniform ids over a large table need a handful -- growing with it after an overflow, up to cap."""
-        W = self.world
-        if W == 1:
-            return min(cap, max(64, (n // 8 + 63) // 64 * 64 * self._cap_scale))
-        want = int(self.cap_slack * self._cap_scale * n / W / 8)
-        return min(cap, max(64, (want + 63) // 64 * 64))
+        of the unclamped main capacity -- uniform ids over a large table need a handful -- growing with it after an overflow, up to cap;
+        a multiple of `fix_cap_min` (64; the tests shrink it to make the fix-up overflow on its own)."""
+        W, q = self.world, self.fix_cap_min
+        want = int(self.cap_slack * self._cap_scale * n / W / 8) if W > 1 else n // 8 * self._cap_scale
+        return min(cap, max(q, (want + q - 1) // q * q))
 
     def _buffers(self, name, n, n_a, d, parity):
         key = (name, n, n_a, parity, self._cap_scale)
