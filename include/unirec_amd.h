@@ -333,7 +333,8 @@ int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_of_slot, in
  *   ur_shard_fixup_apply: compact[(q / cap2) * cap + slot2[q], :] = rows2[q, :] for the received slots with slot2[q] >= 0
  * ur_rows_split_hot splits a plan's unique rows against prev_uniq: hot = in both, cold = the others that have optimizer history
  * (last_step[row] != 0; last_step NULL: all others) -- the rows a lazy catch-up made a step ahead may touch. */
-int ur_comm_all_to_all(const void* send, void* recv, int64_t bytes_per_peer, int32_t ahead, void* stream);
+int ur_comm_all_to_all(const void* send, void* recv, int64_t bytes_per_peer, int32_t ahead, int32_t kind /* 0 ids, 1 rows, 2 row gradients: the timer class */,
+                       void* stream);
 int ur_shard_fixup_plan(const int32_t* recv_ids, int32_t world, int32_t cap, const int32_t* prev_uniq, const int32_t* prev_n_uniq_dev,
                         int64_t prev_n_max, int32_t cap2, int32_t* req2, int32_t* slot2, int32_t* counts_ws /* world ints */,
                         int32_t* flags_dev, void* stream);
@@ -417,6 +418,14 @@ int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v,
  *   ur_sparse_adam_rows_split: hot != 0: ur_sparse_adam_rows over a short row list (the rows the next batch reads as well); a skipped step
  *                              (grad_scale_dev < 0) is applied to them as a zero-gradient step.  hot == 0: over the whole plan except
  *                              the unique ids with skip_mark[u] != 0. */
+/* ur_rows_reduce of the row-sharded step with two riders that used to be launches of their own: step_flags_out4 != NULL (owner-side
+ * reduce: rows_a = the received gradient block [world * cap, d]): out4 as ur_shard_step_flags; write_flag_rows != 0 (requester-side reduce
+ * with out_rows = the exchange slots): this rank's flag row into slot 0 of every block of uniq_grad, as ur_shard_exchange_grads(uniq_grad
+ * = NULL) writes it (loss_out / flags_dev as there). */
+int ur_rows_reduce_riders(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev,
+                          int64_t n, const float* rows_a, int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d,
+                          float* uniq_grad, float* sumsq_dev, const int32_t* out_rows, int32_t world, int32_t cap,
+                          float* step_flags_out4, int32_t write_flag_rows, const float* loss_out, const int32_t* flags_dev, void* stream);
 int ur_rows_reduce_subset(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev,
                           int64_t n, const float* rows_a, int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d,
                           const int32_t* u_list, const int32_t* n_list_dev, int64_t n_list_max, float* out, void* stream);

@@ -276,6 +276,34 @@ def test_rccl_transport_at_world_one():
         assert torch.equal(gin, ops.shard_exchange_grads(ug, uos1, 1, cap, torch.empty(cap, d, device=dev)))
         t = torch.arange(1000, dtype=torch.float32, device=dev)
         assert torch.equal(ops.comm_all_reduce_sum(t.clone()), t)
+        # ---- the row prefetch's use of the two communicators (facility/distributed.py _prefetch_rows): the next batch's slot list and
+        # rows go through the SECOND communicator on a side stream while the step's own exchange (first communicator) runs on the main
+        # stream; then the fix-up: plan against an owner-side plan, gather, exchange on the first communicator, scatter into the table
+        own = ops.rows_plan_merge(recv, [cap])
+        cap2 = 64
+        req2, slot2 = torch.empty(cap2, **i32), torch.empty(cap2, **i32)
+        f2 = torch.zeros(4, **i32)
+        prev = ops.RowsPlan()                       # "the step in flight updates these rows": 40 of the requested ones
+        hot_rows = torch.unique(recv[recv > 0])[:40].contiguous()
+        prev.n, prev.n_a, prev.uniq_idx, prev.n_uniq = 64, 0, torch.cat([hot_rows, torch.zeros(24, **i32)]), torch.tensor([40], **i32)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.shard_fixup_plan(recv, 1, cap, prev, cap2, req2, slot2, f2, torch.zeros(1, **i32))
+            slot2_r = ops.comm_all_to_all(slot2, torch.empty_like(slot2), 1, ahead=True, kind="ids")
+            ws_n, compact_n = torch.empty(cap, d, device=dev), torch.empty(cap, d, device=dev)
+            ops.shard_exchange_rows(table, recv, 1, cap, ws_n, compact=compact_n, transport=False)
+            ops.comm_all_to_all(ws_n, compact_n, 1, ahead=True)
+        ops.shard_exchange_grads(ug, uos1, 1, cap, ws, grads_in=gin, transport=True)      # (main stream, first communicator, meanwhile)
+        torch.cuda.current_stream().wait_stream(side)
+        assert int(f2[0]) == 0 and int((slot2_r >= 0).sum()) == 40
+        table2 = table.clone()
+        table2[hot_rows.long()] += 1.0              # "the update": the prefetched copies of the hot rows are stale now
+        rows2, rows2_r = torch.empty(cap2, d, device=dev), torch.empty(cap2, d, device=dev)
+        ops.shard_exchange_rows(table2, req2, 1, cap2, rows2, compact=rows2_r, transport=True)
+        ops.shard_fixup_apply(compact_n, rows2_r, slot2_r, 1, cap, cap2)
+        assert torch.equal(compact_n[idx_a.long()], table2[ids.long()])
+        assert own.n == cap
         torch.cuda.synchronize()
     finally:
         ops.comm_destroy()

@@ -292,10 +292,11 @@ extern "C" int ur_comm_all_reduce_sum(float* buf, int64_t n, void* stream) {
 
 // equal-split all-to-all of a packed buffer through the library's communicators: ahead != 0 = the second one (the dense all-reduce's and
 // the id exchange's: work issued a step ahead on the plan stream), else the row communicator of the step's own exchanges.
-extern "C" int ur_comm_all_to_all(const void* send, void* recv, int64_t bytes_per_peer, int32_t ahead, void* stream) {
-  UR_REQUIRE(send && recv && bytes_per_peer > 0, UR_ERR_ARG, "ur_comm_all_to_all: bad argument");
+extern "C" int ur_comm_all_to_all(const void* send, void* recv, int64_t bytes_per_peer, int32_t ahead, int32_t kind, void* stream) {
+  UR_REQUIRE(send && recv && bytes_per_peer > 0 && kind >= 0 && kind <= 2, UR_ERR_ARG, "ur_comm_all_to_all: bad argument");
   UR_REQUIRE(g_comm.comm, UR_ERR_ARG, "ur_comm_all_to_all: no communicator (ur_comm_init)");
-  return a2a_bytes(send, recv, (size_t)bytes_per_peer, as_stream(stream), ahead ? g_comm.comm2 : g_comm.comm, PC_A2A_ROWS);
+  const int cls = kind == 0 ? PC_A2A_IDS : kind == 1 ? PC_A2A_ROWS : PC_A2A_GRADS;   // (which per-collective timer the group is booked on)
+  return a2a_bytes(send, recv, (size_t)bytes_per_peer, as_stream(stream), ahead ? g_comm.comm2 : g_comm.comm, cls);
 }
 
 extern "C" int ur_shard_fixup_plan(const int32_t* recv_ids, int32_t world, int32_t cap, const int32_t* prev_uniq,

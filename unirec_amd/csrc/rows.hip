@@ -383,6 +383,18 @@ __device__ __forceinline__ void long_walk(float4 (&acc)[MAXV], int first, int en
   }
 }
 
+// Work of the sharded step that RIDES in a row-reduce launch instead of paying for a launch of its own (5.5 us each on a 0.58 ms step):
+//   step flags (owner side, first workgroup): out4 <- the flags every rank put into slot 0 of its block of the received gradient rows
+//                                             (= exchange.hip shard_step_flags_kernel; rows_a is that buffer);
+//   flag rows  (requester side, last workgroup): this rank's [NaN, overflow, loss, 1] into slot 0 of every block of `out`
+//                                             (= shard_flag_rows_kernel; the sums themselves never land in a slot 0).
+struct ReduceRiders {
+  float* sf_out4 = nullptr;
+  const float* fr_loss = nullptr;
+  const int* fr_flags = nullptr;
+  int fr_on = 0, world = 0, cap = 0;
+};
+
 // One lane group per unique id; positions are summed in sorted (= lookup) order.  Runs longer than LONG_SEG are
 // handled by all groups of the block together: group g takes positions s+g, s+g+groups, ..., the partial sums are
 // combined through LDS in group order -- still a fixed summation order, so results are bit-reproducible.
@@ -393,7 +405,23 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
                                                           const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G,
                                                           int d4, float4* __restrict__ out, int zero_tail,
                                                           const int* __restrict__ out_rows, const int* __restrict__ u_list = nullptr,
-                                                          const int* __restrict__ n_list_dev = nullptr) {
+                                                          const int* __restrict__ n_list_dev = nullptr, ReduceRiders rd = ReduceRiders()) {
+  if (rd.sf_out4 && blockIdx.x == 0 && threadIdx.x == 0) {   // (source-rank order: every rank sums the same values in the same order)
+    float nan = 0.f, ovf = 0.f, loss = 0.f;
+    for (int q = 0; q < rd.world; ++q) {
+      const float4 r = rows_a[(long long)q * rd.cap * d4];
+      nan += r.x; ovf += r.y; loss += r.z;
+    }
+    rd.sf_out4[0] = (nan > 0.f || ovf > 0.f) ? -1.f : 1.f / (float)rd.world;
+    rd.sf_out4[1] = nan > 0.f ? __builtin_nanf("") : loss / (float)rd.world;
+    rd.sf_out4[2] = nan;
+    rd.sf_out4[3] = ovf;
+  }
+  if (rd.fr_on && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < rd.world) {
+    const float loss = rd.fr_loss ? rd.fr_loss[0] : 0.f;
+    const float nan = (rd.fr_loss && (rd.fr_loss[2] < 0.f || loss != loss)) ? 1.f : 0.f;
+    out[(long long)threadIdx.x * rd.cap * d4] = make_float4(nan, (rd.fr_flags && (rd.fr_flags[0] & 1)) ? 1.f : 0.f, nan != 0.f ? 0.f : loss, 1.f);
+  }
   // (these two kernels run beside the bottom layer's weight-gradient launch: their few memory instructions go first -- 0.601 -> 0.596 ms/step)
   __builtin_amdgcn_s_setprio(3);
   constexpr int groups = 256 / TPR;
@@ -434,6 +462,9 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
     for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long frow = uniq_idx[u];
     const long long orow = out_rows ? out_rows[u] : ent;   // (out_rows: the row of unique id u in the caller's layout, e.g. its exchange slot)
+    // slot 0 of every block is the flag row's: the padding id maps there (block 0), and so do keys that an OVERFLOWING pack cut (their
+    // slot_of_uniq entry is stale, initially 0) -- a sum written there after the rider would lose the very flag that reports the overflow
+    if (rd.fr_on && (frow == 0 || orow % rd.cap == 0)) continue;
     if (frow != 0) {
       const int s = seg_start[u], e = seg_start[u + 1];
       if (e - s > LONG_SEG) continue;                      // pass 2
@@ -492,7 +523,8 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
               const float4 x = part[gg][k * TPR + t];
               r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
             }
-            out[(out_rows ? (long long)out_rows[ul] : el_) * d4 + c] = r;
+            const long long orow_l = out_rows ? (long long)out_rows[ul] : el_;
+            if (!(rd.fr_on && orow_l % rd.cap == 0)) out[orow_l * d4 + c] = r;
           }
         }
       }
@@ -1255,7 +1287,8 @@ extern "C" int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_
 static int rows_reduce_impl(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
                             const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
                             const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
-                            const int32_t* u_list, const int32_t* n_list_dev, int64_t n_entries, void* stream) {
+                            const int32_t* u_list, const int32_t* n_list_dev, int64_t n_entries, void* stream,
+                            ReduceRiders rd = ReduceRiders()) {
   UR_REQUIRE(uniq_idx && seg_start && sorted_pos && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_rows_reduce: null pointer");
   UR_REQUIRE(!(out_rows && sumsq_dev), UR_ERR_ARG, "ur_rows_reduce: out_rows with the zeroed tail");
   UR_REQUIRE(n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_rows_reduce: n=%lld n_a=%lld", (long long)n, (long long)n_a);
@@ -1270,7 +1303,7 @@ static int rows_reduce_impl(const int32_t* uniq_idx, const int32_t* seg_start, c
   const int zero_tail = sumsq_dev != nullptr;
 #define GO(T) hipLaunchKernelGGL((rows_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
                                  (long long)n_entries, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,          \
-                                 (float4*)uniq_grad, zero_tail, out_rows, u_list, n_list_dev)
+                                 (float4*)uniq_grad, zero_tail, out_rows, u_list, n_list_dev, rd)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;
@@ -1288,6 +1321,23 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
                               void* stream) {
   return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, uniq_grad, sumsq_dev, out_rows,
                           nullptr, nullptr, n, stream);
+}
+
+// ur_rows_reduce of the sharded step with its riders (ReduceRiders above): step_flags_out4 != NULL: rows_a is the received gradient
+// block [world * cap, d] and out4 gets the step's flags (ur_shard_step_flags); write_flag_rows != 0: this rank's flag row goes into slot 0
+// of every block of uniq_grad [world * cap, d] (what ur_shard_exchange_grads does with uniq_grad == NULL).
+extern "C" int ur_rows_reduce_riders(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
+                                     const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
+                                     const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
+                                     int32_t world, int32_t cap, float* step_flags_out4, int32_t write_flag_rows, const float* loss_out,
+                                     const int32_t* flags_dev, void* stream) {
+  UR_REQUIRE(world >= 1 && world <= 256 && cap > 0, UR_ERR_ARG, "ur_rows_reduce_riders: world=%d cap=%d", world, cap);
+  UR_REQUIRE(!step_flags_out4 || (rows_a && n_a >= (int64_t)(world - 1) * cap + 1), UR_ERR_ARG, "ur_rows_reduce_riders: step flags need the received block as rows_a");
+  UR_REQUIRE(!write_flag_rows || out_rows, UR_ERR_ARG, "ur_rows_reduce_riders: flag rows go with sums written to their slots (out_rows)");
+  ReduceRiders rd;
+  rd.sf_out4 = step_flags_out4; rd.fr_on = write_flag_rows ? 1 : 0; rd.fr_loss = loss_out; rd.fr_flags = flags_dev; rd.world = world; rd.cap = cap;
+  return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, uniq_grad, sumsq_dev, out_rows,
+                          nullptr, nullptr, n, stream, rd);
 }
 
 // the same for a SUBSET of the plan's unique ids: entry i of u_list (indices into uniq_idx, *n_list_dev of them, at most n_list_max)

@@ -87,7 +87,11 @@ def native_transport_selftest(rank, world, group, dev):
     got[::cap] = want[::cap]          # (slot 0 of every block carries the flag row: not part of the comparison)
     s = torch.full((16,), float(rank + 1), device=dev)
     ops.comm_all_reduce_sum(s)
-    ok = torch.tensor([1.0 if torch.equal(got, want) and float(s[0]) == W * (W + 1) / 2 else 0.0], device=dev)
+    ids = (torch.arange(W * cap, device=dev, dtype=torch.int32) + 100 * rank).contiguous()      # the second communicator's all-to-all (work issued a step ahead)
+    got_i = ops.comm_all_to_all(ids, torch.empty_like(ids), W, ahead=True, kind="ids")
+    want_i = torch.empty_like(ids)
+    dist.all_to_all_single(want_i, ids.clone(), group=group)
+    ok = torch.tensor([1.0 if torch.equal(got, want) and torch.equal(got_i, want_i) and float(s[0]) == W * (W + 1) / 2 else 0.0], device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if float(ok) != 1.0:
         ops.comm_destroy()
@@ -175,6 +179,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         # against the rows it owns; the table gradient of a shard is complete on its owner (dense over the shard, no exchange)
         # rows of the next batch fetched a step ahead (_prefetch_rows); UR_PREFETCH_ROWS=0: in the step itself (rounds 1-3).  Not with
         # fullsoftmax: its dense update moves every row of the item shard in every step
+        self._riders = os.environ.get("UR_REDUCE_RIDERS", "1") not in ("", "0")    # flag rows / step flags inside the reduce launches
         self.prefetch_rows = os.environ.get("UR_PREFETCH_ROWS", "1") not in ("", "0") and model.loss_type != "fullsoftmax"
         self._fs_dgrad = None
         if model.loss_type == "fullsoftmax":
@@ -337,7 +342,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             ops.shard_fixup_plan(bf["recv_ids"], W, cap, pown, cap2, bf["req2"], bf["slot2"], bf["flags"], bf["fix_cnt"])
             if W > 1:
                 if self._native:
-                    ops.comm_all_to_all(bf["slot2"], bf["slot2_recv"], W, ahead=True)
+                    ops.comm_all_to_all(bf["slot2"], bf["slot2_recv"], W, ahead=True, kind="ids")
                 else:
                     self._a2a(bf["slot2"], bf["slot2_recv"], "a2a_fix_slots")
             if lazy and st["last"] is not None:
@@ -559,6 +564,19 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             sb, bf = c["sb"], c["bf"]
             d = bf["compact"].shape[1]
             # (the sums land in their exchange slots: no scatter pass; padding slots keep stale bytes that no owner reads)
+            # (this rank's flag row rides in the reduce launch -- slot 0 of every block; the step flags of all ranks ride in the owner-side
+            # reduce of the first table: two launches less per step than ur_shard_exchange_grads(NULL) + ur_shard_step_flags)
+            if self._riders:
+                ops.rows_reduce_riders(c["pl"], rows, coef.reshape(-1) if coef is not None else None, vec, G, d, W, c["cap"], out=sb["send_grads"],
+                                       out_rows=bf["slot"], flag_rows=(loss_buf, bf["flags"]))
+                if self._native:
+                    ops.comm_all_to_all(sb["send_grads"], sb["grads_in"], W, ahead=False, kind="grads")
+                else:
+                    self._a2a(sb["send_grads"], sb["grads_in"], "a2a_row_grads")
+                owner_grads[name] = ops.rows_reduce_riders(c["own"], sb["grads_in"], None, None, 1, d, W, c["cap"],
+                                                           zero_tail=self.grad_clip is not None, step_flags_out4=out4 if first else None)
+                first = False
+                continue
             ops.rows_reduce(c["pl"], rows, coef.reshape(-1) if coef is not None else None, vec, G, d, out=sb["send_grads"], out_rows=bf["slot"])
             ops.shard_exchange_grads(None, bf["uos"], W, c["cap"], sb["send_grads"], grads_in=sb["grads_in"], transport=self._native,
                                      loss_out=loss_buf, flags=bf["flags"])

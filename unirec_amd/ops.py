@@ -374,11 +374,12 @@ def comm_all_reduce_sum(t):
     return t
 
 
-def comm_all_to_all(send, recv, world, ahead=False):
-    """equal-split all-to-all of a packed buffer through the library's communicators (ahead: the second one, for work issued a step ahead)"""
+def comm_all_to_all(send, recv, world, ahead=False, kind="rows"):
+    """equal-split all-to-all of a packed buffer through the library's communicators (ahead: the second one, for work issued a step ahead;
+    kind "ids" / "rows" / "grads": the per-collective timer the group is booked on)"""
     assert send.numel() == recv.numel() and send.dtype == recv.dtype and send.numel() % world == 0
-    check(lib.ur_comm_all_to_all(_p(send), _p(recv), send.numel() * send.element_size() // world, 1 if ahead else 0, _stream()),
-          "ur_comm_all_to_all")
+    check(lib.ur_comm_all_to_all(_p(send), _p(recv), send.numel() * send.element_size() // world, 1 if ahead else 0,
+                                 {"ids": 0, "rows": 1, "grads": 2}[kind], _stream()), "ur_comm_all_to_all")
     return recv
 
 
@@ -482,6 +483,23 @@ def rows_reduce(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, zero_tail=False, out=
     flag = out if zero_tail else None  # non-null sumsq pointer = "zero the rows beyond n_uniq"
     check(lib.ur_rows_reduce(_p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, _p(rows_a), pl.n_a,
                              _p(coef_b), _p(vec_b), int(G), int(d), _p(out), _p(flag), _p(out_rows), _stream()), "ur_rows_reduce")
+    return out
+
+
+def rows_reduce_riders(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, world, cap, out=None, out_rows=None, zero_tail=False, step_flags_out4=None,
+                       flag_rows=None):
+    """rows_reduce of the sharded step + riders: step_flags_out4 (owner side; rows_a = the received block): out4 as shard_step_flags;
+    flag_rows = (loss_out | None, flags | None) (requester side, out_rows = slots): this rank's flag row into slot 0 of every block of out"""
+    _chk(rows_a, torch.float32, "rows_a", allow_none=True); _chk(coef_b, torch.float32, "coef_b", allow_none=True)
+    _chk(vec_b, torch.float32, "vec_b", allow_none=True); _chk(out, torch.float32, "out", allow_none=True)
+    _chk(out_rows, torch.int32, "out_rows", allow_none=True); _chk(step_flags_out4, torch.float32, "step_flags_out4", allow_none=True)
+    if out is None:
+        out = torch.empty(pl.n, d, dtype=torch.float32, device=pl.uniq_idx.device)
+    loss_out, flags = flag_rows if flag_rows is not None else (None, None)
+    check(lib.ur_rows_reduce_riders(_p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, _p(rows_a), pl.n_a, _p(coef_b),
+                                    _p(vec_b), int(G), int(d), _p(out), _p(out if zero_tail else None), _p(out_rows), int(world), int(cap),
+                                    _p(step_flags_out4), 1 if flag_rows is not None else 0, _p(loss_out), _p(flags), _stream()),
+          "ur_rows_reduce_riders")
     return out
 
 
