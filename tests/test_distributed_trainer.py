@@ -248,6 +248,130 @@ def _overflow_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _many_steps_worker(rank, world, port, q, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from unirec_amd.facility.trainer import Trainer
+        from unirec_amd.utils.general import get_class_instance, init_seed
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        cfg = _cfg("SASRec", output_path=tmp, grad_clip_value=0.0)
+        B, n = 16, 9
+        full = _batches(n, B * world)
+        ref = None
+        if rank == 0:
+            init_seed(cfg["seed"])
+            t1 = Trainer(cfg, get_class_instance("SASRec", "unirec_amd/model")(cfg), types.SimpleNamespace(process_index=0, num_processes=1))
+            t1.fit([_to(b, dev) for b in full], save_model=False)
+            ref = list(t1.step_losses)
+        dist.barrier()
+        init_seed(cfg["seed"])
+        tr = Trainer(cfg, get_class_instance("SASRec", "unirec_amd/model")(cfg))
+        tr.fit([_to(b, dev, rank * B, (rank + 1) * B) for b in full], save_model=False)
+        got = list(tr.step_losses)       # read in drain() at the END of the epoch: every entry must still be its own step's value
+        every = [None] * world
+        dist.all_gather_object(every, got)
+        if rank == 0:
+            assert len(got) == n and all(np.array_equal(np.asarray(every[0]), np.asarray(x)) for x in every[1:])
+            rel = np.abs(np.asarray(got) - np.asarray(ref)) / np.abs(np.asarray(ref))
+            assert rel[0] <= LOSS_RTOL_FIRST and rel.max() <= 5 * LOSS_RTOL, (rel.tolist(), got, ref)
+            assert len(set(np.round(got, 6))) == n          # (nine different values, not four repeated)
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_step_losses_of_a_long_epoch_are_each_steps_own(tmp_path):
+    """Advisor r3: train_step returned a view into a four-entry ring that fit() only read at the end of the epoch.  Nine steps per epoch on
+    W = 2: the per-step losses (mean over the ranks) against the 1-rank run on the concatenated batches, every one of the nine."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_many_steps_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(2)], res
+
+
+def _second_table_overflow_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from unirec_amd.facility.distributed import ShardedSparseDenseAdam
+        from unirec_amd.utils.general import get_class_instance, init_seed
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        n_users = 4001
+        cfg = _cfg("MF", grad_clip_value=0.0, n_users=n_users)
+        B = 256
+        g = torch.Generator().manual_seed(17)
+        mine = []
+        for s_ in range(6):
+            lab = torch.zeros(B, G, dtype=torch.int32)
+            lab[:, 0] = 1
+            uid = torch.randperm(n_users // 2 - 1, generator=g)[:B] * 2 + 2      # EVEN user ids only: every one of them lives on rank 0
+            b = dict(item_id=torch.randint(1, N_ITEMS, (B, G), generator=g), label=lab, user_id=uid)
+            mine.append(_to(b, dev))
+
+        def run(slack):
+            init_seed(cfg["seed"])
+            m = get_class_instance("MF", "unirec_amd/model")(cfg)
+            opt = ShardedSparseDenseAdam(m, rank, world, lr=2e-3, cap_slack=slack)
+            m.train()
+            losses = [opt.train_step(b, mine[i + 1] if i + 1 < len(mine) else None) for i, b in enumerate(mine)]
+            opt.flush()
+            torch.cuda.synchronize()
+            return opt, m, [float(x) for x in losses]
+
+        # the ITEM table (first in lookup_tables) fits at slack 1.25; the USER table needs 256 slots on rank 0 where 1.25 x 256 / 2 are planned
+        opt, m, losses = run(1.25)
+        assert opt.n_overflow >= 1 and opt._cap_scale >= 2, (opt.n_overflow, opt._cap_scale)
+        state = [None] * world
+        dist.all_gather_object(state, (opt._cap_scale, opt.n_overflow, opt.t))
+        assert len(set(state)) == 1, state
+        assert opt.t == len(mine) + opt.n_overflow and all(np.isfinite(losses)), losses
+        bias = [None] * world
+        dist.all_gather_object(bias, m.item_bias.data.cpu())
+        assert all(torch.equal(bias[0], x) for x in bias[1:])                  # replicated parameters stayed identical through the skips
+        ref_opt, _, ref_losses = run(4.0)
+        assert ref_opt.n_overflow == 0
+        assert abs(losses[-1] - ref_losses[-1]) < 0.05 * abs(ref_losses[-1]), (losses, ref_losses)
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_overflow_of_the_second_table_skips_the_step_too():
+    """Advisor r3: only the first table's flags reached the step flags.  MF with every user id on one owner: the user table (second in
+    lookup_tables) overflows while the item table fits -- the step must be skipped everywhere, the capacity doubled, the batch re-trained."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_second_table_overflow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(2)], res
+
+
 def _fixup_overflow_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
