@@ -640,6 +640,8 @@ static int gru_step_nut(int B, int H) {
   static const bool off = getenv("UR_GRU_NO_STEP") != nullptr;   // test / tuning hook: the gemm_nt + cell-kernel path of rounds 1-3
   if (off || H % 64 != 0) return 0;
   const int rbs = cdiv(B, GS_ROWS);
+  static const int forced = getenv("UR_GRU_STEP_NUT") ? atoi(getenv("UR_GRU_STEP_NUT")) : 0;   // tuning hook: units per workgroup / 16
+  if (forced >= 1 && forced <= 3 && H % (16 * forced) == 0) return forced;
   for (int nut = 3; nut >= 1; --nut)
     if (H % (16 * nut) == 0 && (nut == 1 || (long long)rbs * (H / (16 * nut)) >= 200)) return nut;
   return 0;
