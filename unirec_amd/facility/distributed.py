@@ -111,12 +111,13 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
 
     The step (round 3): every exchange has FIXED capacity (``cap`` slots per (source, owner) pair, include/unirec_amd.h
     ur_shard_exchange_*), so there is no per-step count exchange, no host synchronisation, and every buffer is allocated once.
-      plan stream, one step AHEAD (ids only): id sort by (owner, row) -> pack -> all-to-all #1 (ids) -> owner-side merge plan ->
-                                              re-indexed lookups -> which of the owner's rows have optimizer history
-      main stream: [tail of the previous step: lazy catch-up of this batch's owner rows] -> gather + all-to-all #2 (rows) -> the model's
-                   own forward_backward on the compact table -> row-gradient reduce -> scatter to slots + all-to-all #3 (slot 0 of every
-                   block carries the rank's NaN / overflow flags and loss: an all-gather riding along) -> owner-side reduce in source-rank
-                   order -> flags -> row update -> catch-up of the NEXT batch's owner rows
+      plan stream, one step AHEAD: id sort by (owner, row) -> pack -> all-to-all #1 (ids) -> owner-side merge plan -> re-indexed lookups
+                   -> (round 4, _prefetch_rows) fix-up plan, zero-gradient steps of the requested rows the step in flight does not
+                   touch, gather + all-to-all #2 (rows) of the NEXT batch
+      main stream: fix-up exchange (the few rows the previous step's update changed after they were fetched; without a lookahead: owner
+                   rows caught up, then the full all-to-all #2) -> the model's own forward_backward on the compact table -> row-gradient
+                   reduce into the exchange slots -> all-to-all #3 (slot 0 of every block carries the rank's NaN / overflow flags and
+                   loss: an all-gather riding along) -> owner-side reduce in source-rank order (+ the step flags) -> row update
       encoder's side stream (no gradient clipping): dense-gradient reductions -> all-reduce (second communicator) -> dense update, joined
                    by the next forward pass after its first launch (SparseDenseAdam's late join)
     With ``grad_clip`` the global norm needs every gradient first: the dense half runs on the main stream behind ONE flat all-reduce
