@@ -789,8 +789,11 @@ def main():
             _lib.lib.ur_prof_enable(1)
         else:
             opt.xchg.profile_start()
+        # (with the lookahead batch, as in the timed region: the rows travel a step ahead and the step itself pays the fix-up exchange --
+        # torch.distributed route: labels a2a_rows (prefetched, plan stream) / a2a_fix_slots / a2a_fix_rows; library route: both row
+        # exchanges are booked on a2a_rows, two calls a step, the slot lists on a2a_ids)
         for i in range(10):
-            step_fn(batches[(a.warmup + i) % len(batches)], None)
+            step_fn(batches[(a.warmup + i) % len(batches)], None if a.no_prefetch else batches[(a.warmup + i + 1) % len(batches)])
         barrier()
         if opt._native:
             _lib.lib.ur_prof_enable(0)
