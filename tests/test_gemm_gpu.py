@@ -96,3 +96,34 @@ def test_gemm_tn(T, R, Cc_, act_on_q):
     ref = P64.T @ (_swish(Q64) if act_on_q else Q64)
     _close(out, ref)
     _close(bo, P64.sum(0))
+
+
+_ACTS = {0: lambda x: 0.5 * x * (1 + torch.erf(x * 0.7071067811865476)), 1: torch.relu, 2: _swish, 3: torch.tanh, 4: torch.sigmoid}
+
+
+@pytest.mark.parametrize("T", [1, 31, 33, 64, 65, 1000, 4097, 21248])
+@pytest.mark.parametrize("R,Cc_", [(128, 128), (256, 128), (128, 512), (512, 128), (384, 128)])
+@pytest.mark.parametrize("act", [-1, 0, 1, 2, 3, 4])
+def test_gemm_tn_128_tile_shapes(T, R, Cc_, act):
+    """Shapes whose R and Cc are multiples of 128 take the 128 x 128 LDS-DMA kernel (round 5): every activation on the Q operand, token
+    counts around the 32-token stage and the split boundaries, strided operands."""
+    from unirec_amd._lib import check, lib
+    if act >= 0 and (T, R) not in ((33, 128), (1000, 128), (21248, 128), (4097, 256)):
+        pytest.skip("activations: a subset of the shapes")
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(T * 3 + R + Cc_ + act)
+    ldp, ldq = R + 4, Cc_ + 8
+    P = torch.randn(T, ldp, device=dev, generator=g)
+    Q = torch.randn(T, ldq, device=dev, generator=g)
+    out = torch.full((R, Cc_), float("nan"), device=dev)
+    bo = torch.full((R,), float("nan"), device=dev)
+    ws = torch.empty(int(lib.ur_gemm_tn_workspace_floats(T, R, Cc_)), device=dev)
+    for rep in range(2):
+        check(lib.ur_gemm_tn(_p(P), ldp, _p(Q), ldq, T, R, Cc_, 1 if act >= 0 else 0, max(act, 0), _p(out), Cc_, _p(bo), _p(ws), _st()), "ur_gemm_tn")
+        if rep == 0:
+            first = (out.clone(), bo.clone())
+    assert torch.equal(first[0], out) and torch.equal(first[1], bo)
+    P64, Q64 = P[:, :R].double(), Q[:, :Cc_].double()
+    ref = P64.T @ (_ACTS[act](Q64) if act >= 0 else Q64)
+    _close(out, ref)
+    _close(bo, P64.sum(0))
