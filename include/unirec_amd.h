@@ -37,6 +37,25 @@ const char* ur_last_error(void);
 int ur_version(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * Id guard -- what nn.Embedding's index check does for the reference (table created at
+ * unirec/model/base/reco_abc.py:168-170: an id < 0 or >= n_rows raises IndexError in its forward).
+ * Every id of a TRAINING batch passes through ur_rows_plan / ur_rows_plan_sharded once; an id outside
+ * [0, n_rows) raises this device's guard there (first offender recorded) and is treated as the
+ * padding id 0 by everything that WRITES through the plan (row reduce, sparse update, row exchange):
+ * no table byte outside or inside is touched on its behalf.  While the guard is raised, every update
+ * entry (ur_sparse_adam_rows*, ur_dense_adam) skips its step exactly like a NaN step, and a sharded
+ * rank reports "NaN" in its step flags so that EVERY rank skips -- no extra launch, no host
+ * synchronisation.  The host polls ur_id_guard_state (a plain load from a host-mapped mirror the plan
+ * kernel writes) at the head of each step and raises IndexError one or two steps after the bad batch.
+ * Forward-only gathers (evaluation) are unguarded in the release build; the bounds-checked build
+ * (`python -m unirec_amd.build --debug-bounds`, loaded when UR_DEBUG_BOUNDS=1) checks every gathered
+ * or scattered row index where it is used and traps.
+ * ur_id_guard_state: 0 = clear; 1 = raised, out3 (nullable) = {offending id, rows of the table it
+ * was aimed at (saturated to 2^31 - 1), 0}.  ur_id_guard_reset clears it (synchronises `stream`). */
+int ur_id_guard_state(int64_t* host_out3);
+int ur_id_guard_reset(void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Embedding lookup: out[i,:] = table[idx[i],:]      (bit-exact copy)
  * replaces nn.Embedding.forward as called by unirec/model/base/recommender.py:67 (forward_item_emb)
  * and :137 (item_embedding_for_user); table created at unirec/model/base/reco_abc.py:168,170.

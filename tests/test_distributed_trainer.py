@@ -303,7 +303,7 @@ def test_step_losses_of_a_long_epoch_are_each_steps_own(tmp_path):
     assert sorted(res) == [(r, "ok") for r in range(2)], res
 
 
-def _second_table_overflow_worker(rank, world, port, q):
+def _second_table_overflow_worker(rank, world, port, q, both=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -321,7 +321,11 @@ def _second_table_overflow_worker(rank, world, port, q):
             lab = torch.zeros(B, G, dtype=torch.int32)
             lab[:, 0] = 1
             uid = torch.randperm(n_users // 2 - 1, generator=g)[:B] * 2 + 2      # EVEN user ids only: every one of them lives on rank 0
-            b = dict(item_id=torch.randint(1, N_ITEMS, (B, G), generator=g), label=lab, user_id=uid)
+            iid = torch.randint(1, N_ITEMS, (B, G), generator=g)
+            if both:      # EVEN item ids only as well: both tables overflow on rank 0 in the SAME step (advisor r4: 1 + 1 = 2 read as "no overflow")
+                perm = (torch.randperm(N_ITEMS // 2 - 1, generator=g) + 1) * 2         # 1000 distinct even ids > the 831 slots planned at slack 1.25
+                iid = torch.cat([perm, perm[: B * G - perm.numel()]]).reshape(B, G)
+            b = dict(item_id=iid, label=lab, user_id=uid)
             mine.append(_to(b, dev))
 
         def run(slack):
@@ -357,13 +361,16 @@ def _second_table_overflow_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_overflow_of_the_second_table_skips_the_step_too():
+@pytest.mark.parametrize("both", [False, True])
+def test_overflow_of_the_second_table_skips_the_step_too(both):
     """Advisor r3: only the first table's flags reached the step flags.  MF with every user id on one owner: the user table (second in
-    lookup_tables) overflows while the item table fits -- the step must be skipped everywhere, the capacity doubled, the batch re-trained."""
+    lookup_tables) overflows while the item table fits -- the step must be skipped everywhere, the capacity doubled, the batch re-trained.
+    both (advisor r4): the item ids sit on that owner too -- two tables raise their flag in the same step, and the merged flag word must
+    still have bit 0 set (a SUM of the two flag words read as 2 = "no overflow")."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_second_table_overflow_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_second_table_overflow_worker, args=(r, 2, port, q, both)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]

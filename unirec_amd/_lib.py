@@ -10,7 +10,9 @@ import torch  # noqa: F401  -- FIRST: the process must use torch's bundled HIP r
 #                              before torch's would put two runtimes in one process ("no ROCm-capable device")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunirec_amd.so")
+# UR_DEBUG_BOUNDS=1: the bounds-checked build (python -m unirec_amd.build --debug-bounds; csrc/common.h: UR_ROW) -- every gathered row
+# index is checked where it is used, a bad one prints its site and traps
+LIB_PATH = os.path.join(_HERE, "libunirec_amd_dbg.so" if os.environ.get("UR_DEBUG_BOUNDS", "0") not in ("", "0") else "libunirec_amd.so")
 
 UR_MAX_LAYERS = 8
 UR_SASREC_N_GLOBAL = 3
@@ -61,6 +63,8 @@ I32 = C.c_int32
 SIGNATURES = {
     "ur_last_error": (C.c_char_p, []),
     "ur_version": (C.c_int, []),
+    "ur_id_guard_state": (C.c_int, [C.POINTER(I64)]),
+    "ur_id_guard_reset": (C.c_int, [P]),
     "ur_embedding_gather_f32": (C.c_int, [P, I64, C.c_int, P, C.c_int, I64, P, P]),
     "ur_sasrec_param_layout": (I64, [C.POINTER(UrSasrecCfg), C.POINTER(I64)]),
     "ur_sasrec_workspace_bytes": (I64, [C.POINTER(UrSasrecCfg)]),

@@ -144,7 +144,7 @@ extern "C" int ur_atthist_fwd(const UrAttHistCfg* cfg, const float* item_table, 
   AttHistWs w = atthist_carve(c, (float*)ws);
   const int M = c.B * c.L, d = c.d;
   const float *W = dense, *bias = dense + (long long)d * d, *h = dense + (long long)d * d + d;
-  if ((rc = gather_rows(item_table, item_seq, 4, M, d, w.x, st))) return rc;
+  if ((rc = gather_rows(item_table, item_seq, 4, M, d, w.x, st, n_items))) return rc;
   GemmArgs g{};
   g.A = w.x; g.lda = d; g.W = W; g.ldw = d; g.C = w.z; g.ldc = d; g.M = M; g.N = d; g.K = d; g.bias = bias;
   if ((rc = gemm_nt(g, PRO_NONE, EPI_BIAS, st))) return rc;

@@ -132,6 +132,51 @@ __device__ __forceinline__ unsigned ur_arrive(unsigned* cnt, int mode) {
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 
+// ---- id guard (round 5; what nn.Embedding's range check does at unirec/model/base/reco_abc.py:170 -- an id >= n_items or < 0 raises
+// IndexError there).  Every training batch's ids pass through the row plan ONCE (rows.hip: the first pass of the sort): an id outside
+// [0, n_rows) raises the device's guard word there, is recorded (first offender wins) and is treated as the padding id 0 from then on
+// -- so no kernel that WRITES through a plan (row reduce, sparse update, exchange) can touch memory outside a table.  The guard word is
+// sticky: every update kernel reads it next to its gradient scale and skips the step like a NaN step while it is raised (no extra
+// launch, no host round trip).  The plan kernel also stores the verdict into a HOST-mapped mirror, which the host polls with a plain
+// load at the head of every step (ops.id_guard_check): IndexError with the offending id one or two steps later, tables untouched since.
+// dev[0] = raised, dev[1..2] = offending id (lo, hi), dev[3] = table rows (saturated to int); host: the same four words.
+struct IdGuard { int* dev; int* host; };   // host: the device-visible address of the host-mapped mirror
+IdGuard id_guard();                         // this device's guard (allocated on first use; {nullptr, nullptr} if that failed)
+__device__ __forceinline__ long long ur_guard_id(long long id, long long n_rows, IdGuard gd) {
+  if ((unsigned long long)id < (unsigned long long)n_rows) return id;
+  if (gd.dev && atomicOr(gd.dev, 1) == 0) {   // first offender of this device: record it, publish to the host mirror
+    gd.dev[1] = (int)(id & 0xFFFFFFFFll); gd.dev[2] = (int)(id >> 32); gd.dev[3] = (int)(n_rows > 0x7FFFFFFFll ? 0x7FFFFFFFll : n_rows);
+    if (gd.host) {
+      gd.host[1] = gd.dev[1]; gd.host[2] = gd.dev[2]; gd.host[3] = gd.dev[3];
+      __hip_atomic_store(gd.host, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  return 0;
+}
+// gradient scale of an update kernel: the caller's device scalar (< 0 = skip the step: NaN loss, trainer.py:343-350), -1 while the
+// device's id guard is raised
+__device__ __forceinline__ float ur_step_scale(const float* scale_dev, const int* guard_dev) {
+  float s = scale_dev ? *scale_dev : 1.0f;
+  if (guard_dev && *guard_dev) s = -1.0f;
+  return s;
+}
+// ---- bounds-checked build (python -m unirec_amd.build --debug-bounds -> libunirec_amd_dbg.so, loaded when UR_DEBUG_BOUNDS=1): every row
+// index a kernel gathers from or scatters to is checked where it is used; a bad one prints the site and traps (the launch fails loudly,
+// like a device-side assert).  The release build compiles the macro away.
+#ifdef UR_DEBUG_BOUNDS
+__device__ __forceinline__ long long ur_dbg_row(long long id, long long n, const char* file, int line) {
+  if (n > 0 && (unsigned long long)id >= (unsigned long long)n) {   // (n <= 0: the caller did not say how many rows the table has)
+    printf("unirec_amd bounds check: row index %lld outside [0, %lld) at %s:%d\n", id, n, file, line);
+    __builtin_trap();
+  }
+  return id;
+}
+#define UR_ROW(id, n) ::ur::ur_dbg_row((long long)(id), (long long)(n), __FILE__, __LINE__)
+#else
+#define UR_ROW(id, n) (id)
+#endif
+
+
 // runtime-width variant (width power of two)
 __device__ __forceinline__ float group_sum_rt(float v, int width) {
   for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -330,7 +330,7 @@ extern "C" int ur_convformer_fwd(const UrConvFormerCfg* cfg, const float* item_t
   const float scale = c.fast ? 1.0f / sqrtf((float)c.L) : 1.0f;
   const DropSpec d_emb = cf_site(c, 0, 0);
   if ((rc = embed_ln_fwd(item_seq, item_table, dense + lay.off[0], dense + lay.off[1], dense + lay.off[2], c.eps, M, c.L, d, w.x0, w.x0hat,
-                         w.rstd0, st, nullptr, nullptr, &d_emb)))
+                         w.rstd0, st, nullptr, nullptr, &d_emb, n_items)))
     return rc;
   const float* x = w.x0;
   for (int i = 0; i < c.n_layers; ++i) {

@@ -75,14 +75,16 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const int* __restrict__
 // [loss is NaN, a capacity overflow, the loss, 1].  The owner's segment sum ignores the row (it belongs to local row 0).
 __global__ __launch_bounds__(256) void shard_scatter_rows_kernel(const float4* __restrict__ rows, const int* __restrict__ u_of_slot,
                                                                  long long n_slots, int cap, int d4, const float* __restrict__ loss_out,
-                                                                 const int* __restrict__ flags, float4* __restrict__ out) {
+                                                                 const int* __restrict__ flags, float4* __restrict__ out,
+                                                                 const int* __restrict__ guard_dev) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_slots * d4) return;
   const long long q = i / d4;
   const int c = (int)(i % d4);
   if (q % cap == 0 && c == 0) {
     const float loss = loss_out ? loss_out[0] : 0.f;
-    const float nan = (loss_out && (loss_out[2] < 0.f || loss != loss)) ? 1.f : 0.f;
+    // (a raised id guard on this rank reads as a NaN loss to every rank: the step is skipped EVERYWHERE, common.h)
+    const float nan = ((loss_out && (loss_out[2] < 0.f || loss != loss)) || (guard_dev && *guard_dev)) ? 1.f : 0.f;
     out[i] = make_float4(nan, (flags && (flags[0] & 1)) ? 1.f : 0.f, nan != 0.f ? 0.f : loss, 1.f);
     return;
   }
@@ -92,11 +94,11 @@ __global__ __launch_bounds__(256) void shard_scatter_rows_kernel(const float4* _
 
 // the flag rows alone (the gradient rows were written into their slots by the reduction itself)
 __global__ void shard_flag_rows_kernel(int world, int cap, int d4, const float* __restrict__ loss_out, const int* __restrict__ flags,
-                                       float4* __restrict__ out) {
+                                       float4* __restrict__ out, const int* __restrict__ guard_dev) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= world) return;
   const float loss = loss_out ? loss_out[0] : 0.f;
-  const float nan = (loss_out && (loss_out[2] < 0.f || loss != loss)) ? 1.f : 0.f;
+  const float nan = ((loss_out && (loss_out[2] < 0.f || loss != loss)) || (guard_dev && *guard_dev)) ? 1.f : 0.f;
   out[(long long)s * cap * d4] = make_float4(nan, (flags && (flags[0] & 1)) ? 1.f : 0.f, nan != 0.f ? 0.f : loss, 1.f);
 }
 
@@ -373,12 +375,12 @@ extern "C" int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_
   hipStream_t st = as_stream(stream);
   const long long n_slots = (long long)world * cap;
   if (!uniq_grad) {
-    hipLaunchKernelGGL(shard_flag_rows_kernel, dim3(cdiv(world, 64)), dim3(64), 0, st, world, cap, d / 4, loss_out, flags_dev, (float4*)send_ws);
+    hipLaunchKernelGGL(shard_flag_rows_kernel, dim3(cdiv(world, 64)), dim3(64), 0, st, world, cap, d / 4, loss_out, flags_dev, (float4*)send_ws, id_guard().dev);
     UR_LAUNCH_CHECK();
   } else {
     ProfScope ps(PC_REDUCE, st, (double)n_slots * d * 8.0);
     hipLaunchKernelGGL(shard_scatter_rows_kernel, dim3(cdiv(n_slots * (d / 4), 256)), dim3(256), 0, st, (const float4*)uniq_grad, u_of_slot,
-                       n_slots, cap, d / 4, loss_out, flags_dev, (float4*)send_ws);
+                       n_slots, cap, d / 4, loss_out, flags_dev, (float4*)send_ws, id_guard().dev);
     UR_LAUNCH_CHECK();
   }
   if (!transport) return UR_OK;

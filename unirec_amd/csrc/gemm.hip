@@ -573,10 +573,12 @@ __global__ __launch_bounds__(256) void gemm_tn_group_kernel(TnGroup g, const flo
 // -- 32 consecutive floats of one token row per half-wave -- read it conflict-free as it lies), the activation of the dW_2 operand is
 // applied to the B fragments behind the LDS read, the bias gradient is summed from the A fragments.
 //   workgroup = 4 waves (2 x 2), wave = 64 x 64 of the tile = four 32 x 32 accumulators (64 VGPRs); stage = 32 tokens x (128 + 128)
-//   columns = 32 KB, double buffered = the 64 KB of static LDS, two workgroups per CU; one barrier per stage (4096 MFMA cycles).
+//   columns = 32 KB, a ring of three (96 KB of dynamic LDS = ONE workgroup per CU), the DMA two stages ahead of the MFMAs behind a counted
+//   vmcnt and a raw s_barrier; one barrier per stage (4096 MFMA cycles).
 // Taken when every product of the group has R % 128 == 0 and Cc % 128 == 0 (d = 128-class shapes; UR_TN_BIG=0 keeps the 64 x 64 kernel).
 constexpr int BT = 128;    // output tile edge
 constexpr int BTK = 32;    // tokens per stage
+constexpr int BTB = 3;     // stages in the LDS ring (96 KB: ONE workgroup per CU -- see the launcher)
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -604,29 +606,46 @@ __device__ __forceinline__ void tn_big_run(const TnBigCtx& c, float* smem, float
       __builtin_amdgcn_global_load_lds((gptr_t)qs, (lptr_t)(Ql + piece * 2 * BT), 16, 0, 0);
     }
   };
+  // ring of BTB stages, the DMA runs two stages ahead: 8 pieces per thread and stage, so "stage s + 1 has landed" = at most the 8
+  // pieces of stage s + 2 still in flight.  Raw s_barrier + counted vmcnt: __syncthreads() would drain the whole queue (hipcc puts
+  // vmcnt(0) in front of a barrier while an LDS-DMA is in flight)
   if (c.nt > 0) issue(0, c.t_begin);
-  __syncthreads();
+  if (c.nt > 1) issue(1, c.t_begin + BTK);
+  if (c.nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
   for (int s_ = 0; s_ < c.nt; ++s_) {
-    const int buf = s_ & 1;
-    if (s_ + 1 < c.nt) issue(buf ^ 1, c.t_begin + (s_ + 1) * BTK);
+    const bool more = s_ + 2 < c.nt;
+    if (more) issue(buf >= 1 ? buf - 1 : BTB - 1, c.t_begin + (s_ + 2) * BTK);   // (buf + 2) % 3: the buffer stage s - 1 was read from
     const float* Pb = smem + buf * (2 * BTK * BT) + c.pa;
     const float* Qb = smem + buf * (2 * BTK * BT) + c.qa;
-#pragma unroll 4
+    float a0 = Pb[0], a1 = Pb[32], b0 = Qb[0], b1 = Qb[32];
+#pragma unroll
     for (int kk = 0; kk < BTK / 2; ++kk) {
-      const float a0 = Pb[kk * 2 * BT], a1 = Pb[kk * 2 * BT + 32];
-      float b0 = Qb[kk * 2 * BT], b1 = Qb[kk * 2 * BT + 32];
+      float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
+      if (kk + 1 < BTK / 2) {   // the next step's fragments are requested in front of this step's MFMAs
+        a0n = Pb[(kk + 1) * 2 * BT]; a1n = Pb[(kk + 1) * 2 * BT + 32];
+        b0n = Qb[(kk + 1) * 2 * BT]; b1n = Qb[(kk + 1) * 2 * BT + 32];
+      }
       if (ACT != UR_ACT_NONE) { b0 = act_fwd(b0, ACT); b1 = act_fwd(b1, ACT); }
       bs0 += a0; bs1 += a1;
+      __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
     }
-    __syncthreads();
+    if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf = buf + 1 < BTB ? buf + 1 : 0;
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_big_kernel(TnGroup g, const float* __restrict__ zero_row) {
+__global__ __launch_bounds__(256) void gemm_tn_big_kernel(TnGroup g, const float* __restrict__ zero_row) {
   int j = 0;
   while (j + 1 < g.n && (int)blockIdx.x >= g.item[j + 1].first_block) ++j;
   const TnItem& it = g.item[j];
@@ -642,7 +661,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_big_kernel(TnGroup g, const fl
   const int r0 = (tile / it.ntc) * BT, c0 = (tile % it.ntc) * BT;
   const bool want_bias = (it.bias_part != nullptr || (S == 1 && it.bias_out != nullptr)) && (tile % it.ntc) == 0;
 
-  __shared__ __attribute__((aligned(16))) float smem[4 * BTK * BT];   // [buf][P | Q][32 tokens][128]; epilogue: Cs[128][128]
+  extern __shared__ __attribute__((aligned(16))) float smem_big[];   // [BTB][P | Q][32 tokens][128]; epilogue: Cs[128][128]
+  float* smem = smem_big;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
   const int hi = lane >> 5, fcol = lane & 31;
   TnBigCtx c;
@@ -720,9 +740,9 @@ long long gemm_tn_group_ws_floats(int R, int Cc) { return (long long)TN_GROUP_SM
 
 // req[i].ws: gemm_tn_group_ws_floats(R, Cc) floats each (untouched until the deferred reduction has run).  defer == nullptr: the
 // reduction of the split products runs right behind the launch.
-// UR_TN_BIG (read once): 1 (default) = 128 x 128 tiles + LDS-DMA for groups whose products all have R, Cc multiples of 128; 0 = the 64 x 64 kernel
+// UR_TN_BIG (read once): 1 = 128 x 128 tiles + LDS-DMA for groups whose products all have R, Cc multiples of 128; 0 (default) = the 64 x 64 kernel
 static int tn_big_mode() {
-  static const int m = getenv("UR_TN_BIG") ? atoi(getenv("UR_TN_BIG")) : 1;
+  static const int m = getenv("UR_TN_BIG") ? atoi(getenv("UR_TN_BIG")) : 0;
   return m;
 }
 // UR_TN_TARGET (read once; tuning aid): workgroups a group launch aims at (default: 864 for the 64 x 64 kernel, 288 for the 128 x 128 one)
@@ -741,8 +761,9 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
   const int tile = big ? BT : GT, stage = big ? BTK : GBT;
   // workgroups per launch.  64 x 64 kernel (~3 per CU: 32 KB of LDS each), measured at C5 (profiles/r03_a_dw_schedule.txt): 288 -> 0.681
   // ms/step, 576 -> 0.660, 864 -> 0.658, 1152+ -> 0.665 -- short workgroups give the CUs back to the main stream's kernels sooner.
-  // 128 x 128 kernel: one workgroup is four times the work per token row; ~1 per CU
-  const int target = tn_target(big ? 288 : 864);
+  // 128 x 128 kernel: ONE workgroup per CU (96 KB of LDS: the dispatcher otherwise packs two onto a CU while other CUs idle -- the two then
+  // share each SIMD's matrix pipe: 35 TF/s isolated against 77 for the 64 x 64 kernel, profiles/r05_a_tn_big.txt) and ~one per CU in the grid
+  const int target = tn_target(big ? 256 : 864);
   TnGroup g{};
   g.n = n;
   double work = 0.0, flops = 0.0;
@@ -762,7 +783,8 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
     TnItem& it = g.item[i];
     int S = (int)(q.T / rows_per + 0.5);
     if (S > q.T / (2 * stage)) S = q.T / (2 * stage);
-    if (S >= 6) S = std::min(TN_GROUP_SMAX, (S + 4) / 8 * 8);
+    if (big) S = std::min(TN_GROUP_SMAX, S);   // (any S: split sp sits on XCD sp % 8, the slots behind S exit)
+    else if (S >= 6) S = std::min(TN_GROUP_SMAX, (S + 4) / 8 * 8);
     if (S < 1) S = 1;
     it.P = q.P; it.Q = q.Q; it.ldp = q.ldp; it.ldq = q.ldq; it.T = q.T; it.t_dev = q.t_dev; it.R = q.R; it.Cc = q.Cc;
     it.pro_act = q.pro_act; it.act = q.act; it.S = S; it.ntr = cdiv(q.R, tile); it.ntc = cdiv(q.Cc, tile);
@@ -774,8 +796,13 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
   }
   {
     ProfScope ps(PC_GEMM_TN, st, flops, true);   // (the launch's own timestamps: on the side stream a recorded bracket would hold the waits of every fork)
-    if (big) UR_LAUNCH_EV(gemm_tn_big_kernel, dim3(blocks), dim3(256), 0, st, g, zeros);
-    else UR_LAUNCH_EV(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g, zeros);
+    if (big) {
+      constexpr int lds = BTB * 2 * BTK * BT * (int)sizeof(float);
+      static const bool attr = (hipFuncSetAttribute((const void*)gemm_tn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+      (void)attr;
+      UR_LAUNCH_EV(gemm_tn_big_kernel, dim3(blocks), dim3(256), lds, st, g, zeros);
+    }
+    else { UR_LAUNCH_EV(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g, zeros); }
   }
   UR_LAUNCH_CHECK();
   for (int i = 0; i < n; ++i) {

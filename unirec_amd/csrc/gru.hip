@@ -714,7 +714,7 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
     hipLaunchKernelGGL(ids_time_major_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, item_seq, B, L, w.seq_tm);
     UR_LAUNCH_CHECK();
   }
-  if ((rc = gather_rows(item_table, w.seq_tm, 4, M, d, w.x, st))) return rc;
+  if ((rc = gather_rows(item_table, w.seq_tm, 4, M, d, w.x, st, n_items))) return rc;
   if (c.p_drop > 0.f && (rc = drop_rows(w.x, M, d, drop_spec(c.p_drop, c.drop_seed, c.drop_step, 0), w.x, st))) return rc;
   GemmArgs g{};
   g.A = w.x; g.lda = d; g.W = dense + lay.w_ih; g.ldw = d; g.C = w.gi; g.ldc = 3 * H; g.M = M; g.N = 3 * H; g.K = d; g.bias = dense + lay.b_ih;

@@ -9,11 +9,12 @@ namespace ur {
 constexpr int LN_BWD_MAX_BLOCKS = 512;
 
 // ---- rowops.hip
-int gather_rows(const float* table, const void* idx, int idx_bytes, long long n, int d, float* out, hipStream_t st);
+// n_rows (here and below; 0 = unknown): rows of the table -- what the bounds-checked build (common.h: UR_ROW) checks every index against
+int gather_rows(const float* table, const void* idx, int idx_bytes, long long n, int d, float* out, hipStream_t st, long long n_rows = 0);
 // tok (nullable): compact row r is token tok[r] of seq (= b*L + l); m_dev (nullable): device-side row count
 int embed_ln_fwd(const int* seq, const float* table, const float* pos, const float* gamma, const float* beta, float eps,
                  int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st, const int* tok = nullptr,
-                 const int* m_dev = nullptr, const DropSpec* drop = nullptr);   // drop: y <- dropout(y), row id = token b*L + l
+                 const int* m_dev = nullptr, const DropSpec* drop = nullptr, long long n_rows = 0);   // drop: y <- dropout(y), row id = token b*L + l
 // out[r,:] = dropout(x[r,:]), row id of row r per `drop` (out may alias x; drop off: a copy, or nothing when aliased)
 int drop_rows(const float* x, long long rows, int d, const DropSpec& drop, float* out, hipStream_t st);
 int ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, int M, int d, float* y,
@@ -187,6 +188,7 @@ struct ChainProjBwdArgs {
 };
 struct ChainEmbedArgs {
   const int* seq;                       // [B*L] item ids of the padded token grid
+  long long n_rows = 0;                 // rows of the item table (bounds-checked build)
   const float *table, *pos;             // item table [N, d]; position table [L, d] (nullable)
   const float *g0, *b0ln; float eps;    // the embedding LayerNorm
   int L; const int* tok;                // tok (nullable): buffer row -> token of the padded grid (compacted rows)

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(NT) void scorer_loss_fwd_kernel(UrLossCfg c, const 
                                                               const int* __restrict__ label, const float* __restrict__ user_bias,
                                                               const float* __restrict__ item_bias, const long long* __restrict__ user_id,
                                                               float* __restrict__ scores, float* __restrict__ loss_rows,
-                                                              float* __restrict__ cnt_rows) {
+                                                              float* __restrict__ cnt_rows, long long n_items) {
   extern __shared__ float sc[];  // [G] scores of this row, then 16 floats of reduction scratch
   float* red = sc + c.G;
   const int b = blockIdx.x, G = c.G, d4 = c.d / 4;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NT) void scorer_loss_fwd_kernel(UrLossCfg c, const 
     float s[UNR];
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
-      id[q] = (gb + q < G) ? item_id[(long long)b * G + gb + q] : 0;
+      id[q] = (gb + q < G) ? UR_ROW(item_id[(long long)b * G + gb + q], n_items) : 0;
       s[q] = 0.f;
     }
 #pragma unroll
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NT) void scorer_loss_bwd_kernel(UrLossCfg c, const 
                                                               const int* __restrict__ label, const float* __restrict__ scores,
                                                               const float* __restrict__ d_loss, const float* __restrict__ norm,
                                                               float* __restrict__ coef, float4* __restrict__ d_user,
-                                                              float* __restrict__ d_user_bias_rows) {
+                                                              float* __restrict__ d_user_bias_rows, long long n_items) {
   extern __shared__ float sh[];  // [G] coef, then [groups][d] partial d_user, then 16 scratch
   constexpr int groups = NT / TPR;
   const int b = blockIdx.x, G = c.G, d4 = c.d / 4, d = c.d;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NT) void scorer_loss_bwd_kernel(UrLossCfg c, const 
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
       const bool in = gb + q < G;
-      id[q] = in ? item_id[(long long)b * G + gb + q] : 0;
+      id[q] = in ? UR_ROW(item_id[(long long)b * G + gb + q], n_items) : 0;
       w[q] = in ? cf[gb + q] : 0.f;
     }
 #pragma unroll
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void scorer_loss_fused_kernel(UrLossCfg c, flo
                                                                 float* __restrict__ cnt_rows, float* __restrict__ coef,
                                                                 float* __restrict__ d_user, float* __restrict__ d_user_bias_rows,
                                                                 float* __restrict__ loss_out, unsigned* __restrict__ done_counter,
-                                                                int arrive_mode) {
+                                                                int arrive_mode, long long n_items) {
   extern __shared__ __attribute__((aligned(16))) float sh[];   // [G][d] rows, [G] scores, [G] coefficients, 16 floats of scratch
   const int b = blockIdx.x, G = c.G, d4 = c.d / 4, d = c.d;
   float* rows = sh;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void scorer_loss_fused_kernel(UrLossCfg c, flo
     float s[UNR];
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
-      id[q] = (gb + q < G) ? item_id[(long long)b * G + gb + q] : 0;
+      id[q] = (gb + q < G) ? UR_ROW(item_id[(long long)b * G + gb + q], n_items) : 0;
       s[q] = 0.f;
     }
 #pragma unroll
@@ -477,7 +477,7 @@ extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_em
   float* cnt_rows = loss_rows + cfg->B;  // loss_rows buffer is [2*B]: losses then counts
 #define GO2(T, U, NT) hipLaunchKernelGGL((scorer_loss_fwd_kernel<T, U, NT>), dim3(cfg->B), dim3(NT), lds, st, *cfg, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, user_bias, item_bias,            \
-                                 (const long long*)user_id, scores, loss_rows, cnt_rows)
+                                 (const long long*)user_id, scores, loss_rows, cnt_rows, (long long)n_items)
 #define GO1(T, U) do { if (wide) GO2(T, U, 1024); else GO2(T, U, 256); } while (0)
 #define GO(T) GO1(T, 8)   /* 8 candidate rows in flight per lane group (2 / 4 / 16 measured slower: round 1) */
   switch (tpr) {
@@ -503,7 +503,6 @@ extern "C" int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_em
              "ur_gather_dot_loss_bwd: null pointer");
   UR_REQUIRE(label || (cfg->loss_type != UR_LOSS_BCE && cfg->loss_type != UR_LOSS_SOFTMAX), UR_ERR_ARG,
              "ur_gather_dot_loss_bwd: label is required for bce/softmax");
-  (void)n_items;
   hipStream_t st = as_stream(stream);
   ProfScope ps(PC_LOSS, st, (double)cfg->B * cfg->G * cfg->d * 4.0);
   const int tpr = pick_tpr(cfg->d);
@@ -515,7 +514,7 @@ extern "C" int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_em
 #define GO(T) do { if (wide) GOB(T, 1024); else GOB(T, 256); } while (0)
 #define GOB(T, NT) hipLaunchKernelGGL((scorer_loss_bwd_kernel<T, NT>), dim3(cfg->B), dim3(NT), lds, st, *cfg, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, scores, d_loss, loss_out, coef,  \
-                                 (float4*)d_user, d_user_bias_rows)
+                                 (float4*)d_user, d_user_bias_rows, (long long)n_items)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;
@@ -580,7 +579,7 @@ extern "C" int ur_gather_dot_loss_fwd_bwd(const UrLossCfg* cfg, const float* use
   float* cnt_rows = loss_rows + cfg->B;
 #define GO(T) hipLaunchKernelGGL((scorer_loss_fused_kernel<T>), dim3(cfg->B), dim3(256), lds, st, *cfg, total, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, user_bias, item_bias,                 \
-                                 (const long long*)user_id, scores, loss_rows, cnt_rows, coef, d_user, d_user_bias_rows, loss_out, counter, ur_arrive_mode())
+                                 (const long long*)user_id, scores, loss_rows, cnt_rows, coef, d_user, d_user_bias_rows, loss_out, counter, ur_arrive_mode(), (long long)n_items)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

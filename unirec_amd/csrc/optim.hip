@@ -11,6 +11,7 @@ thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;   // comm
 namespace ur {
 
 static thread_local char g_err[512] = "";
+static int* g_guard_host[64] = {};   // host addresses of the id guard's mirrors (id_guard below)
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -29,9 +30,9 @@ int fail(int code, const char* fmt, ...) {
 // torch.optim single-tensor update of the flat dense-parameter buffer (rule: opt_elem in common.h)
 __global__ __launch_bounds__(256) void dense_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long long n, AdamK a, float bc1, float bc2s,
-                                                         const float* __restrict__ scale_dev) {
-  const float scale = scale_dev ? *scale_dev : 1.0f;
-  if (scale < 0.f) return;   // update guard: the step's loss was NaN (Trainer skips such a step, trainer.py:343-350)
+                                                         const float* __restrict__ scale_dev, const int* __restrict__ guard_dev) {
+  const float scale = ur_step_scale(scale_dev, guard_dev);
+  if (scale < 0.f) return;   // update guard: the step's loss was NaN (Trainer skips such a step, trainer.py:343-350), or the id guard is raised
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float w = p[i], mi = m[i], vi = v[i];
     opt_elem(w, mi, vi, g[i] * scale, a, bc1, bc2s);
@@ -71,9 +72,58 @@ __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm
   out[0] = (guard && guard[0] < 0.f) ? -1.f : (c < 1.f ? c : 1.f);
 }
 
+// ---- the id guard's storage (common.h): per device, allocated once
+IdGuard id_guard() {
+  static IdGuard g[64] = {};
+  static bool tried[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return IdGuard{nullptr, nullptr};
+  if (!tried[dev]) {
+    tried[dev] = true;
+    int* d = nullptr;
+    int* h = nullptr;
+    if (hipMalloc((void**)&d, 16) == hipSuccess && hipMemset(d, 0, 16) == hipSuccess &&
+        hipHostMalloc((void**)&h, 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      memset(h, 0, 16);
+      void* hd = nullptr;
+      if (hipHostGetDevicePointer(&hd, h, 0) == hipSuccess) g[dev] = IdGuard{d, (int*)hd};
+      g_guard_host[dev] = h;
+      (void)hipDeviceSynchronize();
+    }
+  }
+  return g[dev];
+}
+
 }  // namespace ur
 
 using namespace ur;
+
+// the host's view of this device's id guard, no synchronisation (a plain load of the host-mapped mirror): 0 = clear; 1 = raised, with
+// out3 = {offending id, rows of the table it was aimed at (saturated to 2^31 - 1), 0}
+extern "C" int ur_id_guard_state(int64_t* out3) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  (void)id_guard();
+  volatile int* h = g_guard_host[dev];
+  if (!h || h[0] == 0) return 0;
+  if (out3) {
+    out3[0] = (int64_t)(((uint64_t)(uint32_t)h[2] << 32) | (uint32_t)h[1]);
+    out3[1] = h[3];
+    out3[2] = 0;
+  }
+  return 1;
+}
+// clear the guard (after the IndexError has been handled): device word on `stream`, host mirror at once
+extern "C" int ur_id_guard_reset(void* stream) {
+  int dev = 0;
+  UR_HIP(hipGetDevice(&dev));
+  IdGuard g = id_guard();
+  UR_REQUIRE(g.dev && dev >= 0 && dev < 64 && g_guard_host[dev], UR_ERR_HIP, "ur_id_guard_reset: no guard on this device");
+  UR_HIP(hipMemsetAsync(g.dev, 0, 16, as_stream(stream)));
+  UR_HIP(hipStreamSynchronize(as_stream(stream)));
+  memset(g_guard_host[dev], 0, 16);
+  return UR_OK;
+}
 
 extern "C" const char* ur_last_error(void) { return g_err; }
 extern "C" int ur_version(void) { return 100; }
@@ -90,7 +140,7 @@ extern "C" int ur_dense_adam(const UrAdamCfg* cfg, float* param, const float* gr
   if (blocks > 2048) blocks = 2048;
   ProfScope ps(PC_ADAM, as_stream(stream), (double)n * 4.0 * 7);
   hipLaunchKernelGGL(dense_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, m, v, (long long)n,
-                     AdamK{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo}, bc1, bc2s, grad_scale_dev);
+                     AdamK{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo}, bc1, bc2s, grad_scale_dev, id_guard().dev);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a)
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const long long id = a.seq[full[p]];
+      const long long id = UR_ROW(a.seq[full[p]], a.n_rows);
       x[p] = *(const float4*)(a.table + id * D + et * 4);
     }
 #pragma unroll

@@ -20,14 +20,14 @@ typedef float vf4 __attribute__((ext_vector_type(4)));
 // UNROLL rows in flight per lane group: random 512-B row reads need many outstanding loads per CU.
 template <typename IdxT, int TPR, int UNROLL>
 __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ table, const IdxT* __restrict__ idx,
-                                                     long long n, int d4, float4* __restrict__ out) {
+                                                     long long n, int d4, float4* __restrict__ out, long long n_rows) {
   const int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const long long stride = (long long)gridDim.x * groups * UNROLL;
   for (long long base = ((long long)blockIdx.x * groups + g) * UNROLL; base < n; base += stride) {
     long long id[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) id[u] = (base + u < n) ? (long long)idx[base + u] : 0;
+    for (int u = 0; u < UNROLL; ++u) id[u] = (base + u < n) ? UR_ROW((long long)idx[base + u], n_rows) : 0;
     for (int c = t; c < d4; c += TPR) {
       float4 v[UNROLL];
 #pragma unroll
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ 
 }
 
 template <typename IdxT>
-static int launch_gather(const float* table, const void* idx, long long n, int d, float* out, hipStream_t st) {
+static int launch_gather(const float* table, const void* idx, long long n, int d, float* out, hipStream_t st, long long n_rows) {
   const int d4 = d / 4;
   const int tpr = pick_tpr(d);
   const int groups = 256 / tpr;
@@ -52,7 +52,7 @@ static int launch_gather(const float* table, const void* idx, long long n, int d
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
 #define GO(T) hipLaunchKernelGGL((gather_kernel<IdxT, T, U>), dim3((unsigned)blocks), dim3(256), 0, st, \
-                                 (const float4*)table, (const IdxT*)idx, n, d4, (float4*)out)
+                                 (const float4*)table, (const IdxT*)idx, n, d4, (float4*)out, n_rows)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;
@@ -64,10 +64,10 @@ static int launch_gather(const float* table, const void* idx, long long n, int d
   return UR_OK;
 }
 
-int gather_rows(const float* table, const void* idx, int idx_bytes, long long n, int d, float* out, hipStream_t st) {
+int gather_rows(const float* table, const void* idx, int idx_bytes, long long n, int d, float* out, hipStream_t st, long long n_rows) {
   if (n == 0) return UR_OK;
   ProfScope ps(PC_GATHER, st, (double)n * (d * 4.0 + idx_bytes));  // algorithmic READ bytes
-  return idx_bytes == 8 ? launch_gather<long long>(table, idx, n, d, out, st) : launch_gather<int>(table, idx, n, d, out, st);
+  return idx_bytes == 8 ? launch_gather<long long>(table, idx, n, d, out, st, n_rows) : launch_gather<int>(table, idx, n, d, out, st, n_rows);
 }
 
 // ------------------------------------------------------------------------- gather + pos + LayerNorm
@@ -78,14 +78,14 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
                                                            const float4* __restrict__ beta, float eps, int M, int L, int d4,
                                                            float4* __restrict__ y, float4* __restrict__ xhat,
                                                            float* __restrict__ rstd_out, const int* __restrict__ tok,
-                                                           const int* __restrict__ m_dev, DropSpec drop) {
+                                                           const int* __restrict__ m_dev, DropSpec drop, long long n_rows) {
   const int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const float inv_d = 1.0f / (float)(d4 * 4);
   if (m_dev) M = min(M, *m_dev);
   for (int row = blockIdx.x * groups + g; row < M; row += gridDim.x * groups) {
     const int full = tok ? tok[row] : row;   // position of this (compact) row in the padded [B, L] token grid
-    const long long id = seq[full];
+    const long long id = UR_ROW(seq[full], n_rows);
     const int l = full % L;
     float4 v[MAXV];
     float s = 0.f;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
 
 int embed_ln_fwd(const int* seq, const float* table, const float* pos, const float* gamma, const float* beta,
                  float eps, int M, int L, int d, float* y, float* xhat, float* rstd, hipStream_t st, const int* tok,
-                 const int* m_dev, const DropSpec* drop) {
+                 const int* m_dev, const DropSpec* drop, long long n_rows) {
   const DropSpec ds = drop ? *drop : DropSpec{};
   ProfScope ps(PC_ROWOPS, st, (double)M * d * 4.0 * 3);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
@@ -140,7 +140,7 @@ int embed_ln_fwd(const int* seq, const float* table, const float* pos, const flo
   if (blocks > 4096) blocks = 4096;
 #define GO(T) hipLaunchKernelGGL((embed_ln_fwd_kernel<T>), dim3(blocks), dim3(256), 0, st, seq, (const float4*)table, \
                                  (const float4*)pos, (const float4*)gamma, (const float4*)beta, eps, M, L, d / 4,      \
-                                 (float4*)y, (float4*)xhat, rstd, tok, m_dev, ds)
+                                 (float4*)y, (float4*)xhat, rstd, tok, m_dev, ds, n_rows)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;
@@ -411,7 +411,7 @@ int pos_grad(const float* dx, int B, int L, int d, float* dpos, hipStream_t st) 
 template <int TPR>
 __global__ __launch_bounds__(256) void pool_rows_fwd_kernel(const float4* __restrict__ table, const int* __restrict__ seq,
                                                             const long long* __restrict__ seq_len, const float4* __restrict__ base,
-                                                            float alpha, int B, int L, int d4, float4* __restrict__ out) {
+                                                            float alpha, int B, int L, int d4, float4* __restrict__ out, long long n_rows) {
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int b = blockIdx.x * groups + g;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void pool_rows_fwd_kernel(const float4* __rest
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int l = 0; l < L; ++l) {   // fixed summation order over positions
-    const long long id = seq[(long long)b * L + l];
+    const long long id = UR_ROW(seq[(long long)b * L + l], n_rows);
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int c = t + k * TPR;
@@ -463,7 +463,7 @@ extern "C" int ur_embedding_gather_f32(const float* table, int64_t n_rows, int d
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512, UR_ERR_ARG, "ur_embedding_gather_f32: d=%d must be a multiple of 4, <= 512", d);
   UR_REQUIRE(idx_bytes == 4 || idx_bytes == 8, UR_ERR_ARG, "ur_embedding_gather_f32: idx_bytes=%d (4 or 8)", idx_bytes);
   UR_REQUIRE(n >= 0 && n_rows > 0, UR_ERR_ARG, "ur_embedding_gather_f32: n=%lld n_rows=%lld", (long long)n, (long long)n_rows);
-  return ur::gather_rows(table, idx, idx_bytes, n, d, out, ur::as_stream(stream));
+  return ur::gather_rows(table, idx, idx_bytes, n, d, out, ur::as_stream(stream), n_rows);
 }
 
 extern "C" int ur_pool_rows_fwd(const float* table, int64_t n_rows, int32_t d, const int32_t* item_seq, const int64_t* seq_len,
@@ -474,7 +474,7 @@ extern "C" int ur_pool_rows_fwd(const float* table, int64_t n_rows, int32_t d, c
   ur::ProfScope ps(ur::PC_ROWOPS, st, (double)B * L * d * 4.0);
   const int tpr = ur::pick_tpr(d), groups = 256 / tpr;
 #define GO(T) hipLaunchKernelGGL((ur::pool_rows_fwd_kernel<T>), dim3(ur::cdiv(B, groups)), dim3(256), 0, st, (const float4*)table, item_seq, \
-                                 (const long long*)seq_len, (const float4*)base, alpha, B, L, d / 4, (float4*)user_emb)
+                                 (const long long*)seq_len, (const float4*)base, alpha, B, L, d / 4, (float4*)user_emb, (long long)n_rows)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

@@ -34,10 +34,11 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned dgt, bool act
 }
 
 __global__ void build_keys_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
-                                  long long n_b, unsigned* __restrict__ keys, int* __restrict__ vals, int W, long long n_local) {
+                                  long long n_b, unsigned* __restrict__ keys, int* __restrict__ vals, int W, long long n_local,
+                                  long long n_rows, IdGuard gd) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_a + n_b) return;
-  const long long id = (i < n_a) ? (long long)ids_a[i] : ids_b[i - n_a];
+  const long long id = ur_guard_id((i < n_a) ? (long long)ids_a[i] : ids_b[i - n_a], n_rows, gd);   // (out of range: guard raised, treated as the padding id)
   // row-sharded table: row `id` lives on rank id % W at local row id / W; sorting by (owner, local row)
   // makes every owner's requests contiguous (the all-to-all split sizes are the per-owner unique counts)
   // local row 0 is the padding row on EVERY rank (real items start at local row 1), so "row 0 never moves" holds per shard
@@ -135,7 +136,7 @@ constexpr int RCH = 1024;    // keys per workgroup of the radix_first / radix_pa
 __global__ __launch_bounds__(256) void radix_first_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
                                                           long long n_b, unsigned* __restrict__ keys, int* __restrict__ vals, int W,
                                                           long long n_local, int nchunks, int* __restrict__ hist, int n_later,
-                                                          unsigned* __restrict__ status, int n_status) {
+                                                          unsigned* __restrict__ status, int n_status, long long n_rows, IdGuard gd) {
   __shared__ int cnt[RADIX];
   const int chunk = blockIdx.x;
   const long long n = n_a + n_b, base = (long long)chunk * RCH;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void radix_first_kernel(const int* __restrict_
   for (int it = 0; it < RCH / 256; ++it) {
     const long long i = base + it * 256 + threadIdx.x;
     if (i < n) {
-      const long long id = (i < n_a) ? (long long)ids_a[i] : ids_b[i - n_a];
+      const long long id = ur_guard_id((i < n_a) ? (long long)ids_a[i] : ids_b[i - n_a], n_rows, gd);
       const unsigned key = (W > 1) ? (id ? (unsigned)((id % W) * n_local + id / W + 1) : 0u) : (unsigned)id;   // (build_keys_kernel)
       keys[i] = key;
       vals[i] = (int)i;
@@ -392,6 +393,7 @@ struct ReduceRiders {
   float* sf_out4 = nullptr;
   const float* fr_loss = nullptr;
   const int* fr_flags = nullptr;
+  const int* fr_guard = nullptr;   // this device's id guard: raised = the flag row says "NaN" (skipped on every rank)
   int fr_on = 0, world = 0, cap = 0;
 };
 
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
   }
   if (rd.fr_on && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < rd.world) {
     const float loss = rd.fr_loss ? rd.fr_loss[0] : 0.f;
-    const float nan = (rd.fr_loss && (rd.fr_loss[2] < 0.f || loss != loss)) ? 1.f : 0.f;
+    const float nan = ((rd.fr_loss && (rd.fr_loss[2] < 0.f || loss != loss)) || (rd.fr_guard && *rd.fr_guard)) ? 1.f : 0.f;
     out[(long long)threadIdx.x * rd.cap * d4] = make_float4(nan, (rd.fr_flags && (rd.fr_flags[0] & 1)) ? 1.f : 0.f, nan != 0.f ? 0.f : loss, 1.f);
   }
   // (these two kernels run beside the bottom layer's weight-gradient launch: their few memory instructions go first -- 0.601 -> 0.596 ms/step)
@@ -710,15 +712,16 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
                                                  float4* __restrict__ var, int* __restrict__ last_step,
                                                  const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev, long long n_max,
                                                  const float4* __restrict__ grad, int d4, const float* __restrict__ scale_dev,
-                                                 int bid, int nblk, const int* __restrict__ skip_mark = nullptr) {
+                                                 int bid, int nblk, const int* __restrict__ skip_mark = nullptr,
+                                                 const int* __restrict__ guard_dev = nullptr) {
   // MODE 2 = MODE 0 for rows the NEXT batch reads as well (the "hot" rows of a step whose other updates run beside the next forward
   // pass): when the step is skipped (scale < 0) they still take it as a zero-gradient step, as every row the step does not touch does --
   // the catch-up the next batch's rows would otherwise get behind the update.  skip_mark (MODE 0; per unique id): rows somebody else updates.
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int n_uniq = (int)min((long long)*n_uniq_dev, n_max);
-  const float scale = scale_dev ? *scale_dev : 1.0f;
-  if (MODE == 0 && scale < 0.f) return;   // update guard: NaN loss, the whole step is skipped (see dense_adam_kernel)
+  const float scale = ur_step_scale(scale_dev, MODE == 1 ? nullptr : guard_dev);
+  if (MODE == 0 && scale < 0.f) return;   // update guard: NaN loss or a raised id guard, the whole step is skipped (see dense_adam_kernel)
   const bool skipped = MODE == 2 && scale < 0.f;
   if (bid * groups >= n_uniq) return;     // nothing for this workgroup (the grid is sized for the plan's capacity; a filtered catch-up
                                           // list is often EMPTY: 3 520 workgroups evaluating two powf for nothing were 20 us)
@@ -824,10 +827,11 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
                                                           float4* __restrict__ var, int* __restrict__ last_step,
                                                           const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
                                                           long long n_max, const float4* __restrict__ grad, int d4,
-                                                          const float* __restrict__ scale_dev, const int* __restrict__ skip_mark) {
+                                                          const float* __restrict__ scale_dev, const int* __restrict__ skip_mark,
+                                                          const int* __restrict__ guard_dev) {
   __builtin_amdgcn_s_setprio(3);   // (see rows_reduce_kernel)
   sparse_adam_body<TPR, MODE>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, (int)blockIdx.x, (int)gridDim.x,
-                              skip_mark);
+                              skip_mark, guard_dev);
 }
 template <int TPR>
 __global__ __launch_bounds__(256) void lazy_flush_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
@@ -882,7 +886,8 @@ constexpr int MID_CHUNK = 2048;
 
 __global__ __launch_bounds__(1024) void plan_chunk_sort_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
                                                                long long n_b, int W, long long n_local, unsigned* __restrict__ ckeys,
-                                                               int* __restrict__ cpos, int* __restrict__ owner_counts) {
+                                                               int* __restrict__ cpos, int* __restrict__ owner_counts, long long n_rows,
+                                                               IdGuard gd) {
   __shared__ unsigned long long s[MID_CHUNK];
   const int tid = threadIdx.x;
   const long long n = n_a + n_b, base = (long long)blockIdx.x * MID_CHUNK;
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(1024) void plan_chunk_sort_kernel(const int* __rest
     const long long g = base + i;
     unsigned key = 0xFFFFFFFFu;   // padding of the last chunk: sorts behind every real key
     if (g < n) {
-      const long long id = (g < n_a) ? (long long)ids_a[g] : ids_b[g - n_a];
+      const long long id = ur_guard_id((g < n_a) ? (long long)ids_a[g] : ids_b[g - n_a], n_rows, gd);
       key = (W > 1) ? (id ? (unsigned)((id % W) * n_local + id / W + 1) : 0u) : (unsigned)id;
     }
     s[i] = ((unsigned long long)key << 11) | (unsigned)i;
@@ -1164,6 +1169,7 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
   UR_REQUIRE(n_rows > 0 && n_rows <= (1LL << 31), UR_ERR_ARG, "ur_rows_plan: n_rows=%lld", (long long)n_rows);
   hipStream_t st = as_stream(stream);
   ProfScope ps(PC_SORT, st, (double)n * 8.0);
+  const IdGuard gd = id_guard();   // (every id of a training batch passes here once: the range check rides in the first pass, common.h)
   PlanWs w = carve_plan(n, (char*)ws);
   const int nwaves = (int)((n + CH - 1) / CH);
   const int nblk = cdiv(nwaves, 4);
@@ -1181,7 +1187,7 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
   if (n <= SMALL_N && !no_small && passes > 2) {
     const int nch = cdiv(n, MID_CHUNK);
     hipLaunchKernelGGL(plan_chunk_sort_kernel, dim3(nch), dim3(1024), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b, W,
-                       n_local, w.keys0, w.vals_tmp, owner_counts_dev);
+                       n_local, w.keys0, w.vals_tmp, owner_counts_dev, (long long)n_rows, gd);
     UR_LAUNCH_CHECK();
     hipLaunchKernelGGL(plan_chunk_rank_kernel, dim3(cdiv((long long)nch * MID_CHUNK * (SMALL_N / MID_CHUNK), 256)), dim3(256), 0, st, w.keys0, w.vals_tmp, (int)n, nch,
                        sorted_pos, (int*)w.keys1);
@@ -1196,7 +1202,7 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
   if (!old_multi) {
     const int nchunks = cdiv(n, RCH), hgrid = heads_grid(n);
     hipLaunchKernelGGL(radix_first_kernel, dim3(nchunks), dim3(256), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b,
-                       kbuf[0], vbuf[0], W, n_local, nchunks, w.hist, passes - 1, (unsigned*)w.counts, hgrid <= 1024 ? hgrid : 0);
+                       kbuf[0], vbuf[0], W, n_local, nchunks, w.hist, passes - 1, (unsigned*)w.counts, hgrid <= 1024 ? hgrid : 0, (long long)n_rows, gd);
     UR_LAUNCH_CHECK();
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
@@ -1212,7 +1218,7 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
     return UR_OK;
   }
   hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids_a, (long long)n_a, (const long long*)ids_b,
-                     (long long)n_b, kbuf[0], vbuf[0], W, n_local);
+                     (long long)n_b, kbuf[0], vbuf[0], W, n_local, (long long)n_rows, gd);
   UR_LAUNCH_CHECK();
   int cur = 0;
   for (int p = 0; p < passes; ++p) {
@@ -1335,7 +1341,7 @@ extern "C" int ur_rows_reduce_riders(const int32_t* uniq_idx, const int32_t* seg
   UR_REQUIRE(!step_flags_out4 || (rows_a && n_a >= (int64_t)(world - 1) * cap + 1), UR_ERR_ARG, "ur_rows_reduce_riders: step flags need the received block as rows_a");
   UR_REQUIRE(!write_flag_rows || out_rows, UR_ERR_ARG, "ur_rows_reduce_riders: flag rows go with sums written to their slots (out_rows)");
   ReduceRiders rd;
-  rd.sf_out4 = step_flags_out4; rd.fr_on = write_flag_rows ? 1 : 0; rd.fr_loss = loss_out; rd.fr_flags = flags_dev; rd.world = world; rd.cap = cap;
+  rd.sf_out4 = step_flags_out4; rd.fr_on = write_flag_rows ? 1 : 0; rd.fr_loss = loss_out; rd.fr_flags = flags_dev; rd.fr_guard = id_guard().dev; rd.world = world; rd.cap = cap;
   return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, uniq_grad, sumsq_dev, out_rows,
                           nullptr, nullptr, n, stream, rd);
 }
@@ -1366,8 +1372,10 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
   // 3 520 workgroups that start, read the count and leave -- 20 us of dispatch at the tail of every step beside the dW launch
   if (mode != 0 && blocks > UR_CATCHUP_BLOCKS) blocks = UR_CATCHUP_BLOCKS;   // (mode 2: the short list of rows two consecutive batches share)
   if (blocks < 1) blocks = 1;
+  const int* guard_dev = id_guard().dev;
 #define GO(T, MD) hipLaunchKernelGGL((sparse_adam_kernel<T, MD>), dim3(blocks), dim3(256), 0, st, a, (float4*)table, (float4*)m, \
-                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale, skip_mark)
+                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale, skip_mark, \
+                                     guard_dev)
 #define SW(MD)            \
   switch (tpr) {          \
     case 4: GO(4, MD); break;   \

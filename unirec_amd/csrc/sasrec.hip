@@ -379,7 +379,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     const LayerP p0 = layer_ptrs(dense, lay, 0);
     const int skip_q = (c.last_only && c.n_layers == 1) ? 1 : 0;   // a last-row first layer projects K, V only here
     ChainEmbedArgs ce{};
-    ce.seq = item_seq; ce.table = item_table; ce.pos = pos; ce.g0 = dense + lay.off[1]; ce.b0ln = dense + lay.off[2]; ce.eps = c.eps;
+    ce.seq = item_seq; ce.n_rows = n_items; ce.table = item_table; ce.pos = pos; ce.g0 = dense + lay.off[1]; ce.b0ln = dense + lay.off[2]; ce.eps = c.eps;
     ce.L = c.L; ce.tok = tokmap; ce.drop = d_emb;
     ce.x0 = w.x0; ce.x0hat = w.x0hat; ce.rstd0 = w.rstd0;
     ce.wnT = w.layer[0].wqkvT + skip_q * d; ce.ldwn = 3 * d; ce.bn = p0.bqkv + skip_q * d;
@@ -389,7 +389,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     proj_done = true;
   } else {
     rc = embed_ln_fwd(item_seq, item_table, pos, dense + lay.off[1], dense + lay.off[2], c.eps, M, c.L, d, w.x0, w.x0hat, w.rstd0, st,
-                      tokmap, mv, &d_emb);
+                      tokmap, mv, &d_emb, n_items);
     if (rc) return rc;
   }
   const float* x = w.x0;

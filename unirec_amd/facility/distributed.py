@@ -478,7 +478,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             self.n_overflow += 1
             if scale_then == self._cap_scale:   # (not doubled yet by an earlier entry of the same capacity)
                 self._cap_scale *= 2
-            self._look = None             # made with the old capacity
+            self._drop_look()             # made with the old capacity
             warnings.warn(f"row exchange: capacity overflow at step {step}; capacity x{self._cap_scale}, batch re-trained")
             self._replaying = True
             try:
@@ -486,9 +486,31 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             finally:
                 self._replaying = False
 
+    def _join_look(self):
+        """The current stream waits for the plan stream's work on the lookahead batch.  Since round 4 that work WRITES optimizer state
+        (_prefetch_rows: the zero-gradient steps of the cold rows -- w, m, v, last), so whatever touches the tables on the current
+        stream without adopting the lookahead (a replay, flush, a checkpoint) has to be ordered behind it first."""
+        look = self._look
+        if look is not None and not look.waited and look.event is not None:
+            torch.cuda.current_stream().wait_event(look.event)
+            look.waited = True
+
+    def _drop_look(self):
+        self._join_look()
+        self._look = None
+
     def flush(self):
         self._check_overflow(drain=True)
+        self._join_look()
         return super().flush()
+
+    def state_dict(self):
+        self._join_look()
+        return super().state_dict()
+
+    def mark_tables_current(self):
+        self._join_look()
+        return super().mark_tables_current()
 
     def train_step(self, batch, next_batch=None):
         """One optimisation step of the ONE model on this rank's batch (a dict of device tensors as the Trainer builds it).
@@ -557,9 +579,10 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         owner_grads, out4 = {}, self._out4[self.t % 4]
         first = True
         if len(tabs) > 1:     # ONE flag row per step rides in the first table's exchange: it must say "overflow" for every table
+            # (bitwise OR, not a sum: every consumer tests single bits of flags[0] -- two tables overflowing in one step must not read as "none")
             f0 = next(iter(tabs.values()))["bf"]["flags"]
             for c in list(tabs.values())[1:]:
-                f0.add_(c["bf"]["flags"])
+                f0.bitwise_or_(c["bf"]["flags"])
         for name, c in tabs.items():
             ids_a, rows, ids_b, coef, vec, G = self._collect(name)
             sb, bf = c["sb"], c["bf"]

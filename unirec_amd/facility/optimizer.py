@@ -246,6 +246,7 @@ class SparseDenseAdam:
 
     def flush(self):
         """lazy_dense: apply all pending zero-gradient steps to every row (before eval / checkpoint)."""
+        ops.id_guard_check()      # (an out-of-range id of the last steps: IndexError before anything is evaluated or saved)
         self._join_tail()
         if self.table_mode != "lazy_dense" or self.t == 0:
             return

@@ -248,6 +248,25 @@ def gather_dot_loss_fwd_bwd(cfg, user_emb, item_table, item_id, label=None, user
 
 
 # --------------------------------------------------------------------------------------------- sparse rows
+_GUARD_OUT = (C.c_int64 * 3)()
+
+
+def id_guard_check():
+    """The host half of the id guard (include/unirec_amd.h: ur_id_guard_state; the reference's nn.Embedding raises IndexError for an id
+    outside its table, reco_abc.py:168-170).  A plain load of the host-mapped mirror the plan kernels write -- no synchronisation; called
+    at the head of every plan, so a bad id surfaces one or two steps after its batch.  Every step from that batch on has been skipped on
+    the device (the guard is sticky): the tables hold the state before it.  ``id_guard_reset()`` clears the guard."""
+    if lib.ur_id_guard_state(_GUARD_OUT):
+        bad, n_rows = int(_GUARD_OUT[0]), int(_GUARD_OUT[1])
+        raise IndexError(f"index {bad} is out of range for an embedding table of {n_rows} rows (unirec_amd id guard: the step that "
+                         f"looked it up and every step since were skipped on the device; unirec_amd.ops.id_guard_reset() clears the guard)")
+
+
+def id_guard_reset():
+    """clear this device's id guard (after the IndexError has been handled); synchronises the current stream"""
+    check(lib.ur_id_guard_reset(_stream()), "ur_id_guard_reset")
+
+
 class RowsPlan:
     """Result of ur_rows_plan (all device tensors; n_uniq stays on the device)."""
     __slots__ = ("n", "n_a", "uniq_idx", "seg_start", "sorted_pos", "n_uniq")
@@ -277,6 +296,7 @@ def rows_plan(ids_a, ids_b, n_rows, out=None) -> RowsPlan:
     n = n_a + n_b
     pl, ws = out if out is not None else rows_plan_alloc(n, n_a, dev)
     assert pl.n == n and pl.n_a == n_a
+    id_guard_check()      # (the verdict on EARLIER plans: this one's ids are checked on the device, in its first pass)
     check(lib.ur_rows_plan(_p(ids_a), n_a, _p(ids_b), n_b, int(n_rows), _p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos),
                            _p(pl.n_uniq), _p(ws), _stream()), "ur_rows_plan")
     return pl
@@ -316,6 +336,7 @@ def rows_plan_sharded(ids_a, ids_b, n_rows, world, out=None, want_counts=True):
     else:
         pl, ws = rows_plan_alloc(n, n_a, dev)
         counts = torch.empty(world, dtype=torch.int32, device=dev)
+    id_guard_check()
     check(lib.ur_rows_plan_sharded(_p(ids_a), n_a, _p(ids_b), n_b, int(n_rows), int(world), _p(pl.uniq_idx), _p(pl.seg_start),
                                    _p(pl.sorted_pos), _p(pl.n_uniq), _p(counts if want_counts else None), _p(ws), _stream()),
           "ur_rows_plan_sharded")
