@@ -47,9 +47,11 @@ int ur_version(void);
  * rank reports "NaN" in its step flags so that EVERY rank skips -- no extra launch, no host
  * synchronisation.  The host polls ur_id_guard_state (a plain load from a host-mapped mirror the plan
  * kernel writes) at the head of each step and raises IndexError one or two steps after the bad batch.
- * Forward-only gathers (evaluation) are unguarded in the release build; the bounds-checked build
- * (`python -m unirec_amd.build --debug-bounds`, loaded when UR_DEBUG_BOUNDS=1) checks every gathered
- * or scattered row index where it is used and traps.
+ * The gathers themselves (lookup kernels, scorer: every entry point that is given the table's row
+ * count) read the padding row 0 for an index outside the table in the release build -- a clamp, not
+ * a report: forward-only calls (evaluation) have no plan and raise nothing; the bounds-checked build
+ * (`python -m unirec_amd.build --debug-bounds`, loaded when UR_DEBUG_BOUNDS=1) prints the site of
+ * the first bad index and traps instead.
  * ur_id_guard_state: 0 = clear; 1 = raised, out3 (nullable) = {offending id, rows of the table it
  * was aimed at (saturated to 2^31 - 1), 0}.  ur_id_guard_reset clears it (synchronises `stream`). */
 int ur_id_guard_state(int64_t* host_out3);

@@ -314,7 +314,7 @@ def _second_table_overflow_worker(rank, world, port, q, both=False):
         torch.cuda.set_device(dev)
         n_users = 4001
         cfg = _cfg("MF", grad_clip_value=0.0, n_users=n_users)
-        B = 256
+        B = 128 if both else 256
         g = torch.Generator().manual_seed(17)
         mine = []
         for s_ in range(6):
@@ -323,7 +323,9 @@ def _second_table_overflow_worker(rank, world, port, q, both=False):
             uid = torch.randperm(n_users // 2 - 1, generator=g)[:B] * 2 + 2      # EVEN user ids only: every one of them lives on rank 0
             iid = torch.randint(1, N_ITEMS, (B, G), generator=g)
             if both:      # EVEN item ids only as well: both tables overflow on rank 0 in the SAME step (advisor r4: 1 + 1 = 2 read as "no overflow")
-                perm = (torch.randperm(N_ITEMS // 2 - 1, generator=g) + 1) * 2         # 1000 distinct even ids > the 831 slots planned at slack 1.25
+                # 500 distinct even ids per batch (> the 447 slots planned at slack 1.25 for 640 lookups), from alternating halves of the
+                # id range: consecutive batches share no row, so the fix-up exchange of the reference run (slack 4) stays empty
+                perm = (torch.randperm(500, generator=g) + 1 + 500 * (s_ % 2)) * 2
                 iid = torch.cat([perm, perm[: B * G - perm.numel()]]).reshape(B, G)
             b = dict(item_id=iid, label=lab, user_id=uid)
             mine.append(_to(b, dev))

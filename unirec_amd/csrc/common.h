@@ -162,7 +162,7 @@ __device__ __forceinline__ float ur_step_scale(const float* scale_dev, const int
 }
 // ---- bounds-checked build (python -m unirec_amd.build --debug-bounds -> libunirec_amd_dbg.so, loaded when UR_DEBUG_BOUNDS=1): every row
 // index a kernel gathers from or scatters to is checked where it is used; a bad one prints the site and traps (the launch fails loudly,
-// like a device-side assert).  The release build compiles the macro away.
+// like a device-side assert).  The release build clamps the index to the padding row instead (below).
 #ifdef UR_DEBUG_BOUNDS
 __device__ __forceinline__ long long ur_dbg_row(long long id, long long n, const char* file, int line) {
   if (n > 0 && (unsigned long long)id >= (unsigned long long)n) {   // (n <= 0: the caller did not say how many rows the table has)
@@ -173,7 +173,12 @@ __device__ __forceinline__ long long ur_dbg_row(long long id, long long n, const
 }
 #define UR_ROW(id, n) ::ur::ur_dbg_row((long long)(id), (long long)(n), __FILE__, __LINE__)
 #else
-#define UR_ROW(id, n) (id)
+// release build: an index outside the table reads the padding row 0 instead (one compare + select per id; a gather at row -1 of a table
+// that starts its allocation is a page fault, i.e. an aborted process, long before the host gets to raise the guard's IndexError)
+__device__ __forceinline__ long long ur_clamp_row(long long id, long long n) {
+  return (n > 0 && (unsigned long long)id >= (unsigned long long)n) ? 0 : id;
+}
+#define UR_ROW(id, n) ::ur::ur_clamp_row((long long)(id), (long long)(n))
 #endif
 
 

@@ -630,12 +630,12 @@ __device__ __forceinline__ void tn_big_run(const TnBigCtx& c, float* smem, float
       }
       if (ACT != UR_ACT_NONE) { b0 = act_fwd(b0, ACT); b1 = act_fwd(b1, ACT); }
       bs0 += a0; bs1 += a1;
-      __builtin_amdgcn_sched_barrier(0);
+      if (ACT == UR_ACT_NONE) __builtin_amdgcn_sched_barrier(0);   // (with an activation the scheduler spreads its VALU over the MFMAs itself)
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      if (ACT == UR_ACT_NONE) __builtin_amdgcn_sched_barrier(0);
       a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
     }
     if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -645,15 +645,18 @@ __device__ __forceinline__ void tn_big_run(const TnBigCtx& c, float* smem, float
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_big_kernel(TnGroup g, const float* __restrict__ zero_row) {
+__global__ __launch_bounds__(256) void gemm_tn_big_kernel(TnGroup g, const float* __restrict__ zero_row, int total, int per_xcd) {
+  // Workgroup order w = product-major, then token split, then tile: the tiles of one (product, split) -- which share the split's token
+  // rows of one operand -- are neighbours.  XCD x (= blockIdx % 8) takes the CHUNK w in [x * per_xcd, (x + 1) * per_xcd): the chip holds
+  // one such workgroup per CU, so every XCD must get the same number of them (the first version put split sp on XCD sp % 8: with 21
+  // splits of 12 tiles five XCDs had 36 workgroups for 32 CUs and ran two rounds -- profiles/r05_a_tn_big_insitu_v2.txt)
+  const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || w >= total) return;
   int j = 0;
-  while (j + 1 < g.n && (int)blockIdx.x >= g.item[j + 1].first_block) ++j;
+  while (j + 1 < g.n && w >= g.item[j + 1].first_block) ++j;
   const TnItem& it = g.item[j];
-  const int local = blockIdx.x - it.first_block, ntiles = it.ntr * it.ntc, S = it.S;
-  // all tiles of a token split on one XCD (workgroup n runs on XCD n % 8; first_block % 8 == 0): the split's token rows enter one L2
-  const int xcd = local & 7, qid = local >> 3;
-  const int sp = (qid / ntiles) * 8 + xcd, tile = qid % ntiles;
-  if (sp >= S) return;
+  const int local = w - it.first_block, ntiles = it.ntr * it.ntc, S = it.S;
+  const int sp = local / ntiles, tile = local % ntiles;
   int T = it.T;
   if (it.t_dev) T = min(T, *it.t_dev);
   const int tps = (((T + S - 1) / S + BTK - 1) / BTK) * BTK;
@@ -783,7 +786,7 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
     TnItem& it = g.item[i];
     int S = (int)(q.T / rows_per + 0.5);
     if (S > q.T / (2 * stage)) S = q.T / (2 * stage);
-    if (big) S = std::min(TN_GROUP_SMAX, S);   // (any S: split sp sits on XCD sp % 8, the slots behind S exit)
+    if (big) S = std::min(TN_GROUP_SMAX, S);   // (any S: the launch order is cut into eight equal XCD chunks)
     else if (S >= 6) S = std::min(TN_GROUP_SMAX, (S + 4) / 8 * 8);
     if (S < 1) S = 1;
     it.P = q.P; it.Q = q.Q; it.ldp = q.ldp; it.ldq = q.ldq; it.T = q.T; it.t_dev = q.t_dev; it.R = q.R; it.Cc = q.Cc;
@@ -791,7 +794,7 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
     it.out = q.out; it.bias_out = q.bias_out; it.ldo = q.ldo;
     it.part = q.ws; it.bias_part = q.bias_out ? q.ws + (long long)S * q.R * q.Cc : nullptr;
     it.first_block = blocks;
-    if (big) blocks += 8 * cdiv(S, 8) * it.ntr * it.ntc;   // (split sp on XCD sp % 8; slots sp >= S exit)
+    if (big) blocks += S * it.ntr * it.ntc;   // (first_block = the product's first workgroup in the launch order; XCD chunks: see the kernel)
     else blocks += (S & 7) == 0 ? S * it.ntr * it.ntc : 8 * cdiv(S * it.ntr * it.ntc, 8);   // (every product starts on XCD 0)
   }
   {
@@ -800,7 +803,8 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
       constexpr int lds = BTB * 2 * BTK * BT * (int)sizeof(float);
       static const bool attr = (hipFuncSetAttribute((const void*)gemm_tn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
       (void)attr;
-      UR_LAUNCH_EV(gemm_tn_big_kernel, dim3(blocks), dim3(256), lds, st, g, zeros);
+      const int per_xcd = cdiv(blocks, 8);
+      UR_LAUNCH_EV(gemm_tn_big_kernel, dim3(8 * per_xcd), dim3(256), lds, st, g, zeros, blocks, per_xcd);
     }
     else { UR_LAUNCH_EV(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g, zeros); }
   }
