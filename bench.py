@@ -78,6 +78,9 @@ def parse():
                     "dominant kernel class and its roofline fraction each) into the same JSON line")
     ap.add_argument("--sharded-w1", action="store_true", help="--gpus 1 only: step through the multi-GPU code path (facility/distributed.py, "
                     "fixed-capacity row exchange with world = 1, collectives degenerate) instead of the plain optimizer: its overhead")
+    ap.add_argument("--worker", action="store_true", help="(internal) world > 1: this process IS the benchmark; without it the process the "
+                    "launcher started supervises a --worker child per rung of the fallback ladder (tools/bench_ladder.py)")
+    ap.add_argument("--dry-worker", action="store_true", help="(test aid) the worker walks the phases over gloo with no GPU work")
     ap.add_argument("--no-selfcheck", action="store_true", help="world > 1: skip the W-rank == 1-rank check that runs before the timed region")
     ap.add_argument("--selfcheck-items", type=int, default=1_000_000)
     ap.add_argument("--skip-padding", type=int, default=1, help="0: the encoder carries the padded [B * L] rows (per-sequence layout) instead of "
@@ -619,6 +622,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_ladder
+    if world > 1 and not a.worker:
+        # the launcher's process supervises: the benchmark itself runs in a child per rung of the fallback ladder, under a per-phase
+        # watchdog -- a hung collective ends in a JSON line with "hang", never in silence (tools/bench_ladder.py)
+        raise SystemExit(bench_ladder.supervise(os.path.abspath(__file__), [x for x in sys.argv[1:] if x != "--worker"], rank, world))
+    if a.dry_worker:
+        return bench_ladder.dry_worker(sys.argv[1:])
+    phase = bench_ladder.phase
+    phase("init")
     if os.environ.get("UR_BENCH_SHARE_DEVICE") == "1":   # debugging aid only: several ranks on one GPU (1-GPU dev boxes)
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -642,6 +655,7 @@ def main():
     # ~150 GB of device fills, and the warm-up steps then start on a device that has just been busy.  A device left idle for tens of
     # milliseconds runs the next 20-60 steps 2-5 % slower (tools/warm_probe.py: IDLE_MS = 5 / 50 / 500 in front of a 20-step region:
     # +0.01 / +0.035 / +0.07 ms per step); ~30 batches of a dozen tiny launches each are such a gap.
+    phase("setup")
     batches = make_batches()
     torch.manual_seed(2022 + rank)
     cfg = model_config(a, str(device))
@@ -651,6 +665,7 @@ def main():
         from unirec_amd.facility.distributed import ShardedSparseDenseAdam
         from unirec_amd.sharded import shard_rows
         if world > 1 and not a.no_selfcheck:
+            phase("selfcheck")
             try:
                 selfcheck = multi_gpu_selfcheck(a, device, rank, world)
             except AssertionError as e:      # a parity failure is reported in the line (and on stderr), the timing still runs
@@ -658,13 +673,15 @@ def main():
                 print(f"[bench] rank {rank}: multi-GPU self-check FAILED: {e}", file=sys.stderr)
                 import torch.distributed as dist
                 dist.barrier()
+        phase("setup")
         torch.manual_seed(2022 + rank)
         model = SASRec(dict(cfg, n_items=shard_rows(a.n_items, world)))     # the model's table IS this rank's shard: the 100 M-row
         opt = ShardedSparseDenseAdam(model, rank, world, lr=1e-3, table_mode=a.table_mode,   # table never exists in one piece
                                      full_rows={"item_embedding": a.n_items})
         model.train()
         info = {"parallelism": f"dp{world} + embedding rows sharded {world}-way (3 fixed-capacity all-to-alls + 1 flat all-reduce per step; "
-                               f"transport: {'library RCCL communicators' if opt._native else 'torch.distributed' if world > 1 else 'none (world 1)'})"}
+                               f"transport: {'library RCCL communicators' if opt._native else 'torch.distributed' if world > 1 else 'none (world 1)'}"
+                               f"{'; ladder rung: ' + os.environ['UR_BENCH_RUNG'] if os.environ.get('UR_BENCH_RUNG') else ''})"}
 
         def step_fn(batch, nxt=None):
             return opt.train_step(batch, None if a.no_prefetch else nxt)
@@ -724,6 +741,7 @@ def main():
     # pipeline fill and drain -- the side stream's tail of the last step has no next step to hide under -- ~0.15 ms per region, and a
     # slow ramp over the first ~20 steps after any synchronisation: 20 steps after 5 warm-ups 0.615-0.62 ms, after 50 warm-ups 0.60-0.61,
     # 200 steps 0.596.)
+    phase("warmup")
     n_tail = min(2, a.warmup // 2)
     n_first = (a.warmup - n_tail) // 2
     n_prof = a.warmup - n_tail - n_first
@@ -748,6 +766,7 @@ def main():
         _lib.lib.ur_prof_set_mask(1 << names.index(dom))
     for i in range(n_first + n_prof, a.warmup):     # the last warm-up steps: plain, no read-back behind them
         loss = step_fn(batches[i % len(batches)], batches[(i + 1) % len(batches)])
+    phase("timed")
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -759,6 +778,7 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     _lib.lib.ur_prof_enable(0)
+    phase("post")
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -806,6 +826,9 @@ def main():
             collectives = {k: {"ms_per_step": round(v["ms"] / 10, 4), "MB_to_peers_per_step": round(v["MB_to_peers"] / 10, 3),
                                "calls_per_step": v["calls"] / 10, "route": "torch.distributed"} for k, v in prof.items()}
     if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()      # (every rank's worker ends together: rank 0 prints its line in front of this barrier's counterpart below)
         return
 
     B, L, G, d = a.batch, a.seq_len, a.negatives + 1, a.d
@@ -926,7 +949,10 @@ def main():
         out["other_configs"]["C3"]["e2e"] = c3_e2e_leg(device)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,70 @@
+"""bench.py --gpus N cannot return nothing: the process the launcher starts supervises a worker per rung of the
+fallback ladder under a per-phase watchdog (tools/bench_ladder.py).  Here the supervisor logic runs on the CPU box: two ranks started the
+way the driver starts them (``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2``), ``--dry-worker`` workers that
+walk the phases over gloo, a hang / a dead rank injected by environment.  The GPU version (real workers, two ranks sharing the one GPU
+over gloo) is the ``-m gpu`` test at the bottom."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(extra_env, extra_args=("--dry-worker",), world=2, timeout=240):
+    env = dict(os.environ, UR_BENCH_TIMEOUT_SCALE="0.05", **extra_env)      # limits of 12-30 s instead of minutes
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "2", *extra_args]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+def test_a_clean_run_takes_the_first_rung():
+    j = _launch({})
+    assert j["value"] == 1.0 and j["config"]["rung"] == "native-2comm-prefetch"
+    assert j["ladder"] == [{"rung": "native-2comm-prefetch", "ok": True}]
+
+
+def test_a_rank_that_hangs_mid_step_moves_everyone_down_the_ladder():
+    """rank 1 never arrives at the timed region's collective on rungs 0 and 1: the watchdog aborts the rank group twice, rung 2 completes"""
+    j = _launch({"UR_BENCH_TEST_HANG": "1:timed:0,1"})
+    assert [e["ok"] for e in j["ladder"]] == [False, False, True], j["ladder"]
+    assert j["config"]["rung"] == "native-1comm-1stream" and j["value"] == 1.0
+    assert "timed" in json.dumps(j["ladder"][0]["failed"])          # which phase hung, and on which rank
+    assert "1" in j["ladder"][0]["failed"]
+
+
+def test_a_rank_that_dies_on_every_rung_still_yields_a_line_with_hang():
+    j = _launch({"UR_BENCH_TEST_KILL": "1:warmup:0,1,2,3"})
+    assert [e["ok"] for e in j["ladder"]] == [False] * 4
+    assert j["value"] == 0.0 and j["hang"] == "warmup" and j["config"]["rung"] is None and j["n_gpus"] == 2
+
+
+def test_a_hang_on_every_rung_still_yields_a_line_with_hang():
+    j = _launch({"UR_BENCH_TEST_HANG": "0:selfcheck:0,1,2,3"}, timeout=400)
+    assert j["value"] == 0.0 and j["hang"] == "selfcheck" and len(j["ladder"]) == 4
+
+
+@pytest.mark.gpu
+def test_real_workers_walk_the_ladder_on_one_gpu():
+    """the real benchmark workers, two ranks sharing cuda:0 over gloo (UR_BENCH_SHARE_DEVICE: RCCL refuses two ranks on one device): rank 1
+    hangs in the warm-up of rung 0, rung 1 (rows inside the step) completes and reports a real measurement"""
+    env = {"UR_BENCH_TEST_HANG": "1:warmup:0", "UR_BENCH_SHARE_DEVICE": "1", "UR_BENCH_BACKEND": "gloo", "UR_BENCH_TIMEOUT_SCALE": "0.25"}
+    j = _launch(env, extra_args=("--n-items", "200000", "--selfcheck-items", "20000", "--no-extra-legs", "--no-cpu-baseline"), timeout=900)
+    assert [e["ok"] for e in j["ladder"]] == [False, True], j["ladder"]
+    assert j["config"]["rung"] == "native-2comm" and j["value"] > 0 and j["n_ranks"] == 2 and j["selfcheck"]["ok"]

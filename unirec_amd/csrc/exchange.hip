@@ -213,7 +213,9 @@ Rccl* rccl() {
 }
 // two communicators: [0] the row exchanges (plan stream / caller's stream), [1] the dense all-reduce (the encoder's side stream) --
 // operations on ONE communicator are serialised in issue order, and the all-reduce of step t must not hold up the rows of step t + 1
-struct Comm { ncclComm_t comm = nullptr, comm2 = nullptr; int rank = 0, world = 0; };
+// UR_COMM_SINGLE=1 (read at ur_comm_init; the conservative rung of bench.py's fallback ladder): comm2 IS comm -- every collective of the
+// process goes through one communicator in issue order (the caller then keeps them on one stream: UR_DENSE_SIDE=0, no lookahead)
+struct Comm { ncclComm_t comm = nullptr, comm2 = nullptr; int rank = 0, world = 0; bool single = false; };
 Comm g_comm;
 }  // namespace
 
@@ -267,7 +269,9 @@ extern "C" int ur_comm_init(const void* id, int32_t rank, int32_t world) {
   ncclUniqueId uid[2];
   memcpy(uid, id, sizeof(uid));
   UR_NCCL(rccl()->CommInitRank(&g_comm.comm, world, uid[0], rank));
-  UR_NCCL(rccl()->CommInitRank(&g_comm.comm2, world, uid[1], rank));
+  g_comm.single = getenv("UR_COMM_SINGLE") && atoi(getenv("UR_COMM_SINGLE")) != 0;
+  if (g_comm.single) g_comm.comm2 = g_comm.comm;
+  else UR_NCCL(rccl()->CommInitRank(&g_comm.comm2, world, uid[1], rank));
   g_comm.rank = rank;
   g_comm.world = world;
   return UR_OK;
@@ -278,7 +282,7 @@ extern "C" int ur_comm_world(void) { return !rccl()->ok ? -1 : (g_comm.comm ? g_
 extern "C" int ur_comm_destroy(void) {
   if (g_comm.comm) {
     UR_NCCL(rccl()->CommDestroy(g_comm.comm));
-    if (g_comm.comm2) UR_NCCL(rccl()->CommDestroy(g_comm.comm2));
+    if (g_comm.comm2 && !g_comm.single) UR_NCCL(rccl()->CommDestroy(g_comm.comm2));
     g_comm = Comm{};
   }
   return UR_OK;

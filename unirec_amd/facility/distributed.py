@@ -181,6 +181,10 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         # rows of the next batch fetched a step ahead (_prefetch_rows); UR_PREFETCH_ROWS=0: in the step itself (rounds 1-3).  Not with
         # fullsoftmax: its dense update moves every row of the item shard in every step
         self._riders = os.environ.get("UR_REDUCE_RIDERS", "1") not in ("", "0")    # flag rows / step flags inside the reduce launches
+        # UR_DENSE_SIDE=0 (rung "native-1comm-1stream" of bench.py's fallback ladder): the dense half -- all-reduce + update -- on the main
+        # stream behind the encoder's reductions, as with gradient clipping; with UR_COMM_SINGLE=1 every collective of a step then goes
+        # through ONE communicator on ONE stream, in program order: the shape of the reference's own DDP step
+        self._dense_on_side = os.environ.get("UR_DENSE_SIDE", "1") not in ("", "0")
         self.prefetch_rows = os.environ.get("UR_PREFETCH_ROWS", "1") not in ("", "0") and model.loss_type != "fullsoftmax"
         self._fs_dgrad = None
         if model.loss_type == "fullsoftmax":
@@ -635,7 +639,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             self._update_rows(cfg, tabs, owner_grads, dense_shard, scale)
             self._catchup_next()
             g = getattr(model, "_deferred_dense_grad", None)
-            if g is not None and g.numel() and not self.extra and not bias_ctx:
+            if g is not None and g.numel() and not self.extra and not bias_ctx and self._dense_on_side:
                 side = ops.sasrec_side_stream()
             if side is not None:
                 # the dense half behind the encoder's own reductions on ITS stream: all-reduce (second communicator) + update; the next
