@@ -42,13 +42,6 @@ def test_inline_weight_gradients():
     _run({"UR_SASREC_SIDE": "0"}, [os.path.join(HERE, "test_gpu_parity.py"), "-k", "golden"], expect_min_passed=20)
 
 
-def test_weight_gradients_on_64x64_tiles():
-    """UR_TN_BIG=0: the 64 x 64 register-staged weight-gradient kernel (what shapes with R or Cc not a multiple of 128 take anyway) at the
-    d = 128-class shapes the 128 x 128 LDS-DMA kernel serves by default"""
-    _run({"UR_TN_BIG": "0"}, [os.path.join(HERE, "test_gemm_gpu.py"), os.path.join(HERE, "test_gpu_parity.py"), "-k", "gemm_tn or larger_random"],
-         expect_min_passed=20)
-
-
 def test_multi_launch_id_sort():
     """UR_PLAN_MULTI=1: the multi-launch radix sort (the path of batches with more than 32 768 ids) at the small test shapes"""
     _run({"UR_PLAN_MULTI": "1"}, [os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_sharded.py"), "-k", "rows_plan or golden or world1"],

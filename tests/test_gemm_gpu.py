@@ -105,8 +105,9 @@ _ACTS = {0: lambda x: 0.5 * x * (1 + torch.erf(x * 0.7071067811865476)), 1: torc
 @pytest.mark.parametrize("R,Cc_", [(128, 128), (256, 128), (128, 512), (512, 128), (384, 128)])
 @pytest.mark.parametrize("act", [-1, 0, 1, 2, 3, 4])
 def test_gemm_tn_128_tile_shapes(T, R, Cc_, act):
-    """Shapes whose R and Cc are multiples of 128 take the 128 x 128 LDS-DMA kernel (round 5): every activation on the Q operand, token
-    counts around the 32-token stage and the split boundaries, strided operands."""
+    """The d = 128-class weight-gradient shapes (R, Cc multiples of 128): every activation on the Q operand, token counts around the
+    32-token stage and the split boundaries, strided operands.  (Written for round 5's 128 x 128 LDS-DMA variant of the kernel --
+    profiles/r05_a_tn_big_counterexample.txt: measured, slower in situ, taken out -- and kept for the shipped 64 x 64 kernel.)"""
     from unirec_amd._lib import check, lib
     if act >= 0 and (T, R) not in ((33, 128), (1000, 128), (21248, 128), (4097, 256)):
         pytest.skip("activations: a subset of the shapes")
