@@ -377,6 +377,24 @@ int ur_shard_step_flags(const float* grads_in, int32_t world, int32_t cap, int32
  * rank 0 and handed to every rank's ur_comm_init by the host (a broadcast over its process group).  ur_comm_all_reduce_sum: in place,
  * fp32 -- the flat dense-gradient all-reduce of the step (what DDP's bucketed all-reduce does, trainer.py:346), on `stream`. */
 int ur_comm_world(void);
+/* ---- in-process loopback transport (test / measurement infrastructure of the multi-GPU step on a 1-GPU box; csrc/exchange.hip has the
+ * protocol): W rank contexts in ONE process on one device.  A rank is the THREAD that called ur_loop_attach(group, rank): from then on its
+ * per-context library state (the encoder's side stream and events, hand-off counters) is its own.  A collective is ur_loop_post ->
+ * [host rendezvous of the rank threads] -> ur_loop_all_to_all_pull | ur_loop_all_reduce_pull -> [host rendezvous] -> ur_loop_finish, all
+ * non-blocking and stream-ordered (cross-rank events; no device-host synchronisation).  comm = 0 / 1: the two communicators of the real
+ * transport -- operations of one index run in issue order, as RCCL's do.  ur_loop_finish(all_reduce_out != NULL, n): the summed buffer is
+ * copied in place.  The reference's counterpart: a 2-process NCCL run (tests/test_model/run_ddp_test.sh:28-86). */
+void* ur_loop_create(int32_t world);
+int ur_loop_destroy(void* group);
+int ur_loop_attach(void* group, int32_t rank);
+int ur_loop_detach(void);
+int ur_loop_world(void);
+int ur_loop_post(const void* send, int32_t comm, void* stream);
+int ur_loop_all_to_all_pull(void* recv, int64_t bytes_per_peer, int32_t kind, void* stream);
+int ur_loop_all_reduce_pull(int64_t n, void* stream);
+int ur_loop_finish(int32_t comm, float* all_reduce_out, int64_t n, void* stream);
+/* test aid: a kernel that spins for `us` microseconds on `stream` (skews one stream of a schedule against the others) */
+int ur_debug_delay(int32_t us, void* stream);
 int ur_comm_unique_id(void* id_out256);
 int ur_comm_init(const void* id256, int32_t rank, int32_t world);
 int ur_comm_destroy(void);

@@ -127,7 +127,7 @@ def test_dense_half_on_the_side_stream_is_bit_identical():
             if k in (0, 5):   # read through the public surface right after step(): must be the UPDATED parameters
                 snaps.append(copy.deepcopy({n: t.clone() for n, t in model.state_dict().items()}))
         torch.cuda.synchronize()
-        assert not ops._side_hold or mode == "late"       # ("per-call": the last step() joined itself)
+        assert not ops._side.hold or mode == "late"       # ("per-call": the last step() joined itself)
         return ([float(x) for x in losses], model.dense_flat.data.clone(), opt.dense_m.clone(), opt.dense_v.clone(),
                 model.item_embedding.weight.data.clone(), snaps)
 

@@ -88,6 +88,24 @@ def _to(b, dev, lo=None, hi=None):
     return {k: v[lo:hi].to(dev).contiguous() for k, v in b.items()}
 
 
+class _TdComm:
+    """how a parity body talks to its peers: torch.distributed's default group here, a pgroup.LoopbackGroup in tests/test_loopback_gpu.py"""
+    accelerator = None
+
+    @staticmethod
+    def barrier():
+        dist.barrier()
+
+    @staticmethod
+    def all_gather_object(box, obj):
+        dist.all_gather_object(box, obj)
+
+    @staticmethod
+    def exclusive():
+        import contextlib
+        return contextlib.nullcontext()      # (one process per rank: nothing is shared)
+
+
 def _worker(rank, world, port, q, kind, tmp, clip=0.05, loss=None):
     if loss == "serial-rows":       # the row exchange inside the step (rounds 1-3) instead of a step ahead + fix-up
         os.environ["UR_PREFETCH_ROWS"] = "0"
@@ -96,89 +114,98 @@ def _worker(rank, world, port, q, kind, tmp, clip=0.05, loss=None):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from unirec_amd.facility.trainer import Trainer
-        from unirec_amd.utils.general import get_class_instance, init_seed
-        dev = torch.device("cuda:0")
-        torch.cuda.set_device(dev)
-        cfg = _cfg(kind, output_path=tmp, grad_clip_value=clip, **({"loss_type": loss} if loss else {}))
-        B = 16
-        full = _batches(4, B * world)
-        ev = _batches(2, B * world, seed=9)
-        single = types.SimpleNamespace(process_index=0, num_processes=1)      # forces the 1-GPU path although a group exists
-        ref = {}
-        if rank == 0:      # ---- the reference run: ONE rank on the concatenated batches
-            init_seed(cfg["seed"])
-            m1 = get_class_instance(kind, "unirec_amd/model")(cfg)
-            t1 = Trainer(cfg, m1, single)
-            assert t1.world == 1
-            t1.fit([_to(b, dev) for b in full[:2]], save_model=False)
-            t1.save_model(os.path.join(tmp, "w1.pth"))
-            ref["eval_k"] = t1.evaluate([_to(b, dev) for b in ev], load_best_model=False)
-            if kind != "MF":
-                t1.reset_evaluator("user-item", "one_vs_all")
-                ref["eval_all"] = t1.evaluate([_to(b, dev) for b in ev], load_best_model=False)
-                t1.reset_evaluator("user-item", None)
-            t1.fit([_to(b, dev) for b in full[2:]], save_model=False)
-            t1.optimizer.flush()
-            ref["losses"] = list(t1.step_losses)
-            ref["state"] = {k: v.detach().cpu().clone() for k, v in m1.state_dict().items()}
-        dist.barrier()
-        # ---- W ranks, each on its slice
-        init_seed(cfg["seed"])
-        m = get_class_instance(kind, "unirec_amd/model")(cfg)
-        tr = Trainer(cfg, m)
-        assert tr.world == world and type(tr.optimizer).__name__ == "ShardedSparseDenseAdam"
-        assert m.item_embedding.weight.shape[0] < N_ITEMS                       # the model holds a shard, not the table
-        mine = lambda bs: [_to(b, dev, rank * B, (rank + 1) * B) for b in bs]   # noqa: E731
-        tr.fit(mine(full[:2]), save_model=False)
-        tr.save_model(os.path.join(tmp, "ww.pth"))                              # collective: shards streamed to rank 0
-        got_k = tr.evaluate(mine(ev), load_best_model=False)
-        got_all = None
-        if kind != "MF":
-            tr.reset_evaluator("user-item", "one_vs_all")
-            got_all = tr.evaluate(mine(ev), load_best_model=False)
-            tr.reset_evaluator("user-item", None)
-        tr.load_model(os.path.join(tmp, "w1.pth"))                              # a 1-rank checkpoint dealt out to W ranks
-        tr.fit(mine(full[2:]), save_model=False)
-        losses = [None] * world
-        dist.all_gather_object(losses, list(tr.step_losses))
-        sd = tr.optimizer.gather_state_dict()
-        if rank == 0:
-            # every rank returns the SAME value: the mean over the ranks (trainer.py:353 gather_for_metrics(loss).mean())
-            assert all(np.array_equal(np.asarray(losses[0]), np.asarray(x)) for x in losses[1:])
-            rel = np.abs(np.asarray(losses[0]) - np.asarray(ref["losses"])) / np.abs(np.asarray(ref["losses"]))
-            assert rel[0] <= LOSS_RTOL_FIRST and rel.max() <= LOSS_RTOL, (rel.tolist(), losses[0], ref["losses"])
-            for k, v in ref["state"].items():
-                if k.endswith("key.bias"):
-                    continue
-                np.testing.assert_allclose(sd[k].numpy(), v.numpy(), rtol=1e-4, atol=2e-5, err_msg=k)   # atol = 1% of an lr-sized step
-            # the checkpoint written by W ranks holds FULL tables under the reference's names, equal to the 1-rank one
-            c1 = torch.load(os.path.join(tmp, "w1.pth"), map_location="cpu", weights_only=False)["state_dict"]
-            cw = torch.load(os.path.join(tmp, "ww.pth"), map_location="cpu", weights_only=False)["state_dict"]
-            assert set(c1) == set(cw)
-            for k in c1:
-                assert tuple(c1[k].shape) == tuple(cw[k].shape), k
-                if not k.endswith("key.bias"):
-                    np.testing.assert_allclose(cw[k].numpy(), c1[k].numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
-            # ... and loads into ONE rank
-            init_seed(cfg["seed"] + 1)
-            m2 = get_class_instance(kind, "unirec_amd/model")(cfg)
-            t2 = Trainer(cfg, m2, single)
-            t2.load_model(os.path.join(tmp, "ww.pth"))
-            for k, v in m2.state_dict().items():
-                assert torch.equal(v.detach().cpu(), cw[k]), k
-            # evaluation over the sharded tables == over the full ones
-            for key in ("hit@1", "hit@5", "ndcg@10", "mrr", "group_auc"):
-                assert abs(got_k[key] - ref["eval_k"][key]) < 2e-3, (key, got_k[key], ref["eval_k"][key])
-                if got_all is not None:
-                    assert abs(got_all[key] - ref["eval_all"][key]) < 2e-3, (key, got_all[key], ref["eval_all"][key])
-        dist.barrier()
+        _parity_body(rank, world, kind, tmp, clip, loss, _TdComm)
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
         q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
     finally:
         dist.destroy_process_group()
+
+
+def _parity_body(rank, world, kind, tmp, clip, loss, comm, tweak=None):
+    """W ranks x batch B == 1 rank x the concatenated batch, through Trainer.fit / evaluate / checkpoints (module docstring).
+    comm: the peers (barrier, all_gather_object, the `accelerator` Trainer gets); tweak(optimizer): test hooks on the W-rank optimizer"""
+    from unirec_amd.facility.trainer import Trainer
+    from unirec_amd.utils.general import get_class_instance, init_seed
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    cfg = _cfg(kind, output_path=tmp, grad_clip_value=clip, **({"loss_type": loss} if loss else {}))
+    B = 16
+    full = _batches(4, B * world)
+    ev = _batches(2, B * world, seed=9)
+    single = types.SimpleNamespace(process_index=0, num_processes=1)      # forces the 1-GPU path although a group exists
+    ref = {}
+    if rank == 0:      # ---- the reference run: ONE rank on the concatenated batches
+        init_seed(cfg["seed"])
+        m1 = get_class_instance(kind, "unirec_amd/model")(cfg)
+        t1 = Trainer(cfg, m1, single)
+        assert t1.world == 1
+        t1.fit([_to(b, dev) for b in full[:2]], save_model=False)
+        t1.save_model(os.path.join(tmp, "w1.pth"))
+        ref["eval_k"] = t1.evaluate([_to(b, dev) for b in ev], load_best_model=False)
+        if kind != "MF":
+            t1.reset_evaluator("user-item", "one_vs_all")
+            ref["eval_all"] = t1.evaluate([_to(b, dev) for b in ev], load_best_model=False)
+            t1.reset_evaluator("user-item", None)
+        t1.fit([_to(b, dev) for b in full[2:]], save_model=False)
+        t1.optimizer.flush()
+        ref["losses"] = list(t1.step_losses)
+        ref["state"] = {k: v.detach().cpu().clone() for k, v in m1.state_dict().items()}
+    comm.barrier()
+    # ---- W ranks, each on its slice
+    with comm.exclusive():      # (rank THREADS share the device's random generator: seed + parameter initialisation one rank at a time)
+        init_seed(cfg["seed"])
+        m = get_class_instance(kind, "unirec_amd/model")(cfg)
+    tr = Trainer(cfg, m, comm.accelerator)
+    if tweak is not None:
+        tweak(tr.optimizer)
+    assert tr.world == world and type(tr.optimizer).__name__ == "ShardedSparseDenseAdam"
+    assert m.item_embedding.weight.shape[0] < N_ITEMS                       # the model holds a shard, not the table
+    mine = lambda bs: [_to(b, dev, rank * B, (rank + 1) * B) for b in bs]   # noqa: E731
+    tr.fit(mine(full[:2]), save_model=False)
+    tr.save_model(os.path.join(tmp, "ww.pth"))                              # collective: shards streamed to rank 0
+    got_k = tr.evaluate(mine(ev), load_best_model=False)
+    got_all = None
+    if kind != "MF":
+        tr.reset_evaluator("user-item", "one_vs_all")
+        got_all = tr.evaluate(mine(ev), load_best_model=False)
+        tr.reset_evaluator("user-item", None)
+    tr.load_model(os.path.join(tmp, "w1.pth"))                              # a 1-rank checkpoint dealt out to W ranks
+    tr.fit(mine(full[2:]), save_model=False)
+    losses = [None] * world
+    comm.all_gather_object(losses, list(tr.step_losses))
+    sd = tr.optimizer.gather_state_dict()
+    if rank == 0:
+        # every rank returns the SAME value: the mean over the ranks (trainer.py:353 gather_for_metrics(loss).mean())
+        assert all(np.array_equal(np.asarray(losses[0]), np.asarray(x)) for x in losses[1:])
+        rel = np.abs(np.asarray(losses[0]) - np.asarray(ref["losses"])) / np.abs(np.asarray(ref["losses"]))
+        assert rel[0] <= LOSS_RTOL_FIRST and rel.max() <= LOSS_RTOL, (rel.tolist(), losses[0], ref["losses"])
+        for k, v in ref["state"].items():
+            if k.endswith("key.bias"):
+                continue
+            np.testing.assert_allclose(sd[k].numpy(), v.numpy(), rtol=1e-4, atol=2e-5, err_msg=k)   # atol = 1% of an lr-sized step
+        # the checkpoint written by W ranks holds FULL tables under the reference's names, equal to the 1-rank one
+        c1 = torch.load(os.path.join(tmp, "w1.pth"), map_location="cpu", weights_only=False)["state_dict"]
+        cw = torch.load(os.path.join(tmp, "ww.pth"), map_location="cpu", weights_only=False)["state_dict"]
+        assert set(c1) == set(cw)
+        for k in c1:
+            assert tuple(c1[k].shape) == tuple(cw[k].shape), k
+            if not k.endswith("key.bias"):
+                np.testing.assert_allclose(cw[k].numpy(), c1[k].numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+        # ... and loads into ONE rank
+        init_seed(cfg["seed"] + 1)
+        m2 = get_class_instance(kind, "unirec_amd/model")(cfg)
+        t2 = Trainer(cfg, m2, single)
+        t2.load_model(os.path.join(tmp, "ww.pth"))
+        for k, v in m2.state_dict().items():
+            assert torch.equal(v.detach().cpu(), cw[k]), k
+        # evaluation over the sharded tables == over the full ones
+        for key in ("hit@1", "hit@5", "ndcg@10", "mrr", "group_auc"):
+            assert abs(got_k[key] - ref["eval_k"][key]) < 2e-3, (key, got_k[key], ref["eval_k"][key])
+            if got_all is not None:
+                assert abs(got_all[key] - ref["eval_all"][key]) < 2e-3, (key, got_all[key], ref["eval_all"][key])
+    comm.barrier()
 
 
 @pytest.mark.gpu

@@ -1,0 +1,181 @@
+"""The multi-GPU step at W = 2 / 4 / 8 with REAL stream concurrency on one GPU (VERDICT r4 "missing" 2): W rank threads of one process,
+each with its own model shard, optimizer and three streams, exchanging through the library's loopback transport (pgroup.LoopbackGroup ->
+ur_loop_*: stream-ordered device copies behind cross-rank events, no device-host synchronisation).  The gloo tests of
+test_distributed_trainer.py stage every block through the host and so serialise exactly what is under test here: the plan-stream
+prefetch, the hot / cold split and the fix-up exchange racing the main stream, the side-stream all-reduce, the overflow replay.
+
+Same parity bodies as the gloo tests (W ranks x batch B == 1 rank x the concatenated batch, Trainer.fit / evaluate / checkpoints), plus a
+400 us spin on one rank's plan stream, and the raw collectives against a host statement."""
+import contextlib
+import os
+import threading
+import traceback
+
+import numpy as np
+import pytest
+import torch
+
+from test_distributed_trainer import N_ITEMS, _batches, _cfg, _parity_body, _to
+
+pytestmark = pytest.mark.gpu
+
+
+class _LoopComm:
+    """the peers of a parity body = the rank threads of a LoopbackGroup"""
+
+    def __init__(self, group):
+        self.accelerator = group
+        self._lock = threading.Lock()
+
+    def barrier(self):
+        self.accelerator.barrier()
+
+    def all_gather_object(self, box, obj):
+        self.accelerator.all_gather_object(box, obj)
+
+    @contextlib.contextmanager
+    def exclusive(self):
+        with self._lock:
+            yield
+            torch.cuda.synchronize()
+
+
+def _run_ranks(world, fn, timeout=900):
+    """fn(rank, group, comm) on W rank threads; the first failure aborts the group (peers waiting at a rendezvous raise) and is re-raised"""
+    from unirec_amd.pgroup import LoopbackGroup
+    group = LoopbackGroup(world)
+    comm = _LoopComm(group)
+    errs = [None] * world
+
+    def body(r):
+        try:
+            torch.cuda.set_device(0)
+            group.attach(r)
+            fn(r, group, comm)
+            torch.cuda.synchronize()
+        except BaseException:   # noqa: BLE001
+            errs[r] = traceback.format_exc()
+            group.abort()
+        finally:
+            try:
+                group.detach()
+            except Exception:   # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=body, args=(r,), name=f"rank{r}") for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout)
+    alive = [t.name for t in threads if t.is_alive()]
+    first = next((e for e in errs if e and "BrokenBarrierError" not in e), None) or next((e for e in errs if e), None)
+    assert not alive and first is None, (alive, first)
+    group.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_loopback_collectives_match_a_host_statement(world):
+    """all-to-all (both communicator indices, issued from two streams of a rank) and all-reduce, 40 rounds back to back with no
+    synchronisation in between: every block bit-equal to what the peers sent, every sum the rank-order sum"""
+    cap, d, rounds = 96, 32, 40
+    sent = [[None] * rounds for _ in range(world)]
+    got = [[None] * rounds for _ in range(world)]
+
+    def fn(r, group, comm):
+        dev = torch.device("cuda:0")
+        g = torch.Generator(device="cpu").manual_seed(100 + r)
+        side = torch.cuda.Stream()
+        sends = [torch.randn(world * cap, d, generator=g).to(dev) for _ in range(rounds)]
+        recvs = [torch.empty(world * cap, d, device=dev) for _ in range(rounds)]
+        ar = [torch.randn(1000, generator=g).to(dev) for _ in range(rounds)]
+        ar_in = [t.clone() for t in ar]
+        comm.barrier()
+        main = torch.cuda.current_stream()
+        for i in range(rounds):
+            if i % 2:      # odd rounds on the side stream through communicator 1, as the plan stream's traffic
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    group.all_to_all(sends[i], recvs[i], ahead=True, kind="rows")
+            else:
+                group.all_to_all(sends[i], recvs[i], ahead=False, kind="grads")
+            group.all_reduce_sum(ar[i])
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        for i in range(rounds):
+            sent[r][i] = (sends[i].cpu(), ar_in[i].cpu())
+            got[r][i] = (recvs[i].cpu(), ar[i].cpu())
+
+    _run_ranks(world, fn)
+    for i in range(rounds):
+        want_sum = sent[0][i][1].clone()
+        for p in range(1, world):
+            want_sum += sent[p][i][1]
+        for r in range(world):
+            for p in range(world):
+                assert torch.equal(got[r][i][0][p * cap:(p + 1) * cap], sent[p][i][0][r * cap:(r + 1) * cap]), (i, r, p)
+            assert torch.equal(got[r][i][1], want_sum), (i, r)
+
+
+@pytest.mark.parametrize("kind,world,clip,loss,skew", [
+    ("SASRec", 2, 0.0, None, 0), ("SASRec", 4, 0.0, None, 0), ("SASRec", 8, 0.0, None, 0),      # clip 0: the dense half on the side stream
+    ("SASRec", 4, 0.05, None, 0), ("GRU", 2, 0.0, None, 0), ("MF", 4, 0.05, None, 0),
+    ("SASRec", 4, 0.0, "fullsoftmax", 0), ("MF", 2, 0.05, "fullsoftmax", 0),
+    ("SASRec", 2, 0.0, "serial-rows", 0),
+    ("SASRec", 4, 0.0, None, 400), ("SASRec", 8, 0.0, None, 400)])                              # rank 1's plan stream runs 400 us late
+def test_trainer_fit_on_loopback_ranks_equals_one_rank(kind, world, clip, loss, skew, tmp_path):
+    env_before = os.environ.get("UR_PREFETCH_ROWS")
+    if loss == "serial-rows":
+        os.environ["UR_PREFETCH_ROWS"] = "0"
+        loss = None
+    try:
+        def tweak(opt):
+            if skew and opt.rank == 1:
+                opt.plan_delay_us = skew
+
+        _run_ranks(world, lambda r, group, comm: _parity_body(r, world, kind, str(tmp_path), clip, loss, comm, tweak=tweak))
+    finally:
+        if env_before is None:
+            os.environ.pop("UR_PREFETCH_ROWS", None)
+        else:
+            os.environ["UR_PREFETCH_ROWS"] = env_before
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_capacity_overflow_replay_in_lockstep_on_the_loopback(world):
+    """a quarter of the needed capacity: the first steps overflow on every rank; the flag travels with the row gradients, every rank skips,
+    the hosts read it two steps later, double the capacity and train the batch again -- with the plan stream a step ahead all along"""
+    from unirec_amd.facility.distributed import ShardedSparseDenseAdam
+    from unirec_amd.utils.general import get_class_instance, init_seed
+    out = [None] * world
+
+    def fn(rank, group, comm):
+        dev = torch.device("cuda:0")
+        cfg = _cfg("SASRec", grad_clip_value=0.0)
+        B = 16
+        full = _batches(8, B * world)
+        mine = [_to(b, dev, rank * B, (rank + 1) * B) for b in full]
+
+        def run(slack):
+            with comm.exclusive():
+                init_seed(cfg["seed"])
+                m = get_class_instance("SASRec", "unirec_amd/model")(cfg)
+            opt = ShardedSparseDenseAdam(m, rank, world, group=group, lr=2e-3, cap_slack=slack)
+            m.train()
+            losses = [opt.train_step(b, mine[i + 1] if i + 1 < len(mine) else None) for i, b in enumerate(mine)]
+            opt.flush()
+            m.join_side_updates()
+            torch.cuda.synchronize()
+            return opt, m, [float(x) for x in losses]
+
+        opt, m, losses = run(0.25)
+        assert opt.n_overflow >= 1 and opt._cap_scale >= 2, (opt.n_overflow, opt._cap_scale)
+        assert opt.t == len(mine) + opt.n_overflow
+        assert all(np.isfinite(losses[-3:])), losses
+        ref_opt, _, ref_losses = run(1.5)
+        assert ref_opt.n_overflow == 0
+        assert abs(losses[-1] - ref_losses[-1]) < 0.05 * abs(ref_losses[-1])
+        out[rank] = ((opt._cap_scale, opt.n_overflow, opt.t), m.dense_flat.data.cpu().clone())
+
+    _run_ranks(world, fn)
+    assert len({o[0] for o in out}) == 1, [o[0] for o in out]             # lockstep: every rank doubled at the same steps
+    assert all(torch.equal(out[0][1], o[1]) for o in out[1:])              # the replicas stayed identical through the skips

@@ -93,6 +93,16 @@ SIGNATURES = {
     "ur_shard_exchange_grads": (C.c_int, [P, P, I32, I32, I32, P, P, P, P, I32, P]),
     "ur_shard_step_flags": (C.c_int, [P, I32, I32, I32, P, P]),
     "ur_comm_world": (C.c_int, []),
+    "ur_loop_create": (P, [I32]),
+    "ur_loop_destroy": (C.c_int, [P]),
+    "ur_loop_attach": (C.c_int, [P, I32]),
+    "ur_loop_detach": (C.c_int, []),
+    "ur_loop_world": (C.c_int, []),
+    "ur_loop_post": (C.c_int, [P, I32, P]),
+    "ur_loop_all_to_all_pull": (C.c_int, [P, I64, I32, P]),
+    "ur_loop_all_reduce_pull": (C.c_int, [I64, P]),
+    "ur_loop_finish": (C.c_int, [I32, P, I64, P]),
+    "ur_debug_delay": (C.c_int, [I32, P]),
     "ur_comm_unique_id": (C.c_int, [P]),
     "ur_comm_init": (C.c_int, [P, I32, I32]),
     "ur_comm_destroy": (C.c_int, []),
@@ -179,6 +189,29 @@ def _load():
 
 
 lib = _load()
+
+# ---- one library call at a time (the in-process loopback transport, pgroup.LoopbackGroup: W rank THREADS call into the library, ctypes
+# releases the GIL around a foreign call, and the library's lazily initialised per-device state -- zero rows, hand-off counters, event
+# rings -- is written for one calling thread).  Off by default: a single-threaded process pays nothing.  The calls are short host-side
+# enqueues; the rendezvous of the rank threads happens in Python, outside the lock.
+import threading as _threading
+
+_CALL_LOCK = _threading.Lock()
+_RAW = {}
+
+
+def serialize_calls(on=True):
+    for name in SIGNATURES:
+        if on and name not in _RAW:
+            raw = getattr(lib, name)
+            _RAW[name] = raw
+
+            def locked(*a, _f=raw):
+                with _CALL_LOCK:
+                    return _f(*a)
+            setattr(lib, name, locked)
+        elif not on and name in _RAW:
+            setattr(lib, name, _RAW.pop(name))
 
 
 def check(rc, what=""):

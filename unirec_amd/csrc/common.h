@@ -40,6 +40,11 @@ int fail(int code, const char* fmt, ...);
 // stream waits for that packet: ~5 us of idle stream at every fork of the backward pass.  hipExtLaunchKernelGGL binds the event to the
 // kernel's own completion signal instead: nothing is inserted.  A caller arms `g_stop_event` right before calling a helper whose LAST
 // launch goes through UR_LAUNCH_EV; that launch consumes it (other launches of the helper leave it alone).
+// Context id of the calling thread: 0 = the process's default context; ur_loop_attach (exchange.hip: the in-process loopback transport, W
+// rank threads in one process) sets rank + 1.  Per-context state -- the encoder's side stream and its events (sasrec.hip), the split
+// kernels' hand-off counters (rowchain.hip) -- is indexed by it, so that rank threads sharing a process do not share it.
+constexpr int UR_MAX_CTX = 65;
+extern thread_local int g_ctx_id;
 extern thread_local hipEvent_t g_stop_event;
 // The profiler's kernel-bound brackets (ProfScope with kernel_events): the next UR_LAUNCH_EV launch carries the scope's two events as ITS
 // start / completion timestamps -- the dispatch's own begin and end, not the stream's: an event RECORDED in front of a kernel is stamped

@@ -5,6 +5,7 @@
 #include "kernels.h"
 
 namespace ur {
+thread_local int g_ctx_id = 0;                    // common.h: context id of the calling thread
 thread_local hipEvent_t g_stop_event = nullptr;   // common.h: UR_LAUNCH_EV
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;   // common.h: ProfScope with kernel_events
 }

@@ -1133,16 +1133,19 @@ long long chain_split_part_floats(int M, int d, int inner) {
 }
 // counters of the split kernels: one per row block, zeroed once per device, reset by the kernel that used them
 static unsigned* chain_split_counters() {
-  static unsigned* z[64] = {};
+  // per device AND per context of the calling thread (common.h: g_ctx_id): launches of two rank threads of the loopback transport run
+  // concurrently on their own streams and must not share hand-off counters
+  static unsigned* z[64][UR_MAX_CTX] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!z[dev]) {
+  unsigned*& slot = z[dev][(g_ctx_id >= 0 && g_ctx_id < UR_MAX_CTX) ? g_ctx_id : 0];
+  if (!slot) {
     unsigned* p = nullptr;
     if (hipMalloc((void**)&p, 2 * CHAIN_SPLIT_MAX_BLOCKS * sizeof(unsigned)) != hipSuccess) return nullptr;
     if (hipMemset(p, 0, 2 * CHAIN_SPLIT_MAX_BLOCKS * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-    z[dev] = p;
+    slot = p;
   }
-  return z[dev];
+  return slot;
 }
 
 int chain_ffn_fwd_split(const ChainFwdArgs& a0, int d, hipStream_t st) {

@@ -309,7 +309,14 @@ __global__ void side_delay_kernel(long long cycles) {
 int g_side_enabled = 1;   // runtime switch (ur_sasrec_set_side_stream)
 SideCtx* side_ctx(bool even_if_disabled = false) {
   if (!g_side_enabled && !even_if_disabled) return nullptr;
-  static SideCtx* ctx = []() -> SideCtx* {
+  // one side stream (and set of events) per CONTEXT of the calling thread (common.h: g_ctx_id): the rank threads of the in-process loopback
+  // transport each have their own; every other caller is context 0, as before
+  static SideCtx* ctxs[UR_MAX_CTX] = {};
+  static bool made[UR_MAX_CTX] = {};
+  const int id = (g_ctx_id >= 0 && g_ctx_id < UR_MAX_CTX) ? g_ctx_id : 0;
+  if (made[id]) return ctxs[id];
+  made[id] = true;
+  ctxs[id] = []() -> SideCtx* {
     const char* e = getenv("UR_SASREC_SIDE");
     if (e && atoi(e) == 0) return nullptr;
     SideCtx* c = new SideCtx();
@@ -325,7 +332,7 @@ SideCtx* side_ctx(bool even_if_disabled = false) {
     c->ok = true;
     return c;
   }();
-  return ctx;
+  return ctxs[id];
 }
 }  // namespace
 
@@ -958,8 +965,8 @@ extern "C" int ur_sasrec_side_publish(int late) {
 // `waiter` waits for everything enqueued on `waited` so far (both streams of the current device), through an event WITHOUT the
 // system-scope fence (see side_ctx): what torch's Stream.wait_stream does with a default event, ~1.5 us cheaper on the recording stream.
 extern "C" int ur_stream_wait_stream(void* waiter, void* waited) {
-  static hipEvent_t ring[16];
-  static int made = 0, next = 0;
+  static thread_local hipEvent_t ring[16];      // (per thread: rank threads of the loopback transport call this concurrently)
+  static thread_local int made = 0, next = 0;
   if (!made) {
     for (auto& e : ring) UR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
     made = 1;
@@ -967,6 +974,15 @@ extern "C" int ur_stream_wait_stream(void* waiter, void* waited) {
   hipEvent_t e = ring[next++ & 15];
   UR_HIP(hipEventRecord(e, as_stream(waited)));
   UR_HIP(hipStreamWaitEvent(as_stream(waiter), e, 0));
+  return UR_OK;
+}
+
+// test aid: a kernel that spins for `us` microseconds on `stream` -- skews one stream against the others (a rank's plan stream running
+// late: tests/test_loopback_gpu.py)
+extern "C" int ur_debug_delay(int32_t us, void* stream) {
+  UR_REQUIRE(us >= 0 && us <= 1000000, UR_ERR_ARG, "ur_debug_delay: us=%d", us);
+  if (us > 0) hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(64), 0, as_stream(stream), (long long)us * 100);   // wall_clock64: 100 MHz
+  UR_LAUNCH_CHECK();
   return UR_OK;
 }
 

@@ -30,7 +30,8 @@ import os
 import warnings
 
 import torch
-import torch.distributed as dist
+
+from .. import pgroup as dist     # torch.distributed's surface, or the in-process loopback group's (pgroup.py)
 
 from .. import ops
 from ..sharded import RowExchange, shard_rows   # noqa: F401  (shard_rows: re-exported for callers)
@@ -44,9 +45,19 @@ def dist_info(accelerator=None):
     default torch.distributed group, else (0, 1)."""
     if accelerator is not None and hasattr(accelerator, "num_processes"):
         return int(accelerator.process_index), int(accelerator.num_processes)
+    if dist.is_loopback(accelerator):
+        return accelerator.rank, accelerator.world
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def dist_group(accelerator=None):
+    """the process group the ranks of `accelerator` talk through: its ``process_group`` attribute when it has one (a
+    pgroup.LoopbackGroup: W rank threads in this process), else None = torch.distributed's default group"""
+    if dist.is_loopback(accelerator):
+        return accelerator
+    return getattr(accelerator, "process_group", None)
 
 
 def owned_ids(n_rows, rank, world):
@@ -165,6 +176,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         self._cap_scale = 1               # doubled after a capacity overflow
         # native transport: RCCL through the library's own communicators, on whatever stream the step is on
         self._native = False
+        self._loop = self.xchg.loop      # the in-process loopback group (pgroup.LoopbackGroup), or None
         if (world > 1 and dev.type == "cuda" and dist.get_backend(group) == "nccl" and ops.comm_world() >= 0
                 and os.environ.get("UR_NATIVE_TRANSPORT", "1") not in ("", "0")):
             self._native = bool(ops.comm_init(rank, world, group)) and self._native_selftest(dev)
@@ -185,6 +197,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         # stream behind the encoder's reductions, as with gradient clipping; with UR_COMM_SINGLE=1 every collective of a step then goes
         # through ONE communicator on ONE stream, in program order: the shape of the reference's own DDP step
         self._dense_on_side = os.environ.get("UR_DENSE_SIDE", "1") not in ("", "0")
+        self.plan_delay_us = 0            # test aid (see prefetch)
         self.prefetch_rows = os.environ.get("UR_PREFETCH_ROWS", "1") not in ("", "0") and model.loss_type != "fullsoftmax"
         self._fs_dgrad = None
         if model.loss_type == "fullsoftmax":
@@ -210,11 +223,19 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             else:
                 dist.broadcast(piece, src=0, group=self.xchg.group)
 
-    def _a2a(self, send, recv, label):
-        """equal-split all-to-all of a packed block through torch.distributed (the non-native route)"""
+    _LOOP_KIND = {"a2a_ids": ("ids", True), "a2a_fix_slots": ("ids", True), "a2a_rows": ("rows", None), "a2a_fix_rows": ("rows", False),
+                  "a2a_row_grads": ("grads", False)}
+
+    def _a2a(self, send, recv, label, ahead=None):
+        """equal-split all-to-all of a packed block when the library's RCCL communicators are not in use: the in-process loopback
+        transport (stream-ordered copies, communicator index as the RCCL route would pick it: `ahead` = issued a step ahead), else
+        torch.distributed"""
         if self.world == 1:
             assert recv.data_ptr() == send.data_ptr()     # (aliased at world 1: see _buffers)
             return recv
+        if self._loop is not None:
+            kind, dflt = self._LOOP_KIND[label]
+            return self._loop.all_to_all(send, recv, ahead=dflt if ahead is None else ahead, kind=kind)
         recv.copy_(self.xchg.all_to_all_equal(send, label=label))
         return recv
 
@@ -223,6 +244,8 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             return t
         if self._native:
             return ops.comm_all_reduce_sum(t)
+        if self._loop is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+            return self._loop.all_reduce_sum(t)
         r = self.xchg.all_reduce_sum(t)
         if r is not t:
             t.copy_(r)
@@ -360,7 +383,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                 if self._native:
                     ops.comm_all_to_all(bf["rows_ws"], bf["compact"], W, ahead=True)
                 else:
-                    self._a2a(bf["rows_ws"], bf["compact"], "a2a_rows")
+                    self._a2a(bf["rows_ws"], bf["compact"], "a2a_rows", ahead=True)
             c["rows_ready"] = True
 
     def prefetch(self, batch, cur_tabs=None):
@@ -372,6 +395,8 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.model.device)
         ops.stream_wait_stream(self._side, main)      # the ids may still be in flight on the main stream; `last` is being updated there
+        if self.plan_delay_us:      # test aid: this rank's plan stream runs late (tests/test_loopback_gpu.py)
+            ops.debug_delay(self.plan_delay_us, self._side)
         look = _Look()
         self._parity ^= 1
         with torch.cuda.stream(self._side):
@@ -557,7 +582,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             else:
                 ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, c["cap"], bf["rows_ws"], compact=bf["compact"], transport=self._native)
                 if not self._native:
-                    self._a2a(bf["rows_ws"], bf["compact"], "a2a_rows")
+                    self._a2a(bf["rows_ws"], bf["compact"], "a2a_rows", ahead=False)
             if c["ka"] is not None:
                 cbatch[c["ka"]] = bf["idx_a"].view(batch[c["ka"]].shape)
             if c["kb"] is not None:
@@ -771,7 +796,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             ops.shard_exchange_rows(st["w"], bf["recv_ids"], W, c["cap"], bf["rows_ws"] if W > 1 else compact, compact=compact,
                                     transport=self._native)
             if not self._native and W > 1:
-                self._a2a(bf["rows_ws"], compact, "a2a_rows")
+                self._a2a(bf["rows_ws"], compact, "a2a_rows", ahead=False)
             if c["ka"] is not None:
                 cbatch[c["ka"]] = bf["idx_a"].clone().view(batch[c["ka"]].shape)
             if c["kb"] is not None:

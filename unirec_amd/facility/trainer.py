@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-from .distributed import ShardedSparseDenseAdam, dist_info
+from .distributed import ShardedSparseDenseAdam, dist_group, dist_info
 from .optimizer import SparseDenseAdam
 
 
@@ -204,8 +204,8 @@ class Trainer(object):
             self.logger.warning("Received unrecognized optimizer, set default Adam optimizer")
             opt_type, wd = "adam", 0.0          # the reference's fall-back drops weight_decay too (trainer.py:151)
         if self.world > 1:
-            return ShardedSparseDenseAdam(self.model, self.rank, self.world, lr=self.learning_rate, weight_decay=wd,
-                                          grad_clip=self.grad_clip_value, table_mode=table_mode, algo=opt_type)
+            return ShardedSparseDenseAdam(self.model, self.rank, self.world, group=dist_group(self.accelerator), lr=self.learning_rate,
+                                          weight_decay=wd, grad_clip=self.grad_clip_value, table_mode=table_mode, algo=opt_type)
         return SparseDenseAdam(self.model, lr=self.learning_rate, weight_decay=wd, grad_clip=self.grad_clip_value, table_mode=table_mode,
                                algo=opt_type)
 
@@ -387,7 +387,7 @@ class Trainer(object):
         batches)."""
         if self.world == 1:
             return np.concatenate(per_batch) if per_batch else np.zeros(0)
-        import torch.distributed as dist
+        from .. import pgroup as dist
         box = [None] * self.world
         dist.all_gather_object(box, per_batch, group=self.optimizer.xchg.cpu_group or self.optimizer.xchg.group)
         out = [box[r][k] for k in range(len(per_batch)) for r in range(self.world) if k < len(box[r])]

@@ -2,6 +2,7 @@
 HIP stream.  PyTorch is only the allocator / stream provider here; all arithmetic is in the HIP library.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -89,8 +90,8 @@ def sasrec_fwd(cfg, item_table, dense, item_seq, ws):
     user_emb = torch.empty(cfg.B, cfg.d, dtype=torch.float32, device=dense.device)
     check(lib.ur_sasrec_fwd(C.byref(cfg), _p(item_table), item_table.shape[0], _p(dense), _p(item_seq), _p(user_emb),
                             _p(ws), _stream()), "ur_sasrec_fwd")
-    _side_hold.clear()   # (a late join of side-stream work, if one was pending, is now enqueued on this stream)
-    _side_late[0] = False
+    _side.hold.clear()   # (a late join of side-stream work, if one was pending, is now enqueued on this stream)
+    _side.late = False
     return user_emb
 
 
@@ -108,8 +109,8 @@ def sasrec_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws, defer_join=Fals
 
 def sasrec_bwd_join():
     check(lib.ur_sasrec_bwd_join(_stream()), "ur_sasrec_bwd_join")
-    _side_hold.clear()
-    _side_late[0] = False
+    _side.hold.clear()
+    _side.late = False
 
 
 def stream_wait_stream(waiter, waited):
@@ -123,8 +124,16 @@ def sasrec_side_stream():
     return torch.cuda.ExternalStream(p) if p else None
 
 
-_side_late = [False]   # a late join is armed (sasrec_side_publish(late=True)) and no forward pass / explicit join has taken it yet
-_side_hold = []   # tensors the side-stream work reads (allocated under the main stream): kept alive until the main stream has joined
+class _SideState(threading.local):
+    """per THREAD, as the library's side-stream context is (csrc/common.h: g_ctx_id): the rank threads of the in-process loopback
+    transport each have their own encoder side stream"""
+
+    def __init__(self):
+        self.late = False    # a late join is armed (sasrec_side_publish(late=True)) and no forward pass / explicit join has taken it yet
+        self.hold = []       # tensors the side-stream work reads (allocated under the main stream): kept alive until the main stream has joined
+
+
+_side = _SideState()
 
 
 def sasrec_side_publish(late=True, hold=()):
@@ -132,8 +141,8 @@ def sasrec_side_publish(late=True, hold=()):
     `hold`: tensors that work reads -- kept referenced until that join is enqueued (their memory belongs to the main stream's allocator)."""
     check(lib.ur_sasrec_side_publish(1 if late else 0), "ur_sasrec_side_publish")
     if late:
-        _side_hold.extend(hold)
-        _side_late[0] = True
+        _side.hold.extend(hold)
+        _side.late = True
     else:
         sasrec_bwd_join()
 
@@ -141,7 +150,7 @@ def sasrec_side_publish(late=True, hold=()):
 def sasrec_side_join():
     """Joins a late side-stream update now, on the current stream (no-op when none is pending): for readers of the dense parameters
     other than the encoder's forward pass."""
-    if _side_late[0]:
+    if _side.late:
         sasrec_bwd_join()
 
 
@@ -383,6 +392,12 @@ def comm_init(rank, world, group=None):
         return False
     check(lib.ur_comm_init(buf, int(rank), int(world)), "ur_comm_init")
     return True
+
+
+def debug_delay(us, stream=None):
+    """test aid: a spin kernel of `us` microseconds on `stream` (default: the current one)"""
+    st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    check(lib.ur_debug_delay(int(us), st), "ur_debug_delay")
 
 
 def comm_destroy():

@@ -8,7 +8,8 @@ padding row of every shard); the step itself is ``facility/distributed.py::Shard
 ``RowExchange`` is pure torch.distributed (any backend / device): the world_size-2 gloo tests drive it on the CPU.
 """
 import torch
-import torch.distributed as dist
+
+from . import pgroup as dist   # torch.distributed's surface, or the in-process loopback group's (pgroup.py)
 
 
 class RowExchange:
@@ -20,6 +21,7 @@ class RowExchange:
         self.profile = None        # {label: [ms, bytes sent to peers, calls]} while profiling is on (bench.py: per-collective times)
         self._pending = []
         self.cpu_group = group if world > 1 and dist.get_backend(group) == "gloo" else None
+        self.loop = group if dist.is_loopback(group) else None      # W rank threads in this process (pgroup.LoopbackGroup)
 
     # ---- per-collective timing (off by default: two events per collective).  bytes = what this rank sends to its W - 1 peers.
     def profile_start(self):
@@ -48,7 +50,7 @@ class RowExchange:
         return r
 
     def _staged(self, t: torch.Tensor):
-        return t.is_cuda and self.world > 1 and dist.get_backend(self.group) != "nccl"
+        return t.is_cuda and self.world > 1 and dist.get_backend(self.group) not in ("nccl", "loopback")
 
     def all_to_all_equal(self, send: torch.Tensor, label="all_to_all") -> torch.Tensor:
         """send: [world * cap, ...], block p -> rank p; returns [world * cap, ...], block p <- rank p (fixed-capacity exchange)."""
