@@ -78,6 +78,9 @@ def parse():
                     "dominant kernel class and its roofline fraction each) into the same JSON line")
     ap.add_argument("--sharded-w1", action="store_true", help="--gpus 1 only: step through the multi-GPU code path (facility/distributed.py, "
                     "fixed-capacity row exchange with world = 1, collectives degenerate) instead of the plain optimizer: its overhead")
+    ap.add_argument("--loopback", type=int, default=0, help="--gpus 1 only: W rank THREADS of this process share the GPU and train ONE model "
+                    "through the in-process loopback transport (unirec_amd/pgroup.py): the multi-GPU step's real schedule at true W-rank shapes "
+                    "(merge plan, capacities) with real stream concurrency; prints wall time per step and per rank-step")
     ap.add_argument("--worker", action="store_true", help="(internal) world > 1: this process IS the benchmark; without it the process the "
                     "launcher started supervises a --worker child per rung of the fallback ladder (tools/bench_ladder.py)")
     ap.add_argument("--dry-worker", action="store_true", help="(test aid) the worker walks the phases over gloo with no GPU work")
@@ -191,6 +194,89 @@ def cpu_baseline(a):
                       f"B={B}, L={L}, d={d}, K={a.negatives}, table reduced to N={N} rows (dense Adam is O(N): {dt * 1e3:.0f} ms/step here, "
                       f"would be ~{dt * 1e3 * a.n_items / N:.0f} ms/step at N={a.n_items} by per-row extrapolation); "
                       f"{cores} torch threads (fastest of the counts tried, {avail} cores available); torch {torch.__version__} CPU"}
+
+
+def loopback_leg(a, device, W):
+    """W rank threads on ONE GPU (pgroup.LoopbackGroup): every rank holds its shard of the 100 M-row table and its optimizer state
+    (W x 19 GB at W = 8), steps through ShardedSparseDenseAdam.train_step with the lookahead batch, and exchanges through stream-ordered
+    device copies.  All W ranks' kernels share the one device, so `wall / W` is the device time one rank-step costs at true W-rank shapes
+    (W-run merge plans, cap = 1.25 x lookups / W) including the device-to-device copies that stand in for xGMI; the copies are bracketed
+    by the library's per-collective timers and reported apart."""
+    import threading
+    import traceback
+    import ctypes as C
+    from unirec_amd import _lib
+    from unirec_amd.facility.distributed import ShardedSparseDenseAdam
+    from unirec_amd.model.sequential.sasrec import SASRec
+    from unirec_amd.pgroup import LoopbackGroup
+    from unirec_amd.sharded import shard_rows
+    group = LoopbackGroup(W)
+    lock = threading.Lock()
+    res, errs = [None] * W, [None] * W
+    ncls = _lib.lib.ur_prof_num_classes()
+    names = [_lib.lib.ur_prof_class_name(i).decode() for i in range(ncls)]
+    coll = ("a2a_ids", "a2a_rows", "a2a_row_grads", "allreduce")
+
+    def body(r):
+        try:
+            torch.cuda.set_device(device)
+            group.attach(r)
+            batches = synth_batches(a, a.n_items, device, 2022 + 7919 * r, n_batches=a.warmup + a.steps + 1)
+            with lock:
+                torch.manual_seed(2022 + r)
+                model = SASRec(dict(model_config(a, str(device)), n_items=shard_rows(a.n_items, W)))
+                torch.cuda.synchronize()
+            opt = ShardedSparseDenseAdam(model, r, W, group=group, lr=1e-3, table_mode=a.table_mode, full_rows={"item_embedding": a.n_items})
+            model.train()
+            loss = None
+            for i in range(a.warmup):
+                loss = opt.train_step(batches[i], batches[i + 1])
+            group.barrier()
+            if r == 0:
+                _lib.lib.ur_prof_reset()
+                _lib.lib.ur_prof_set_mask(sum(1 << names.index(n) for n in coll))
+                _lib.lib.ur_prof_enable(1)
+            group.barrier()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                loss = opt.train_step(batches[a.warmup + i], batches[a.warmup + i + 1])
+            torch.cuda.current_stream().synchronize()
+            model.join_side_updates()
+            group.barrier()
+            dt = time.perf_counter() - t0
+            bf = next(iter(opt._bufs.values()))
+            res[r] = dict(dt=dt, loss=float(loss), cap=bf.get("cap"), cap2=bf.get("cap2"), n_overflow=opt.n_overflow)
+            if r == 0:
+                _lib.lib.ur_prof_enable(0)
+                ms, cnt, work = (C.c_double * ncls)(), (C.c_int64 * ncls)(), (C.c_double * ncls)()
+                _lib.check(_lib.lib.ur_prof_read(ms, cnt, work), "ur_prof_read")
+                res[r]["copies"] = {n: dict(ms=ms[names.index(n)], calls=int(cnt[names.index(n)])) for n in coll}
+                _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
+            opt.flush()
+            torch.cuda.synchronize()
+        except BaseException:   # noqa: BLE001
+            errs[r] = traceback.format_exc()
+            group.abort()
+        finally:
+            group.detach()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    bad = next((e for e in errs if e and "BrokenBarrierError" not in e), None) or next((e for e in errs if e), None)
+    if bad:
+        raise SystemExit("loopback leg failed:\n" + bad)
+    dt = max(x["dt"] for x in res)
+    copies_ms = sum(v["ms"] for v in res[0]["copies"].values())       # all ranks' brackets (one profiler per process)
+    wall = dt / a.steps * 1e3
+    return {"ranks": W, "steps": a.steps, "ms_per_step_wall_all_ranks_on_one_gpu": round(wall, 4), "ms_per_rank_step": round(wall / W, 4),
+            "copies_ms_per_rank_step": round(copies_ms / a.steps / W, 4), "ms_per_rank_step_without_copies": round(wall / W - copies_ms / a.steps / W, 4),
+            "cap": res[0]["cap"], "cap2": res[0]["cap2"], "overflows": res[0]["n_overflow"], "final_loss_rank0": round(res[0]["loss"], 6),
+            "copies": {k: {"ms_per_rank_step": round(v["ms"] / a.steps / W, 4), "calls_per_rank_step": v["calls"] / a.steps / W} for k, v in res[0]["copies"].items()},
+            "note": "W rank threads of ONE process on ONE GPU through the in-process loopback transport (stream-ordered device copies stand in for "
+                    "xGMI); every rank's kernels share the device, so wall / W is one rank-step's device time at true W-rank shapes"}
 
 
 def multi_gpu_selfcheck(a, device, rank, world):
@@ -632,6 +718,11 @@ def main():
         return bench_ladder.dry_worker(sys.argv[1:])
     phase = bench_ladder.phase
     phase("init")
+    if a.loopback > 1:
+        assert world == 1, "--loopback runs W rank threads inside ONE process"
+        torch.cuda.set_device(local_rank)
+        print(json.dumps({"loopback": loopback_leg(a, torch.device("cuda", local_rank), a.loopback)}), flush=True)
+        return
     if os.environ.get("UR_BENCH_SHARE_DEVICE") == "1":   # debugging aid only: several ranks on one GPU (1-GPU dev boxes)
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)

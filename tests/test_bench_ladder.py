@@ -23,7 +23,7 @@ def _free_port():
 
 
 def _launch(extra_env, extra_args=("--dry-worker",), world=2, timeout=240):
-    env = dict(os.environ, UR_BENCH_TIMEOUT_SCALE="0.05", **extra_env)      # limits of 12-30 s instead of minutes
+    env = dict(os.environ, **{"UR_BENCH_TIMEOUT_SCALE": "0.05", **extra_env})      # limits of 12-30 s instead of minutes
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
