@@ -44,12 +44,13 @@ __global__ __launch_bounds__(256) void v0(const fx4* __restrict__ table, const l
   out[(long long)blockIdx.x * blockDim.x + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
 }
 
-// MODE 1: shape only; 2: + dot, group sum, score store, LDS copy; 3: 2 + scalar next-trip ids
-template <int MODE>
-__global__ __launch_bounds__(1024) void v123(const fx4* __restrict__ table, const long long* __restrict__ ids, int G, const fx4* __restrict__ user,
+// MODE 1: shape only; 2: + dot, group sum, score store, LDS copy; 3: 2 + scalar next-trip ids; 4: 2 without the global score store;
+// 5: 2 with a TRANSPOSED reduction (8 rows x 32 lanes -> one row total per lane in 9 exchanges instead of 40) and one 32-byte store per group
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void v123(const fx4* __restrict__ table, const long long* __restrict__ ids, int G, const fx4* __restrict__ user,
                                              float* __restrict__ scores, float* __restrict__ out) {
   extern __shared__ float sc[];
-  const int b = blockIdx.x, t = threadIdx.x & 31, g0 = threadIdx.x >> 5, groups = 32;
+  const int b = blockIdx.x, t = threadIdx.x & 31, g0 = threadIdx.x >> 5, groups = NT / 32;
   const long long* my = ids + (long long)b * G;
   const fx4 u = user[(long long)b * 32 + t];
   fx4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -92,12 +93,27 @@ __global__ __launch_bounds__(1024) void v123(const fx4* __restrict__ table, cons
       if (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < U; ++q) acc += e[q];
+      } else if (MODE == 5) {
+        float v[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) v[q] = (e[q].x * u.x + e[q].y * u.y) + (e[q].z * u.z + e[q].w * u.w);
+        const bool b0 = t & 1, b1 = t & 2, b2 = t & 4;
+        float r4[4], r2[2], r1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r4[i] = (b0 ? v[4 + i] : v[i]) + dpp<0xB1>(b0 ? v[i] : v[4 + i]);          // lanes l, l ^ 1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) r2[i] = (b1 ? r4[2 + i] : r4[i]) + dpp<0x4E>(b1 ? r4[i] : r4[2 + i]);      // l ^ 2
+        r1 = (b2 ? r2[1] : r2[0]) + __shfl_xor(b2 ? r2[0] : r2[1], 4, 64);                                     // l ^ 4
+        r1 += __shfl_xor(r1, 8, 64);
+        r1 += __shfl_xor(r1, 16, 64);
+        const int row = 4 * (t & 1) + 2 * ((t >> 1) & 1) + ((t >> 2) & 1);     // the row whose total this lane holds
+        if (t < 8 && gb + row < G) { sc[gb + row] = r1; scores[(long long)b * G + gb + row] = r1; }
       } else {
 #pragma unroll
         for (int q = 0; q < U; ++q) {
           float s = (e[q].x * u.x + e[q].y * u.y) + (e[q].z * u.z + e[q].w * u.w);
           s = sum32(s);
-          if (t == 0 && gb + q < G) { sc[gb + q] = s; scores[(long long)b * G + gb + q] = s; }
+          if (t == 0 && gb + q < G) { sc[gb + q] = s; if (MODE != 4) scores[(long long)b * G + gb + q] = s; }
         }
       }
     }
@@ -139,6 +155,13 @@ __global__ __launch_bounds__(64 * WAVES) void v4(const fx2* __restrict__ table, 
   if (threadIdx.x == 0) out[b] = sc[0];
 }
 
+__global__ void fill_random(unsigned* p, long long n) {   // (zero-filled tables read faster than real data on this part: DVFS, MI355X_MICROARCH.md)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = 0x3C000000u | (x & 0x03FFFFFFu);   // floats in [2^-7, 2^-3): finite, every bit of the mantissa in use
+  }
+}
+
 template <typename F> static float timeit(F launch, int reps = 8) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   launch(); hipDeviceSynchronize();
@@ -150,10 +173,13 @@ template <typename F> static float timeit(F launch, int reps = 8) {
   return best;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool random_data = argc > 1;
   const int B = 4096, G = 1001;
   const long long n = (long long)B * G, rows = 100000000LL;
   fx4* table; CK(hipMalloc(&table, rows * 512)); CK(hipMemset(table, 0, rows * 512));
+  if (random_data) { hipLaunchKernelGGL(fill_random, dim3(8192), dim3(256), 0, 0, (unsigned*)table, rows * 128); CK(hipDeviceSynchronize()); }
+  printf("table contents: %s\n", random_data ? "random floats" : "zeros");
   std::vector<long long> h(n);
   unsigned long long s = 88172645463325252ULL;
   for (long long i = 0; i < n; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (long long)(s % (unsigned long long)(rows - 1)) + 1; }
@@ -164,9 +190,13 @@ int main() {
   auto rep = [&](const char* tag, float ms) { printf("%-58s %7.3f ms  %7.1f GB/s  %.3f of 8 TB/s\n", tag, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0); };
   rep("V0 ceiling: grid-stride groups, U=8, nt (2048 wgs)", timeit([&] { hipLaunchKernelGGL(v0, dim3(2048), dim3(256), 0, 0, table, ids, n, out); }));
   const size_t lds = (G + 16) * 4;
-  rep("V1 scorer shape (1024-thread wg per b), no dot", timeit([&] { hipLaunchKernelGGL(v123<1>, dim3(B), dim3(1024), lds, 0, table, ids, G, user, scores, out); }));
-  rep("V2 + dot, 32-lane sum, score store, LDS copy", timeit([&] { hipLaunchKernelGGL(v123<2>, dim3(B), dim3(1024), lds, 0, table, ids, G, user, scores, out); }));
-  rep("V3 + next trip's ids by scalar loads (SGPRs)", timeit([&] { hipLaunchKernelGGL(v123<3>, dim3(B), dim3(1024), lds, 0, table, ids, G, user, scores, out); }));
+  rep("V1 scorer shape (1024-thread wg per b), no dot", timeit([&] { hipLaunchKernelGGL((v123<1, 1024>), dim3(B), dim3(1024), lds, 0, table, ids, G, user, scores, out); }));
+  rep("V2 + dot, 32-lane sum, score store, LDS copy", timeit([&] { hipLaunchKernelGGL((v123<2, 1024>), dim3(B), dim3(1024), lds, 0, table, ids, G, user, scores, out); }));
+  rep("V3 + next trip's ids by scalar loads (SGPRs)", timeit([&] { hipLaunchKernelGGL((v123<3, 1024>), dim3(B), dim3(1024), lds, 0, table, ids, G, user, scores, out); }));
+  rep("V2 at 256 threads per wg (the library's launch for B > 512)", timeit([&] { hipLaunchKernelGGL((v123<2, 256>), dim3(B), dim3(256), lds, 0, table, ids, G, user, scores, out); }));
+  rep("V2 without the global score store (LDS copy only)", timeit([&] { hipLaunchKernelGGL((v123<4, 1024>), dim3(B), dim3(1024), lds, 0, table, ids, G, user, scores, out); }));
+  rep("V5 transposed reduction, one 32-byte score store per group", timeit([&] { hipLaunchKernelGGL((v123<5, 1024>), dim3(B), dim3(1024), lds, 0, table, ids, G, user, scores, out); }));
+  rep("V5 at 256 threads per wg", timeit([&] { hipLaunchKernelGGL((v123<5, 256>), dim3(B), dim3(256), lds, 0, table, ids, G, user, scores, out); }));
   rep("V4 row per wave (64 x 8 B), scalar ids, 16 waves per wg", timeit([&] { hipLaunchKernelGGL(v4<16>, dim3(B), dim3(1024), lds, 0, (const fx2*)table, ids, G, (const fx2*)user, scores, out); }));
   rep("V4 row per wave, 8 waves per wg", timeit([&] { hipLaunchKernelGGL(v4<8>, dim3(B), dim3(512), lds, 0, (const fx2*)table, ids, G, (const fx2*)user, scores, out); }));
   rep("V4 row per wave, 4 waves per wg", timeit([&] { hipLaunchKernelGGL(v4<4>, dim3(B), dim3(256), lds, 0, (const fx2*)table, ids, G, (const fx2*)user, scores, out); }));

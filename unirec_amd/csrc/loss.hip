@@ -33,7 +33,10 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // NT threads per workgroup: 256, or 1024 for few rows with many candidates (C3: B = 128 rows of 1001 candidates leave half of the
 // CUs without a workgroup; four times the lane groups per row = four times the candidate rows in flight)
-template <int TPR, int UNR, int NT>
+// KV = float4 chunks of a row per lane = ceil(d / 4 / TPR): 1 for every d <= 128.  (Round 5: the kernel used to carry MAXV = 4 chunks for
+// every shape -- 152 VGPRs at 256 threads, scratch spills at 1024 -- for loops whose upper three trips never run at d = 128; the gather
+// ran at 0.70-0.72 of the HBM peak where the same loop without them reaches 0.77: tools/probe/scorer_probe.hip, profiles/r05_d_*.)
+template <int TPR, int UNR, int NT, int KV>
 __global__ __launch_bounds__(NT) void scorer_loss_fwd_kernel(UrLossCfg c, const float4* __restrict__ user_emb,
                                                               const float4* __restrict__ table, const long long* __restrict__ item_id,
                                                               const int* __restrict__ label, const float* __restrict__ user_bias,
@@ -44,9 +47,9 @@ __global__ __launch_bounds__(NT) void scorer_loss_fwd_kernel(UrLossCfg c, const 
   float* red = sc + c.G;
   const int b = blockIdx.x, G = c.G, d4 = c.d / 4;
   const int groups = NT / TPR, g0 = threadIdx.x / TPR, t = threadIdx.x % TPR;
-  float4 u[MAXV];
+  float4 u[KV];
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
+  for (int k = 0; k < KV; ++k) {
     const int col = t + k * TPR;
     u[k] = col < d4 ? user_emb[(long long)b * d4 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -59,11 +62,15 @@ __global__ __launch_bounds__(NT) void scorer_loss_fwd_kernel(UrLossCfg c, const 
     float s[UNR];
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
-      id[q] = (gb + q < G) ? UR_ROW(item_id[(long long)b * G + gb + q], n_items) : 0;
+      // unconditional loads at a clamped position, the range check behind ALL of them: a load inside a select is branched around and
+      // waited for on the spot (eight dependent round trips per trip: measured -5 % on the gather, profiles/r05_d_scorer_probe.txt)
+      id[q] = item_id[(long long)b * G + min(gb + q, G - 1)];
       s[q] = 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
+    for (int q = 0; q < UNR; ++q) id[q] = UR_ROW(id[q], n_items);
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
       const int col = t + k * TPR;
       if (col < d4) {
         float4 e[UNR];
@@ -86,15 +93,22 @@ __global__ __launch_bounds__(NT) void scorer_loss_fwd_kernel(UrLossCfg c, const 
         if (g < G) {
           float v = s[q] + ub;
           if (item_bias) v += item_bias[id[q]];
-          v = v / c.tau;
-          if (c.score_clip > 0.f) v = fminf(fmaxf(v, -c.score_clip), c.score_clip);
           sc[g] = v;
-          scores[(long long)b * G + g] = v;
         }
       }
     }
   }
   (void)inv_tau;
+  __syncthreads();
+  // the division by tau, the clip and the stores in ONE coalesced pass over the row's LDS copy, every thread at work: a 4-byte store per
+  // candidate row from inside the gather loop cost the gather 5-7 % (tools/probe/scorer_probe.hip "V2 without the global score store" =
+  // the random-row ceiling, profiles/r05_d_*), and the divide ran on one lane of 32 there.  Same operations per score, same order.
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float v = sc[g] / c.tau;
+    if (c.score_clip > 0.f) v = fminf(fmaxf(v, -c.score_clip), c.score_clip);
+    sc[g] = v;
+    scores[(long long)b * G + g] = v;
+  }
   __syncthreads();
   // ---- per-row loss
   float part = 0.f, cnt = 0.f;
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
   }
 }
 
-template <int TPR, int NT>
+template <int TPR, int NT, int KV>   // KV: float4 chunks of a row per lane (see the forward kernel)
 __global__ __launch_bounds__(NT) void scorer_loss_bwd_kernel(UrLossCfg c, const float4* __restrict__ user_emb,
                                                               const float4* __restrict__ table, const long long* __restrict__ item_id,
                                                               const int* __restrict__ label, const float* __restrict__ scores,
@@ -224,21 +238,23 @@ __global__ __launch_bounds__(NT) void scorer_loss_bwd_kernel(UrLossCfg c, const 
   }
   __syncthreads();
   // ---- d_user[b,:] = sum_g coef[g] * E[item_id[b,g],:]
-  float4 acc[MAXV];
+  float4 acc[KV];
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int UNR = 4;   // candidate rows in flight per lane group (see the forward kernel)
+  for (int k = 0; k < KV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int UNR = KV == 1 ? 8 : 4;   // candidate rows in flight per lane group (see the forward kernel; 8 where one chunk per lane leaves the registers)
   for (int gb = g0 * UNR; gb < G; gb += groups * UNR) {
     long long id[UNR];
     float w[UNR];
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
       const bool in = gb + q < G;
-      id[q] = in ? UR_ROW(item_id[(long long)b * G + gb + q], n_items) : 0;
+      id[q] = item_id[(long long)b * G + min(gb + q, G - 1)];   // (unconditional, clamped position: see the forward kernel)
       w[q] = in ? cf[gb + q] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
+    for (int q = 0; q < UNR; ++q) id[q] = UR_ROW(id[q], n_items);
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
       const int col = t + k * TPR;
       if (col < d4) {
         float4 e[UNR];
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(NT) void scorer_loss_bwd_kernel(UrLossCfg c, const 
     }
   }
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
+  for (int k = 0; k < KV; ++k) {
     const int col = t + k * TPR;
     if (col < d4) *(float4*)(acc_lds + g0 * d + col * 4) = acc[k];
   }
@@ -310,9 +326,13 @@ __global__ __launch_bounds__(256) void scorer_loss_fused_kernel(UrLossCfg c, flo
     float s[UNR];
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
-      id[q] = (gb + q < G) ? UR_ROW(item_id[(long long)b * G + gb + q], n_items) : 0;
+      // unconditional loads at a clamped position, the range check behind ALL of them: a load inside a select is branched around and
+      // waited for on the spot (eight dependent round trips per trip: measured -5 % on the gather, profiles/r05_d_scorer_probe.txt)
+      id[q] = item_id[(long long)b * G + min(gb + q, G - 1)];
       s[q] = 0.f;
     }
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) id[q] = UR_ROW(id[q], n_items);
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int col = t + k * TPR;
@@ -475,9 +495,11 @@ extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_em
   const size_t lds = (cfg->G + 16) * sizeof(float);
   const bool wide = cfg->G >= 512 && cfg->B <= 512;   // few rows, many candidates: 1024-thread workgroups
   float* cnt_rows = loss_rows + cfg->B;  // loss_rows buffer is [2*B]: losses then counts
-#define GO2(T, U, NT) hipLaunchKernelGGL((scorer_loss_fwd_kernel<T, U, NT>), dim3(cfg->B), dim3(NT), lds, st, *cfg, (const float4*)user_emb, \
+  const int kv = cdiv(cfg->d / 4, tpr);   // float4 chunks per lane (1 for d <= 128)
+#define GO3(T, U, NT, KV_) hipLaunchKernelGGL((scorer_loss_fwd_kernel<T, U, NT, KV_>), dim3(cfg->B), dim3(NT), lds, st, *cfg, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, user_bias, item_bias,            \
                                  (const long long*)user_id, scores, loss_rows, cnt_rows, (long long)n_items)
+#define GO2(T, U, NT) do { if (kv <= 1) GO3(T, U, NT, 1); else if (kv == 2) GO3(T, U, NT, 2); else GO3(T, U, NT, 4); } while (0)
 #define GO1(T, U) do { if (wide) GO2(T, U, 1024); else GO2(T, U, 256); } while (0)
 #define GO(T) GO1(T, 8)   /* 8 candidate rows in flight per lane group (2 / 4 / 16 measured slower: round 1) */
   switch (tpr) {
@@ -487,6 +509,9 @@ extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_em
     default: GO(32); break;
   }
 #undef GO
+#undef GO1
+#undef GO2
+#undef GO3
   UR_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, loss_rows, cnt_rows, cfg->B, loss_out);
   UR_LAUNCH_CHECK();
@@ -511,10 +536,12 @@ extern "C" int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_em
   const int groups = (wide ? 1024 : 256) / tpr;
   const size_t lds = ((size_t)cfg->G + (size_t)groups * cfg->d + 16) * sizeof(float);
   UR_REQUIRE(lds <= 64 * 1024, UR_ERR_UNSUPPORTED, "ur_gather_dot_loss_bwd: LDS need %zu bytes", lds);
+  const int kv = cdiv(cfg->d / 4, tpr);
 #define GO(T) do { if (wide) GOB(T, 1024); else GOB(T, 256); } while (0)
-#define GOB(T, NT) hipLaunchKernelGGL((scorer_loss_bwd_kernel<T, NT>), dim3(cfg->B), dim3(NT), lds, st, *cfg, (const float4*)user_emb, \
+#define GOK(T, NT, KV_) hipLaunchKernelGGL((scorer_loss_bwd_kernel<T, NT, KV_>), dim3(cfg->B), dim3(NT), lds, st, *cfg, (const float4*)user_emb, \
                                  (const float4*)item_table, (const long long*)item_id, label, scores, d_loss, loss_out, coef,  \
                                  (float4*)d_user, d_user_bias_rows, (long long)n_items)
+#define GOB(T, NT) do { if (kv <= 1) GOK(T, NT, 1); else if (kv == 2) GOK(T, NT, 2); else GOK(T, NT, 4); } while (0)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;

@@ -67,21 +67,6 @@ class SparseDenseAdam:
         # next step (`plan_batch`)
         self._dense_side = dense_side or ""
         self._prefetched, self._side = None, None
-        # The row update of step t beside the forward pass of step t + 1 (round 4).  With the NEXT batch's plan in hand (prefetch_plan),
-        # this step's unique rows split into the few the next batch reads too ("hot": reduced and updated on the main stream, at once)
-        # and the rest, whose reduction and update go to a third stream ("tail") that nobody waits for: the next forward pass reads
-        # none of them, the planning stream waits for the tail before it touches optimizer state, and the main stream makes sure the
-        # tail of step t - 1 is done before step t + 1's forward pass is enqueued.  The next batch's OTHER rows take their missed
-        # zero-gradient steps, this one included, a step ahead on the planning stream (the step in flight gives them a zero gradient by
-        # construction).  MEASURED AND NOT THE DEFAULT (profiles/r04_c_experiments.txt, 1): the main stream then simply waits -- 66 us -- for
-        # the dense half on the encoder's side stream, the OTHER chain of the step boundary, and the forward pass loses 12 us to the
-        # row work beside it: 0.549 -> 0.566 ms/step.  UR_TAIL_OVERLAP=1 switches it on (tests/test_catchup_ahead_gpu.py keeps it exact).
-        self.overlap_tail = (os.environ.get("UR_TAIL_OVERLAP", "0") not in ("", "0") and self.grad_clip is None
-                             and getattr(model, "loss_type", None) != "fullsoftmax" and model.device.type == "cuda")
-        self._tail, self._tail_ev, self._tail_hold = None, None, collections.deque()
-        if self.overlap_tail:
-            object.__setattr__(model, "_row_tail_join", self._join_tail)     # model.state_dict() / train() / eval() join it
-        self._tail_safe_key = None        # ids key of the prefetched plan whose split was made against the plans of the deferred step
         self._scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [0] sumsq, [1] clip coef
         self._sumsq_ws = torch.empty(2048, dtype=torch.float32, device=dev)
         self.param_groups = [dict(lr=lr)]  # enough of torch's surface for schedulers / logging
@@ -95,15 +80,8 @@ class SparseDenseAdam:
         self.model.sparse_grads.clear()
         self.model.dense_table_grads.clear()
 
-    def _join_tail(self):
-        """the current stream waits for the deferred row updates (the tail stream): in front of anything that reads tables or row state"""
-        if self._tail_ev is not None:
-            torch.cuda.current_stream().wait_event(self._tail_ev)
-            self._tail_ev, self._tail_safe_key = None, None
-
     def state_dict(self):
         self.model.join_side_updates()
-        self._join_tail()
         return dict(t=self.t, dense_m=self.dense_m, dense_v=self.dense_v, param_groups=self.param_groups,
                     tables={k: {kk: vv for kk, vv in v.items() if kk != "w"} for k, v in self.tables.items()})
 
@@ -150,42 +128,12 @@ class SparseDenseAdam:
         req = self._plan_inputs(item_seq, item_id, user_id)
         bufs = {name: ops.rows_plan_alloc((a.numel() if a is not None else 0) + (b.numel() if b is not None else 0),
                                           a.numel() if a is not None else 0, self.model.device) for name, (a, b) in req.items()}
-        # hot / cold split of the next batch's rows against the step in flight's (its plans are self._plans: plan_batch ran)
-        do_split = self.overlap_tail and bool(self._plans) and all(name in self._plans for name in req)
-        split_bufs = {}
-        if do_split:
-            dev = self.model.device
-            for name in req:
-                n_next, n_cur = bufs[name][0].n, self._plans[name].n
-                lst = []
-                for _ in range(2):
-                    o = ops.RowsPlan()
-                    o.n, o.n_a, o.seg_start, o.sorted_pos = n_next, 0, None, None
-                    o.uniq_idx = torch.empty(n_next, dtype=torch.int32, device=dev)
-                    o.n_uniq = torch.empty(1, dtype=torch.int32, device=dev)
-                    lst.append(o)
-                split_bufs[name] = (lst[0], lst[1], torch.empty(n_next, dtype=torch.int32, device=dev),
-                                    torch.empty(n_cur, dtype=torch.int32, device=dev))
         # (through an event without the system-scope fence: ~2 us cheaper on the recording stream than Stream.wait_stream)
         ops.stream_wait_stream(self._side, main)   # the ids may still be in flight (H2D copy) on the main stream; `last` is being updated there
-        if do_split and self._tail is not None:
-            ops.stream_wait_stream(self._side, self._tail)   # deferred row updates of the previous step: rows the catch-up below may touch
-        ahead, split = None, None
         with torch.cuda.stream(self._side):
             plans = {name: ops.rows_plan(a, b, self.tables[name]["w"].shape[0], out=bufs[name]) for name, (a, b) in req.items()}
             filtered = None
-            if do_split:
-                split = {}
-                lazy = self.table_mode == "lazy_dense"
-                cfg = self._cfg(self.t + 2)     # the state after the step in flight (self.t + 1)
-                for name, pl in plans.items():
-                    st = self.tables[name]
-                    last = st["last"] if (lazy and self.wd == 0.0) else None
-                    split[name] = ops.rows_split_hot(pl, last, self._plans[name], out=split_bufs[name], want_u=True)
-                    if lazy and st["last"] is not None:   # rows the step in flight does not touch: their zero-gradient steps, that one included
-                        ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], split[name][0])
-                ahead = self.t + 1
-            elif self.table_mode == "lazy_dense" and self.wd == 0.0:
+            if self.table_mode == "lazy_dense" and self.wd == 0.0:
                 # rows of the next batch that have any optimizer history at all: the catch-up at the tail of this step only walks those
                 # (a row first touched by the step in flight is missed here and needs no catch-up: its update leaves it current)
                 filtered = {name: ops.rows_filter_touched(pl, self.tables[name]["last"]) for name, pl in plans.items()
@@ -194,7 +142,7 @@ class SparseDenseAdam:
             ev.record(self._side)
         # keep ids + workspaces alive until the plan is adopted (the side stream reads / writes them asynchronously)
         # (and the in-flight step's plans: the catch-up reads their row lists after step() has dropped them)
-        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev, (req, bufs, dict(self._plans)), ahead, filtered, split)
+        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev, (req, bufs, dict(self._plans)), None, filtered)
 
     def plan_batch(self, item_seq=None, item_id=None, user_id=None):
         """Sort/unique the ids this batch will look up (or adopt the plan `prefetch_plan` made for the same tensors);
@@ -211,11 +159,8 @@ class SparseDenseAdam:
         caught_up = False
         if pre is not None and pre[0] == self._ids_key(item_seq, item_id, user_id):
             self._plans = pre[1]
-            caught_up = pre[4] == self.t      # the side stream already brought these rows to the state after step t
-            if self._tail_ev is not None and self._tail_safe_key != pre[0]:
-                self._join_tail()
+            caught_up = pre[4] == self.t      # the tail of the previous step() already brought these rows to the state after step t
         else:
-            self._join_tail()                 # (rows of an unplanned batch may be among the deferred updates)
             self._plans = self._make_plans(item_seq, item_id, user_id)
         if self.table_mode == "lazy_dense" and self.t > 0 and not caught_up:
             cfg = self._cfg(self.t + 1)
@@ -247,7 +192,6 @@ class SparseDenseAdam:
     def flush(self):
         """lazy_dense: apply all pending zero-gradient steps to every row (before eval / checkpoint)."""
         ops.id_guard_check()      # (an out-of-range id of the last steps: IndexError before anything is evaluated or saved)
-        self._join_tail()
         if self.table_mode != "lazy_dense" or self.t == 0:
             return
         self.model.join_side_updates()
@@ -259,7 +203,6 @@ class SparseDenseAdam:
     def mark_tables_current(self):
         """The table rows were just replaced from outside (checkpoint load): they are up to date as of step ``t``, so no
         zero-gradient replay is pending for any of them."""
-        self._join_tail()
         for st in self.tables.values():
             if st["last"] is not None:
                 st["last"].fill_(self.t)
@@ -289,17 +232,6 @@ class SparseDenseAdam:
         cfg = self._cfg(self.t)
         reduced = {}
         guard = getattr(model, "loss_guard", None)
-        # ---- the deferred form (see __init__: overlap_tail): possible when the NEXT batch's plan was split against this step's plans
-        pre = self._prefetched
-        split = pre[6] if (pre is not None and len(pre) > 6 and late_join and self.overlap_tail and not model.dense_table_grads) else None
-        if split is not None and any(self._plans.get(n) is None or n not in split for n in self._plans):
-            split = None
-        while self._tail_hold and self._tail_hold[0][0].query():    # what finished tails were reading
-            self._tail_hold.popleft()
-        if self._tail_ev is not None:      # the tail of the step before: done before this step's updates, and before the next forward pass
-            torch.cuda.current_stream().wait_event(self._tail_ev)
-            self._tail_ev = None
-        deferred = []
         for name, st in self.tables.items():
             ids_a, rows, ids_b, coef, vec, G = self._collect(name)
             if ids_a is None and ids_b is None:
@@ -310,27 +242,7 @@ class SparseDenseAdam:
                     raise RuntimeError("lazy_dense mode: call optimizer.plan_batch(...) before the forward pass")
                 pl = ops.rows_plan(ids_a.contiguous() if ids_a is not None else None, ids_b, st["w"].shape[0])
             d = st["w"].shape[1]
-            if split is not None and name in split:
-                _, hot, hot_u, mark = split[name]
-                ug_hot = ops.rows_reduce_subset(pl, rows, coef, vec, G, d, hot_u, hot.n_uniq, hot.n)
-                ops.sparse_adam_rows_split(cfg, st["w"], st["m"], st["v"], hot, ug_hot, st["last"], guard, hot=True)
-                deferred.append((name, st, pl, rows, coef, vec, G, d, mark))
-                continue
             reduced[name] = (pl, ops.rows_reduce(pl, rows, coef, vec, G, d, zero_tail=self.grad_clip is not None))
-        if deferred:
-            main = torch.cuda.current_stream()
-            if self._tail is None:
-                self._tail = torch.cuda.Stream(device=model.device)
-            ops.stream_wait_stream(self._tail, main)     # the backward pass's row gradients, the loss guard, the hot rows' update
-            with torch.cuda.stream(self._tail):
-                for name, st, pl, rows, coef, vec, G, d, mark in deferred:
-                    ug = ops.rows_reduce(pl, rows, coef, vec, G, d)
-                    ops.sparse_adam_rows_split(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], guard, hot=False, skip_mark=mark)
-                ev = torch.cuda.Event()
-                ev.record(self._tail)
-            # (tensors of the main stream's allocator that the tail reads: held until its event has completed)
-            self._tail_hold.append((ev, deferred, guard, split, dict(self._plans)))
-            self._tail_ev, self._tail_safe_key = ev, pre[0]
         # fullsoftmax: the table's gradient is dense; the encoder's row-sparse part is folded into it
         dense_tables = dict(model.dense_table_grads)
         for name, dg in dense_tables.items():
@@ -348,14 +260,6 @@ class SparseDenseAdam:
                 st = self.tables[name]
                 ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
             sparse_done = True
-            if not deferred and pre is not None and len(pre) > 6 and pre[6] is not None and self.table_mode == "lazy_dense":
-                # the next batch's rows were split but this step's update was not (no step follows at once): its rows that are also the
-                # next batch's are current after the update above -- unless the step was skipped; then they take it as a zero-gradient step
-                nxt = self._cfg(self.t + 1)
-                for name, sp in pre[6].items():
-                    st = self.tables[name]
-                    if st["last"] is not None:
-                        ops.lazy_adam_catchup(nxt, st["w"], st["m"], st["v"], st["last"], sp[1])
             self._catchup_prefetched()
         side = None
         if (self.grad_clip is None and dense_side in ("late", "join") and getattr(model, "_deferred_dense_grad", None) is not None
