@@ -225,7 +225,7 @@ int ur_sasrec_set_side_stream(int on);
  * bits 8 / 16; d in {64, 128}, head dim 4 / 8 / 16, 8 <= L <= 64, inner_size 256 / 512): the WHOLE last-row layer as two launches --
  * query projection, one-query attention, out-projection, feed-forward for the B last rows (unirec/model/modules.py:284-316, 347-355,
  * row L-1 only: unirec/model/sequential/sasrec.py:75), and their mirror image including the layer's full input gradient.  Returns the previous mask.  The default mask and the
- * measurements behind it: DESIGN.md section 6d; environment UR_SASREC_CHAIN=<mask>. */
+ * measurements behind it: DESIGN.md section 6d; test hook UR_TEST=chain_mask=<mask>. */
 int ur_sasrec_set_chain(int mask);
 
 /* ---------------------------------------------------------------------------------------------
@@ -465,12 +465,8 @@ int ur_rows_reduce_riders(const int32_t* uniq_idx, const int32_t* seg_start, con
                           int64_t n, const float* rows_a, int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d,
                           float* uniq_grad, float* sumsq_dev, const int32_t* out_rows, int32_t world, int32_t cap,
                           float* step_flags_out4, int32_t write_flag_rows, const float* loss_out, const int32_t* flags_dev, void* stream);
-int ur_rows_reduce_subset(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev,
-                          int64_t n, const float* rows_a, int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d,
-                          const int32_t* u_list, const int32_t* n_list_dev, int64_t n_list_max, float* out, void* stream);
-int ur_sparse_adam_rows_split(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, const int32_t* uniq_idx,
-                              const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad, int32_t d, const float* grad_scale_dev,
-                              int32_t hot, const int32_t* skip_mark, void* stream);
+
+
 /* out_idx[0 .. *out_n_dev) = the rows of uniq_idx[0 .. *n_uniq_dev) that were ever updated (last_step != 0), in arbitrary order: with
  * weight_decay == 0 the only rows ur_lazy_adam_catchup has work for.  Made next to the plan (side stream), it keeps the catch-up of a
  * batch of never-seen rows -- a chain of random last_step reads and nothing else -- off the main stream.  out_idx: n_max ints. */

@@ -30,11 +30,6 @@ def _batches(n, B=16, L=10, N=300, seed=0):
     return out
 
 
-@pytest.fixture(autouse=True)
-def _tail_overlap_on(monkeypatch):
-    monkeypatch.setenv("UR_TAIL_OVERLAP", "1")      # (read by SparseDenseAdam.__init__; the "defer" runs need it, the others ignore it)
-
-
 def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14, nan_at=None, table_mode="lazy_dense"):
     """ahead: False = catch-up at the head of the next step (no plan lookahead), "tail" = on the main stream between the row update and
     the join of the dense-gradient stream (what a prefetched plan gives)"""
@@ -59,9 +54,8 @@ def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14, nan_at=None, ta
         loss = model.forward_backward(item_id=b["item_id"], label=lab, item_seq=b["item_seq"])
         if nan_at == s:                       # a NaN loss: the update kernels read the guard and skip the step
             model.loss_guard.fill_(-1.0)
-        # "defer": the loop says another step follows (as Trainer.fit / bench.py do): the rows the next batch does not read are reduced
-        # and updated on the optimizer's tail stream, beside the next forward pass; the others at once, on the main stream
-        opt.step(late_join=(ahead == "defer" and s + 1 < n_steps))
+        # "late": the loop says another step follows (as Trainer.fit / bench.py do): the next forward pass joins the dense half
+        opt.step(late_join=(ahead == "late" and s + 1 < n_steps))
         losses.append(float(loss))
     opt.flush()
     torch.cuda.synchronize()
@@ -72,7 +66,7 @@ def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14, nan_at=None, ta
 @pytest.mark.parametrize("algo,wd", [("adam", 0.0), ("adamw", 0.01), ("adam", 0.001), ("rmsprop", 0.0)])
 def test_catchup_ahead_is_bit_identical(algo, wd):
     b = _train(False, algo, wd)
-    for mode in ("tail", "defer"):
+    for mode in ("tail", "late"):
         a = _train(mode, algo, wd)
         assert a[0] == b[0]
         for x, y, what in zip(a[1:], b[1:], ("w", "m", "v", "dense")):
@@ -83,7 +77,7 @@ def test_a_prefetched_batch_that_is_not_trained_on_changes_nothing():
     """rows caught up for a batch that is then not trained on are simply up to date earlier: the same zero-gradient steps, summed in
     two pieces instead of one (fp32 re-association of the replay sum: a few ulp of an lr-sized term, not bit-equal)"""
     c = _train(False)
-    for mode in ("tail", "defer"):
+    for mode in ("tail", "late"):
         a = _train(mode, swap_at=5)
         for x, z, what in zip(a[1:4], c[1:4], ("w", "m", "v")):
             assert torch.allclose(x, z, rtol=1e-4, atol=1e-6), (mode, what, float((x - z).abs().max()))
@@ -143,13 +137,11 @@ def test_dense_half_on_the_side_stream_is_bit_identical():
 
 
 @pytest.mark.parametrize("table_mode", ["lazy_dense", "rowwise"])
-def test_deferred_row_update_with_a_skipped_step_is_bit_identical(table_mode):
-    """The row update split over the main stream (rows the next batch reads as well) and the tail stream (the rest, beside the next
-    forward pass), with a step whose NaN guard skips the update in the middle: the rows two batches share take the skipped step as a
-    zero-gradient step (as every row the step does not touch), the others are left alone -- the trajectory of catching up at the head
-    of the next step, bit for bit.  300 rows, 16 x 15 lookups per batch: about half of a batch's rows are the next one's too."""
+def test_a_skipped_step_in_the_middle_is_bit_identical_with_the_lookahead(table_mode):
+    """a step whose NaN guard skips the update, in the middle of a run with the plan lookahead and the late join: the rows the next batch
+    reads take the skipped step as a zero-gradient step -- the trajectory of catching up at the head of the next step, bit for bit"""
     b = _train(False, nan_at=6, table_mode=table_mode)
-    a = _train("defer", nan_at=6, table_mode=table_mode)
+    a = _train("late", nan_at=6, table_mode=table_mode)
     assert a[0] == b[0]
     for x, y, what in zip(a[1:], b[1:], ("w", "m", "v", "dense")):
         assert torch.equal(x, y), (what, float((x - y).abs().max()))

@@ -278,11 +278,11 @@ def test_sharded_two_phase_count_equals_the_whole_catalogue(d, W, with_bias):
 
 @pytest.mark.gpu
 def test_topk_candidate_overflow_falls_back_to_the_chunked_path():
-    """UR_TOPK_CAP=16 forces every row's candidate list of the pruned path to overflow; the result must still be the oracle's."""
+    """UR_TEST=topk_cap=16 forces every row's candidate list of the pruned path to overflow; the result must still be the oracle's."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, UR_TOPK_CAP="16")
+    env = dict(os.environ, UR_TEST="topk_cap=16")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
                         "test_gpu_topk_matches_oracle and 3200003"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

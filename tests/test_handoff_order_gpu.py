@@ -1,12 +1,11 @@
 """Cross-workgroup hand-offs ("the workgroup that arrives last finishes the job": the fused scorer's batch loss / NaN guard, the split
-last-row chain kernels' partial tiles) under arrival skew, in both memory orders.
+last-row chain kernels' partial tiles) under arrival skew.
 
-Default: the arrival counter is incremented with a RELEASE-ACQUIRE device-scope RMW (csrc/common.h: ur_arrive) -- the form the HIP
-memory model recognises; the data travels in device-scope RMWs whose old values have returned before the arrival.  UR_STRICT_ORDER=0
-is rounds 2-3's relaxed arrival, resting on that ISA-level behaviour alone.  UR_ARRIVAL_SKEW_US=k delays every workgroup's arrival
-by (hash of the workgroup) % k microseconds, so the last arriver -- and the XCD it sits on -- changes from launch to launch while
-the partial buffers still hold the previous launch's values.  All three processes must produce the same bits: the summation order
-is fixed (index order), so any stale read shows up as a different bit pattern."""
+The arrival counter is incremented with a RELEASE-ACQUIRE device-scope RMW (csrc/common.h: ur_arrive) -- the form the HIP memory model
+recognises; the data travels in device-scope RMWs whose old values have returned before the arrival.  UR_TEST=arrival_skew_us=k delays every
+workgroup's arrival by (hash of the workgroup) % k microseconds, so the last arriver -- and the XCD it sits on -- changes from launch to
+launch while the partial buffers still hold the previous launch's values.  Every process must produce the same bits: the summation
+order is fixed (index order), so any stale read shows up as a different bit pattern."""
 import os
 import subprocess
 import sys
@@ -54,8 +53,7 @@ print("DIGEST", h.hexdigest())
 
 def _run(**env):
     e = dict(os.environ)
-    e.pop("UR_STRICT_ORDER", None)
-    e.pop("UR_ARRIVAL_SKEW_US", None)
+    e.pop("UR_TEST", None)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, "-c", CHILD], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -63,8 +61,7 @@ def _run(**env):
 
 
 @pytest.mark.gpu
-def test_handoffs_give_the_same_bits_under_arrival_skew_and_in_both_memory_orders():
-    base = _run()                                                      # release-acquire arrival (the default)
-    assert _run(UR_ARRIVAL_SKEW_US=30) == base                         # ... with the last arriver spread over the XCDs
-    assert _run(UR_STRICT_ORDER=0) == base                             # relaxed arrival (rounds 2-3)
-    assert _run(UR_STRICT_ORDER=0, UR_ARRIVAL_SKEW_US=30) == base
+def test_handoffs_give_the_same_bits_under_arrival_skew():
+    base = _run()
+    assert _run(UR_TEST="arrival_skew_us=30") == base                  # the last arriver spread over the XCDs
+    assert _run(UR_TEST="arrival_skew_us=200") == base

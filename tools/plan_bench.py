@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of ur_rows_plan (the batch's id sort + segment heads).  UR_PLAN_MULTI=1 forces the multi-launch path."""
+"""Micro-benchmark of ur_rows_plan (the batch's id sort + segment heads).  UR_TEST=plan_multi forces the multi-launch path."""
 import os
 import sys
 import json
@@ -27,7 +27,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         print(json.dumps({"op": "ur_rows_plan", "n": B * (L + G), "n_rows": N, "us": round(e0.elapsed_time(e1) / reps * 1e3, 1),
-                          "n_uniq": int(pl.n_uniq.item()), "multi": bool(os.environ.get("UR_PLAN_MULTI"))}))
+                          "n_uniq": int(pl.n_uniq.item()), "multi": "plan_multi" in os.environ.get("UR_TEST", "")}))
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ cd $GRAFT_REPO_ROOT
 TAILN=100 bash tools/timeline.sh > $out/${tag}_timeline.txt 2>&1
 head -8 $out/${tag}_timeline.txt
 cat $out/${tag}_sharded_w1.txt
-(UR_PLAN_MULTI=1 python tools/plan_bench.py; python tools/plan_bench.py) 2>/dev/null | grep ur_rows_plan > $out/${tag}_plan_bench.txt
-(python tools/probe/gru_host.py 768; UR_GRU_NO_STEP=1 python tools/probe/gru_host.py 768; python tools/gru_bench.py --hidden 768 --steps 30 | tail -1; UR_GRU_NO_STEP=1 python tools/gru_bench.py --hidden 768 --steps 30 | tail -1) 2>/dev/null | grep -v amdgpu.ids > $out/${tag}_gru_h768.txt
+(UR_TEST=plan_multi python tools/plan_bench.py; python tools/plan_bench.py) 2>/dev/null | grep ur_rows_plan > $out/${tag}_plan_bench.txt
+(python tools/probe/gru_host.py 768; UR_TEST=gru_no_step python tools/probe/gru_host.py 768; python tools/gru_bench.py --hidden 768 --steps 30 | tail -1; UR_TEST=gru_no_step python tools/gru_bench.py --hidden 768 --steps 30 | tail -1) 2>/dev/null | grep -v amdgpu.ids > $out/${tag}_gru_h768.txt
 (for m in "" 0; do UR_PREFETCH_ROWS=${m:-1} python bench.py --no-extra-legs --no-cpu-baseline --no-gather-bench --steps 200 --warmup 30 --sharded-w1 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sharded_w1 UR_PREFETCH_ROWS=${m:-1}', j['ms_per_step'], j['final_loss'])"; done) >> $out/${tag}_sharded_w1.txt
 cat $out/${tag}_plan_bench.txt $out/${tag}_gru_h768.txt

@@ -112,8 +112,6 @@ SIGNATURES = {
     "ur_shard_fixup_apply": (C.c_int, [P, P, P, I32, I32, I32, I32, P]),
     "ur_rows_split_hot": (C.c_int, [P, P, I64, P, P, P, I64, P, P, P, P, P, P, P]),
     "ur_rows_reduce_riders": (C.c_int, [P, P, P, P, I64, P, I64, P, P, I32, I32, P, P, P, I32, I32, P, I32, P, P, P]),
-    "ur_rows_reduce_subset": (C.c_int, [P, P, P, P, I64, P, I64, P, P, I32, I32, P, P, I64, P, P]),
-    "ur_sparse_adam_rows_split": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, P, I32, P, I32, P, P]),
     "ur_rows_reduce": (C.c_int, [P, P, P, P, I64, P, I64, P, P, I32, I32, P, P, P, P]),
     "ur_dense_adam": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, P, P]),
     "ur_sparse_adam_rows": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, P, I32, P, P]),

@@ -700,351 +700,9 @@ long long attn_lse_floats(int B, int H, int L) { return (long long)B * H * L; }
 long long attn_bwd_ws_floats(int B, int H, int L) { return (long long)B * H * L + 64; }
 
 // ------------------------------------------------------------------------------------------------------------
-// MFMA forward for short sequences (L <= 64) and small heads (head dim 4 / 8 / 16): one wave per (sequence, head).
-//   S^T[j,i] = K_j . Q_i   : v_mfma_f32_32x32x2_f32 with A = K rows, B = Q rows; the k index of an MFMA step is a
-//                            free permutation, so lane-half h2 feeds dims [h2*HD/2, (h2+1)*HD/2) (one vector load).
-//                            Accumulator register r of lane (i = lane&31, h2) is key j = (r&3)+8*(r>>2)+4*h2:
-//                            every lane owns ONE query and 16 keys per 32x32 tile -> the softmax is lane-local plus
-//                            one cross-half shuffle.
-//   O^T[c,i] = sum_j V[j,c] P[i,j] : the probabilities are used AS THEY SIT in the accumulators as the B operand of
-//                            step r (again a k permutation: step r <-> keys {(r&3)+8*(r>>2)+4*h2}); A = V gathered in
-//                            that key order.  Lane (i, h2) ends with O[i, 4*h2 .. 4*h2+3] (+8 for HD = 16): one
-//                            16-byte store.
-// Masks, dead rows and the literal (-10000) path of an all-padding sequence are those of attn_fwd_rl_kernel.
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-template <int HD, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, const int* __restrict__ seq, AttnDims p,
-                                                            float* __restrict__ ctx, float* __restrict__ lse) {
-  constexpr int KH = HD / 2;
-  const int lane = threadIdx.x & 63;
-  const int h = UR_UNIFORM((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
-  if (h >= p.H) return;
-  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
-  const int c32 = lane & 31, h2 = lane >> 5;
-  long long row0;
-  int pad;
-  seq_rows(p, b, row0, pad);
-  const float* __restrict__ base = qkv + row0 * ld + h * HD;
-  const int* __restrict__ sq = seq + (long long)b * L;
-  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
-  const bool literal = fv >= L;
-  const bool causal = p.causal && !literal;
-  const unsigned long long kmask = __ballot(lane < L && (literal || sq[min(lane, L - 1)] > 0));   // bit j: key j may be attended
-  const int nt = L > 32 ? 2 : 1;   // 32-row tiles along keys and queries
-
-  // all global loads of the wave are issued here, in one batch: Q / K fragments and V as whole rows (lane = key);
-  // V reaches its MFMA operand layout through a 64 x HD LDS tile (one global round trip per wave instead of three)
-  __shared__ float vs_all[4][64][HD + 1];
-  float (*vs)[HD + 1] = vs_all[threadIdx.x >> 6];
-  float qf[2][KH], kf[2][KH], vrow[HD];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int row = max(min(t * 32 + c32, L - 1), pad);
-#pragma unroll
-    for (int c = 0; c < KH; ++c) {
-      qf[t][c] = base[(long long)row * ld + h2 * KH + c];
-      kf[t][c] = base[(long long)row * ld + p.d + h2 * KH + c];
-    }
-  }
-  {
-    const int row = max(min(lane, L - 1), pad);
-#pragma unroll
-    for (int c = 0; c < HD; ++c) vrow[c] = base[(long long)row * ld + 2 * p.d + c];
-#pragma unroll
-    for (int c = 0; c < HD; ++c) vs[lane][c] = vrow[c];
-  }
-  // ---- scores (transposed): st[jt][it][r] = K_{32 jt + jl(r)} . Q_{32 it + c32}
-  floatx16 st[2][2];
-#pragma unroll
-  for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[jt][it][r] = 0.f;
-      if (jt < nt && it < nt && !(causal && jt > it)) {   // wave-uniform; (key tile 1, query tile 0) is fully causal-masked
-#pragma unroll
-        for (int c = 0; c < KH; ++c) st[jt][it] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[jt][c], qf[it][c], st[jt][it], 0, 0, 0);
-      }
-    }
-  // ---- lane-local softmax over this lane's keys, both halves combined with one shuffle.  Work in base 2:
-  // p = 2^(s*log2e - m2).  Visibility of key j = 32 jt + jl + 4 h2 for query i = 32 it + c32 is a bit test on a
-  // per-lane 32-bit mask (key validity & causal limit), jl = (r&3) + 8 (r>>2) being a compile-time constant.
-  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-  const unsigned km[2] = {(unsigned)(kmask >> (4 * h2)), (unsigned)(kmask >> (32 + 4 * h2))};
-  const int lim = c32 - 4 * h2;                                  // diagonal tiles: jl <= lim
-  const unsigned cm = !causal ? 0xFFFFFFFFu : (lim < 0 ? 0u : (lim >= 31 ? 0xFFFFFFFFu : ((2u << lim) - 1u)));
-  const float sc2 = p.scale * LOG2E;
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    if (it >= nt) break;
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-      if (jt >= nt || (causal && jt > it)) continue;
-      const unsigned vis = km[jt] & ((causal && jt == it) ? cm : 0xFFFFFFFFu);
-      if (literal) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float sv = (st[jt][it][r] / p.sqrt_hd + -10000.0f) * LOG2E;
-          st[jt][it][r] = (vis >> ((r & 3) + 8 * (r >> 2))) & 1u ? sv : -INFINITY;
-          m[it] = fmaxf(m[it], st[jt][it][r]);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          st[jt][it][r] = (vis >> ((r & 3) + 8 * (r >> 2))) & 1u ? st[jt][it][r] * sc2 : -INFINITY;
-          m[it] = fmaxf(m[it], st[jt][it][r]);
-        }
-      }
-    }
-    m[it] = fmaxf(m[it], __shfl_xor(m[it], 32, 64));
-    const float mm = m[it] == -INFINITY ? 0.f : m[it];   // dead row: every exponent is -inf -> p = 0
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-      if (jt >= nt || (causal && jt > it)) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(st[jt][it][r] - mm);   // v_exp_f32; exp2(-inf) = 0 for masked keys
-        st[jt][it][r] = pv;
-        l[it] += pv;
-      }
-    }
-    l[it] += __shfl_xor(l[it], 32, 64);
-    if constexpr (DROP) {   // dropout on the probabilities (the normaliser l is that of the undropped softmax)
-      const unsigned rk = attn_rowkey(p, b, h, it * 32 + c32);
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        if (jt >= nt || (causal && jt > it)) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          st[jt][it][r] *= drop_mul(rk, (unsigned)(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2), p.dthresh, p.dscale);
-      }
-    }
-  }
-  // ---- O^T = V^T P^T
-  floatx16 oa[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oa[it][r] = 0.f;
-#pragma unroll
-  for (int jt = 0; jt < 2; ++jt) {
-    if (jt >= nt) break;
-    float vf[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;   // keys >= L carry probability 0 (their LDS rows repeat row L-1)
-      vf[r] = c32 < HD ? vs[j][c32] : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      if (it >= nt || (causal && jt > it)) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oa[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[jt][it][r], oa[it], 0, 0, 0);
-    }
-  }
-  // ---- normalise and store: lane (i, h2) holds O[i, 4*h2 + (0..3)] in oa[.][0..3] (and 8 + ... in [4..7] for HD = 16)
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int i = it * 32 + c32;
-    if (it >= nt || i >= L || i < pad) continue;
-    const bool dead = l[it] == 0.f;   // padded-prefix row of a non-empty sequence: unreachable from the loss
-    const float inv_l = dead ? 0.f : 1.0f / l[it];
-    float* out = ctx + (row0 + i) * p.d + h * HD;
-    if (HD >= 8 || h2 == 0) {
-      float4 o = make_float4(oa[it][0] * inv_l, oa[it][1] * inv_l, oa[it][2] * inv_l, oa[it][3] * inv_l);
-      *(float4*)(out + 4 * h2) = o;
-    }
-    if (HD == 16) {
-      float4 o = make_float4(oa[it][4] * inv_l, oa[it][5] * inv_l, oa[it][6] * inv_l, oa[it][7] * inv_l);
-      *(float4*)(out + 8 + 4 * h2) = o;
-    }
-    if (h2 == 0) lse[((long long)b * p.H + h) * L + i] = dead ? 0.f : (m[it] + __log2f(l[it])) * LN2;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// MFMA backward, same scope (L <= 64, head dim 4 / 8 / 16), one wave per (sequence, head), two phases:
-//   A (lane = query i):  S^T = K Q^T and dP^T = V dO^T by MFMA; dS^T = P^T (dP^T - D_i) lane-locally;
-//                        dQ^T = K^T dS^T with dS^T used as the B operand where it sits (k permutation as in the forward).
-//   B (lane = key j):    S = Q K^T and dP = dO V^T by MFMA (same values, other layout: registers run over queries);
-//                        dV^T = dO^T P and dK^T = Q^T dS, again with P / dS straight from the accumulators.
-// Q, K, V, dO rows go through per-wave LDS tiles once (lane = row, one global round trip); the "gathered" A operands
-// (rows picked in accumulator-register order) and the per-query lse / D values are read from there.
-template <int HD, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const int* __restrict__ seq,
-                                                            const float* __restrict__ ctx, const float* __restrict__ dctx,
-                                                            const float* __restrict__ lse, AttnDims p, float* __restrict__ dqkv) {
-  constexpr int KH = HD / 2, LDSW = HD + 1;
-  constexpr float LOG2E = 1.4426950408889634f;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int h = UR_UNIFORM((int)(blockIdx.y * 4 + w));
-  if (h >= p.H) return;
-  const int b = blockIdx.x, L = p.L, ld = 3 * p.d;
-  const int c32 = lane & 31, h2 = lane >> 5;
-  long long row0;
-  int pad;
-  seq_rows(p, b, row0, pad);
-  const float* __restrict__ base = qkv + row0 * ld + h * HD;
-  const int* __restrict__ sq = seq + (long long)b * L;
-  const int fv = UR_UNIFORM(first_valid_key(sq, L, lane));
-  const bool literal = fv >= L;
-  const bool causal = p.causal && !literal;
-  const unsigned long long kmask = __ballot(lane < L && (literal || sq[min(lane, L - 1)] > 0));
-  const unsigned long long qmask = __ballot(lane < L && lane >= pad);   // query rows that exist (compact mode: not the padded prefix)
-  const int nt = L > 32 ? 2 : 1;
-  const float f = literal ? 1.0f / p.sqrt_hd : p.scale;   // d(score)/d(q.k)
-  const float sc2 = f * LOG2E;
-
-  __shared__ float tiles[4][4][64][LDSW];   // [wave][Q,K,V,dO][row][dim]
-  __shared__ float rowv[4][2][64];          // [wave][lse*log2e, D][row]
-  __shared__ unsigned rowk[4][64];          // [wave][row]: dropout row key of query `row`
-  float (*qs)[LDSW] = tiles[w][0];
-  float (*ks)[LDSW] = tiles[w][1];
-  float (*vs)[LDSW] = tiles[w][2];
-  float (*gs)[LDSW] = tiles[w][3];
-  {
-    const int row = max(min(lane, L - 1), pad);
-    const float* qr = base + (long long)row * ld;
-    const float* gr = dctx + (row0 + row) * p.d + h * HD;
-    const float* orr = ctx + (row0 + row) * p.d + h * HD;
-    float D = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD; ++c) {
-      const float g = gr[c];
-      qs[lane][c] = qr[c];
-      ks[lane][c] = qr[p.d + c];
-      vs[lane][c] = qr[2 * p.d + c];
-      gs[lane][c] = g;
-      D = fmaf(g, orr[c], D);
-    }
-    rowv[w][0][lane] = lse[((long long)b * p.H + h) * L + row] * LOG2E;
-    rowv[w][1][lane] = D;
-    rowk[w][lane] = attn_rowkey(p, b, h, min(lane, L - 1));
-  }
-  // row-type MFMA fragments: row 32 t + c32, dims h2*KH .. h2*KH + KH-1
-  float qf[2][KH], kf[2][KH], vf[2][KH], gf[2][KH];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int c = 0; c < KH; ++c) {
-      qf[t][c] = qs[t * 32 + c32][h2 * KH + c];
-      kf[t][c] = ks[t * 32 + c32][h2 * KH + c];
-      vf[t][c] = vs[t * 32 + c32][h2 * KH + c];
-      gf[t][c] = gs[t * 32 + c32][h2 * KH + c];
-    }
-  float* orow = dqkv + row0 * ld + h * HD;
-
-  // =========================================================================== phase A: lane = query i
-  {
-    const unsigned km[2] = {(unsigned)(kmask >> (4 * h2)), (unsigned)(kmask >> (32 + 4 * h2))};
-    const int lim = c32 - 4 * h2;   // diagonal tiles: key register jl visible iff jl <= lim
-    const unsigned cm = !causal ? 0xFFFFFFFFu : (lim < 0 ? 0u : (lim >= 31 ? 0xFFFFFFFFu : ((2u << lim) - 1u)));
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      if (it >= nt) break;
-      const int i = it * 32 + c32;
-      const float lse2 = rowv[w][0][i], Di = rowv[w][1][i];
-      const unsigned rk = rowk[w][i];
-      floatx16 dq;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        if (jt >= nt || (causal && jt > it)) continue;
-        floatx16 sT, dpT;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
-#pragma unroll
-        for (int c = 0; c < KH; ++c) {
-          sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[jt][c], qf[it][c], sT, 0, 0, 0);
-          dpT = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[jt][c], gf[it][c], dpT, 0, 0, 0);
-        }
-        const unsigned vis = km[jt] & ((causal && jt == it) ? cm : 0xFFFFFFFFu);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = literal ? (sT[r] / p.sqrt_hd + -10000.0f) * LOG2E : sT[r] * sc2;
-          const float pv = (vis >> ((r & 3) + 8 * (r >> 2))) & 1u ? __builtin_amdgcn_exp2f(e - lse2) : 0.f;
-          const float mk = attn_keep<DROP>(p, rk, jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2);
-          sT[r] = pv * (mk * dpT[r] - Di);   // dS^T
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float kg = c32 < HD ? ks[jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2][c32] : 0.f;
-          dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kg, sT[r], dq, 0, 0, 0);
-        }
-      }
-      if (i < L && i >= pad) {
-        float* out = orow + (long long)i * ld;
-        if (HD >= 8 || h2 == 0) *(float4*)(out + 4 * h2) = make_float4(dq[0] * f, dq[1] * f, dq[2] * f, dq[3] * f);
-        if (HD == 16) *(float4*)(out + 8 + 4 * h2) = make_float4(dq[4] * f, dq[5] * f, dq[6] * f, dq[7] * f);
-      }
-    }
-  }
-  // =========================================================================== phase B: lane = key j
-  {
-    const int limB = c32 - 4 * h2;   // diagonal tiles: query register il visible iff il >= limB
-    const unsigned cmB = !causal ? 0xFFFFFFFFu : (limB <= 0 ? 0xFFFFFFFFu : (limB >= 32 ? 0u : ~((1u << limB) - 1u)));
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-      if (jt >= nt) break;
-      const int j = jt * 32 + c32;
-      const bool kv = (kmask >> j) & 1ull;
-      floatx16 dk, dv;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        if (it >= nt || (causal && jt > it)) continue;
-        floatx16 sM, dpM;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sM[r] = 0.f; dpM[r] = 0.f; }
-#pragma unroll
-        for (int c = 0; c < KH; ++c) {
-          sM = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[it][c], kf[jt][c], sM, 0, 0, 0);
-          dpM = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[it][c], vf[jt][c], dpM, 0, 0, 0);
-        }
-        const unsigned qm = (unsigned)(qmask >> (32 * it + 4 * h2));   // query rows < L
-        const unsigned vis = kv ? (qm & ((causal && jt == it) ? cmB : 0xFFFFFFFFu)) : 0u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int il = (r & 3) + 8 * (r >> 2), i = it * 32 + il + 4 * h2;
-          const float e = literal ? (sM[r] / p.sqrt_hd + -10000.0f) * LOG2E : sM[r] * sc2;
-          const float pv = (vis >> il) & 1u ? __builtin_amdgcn_exp2f(e - rowv[w][0][i]) : 0.f;
-          const float mk = DROP ? drop_mul(rowk[w][i], (unsigned)j, p.dthresh, p.dscale) : 1.0f;
-          sM[r] = pv * mk;                             // dropout(P)
-          dpM[r] = pv * (mk * dpM[r] - rowv[w][1][i]); // dS
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-          const float gg = c32 < HD ? gs[i][c32] : 0.f;
-          const float qg = c32 < HD ? qs[i][c32] : 0.f;
-          dv = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, sM[r], dv, 0, 0, 0);
-          dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qg, dpM[r], dk, 0, 0, 0);
-        }
-      }
-      if (j < L && j >= pad) {
-        float* out = orow + (long long)j * ld;
-        if (HD >= 8 || h2 == 0) {
-          *(float4*)(out + p.d + 4 * h2) = make_float4(dk[0] * f, dk[1] * f, dk[2] * f, dk[3] * f);
-          *(float4*)(out + 2 * p.d + 4 * h2) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-        }
-        if (HD == 16) {
-          *(float4*)(out + p.d + 8 + 4 * h2) = make_float4(dk[4] * f, dk[5] * f, dk[6] * f, dk[7] * f);
-          *(float4*)(out + 2 * p.d + 8 + 4 * h2) = make_float4(dv[4], dv[5], dv[6], dv[7]);
-        }
-      }
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------
-// 16x16x4-MFMA attention for ANY sequence length (head dim 4 / 8 / 16), forward.  The 32x32 kernels above keep the whole
-// [L, L] score block of a (sequence, head) in accumulators, which stops at L = 64 and wastes most of every 32-row MFMA on
-// an 8-wide head; here the block is walked in 16 x 16 tiles, flash-attention style:
+// 16x16x4-MFMA attention for ANY sequence length (head dim 4 / 8 / 16), forward.  (Rounds 1-3 also had 32 x 32 single-block kernels
+// for L <= 64: they kept the whole [L, L] score block of a (sequence, head) in accumulators and wasted most of every 32-row MFMA on an
+// 8-wide head; measured slower at every shape and taken out in round 5.)  The block is walked in 16 x 16 tiles, flash-attention style:
 //   * one wave = one (sequence, head, chunk of 64 queries); K and V rows of the keys the chunk can see are staged ONCE in
 //     the wave's LDS slice;
 //   * S^T tile [16 keys, 16 queries] = K Q^T by HD/4 v_mfma_f32_16x16x4_f32 (lane quarter kq feeds dims kq*HD/4 + s: the k
@@ -1722,22 +1380,20 @@ static int make_dims(int B, int L, int d, int H, int causal, AttnDims* p) {
   return UR_OK;
 }
 
+// test hooks (common.h: UR_TEST): attn_no_mfma = the VALU kernels at every shape (what head dims 2 / 32 / 64 and sequences beyond the LDS
+// budget take anyway; no compact rows); attn_no_m16 = the same through the 16x16 kernels' own gate
+static bool attn_no_mfma() {
+  static const bool off = ur_test_hook("attn_no_mfma") != 0;
+  return off;
+}
 static bool attn_m16_supported(int L, int hd) {
-  static const bool off = getenv("UR_ATTN_NO_M16") != nullptr;   // test / tuning hook
+  static const bool off = ur_test_hook("attn_no_m16") != 0;
   return !off && (hd == 4 || hd == 8 || hd == 16) && (long long)attn_m16_lds_floats_per_wave(L, hd) * 4 <= 64 * 1024;
 }
-// 16x16-tile forward for L <= 64 as well (measured 30.5 vs 35 us at B = 512, L = 50, 16 heads of 8); UR_ATTN_FWD32=1 restores the
-// 32x32 single-block forward
-static bool attn_m16_short() {
-  static const bool off = getenv("UR_ATTN_FWD32") != nullptr;
-  return !off;
-}
-
 bool attn_compact_supported(int L, int d, int H) {
   if (H <= 0 || d % H) return false;
   const int hd = d / H;
-  if (getenv("UR_ATTN_NO_MFMA") != nullptr || !(hd == 4 || hd == 8 || hd == 16)) return false;
-  if (L <= 64) return true;                                  // 32x32 single-block kernels / 16x16 backward
+  if (attn_no_mfma() || !(hd == 4 || hd == 8 || hd == 16)) return false;
   return attn_m16_supported(L, hd) && (long long)attn_m16_bwd_lds_floats(L, hd) * 4 <= 80 * 1024;   // 16x16-tile kernels, both passes
 }
 
@@ -1752,8 +1408,7 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
   p.seq_pad = seq_pad;
   if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need head dim 4/8/16 and a sequence that fits the MFMA kernels");
-  static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
-  if (attn_m16_supported(L, p.hd) && !no_mfma && (L > 64 || attn_m16_short())) {
+  if (attn_m16_supported(L, p.hd) && !attn_no_mfma()) {
     const size_t lds = (size_t)attn_m16_lds_floats_per_wave(L, p.hd) * sizeof(float);
     dim3 g3(attn_bh_grid(B, H, p.hd));
 #define GM(HD)                                                                                                                     \
@@ -1765,14 +1420,6 @@ int attn_fwd(const float* qkv, const int* seq, int B, int L, int d, int H, int c
     } while (0)
     if (p.hd == 4) GM(4); else if (p.hd == 8) GM(8); else GM(16);
 #undef GM
-    UR_LAUNCH_CHECK();
-    return UR_OK;
-  }
-  if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
-    dim3 g2(B, cdiv(H, 4));
-    if (p.hd == 4) UR_ATTN_LAUNCH(attn_fwd_mfma_kernel, 4, g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
-    else if (p.hd == 8) UR_ATTN_LAUNCH(attn_fwd_mfma_kernel, 8, g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
-    else UR_ATTN_LAUNCH(attn_fwd_mfma_kernel, 16, g2, dim3(256), 0, st, qkv, seq, p, ctx, lse);
     UR_LAUNCH_CHECK();
     return UR_OK;
   }
@@ -1805,14 +1452,11 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
   p.seq_pad = seq_pad;
   if (drop && drop->thresh) { p.dkey = drop->key; p.dthresh = drop->thresh; p.dscale = drop->scale; }
   if (seq_base && !attn_compact_supported(L, d, H)) return fail(UR_ERR_UNSUPPORTED, "attention: compacted rows need head dim 4/8/16 and a sequence that fits the MFMA kernels");
-  static const bool no_mfma = getenv("UR_ATTN_NO_MFMA") != nullptr;   // test / tuning hook
-  static const bool bwd32 = getenv("UR_ATTN_BWD32") != nullptr;   // tuning hook: the 32x32 single-block backward for L <= 64
-  if (attn_m16_supported(L, p.hd) && (long long)attn_m16_bwd_lds_floats(L, p.hd) * 4 <= 80 * 1024 && !no_mfma && (L > 64 || !bwd32)) {
-    // (also for L <= 64: measured 99 vs 112-122 us at B = 512, L = 50, 16 heads of 8 -- the 16-row tiles waste less of each MFMA)
+  if (attn_compact_supported(L, d, H)) {   // (= the 16x16-tile kernels take the shape, both passes)
     dim3 g3(attn_bh_grid(B, H, p.hd));
-    static const bool no_t = getenv("UR_ATTN_NO_M16T") != nullptr;   // test / tuning hook: the un-transposed kernel for short L too
+    static const bool no_t = ur_test_hook("attn_no_m16t") != 0;   // test hook: the un-transposed kernel for short L too
     const size_t lds_t = (size_t)attn_m16t_lds_floats(L, p.hd) * sizeof(float);
-    static const bool no_w = getenv("UR_ATTN_NO_M16W") != nullptr;   // test / tuning hook: the workgroup-per-head kernels for L <= 64 as well
+    static const bool no_w = ur_test_hook("attn_no_m16w") != 0;   // test hook: the workgroup-per-head kernels for L <= 64 as well
     const size_t lds_w = (size_t)attn_m16w_lds_floats(L, p.hd) * sizeof(float);
     if (!no_t && !no_w && L <= 64 && lds_w <= 64 * 1024) {   // four heads per workgroup, a wave per head, one pass over the tile pairs
       dim3 gw(B * cdiv(H, M16W_HEADS));
@@ -1839,14 +1483,6 @@ int attn_bwd(const float* qkv, const int* seq, const float* ctx, const float* dc
     } while (0)
     if (p.hd == 4) GM(4); else if (p.hd == 8) GM(8); else GM(16);
 #undef GM
-    UR_LAUNCH_CHECK();
-    return UR_OK;
-  }
-  if (L <= 64 && (p.hd == 4 || p.hd == 8 || p.hd == 16) && !no_mfma) {
-    dim3 g2(B, cdiv(H, 4));
-    if (p.hd == 4) UR_ATTN_LAUNCH(attn_bwd_mfma_kernel, 4, g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
-    else if (p.hd == 8) UR_ATTN_LAUNCH(attn_bwd_mfma_kernel, 8, g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
-    else UR_ATTN_LAUNCH(attn_bwd_mfma_kernel, 16, g2, dim3(256), 0, st, qkv, seq, ctx, dctx, lse, p, dqkv);
     UR_LAUNCH_CHECK();
     return UR_OK;
   }

@@ -110,18 +110,26 @@ __device__ __forceinline__ float group_max(float v) {
   if constexpr (WIDTH >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
-// ---- arrival at a cross-workgroup hand-off ("whoever arrives last finishes the job").  mode bit 0 (default ON; UR_STRICT_ORDER=0
-// clears it): the counter increment is release-acquire at agent scope, the form the HIP memory model recognises -- buffer_wbl2 sc1 in
-// front of the RMW (the XCD's L2 written back, dirty lines of every other kernel included), buffer_inv sc1 behind it.  One thread per
-// workgroup arrives: measured +2 us on the 0.55 ms step (three interleaved pairs, profiles/r04_c_strict_order.txt) -- rounds 2-3 had
-// priced a __threadfence() by all 256 threads (+20 us) and kept a relaxed counter instead, resting on the ISA-level behaviour that
-// device-scope RMWs are performed at the one point all XCDs agree on and have been performed once their old value has returned.  The
-// DATA still travels in such RMWs (no reader can hit a stale L2 line whatever the order of the arrivals); the counter now carries the
-// ordering the model asks for.  mode >> 1 (UR_ARRIVAL_SKEW_US, test hook): the arriving thread first waits (hash of the workgroup) %
-// skew microseconds, so the last arriver moves over all XCDs (tests/test_handoff_order_gpu.py).
+// ---- test hooks.  ONE environment variable, read once per process: UR_TEST="name[=value],name[=value],..." -- the kernel families that
+// are not the default at the benchmark shapes (but ARE the path of other shapes) forced on at test shapes, and timing skews:
+//   attn_no_mfma / attn_no_m16 / attn_no_m16t / attn_no_m16w   attention kernel families (attention.hip)
+//   gru_no_seq / gru_no_step                                   GRU recurrence paths (gru.hip)
+//   plan_multi                                                 the multi-launch id sort at every batch size (rows.hip)
+//   chain_mask=<bits>                                          which row-chain kernels are on (rowchain.hip; all on by default)
+//   topk_cap=<n>  arrival_skew_us=<n>  side_delay_us=<n>       list overflows, hand-off skew, a late side stream
+// ur_test_hook(name): the hook's value (1 when listed without a value), `absent` when not listed.  The SUPPORTED switches are separate,
+// documented environment variables (README.md): UR_SASREC_SIDE, UR_COMM_SINGLE and the Python-level ones.
+int ur_test_hook(const char* name, int absent = 0);
+
+// ---- arrival at a cross-workgroup hand-off ("whoever arrives last finishes the job").  The counter increment is release-acquire at
+// agent scope, the form the HIP memory model recognises -- buffer_wbl2 sc1 in front of the RMW (the XCD's L2 written back, dirty lines
+// of every other kernel included), buffer_inv sc1 behind it -- by ONE thread per workgroup: +2 us on the 0.55 ms step (round 4,
+// profiles/r04_c_strict_order.txt; rounds 2-3 had priced a __threadfence() by all 256 threads at +20 us and kept a relaxed counter).
+// The DATA still travels in device-scope RMWs (no reader can hit a stale L2 line whatever the order of the arrivals).
+// mode >> 1 (test hook arrival_skew_us): the arriving thread first waits (hash of the workgroup) % skew microseconds, so that the
+// last arriver moves over all XCDs (tests/test_handoff_order_gpu.py).
 static inline int ur_arrive_mode() {   // read once per process
-  static const int mode = (getenv("UR_STRICT_ORDER") && !atoi(getenv("UR_STRICT_ORDER")) ? 0 : 1) |
-                          ((getenv("UR_ARRIVAL_SKEW_US") ? atoi(getenv("UR_ARRIVAL_SKEW_US")) : 0) << 1);
+  static const int mode = 1 | (ur_test_hook("arrival_skew_us") << 1);
   return mode;
 }
 __device__ __forceinline__ unsigned ur_arrive(unsigned* cnt, int mode) {
@@ -132,8 +140,7 @@ __device__ __forceinline__ unsigned ur_arrive(unsigned* cnt, int mode) {
     const long long t0 = wall_clock64(), wait = (long long)(h % (unsigned)skew) * 100;   // wall_clock64: 100 MHz
     while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
   }
-  return (mode & 1) ? __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
-                    : __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 

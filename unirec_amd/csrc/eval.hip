@@ -657,7 +657,7 @@ extern "C" int ur_full_topk(const float* user_emb, const float* item_table, int6
   // k-th best score; then ALL items are streamed once by the ranking kernel in EMIT mode -- scores stay in the MFMA accumulators,
   // only the few that beat the bound are written -- and the k best of those candidates are the answer.  No [B, N] score ever
   // reaches HBM.  Falls back to the chunked path when a row's candidate list overflows (k * N / chunk too large).
-  static const long long cap_env = getenv("UR_TOPK_CAP") ? atoll(getenv("UR_TOPK_CAP")) : 0;   // test hook: force list overflows
+  static const long long cap_env = ur_test_hook("topk_cap");   // test hook: force list overflows
   // size of the first range: large enough that few items beat its k-th best (expected survivors per row: k * N / first),
   // small enough that the score-matrix pipeline over it is a fraction of the streaming pass
   const long long first = std::min<long long>(chunk, std::max<long long>(65536, (n_items / 16) & ~3LL));

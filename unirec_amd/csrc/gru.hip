@@ -637,11 +637,9 @@ __global__ __launch_bounds__(256) void gru_step_kernel(GruStepArgs a) {
 
 // units per workgroup (in 16s) of the step kernels, 0 = not applicable: the widest tile that still gives ~a workgroup per CU
 static int gru_step_nut(int B, int H) {
-  static const bool off = getenv("UR_GRU_NO_STEP") != nullptr;   // test / tuning hook: the gemm_nt + cell-kernel path of rounds 1-3
+  static const bool off = ur_test_hook("gru_no_step") != 0;   // test hook: the gemm_nt + cell-kernel path (what H % 64 != 0 takes)
   if (off || H % 64 != 0) return 0;
   const int rbs = cdiv(B, GS_ROWS);
-  static const int forced = getenv("UR_GRU_STEP_NUT") ? atoi(getenv("UR_GRU_STEP_NUT")) : 0;   // tuning hook: units per workgroup / 16
-  if (forced >= 1 && forced <= 3 && H % (16 * forced) == 0) return forced;
   for (int nut = 3; nut >= 1; --nut)
     if (H % (16 * nut) == 0 && (nut == 1 || (long long)rbs * (H / (16 * nut)) >= 200)) return nut;
   return 0;
@@ -674,7 +672,7 @@ static int gru_step_launch(int nut, GruStepArgs a, hipStream_t st) {
 static bool gru_seq4_supported(int H) { return H == 64 || H == 128; }
 
 static bool gru_seq_supported(int H) {
-  static const bool off = getenv("UR_GRU_NO_SEQ") != nullptr;   // test / tuning hook
+  static const bool off = ur_test_hook("gru_no_seq") != 0;   // test hook
   return !off && (H == 32 || H == 64 || H == 128);   // (H = 64 / 128: the four-sequence kernels, H = 32: the 16-sequence ones)
 }
 

@@ -132,7 +132,7 @@ int transpose_batch(TransposeBatch& tb, hipStream_t st);   // every queued trans
 
 // ---- rowchain.hip: row-block chain kernels (a workgroup carries BM token rows through a sequence of GEMMs, tiles in LDS)
 constexpr int CHAIN_FWD = 1, CHAIN_BWD = 2, CHAIN_PROJ = 4, CHAIN_LAST = 8, CHAIN_LAST_BWD = 16, CHAIN_EMBED = 32, CHAIN_LASTROW = 64, CHAIN_ALL = 127;   // LAST*: the B last rows of the last-row layer through the row-chain kernels; EMBED: lookup + LN + first projection; LASTROW: the last-row layer as two launches (lastrow.hip; wins over LAST*)
-constexpr int CHAIN_DEFAULT = CHAIN_ALL;  // which chain kernels run by default (UR_SASREC_CHAIN / ur_sasrec_set_chain: bit mask); DESIGN.md 6d
+constexpr int CHAIN_DEFAULT = CHAIN_ALL;  // which chain kernels run by default (test hook chain_mask / ur_sasrec_set_chain: bit mask); DESIGN.md 6d
 bool chain_supported(int d, int inner, int which);
 bool chain_shape_ok(int d, int inner);              // the kernels exist for this shape (whatever the switch says)   // d in {32, 64, 128}, inner % d == 0, and the bit(s) `which` switched on
 int chain_rows_per_block(int d);

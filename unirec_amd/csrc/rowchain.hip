@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a)
 // the CUs with them any more -- in the forward pass the side stream is idle and nothing is lost.
 static int g_chain_on = -1;   // bit mask: 1 forward chain, 2 backward chain, 4 projection-gradient chain, 8 / 16 forward / backward chain of the last-row layer, 32 input block, 64 the last-row layer as two launches
 int chain_set_enabled(int on) {
-  if (g_chain_on < 0) g_chain_on = getenv("UR_SASREC_CHAIN") ? (atoi(getenv("UR_SASREC_CHAIN")) & CHAIN_ALL) : CHAIN_DEFAULT;
+  if (g_chain_on < 0) g_chain_on = ur_test_hook("chain_mask", CHAIN_DEFAULT) & CHAIN_ALL;   // (test hook: the GEMM-per-op paths of other widths)
   const int prev = g_chain_on;
   if (on >= 0) g_chain_on = on & CHAIN_ALL;
   return prev;

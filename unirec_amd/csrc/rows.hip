@@ -33,95 +33,6 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned dgt, bool act
   return m;
 }
 
-__global__ void build_keys_kernel(const int* __restrict__ ids_a, long long n_a, const long long* __restrict__ ids_b,
-                                  long long n_b, unsigned* __restrict__ keys, int* __restrict__ vals, int W, long long n_local,
-                                  long long n_rows, IdGuard gd) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_a + n_b) return;
-  const long long id = ur_guard_id((i < n_a) ? (long long)ids_a[i] : ids_b[i - n_a], n_rows, gd);   // (out of range: guard raised, treated as the padding id)
-  // row-sharded table: row `id` lives on rank id % W at local row id / W; sorting by (owner, local row)
-  // makes every owner's requests contiguous (the all-to-all split sizes are the per-owner unique counts)
-  // local row 0 is the padding row on EVERY rank (real items start at local row 1), so "row 0 never moves" holds per shard
-  keys[i] = (W > 1) ? (id ? (unsigned)((id % W) * n_local + id / W + 1) : 0u) : (unsigned)id;
-  vals[i] = (int)i;
-}
-
-// hist[digit * nwaves + wave] = number of keys of this wave's chunk with that digit
-__global__ __launch_bounds__(256) void radix_hist_kernel(const unsigned* __restrict__ keys, long long n, int shift, int nwaves,
-                                                         int* __restrict__ hist) {
-  __shared__ int cnt[4][RADIX];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + w;
-  for (int i = lane; i < RADIX; i += 64) cnt[w][i] = 0;
-  __builtin_amdgcn_wave_barrier();
-  if (wave < nwaves) {
-    const long long base = (long long)wave * CH;
-    for (int it = 0; it < CH / 64; ++it) {
-      const long long i = base + it * 64 + lane;
-      if (i < n) atomicAdd(&cnt[w][(keys[i] >> shift) & 0xFF], 1);
-    }
-  }
-  __syncthreads();
-  if (wave < nwaves)
-    for (int dgt = lane; dgt < RADIX; dgt += 64) hist[(long long)dgt * nwaves + wave] = cnt[w][dgt];
-}
-
-// in-place exclusive scan of `len` ints by ONE block of 1024 threads; total -> *total_out (nullable)
-__global__ __launch_bounds__(1024) void scan_exclusive_kernel(int* __restrict__ data, long long len, int* __restrict__ total_out) {
-  __shared__ int part[1024];
-  const int t = threadIdx.x;
-  const long long per = (len + 1023) / 1024;
-  const long long b = (long long)t * per, e = b + per < len ? b + per : len;
-  int s = 0;
-  for (long long i = b; i < e; ++i) s += data[i];
-  part[t] = s;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    int v = (t >= off) ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  int run = (t == 0) ? 0 : part[t - 1];
-  for (long long i = b; i < e; ++i) {
-    const int v = data[i];
-    data[i] = run;
-    run += v;
-  }
-  if (total_out && t == 1023) *total_out = part[1023];
-}
-
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in,
-                                                            long long n, int shift, int nwaves, const int* __restrict__ hist_scanned,
-                                                            unsigned* __restrict__ keys_out, int* __restrict__ vals_out) {
-  __shared__ int cnt[4][RADIX];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + w;
-  if (wave >= nwaves) return;
-  for (int dgt = lane; dgt < RADIX; dgt += 64) cnt[w][dgt] = hist_scanned[(long long)dgt * nwaves + wave];
-  __builtin_amdgcn_wave_barrier();
-  const long long base = (long long)wave * CH;
-  const unsigned long long lt = lanemask_lt();
-  for (int it = 0; it < CH / 64; ++it) {
-    const long long i = base + it * 64 + lane;
-    const bool active = i < n;
-    const unsigned key = active ? keys_in[i] : 0u;
-    const int val = active ? vals_in[i] : 0;
-    const unsigned dgt = (key >> shift) & 0xFF;
-    const unsigned long long m = match_digit(dgt, active);
-    const int rank = __popcll(m & lt);
-    int pos = 0;
-    if (active) pos = cnt[w][dgt] + rank;
-    __builtin_amdgcn_wave_barrier();
-    if (active && rank == 0) cnt[w][dgt] += __popcll(m);
-    __builtin_amdgcn_wave_barrier();
-    if (active) {
-      keys_out[pos] = key;
-      vals_out[pos] = val;
-    }
-  }
-}
-
 // ---- round 4: the multi-launch sort (n > SMALL_N: C3's 154 K ids per batch) as passes + 2 launches.  Rounds 1-3 ran three launches per
 // 8-bit pass (per-wave histogram, a ONE-workgroup scan of the [digit][wave] table, scatter) + build + three for the heads: 13 launches,
 // 0.34 ms at n = 153 728.  Now:
@@ -147,7 +58,9 @@ __global__ __launch_bounds__(256) void radix_first_kernel(const int* __restrict_
     const long long i = base + it * 256 + threadIdx.x;
     if (i < n) {
       const long long id = ur_guard_id((i < n_a) ? (long long)ids_a[i] : ids_b[i - n_a], n_rows, gd);
-      const unsigned key = (W > 1) ? (id ? (unsigned)((id % W) * n_local + id / W + 1) : 0u) : (unsigned)id;   // (build_keys_kernel)
+      // row-sharded table: row `id` lives on rank id % W at local row id / W + 1 (local row 0 = the padding row of EVERY shard); sorting by
+      // (owner, local row) makes every owner's requests contiguous
+      const unsigned key = (W > 1) ? (id ? (unsigned)((id % W) * n_local + id / W + 1) : 0u) : (unsigned)id;
       keys[i] = key;
       vals[i] = (int)i;
       atomicAdd(&cnt[key & 0xFF], 1);
@@ -253,47 +166,6 @@ __global__ __launch_bounds__(256) void radix_pass_kernel(const unsigned* __restr
 }
 
 // ---- segment heads: count per wave -> scan -> write (uniq_idx, seg_start)
-__global__ __launch_bounds__(256) void heads_count_kernel(const unsigned* __restrict__ keys, long long n, int nwaves,
-                                                          int* __restrict__ counts) {
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + w;
-  if (wave >= nwaves) return;
-  const long long base = (long long)wave * CH;
-  int c = 0;
-  for (int it = 0; it < CH / 64; ++it) {
-    const long long i = base + it * 64 + lane;
-    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
-    c += __popcll(__ballot(head));
-  }
-  if (lane == 0) counts[wave] = c;
-}
-
-__global__ __launch_bounds__(256) void heads_write_kernel(const unsigned* __restrict__ keys, long long n, int nwaves,
-                                                          const int* __restrict__ counts_scanned, const int* __restrict__ n_uniq,
-                                                          int* __restrict__ uniq_idx, int* __restrict__ seg_start,
-                                                          int* __restrict__ owner_counts, long long n_local) {
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + w;
-  if (wave >= nwaves) return;
-  const long long base = (long long)wave * CH;
-  int run = counts_scanned[wave];
-  const unsigned long long lt = lanemask_lt();
-  for (int it = 0; it < CH / 64; ++it) {
-    const long long i = base + it * 64 + lane;
-    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
-    const unsigned long long m = __ballot(head);
-    if (head) {
-      const int seg = run + __popcll(m & lt);
-      uniq_idx[seg] = (int)keys[i];
-      seg_start[seg] = (int)i;
-      if (owner_counts) atomicAdd(&owner_counts[keys[i] / n_local], 1);   // integer atomics: deterministic totals
-    }
-    run += __popcll(m);
-  }
-  if (wave == 0 && lane == 0) seg_start[*n_uniq] = (int)n;
-}
-
-
 // small batches (n <= SMALL_N ids: every training batch of the C2 / C4 / C5 shapes) take the chunk-sort path further down
 constexpr int SMALL_N = 32768;
 constexpr int SMALL_N_MID = SMALL_N;          // (named apart because the chunk-sort kernels are defined further up)
@@ -406,8 +278,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
                                                           long long n, const float4* __restrict__ rows_a, long long n_a,
                                                           const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G,
                                                           int d4, float4* __restrict__ out, int zero_tail,
-                                                          const int* __restrict__ out_rows, const int* __restrict__ u_list = nullptr,
-                                                          const int* __restrict__ n_list_dev = nullptr, ReduceRiders rd = ReduceRiders()) {
+                                                          const int* __restrict__ out_rows, ReduceRiders rd = ReduceRiders()) {
   if (rd.sf_out4 && blockIdx.x == 0 && threadIdx.x == 0) {   // (source-rank order: every rank sums the same values in the same order)
     float nan = 0.f, ovf = 0.f, loss = 0.f;
     for (int q = 0; q < rd.world; ++q) {
@@ -431,10 +302,8 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
   __shared__ int long_list[256];
   __shared__ int long_cnt;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
-  // u_list (nullable): only the unique ids u_list[0 .. *n_list_dev) are reduced, entry i into out row i (ur_rows_reduce_subset);
-  // below, an ENTRY is a position of that list, or the unique id itself without one
-  const int n_uniq = u_list ? min(*n_list_dev, *n_uniq_dev) : *n_uniq_dev;
-  auto uid = [&](long long i) -> long long { return u_list ? (long long)u_list[i] : i; };
+  const int n_uniq = *n_uniq_dev;
+  auto uid = [&](long long i) -> long long { return i; };
   // (pass 2's first candidate test is issued here, so that its loads travel with pass 1's instead of after them)
   const long long gstride = gridDim.x;
   const long long uc0 = blockIdx.x + gstride * threadIdx.x;
@@ -712,21 +581,16 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
                                                  float4* __restrict__ var, int* __restrict__ last_step,
                                                  const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev, long long n_max,
                                                  const float4* __restrict__ grad, int d4, const float* __restrict__ scale_dev,
-                                                 int bid, int nblk, const int* __restrict__ skip_mark = nullptr,
-                                                 const int* __restrict__ guard_dev = nullptr) {
-  // MODE 2 = MODE 0 for rows the NEXT batch reads as well (the "hot" rows of a step whose other updates run beside the next forward
-  // pass): when the step is skipped (scale < 0) they still take it as a zero-gradient step, as every row the step does not touch does --
-  // the catch-up the next batch's rows would otherwise get behind the update.  skip_mark (MODE 0; per unique id): rows somebody else updates.
+                                                 int bid, int nblk, const int* __restrict__ guard_dev = nullptr) {
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int n_uniq = (int)min((long long)*n_uniq_dev, n_max);
   const float scale = ur_step_scale(scale_dev, MODE == 1 ? nullptr : guard_dev);
   if (MODE == 0 && scale < 0.f) return;   // update guard: NaN loss or a raised id guard, the whole step is skipped (see dense_adam_kernel)
-  const bool skipped = MODE == 2 && scale < 0.f;
   if (bid * groups >= n_uniq) return;     // nothing for this workgroup (the grid is sized for the plan's capacity; a filtered catch-up
                                           // list is often EMPTY: 3 520 workgroups evaluating two powf for nothing were 20 us)
   const float bc1 = 1.f - powf(a.b1, (float)a.step), bc2s = sqrtf(1.f - powf(a.b2, (float)a.step));
-  if (MODE != 1 && d4 <= TPR && !skipped) {   // (MODE 2 too: the rows two batches share go through the SAME instruction sequence as the rest)
+  if (MODE != 1 && d4 <= TPR) {
     // One float4 per lane and row: FOUR rows per lane group in flight.  The rows are random 512-byte reads over tables of tens of
     // GB (w, m, v: three TLB misses per row); with one row per group the kernel is a chain of dependent round trips (plan entry ->
     // last_step -> row) at 1.4 TB/s.  Here every load of a trip is issued before the first use; indices are clamped and the loads
@@ -751,7 +615,7 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
       }
 #pragma unroll
       for (int i = 0; i < U; ++i) {
-        if (u0 + i >= n_uniq || row[i] == 0 || (skip_mark && skip_mark[u0 + i])) continue;   // group-uniform
+        if (u0 + i >= n_uniq || row[i] == 0) continue;   // group-uniform
         if (last_step) {
           const LazyRow lr = lazy_row_prepare<TPR>(last[i], a.step - 1, a, t);
           lazy_row_apply(lr, w[i], m[i], v[i], a);
@@ -772,26 +636,8 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
   }
   for (int u = bid * groups + g; u < n_uniq; u += nblk * groups) {
     const long long row = uniq_idx[u];
-    if (row == 0 || (MODE == 0 && skip_mark && skip_mark[u])) continue;
+    if (row == 0) continue;
     const int last = last_step ? last_step[row] : a.step - 1;
-    if (skipped) {   // (MODE 2, the step is skipped: the zero-gradient steps up to and including this one)
-      if (!last_step || last >= a.step) continue;
-      const LazyRow lz = lazy_row_prepare<TPR>(last, a.step, a, t);
-#pragma unroll
-      for (int k = 0; k < MAXV; ++k) {
-        const int c = t + k * TPR;
-        if (c < d4) {
-          float4 w = table[row * d4 + c], m = mom[row * d4 + c], v = var[row * d4 + c];
-          lazy_row_apply(lz, w, m, v, a);
-          table[row * d4 + c] = w;
-          mom[row * d4 + c] = m;
-          var[row * d4 + c] = v;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (t == 0) last_step[row] = a.step;
-      continue;
-    }
     if (MODE == 1 && last >= a.step - 1) continue;   // already there (updated by the step in between, or caught up ahead of time)
     if (MODE == 1 && last == 0 && a.wd == 0.f) {   // never updated: m = v = 0, every zero-gradient step is a no-op
       if (t == 0) last_step[row] = a.step - 1;
@@ -827,11 +673,10 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
                                                           float4* __restrict__ var, int* __restrict__ last_step,
                                                           const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
                                                           long long n_max, const float4* __restrict__ grad, int d4,
-                                                          const float* __restrict__ scale_dev, const int* __restrict__ skip_mark,
-                                                          const int* __restrict__ guard_dev) {
+                                                          const float* __restrict__ scale_dev, const int* __restrict__ guard_dev) {
   __builtin_amdgcn_s_setprio(3);   // (see rows_reduce_kernel)
   sparse_adam_body<TPR, MODE>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, (int)blockIdx.x, (int)gridDim.x,
-                              skip_mark, guard_dev);
+                              guard_dev);
 }
 template <int TPR>
 __global__ __launch_bounds__(256) void lazy_flush_kernel(AdamK a, float4* __restrict__ table, float4* __restrict__ mom,
@@ -1171,8 +1016,6 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
   ProfScope ps(PC_SORT, st, (double)n * 8.0);
   const IdGuard gd = id_guard();   // (every id of a training batch passes here once: the range check rides in the first pass, common.h)
   PlanWs w = carve_plan(n, (char*)ws);
-  const int nwaves = (int)((n + CH - 1) / CH);
-  const int nblk = cdiv(nwaves, 4);
   const long long n_local = (W > 1) ? (n_rows + W - 1) / W + 1 : n_rows;   // rows per shard incl. its padding row 0
   UR_REQUIRE(n_local * W <= (1LL << 31), UR_ERR_ARG, "ur_rows_plan: sharded key space too large");
   const int passes = (bits_for(W > 1 ? n_local * W : n_rows) + 7) / 8;
@@ -1181,7 +1024,7 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
   int* vbuf[2];
   vbuf[passes & 1] = sorted_pos;       // after `passes` swaps the result sits in index (passes & 1)
   vbuf[(passes & 1) ^ 1] = w.vals_tmp;
-  static const bool no_small = getenv("UR_PLAN_MULTI") != nullptr;   // test hook: force the multi-launch path
+  static const bool no_small = ur_test_hook("plan_multi") != 0;   // test hook: the multi-launch path at every batch size
   // (two 8-bit passes -- tables of up to 65 536 rows, BASELINE config C2 -- are 5 short launches of the radix path: 23 us at n = 28 160 against
   // 35 for the chunk-sort + bisection path, whose cost does not depend on the key width; 4 passes: 40 against 35)
   if (n <= SMALL_N && !no_small && passes > 2) {
@@ -1198,9 +1041,8 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
     return UR_OK;
   }
   if (owner_counts_dev) UR_HIP(hipMemsetAsync(owner_counts_dev, 0, sizeof(int) * W, st));
-  static const bool old_multi = getenv("UR_PLAN_MULTI_OLD") != nullptr;   // test hook: the three-launches-per-pass sort of rounds 1-3
-  if (!old_multi) {
-    const int nchunks = cdiv(n, RCH), hgrid = heads_grid(n);
+  const int nchunks = cdiv(n, RCH), hgrid = heads_grid(n);
+  {
     hipLaunchKernelGGL(radix_first_kernel, dim3(nchunks), dim3(256), 0, st, ids_a, (long long)n_a, (const long long*)ids_b, (long long)n_b,
                        kbuf[0], vbuf[0], W, n_local, nchunks, w.hist, passes - 1, (unsigned*)w.counts, hgrid <= 1024 ? hgrid : 0, (long long)n_rows, gd);
     UR_LAUNCH_CHECK();
@@ -1215,30 +1057,7 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
     hipLaunchKernelGGL(plan_merge_heads_kernel, dim3(hgrid), dim3(1024), 0, st, (const int*)kbuf[cur], (int)n, uniq_idx, seg_start, n_uniq_dev,
                        owner_counts_dev, n_local, hgrid <= 1024 ? (unsigned*)w.counts : (unsigned*)nullptr);
     UR_LAUNCH_CHECK();
-    return UR_OK;
   }
-  hipLaunchKernelGGL(build_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids_a, (long long)n_a, (const long long*)ids_b,
-                     (long long)n_b, kbuf[0], vbuf[0], W, n_local, (long long)n_rows, gd);
-  UR_LAUNCH_CHECK();
-  int cur = 0;
-  for (int p = 0; p < passes; ++p) {
-    const int shift = 8 * p;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], n, shift, nwaves, w.hist);
-    UR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, st, w.hist, (long long)nwaves * RADIX, (int*)nullptr);
-    UR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], vbuf[cur], n, shift, nwaves, w.hist,
-                       kbuf[cur ^ 1], vbuf[cur ^ 1]);
-    UR_LAUNCH_CHECK();
-    cur ^= 1;
-  }
-  hipLaunchKernelGGL(heads_count_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], n, nwaves, w.counts);
-  UR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, st, w.counts, (long long)nwaves, n_uniq_dev);
-  UR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(heads_write_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], n, nwaves, w.counts, n_uniq_dev, uniq_idx, seg_start,
-                     owner_counts_dev, n_local);
-  UR_LAUNCH_CHECK();
   return UR_OK;
 }
 
@@ -1293,8 +1112,8 @@ extern "C" int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_
 static int rows_reduce_impl(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
                             const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
                             const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
-                            const int32_t* u_list, const int32_t* n_list_dev, int64_t n_entries, void* stream,
-                            ReduceRiders rd = ReduceRiders()) {
+                            void* stream, ReduceRiders rd = ReduceRiders()) {
+  const int64_t n_entries = n;
   UR_REQUIRE(uniq_idx && seg_start && sorted_pos && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_rows_reduce: null pointer");
   UR_REQUIRE(!(out_rows && sumsq_dev), UR_ERR_ARG, "ur_rows_reduce: out_rows with the zeroed tail");
   UR_REQUIRE(n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_rows_reduce: n=%lld n_a=%lld", (long long)n, (long long)n_a);
@@ -1303,13 +1122,12 @@ static int rows_reduce_impl(const int32_t* uniq_idx, const int32_t* seg_start, c
   hipStream_t st = as_stream(stream);
   ProfScope ps(PC_REDUCE, st, (double)n * d * 4.0 * 2);
   const int tpr = pick_tpr(d), groups = 256 / tpr;
-  int blocks = cdiv(n_entries, groups);   // (entries = the plan's capacity, or the subset list's)
+  int blocks = cdiv(n_entries, groups);   // (entries = the plan's capacity)
   if (blocks > 8192) blocks = 8192;
-  if (u_list && blocks > 512) blocks = 512;   // (a subset list is sized for the worst case and usually short: grid-stride over it)
   const int zero_tail = sumsq_dev != nullptr;
 #define GO(T) hipLaunchKernelGGL((rows_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
                                  (long long)n_entries, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,          \
-                                 (float4*)uniq_grad, zero_tail, out_rows, u_list, n_list_dev, rd)
+                                 (float4*)uniq_grad, zero_tail, out_rows, rd)
   switch (tpr) {
     case 4: GO(4); break;
     case 8: GO(8); break;
@@ -1325,8 +1143,7 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
                               const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
                               const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
                               void* stream) {
-  return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, uniq_grad, sumsq_dev, out_rows,
-                          nullptr, nullptr, n, stream);
+  return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, uniq_grad, sumsq_dev, out_rows, stream);
 }
 
 // ur_rows_reduce of the sharded step with its riders (ReduceRiders above): step_flags_out4 != NULL: rows_a is the received gradient
@@ -1342,25 +1159,13 @@ extern "C" int ur_rows_reduce_riders(const int32_t* uniq_idx, const int32_t* seg
   UR_REQUIRE(!write_flag_rows || out_rows, UR_ERR_ARG, "ur_rows_reduce_riders: flag rows go with sums written to their slots (out_rows)");
   ReduceRiders rd;
   rd.sf_out4 = step_flags_out4; rd.fr_on = write_flag_rows ? 1 : 0; rd.fr_loss = loss_out; rd.fr_flags = flags_dev; rd.fr_guard = id_guard().dev; rd.world = world; rd.cap = cap;
-  return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, uniq_grad, sumsq_dev, out_rows,
-                          nullptr, nullptr, n, stream, rd);
-}
-
-// the same for a SUBSET of the plan's unique ids: entry i of u_list (indices into uniq_idx, *n_list_dev of them, at most n_list_max)
-// -> row i of out [n_list_max, d].  Same sums in the same order as ur_rows_reduce gives those ids.
-extern "C" int ur_rows_reduce_subset(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
-                                     const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
-                                     const float* vec_b, int32_t G, int32_t d, const int32_t* u_list, const int32_t* n_list_dev,
-                                     int64_t n_list_max, float* out, void* stream) {
-  UR_REQUIRE(u_list && n_list_dev && n_list_max > 0, UR_ERR_ARG, "ur_rows_reduce_subset: list");
-  return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, out, nullptr, nullptr, u_list,
-                          n_list_dev, n_list_max, stream);
+  return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, uniq_grad, sumsq_dev, out_rows, stream, rd);
 }
 
 constexpr int UR_CATCHUP_BLOCKS = 1024;
 static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* grad, int d,
-                              const float* scale, hipStream_t st, const int32_t* skip_mark = nullptr) {
+                              const float* scale, hipStream_t st) {
   ProfScope ps(PC_ADAM, st, (double)n_max * d * 4.0 * 7);
   AdamK a{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
   a.lb1 = cfg->beta1 > 0.f ? (float)log2((double)cfg->beta1) : -1e30f;
@@ -1370,12 +1175,11 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
   if (blocks > 8192) blocks = 8192;
   // the catch-up walks a (usually short, often empty) filtered list with a grid-stride loop: a grid sized for the plan's capacity was
   // 3 520 workgroups that start, read the count and leave -- 20 us of dispatch at the tail of every step beside the dW launch
-  if (mode != 0 && blocks > UR_CATCHUP_BLOCKS) blocks = UR_CATCHUP_BLOCKS;   // (mode 2: the short list of rows two consecutive batches share)
+  if (mode != 0 && blocks > UR_CATCHUP_BLOCKS) blocks = UR_CATCHUP_BLOCKS;
   if (blocks < 1) blocks = 1;
   const int* guard_dev = id_guard().dev;
 #define GO(T, MD) hipLaunchKernelGGL((sparse_adam_kernel<T, MD>), dim3(blocks), dim3(256), 0, st, a, (float4*)table, (float4*)m, \
-                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale, skip_mark, \
-                                     guard_dev)
+                                     (float4*)v, last_step, uniq_idx, n_uniq_dev, (long long)n_max, (const float4*)grad, d / 4, scale, guard_dev)
 #define SW(MD)            \
   switch (tpr) {          \
     case 4: GO(4, MD); break;   \
@@ -1383,7 +1187,7 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
     case 16: GO(16, MD); break; \
     default: GO(32, MD); break; \
   }
-  if (mode == 0) { SW(0) } else if (mode == 1) { SW(1) } else { SW(2) }
+  if (mode == 0) { SW(0) } else { SW(1) }
 #undef SW
 #undef GO
   UR_LAUNCH_CHECK();
@@ -1405,21 +1209,6 @@ extern "C" int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m,
   UR_REQUIRE(table && m && v && uniq_idx && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_sparse_adam_rows: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_sparse_adam_rows: d=%d n_max=%lld", d, (long long)n_max);
   return launch_sparse_adam(0, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, uniq_grad, d, grad_scale_dev, as_stream(stream));
-}
-
-// ur_sparse_adam_rows split over two launches (the update of a step running beside the NEXT forward pass, facility/optimizer.py):
-// hot != 0: the rows the next batch reads too, a short list with its own gradients (ur_rows_reduce_subset) -- and when the step is
-// skipped (grad_scale_dev < 0) they take it as a zero-gradient step; hot == 0: the whole plan minus the ids with skip_mark[u] != 0.
-extern "C" int ur_sparse_adam_rows_split(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
-                                         const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad,
-                                         int32_t d, const float* grad_scale_dev, int32_t hot, const int32_t* skip_mark, void* stream) {
-  int rc = check_adam(cfg, "ur_sparse_adam_rows_split");
-  if (rc) return rc;
-  UR_REQUIRE(table && m && v && uniq_idx && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_sparse_adam_rows_split: null pointer");
-  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_sparse_adam_rows_split: d=%d n_max=%lld", d, (long long)n_max);
-  UR_REQUIRE(hot ? skip_mark == nullptr : skip_mark != nullptr, UR_ERR_ARG, "ur_sparse_adam_rows_split: hot list XOR skip marks");
-  return launch_sparse_adam(hot ? 2 : 0, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, uniq_grad, d, grad_scale_dev,
-                            as_stream(stream), skip_mark);
 }
 
 extern "C" int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,

@@ -300,7 +300,7 @@ struct SideCtx {
   bool late_join = false;      // ur_sasrec_side_publish: the next ur_sasrec_fwd joins `done` itself, after its first launch
   bool ok = false;
 };
-// test aid (UR_SIDE_TEST_DELAY_US): a kernel that spins for that long on the side stream -- it widens every window in which the main stream
+// test aid (UR_TEST hook side_delay_us): a kernel that spins for that long on the side stream -- it widens every window in which the main stream
 // could touch what the side stream has not finished with (tools/race_runs.sh, tests/test_fallback_paths_gpu.py)
 __global__ void side_delay_kernel(long long cycles) {
   const long long t0 = wall_clock64();
@@ -597,9 +597,9 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       UR_HIP(hipStreamWaitEvent(sc->stream, sc->ev[n_fork], 0));
       ++n_fork;
       s2 = sc->stream;
-      // test aid (UR_SIDE_TEST_DELAY_US, see ur_sasrec_side_stream): the side stream starts this pass's work that much late, i.e. the
+      // test aid (hook side_delay_us, see ur_sasrec_side_stream): the side stream starts this pass's work that much late, i.e. the
       // main stream runs that far ahead of everything the side stream still has to read
-      static const int delay_us = getenv("UR_SIDE_TEST_DELAY_US") ? atoi(getenv("UR_SIDE_TEST_DELAY_US")) : 0;
+      static const int delay_us = ur_test_hook("side_delay_us");
       if (delay_us > 0 && n_fork == 1) hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(64), 0, s2, (long long)delay_us * 100);
     }
     {   // every queued product in ONE launch (gemm_tn_group_kernel): few token splits each, small partial tiles
@@ -942,11 +942,11 @@ extern "C" int ur_sasrec_bwd_join(void* stream) {
 // The side stream while a deferred pass is pending (else NULL): what the caller enqueues there runs behind the pass's dense-gradient
 // reductions with no cross-stream wait in between (the dense half of the optimizer step: the main stream's wait for `done` + the launch
 // + the wait's latency were ~30 us at the end of every step during which the main stream did 5 us of work).
-// (UR_SIDE_TEST_DELAY_US: the spin kernel goes in front of whatever the caller enqueues on the side stream)
+// (hook side_delay_us: the spin kernel goes in front of whatever the caller enqueues on the side stream)
 extern "C" void* ur_sasrec_side_stream(void) {
   SideCtx* sc = side_ctx(true);
   if (!(sc && sc->join_pending)) return nullptr;
-  static const int delay_us = getenv("UR_SIDE_TEST_DELAY_US") ? atoi(getenv("UR_SIDE_TEST_DELAY_US")) : 0;
+  static const int delay_us = ur_test_hook("side_delay_us");
   if (delay_us > 0) hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(64), 0, sc->stream, (long long)delay_us * 100);   // wall_clock64: 100 MHz
   return (void*)sc->stream;
 }

@@ -192,7 +192,6 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         # against the rows it owns; the table gradient of a shard is complete on its owner (dense over the shard, no exchange)
         # rows of the next batch fetched a step ahead (_prefetch_rows); UR_PREFETCH_ROWS=0: in the step itself (rounds 1-3).  Not with
         # fullsoftmax: its dense update moves every row of the item shard in every step
-        self._riders = os.environ.get("UR_REDUCE_RIDERS", "1") not in ("", "0")    # flag rows / step flags inside the reduce launches
         # UR_DENSE_SIDE=0 (rung "native-1comm-1stream" of bench.py's fallback ladder): the dense half -- all-reduce + update -- on the main
         # stream behind the encoder's reductions, as with gradient clipping; with UR_COMM_SINGLE=1 every collective of a step then goes
         # through ONE communicator on ONE stream, in program order: the shape of the reference's own DDP step
@@ -618,27 +617,17 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
             d = bf["compact"].shape[1]
             # (the sums land in their exchange slots: no scatter pass; padding slots keep stale bytes that no owner reads)
             # (this rank's flag row rides in the reduce launch -- slot 0 of every block; the step flags of all ranks ride in the owner-side
-            # reduce of the first table: two launches less per step than ur_shard_exchange_grads(NULL) + ur_shard_step_flags)
-            if self._riders:
-                ops.rows_reduce_riders(c["pl"], rows, coef.reshape(-1) if coef is not None else None, vec, G, d, W, c["cap"], out=sb["send_grads"],
-                                       out_rows=bf["slot"], flag_rows=(loss_buf, bf["flags"]))
-                if self._native:
-                    ops.comm_all_to_all(sb["send_grads"], sb["grads_in"], W, ahead=False, kind="grads")
-                else:
-                    self._a2a(sb["send_grads"], sb["grads_in"], "a2a_row_grads")
-                owner_grads[name] = ops.rows_reduce_riders(c["own"], sb["grads_in"], None, None, 1, d, W, c["cap"],
-                                                           zero_tail=self.grad_clip is not None, step_flags_out4=out4 if first else None)
-                first = False
-                continue
-            ops.rows_reduce(c["pl"], rows, coef.reshape(-1) if coef is not None else None, vec, G, d, out=sb["send_grads"], out_rows=bf["slot"])
-            ops.shard_exchange_grads(None, bf["uos"], W, c["cap"], sb["send_grads"], grads_in=sb["grads_in"], transport=self._native,
-                                     loss_out=loss_buf, flags=bf["flags"])
-            if not self._native:
+            # reduce of the first table: two launches less per step than ur_shard_exchange_grads(NULL) + ur_shard_step_flags, which
+            # remain in the ABI for callers that reduce elsewhere)
+            ops.rows_reduce_riders(c["pl"], rows, coef.reshape(-1) if coef is not None else None, vec, G, d, W, c["cap"], out=sb["send_grads"],
+                                   out_rows=bf["slot"], flag_rows=(loss_buf, bf["flags"]))
+            if self._native:
+                ops.comm_all_to_all(sb["send_grads"], sb["grads_in"], W, ahead=False, kind="grads")
+            else:
                 self._a2a(sb["send_grads"], sb["grads_in"], "a2a_row_grads")
-            if first:
-                ops.shard_step_flags(sb["grads_in"], W, c["cap"], out4)
-                first = False
-            owner_grads[name] = ops.rows_reduce(c["own"], sb["grads_in"], None, None, 1, d, zero_tail=self.grad_clip is not None)
+            owner_grads[name] = ops.rows_reduce_riders(c["own"], sb["grads_in"], None, None, 1, d, W, c["cap"],
+                                                       zero_tail=self.grad_clip is not None, step_flags_out4=out4 if first else None)
+            first = False
         dense_shard = {}
         if self._fs_dgrad is not None:      # fullsoftmax: the encoder's row-sparse part of the item table's gradient folds into the dense one
             dense_shard["item_embedding"] = self._fs_dgrad

@@ -229,15 +229,10 @@ class BaseRecommender(AbstractRecommender):
     _deferred_dense_grad = None
     _deferred_reads = ()
 
-    _row_tail_join = None     # set by the optimizer while row updates of a step may be running on its tail stream
-
     def join_side_updates(self):
         """The optimizer may leave the dense half of its step running on the encoder's side stream (joined by the next encoder forward
-        pass) and most of the row updates on its tail stream (nothing the next forward pass reads): anything else that reads parameters
-        or their optimizer state on the current stream calls this first."""
+        pass): anything else that reads parameters or their optimizer state on the current stream calls this first."""
         ops.sasrec_side_join()
-        if self._row_tail_join is not None:
-            self._row_tail_join()
 
     def state_dict(self, *args, **kwargs):
         self.join_side_updates()

@@ -437,11 +437,9 @@ def shard_fixup_apply(compact, rows2, slot2, world, cap, cap2):
     check(lib.ur_shard_fixup_apply(_p(compact), _p(rows2), _p(slot2), int(world), int(cap), int(cap2), d, _stream()), "ur_shard_fixup_apply")
 
 
-def rows_split_hot(pl: RowsPlan, last_step, excl: RowsPlan, out=None, want_u=False):
+def rows_split_hot(pl: RowsPlan, last_step, excl: RowsPlan, out=None):
     """pl's unique rows split against excl's (sorted unique): -> (cold, hot) plan-like lists (uniq_idx / n_uniq only, arbitrary order);
-    cold = not in excl and (last_step is None or last_step[row] != 0), hot = in both.  out: the result of an earlier call, reused.
-    want_u: -> (cold, hot, hot_u int32[n], excl_mark int32[excl.n]): the index of every hot row in excl's unique list, and the marks of
-    those entries (what splits excl's own update: ops.rows_reduce_subset / sparse_adam_rows_split)."""
+    cold = not in excl and (last_step is None or last_step[row] != 0), hot = in both.  out: the result of an earlier call, reused."""
     _chk(last_step, torch.int32, "last_step", allow_none=True)
     dev = pl.uniq_idx.device
     if out is None:
@@ -453,17 +451,11 @@ def rows_split_hot(pl: RowsPlan, last_step, excl: RowsPlan, out=None, want_u=Fal
             o.n_uniq = torch.empty(1, dtype=torch.int32, device=dev)
             o.seg_start = o.sorted_pos = None
             out.append(o)
-        if want_u:
-            out.append(torch.empty(pl.n, dtype=torch.int32, device=dev))
-            out.append(torch.zeros(excl.n if excl is not None else 1, dtype=torch.int32, device=dev))
         out = tuple(out)
     cold, hot = out[0], out[1]
-    hot_u, mark = (out[2], out[3]) if want_u else (None, None)
     eu, en, em = (excl.uniq_idx, excl.n_uniq, excl.n) if excl is not None else (None, None, 0)
-    if mark is not None and excl is not None and mark.numel() < excl.n:
-        raise _lib.UnirecAmdError("rows_split_hot: reused mark buffer is smaller than the exclusion plan")
     check(lib.ur_rows_split_hot(_p(pl.uniq_idx), _p(pl.n_uniq), pl.n, _p(last_step), _p(eu), _p(en), int(em), _p(cold.uniq_idx),
-                                _p(cold.n_uniq), _p(hot.uniq_idx), _p(hot.n_uniq), _p(hot_u), _p(mark), _stream()), "ur_rows_split_hot")
+                                _p(cold.n_uniq), _p(hot.uniq_idx), _p(hot.n_uniq), None, None, _stream()), "ur_rows_split_hot")
     return out
 
 
@@ -539,18 +531,6 @@ def rows_reduce_riders(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, world, cap, ou
     return out
 
 
-def rows_reduce_subset(pl: RowsPlan, rows_a, coef_b, vec_b, G, d, u_list, n_list, n_list_max, out=None) -> torch.Tensor:
-    """rows_reduce for the unique ids u_list[0 .. n_list) only (n_list: device int32[1]); entry i -> out[i, :]"""
-    _chk(rows_a, torch.float32, "rows_a", allow_none=True); _chk(coef_b, torch.float32, "coef_b", allow_none=True)
-    _chk(vec_b, torch.float32, "vec_b", allow_none=True); _chk(u_list, torch.int32, "u_list"); _chk(n_list, torch.int32, "n_list")
-    if out is None:
-        out = torch.empty(n_list_max, d, dtype=torch.float32, device=pl.uniq_idx.device)
-    check(lib.ur_rows_reduce_subset(_p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, _p(rows_a), pl.n_a,
-                                    _p(coef_b), _p(vec_b), int(G), int(d), _p(u_list), _p(n_list), int(n_list_max), _p(out), _stream()),
-          "ur_rows_reduce_subset")
-    return out
-
-
 # --------------------------------------------------------------------------------------------- optimizer
 OPT_ALGOS = {"adam": 0, "adamw": 1, "sgd": 2, "adagrad": 3, "rmsprop": 4}
 # torch's defaults for what the reference does not pass (trainer.py:134-152): (beta1, beta2 | alpha, eps)
@@ -577,16 +557,6 @@ def sparse_adam_rows(cfg, table, m, v, pl: RowsPlan, uniq_grad, last_step=None, 
     _chk(last_step, torch.int32, "last_step", allow_none=True)
     check(lib.ur_sparse_adam_rows(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
                                   _p(uniq_grad), table.shape[1], _p(grad_scale), _stream()), "ur_sparse_adam_rows")
-
-
-def sparse_adam_rows_split(cfg, table, m, v, pl: RowsPlan, uniq_grad, last_step=None, grad_scale=None, hot=False, skip_mark=None):
-    """hot: pl is the short list of rows the next batch reads too (uniq_grad in list order; a skipped step becomes a zero-gradient step);
-    else: the whole plan minus the unique ids with skip_mark[u] != 0 -- see ur_sparse_adam_rows_split"""
-    _chk(table, torch.float32, "table")
-    _chk(last_step, torch.int32, "last_step", allow_none=True); _chk(skip_mark, torch.int32, "skip_mark", allow_none=True)
-    check(lib.ur_sparse_adam_rows_split(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
-                                        _p(uniq_grad), table.shape[1], _p(grad_scale), 1 if hot else 0, _p(skip_mark), _stream()),
-          "ur_sparse_adam_rows_split")
 
 
 def rows_filter_touched(pl: RowsPlan, last_step) -> RowsPlan:

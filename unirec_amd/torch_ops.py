@@ -357,8 +357,6 @@ NOT_OPS = {
     "ur_loop_world": _COMM, "ur_loop_post": _COMM, "ur_loop_all_to_all_pull": _COMM, "ur_loop_all_reduce_pull": _COMM, "ur_loop_finish": _COMM, "ur_comm_unique_id": _COMM, "ur_comm_init": _COMM, "ur_comm_destroy": _COMM, "ur_comm_all_reduce_sum": _COMM,
     "ur_comm_all_to_all": _COMM, "ur_shard_fixup_plan": _SHARD, "ur_shard_fixup_apply": _SHARD, "ur_rows_split_hot": _SHARD,
     "ur_rows_reduce_riders": "ur_rows_reduce + the flag rows / step flags of the row-sharded step riding in the same launch: a scheduling variant of the registered ops rows_reduce and a2a_embedding_grads",
-    "ur_rows_reduce_subset": "ur_rows_reduce over a subset of the plan's ids (the update of a step split so that most of it runs beside the next forward pass): a scheduling variant of the registered op rows_reduce",
-    "ur_sparse_adam_rows_split": "ur_sparse_adam_rows over a row list / minus marked ids (same split): a scheduling variant of the registered op sparse_adam_rows",
     "ur_sumsq": _FAMILY + " (gradient-clipping helpers of the optimizer)", "ur_clip_coef": _FAMILY + " (gradient-clipping helpers)",
     "ur_clip_coef_guarded": _FAMILY + " (gradient-clipping helpers)",
     "ur_sample_negatives_pop": _FAMILY + " (popularity-biased sampler)", "ur_device_build_seq": _FAMILY + " (device row builder)",
