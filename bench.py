@@ -648,8 +648,18 @@ def gather_microbench(table, device):
     read = n * (d * 4 + 8) / (best * 1e-3) / 1e9
     # HBM bytes per launch from the committed rocprofv3 PMC passes of the same two launches (tools/gather_pmc.sh: FETCH_SIZE x 2 per
     # the gfx950 note, + WRITE_SIZE; separate passes, kernel trace only): counters cannot be read from inside this process
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_b_gather_pmc.json")
-    pmc = json.load(open(pmc_path)).get("per_kernel", {}) if os.path.exists(pmc_path) else {}
+    # (the newest profiles/r*_gather_pmc.json whose kernel-source digest is THIS tree's -- tools/gather_pmc.sh writes it -- else none:
+    # a summary of other kernels is not quoted)
+    import glob
+    pmc, pmc_src = {}, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gather_pmc.json")), reverse=True):
+        try:
+            js = json.load(open(f))
+        except Exception:    # noqa: BLE001
+            continue
+        if js.get("csrc_digest") == csrc_digest():
+            pmc, pmc_src = js.get("per_kernel", {}), os.path.basename(f)
+            break
 
     def traffic(tag):
         for k, v in pmc.items():
@@ -659,7 +669,7 @@ def gather_microbench(table, device):
                 return {"hbm_read_bytes": int(2 * v["FETCH_SIZE"] * 1024), "hbm_write_bytes": int(v.get("WRITE_SIZE", 0) * 1024),
                         "l2_hit_rate": round(v["TCC_HIT_sum"] / tot, 3) if tot else None,
                         "l1_tlb_miss_rate": round(v.get("TCP_UTCL1_TRANSLATION_MISS_sum", 0) / tlb, 3) if tlb else None,
-                        "source": "profiles/r02_b_gather_pmc.json (same launch shape)"}
+                        "source": f"profiles/{pmc_src} (same launch shape; kernel sources digest {csrc_digest()}: taken on this tree)"}
         return None
     copy = {"bound": "hbm", "kernel": "gather_kernel<int64,32,4> (gather that WRITES the rows back: n*d*4 B of stores compete for HBM; non-temporal loads and stores)",
             "achieved": round(read, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(read / HBM_PEAK_GBPS, 4),
@@ -975,7 +985,11 @@ def main():
         if dom in per_class and per_class[dom]:
             roof["traffic"] = per_class[dom]["hbm_bytes_per_launch"]
             roof["traffic_unit"] = f"HBM bytes per launch (rocprofv3 PMC, profiles/{os.path.basename(pmc)})"
-            roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * valid_frac * 1e6 / max(1, c["launches"] / max(1, (a.steps + PROF_EVERY - 1) // PROF_EVERY)))
+            # per launch of the SAME kernels the PMC summary counts (the class's main kernel: gemm_tn = the grouped weight-gradient launches,
+            # two a step; the deferred reduce_batch launches of the class are a PMC class of their own and carry no operand traffic)
+            lps = per_class[dom]["launches"] / max(1, pmc_json.get("steps_profiled", 1))
+            roof["algorithmic_bytes_per_launch"] = int(ALGO_BYTES_PER_STEP.get(dom, 0) * valid_frac * 1e6 / max(1.0, lps))
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(1, roof["algorithmic_bytes_per_launch"]), 3)
     # the whole step against its two floors: algorithmic flops of the MFMA classes (the launchers' own counts from the bracketed warm-up
     # steps, padded-row counts scaled to the real token rows) at the fp32 MFMA peak, and every kernel's PMC bytes at the rate a
     # streaming copy reaches on this part

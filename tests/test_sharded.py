@@ -467,14 +467,7 @@ def test_fixup_plan_split_and_apply_match_a_host_statement(world, cap, cap2, n_p
     touched = rng.random(n_local) < 0.5
     last[torch.from_numpy(np.nonzero(touched)[0]).to(dev)] = 3
     for use_last in (True, False):
-        cold, hot, hot_u, mark = ops.rows_split_hot(own, last if use_last else None, prev, want_u=prev is not None) if prev is not None \
-            else ops.rows_split_hot(own, last if use_last else None, prev) + (None, None)
-        if hot_u is not None:       # the index of every hot row in the other plan's unique list, and that list's marks
-            nh = int(hot.n_uniq)
-            assert torch.equal(prev.uniq_idx[hot_u[:nh].long()], hot.uniq_idx[:nh])
-            exp_mark = torch.zeros(prev.n, dtype=torch.int32, device=dev)
-            exp_mark[hot_u[:nh].long()] = 1
-            assert torch.equal(mark[: prev.n], exp_mark)
+        cold, hot = ops.rows_split_hot(own, last if use_last else None, prev)
         got_c = sorted(cold.uniq_idx[: int(cold.n_uniq)].cpu().tolist())
         got_h = sorted(hot.uniq_idx[: int(hot.n_uniq)].cpu().tolist())
         assert got_h == sorted(int(r) for r in own_rows if r != 0 and int(r) in hotset)

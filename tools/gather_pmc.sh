@@ -22,7 +22,13 @@ for f in sorted(glob.glob("/tmp/gp_*/g_counter_collection.csv")):
         for c, v in cs.items():
             res[k][c].append(v)
 out = {k: {c: sorted(v)[len(v) // 2] for c, v in cs.items()} for k, cs in res.items()}   # median over the launches of a kernel
-json.dump({"source": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python tools/gather_pmc.py (median over 3 launches per kernel)",
+import hashlib, os
+root = os.path.join("$GRAFT_REPO_ROOT", "unirec_amd", "csrc")
+h = hashlib.sha256()
+for f in sorted(os.listdir(root)):
+    if f.endswith((".hip", ".h", ".cpp")):
+        h.update(f.encode()); h.update(open(os.path.join(root, f), "rb").read())
+json.dump({"csrc_digest": h.hexdigest()[:16], "source": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python tools/gather_pmc.py (median over 3 launches per kernel)",
            "units": "FETCH_SIZE / WRITE_SIZE in KB (gfx950: HBM read bytes = 2 x FETCH_SIZE, MI355X_MICROARCH.md)", "per_kernel": out},
           open("$out/${tag}_gather_pmc.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
