@@ -136,6 +136,7 @@ extern "C" int64_t ur_atthist_workspace_bytes(const UrAttHistCfg* cfg) {
 
 extern "C" int ur_atthist_fwd(const UrAttHistCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                               const int32_t* item_seq, float* user_emb, void* ws, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = atthist_check(cfg);
   if (rc) return rc;
   UR_REQUIRE(item_table && dense && item_seq && user_emb && ws && n_items > 0, UR_ERR_ARG, "ur_atthist_fwd: null pointer");
@@ -159,6 +160,7 @@ extern "C" int ur_atthist_fwd(const UrAttHistCfg* cfg, const float* item_table, 
 extern "C" int ur_atthist_bwd(const UrAttHistCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                               const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad, float* d_emb_rows,
                               void* stream) {
+  UR_TRACE_SCOPE();
   int rc = atthist_check(cfg);
   if (rc) return rc;
   UR_REQUIRE(dense && item_seq && d_user_emb && ws && dense_grad && d_emb_rows, UR_ERR_ARG, "ur_atthist_bwd: null pointer");

@@ -79,6 +79,17 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// ---- tracing hooks ("roctx ranges per op"; the reference wraps a run in cProfile, unirec/main/main.py:490-499).  UR_ROCTX=1:
+// every C-ABI entry that enqueues device work pushes a roctx range named after itself for the duration of the call (roctxRangePushA /
+// roctxRangePop, resolved at run time from libroctx64.so): a `rocprofv3 --marker-trace --kernel-trace` timeline then shows which entry
+// point each launch belongs to.  Off (the default): one predictable branch per call.
+struct TraceScope {
+  bool on;
+  explicit TraceScope(const char* name);
+  ~TraceScope();
+};
+#define UR_TRACE_SCOPE() ::ur::TraceScope ur_trace_scope_(__func__)
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -318,6 +318,7 @@ extern "C" int64_t ur_convformer_workspace_bytes(const UrConvFormerCfg* cfg) {
 
 extern "C" int ur_convformer_fwd(const UrConvFormerCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                                  const int32_t* item_seq, const int64_t* seq_len, float* user_emb, void* ws, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = cf_check(cfg);
   if (rc) return rc;
   UR_REQUIRE(item_table && dense && item_seq && user_emb && ws && n_items > 0, UR_ERR_ARG, "ur_convformer_fwd: null pointer");
@@ -367,6 +368,7 @@ extern "C" int ur_convformer_fwd(const UrConvFormerCfg* cfg, const float* item_t
 extern "C" int ur_convformer_bwd(const UrConvFormerCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                                  const int32_t* item_seq, const int64_t* seq_len, const float* d_user_emb, void* ws, float* dense_grad,
                                  float* d_emb_rows, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = cf_check(cfg);
   if (rc) return rc;
   UR_REQUIRE(dense && item_seq && d_user_emb && ws && dense_grad && d_emb_rows, UR_ERR_ARG, "ur_convformer_bwd: null pointer");

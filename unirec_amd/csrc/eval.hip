@@ -615,6 +615,7 @@ extern "C" int ur_full_rank(const float* user_emb, const float* item_table, int6
                             const int64_t* target, const int64_t* user_id, const int64_t* hist_ptr, const int32_t* hist_sorted,
                             int64_t n_users, const float* user_bias, const float* item_bias, float tau, int32_t* rank,
                             float* target_score, float* thr_ws, void* stream) {
+  UR_TRACE_SCOPE();
   return full_rank_impl(0, user_emb, item_table, n_items, B, d, target, user_id, hist_ptr, hist_sorted, n_users, user_bias, item_bias, tau,
                         rank, target_score, thr_ws, stream);
 }
@@ -623,6 +624,7 @@ extern "C" int ur_full_rank_shard(int32_t phase, const float* user_emb, const fl
                                   const int64_t* local_target, const int64_t* user_id, const int64_t* hist_ptr,
                                   const int32_t* hist_sorted_local, int64_t n_users, const float* item_bias_local, int64_t excl_row,
                                   float* thr, int32_t* rank_partial, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(phase == 1 || phase == 2, UR_ERR_ARG, "ur_full_rank_shard: phase=%d", phase);
   UR_REQUIRE(excl_row < n_local, UR_ERR_ARG, "ur_full_rank_shard: excl_row=%lld", (long long)excl_row);
   return full_rank_impl(phase, user_emb, shard_table, n_local, B, d, local_target, user_id, phase == 2 ? hist_ptr : nullptr,
@@ -640,6 +642,7 @@ extern "C" int ur_full_topk(const float* user_emb, const float* item_table, int6
                             const int64_t* user_id, const int64_t* hist_ptr, const int32_t* hist_sorted, int64_t n_users,
                             const float* user_bias, const float* item_bias, float tau, float* topk_scores, int64_t* topk_ids, void* ws,
                             void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(user_emb && item_table && topk_scores && topk_ids && ws, UR_ERR_ARG, "ur_full_topk: null pointer");
   UR_REQUIRE(B > 0 && d > 0 && d % 4 == 0 && n_items > 0 && n_items < (1LL << 31), UR_ERR_ARG, "ur_full_topk: shape");
   UR_REQUIRE(k > 0 && k <= 1024, UR_ERR_UNSUPPORTED, "ur_full_topk: k=%d (1..1024)", k);

@@ -326,6 +326,7 @@ extern "C" int ur_loop_detach(void) {
   return UR_OK;
 }
 extern "C" int ur_loop_post(const void* send, int32_t comm, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(t_loop.g && send && (comm == 0 || comm == 1), UR_ERR_ARG, "ur_loop_post: not attached / bad argument");
   LoopRank& me = t_loop.g->rank[t_loop.rank];
   hipStream_t st = as_stream(stream);
@@ -335,6 +336,7 @@ extern "C" int ur_loop_post(const void* send, int32_t comm, void* stream) {
   return UR_OK;
 }
 extern "C" int ur_loop_all_to_all_pull(void* recv, int64_t bytes_per_peer, int32_t kind, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(t_loop.g && recv && bytes_per_peer > 0 && kind >= 0 && kind <= 2, UR_ERR_ARG, "ur_loop_all_to_all_pull: not attached / bad argument");
   LoopGroup& g = *t_loop.g;
   hipStream_t st = as_stream(stream);
@@ -350,6 +352,7 @@ extern "C" int ur_loop_all_to_all_pull(void* recv, int64_t bytes_per_peer, int32
   return UR_OK;
 }
 extern "C" int ur_loop_all_reduce_pull(int64_t n, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(t_loop.g && n > 0, UR_ERR_ARG, "ur_loop_all_reduce_pull: not attached / bad argument");
   LoopGroup& g = *t_loop.g;
   LoopRank& me = g.rank[t_loop.rank];
@@ -373,6 +376,7 @@ extern "C" int ur_loop_all_reduce_pull(int64_t n, void* stream) {
   return UR_OK;
 }
 extern "C" int ur_loop_finish(int32_t comm, float* all_reduce_out, int64_t n, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(t_loop.g && (comm == 0 || comm == 1), UR_ERR_ARG, "ur_loop_finish: not attached / bad argument");
   LoopGroup& g = *t_loop.g;
   LoopRank& me = g.rank[t_loop.rank];
@@ -429,6 +433,7 @@ extern "C" int ur_comm_destroy(void) {
 }
 
 extern "C" int ur_comm_all_reduce_sum(float* buf, int64_t n, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(buf && n > 0, UR_ERR_ARG, "ur_comm_all_reduce_sum: bad argument");
   UR_REQUIRE(g_comm.comm, UR_ERR_ARG, "ur_comm_all_reduce_sum: no communicator (ur_comm_init)");
   ProfScope ps(PC_ALLREDUCE, as_stream(stream), (double)n * 4.0 * 2.0 * (g_comm.world - 1) / g_comm.world);   // (ring all-reduce: 2 (W - 1) / W of the buffer leaves the rank)
@@ -439,6 +444,7 @@ extern "C" int ur_comm_all_reduce_sum(float* buf, int64_t n, void* stream) {
 // equal-split all-to-all of a packed buffer through the library's communicators: ahead != 0 = the second one (the dense all-reduce's and
 // the id exchange's: work issued a step ahead on the plan stream), else the row communicator of the step's own exchanges.
 extern "C" int ur_comm_all_to_all(const void* send, void* recv, int64_t bytes_per_peer, int32_t ahead, int32_t kind, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(send && recv && bytes_per_peer > 0 && kind >= 0 && kind <= 2, UR_ERR_ARG, "ur_comm_all_to_all: bad argument");
   UR_REQUIRE(g_comm.comm, UR_ERR_ARG, "ur_comm_all_to_all: no communicator (ur_comm_init)");
   const int cls = kind == 0 ? PC_A2A_IDS : kind == 1 ? PC_A2A_ROWS : PC_A2A_GRADS;   // (which per-collective timer the group is booked on)
@@ -448,6 +454,7 @@ extern "C" int ur_comm_all_to_all(const void* send, void* recv, int64_t bytes_pe
 extern "C" int ur_shard_fixup_plan(const int32_t* recv_ids, int32_t world, int32_t cap, const int32_t* prev_uniq,
                                    const int32_t* prev_n_uniq_dev, int64_t prev_n_max, int32_t cap2, int32_t* req2, int32_t* slot2,
                                    int32_t* counts_ws, int32_t* flags_dev, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(recv_ids && req2 && slot2 && counts_ws && flags_dev, UR_ERR_ARG, "ur_shard_fixup_plan: null pointer");
   UR_REQUIRE(world >= 1 && cap > 0 && cap2 > 0 && cap2 <= cap && (world == 1 || cap >= 64) &&
                  (prev_uniq == nullptr || (prev_n_uniq_dev && prev_n_max > 0 && prev_n_max < (1LL << 31))),
@@ -466,6 +473,7 @@ extern "C" int ur_shard_fixup_plan(const int32_t* recv_ids, int32_t world, int32
 
 extern "C" int ur_shard_fixup_apply(float* compact, const float* rows2, const int32_t* slot2, int32_t world, int32_t cap, int32_t cap2,
                                     int32_t d, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(compact && rows2 && slot2, UR_ERR_ARG, "ur_shard_fixup_apply: null pointer");
   UR_REQUIRE(world >= 1 && cap > 0 && cap2 > 0 && d > 0 && d % 4 == 0, UR_ERR_ARG, "ur_shard_fixup_apply: world=%d cap=%d cap2=%d d=%d", world, cap, cap2, d);
   const long long n2 = (long long)world * cap2;
@@ -480,6 +488,7 @@ extern "C" int ur_shard_fixup_apply(float* compact, const float* rows2, const in
 extern "C" int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_uniq_dev, int32_t* counts_dev, int64_t n_local,
                                      int32_t world, int32_t cap, int32_t* send_ids, int32_t* slot_of_uniq, int32_t* u_of_slot,
                                      int32_t* flags_dev, int32_t* recv_ids, int32_t transport, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(uniq_key && n_uniq_dev && send_ids && slot_of_uniq && u_of_slot && flags_dev, UR_ERR_ARG,
              "ur_shard_exchange_ids: null pointer");
   UR_REQUIRE(world >= 1 && world <= 64 && cap > 0 && (long long)world * cap < (1LL << 31), UR_ERR_ARG,
@@ -499,6 +508,7 @@ extern "C" int ur_shard_exchange_ids(const int32_t* uniq_key, const int32_t* n_u
 // all-to-all into compact [world * cap, d]: row q of `compact` is the row slot q of ur_shard_exchange_ids asked for.
 extern "C" int ur_shard_exchange_rows(const float* table, const int32_t* req_ids, int32_t world, int32_t cap, int32_t d, float* rows_ws,
                                       float* compact, int32_t transport, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(table && req_ids && rows_ws, UR_ERR_ARG, "ur_shard_exchange_rows: null pointer");
   UR_REQUIRE(world >= 1 && cap > 0 && d > 0 && d % 4 == 0, UR_ERR_ARG, "ur_shard_exchange_rows: world=%d cap=%d d=%d", world, cap, d);
   hipStream_t st = as_stream(stream);
@@ -514,6 +524,7 @@ extern "C" int ur_shard_exchange_rows(const float* table, const int32_t* req_ids
 extern "C" int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_of_slot, int32_t world, int32_t cap, int32_t d,
                                        const float* loss_out, const int32_t* flags_dev, float* send_ws, float* grads_in,
                                        int32_t transport, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE((uniq_grad == nullptr || u_of_slot) && send_ws, UR_ERR_ARG, "ur_shard_exchange_grads: null pointer");
   UR_REQUIRE(world >= 1 && cap > 0 && d > 0 && d % 4 == 0, UR_ERR_ARG, "ur_shard_exchange_grads: world=%d cap=%d d=%d", world, cap, d);
   hipStream_t st = as_stream(stream);
@@ -536,6 +547,7 @@ extern "C" int ur_shard_exchange_grads(const float* uniq_grad, const int32_t* u_
 // after (3): the flags every rank put into slot 0 of its blocks -> out4 = [gradient scale (1 / world, or -1 = skip the step), mean loss,
 // ranks with a NaN loss, ranks with a capacity overflow]
 extern "C" int ur_shard_step_flags(const float* grads_in, int32_t world, int32_t cap, int32_t d, float* out4, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(grads_in && out4 && world >= 1 && cap > 0 && d >= 4, UR_ERR_ARG, "ur_shard_step_flags: bad argument");
   hipLaunchKernelGGL(shard_step_flags_kernel, dim3(1), dim3(64), 0, as_stream(stream), grads_in, world, cap, d, out4);
   UR_LAUNCH_CHECK();

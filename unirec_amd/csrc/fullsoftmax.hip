@@ -242,6 +242,7 @@ extern "C" int ur_full_softmax_fwd(const float* user_emb, const float* item_tabl
                                    const int64_t* target, const int64_t* user_id, const float* user_bias, const float* item_bias,
                                    float tau, float score_clip, const float* target_score, float* lse, float* loss_out, void* ws,
                                    void* stream) {
+  UR_TRACE_SCOPE();
   int rc = fs_check(user_emb, item_table, n_items, B, d, target, user_id, user_bias, tau, "ur_full_softmax_fwd");
   if (rc) return rc;
   UR_REQUIRE(target_score && lse && loss_out && ws, UR_ERR_ARG, "ur_full_softmax_fwd: null pointer");
@@ -274,6 +275,7 @@ extern "C" int ur_full_softmax_fwd(const float* user_emb, const float* item_tabl
 extern "C" int ur_full_softmax_fwd_shard(const float* user_emb, const float* shard_rows, int64_t n_rows, int32_t B, int32_t d,
                                          const int64_t* target_row, const int64_t* user_id, const float* user_bias,
                                          const float* item_bias_rows, float tau, float score_clip, float* part3, void* ws, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = fs_check(user_emb, shard_rows, n_rows, B, d, target_row, user_id, user_bias, tau, "ur_full_softmax_fwd_shard");
   if (rc) return rc;
   UR_REQUIRE(part3 && ws, UR_ERR_ARG, "ur_full_softmax_fwd_shard: null pointer");
@@ -303,6 +305,7 @@ extern "C" int ur_full_softmax_fwd_shard(const float* user_emb, const float* sha
 
 extern "C" int ur_full_softmax_combine_shards(const float* parts, int32_t world, int32_t B_all, int32_t col0, int32_t B_own, float* lse,
                                               float* loss_out, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(parts && lse && loss_out, UR_ERR_ARG, "ur_full_softmax_combine_shards: null pointer");
   UR_REQUIRE(world > 0 && B_all > 0 && B_own > 0 && col0 >= 0 && col0 + B_own <= B_all, UR_ERR_ARG, "ur_full_softmax_combine_shards: shape");
   hipStream_t st = as_stream(stream);
@@ -354,6 +357,7 @@ extern "C" int ur_full_softmax_bwd(const float* user_emb, const float* item_tabl
                                    const int64_t* target, const int64_t* user_id, const float* user_bias, const float* item_bias,
                                    float tau, float score_clip, const float* lse, const float* d_loss, float* d_user_emb,
                                    float* d_item_table, float* d_item_bias, void* ws, void* stream) {
+  UR_TRACE_SCOPE();
   return fs_bwd_impl(user_emb, item_table, n_items, B, d, target, user_id, user_bias, item_bias, tau, score_clip, lse, d_loss, d_user_emb,
                      d_item_table, d_item_bias, ws, stream, 1);
 }
@@ -362,6 +366,7 @@ extern "C" int ur_full_softmax_bwd_shard(const float* user_emb, const float* sha
                                          const int64_t* target_row, const int64_t* user_id, const float* user_bias, const float* item_bias_rows,
                                          float tau, float score_clip, const float* lse, const float* d_loss, float* d_user_emb,
                                          float* d_shard_rows, float* d_item_bias_rows, int32_t zero_row0, void* ws, void* stream) {
+  UR_TRACE_SCOPE();
   return fs_bwd_impl(user_emb, shard_rows, n_rows, B, d, target_row, user_id, user_bias, item_bias_rows, tau, score_clip, lse, d_loss,
                      d_user_emb, d_shard_rows, d_item_bias_rows, ws, stream, zero_row0 ? 1 : 0);
 }

@@ -783,6 +783,7 @@ int transpose_batch(TransposeBatch& tb, hipStream_t st) {
 extern "C" int ur_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int pro,
                           int epi, int act, const float* bias, const float* aux, int ldaux, const float* gamma, const float* beta,
                           float eps, float* xhat, float* rstd, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, UR_ERR_ARG, "ur_gemm_nt: bad argument");
   ur::GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act; g.bias = bias;
@@ -792,6 +793,7 @@ extern "C" int ur_gemm_nt(const float* A, int lda, const float* W, int ldw, floa
 extern "C" int64_t ur_gemm_tn_workspace_floats(int T, int R, int Cc) { return ur::gemm_tn_ws_floats(T, R, Cc); }
 extern "C" int ur_gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act,
                           float* out, int ldo, float* bias_out, float* ws, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(P && Q && out && ws, UR_ERR_ARG, "ur_gemm_tn: null pointer");
   return ur::gemm_tn(P, ldp, Q, ldq, T, R, Cc, pro_act_on_q, act, out, ldo, bias_out, ws, ur::as_stream(stream));
 }

@@ -699,6 +699,7 @@ extern "C" int64_t ur_gru_workspace_bytes(const UrGruCfg* cfg) {
 
 extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                           const int32_t* item_seq, float* user_emb, void* ws, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = gru_check(cfg);
   if (rc) return rc;
   UR_REQUIRE(item_table && dense && item_seq && user_emb && ws && n_items > 0, UR_ERR_ARG, "ur_gru_fwd: null pointer");
@@ -764,6 +765,7 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
 extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                           const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad, float* d_emb_rows,
                           void* stream) {
+  UR_TRACE_SCOPE();
   int rc = gru_check(cfg);
   if (rc) return rc;
   UR_REQUIRE(dense && d_user_emb && ws && dense_grad && d_emb_rows, UR_ERR_ARG, "ur_gru_bwd: null pointer");

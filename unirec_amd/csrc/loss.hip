@@ -482,6 +482,7 @@ extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_em
                                       const int64_t* item_id, const int32_t* label, const float* user_bias,
                                       const float* item_bias, const int64_t* user_id, float* scores, float* loss_rows,
                                       float* loss_out, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = check_loss_cfg(cfg, "ur_gather_dot_loss_fwd", true);
   if (rc) return rc;
   UR_REQUIRE(user_emb && item_table && item_id && scores && loss_rows && loss_out, UR_ERR_ARG, "ur_gather_dot_loss_fwd: null pointer");
@@ -522,6 +523,7 @@ extern "C" int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_em
                                       const int64_t* item_id, const int32_t* label, const float* scores,
                                       const float* loss_out, const float* d_loss, float* coef, float* d_user,
                                       float* d_user_bias_rows, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = check_loss_cfg(cfg, "ur_gather_dot_loss_bwd");
   if (rc) return rc;
   UR_REQUIRE(user_emb && item_table && item_id && scores && loss_out && coef && d_user, UR_ERR_ARG,
@@ -586,6 +588,7 @@ extern "C" int ur_gather_dot_loss_fwd_bwd(const UrLossCfg* cfg, const float* use
                                           const int64_t* item_id, const int32_t* label, const float* user_bias,
                                           const float* item_bias, const int64_t* user_id, float* scores, float* loss_rows,
                                           float* loss_out, float* coef, float* d_user, float* d_user_bias_rows, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = check_loss_cfg(cfg, "ur_gather_dot_loss_fwd_bwd");
   if (rc) return rc;
   UR_REQUIRE(user_emb && item_table && item_id && scores && loss_rows && loss_out && coef && d_user, UR_ERR_ARG,

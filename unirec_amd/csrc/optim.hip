@@ -1,6 +1,7 @@
 // Dense Adam over the flat dense-parameter buffer, gradient-norm helpers, and the library's error plumbing.
 #include <stdarg.h>
 
+#include <dlfcn.h>
 #include <string>
 
 #include "common.h"
@@ -75,6 +76,36 @@ __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm
   out[0] = (guard && guard[0] < 0.f) ? -1.f : (c < 1.f ? c : 1.f);
 }
 
+// ---- roctx ranges (common.h: TraceScope)
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool on = false;
+};
+const Roctx& roctx() {
+  static const Roctx r = [] {
+    Roctx x;
+    const char* e = getenv("UR_ROCTX");
+    if (!e || atoi(e) == 0) return x;
+    void* h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return x;
+    x.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    x.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    x.on = x.push && x.pop;
+    return x;
+  }();
+  return r;
+}
+}  // namespace
+TraceScope::TraceScope(const char* name) : on(roctx().on) {
+  if (on) (void)roctx().push(name);
+}
+TraceScope::~TraceScope() {
+  if (on) (void)roctx().pop();
+}
+
 // ---- the test hooks (common.h): UR_TEST parsed once
 int ur_test_hook(const char* name, int absent) {
   static const std::string spec = [] { const char* e = getenv("UR_TEST"); return std::string(e ? e : ""); }();
@@ -134,6 +165,7 @@ extern "C" int ur_id_guard_state(int64_t* out3) {
 }
 // clear the guard (after the IndexError has been handled): device word on `stream`, host mirror at once
 extern "C" int ur_id_guard_reset(void* stream) {
+  UR_TRACE_SCOPE();
   int dev = 0;
   UR_HIP(hipGetDevice(&dev));
   IdGuard g = id_guard();
@@ -149,6 +181,7 @@ extern "C" int ur_version(void) { return 100; }
 
 extern "C" int ur_dense_adam(const UrAdamCfg* cfg, float* param, const float* grad, float* m, float* v, int64_t n,
                              const float* grad_scale_dev, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(cfg && param && grad && m && v, UR_ERR_ARG, "ur_dense_adam: null pointer");
   UR_REQUIRE(cfg->step >= 1 && n >= 0, UR_ERR_ARG, "ur_dense_adam: step=%d n=%lld", cfg->step, (long long)n);
   UR_REQUIRE(cfg->algo >= UR_OPT_ADAM && cfg->algo <= UR_OPT_RMSPROP, UR_ERR_ARG, "ur_dense_adam: algo=%d", cfg->algo);
@@ -165,6 +198,7 @@ extern "C" int ur_dense_adam(const UrAdamCfg* cfg, float* param, const float* gr
 }
 
 extern "C" int ur_sumsq(const float* x, int64_t n, float* out, int accumulate, void* ws_2048_floats, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(x && out && ws_2048_floats && n >= 0, UR_ERR_ARG, "ur_sumsq: bad argument");
   hipStream_t st = as_stream(stream);
   int nparts = (int)((n + 4095) / 4096);
@@ -184,9 +218,11 @@ static int clip_coef_impl(const float* sumsq, float max_norm, float* scale_out, 
   return UR_OK;
 }
 extern "C" int ur_clip_coef(const float* sumsq, float max_norm, float* scale_out, void* stream) {
+  UR_TRACE_SCOPE();
   return clip_coef_impl(sumsq, max_norm, scale_out, nullptr, stream);
 }
 extern "C" int ur_clip_coef_guarded(const float* sumsq, float max_norm, const float* guard, float* scale_out, void* stream) {
+  UR_TRACE_SCOPE();
   return clip_coef_impl(sumsq, max_norm, scale_out, guard, stream);
 }
 

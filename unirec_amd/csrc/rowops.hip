@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const float4* __rest
 
 extern "C" int ur_embedding_gather_f32(const float* table, int64_t n_rows, int d, const void* idx, int idx_bytes,
                                        int64_t n, float* out, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(table && ((out && idx) || n == 0), UR_ERR_ARG, "ur_embedding_gather_f32: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512, UR_ERR_ARG, "ur_embedding_gather_f32: d=%d must be a multiple of 4, <= 512", d);
   UR_REQUIRE(idx_bytes == 4 || idx_bytes == 8, UR_ERR_ARG, "ur_embedding_gather_f32: idx_bytes=%d (4 or 8)", idx_bytes);
@@ -468,6 +469,7 @@ extern "C" int ur_embedding_gather_f32(const float* table, int64_t n_rows, int d
 
 extern "C" int ur_pool_rows_fwd(const float* table, int64_t n_rows, int32_t d, const int32_t* item_seq, const int64_t* seq_len,
                                 const float* base, float alpha, int32_t B, int32_t L, float* user_emb, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(table && item_seq && seq_len && user_emb, UR_ERR_ARG, "ur_pool_rows_fwd: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && B > 0 && L > 0 && n_rows > 0, UR_ERR_ARG, "ur_pool_rows_fwd: d=%d B=%d L=%d", d, B, L);
   hipStream_t st = ur::as_stream(stream);
@@ -488,6 +490,7 @@ extern "C" int ur_pool_rows_fwd(const float* table, int64_t n_rows, int32_t d, c
 
 extern "C" int ur_pool_rows_bwd(const float* d_user_emb, const int64_t* seq_len, float alpha, int32_t B, int32_t L, int32_t d,
                                 float* d_rows, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(d_user_emb && seq_len && d_rows, UR_ERR_ARG, "ur_pool_rows_bwd: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && B > 0 && L > 0, UR_ERR_ARG, "ur_pool_rows_bwd: d=%d B=%d L=%d", d, B, L);
   hipStream_t st = ur::as_stream(stream);

@@ -983,6 +983,7 @@ static inline int heads_grid(long long n) { return (int)((n + HEADS_SPAN - 1) / 
 
 extern "C" int ur_rows_plan_merge(const int32_t* ids, int64_t n, const int32_t* host_run_start, int32_t n_runs, int32_t* uniq_idx,
                                   int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(ids && host_run_start && uniq_idx && seg_start && sorted_pos && n_uniq_dev && ws, UR_ERR_ARG, "ur_rows_plan_merge: null pointer");
   UR_REQUIRE(n > 0 && n < (1LL << 30) && n_runs >= 1 && n_runs <= 65, UR_ERR_ARG, "ur_rows_plan_merge: n=%lld runs=%d", (long long)n, n_runs);
   RunStarts rs;
@@ -1064,12 +1065,14 @@ static int rows_plan_impl(const int32_t* ids_a, int64_t n_a, const int64_t* ids_
 extern "C" int ur_rows_plan(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
                             int32_t* uniq_idx, int32_t* seg_start, int32_t* sorted_pos, int32_t* n_uniq_dev, void* ws,
                             void* stream) {
+  UR_TRACE_SCOPE();
   return rows_plan_impl(ids_a, n_a, ids_b, n_b, n_rows, 1, uniq_idx, seg_start, sorted_pos, n_uniq_dev, nullptr, ws, stream);
 }
 
 extern "C" int ur_rows_plan_sharded(const int32_t* ids_a, int64_t n_a, const int64_t* ids_b, int64_t n_b, int64_t n_rows,
                                     int32_t world, int32_t* uniq_key, int32_t* seg_start, int32_t* sorted_pos,
                                     int32_t* n_uniq_dev, int32_t* owner_counts_dev, void* ws, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(world >= 1 && world <= 1024, UR_ERR_ARG, "ur_rows_plan_sharded: world=%d", world);
   return rows_plan_impl(ids_a, n_a, ids_b, n_b, n_rows, world, uniq_key, seg_start, sorted_pos, n_uniq_dev, owner_counts_dev, ws,
                         stream);
@@ -1099,6 +1102,7 @@ __global__ __launch_bounds__(256) void compact_index_kernel(const int* __restric
 
 extern "C" int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n,
                                 int64_t n_a, const int32_t* slot_of_uniq, int32_t* idx_a, int64_t* idx_b, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(seg_start && sorted_pos && n_uniq_dev && n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_compact_index: bad argument");
   UR_REQUIRE((idx_a || n_a == 0) && (idx_b || n_a == n), UR_ERR_ARG, "ur_compact_index: null output");
   UR_REQUIRE(n < (1LL << 31), UR_ERR_UNSUPPORTED, "ur_compact_index: n=%lld", (long long)n);
@@ -1143,6 +1147,7 @@ extern "C" int ur_rows_reduce(const int32_t* uniq_idx, const int32_t* seg_start,
                               const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
                               const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
                               void* stream) {
+  UR_TRACE_SCOPE();
   return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, uniq_grad, sumsq_dev, out_rows, stream);
 }
 
@@ -1154,6 +1159,7 @@ extern "C" int ur_rows_reduce_riders(const int32_t* uniq_idx, const int32_t* seg
                                      const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
                                      int32_t world, int32_t cap, float* step_flags_out4, int32_t write_flag_rows, const float* loss_out,
                                      const int32_t* flags_dev, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(world >= 1 && world <= 256 && cap > 0, UR_ERR_ARG, "ur_rows_reduce_riders: world=%d cap=%d", world, cap);
   UR_REQUIRE(!step_flags_out4 || (rows_a && n_a >= (int64_t)(world - 1) * cap + 1), UR_ERR_ARG, "ur_rows_reduce_riders: step flags need the received block as rows_a");
   UR_REQUIRE(!write_flag_rows || out_rows, UR_ERR_ARG, "ur_rows_reduce_riders: flag rows go with sums written to their slots (out_rows)");
@@ -1204,6 +1210,7 @@ static int check_adam(const UrAdamCfg* c, const char* who) {
 extern "C" int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                                    const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad,
                                    int32_t d, const float* grad_scale_dev, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = check_adam(cfg, "ur_sparse_adam_rows");
   if (rc) return rc;
   UR_REQUIRE(table && m && v && uniq_idx && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_sparse_adam_rows: null pointer");
@@ -1213,6 +1220,7 @@ extern "C" int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m,
 
 extern "C" int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                                     const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = check_adam(cfg, "ur_lazy_adam_catchup");
   if (rc) return rc;
   UR_REQUIRE(table && m && v && last_step && uniq_idx && n_uniq_dev, UR_ERR_ARG, "ur_lazy_adam_catchup: null pointer");
@@ -1238,6 +1246,7 @@ __global__ __launch_bounds__(256) void rows_filter_touched_kernel(const int* __r
 }
 extern "C" int ur_rows_filter_touched(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const int32_t* last_step,
                                       int32_t* out_idx, int32_t* out_n_dev, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(uniq_idx && n_uniq_dev && last_step && out_idx && out_n_dev && n_max > 0 && n_max < (1LL << 31), UR_ERR_ARG,
              "ur_rows_filter_touched: null pointer or n_max=%lld", (long long)n_max);
   hipStream_t st = as_stream(stream);
@@ -1292,6 +1301,7 @@ extern "C" int ur_rows_split_hot(const int32_t* uniq_idx, const int32_t* n_uniq_
                                  const int32_t* excl_sorted, const int32_t* excl_n_dev, int64_t excl_max, int32_t* cold_idx,
                                  int32_t* cold_n_dev, int32_t* hot_idx, int32_t* hot_n_dev, int32_t* hot_u, int32_t* excl_mark,
                                  void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(uniq_idx && n_uniq_dev && cold_idx && cold_n_dev && hot_idx && hot_n_dev && n_max > 0 && n_max < (1LL << 31), UR_ERR_ARG,
              "ur_rows_split_hot: null pointer or n_max=%lld", (long long)n_max);
   UR_REQUIRE(!excl_sorted || (excl_n_dev && excl_max > 0 && excl_max < (1LL << 31)), UR_ERR_ARG, "ur_rows_split_hot: exclusion list");
@@ -1307,6 +1317,7 @@ extern "C" int ur_rows_split_hot(const int32_t* uniq_idx, const int32_t* n_uniq_
 
 extern "C" int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, int64_t row0,
                                   int64_t n, int32_t d, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(cfg != nullptr && cfg->step >= 0, UR_ERR_ARG, "ur_lazy_adam_flush: cfg");
   UR_REQUIRE(table && m && v && last_step, UR_ERR_ARG, "ur_lazy_adam_flush: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n >= 0 && row0 >= 0, UR_ERR_ARG, "ur_lazy_adam_flush: d=%d", d);
@@ -1333,6 +1344,7 @@ extern "C" int ur_lazy_adam_flush(const UrAdamCfg* cfg, float* table, float* m, 
 
 extern "C" int ur_rows_scatter_add(const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* rows, int32_t d,
                                    float* dense, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(uniq_idx && n_uniq_dev && rows && dense && n_max > 0 && d > 0 && d % 4 == 0, UR_ERR_ARG, "ur_rows_scatter_add: bad argument");
   hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(cdiv(n_max * (d / 4), 256)), dim3(256), 0, as_stream(stream), uniq_idx, n_uniq_dev,
                      (long long)n_max, (const float4*)rows, d / 4, (float4*)dense);

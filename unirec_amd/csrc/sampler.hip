@@ -171,6 +171,7 @@ static int sample_negatives_impl(const int64_t* user_id, const int64_t* pos_item
 extern "C" int ur_sample_negatives(const int64_t* user_id, const int64_t* pos_item, int32_t B, int32_t K, int64_t n_items,
                                    int64_t n_users, const int64_t* hist_ptr, const int32_t* hist_sorted, uint64_t seed,
                                    uint32_t step, int64_t* item_id, int32_t* label, void* stream) {
+  UR_TRACE_SCOPE();
   return sample_negatives_impl(user_id, pos_item, B, K, n_items, n_users, hist_ptr, hist_sorted, nullptr, nullptr, seed, step, item_id, label,
                                stream);
 }
@@ -179,6 +180,7 @@ extern "C" int ur_sample_negatives_pop(const int64_t* user_id, const int64_t* po
                                        int64_t n_users, const int64_t* hist_ptr, const int32_t* hist_sorted, const double* alias_odds,
                                        const int64_t* alias_idx, uint64_t seed, uint32_t step, int64_t* item_id, int32_t* label,
                                        void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(alias_odds && alias_idx, UR_ERR_ARG, "ur_sample_negatives_pop: null alias table");
   return sample_negatives_impl(user_id, pos_item, B, K, n_items, n_users, hist_ptr, hist_sorted, alias_odds, alias_idx, seed, step, item_id,
                                label, stream);
@@ -188,6 +190,7 @@ extern "C" int ur_device_build_seq(const int64_t* user_id, const int64_t* item_i
                                    const int64_t* hist_ptr, const int32_t* hist_items, int32_t mask_mode, int32_t seq_last,
                                    int32_t match_all, int32_t L, uint64_t seed, uint32_t step, int32_t* item_seq, int64_t* seq_len,
                                    void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(user_id && item_id && hist_ptr && hist_items && item_seq, UR_ERR_ARG, "ur_device_build_seq: null pointer");
   UR_REQUIRE(B > 0 && G > 0 && L > 0 && n_users >= 0, UR_ERR_ARG, "ur_device_build_seq: B=%d G=%d L=%d", B, G, L);
   UR_REQUIRE(mask_mode >= 0 && mask_mode <= 2, UR_ERR_ARG, "ur_device_build_seq: mask_mode=%d", mask_mode);

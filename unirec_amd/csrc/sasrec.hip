@@ -338,6 +338,7 @@ SideCtx* side_ctx(bool even_if_disabled = false) {
 
 extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                              const int32_t* item_seq, float* user_emb, void* ws, void* stream) {
+  UR_TRACE_SCOPE();
   int rc = check_cfg(cfg);
   if (rc) return rc;
   UR_REQUIRE(item_table && dense && item_seq && user_emb && ws, UR_ERR_ARG, "ur_sasrec_fwd: null pointer");
@@ -920,16 +921,19 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
 extern "C" int ur_sasrec_bwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                              const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
                              float* d_emb_rows, void* stream) {
+  UR_TRACE_SCOPE();
   return sasrec_bwd_impl(cfg, item_table, n_items, dense, item_seq, d_user_emb, ws, dense_grad, d_emb_rows, stream, false);
 }
 
 extern "C" int ur_sasrec_bwd_deferred(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                                       const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad,
                                       float* d_emb_rows, void* stream) {
+  UR_TRACE_SCOPE();
   return sasrec_bwd_impl(cfg, item_table, n_items, dense, item_seq, d_user_emb, ws, dense_grad, d_emb_rows, stream, true);
 }
 
 extern "C" int ur_sasrec_bwd_join(void* stream) {
+  UR_TRACE_SCOPE();
   SideCtx* sc = side_ctx(true);   // (a pass deferred before ur_sasrec_set_side_stream(0) still has to be joined)
   if (sc && sc->join_pending) {
     UR_HIP(hipStreamWaitEvent(as_stream(stream), sc->done, 0));
@@ -944,6 +948,7 @@ extern "C" int ur_sasrec_bwd_join(void* stream) {
 // + the wait's latency were ~30 us at the end of every step during which the main stream did 5 us of work).
 // (hook side_delay_us: the spin kernel goes in front of whatever the caller enqueues on the side stream)
 extern "C" void* ur_sasrec_side_stream(void) {
+  UR_TRACE_SCOPE();
   SideCtx* sc = side_ctx(true);
   if (!(sc && sc->join_pending)) return nullptr;
   static const int delay_us = ur_test_hook("side_delay_us");
@@ -965,6 +970,7 @@ extern "C" int ur_sasrec_side_publish(int late) {
 // `waiter` waits for everything enqueued on `waited` so far (both streams of the current device), through an event WITHOUT the
 // system-scope fence (see side_ctx): what torch's Stream.wait_stream does with a default event, ~1.5 us cheaper on the recording stream.
 extern "C" int ur_stream_wait_stream(void* waiter, void* waited) {
+  UR_TRACE_SCOPE();
   static thread_local hipEvent_t ring[16];      // (per thread: rank threads of the loopback transport call this concurrently)
   static thread_local int made = 0, next = 0;
   if (!made) {
@@ -980,6 +986,7 @@ extern "C" int ur_stream_wait_stream(void* waiter, void* waited) {
 // test aid: a kernel that spins for `us` microseconds on `stream` -- skews one stream against the others (a rank's plan stream running
 // late: tests/test_loopback_gpu.py)
 extern "C" int ur_debug_delay(int32_t us, void* stream) {
+  UR_TRACE_SCOPE();
   UR_REQUIRE(us >= 0 && us <= 1000000, UR_ERR_ARG, "ur_debug_delay: us=%d", us);
   if (us > 0) hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(64), 0, as_stream(stream), (long long)us * 100);   // wall_clock64: 100 MHz
   UR_LAUNCH_CHECK();
@@ -987,6 +994,7 @@ extern "C" int ur_debug_delay(int32_t us, void* stream) {
 }
 
 extern "C" int ur_sasrec_set_side_stream(int on) {
+  UR_TRACE_SCOPE();
   const int prev = g_side_enabled;
   g_side_enabled = on ? 1 : 0;
   return prev;
