@@ -397,6 +397,8 @@ def e2e_leg(a, model, opt, device, steps):
     # the product loader (facility/trainer.py): builds run on its own stream, two batches ahead of the step that consumes them
     from unirec_amd.facility.trainer import DeviceBatchLoader
     loader = DeviceBatchLoader(pairs, bld, a.batch, shuffle=False)
+    if hasattr(opt, "plan_stream"):
+        loader.use_stream(opt.plan_stream(), joined=True)     # (as Trainer.fit does: one stream for everything that runs a batch ahead)
     it = iter(loader)
 
     def step(b, nxt):
@@ -439,19 +441,29 @@ def trainer_fit_leg(a, device, steps=200):
     from unirec_amd.data.rows import DeviceRowBuilder, HistoryCSR
     from unirec_amd.facility.trainer import DeviceBatchLoader, Trainer
     from unirec_amd.model.sequential.sasrec import SASRec
-    n_users = 100_000
+    # every user is drawn ONCE (the headline's statistics: its synthetic batches are uniform ids over the 100 M rows, a row practically never
+    # comes back inside a run, so the lazy-Adam replay list stays empty).  `e2e` draws users with replacement from a 100 k population
+    # instead: there a history returns every epoch and the replay of ~50 rows per returning user is part of the step (+35 us).
+    warm_batches = 12
+    n_users = a.batch * (steps + warm_batches) if not os.environ.get("UR_FIT_RECURRING_USERS") else 100_000
     rng = np.random.default_rng(1)
-    lens = np.clip(np.exp(rng.normal(4.25, 1.0, n_users)).astype(np.int64), 5, 1000) + 1
+    # (only the last L items before the target are ever read: histories are stored up to L + 10 long, same sequences as the e2e leg's 1000)
+    lens = np.clip(np.exp(rng.normal(4.25, 1.0, n_users)).astype(np.int64), 5, a.seq_len + 10) + 1
     ptr = np.zeros(n_users + 1, dtype=np.int64)
     np.cumsum(lens, out=ptr[1:])
     items = rng.integers(1, a.n_items, int(ptr[-1])).astype(np.int32)
     csr = HistoryCSR.__new__(HistoryCSR)
     csr.ptr, csr.items, csr.n_users, csr._dev = ptr, items, n_users, None
-    order = np.lexsort((items, np.repeat(np.arange(n_users), lens)))
-    csr.sorted = items[order]
+    key = np.repeat(np.arange(n_users, dtype=np.int64), lens) << 32 | items       # per-user sorted item lists: one key sort
+    key.sort()
+    csr.sorted = (key & 0xFFFFFFFF).astype(np.int32)
+    del key
 
-    def loader(n_batches, seed):
-        users = np.random.default_rng(seed).integers(0, n_users, a.batch * n_batches)
+    def loader(n_batches, seed, first=0):
+        if n_users == 100_000:
+            users = np.random.default_rng(seed).integers(0, n_users, a.batch * n_batches)
+        else:
+            users = first + np.random.default_rng(seed).permutation(a.batch * n_batches)
         pos = items[ptr[users] + lens[users] - 1]
         pairs = torch.from_numpy(np.stack([users, pos.astype(np.int64)], 1)).to(device)
         bld = DeviceRowBuilder(n_users, a.n_items, a.negatives, a.seq_len, csr, reject_history=True, mask_mode="autoregressive", seq_last=0,
@@ -464,9 +476,9 @@ def trainer_fit_leg(a, device, steps=200):
     torch.manual_seed(7)
     model = SASRec(cfg)
     tr = Trainer(cfg, model)
-    tr.fit(loader(12, 3), valid_data=None, save_model=False)      # warm-up epoch (code objects, workspaces, the collector's freeze)
+    tr.fit(loader(warm_batches, 3), valid_data=None, save_model=False)      # warm-up epoch (code objects, workspaces, the collector's freeze)
     torch.cuda.synchronize()
-    data = loader(steps, 4)
+    data = loader(steps, 4, first=a.batch * warm_batches)
     t0 = time.perf_counter()
     tr.fit(data, valid_data=None, save_model=False)
     torch.cuda.synchronize()
@@ -602,6 +614,7 @@ def other_config(name, device):
     for i in range(steps):
         _lib.lib.ur_prof_enable(1 if i % PROF_EVERY == 0 else 0)
         step(batches[warm + i], batches[warm + i + 1])
+    t_host = time.perf_counter() - t0      # everything queued: close to dt = the leg is bound by the host's launch rate, not by the device
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _lib.lib.ur_prof_enable(0)
@@ -618,6 +631,7 @@ def other_config(name, device):
     peak = MFMA_F32_PEAK_TFLOPS if mfma else HBM_PEAK_GBPS
     out = {"workload": f"{cfg['model']} n_items={a.n_items} d={d} L={L} B={a.batch} K={a.negatives} {a.loss}",
            "ms_per_step": round(dt / steps * 1e3, 4), "examples_per_s": round(a.batch * steps / dt, 1),
+           "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 4),
            "roofline": {"bound": "mfma" if mfma else "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": peak,
                         "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "launches": c["launches"],
                         "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2)},
@@ -1048,7 +1062,7 @@ def main():
         del model, opt
         torch.cuda.empty_cache()
     if world == 1 and not a.no_extra_legs and not a.autograd and not a.sharded_w1 and a.dropout == 0.0:
-        out["trainer_fit"] = trainer_fit_leg(a, device)      # (after the headline's model is gone: a second 100 M-row table + state)
+        out["trainer_fit"] = trainer_fit_leg(a, device, steps=min(1000, max(200, a.steps)))      # (as many steps as the headline: the same table ageing; after the headline's model is gone: a second 100 M-row table + state)
     if world == 1 and a.all_configs:
         out["other_configs"] = {n: other_config(n, device) for n in ("C2", "C3", "C4_encoder", "C4_encoder_h768")}
         out["other_configs"]["C3"]["e2e"] = c3_e2e_leg(device)

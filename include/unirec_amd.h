@@ -57,6 +57,11 @@ int ur_version(void);
 int ur_id_guard_state(int64_t* host_out3);
 int ur_id_guard_reset(void* stream);
 
+/* Tracing (SURVEY.md 5 "roctx ranges per op"; the reference has none: torch.profiler ranges are its closest facility).  With UR_ROCTX=1 in
+ * the environment every entry point that enqueues device work pushes / pops a roctx range named after itself (libroctx64 resolved at run
+ * time; rocprofv3 --marker-trace shows them).  -> the number of ranges pushed so far (0 with the switch off). */
+int64_t ur_trace_ranges_pushed(void);
+
 /* ---------------------------------------------------------------------------------------------
  * Embedding lookup: out[i,:] = table[idx[i],:]      (bit-exact copy)
  * replaces nn.Embedding.forward as called by unirec/model/base/recommender.py:67 (forward_item_emb)

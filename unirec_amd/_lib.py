@@ -65,6 +65,7 @@ SIGNATURES = {
     "ur_version": (C.c_int, []),
     "ur_id_guard_state": (C.c_int, [C.POINTER(I64)]),
     "ur_id_guard_reset": (C.c_int, [P]),
+    "ur_trace_ranges_pushed": (C.c_int64, []),
     "ur_embedding_gather_f32": (C.c_int, [P, I64, C.c_int, P, C.c_int, I64, P, P]),
     "ur_sasrec_param_layout": (I64, [C.POINTER(UrSasrecCfg), C.POINTER(I64)]),
     "ur_sasrec_workspace_bytes": (I64, [C.POINTER(UrSasrecCfg)]),

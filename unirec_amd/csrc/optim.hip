@@ -1,6 +1,7 @@
 // Dense Adam over the flat dense-parameter buffer, gradient-norm helpers, and the library's error plumbing.
 #include <stdarg.h>
 
+#include <atomic>
 #include <dlfcn.h>
 #include <string>
 
@@ -99,8 +100,12 @@ const Roctx& roctx() {
   return r;
 }
 }  // namespace
+std::atomic<long long> g_ranges_pushed{0};
 TraceScope::TraceScope(const char* name) : on(roctx().on) {
-  if (on) (void)roctx().push(name);
+  if (on) {
+    (void)roctx().push(name);
+    g_ranges_pushed.fetch_add(1, std::memory_order_relaxed);
+  }
 }
 TraceScope::~TraceScope() {
   if (on) (void)roctx().pop();
@@ -176,6 +181,7 @@ extern "C" int ur_id_guard_reset(void* stream) {
   return UR_OK;
 }
 
+extern "C" int64_t ur_trace_ranges_pushed(void) { return g_ranges_pushed.load(std::memory_order_relaxed); }
 extern "C" const char* ur_last_error(void) { return g_err; }
 extern "C" int ur_version(void) { return 100; }
 

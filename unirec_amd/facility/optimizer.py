@@ -116,6 +116,12 @@ class SparseDenseAdam:
     def _ids_key(item_seq, item_id, user_id):
         return tuple((t.data_ptr(), t.numel()) if t is not None else None for t in (item_seq, item_id, user_id))
 
+    def plan_stream(self):
+        """the stream the NEXT batch's id plan runs on (created on first use); a device batch loader builds its batches there too"""
+        if self._side is None and self.model.device.type == "cuda":
+            self._side = torch.cuda.Stream(device=self.model.device)
+        return self._side
+
     def prefetch_plan(self, item_seq=None, item_id=None, user_id=None):
         """Sort/unique the ids of the NEXT batch on a side stream, so that the (latency-bound, ~0.15 ms) plan overlaps
         with the current step's forward/backward.  The plan depends on the ids only, never on the model state."""

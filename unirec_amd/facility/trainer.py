@@ -60,6 +60,20 @@ class DeviceBatchLoader:
         self.rank, self.world, self.with_seq, self.epoch = rank, world, with_seq, 0
         self.lookahead = max(1, int(lookahead))
         self.stream = torch.cuda.Stream(device=self.pairs.device) if self.pairs.is_cuda else None
+        self.joined = False
+
+    def use_stream(self, stream, joined=False):
+        """Build on `stream` instead of a stream of the loader's own.  Trainer.fit hands over the optimizer's PLAN stream (the id sort of the
+        next batch runs there, under the step in flight): a process has a handful of hardware queues and HIP deals streams onto them
+        round-robin -- the loader's own stream landed on the queue of the encoder's side stream (weight-gradient launches, dense update),
+        its half-dozen small kernels queued among them, and the step boundary waited 60-90 us for that chain (profiles/r05_e_fit_gap.txt).
+
+        joined=True is a promise of the consumer that saves the two packets a hand-out otherwise puts into ITS queue (a barrier and an
+        event, ~8 us of idle main stream per step): (a) before it reads a batch other than the first of an epoch, its stream has waited for
+        an event recorded on `stream` after that batch was handed out; (b) once per step, before it enqueues anything on `stream`, it makes
+        `stream` wait for its own stream.  SparseDenseAdam.prefetch_plan / plan_batch do both for a batch passed as `next_batch`."""
+        if stream is not None and self.pairs.is_cuda:
+            self.stream, self.joined = stream, bool(joined)
 
     def __len__(self):
         nb = (len(self.pairs) + self.batch_size - 1) // self.batch_size
@@ -69,6 +83,19 @@ class DeviceBatchLoader:
         B = self.batch_size
         sel = self.pairs[order[b * B:(b + 1) * B]]
         return self.builder.build(sel[:, 0].contiguous(), sel[:, 1].contiguous(), with_seq=self.with_seq, step=base + b)
+
+    def _epoch_columns(self, order):
+        """the epoch's (user, item) columns in visiting order, [2, n] contiguous: every batch is then two VIEWS (no per-batch index gather
+        and column copies: three launches and ~30 us of host time a step); made once per epoch, or once for good without shuffling"""
+        if not self.shuffle:
+            if getattr(self, "_cols", None) is None:
+                self._cols = self.pairs.t().contiguous()
+            return self._cols
+        return self.pairs[order].t().contiguous()
+
+    def _build_cols(self, cols, b, base):
+        B = self.batch_size
+        return self.builder.build(cols[0, b * B:(b + 1) * B], cols[1, b * B:(b + 1) * B], with_seq=self.with_seq, step=base + b)
 
     def __iter__(self):
         n, B = len(self.pairs), self.batch_size
@@ -82,34 +109,52 @@ class DeviceBatchLoader:
         base = self.epoch * nb
         self.epoch += 1
         ks = iter(range((nb + self.world - 1) // self.world))   # equal step counts on every rank (see BatchLoader)
+        cols = self._epoch_columns(order)
         if self.stream is None:
             for k in ks:
-                yield self._build(order, (k * self.world + self.rank) % nb, base)
+                yield self._build_cols(cols, (k * self.world + self.rank) % nb, base)
             return
-        self.stream.wait_stream(torch.cuda.current_stream(dev))   # (`order` was made on the caller's stream)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))   # (`order` / `cols` were made on the caller's stream)
         pending = collections.deque()
+        # Batches are made on the loader's stream and read on the caller's.  Tensor.record_stream would keep the allocator from recycling
+        # them early, but it costs one event packet IN THE CALLER'S QUEUE per tensor when the batch is dropped (five per step, each a
+        # marker the step's next kernel queues behind: ~25 us of idle main stream per 0.55 ms step, profiles/r05_e_fit_gap.txt).  Instead:
+        # at every hand-out the loader's stream waits for the caller's stream (one fence-less event), so any build issued from then on
+        # runs behind every step the caller has enqueued so far; a handed-out batch stays referenced here for two more hand-outs, by which
+        # time the step that read it is enqueued, and its memory (the loader stream's pool) can only be recycled by such a later build.
+        # (joined: the consumer's own once-per-step wait orders this stream one step later than a wait here would: one more batch held)
+        handed = collections.deque(maxlen=4 if self.joined else 3)
 
         def issue():
             k = next(ks, None)
             if k is None:
                 return
             with torch.cuda.stream(self.stream):
-                batch = self._build(order, (k * self.world + self.rank) % nb, base)
+                batch = self._build_cols(cols, (k * self.world + self.rank) % nb, base)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
             pending.append((batch, ev))
 
         for _ in range(self.lookahead):
             issue()
-        while pending:
-            batch, ev = pending.popleft()
-            cur = torch.cuda.current_stream(dev)
-            cur.wait_event(ev)
-            for t in batch.values():      # made on the loader's stream, used on the caller's: the allocator must not recycle them early
-                if torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(cur)
-            issue()
-            yield batch
+        from .. import ops
+        try:
+            while pending:
+                batch, ev = pending.popleft()
+                cur = torch.cuda.current_stream(dev)
+                if not (self.joined and handed):
+                    cur.wait_event(ev)
+                handed.append(batch)
+                if not self.joined:
+                    ops.stream_wait_stream(self.stream, cur)
+                issue()
+                yield batch
+        finally:
+            # the last batches (and an iteration abandoned half way): the caller may still be reading them when the generator goes away
+            for b in list(handed) + [b for b, _ in pending]:
+                for t in b.values():
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(torch.cuda.current_stream(dev))
 
 
 class StepLRByScore:
@@ -295,6 +340,9 @@ class Trainer(object):
                     self.scheduler.step(score)
                     self.logger.info("epoch: %d, learning rate: %s", epoch_idx, self.optimizer.param_groups[0]["lr"])
             t0 = time.time()
+            if hasattr(train_data, "use_stream") and hasattr(self.optimizer, "plan_stream"):
+                # one stream for everything that runs a batch AHEAD; train_step(cur, nxt) plans `nxt` there and joins it (see use_stream)
+                train_data.use_stream(self.optimizer.plan_stream(), joined=self.world == 1)
             losses, it = [], iter(train_data)
             epoch_sum, n_nan = 0.0, 0
 
@@ -302,12 +350,12 @@ class Trainer(object):
                 nonlocal epoch_sum, n_nan
                 if not losses:
                     return
-                stacked = torch.stack(losses)
+                vals = np.asarray(torch.stack(losses).tolist(), dtype=np.float64)      # one launch, one copy
                 losses.clear()
-                nan = torch.isnan(stacked)
+                nan = np.isnan(vals)
                 n_nan += int(nan.sum())
-                epoch_sum += float(stacked[~nan].sum())
-                self.step_losses.extend(stacked.tolist())
+                epoch_sum += float(vals[~nan].sum())      # (a Python-float running sum of loss.item(), as trainer.py:354-355)
+                self.step_losses.extend(vals.tolist())
 
             cur = next(it, None)
             while cur is not None:          # one batch of lookahead: the next batch's plan overlaps this step
