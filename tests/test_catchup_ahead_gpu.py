@@ -31,13 +31,17 @@ def _batches(n, B=16, L=10, N=300, seed=0):
 
 
 def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14, nan_at=None, table_mode="lazy_dense"):
-    """ahead: False = catch-up at the head of the next step (no plan lookahead), "tail" = on the main stream between the row update and
-    the join of the dense-gradient stream (what a prefetched plan gives)"""
+    """ahead: False = catch-up at the head of the next step (no plan lookahead); "tail" / "late" / "early" = with a prefetched plan: on
+    the main stream between the row update and the join of the dense-gradient stream ("early": only the rows in both batches there, the
+    others on the plan stream under the step in flight)"""
     from unirec_amd.facility.optimizer import SparseDenseAdam
     from unirec_amd.utils.general import get_class_instance, init_seed
     init_seed(4)
     model = get_class_instance("SASRec", "unirec_amd/model")(_cfg())
     opt = SparseDenseAdam(model, lr=5e-3, weight_decay=wd, algo=algo, table_mode=table_mode)
+    # "early": rows of the next batch that the step in flight does not touch are replayed on the PLAN stream under that step (what a
+    # plan of >= 65 536 ids gets by itself); "tail" / "late": the whole replay at the tail of step(), main stream
+    opt._early_catchup = ahead == "early"
     model.train()
     bs = _batches(n_steps + 2)
     other = _batches(3, seed=99)
@@ -55,7 +59,7 @@ def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14, nan_at=None, ta
         if nan_at == s:                       # a NaN loss: the update kernels read the guard and skip the step
             model.loss_guard.fill_(-1.0)
         # "late": the loop says another step follows (as Trainer.fit / bench.py do): the next forward pass joins the dense half
-        opt.step(late_join=(ahead == "late" and s + 1 < n_steps))
+        opt.step(late_join=(ahead in ("late", "early") and s + 1 < n_steps))
         losses.append(float(loss))
     opt.flush()
     torch.cuda.synchronize()
@@ -66,7 +70,7 @@ def _train(ahead, algo="adam", wd=0.0, swap_at=None, n_steps=14, nan_at=None, ta
 @pytest.mark.parametrize("algo,wd", [("adam", 0.0), ("adamw", 0.01), ("adam", 0.001), ("rmsprop", 0.0)])
 def test_catchup_ahead_is_bit_identical(algo, wd):
     b = _train(False, algo, wd)
-    for mode in ("tail", "late"):
+    for mode in ("tail", "late", "early"):
         a = _train(mode, algo, wd)
         assert a[0] == b[0]
         for x, y, what in zip(a[1:], b[1:], ("w", "m", "v", "dense")):
@@ -77,7 +81,7 @@ def test_a_prefetched_batch_that_is_not_trained_on_changes_nothing():
     """rows caught up for a batch that is then not trained on are simply up to date earlier: the same zero-gradient steps, summed in
     two pieces instead of one (fp32 re-association of the replay sum: a few ulp of an lr-sized term, not bit-equal)"""
     c = _train(False)
-    for mode in ("tail", "late"):
+    for mode in ("tail", "late", "early"):
         a = _train(mode, swap_at=5)
         for x, z, what in zip(a[1:4], c[1:4], ("w", "m", "v")):
             assert torch.allclose(x, z, rtol=1e-4, atol=1e-6), (mode, what, float((x - z).abs().max()))
@@ -141,7 +145,41 @@ def test_a_skipped_step_in_the_middle_is_bit_identical_with_the_lookahead(table_
     """a step whose NaN guard skips the update, in the middle of a run with the plan lookahead and the late join: the rows the next batch
     reads take the skipped step as a zero-gradient step -- the trajectory of catching up at the head of the next step, bit for bit"""
     b = _train(False, nan_at=6, table_mode=table_mode)
-    a = _train("late", nan_at=6, table_mode=table_mode)
-    assert a[0] == b[0]
-    for x, y, what in zip(a[1:], b[1:], ("w", "m", "v", "dense")):
-        assert torch.equal(x, y), (what, float((x - y).abs().max()))
+    for mode in ("late", "early"):
+        a = _train(mode, nan_at=6, table_mode=table_mode)
+        assert a[0] == b[0]
+        for x, y, what in zip(a[1:], b[1:], ("w", "m", "v", "dense")):
+            assert torch.equal(x, y), (mode, what, float((x - y).abs().max()))
+
+
+def test_flush_with_a_plan_ahead_pending_sees_its_replay():
+    """flush() (evaluation, checkpoints) right after a step whose lookahead replayed rows on the plan stream: the current stream is ordered
+    behind that replay first, and the flushed table is the one of a run without lookahead, bit for bit."""
+    from unirec_amd.facility.optimizer import SparseDenseAdam
+    from unirec_amd.utils.general import get_class_instance, init_seed
+
+    def run(ahead):
+        init_seed(4)
+        model = get_class_instance("SASRec", "unirec_amd/model")(_cfg())
+        opt = SparseDenseAdam(model, lr=5e-3, table_mode="lazy_dense")
+        opt._early_catchup = True
+        model.train()
+        bs = _batches(8)
+        lab = torch.zeros(16, 5, dtype=torch.int32, device="cuda:0")
+        lab[:, 0] = 1
+        for s in range(6):
+            b = bs[s]
+            opt.zero_grad()
+            opt.plan_batch(item_seq=b["item_seq"], item_id=b["item_id"])
+            if ahead:
+                opt.prefetch_plan(item_seq=bs[s + 1]["item_seq"], item_id=bs[s + 1]["item_id"])
+            model.forward_backward(item_id=b["item_id"], label=lab, item_seq=b["item_seq"])
+            opt.step()
+        opt.flush()                      # (a plan for batch 6 is pending in the `ahead` run)
+        st = opt.tables["item_embedding"]
+        out = (st["w"].clone(), st["m"].clone(), st["v"].clone(), st["last"].clone())
+        torch.cuda.synchronize()
+        return out
+
+    for x, y in zip(run(True), run(False)):
+        assert torch.equal(x, y)

@@ -67,6 +67,9 @@ class SparseDenseAdam:
         # next step (`plan_batch`)
         self._dense_side = dense_side or ""
         self._prefetched, self._side = None, None
+        # None: by size (prefetch_plan); True / False: forced (tests; UR_EARLY_CATCHUP=0/1 for A/B runs of whole benchmarks)
+        import os
+        self._early_catchup = {"0": False, "1": True}.get(os.environ.get("UR_EARLY_CATCHUP", ""))
         self._scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [0] sumsq, [1] clip coef
         self._sumsq_ws = torch.empty(2048, dtype=torch.float32, device=dev)
         self.param_groups = [dict(lr=lr)]  # enough of torch's surface for schedulers / logging
@@ -82,6 +85,7 @@ class SparseDenseAdam:
 
     def state_dict(self):
         self.model.join_side_updates()
+        self._join_plan_stream()
         return dict(t=self.t, dense_m=self.dense_m, dense_v=self.dense_v, param_groups=self.param_groups,
                     tables={k: {kk: vv for kk, vv in v.items() if kk != "w"} for k, v in self.tables.items()})
 
@@ -139,11 +143,32 @@ class SparseDenseAdam:
         with torch.cuda.stream(self._side):
             plans = {name: ops.rows_plan(a, b, self.tables[name]["w"].shape[0], out=bufs[name]) for name, (a, b) in req.items()}
             filtered = None
-            if self.table_mode == "lazy_dense" and self.wd == 0.0:
+            lazy = [name for name in plans if self.tables[name]["last"] is not None] if self.table_mode == "lazy_dense" else []
+            early = self._early_catchup
+            if early is None:
+                # The tail of step() hides a replay as long as row reduce + row update + replay fit under the side stream's last
+                # weight-gradient launch + reductions + dense update (~135 us at 25 600 tokens): ~50 us of replay = 65 K rows x 6 row
+                # arrays at the random-row rate.  Measured on one box (tools/ab_early.sh): C5 (28 K ids a step) tail 0.550 / early 0.553 ms,
+                # aged table 0.574 / 0.586; C3 (154 K ids a step) tail 0.853 / early 0.814 ms.
+                early = sum(plans[name].n for name in lazy) >= 65536
+            if lazy and early and all(name in self._plans for name in lazy):
+                # Called between plan_batch(t) and step(t) (self.t == t - 1): the next batch's rows split against the plan of the step in
+                # flight.  COLD rows (not in batch t, some optimizer history) get a zero gradient at step t by construction, so their replay
+                # up to and INCLUDING step t depends on step indices only: it runs right here, on the plan stream, under step t's forward /
+                # backward (disjoint from every row step t reads or writes).  HOT rows (in both batches) are brought to step t by step t's
+                # own update; the tail of step() walks just that list (a no-op unless the update was skipped: NaN loss, id guard).
+                # Same single replay per row as at the tail, bit for bit -- at C3 (150 K rows a step) it was 148 us of the main stream.
+                filtered = {}
+                cfg2 = self._cfg(self.t + 2)
+                for name in lazy:
+                    st = self.tables[name]
+                    cold, hot = ops.rows_split_hot(plans[name], st["last"] if self.wd == 0.0 else None, self._plans[name])
+                    ops.lazy_adam_catchup(cfg2, st["w"], st["m"], st["v"], st["last"], cold)
+                    filtered[name] = hot
+            elif lazy and self.wd == 0.0:
                 # rows of the next batch that have any optimizer history at all: the catch-up at the tail of this step only walks those
                 # (a row first touched by the step in flight is missed here and needs no catch-up: its update leaves it current)
-                filtered = {name: ops.rows_filter_touched(pl, self.tables[name]["last"]) for name, pl in plans.items()
-                            if self.tables[name]["last"] is not None}
+                filtered = {name: ops.rows_filter_touched(plans[name], self.tables[name]["last"]) for name in lazy}
             ev = torch.cuda.Event()
             ev.record(self._side)
         # keep ids + workspaces alive until the plan is adopted (the side stream reads / writes them asynchronously)
@@ -198,6 +223,7 @@ class SparseDenseAdam:
     def flush(self):
         """lazy_dense: apply all pending zero-gradient steps to every row (before eval / checkpoint)."""
         ops.id_guard_check()      # (an out-of-range id of the last steps: IndexError before anything is evaluated or saved)
+        self._join_plan_stream()
         if self.table_mode != "lazy_dense" or self.t == 0:
             return
         self.model.join_side_updates()
@@ -206,9 +232,16 @@ class SparseDenseAdam:
             if st["last"] is not None:
                 ops.lazy_adam_flush(cfg, st["w"], st["m"], st["v"], st["last"])
 
+    def _join_plan_stream(self):
+        """a plan made ahead replays rows of its batch on the plan stream (prefetch_plan): whoever reads or rewrites the tables outside a
+        step (flush, checkpoints, evaluation) orders the current stream behind it first"""
+        if self._prefetched is not None:
+            torch.cuda.current_stream().wait_event(self._prefetched[2])
+
     def mark_tables_current(self):
         """The table rows were just replaced from outside (checkpoint load): they are up to date as of step ``t``, so no
         zero-gradient replay is pending for any of them."""
+        self._join_plan_stream()
         for st in self.tables.values():
             if st["last"] is not None:
                 st["last"].fill_(self.t)
