@@ -455,6 +455,14 @@ int ur_dense_adam(const UrAdamCfg* cfg, float* param, const float* grad, float* 
 int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                         const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* uniq_grad,
                         int32_t d, const float* grad_scale_dev, void* stream);
+/* ur_rows_reduce + ur_sparse_adam_rows in ONE launch: the per-row gradient sums (ur_rows_reduce's arguments, same summation order) go
+ * straight into the row update (ur_sparse_adam_rows's arguments, same arithmetic) and never reach HBM -- bit-identical tables, two row-array
+ * passes and one dependent launch fewer.  No uniq_grad comes out: a caller that clips by the global norm (the reference's
+ * clip_grad_norm_, unirec/facility/trainer.py:347-348) or exchanges row gradients between ranks uses the two calls. */
+int ur_rows_reduce_update(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n,
+                          const float* rows_a, int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d,
+                          const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, const float* grad_scale_dev,
+                          void* stream);
 /* brings rows uniq_idx[0..n_uniq) to the state "after step (cfg->step - 1)" */
 int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                          const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,

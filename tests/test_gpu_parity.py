@@ -231,6 +231,40 @@ def test_rows_plan_and_reduce_vs_numpy():
         assert torch.equal(ug[:nu], ug2[:nu])
 
 
+@pytest.mark.parametrize("algo,wd,lazy", [("adam", 0.0, True), ("adam", 0.0, False), ("adamw", 0.01, True), ("rmsprop", 0.0, True), ("sgd", 0.0, False)])
+def test_rows_reduce_update_equals_reduce_then_update(algo, wd, lazy):
+    """ur_rows_reduce_update (the row update as the reduce kernel's epilogue) == ur_rows_reduce followed by ur_sparse_adam_rows, bit for
+    bit: tables, moments, stamps -- short, medium and block-cooperative runs, 1-4 float4 per lane, a skipped step (scale < 0) writes nothing."""
+    from unirec_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    for (n_a, n_b, G, n_rows, d) in ((700, 330, 11, 97, 32), (3000, 1200, 3, 5, 64), (4000, 1000, 5, 40, 256), (2000, 600, 3, 7, 512),
+                                     (6000, 1500, 5, 300, 128), (25600, 2560, 5, 1_000_000, 128), (0, 2048, 4, 50_000, 16)):
+        ta = torch.from_numpy(rng.integers(0, n_rows, n_a).astype(np.int32)).to(dev) if n_a else None
+        tb = torch.from_numpy(rng.integers(0, n_rows, n_b).astype(np.int64)).to(dev) if n_b else None
+        rows_a = torch.from_numpy(rng.standard_normal((n_a, d)).astype(np.float32)).to(dev) if n_a else None
+        coef = torch.from_numpy(rng.standard_normal(n_b).astype(np.float32)).to(dev) if n_b else None
+        vec = torch.from_numpy(rng.standard_normal((max(n_b // G, 1), d)).astype(np.float32)).to(dev) if n_b else None
+        pl = ops.rows_plan(ta, tb, n_rows)
+        w0 = torch.from_numpy(rng.standard_normal((n_rows, d)).astype(np.float32)).to(dev)
+        m0 = torch.from_numpy((0.1 * rng.standard_normal((n_rows, d))).astype(np.float32)).to(dev)
+        v0 = torch.from_numpy((0.01 * rng.random((n_rows, d))).astype(np.float32)).to(dev)
+        last0 = torch.from_numpy(rng.integers(0, 40, n_rows).astype(np.int32)).to(dev) if lazy else None
+        for scale_v in (1.0, 0.5, -1.0):
+            scale = torch.tensor([scale_v], dtype=torch.float32, device=dev)
+            cfg = ops.adam_cfg(1e-2, 41, wd, algo=algo)
+            a = [w0.clone(), m0.clone(), v0.clone(), last0.clone() if lazy else None]
+            b = [w0.clone(), m0.clone(), v0.clone(), last0.clone() if lazy else None]
+            ug = ops.rows_reduce(pl, rows_a, coef, vec, G, d)
+            ops.sparse_adam_rows(cfg, a[0], a[1], a[2], pl, ug, a[3], scale)
+            ops.rows_reduce_update(cfg, b[0], b[1], b[2], pl, rows_a, coef, vec, G, b[3], scale)
+            for x, y, what in zip(a, b, ("w", "m", "v", "last")):
+                if x is not None:
+                    assert torch.equal(x, y), (algo, n_a, n_b, d, scale_v, what)
+            if scale_v < 0:
+                assert torch.equal(b[0], w0) and torch.equal(b[1], m0) and (not lazy or torch.equal(b[3], last0))
+
+
 # ------------------------------------------------------------------------------------------ optimizer trajectory
 @pytest.mark.parametrize("name", ["g9_adam_wd0", "g9_adam_wd1e-6_clip"])
 def test_three_steps_match_reference_dense_adam(name):

@@ -220,7 +220,10 @@ struct AdamK {
   float lb1 = 0.f, lb2 = 0.f;   // log2(b1), log2(b2) (host, double precision): b^j = exp2(j * lb) in the lazy-replay series (rows.hip)
 };
 // one element, gradient gr (already scaled / clipped); bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t)
+// (no fp contraction: whether a product is fused into the following add would otherwise be decided per call site, and the same rule
+// inlined into two kernels -- the row update and the reduce kernel's fused epilogue -- could differ in the last bit)
 __device__ __forceinline__ void opt_elem(float& w, float& m, float& v, float gr, const AdamK& a, float bc1, float bc2s) {
+#pragma clang fp contract(off)
   switch (a.algo) {
     case UR_OPT_ADAMW:      // decoupled decay, then Adam on the raw gradient
       w *= 1.f - a.lr * a.wd;

@@ -269,16 +269,39 @@ struct ReduceRiders {
   int fr_on = 0, world = 0, cap = 0;
 };
 
+// ur_rows_reduce_update: the row update as the reduce kernel's epilogue -- the sum of a row's gradients goes straight into the optimizer
+// rule for that row instead of out to uniq_grad and back in (two of the nine row-array passes of reduce + update, and one dependent
+// launch).  Only where nothing needs the row gradients in between: no global-norm clipping, one rank.
+struct FusedUpdate {
+  int on = 0;
+  AdamK a{};
+  float4* table = nullptr; float4* mom = nullptr; float4* var = nullptr;
+  int* last = nullptr;
+  const float* scale_dev = nullptr;
+  const int* guard_dev = nullptr;
+};
+template <int TPR>
+__device__ __forceinline__ void fused_row_update(const FusedUpdate& fu, long long row, const float4 (&grad)[MAXV], int t, int d4, float scale,
+                                                 float bc1, float bc2s);
+
 // One lane group per unique id; positions are summed in sorted (= lookup) order.  Runs longer than LONG_SEG are
 // handled by all groups of the block together: group g takes positions s+g, s+g+groups, ..., the partial sums are
 // combined through LDS in group order -- still a fixed summation order, so results are bit-reproducible.
-template <int TPR>
+template <int TPR, bool FUSED = false>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict__ uniq_idx, const int* __restrict__ seg_start,
                                                           const int* __restrict__ sorted_pos, const int* __restrict__ n_uniq_dev,
                                                           long long n, const float4* __restrict__ rows_a, long long n_a,
                                                           const float* __restrict__ coef_b, const float4* __restrict__ vec_b, int G,
                                                           int d4, float4* __restrict__ out, int zero_tail,
-                                                          const int* __restrict__ out_rows, ReduceRiders rd = ReduceRiders()) {
+                                                          const int* __restrict__ out_rows, ReduceRiders rd = ReduceRiders(),
+                                                          FusedUpdate fu = FusedUpdate()) {
+  float fscale = 1.f, fbc1 = 1.f, fbc2s = 1.f;
+  if constexpr (FUSED) {
+    fscale = ur_step_scale(fu.scale_dev, fu.guard_dev);
+    if (fscale < 0.f) return;     // update guard (NaN loss, id guard): the whole step is skipped, nothing is written
+    fbc1 = 1.f - powf(fu.a.b1, (float)fu.a.step);
+    fbc2s = sqrtf(1.f - powf(fu.a.b2, (float)fu.a.step));
+  }
   if (rd.sf_out4 && blockIdx.x == 0 && threadIdx.x == 0) {   // (source-rank order: every rank sums the same values in the same order)
     float nan = 0.f, ovf = 0.f, loss = 0.f;
     for (int q = 0; q < rd.world; ++q) {
@@ -344,6 +367,10 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
       else
         for (int q = s; q < e; ++q) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
     }
+    if constexpr (FUSED) {
+      if (frow != 0) fused_row_update<TPR>(fu, frow, acc, t, d4, fscale, fbc1, fbc2s);   // (group-uniform)
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       const int c = t + k * TPR;
@@ -385,19 +412,25 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
       for (int k = 0; k < MAXV; ++k) part[g][k * TPR + t] = acc[k];
       __syncthreads();
       if (g == 0) {
+        float4 tot[MAXV];
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
           const int c = t + k * TPR;
+          tot[k] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (c < d4) {
             float4 r = part[0][k * TPR + t];
             for (int gg = 1; gg < groups; ++gg) {
               const float4 x = part[gg][k * TPR + t];
               r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
             }
-            const long long orow_l = out_rows ? (long long)out_rows[ul] : el_;
-            if (!(rd.fr_on && orow_l % rd.cap == 0)) out[orow_l * d4 + c] = r;
+            tot[k] = r;
+            if constexpr (!FUSED) {
+              const long long orow_l = out_rows ? (long long)out_rows[ul] : el_;
+              if (!(rd.fr_on && orow_l % rd.cap == 0)) out[orow_l * d4 + c] = r;
+            }
           }
         }
+        if constexpr (FUSED) fused_row_update<TPR>(fu, (long long)uniq_idx[ul], tot, t, d4, fscale, fbc1, fbc2s);
       }
       __syncthreads();
     }
@@ -573,6 +606,34 @@ __device__ __forceinline__ void lazy_row_apply(const LazyRow& r, float4& w, floa
     }
   }
   lazy_replay4(w, m, v, r.from, r.to, a);
+}
+
+// (rows_reduce_kernel's epilogue: same arithmetic per element as sparse_adam_body, MODE 0)
+template <int TPR>
+__device__ __forceinline__ void fused_row_update(const FusedUpdate& fu, long long row, const float4 (&grad)[MAXV], int t, int d4, float scale,
+                                                 float bc1, float bc2s) {
+  const AdamK& a = fu.a;
+  const int last = fu.last ? fu.last[row] : a.step - 1;
+  LazyRow lr;
+  if (fu.last) lr = lazy_row_prepare<TPR>(last, a.step - 1, a, t);   // (every lane of the group: the sums are a group effort)
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = t + k * TPR;
+    if (c < d4) {
+      float4 w = fu.table[row * d4 + c], m = fu.mom[row * d4 + c], v = fu.var[row * d4 + c];
+      if (fu.last) lazy_row_apply(lr, w, m, v, a);
+      const float4 gr = grad[k];
+      opt_elem(w.x, m.x, v.x, gr.x * scale, a, bc1, bc2s);
+      opt_elem(w.y, m.y, v.y, gr.y * scale, a, bc1, bc2s);
+      opt_elem(w.z, m.z, v.z, gr.z * scale, a, bc1, bc2s);
+      opt_elem(w.w, m.w, v.w, gr.w * scale, a, bc1, bc2s);
+      fu.table[row * d4 + c] = w;
+      fu.mom[row * d4 + c] = m;
+      fu.var[row * d4 + c] = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (fu.last && t == 0) fu.last[row] = a.step;
 }
 
 // MODE 0: update with gradient (catch-up first when last_step != null); MODE 1: catch-up only (to step-1)
@@ -1116,27 +1177,36 @@ extern "C" int ur_compact_index(const int32_t* seg_start, const int32_t* sorted_
 static int rows_reduce_impl(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
                             const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
                             const float* vec_b, int32_t G, int32_t d, float* uniq_grad, float* sumsq_dev, const int32_t* out_rows,
-                            void* stream, ReduceRiders rd = ReduceRiders()) {
+                            void* stream, ReduceRiders rd = ReduceRiders(), FusedUpdate fu = FusedUpdate()) {
   const int64_t n_entries = n;
-  UR_REQUIRE(uniq_idx && seg_start && sorted_pos && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_rows_reduce: null pointer");
+  UR_REQUIRE(uniq_idx && seg_start && sorted_pos && n_uniq_dev && (uniq_grad || fu.on), UR_ERR_ARG, "ur_rows_reduce: null pointer");
   UR_REQUIRE(!(out_rows && sumsq_dev), UR_ERR_ARG, "ur_rows_reduce: out_rows with the zeroed tail");
   UR_REQUIRE(n > 0 && n_a >= 0 && n_a <= n, UR_ERR_ARG, "ur_rows_reduce: n=%lld n_a=%lld", (long long)n, (long long)n_a);
   UR_REQUIRE((rows_a || n_a == 0) && ((coef_b && vec_b && G > 0) || n_a == n), UR_ERR_ARG, "ur_rows_reduce: missing source");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512, UR_ERR_ARG, "ur_rows_reduce: d=%d", d);
   hipStream_t st = as_stream(stream);
-  ProfScope ps(PC_REDUCE, st, (double)n * d * 4.0 * 2);
+  ProfScope ps(fu.on ? PC_ADAM : PC_REDUCE, st, (double)n * d * 4.0 * (fu.on ? 7 : 2));
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(n_entries, groups);   // (entries = the plan's capacity)
   if (blocks > 8192) blocks = 8192;
   const int zero_tail = sumsq_dev != nullptr;
-#define GO(T) hipLaunchKernelGGL((rows_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
-                                 (long long)n_entries, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,          \
-                                 (float4*)uniq_grad, zero_tail, out_rows, rd)
-  switch (tpr) {
-    case 4: GO(4); break;
-    case 8: GO(8); break;
-    case 16: GO(16); break;
-    default: GO(32); break;
+#define GO(T, F) hipLaunchKernelGGL((rows_reduce_kernel<T, F>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
+                                    (long long)n_entries, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,       \
+                                    (float4*)uniq_grad, zero_tail, out_rows, rd, fu)
+  if (fu.on) {
+    switch (tpr) {
+      case 4: GO(4, true); break;
+      case 8: GO(8, true); break;
+      case 16: GO(16, true); break;
+      default: GO(32, true); break;
+    }
+  } else {
+    switch (tpr) {
+      case 4: GO(4, false); break;
+      case 8: GO(8, false); break;
+      case 16: GO(16, false); break;
+      default: GO(32, false); break;
+    }
   }
 #undef GO
   UR_LAUNCH_CHECK();
@@ -1216,6 +1286,27 @@ extern "C" int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m,
   UR_REQUIRE(table && m && v && uniq_idx && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_sparse_adam_rows: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_sparse_adam_rows: d=%d n_max=%lld", d, (long long)n_max);
   return launch_sparse_adam(0, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, uniq_grad, d, grad_scale_dev, as_stream(stream));
+}
+
+// ur_rows_reduce + ur_sparse_adam_rows in ONE launch (FusedUpdate above): the per-row gradient sums never reach HBM.  Same sums, same
+// update arithmetic, bit for bit; no uniq_grad comes out, so a caller that clips by the global norm takes the two-launch path.
+extern "C" int ur_rows_reduce_update(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
+                                     const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
+                                     const float* vec_b, int32_t G, int32_t d, const UrAdamCfg* cfg, float* table, float* m, float* v,
+                                     int32_t* last_step, const float* grad_scale_dev, void* stream) {
+  UR_TRACE_SCOPE();
+  int rc = check_adam(cfg, "ur_rows_reduce_update");
+  if (rc) return rc;
+  UR_REQUIRE(table && m && v, UR_ERR_ARG, "ur_rows_reduce_update: null pointer");
+  FusedUpdate fu;
+  fu.on = 1;
+  fu.a = AdamK{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
+  fu.a.lb1 = cfg->beta1 > 0.f ? (float)log2((double)cfg->beta1) : -1e30f;
+  fu.a.lb2 = cfg->beta2 > 0.f ? (float)log2((double)cfg->beta2) : -1e30f;
+  fu.table = (float4*)table; fu.mom = (float4*)m; fu.var = (float4*)v; fu.last = last_step;
+  fu.scale_dev = grad_scale_dev; fu.guard_dev = id_guard().dev;
+  return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, nullptr, nullptr, nullptr, stream,
+                          ReduceRiders(), fu);
 }
 
 extern "C" int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,

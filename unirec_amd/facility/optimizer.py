@@ -70,6 +70,7 @@ class SparseDenseAdam:
         # None: by size (prefetch_plan); True / False: forced (tests; UR_EARLY_CATCHUP=0/1 for A/B runs of whole benchmarks)
         import os
         self._early_catchup = {"0": False, "1": True}.get(os.environ.get("UR_EARLY_CATCHUP", ""))
+        self._fused_update = os.environ.get("UR_FUSED_UPDATE", "1") != "0"     # row reduce + row update in one launch (no clipping)
         self._scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [0] sumsq, [1] clip coef
         self._sumsq_ws = torch.empty(2048, dtype=torch.float32, device=dev)
         self.param_groups = [dict(lr=lr)]  # enough of torch's surface for schedulers / logging
@@ -148,7 +149,7 @@ class SparseDenseAdam:
             if early is None:
                 # The tail of step() hides a replay as long as row reduce + row update + replay fit under the side stream's last
                 # weight-gradient launch + reductions + dense update (~135 us at 25 600 tokens): ~50 us of replay = 65 K rows x 6 row
-                # arrays at the random-row rate.  Measured on one box (tools/ab_early.sh): C5 (28 K ids a step) tail 0.550 / early 0.553 ms,
+                # arrays at the random-row rate.  Measured on one box (tools/ab_switch.sh): C5 (28 K ids a step) tail 0.550 / early 0.553 ms,
                 # aged table 0.574 / 0.586; C3 (154 K ids a step) tail 0.853 / early 0.814 ms.
                 early = sum(plans[name].n for name in lazy) >= 65536
             if lazy and early and all(name in self._plans for name in lazy):
@@ -281,6 +282,10 @@ class SparseDenseAdam:
                     raise RuntimeError("lazy_dense mode: call optimizer.plan_batch(...) before the forward pass")
                 pl = ops.rows_plan(ids_a.contiguous() if ids_a is not None else None, ids_b, st["w"].shape[0])
             d = st["w"].shape[1]
+            if self._fused_update and self.grad_clip is None and name not in model.dense_table_grads:
+                # nothing needs this table's row gradients between the reduction and the update: one launch, the sums stay on chip
+                ops.rows_reduce_update(cfg, st["w"], st["m"], st["v"], pl, rows, coef, vec, G, st["last"], guard)
+                continue
             reduced[name] = (pl, ops.rows_reduce(pl, rows, coef, vec, G, d, zero_tail=self.grad_clip is not None))
         # fullsoftmax: the table's gradient is dense; the encoder's row-sparse part is folded into it
         dense_tables = dict(model.dense_table_grads)

@@ -559,6 +559,16 @@ def sparse_adam_rows(cfg, table, m, v, pl: RowsPlan, uniq_grad, last_step=None, 
                                   _p(uniq_grad), table.shape[1], _p(grad_scale), _stream()), "ur_sparse_adam_rows")
 
 
+def rows_reduce_update(cfg, table, m, v, pl: RowsPlan, rows_a, coef_b, vec_b, G, last_step=None, grad_scale=None):
+    """rows_reduce + sparse_adam_rows in one launch (ur_rows_reduce_update): no row-gradient tensor comes out"""
+    _chk(table, torch.float32, "table"); _chk(last_step, torch.int32, "last_step", allow_none=True)
+    _chk(rows_a, torch.float32, "rows_a", allow_none=True); _chk(coef_b, torch.float32, "coef_b", allow_none=True)
+    _chk(vec_b, torch.float32, "vec_b", allow_none=True)
+    check(lib.ur_rows_reduce_update(_p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, _p(rows_a), pl.n_a, _p(coef_b),
+                                    _p(vec_b), int(G), table.shape[1], C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(grad_scale),
+                                    _stream()), "ur_rows_reduce_update")
+
+
 def rows_filter_touched(pl: RowsPlan, last_step) -> RowsPlan:
     """-> a plan-like list (uniq_idx / n_uniq only, arbitrary order) of pl's rows that were ever updated (ur_rows_filter_touched)"""
     _chk(last_step, torch.int32, "last_step")

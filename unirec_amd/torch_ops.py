@@ -259,6 +259,16 @@ def sparse_adam_rows(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, last
     ops.sparse_adam_rows(ops.adam_cfg(lr, step, weight_decay, algo=algo), table, m, v, pl, uniq_grad, last_step, grad_scale)
 
 
+@custom_op(f"{NS}::rows_reduce_update", mutates_args=("table", "m", "v", "last_step"))
+def rows_reduce_update(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, last_step: Optional[torch.Tensor], uniq_idx: torch.Tensor,
+                       seg_start: torch.Tensor, sorted_pos: torch.Tensor, n_uniq: torch.Tensor, rows_a: Optional[torch.Tensor],
+                       coef_b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], n_a: int, G: int, grad_scale: Optional[torch.Tensor],
+                       lr: float, step: int, weight_decay: float = 0.0, algo: str = "adam") -> None:
+    """rows_reduce + sparse_adam_rows in one launch: the row-gradient sums never reach HBM"""
+    pl = _plan(uniq_idx, seg_start, sorted_pos, n_uniq, uniq_idx.numel(), n_a)
+    ops.rows_reduce_update(ops.adam_cfg(lr, step, weight_decay, algo=algo), table, m, v, pl, rows_a, coef_b, vec_b, G, last_step, grad_scale)
+
+
 @custom_op(f"{NS}::lazy_adam_catchup", mutates_args=("table", "m", "v", "last_step"))
 def lazy_adam_catchup(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, last_step: torch.Tensor, uniq_idx: torch.Tensor,
                       n_uniq: torch.Tensor, lr: float, step: int, weight_decay: float = 0.0, algo: str = "adam") -> None:
@@ -278,7 +288,7 @@ def dense_adam(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torc
     ops.dense_adam(ops.adam_cfg(lr, step, weight_decay, algo=algo), param, grad, m, v, grad_scale)
 
 
-for _op in (sparse_adam_rows, lazy_adam_catchup, lazy_adam_flush, dense_adam):
+for _op in (sparse_adam_rows, rows_reduce_update, lazy_adam_catchup, lazy_adam_flush, dense_adam):
     _op.register_fake(lambda *a, **k: None)
 
 
@@ -326,6 +336,7 @@ HEADER_TO_OP = {
     "ur_shard_exchange_grads": "a2a_embedding_grads",
     "ur_rows_reduce": "rows_reduce",
     "ur_sparse_adam_rows": "sparse_adam_rows",
+    "ur_rows_reduce_update": "rows_reduce_update",
     "ur_lazy_adam_catchup": "lazy_adam_catchup",
     "ur_lazy_adam_flush": "lazy_adam_flush",
     "ur_dense_adam": "dense_adam",
