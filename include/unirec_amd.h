@@ -467,6 +467,10 @@ int ur_rows_reduce_update(const int32_t* uniq_idx, const int32_t* seg_start, con
 int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                          const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,
                          void* stream);
+/* the same replay for a launch issued under a step's compute (a side stream beside forward / backward kernels): a grid of at most one
+ * workgroup per CU, default wave priority.  Same values. */
+int ur_lazy_adam_catchup_background(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                                    const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d, void* stream);
 /* The row update of a step in two launches, so that most of it can run beside the NEXT forward pass (facility/optimizer.py; no
  * reference counterpart: torch.optim steps every parameter before the next forward, unirec/facility/trainer.py:349):
  *   ur_rows_reduce_subset    : ur_rows_reduce for the unique ids u_list[0 .. *n_list_dev) only, entry i -> out[i, :] (same sums, same order)

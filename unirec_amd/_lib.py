@@ -118,6 +118,7 @@ SIGNATURES = {
     "ur_sparse_adam_rows": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, P, I32, P, P]),
     "ur_rows_reduce_update": (C.c_int, [P, P, P, P, I64, P, I64, P, P, I32, I32, C.POINTER(UrAdamCfg), P, P, P, P, P, P]),
     "ur_lazy_adam_catchup": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, I32, P]),
+    "ur_lazy_adam_catchup_background": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, P, P, I64, I32, P]),
     "ur_rows_filter_touched": (C.c_int, [P, P, I64, P, P, P, P]),
     "ur_lazy_adam_flush": (C.c_int, [C.POINTER(UrAdamCfg), P, P, P, P, I64, I64, I32, P]),
     "ur_sumsq": (C.c_int, [P, I64, P, C.c_int, P, P]),

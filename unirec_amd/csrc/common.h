@@ -218,6 +218,7 @@ struct AdamK {
   float lr, b1, b2, eps, wd;
   int step, algo;
   float lb1 = 0.f, lb2 = 0.f;   // log2(b1), log2(b2) (host, double precision): b^j = exp2(j * lb) in the lazy-replay series (rows.hip)
+  int background = 0;           // the launch runs UNDER a step's compute (plan stream): default wave priority, a small grid
 };
 // one element, gradient gr (already scaled / clipped); bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t)
 // (no fp contraction: whether a product is fused into the following add would otherwise be decided per call site, and the same rule

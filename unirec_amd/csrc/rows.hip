@@ -283,6 +283,11 @@ struct FusedUpdate {
 template <int TPR>
 __device__ __forceinline__ void fused_row_update(const FusedUpdate& fu, long long row, const float4 (&grad)[MAXV], int t, int d4, float scale,
                                                  float bc1, float bc2s);
+// (one float4 per lane, the row's state already in registers: requested before the gradient walk, so the two chains of dependent round
+// trips -- plan entry -> positions -> gradient rows, and row id -> stamp, w, m, v -- travel together)
+template <int TPR>
+__device__ __forceinline__ void fused_row_update1(const FusedUpdate& fu, long long row, float4 gr, int last, float4 w, float4 m, float4 v,
+                                                  int t, int c, bool cin, int d4, float scale, float bc1, float bc2s);
 
 // One lane group per unique id; positions are summed in sorted (= lookup) order.  Runs longer than LONG_SEG are
 // handled by all groups of the block together: group g takes positions s+g, s+g+groups, ..., the partial sums are
@@ -359,6 +364,16 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
     // slot 0 of every block is the flag row's: the padding id maps there (block 0), and so do keys that an OVERFLOWING pack cut (their
     // slot_of_uniq entry is stale, initially 0) -- a sum written there after the rider would lose the very flag that reports the overflow
     if (rd.fr_on && (frow == 0 || orow % rd.cap == 0)) continue;
+    float4 pw, pm, pv;
+    int plast = 0;
+    const bool pre = FUSED && d4 <= TPR;
+    const int pc = min(t, d4 - 1);
+    if constexpr (FUSED) {
+      if (pre && frow != 0) {     // (unconditional loads at a clamped column: a load behind a per-lane test is waited for on the spot)
+        plast = fu.last ? fu.last[frow] : fu.a.step - 1;
+        pw = fu.table[frow * d4 + pc]; pm = fu.mom[frow * d4 + pc]; pv = fu.var[frow * d4 + pc];
+      }
+    }
     if (frow != 0) {
       const int s = seg_start[u], e = seg_start[u + 1];
       if (e - s > LONG_SEG) continue;                      // pass 2
@@ -368,7 +383,10 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
         for (int q = s; q < e; ++q) add_pos<TPR>(acc, sorted_pos[q], n_a, rows_a, coef_b, vec_b, G, d4, t);
     }
     if constexpr (FUSED) {
-      if (frow != 0) fused_row_update<TPR>(fu, frow, acc, t, d4, fscale, fbc1, fbc2s);   // (group-uniform)
+      if (frow != 0) {   // (group-uniform)
+        if (pre) fused_row_update1<TPR>(fu, frow, acc[0], plast, pw, pm, pv, t, pc, t < d4, d4, fscale, fbc1, fbc2s);
+        else fused_row_update<TPR>(fu, frow, acc, t, d4, fscale, fbc1, fbc2s);
+      }
       continue;
     }
 #pragma unroll
@@ -636,6 +654,27 @@ __device__ __forceinline__ void fused_row_update(const FusedUpdate& fu, long lon
   if (fu.last && t == 0) fu.last[row] = a.step;
 }
 
+template <int TPR>
+__device__ __forceinline__ void fused_row_update1(const FusedUpdate& fu, long long row, float4 gr, int last, float4 w, float4 m, float4 v,
+                                                  int t, int c, bool cin, int d4, float scale, float bc1, float bc2s) {
+  const AdamK& a = fu.a;
+  if (fu.last) {
+    const LazyRow lr = lazy_row_prepare<TPR>(last, a.step - 1, a, t);
+    lazy_row_apply(lr, w, m, v, a);
+  }
+  opt_elem(w.x, m.x, v.x, gr.x * scale, a, bc1, bc2s);
+  opt_elem(w.y, m.y, v.y, gr.y * scale, a, bc1, bc2s);
+  opt_elem(w.z, m.z, v.z, gr.z * scale, a, bc1, bc2s);
+  opt_elem(w.w, m.w, v.w, gr.w * scale, a, bc1, bc2s);
+  if (cin) {
+    fu.table[row * d4 + c] = w;
+    fu.mom[row * d4 + c] = m;
+    fu.var[row * d4 + c] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (fu.last && t == 0) fu.last[row] = a.step;
+}
+
 // MODE 0: update with gradient (catch-up first when last_step != null); MODE 1: catch-up only (to step-1)
 template <int TPR, int MODE>
 __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restrict__ table, float4* __restrict__ mom,
@@ -735,7 +774,7 @@ __global__ __launch_bounds__(256) void sparse_adam_kernel(AdamK a, float4* __res
                                                           const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev,
                                                           long long n_max, const float4* __restrict__ grad, int d4,
                                                           const float* __restrict__ scale_dev, const int* __restrict__ guard_dev) {
-  __builtin_amdgcn_s_setprio(3);   // (see rows_reduce_kernel)
+  if (!a.background) __builtin_amdgcn_s_setprio(3);   // (see rows_reduce_kernel)
   sparse_adam_body<TPR, MODE>(a, table, mom, var, last_step, uniq_idx, n_uniq_dev, n_max, grad, d4, scale_dev, (int)blockIdx.x, (int)gridDim.x,
                               guard_dev);
 }
@@ -1239,6 +1278,7 @@ extern "C" int ur_rows_reduce_riders(const int32_t* uniq_idx, const int32_t* seg
 }
 
 constexpr int UR_CATCHUP_BLOCKS = 1024;
+constexpr int UR_BACKGROUND_BLOCKS = 256;
 static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* grad, int d,
                               const float* scale, hipStream_t st) {
@@ -1252,6 +1292,10 @@ static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, floa
   // the catch-up walks a (usually short, often empty) filtered list with a grid-stride loop: a grid sized for the plan's capacity was
   // 3 520 workgroups that start, read the count and leave -- 20 us of dispatch at the tail of every step beside the dW launch
   if (mode != 0 && blocks > UR_CATCHUP_BLOCKS) blocks = UR_CATCHUP_BLOCKS;
+  if (mode == 2) {   // background replay (ur_lazy_adam_catchup_background): one workgroup per CU at most, no raised priority
+    a.background = 1;
+    if (blocks > UR_BACKGROUND_BLOCKS) blocks = UR_BACKGROUND_BLOCKS;
+  }
   if (blocks < 1) blocks = 1;
   const int* guard_dev = id_guard().dev;
 #define GO(T, MD) hipLaunchKernelGGL((sparse_adam_kernel<T, MD>), dim3(blocks), dim3(256), 0, st, a, (float4*)table, (float4*)m, \
@@ -1286,6 +1330,18 @@ extern "C" int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m,
   UR_REQUIRE(table && m && v && uniq_idx && n_uniq_dev && uniq_grad, UR_ERR_ARG, "ur_sparse_adam_rows: null pointer");
   UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_sparse_adam_rows: d=%d n_max=%lld", d, (long long)n_max);
   return launch_sparse_adam(0, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, uniq_grad, d, grad_scale_dev, as_stream(stream));
+}
+
+// ur_lazy_adam_catchup for a replay issued UNDER a step's compute (the plan stream of the step in flight): at most one workgroup per CU and
+// no raised wave priority -- at its usual priority and grid the replay of 140 K rows stretched the FFN chain beside it from 63 to 152 us.
+extern "C" int ur_lazy_adam_catchup_background(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
+                                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d, void* stream) {
+  UR_TRACE_SCOPE();
+  int rc = check_adam(cfg, "ur_lazy_adam_catchup_background");
+  if (rc) return rc;
+  UR_REQUIRE(table && m && v && last_step && uniq_idx && n_uniq_dev, UR_ERR_ARG, "ur_lazy_adam_catchup_background: null pointer");
+  UR_REQUIRE(d > 0 && d % 4 == 0 && d <= 512 && n_max > 0, UR_ERR_ARG, "ur_lazy_adam_catchup_background: d=%d", d);
+  return launch_sparse_adam(2, cfg, table, m, v, last_step, uniq_idx, n_uniq_dev, n_max, nullptr, d, nullptr, as_stream(stream));
 }
 
 // ur_rows_reduce + ur_sparse_adam_rows in ONE launch (FusedUpdate above): the per-row gradient sums never reach HBM.  Same sums, same

@@ -164,7 +164,7 @@ class SparseDenseAdam:
                 for name in lazy:
                     st = self.tables[name]
                     cold, hot = ops.rows_split_hot(plans[name], st["last"] if self.wd == 0.0 else None, self._plans[name])
-                    ops.lazy_adam_catchup(cfg2, st["w"], st["m"], st["v"], st["last"], cold)
+                    ops.lazy_adam_catchup(cfg2, st["w"], st["m"], st["v"], st["last"], cold, background=True)
                     filtered[name] = hot
             elif lazy and self.wd == 0.0:
                 # rows of the next batch that have any optimizer history at all: the catch-up at the tail of this step only walks those

@@ -582,10 +582,12 @@ def rows_filter_touched(pl: RowsPlan, last_step) -> RowsPlan:
     return out
 
 
-def lazy_adam_catchup(cfg, table, m, v, last_step, pl: RowsPlan):
+def lazy_adam_catchup(cfg, table, m, v, last_step, pl: RowsPlan, background=False):
+    """background: the launch sits on a side stream under a step's compute (ur_lazy_adam_catchup_background: small grid, default priority)"""
     _chk(last_step, torch.int32, "last_step")
-    check(lib.ur_lazy_adam_catchup(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n,
-                                   table.shape[1], _stream()), "ur_lazy_adam_catchup")
+    fn = lib.ur_lazy_adam_catchup_background if background else lib.ur_lazy_adam_catchup
+    check(fn(C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(pl.uniq_idx), _p(pl.n_uniq), pl.n, table.shape[1], _stream()),
+          "ur_lazy_adam_catchup")
 
 
 def lazy_adam_flush(cfg, table, m, v, last_step, row0=0, n=None):

@@ -338,6 +338,7 @@ HEADER_TO_OP = {
     "ur_sparse_adam_rows": "sparse_adam_rows",
     "ur_rows_reduce_update": "rows_reduce_update",
     "ur_lazy_adam_catchup": "lazy_adam_catchup",
+    "ur_lazy_adam_catchup_background": "lazy_adam_catchup",
     "ur_lazy_adam_flush": "lazy_adam_flush",
     "ur_dense_adam": "dense_adam",
     "ur_full_rank": "full_rank",
