@@ -118,7 +118,9 @@ int64_t ur_sasrec_workspace_bytes(const UrSasrecCfg* cfg);
 /* forward: writes user_emb [B,d]; activations needed by the backward stay in `ws` -- and so do the K-major copies of every layer's
  * weights the forward makes at its head (one transpose launch).  CONTRACT of the pair: ur_sasrec_bwd must be given the SAME ws and the
  * SAME `dense` values as the ur_sasrec_fwd it differentiates, with no other forward on that ws and no update of `dense` in between
- * (what autograd guarantees for a torch module; an evaluation forward in between needs a workspace of its own). */
+ * (what autograd guarantees for a torch module; an evaluation forward in between needs a workspace of its own).  The library remembers,
+ * per calling thread, which (dense, item_seq, shape) the last forward on each of the last 8 workspaces saw, and ur_sasrec_bwd returns
+ * UR_ERR_ARG when it is handed a workspace whose last forward saw something else. */
 int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                   const int32_t* item_seq, float* user_emb, void* ws, void* stream);
 /* backward (autograd of the above; the reference has no hand-written backward):

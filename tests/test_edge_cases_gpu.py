@@ -219,3 +219,26 @@ def test_roctx_ranges_behind_their_switch():
         e = {k: v for k, v in os.environ.items() if k != "UR_ROCTX"}
         r = subprocess.run([sys.executable, "-c", code], env=dict(e, **env), cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and want in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_backward_on_a_workspace_of_another_forward_is_refused():
+    """ur_sasrec_bwd reads the K-major weight copies, row maps and activations the LAST ur_sasrec_fwd on its workspace left there:
+    a backward pass handed a workspace whose last forward saw other ids or other weights is an error, not a silent stale read."""
+    from unirec_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    cfg = ops.sasrec_cfg(8, 10, 32, 4, 64, 2, "gelu", True, 1e-10)
+    _, total = ops.sasrec_param_layout(cfg)
+    table = torch.randn(50, 32, device=dev)
+    dense, dense2 = torch.randn(total, device=dev) * 0.1, torch.randn(total, device=dev) * 0.1
+    seq = torch.randint(1, 50, (8, 10), dtype=torch.int32, device=dev)
+    seq2 = torch.randint(1, 50, (8, 10), dtype=torch.int32, device=dev)
+    ws = ops.sasrec_workspace(cfg, dev)
+    ue = ops.sasrec_fwd(cfg, table, dense, seq, ws)
+    ops.sasrec_bwd(cfg, table, dense, seq, torch.ones_like(ue), ws)            # the pair as intended
+    ops.sasrec_fwd(cfg, table, dense, seq2, ws)                                 # another forward on the same workspace ...
+    with pytest.raises(_lib.UnirecAmdError, match="last ur_sasrec_fwd on this workspace"):
+        ops.sasrec_bwd(cfg, table, dense, seq, torch.ones_like(ue), ws)        # ... and a backward for the first one
+    ops.sasrec_fwd(cfg, table, dense2, seq, ws)
+    with pytest.raises(_lib.UnirecAmdError, match="last ur_sasrec_fwd on this workspace"):
+        ops.sasrec_bwd(cfg, table, dense, seq, torch.ones_like(ue), ws)
+    torch.cuda.synchronize()

@@ -336,6 +336,27 @@ SideCtx* side_ctx(bool even_if_disabled = false) {
 }
 }  // namespace
 
+// Which forward pass a workspace holds (host side, per thread): ur_sasrec_bwd reads the K-major weight copies, row maps and activations the
+// LAST ur_sasrec_fwd on that workspace left there.  A backward pass on a workspace whose last forward pass saw other weights, another
+// id matrix or another shape would compute with stale or foreign state without any error: it is refused instead.
+namespace {
+struct FwdStamp { const void* ws; const void* dense; const void* seq; int B, L, d, n_layers; };
+thread_local FwdStamp g_fwd_stamps[8] = {};
+thread_local int g_fwd_next = 0;
+void stamp_forward(const void* ws, const void* dense, const void* seq, const UrSasrecCfg& c) {
+  for (auto& e : g_fwd_stamps)
+    if (e.ws == ws) { e = FwdStamp{ws, dense, seq, c.B, c.L, c.d, c.n_layers}; return; }
+  g_fwd_stamps[g_fwd_next] = FwdStamp{ws, dense, seq, c.B, c.L, c.d, c.n_layers};
+  g_fwd_next = (g_fwd_next + 1) % 8;
+}
+// -> 0 ok, 1 mismatch, -1 unknown workspace (stamped by another thread, or more than 8 workspaces ago: not checked)
+int check_forward(const void* ws, const void* dense, const void* seq, const UrSasrecCfg& c) {
+  for (const auto& e : g_fwd_stamps)
+    if (e.ws == ws) return (e.dense == dense && e.seq == seq && e.B == c.B && e.L == c.L && e.d == c.d && e.n_layers == c.n_layers) ? 0 : 1;
+  return -1;
+}
+}  // namespace
+
 extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, int64_t n_items, const float* dense,
                              const int32_t* item_seq, float* user_emb, void* ws, void* stream) {
   UR_TRACE_SCOPE();
@@ -344,6 +365,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
   UR_REQUIRE(item_table && dense && item_seq && user_emb && ws, UR_ERR_ARG, "ur_sasrec_fwd: null pointer");
   UR_REQUIRE(n_items > 0, UR_ERR_ARG, "ur_sasrec_fwd: n_items=%lld", (long long)n_items);
   const UrSasrecCfg& c = *cfg;
+  stamp_forward(ws, dense, item_seq, c);
   hipStream_t st = as_stream(stream);
   const Layout lay = make_layout(c);
   Ws w = carve(c, (float*)ws);
@@ -529,6 +551,8 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   UR_REQUIRE(dense && item_seq && d_user_emb && ws && dense_grad && d_emb_rows, UR_ERR_ARG, "ur_sasrec_bwd: null pointer");
   (void)item_table; (void)n_items;
   const UrSasrecCfg& c = *cfg;
+  UR_REQUIRE(check_forward(ws, dense, item_seq, c) != 1, UR_ERR_ARG,
+             "ur_sasrec_bwd: the last ur_sasrec_fwd on this workspace saw other weights / ids / shapes (the backward pass reads what it left there)");
   hipStream_t st = as_stream(stream);
   if ((rc = ur_sasrec_bwd_join(stream))) return rc;   // (a deferred pass nobody joined)
   const Layout lay = make_layout(c);

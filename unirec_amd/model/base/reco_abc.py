@@ -93,6 +93,11 @@ class AbstractRecommender(nn.Module):
         self.SCORE_CLIP = config.get("score_clip_value", -1) or -1
         self.has_user_bias = bool(config.get("has_user_bias", False))
         self.has_item_bias = bool(config.get("has_item_bias", False))
+        if self.loss_type == "fullsoftmax" and self.has_user_bias and self.SCORE_CLIP > 0:
+            # the fullsoftmax kernels take d loss / d user_bias as exactly 0 (a per-user shift cancels in the softmax over n); a score clamp
+            # (recommender.py:94-95) breaks that invariance wherever it saturates, and that term is not computed: refuse instead of drifting
+            raise NotImplementedError("loss_type='fullsoftmax' with has_user_bias and score_clip_value > 0: the user-bias gradient under an "
+                                      "active score clamp is not implemented (drop the clamp or the user bias)")
         self.tau = config.get("tau", 1.0)
 
     def _init_modules(self):  # reco_abc.py:159-208
