@@ -172,7 +172,8 @@ constexpr int SMALL_N_MID = SMALL_N;          // (named apart because the chunk-
 
 // ------------------------------------------------------------------------------- segment reduce
 constexpr int MAXV = 4;
-constexpr int LONG_SEG = 64;   // runs longer than this (hot items under Zipfian ids) are reduced by the whole block
+constexpr int LONG_SEG = 64;
+constexpr int FU_ROWS = 4;        // rows_reduce_kernel<.., FUSED>: unique ids a lane group has in flight at a time   // runs longer than this (hot items under Zipfian ids) are reduced by the whole block
 
 // acc += gradient row of lookup position p (explicit row, or coef * vec for the scorer's implicit candidate rows)
 template <int TPR>
@@ -340,8 +341,61 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
     const long long u0 = uid(uc0);
     cand0 = uniq_idx[u0] != 0 && seg_start[u0 + 1] - seg_start[u0] > LONG_SEG;
   }
+  // ---- pass 1, fused update with one float4 per lane (d <= 4 TPR: every benchmark shape): FU_ROWS unique ids per lane group at a time.
+  // The kernel is a chain of dependent round trips per row -- plan entry -> position -> gradient row, and row id -> stamp, w, m, v, random
+  // 512-byte reads over tables of tens of GB -- so its time is round trips x rounds: here every load of a stage is issued for all
+  // FU_ROWS rows before the first use (unconditional loads at clamped indices, see sparse_adam_body).  Same adds in the same order
+  // (first position as fma(w, r, 0), the rest by long_walk), same update arithmetic: bit-identical to the one-row loop below.
+  bool pass1_done = false;
+  if constexpr (FUSED) {
+    if (d4 <= TPR) {
+      constexpr int U = FU_ROWS;
+      const float* cb = coef_b ? coef_b : (const float*)rows_a;
+      const float4* vb = vec_b ? vec_b : rows_a;
+      const int pc = min(t, d4 - 1);
+      for (long long e0 = ((long long)blockIdx.x * groups + g) * U; e0 < n_uniq; e0 += (long long)gridDim.x * groups * U) {
+        long long row[U];
+        int sg[U], eg[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+          const long long u = min(e0 + i, (long long)n_uniq - 1);
+          row[i] = uniq_idx[u]; sg[i] = seg_start[u]; eg[i] = seg_start[u + 1];
+        }
+        int last[U], p0[U];
+        float4 w[U], m[U], v[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+          last[i] = fu.last ? fu.last[row[i]] : fu.a.step - 1;
+          w[i] = fu.table[row[i] * d4 + pc]; m[i] = fu.mom[row[i] * d4 + pc]; v[i] = fu.var[row[i] * d4 + pc];
+          p0[i] = sorted_pos[sg[i]];      // (a unique id has at least one position)
+        }
+        float cw[U];
+        const float4* src[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+          const bool is_a = p0[i] < n_a;
+          const int pb = is_a ? 0 : p0[i] - (int)n_a;
+          const float c = cb[pb];
+          cw[i] = is_a ? 1.0f : c;
+          src[i] = is_a ? rows_a + (long long)p0[i] * d4 : vb + (long long)(pb / G) * d4;
+        }
+        float4 r0[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) r0[i] = src[i][pc];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+          if (e0 + i >= n_uniq || row[i] == 0 || eg[i] - sg[i] > LONG_SEG) continue;   // group-uniform (long runs: pass 2)
+          float4 acc[MAXV];
+          acc[0] = make_float4(fmaf(cw[i], r0[i].x, 0.f), fmaf(cw[i], r0[i].y, 0.f), fmaf(cw[i], r0[i].z, 0.f), fmaf(cw[i], r0[i].w, 0.f));
+          if (eg[i] - sg[i] > 1) long_walk<TPR, 1>(acc, sg[i] + 1, eg[i], 1, sorted_pos, n_a, rows_a, coef_b, vec_b, G, d4, t);
+          fused_row_update1<TPR>(fu, row[i], acc[0], last[i], w[i], m[i], v[i], t, pc, t < d4, d4, fscale, fbc1, fbc2s);
+        }
+      }
+      pass1_done = true;
+    }
+  }
   // ---- pass 1: one lane group per unique id, neighbouring ids in one workgroup (coalesced plan reads).  Long runs are left out.
-  for (long long base = (long long)blockIdx.x * groups; base < n; base += (long long)gridDim.x * groups) {
+  for (long long base = (long long)blockIdx.x * groups; base < n && !pass1_done; base += (long long)gridDim.x * groups) {
     if (base >= n_uniq && !zero_tail) break;   // block-uniform
     const long long ent = base + g;
     if (ent >= n) continue;
@@ -1227,6 +1281,7 @@ static int rows_reduce_impl(const int32_t* uniq_idx, const int32_t* seg_start, c
   ProfScope ps(fu.on ? PC_ADAM : PC_REDUCE, st, (double)n * d * 4.0 * (fu.on ? 7 : 2));
   const int tpr = pick_tpr(d), groups = 256 / tpr;
   int blocks = cdiv(n_entries, groups);   // (entries = the plan's capacity)
+  if (fu.on && d / 4 <= tpr) blocks = cdiv(n_entries, groups * FU_ROWS);
   if (blocks > 8192) blocks = 8192;
   const int zero_tail = sumsq_dev != nullptr;
 #define GO(T, F) hipLaunchKernelGGL((rows_reduce_kernel<T, F>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
