@@ -465,6 +465,13 @@ int ur_rows_reduce_update(const int32_t* uniq_idx, const int32_t* seg_start, con
                           const float* rows_a, int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d,
                           const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, const float* grad_scale_dev,
                           void* stream);
+/* ur_rows_reduce_update on the OWNER side of the row-sharded step (= ur_rows_reduce_riders with step_flags_out4, + ur_sparse_adam_rows):
+ * recv_rows is the received gradient block [world * cap, d] (n = world * cap plan entries, every position an explicit row); the gradient
+ * scale is the step's flags found in slot 0 of its source blocks (1 / world, or skip the step: a NaN loss, an id out of range or a capacity
+ * overflow on ANY rank), published to step_flags_out4 as ur_shard_step_flags does. */
+int ur_rows_reduce_update_owner(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev,
+                                int64_t n, const float* recv_rows, int32_t d, int32_t world, int32_t cap, float* step_flags_out4,
+                                const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, void* stream);
 /* brings rows uniq_idx[0..n_uniq) to the state "after step (cfg->step - 1)" */
 int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                          const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, int32_t d,

@@ -303,12 +303,37 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
                                                           FusedUpdate fu = FusedUpdate()) {
   float fscale = 1.f, fbc1 = 1.f, fbc2s = 1.f;
   if constexpr (FUSED) {
-    fscale = ur_step_scale(fu.scale_dev, fu.guard_dev);
-    if (fscale < 0.f) return;     // update guard (NaN loss, id guard): the whole step is skipped, nothing is written
+    if (rd.sf_out4) {
+      // owner side of the sharded step: the gradient scale IS the step's flags, which sit in slot 0 of every source block of the received
+      // gradient rows -- every workgroup sums them itself (world x 16 bytes, source-rank order: the same value everywhere), the first
+      // one also publishes them (what the unfused launch's rider does)
+      __shared__ float s_scale;
+      if (threadIdx.x == 0) {
+        float nan = 0.f, ovf = 0.f, loss = 0.f;
+        for (int q = 0; q < rd.world; ++q) {
+          const float4 r = rows_a[(long long)q * rd.cap * d4];
+          nan += r.x; ovf += r.y; loss += r.z;
+        }
+        float sc = (nan > 0.f || ovf > 0.f) ? -1.f : 1.f / (float)rd.world;
+        if (blockIdx.x == 0) {
+          rd.sf_out4[0] = sc;
+          rd.sf_out4[1] = nan > 0.f ? __builtin_nanf("") : loss / (float)rd.world;
+          rd.sf_out4[2] = nan;
+          rd.sf_out4[3] = ovf;
+        }
+        if (fu.guard_dev && *fu.guard_dev) sc = -1.f;
+        s_scale = sc;
+      }
+      __syncthreads();
+      fscale = s_scale;
+    } else {
+      fscale = ur_step_scale(fu.scale_dev, fu.guard_dev);
+    }
+    if (fscale < 0.f) return;     // update guard (NaN loss, id guard, overflow): the whole step is skipped, nothing is written
     fbc1 = 1.f - powf(fu.a.b1, (float)fu.a.step);
     fbc2s = sqrtf(1.f - powf(fu.a.b2, (float)fu.a.step));
   }
-  if (rd.sf_out4 && blockIdx.x == 0 && threadIdx.x == 0) {   // (source-rank order: every rank sums the same values in the same order)
+  if (!FUSED && rd.sf_out4 && blockIdx.x == 0 && threadIdx.x == 0) {   // (source-rank order: every rank sums the same values in the same order)
     float nan = 0.f, ovf = 0.f, loss = 0.f;
     for (int q = 0; q < rd.world; ++q) {
       const float4 r = rows_a[(long long)q * rd.cap * d4];
@@ -1418,6 +1443,32 @@ extern "C" int ur_rows_reduce_update(const int32_t* uniq_idx, const int32_t* seg
   fu.scale_dev = grad_scale_dev; fu.guard_dev = id_guard().dev;
   return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, nullptr, nullptr, nullptr, stream,
                           ReduceRiders(), fu);
+}
+
+// ur_rows_reduce_update on the OWNER side of the sharded step (ur_rows_reduce_riders with step_flags_out4, + the row update): rows_a is
+// the received gradient block [world * cap, d]; the gradient scale is the step's flags found in slot 0 of its source blocks (1 / world, or
+// skip: a NaN loss, an id out of range or a capacity overflow on ANY rank), published to step_flags_out4 as ur_shard_step_flags does.
+extern "C" int ur_rows_reduce_update_owner(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
+                                           const int32_t* n_uniq_dev, int64_t n, const float* recv_rows, int32_t d, int32_t world, int32_t cap,
+                                           float* step_flags_out4, const UrAdamCfg* cfg, float* table, float* m, float* v,
+                                           int32_t* last_step, void* stream) {
+  UR_TRACE_SCOPE();
+  int rc = check_adam(cfg, "ur_rows_reduce_update_owner");
+  if (rc) return rc;
+  UR_REQUIRE(table && m && v && recv_rows && step_flags_out4, UR_ERR_ARG, "ur_rows_reduce_update_owner: null pointer");
+  UR_REQUIRE(world >= 1 && world <= 256 && cap > 0 && n >= (int64_t)(world - 1) * cap + 1, UR_ERR_ARG,
+             "ur_rows_reduce_update_owner: world=%d cap=%d n=%lld", world, cap, (long long)n);
+  FusedUpdate fu;
+  fu.on = 1;
+  fu.a = AdamK{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
+  fu.a.lb1 = cfg->beta1 > 0.f ? (float)log2((double)cfg->beta1) : -1e30f;
+  fu.a.lb2 = cfg->beta2 > 0.f ? (float)log2((double)cfg->beta2) : -1e30f;
+  fu.table = (float4*)table; fu.mom = (float4*)m; fu.var = (float4*)v; fu.last = last_step;
+  fu.guard_dev = id_guard().dev;
+  ReduceRiders rd;
+  rd.sf_out4 = step_flags_out4; rd.world = world; rd.cap = cap;
+  return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, recv_rows, n, nullptr, nullptr, 1, d, nullptr, nullptr, nullptr, stream,
+                          rd, fu);
 }
 
 extern "C" int ur_lazy_adam_catchup(const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,

@@ -469,7 +469,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
 
     def _update_rows(self, cfg, tabs, owner_grads, dense_shard, scale):
         for name, c in tabs.items():
-            if name not in dense_shard:
+            if name not in dense_shard and name in owner_grads:     # (not in owner_grads: updated by the fused owner-side launch already)
                 st = self.tables[name]
                 ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], c["own"], owner_grads[name], st["last"], scale)
         for name, dg in dense_shard.items():      # fullsoftmax: every row of the shard moves -> plain dense rule on the shard
@@ -606,6 +606,7 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         # ---- 4. row gradients: reduce per unique key, scatter to slots (+ this rank's flags in slot 0), owners sum in source-rank order
         owner_grads, out4 = {}, self._out4[self.t % 4]
         first = True
+        fuse_first = self._fused_update and self.grad_clip is None
         if len(tabs) > 1:     # ONE flag row per step rides in the first table's exchange: it must say "overflow" for every table
             # (bitwise OR, not a sum: every consumer tests single bits of flags[0] -- two tables overflowing in one step must not read as "none")
             f0 = next(iter(tabs.values()))["bf"]["flags"]
@@ -625,8 +626,17 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
                 ops.comm_all_to_all(sb["send_grads"], sb["grads_in"], W, ahead=False, kind="grads")
             else:
                 self._a2a(sb["send_grads"], sb["grads_in"], "a2a_row_grads")
-            owner_grads[name] = ops.rows_reduce_riders(c["own"], sb["grads_in"], None, None, 1, d, W, c["cap"],
-                                                       zero_tail=self.grad_clip is not None, step_flags_out4=out4 if first else None)
+            if first and fuse_first and not (name == "item_embedding" and self._fs_dgrad is not None):
+                # nothing needs the owner-side row gradients between their reduction and the update (no clipping, no dense fold): the
+                # update is the reduce launch's epilogue, and the scale it needs -- the step flags in the block it reduces -- is read there
+                st = self.tables[name]
+                ops.rows_reduce_update_owner(cfg, st["w"], st["m"], st["v"], c["own"], sb["grads_in"], W, c["cap"], out4, st["last"])
+            elif not first and fuse_first and not (name == "item_embedding" and self._fs_dgrad is not None):
+                st = self.tables[name]      # (a later table of the step: the flags are on the device already)
+                ops.rows_reduce_update(cfg, st["w"], st["m"], st["v"], c["own"], sb["grads_in"], None, None, 1, st["last"], out4[0:1])
+            else:
+                owner_grads[name] = ops.rows_reduce_riders(c["own"], sb["grads_in"], None, None, 1, d, W, c["cap"],
+                                                           zero_tail=self.grad_clip is not None, step_flags_out4=out4 if first else None)
             first = False
         dense_shard = {}
         if self._fs_dgrad is not None:      # fullsoftmax: the encoder's row-sparse part of the item table's gradient folds into the dense one

@@ -569,6 +569,16 @@ def rows_reduce_update(cfg, table, m, v, pl: RowsPlan, rows_a, coef_b, vec_b, G,
                                     _stream()), "ur_rows_reduce_update")
 
 
+def rows_reduce_update_owner(cfg, table, m, v, pl: RowsPlan, recv_rows, world, cap, step_flags_out4, last_step=None):
+    """owner side of the sharded step: rows_reduce_riders(step_flags_out4=...) + sparse_adam_rows in one launch (ur_rows_reduce_update_owner)"""
+    _chk(table, torch.float32, "table"); _chk(last_step, torch.int32, "last_step", allow_none=True)
+    _chk(recv_rows, torch.float32, "recv_rows"); _chk(step_flags_out4, torch.float32, "step_flags_out4")
+    assert pl.n == pl.n_a == world * cap and recv_rows.numel() == pl.n * table.shape[1]
+    check(lib.ur_rows_reduce_update_owner(_p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, _p(recv_rows), table.shape[1],
+                                          int(world), int(cap), _p(step_flags_out4), C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _stream()),
+          "ur_rows_reduce_update_owner")
+
+
 def rows_filter_touched(pl: RowsPlan, last_step) -> RowsPlan:
     """-> a plan-like list (uniq_idx / n_uniq only, arbitrary order) of pl's rows that were ever updated (ur_rows_filter_touched)"""
     _chk(last_step, torch.int32, "last_step")

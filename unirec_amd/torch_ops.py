@@ -354,6 +354,7 @@ _SHARD = "row-sharded (multi-GPU) variant driven by facility/distributed.py arou
 _COMM = "the library's RCCL communicator (process-wide state behind the a2a_embedding_exchange ops): set-up / tear-down / the flat all-reduce, no tensor dispatch"
 _FAMILY = "sibling model family / loss outside the north_star's named ops (SURVEY.md 8 f4): reached through unirec_amd.ops"
 NOT_OPS = {
+    "ur_rows_reduce_update_owner": _SHARD,
     "ur_last_error": _QUERY, "ur_version": _QUERY, "ur_id_guard_state": _QUERY, "ur_id_guard_reset": _SWITCH, "ur_trace_ranges_pushed": _QUERY, "ur_sasrec_param_layout": _QUERY, "ur_gru_param_layout": _QUERY,
     "ur_gru_workspace_bytes": _QUERY, "ur_rows_plan_workspace_bytes": _QUERY, "ur_gemm_tn_workspace_floats": _QUERY,
     "ur_full_topk_workspace_bytes": _QUERY, "ur_full_softmax_workspace_bytes": _QUERY, "ur_convformer_param_layout": _QUERY,
