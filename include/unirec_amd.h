@@ -460,11 +460,17 @@ int ur_sparse_adam_rows(const UrAdamCfg* cfg, float* table, float* m, float* v, 
 /* ur_rows_reduce + ur_sparse_adam_rows in ONE launch: the per-row gradient sums (ur_rows_reduce's arguments, same summation order) go
  * straight into the row update (ur_sparse_adam_rows's arguments, same arithmetic) and never reach HBM -- bit-identical tables, two row-array
  * passes and one dependent launch fewer.  No uniq_grad comes out: a caller that clips by the global norm (the reference's
- * clip_grad_norm_, unirec/facility/trainer.py:347-348) or exchanges row gradients between ranks uses the two calls. */
+ * clip_grad_norm_, unirec/facility/trainer.py:347-348) or exchanges row gradients between ranks uses the two calls.
+ * next_cold_idx / next_hot_idx (optional, lazy-dense tables; ur_rows_split_hot's two outputs for the NEXT batch's plan against this one,
+ * capacity next_list_max each): the next batch's lazy replay rides in the same launch -- extra workgroups bring its `cold` rows (not in
+ * this step's plan: disjoint from every row the update writes) to "after step cfg->step"; its `hot` rows (in both plans) are made current
+ * by the update itself, and replayed like the cold ones when the step is skipped (grad_scale < 0).  Replaces the ur_lazy_adam_catchup
+ * launch that would follow. */
 int ur_rows_reduce_update(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos, const int32_t* n_uniq_dev, int64_t n,
                           const float* rows_a, int64_t n_a, const float* coef_b, const float* vec_b, int32_t G, int32_t d,
                           const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step, const float* grad_scale_dev,
-                          void* stream);
+                          const int32_t* next_cold_idx, const int32_t* next_cold_n_dev, const int32_t* next_hot_idx,
+                          const int32_t* next_hot_n_dev, int64_t next_list_max, void* stream);
 /* ur_rows_reduce_update on the OWNER side of the row-sharded step (= ur_rows_reduce_riders with step_flags_out4, + ur_sparse_adam_rows):
  * recv_rows is the received gradient block [world * cap, d] (n = world * cap plan entries, every position an explicit row); the gradient
  * scale is the step's flags found in slot 0 of its source blocks (1 / world, or skip the step: a NaN loss, an id out of range or a capacity

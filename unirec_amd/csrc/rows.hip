@@ -172,6 +172,8 @@ constexpr int SMALL_N_MID = SMALL_N;          // (named apart because the chunk-
 
 // ------------------------------------------------------------------------------- segment reduce
 constexpr int MAXV = 4;
+constexpr int UR_CATCHUP_BLOCKS = 1024;
+constexpr int UR_BACKGROUND_BLOCKS = 256;
 constexpr int LONG_SEG = 64;
 constexpr int FU_ROWS = 4;        // rows_reduce_kernel<.., FUSED>: unique ids a lane group has in flight at a time   // runs longer than this (hot items under Zipfian ids) are reduced by the whole block
 
@@ -280,7 +282,20 @@ struct FusedUpdate {
   int* last = nullptr;
   const float* scale_dev = nullptr;
   const int* guard_dev = nullptr;
+  // the NEXT batch's lazy replay riding in the same launch (workgroups nb_main .. gridDim - 1): `cold` = its rows this step does not touch
+  // (disjoint from every row the update writes), brought to "after this step"; `hot` = its rows that are in this step's plan too: current
+  // through the update -- unless the step is skipped, then they are replayed as well
+  const int* cold_idx = nullptr; const int* cold_n = nullptr;
+  const int* hot_idx = nullptr; const int* hot_n = nullptr;
+  long long list_max = 0;
+  int nb_main = 0;     // workgroups of the reduction itself (0: all of them)
 };
+template <int TPR, int MODE>
+__device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restrict__ table, float4* __restrict__ mom,
+                                                 float4* __restrict__ var, int* __restrict__ last_step,
+                                                 const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev, long long n_max,
+                                                 const float4* __restrict__ grad, int d4, const float* __restrict__ scale_dev,
+                                                 int bid, int nblk, const int* __restrict__ guard_dev = nullptr);
 template <int TPR>
 __device__ __forceinline__ void fused_row_update(const FusedUpdate& fu, long long row, const float4 (&grad)[MAXV], int t, int d4, float scale,
                                                  float bc1, float bc2s);
@@ -329,10 +344,21 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
     } else {
       fscale = ur_step_scale(fu.scale_dev, fu.guard_dev);
     }
+    if (fu.nb_main > 0 && (int)blockIdx.x >= fu.nb_main) {
+      // replay workgroups: the next batch's rows take their zero-gradient steps up to and including this one (MODE 1 walks to step - 1)
+      AdamK a2 = fu.a;
+      a2.step = fu.a.step + 1;
+      const int rb = (int)blockIdx.x - fu.nb_main, rn = (int)gridDim.x - fu.nb_main;
+      if (fu.cold_idx) sparse_adam_body<TPR, 1>(a2, fu.table, fu.mom, fu.var, fu.last, fu.cold_idx, fu.cold_n, fu.list_max, nullptr, d4, nullptr, rb, rn);
+      if (fscale < 0.f && fu.hot_idx)     // a skipped step updates nothing: its rows of the next batch are replayed like the others
+        sparse_adam_body<TPR, 1>(a2, fu.table, fu.mom, fu.var, fu.last, fu.hot_idx, fu.hot_n, fu.list_max, nullptr, d4, nullptr, rb, rn);
+      return;
+    }
     if (fscale < 0.f) return;     // update guard (NaN loss, id guard, overflow): the whole step is skipped, nothing is written
     fbc1 = 1.f - powf(fu.a.b1, (float)fu.a.step);
     fbc2s = sqrtf(1.f - powf(fu.a.b2, (float)fu.a.step));
   }
+  const int nblk = (FUSED && fu.nb_main > 0) ? fu.nb_main : (int)gridDim.x;   // (workgroups of the reduction)
   if (!FUSED && rd.sf_out4 && blockIdx.x == 0 && threadIdx.x == 0) {   // (source-rank order: every rank sums the same values in the same order)
     float nan = 0.f, ovf = 0.f, loss = 0.f;
     for (int q = 0; q < rd.world; ++q) {
@@ -359,7 +385,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
   const int n_uniq = *n_uniq_dev;
   auto uid = [&](long long i) -> long long { return i; };
   // (pass 2's first candidate test is issued here, so that its loads travel with pass 1's instead of after them)
-  const long long gstride = gridDim.x;
+  const long long gstride = nblk;
   const long long uc0 = blockIdx.x + gstride * threadIdx.x;
   bool cand0 = false;
   if (uc0 < n_uniq) {
@@ -378,7 +404,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
       const float* cb = coef_b ? coef_b : (const float*)rows_a;
       const float4* vb = vec_b ? vec_b : rows_a;
       const int pc = min(t, d4 - 1);
-      for (long long e0 = ((long long)blockIdx.x * groups + g) * U; e0 < n_uniq; e0 += (long long)gridDim.x * groups * U) {
+      for (long long e0 = ((long long)blockIdx.x * groups + g) * U; e0 < n_uniq; e0 += (long long)nblk * groups * U) {
         long long row[U];
         int sg[U], eg[U];
 #pragma unroll
@@ -420,7 +446,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const int* __restrict_
     }
   }
   // ---- pass 1: one lane group per unique id, neighbouring ids in one workgroup (coalesced plan reads).  Long runs are left out.
-  for (long long base = (long long)blockIdx.x * groups; base < n && !pass1_done; base += (long long)gridDim.x * groups) {
+  for (long long base = (long long)blockIdx.x * groups; base < n && !pass1_done; base += (long long)nblk * groups) {
     if (base >= n_uniq && !zero_tail) break;   // block-uniform
     const long long ent = base + g;
     if (ent >= n) continue;
@@ -760,7 +786,7 @@ __device__ __forceinline__ void sparse_adam_body(const AdamK& a, float4* __restr
                                                  float4* __restrict__ var, int* __restrict__ last_step,
                                                  const int* __restrict__ uniq_idx, const int* __restrict__ n_uniq_dev, long long n_max,
                                                  const float4* __restrict__ grad, int d4, const float* __restrict__ scale_dev,
-                                                 int bid, int nblk, const int* __restrict__ guard_dev = nullptr) {
+                                                 int bid, int nblk, const int* __restrict__ guard_dev) {
   constexpr int groups = 256 / TPR;
   const int g = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int n_uniq = (int)min((long long)*n_uniq_dev, n_max);
@@ -1308,6 +1334,10 @@ static int rows_reduce_impl(const int32_t* uniq_idx, const int32_t* seg_start, c
   int blocks = cdiv(n_entries, groups);   // (entries = the plan's capacity)
   if (fu.on && d / 4 <= tpr) blocks = cdiv(n_entries, groups * FU_ROWS);
   if (blocks > 8192) blocks = 8192;
+  if (fu.on && (fu.cold_idx || fu.hot_idx)) {   // + the replay workgroups (FusedUpdate): one per CU walks the lists with a grid stride
+    fu.nb_main = blocks;
+    blocks += UR_BACKGROUND_BLOCKS;
+  }
   const int zero_tail = sumsq_dev != nullptr;
 #define GO(T, F) hipLaunchKernelGGL((rows_reduce_kernel<T, F>), dim3(blocks), dim3(256), 0, st, uniq_idx, seg_start, sorted_pos, n_uniq_dev, \
                                     (long long)n_entries, (const float4*)rows_a, (long long)n_a, coef_b, (const float4*)vec_b, G, d / 4,       \
@@ -1357,8 +1387,6 @@ extern "C" int ur_rows_reduce_riders(const int32_t* uniq_idx, const int32_t* seg
   return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, uniq_grad, sumsq_dev, out_rows, stream, rd);
 }
 
-constexpr int UR_CATCHUP_BLOCKS = 1024;
-constexpr int UR_BACKGROUND_BLOCKS = 256;
 static int launch_sparse_adam(int mode, const UrAdamCfg* cfg, float* table, float* m, float* v, int32_t* last_step,
                               const int32_t* uniq_idx, const int32_t* n_uniq_dev, int64_t n_max, const float* grad, int d,
                               const float* scale, hipStream_t st) {
@@ -1429,11 +1457,16 @@ extern "C" int ur_lazy_adam_catchup_background(const UrAdamCfg* cfg, float* tabl
 extern "C" int ur_rows_reduce_update(const int32_t* uniq_idx, const int32_t* seg_start, const int32_t* sorted_pos,
                                      const int32_t* n_uniq_dev, int64_t n, const float* rows_a, int64_t n_a, const float* coef_b,
                                      const float* vec_b, int32_t G, int32_t d, const UrAdamCfg* cfg, float* table, float* m, float* v,
-                                     int32_t* last_step, const float* grad_scale_dev, void* stream) {
+                                     int32_t* last_step, const float* grad_scale_dev, const int32_t* next_cold_idx,
+                                     const int32_t* next_cold_n_dev, const int32_t* next_hot_idx, const int32_t* next_hot_n_dev,
+                                     int64_t next_list_max, void* stream) {
   UR_TRACE_SCOPE();
   int rc = check_adam(cfg, "ur_rows_reduce_update");
   if (rc) return rc;
   UR_REQUIRE(table && m && v, UR_ERR_ARG, "ur_rows_reduce_update: null pointer");
+  UR_REQUIRE((!next_cold_idx && !next_hot_idx) || (last_step && next_list_max > 0 && (!next_cold_idx || next_cold_n_dev) &&
+                                                   (!next_hot_idx || next_hot_n_dev)),
+             UR_ERR_ARG, "ur_rows_reduce_update: the next batch's replay lists need last_step, their counts and a capacity");
   FusedUpdate fu;
   fu.on = 1;
   fu.a = AdamK{cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->step, cfg->algo};
@@ -1441,6 +1474,7 @@ extern "C" int ur_rows_reduce_update(const int32_t* uniq_idx, const int32_t* seg
   fu.a.lb2 = cfg->beta2 > 0.f ? (float)log2((double)cfg->beta2) : -1e30f;
   fu.table = (float4*)table; fu.mom = (float4*)m; fu.var = (float4*)v; fu.last = last_step;
   fu.scale_dev = grad_scale_dev; fu.guard_dev = id_guard().dev;
+  fu.cold_idx = next_cold_idx; fu.cold_n = next_cold_n_dev; fu.hot_idx = next_hot_idx; fu.hot_n = next_hot_n_dev; fu.list_max = next_list_max;
   return rows_reduce_impl(uniq_idx, seg_start, sorted_pos, n_uniq_dev, n, rows_a, n_a, coef_b, vec_b, G, d, nullptr, nullptr, nullptr, stream,
                           ReduceRiders(), fu);
 }

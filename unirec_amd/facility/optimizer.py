@@ -143,7 +143,7 @@ class SparseDenseAdam:
         ops.stream_wait_stream(self._side, main)   # the ids may still be in flight (H2D copy) on the main stream; `last` is being updated there
         with torch.cuda.stream(self._side):
             plans = {name: ops.rows_plan(a, b, self.tables[name]["w"].shape[0], out=bufs[name]) for name, (a, b) in req.items()}
-            filtered = None
+            filtered = splits = None
             lazy = [name for name in plans if self.tables[name]["last"] is not None] if self.table_mode == "lazy_dense" else []
             early = self._early_catchup
             if early is None:
@@ -166,6 +166,11 @@ class SparseDenseAdam:
                     cold, hot = ops.rows_split_hot(plans[name], st["last"] if self.wd == 0.0 else None, self._plans[name])
                     ops.lazy_adam_catchup(cfg2, st["w"], st["m"], st["v"], st["last"], cold, background=True)
                     filtered[name] = hot
+            elif lazy and self._fused_update and self.grad_clip is None and all(name in self._plans for name in lazy):
+                # small plans: the replay stays at the tail of the step, but RIDES in the fused reduce + update launch (extra workgroups walk
+                # the cold list there; ur_rows_reduce_update) instead of being a launch of its own behind it: the split is made here
+                splits = {name: ops.rows_split_hot(plans[name], self.tables[name]["last"] if self.wd == 0.0 else None, self._plans[name])
+                          for name in lazy}
             elif lazy and self.wd == 0.0:
                 # rows of the next batch that have any optimizer history at all: the catch-up at the tail of this step only walks those
                 # (a row first touched by the step in flight is missed here and needs no catch-up: its update leaves it current)
@@ -174,7 +179,7 @@ class SparseDenseAdam:
             ev.record(self._side)
         # keep ids + workspaces alive until the plan is adopted (the side stream reads / writes them asynchronously)
         # (and the in-flight step's plans: the catch-up reads their row lists after step() has dropped them)
-        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev, (req, bufs, dict(self._plans)), None, filtered)
+        self._prefetched = (self._ids_key(item_seq, item_id, user_id), plans, ev, (req, bufs, dict(self._plans)), None, filtered, splits)
 
     def plan_batch(self, item_seq=None, item_id=None, user_id=None):
         """Sort/unique the ids this batch will look up (or adopt the plan `prefetch_plan` made for the same tensors);
@@ -201,7 +206,7 @@ class SparseDenseAdam:
                 if st["last"] is not None:
                     ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
 
-    def _catchup_prefetched(self):
+    def _catchup_prefetched(self, rode=()):
         """step(), after the row update: the NEXT batch's rows (plan already made by `prefetch_plan`) take their zero-gradient steps
         up to and including this one now, on the main stream, while the dense-gradient reductions are still running on the side
         stream -- the same launch `plan_batch` would make at the head of the next step, moved into a slot where the main stream
@@ -210,12 +215,14 @@ class SparseDenseAdam:
         if pre is None or self.table_mode != "lazy_dense" or pre[4] is not None:
             return
         cur = torch.cuda.current_stream()
-        cur.wait_event(pre[2])
+        pw = getattr(self, "_pre_waited", None)
+        if pw is None or pw[0] is not pre[2] or pw[1] != cur.cuda_stream:
+            cur.wait_event(pre[2])
         self._pre_waited = (pre[2], cur.cuda_stream)   # (the event object itself: an id() could be re-used by the next plan's event)
         cfg = self._cfg(self.t + 1)
         for name, pl in pre[1].items():
             st = self.tables[name]
-            if st["last"] is not None:
+            if st["last"] is not None and name not in rode:     # (rode: replayed inside this step's fused reduce + update launch)
                 if pre[5] is not None and name in pre[5]:
                     pl = pre[5][name]
                 ops.lazy_adam_catchup(cfg, st["w"], st["m"], st["v"], st["last"], pl)
@@ -270,7 +277,7 @@ class SparseDenseAdam:
         dense_side = self._dense_side or ("late" if late_join else "join")
         self.t += 1
         cfg = self._cfg(self.t)
-        reduced = {}
+        reduced, rode = {}, set()
         guard = getattr(model, "loss_guard", None)
         for name, st in self.tables.items():
             ids_a, rows, ids_b, coef, vec, G = self._collect(name)
@@ -284,7 +291,17 @@ class SparseDenseAdam:
             d = st["w"].shape[1]
             if self._fused_update and self.grad_clip is None and name not in model.dense_table_grads:
                 # nothing needs this table's row gradients between the reduction and the update: one launch, the sums stay on chip
-                ops.rows_reduce_update(cfg, st["w"], st["m"], st["v"], pl, rows, coef, vec, G, st["last"], guard)
+                split = None
+                pre = self._prefetched
+                if pre is not None and pre[4] is None and pre[6] and name in pre[6] and st["last"] is not None:
+                    cur = torch.cuda.current_stream()    # the next batch's replay lists were made on the plan stream
+                    pw = getattr(self, "_pre_waited", None)
+                    if pw is None or pw[0] is not pre[2] or pw[1] != cur.cuda_stream:
+                        cur.wait_event(pre[2])
+                        self._pre_waited = (pre[2], cur.cuda_stream)
+                    split = pre[6][name]
+                    rode.add(name)
+                ops.rows_reduce_update(cfg, st["w"], st["m"], st["v"], pl, rows, coef, vec, G, st["last"], guard, next_split=split)
                 continue
             reduced[name] = (pl, ops.rows_reduce(pl, rows, coef, vec, G, d, zero_tail=self.grad_clip is not None))
         # fullsoftmax: the table's gradient is dense; the encoder's row-sparse part is folded into it
@@ -304,7 +321,7 @@ class SparseDenseAdam:
                 st = self.tables[name]
                 ops.sparse_adam_rows(cfg, st["w"], st["m"], st["v"], pl, ug, st["last"], scale)
             sparse_done = True
-            self._catchup_prefetched()
+            self._catchup_prefetched(rode)
         side = None
         if (self.grad_clip is None and dense_side in ("late", "join") and getattr(model, "_deferred_dense_grad", None) is not None
                 and model._deferred_dense_grad.numel()):

@@ -559,14 +559,18 @@ def sparse_adam_rows(cfg, table, m, v, pl: RowsPlan, uniq_grad, last_step=None, 
                                   _p(uniq_grad), table.shape[1], _p(grad_scale), _stream()), "ur_sparse_adam_rows")
 
 
-def rows_reduce_update(cfg, table, m, v, pl: RowsPlan, rows_a, coef_b, vec_b, G, last_step=None, grad_scale=None):
-    """rows_reduce + sparse_adam_rows in one launch (ur_rows_reduce_update): no row-gradient tensor comes out"""
+def rows_reduce_update(cfg, table, m, v, pl: RowsPlan, rows_a, coef_b, vec_b, G, last_step=None, grad_scale=None, next_split=None):
+    """rows_reduce + sparse_adam_rows in one launch (ur_rows_reduce_update): no row-gradient tensor comes out.
+    next_split: rows_split_hot(next batch's plan, last_step, excl=pl) -- its lazy replay rides in the launch too"""
+    cold, hot = next_split if next_split is not None else (None, None)
     _chk(table, torch.float32, "table"); _chk(last_step, torch.int32, "last_step", allow_none=True)
     _chk(rows_a, torch.float32, "rows_a", allow_none=True); _chk(coef_b, torch.float32, "coef_b", allow_none=True)
     _chk(vec_b, torch.float32, "vec_b", allow_none=True)
     check(lib.ur_rows_reduce_update(_p(pl.uniq_idx), _p(pl.seg_start), _p(pl.sorted_pos), _p(pl.n_uniq), pl.n, _p(rows_a), pl.n_a, _p(coef_b),
                                     _p(vec_b), int(G), table.shape[1], C.byref(cfg), _p(table), _p(m), _p(v), _p(last_step), _p(grad_scale),
-                                    _stream()), "ur_rows_reduce_update")
+                                    _p(cold.uniq_idx) if cold is not None else None, _p(cold.n_uniq) if cold is not None else None,
+                                    _p(hot.uniq_idx) if hot is not None else None, _p(hot.n_uniq) if hot is not None else None,
+                                    int(cold.n if cold is not None else (hot.n if hot is not None else 0)), _stream()), "ur_rows_reduce_update")
 
 
 def rows_reduce_update_owner(cfg, table, m, v, pl: RowsPlan, recv_rows, world, cap, step_flags_out4, last_step=None):
