@@ -35,7 +35,7 @@ RUNGS = [
 ]
 # seconds a phase may take before the rank group is aborted (x UR_BENCH_TIMEOUT_SCALE).  Generous: the first `import torch` on a fresh box
 # pages the image in for 1-2 minutes, a 100 M-row table plus optimizer state is ~150 GB of fills, RCCL's first communicator takes seconds
-LIMITS = {"start": 420.0, "init": 300.0, "setup": 600.0, "selfcheck": 420.0, "warmup": 240.0, "timed": 240.0, "post": 600.0}
+LIMITS = {"start": 300.0, "init": 180.0, "setup": 420.0, "selfcheck": 300.0, "warmup": 180.0, "timed": 180.0, "post": 420.0}
 PHASES = list(LIMITS)
 
 
