@@ -564,178 +564,6 @@ __global__ __launch_bounds__(256) void gemm_tn_group_kernel(TnGroup g, const flo
   }
 }
 
-// ---- round 5: the same products on 128 x 128 output tiles with the operands DMA'd straight into LDS (gemm_tn_big_kernel).
-// Why: at 64 x 64 a workgroup pulls 16 KB per 32-token stage for 1024 MFMA cycles per SIMD -- 16 B/clk/CU at the MFMA peak, 525 MB of
-// operand traffic through L2 for the bottom layer's four products, and the staging pass (2 x float4 through VGPRs, the activation,
-// ds_write_b128) shares the issue slots with the MFMAs (pipes 0.49 busy alone).  A 128 x 128 tile halves the bytes per flop (32 KB per
-// 4096 MFMA cycles = 8 B/clk/CU; every token row of P is read by ONE workgroup, of Q by R / 128), `global_load_lds_dwordx4` takes the
-// staging out of the instruction stream altogether (the LDS image is the global one: [token][128 columns], and the 32x32x2 fragments
-// -- 32 consecutive floats of one token row per half-wave -- read it conflict-free as it lies), the activation of the dW_2 operand is
-// applied to the B fragments behind the LDS read, the bias gradient is summed from the A fragments.
-//   workgroup = 4 waves (2 x 2), wave = 64 x 64 of the tile = four 32 x 32 accumulators (64 VGPRs); stage = 32 tokens x (128 + 128)
-//   columns = 32 KB, a ring of three (96 KB of dynamic LDS = ONE workgroup per CU), the DMA two stages ahead of the MFMAs behind a counted
-//   vmcnt and a raw s_barrier; one barrier per stage (4096 MFMA cycles).
-// Taken when every product of the group has R % 128 == 0 and Cc % 128 == 0 (d = 128-class shapes; UR_TN_BIG=0 keeps the 64 x 64 kernel).
-constexpr int BT = 128;    // output tile edge
-constexpr int BTK = 32;    // tokens per stage
-constexpr int BTB = 3;     // stages in the LDS ring (96 KB: ONE workgroup per CU -- see the launcher)
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-struct TnBigCtx {
-  const float *Pg, *Qg, *zero_row;   // this lane's column of the P / Q tile (token row 0); a few zero floats
-  long long ldp, ldq;
-  int t_begin, t_end, nt, wave, hi, qrow, pa, qa;
-};
-// the stages of one workgroup: the LDS-DMA of stage s + 1 is issued in front of the MFMAs of stage s (one barrier per stage; hipcc drains
-// the DMA queue -- vmcnt(0) -- in front of a barrier while an LDS-DMA is in flight, and nowhere else in the loop).  ACT: the activation
-// applied to the B fragments (dW_2 = g^T act(h1)); one instantiation per activation so that the accumulators live in ONE register set.
-// BC: columns of the output tile (128, or 64: three quarters of the operand bytes per flop of the 64 x 64 kernel instead of half, 72 KB of
-// LDS = two workgroups per CU instead of one)
-template <int ACT, int BC>
-__device__ __forceinline__ void tn_big_run(const TnBigCtx& c, float* smem, floatx16 (&acc)[2][BC / 64], float& bs0, float& bs1) {
-  constexpr int STG = BTK * (BT + BC);       // floats per stage
-  constexpr int QR = 256 / BC;               // token rows of the Q tile one wave instruction (64 lanes x 16 B) brings
-  constexpr int QI = BTK / QR / 4;           // Q instructions per wave and stage
-  constexpr int NJ = BC / 64;                // 32-column accumulator tiles per wave along the columns
-  auto issue = [&](int buf, int t0) {
-    float* Pl = smem + buf * STG;
-    float* Ql = Pl + BTK * BT;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = c.wave + 4 * i;   // one wave instruction = two token rows of the P tile
-      const int t = t0 + 2 * piece + c.hi;
-      const float* ps = t < c.t_end ? c.Pg + t * c.ldp : c.zero_row;
-      __builtin_amdgcn_global_load_lds((gptr_t)ps, (lptr_t)(Pl + piece * 2 * BT), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < QI; ++i) {
-      const int piece = c.wave + 4 * i;
-      const int t = t0 + QR * piece + c.qrow;
-      const float* qs = t < c.t_end ? c.Qg + t * c.ldq : c.zero_row;
-      __builtin_amdgcn_global_load_lds((gptr_t)qs, (lptr_t)(Ql + piece * QR * BC), 16, 0, 0);
-    }
-  };
-  // ring of BTB stages, the DMA runs two stages ahead: 4 + QI pieces per thread and stage, so "stage s + 1 has landed" = at most the
-  // pieces of stage s + 2 still in flight.  Raw s_barrier + counted vmcnt: __syncthreads() would drain the whole queue
-  if (c.nt > 0) issue(0, c.t_begin);
-  if (c.nt > 1) issue(1, c.t_begin + BTK);
-  if (c.nt > 1) { if (QI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  int buf = 0;
-  for (int s_ = 0; s_ < c.nt; ++s_) {
-    const bool more = s_ + 2 < c.nt;
-    if (more) issue(buf >= 1 ? buf - 1 : BTB - 1, c.t_begin + (s_ + 2) * BTK);   // (buf + 2) % 3: the buffer stage s - 1 was read from
-    const float* Pb = smem + buf * STG + c.pa;
-    const float* Qb = smem + buf * STG + c.qa;
-    float a0 = Pb[0], a1 = Pb[32], b0 = Qb[0], b1 = NJ == 2 ? Qb[32] : 0.f;
-#pragma unroll
-    for (int kk = 0; kk < BTK / 2; ++kk) {
-      float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
-      if (kk + 1 < BTK / 2) {   // the next step's fragments are requested in front of this step's MFMAs
-        a0n = Pb[(kk + 1) * 2 * BT]; a1n = Pb[(kk + 1) * 2 * BT + 32];
-        b0n = Qb[(kk + 1) * 2 * BC];
-        if (NJ == 2) b1n = Qb[(kk + 1) * 2 * BC + 32];
-      }
-      if (ACT != UR_ACT_NONE) { b0 = act_fwd(b0, ACT); if (NJ == 2) b1 = act_fwd(b1, ACT); }
-      bs0 += a0; bs1 += a1;
-      if (ACT == UR_ACT_NONE) __builtin_amdgcn_sched_barrier(0);   // (with an activation the scheduler spreads its VALU over the MFMAs itself)
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      if (NJ == 2) acc[0][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][NJ - 1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      if (NJ == 2) acc[1][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][NJ - 1], 0, 0, 0);
-      if (ACT == UR_ACT_NONE) __builtin_amdgcn_sched_barrier(0);
-      a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
-    }
-    if (more) { if (QI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    buf = buf + 1 < BTB ? buf + 1 : 0;
-  }
-}
-
-template <int BC>
-__global__ __launch_bounds__(256) void gemm_tn_big_kernel(TnGroup g, const float* __restrict__ zero_row, int total, int per_xcd) {
-  // Workgroup order w = product-major, then token split, then tile: the tiles of one (product, split) -- which share the split's token
-  // rows of one operand -- are neighbours.  XCD x (= blockIdx % 8) takes the CHUNK w in [x * per_xcd, (x + 1) * per_xcd): every XCD must
-  // get the same number of workgroups (profiles/r05_a_tn_big_insitu_v2.txt)
-  constexpr int NJ = BC / 64;
-  const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per_xcd || w >= total) return;
-  int j = 0;
-  while (j + 1 < g.n && w >= g.item[j + 1].first_block) ++j;
-  const TnItem& it = g.item[j];
-  const int local = w - it.first_block, ntiles = it.ntr * it.ntc, S = it.S;
-  const int sp = local / ntiles, tile = local % ntiles;
-  int T = it.T;
-  if (it.t_dev) T = min(T, *it.t_dev);
-  const int tps = (((T + S - 1) / S + BTK - 1) / BTK) * BTK;
-  const int Cc = it.Cc, R = it.R;
-  const int r0 = (tile / it.ntc) * BT, c0 = (tile % it.ntc) * BC;
-  const bool want_bias = (it.bias_part != nullptr || (S == 1 && it.bias_out != nullptr)) && (tile % it.ntc) == 0;
-
-  extern __shared__ __attribute__((aligned(16))) float smem_big[];   // [BTB][P: 32 tokens x 128 | Q: 32 tokens x BC]; epilogue: Cs[128][BC]
-  float* smem = smem_big;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-  const int hi = lane >> 5, fcol = lane & 31;
-  TnBigCtx c;
-  c.Pg = it.P + r0 + fcol * 4; c.Qg = it.Q + c0 + (lane % (BC / 4)) * 4; c.zero_row = zero_row; c.ldp = it.ldp; c.ldq = it.ldq;
-  c.t_begin = sp * tps; c.t_end = min(T, c.t_begin + tps); c.nt = (c.t_end - c.t_begin + BTK - 1) / BTK;
-  c.wave = wave; c.hi = hi; c.qrow = lane / (BC / 4);
-  c.pa = hi * BT + wr * 64 + fcol; c.qa = BTK * BT + hi * BC + wc * (BC / 2) + fcol;
-  floatx16 acc[2][NJ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
-  float bs0 = 0.f, bs1 = 0.f;
-  switch (it.pro_act ? it.act : UR_ACT_NONE) {   // (wave-uniform, once per workgroup)
-    case UR_ACT_GELU: tn_big_run<UR_ACT_GELU, BC>(c, smem, acc, bs0, bs1); break;
-    case UR_ACT_RELU: tn_big_run<UR_ACT_RELU, BC>(c, smem, acc, bs0, bs1); break;
-    case UR_ACT_SWISH: tn_big_run<UR_ACT_SWISH, BC>(c, smem, acc, bs0, bs1); break;
-    case UR_ACT_TANH: tn_big_run<UR_ACT_TANH, BC>(c, smem, acc, bs0, bs1); break;
-    case UR_ACT_SIGMOID: tn_big_run<UR_ACT_SIGMOID, BC>(c, smem, acc, bs0, bs1); break;
-    default: tn_big_run<UR_ACT_NONE, BC>(c, smem, acc, bs0, bs1); break;
-  }
-  // ---- epilogue through LDS (the stages are done with it): coalesced float4 row stores of the (partial) tile
-  float* Cs = smem;
-  {
-    const int lrow4 = 4 * hi;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          Cs[(wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + lrow4) * BC + wc * (BC / 2) + jj * 32 + fcol] = acc[i][jj][r];
-  }
-  __syncthreads();
-  const bool direct = S == 1;
-  float* out = direct ? it.out : it.part + (long long)sp * R * Cc;
-  const int ldo = direct ? it.ldo : Cc;
-  {
-    constexpr int C4 = BC / 4, RPP = 256 / C4;
-    const int c4 = tid % C4, row0 = tid / C4;
-#pragma unroll 4
-    for (int k = 0; k < BT / RPP; ++k) {
-      const int rl = row0 + RPP * k;
-      *(float4*)(out + (long long)(r0 + rl) * ldo + c0 + c4 * 4) = *(const float4*)(Cs + rl * BC + c4 * 4);
-    }
-  }
-  if (want_bias && wc == 0) {   // the two token parities of a row sit 32 lanes apart
-    bs0 += __shfl_xor(bs0, 32, 64);
-    bs1 += __shfl_xor(bs1, 32, 64);
-    if (hi == 0) {
-      float* bo = direct ? it.bias_out : it.bias_part + (long long)sp * R;
-      bo[r0 + wr * 64 + fcol] = bs0;
-      bo[r0 + wr * 64 + 32 + fcol] = bs1;
-    }
-  }
-}
-
 // a few zero floats in device memory (per device, allocated once): what out-of-range token rows load
 static const float* tn_zero_buf() {
   static float* z[64] = {};
@@ -755,33 +583,14 @@ long long gemm_tn_group_ws_floats(int R, int Cc) { return (long long)TN_GROUP_SM
 
 // req[i].ws: gemm_tn_group_ws_floats(R, Cc) floats each (untouched until the deferred reduction has run).  defer == nullptr: the
 // reduction of the split products runs right behind the launch.
-// test hook tn_big (UR_TEST=tn_big=128 / tn_big=64): 128 x 128 / 128 x 64 tiles + LDS-DMA for groups whose products all have R a multiple of
-// 128 and Cc a multiple of the tile width; unset = the 64 x 64 kernel (the default: profiles/r05_a_*).  tn_target: workgroups a launch aims at
-static int tn_big_mode() {
-  static const int m = ur_test_hook("tn_big", 0);
-  return m;
-}
-static int tn_target(int dflt) {
-  static const int t = ur_test_hook("tn_target", 0);
-  return t > 0 ? t : dflt;
-}
-
 int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
   if (n <= 0) return UR_OK;
   if (n > TnGroup::MAX) return fail(UR_ERR_ARG, "gemm_tn_group: %d products (max %d)", n, TnGroup::MAX);
   const float* zeros = tn_zero_buf();
   if (!zeros) return fail(UR_ERR_HIP, "gemm_tn: no device memory for the zero row");
-  int bigc = tn_big_mode();      // 0, or the column width of the LDS-DMA kernel's tiles (128 / 64)
-  if (bigc != 0 && bigc != 64) bigc = 128;
-  for (int i = 0; i < n && bigc; ++i)
-    if ((req[i].R % BT) || (req[i].Cc % bigc)) bigc = 0;
-  const bool big = bigc != 0;
-  const int tile = big ? BT : GT, tile_c = big ? bigc : GT, stage = big ? BTK : GBT;
-  // workgroups per launch.  64 x 64 kernel (~3 per CU: 32 KB of LDS each), measured at C5 (profiles/r03_a_dw_schedule.txt): 288 -> 0.681
-  // ms/step, 576 -> 0.660, 864 -> 0.658, 1152+ -> 0.665 -- short workgroups give the CUs back to the main stream's kernels sooner.
-  // 128 x 128 kernel: ONE workgroup per CU (96 KB of LDS: the dispatcher otherwise packs two onto a CU while other CUs idle -- the two then
-  // share each SIMD's matrix pipe: 35 TF/s isolated against 77 for the 64 x 64 kernel, profiles/r05_a_tn_big.txt) and ~one per CU in the grid
-  const int target = tn_target(big ? (bigc == 64 ? 512 : 256) : 864);
+  // workgroups per launch (~3 per CU: 32 KB of LDS each).  Measured at C5 (profiles/r03_a_dw_schedule.txt): 288 -> 0.681 ms/step, 576 ->
+  // 0.660, 864 -> 0.658, 1152+ -> 0.665 -- short workgroups give the CUs back to the main stream's kernels sooner
+  constexpr int target = 864;
   TnGroup g{};
   g.n = n;
   double work = 0.0, flops = 0.0;
@@ -789,10 +598,10 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
     const TnReq& q = req[i];
     if ((q.R & 3) || (q.Cc & 3) || (q.ldp & 3) || (q.ldq & 3) || (q.ldo & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
     if (q.T <= 0) return fail(UR_ERR_ARG, "gemm_tn: T=%d", q.T);
-    work += (double)cdiv(q.R, tile) * cdiv(q.Cc, tile_c) * q.T;
+    work += (double)cdiv(q.R, GT) * cdiv(q.Cc, GT) * q.T;
     flops += 2.0 * q.T * q.R * q.Cc;
   }
-  const double rows_per = std::max(big ? 256.0 : 128.0, work / target);   // token rows one workgroup walks
+  const double rows_per = std::max(128.0, work / target);   // token rows one workgroup walks
   int blocks = 0;
   ReduceBatch local;
   ReduceBatch* rb = defer ? defer : &local;
@@ -800,30 +609,19 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
     const TnReq& q = req[i];
     TnItem& it = g.item[i];
     int S = (int)(q.T / rows_per + 0.5);
-    if (S > q.T / (2 * stage)) S = q.T / (2 * stage);
-    if (big) S = std::min(TN_GROUP_SMAX, S);   // (any S: the launch order is cut into eight equal XCD chunks)
-    else if (S >= 6) S = std::min(TN_GROUP_SMAX, (S + 4) / 8 * 8);
+    if (S > q.T / (2 * GBT)) S = q.T / (2 * GBT);
+    if (S >= 6) S = std::min(TN_GROUP_SMAX, (S + 4) / 8 * 8);
     if (S < 1) S = 1;
     it.P = q.P; it.Q = q.Q; it.ldp = q.ldp; it.ldq = q.ldq; it.T = q.T; it.t_dev = q.t_dev; it.R = q.R; it.Cc = q.Cc;
-    it.pro_act = q.pro_act; it.act = q.act; it.S = S; it.ntr = cdiv(q.R, tile); it.ntc = cdiv(q.Cc, tile_c);
+    it.pro_act = q.pro_act; it.act = q.act; it.S = S; it.ntr = cdiv(q.R, GT); it.ntc = cdiv(q.Cc, GT);
     it.out = q.out; it.bias_out = q.bias_out; it.ldo = q.ldo;
     it.part = q.ws; it.bias_part = q.bias_out ? q.ws + (long long)S * q.R * q.Cc : nullptr;
     it.first_block = blocks;
-    if (big) blocks += S * it.ntr * it.ntc;   // (first_block = the product's first workgroup in the launch order; XCD chunks: see the kernel)
-    else blocks += (S & 7) == 0 ? S * it.ntr * it.ntc : 8 * cdiv(S * it.ntr * it.ntc, 8);   // (every product starts on XCD 0)
+    blocks += (S & 7) == 0 ? S * it.ntr * it.ntc : 8 * cdiv(S * it.ntr * it.ntc, 8);   // (every product starts on XCD 0)
   }
   {
     ProfScope ps(PC_GEMM_TN, st, flops, true);   // (the launch's own timestamps: on the side stream a recorded bracket would hold the waits of every fork)
-    if (big) {
-      const int lds = BTB * BTK * (BT + bigc) * (int)sizeof(float);
-      static const bool attr = (hipFuncSetAttribute((const void*)gemm_tn_big_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, BTB * BTK * (BT + 128) * 4),
-                                hipFuncSetAttribute((const void*)gemm_tn_big_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, BTB * BTK * (BT + 64) * 4), true);
-      (void)attr;
-      const int per_xcd = cdiv(blocks, 8);
-      if (bigc == 128) { UR_LAUNCH_EV(gemm_tn_big_kernel<128>, dim3(8 * per_xcd), dim3(256), lds, st, g, zeros, blocks, per_xcd); }
-      else { UR_LAUNCH_EV(gemm_tn_big_kernel<64>, dim3(8 * per_xcd), dim3(256), lds, st, g, zeros, blocks, per_xcd); }
-    }
-    else { UR_LAUNCH_EV(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g, zeros); }
+    UR_LAUNCH_EV(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, st, g, zeros);
   }
   UR_LAUNCH_CHECK();
   for (int i = 0; i < n; ++i) {
