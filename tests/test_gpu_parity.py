@@ -265,6 +265,80 @@ def test_rows_reduce_update_equals_reduce_then_update(algo, wd, lazy):
                 assert torch.equal(b[0], w0) and torch.equal(b[1], m0) and (not lazy or torch.equal(b[3], last0))
 
 
+@pytest.mark.parametrize("skipped", [False, True])
+def test_replay_riding_in_the_fused_launch_equals_the_separate_catchup(skipped):
+    """ur_rows_reduce_update with the next batch's (cold, hot) lists == reduce + update + ur_lazy_adam_catchup over the next batch's plan, bit for
+    bit -- and when the step is skipped (scale < 0) nothing is updated but BOTH lists are replayed."""
+    from unirec_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(11)
+    n_rows, d = 4000, 128
+    ids_t = torch.from_numpy(rng.integers(1, n_rows, 3000).astype(np.int32)).to(dev)
+    ids_n = torch.from_numpy(rng.integers(1, n_rows, 3000).astype(np.int32)).to(dev)       # the next batch: ~half of its rows are in this one too
+    rows_a = torch.from_numpy(rng.standard_normal((3000, d)).astype(np.float32)).to(dev)
+    pl, pn = ops.rows_plan(ids_t, None, n_rows), ops.rows_plan(ids_n, None, n_rows)
+    w0 = torch.from_numpy(rng.standard_normal((n_rows, d)).astype(np.float32)).to(dev)
+    m0 = torch.from_numpy((0.1 * rng.standard_normal((n_rows, d))).astype(np.float32)).to(dev)
+    v0 = torch.from_numpy((0.01 * rng.random((n_rows, d))).astype(np.float32)).to(dev)
+    # (stamps >= 1: a never-updated row -- stamp 0, moments 0 -- is left out of the replay lists, its stamp stays 0 where the separate
+    # launch would write 31: the same state, nothing to replay either way)
+    last0 = torch.from_numpy(rng.integers(1, 30, n_rows).astype(np.int32)).to(dev)
+    scale = torch.tensor([-1.0 if skipped else 1.0], dtype=torch.float32, device=dev)
+    cfg, cfg_next = ops.adam_cfg(1e-2, 31, 0.0), ops.adam_cfg(1e-2, 32, 0.0)
+    a = [w0.clone(), m0.clone(), v0.clone(), last0.clone()]
+    ug = ops.rows_reduce(pl, rows_a, None, None, 1, d)
+    ops.sparse_adam_rows(cfg, a[0], a[1], a[2], pl, ug, a[3], scale)
+    ops.lazy_adam_catchup(cfg_next, a[0], a[1], a[2], a[3], pn)                            # the next batch's rows: through step 31
+    b = [w0.clone(), m0.clone(), v0.clone(), last0.clone()]
+    split = ops.rows_split_hot(pn, b[3], pl)
+    ops.rows_reduce_update(cfg, b[0], b[1], b[2], pl, rows_a, None, None, 1, b[3], scale, next_split=split)
+    for x, y, what in zip(a, b, ("w", "m", "v", "last")):
+        assert torch.equal(x, y), (skipped, what)
+    nxt = torch.unique(ids_n.long())
+    assert bool((b[3][nxt] == 31).all())                                                   # every row of the next batch is current
+    if skipped:
+        only_t = torch.unique(ids_t.long())
+        only_t = only_t[~torch.isin(only_t, nxt)]
+        assert torch.equal(b[0][only_t], w0[only_t]) and torch.equal(b[3][only_t], last0[only_t])   # this step's other rows: untouched
+
+
+def test_owner_side_fused_update_equals_riders_then_update():
+    """ur_rows_reduce_update_owner == ur_rows_reduce_riders(step_flags_out4) + ur_sparse_adam_rows on a received block of W source blocks whose
+    slot 0 carries the step's flags: same flags out, same tables; a NaN / overflow flag on any rank skips the update."""
+    from unirec_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(12)
+    W, cap, d, n_local = 4, 256, 128, 3000
+    for flags in ((0.0, 0.0), (1.0, 0.0), (0.0, 1.0)):
+        # received ids: per source block ascending local rows behind padding slots (slot 0 reserved); rows = their gradient rows
+        ids = np.zeros((W, cap), dtype=np.int32)
+        for q in range(W):
+            k = int(rng.integers(cap // 2, cap - 1))
+            ids[q, cap - k:] = np.sort(rng.choice(np.arange(1, n_local), k, replace=False))
+        recv = torch.from_numpy(rng.standard_normal((W * cap, d)).astype(np.float32)).to(dev)
+        for q in range(W):
+            recv[q * cap] = 0.0
+            recv[q * cap, 0], recv[q * cap, 1], recv[q * cap, 2], recv[q * cap, 3] = (flags[0] if q == 2 else 0.0), (flags[1] if q == 1 else 0.0), 0.25 * (q + 1), 1.0
+        own = ops.rows_plan(torch.from_numpy(ids.reshape(-1)).to(dev), None, n_local)
+        w0 = torch.from_numpy(rng.standard_normal((n_local, d)).astype(np.float32)).to(dev)
+        m0 = torch.from_numpy((0.1 * rng.standard_normal((n_local, d))).astype(np.float32)).to(dev)
+        v0 = torch.from_numpy((0.01 * rng.random((n_local, d))).astype(np.float32)).to(dev)
+        last0 = torch.from_numpy(rng.integers(0, 20, n_local).astype(np.int32)).to(dev)
+        cfg = ops.adam_cfg(1e-2, 21, 0.0)
+        a = [w0.clone(), m0.clone(), v0.clone(), last0.clone()]
+        out_a = torch.zeros(4, device=dev)
+        ug = ops.rows_reduce_riders(own, recv, None, None, 1, d, W, cap, step_flags_out4=out_a)
+        ops.sparse_adam_rows(cfg, a[0], a[1], a[2], own, ug, a[3], out_a[0:1])
+        b = [w0.clone(), m0.clone(), v0.clone(), last0.clone()]
+        out_b = torch.zeros(4, device=dev)
+        ops.rows_reduce_update_owner(cfg, b[0], b[1], b[2], own, recv, W, cap, out_b, b[3])
+        assert torch.equal(out_a.isnan(), out_b.isnan()) and torch.equal(out_a.nan_to_num(), out_b.nan_to_num()), (flags, out_a, out_b)
+        for x, y, what in zip(a, b, ("w", "m", "v", "last")):
+            assert torch.equal(x, y), (flags, what)
+        if flags != (0.0, 0.0):
+            assert float(out_b[0]) == -1.0 and torch.equal(b[0], w0)
+
+
 # ------------------------------------------------------------------------------------------ optimizer trajectory
 @pytest.mark.parametrize("name", ["g9_adam_wd0", "g9_adam_wd1e-6_clip"])
 def test_three_steps_match_reference_dense_adam(name):
