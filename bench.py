@@ -429,7 +429,7 @@ def e2e_leg(a, model, opt, device, steps):
     return {"ms_per_step": round(dt / steps * 1e3, 4), "examples_per_s": round(a.batch * steps / dt, 1), "steps": steps,
             "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 4), "real_token_fraction": round(float(real), 4), "negatives": a.negatives,
             "pipeline": "device-resident: ur_sample_negatives (uniform, history-rejecting) + ur_device_build_seq per step, inside the clock "
-                        "(DeviceBatchLoader: built on the loader's stream two batches ahead); history lengths as the headline's"}
+                        "(DeviceBatchLoader: built on the optimizer's plan stream two batches ahead); a recurring population of 100 K users: returning rows pay the lazy replay; history lengths as the headline's"}
 
 
 def trainer_fit_leg(a, device, steps=200):
