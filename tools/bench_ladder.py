@@ -121,7 +121,31 @@ def supervise(bench_py, argv, rank, world, out=sys.stdout):
         failed_flag = os.path.join(root, f"rung{k}.failed")
         verdict = os.path.join(root, f"rung{k}.verdict")
         env = dict(os.environ, **env_add)
-        env.update(MASTER_PORT=str(base_port + 101 + 7 * k), UR_BENCH_STATUS=status, UR_BENCH_RUNG=name, UR_BENCH_RUNG_INDEX=str(k),
+        # the workers' own rendezvous port: rank 0's supervisor asks the kernel for a free one and publishes it (a fixed offset from the
+        # launcher's port can be taken -- the rung would then fail in `init` for no fault of its own)
+        port_file = os.path.join(root, f"rung{k}.port")
+        port = base_port + 101 + 7 * k
+        if rank == 0:
+            try:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("", 0))
+                    port = sk.getsockname()[1]
+            except OSError:
+                pass
+            with open(port_file + ".tmp", "w") as f:
+                f.write(str(port))
+            os.replace(port_file + ".tmp", port_file)
+        else:
+            deadline = time.time() + 60.0
+            while not os.path.exists(port_file) and time.time() < deadline:
+                time.sleep(0.05)
+            try:
+                with open(port_file) as f:
+                    port = int(f.read().strip())
+            except (OSError, ValueError):
+                pass
+        env.update(MASTER_PORT=str(port), UR_BENCH_STATUS=status, UR_BENCH_RUNG=name, UR_BENCH_RUNG_INDEX=str(k),
                    MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"))
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # the children rendezvous among themselves (rank 0's child hosts the store)
         so_path = os.path.join(root, f"rung{k}.rank{rank}.stdout")
