@@ -276,6 +276,9 @@ typedef struct UrLossCfg {
   float tau;
   float score_clip;    /* <= 0: off */
   float ccl_w, ccl_m;
+  int32_t group_size;  /* 0: off.  > 0: the user-item-label row format (unirec/model/base/reco_abc.py:233-236): G == 1, one (user, item,
+                        * label) triple per row, every group_size consecutive rows are ONE score row of the loss; loss_rows then holds
+                        * B / group_size row losses.  ur_gather_dot_loss_fused_supported answers 0: call _fwd and _bwd. */
 } UrLossCfg;
 /* user_bias / item_bias / user_id may be NULL (bias off). label (int32 [B,G]) is required for BCE and
  * SOFTMAX. Outputs: scores [B,G]; loss_out[4] ([3] unused): [2] = update guard (1, or -1 when the loss is NaN), [0] = reduced loss (reduction=True), [1] = the mean's
@@ -589,6 +592,18 @@ int ur_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int l
                int act, const float* bias, const float* aux, int ldaux, const float* gamma, const float* beta, float eps,
                float* xhat, float* rstd, void* stream);
 int64_t ur_gemm_tn_workspace_floats(int T, int R, int Cc);
+/* n <= 12 such products in ONE launch (+ one deferred-reduction launch): how the encoders' backward passes issue the weight gradients
+ * queued at one fork (every product fills a share of the chip; csrc/sasrec.hip).  Arrays of n; bias_out / pro_act_on_q nullable. */
+int ur_gemm_tn_group(int n, const float* const* P, const int* ldp, const float* const* Q, const int* ldq, const int* T, const int* R,
+                     const int* Cc, const int* pro_act_on_q, int act, float* const* out, const int* ldo, float* const* bias_out,
+                     float* const* ws, void* stream);
+/* Arithmetic of the dense fp32 contractions (process-wide; round 6).  0 = exact fp32-input MFMA (v_mfma_f32_32x32x2_f32, the default).
+ * 6 / 9 = every fp32 operand written as the EXACT sum of three bf16 pieces and the product accumulated in fp32 from the six (nine)
+ * piece products on v_mfma_f32_32x32x16_bf16 -- fp32-equivalent results (measured error vs fp64 in profiles/r06_*), 16x the matrix
+ * rate per instruction.  3 = a three-term split, NARROWER than fp32, for error studies only.  Replaces nothing in the reference: it is
+ * how torch's fp32 matmul (unirec/model/modules.py:285-287,312,347-355 and their autograd) is evaluated here. */
+int ur_set_mfma_arith(int terms);
+int ur_get_mfma_arith(void);
 int ur_gemm_tn(const float* P, int ldp, const float* Q, int ldq, int T, int R, int Cc, int pro_act_on_q, int act, float* out,
                int ldo, float* bias_out, float* ws, void* stream);
 

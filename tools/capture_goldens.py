@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("UR_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def _shims():
@@ -247,6 +247,35 @@ def main():
     out = run_model(m, batch)
     save("g8_mf_bpr_bias", **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}),
          **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
+
+    # ---------------------------------------------------------------- G8b / G5b: `user-item-label` rows (group_size > 0)
+    # ONE (user, item, label) triple per row; _cal_loss views the [rows] scores as [-1, group_size] (reco_abc.py:233-236).  Rows of a
+    # group share the user and the history, as the rank data sets deliver them -- except the last group, whose rows differ.
+    def group_rows_batch(rng_, n_groups, gs, L, n_items, n_users, two_positives):
+        b = make_batch(rng_, n_groups * gs, L, 2, n_items, n_users)
+        b["item_id"] = b["item_id"][:, 0].copy()
+        for gi in range(n_groups - 1):
+            for k in ("user_id", "item_seq", "item_seq_len"):
+                b[k][gi * gs:(gi + 1) * gs] = b[k][gi * gs]
+        lab = np.zeros((n_groups, gs), dtype=np.int32)
+        lab[:, 0] = 1
+        if two_positives:
+            lab[1, 3] = 1
+        b["label"] = lab.reshape(-1)
+        return b
+
+    for tag, cls, kw, two in (("g8_mf_grouprows_softmax", MF, dict(model="MF", has_user_emb=True, loss_type="softmax", tau=0.7), True),
+                              ("g8_mf_grouprows_bpr_bias", MF, dict(model="MF", has_user_emb=True, has_user_bias=True, has_item_bias=True,
+                                                                    loss_type="bpr"), False),
+                              ("g5_sasrec_grouprows_bce", SASRec, dict(model="SASRec", loss_type="bce"), True),
+                              ("g5_sasrec_grouprows_ccl", SASRec, dict(model="SASRec", loss_type="ccl", ccl_w=150, ccl_m=0.4), False)):
+        cfg = base_cfg(train_file_format="user-item-label", group_size=5, embedding_size=16, hidden_size=16, **kw)
+        torch.manual_seed(31)
+        m = cls(cfg)
+        batch = group_rows_batch(np.random.default_rng(77), 4, 5, cfg["max_seq_len"], cfg["n_items"], cfg["n_users"], two)
+        out = run_model(m, batch)
+        assert out["out.scores"].shape == (20,)
+        save(tag, **pack("cfg.", {k: np.array(v) for k, v in cfg.items()}), **pack("sd.", sd_np(m)), **pack("in.", batch), **out)
 
     # ---------------------------------------------------------------- G9 optimizer: 3 dense-Adam steps
     for tag, wd, clip in (("wd0", 0.0, None), ("wd1e-6_clip", 1e-6, 0.1)):
@@ -617,5 +646,82 @@ def capture_g3_g10():
     print("G10: %d steps, first %.6f last %.6f" % (len(losses), losses[0], losses[-1]))
 
 
+def capture_g10_gru_mf():
+    """G10 for the other two model families SURVEY.md 8(c) names: the reference's own Trainer.fit losses and final parameters for
+    GRU (tests/golden/g12_dataset) and for MF + BPR at BASELINE configs[0]'s shape (C1: ML-100K-shaped synthetic data written by
+    tests/ml100k_shaped.py, 943 users x 1 682 items, d = 64 per unirec/config/model/MF.yaml:2, batch 400, one epoch = 250 steps)."""
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    _shims()
+    import json
+    import logging
+    import accelerate
+    import ml100k_shaped
+    from unirec.data.dataset.basedataset import BaseDataset
+    from unirec.data.dataset.seqrecdataset import SeqRecDataset
+    from unirec.data.transform.adduserhistory import AddUserHistory
+    from unirec.facility.trainer import Trainer
+    from unirec.main import main as refmain
+    from unirec.model.cf.mf import MF
+    from unirec.model.sequential.gru import GRU
+    from unirec.utils.general import load_user_history
+
+    def fit(cfg, model, mk_loader, seed):
+        losses, orig = [], Trainer._check_nan
+
+        def rec(self, loss):
+            losses.append(float(loss.detach()))
+            return orig(self, loss)
+        Trainer._check_nan = rec
+        try:
+            tr = Trainer(cfg, model, accelerate.Accelerator(cpu=True))
+            tr.evaluate = lambda *a, **k: {cfg["key_metric"]: 0.0}
+            random.seed(seed)
+            tr.fit(mk_loader(), valid_data=None, save_model=False, verbose=2)
+        finally:
+            Trainer._check_nan = orig
+        return np.array(losses, dtype=np.float64)
+
+    common = dict(train_file_format="user-item", num_workers=0, n_sample_neg_train=4, shuffle_train=0, pin_memory=False,
+                  persistent_workers=False, use_features=0, time_seq=0, output_path="/tmp/g10_out", checkpoint_dir="ck", optimizer="adam",
+                  scheduler="off", scheduler_factor=0.1, weight_decay=0, use_tensorboard=0, use_wandb=0, freeze=0, early_stop=0,
+                  metrics="['hit@5']", key_metric="hit@5", verbose=0, task="train")
+    # ---- GRU on the small data set
+    ddir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g12_dataset")
+    info = json.load(open(os.path.join(ddir, "data.info")))
+    u2h, _ = load_user_history(ddir, "user_history", n_users=info["n_users"], format="user-item")
+    cfg = base_cfg(model="GRU", n_users=info["n_users"], n_items=info["n_items"], loss_type="bpr", max_seq_len=8, n_layers=1, dataset_path=ddir,
+                   batch_size=64, history_mask_mode="autoregressive", seq_last=0, dataloader="SeqRecDataset", learning_rate=2e-3,
+                   grad_clip_value=0.5, epochs=2, seed=23, **common)
+    logging.getLogger(cfg["exp_name"]).setLevel(logging.ERROR)
+    torch.manual_seed(34)
+    m = GRU(cfg)
+    sd0 = sd_np(m)
+    losses = fit(cfg, m, lambda: refmain.get_data_loader(cfg, "train", AddUserHistory, SeqRecDataset, ddir, "train", user2history=u2h), 23)
+    arrs = pack("cfg.", {k: (np.array(v) if not isinstance(v, (list, dict)) else np.array(str(v))) for k, v in cfg.items() if k != "dataset_path"})
+    arrs.update(pack("sd0.", sd0))
+    arrs.update(pack("sd1.", sd_np(m)))
+    arrs["step_losses"] = losses
+    save("g10_trainer_fit_gru", **arrs)
+    print("G10 GRU: %d steps, first %.6f last %.6f" % (len(losses), losses[0], losses[-1]))
+    # ---- MF + BPR at C1's shape
+    ddir = ml100k_shaped.write("/tmp/g10_ml100k_shaped")
+    u2h, _ = load_user_history(ddir, "user_history", n_users=ml100k_shaped.N_USERS, format="user-item")
+    cfg = base_cfg(model="MF", n_users=ml100k_shaped.N_USERS, n_items=ml100k_shaped.N_ITEMS, has_user_emb=True, loss_type="bpr", embedding_size=64,
+                   hidden_size=64, dataset_path=ddir, batch_size=400, history_mask_mode="unorder", seq_last=0, dataloader="BaseDataset",
+                   learning_rate=1e-3, grad_clip_value=-1, epochs=1, seed=25, **common)
+    m = MF(cfg)
+    sd0 = ml100k_shaped.initial_state()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd0.items()})
+    losses = fit(cfg, m, lambda: refmain.get_data_loader(cfg, "train", None, BaseDataset, ddir, "train", user2history=u2h), 25)
+    arrs = pack("cfg.", {k: (np.array(v) if not isinstance(v, (list, dict)) else np.array(str(v))) for k, v in cfg.items() if k != "dataset_path"})
+    arrs.update(pack("sd1_every8.", {k: v[::8].copy() for k, v in sd_np(m).items()}))      # (sd0 = ml100k_shaped.initial_state())
+    arrs["step_losses"] = losses
+    save("g10_trainer_fit_mf_c1", **arrs)
+    print("G10 MF C1: %d steps, first %.6f last %.6f" % (len(losses), losses[0], losses[-1]))
+
+
 if __name__ == "__main__" and (not ONLY or any(p in ("g3", "g10") for p in ONLY)):
     capture_g3_g10()
+if __name__ == "__main__" and (not ONLY or any(p.startswith("g10") for p in ONLY)):
+    capture_g10_gru_mf()

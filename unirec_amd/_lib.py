@@ -41,7 +41,8 @@ class UrAttHistCfg(C.Structure):
 
 class UrLossCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("G", C.c_int32), ("d", C.c_int32), ("loss_type", C.c_int32),
-                ("tau", C.c_float), ("score_clip", C.c_float), ("ccl_w", C.c_float), ("ccl_m", C.c_float)]
+                ("tau", C.c_float), ("score_clip", C.c_float), ("ccl_w", C.c_float), ("ccl_m", C.c_float),
+                ("group_size", C.c_int32)]
 
 
 class UrAdamCfg(C.Structure):
@@ -140,6 +141,9 @@ SIGNATURES = {
     "ur_gemm_nt": (C.c_int, [P, C.c_int, P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, C.c_int,
                              P, P, C.c_float, P, P, P]),
     "ur_gemm_tn_workspace_floats": (I64, [C.c_int, C.c_int, C.c_int]),
+    "ur_gemm_tn_group": (C.c_int, [C.c_int, P, P, P, P, P, P, P, P, C.c_int, P, P, P, P, P]),
+    "ur_set_mfma_arith": (C.c_int, [C.c_int]),
+    "ur_get_mfma_arith": (C.c_int, []),
     "ur_gemm_tn": (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),
     "ur_convformer_param_layout": (I64, [P, P]),
     "ur_convformer_workspace_bytes": (I64, [P]),

@@ -16,6 +16,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -564,6 +566,231 @@ __global__ __launch_bounds__(256) void gemm_tn_group_kernel(TnGroup g, const flo
   }
 }
 
+// ======================================================================================== gemm_tn on the bf16 matrix pipes
+// fp32-EQUIVALENT arithmetic on v_mfma_f32_32x32x16_bf16 (round 6).  Every fp32 operand value is written as the EXACT sum of three
+// bf16 pieces, x = x1 + x2 + x3 (truncation split: x1 = the upper 16 bits of x, x2 = the upper 16 bits of x - x1, x3 = x - x1 - x2, which
+// has at most 8 significant bits left: 3 x 8 = 24 mantissa bits), and the product sum_t p q is accumulated in fp32 from the SIX piece
+// products of order <= 2^-16 (p1q1, p1q2, p2q1, p2q2, p1q3, p3q1); the three dropped ones are <= 2^-24 relative, i.e. one fp32
+// rounding of the exact product.  Piece products are exact in fp32 (8 x 8 bits), a K = 16 instruction rounds the accumulator once where
+// the fp32-input MFMA rounds 8 times.  NTERM = 9 keeps all nine.  The bf16 pipe runs 16 x the fp32-input MFMA rate, so six
+// instructions cost 6/16 of the exact kernel's matrix time (ceiling 2500 / 6 = 417 TFLOP/s fp32-equivalent against 157.3).
+//   workgroup = 8 waves (2 x 4) on a 128 x 128 output tile, wave = 64 x 32 = two 32 x 32 accumulators; two 60 KB workgroups per CU =
+//   four waves per SIMD, so one workgroup's split (VALU) runs under the other's MFMAs;
+//   stage = 32 tokens x (128 + 128) features: wave w stages the 32-feature slab w of (P | Q): lane = (token group of four g = lane & 7,
+//   feature quad q = lane >> 3) loads 4 token rows x float4 (PF stages ahead), splits, and writes -- per feature and piece -- its 4
+//   tokens as one ds_write_b64: the LDS image is [operand][piece][feature][32 tokens] bf16, i.e. TOKEN-major inside a feature row, which
+//   is what the MFMA wants (lane l of an A / B fragment holds 8 consecutive k of row / column l & 31, k group l >> 5): every fragment is
+//   one ds_read_b128.  Rows are padded to 80 B: conflict-free for the b128 reads (16-lane groups: 20 l mod 64 distinct) and the b64
+//   writes (16-lane groups: 2 g + 80 q' dwords mod 32 distinct).
+//   Inf / NaN operands give NaN (inf - inf in the split), where the exact kernel may give inf: such a step is skipped either way.
+constexpr int ST = 128;    // output tile edge
+constexpr int SBT = 32;    // tokens per stage
+constexpr int SRS = 80;    // bytes per LDS row (32 bf16 + 16 B pad)
+constexpr int S_STAGE_BYTES = 6 * ST * SRS;   // 61 440 B
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// The body of one workgroup, specialised on the term count and on the activation applied to Q (ACT < 0: none): the hot loop then has no
+// data-dependent branch at all -- full stages only; a split's ragged last stage is peeled off and staged with clamped, zeroed rows.
+template <int NTERM, int ACT>
+__device__ __forceinline__ void tn_split_wg(const TnItem& it, const int sp, const int tile, const float* __restrict__ zero_row,
+                                            unsigned char* smem, long long* trace) {
+  int T = it.T;
+  if (it.t_dev) T = min(T, *it.t_dev);
+  const int S = it.S;
+  const int tps = (((T + S - 1) / S + SBT - 1) / SBT) * SBT;
+  const int t_begin = sp * tps, t_end = min(T, t_begin + tps);
+  const int R = it.R, Cc = it.Cc;
+  const int r0 = (tile / it.ntc) * ST, c0 = (tile % it.ntc) * ST;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
+  // ---- staging role: waves 0-3 stage P, 4-7 stage Q; a wave = a 32-feature slab; lane = (token group of four sg = lane & 7, feature
+  // quad lane >> 3): four token rows x float4 per stage
+  const int so = wave >> 2, sg = lane & 7, sf0 = (wave & 3) * 32 + (lane >> 3) * 4;
+  const int sdim = so ? Cc : R, sorg = so ? c0 : r0;
+  const bool fin = sorg + sf0 < sdim;
+  // a feature quad beyond the operand's width reads the zero row at stride 0: no select per load
+  const float* const sbase = fin ? (so ? it.Q : it.P) + sorg + sf0 : zero_row;
+  const long long sld = fin ? (so ? it.ldq : it.ldp) : 0;
+  const bool want_bias = so == 0 && (it.bias_part != nullptr || (S == 1 && it.bias_out != nullptr)) && (tile % it.ntc) == 0;
+  typedef float tfx4 __attribute__((ext_vector_type(4)));
+  tfx4 xa[4], xb[4];   // the stages in flight: loaded two stages before they are split
+  tfx4 bs = {0.f, 0.f, 0.f, 0.f};
+  const int n_tok = max(t_end - t_begin, 0);
+  const int nfull = n_tok / SBT, ntail = n_tok - nfull * SBT, nt = nfull + (ntail ? 1 : 0);
+  const float* sptr = sbase + (long long)(t_begin + 4 * sg) * sld;   // row of this lane's first token; moves by 32 rows a stage
+  const long long sstep = (long long)SBT * sld;
+  auto load_full = [&](tfx4 (&x)[4], int stage) {
+    const float* p0 = sptr + (long long)stage * sstep;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = *(const tfx4*)(p0 + (long long)i * sld);
+  };
+  auto load_tail = [&](tfx4 (&x)[4]) {   // the ragged last stage: rows clamped to the split's last token, zeroed behind it
+    const int t0 = t_begin + nfull * SBT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + 4 * sg + i;
+      x[i] = *(const tfx4*)(sbase + (long long)min(t, t_end - 1) * sld);
+      if (t >= t_end) x[i] = tfx4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  unsigned char* const sdst = smem + (so * 3 * ST + sf0) * SRS + sg * 8;
+  auto split_store = [&](tfx4 (&x)[4]) {
+    if (ACT >= 0 && so) {   // (wave-uniform) the activation of the FFN's hidden rows, recomputed as in gemm_tn_group_kernel
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[i][e] = act_fwd(x[i][e], ACT);
+    }
+    if (want_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bs += x[i];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // feature sf0 + e: four consecutive tokens -> 8 bytes per piece
+      float r[4], r2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = x[i][e] - __uint_as_float(__float_as_uint(x[i][e]) & 0xFFFF0000u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r2[i] = r[i] - __uint_as_float(__float_as_uint(r[i]) & 0xFFFF0000u);
+      u32x2 hi, mid, lo;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {   // (odd token's upper half | even token's upper half)
+        hi[h] = __builtin_amdgcn_perm(__float_as_uint(x[2 * h + 1][e]), __float_as_uint(x[2 * h][e]), 0x07060302u);
+        mid[h] = __builtin_amdgcn_perm(__float_as_uint(r[2 * h + 1]), __float_as_uint(r[2 * h]), 0x07060302u);
+        lo[h] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * h + 1]), __float_as_uint(r2[2 * h]), 0x07060302u);
+      }
+      *(u32x2*)(sdst + e * SRS) = hi;
+      *(u32x2*)(sdst + (ST + e) * SRS) = mid;
+      *(u32x2*)(sdst + (2 * ST + e) * SRS) = lo;
+    }
+  };
+  floatx16 acc[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  const unsigned char* const fa0 = smem + (wr * 64 + (lane & 31)) * SRS + (lane >> 5) * 16;
+  const unsigned char* const fb0 = smem + (3 * ST + wc * 32 + (lane & 31)) * SRS + (lane >> 5) * 16;
+  auto compute = [&]() {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 fa[2][3], fb[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fb[p] = *(const bf16x8*)(fb0 + (p * ST) * SRS + kb * 32);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) fa[m][p] = *(const bf16x8*)(fa0 + (p * ST + m * 32) * SRS + kb * 32);
+      }
+      // small terms first, the leading product last
+      constexpr int PA[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+      constexpr int PB[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int tm = 9 - NTERM; tm < 9; ++tm)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA[tm]], fb[PB[tm]], acc[m], 0, 0, 0);
+    }
+  };
+  int tr = 0;
+  auto stamp = [&]() {
+    if (trace && tid == 0 && tr < 62) trace[blockIdx.x * 64 + 2 + tr++] = (long long)__builtin_amdgcn_s_memtime();
+  };
+  // ---- prologue: stage 0 -> LDS; stages 1 and 2 on their way
+  stamp();
+  if (nfull > 0) {
+    load_full(xa, 0);
+    if (nfull > 1) load_full(xb, 1);
+    split_store(xa);
+    if (nfull > 2) load_full(xa, 2);
+  } else if (ntail) {
+    load_tail(xa);
+    split_store(xa);
+  }
+  __syncthreads();
+  stamp();
+  // ---- full stages, two per trip: stage s computes from LDS while s + 1 waits in registers (xb, then xa) and s + 2 / s + 3 are requested
+  int s_ = 0;
+  for (; s_ + 2 < nfull; s_ += 2) {
+    compute();
+    stamp();
+    __syncthreads();
+    split_store(xb);                                   // stage s + 1
+    if (s_ + 3 < nfull) load_full(xb, s_ + 3);
+    stamp();
+    __syncthreads();
+    compute();
+    __syncthreads();
+    split_store(xa);                                   // stage s + 2
+    if (s_ + 4 < nfull) load_full(xa, s_ + 4);
+    __syncthreads();
+    stamp();
+  }
+  // ---- the last one or two full stages and the ragged tail
+  if (s_ < nfull) {           // stage s_ is in LDS; s_ + 1 (if any) waits in xb
+    compute();
+    __syncthreads();
+    if (s_ + 1 < nfull) {
+      split_store(xb);
+      __syncthreads();
+      compute();
+      __syncthreads();
+    }
+    if (ntail) {
+      load_tail(xa);
+      split_store(xa);
+      __syncthreads();
+      compute();
+    }
+  } else if (nfull == 0 && ntail) {
+    compute();
+  }
+  stamp();
+  // ---- epilogue: a store instruction writes two 128-byte row pieces (lanes 0-31 | 32-63)
+  const bool direct = S == 1;
+  float* out = direct ? it.out : it.part + (long long)sp * R * Cc;
+  const int ldo = direct ? it.ldo : Cc;
+  const int c = c0 + wc * 32 + (lane & 31);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = r0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (rr < R && c < Cc) out[(long long)rr * ldo + c] = acc[m][r];
+    }
+  if (want_bias) {   // (wave-uniform: so == 0) column sums of P: the eight token groups of a feature quad are eight adjacent lanes
+    bs.x = group_sum<8>(bs.x); bs.y = group_sum<8>(bs.y); bs.z = group_sum<8>(bs.z); bs.w = group_sum<8>(bs.w);
+    if (sg == 0 && fin) {
+      float* bo = direct ? it.bias_out : it.bias_part + (long long)sp * R;
+      *(tfx4*)(bo + r0 + sf0) = bs;
+    }
+  }
+  stamp();
+  if (trace && tid == 0) { trace[blockIdx.x * 64] = tr; trace[blockIdx.x * 64 + 1] = nt; }
+}
+
+template <int NTERM>
+__global__ __launch_bounds__(512, 4) void gemm_tn_split_kernel(TnGroup g, const float* __restrict__ zero_row, long long* trace) {
+  int j = 0;
+  while (j + 1 < g.n && (int)blockIdx.x >= g.item[j + 1].first_block) ++j;
+  const TnItem& it = g.item[j];
+  const int local = blockIdx.x - it.first_block, ntiles = it.ntr * it.ntc, S = it.S;
+  int sp, tile;
+  if ((S & 7) == 0) {
+    const int xcd = local & 7, qid = local >> 3;
+    sp = (qid / ntiles) * 8 + xcd; tile = qid % ntiles;
+  } else { sp = local % S; tile = local / S; }
+  if (sp >= S || tile >= ntiles) return;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[S_STAGE_BYTES];
+  if (!it.pro_act) { tn_split_wg<NTERM, -1>(it, sp, tile, zero_row, smem, trace); return; }
+  switch (it.act) {   // (one specialised loop per activation: the workgroup runs exactly one of them)
+    case UR_ACT_GELU: tn_split_wg<NTERM, UR_ACT_GELU>(it, sp, tile, zero_row, smem, trace); break;
+    case UR_ACT_RELU: tn_split_wg<NTERM, UR_ACT_RELU>(it, sp, tile, zero_row, smem, trace); break;
+    case UR_ACT_SWISH: tn_split_wg<NTERM, UR_ACT_SWISH>(it, sp, tile, zero_row, smem, trace); break;
+    case UR_ACT_TANH: tn_split_wg<NTERM, UR_ACT_TANH>(it, sp, tile, zero_row, smem, trace); break;
+    case UR_ACT_SIGMOID: tn_split_wg<NTERM, UR_ACT_SIGMOID>(it, sp, tile, zero_row, smem, trace); break;
+    default: tn_split_wg<NTERM, -1>(it, sp, tile, zero_row, smem, trace); break;
+  }
+}
+
 // a few zero floats in device memory (per device, allocated once): what out-of-range token rows load
 static const float* tn_zero_buf() {
   static float* z[64] = {};
@@ -578,16 +805,114 @@ static const float* tn_zero_buf() {
   return z[dev];
 }
 
-constexpr int TN_GROUP_SMAX = 32;
-long long gemm_tn_group_ws_floats(int R, int Cc) { return (long long)TN_GROUP_SMAX * ((long long)R * Cc + R) + 64; }
+constexpr int TN_GROUP_SMAX = 32;         // token splits of a product, exact-fp32 kernel (64 x 64 tiles)
+constexpr int TN_SPLIT_SMAX = 48;         // ... split-bf16 kernel (128 x 128 tiles: a quarter of the tiles, so more splits fill the chip)
+long long gemm_tn_group_ws_floats(int R, int Cc) { return (long long)TN_SPLIT_SMAX * ((long long)R * Cc + R) + 64; }
 
 // req[i].ws: gemm_tn_group_ws_floats(R, Cc) floats each (untouched until the deferred reduction has run).  defer == nullptr: the
 // reduction of the split products runs right behind the launch.
+// ---- which arithmetic the weight-gradient products run in: 0 = exact fp32 MFMA (the default), 6 / 9 = bf16x6 / bf16x9 split on the
+// bf16 pipes (fp32-equivalent; gemm_tn_split_kernel), 3 = a three-term split (NARROWER than fp32: error studies only).
+// Initial value: test hook tn_split=<n>; ur_set_mfma_arith overrides it.
+static std::atomic<int> g_mfma_arith{-1};
+int mfma_arith() {
+  int m = g_mfma_arith.load(std::memory_order_relaxed);
+  if (m < 0) {
+    m = ur_test_hook("tn_split", 0);
+    if (m != 3 && m != 6 && m != 9) m = 0;
+    g_mfma_arith.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+int set_mfma_arith(int m) {
+  if (m != 0 && m != 3 && m != 6 && m != 9) return fail(UR_ERR_ARG, "mfma_arith: %d (0 = exact fp32, 6 / 9 = split bf16 terms)", m);
+  g_mfma_arith.store(m, std::memory_order_relaxed);
+  return UR_OK;
+}
+
+static int gemm_tn_group_split(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer, int nterm, const float* zeros) {
+  // two 60 KB workgroups per CU; a workgroup should walk >= 8 stages between its cold prologue and its 64 KB partial-tile store
+  const int target = ur_test_hook("tn_split_target", 512);
+  TnGroup g{};
+  g.n = n;
+  double work = 0.0, flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const TnReq& q = req[i];
+    if ((q.R & 3) || (q.Cc & 3) || (q.ldp & 3) || (q.ldq & 3) || (q.ldo & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
+    if (q.T <= 0) return fail(UR_ERR_ARG, "gemm_tn: T=%d", q.T);
+    work += (double)cdiv(q.R, ST) * cdiv(q.Cc, ST) * q.T;
+    flops += 2.0 * q.T * q.R * q.Cc;
+  }
+  const double rows_per = std::max(256.0, work / target);
+  int blocks = 0;
+  ReduceBatch local;
+  ReduceBatch* rb = defer ? defer : &local;
+  for (int i = 0; i < n; ++i) {
+    const TnReq& q = req[i];
+    TnItem& it = g.item[i];
+    int S = (int)(q.T / rows_per + 0.5);
+    if (S > q.T / (2 * SBT)) S = q.T / (2 * SBT);
+    if (S >= 6) S = std::min(TN_SPLIT_SMAX, (S + 4) / 8 * 8);
+    if (S < 1) S = 1;
+    it.P = q.P; it.Q = q.Q; it.ldp = q.ldp; it.ldq = q.ldq; it.T = q.T; it.t_dev = q.t_dev; it.R = q.R; it.Cc = q.Cc;
+    it.pro_act = q.pro_act; it.act = q.act; it.S = S; it.ntr = cdiv(q.R, ST); it.ntc = cdiv(q.Cc, ST);
+    it.out = q.out; it.bias_out = q.bias_out; it.ldo = q.ldo;
+    it.part = q.ws; it.bias_part = q.bias_out ? q.ws + (long long)S * q.R * q.Cc : nullptr;
+    it.first_block = blocks;
+    blocks += (S & 7) == 0 ? S * it.ntr * it.ntc : 8 * cdiv(S * it.ntr * it.ntc, 8);
+  }
+  {
+    ProfScope ps(PC_GEMM_TN, st, flops, true);
+    long long* trace = nullptr;
+    static const int want_trace = ur_test_hook("tn_split_trace", 0);
+    static long long* trace_buf = nullptr;
+    if (want_trace) {
+      if (!trace_buf && hipMalloc((void**)&trace_buf, 4096 * 64 * sizeof(long long)) != hipSuccess) trace_buf = nullptr;
+      trace = blocks <= 4096 ? trace_buf : nullptr;
+    }
+    if (nterm == 9) { UR_LAUNCH_EV(gemm_tn_split_kernel<9>, dim3(blocks), dim3(512), 0, st, g, zeros, trace); }
+    else if (nterm == 3) { UR_LAUNCH_EV(gemm_tn_split_kernel<3>, dim3(blocks), dim3(512), 0, st, g, zeros, trace); }
+    else { UR_LAUNCH_EV(gemm_tn_split_kernel<6>, dim3(blocks), dim3(512), 0, st, g, zeros, trace); }
+    if (trace && want_trace == 2) {   // debugging aid: print the phase stamps of a few workgroups of THIS launch
+      static int printed = 0;
+      if (printed++ == 3 && hipStreamSynchronize(st) == hipSuccess) {
+        std::vector<long long> h((size_t)blocks * 64);
+        if (hipMemcpy(h.data(), trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+          long long t0 = -1, t1 = 0;
+          for (int b = 0; b < blocks; ++b) if (h[b * 64] > 0) { if (t0 < 0 || h[b * 64 + 2] < t0) t0 = h[b * 64 + 2]; t1 = std::max(t1, h[b * 64 + 1 + h[b * 64]]); }
+          fprintf(stderr, "tn_split trace: %d workgroups, first stamp -> last stamp %lld ticks\n", blocks, t1 - t0);
+          for (int b = 0; b < blocks; b += std::max(1, blocks / 12)) {
+            const int n = (int)h[b * 64];
+            fprintf(stderr, "  wg %4d nt %2lld start %7lld :", b, h[b * 64 + 1], h[b * 64 + 2] - t0);
+            for (int k = 1; k < n; ++k) fprintf(stderr, " %lld", h[b * 64 + 2 + k] - h[b * 64 + 2 + k - 1]);
+            fprintf(stderr, "\n");
+          }
+        }
+      }
+    }
+  }
+  UR_LAUNCH_CHECK();
+  for (int i = 0; i < n; ++i) {
+    const TnItem& it = g.item[i];
+    if (it.S == 1) continue;
+    const long long ne = (long long)it.R * it.Cc;
+    if (rb->full(2)) {
+      int rc = reduce_batch(*rb, st);
+      if (rc) return rc;
+    }
+    rb->add(it.part, ne, it.S, ne, it.Cc, it.out, it.ldo);
+    if (it.bias_out) rb->add(it.bias_part, it.R, it.S, it.R, it.R, it.bias_out, it.R);
+  }
+  if (!defer) return reduce_batch(local, st);
+  return UR_OK;
+}
+
 int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
   if (n <= 0) return UR_OK;
   if (n > TnGroup::MAX) return fail(UR_ERR_ARG, "gemm_tn_group: %d products (max %d)", n, TnGroup::MAX);
   const float* zeros = tn_zero_buf();
   if (!zeros) return fail(UR_ERR_HIP, "gemm_tn: no device memory for the zero row");
+  if (const int arith = mfma_arith()) return gemm_tn_group_split(req, n, st, defer, arith, zeros);
   // workgroups per launch (~3 per CU: 32 KB of LDS each).  Measured at C5 (profiles/r03_a_dw_schedule.txt): 288 -> 0.681 ms/step, 576 ->
   // 0.660, 864 -> 0.658, 1152+ -> 0.665 -- short workgroups give the CUs back to the main stream's kernels sooner
   constexpr int target = 864;
@@ -797,3 +1122,21 @@ extern "C" int ur_gemm_tn(const float* P, int ldp, const float* Q, int ldq, int 
   UR_REQUIRE(P && Q && out && ws, UR_ERR_ARG, "ur_gemm_tn: null pointer");
   return ur::gemm_tn(P, ldp, Q, ldq, T, R, Cc, pro_act_on_q, act, out, ldo, bias_out, ws, ur::as_stream(stream));
 }
+extern "C" int ur_gemm_tn_group(int n, const float* const* P, const int* ldp, const float* const* Q, const int* ldq, const int* T,
+                                const int* R, const int* Cc, const int* pro_act_on_q, int act, float* const* out, const int* ldo,
+                                float* const* bias_out, float* const* ws, void* stream) {
+  UR_TRACE_SCOPE();
+  UR_REQUIRE(n > 0 && n <= 12 && P && ldp && Q && ldq && T && R && Cc && out && ldo && ws, UR_ERR_ARG, "ur_gemm_tn_group: bad argument (1 <= n <= 12)");
+  ur::TnReq rq[12];
+  for (int i = 0; i < n; ++i) {
+    UR_REQUIRE(P[i] && Q[i] && out[i] && ws[i], UR_ERR_ARG, "ur_gemm_tn_group: null pointer in product %d", i);
+    rq[i] = ur::TnReq{P[i], ldp[i], Q[i], ldq[i], T[i], R[i], Cc[i], pro_act_on_q ? pro_act_on_q[i] : 0, act, out[i], ldo[i],
+                      bias_out ? bias_out[i] : nullptr, ws[i], nullptr};
+  }
+  return ur::gemm_tn_group(rq, n, ur::as_stream(stream));
+}
+extern "C" int ur_set_mfma_arith(int terms) {
+  UR_TRACE_SCOPE();
+  return ur::set_mfma_arith(terms);
+}
+extern "C" int ur_get_mfma_arith(void) { return ur::mfma_arith(); }

@@ -112,6 +112,9 @@ struct TnReq {
 };
 long long gemm_tn_group_ws_floats(int R, int Cc);
 int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer = nullptr);
+// arithmetic of the dense contractions: 0 = exact fp32 MFMA, 6 / 9 = split-bf16 terms (fp32-equivalent), 3 = error studies only
+int mfma_arith();
+int set_mfma_arith(int terms);
 // dst[c,r] = src[r,c]
 int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
 struct TransposeItem { const float* src; float* dst; int rows, cols, first_block; };

@@ -31,6 +31,47 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return s;
 }
 
+// ---- the loss of ONE score row sc[0..G) (LDS; tau and the clip applied): numerator `part` and denominator share `cnt` of the batch mean
+// (AbstractRecommender._cal_loss, unirec/model/base/reco_abc.py:238-266; modules.py:15-67).  Every thread of the workgroup calls it.
+__device__ __forceinline__ void row_loss(const UrLossCfg& c, const int G, const float* sc, const int* __restrict__ label, float* red,
+                                         float& part, float& cnt) {
+  part = 0.f; cnt = 0.f;
+  if (c.loss_type < 0) {  // UR_LOSS_NONE: scores only
+    cnt = 1.f;
+  } else if (c.loss_type == UR_LOSS_BPR) {
+    const float s0 = sc[0];
+    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) part += -logf(kEps + 1.0f / (1.0f + expf(-(s0 - sc[g]))));
+    part = block_sum(part, red) / (float)(G - 1);
+    cnt = 1.f;
+  } else if (c.loss_type == UR_LOSS_SOFTMAX) {
+    float m = -INFINITY;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) m = fmaxf(m, sc[g]);
+    m = block_max(m, red);
+    float l = 0.f;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) l += expf(sc[g] - m);
+    const float lse = m + logf(block_sum(l, red));
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+      if (label[g] > 0) {
+        part += lse - sc[g];
+        cnt += 1.f;
+      }
+    part = block_sum(part, red);
+    cnt = block_sum(cnt, red);
+  } else if (c.loss_type == UR_LOSS_BCE) {
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+      const float p = 1.0f / (1.0f + expf(-sc[g]));  // clamp(sigmoid, -EPS, 1-EPS) is the identity in fp32
+      const float y = (float)label[g];
+      part += -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+    }
+    part = block_sum(part, red);
+    cnt = (float)G;
+  } else {  // CCL
+    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) part += fmaxf(sc[g] - c.ccl_m, 0.f);
+    part = 1.f - sc[0] + c.ccl_w * block_sum(part, red) / (float)(G - 1);
+    cnt = 1.f;
+  }
+}
+
 // NT threads per workgroup: 256, or 1024 for few rows with many candidates (C3: B = 128 rows of 1001 candidates leave half of the
 // CUs without a workgroup; four times the lane groups per row = four times the candidate rows in flight)
 // KV = float4 chunks of a row per lane = ceil(d / 4 / TPR): 1 for every d <= 128.  (Round 5: the kernel used to carry MAXV = 4 chunks for
@@ -111,41 +152,8 @@ __global__ __launch_bounds__(NT) void scorer_loss_fwd_kernel(UrLossCfg c, const 
   }
   __syncthreads();
   // ---- per-row loss
-  float part = 0.f, cnt = 0.f;
-  if (c.loss_type < 0) {  // UR_LOSS_NONE: scores only
-    cnt = 1.f;
-  } else if (c.loss_type == UR_LOSS_BPR) {
-    const float s0 = sc[0];
-    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) part += -logf(kEps + 1.0f / (1.0f + expf(-(s0 - sc[g]))));
-    part = block_sum(part, red) / (float)(G - 1);
-    cnt = 1.f;
-  } else if (c.loss_type == UR_LOSS_SOFTMAX) {
-    float m = -INFINITY;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) m = fmaxf(m, sc[g]);
-    m = block_max(m, red);
-    float l = 0.f;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) l += expf(sc[g] - m);
-    const float lse = m + logf(block_sum(l, red));
-    for (int g = threadIdx.x; g < G; g += blockDim.x)
-      if (label[(long long)b * G + g] > 0) {
-        part += lse - sc[g];
-        cnt += 1.f;
-      }
-    part = block_sum(part, red);
-    cnt = block_sum(cnt, red);
-  } else if (c.loss_type == UR_LOSS_BCE) {
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
-      const float p = 1.0f / (1.0f + expf(-sc[g]));  // clamp(sigmoid, -EPS, 1-EPS) is the identity in fp32
-      const float y = (float)label[(long long)b * G + g];
-      part += -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
-    }
-    part = block_sum(part, red);
-    cnt = (float)G;
-  } else {  // CCL
-    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) part += fmaxf(sc[g] - c.ccl_m, 0.f);
-    part = 1.f - sc[0] + c.ccl_w * block_sum(part, red) / (float)(G - 1);
-    cnt = 1.f;
-  }
+  float part, cnt;
+  row_loss(c, G, sc, label ? label + (long long)b * G : nullptr, red, part, cnt);
   if (threadIdx.x == 0) {
     loss_rows[b] = part;
     cnt_rows[b] = cnt;
@@ -170,6 +178,47 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
   }
 }
 
+// ---- d (batch-mean loss) / d score' of ONE score row s[0..G) -> cf[0..G) (LDS), `total` = the mean's denominator; the caller
+// scales by the upstream gradient / tau and applies the clip's gate.
+__device__ __forceinline__ void row_coef(const UrLossCfg& c, const int G, const float* __restrict__ s, const int* __restrict__ label,
+                                         float total, float* cf, float* red) {
+  if (c.loss_type == UR_LOSS_BPR) {
+    float a0 = 0.f;
+    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) {
+      const float sg = 1.0f / (1.0f + expf(-(s[0] - s[g])));
+      const float w = sg * (1.f - sg) / (kEps + sg) / ((float)(G - 1) * total);
+      cf[g] = w;
+      a0 -= w;
+    }
+    a0 = block_sum(a0, red);
+    if (threadIdx.x == 0) cf[0] = a0;
+  } else if (c.loss_type == UR_LOSS_SOFTMAX) {
+    float m = -INFINITY;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) m = fmaxf(m, s[g]);
+    m = block_max(m, red);
+    float l = 0.f, np = 0.f;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+      l += expf(s[g] - m);
+      np += (label[g] > 0) ? 1.f : 0.f;
+    }
+    l = block_sum(l, red);
+    np = block_sum(np, red);
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+      cf[g] = (np * expf(s[g] - m) / l - ((label[g] > 0) ? 1.f : 0.f)) / total;
+  } else if (c.loss_type == UR_LOSS_BCE) {
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+      const float p = 1.0f / (1.0f + expf(-s[g]));
+      const float y = (float)label[g];
+      // d/ds of -(y log p + (1-y) log(1-p)) with torch's log clamp at -100 (gradient 0 where clamped)
+      const float gp = (logf(p) > -100.f ? y * (1.f - p) : 0.f) - (logf(1.f - p) > -100.f ? (1.f - y) * p : 0.f);
+      cf[g] = -gp / total;
+    }
+  } else {  // CCL
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+      cf[g] = (g == 0) ? -1.f / total : ((s[g] - c.ccl_m > 0.f) ? c.ccl_w / ((float)(G - 1) * total) : 0.f);
+  }
+}
+
 template <int TPR, int NT, int KV>   // KV: float4 chunks of a row per lane (see the forward kernel)
 __global__ __launch_bounds__(NT) void scorer_loss_bwd_kernel(UrLossCfg c, const float4* __restrict__ user_emb,
                                                               const float4* __restrict__ table, const long long* __restrict__ item_id,
@@ -188,41 +237,7 @@ __global__ __launch_bounds__(NT) void scorer_loss_bwd_kernel(UrLossCfg c, const 
   const float total = norm[1];  // denominator of the mean (rows, pairs or positives)
   const float* s = scores + (long long)b * G;
   // ---- d loss / d score'
-  if (c.loss_type == UR_LOSS_BPR) {
-    float a0 = 0.f;
-    for (int g = 1 + threadIdx.x; g < G; g += blockDim.x) {
-      const float sg = 1.0f / (1.0f + expf(-(s[0] - s[g])));
-      const float w = sg * (1.f - sg) / (kEps + sg) / ((float)(G - 1) * total);
-      cf[g] = w;
-      a0 -= w;
-    }
-    a0 = block_sum(a0, red);
-    if (threadIdx.x == 0) cf[0] = a0;
-  } else if (c.loss_type == UR_LOSS_SOFTMAX) {
-    float m = -INFINITY;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) m = fmaxf(m, s[g]);
-    m = block_max(m, red);
-    float l = 0.f, np = 0.f;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
-      l += expf(s[g] - m);
-      np += (label[(long long)b * G + g] > 0) ? 1.f : 0.f;
-    }
-    l = block_sum(l, red);
-    np = block_sum(np, red);
-    for (int g = threadIdx.x; g < G; g += blockDim.x)
-      cf[g] = (np * expf(s[g] - m) / l - ((label[(long long)b * G + g] > 0) ? 1.f : 0.f)) / total;
-  } else if (c.loss_type == UR_LOSS_BCE) {
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
-      const float p = 1.0f / (1.0f + expf(-s[g]));
-      const float y = (float)label[(long long)b * G + g];
-      // d/ds of -(y log p + (1-y) log(1-p)) with torch's log clamp at -100 (gradient 0 where clamped)
-      const float gp = (logf(p) > -100.f ? y * (1.f - p) : 0.f) - (logf(1.f - p) > -100.f ? (1.f - y) * p : 0.f);
-      cf[g] = -gp / total;
-    }
-  } else {  // CCL
-    for (int g = threadIdx.x; g < G; g += blockDim.x)
-      cf[g] = (g == 0) ? -1.f / total : ((s[g] - c.ccl_m > 0.f) ? c.ccl_w / ((float)(G - 1) * total) : 0.f);
-  }
+  row_coef(c, G, s, label ? label + (long long)b * G : nullptr, total, cf, red);
   __syncthreads();
   float bsum = 0.f;
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
@@ -456,6 +471,56 @@ __global__ __launch_bounds__(256) void scorer_loss_fused_kernel(UrLossCfg c, flo
   }
 }
 
+// ---- group mode (UrLossCfg.group_size > 0): the `user-item-label` row format.  The batch holds ONE (user, item, label) triple per row
+// and AbstractRecommender._cal_loss views the [rows] scores as [rows / group_size, group_size] before the loss
+// (unirec/model/base/reco_abc.py:233-236): every group_size consecutive rows are one score row, each with its own user vector.  The scorer
+// runs as the G = 1 kernel over the rows; these kernels apply the loss / its gradient to the regrouped scores (same row_loss / row_coef
+// as the one-launch-per-row kernels), and the user gradient of a row is its coefficient times its single candidate row.
+__global__ __launch_bounds__(256) void group_loss_fwd_kernel(UrLossCfg c, const float* __restrict__ scores, const int* __restrict__ label,
+                                                             float* __restrict__ loss_rows, float* __restrict__ cnt_rows) {
+  extern __shared__ float sc[];   // [group_size] scores, then 16 floats of reduction scratch
+  const int gs = c.group_size, b = blockIdx.x;
+  float* red = sc + gs;
+  for (int g = threadIdx.x; g < gs; g += blockDim.x) sc[g] = scores[(long long)b * gs + g];
+  __syncthreads();
+  float part, cnt;
+  row_loss(c, gs, sc, label ? label + (long long)b * gs : nullptr, red, part, cnt);
+  if (threadIdx.x == 0) {
+    loss_rows[b] = part;
+    cnt_rows[b] = cnt;
+  }
+}
+__global__ __launch_bounds__(256) void group_loss_bwd_kernel(UrLossCfg c, const float* __restrict__ scores, const int* __restrict__ label,
+                                                             const float* __restrict__ d_loss, const float* __restrict__ norm,
+                                                             float* __restrict__ coef, float* __restrict__ d_user_bias_rows) {
+  extern __shared__ float cf[];   // [group_size] coefficients, then 16 floats of reduction scratch
+  const int gs = c.group_size, b = blockIdx.x;
+  float* red = cf + gs;
+  const float* s = scores + (long long)b * gs;
+  row_coef(c, gs, s, label ? label + (long long)b * gs : nullptr, norm[1], cf, red);
+  __syncthreads();
+  const float up = d_loss ? d_loss[0] : 1.0f;
+  for (int g = threadIdx.x; g < gs; g += blockDim.x) {
+    float v = cf[g] * up / c.tau;
+    if (c.score_clip > 0.f && fabsf(s[g]) >= c.score_clip) v = 0.f;
+    coef[(long long)b * gs + g] = v;
+    if (d_user_bias_rows) d_user_bias_rows[(long long)b * gs + g] = v;
+  }
+}
+// d_user[r,:] = coef[r] * E[item_id[r],:]  (one 32-lane group per row)
+__global__ __launch_bounds__(256) void coef_rows_kernel(const float* __restrict__ coef, const float4* __restrict__ table,
+                                                        const long long* __restrict__ item_id, float4* __restrict__ d_user, int rows, int d4,
+                                                        long long n_items) {
+  const int r = blockIdx.x * 8 + (threadIdx.x >> 5), t = threadIdx.x & 31;
+  if (r >= rows) return;
+  const long long id = UR_ROW(item_id[r], n_items);
+  const float w = coef[r];
+  for (int col = t; col < d4; col += 32) {
+    const float4 e = table[id * d4 + col];
+    d_user[(long long)r * d4 + col] = make_float4(w * e.x, w * e.y, w * e.z, w * e.w);
+  }
+}
+
 static inline int pick_tpr(int d) {
   int d4 = d / 4, t = 4;
   while (t < d4 && t < 32) t <<= 1;
@@ -473,7 +538,14 @@ static int check_loss_cfg(const UrLossCfg* c, const char* who, bool fwd = false)
   UR_REQUIRE(c->G <= 8192, UR_ERR_UNSUPPORTED, "%s: group size G=%d > 8192", who, c->G);
   UR_REQUIRE(c->loss_type >= (fwd ? UR_LOSS_NONE : UR_LOSS_BCE) && c->loss_type <= UR_LOSS_CCL, UR_ERR_UNSUPPORTED,
              "%s: loss_type=%d is not a sampled loss (fullsoftmax scores all N items: not implemented)", who, c->loss_type);
-  UR_REQUIRE((c->loss_type != UR_LOSS_BPR && c->loss_type != UR_LOSS_CCL) || c->G >= 2, UR_ERR_ARG, "%s: pairwise loss needs G >= 2", who);
+  UR_REQUIRE(c->group_size >= 0 && c->group_size <= 8192, UR_ERR_ARG, "%s: group_size=%d", who, c->group_size);
+  if (c->group_size > 0) {   // user-item-label rows: one candidate per row, group_size consecutive rows = one score row of the loss
+    UR_REQUIRE(c->G == 1 && c->B % c->group_size == 0, UR_ERR_ARG, "%s: group_size=%d needs G == 1 and B %% group_size == 0 (B=%d G=%d)", who,
+               c->group_size, c->B, c->G);
+    UR_REQUIRE(c->loss_type != UR_LOSS_NONE, UR_ERR_ARG, "%s: group_size with loss_type none", who);
+  }
+  UR_REQUIRE((c->loss_type != UR_LOSS_BPR && c->loss_type != UR_LOSS_CCL) || (c->group_size > 0 ? c->group_size : c->G) >= 2, UR_ERR_ARG,
+             "%s: pairwise loss needs G >= 2", who);
   UR_REQUIRE(c->tau != 0.f, UR_ERR_ARG, "%s: tau == 0", who);
   return UR_OK;
 }
@@ -492,6 +564,13 @@ extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_em
   UR_REQUIRE(!user_bias || user_id, UR_ERR_ARG, "ur_gather_dot_loss_fwd: user_bias needs user_id");
   hipStream_t st = as_stream(stream);
   ProfScope ps(PC_LOSS, st, (double)cfg->B * cfg->G * cfg->d * 4.0);
+  const int gs = cfg->group_size, loss_type_in = cfg->loss_type;
+  UrLossCfg rows_cfg = *cfg;
+  if (gs > 0) {   // group mode: the scorer alone over the rows (G = 1), the loss on the regrouped scores below
+    rows_cfg.group_size = 0;
+    rows_cfg.loss_type = UR_LOSS_NONE;
+    cfg = &rows_cfg;
+  }
   const int tpr = pick_tpr(cfg->d);
   const size_t lds = (cfg->G + 16) * sizeof(float);
   const bool wide = cfg->G >= 512 && cfg->B <= 512;   // few rows, many candidates: 1024-thread workgroups
@@ -514,7 +593,16 @@ extern "C" int ur_gather_dot_loss_fwd(const UrLossCfg* cfg, const float* user_em
 #undef GO2
 #undef GO3
   UR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, loss_rows, cnt_rows, cfg->B, loss_out);
+  int n_loss_rows = cfg->B;
+  if (gs > 0) {
+    UrLossCfg gc = *cfg;
+    gc.group_size = gs;
+    gc.loss_type = loss_type_in;
+    n_loss_rows = cfg->B / gs;
+    hipLaunchKernelGGL(group_loss_fwd_kernel, dim3(n_loss_rows), dim3(256), (gs + 16) * sizeof(float), st, gc, scores, label, loss_rows, cnt_rows);
+    UR_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, loss_rows, cnt_rows, n_loss_rows, loss_out);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }
@@ -532,6 +620,16 @@ extern "C" int ur_gather_dot_loss_bwd(const UrLossCfg* cfg, const float* user_em
              "ur_gather_dot_loss_bwd: label is required for bce/softmax");
   hipStream_t st = as_stream(stream);
   ProfScope ps(PC_LOSS, st, (double)cfg->B * cfg->G * cfg->d * 4.0);
+  if (cfg->group_size > 0) {   // group mode: coefficients from the regrouped scores, then d_user[r] = coef[r] * E[item_id[r]]
+    const int gs = cfg->group_size;
+    hipLaunchKernelGGL(group_loss_bwd_kernel, dim3(cfg->B / gs), dim3(256), (gs + 16) * sizeof(float), st, *cfg, scores, label, d_loss, loss_out,
+                       coef, d_user_bias_rows);
+    UR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(coef_rows_kernel, dim3(cdiv(cfg->B, 8)), dim3(256), 0, st, coef, (const float4*)item_table, (const long long*)item_id,
+                       (float4*)d_user, cfg->B, cfg->d / 4, (long long)n_items);
+    UR_LAUNCH_CHECK();
+    return UR_OK;
+  }
   const int tpr = pick_tpr(cfg->d);
   bool wide = cfg->G >= 512 && cfg->B <= 512;   // few rows, many candidates: 1024-thread workgroups
   if (wide && ((size_t)cfg->G + (size_t)(1024 / tpr) * cfg->d + 16) * sizeof(float) > 64 * 1024) wide = false;
@@ -579,7 +677,7 @@ static unsigned* fused_counter(hipStream_t st) {
 }
 
 extern "C" int ur_gather_dot_loss_fused_supported(const UrLossCfg* cfg) {
-  if (!cfg) return 0;
+  if (!cfg || cfg->group_size > 0) return 0;
   if (!(cfg->loss_type == UR_LOSS_BPR || cfg->loss_type == UR_LOSS_BCE || cfg->loss_type == UR_LOSS_CCL)) return 0;
   return ((size_t)cfg->G * cfg->d + 2 * (size_t)cfg->G + 16) * sizeof(float) <= 32 * 1024 && cfg->d % 4 == 0 && cfg->d <= 512;
 }

@@ -340,36 +340,50 @@ class Trainer(object):
                     self.scheduler.step(score)
                     self.logger.info("epoch: %d, learning rate: %s", epoch_idx, self.optimizer.param_groups[0]["lr"])
             t0 = time.time()
+            borrowed = None
             if hasattr(train_data, "use_stream") and hasattr(self.optimizer, "plan_stream"):
-                # one stream for everything that runs a batch AHEAD; train_step(cur, nxt) plans `nxt` there and joins it (see use_stream)
+                # one stream for everything that runs a batch AHEAD; train_step(cur, nxt) plans `nxt` there and joins it (see use_stream).
+                # The promise behind joined=True is kept by THIS loop only, so the loader gets its own stream and the waiting hand-out
+                # back when the epoch ends, however it ends: evaluate(), a user loop or a train_step override that skips prefetch_plan
+                # must never read a batch the plan stream has not built yet
+                borrowed = (train_data.stream, train_data.joined)
                 train_data.use_stream(self.optimizer.plan_stream(), joined=self.world == 1)
-            losses, it = [], iter(train_data)
-            epoch_sum, n_nan = 0.0, 0
-
-            def drain():      # device scalars -> host: one sync per 4096 steps (and one per epoch), not one per step
-                nonlocal epoch_sum, n_nan
-                if not losses:
-                    return
-                vals = np.asarray(torch.stack(losses).tolist(), dtype=np.float64)      # one launch, one copy
-                losses.clear()
-                nan = np.isnan(vals)
-                n_nan += int(nan.sum())
-                epoch_sum += float(vals[~nan].sum())      # (a Python-float running sum of loss.item(), as trainer.py:354-355)
-                self.step_losses.extend(vals.tolist())
-
-            cur = next(it, None)
-            while cur is not None:          # one batch of lookahead: the next batch's plan overlaps this step
-                nxt = next(it, None)
-                losses.append(self.train_step(cur, nxt))
-                if len(losses) >= 4096:
-                    drain()
-                cur = nxt
-            drain()
+            try:
+                epoch_sum, n_nan = self._run_epoch(train_data)
+            finally:
+                if borrowed is not None:
+                    train_data.stream, train_data.joined = borrowed
             if n_nan:
                 self.logger.error("Training loss is nan in %d steps of epoch %d", n_nan, epoch_idx + 1)
             # reported train loss = SUM over batches of the batch loss (trainer.py:354-355)
             self.logger.info("epoch %d training [time: %.2fs, train loss: %.4f]", epoch_idx + 1, time.time() - t0, epoch_sum)
         return self.best_valid_score
+
+    def _run_epoch(self, train_data):
+        """the loop body of Trainer.fit (trainer.py:327-357) over one epoch -> (sum of the batch losses, number of NaN steps)"""
+        losses, it = [], iter(train_data)
+        epoch_sum, n_nan = 0.0, 0
+
+        def drain():      # device scalars -> host: one sync per 4096 steps (and one per epoch), not one per step
+            nonlocal epoch_sum, n_nan
+            if not losses:
+                return
+            vals = np.asarray(torch.stack(losses).tolist(), dtype=np.float64)      # one launch, one copy
+            losses.clear()
+            nan = np.isnan(vals)
+            n_nan += int(nan.sum())
+            epoch_sum += float(vals[~nan].sum())      # (a Python-float running sum of loss.item(), as trainer.py:354-355)
+            self.step_losses.extend(vals.tolist())
+
+        cur = next(it, None)
+        while cur is not None:          # one batch of lookahead: the next batch's plan overlaps this step
+            nxt = next(it, None)
+            losses.append(self.train_step(cur, nxt))
+            if len(losses) >= 4096:
+                drain()
+            cur = nxt
+        drain()
+        return epoch_sum, n_nan
 
     # ------------------------------------------------------------------ evaluation
     @staticmethod
@@ -473,6 +487,11 @@ class Trainer(object):
             if predict_only:
                 ranks.append(scores.cpu().numpy())
                 continue
+            if scores.dim() == 1:   # user-item-label rows: group_size consecutive rows are one ranking list (onepos.py:105-107)
+                gs = int(self.config.get("group_size", -1) or -1)
+                if gs <= 0:
+                    raise ValueError("evaluating one score per row (user-item-label data) needs a positive group_size")
+                scores = scores.view(-1, gs)
             ranks.append((scores[:, 1:] > scores[:, :1]).sum(1).cpu().numpy())   # 0-based rank of the positive
         if predict_only:
             return self._gather_for_metrics(ranks, eval_data)

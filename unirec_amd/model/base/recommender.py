@@ -21,7 +21,7 @@ class _ScoreLossFn(torch.autograd.Function):
     def forward(ctx, user_emb, model, item_id, label, user_id):
         B, G = item_id.shape
         cfg = ops.loss_cfg(B, G, model.embedding_size, model.loss_type, model.tau, model.SCORE_CLIP,
-                           model.config.get("ccl_w", 0.0), model.config.get("ccl_m", 0.0))
+                           model.config.get("ccl_w", 0.0), model.config.get("ccl_m", 0.0), model._group_rows(B, G))
         ub = model.user_bias.data if model.has_user_bias else None
         ib = model.item_bias.data if model.has_item_bias else None
         table = model.item_embedding.weight.data
@@ -142,29 +142,29 @@ class BaseRecommender(AbstractRecommender):
             user_emb = self.forward_user_emb(user_id, item_seq, item_seq_len, item_seq_features, time_seq)
             target = item_id.reshape(item_id.shape[0], -1)[:, 0].contiguous()
             return _FullSoftmaxFn.apply(user_emb, self, target, user_id), None, None, None
-        if item_id.dim() == 1:
+        squeeze = item_id.dim() == 1     # one candidate per row (user-item-label rows): the reference's scores are [B] then (modules.py:53-55)
+        if squeeze:
             item_id = item_id.unsqueeze(1)
             label = label.unsqueeze(1) if label is not None and label.dim() == 1 else label
-        squeeze = False
         item_id = item_id.contiguous()
         user_emb = self.forward_user_emb(user_id, item_seq, item_seq_len, item_seq_features, time_seq)
-        if self.group_size > 0 and self.training:
-            # reference reshapes scores to [-1, group_size] (reco_abc.py:233-236): rows of one group share a user
-            raise NotImplementedError("group_size > 0 (user-item-label rows) is not on the accelerated path")
         lab = label.to(torch.int32).contiguous() if label is not None else None
         if self.training:
             loss, scores, loss_rows = _ScoreLossFn.apply(user_emb, self, item_id, lab, user_id)
             if not reduction:
                 if self.loss_type in ("bpr", "ccl"):
-                    loss = loss_rows[: item_id.shape[0]]
+                    gs = self._group_rows(*item_id.shape)
+                    loss = loss_rows[: item_id.shape[0] // gs if gs else item_id.shape[0]]
                 else:
                     raise NotImplementedError("reduction=False is implemented for bpr/ccl only")
             if return_loss_only:
                 return loss, None, None, None
+            if squeeze:
+                return loss, scores.squeeze(1), user_emb, self.forward_item_emb(item_id.squeeze(1))
             return loss, scores, user_emb, self.forward_item_emb(item_id)
         scores = self._predict_layer(user_emb, None, user_id, item_id)
         if squeeze:
-            scores = scores.squeeze(1)
+            return None, scores.squeeze(1), user_emb, self.forward_item_emb(item_id.squeeze(1))
         return None, scores, user_emb, self.forward_item_emb(item_id)
 
     def _full_softmax_backward(self, user_emb, target, lse, ws, user_id, d_loss):
@@ -281,8 +281,6 @@ class BaseRecommender(AbstractRecommender):
             self._encode_backward(state, self._fs_d_user)
             object.__setattr__(self, "loss_guard", loss_out[2:3])
             return loss_out[0]
-        if self.group_size > 0:
-            raise NotImplementedError("group_size > 0 (user-item-label rows) is not on the accelerated path")
         if item_id.dim() == 1:
             item_id = item_id.unsqueeze(1)
             label = label.unsqueeze(1) if label is not None and label.dim() == 1 else label
@@ -292,7 +290,7 @@ class BaseRecommender(AbstractRecommender):
         user_emb = user_emb.contiguous()
         B, G = item_id.shape
         cfg = ops.loss_cfg(B, G, self.embedding_size, self.loss_type, self.tau, self.SCORE_CLIP,
-                           self.config.get("ccl_w", 0.0), self.config.get("ccl_m", 0.0))
+                           self.config.get("ccl_w", 0.0), self.config.get("ccl_m", 0.0), self._group_rows(B, G))
         ub = self.user_bias.data if self.has_user_bias else None
         ib = self.item_bias.data if self.has_item_bias else None
         table = self.item_embedding.weight.data
@@ -311,6 +309,17 @@ class BaseRecommender(AbstractRecommender):
         self._encode_backward(state, d_user)
         object.__setattr__(self, "loss_guard", loss_out[2:3])   # device flag: -1 = this step's loss is NaN (optimizer skips the update)
         return loss_out[0]
+
+    def _group_rows(self, B, G):
+        """``group_size`` of the loss's reshape (reco_abc.py:233-236: ``scores.view(-1, group_size)``) for a [B, G] candidate matrix.
+        G == group_size: the rows already are the groups (the view is the identity).  G == 1 -- the user-item-label format, one
+        (user, item, label) triple per row -- regroups every group_size consecutive rows into one score row (UrLossCfg.group_size)."""
+        gs = int(self.group_size) if self.group_size else 0
+        if gs <= 0 or G == gs:
+            return 0
+        if G != 1 or B % gs:
+            raise ValueError(f"group_size={gs}: scores of shape [{B}, {G}] cannot be viewed as [-1, {gs}] row groups")
+        return gs
 
     def _predict_layer(self, user_emb, items_emb, user_id, item_id):
         """scores only (no loss), through the same fused gather-dot kernel; items_emb is ignored."""

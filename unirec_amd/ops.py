@@ -194,8 +194,11 @@ def gru_bwd(cfg, item_table, dense, item_seq, d_user_emb, ws):
 
 
 # --------------------------------------------------------------------------------------------- scorer + loss
-def loss_cfg(B, G, d, loss_type, tau=1.0, score_clip=-1.0, ccl_w=0.0, ccl_m=0.0) -> UrLossCfg:
-    return UrLossCfg(B, G, d, LOSS_IDS[loss_type], float(tau), float(score_clip if score_clip else -1.0), float(ccl_w), float(ccl_m))
+def loss_cfg(B, G, d, loss_type, tau=1.0, score_clip=-1.0, ccl_w=0.0, ccl_m=0.0, group_size=0) -> UrLossCfg:
+    """group_size > 0: the user-item-label row format (G == 1; every group_size consecutive rows form one score row of the loss,
+    unirec/model/base/reco_abc.py:233-236)."""
+    return UrLossCfg(B, G, d, LOSS_IDS[loss_type], float(tau), float(score_clip if score_clip else -1.0), float(ccl_w), float(ccl_m),
+                     int(group_size) if group_size and group_size > 0 else 0)
 
 
 def gather_dot_loss_fwd(cfg, user_emb, item_table, item_id, label=None, user_bias=None, item_bias=None, user_id=None):

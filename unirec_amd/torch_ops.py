@@ -362,8 +362,8 @@ NOT_OPS = {
     "ur_host_sampler_create": _HOST, "ur_host_sampler_destroy": _HOST, "ur_host_sampler_getrandbits": _HOST, "ur_host_sampler_random": _HOST,
     "ur_host_sampler_randint": _HOST, "ur_host_sampler_set_alias": _HOST, "ur_host_build_rows": _HOST, "ur_alias_table_build": _HOST,
     "ur_sasrec_set_side_stream": _SWITCH, "ur_sasrec_set_chain": _SWITCH, "ur_prof_enable": _SWITCH, "ur_prof_set_mask": _SWITCH,
-    "ur_prof_reset": _SWITCH, "ur_prof_num_classes": _SWITCH, "ur_prof_class_name": _SWITCH, "ur_prof_read": _SWITCH,
-    "ur_gemm_nt": _HOOK, "ur_gemm_tn": _HOOK, "ur_debug_delay": _HOOK,
+    "ur_set_mfma_arith": _SWITCH, "ur_get_mfma_arith": _SWITCH, "ur_prof_reset": _SWITCH, "ur_prof_num_classes": _SWITCH, "ur_prof_class_name": _SWITCH, "ur_prof_read": _SWITCH,
+    "ur_gemm_nt": _HOOK, "ur_gemm_tn": _HOOK, "ur_gemm_tn_group": _HOOK, "ur_debug_delay": _HOOK,
     "ur_sasrec_bwd_deferred": _PLUMB, "ur_sasrec_bwd_join": _PLUMB, "ur_stream_wait_stream": _PLUMB, "ur_sasrec_side_stream": _PLUMB, "ur_sasrec_side_publish": _PLUMB,
     "ur_rows_plan_merge": _SHARD, "ur_rows_plan_sharded": _SHARD, "ur_compact_index": _SHARD, "ur_full_rank_shard": _SHARD,
     "ur_shard_step_flags": _SHARD, "ur_comm_world": _COMM, "ur_loop_create": _COMM, "ur_loop_destroy": _COMM, "ur_loop_attach": _COMM, "ur_loop_detach": _COMM,
