@@ -38,6 +38,28 @@ PROF_EVERY = 10   # the dominant kernel class is bracketed with HIP events on ev
 ALGO_BYTES_PER_STEP = {"gemm_nt": 598.0, "gemm_tn": 247.0, "row_chain": 498.0}
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def split_ceiling_tflops():
+    """fp32-equivalent ceiling of the split-bf16 arithmetic: the bf16 peak / the piece products per fp32 product (None: exact fp32 MFMA)"""
+    from unirec_amd import ops
+    t = ops.default_mfma_arith() & 0xFF
+    return MFMA_BF16_PEAK_TFLOPS / t if t in (6, 9) else None
+
+
+def mfma_arith_note():
+    from unirec_amd import ops
+    t = ops.default_mfma_arith() & 0xFF
+    if t not in (6, 9):
+        return {"weight_gradients": "exact fp32-input MFMA (v_mfma_f32_32x32x2_f32)", "terms": 0}
+    return {"weight_gradients": f"bf16x{t} split: fp32 operands = exact sums of three bf16 pieces, {t} piece products accumulated in fp32 on "
+                                "v_mfma_f32_32x32x16_bf16; error vs fp64 <= the exact fp32-MFMA kernel's (profiles/r06_a_stage_a.txt, "
+                                "tests/test_gemm_gpu.py::test_split_bf16_products_are_fp32_equivalent)",
+            "terms": t, "split_ceiling_TFLOPs": round(MFMA_BF16_PEAK_TFLOPS / t, 1), "fp32_mfma_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
+            "everything_else": "exact fp32-input MFMA"}
+
+
 def csrc_digest():
     """sha256 over the kernel sources: a committed PMC summary (tools/pmc_hbm.py writes the digest it was measured on) is only quoted
     in the line when it was taken on THIS tree's kernels"""
@@ -83,6 +105,8 @@ def parse():
                     "(merge plan, capacities) with real stream concurrency; prints wall time per step and per rank-step")
     ap.add_argument("--worker", action="store_true", help="(internal) world > 1: this process IS the benchmark; without it the process the "
                     "launcher started supervises a --worker child per rung of the fallback ladder (tools/bench_ladder.py)")
+    ap.add_argument("--supervised", action="store_true", help="--gpus 1 only: run the ONE-rank benchmark the way a multi-GPU launch runs -- a supervisor, "
+                    "a --worker child per ladder rung, the row-sharded step (--sharded-w1) through the library's RCCL communicators at world 1")
     ap.add_argument("--dry-worker", action="store_true", help="(test aid) the worker walks the phases over gloo with no GPU work")
     ap.add_argument("--no-selfcheck", action="store_true", help="world > 1: skip the W-rank == 1-rank check that runs before the timed region")
     ap.add_argument("--selfcheck-items", type=int, default=1_000_000)
@@ -307,6 +331,13 @@ def multi_gpu_selfcheck(a, device, rank, world):
         losses.append(float(opt.train_step(mine, nxt)))
     all_losses = [None] * world
     dist.all_gather_object(all_losses, losses)
+    # "did RCCL see N ranks" from RCCL itself: ncclCommCount / ncclCommUserRank of the library's two communicators (0 = the packed blocks
+    # travel through torch.distributed on this rung); every rank must report the same count, and it must be WORLD_SIZE
+    from unirec_amd import ops as _ops
+    counts = [None] * world
+    dist.all_gather_object(counts, _ops.comm_count())
+    if any(c not in (0, world) for c in counts) or len(set(counts)) != 1:
+        raise RuntimeError(f"multi-GPU self-check: RCCL reports {counts} ranks per process, torch.distributed world is {world}")
     sd = opt.gather_state_dict()
     report = None
     if rank == 0:
@@ -330,7 +361,7 @@ def multi_gpu_selfcheck(a, device, rank, world):
             got, want = sd[k].numpy(), v.detach().cpu().numpy()
             np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5, err_msg=f"multi-GPU self-check: {k}")
             worst = max(worst, float(np.abs(got - want).max()))
-        report = {"ok": True, "steps": 3, "n_items": N, "ranks": world, "backend": dist.get_backend(),
+        report = {"ok": True, "steps": 3, "n_items": N, "ranks": world, "rccl_ranks": counts[0], "backend": dist.get_backend(),
                   "max_abs_param_diff_vs_1_rank": worst, "losses": [round(float(x), 6) for x in np.mean(all_losses, axis=0)]}
         del m1, o1
     del model, opt, sd
@@ -734,10 +765,14 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_ladder
-    if world > 1 and not a.worker:
+    if (world > 1 or a.supervised) and not a.worker:
         # the launcher's process supervises: the benchmark itself runs in a child per rung of the fallback ladder, under a per-phase
         # watchdog -- a hung collective ends in a JSON line with "hang", never in silence (tools/bench_ladder.py)
-        raise SystemExit(bench_ladder.supervise(os.path.abspath(__file__), [x for x in sys.argv[1:] if x != "--worker"], rank, world))
+        argv = [x for x in sys.argv[1:] if x not in ("--worker", "--supervised")]
+        if world == 1:      # one rank: the multi-GPU step at world 1, RCCL at world 1 on the native rungs
+            argv += ["--sharded-w1"]
+            os.environ["UR_NATIVE_W1"] = "1"
+        raise SystemExit(bench_ladder.supervise(os.path.abspath(__file__), argv, rank, world))
     if a.dry_worker:
         return bench_ladder.dry_worker(sys.argv[1:])
     phase = bench_ladder.phase
@@ -966,6 +1001,10 @@ def main():
                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "launches": c["launches"], "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2),
                 "real_token_fraction": round(valid_frac, 4)}
+        if dom == "gemm_tn" and split_ceiling_tflops():   # the class runs on the bf16 pipes: quoted against BOTH ceilings
+            roof["kernel"] = "gemm_tn kernels (v_mfma_f32_32x32x16_bf16 on exactly split fp32 operands)"
+            roof["frac_of_split_ceiling"] = round(achieved / split_ceiling_tflops(), 4)
+            roof["split_ceiling"] = round(split_ceiling_tflops(), 1)
         if iso is not None and iso["ms"] > 0:
             ach_iso = iso["work"] * valid_frac / (iso["ms"] * 1e-3) / 1e12
             roof["isolated"] = {"achieved": round(ach_iso, 2), "frac": round(ach_iso / MFMA_F32_PEAK_TFLOPS, 4), "launches": iso["launches"],
@@ -1031,6 +1070,9 @@ def main():
                    "global_batch": world * B, "seq_len": L, "parallelism": info["parallelism"]},
         "hbm_embedding_GBps_algorithmic": round(ex_per_s * emb_bytes_per_example / 1e9, 2),
         "final_loss": round(final_loss, 6),
+        # arithmetic of the dense contractions: every value is fp32 (`dtype`); the weight-gradient products are evaluated either on the
+        # fp32-input MFMA or -- the default since round 6 -- as six bf16 piece products of exactly split fp32 operands, fp32-accumulated
+        "mfma_arith": mfma_arith_note(),
         "roofline": roof,
         "step_floor": step_floor,
         "kernel_time_ms_per_step_warmup": {k: round(v["ms"] / max(1, n_prof), 4) for k, v in warm.items() if v["launches"]},
@@ -1038,12 +1080,19 @@ def main():
         # of the real token rows / device time of the class, in situ -- the weight-gradient GEMMs share the CUs with the main stream)
         "mfma_classes_warmup": {k: {"TFLOPs": round(v["work"] * (valid_frac if k in ("gemm_nt", "gemm_tn", "row_chain") else 1.0) / (v["ms"] * 1e-3) / 1e12, 2),
                                     "frac": round(v["work"] * (valid_frac if k in ("gemm_nt", "gemm_tn", "row_chain") else 1.0) / (v["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                                    "launches_per_step": round(v["launches"] / max(1, n_prof), 1)}
+                                    "launches_per_step": round(v["launches"] / max(1, n_prof), 1),
+                                    **({"frac_of_split_ceiling": round(v["work"] * valid_frac / (v["ms"] * 1e-3) / 1e12 / split_ceiling_tflops(), 4)}
+                                       if k == "gemm_tn" and split_ceiling_tflops() else {})}
                                 for k, v in warm.items() if k in MFMA_CLASSES and v["ms"] > 0 and v["work"] > 0},
     }
+    if world == 1 and a.sharded_w1:
+        from unirec_amd import ops as _ops
+        out["n_ranks"], out["rccl_ranks"] = 1, _ops.comm_count()
     if world > 1:
         import torch.distributed as dist
         out["n_ranks"] = dist.get_world_size()
+        from unirec_amd import ops as _ops
+        out["rccl_ranks"] = _ops.comm_count()     # ncclCommCount of the library's own communicators (0: the torch.distributed route carried the exchange)
         out["backend"] = dist.get_backend()
         out["selfcheck"] = selfcheck if selfcheck is not None else "skipped (--no-selfcheck)"
         out["collectives"] = collectives

@@ -98,6 +98,12 @@ typedef struct UrSasrecCfg {
   float p_attn;         /* attn_dropout_prob */
   int64_t drop_seed;
   int64_t drop_step;
+  int32_t mfma_arith;   /* arithmetic of the weight-gradient products (autograd of modules.py:285-287,312,347-355): 0 = exact fp32-input
+                         * MFMA; 6 / 9 = the fp32 operands split exactly into three bf16 pieces, six / nine piece products accumulated in
+                         * fp32 on the bf16 pipes (fp32-equivalent: measured error vs fp64 <= the exact kernel's, profiles/r06_*_stage_a*);
+                         * see ur_set_mfma_arith.  Products narrower than the split kernel's 128 x 128 tile keep the exact kernel unless 0x100 is
+                         * added (unit tests). */
+  int32_t reserved_;
 } UrSasrecCfg;
 
 /* Layout of the flat dense-parameter buffer (and of its gradient buffer). offsets_out receives
@@ -252,6 +258,8 @@ typedef struct UrGruCfg {
    * (counter-based hash, same (drop_seed, drop_step) for the backward); row id of element (b, t, :) is t*B + b. */
   float p_drop;
   int64_t drop_seed, drop_step;
+  int32_t mfma_arith;   /* as UrSasrecCfg.mfma_arith: the dW_ih / dW_hh products */
+  int32_t reserved_;
 } UrGruCfg;
 int64_t ur_gru_param_layout(const UrGruCfg* cfg, int64_t* offsets_out);
 int64_t ur_gru_workspace_bytes(const UrGruCfg* cfg);
@@ -390,6 +398,10 @@ int ur_shard_step_flags(const float* grads_in, int32_t world, int32_t cap, int32
  * rank 0 and handed to every rank's ur_comm_init by the host (a broadcast over its process group).  ur_comm_all_reduce_sum: in place,
  * fp32 -- the flat dense-gradient all-reduce of the step (what DDP's bucketed all-reduce does, trainer.py:346), on `stream`. */
 int ur_comm_world(void);
+/* RCCL's own view of the two communicators (ncclCommCount / ncclCommUserRank): out4 (nullable) = {ranks of the row communicator, ranks
+ * of the ahead communicator, this rank in each}; returns the rank count (0: not initialised), < 0 if they disagree with each other or
+ * with ur_comm_init's arguments.  What `bench.py --gpus N` prints as rccl_ranks (trainer.py:67,261: Accelerate's num_processes). */
+int ur_comm_count(int32_t* out4);
 /* ---- in-process loopback transport (test / measurement infrastructure of the multi-GPU step on a 1-GPU box; csrc/exchange.hip has the
  * protocol): W rank contexts in ONE process on one device.  A rank is the THREAD that called ur_loop_attach(group, rank): from then on its
  * per-context library state (the encoder's side stream and events, hand-off counters) is its own.  A collective is ur_loop_post ->

@@ -31,13 +31,20 @@ def _launch(extra_env, extra_args=("--dry-worker",), world=2, timeout=240):
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
-    return json.loads(lines[0])
+    j = json.loads(lines[0])
+    # evidence after EVERY rung (a launch killed half way still says what was tried): one marked line per rung, on stdout and stderr,
+    # each holding the ladder so far -- and never mistaken for THE line (they do not start with a brace)
+    for stream in (r.stdout, r.stderr):
+        partial = [json.loads(ln.split("] ", 1)[1]) for ln in stream.splitlines() if ln.startswith("[bench-ladder partial] ")]
+        assert [len(q["ladder"]) for q in partial] == list(range(1, len(j["ladder"]) + 1)), stream[-1500:]
+        assert partial[-1]["ladder"] == j["ladder"]
+    return j
 
 
 def test_a_clean_run_takes_the_first_rung():
     j = _launch({})
     assert j["value"] == 1.0 and j["config"]["rung"] == "native-2comm-prefetch"
-    assert j["ladder"] == [{"rung": "native-2comm-prefetch", "ok": True}]
+    assert [(e["rung"], e["ok"]) for e in j["ladder"]] == [("native-2comm-prefetch", True)] and j["ladder"][0]["seconds"] > 0
 
 
 def test_a_rank_that_hangs_mid_step_moves_everyone_down_the_ladder():
@@ -58,6 +65,15 @@ def test_a_rank_that_dies_on_every_rung_still_yields_a_line_with_hang():
 def test_a_hang_on_every_rung_still_yields_a_line_with_hang():
     j = _launch({"UR_BENCH_TEST_HANG": "0:selfcheck:0,1,2,3"}, timeout=400)
     assert j["value"] == 0.0 and j["hang"] == "selfcheck" and len(j["ladder"]) == 4
+
+
+def test_four_hung_rungs_end_within_eighteen_minutes():
+    """whatever the phases do, a rung is aborted at its budget -- 18 minutes for the whole ladder, 12 under the
+    driver's 30-minute limit; and a worker that keeps passing phase marks but never finishes is cut by the budget, not by a phase limit"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_ladder
+    assert sum(bench_ladder.RUNG_BUDGET) <= 18 * 60 and len(bench_ladder.RUNG_BUDGET) == len(bench_ladder.RUNGS)
+    assert all(v <= bench_ladder.RUNG_BUDGET[0] for v in bench_ladder.LIMITS.values())
 
 
 @pytest.mark.gpu

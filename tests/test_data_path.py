@@ -283,3 +283,41 @@ def test_batch_loader_reproduces_the_references_dataloader_batches():
                 assert got.shape == want.shape, (e, i, k, got.shape, want.shape)
                 assert np.array_equal(got.astype(np.int64), want.astype(np.int64)), (e, i, k)
             assert b["item_seq"].dtype == torch.int32 and b["item_id"].dtype == torch.int64     # the dtypes the reference collates to
+
+
+def test_loss_check_draw_keeps_the_sampler_on_the_references_stream():
+    """The reference's BPR / CCL loss draws ``random.random()`` once per training forward (the 10 % label check,
+    unirec/model/base/reco_abc.py:238-246) from the process-global stream its negative sampler uses -- between the rows of batch i and
+    those of batch i + 1.  BatchLoader.loss_check_draws = 1 (set by Trainer.fit for those losses) does the same on the native stream:
+    the batches then equal CPython's own ``random`` driven that way."""
+    import random
+    from unirec_amd.data.dataset.basedataset import BaseDataset
+    from unirec_amd.data.transform.addnegsamples import AddNegSamples
+    from unirec_amd.facility.trainer import BatchLoader
+    n_users, n_items, K, B = 30, 400, 4, 16
+    rng = np.random.default_rng(9)
+    data = np.stack([rng.integers(1, n_users, 80), rng.integers(1, n_items, 80)], 1)
+    ds = BaseDataset({}, transform=AddNegSamples(n_users, n_items, K, seed=77), data=data)
+    ld = BatchLoader(ds, B, device="cpu")
+    ld.loss_check_draws = 1
+    got = [b["item_id"].numpy() for b in ld]
+    random.seed(77)
+
+    def rows_of(i):
+        want = []
+        for p in data[i * B:(i + 1) * B, 1]:
+            row = [int(p)]
+            while len(row) < K + 1:                      # addnegsamples.py:90-108 without a history: redraw what equals the positive
+                x = random.randint(1, n_items - 1)
+                if x != int(p):
+                    row.append(x)
+            want.append(row)
+        return np.array(want)
+    # Accelerate's DataLoaderShard (the reference's prepared loader) builds batch i + 1 before it hands out batch i: rows(0), rows(1),
+    # step 0's draw, rows(2), step 1's draw, ...
+    want = [rows_of(0)]
+    for i in range(1, len(got)):
+        want.append(rows_of(i))
+        random.random()
+    for i, g in enumerate(got):
+        assert np.array_equal(g, want[i]), i

@@ -122,9 +122,12 @@ def test_c2_sasrec_60k_items_d64_step():
     _check_step_at_full_size(SASRec, _cfg("SASRec", 60_000, 64, 50), B=512, K=4)
 
 
-def test_c5_sasrec_100m_items_step_equals_the_oracle_on_the_touched_rows():
+@pytest.mark.parametrize("mfma_arith", [6, 9, 0])
+def test_c5_sasrec_100m_items_step_equals_the_oracle_on_the_touched_rows(mfma_arith):
+    """mfma_arith: the weight-gradient products in the split-bf16 arithmetic (6 = the default, 9) and in the exact fp32-input MFMA (0):
+    the same oracle at the same tolerances (C3 and C4 below run the default)."""
     from unirec_amd.model.sequential.sasrec import SASRec
-    _check_step_at_full_size(SASRec, _cfg("SASRec", 100_000_000, 128, 50), B=512, K=4)
+    _check_step_at_full_size(SASRec, _cfg("SASRec", 100_000_000, 128, 50, mfma_arith=mfma_arith), B=512, K=4)
 
 
 def test_c3_sasrec_2m_items_L200_K1000_softmax_step():

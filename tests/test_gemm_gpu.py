@@ -75,9 +75,24 @@ def test_gemm_nt(M, N, K, pro, epi):
     _close(Cc, ref, 2e-4 if epi == 2 else 1e-4)
 
 
+@pytest.fixture
+def arith(request):
+    """the arithmetic of the weight-gradient products for ONE test (ur_set_mfma_arith is process-wide): 0 = exact fp32-input MFMA,
+    6 / 9 = split-bf16 terms; the raw hooks take the split kernel at every shape"""
+    from unirec_amd._lib import check, lib
+    check(lib.ur_set_mfma_arith(request.param), "ur_set_mfma_arith")
+    assert lib.ur_get_mfma_arith() == request.param
+    yield request.param
+    check(lib.ur_set_mfma_arith(0), "ur_set_mfma_arith")
+
+
+ARITHS = pytest.mark.parametrize("arith", [0, 6, 9], indirect=True)
+
+
+@ARITHS
 @pytest.mark.parametrize("T,R,Cc_", [(25600, 128, 512), (25600, 384, 128), (512, 128, 128), (700, 100, 36), (5, 128, 128), (3000, 260, 132)])
 @pytest.mark.parametrize("act_on_q", [0, 1])
-def test_gemm_tn(T, R, Cc_, act_on_q):
+def test_gemm_tn(T, R, Cc_, act_on_q, arith):
     from unirec_amd._lib import check, lib
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(T + R + Cc_)
@@ -103,11 +118,12 @@ _ACTS = {0: lambda x: 0.5 * x * (1 + torch.erf(x * 0.7071067811865476)), 1: torc
 
 @pytest.mark.parametrize("T", [1, 31, 33, 64, 65, 1000, 4097, 21248])
 @pytest.mark.parametrize("R,Cc_", [(128, 128), (256, 128), (128, 512), (512, 128), (384, 128)])
+@ARITHS
 @pytest.mark.parametrize("act", [-1, 0, 1, 2, 3, 4])
-def test_gemm_tn_128_tile_shapes(T, R, Cc_, act):
+def test_gemm_tn_128_tile_shapes(T, R, Cc_, act, arith):
     """The d = 128-class weight-gradient shapes (R, Cc multiples of 128): every activation on the Q operand, token counts around the
-    32-token stage and the split boundaries, strided operands.  (Written for round 5's 128 x 128 LDS-DMA variant of the kernel --
-    profiles/r05_a_tn_big_counterexample.txt: measured, slower in situ, taken out -- and kept for the shipped 64 x 64 kernel.)"""
+    32-token stage and the split boundaries, strided operands -- in the exact fp32 arithmetic (64 x 64 tiles) and in the split-bf16
+    arithmetic (round 6: 128 x 128 tiles, 32-token stages, ragged last stage peeled)."""
     from unirec_amd._lib import check, lib
     if act >= 0 and (T, R) not in ((33, 128), (1000, 128), (21248, 128), (4097, 256)):
         pytest.skip("activations: a subset of the shapes")
@@ -128,3 +144,68 @@ def test_gemm_tn_128_tile_shapes(T, R, Cc_, act):
     ref = P64.T @ (_ACTS[act](Q64) if act >= 0 else Q64)
     _close(out, ref)
     _close(bo, P64.sum(0))
+
+
+@pytest.mark.parametrize("kind", ["randn", "grad-like", "cancelling"])
+@pytest.mark.parametrize("R,Cc_", [(384, 128), (128, 512)])
+def test_split_bf16_products_are_fp32_equivalent(R, Cc_, kind):
+    """VERDICT r5 item 1's gate, kept as a test: against an fp64 product of the SAME fp32 operands, the error of the six- and nine-term
+    split-bf16 arithmetic (max over outputs of |err| / sum_t |p q|, the fp32-roundoff yardstick) is at most 1.5 x the exact fp32-MFMA
+    kernel's -- and the three-term split, which IS narrower than fp32, fails that by an order of magnitude (so the yardstick can tell)."""
+    from unirec_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    T = 21248
+    g = torch.Generator(device=dev).manual_seed(R + Cc_)
+    if kind == "randn":
+        P, Q = torch.randn(T, R, device=dev, generator=g), torch.randn(T, Cc_, device=dev, generator=g)
+    elif kind == "grad-like":     # small gradients with column scales over four decades x swish activations
+        P = torch.randn(T, R, device=dev, generator=g) * (torch.exp(torch.randn(R, device=dev, generator=g) * 2.3) * 1e-5)
+        x = torch.randn(T, Cc_, device=dev, generator=g) * 3
+        Q = x * torch.sigmoid(x)
+    else:                         # the exact sum nearly cancels: the yardstick is ~1e3 x the result
+        P, Q = torch.randn(T, R, device=dev, generator=g), torch.randn(T, Cc_, device=dev, generator=g)
+        P[T // 2:] = -P[:T - T // 2] * (1 + 1e-3 * torch.randn(T - T // 2, R, device=dev, generator=g))
+        Q[T // 2:] = Q[:T - T // 2]
+    ref = P.double().T @ Q.double()
+    yard = P.double().abs().T @ Q.double().abs()
+    ws = torch.empty(int(lib.ur_gemm_tn_workspace_floats(T, R, Cc_)), device=dev)
+    err = {}
+    try:
+        for a in (0, 6, 9, 3):
+            check(lib.ur_set_mfma_arith(a), "ur_set_mfma_arith")
+            out = torch.full((R, Cc_), float("nan"), device=dev)
+            check(lib.ur_gemm_tn(_p(P), R, _p(Q), Cc_, T, R, Cc_, 0, 0, _p(out), Cc_, None, _p(ws), _st()), "ur_gemm_tn")
+            err[a] = float(((out.double() - ref).abs() / yard).max())
+    finally:
+        check(lib.ur_set_mfma_arith(0), "ur_set_mfma_arith")
+    assert err[0] < 1e-7                      # an fmaf chain over 21 248 products, split 32 ways
+    assert err[6] <= 1.5 * err[0], err
+    assert err[9] <= 1.5 * err[0], err
+    assert err[3] > 5 * err[0], err
+
+
+@ARITHS
+def test_gemm_tn_group_equals_one_product_at_a_time(arith):
+    """ur_gemm_tn_group (how the encoders' backward passes issue the products queued at one fork) == ur_gemm_tn per product up to the
+    summation order of the token splits (a group gives every product fewer splits), bias gradients included."""
+    from unirec_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    T = 5000
+    shapes = [(384, 128, 0), (128, 128, 0), (512, 128, 0), (128, 512, 1), (68, 36, 0)]
+    g = torch.Generator(device=dev).manual_seed(7)
+    n = len(shapes)
+    Ps = [torch.randn(T, R, device=dev, generator=g) for R, _, _ in shapes]
+    Qs = [torch.randn(T, c, device=dev, generator=g) for _, c, _ in shapes]
+    outs = [torch.full((R, c), float("nan"), device=dev) for R, c, _ in shapes]
+    bos = [torch.full((R,), float("nan"), device=dev) for R, _, _ in shapes]
+    wss = [torch.empty(int(lib.ur_gemm_tn_workspace_floats(T, R, c)), device=dev) for R, c, _ in shapes]
+    ap = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+    ai = lambda vs: (C.c_int * n)(*vs)  # noqa: E731
+    check(lib.ur_gemm_tn_group(n, ap(Ps), ai([R for R, _, _ in shapes]), ap(Qs), ai([c for _, c, _ in shapes]), ai([T] * n),
+                               ai([R for R, _, _ in shapes]), ai([c for _, c, _ in shapes]), ai([pa for _, _, pa in shapes]), ACT, ap(outs),
+                               ai([c for _, c, _ in shapes]), ap(bos), ap(wss), _st()), "ur_gemm_tn_group")
+    for (R, c, pa), P, Q, o, b in zip(shapes, Ps, Qs, outs, bos):
+        ref = P.double().T @ (_swish(Q.double()) if pa else Q.double())
+        _close(o, ref)
+        _close(b, P.double().sum(0))
+

@@ -85,13 +85,19 @@ MODEL_FIXTURES = sorted(os.path.basename(p)[:-4] for pat in ("g[578]_*.npz", "g1
                         if "fullsoftmax" not in p)
 
 
+@pytest.mark.parametrize("arith", [0x106, 0])
 @pytest.mark.parametrize("skip_padding", [1, 0])
 @pytest.mark.parametrize("last_row_only", [1, 0])
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
-def test_model_forward_backward_vs_reference_golden(name, last_row_only, skip_padding):
+def test_model_forward_backward_vs_reference_golden(name, last_row_only, skip_padding, arith):
+    """arith: UrSasrecCfg / UrGruCfg .mfma_arith -- 0x106 = the six-term split-bf16 weight-gradient kernel at EVERY shape (the default, 6,
+    keeps the exact kernel for these narrow test shapes), 0 = the exact fp32-input MFMA: the same goldens at the same tolerances."""
     cfg, g = load_golden(name)
     if cfg["model"] != "SASRec" and not (last_row_only and skip_padding):
         pytest.skip("last_row_only / skip_padding only exist for SASRec")
+    if arith == 0 and (cfg["model"] not in ("SASRec", "GRU") or not (last_row_only and skip_padding)):
+        pytest.skip("the exact arithmetic: once per encoder fixture")
+    cfg["mfma_arith"] = arith
     cfg["last_row_only"] = last_row_only   # 1: exact last-row specialisation of the final layer; 0: every row
     cfg["skip_padding"] = skip_padding     # 1: padded prefixes get no token rows (compact); 0: all B*L rows
     dev = _dev()

@@ -250,6 +250,7 @@ def test_rccl_transport_at_world_one():
     dev = torch.device("cuda:0")
     ops.comm_init(0, 1)
     assert ops.comm_world() == 1
+    assert ops.comm_count() == 1       # RCCL's own answer (ncclCommCount / ncclCommUserRank of both communicators)
     try:
         N, d = 3001, 32
         g = torch.Generator().manual_seed(3)

@@ -49,6 +49,7 @@ def test_fit_losses_follow_the_oracle(model_name, loss):
     P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     tr = Trainer(cfg, model)
     loader = BatchLoader(ds, cfg["batch_size"], device="cuda:0")
+    loader.loss_check_draws = int(loss in ("bpr", "ccl"))              # (what fit() sets: the reference's per-step random.random() of those losses)
     batches = [{k: v.cpu() for k, v in b.items()} for b in loader]     # the builder's stream is consumed here ...
     cfg2, ds2 = _setup(model_name, loss)                                # ... so rebuild an identical one for training
     tr.fit(BatchLoader(ds2, cfg["batch_size"], device="cuda:0"))

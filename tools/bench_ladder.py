@@ -35,8 +35,12 @@ RUNGS = [
 ]
 # seconds a phase may take before the rank group is aborted (x UR_BENCH_TIMEOUT_SCALE).  Generous: the first `import torch` on a fresh box
 # pages the image in for 1-2 minutes, a 100 M-row table plus optimizer state is ~150 GB of fills, RCCL's first communicator takes seconds
-LIMITS = {"start": 300.0, "init": 180.0, "setup": 420.0, "selfcheck": 300.0, "warmup": 180.0, "timed": 180.0, "post": 420.0}
+LIMITS = {"start": 300.0, "init": 180.0, "setup": 300.0, "selfcheck": 240.0, "warmup": 150.0, "timed": 150.0, "post": 300.0}
 PHASES = list(LIMITS)
+# ... and seconds a whole RUNG may take, whatever its phases do (x UR_BENCH_TIMEOUT_SCALE): four rungs that all hang end within
+# 480 + 280 + 180 + 140 s = 18 min, under the driver's 30-minute limit with a cold node's first `import torch` inside rung 0 (the later
+# rungs start with the image paged in and the file cache warm: a healthy rung takes 2-3 min on a cold node, ~1 min after)
+RUNG_BUDGET = [480.0, 280.0, 180.0, 140.0]
 
 
 # ---------------------------------------------------------------------------------------------------------------- worker side
@@ -163,6 +167,8 @@ def supervise(bench_py, argv, rank, world, out=sys.stdout):
                     result = ("peer failed", st[0])
                 elif time.time() - st[1] > LIMITS.get(st[0], 300.0) * scale:
                     result = ("hang", st[0])
+                elif time.time() - t_start > RUNG_BUDGET[min(k, len(RUNG_BUDGET) - 1)] * scale:
+                    result = ("over the rung's budget", st[0])
             if result[0] != "ok":
                 try:
                     with open(failed_flag, "a") as f:
@@ -187,7 +193,12 @@ def supervise(bench_py, argv, rank, world, out=sys.stdout):
                 f.write("ok" if ok else "failed")
             os.replace(verdict + ".tmp", verdict)
             who = {r: v for r, v in seen.items() if not v.startswith("ok")}
-            ladder.append({"rung": name, "ok": ok, **({"failed": who} if who else {})})
+            ladder.append({"rung": name, "ok": ok, "seconds": round(time.time() - t_start, 1), **({"failed": who} if who else {})})
+            # evidence after EVERY rung, in case the launch is killed before the ladder ends: a marked line (not the JSON line the
+            # contract asks for -- that one comes last, once) on both streams
+            note = "[bench-ladder partial] " + json.dumps({"n_gpus": world, "ladder": ladder})
+            print(note, file=out, flush=True)
+            print(note, file=sys.stderr, flush=True)
         else:
             deadline = time.time() + 90.0 * max(1.0, scale)
             while not os.path.exists(verdict) and time.time() < deadline:

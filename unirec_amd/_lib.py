@@ -26,7 +26,8 @@ class UrSasrecCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32), ("n_heads", C.c_int32),
                 ("inner", C.c_int32), ("n_layers", C.c_int32), ("act", C.c_int32), ("use_pos", C.c_int32),
                 ("eps", C.c_float), ("last_only", C.c_int32), ("skip_padding", C.c_int32),
-                ("p_hidden", C.c_float), ("p_attn", C.c_float), ("drop_seed", C.c_int64), ("drop_step", C.c_int64)]
+                ("p_hidden", C.c_float), ("p_attn", C.c_float), ("drop_seed", C.c_int64), ("drop_step", C.c_int64),
+                ("mfma_arith", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class UrConvFormerCfg(C.Structure):
@@ -52,7 +53,7 @@ class UrAdamCfg(C.Structure):
 
 class UrGruCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("d", C.c_int32), ("H", C.c_int32),
-                ("p_drop", C.c_float), ("drop_seed", C.c_int64), ("drop_step", C.c_int64)]
+                ("p_drop", C.c_float), ("drop_seed", C.c_int64), ("drop_step", C.c_int64), ("mfma_arith", C.c_int32), ("reserved_", C.c_int32)]
 
 
 P = C.c_void_p
@@ -95,6 +96,7 @@ SIGNATURES = {
     "ur_shard_exchange_grads": (C.c_int, [P, P, I32, I32, I32, P, P, P, P, I32, P]),
     "ur_shard_step_flags": (C.c_int, [P, I32, I32, I32, P, P]),
     "ur_comm_world": (C.c_int, []),
+    "ur_comm_count": (C.c_int, [P]),
     "ur_loop_create": (P, [I32]),
     "ur_loop_destroy": (C.c_int, [P]),
     "ur_loop_attach": (C.c_int, [P, I32]),

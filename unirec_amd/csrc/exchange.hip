@@ -194,6 +194,8 @@ struct Rccl {
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;       // (optional: only ur_comm_count needs them)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   bool ok = false;
 };
 Rccl* rccl() {
@@ -206,6 +208,7 @@ Rccl* rccl() {
     UR_SYM(GetUniqueId, "ncclGetUniqueId"); UR_SYM(CommInitRank, "ncclCommInitRank"); UR_SYM(CommDestroy, "ncclCommDestroy");
     UR_SYM(GroupStart, "ncclGroupStart"); UR_SYM(GroupEnd, "ncclGroupEnd"); UR_SYM(Send, "ncclSend"); UR_SYM(Recv, "ncclRecv");
     UR_SYM(AllReduce, "ncclAllReduce"); UR_SYM(GetErrorString, "ncclGetErrorString");
+    UR_SYM(CommCount, "ncclCommCount"); UR_SYM(CommUserRank, "ncclCommUserRank");
 #undef UR_SYM
     x->ok = x->GetUniqueId && x->CommInitRank && x->CommDestroy && x->GroupStart && x->GroupEnd && x->Send && x->Recv && x->AllReduce &&
             x->GetErrorString;
@@ -421,6 +424,25 @@ extern "C" int ur_comm_init(const void* id, int32_t rank, int32_t world) {
 }
 
 extern "C" int ur_comm_world(void) { return !rccl()->ok ? -1 : (g_comm.comm ? g_comm.world : 0); }
+
+// What RCCL ITSELF says about the library's communicators (ncclCommCount / ncclCommUserRank of each): out[0..1] = ranks in the row /
+// the ahead communicator, out[2..3] = this process's rank in them.  Returns the rank count both agree on, 0 when not initialised,
+// < 0 on error (no RCCL, the two communicators disagree, or they disagree with what ur_comm_init was told).
+extern "C" int ur_comm_count(int32_t* out4) {
+  UR_REQUIRE(rccl()->ok, UR_ERR_UNSUPPORTED, "ur_comm_count: no RCCL library in this process");
+  if (!g_comm.comm) return 0;
+  UR_REQUIRE(rccl()->CommCount && rccl()->CommUserRank, UR_ERR_UNSUPPORTED, "ur_comm_count: this RCCL exports no ncclCommCount / ncclCommUserRank");
+  int n[2] = {0, 0}, r[2] = {-1, -1};
+  UR_NCCL(rccl()->CommCount(g_comm.comm, &n[0]));
+  UR_NCCL(rccl()->CommCount(g_comm.comm2, &n[1]));
+  UR_NCCL(rccl()->CommUserRank(g_comm.comm, &r[0]));
+  UR_NCCL(rccl()->CommUserRank(g_comm.comm2, &r[1]));
+  if (out4) { out4[0] = n[0]; out4[1] = n[1]; out4[2] = r[0]; out4[3] = r[1]; }
+  UR_REQUIRE(n[0] == n[1] && n[0] == g_comm.world && r[0] == r[1] && r[0] == g_comm.rank, UR_ERR_ARG,
+             "ur_comm_count: RCCL reports %d / %d ranks (this process %d / %d), ur_comm_init was told rank %d of %d", n[0], n[1], r[0], r[1],
+             g_comm.rank, g_comm.world);
+  return n[0];
+}
 extern "C" int ur_loop_world(void) { return t_loop.g ? t_loop.g->world : 0; }
 
 extern "C" int ur_comm_destroy(void) {

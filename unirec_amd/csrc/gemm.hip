@@ -434,7 +434,7 @@ struct TnItem {
   float *out, *bias_out; int ldo;   // S == 1: the result itself
   int S, ntr, ntc, first_block;
 };
-struct TnGroup { static constexpr int MAX = 12; TnItem item[MAX]; int n; };
+struct TnGroup { static constexpr int MAX = 12; TnItem item[MAX]; int n; int pro_prio; };
 
 __global__ __launch_bounds__(256) void gemm_tn_group_kernel(TnGroup g, const float* __restrict__ zero_row) {
   int j = 0;
@@ -695,6 +695,7 @@ __device__ __forceinline__ void tn_split_wg(const TnItem& it, const int sp, cons
     if (trace && tid == 0 && tr < 62) trace[blockIdx.x * 64 + 2 + tr++] = (long long)__builtin_amdgcn_s_memtime();
   };
   // ---- prologue: stage 0 -> LDS; stages 1 and 2 on their way
+  if (trace && tid == 0) trace[blockIdx.x * 64 + 62] = wall_clock64();   // (100 MHz, the same counter on every CU)
   stamp();
   if (nfull > 0) {
     load_full(xa, 0);
@@ -764,7 +765,7 @@ __device__ __forceinline__ void tn_split_wg(const TnItem& it, const int sp, cons
     }
   }
   stamp();
-  if (trace && tid == 0) { trace[blockIdx.x * 64] = tr; trace[blockIdx.x * 64 + 1] = nt; }
+  if (trace && tid == 0) { trace[blockIdx.x * 64] = tr; trace[blockIdx.x * 64 + 1] = nt; trace[blockIdx.x * 64 + 63] = wall_clock64(); }
 }
 
 template <int NTERM>
@@ -781,6 +782,7 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_split_kernel(TnGroup g, const 
   if (sp >= S || tile >= ntiles) return;
   __shared__ __attribute__((aligned(16))) unsigned char smem[S_STAGE_BYTES];
   if (!it.pro_act) { tn_split_wg<NTERM, -1>(it, sp, tile, zero_row, smem, trace); return; }
+  if (g.pro_prio) __builtin_amdgcn_s_setprio(1);
   switch (it.act) {   // (one specialised loop per activation: the workgroup runs exactly one of them)
     case UR_ACT_GELU: tn_split_wg<NTERM, UR_ACT_GELU>(it, sp, tile, zero_row, smem, trace); break;
     case UR_ACT_RELU: tn_split_wg<NTERM, UR_ACT_RELU>(it, sp, tile, zero_row, smem, trace); break;
@@ -815,7 +817,14 @@ long long gemm_tn_group_ws_floats(int R, int Cc) { return (long long)TN_SPLIT_SM
 // bf16 pipes (fp32-equivalent; gemm_tn_split_kernel), 3 = a three-term split (NARROWER than fp32: error studies only).
 // Initial value: test hook tn_split=<n>; ur_set_mfma_arith overrides it.
 static std::atomic<int> g_mfma_arith{-1};
+static thread_local int g_arith_scope = -1;   // >= 0: the arithmetic of the encoder call in progress (UrSasrecCfg / UrGruCfg .mfma_arith)
+ArithScope::ArithScope(int terms) : prev(g_arith_scope) {
+  const int base = terms & 0xFF;
+  g_arith_scope = (base == 6 || base == 9 || base == 3) ? terms & 0x1FF : 0;
+}
+ArithScope::~ArithScope() { g_arith_scope = prev; }
 int mfma_arith() {
+  if (g_arith_scope >= 0) return g_arith_scope;
   int m = g_mfma_arith.load(std::memory_order_relaxed);
   if (m < 0) {
     m = ur_test_hook("tn_split", 0);
@@ -833,14 +842,18 @@ int set_mfma_arith(int m) {
 static int gemm_tn_group_split(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer, int nterm, const float* zeros) {
   // two 60 KB workgroups per CU; a workgroup should walk >= 8 stages between its cold prologue and its 64 KB partial-tile store
   const int target = ur_test_hook("tn_split_target", 512);
+  // a stage of a product whose Q operand takes the activation costs its staging waves ~1/3 more (measured: profiles/r06_*_tn_split_trace):
+  // such a product gets proportionally more, shorter splits, so that the workgroups of a launch end together
+  const double pro_cost = ur_test_hook("tn_split_procost", 135) * 0.01;
   TnGroup g{};
   g.n = n;
+  g.pro_prio = ur_test_hook("tn_split_proprio", 0);
   double work = 0.0, flops = 0.0;
   for (int i = 0; i < n; ++i) {
     const TnReq& q = req[i];
     if ((q.R & 3) || (q.Cc & 3) || (q.ldp & 3) || (q.ldq & 3) || (q.ldo & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
     if (q.T <= 0) return fail(UR_ERR_ARG, "gemm_tn: T=%d", q.T);
-    work += (double)cdiv(q.R, ST) * cdiv(q.Cc, ST) * q.T;
+    work += (double)cdiv(q.R, ST) * cdiv(q.Cc, ST) * q.T * (q.pro_act ? pro_cost : 1.0);
     flops += 2.0 * q.T * q.R * q.Cc;
   }
   const double rows_per = std::max(256.0, work / target);
@@ -850,7 +863,7 @@ static int gemm_tn_group_split(const TnReq* req, int n, hipStream_t st, ReduceBa
   for (int i = 0; i < n; ++i) {
     const TnReq& q = req[i];
     TnItem& it = g.item[i];
-    int S = (int)(q.T / rows_per + 0.5);
+    int S = (int)(q.T * (q.pro_act ? pro_cost : 1.0) / rows_per + 0.5);
     if (S > q.T / (2 * SBT)) S = q.T / (2 * SBT);
     if (S >= 6) S = std::min(TN_SPLIT_SMAX, (S + 4) / 8 * 8);
     if (S < 1) S = 1;
@@ -878,13 +891,18 @@ static int gemm_tn_group_split(const TnReq* req, int n, hipStream_t st, ReduceBa
       if (printed++ == 3 && hipStreamSynchronize(st) == hipSuccess) {
         std::vector<long long> h((size_t)blocks * 64);
         if (hipMemcpy(h.data(), trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
-          long long t0 = -1, t1 = 0;
-          for (int b = 0; b < blocks; ++b) if (h[b * 64] > 0) { if (t0 < 0 || h[b * 64 + 2] < t0) t0 = h[b * 64 + 2]; t1 = std::max(t1, h[b * 64 + 1 + h[b * 64]]); }
-          fprintf(stderr, "tn_split trace: %d workgroups, first stamp -> last stamp %lld ticks\n", blocks, t1 - t0);
-          for (int b = 0; b < blocks; b += std::max(1, blocks / 12)) {
+          long long w0 = -1, w1 = 0;
+          for (int b = 0; b < blocks; ++b) if (h[b * 64] > 0) { if (w0 < 0 || h[b * 64 + 62] < w0) w0 = h[b * 64 + 62]; w1 = std::max(w1, h[b * 64 + 63]); }
+          fprintf(stderr, "tn_split trace: %d workgroups, first start -> last end %.2f us (100 MHz wall clock)\n", blocks, (w1 - w0) * 0.01);
+          for (int b = 0; b < blocks; b += std::max(1, blocks / 24)) {
             const int n = (int)h[b * 64];
-            fprintf(stderr, "  wg %4d nt %2lld start %7lld :", b, h[b * 64 + 1], h[b * 64 + 2] - t0);
-            for (int k = 1; k < n; ++k) fprintf(stderr, " %lld", h[b * 64 + 2 + k] - h[b * 64 + 2 + k - 1]);
+            long long cyc = 0;
+            for (int k = 1; k < n; ++k) cyc += h[b * 64 + 2 + k] - h[b * 64 + 2 + k - 1];
+            fprintf(stderr, "  wg %4d nt %2lld  starts at %6.2f us, lives %6.2f us = %7lld shader ticks; prologue %lld, first trips", b, h[b * 64 + 1],
+                    (h[b * 64 + 62] - w0) * 0.01, (h[b * 64 + 63] - h[b * 64 + 62]) * 0.01, cyc, n > 1 ? h[b * 64 + 3] - h[b * 64 + 2] : 0);
+            for (int k = 2; k < std::min(n, 8); ++k) fprintf(stderr, " %lld", h[b * 64 + 2 + k] - h[b * 64 + 2 + k - 1]);
+            fprintf(stderr, " ... last");
+            for (int k = std::max(8, n - 5); k < n; ++k) fprintf(stderr, " %lld", h[b * 64 + 2 + k] - h[b * 64 + 2 + k - 1]);
             fprintf(stderr, "\n");
           }
         }
@@ -912,7 +930,18 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
   if (n > TnGroup::MAX) return fail(UR_ERR_ARG, "gemm_tn_group: %d products (max %d)", n, TnGroup::MAX);
   const float* zeros = tn_zero_buf();
   if (!zeros) return fail(UR_ERR_HIP, "gemm_tn: no device memory for the zero row");
-  if (const int arith = mfma_arith()) return gemm_tn_group_split(req, n, st, defer, arith, zeros);
+  if (const int arith = mfma_arith()) {
+    // the split kernel works on 128 x 128 output tiles: products narrower than a tile (d = 64 models) would stage and multiply padding --
+    // inside an encoder call they keep the exact kernel's 64 x 64 tiles unless the cfg says 0x100 | terms ("every shape": the unit
+    // tests); the raw hooks (ur_gemm_tn / ur_gemm_tn_group under ur_set_mfma_arith) take the split kernel at every shape
+    double used = 0.0, tiled = 0.0;
+    for (int i = 0; i < n; ++i) {
+      used += (double)req[i].R * req[i].Cc * req[i].T;
+      tiled += (double)cdiv(req[i].R, ST) * cdiv(req[i].Cc, ST) * ST * ST * req[i].T;
+    }
+    const bool any = g_arith_scope < 0 || (arith & 0x100);
+    if (any || used >= 0.7 * tiled) return gemm_tn_group_split(req, n, st, defer, arith & 0xFF, zeros);
+  }
   // workgroups per launch (~3 per CU: 32 KB of LDS each).  Measured at C5 (profiles/r03_a_dw_schedule.txt): 288 -> 0.681 ms/step, 576 ->
   // 0.660, 864 -> 0.658, 1152+ -> 0.665 -- short workgroups give the CUs back to the main stream's kernels sooner
   constexpr int target = 864;

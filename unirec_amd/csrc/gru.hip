@@ -766,6 +766,7 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
                           const int32_t* item_seq, const float* d_user_emb, void* ws, float* dense_grad, float* d_emb_rows,
                           void* stream) {
   UR_TRACE_SCOPE();
+  const ur::ArithScope arith_scope(cfg ? cfg->mfma_arith : 0);   // (the weight-gradient products of this pass: gemm.hip)
   int rc = gru_check(cfg);
   if (rc) return rc;
   UR_REQUIRE(dense && d_user_emb && ws && dense_grad && d_emb_rows, UR_ERR_ARG, "ur_gru_bwd: null pointer");

@@ -115,6 +115,8 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer = 
 // arithmetic of the dense contractions: 0 = exact fp32 MFMA, 6 / 9 = split-bf16 terms (fp32-equivalent), 3 = error studies only
 int mfma_arith();
 int set_mfma_arith(int terms);
+// the arithmetic of ONE encoder call (its cfg's mfma_arith field) for every product the calling thread launches inside the scope
+struct ArithScope { int prev; explicit ArithScope(int terms); ~ArithScope(); ArithScope(const ArithScope&) = delete; ArithScope& operator=(const ArithScope&) = delete; };
 // dst[c,r] = src[r,c]
 int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
 struct TransposeItem { const float* src; float* dst; int rows, cols, first_block; };

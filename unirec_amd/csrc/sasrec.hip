@@ -554,6 +554,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   UR_REQUIRE(check_forward(ws, dense, item_seq, c) != 1, UR_ERR_ARG,
              "ur_sasrec_bwd: the last ur_sasrec_fwd on this workspace saw other weights / ids / shapes (the backward pass reads what it left there)");
   hipStream_t st = as_stream(stream);
+  const ArithScope arith_scope(c.mfma_arith);   // (the weight-gradient products of this pass: gemm.hip)
   if ((rc = ur_sasrec_bwd_join(stream))) return rc;   // (a deferred pass nobody joined)
   const Layout lay = make_layout(c);
   Ws w = carve(c, (float*)ws);

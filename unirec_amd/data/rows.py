@@ -89,6 +89,11 @@ class HostRowBuilder:
     def randint(self, a, b):
         return lib.ur_host_sampler_randint(self._h, a, b)
 
+    def random(self):
+        """``random.random()`` of the stream (53 bits from two 32-bit words, as CPython): what the reference's loss draws once per training
+        forward for its 10 % label check (unirec/model/base/reco_abc.py:240) -- from the SAME global stream its samplers use"""
+        return float(lib.ur_host_sampler_random(self._h))
+
     def build(self, user_id, pos_item, with_seq=True):
         """-> dict(user_id int64[n], item_id int64[n,G], label int32[n,G], item_seq int32[n,L], item_seq_len int64[n])."""
         user_id = np.ascontiguousarray(user_id, dtype=np.int64)

@@ -180,6 +180,12 @@ class ShardedSparseDenseAdam(SparseDenseAdam):
         if (world > 1 and dev.type == "cuda" and dist.get_backend(group) == "nccl" and ops.comm_world() >= 0
                 and os.environ.get("UR_NATIVE_TRANSPORT", "1") not in ("", "0")):
             self._native = bool(ops.comm_init(rank, world, group)) and self._native_selftest(dev)
+        elif (world == 1 and dev.type == "cuda" and self._loop is None and os.environ.get("UR_NATIVE_W1", "0") not in ("", "0")
+              and os.environ.get("UR_NATIVE_TRANSPORT", "1") not in ("", "0") and ops.comm_world() >= 0):
+            # one rank through the library's RCCL communicators (every exchange a send / recv to itself, the all-reduce the identity):
+            # what a one-GPU box can execute of the multi-GPU transport (bench.py --gpus 1 --supervised; there is no second route to
+            # compare with at world 1, so no self-test)
+            self._native = bool(ops.comm_init(0, 1))
         self._bufs = {}                   # (table, n, n_a, parity) -> preallocated exchange buffers
         self._look = None                 # _Look of the next batch (plan stream)
         self._parity = 0

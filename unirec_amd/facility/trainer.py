@@ -25,6 +25,11 @@ class BatchLoader:
     def __init__(self, dataset, batch_size, shuffle=False, seed=2022, rank=0, world=1, device="cuda:0"):
         self.dataset, self.batch_size, self.shuffle, self.seed = dataset, batch_size, shuffle, seed
         self.rank, self.world, self.device, self.epoch = rank, world, torch.device(device), 0
+        # 1: one ``random()`` is drawn from the row builder's stream behind every batch.  The reference's BPR / CCL loss draws
+        # ``random.random()`` once per training forward (its 10 % label check, unirec/model/base/reco_abc.py:238-246) from the process-global
+        # stream its negative sampler and history cut use, i.e. in the middle of the row stream (__iter__ says where): Trainer.fit sets this
+        # for those losses, so the sampled negatives stay the reference's over a whole run (tests/golden/g10_trainer_fit_{gru,mf_c1})
+        self.loss_check_draws = 0
 
     def __len__(self):
         nb = (len(self.dataset) + self.batch_size - 1) // self.batch_size
@@ -37,10 +42,24 @@ class BatchLoader:
         nb = (n + self.batch_size - 1) // self.batch_size
         # every rank takes the same number of steps (the step is collective): a rank whose share runs out wraps around to
         # the first batches, as Accelerate's even_batches default does
+        draws = bool(self.loss_check_draws) and hasattr(self.dataset, "_builder")
+        held = None
         for k in range((nb + self.world - 1) // self.world):
             b = (k * self.world + self.rank) % nb
             rows = self.dataset.get_batch(order[b * self.batch_size:(b + 1) * self.batch_size])
-            yield {k: torch.from_numpy(v).to(self.device, non_blocking=True) for k, v in rows.items()}
+            batch = {k: torch.from_numpy(v).to(self.device, non_blocking=True) for k, v in rows.items()}
+            if not draws:
+                yield batch
+                continue
+            # the reference trains through Accelerate's DataLoaderShard, which builds batch i + 1 BEFORE it hands out batch i (it looks one
+            # batch ahead to flag the last one), so the loss's draw of step i lands between the rows of batch i + 1 and those of batch i + 2
+            if held is not None:
+                yield held
+                self.dataset._builder().random()
+            held = batch
+        if held is not None:
+            yield held
+            self.dataset._builder().random()
 
 
 class DeviceBatchLoader:
@@ -348,9 +367,14 @@ class Trainer(object):
                 # must never read a batch the plan stream has not built yet
                 borrowed = (train_data.stream, train_data.joined)
                 train_data.use_stream(self.optimizer.plan_stream(), joined=self.world == 1)
+            draws = getattr(train_data, "loss_check_draws", None)
+            if draws is not None and self.model.loss_type in ("bpr", "ccl"):
+                train_data.loss_check_draws = 1     # (the reference's per-step random.random(): see BatchLoader)
             try:
                 epoch_sum, n_nan = self._run_epoch(train_data)
             finally:
+                if draws is not None:
+                    train_data.loss_check_draws = draws
                 if borrowed is not None:
                     train_data.stream, train_data.joined = borrowed
             if n_nan:

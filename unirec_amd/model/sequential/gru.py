@@ -43,7 +43,7 @@ class GRU(BaseRecommender):
             object.__setattr__(self, "_drop_step", getattr(self, "_drop_step", 0) + 1)
         return ops.gru_cfg(B, self.config["max_seq_len"], self.embedding_size, self.hidden_size, p_drop=p if drop else 0.0,
                            drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0),
-                           drop_step=getattr(self, "_drop_step", 0))
+                           drop_step=getattr(self, "_drop_step", 0), mfma_arith=self.config.get("mfma_arith"))
 
     def _workspace(self, cfg, train=False):
         return self._ws_slot(cfg.B, train, lambda: ops.gru_workspace(cfg, self.device))

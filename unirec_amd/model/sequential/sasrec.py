@@ -62,7 +62,8 @@ class SASRec(BaseRecommender):
                               last_only=int(self.config.get("last_row_only", 1)),
                               skip_padding=int(self.config.get("skip_padding", 1)),
                               p_hidden=self.hidden_dropout_prob if drop else 0.0, p_attn=self.attn_dropout_prob if drop else 0.0,
-                              drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0), drop_step=self._drop_step)
+                              drop_seed=int(self.config.get("dropout_seed", self.config.get("seed", 0)) or 0), drop_step=self._drop_step,
+                              mfma_arith=self.config.get("mfma_arith"))
 
     def _workspace(self, cfg, train=False):
         def alloc():

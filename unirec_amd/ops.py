@@ -2,6 +2,7 @@
 HIP stream.  PyTorch is only the allocator / stream provider here; all arithmetic is in the HIP library.
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -59,14 +60,30 @@ def embedding_gather(table: torch.Tensor, idx: torch.Tensor, out: torch.Tensor =
 
 
 # --------------------------------------------------------------------------------------------- SASRec
+def default_mfma_arith() -> int:
+    """Arithmetic of the weight-gradient products when a model's config does not say (``mfma_arith``): 6 = the fp32 operands split
+    exactly into three bf16 pieces, six piece products accumulated in fp32 on the bf16 matrix pipes (fp32-equivalent; include/
+    unirec_amd.h: ur_set_mfma_arith); ``UR_MFMA_ARITH=0`` (or 9) in the environment selects the exact fp32-input MFMA (all nine terms)."""
+    v = os.environ.get("UR_MFMA_ARITH", "")
+    return int(v) if v in ("0", "6", "9") else 6
+
+
+def _arith(v) -> int:
+    v = default_mfma_arith() if v is None else int(v)
+    if (v & 0xFF) not in (0, 3, 6, 9) or v & ~0x1FF:
+        raise ValueError(f"mfma_arith={v}: 0 (exact fp32 MFMA), 6 or 9 (split-bf16 terms); + 0x100 = also for products narrower than the "
+                         "split kernel's 128 x 128 tile (unit tests)")
+    return v
+
+
 def sasrec_cfg(B, L, d, n_heads, inner, n_layers, act, use_pos, eps, last_only=1, skip_padding=1, p_hidden=0.0, p_attn=0.0,
-               drop_seed=0, drop_step=0) -> UrSasrecCfg:
+               drop_seed=0, drop_step=0, mfma_arith=None) -> UrSasrecCfg:
     """last_only=1: exact last-row specialisation of the final layer (only position L-1 reaches the loss).
     skip_padding=1: padded prefixes get no token rows (exact; applies when L <= 64 and head dim is 4/8/16).
     p_hidden / p_attn: training-time dropout; the mask is a function of (drop_seed, drop_step), the backward must get the
     same cfg as the forward."""
     return UrSasrecCfg(B, L, d, n_heads, inner, n_layers, ACT_IDS[act], int(bool(use_pos)), float(eps), int(last_only), int(skip_padding),
-                       float(p_hidden), float(p_attn), int(drop_seed), int(drop_step))
+                       float(p_hidden), float(p_attn), int(drop_seed), int(drop_step), _arith(mfma_arith), 0)
 
 
 def sasrec_param_layout(cfg: UrSasrecCfg):
@@ -155,8 +172,8 @@ def sasrec_side_join():
 
 
 # --------------------------------------------------------------------------------------------- GRU
-def gru_cfg(B, L, d, H, p_drop=0.0, drop_seed=0, drop_step=0):
-    return _lib.UrGruCfg(B, L, d, H, float(p_drop), int(drop_seed), int(drop_step))
+def gru_cfg(B, L, d, H, p_drop=0.0, drop_seed=0, drop_step=0, mfma_arith=None):
+    return _lib.UrGruCfg(B, L, d, H, float(p_drop), int(drop_seed), int(drop_step), _arith(mfma_arith), 0)
 
 
 def gru_param_layout(cfg):
@@ -374,6 +391,15 @@ def compact_index(pl: RowsPlan, slot_of_uniq=None, out=None):
 def comm_world():
     """-1: no RCCL library in the process, 0: the library's communicator is not initialised, else its size."""
     return int(lib.ur_comm_world())
+
+
+def comm_count():
+    """RCCL's OWN rank count of the library's two communicators (ncclCommCount of each; raises if they disagree with each other or with
+    comm_init's arguments); 0: not initialised (the torch.distributed / loopback routes carry the exchange)."""
+    if comm_world() <= 0:
+        return 0
+    out = (C.c_int32 * 4)()
+    return check(lib.ur_comm_count(out), "ur_comm_count")
 
 
 def comm_init(rank, world, group=None):

@@ -366,7 +366,7 @@ NOT_OPS = {
     "ur_gemm_nt": _HOOK, "ur_gemm_tn": _HOOK, "ur_gemm_tn_group": _HOOK, "ur_debug_delay": _HOOK,
     "ur_sasrec_bwd_deferred": _PLUMB, "ur_sasrec_bwd_join": _PLUMB, "ur_stream_wait_stream": _PLUMB, "ur_sasrec_side_stream": _PLUMB, "ur_sasrec_side_publish": _PLUMB,
     "ur_rows_plan_merge": _SHARD, "ur_rows_plan_sharded": _SHARD, "ur_compact_index": _SHARD, "ur_full_rank_shard": _SHARD,
-    "ur_shard_step_flags": _SHARD, "ur_comm_world": _COMM, "ur_loop_create": _COMM, "ur_loop_destroy": _COMM, "ur_loop_attach": _COMM, "ur_loop_detach": _COMM,
+    "ur_shard_step_flags": _SHARD, "ur_comm_world": _COMM, "ur_comm_count": _COMM, "ur_loop_create": _COMM, "ur_loop_destroy": _COMM, "ur_loop_attach": _COMM, "ur_loop_detach": _COMM,
     "ur_loop_world": _COMM, "ur_loop_post": _COMM, "ur_loop_all_to_all_pull": _COMM, "ur_loop_all_reduce_pull": _COMM, "ur_loop_finish": _COMM, "ur_comm_unique_id": _COMM, "ur_comm_init": _COMM, "ur_comm_destroy": _COMM, "ur_comm_all_reduce_sum": _COMM,
     "ur_comm_all_to_all": _COMM, "ur_shard_fixup_plan": _SHARD, "ur_shard_fixup_apply": _SHARD, "ur_rows_split_hot": _SHARD,
     "ur_rows_reduce_riders": "ur_rows_reduce + the flag rows / step flags of the row-sharded step riding in the same launch: a scheduling variant of the registered ops rows_reduce and a2a_embedding_grads",
