@@ -181,43 +181,46 @@ def cpu_baseline(a):
         P[pre + "feed_forward.LayerNorm.weight"] = torch.ones(d)
         P[pre + "feed_forward.LayerNorm.bias"] = torch.zeros(d)
     P["item_embedding.weight"][0].zero_()
-    B, G = a.batch, a.negatives + 1
-    seq = torch.randint(1, N, (B, L), generator=g, dtype=torch.int32)
-    lens = torch.randint(5, L + 1, (B,), generator=g)
-    seq = torch.where(torch.arange(L).unsqueeze(0) >= (L - lens).unsqueeze(1), seq, torch.zeros_like(seq))
-    label = torch.zeros(B, G, dtype=torch.int32)
-    label[:, 0] = 1
-    batch = dict(item_seq=seq, item_id=torch.randint(1, N, (B, G), generator=g), label=label,
-                 user_id=torch.ones(B, dtype=torch.int64))
+    B = a.batch
+    # the protocol of BASELINE.md 3 / SURVEY.md 8(d): 5 warm-up steps, then >= 20 timed steps, one DISTINCT batch per step drawn by the
+    # generator the GPU run's batches come from (synth_batches, same seed; ids over the reduced table), median + p10 / p90 of the step times
+    n_warm, n_timed = 5, 20
+    batches = [dict(b, user_id=torch.ones(B, dtype=torch.int64)) for b in synth_batches(a, N, torch.device("cpu"), 2022, n_batches=n_warm + n_timed + 8)]
     state = {}
-    # pick the thread count torch-CPU actually runs fastest with on this host (all cores is often NOT it)
-    best = None
-    budget0 = time.perf_counter()
+    # pick the thread count torch-CPU actually runs fastest with on this host (all cores is often NOT it): one probe step each
+    best, probe = None, 0
     for th in sorted({min(avail, 16), min(avail, 32), min(avail, 64), avail}):
         torch.set_num_threads(th)
-        model_ref.train_step(P, state, batch, cfg)  # warm-up at this thread count
+        model_ref.train_step(P, state, batches[probe], cfg)      # (first step at this thread count: pool start-up)
         t0 = time.perf_counter()
-        model_ref.train_step(P, state, batch, cfg)
+        model_ref.train_step(P, state, batches[probe + 1], cfg)
         one = time.perf_counter() - t0
+        probe += 2
         if best is None or one < best[1]:
             best = (th, one)
         elif one > 1.2 * best[1]:
             break  # past the sweet spot: more threads only oversubscribe
-        if time.perf_counter() - budget0 > 25.0:
-            break
     cores = best[0]
     torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    n = 0
-    while n < 3 or (time.perf_counter() - t0 < 12.0 and n < 40):
-        model_ref.train_step(P, state, batch, cfg)
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return {"value": round(B / dt, 1), "unit": "examples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of oracle/model_ref.train_step (reference semantics: dense [N,d] embedding gradient + dense Adam), "
-                      f"B={B}, L={L}, d={d}, K={a.negatives}, table reduced to N={N} rows (dense Adam is O(N): {dt * 1e3:.0f} ms/step here, "
-                      f"would be ~{dt * 1e3 * a.n_items / N:.0f} ms/step at N={a.n_items} by per-row extrapolation); "
-                      f"{cores} torch threads (fastest of the counts tried, {avail} cores available); torch {torch.__version__} CPU"}
+    rest = batches[probe:]
+    for b in rest[:n_warm]:
+        model_ref.train_step(P, state, b, cfg)
+    times = []
+    for b in rest[n_warm:n_warm + n_timed]:
+        t0 = time.perf_counter()
+        model_ref.train_step(P, state, b, cfg)
+        times.append(time.perf_counter() - t0)
+    ts = sorted(times)
+    med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+    p10, p90 = ts[int(0.1 * (len(ts) - 1))], ts[int(round(0.9 * (len(ts) - 1)))]
+    return {"value": round(B / med, 1), "unit": "examples/s", "cores": cores, "kind": "port",
+            "protocol": {"warmup_steps": n_warm, "timed_steps": len(ts), "statistic": "median of the per-step wall times", "distinct_batches": True,
+                         "ms_per_step_median": round(med * 1e3, 1), "ms_per_step_p10": round(p10 * 1e3, 1), "ms_per_step_p90": round(p90 * 1e3, 1),
+                         "examples_per_s_p10_p90": [round(B / p90, 1), round(B / p10, 1)]},
+            "sample": f"{len(ts)} timed steps (after {n_warm} warm-ups, one distinct batch each) of oracle/model_ref.train_step (reference semantics: "
+                      f"dense [N,d] embedding gradient + dense Adam), B={B}, L={L}, d={d}, K={a.negatives}, table reduced to N={N} rows (dense Adam "
+                      f"is O(N): {med * 1e3:.0f} ms/step here, would be ~{med * 1e3 * a.n_items / N:.0f} ms/step at N={a.n_items} by per-row "
+                      f"extrapolation); {cores} torch threads (fastest of the counts probed, {avail} cores available); torch {torch.__version__} CPU"}
 
 
 def loopback_leg(a, device, W):

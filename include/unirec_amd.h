@@ -594,6 +594,27 @@ int ur_device_build_seq(const int64_t* user_id, const int64_t* item_id, int32_t 
                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The same rows on the REFERENCE's random stream, on the device (round 6).  The reference draws negatives and history cuts from one
+ * process-global CPython `random` (MT19937) stream, row after row (unirec/data/transform/addnegsamples.py:75-115: up to 100 x
+ * random.randint(1, n_items - 1) per negative; adduserhistory.py:32-73: random.choice of the occurrence to cut at).  ur_mt_build_rows walks
+ * THAT stream (csrc/mt_sampler.hip: block-parallel twist, acceptable words indexed by a prefix count, a speculative row chain, exact
+ * replay of the rare rows with a rejected candidate): item_id / label equal ur_host_build_rows' and the reference DataLoader's bit for bit.
+ *   state  uint32[626] device: mt[624], position (624 = twist first), sticky error (workspace exhausted); initialise it with
+ *          ur_host_sampler_state of a host sampler seeded like random.seed(s).  Advanced by exactly the words the reference consumes.
+ *   want_cut = 1: 'autoregressive' masking with seq_last = 0 -- choice[B] receives the index (history order) of the occurrence each row's
+ *          history is cut before (-1: none), to be passed to ur_device_build_seq_choice.
+ *   ws     ur_mt_workspace_bytes(B, K, n_items, want_cut) bytes. */
+int ur_host_sampler_state(void* sampler, uint32_t* out625);      /* mt[624] + position of a host sampler (host memory) */
+int64_t ur_mt_workspace_bytes(int32_t B, int32_t K, int64_t n_items, int32_t want_cut);
+int ur_mt_build_rows(uint32_t* state, const int64_t* user_id, const int64_t* pos_item, int32_t B, int32_t K, int64_t n_items,
+                     int64_t n_users, const int64_t* hist_ptr, const int32_t* hist_items, const int32_t* hist_sorted,
+                     int32_t reject_history, int32_t want_cut, int64_t* item_id, int32_t* label, int32_t* choice, void* ws,
+                     void* stream);
+int ur_device_build_seq_choice(const int64_t* user_id, const int64_t* item_id, int32_t B, int32_t G, int64_t n_users,
+                               const int64_t* hist_ptr, const int32_t* hist_items, int32_t mask_mode, int32_t seq_last,
+                               int32_t match_all, int32_t L, const int32_t* choice, int32_t* item_seq, int64_t* seq_len, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The two fp32-MFMA GEMM kernels of the encoders, exposed for unit tests and micro-benchmarks.
  *   ur_gemm_nt: C[M,N] = epi( pro(A)[M,K] @ W[N,K]^T )  == nn.Linear (unirec/model/modules.py:285-287,312,347-350)
  *     pro: 0 none, 1 activation `act` on A;  epi: 0 none, 1 +bias[N], 2 LayerNorm(acc+bias+aux) (writes xhat, rstd; N<=256),

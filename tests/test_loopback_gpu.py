@@ -179,3 +179,26 @@ def test_capacity_overflow_replay_in_lockstep_on_the_loopback(world):
     _run_ranks(world, fn)
     assert len({o[0] for o in out}) == 1, [o[0] for o in out]             # lockstep: every rank doubled at the same steps
     assert all(torch.equal(out[0][1], o[1]) for o in out[1:])              # the replicas stayed identical through the skips
+
+
+def test_bench_loopback_at_the_true_w8_shapes_of_c5():
+    """`bench.py --loopback 8` -- eight rank threads on this one GPU, each with its shard of the 100 M-row table and its
+    optimizer state (8 x 19 GB), the sharded step's real schedule at the W = 8 shapes of BASELINE's C5 (28 161 lookups per rank,
+    cap = 4 416, cap2 = 576, eight-run merge plans): finite loss, no capacity overflow."""
+    import json
+    import math
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--loopback", "8", "--steps", "5", "--warmup", "3"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    lb = json.loads(lines[0])["loopback"]
+    assert lb["ranks"] == 8 and lb["steps"] == 5 and lb["overflows"] == 0
+    assert math.isfinite(lb["final_loss_rank0"]) and 0.0 < lb["final_loss_rank0"] < 5.0
+    assert lb["cap"] == 4416 and lb["cap2"] == 576          # the shapes DESIGN.md section 7 quotes

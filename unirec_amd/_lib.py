@@ -132,6 +132,10 @@ SIGNATURES = {
     "ur_host_sampler_destroy": (None, [P]),
     "ur_host_sampler_getrandbits": (C.c_uint64, [P, C.c_int]),
     "ur_host_sampler_random": (C.c_double, [P]),
+    "ur_host_sampler_state": (C.c_int, [P, P]),
+    "ur_mt_workspace_bytes": (I64, [C.c_int32, C.c_int32, I64, C.c_int32]),
+    "ur_mt_build_rows": (C.c_int, [P, P, P, C.c_int32, C.c_int32, I64, I64, P, P, P, C.c_int32, C.c_int32, P, P, P, P, P]),
+    "ur_device_build_seq_choice": (C.c_int, [P, P, C.c_int32, C.c_int32, I64, P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P, P]),
     "ur_host_sampler_randint": (I64, [P, I64, I64]),
     "ur_host_sampler_set_alias": (C.c_int, [P, P, I64]),
     "ur_host_build_rows": (C.c_int, [P, P, P, I64, I64, I64, I32, P, P, P, I32, I32, I32, I32, P, P, P]),

@@ -93,6 +93,13 @@ extern "C" void* ur_host_sampler_create(uint64_t seed) {
 extern "C" void ur_host_sampler_destroy(void* h) { delete (Sampler*)h; }
 extern "C" uint64_t ur_host_sampler_getrandbits(void* h, int k) { return ((Sampler*)h)->rng.getrandbits(k); }
 extern "C" double ur_host_sampler_random(void* h) { return ((Sampler*)h)->rng.random(); }
+extern "C" int ur_host_sampler_state(void* h, uint32_t* out625) {
+  UR_REQUIRE(h && out625, UR_ERR_ARG, "ur_host_sampler_state: null pointer");
+  const MT& r = ((Sampler*)h)->rng;
+  memcpy(out625, r.mt, sizeof(r.mt));
+  out625[624] = (uint32_t)r.idx;
+  return UR_OK;
+}
 extern "C" int64_t ur_host_sampler_randint(void* h, int64_t a, int64_t b) { return a + (int64_t)((Sampler*)h)->rng.randbelow((uint64_t)(b - a + 1)); }
 
 // Alias table as unirec/utils/sampling.py:9-24 builds it (same traversal order => same table): odds[i] in [0,1], alias[i]

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void build_seq_kernel(const long long* __restr
                                                         int B, int G, long long n_users, const long long* __restrict__ hist_ptr,
                                                         const int* __restrict__ hist_items, int mask_mode, int seq_last, int match_all,
                                                         int L, uint32_t seed_lo, uint32_t seed_hi, uint32_t step,
-                                                        int* __restrict__ item_seq, long long* __restrict__ seq_len) {
+                                                        int* __restrict__ item_seq, long long* __restrict__ seq_len,
+                                                        const int* __restrict__ choice) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;   // wave-uniform
@@ -119,7 +120,9 @@ __global__ __launch_bounds__(256) void build_seq_kernel(const long long* __restr
     }
     if (count > 0) {
       int t = count - 1;
-      if (!seq_last) {
+      if (!seq_last && choice) {
+        t = min(max(choice[b], 0), count - 1);   // the occurrence the MT19937 stream chose (ur_mt_build_rows): random.choice(n)
+      } else if (!seq_last) {
         uint32_t w[4];
         philox4x32_10(step, (uint32_t)b, 0xFFFFFFFFu, 0u, seed_lo, seed_hi, w);
         t = (int)(((unsigned long long)w[0] * (unsigned)count) >> 32);
@@ -198,7 +201,26 @@ extern "C" int ur_device_build_seq(const int64_t* user_id, const int64_t* item_i
   ProfScope ps(PC_MISC, st, (double)B * L * 4.0);
   hipLaunchKernelGGL(build_seq_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, (const long long*)user_id, (const long long*)item_id, B, G,
                      (long long)n_users, (const long long*)hist_ptr, hist_items, mask_mode, seq_last, match_all, L,
-                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step, item_seq, (long long*)seq_len);
+                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step, item_seq, (long long*)seq_len, (const int*)nullptr);
+  UR_LAUNCH_CHECK();
+  return UR_OK;
+}
+
+// the same rows with the cut chosen by the caller: choice[b] = index (history order) of the occurrence the history is cut before -- what
+// ur_mt_build_rows drew from the reference's MT19937 stream for row b
+extern "C" int ur_device_build_seq_choice(const int64_t* user_id, const int64_t* item_id, int32_t B, int32_t G, int64_t n_users,
+                                          const int64_t* hist_ptr, const int32_t* hist_items, int32_t mask_mode, int32_t seq_last,
+                                          int32_t match_all, int32_t L, const int32_t* choice, int32_t* item_seq, int64_t* seq_len,
+                                          void* stream) {
+  UR_TRACE_SCOPE();
+  UR_REQUIRE(user_id && item_id && hist_ptr && hist_items && item_seq && choice, UR_ERR_ARG, "ur_device_build_seq_choice: null pointer");
+  UR_REQUIRE(B > 0 && G > 0 && L > 0 && n_users >= 0, UR_ERR_ARG, "ur_device_build_seq_choice: B=%d G=%d L=%d", B, G, L);
+  UR_REQUIRE(mask_mode >= 0 && mask_mode <= 2, UR_ERR_ARG, "ur_device_build_seq_choice: mask_mode=%d", mask_mode);
+  hipStream_t st = as_stream(stream);
+  ProfScope ps(PC_MISC, st, (double)B * L * 4.0);
+  hipLaunchKernelGGL(build_seq_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, (const long long*)user_id, (const long long*)item_id, B, G,
+                     (long long)n_users, (const long long*)hist_ptr, hist_items, mask_mode, seq_last, match_all, L, 0u, 0u, 0u, item_seq,
+                     (long long*)seq_len, choice);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }

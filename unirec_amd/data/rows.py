@@ -166,8 +166,19 @@ class DeviceRowBuilder:
     MASK = {"unorder": 0, "autoregressive": 1}
 
     def __init__(self, n_users, n_items, n_neg, max_seq_len=0, history: HistoryCSR = None, reject_history=True,
-                 mask_mode="autoregressive", seq_last=0, seed=2022, device="cuda:0", item_popularity=None, neg_by_pop_alpha=1.0):
+                 mask_mode="autoregressive", seq_last=0, seed=2022, device="cuda:0", item_popularity=None, neg_by_pop_alpha=1.0,
+                 rng="philox"):
+        """rng="philox" (default): counter-based, order independent, 22 M rows/s.  rng="mt19937": the REFERENCE's stream -- CPython's
+        `random` seeded like ``random.seed(seed)``, walked on the device row after row (ur_mt_build_rows): negatives and history cuts equal
+        the reference DataLoader's (and HostRowBuilder's) bit for bit; batches must be built in the order the reference reads them."""
         self.n_users, self.n_items, self.n_neg, self.L = n_users, n_items, n_neg, max_seq_len
+        if rng not in ("philox", "mt19937"):
+            raise ValueError(f"rng={rng!r}: 'philox' or 'mt19937'")
+        self.rng = rng
+        self._mt_state, self._mt_ws = None, {}
+        if rng == "mt19937" and item_popularity is not None:
+            raise NotImplementedError("popularity-biased negatives draw random.random() (two words a draw): only the host builder walks that on the "
+                                      "reference's stream; the device builder does with rng='philox'")
         self.alias = None
         if item_popularity is not None:       # popularity-biased negatives: the alias table lives in HBM
             odds, idx = alias_table(pop_sample_ratio(item_popularity, neg_by_pop_alpha))
@@ -183,6 +194,8 @@ class DeviceRowBuilder:
         self.step = step + 1
         dev = pos_item.device
         B, G = pos_item.numel(), self.n_neg + 1
+        if self.rng == "mt19937":
+            return self._build_mt(user_id, pos_item, with_seq and self.L > 0)
         item_id, label = sample_negatives_device(pos_item, self.n_neg, self.n_items, user_id,
                                                  self.history if self.reject else None, self.seed, step, alias=self.alias)
         out = dict(user_id=user_id, item_id=item_id, label=label)
@@ -198,5 +211,58 @@ class DeviceRowBuilder:
                                           self.seq_last, 0 if self.reject else 1, self.L, self.seed & 0xFFFFFFFFFFFFFFFF,
                                           step & 0xFFFFFFFF, p(seq), p(slen), ops._stream()),
                   "ur_device_build_seq")
+            out["item_seq"], out["item_seq_len"] = seq, slen
+        return out
+
+    # ---- the reference's MT19937 stream on the device
+    def mt_state(self, dev):
+        """uint32[626] on the device: mt[624], position, sticky error -- seeded like CPython's random.seed(seed) by the host sampler"""
+        if self._mt_state is None:
+            h = lib.ur_host_sampler_create(int(self.seed) & 0xFFFFFFFFFFFFFFFF)
+            st = np.zeros(626, dtype=np.uint32)
+            try:
+                check(lib.ur_host_sampler_state(h, st.ctypes.data_as(C.c_void_p)), "ur_host_sampler_state")
+            finally:
+                lib.ur_host_sampler_destroy(h)
+            self._mt_state = torch.from_numpy(st.view(np.int32)).to(dev)
+        return self._mt_state
+
+    def check(self):
+        """raise if a batch exhausted its workspace (the kernel then left the stream where it was): synchronises"""
+        if self._mt_state is not None and int(self._mt_state[625].item()) != 0:
+            raise RuntimeError("DeviceRowBuilder(rng='mt19937'): a batch needed more random words than its workspace holds")
+
+    def _build_mt(self, user_id, pos_item, with_seq):
+        dev = pos_item.device
+        B, K = pos_item.numel(), self.n_neg
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)  # noqa: E731
+        h = self.history
+        want_cut = int(with_seq and h is not None and self.mask_mode == 1 and not self.seq_last)
+        if with_seq and h is None:
+            raise RuntimeError("item_seq needs a user history")
+        key = (B, K, want_cut)
+        if key not in self._mt_ws:
+            nbytes = check(lib.ur_mt_workspace_bytes(B, K, self.n_items, want_cut), "ur_mt_workspace_bytes")
+            self._mt_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ptr = srt = items = None
+        if h is not None:
+            ptr, srt = h.to_device(dev)
+            items = h.items_to_device(dev)
+        user_id = user_id.contiguous()
+        pos_item = pos_item.contiguous()
+        item_id = torch.empty(B, K + 1, dtype=torch.int64, device=dev)
+        label = torch.empty(B, K + 1, dtype=torch.int32, device=dev)
+        choice = torch.empty(B, dtype=torch.int32, device=dev)
+        reject = int(self.reject and h is not None)
+        check(lib.ur_mt_build_rows(p(self.mt_state(dev)), p(user_id), p(pos_item), B, K, self.n_items, h.n_users if h is not None else 0,
+                                   p(ptr), p(items), p(srt), reject, want_cut, p(item_id), p(label), p(choice), p(self._mt_ws[key]),
+                                   ops._stream()), "ur_mt_build_rows")
+        out = dict(user_id=user_id, item_id=item_id, label=label)
+        if with_seq:
+            seq = torch.empty(B, self.L, dtype=torch.int32, device=dev)
+            slen = torch.empty(B, dtype=torch.int64, device=dev)
+            check(lib.ur_device_build_seq_choice(p(user_id), p(item_id), B, K + 1, h.n_users, p(ptr), p(items), self.mask_mode, self.seq_last,
+                                                 0 if reject else 1, self.L, p(choice), p(seq), p(slen), ops._stream()),
+                  "ur_device_build_seq_choice")
             out["item_seq"], out["item_seq_len"] = seq, slen
         return out

@@ -372,7 +372,8 @@ NOT_OPS = {
     "ur_rows_reduce_riders": "ur_rows_reduce + the flag rows / step flags of the row-sharded step riding in the same launch: a scheduling variant of the registered ops rows_reduce and a2a_embedding_grads",
     "ur_sumsq": _FAMILY + " (gradient-clipping helpers of the optimizer)", "ur_clip_coef": _FAMILY + " (gradient-clipping helpers)",
     "ur_clip_coef_guarded": _FAMILY + " (gradient-clipping helpers)",
-    "ur_sample_negatives_pop": _FAMILY + " (popularity-biased sampler)", "ur_device_build_seq": _FAMILY + " (device row builder)",
+    "ur_sample_negatives_pop": _FAMILY + " (popularity-biased sampler)", "ur_host_sampler_state": _HOST, "ur_mt_workspace_bytes": _QUERY,
+    "ur_mt_build_rows": _FAMILY + " (device row builder on the reference's MT19937 stream)", "ur_device_build_seq_choice": _FAMILY + " (device row builder)", "ur_device_build_seq": _FAMILY + " (device row builder)",
     "ur_convformer_fwd": _FAMILY, "ur_convformer_bwd": _FAMILY, "ur_atthist_fwd": _FAMILY, "ur_atthist_bwd": _FAMILY,
     "ur_pool_rows_fwd": _FAMILY, "ur_pool_rows_bwd": _FAMILY, "ur_full_softmax_fwd": _FAMILY, "ur_full_softmax_bwd": _FAMILY,
     "ur_full_softmax_fwd_shard": _SHARD, "ur_full_softmax_combine_shards": _SHARD, "ur_full_softmax_bwd_shard": _SHARD,
