@@ -526,6 +526,10 @@ def trainer_fit_leg(a, device, steps=200):
     losses = tr.step_losses[-steps:]
     out = {"ms_per_step": round(dt / steps * 1e3, 4), "examples_per_s": round(a.batch * steps / dt, 1), "steps": steps,
            "final_loss": round(float(losses[-1]), 6) if losses else None, "flush_ms_once": round(dt_flush * 1e3, 2),
+           # which user population the leg draws: "unique" = every user once, like the headline's uniform ids -- no returning
+           # rows, so no lazy-Adam replay inside the step; "recurring-100k" (UR_FIT_RECURRING_USERS=1, and what `e2e` always does) = users with
+           # replacement from 100 K, histories up to L + 10 items: the replay of returning rows is part of the step (~ + 35 us)
+           "users": "recurring-100k" if n_users == 100_000 else "unique", "history_items_kept": a.seq_len + 10,
            "what": "Trainer(config, model).fit(DeviceBatchLoader) -- one epoch, wall clock around fit() (its loss list and drain() included); "
                    "flush_ms_once = optimizer.flush() behind it (every row's pending zero-gradient steps: once per evaluation / checkpoint)"}
     del tr, model

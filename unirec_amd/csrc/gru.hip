@@ -312,19 +312,28 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(const float* __restr
 //             the backward) -- gi_t is prefetched under the MFMAs.  Two barriers per step.
 //   backward: dh_{t-1} = dgh_t W_hh + dh_t z: H columns x 3H deep = 8 units, one per wave (three interleaved accumulator chains);
 //             thread (i, j) keeps dh[i][j] in a register across the sweep.
+// Round 6: ROWS sequences per workgroup, 4 or 2.  A step is a serial chain MFMA -> partials through LDS -> gate math -> h through LDS, and
+// its wall time is ONE workgroup's latency (profiles/r05_i_gru_h128_pmc.txt: per step 1 536 MFMA cycles + ~1 590 VALU issue cycles per
+// SIMD + waits).  With 2 rows the gate math of a step is 2 H values = one wave per SIMD instead of two -- half the VALU leg at the same
+// MFMA count (A rows 2 and 3 of every 4 x 4 block are zero) -- and B = 512 becomes 256 workgroups: every CU of the chip instead of half.
 constexpr int GRU4_ROWS = 4;
+static int gru_seq4_rows(int B) {
+  static const int forced = ur_test_hook("gru_rows", 0);
+  if (forced == 2 || forced == 4) return forced;
+  return cdiv(B, 4) <= 160 ? 2 : 4;
+}
 
-template <int H>
+template <int H, int ROWS>
 __global__ __launch_bounds__(512) void gru_seq4_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                            const float* __restrict__ b_hh, int B, int L, float* __restrict__ h_all,
                                                            float* __restrict__ r_s, float* __restrict__ z_s, float* __restrict__ n_s,
                                                            float* __restrict__ hn_s) {
   constexpr int C = 3 * H, NCG = C / 64, KSPL = 24 / NCG, KU = H / KSPL;   // column groups, K splits, k per unit
   constexpr int LDH = H + 4;
-  __shared__ __attribute__((aligned(16))) float hs[2][GRU4_ROWS][LDH];
-  __shared__ __attribute__((aligned(16))) float part[KSPL][GRU4_ROWS][C];
+  __shared__ __attribute__((aligned(16))) float hs[2][ROWS][LDH];
+  __shared__ __attribute__((aligned(16))) float part[KSPL][ROWS][C];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int b0 = blockIdx.x * GRU4_ROWS;
+  const int b0 = blockIdx.x * ROWS;
   int uc[3], uk[3], us[3];   // this wave's units: gate column of this lane, first k, split index
   float wf[3][KU];
 #pragma unroll
@@ -339,11 +348,11 @@ __global__ __launch_bounds__(512) void gru_seq4_fwd_kernel(const float* __restri
       wf[q][k] = v.x; wf[q][k + 1] = v.y; wf[q][k + 2] = v.z; wf[q][k + 3] = v.w;
     }
   }
-  const bool gact = tid < GRU4_ROWS * H;       // gate thread (row gi_i, hidden unit gj)
+  const bool gact = tid < ROWS * H;       // gate thread (row gi_i, hidden unit gj)
   const int gi_i = tid / H, gj = tid % H;
   const int gb = min(b0 + gi_i, B - 1);
   const float bh_r = b_hh[gj], bh_z = b_hh[H + gj], bh_n = b_hh[2 * H + gj];
-  for (int i = tid; i < GRU4_ROWS * LDH; i += 512) (&hs[0][0][0])[i] = 0.f;   // h_0 = 0
+  for (int i = tid; i < ROWS * LDH; i += 512) (&hs[0][0][0])[i] = 0.f;   // h_0 = 0
   __syncthreads();
   const int ai = lane & 3;   // row of the A operand this lane supplies
   for (int t = 0; t < L; ++t) {
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(512) void gru_seq4_fwd_kernel(const float* __restri
     for (int k = 0; k < KU; k += 4) {
       float4 a4[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a4[q] = *(const float4*)&hs[cur][ai][uk[q] + k];
+      for (int q = 0; q < 3; ++q) a4[q] = ai < ROWS ? *(const float4*)&hs[cur][ai][uk[q] + k] : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].x, wf[q][k], acc[q], 0, 0, 0);
 #pragma unroll
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(512) void gru_seq4_fwd_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int r = 0; r < GRU4_ROWS; ++r) part[us[q]][r][uc[q]] = acc[q][r];
+      for (int r = 0; r < ROWS; ++r) part[us[q]][r][uc[q]] = acc[q][r];
     __syncthreads();
     if (gact) {
       float pr = 0.f, pz = 0.f, pn = 0.f;
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(512) void gru_seq4_fwd_kernel(const float* __restri
   }
 }
 
-template <int H>
+template <int H, int ROWS>
 __global__ __launch_bounds__(512) void gru_seq4_bwd_kernel(const float* __restrict__ dh_in, const float* __restrict__ w_hh,
                                                            const float* __restrict__ r_s, const float* __restrict__ z_s,
                                                            const float* __restrict__ n_s, const float* __restrict__ hn_s,
@@ -403,15 +412,15 @@ __global__ __launch_bounds__(512) void gru_seq4_bwd_kernel(const float* __restri
                                                            float* __restrict__ dgh) {
   constexpr int C = 3 * H, NCG = H / 64, KSPL = 8 / NCG, KU = C / KSPL;   // H = 128: 2 column groups x 4 splits of 96; H = 64: 1 x 8 of 24
   constexpr int LDG = C + 4;
-  __shared__ __attribute__((aligned(16))) float dg[GRU4_ROWS][LDG];
-  __shared__ __attribute__((aligned(16))) float part[KSPL][GRU4_ROWS][H];
+  __shared__ __attribute__((aligned(16))) float dg[ROWS][LDG];
+  __shared__ __attribute__((aligned(16))) float part[KSPL][ROWS][H];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int b0 = blockIdx.x * GRU4_ROWS;
+  const int b0 = blockIdx.x * ROWS;
   const int ks = w / NCG, col = 64 * (w % NCG) + lane, k0 = ks * KU;
   float wf[KU];   // W_hh[k0 + k][col]: the B operand of dh_{t-1}[i, col] = sum_c dgh[i, c] W_hh[c, col]
 #pragma unroll
   for (int k = 0; k < KU; ++k) wf[k] = w_hh[(long long)(k0 + k) * H + col];
-  const bool gact = tid < GRU4_ROWS * H;
+  const bool gact = tid < ROWS * H;
   const int gi_i = tid / H, gj = tid % H;
   const int gb = min(b0 + gi_i, B - 1);
   float dh = gact ? dh_in[(long long)gb * H + gj] : 0.f;
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(512) void gru_seq4_bwd_kernel(const float* __restri
     for (int k = 0; k < KU; k += 12) {   // three interleaved accumulator chains (KU is a multiple of 12 for H = 64, 128)
       float4 a4[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a4[q] = *(const float4*)&dg[ai][k0 + k + 4 * q];
+      for (int q = 0; q < 3; ++q) a4[q] = ai < ROWS ? *(const float4*)&dg[ai][k0 + k + 4 * q] : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].x, wf[k + 4 * q], acc[q], 0, 0, 0);
 #pragma unroll
@@ -455,7 +464,7 @@ __global__ __launch_bounds__(512) void gru_seq4_bwd_kernel(const float* __restri
       for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[q].w, wf[k + 4 * q + 3], acc[q], 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < GRU4_ROWS; ++r) part[ks][r][col] = (acc[0][r] + acc[1][r]) + acc[2][r];
+    for (int r = 0; r < ROWS; ++r) part[ks][r][col] = (acc[0][r] + acc[1][r]) + acc[2][r];
     __syncthreads();
     if (gact) {
       float sum = 0.f;
@@ -722,10 +731,15 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   if (gru_seq_supported(H)) {   // the whole recurrence in one launch
     ProfScope ps(PC_GRU, st, 2.0 * B * L * 3.0 * H * H);   // h_{t-1} W_hh^T of every step
     if (gru_seq4_supported(H)) {   // four sequences per workgroup (4x4x1 MFMA): B / 4 workgroups
-#define GO4(HH) hipLaunchKernelGGL((gru_seq4_fwd_kernel<HH>), dim3(cdiv(B, GRU4_ROWS)), dim3(512), 0, st, w.gi, dense + lay.w_hh, dense + lay.b_hh, \
+#define GO4(HH) GO4R(HH, 4)
+#define GO4R(HH, RR) hipLaunchKernelGGL((gru_seq4_fwd_kernel<HH, RR>), dim3(cdiv(B, RR)), dim3(512), 0, st, w.gi, dense + lay.w_hh, dense + lay.b_hh, \
                                    B, L, w.h_all, w.r, w.z, w.n, w.hn)
-      if (H == 64) GO4(64); else GO4(128);
+      // two rows per workgroup while that still leaves CUs free at four (B <= 640 on 256 CUs): test hook gru_rows = 2 / 4 forces
+      const int rows = gru_seq4_rows(B);
+      if (H == 64) { if (rows == 2) GO4R(64, 2); else GO4R(64, 4); }
+      else { if (rows == 2) GO4R(128, 2); else GO4R(128, 4); }
 #undef GO4
+#undef GO4R
     } else {
       const dim3 grid(cdiv(B, GRU_SEQ_ROWS));
 #define GO(HH) hipLaunchKernelGGL((gru_seq_fwd_kernel<HH>), grid, dim3(HH * 4), 0, st, w.gi, dense + lay.w_hh, dense + lay.b_hh, B, L, w.h_all, \
@@ -788,10 +802,14 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   if (gru_seq_supported(H)) {   // the whole backward sweep in one launch
     ProfScope ps(PC_GRU, st, 2.0 * B * L * 3.0 * H * H);   // dgh_t W_hh of every step
     if (gru_seq4_supported(H)) {
-#define GO4(HH) hipLaunchKernelGGL((gru_seq4_bwd_kernel<HH>), dim3(cdiv(B, GRU4_ROWS)), dim3(512), 0, st, w.dh, dense + lay.w_hh, w.r, w.z, w.n, w.hn, \
+#define GO4(HH) GO4R(HH, 4)
+#define GO4R(HH, RR) hipLaunchKernelGGL((gru_seq4_bwd_kernel<HH, RR>), dim3(cdiv(B, RR)), dim3(512), 0, st, w.dh, dense + lay.w_hh, w.r, w.z, w.n, w.hn, \
                                    w.h_all, B, L, w.dgi, w.dgh)
-      if (H == 64) GO4(64); else GO4(128);
+      const int rows = gru_seq4_rows(B);
+      if (H == 64) { if (rows == 2) GO4R(64, 2); else GO4R(64, 4); }
+      else { if (rows == 2) GO4R(128, 2); else GO4R(128, 4); }
 #undef GO4
+#undef GO4R
     } else {
       const dim3 grid(cdiv(B, GRU_SEQ_ROWS));
 #define GO(HH) hipLaunchKernelGGL((gru_seq_bwd_kernel<HH>), grid, dim3(HH * 4), 0, st, w.dh, dense + lay.w_hh, w.r, w.z, w.n, w.hn, w.h_all, B, L, \
