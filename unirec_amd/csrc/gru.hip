@@ -312,15 +312,17 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(const float* __restr
 //             the backward) -- gi_t is prefetched under the MFMAs.  Two barriers per step.
 //   backward: dh_{t-1} = dgh_t W_hh + dh_t z: H columns x 3H deep = 8 units, one per wave (three interleaved accumulator chains);
 //             thread (i, j) keeps dh[i][j] in a register across the sweep.
-// Round 6: ROWS sequences per workgroup, 4 or 2.  A step is a serial chain MFMA -> partials through LDS -> gate math -> h through LDS, and
-// its wall time is ONE workgroup's latency (profiles/r05_i_gru_h128_pmc.txt: per step 1 536 MFMA cycles + ~1 590 VALU issue cycles per
-// SIMD + waits).  With 2 rows the gate math of a step is 2 H values = one wave per SIMD instead of two -- half the VALU leg at the same
-// MFMA count (A rows 2 and 3 of every 4 x 4 block are zero) -- and B = 512 becomes 256 workgroups: every CU of the chip instead of half.
+// Round 6: ROWS sequences per workgroup, 4 (the default) or 2 (test hook gru_rows=2).  A step is a serial chain MFMA -> partials through LDS
+// -> gate math -> h through LDS, and its wall time is ONE workgroup's latency (profiles/r05_i_gru_h128_pmc.txt: per step 1 536 MFMA cycles
+// + ~1 590 VALU issue cycles per SIMD + waits).  Round 5 proposed 2 rows: the gate math of a step is then one wave per SIMD instead of two
+// at the same MFMA count (A rows 2 and 3 of every 4 x 4 block zero), and B = 512 fills all 256 CUs.  Built and measured: SLOWER (C4 encoder
+// 0.441 -> 0.492 ms, H = 64 0.320 -> 0.340): the VALU leg is latency, not issue, and twice the workgroups re-read W_hh and gi.
 constexpr int GRU4_ROWS = 4;
 static int gru_seq4_rows(int B) {
   static const int forced = ur_test_hook("gru_rows", 0);
   if (forced == 2 || forced == 4) return forced;
-  return cdiv(B, 4) <= 160 ? 2 : 4;
+  (void)B;
+  return 4;   // measured (profiles/r06_e_gru_rows_counterexample.txt): 2 rows per workgroup are SLOWER at B = 512 (gru class 0.189 -> 0.238 ms)
 }
 
 template <int H, int ROWS>
