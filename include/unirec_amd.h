@@ -415,8 +415,8 @@ int ur_loop_attach(void* group, int32_t rank);
 int ur_loop_detach(void);
 int ur_loop_world(void);
 int ur_loop_post(const void* send, int32_t comm, void* stream);
-int ur_loop_all_to_all_pull(void* recv, int64_t bytes_per_peer, int32_t kind, void* stream);
-int ur_loop_all_reduce_pull(int64_t n, void* stream);
+int ur_loop_all_to_all_pull(void* recv, int64_t bytes_per_peer, int32_t kind, int32_t comm, void* stream);
+int ur_loop_all_reduce_pull(int64_t n, int32_t comm, void* stream);
 int ur_loop_finish(int32_t comm, float* all_reduce_out, int64_t n, void* stream);
 /* test aid: a kernel that spins for `us` microseconds on `stream` (skews one stream of a schedule against the others) */
 int ur_debug_delay(int32_t us, void* stream);

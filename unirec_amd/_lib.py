@@ -103,8 +103,8 @@ SIGNATURES = {
     "ur_loop_detach": (C.c_int, []),
     "ur_loop_world": (C.c_int, []),
     "ur_loop_post": (C.c_int, [P, I32, P]),
-    "ur_loop_all_to_all_pull": (C.c_int, [P, I64, I32, P]),
-    "ur_loop_all_reduce_pull": (C.c_int, [I64, P]),
+    "ur_loop_all_to_all_pull": (C.c_int, [P, I64, I32, I32, P]),
+    "ur_loop_all_reduce_pull": (C.c_int, [I64, I32, P]),
     "ur_loop_finish": (C.c_int, [I32, P, I64, P]),
     "ur_debug_delay": (C.c_int, [I32, P]),
     "ur_comm_unique_id": (C.c_int, [P]),
@@ -212,7 +212,17 @@ _CALL_LOCK = _threading.Lock()
 _RAW = {}
 
 
+_SERIAL_USERS = 0
+
+
 def serialize_calls(on=True):
+    """One library call at a time (a global lock around every entry point) while any LoopbackGroup is open: reference-counted, the raw
+    functions are restored when the last group closes (the lock used to stay for the rest of the process)."""
+    global _SERIAL_USERS
+    with _CALL_LOCK:
+        _SERIAL_USERS = max(0, _SERIAL_USERS + (1 if on else -1))
+        if (on and _SERIAL_USERS > 1) or (not on and _SERIAL_USERS > 0):
+            return
     for name in SIGNATURES:
         if on and name not in _RAW:
             raw = getattr(lib, name)

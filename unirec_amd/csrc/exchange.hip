@@ -266,14 +266,16 @@ using namespace ur;
 //                       buffer; then records this rank's "done" event;
 //   ur_loop_finish      (all ranks have pulled) the stream waits for every peer's "done" -- nobody still reads this rank's send buffer --
 //                       copies the all-reduce result in place, and records the communicator's "last operation" event.
-// Every rank issues the same collectives in the same order (one Python thread per rank, the same program): one slot per rank suffices.
+// Every rank issues the same collectives in the same order (one Python thread per rank, the same program).  The slots (send pointer, ready /
+// done events, the all-reduce's private buffer) are PER COMMUNICATOR INDEX, as RCCL's are: operations of the two indices run on different
+// streams and may overlap on the device (one shared slot was correct only because every all-reduce used index 1).
 namespace {
 struct LoopRank {
-  const void* send = nullptr;
-  hipEvent_t ready = nullptr, done = nullptr, last[2] = {nullptr, nullptr};
+  const void* send[2] = {nullptr, nullptr};
+  hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}, last[2] = {nullptr, nullptr};
   bool last_valid[2] = {false, false};
-  float* ar_tmp = nullptr;
-  long long ar_tmp_n = 0;
+  float* ar_tmp[2] = {nullptr, nullptr};
+  long long ar_tmp_n[2] = {0, 0};
 };
 struct LoopGroup { int world = 0; LoopRank rank[64]; };
 struct LoopCtx { LoopGroup* g = nullptr; int rank = 0; };
@@ -295,7 +297,8 @@ extern "C" void* ur_loop_create(int32_t world) {
   const unsigned evf = hipEventDisableTiming | (unsigned)hipEventDisableSystemFence;   // (one device: no system-scope fence, see sasrec.hip)
   for (int r = 0; r < world; ++r) {
     LoopRank& k = g->rank[r];
-    if (hipEventCreateWithFlags(&k.ready, evf) != hipSuccess || hipEventCreateWithFlags(&k.done, evf) != hipSuccess ||
+    if (hipEventCreateWithFlags(&k.ready[0], evf) != hipSuccess || hipEventCreateWithFlags(&k.done[0], evf) != hipSuccess ||
+        hipEventCreateWithFlags(&k.ready[1], evf) != hipSuccess || hipEventCreateWithFlags(&k.done[1], evf) != hipSuccess ||
         hipEventCreateWithFlags(&k.last[0], evf) != hipSuccess || hipEventCreateWithFlags(&k.last[1], evf) != hipSuccess) {
       fail(UR_ERR_HIP, "ur_loop_create: event creation failed");
       return nullptr;
@@ -308,8 +311,10 @@ extern "C" int ur_loop_destroy(void* group) {
   if (!g) return UR_OK;
   for (int r = 0; r < g->world; ++r) {
     LoopRank& k = g->rank[r];
-    (void)hipEventDestroy(k.ready); (void)hipEventDestroy(k.done); (void)hipEventDestroy(k.last[0]); (void)hipEventDestroy(k.last[1]);
-    if (k.ar_tmp) (void)hipFree(k.ar_tmp);
+    for (int c = 0; c < 2; ++c) {
+      (void)hipEventDestroy(k.ready[c]); (void)hipEventDestroy(k.done[c]); (void)hipEventDestroy(k.last[c]);
+      if (k.ar_tmp[c]) (void)hipFree(k.ar_tmp[c]);
+    }
   }
   delete g;
   return UR_OK;
@@ -334,48 +339,49 @@ extern "C" int ur_loop_post(const void* send, int32_t comm, void* stream) {
   LoopRank& me = t_loop.g->rank[t_loop.rank];
   hipStream_t st = as_stream(stream);
   if (me.last_valid[comm]) UR_HIP(hipStreamWaitEvent(st, me.last[comm], 0));   // one communicator: operations in issue order
-  me.send = send;
-  UR_HIP(hipEventRecord(me.ready, st));
+  me.send[comm] = send;
+  UR_HIP(hipEventRecord(me.ready[comm], st));
   return UR_OK;
 }
-extern "C" int ur_loop_all_to_all_pull(void* recv, int64_t bytes_per_peer, int32_t kind, void* stream) {
+extern "C" int ur_loop_all_to_all_pull(void* recv, int64_t bytes_per_peer, int32_t kind, int32_t comm, void* stream) {
   UR_TRACE_SCOPE();
-  UR_REQUIRE(t_loop.g && recv && bytes_per_peer > 0 && kind >= 0 && kind <= 2, UR_ERR_ARG, "ur_loop_all_to_all_pull: not attached / bad argument");
+  UR_REQUIRE(t_loop.g && recv && bytes_per_peer > 0 && kind >= 0 && kind <= 2 && (comm == 0 || comm == 1), UR_ERR_ARG,
+             "ur_loop_all_to_all_pull: not attached / bad argument");
   LoopGroup& g = *t_loop.g;
   hipStream_t st = as_stream(stream);
   const int cls = kind == 0 ? PC_A2A_IDS : kind == 1 ? PC_A2A_ROWS : PC_A2A_GRADS;
-  for (int p = 0; p < g.world; ++p) UR_HIP(hipStreamWaitEvent(st, g.rank[p].ready, 0));
+  for (int p = 0; p < g.world; ++p) UR_HIP(hipStreamWaitEvent(st, g.rank[p].ready[comm], 0));
   {
     ProfScope ps(cls, st, (double)bytes_per_peer * (g.world - 1));   // (the copies alone: what a loopback run subtracts from a rank's device time)
     for (int p = 0; p < g.world; ++p)
-      UR_HIP(hipMemcpyAsync((char*)recv + (size_t)p * bytes_per_peer, (const char*)g.rank[p].send + (size_t)t_loop.rank * bytes_per_peer,
+      UR_HIP(hipMemcpyAsync((char*)recv + (size_t)p * bytes_per_peer, (const char*)g.rank[p].send[comm] + (size_t)t_loop.rank * bytes_per_peer,
                             (size_t)bytes_per_peer, hipMemcpyDeviceToDevice, st));
   }
-  UR_HIP(hipEventRecord(g.rank[t_loop.rank].done, st));
+  UR_HIP(hipEventRecord(g.rank[t_loop.rank].done[comm], st));
   return UR_OK;
 }
-extern "C" int ur_loop_all_reduce_pull(int64_t n, void* stream) {
+extern "C" int ur_loop_all_reduce_pull(int64_t n, int32_t comm, void* stream) {
   UR_TRACE_SCOPE();
-  UR_REQUIRE(t_loop.g && n > 0, UR_ERR_ARG, "ur_loop_all_reduce_pull: not attached / bad argument");
+  UR_REQUIRE(t_loop.g && n > 0 && (comm == 0 || comm == 1), UR_ERR_ARG, "ur_loop_all_reduce_pull: not attached / bad argument");
   LoopGroup& g = *t_loop.g;
   LoopRank& me = g.rank[t_loop.rank];
   hipStream_t st = as_stream(stream);
-  if (me.ar_tmp_n < n) {   // (grown on first use: a hipMalloc synchronises the device once, not per step)
-    if (me.ar_tmp) UR_HIP(hipFree(me.ar_tmp));
-    UR_HIP(hipMalloc((void**)&me.ar_tmp, (size_t)n * sizeof(float)));
-    me.ar_tmp_n = n;
+  if (me.ar_tmp_n[comm] < n) {   // (grown on first use: a hipMalloc synchronises the device once, not per step)
+    if (me.ar_tmp[comm]) UR_HIP(hipFree(me.ar_tmp[comm]));
+    UR_HIP(hipMalloc((void**)&me.ar_tmp[comm], (size_t)n * sizeof(float)));
+    me.ar_tmp_n[comm] = n;
   }
   LoopPtrs src{};
   for (int p = 0; p < g.world; ++p) {
-    UR_HIP(hipStreamWaitEvent(st, g.rank[p].ready, 0));
-    src.p[p] = (const float*)g.rank[p].send;
+    UR_HIP(hipStreamWaitEvent(st, g.rank[p].ready[comm], 0));
+    src.p[p] = (const float*)g.rank[p].send[comm];
   }
   {
     ProfScope ps(PC_ALLREDUCE, st, (double)n * 4.0 * 2.0 * (g.world - 1) / g.world);
-    hipLaunchKernelGGL(loop_all_reduce_kernel, dim3((unsigned)std::min<long long>(1024, (n + 255) / 256)), dim3(256), 0, st, src, g.world, (long long)n, me.ar_tmp);
+    hipLaunchKernelGGL(loop_all_reduce_kernel, dim3((unsigned)std::min<long long>(1024, (n + 255) / 256)), dim3(256), 0, st, src, g.world, (long long)n, me.ar_tmp[comm]);
     UR_LAUNCH_CHECK();
   }
-  UR_HIP(hipEventRecord(me.done, st));
+  UR_HIP(hipEventRecord(me.done[comm], st));
   return UR_OK;
 }
 extern "C" int ur_loop_finish(int32_t comm, float* all_reduce_out, int64_t n, void* stream) {
@@ -384,10 +390,10 @@ extern "C" int ur_loop_finish(int32_t comm, float* all_reduce_out, int64_t n, vo
   LoopGroup& g = *t_loop.g;
   LoopRank& me = g.rank[t_loop.rank];
   hipStream_t st = as_stream(stream);
-  for (int p = 0; p < g.world; ++p) UR_HIP(hipStreamWaitEvent(st, g.rank[p].done, 0));
+  for (int p = 0; p < g.world; ++p) UR_HIP(hipStreamWaitEvent(st, g.rank[p].done[comm], 0));
   if (all_reduce_out) {
-    UR_REQUIRE(n > 0 && n <= me.ar_tmp_n, UR_ERR_ARG, "ur_loop_finish: n=%lld", (long long)n);
-    UR_HIP(hipMemcpyAsync(all_reduce_out, me.ar_tmp, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    UR_REQUIRE(n > 0 && n <= me.ar_tmp_n[comm], UR_ERR_ARG, "ur_loop_finish: n=%lld", (long long)n);
+    UR_HIP(hipMemcpyAsync(all_reduce_out, me.ar_tmp[comm], (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   UR_HIP(hipEventRecord(me.last[comm], st));
   me.last_valid[comm] = true;

@@ -284,7 +284,10 @@ def id_guard_check():
     """The host half of the id guard (include/unirec_amd.h: ur_id_guard_state; the reference's nn.Embedding raises IndexError for an id
     outside its table, reco_abc.py:168-170).  A plain load of the host-mapped mirror the plan kernels write -- no synchronisation; called
     at the head of every plan, so a bad id surfaces one or two steps after its batch.  Every step from that batch on has been skipped on
-    the device (the guard is sticky): the tables hold the state before it.  ``id_guard_reset()`` clears the guard."""
+    the device (the guard is sticky).  The batch is planned a step AHEAD, on the plan stream, so the guard can go up while the step in
+    front of it is still being applied: that one step may be applied in part (its row update done, its dense update skipped, or -- on
+    several ranks -- applied on some ranks only).  The error is fatal for the run: restart from the last checkpoint rather
+    than catching it and training on or saving the tables.  ``id_guard_reset()`` clears the guard."""
     if lib.ur_id_guard_state(_GUARD_OUT):
         bad, n_rows = int(_GUARD_OUT[0]), int(_GUARD_OUT[1])
         raise IndexError(f"index {bad} is out of range for an embedding table of {n_rows} rows (unirec_amd id guard: the step that "

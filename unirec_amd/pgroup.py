@@ -72,14 +72,21 @@ class LoopbackGroup:
         """equal-split all-to-all of a packed block (block p of `send` -> rank p) on the CURRENT stream; ahead: communicator index 1"""
         import ctypes as C
         assert send.is_contiguous() and recv.is_contiguous() and send.numel() == recv.numel() and send.numel() % self.world == 0
+        assert ahead is not None, "which communicator: ahead=True (work issued a step ahead) or False (the step's own exchanges)"
         comm = 1 if ahead else 0
         st = self._stream()
-        check(lib.ur_loop_post(C.c_void_p(send.data_ptr()), comm, st), "ur_loop_post")
-        self._bar.wait()
-        check(lib.ur_loop_all_to_all_pull(C.c_void_p(recv.data_ptr()), send.numel() * send.element_size() // self.world,
-                                          {"ids": 0, "rows": 1, "grads": 2}[kind], st), "ur_loop_all_to_all_pull")
-        self._bar.wait()
-        check(lib.ur_loop_finish(comm, None, 0, st), "ur_loop_finish")
+        try:
+            check(lib.ur_loop_post(C.c_void_p(send.data_ptr()), comm, st), "ur_loop_post")
+            self._bar.wait()
+            check(lib.ur_loop_all_to_all_pull(C.c_void_p(recv.data_ptr()), send.numel() * send.element_size() // self.world,
+                                              {"ids": 0, "rows": 1, "grads": 2}[kind], comm, st), "ur_loop_all_to_all_pull")
+            self._bar.wait()
+            check(lib.ur_loop_finish(comm, None, 0, st), "ur_loop_finish")
+        except threading.BrokenBarrierError:
+            raise
+        except BaseException:
+            self.abort()       # a rank that fails between post and finish releases its peers at once (not after TIMEOUT seconds)
+            raise
         return recv
 
     def all_reduce_sum(self, t, ahead=True):
@@ -88,11 +95,17 @@ class LoopbackGroup:
         assert t.is_contiguous() and t.dtype == torch.float32
         comm = 1 if ahead else 0
         st = self._stream()
-        check(lib.ur_loop_post(C.c_void_p(t.data_ptr()), comm, st), "ur_loop_post")
-        self._bar.wait()
-        check(lib.ur_loop_all_reduce_pull(t.numel(), st), "ur_loop_all_reduce_pull")
-        self._bar.wait()
-        check(lib.ur_loop_finish(comm, C.c_void_p(t.data_ptr()), t.numel(), st), "ur_loop_finish")
+        try:
+            check(lib.ur_loop_post(C.c_void_p(t.data_ptr()), comm, st), "ur_loop_post")
+            self._bar.wait()
+            check(lib.ur_loop_all_reduce_pull(t.numel(), comm, st), "ur_loop_all_reduce_pull")
+            self._bar.wait()
+            check(lib.ur_loop_finish(comm, C.c_void_p(t.data_ptr()), t.numel(), st), "ur_loop_finish")
+        except threading.BrokenBarrierError:
+            raise
+        except BaseException:
+            self.abort()
+            raise
         return t
 
     # ---- everything else: a synchronised rendezvous through host slots
@@ -175,6 +188,7 @@ class LoopbackGroup:
         if self.handle:
             lib.ur_loop_destroy(self.handle)
             self.handle = None
+            _lib.serialize_calls(False)     # (reference-counted: the raw entry points come back with the last open group)
 
 
 def is_loopback(group):
