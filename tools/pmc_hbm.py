@@ -32,6 +32,8 @@ def per_kernel(path, counter):
 
 
 def cls(name):
+    if "gemm_tn" in name:      # gemm_tn_group_kernel and (round 6) gemm_tn_split_kernel: the weight-gradient class
+        return "gemm_tn"
     if "_split_kernel" in name or "lastrow_" in name:
         return "row_chain_last"
     for c in ("chain_ffn_fwd_kernel", "chain_ffn_bwd_kernel", "chain_proj_bwd_kernel", "chain_embed_proj_kernel"):
