@@ -958,7 +958,7 @@ def main():
         iso = prof_read()[dom]
     _lib.lib.ur_prof_set_mask(0xFFFFFFFF)
     collectives = None
-    if world > 1:   # per-collective device time and bytes to the peers, 10 extra steps after the timed region (all ranks take part)
+    if world > 1 or (a.sharded_w1 and getattr(opt, "_native", False)):   # per-collective device time and bytes to the peers, 10 extra steps after the timed region (all ranks take part; one rank through RCCL: the groups' fixed cost)
         coll_names = ("a2a_ids", "a2a_rows", "a2a_row_grads", "allreduce")
         if opt._native:   # the library's RCCL route: its own profiler classes (events on the stream each group runs on)
             _lib.lib.ur_prof_reset()
@@ -1095,6 +1095,8 @@ def main():
     if world == 1 and a.sharded_w1:
         from unirec_amd import ops as _ops
         out["n_ranks"], out["rccl_ranks"] = 1, _ops.comm_count()
+        if collectives is not None:
+            out["collectives"] = collectives
     if world > 1:
         import torch.distributed as dist
         out["n_ranks"] = dist.get_world_size()
