@@ -13,7 +13,8 @@ arith = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 21248
 dev = torch.device("cuda:0")
-shapes = [(384, 128, 0), (128, 128, 0), (512, 128, 0), (128, 512, 1)]
+pro = os.environ.get("TN_PRO", "0001")   # which of the four products apply the activation to Q (the real layer: the last one)
+shapes = [(384, 128, int(pro[0])), (128, 128, int(pro[1])), (512, 128, int(pro[2])), (128, 512, int(pro[3]))]
 g = torch.Generator(device=dev).manual_seed(T)
 Ps = [torch.randn(T, R, device=dev, generator=g) for R, _, _ in shapes]
 Qs = [torch.randn(T, Cc, device=dev, generator=g) for _, Cc, _ in shapes]
