@@ -101,8 +101,9 @@ typedef struct UrSasrecCfg {
   int32_t mfma_arith;   /* arithmetic of the weight-gradient products (autograd of modules.py:285-287,312,347-355): 0 = exact fp32-input
                          * MFMA; 6 / 9 = the fp32 operands split exactly into three bf16 pieces, six / nine piece products accumulated in
                          * fp32 on the bf16 pipes (fp32-equivalent: measured error vs fp64 <= the exact kernel's, profiles/r06_*_stage_a*);
-                         * see ur_set_mfma_arith.  Products narrower than the split kernel's 128 x 128 tile keep the exact kernel unless 0x100 is
-                         * added (unit tests). */
+                         * see ur_set_mfma_arith.  128-wide products take the wide form (128 x 128 tiles), 64-wide ones the narrow form; products that
+                         * fill < 70 % of even 64 x 64 tiles, and groups too small to put two wide workgroups on a CU, keep the exact kernel
+                         * unless 0x100 is added (unit tests). */
   int32_t reserved_;
 } UrSasrecCfg;
 

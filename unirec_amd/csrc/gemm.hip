@@ -583,29 +583,33 @@ __global__ __launch_bounds__(256) void gemm_tn_group_kernel(TnGroup g, const flo
 //   one ds_read_b128.  Rows are padded to 80 B: conflict-free for the b128 reads (16-lane groups: 20 l mod 64 distinct) and the b64
 //   writes (16-lane groups: 2 g + 80 q' dwords mod 32 distinct).
 //   Inf / NaN operands give NaN (inf - inf in the split), where the exact kernel may give inf: such a step is skipped either way.
-constexpr int ST = 128;    // output tile edge
+constexpr int ST = 128;    // output tile edge of the wide form (d = 128-class products); the narrow form (TS = 64: d = 64 models) below
 constexpr int SBT = 32;    // tokens per stage
 constexpr int SRS = 80;    // bytes per LDS row (32 bf16 + 16 B pad)
-constexpr int S_STAGE_BYTES = 6 * ST * SRS;   // 61 440 B
+constexpr int S_STAGE_BYTES = 6 * ST * SRS;   // 61 440 B (TS = 128); 30 720 B at TS = 64
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // The body of one workgroup, specialised on the term count and on the activation applied to Q (ACT < 0: none): the hot loop then has no
 // data-dependent branch at all -- full stages only; a split's ragged last stage is peeled off and staged with clamped, zeroed rows.
-template <int NTERM, int ACT>
+// TS = tile edge: 128 = 8 waves (2 x 4), a wave = 64 x 32 (two accumulators); 64 = 4 waves (2 x 2), a wave = 32 x 32 (one): the same
+// staging map (a wave = one 32-feature slab of P or Q, 16 elements per lane and stage), half the MFMAs per staged element.
+template <int NTERM, int ACT, int TS>
 __device__ __forceinline__ void tn_split_wg(const TnItem& it, const int sp, const int tile, const float* __restrict__ zero_row,
                                             unsigned char* smem, long long* trace) {
+  constexpr int SW = TS / 32;            // staging waves per operand = waves across the tile's columns
+  constexpr int MI = TS / 64;            // 32-row accumulator blocks per wave (the wave grid is 2 x SW)
   int T = it.T;
   if (it.t_dev) T = min(T, *it.t_dev);
   const int S = it.S;
   const int tps = (((T + S - 1) / S + SBT - 1) / SBT) * SBT;
   const int t_begin = sp * tps, t_end = min(T, t_begin + tps);
   const int R = it.R, Cc = it.Cc;
-  const int r0 = (tile / it.ntc) * ST, c0 = (tile % it.ntc) * ST;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
+  const int r0 = (tile / it.ntc) * TS, c0 = (tile % it.ntc) * TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / SW, wc = wave % SW;
   // ---- staging role: waves 0-3 stage P, 4-7 stage Q; a wave = a 32-feature slab; lane = (token group of four sg = lane & 7, feature
   // quad lane >> 3): four token rows x float4 per stage
-  const int so = wave >> 2, sg = lane & 7, sf0 = (wave & 3) * 32 + (lane >> 3) * 4;
+  const int so = wave / SW, sg = lane & 7, sf0 = (wave % SW) * 32 + (lane >> 3) * 4;
   const int sdim = so ? Cc : R, sorg = so ? c0 : r0;
   const bool fin = sorg + sf0 < sdim;
   // a feature quad beyond the operand's width reads the zero row at stride 0: no select per load
@@ -633,7 +637,7 @@ __device__ __forceinline__ void tn_split_wg(const TnItem& it, const int sp, cons
       if (t >= t_end) x[i] = tfx4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  unsigned char* const sdst = smem + (so * 3 * ST + sf0) * SRS + sg * 8;
+  unsigned char* const sdst = smem + (so * 3 * TS + sf0) * SRS + sg * 8;
   auto split_store = [&](tfx4 (&x)[4]) {
     if (ACT >= 0 && so) {   // (wave-uniform) the activation of the FFN's hidden rows, recomputed as in gemm_tn_group_kernel
 #pragma unroll
@@ -660,26 +664,26 @@ __device__ __forceinline__ void tn_split_wg(const TnItem& it, const int sp, cons
         lo[h] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * h + 1]), __float_as_uint(r2[2 * h]), 0x07060302u);
       }
       *(u32x2*)(sdst + e * SRS) = hi;
-      *(u32x2*)(sdst + (ST + e) * SRS) = mid;
-      *(u32x2*)(sdst + (2 * ST + e) * SRS) = lo;
+      *(u32x2*)(sdst + (TS + e) * SRS) = mid;
+      *(u32x2*)(sdst + (2 * TS + e) * SRS) = lo;
     }
   };
-  floatx16 acc[2];
+  floatx16 acc[MI];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MI; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-  const unsigned char* const fa0 = smem + (wr * 64 + (lane & 31)) * SRS + (lane >> 5) * 16;
-  const unsigned char* const fb0 = smem + (3 * ST + wc * 32 + (lane & 31)) * SRS + (lane >> 5) * 16;
+  const unsigned char* const fa0 = smem + (wr * 32 * MI + (lane & 31)) * SRS + (lane >> 5) * 16;
+  const unsigned char* const fb0 = smem + (3 * TS + wc * 32 + (lane & 31)) * SRS + (lane >> 5) * 16;
   auto compute = [&]() {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      bf16x8 fa[2][3], fb[3];
+      bf16x8 fa[MI][3], fb[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        fb[p] = *(const bf16x8*)(fb0 + (p * ST) * SRS + kb * 32);
+        fb[p] = *(const bf16x8*)(fb0 + (p * TS) * SRS + kb * 32);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) fa[m][p] = *(const bf16x8*)(fa0 + (p * ST + m * 32) * SRS + kb * 32);
+        for (int m = 0; m < MI; ++m) fa[m][p] = *(const bf16x8*)(fa0 + (p * TS + m * 32) * SRS + kb * 32);
       }
       // small terms first, the leading product last
       constexpr int PA[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
@@ -687,7 +691,7 @@ __device__ __forceinline__ void tn_split_wg(const TnItem& it, const int sp, cons
 #pragma unroll
       for (int tm = 9 - NTERM; tm < 9; ++tm)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA[tm]], fb[PB[tm]], acc[m], 0, 0, 0);
+        for (int m = 0; m < MI; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA[tm]], fb[PB[tm]], acc[m], 0, 0, 0);
     }
   };
   int tr = 0;
@@ -751,10 +755,10 @@ __device__ __forceinline__ void tn_split_wg(const TnItem& it, const int sp, cons
   const int ldo = direct ? it.ldo : Cc;
   const int c = c0 + wc * 32 + (lane & 31);
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MI; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int rr = r0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int rr = r0 + wr * 32 * MI + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (rr < R && c < Cc) out[(long long)rr * ldo + c] = acc[m][r];
     }
   if (want_bias) {   // (wave-uniform: so == 0) column sums of P: the eight token groups of a feature quad are eight adjacent lanes
@@ -768,8 +772,8 @@ __device__ __forceinline__ void tn_split_wg(const TnItem& it, const int sp, cons
   if (trace && tid == 0) { trace[blockIdx.x * 64] = tr; trace[blockIdx.x * 64 + 1] = nt; trace[blockIdx.x * 64 + 63] = wall_clock64(); }
 }
 
-template <int NTERM>
-__global__ __launch_bounds__(512, 4) void gemm_tn_split_kernel(TnGroup g, const float* __restrict__ zero_row, long long* trace) {
+template <int NTERM, int TS>
+__global__ __launch_bounds__(TS * 4, 4) void gemm_tn_split_kernel(TnGroup g, const float* __restrict__ zero_row, long long* trace) {
   int j = 0;
   while (j + 1 < g.n && (int)blockIdx.x >= g.item[j + 1].first_block) ++j;
   const TnItem& it = g.item[j];
@@ -780,16 +784,16 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_split_kernel(TnGroup g, const 
     sp = (qid / ntiles) * 8 + xcd; tile = qid % ntiles;
   } else { sp = local % S; tile = local / S; }
   if (sp >= S || tile >= ntiles) return;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[S_STAGE_BYTES];
-  if (!it.pro_act) { tn_split_wg<NTERM, -1>(it, sp, tile, zero_row, smem, trace); return; }
+  __shared__ __attribute__((aligned(16))) unsigned char smem[6 * TS * SRS];
+  if (!it.pro_act) { tn_split_wg<NTERM, -1, TS>(it, sp, tile, zero_row, smem, trace); return; }
   if (g.pro_prio) __builtin_amdgcn_s_setprio(1);
   switch (it.act) {   // (one specialised loop per activation: the workgroup runs exactly one of them)
-    case UR_ACT_GELU: tn_split_wg<NTERM, UR_ACT_GELU>(it, sp, tile, zero_row, smem, trace); break;
-    case UR_ACT_RELU: tn_split_wg<NTERM, UR_ACT_RELU>(it, sp, tile, zero_row, smem, trace); break;
-    case UR_ACT_SWISH: tn_split_wg<NTERM, UR_ACT_SWISH>(it, sp, tile, zero_row, smem, trace); break;
-    case UR_ACT_TANH: tn_split_wg<NTERM, UR_ACT_TANH>(it, sp, tile, zero_row, smem, trace); break;
-    case UR_ACT_SIGMOID: tn_split_wg<NTERM, UR_ACT_SIGMOID>(it, sp, tile, zero_row, smem, trace); break;
-    default: tn_split_wg<NTERM, -1>(it, sp, tile, zero_row, smem, trace); break;
+    case UR_ACT_GELU: tn_split_wg<NTERM, UR_ACT_GELU, TS>(it, sp, tile, zero_row, smem, trace); break;
+    case UR_ACT_RELU: tn_split_wg<NTERM, UR_ACT_RELU, TS>(it, sp, tile, zero_row, smem, trace); break;
+    case UR_ACT_SWISH: tn_split_wg<NTERM, UR_ACT_SWISH, TS>(it, sp, tile, zero_row, smem, trace); break;
+    case UR_ACT_TANH: tn_split_wg<NTERM, UR_ACT_TANH, TS>(it, sp, tile, zero_row, smem, trace); break;
+    case UR_ACT_SIGMOID: tn_split_wg<NTERM, UR_ACT_SIGMOID, TS>(it, sp, tile, zero_row, smem, trace); break;
+    default: tn_split_wg<NTERM, -1, TS>(it, sp, tile, zero_row, smem, trace); break;
   }
 }
 
@@ -839,9 +843,10 @@ int set_mfma_arith(int m) {
   return UR_OK;
 }
 
-static int gemm_tn_group_split(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer, int nterm, const float* zeros) {
+static int gemm_tn_group_split(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer, int nterm, const float* zeros, int ts) {
   // two 60 KB workgroups per CU; a workgroup should walk >= 8 stages between its cold prologue and its 64 KB partial-tile store
-  const int target = ur_test_hook("tn_split_target", 512);
+  // (the narrow form's workgroups are 4 waves and 30 KB: four of them fit where two wide ones do)
+  const int target = ur_test_hook("tn_split_target", ts == ST ? 512 : 1024);
   // a stage of a product whose Q operand takes the activation costs its staging waves ~1/3 more (measured: profiles/r06_*_tn_split_trace):
   // such a product gets proportionally more, shorter splits, so that the workgroups of a launch end together
   const double pro_cost = ur_test_hook("tn_split_procost", 135) * 0.01;
@@ -853,7 +858,7 @@ static int gemm_tn_group_split(const TnReq* req, int n, hipStream_t st, ReduceBa
     const TnReq& q = req[i];
     if ((q.R & 3) || (q.Cc & 3) || (q.ldp & 3) || (q.ldq & 3) || (q.ldo & 3)) return fail(UR_ERR_ARG, "gemm_tn: R/Cc/ld must be multiples of 4");
     if (q.T <= 0) return fail(UR_ERR_ARG, "gemm_tn: T=%d", q.T);
-    work += (double)cdiv(q.R, ST) * cdiv(q.Cc, ST) * q.T * (q.pro_act ? pro_cost : 1.0);
+    work += (double)cdiv(q.R, ts) * cdiv(q.Cc, ts) * q.T * (q.pro_act ? pro_cost : 1.0);
     flops += 2.0 * q.T * q.R * q.Cc;
   }
   const double rows_per = std::max(256.0, work / target);
@@ -868,7 +873,7 @@ static int gemm_tn_group_split(const TnReq* req, int n, hipStream_t st, ReduceBa
     if (S >= 6) S = std::min(TN_SPLIT_SMAX, (S + 4) / 8 * 8);
     if (S < 1) S = 1;
     it.P = q.P; it.Q = q.Q; it.ldp = q.ldp; it.ldq = q.ldq; it.T = q.T; it.t_dev = q.t_dev; it.R = q.R; it.Cc = q.Cc;
-    it.pro_act = q.pro_act; it.act = q.act; it.S = S; it.ntr = cdiv(q.R, ST); it.ntc = cdiv(q.Cc, ST);
+    it.pro_act = q.pro_act; it.act = q.act; it.S = S; it.ntr = cdiv(q.R, ts); it.ntc = cdiv(q.Cc, ts);
     it.out = q.out; it.bias_out = q.bias_out; it.ldo = q.ldo;
     it.part = q.ws; it.bias_part = q.bias_out ? q.ws + (long long)S * q.R * q.Cc : nullptr;
     it.first_block = blocks;
@@ -883,9 +888,12 @@ static int gemm_tn_group_split(const TnReq* req, int n, hipStream_t st, ReduceBa
       if (!trace_buf && hipMalloc((void**)&trace_buf, 4096 * 64 * sizeof(long long)) != hipSuccess) trace_buf = nullptr;
       trace = blocks <= 4096 ? trace_buf : nullptr;
     }
-    if (nterm == 9) { UR_LAUNCH_EV(gemm_tn_split_kernel<9>, dim3(blocks), dim3(512), 0, st, g, zeros, trace); }
-    else if (nterm == 3) { UR_LAUNCH_EV(gemm_tn_split_kernel<3>, dim3(blocks), dim3(512), 0, st, g, zeros, trace); }
-    else { UR_LAUNCH_EV(gemm_tn_split_kernel<6>, dim3(blocks), dim3(512), 0, st, g, zeros, trace); }
+#define UR_TNS(N_) do { if (ts == ST) { UR_LAUNCH_EV((gemm_tn_split_kernel<N_, 128>), dim3(blocks), dim3(512), 0, st, g, zeros, trace); } \
+                       else { UR_LAUNCH_EV((gemm_tn_split_kernel<N_, 64>), dim3(blocks), dim3(256), 0, st, g, zeros, trace); } } while (0)
+    if (nterm == 9) UR_TNS(9);
+    else if (nterm == 3) UR_TNS(3);
+    else UR_TNS(6);
+#undef UR_TNS
     if (trace && want_trace == 2) {   // debugging aid: print the phase stamps of a few workgroups of THIS launch
       static int printed = 0;
       if (printed++ == 3 && hipStreamSynchronize(st) == hipSuccess) {
@@ -931,17 +939,29 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
   const float* zeros = tn_zero_buf();
   if (!zeros) return fail(UR_ERR_HIP, "gemm_tn: no device memory for the zero row");
   if (const int arith = mfma_arith()) {
-    // the split kernel works on 128 x 128 output tiles: products narrower than a tile (d = 64 models) would stage and multiply padding --
-    // inside an encoder call they keep the exact kernel's 64 x 64 tiles unless the cfg says 0x100 | terms ("every shape": the unit
-    // tests); the raw hooks (ur_gemm_tn / ur_gemm_tn_group under ur_set_mfma_arith) take the split kernel at every shape
-    double used = 0.0, tiled = 0.0;
+    // the split kernel has a wide (128 x 128 tiles, 8 waves) and a narrow (64 x 64, 4 waves) form; products that would fill less than
+    // 70 % of even the narrow tiles keep the exact kernel inside an encoder call unless the cfg says 0x100 | terms ("every shape": the
+    // unit tests); the raw hooks (ur_gemm_tn / ur_gemm_tn_group under ur_set_mfma_arith) take a split form at every shape
+    double used = 0.0, tiled = 0.0, tiled64 = 0.0;
     for (int i = 0; i < n; ++i) {
       used += (double)req[i].R * req[i].Cc * req[i].T;
       tiled += (double)cdiv(req[i].R, ST) * cdiv(req[i].Cc, ST) * ST * ST * req[i].T;
+      tiled64 += (double)cdiv(req[i].R, 64) * cdiv(req[i].Cc, 64) * 64 * 64 * req[i].T;
     }
     const bool any = g_arith_scope < 0 || (arith & 0x100);
-    if (any || used >= 0.7 * tiled) return gemm_tn_group_split(req, n, st, defer, arith & 0xFF, zeros);
+    static const int force_ts = ur_test_hook("tn_split_ts", 0);
+    if (force_ts == 64 || force_ts == 128) return gemm_tn_group_split(req, n, st, defer, arith & 0xFF, zeros, force_ts);
+    // (the wide form needs a partner workgroup on its CU -- one's split runs under the other's MFMAs: a group of few tiles cannot be cut
+    // into ~2 workgroups per CU (C4's encoder at H = 128: two products, six tiles, measured 8 % slower than the exact kernel) and stays exact)
+    long long tiles128 = 0;
+    for (int i = 0; i < n; ++i) tiles128 += (long long)cdiv(req[i].R, ST) * cdiv(req[i].Cc, ST) * (req[i].T >= 2048 ? 1 : 0);
+    static const int min_wg = ur_test_hook("tn_split_minwg", 384);
+    const bool enough = any || tiles128 * TN_SPLIT_SMAX >= min_wg;
+    if (used >= 0.7 * tiled && enough) return gemm_tn_group_split(req, n, st, defer, arith & 0xFF, zeros, ST);     // d = 128-class products
+    if (used >= 0.7 * tiled && !enough) goto exact;
+    if (any || used >= 0.7 * tiled64) return gemm_tn_group_split(req, n, st, defer, arith & 0xFF, zeros, 64);   // d = 64-class (round 6b)
   }
+exact:
   // workgroups per launch (~3 per CU: 32 KB of LDS each).  Measured at C5 (profiles/r03_a_dw_schedule.txt): 288 -> 0.681 ms/step, 576 ->
   // 0.660, 864 -> 0.658, 1152+ -> 0.665 -- short workgroups give the CUs back to the main stream's kernels sooner
   constexpr int target = 864;
