@@ -1,5 +1,10 @@
 """Row-chain kernels (csrc/rowchain.hip) against the one-GEMM-per-launch path they replace, on identical inputs.
 
+These comparisons run in the EXACT arithmetic (mfma_arith = 0: the fp32-input MFMA on both sides); the split-bf16 form of the chains
+(the default, round 6) is held against an fp64 evaluation of the oracle instead -- its error may not exceed 1.5 x the exact chains'
+(test_split_row_chains_are_fp32_equivalent, the yardstick of tools/split_bf16_stage_a.py) -- and against the goldens and the oracle
+at the model level (tests/test_gpu_parity.py, tests/test_full_size_gpu.py: mfma_arith = 6 / 9 / 0 at the same tolerances).
+
 The chain kernels keep the K order of the stand-alone GEMMs, so the FORWARD agrees to fp32 rounding of the LayerNorm sums (1e-6
 of the output scale; the MFMA sums themselves are the same sequence); the backward sums the LayerNorm-affine partials over a different workgroup partition,
 so gradients are compared at 2e-6 of each tensor's scale (pure fp32 re-association).  Shapes: the three supported widths
@@ -13,7 +18,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg_kw, B, seed, chain, train_drop=0.0):
+def _run(cfg_kw, B, seed, chain, train_drop=0.0, arith=0):
     from unirec_amd import _lib, ops
     dev = torch.device("cuda:0")
     d, L, I, H, nl = cfg_kw["d"], cfg_kw["L"], cfg_kw["inner"], cfg_kw["heads"], cfg_kw["layers"]
@@ -21,7 +26,8 @@ def _run(cfg_kw, B, seed, chain, train_drop=0.0):
     prev = _lib.lib.ur_sasrec_set_chain(int(chain) if not isinstance(chain, bool) else (127 if chain else 0))   # bit mask: 1 fwd, 2 bwd, 4 projection, 8 / 16 fwd / bwd of the last-row layer (row-chain kernels), 32 input block, 64 the last-row layer as two launches (lastrow.hip)
     try:
         cfg = ops.sasrec_cfg(B, L, d, H, I, nl, cfg_kw.get("act", "swish"), True, 1e-10, last_only=cfg_kw.get("last_only", 1),
-                             skip_padding=cfg_kw.get("skip_padding", 1), p_hidden=train_drop, p_attn=0.0, drop_seed=7, drop_step=3)
+                             skip_padding=cfg_kw.get("skip_padding", 1), p_hidden=train_drop, p_attn=0.0, drop_seed=7, drop_step=3,
+                             mfma_arith=arith)
         offs, total = ops.sasrec_param_layout(cfg)
         g = torch.Generator(device=dev).manual_seed(seed)
         dense = torch.randn(total, device=dev, generator=g) * 0.08
@@ -151,3 +157,74 @@ def test_last_row_split_kernels_are_race_free_over_repeated_steps():
         for k, tol in ((0, 5e-6), (1, 3e-4), (2, 5e-6)):
             assert torch.equal(x[k], y[k]), (step, k)
             _close(x[k], z[k], tol, (step, k))
+
+
+def _l2(a, ref):
+    return float((a.double() - ref.double()).norm() / max(1e-300, float(ref.double().norm())))
+
+
+@pytest.mark.parametrize("d,L,heads,B", [(128, 50, 16, 256), (64, 50, 16, 256), (32, 20, 4, 128), (128, 200, 16, 32)])
+def test_split_row_chains_are_fp32_equivalent(d, L, heads, B):
+    """The row-chain kernels in split-bf16 arithmetic (mfma_arith = 6, the default: six piece products per product of two fp32 values on
+    the bf16 matrix pipe) against the same kernels on the fp32-input MFMA (mfma_arith = 0), both measured against the ORACLE EVALUATED
+    IN fp64: the relative L2 error of the user vectors, of every dense gradient and of the item-table gradient in split arithmetic may
+    not exceed 1.5 x the exact arithmetic's (2 x for the d-element vectors).  UR_ERROR_TABLE_OUT=<file>: the table is appended there (profiles/r06_k_chain_split_error.txt)."""
+    import os
+    from oracle import model_ref
+    from unirec_amd.model.sequential.sasrec import SASRec
+    from test_gpu_parity import _dense_table_grad
+    N, K = 3000, 4
+    cfg = dict(model="SASRec", n_users=10, n_items=N, device="cuda:0", loss_type="bpr", embedding_size=d, hidden_size=d, dropout_prob=0.0,
+               init_method="normal", init_mean=0.0, init_std=0.05, has_user_emb=False, has_user_bias=False, has_item_bias=False,
+               distance_type="dot", tau=1.0, train_file_format="user-item", exp_name="t", n_layers=2, n_heads=heads, inner_size=4 * d,
+               hidden_dropout_prob=0.0, attn_dropout_prob=0.0, hidden_act="swish", layer_norm_eps=1e-10, max_seq_len=L,
+               use_position_emb=True, seed=2022)
+    g = torch.Generator().manual_seed(d + L)
+    seq = torch.randint(1, N, (B, L), generator=g, dtype=torch.int64).to(torch.int32)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[::4] = L
+    seq = torch.where(torch.arange(L)[None, :] >= (L - lens)[:, None], seq, torch.zeros_like(seq)).contiguous()
+    item_id = torch.randint(1, N, (B, K + 1), generator=g)
+    label = torch.zeros(B, K + 1, dtype=torch.int32)
+    label[:, 0] = 1
+    got = {}
+    sd = None
+    for arith in (6, 0):
+        torch.manual_seed(1)
+        m = SASRec(dict(cfg, mfma_arith=arith))
+        if sd is None:
+            sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+            for k in sd:                       # trained-looking weights: LayerNorm affine and biases off their initial 1 / 0
+                if sd[k].dim() == 1:
+                    sd[k] += 0.1 * torch.randn(sd[k].shape, generator=g)
+        m.load_state_dict(sd)
+        m.check_views()
+        m.train()
+        loss, _, ue, _ = m(item_id=item_id.cuda(), label=label.cuda(), item_seq=seq.cuda(), return_loss_only=False)
+        loss.backward()
+        torch.cuda.synchronize()
+        out = {"user_emb": ue.detach().cpu(), "item_embedding.weight": torch.from_numpy(_dense_table_grad(m, "item_embedding", N, d))}
+        for k, p in m.named_parameters():
+            if k == "item_embedding.weight" or not p.requires_grad:
+                continue
+            off = (p.data_ptr() - m.dense_flat.data_ptr()) // 4
+            out[k] = m.dense_flat.grad[off:off + p.numel()].view(p.shape).cpu().clone()
+        got[arith] = out
+    P64 = {k: v.double() for k, v in sd.items()}
+    _, _, ue64, G64 = model_ref.grads_of(P64, dict(item_seq=seq, item_id=item_id, label=label, user_id=torch.ones(B, dtype=torch.int64)), cfg)
+    ref = dict(G64)
+    ref["user_emb"] = ue64
+    lines, worst = [], 0.0
+    for k in got[6]:
+        if k.endswith("key.bias"):             # analytically zero (softmax shift invariance): rounding noise on both sides
+            continue
+        e6, e0 = _l2(got[6][k], ref[k]), _l2(got[0][k], ref[k])
+        lines.append(f"  {k:48s} split {e6:.3e}   exact {e0:.3e}   ratio {e6 / max(e0, 1e-30):.2f}")
+        worst = max(worst, e6 / max(e0, 1e-30))
+        gate = 1.5 if ref[k].numel() >= 1024 else 2.0   # (a d-element vector: few samples, the L2 statistic itself scatters by ~ 30 %)
+        assert e6 <= gate * e0 + 1e-9, (k, e6, e0)
+    text = f"d={d} L={L} heads={heads} B={B} inner={4 * d} 2 layers: relative L2 error vs the fp64 oracle; worst ratio {worst:.2f}\n" + "\n".join(lines)
+    print(text)
+    if os.environ.get("UR_ERROR_TABLE_OUT"):
+        with open(os.environ["UR_ERROR_TABLE_OUT"], "a") as f:
+            f.write(text + "\n")

@@ -824,7 +824,7 @@ static std::atomic<int> g_mfma_arith{-1};
 static thread_local int g_arith_scope = -1;   // >= 0: the arithmetic of the encoder call in progress (UrSasrecCfg / UrGruCfg .mfma_arith)
 ArithScope::ArithScope(int terms) : prev(g_arith_scope) {
   const int base = terms & 0xFF;
-  g_arith_scope = (base == 6 || base == 9 || base == 3) ? terms & 0x1FF : 0;
+  g_arith_scope = (base == 6 || base == 9 || base == 3) ? terms & 0x3FF : 0;
 }
 ArithScope::~ArithScope() { g_arith_scope = prev; }
 int mfma_arith() {
@@ -952,11 +952,13 @@ int gemm_tn_group(const TnReq* req, int n, hipStream_t st, ReduceBatch* defer) {
     static const int force_ts = ur_test_hook("tn_split_ts", 0);
     if (force_ts == 64 || force_ts == 128) return gemm_tn_group_split(req, n, st, defer, arith & 0xFF, zeros, force_ts);
     // (the wide form needs a partner workgroup on its CU -- one's split runs under the other's MFMAs: a group of few tiles cannot be cut
-    // into ~2 workgroups per CU (C4's encoder at H = 128: two products, six tiles, measured 8 % slower than the exact kernel) and stays exact)
+    // into ~2 workgroups per CU (C4's encoder at H = 128: two products, six tiles, measured 8 % slower than the exact kernel) and stays exact;
+    // scope bit 0x200 -- set by ur_sasrec_bwd -- waives that: its small group (the last-row layer's K, V product + B-row products) runs
+    // on the side stream UNDER the backward row chain, where the shorter matrix-pipe time matters and the fill does not: - 4.5 us per step)
     long long tiles128 = 0;
     for (int i = 0; i < n; ++i) tiles128 += (long long)cdiv(req[i].R, ST) * cdiv(req[i].Cc, ST) * (req[i].T >= 2048 ? 1 : 0);
     static const int min_wg = ur_test_hook("tn_split_minwg", 384);
-    const bool enough = any || tiles128 * TN_SPLIT_SMAX >= min_wg;
+    const bool enough = any || (arith & 0x200) || tiles128 * TN_SPLIT_SMAX >= min_wg;
     if (used >= 0.7 * tiled && enough) return gemm_tn_group_split(req, n, st, defer, arith & 0xFF, zeros, ST);     // d = 128-class products
     if (used >= 0.7 * tiled && !enough) goto exact;
     if (any || used >= 0.7 * tiled64) return gemm_tn_group_split(req, n, st, defer, arith & 0xFF, zeros, 64);   // d = 64-class (round 6b)
@@ -1119,6 +1121,34 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb)
   int j = 0;
   while (j + 1 < tb.n && (int)blockIdx.x >= tb.item[j + 1].first_block) ++j;
   const TransposeItem it = tb.item[j];
+  if (it.mode) {   // split copy: a thread = (K-slice kb, k group g, column n) = one 16-byte cell of each of the three piece planes
+    const int K = it.mode == 1 ? it.rows : it.cols, N = it.mode == 1 ? it.cols : it.rows;
+    const long long cell = (long long)(blockIdx.x - it.first_block) * 256 + threadIdx.x;
+    if (cell >= (long long)(K / 16) * 2 * N) return;
+    const int n = (int)(cell % N), g = (int)(cell / N) & 1, kb = (int)(cell / (2LL * N));
+    float x[8];
+    if (it.mode == 1) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = it.src[(long long)(16 * kb + 4 * g + (q & 3) + 8 * (q >> 2)) * N + n];
+    } else {
+      const float4 lo4 = *(const float4*)(it.src + (long long)n * K + 16 * kb + 4 * g), hi4 = *(const float4*)(it.src + (long long)n * K + 16 * kb + 8 + 4 * g);
+      x[0] = lo4.x; x[1] = lo4.y; x[2] = lo4.z; x[3] = lo4.w; x[4] = hi4.x; x[5] = hi4.y; x[6] = hi4.z; x[7] = hi4.w;
+    }
+    typedef unsigned int tu32x4 __attribute__((ext_vector_type(4)));
+    tu32x4 pc[3];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {   // (odd element's upper half | even element's upper half), as tn_split_wg::split_store
+      const float xe = x[2 * h], xo = x[2 * h + 1];
+      const float re = xe - __uint_as_float(__float_as_uint(xe) & 0xFFFF0000u), ro = xo - __uint_as_float(__float_as_uint(xo) & 0xFFFF0000u);
+      const float se = re - __uint_as_float(__float_as_uint(re) & 0xFFFF0000u), so = ro - __uint_as_float(__float_as_uint(ro) & 0xFFFF0000u);
+      pc[0][h] = __builtin_amdgcn_perm(__float_as_uint(xo), __float_as_uint(xe), 0x07060302u);
+      pc[1][h] = __builtin_amdgcn_perm(__float_as_uint(ro), __float_as_uint(re), 0x07060302u);
+      pc[2][h] = __builtin_amdgcn_perm(__float_as_uint(so), __float_as_uint(se), 0x07060302u);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ((tu32x4*)it.dst)[((long long)(kb * 3 + q) * 2 + g) * N + n] = pc[q];
+    return;
+  }
   const int t = blockIdx.x - it.first_block, tcols = (it.cols + 31) / 32;
   const int bx = (t % tcols) * 32, by = (t / tcols) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -1135,6 +1165,12 @@ int transpose_batch(TransposeBatch& tb, hipStream_t st) {
   int blocks = 0;
   for (int i = 0; i < tb.n; ++i) {
     tb.item[i].first_block = blocks;
+    if (tb.item[i].mode) {
+      const int K = tb.item[i].mode == 1 ? tb.item[i].rows : tb.item[i].cols, N = tb.item[i].mode == 1 ? tb.item[i].cols : tb.item[i].rows;
+      if (K % 16) return fail(UR_ERR_ARG, "transpose_batch: split copy of a matrix with K=%d", K);
+      blocks += cdiv((long long)(K / 16) * 2 * N, 256);
+      continue;
+    }
     blocks += cdiv(tb.item[i].cols, 32) * cdiv(tb.item[i].rows, 32);
   }
   if (tb.zero_ptr) {

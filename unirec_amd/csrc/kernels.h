@@ -119,9 +119,9 @@ int set_mfma_arith(int terms);
 struct ArithScope { int prev; explicit ArithScope(int terms); ~ArithScope(); ArithScope(const ArithScope&) = delete; ArithScope& operator=(const ArithScope&) = delete; };
 // dst[c,r] = src[r,c]
 int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
-struct TransposeItem { const float* src; float* dst; int rows, cols, first_block; };
+struct TransposeItem { const float* src; float* dst; int rows, cols, first_block, mode; };   // mode 0: transpose; 1 / 2: split copy (add_split)
 struct TransposeBatch {
-  static constexpr int MAX = 32;
+  static constexpr int MAX = 48;
   TransposeItem item[MAX]; int n = 0;
   float* zero_ptr = nullptr; long long zero_n = 0; int zero_first_block = 0;   // optional: also zero-fill a buffer (n % 4 == 0)
   float* zero2_ptr = nullptr; long long zero2_n = 0; int zero2_first_block = 0; // ... and a second one
@@ -129,7 +129,14 @@ struct TransposeBatch {
   const int* copy_src = nullptr; int* copy_dst = nullptr;                        // optional rider: one int copied (the backward's own copy of the valid-row count)
   bool add(const float* src, int rows, int cols, float* dst) {
     if (n >= MAX) return false;
-    item[n++] = TransposeItem{src, dst, rows, cols, 0};
+    item[n++] = TransposeItem{src, dst, rows, cols, 0, 0};
+    return true;
+  }
+  // the SPLIT copy the row-chain kernels stream in split-bf16 arithmetic (rowchain.hip: RcW<true>) of the K-major matrix Wt [K, N]:
+  // Wt = src [rows = K, cols = N] (as_stored) or Wt = src^T with src [rows = N, cols = K].  K % 16 == 0; dst: 3/2 K N floats
+  bool add_split(const float* src, int rows, int cols, float* dst, bool as_stored) {
+    if (n >= MAX) return false;
+    item[n++] = TransposeItem{src, dst, rows, cols, 0, as_stored ? 1 : 2};
     return true;
   }
 };
@@ -160,6 +167,7 @@ struct ChainFwdArgs {
   float* split_part = nullptr;          // chain_ffn_fwd_split: [row blocks][I/d][rows per block][d] partial dense_2 outputs
   unsigned* split_cnt = nullptr;        //   and one completion counter per row block (zero on entry, reset by the kernel)
   int arrive_mode = 0;                  //   ur_arrive_mode(): memory order of the arrival / test skew (common.h)
+  bool wsplit = false;                  // the weight pointers name SPLIT copies (three bf16 pieces per weight, rowchain.hip: RcW<true>): split-bf16 arithmetic
 };
 struct ChainBwdArgs {
   const float* gy;                      // d loss / d y  [M, d]
@@ -180,6 +188,7 @@ struct ChainBwdArgs {
   // unmasked g_tf / g_ta; the GEMMs (and the weight-gradient products) take the masked copies, written to g_tfd / g_tad
   DropSpec drop_ffn = {}, drop_out = {};
   float *g_tfd = nullptr, *g_tad = nullptr;
+  bool wsplit = false;                  // the weight pointers name SPLIT copies (three bf16 pieces per weight, rowchain.hip: RcW<true>): split-bf16 arithmetic
 };
 struct ChainProjBwdArgs {
   const float* g; int ldg; int K;       // [M, K] gradient of the projection output; K % d == 0
@@ -190,6 +199,7 @@ struct ChainProjBwdArgs {
   float* part;                          // with LayerNorm: [workgroups][2 d] d gamma | d beta partial sums
   int M; const int* m_dev;
   DropSpec drop = {};                   // with LayerNorm: x0 = dropout(LN0(.)) -- the result is masked before the LayerNorm backward (thresh 0: off)
+  bool wsplit = false;                  // the weight pointers name SPLIT copies (three bf16 pieces per weight, rowchain.hip: RcW<true>): split-bf16 arithmetic
 };
 struct ChainEmbedArgs {
   const int* seq;                       // [B*L] item ids of the padded token grid
@@ -201,6 +211,7 @@ struct ChainEmbedArgs {
   float *x0, *x0hat, *rstd0;            // outputs: the layer input [M, d], its normalised copy and 1/std (for the backward)
   const float *wnT, *bn; float* outn; int ldn, Nn, ldwn;   // first projection: x0 Wn^T + bn; WnT [d, ldwn] (columns = outputs), Nn % d == 0
   int M; const int* m_dev;
+  bool wsplit = false;                  // the weight pointers name SPLIT copies (three bf16 pieces per weight, rowchain.hip: RcW<true>): split-bf16 arithmetic
 };
 int chain_embed_proj(const ChainEmbedArgs& a, int d, hipStream_t st);   // lookup + position + LayerNorm + the first layer's Q/K/V projection
 int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st);

@@ -58,7 +58,6 @@ struct RcGeom {
   static constexpr int RS = D + 4;                  // row stride of the reduction scratch laid over a dead tile
   static constexpr int TPR = D / 4;                 // lanes per row in the row-wise epilogues (one float4 each)
   static constexpr int RPP = 256 / TPR;             // rows per epilogue pass; 4 passes cover the BM rows
-  static constexpr int WV = 2;                      // fx4 registers per lane per weight slice: k offsets fk .. fk+3 and 8 + fk .. of ITS column
   static constexpr int TILE = BM * TS;              // floats per activation tile
   static constexpr size_t LDS_BYTES = (size_t)(2 * TILE) * sizeof(float);
 };
@@ -75,13 +74,25 @@ __device__ __forceinline__ int rc_toff(int r, int c4) {
 // (rc_woff, a function of the row stride only): column = the wave's 32-column block + lane & 31, k offset 4 (lane >> 5) (the
 // fragment layout of rc_gemm).  Eight dword loads per slice off one 32-bit lane offset -- with a per-lane 64-bit pointer the eight row
 // addresses of a slice cost 16 registers per stream and the forward chain spilled.
-template <int D>
+// SP = true (round 6): the streamed weight matrix is a SPLIT copy -- every fp32 weight as three bf16 pieces (gemm.hip: split-bf16
+// arithmetic) in the fragment layout of v_mfma_f32_32x32x16_bf16: [K / 16][piece][k group g][column n][8 bf16 = k 16 kb + 4 g + {0..3}, 16 kb + 8 + 4 g + {0..3}]
+// (weight_split_kernel, gemm.hip), i.e. 16 B per (slice, piece, lane) where the fp32 stream has eight dwords per (slice, lane): three
+// b128 loads per slice, 512 contiguous bytes per half-wave.  Pointers into a split copy are kept in float units (4 per 16-byte cell).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <bool SP> struct RcW { typedef fx4 T; static constexpr int N = 2; };          // fp32 stream: k offsets fk .. fk+3 and 8 + fk .. of ITS column
+template <> struct RcW<true> { typedef bf16x8 T; static constexpr int N = 3; };        // split stream: the hi / mid / lo pieces of the same eight k
+template <bool SP>
+__device__ __forceinline__ long long rc_kstep(int ldt) { return (SP ? 24LL : (long long)RC_BK) * ldt; }   // floats from one K-slice to the next
+template <int D, bool SP>
 __device__ __forceinline__ const float* rc_wptr(const float* Wt, int ldt, int col0, int k0) {
+  if (SP) return Wt + (long long)(k0 / RC_BK) * 24 * ldt + 4LL * col0;
   return Wt + (long long)k0 * ldt + col0;
 }
-template <int D>
+template <int D, bool SP>
 __device__ __forceinline__ unsigned rc_woff(int ldt, int tid) {   // BYTE offset, unsigned: base + zext(offset) is the scalar-base addressing mode
   const int lane = tid & 63, wc = (tid >> 6) % RcGeom<D>::WC;
+  if (SP) return 16u * (unsigned)((lane >> 5) * ldt + wc * 32 + (lane & 31));
   return 4u * (unsigned)(4 * (lane >> 5) * ldt + wc * 32 + (lane & 31));
 }
 // (buffer loads: the wave-uniform part of an address -- segment base in the resource, k-row offset in the scalar offset -- stays in
@@ -91,20 +102,48 @@ __device__ __forceinline__ float rc_ld(__amdgpu_buffer_rsrc_t rs, unsigned boff,
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)boff, sbyte, 0));
 }
 template <int D>
-__device__ __forceinline__ void rc_wload(fx4 (&r)[RcGeom<D>::WV], const float* p, int ldt, unsigned off) {
+__device__ __forceinline__ void rc_wload(fx4 (&r)[2], const float* p, int ldt, unsigned off) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000);
   const int lb = ldt * 4;
   r[0][0] = rc_ld(rs, off, 0); r[0][1] = rc_ld(rs, off, lb); r[0][2] = rc_ld(rs, off, 2 * lb); r[0][3] = rc_ld(rs, off, 3 * lb);
   r[1][0] = rc_ld(rs, off, 8 * lb); r[1][1] = rc_ld(rs, off, 9 * lb); r[1][2] = rc_ld(rs, off, 10 * lb); r[1][3] = rc_ld(rs, off, 11 * lb);
+}
+template <int D>
+__device__ __forceinline__ void rc_wload(bf16x8 (&r)[3], const float* p, int ldt, unsigned off) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000);
+  const int pb = ldt * 32;   // bytes from one piece plane of a slice to the next: 2 k groups x ldt columns x 16 B
+#pragma unroll
+  for (int q = 0; q < 3; ++q) r[q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, q * pb, 0));
+}
+
+// the three bf16 pieces of eight fp32 values (gemm.hip: tn_split_wg::split_store), element j of a piece = x[j].  The remainders are
+// taken two values at a time (v_pk_add_f32): 9 VALU instructions per pair of values
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rc_split8(const float4 a0, const float4 a1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  const f32x2 x[4] = {{a0.x, a0.y}, {a0.z, a0.w}, {a1.x, a1.y}, {a1.z, a1.w}};
+  u32x4 h, m, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 r = x[j] - __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, x[j]) & 0xFFFF0000u);
+    const f32x2 t = r - __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, r) & 0xFFFF0000u);
+    h[j] = __builtin_amdgcn_perm(__float_as_uint(x[j][1]), __float_as_uint(x[j][0]), 0x07060302u);
+    m[j] = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
+    l[j] = __builtin_amdgcn_perm(__float_as_uint(t[1]), __float_as_uint(t[0]), 0x07060302u);
+  }
+  hi = __builtin_bit_cast(bf16x8, h); mid = __builtin_bit_cast(bf16x8, m); lo = __builtin_bit_cast(bf16x8, l);
 }
 
 // acc += As[BM, D] @ Wt[seg], K = D in NK = D / 16 slices (ldw / ldwn: the k-row strides of this / the next segment's matrix).  As: an LDS activation tile (row stride TS).
 // The weight-slice stream runs TWO slices ahead of the MFMAs (an L2 round trip is longer than one K-step of 8 MFMAs) and never drains
 // inside a workgroup: wp / wnp are rc_wptr of this / the next segment (wnp nullable: the stream then re-reads this segment, unused).
 // Ends with a barrier: every wave is done reading As.
-template <int D>
+// SP: the lane splits its A fragment (the same eight k of its row) into three bf16 pieces in registers and issues the six piece
+// products of order <= 2^-16 on the bf16 pipe -- 6 x 8 passes where the fp32-input MFMA takes 8 x 16: fp32-equivalent results
+// (gemm.hip; profiles/r06_a_stage_a.txt), not bit-identical to the exact stream's.
+template <int D, bool SP>
 __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const float* wp, int ldw, unsigned woff, const float* wnp, int ldwn,
-                                        unsigned wnoff, fx4 (&wreg)[2][RcGeom<D>::WV], int wr, int lane) {
+                                        unsigned wnoff, typename RcW<SP>::T (&wreg)[2][RcW<SP>::N], int wr, int lane) {
   constexpr int NK = D / RC_BK;
   static_assert(NK % 2 == 0, "the two-slot ring assumes an even number of slices per segment");
   const int frow = lane & 31, fk = 4 * (lane >> 5);
@@ -124,32 +163,46 @@ __device__ __forceinline__ void rc_gemm(floatx16& acc, const float* As, const fl
   }
 #pragma unroll
   for (int kt = 0; kt < NK; ++kt) {
-    const fx4 b0 = wreg[kt & 1][0], b1 = wreg[kt & 1][1];
-    if (kt + 2 < NK) rc_wload<D>(wreg[kt & 1], wp + (long long)(kt + 2) * RC_BK * ldw, ldw, woff);
-    else rc_wload<D>(wreg[kt & 1], wnp + (long long)(kt + 2 - NK) * RC_BK * ldwn, ldwn, wnoff);
+    typename RcW<SP>::T b[RcW<SP>::N];
+#pragma unroll
+    for (int q = 0; q < RcW<SP>::N; ++q) b[q] = wreg[kt & 1][q];
+    if (kt + 2 < NK) rc_wload<D>(wreg[kt & 1], wp + (kt + 2) * rc_kstep<SP>(ldw), ldw, woff);
+    else rc_wload<D>(wreg[kt & 1], wnp + (kt + 2 - NK) * rc_kstep<SP>(ldwn), ldwn, wnoff);
     __builtin_amdgcn_sched_barrier(0);   // (the loads stay here: the scheduler would sink them to just ahead of their use)
     const float4 a0 = *(const float4*)(As + aoff[kt % NA][0] + (kt / NA) * 64);
     const float4 a1 = *(const float4*)(As + aoff[kt % NA][1] + (kt / NA) * 64);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
+    if constexpr (SP) {
+      bf16x8 ah, am, al;
+      rc_split8(a0, a1, ah, am, al);
+      // small terms first, the leading product last
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0], acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[0][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b[0][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b[0][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b[0][3], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b[1][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b[1][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b[1][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b[1][3], acc, 0, 0, 0);
+    }
   }
   __syncthreads();   // every wave is done reading As: the caller may overwrite it
 }
 
 // start of the stream: slice 0 of the first segment at kernel entry, slice 1 behind the tile staging loads
-template <int D>
-__device__ __forceinline__ void rc_prime_load(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw, unsigned woff) {
+template <int D, bool SP>
+__device__ __forceinline__ void rc_prime_load(typename RcW<SP>::T (&wreg)[2][RcW<SP>::N], const float* wp, int ldw, unsigned woff) {
   rc_wload<D>(wreg[0], wp, ldw, woff);
 }
-template <int D>
-__device__ __forceinline__ void rc_prime_next(fx4 (&wreg)[2][RcGeom<D>::WV], const float* wp, int ldw, unsigned woff) {   // slice 1, once the tile staging loads are out
-  rc_wload<D>(wreg[1], wp + (long long)RC_BK * ldw, ldw, woff);
+template <int D, bool SP>
+__device__ __forceinline__ void rc_prime_next(typename RcW<SP>::T (&wreg)[2][RcW<SP>::N], const float* wp, int ldw, unsigned woff) {   // slice 1, once the tile staging loads are out
+  rc_wload<D>(wreg[1], wp + rc_kstep<SP>(ldw), ldw, woff);
 }
 
 // accumulator tile -> LDS tile.  acc[r]: row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of the wave's 32 x 32 tile.
@@ -260,7 +313,7 @@ __device__ __forceinline__ void rc_block_colsum(float4 dg, float4 db, float* red
 
 // =============================================================================================== forward
 
-template <int D>
+template <int D, bool SP>
 __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   using G = RcGeom<D>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -273,10 +326,10 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / G::WC, wc = wave % G::WC;
   const float inv_n = 1.0f / (float)D;
-  fx4 wreg[2][G::WV];
-  const unsigned woff_d = rc_woff<D>(D, tid), woff_i = rc_woff<D>(a.I, tid), woff_n = a.wnT ? rc_woff<D>(a.ldwn, tid) : 0;
+  typename RcW<SP>::T wreg[2][RcW<SP>::N];
+  const unsigned woff_d = rc_woff<D, SP>(D, tid), woff_i = rc_woff<D, SP>(a.I, tid), woff_n = a.wnT ? rc_woff<D, SP>(a.ldwn, tid) : 0;
   auto WOFF = [&](int ld) { return ld == D ? woff_d : (ld == a.I ? woff_i : woff_n); };   // this lane's element offset in a K-major matrix of row stride ld
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D));   // the first weight slice is in flight while the ctx tile is staged
+  rc_prime_load<D, SP>(wreg, rc_wptr<D, SP>(a.woT, D, 0, 0), D, WOFF(D));   // the first weight slice is in flight while the ctx tile is staged
   {
   const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
 #pragma unroll
@@ -287,13 +340,13 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
     *(float4*)(At + rc_toff<D>(ml, et)) = v;
   }
   }
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D));
+  rc_prime_next<D, SP>(wreg, rc_wptr<D, SP>(a.woT, D, 0, 0), D, WOFF(D));
   __syncthreads();
 
   // ---- 1. attention output projection + residual + LayerNorm
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D), rc_wptr<D>(a.w1T, a.I, 0, 0), a.I, WOFF(a.I), wreg, wr, lane);
+    rc_gemm<D, SP>(acc, At, rc_wptr<D, SP>(a.woT, D, 0, 0), D, WOFF(D), rc_wptr<D, SP>(a.w1T, a.I, 0, 0), a.I, WOFF(a.I), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -330,10 +383,10 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   floatx16 accy = zero16();
   const int nc = a.I / D;
   for (int c = 0; c < nc; ++c) {
-    const float* w2p = rc_wptr<D>(a.w2T, D, 0, c * D);
+    const float* w2p = rc_wptr<D, SP>(a.w2T, D, 0, c * D);
     {
       floatx16 acch = zero16();
-      rc_gemm<D>(acch, At, rc_wptr<D>(a.w1T, a.I, c * D, 0), a.I, WOFF(a.I), w2p, D, WOFF(D), wreg, wr, lane);
+      rc_gemm<D, SP>(acch, At, rc_wptr<D, SP>(a.w1T, a.I, c * D, 0), a.I, WOFF(a.I), w2p, D, WOFF(D), wreg, wr, lane);
       rc_acc_to_tile<D>(acch, Ht, wr, wc, lane);
     }
     __syncthreads();
@@ -357,8 +410,8 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
       }
     }
     __syncthreads();
-    const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w1T, a.I, (c + 1) * D, 0) : (a.wnT ? rc_wptr<D>(a.wnT, a.ldwn, 0, 0) : nullptr);
-    rc_gemm<D>(accy, Ht, w2p, D, WOFF(D), nxp, c + 1 < nc ? a.I : a.ldwn, WOFF(c + 1 < nc ? a.I : a.ldwn), wreg, wr, lane);
+    const float* nxp = c + 1 < nc ? rc_wptr<D, SP>(a.w1T, a.I, (c + 1) * D, 0) : (a.wnT ? rc_wptr<D, SP>(a.wnT, a.ldwn, 0, 0) : nullptr);
+    rc_gemm<D, SP>(accy, Ht, w2p, D, WOFF(D), nxp, c + 1 < nc ? a.I : a.ldwn, WOFF(c + 1 < nc ? a.I : a.ldwn), wreg, wr, lane);
   }
 
   // ---- 3. y = LN(drop(acc + b2) + a)
@@ -398,7 +451,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_fwd_kernel(ChainFwdArgs a) {
   const int nn = a.Nn / D;
   for (int c = 0; c < nn; ++c) {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wnT, a.ldwn, c * D, 0), a.ldwn, WOFF(a.ldwn), c + 1 < nn ? rc_wptr<D>(a.wnT, a.ldwn, (c + 1) * D, 0) : nullptr, a.ldwn, WOFF(a.ldwn), wreg, wr, lane);
+    rc_gemm<D, SP>(acc, At, rc_wptr<D, SP>(a.wnT, a.ldwn, c * D, 0), a.ldwn, WOFF(a.ldwn), c + 1 < nn ? rc_wptr<D, SP>(a.wnT, a.ldwn, (c + 1) * D, 0) : nullptr, a.ldwn, WOFF(a.ldwn), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
     __syncthreads();
     const int eg = rc_fresh(tid / G::TPR), et = rc_fresh(tid % G::TPR);
@@ -487,10 +540,10 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   const int wr = wave / G::WC, wc = wave % G::WC;
   const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_n = 1.0f / (float)D;
-  fx4 wreg[2][G::WV];
-  const unsigned woff_d = rc_woff<D>(D, tid), woff_i = rc_woff<D>(a.I, tid);
+  fx4 wreg[2][2];
+  const unsigned woff_d = rc_woff<D, false>(D, tid), woff_i = rc_woff<D, false>(a.I, tid);
   auto WOFF = [&](int ld) { return ld == D ? woff_d : woff_i; };
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D));
+  rc_prime_load<D, false>(wreg, rc_wptr<D, false>(a.woT, D, 0, 0), D, WOFF(D));
   // every small operand of the epilogues is requested HERE (one workgroup per CU, parameters rewritten by the optimizer a moment ago:
   // each of these is a miss all the way to HBM, ~2 us when it is asked for where it is used, behind a barrier)
   const float4 q_bo = *(const float4*)(a.bo + et * 4), q_g1 = *(const float4*)(a.g1 + et * 4), q_b1ln = *(const float4*)(a.b1ln + et * 4);
@@ -506,12 +559,12 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
     if (m < M) v = *(const float4*)(a.ctx + (long long)m * a.ldctx + et * 4);
     *(float4*)(At + rc_toff<D>(ml, et)) = v;
   }
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D));
+  rc_prime_next<D, false>(wreg, rc_wptr<D, false>(a.woT, D, 0, 0), D, WOFF(D));
   __syncthreads();
   // ---- 1. attention output projection + residual + LayerNorm (every chunk's workgroup; chunk 0 writes a / ahat / rstd1)
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.woT, D, 0, 0), D, WOFF(D), rc_wptr<D>(a.w1T, a.I, c * D, 0), a.I, WOFF(a.I), wreg, wr, lane);
+    rc_gemm<D, false>(acc, At, rc_wptr<D, false>(a.woT, D, 0, 0), D, WOFF(D), rc_wptr<D, false>(a.w1T, a.I, c * D, 0), a.I, WOFF(a.I), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -544,10 +597,10 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   }
   __syncthreads();
   // ---- 2. dense_1 + activation for chunk c, then this chunk's partial of dense_2
-  const float* w2p = rc_wptr<D>(a.w2T, D, 0, c * D);
+  const float* w2p = rc_wptr<D, false>(a.w2T, D, 0, c * D);
   {
     floatx16 acch = zero16();
-    rc_gemm<D>(acch, At, rc_wptr<D>(a.w1T, a.I, c * D, 0), a.I, WOFF(a.I), w2p, D, WOFF(D), wreg, wr, lane);
+    rc_gemm<D, false>(acch, At, rc_wptr<D, false>(a.w1T, a.I, c * D, 0), a.I, WOFF(a.I), w2p, D, WOFF(D), wreg, wr, lane);
     rc_acc_to_tile<D>(acch, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -571,7 +624,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
   }
   __syncthreads();
   floatx16 accy = zero16();
-  rc_gemm<D>(accy, Ht, w2p, D, WOFF(D), nullptr, D, WOFF(D), wreg, wr, lane);
+  rc_gemm<D, false>(accy, Ht, w2p, D, WOFF(D), nullptr, D, WOFF(D), wreg, wr, lane);
   rc_acc_to_tile<D>(accy, Ht, wr, wc, lane);
   __syncthreads();
   // ---- 3. the partial -> memory (device scope), count, and the last workgroup of the row block finishes
@@ -624,7 +677,7 @@ __global__ __launch_bounds__(256) void chain_ffn_fwd_split_kernel(ChainFwdArgs a
 
 // =============================================================================================== backward of the same block
 
-template <int D>
+template <int D, bool SP>
 __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   using G = RcGeom<D>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -641,10 +694,10 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   }
   const int wr = wave / G::WC, wc = wave % G::WC;
   const float inv_d = 1.0f / (float)D;
-  fx4 wreg[2][G::WV];
-  const unsigned woff_d = rc_woff<D>(D, tid), woff_i = rc_woff<D>(a.I, tid);
+  typename RcW<SP>::T wreg[2][RcW<SP>::N];
+  const unsigned woff_d = rc_woff<D, SP>(D, tid), woff_i = rc_woff<D, SP>(a.I, tid);
   auto WOFF = [&](int ld) { return ld == D ? woff_d : woff_i; };
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.w2, a.I, 0, 0), a.I, WOFF(a.I));
+  rc_prime_load<D, SP>(wreg, rc_wptr<D, SP>(a.w2, a.I, 0, 0), a.I, WOFF(a.I));
 
   // ---- 0. feed-forward LayerNorm backward: g_tf (also the residual branch of g_a)
   {
@@ -669,17 +722,17 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
     }
     rc_block_colsum<D>(dg, db, Ht, part, eg, et, tid);
   }
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.w2, a.I, 0, 0), a.I, WOFF(a.I));
+  rc_prime_next<D, SP>(wreg, rc_wptr<D, SP>(a.w2, a.I, 0, 0), a.I, WOFF(a.I));
   __syncthreads();
 
   // ---- 1. g_h1 chunk = (g_tf W2[:, chunk]) * act'(h1 chunk);   g_a += g_h1 chunk W1[chunk, :]
   floatx16 acca = zero16();
   const int nc = a.I / D;
   for (int c = 0; c < nc; ++c) {
-    const float* w1p = rc_wptr<D>(a.w1, D, 0, c * D);
+    const float* w1p = rc_wptr<D, SP>(a.w1, D, 0, c * D);
     {
       floatx16 accu = zero16();
-      rc_gemm<D>(accu, At, rc_wptr<D>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I), w1p, D, WOFF(D), wreg, wr, lane);
+      rc_gemm<D, SP>(accu, At, rc_wptr<D, SP>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I), w1p, D, WOFF(D), wreg, wr, lane);
       rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
     }
     __syncthreads();
@@ -705,8 +758,8 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
       }
     }
     __syncthreads();
-    const float* nxp = c + 1 < nc ? rc_wptr<D>(a.w2, a.I, (c + 1) * D, 0) : rc_wptr<D>(a.wo, D, 0, 0);
-    rc_gemm<D>(acca, Ht, w1p, D, WOFF(D), nxp, c + 1 < nc ? a.I : D, WOFF(c + 1 < nc ? a.I : D), wreg, wr, lane);
+    const float* nxp = c + 1 < nc ? rc_wptr<D, SP>(a.w2, a.I, (c + 1) * D, 0) : rc_wptr<D, SP>(a.wo, D, 0, 0);
+    rc_gemm<D, SP>(acca, Ht, w1p, D, WOFF(D), nxp, c + 1 < nc ? a.I : D, WOFF(c + 1 < nc ? a.I : D), wreg, wr, lane);
   }
 
   // ---- 2. g_a = acc + g_tf;  attention LayerNorm backward -> g_ta
@@ -742,7 +795,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
   // ---- 3. g_ctx = g_ta Wo
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0), D, WOFF(D), nullptr, 0, WOFF(0), wreg, wr, lane);
+    rc_gemm<D, SP>(acc, At, rc_wptr<D, SP>(a.wo, D, 0, 0), D, WOFF(D), nullptr, 0, WOFF(0), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -756,7 +809,7 @@ __global__ __launch_bounds__(256, 3) void chain_ffn_bwd_kernel(ChainBwdArgs a) {
 
 // =============================================================================================== g_x = g_qkv Wqkv (+ g_ta) (+ LN0 backward)
 
-template <int D>
+template <int D, bool SP>
 __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a) {
   using G = RcGeom<D>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -773,11 +826,11 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   }
   const int wr = wave / G::WC, wc = wave % G::WC;
   const int et = tid % G::TPR, eg = tid / G::TPR;
-  fx4 wreg[2][G::WV];
-  const unsigned woff_w = rc_woff<D>(a.ldw, tid);
+  typename RcW<SP>::T wreg[2][RcW<SP>::N];
+  const unsigned woff_w = rc_woff<D, SP>(a.ldw, tid);
   auto WOFF = [&](int) { return woff_w; };
   const int nkc = a.K / D;
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.w, a.ldw, 0, 0), a.ldw, WOFF(a.ldw));
+  rc_prime_load<D, SP>(wreg, rc_wptr<D, SP>(a.w, a.ldw, 0, 0), a.ldw, WOFF(a.ldw));
   float4 ra[4];
   auto load_a = [&](int kc) {
 #pragma unroll
@@ -792,13 +845,13 @@ __global__ __launch_bounds__(256) void chain_proj_bwd_kernel(ChainProjBwdArgs a)
   };
   load_a(0);
   store_a();
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.w, a.ldw, 0, 0), a.ldw, WOFF(a.ldw));
+  rc_prime_next<D, SP>(wreg, rc_wptr<D, SP>(a.w, a.ldw, 0, 0), a.ldw, WOFF(a.ldw));
   __syncthreads();
   floatx16 acc = zero16();
   for (int kc = 0; kc < nkc; ++kc) {
     const bool more = kc + 1 < nkc;
     if (more) load_a(kc + 1);   // the next slice of g is in flight underneath this chunk's MFMAs
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.w, a.ldw, 0, kc * D), a.ldw, WOFF(a.ldw), more ? rc_wptr<D>(a.w, a.ldw, 0, (kc + 1) * D) : nullptr, a.ldw, WOFF(a.ldw), wreg, wr, lane);
+    rc_gemm<D, SP>(acc, At, rc_wptr<D, SP>(a.w, a.ldw, 0, kc * D), a.ldw, WOFF(a.ldw), more ? rc_wptr<D, SP>(a.w, a.ldw, 0, (kc + 1) * D) : nullptr, a.ldw, WOFF(a.ldw), wreg, wr, lane);
     if (more) {
       store_a();
       __syncthreads();
@@ -855,10 +908,10 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   const int wr = wave / G::WC, wc = wave % G::WC;
   const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_d = 1.0f / (float)D;
-  fx4 wreg[2][G::WV];
-  const unsigned woff_d = rc_woff<D>(D, tid), woff_i = rc_woff<D>(a.I, tid);
+  fx4 wreg[2][2];
+  const unsigned woff_d = rc_woff<D, false>(D, tid), woff_i = rc_woff<D, false>(a.I, tid);
   auto WOFF = [&](int ld) { return ld == D ? woff_d : woff_i; };
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I));
+  rc_prime_load<D, false>(wreg, rc_wptr<D, false>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I));
   // (what the later epilogues read from memory is requested here: see chain_ffn_fwd_split_kernel)
   const float4 q_g1 = *(const float4*)(a.g1 + et * 4);
   float4 q_h1[4], q_ahat[4];
@@ -894,13 +947,13 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
     }
     if (c == 0) rc_block_colsum<D>(dg, db, Ht, part, eg, et, tid);   // (workgroup-uniform branch: the barriers inside are fine)
   }
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I));
+  rc_prime_next<D, false>(wreg, rc_wptr<D, false>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I));
   __syncthreads();
   // ---- 1. g_h1 chunk = (g_tf W2[:, chunk]) * act'(h1 chunk);   partial of g_a = g_h1 chunk W1[chunk, :]
-  const float* w1p = rc_wptr<D>(a.w1, D, 0, c * D);
+  const float* w1p = rc_wptr<D, false>(a.w1, D, 0, c * D);
   {
     floatx16 accu = zero16();
-    rc_gemm<D>(accu, At, rc_wptr<D>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I), w1p, D, WOFF(D), wreg, wr, lane);
+    rc_gemm<D, false>(accu, At, rc_wptr<D, false>(a.w2, a.I, c * D, 0), a.I, WOFF(a.I), w1p, D, WOFF(D), wreg, wr, lane);
     rc_acc_to_tile<D>(accu, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -925,7 +978,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   }
   __syncthreads();
   floatx16 acca = zero16();
-  rc_gemm<D>(acca, Ht, w1p, D, WOFF(D), rc_wptr<D>(a.wo, D, 0, 0), D, WOFF(D), wreg, wr, lane);
+  rc_gemm<D, false>(acca, Ht, w1p, D, WOFF(D), rc_wptr<D, false>(a.wo, D, 0, 0), D, WOFF(D), wreg, wr, lane);
   rc_acc_to_tile<D>(acca, Ht, wr, wc, lane);
   __syncthreads();
   // ---- 2. the partial -> memory (device scope), count; the last workgroup of the row block goes on
@@ -979,7 +1032,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
   // ---- 4. g_ctx = g_ta Wo
   {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wo, D, 0, 0), D, WOFF(D), nullptr, 0, WOFF(0), wreg, wr, lane);
+    rc_gemm<D, false>(acc, At, rc_wptr<D, false>(a.wo, D, 0, 0), D, WOFF(D), nullptr, 0, WOFF(0), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
   }
   __syncthreads();
@@ -995,7 +1048,7 @@ __global__ __launch_bounds__(256) void chain_ffn_bwd_split_kernel(ChainBwdArgs a
 // through the LayerNorm into the LDS tile (and out to x0 / x0hat / rstd0 for the backward) and are the A operand of the projection
 // straight away -- the stand-alone lookup kernel (10-13 us) and the x0 round trip disappear.  Same arithmetic as embed_ln_fwd_kernel
 // (rowops.hip) + the stand-alone projection GEMM (same K order).
-template <int D>
+template <int D, bool SP>
 __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a) {
   using G = RcGeom<D>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1009,10 +1062,10 @@ __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a)
   const int wr = wave / G::WC, wc = wave % G::WC;
   const int et = tid % G::TPR, eg = tid / G::TPR;
   const float inv_n = 1.0f / (float)D;
-  fx4 wreg[2][G::WV];
-  const unsigned woff_n = rc_woff<D>(a.ldwn, tid);
+  typename RcW<SP>::T wreg[2][RcW<SP>::N];
+  const unsigned woff_n = rc_woff<D, SP>(a.ldwn, tid);
   auto WOFF = [&](int) { return woff_n; };
-  rc_prime_load<D>(wreg, rc_wptr<D>(a.wnT, a.ldwn, 0, 0), a.ldwn, WOFF(a.ldwn));   // the first weight slice is in flight while the rows are gathered
+  rc_prime_load<D, SP>(wreg, rc_wptr<D, SP>(a.wnT, a.ldwn, 0, 0), a.ldwn, WOFF(a.ldwn));   // the first weight slice is in flight while the rows are gathered
   {
     const float4 gm = *(const float4*)(a.g0 + et * 4), bt = *(const float4*)(a.b0ln + et * 4);
     int full[4];
@@ -1047,12 +1100,12 @@ __global__ __launch_bounds__(256) void chain_embed_proj_kernel(ChainEmbedArgs a)
       *(float4*)(At + rc_toff<D>(ml, et)) = o;
     }
   }
-  rc_prime_next<D>(wreg, rc_wptr<D>(a.wnT, a.ldwn, 0, 0), a.ldwn, WOFF(a.ldwn));
+  rc_prime_next<D, SP>(wreg, rc_wptr<D, SP>(a.wnT, a.ldwn, 0, 0), a.ldwn, WOFF(a.ldwn));
   __syncthreads();
   const int nn = a.Nn / D;
   for (int c = 0; c < nn; ++c) {
     floatx16 acc = zero16();
-    rc_gemm<D>(acc, At, rc_wptr<D>(a.wnT, a.ldwn, c * D, 0), a.ldwn, WOFF(a.ldwn), c + 1 < nn ? rc_wptr<D>(a.wnT, a.ldwn, (c + 1) * D, 0) : nullptr, a.ldwn, WOFF(a.ldwn), wreg, wr, lane);
+    rc_gemm<D, SP>(acc, At, rc_wptr<D, SP>(a.wnT, a.ldwn, c * D, 0), a.ldwn, WOFF(a.ldwn), c + 1 < nn ? rc_wptr<D, SP>(a.wnT, a.ldwn, (c + 1) * D, 0) : nullptr, a.ldwn, WOFF(a.ldwn), wreg, wr, lane);
     rc_acc_to_tile<D>(acc, Ht, wr, wc, lane);
     __syncthreads();
     const float4 bs = *(const float4*)(a.bn + c * D + et * 4);
@@ -1092,11 +1145,18 @@ static void set_lds(KernelT k, size_t bytes) {
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-#define UR_CHAIN_DISPATCH(D_, KERNEL, ARGS, GRID)                                                                   \
+#define UR_CHAIN_LAUNCH(TAG, K, LDS, ARGS, GRID)                                                                     \
   do {                                                                                                              \
-    static bool attr_##D_ = (set_lds(KERNEL<D_>, RcGeom<D_>::LDS_BYTES), true);                                     \
-    (void)attr_##D_;                                                                                                \
-    UR_LAUNCH_EV((KERNEL<D_>), dim3(GRID), dim3(256), RcGeom<D_>::LDS_BYTES, st, ARGS);                             \
+    static bool attr_##TAG = (set_lds(K, LDS), true);                                                               \
+    (void)attr_##TAG;                                                                                               \
+    UR_LAUNCH_EV((K), dim3(GRID), dim3(256), LDS, st, ARGS);                                                        \
+  } while (0)
+#define UR_CHAIN_DISPATCH(D_, KERNEL, ARGS, GRID) UR_CHAIN_LAUNCH(D_, KERNEL<D_>, RcGeom<D_>::LDS_BYTES, ARGS, GRID)
+// the kernels with a split-bf16 form: ARGS.wsplit says which weight copies the pointers name (kernels.h)
+#define UR_CHAIN_DISPATCH_SP(D_, KERNEL, ARGS, GRID)                                                                \
+  do {                                                                                                              \
+    if ((ARGS).wsplit) UR_CHAIN_LAUNCH(s##D_, (KERNEL<D_, true>), RcGeom<D_>::LDS_BYTES, ARGS, GRID);               \
+    else UR_CHAIN_LAUNCH(e##D_, (KERNEL<D_, false>), RcGeom<D_>::LDS_BYTES, ARGS, GRID);                            \
   } while (0)
 
 int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
@@ -1105,9 +1165,9 @@ int chain_ffn_fwd(const ChainFwdArgs& a, int d, hipStream_t st) {
   ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I + (a.wnT ? a.Nn : 0)), true);
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
-    case 32: UR_CHAIN_DISPATCH(32, chain_ffn_fwd_kernel, a, grid); break;
-    case 64: UR_CHAIN_DISPATCH(64, chain_ffn_fwd_kernel, a, grid); break;
-    default: UR_CHAIN_DISPATCH(128, chain_ffn_fwd_kernel, a, grid); break;
+    case 32: UR_CHAIN_DISPATCH_SP(32, chain_ffn_fwd_kernel, a, grid); break;
+    case 64: UR_CHAIN_DISPATCH_SP(64, chain_ffn_fwd_kernel, a, grid); break;
+    default: UR_CHAIN_DISPATCH_SP(128, chain_ffn_fwd_kernel, a, grid); break;
   }
   UR_LAUNCH_CHECK();
   return UR_OK;
@@ -1119,9 +1179,9 @@ int chain_embed_proj(const ChainEmbedArgs& a, int d, hipStream_t st) {
   ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * (double)a.Nn, true);
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
-    case 32: UR_CHAIN_DISPATCH(32, chain_embed_proj_kernel, a, grid); break;
-    case 64: UR_CHAIN_DISPATCH(64, chain_embed_proj_kernel, a, grid); break;
-    default: UR_CHAIN_DISPATCH(128, chain_embed_proj_kernel, a, grid); break;
+    case 32: UR_CHAIN_DISPATCH_SP(32, chain_embed_proj_kernel, a, grid); break;
+    case 64: UR_CHAIN_DISPATCH_SP(64, chain_embed_proj_kernel, a, grid); break;
+    default: UR_CHAIN_DISPATCH_SP(128, chain_embed_proj_kernel, a, grid); break;
   }
   UR_LAUNCH_CHECK();
   return UR_OK;
@@ -1195,9 +1255,9 @@ int chain_ffn_bwd(const ChainBwdArgs& a, int d, hipStream_t st) {
   ProfScope ps(chain_class(a.M, d), st, 2.0 * a.M * d * ((double)d + 2.0 * a.I), true);
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
-    case 32: UR_CHAIN_DISPATCH(32, chain_ffn_bwd_kernel, a, grid); break;
-    case 64: UR_CHAIN_DISPATCH(64, chain_ffn_bwd_kernel, a, grid); break;
-    default: UR_CHAIN_DISPATCH(128, chain_ffn_bwd_kernel, a, grid); break;
+    case 32: UR_CHAIN_DISPATCH_SP(32, chain_ffn_bwd_kernel, a, grid); break;
+    case 64: UR_CHAIN_DISPATCH_SP(64, chain_ffn_bwd_kernel, a, grid); break;
+    default: UR_CHAIN_DISPATCH_SP(128, chain_ffn_bwd_kernel, a, grid); break;
   }
   UR_LAUNCH_CHECK();
   return UR_OK;
@@ -1209,9 +1269,9 @@ int chain_proj_bwd(const ChainProjBwdArgs& a, int d, hipStream_t st) {
   ProfScope ps(PC_CHAIN, st, 2.0 * a.M * d * (double)a.K, true);
   const int grid = cdiv(a.M, chain_rows_per_block(d));
   switch (d) {
-    case 32: UR_CHAIN_DISPATCH(32, chain_proj_bwd_kernel, a, grid); break;
-    case 64: UR_CHAIN_DISPATCH(64, chain_proj_bwd_kernel, a, grid); break;
-    default: UR_CHAIN_DISPATCH(128, chain_proj_bwd_kernel, a, grid); break;
+    case 32: UR_CHAIN_DISPATCH_SP(32, chain_proj_bwd_kernel, a, grid); break;
+    case 64: UR_CHAIN_DISPATCH_SP(64, chain_proj_bwd_kernel, a, grid); break;
+    default: UR_CHAIN_DISPATCH_SP(128, chain_proj_bwd_kernel, a, grid); break;
   }
   UR_LAUNCH_CHECK();
   return UR_OK;

@@ -58,6 +58,9 @@ static LayerP layer_ptrs(const float* base, const Layout& l, int i) {
 struct LayerWs {
   float *qkv, *lse, *ctx, *a, *ahat, *rstd1, *h1, *y, *yhat, *rstd2;
   float *wqkvT, *woT, *w1T, *w2T;
+  // split-bf16 copies streamed by the row-chain kernels (kernels.h: TransposeBatch::add_split; 3/2 floats per weight): of the K-major
+  // (transposed) weights for the forward chains, of the weights as stored for the backward chains.  nullptr when the shape has no chains
+  float *s_wqkvT, *s_woT, *s_w1T, *s_w2T, *s_wqkv, *s_wo, *s_w1, *s_w2;
   float *g_tf, *g_ta, *g_h1, *g_qkv;   // backward: LN-backward outputs (FFN / attention block), d h1, d qkv
   float *g_tfd, *g_tad;                // hidden dropout on: dropout-masked g_tf / g_ta (what the block's GEMMs consume)
 };
@@ -90,6 +93,11 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
     lw.a = take(M * d); lw.ahat = take(M * d); lw.rstd1 = take(M); lw.h1 = take(M * I);
     lw.y = take(M * d); lw.yhat = take(M * d); lw.rstd2 = take(M);
     lw.wqkvT = take(3 * d * d); lw.woT = take(d * d); lw.w1T = take(I * d); lw.w2T = take(I * d);
+    lw.s_wqkvT = lw.s_woT = lw.s_w1T = lw.s_w2T = lw.s_wqkv = lw.s_wo = lw.s_w1 = lw.s_w2 = nullptr;
+    if (chain_shape_ok(c.d, c.inner)) {
+      lw.s_wqkvT = take(3 * d * d * 3 / 2); lw.s_woT = take(d * d * 3 / 2); lw.s_w1T = take(I * d * 3 / 2); lw.s_w2T = take(I * d * 3 / 2);
+      lw.s_wqkv = take(3 * d * d * 3 / 2); lw.s_wo = take(d * d * 3 / 2); lw.s_w1 = take(I * d * 3 / 2); lw.s_w2 = take(I * d * 3 / 2);
+    }
     // backward scratch that the weight-gradient GEMMs read: per layer, written once per backward pass, so those GEMMs
     // can run on the side stream without write-after-read hazards against the activation-gradient chain
     lw.g_tf = take(M * d); lw.g_ta = take(M * d); lw.g_h1 = take(M * I); lw.g_qkv = take(M * 3 * d);
@@ -117,6 +125,13 @@ static Ws carve(const UrSasrecCfg& c, float* base) {
   w.m_valid = (int*)take(64);
   w.total_floats = o;
   return w;
+}
+
+// The row-chain kernels run their products in the cfg's arithmetic: split bf16 (six piece products, fp32-equivalent) whenever
+// mfma_arith names a split form, the exact fp32-input MFMA at mfma_arith = 0 (test hook chain_split=0: exact whatever the cfg says).
+static bool chains_split(const UrSasrecCfg& c) {
+  const int base = c.mfma_arith & 0xFF;
+  return (base == 6 || base == 9) && chain_shape_ok(c.d, c.inner) && ur_test_hook("chain_split", 1) != 0;
 }
 
 static int check_cfg(const UrSasrecCfg* c) {
@@ -340,19 +355,19 @@ SideCtx* side_ctx(bool even_if_disabled = false) {
 // LAST ur_sasrec_fwd on that workspace left there.  A backward pass on a workspace whose last forward pass saw other weights, another
 // id matrix or another shape would compute with stale or foreign state without any error: it is refused instead.
 namespace {
-struct FwdStamp { const void* ws; const void* dense; const void* seq; int B, L, d, n_layers; };
+struct FwdStamp { const void* ws; const void* dense; const void* seq; int B, L, d, n_layers; bool wsp; };   // wsp: the split-bf16 weight copies were made (chains_split)
 thread_local FwdStamp g_fwd_stamps[8] = {};
 thread_local int g_fwd_next = 0;
 void stamp_forward(const void* ws, const void* dense, const void* seq, const UrSasrecCfg& c) {
   for (auto& e : g_fwd_stamps)
-    if (e.ws == ws) { e = FwdStamp{ws, dense, seq, c.B, c.L, c.d, c.n_layers}; return; }
-  g_fwd_stamps[g_fwd_next] = FwdStamp{ws, dense, seq, c.B, c.L, c.d, c.n_layers};
+    if (e.ws == ws) { e = FwdStamp{ws, dense, seq, c.B, c.L, c.d, c.n_layers, chains_split(c)}; return; }
+  g_fwd_stamps[g_fwd_next] = FwdStamp{ws, dense, seq, c.B, c.L, c.d, c.n_layers, chains_split(c)};
   g_fwd_next = (g_fwd_next + 1) % 8;
 }
 // -> 0 ok, 1 mismatch, -1 unknown workspace (stamped by another thread, or more than 8 workspaces ago: not checked)
 int check_forward(const void* ws, const void* dense, const void* seq, const UrSasrecCfg& c) {
   for (const auto& e : g_fwd_stamps)
-    if (e.ws == ws) return (e.dense == dense && e.seq == seq && e.B == c.B && e.L == c.L && e.d == c.d && e.n_layers == c.n_layers) ? 0 : 1;
+    if (e.ws == ws) return (e.dense == dense && e.seq == seq && e.B == c.B && e.L == c.L && e.d == c.d && e.n_layers == c.n_layers && e.wsp == chains_split(c)) ? 0 : 1;
   return -1;
 }
 }  // namespace
@@ -386,17 +401,24 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     sc->join_pending = false;
     sc->late_join = false;
   }
+  const bool wsp = chains_split(c);
   {   // K-major copies of every layer's weights, one launch: the forward chain kernels stream THEM (coalesced B operand, rowchain.hip);
       // the backward's unfused GEMMs (gemm_nt: C = A W^T) read the same copies -- the weights do not change between the two passes
     TransposeBatch tb;
     for (int i = 0; i < c.n_layers; ++i) {
       const LayerP p = layer_ptrs(dense, lay, i);
       LayerWs& lw = w.layer[i];
-      if (tb.n + 4 > TransposeBatch::MAX) {
+      if (tb.n + 12 > TransposeBatch::MAX) {
         if ((rc = transpose_batch(tb, st))) return rc;
         tb.n = 0;
       }
       tb.add(p.wqkv, 3 * d, d, lw.wqkvT); tb.add(p.wo, d, d, lw.woT); tb.add(p.w1, I, d, lw.w1T); tb.add(p.w2, d, I, lw.w2T);
+      if (wsp) {   // ... and the split-bf16 copies both passes' chain kernels stream
+        tb.add_split(p.wqkv, 3 * d, d, lw.s_wqkvT, false); tb.add_split(p.wo, d, d, lw.s_woT, false);
+        tb.add_split(p.w1, I, d, lw.s_w1T, false); tb.add_split(p.w2, d, I, lw.s_w2T, false);
+        tb.add_split(p.wqkv, 3 * d, d, lw.s_wqkv, true); tb.add_split(p.wo, d, d, lw.s_wo, true);
+        tb.add_split(p.w1, I, d, lw.s_w1, true); tb.add_split(p.w2, d, I, lw.s_w2, true);
+      }
     }
     if ((rc = transpose_batch(tb, st))) return rc;
   }
@@ -413,6 +435,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
     ce.L = c.L; ce.tok = tokmap; ce.drop = d_emb;
     ce.x0 = w.x0; ce.x0hat = w.x0hat; ce.rstd0 = w.rstd0;
     ce.wnT = w.layer[0].wqkvT + skip_q * d; ce.ldwn = 3 * d; ce.bn = p0.bqkv + skip_q * d;
+    if (wsp) { ce.wnT = w.layer[0].s_wqkvT + 4 * skip_q * d; ce.wsplit = true; }   // (a 16-byte cell per column of a slice plane)
     ce.outn = w.layer[0].qkv + skip_q * d; ce.ldn = 3 * d; ce.Nn = (3 - skip_q) * d;
     ce.M = M; ce.m_dev = mv;
     if ((rc = chain_embed_proj(ce, d, st))) return rc;
@@ -512,10 +535,11 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
       if (i + 1 < c.n_layers) {   // the next layer's input projection rides along: K,V only when that layer is the last-row one
         const LayerP pn = layer_ptrs(dense, lay, i + 1);
         const int skip_q = (c.last_only && i + 1 == c.n_layers - 1) ? 1 : 0;
-        ca.wnT = w.layer[i + 1].wqkvT + skip_q * d; ca.ldwn = 3 * d; ca.bn = pn.bqkv + skip_q * d;
+        ca.wnT = (wsp ? w.layer[i + 1].s_wqkvT + 4 * skip_q * d : w.layer[i + 1].wqkvT + skip_q * d); ca.ldwn = 3 * d; ca.bn = pn.bqkv + skip_q * d;
         ca.outn = w.layer[i + 1].qkv + skip_q * d; ca.ldn = 3 * d; ca.Nn = (3 - skip_q) * d;
         proj_done = true;
       }
+      if (wsp) { ca.woT = lw.s_woT; ca.w1T = lw.s_w1T; ca.w2T = lw.s_w2T; ca.wsplit = true; }
       if ((rc = chain_ffn_fwd(ca, d, st))) return rc;
       x = lw.y;
       continue;
@@ -552,9 +576,9 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   (void)item_table; (void)n_items;
   const UrSasrecCfg& c = *cfg;
   UR_REQUIRE(check_forward(ws, dense, item_seq, c) != 1, UR_ERR_ARG,
-             "ur_sasrec_bwd: the last ur_sasrec_fwd on this workspace saw other weights / ids / shapes (the backward pass reads what it left there)");
+             "ur_sasrec_bwd: the last ur_sasrec_fwd on this workspace saw other weights / ids / shapes / mfma_arith (the backward pass reads what it left there)");
   hipStream_t st = as_stream(stream);
-  const ArithScope arith_scope(c.mfma_arith);   // (the weight-gradient products of this pass: gemm.hip)
+  const ArithScope arith_scope(c.mfma_arith | 0x200);   // (the weight-gradient products of this pass: gemm.hip; 0x200: small groups take the split kernel too)
   if ((rc = ur_sasrec_bwd_join(stream))) return rc;   // (a deferred pass nobody joined)
   const Layout lay = make_layout(c);
   Ws w = carve(c, (float*)ws);
@@ -567,6 +591,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
   // does not carry the second, dropout-masked copy of the LayerNorm-backward outputs)
   const bool chain_bwd = chain_supported(d, I, CHAIN_BWD);   // (hidden dropout: the masks are re-evaluated in the kernel)
   const bool chain_proj = chain_supported(d, I, CHAIN_PROJ);
+  const bool wsp = chains_split(c);   // (the split copies of the weights were made by ur_sasrec_fwd, like the K-major ones)
   const bool chain_last_bwd = chain_supported(d, I, CHAIN_LAST_BWD);
   bool ln0_done = false;                // the embedding LayerNorm backward already ran in the epilogue of the bottom layer's last GEMM
   // LayerNorm backward in the epilogue of the GEMM that produces its input gradient (EPI_ADD_LNBWD): the attention block's
@@ -686,6 +711,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
     ChainProjBwdArgs cp{};
     cp.g = lw.g_qkv; cp.ldg = 3 * d; cp.K = 3 * d; cp.w = layer_ptrs(dense, lay, i).wqkv; cp.ldw = d; cp.res = lw.g_ta;
     cp.out = w.g_y; cp.M = M; cp.m_dev = mv;
+    if (wsp) { cp.w = lw.s_wqkv; cp.wsplit = true; }
     if (i == 0) {
       float* part0 = w.chain_part + 4LL * c.n_layers * w.chain_blocks * d;
       cp.xhat = w.x0hat; cp.rstd = w.rstd0; cp.gamma = dense + lay.off[1]; cp.out = d_emb_rows; cp.out_rows = compact ? w.tok_full : nullptr;
@@ -854,6 +880,7 @@ static int sasrec_bwd_impl(const UrSasrecCfg* cfg, const float* item_table, int6
       cb.g_tf = lw.g_tf; cb.g_h1 = lw.g_h1; cb.g_ta = lw.g_ta; cb.g_ctx = w.g_ctx; cb.part = part;
       cb.M = M; cb.m_dev = mv; cb.I = I; cb.act = c.act;
       cb.drop_ffn = d_ffn; cb.drop_out = d_out; cb.g_tfd = lw.g_tfd; cb.g_tad = lw.g_tad;
+      if (wsp) { cb.w2 = lw.s_w2; cb.w1 = lw.s_w1; cb.wo = lw.s_wo; cb.wsplit = true; }
       if ((rc = chain_ffn_bwd(cb, d, st))) return rc;
       if (rb.full(4) && (rc = reduce_batch(rb, st))) return rc;
       rb.add(part, 4 * d, nblk, d, d, G + o[14], d);
