@@ -48,6 +48,27 @@ def split_ceiling_tflops():
     return MFMA_BF16_PEAK_TFLOPS / t if t in (6, 9) else None
 
 
+def class_terms(k):
+    """piece products per fp32 product of an MFMA class's kernels (0: exact fp32-input MFMA): the weight-gradient products follow
+    mfma_arith (6 / 9), the row chains run the six-term form whenever mfma_arith names a split form (test hook chain_split=0: exact)"""
+    from unirec_amd import ops
+    t = ops.default_mfma_arith() & 0xFF
+    if t not in (6, 9):
+        return 0
+    if k == "gemm_tn":
+        return t
+    if k == "row_chain":
+        return 0 if "chain_split=0" in os.environ.get("UR_TEST", "") else 6
+    return 0
+
+
+def class_peak_tflops(k):
+    """the ceiling a class is priced against: the dense bf16 MFMA peak / its piece products when it runs split arithmetic (fp32-equivalent
+    TFLOP/s), the fp32-input MFMA peak otherwise"""
+    t = class_terms(k)
+    return MFMA_BF16_PEAK_TFLOPS / t if t else MFMA_F32_PEAK_TFLOPS
+
+
 def mfma_arith_note():
     from unirec_amd import ops
     t = ops.default_mfma_arith() & 0xFF
@@ -57,7 +78,11 @@ def mfma_arith_note():
                                 "v_mfma_f32_32x32x16_bf16; error vs fp64 <= the exact fp32-MFMA kernel's (profiles/r06_a_stage_a.txt, "
                                 "tests/test_gemm_gpu.py::test_split_bf16_products_are_fp32_equivalent)",
             "terms": t, "split_ceiling_TFLOPs": round(MFMA_BF16_PEAK_TFLOPS / t, 1), "fp32_mfma_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
-            "everything_else": "exact fp32-input MFMA"}
+            "row_chains": ("the same split, six piece products per product: weights pre-split where the K-major copies are made, the activation "
+                           "fragment split in registers; error vs an fp64 evaluation of the oracle <= 1.5 x the exact chains' "
+                           "(profiles/r06_k_chain_split_error.txt, tests/test_rowchain_gpu.py::test_split_row_chains_are_fp32_equivalent)")
+                          if class_terms("row_chain") else "exact fp32-input MFMA",
+            "everything_else": "exact fp32-input MFMA (attention, last-row layer, GRU, one-product-per-launch GEMMs)"}
 
 
 def csrc_digest():
@@ -666,7 +691,7 @@ def other_config(name, device):
     mfma = dom in MFMA_CLASSES
     scale = frac if dom in ("gemm_nt", "gemm_tn", "row_chain") else 1.0     # GEMM work is counted on the padded row count
     ach = c["work"] * scale / max(c["ms"] * 1e-3, 1e-12) / (1e12 if mfma else 1e9)
-    peak = MFMA_F32_PEAK_TFLOPS if mfma else HBM_PEAK_GBPS
+    peak = round(class_peak_tflops(dom), 1) if mfma else HBM_PEAK_GBPS   # (a class in split arithmetic: the dense bf16 peak / its piece products)
     out = {"workload": f"{cfg['model']} n_items={a.n_items} d={d} L={L} B={a.batch} K={a.negatives} {a.loss}",
            "ms_per_step": round(dt / steps * 1e3, 4), "examples_per_s": round(a.batch * steps / dt, 1),
            "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 4),
@@ -1004,17 +1029,20 @@ def main():
         # the library counts 2*M*N*K with the PADDED row count M = B*L; with padding skipped (the default) only the rows
         # of real tokens are computed, so the algorithmic flops are scaled by the batches' real-token fraction
         achieved = c["work"] * valid_frac / (c["ms"] * 1e-3) / 1e12
+        # priced against the ceiling of the pipe the class RUNS on: a class in split arithmetic executes `terms` bf16 MFMA flops per
+        # algorithmic (fp32-equivalent) flop, so its ceiling is the dense bf16 peak / terms; the fraction of the fp32-input peak is kept beside it
+        peak, terms = class_peak_tflops(dom), class_terms(dom)
         roof = {"bound": "mfma", "kernel": f"{dom} kernels (v_mfma_f32_32x32x2_f32)", "achieved": round(achieved, 2),
-                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                 "launches": c["launches"], "avg_launch_us": round(c["ms"] * 1e3 / max(1, c["launches"]), 2),
                 "real_token_fraction": round(valid_frac, 4)}
-        if dom == "gemm_tn" and split_ceiling_tflops():   # the class runs on the bf16 pipes: quoted against BOTH ceilings
-            roof["kernel"] = "gemm_tn kernels (v_mfma_f32_32x32x16_bf16 on exactly split fp32 operands)"
-            roof["frac_of_split_ceiling"] = round(achieved / split_ceiling_tflops(), 4)
-            roof["split_ceiling"] = round(split_ceiling_tflops(), 1)
+        if terms:
+            roof["kernel"] = f"{dom} kernels (v_mfma_f32_32x32x16_bf16 on exactly split fp32 operands, {terms} piece products per product)"
+            roof["peak_is"] = f"dense bf16 MFMA peak {MFMA_BF16_PEAK_TFLOPS:.0f} / {terms}: fp32-equivalent TFLOP/s"
+            roof["frac_of_fp32_mfma_peak"] = round(achieved / MFMA_F32_PEAK_TFLOPS, 4)
         if iso is not None and iso["ms"] > 0:
             ach_iso = iso["work"] * valid_frac / (iso["ms"] * 1e-3) / 1e12
-            roof["isolated"] = {"achieved": round(ach_iso, 2), "frac": round(ach_iso / MFMA_F32_PEAK_TFLOPS, 4), "launches": iso["launches"],
+            roof["isolated"] = {"achieved": round(ach_iso, 2), "frac": round(ach_iso / peak, 4), "launches": iso["launches"],
                                 "avg_launch_us": round(iso["ms"] * 1e3 / max(1, iso["launches"]), 2),
                                 "note": "same class, 10 extra steps after the timed region with the side stream off (no concurrent dW GEMMs)"}
     else:
@@ -1058,13 +1086,15 @@ def main():
     pmc_bytes = pmc_json.get("hbm_bytes_per_step_all_kernels") if (pmc_json and a.n_items == 100_000_000 and a.batch == 512) else None
     step_floor = None
     if useful > 0:
-        mfma_floor_ms = useful / (MFMA_F32_PEAK_TFLOPS * 1e3) * 1e3
+        # every class at the ceiling of the pipe it runs on (split arithmetic: the dense bf16 peak / piece products)
+        mfma_floor_ms = sum(v["work"] * (valid_frac if k in ("gemm_nt", "gemm_tn", "row_chain") else 1.0) / class_peak_tflops(k)
+                            for k, v in warm.items() if k in MFMA_CLASSES) / n_prof_steps / 1e12 * 1e3
         step_floor = {"useful_gflop": round(useful, 2), "mfma_floor_ms": round(mfma_floor_ms, 4), "frac_of_mfma_floor": round(mfma_floor_ms / ms_per_step, 4),
                       "pmc_bytes": pmc_bytes,
                       "hbm_floor_ms": round(pmc_bytes / (HBM_COPY_GBPS * 1e9) * 1e3, 4) if pmc_bytes else None,
                       "frac_of_hbm_floor": round(pmc_bytes / (HBM_COPY_GBPS * 1e9) * 1e3 / ms_per_step, 4) if pmc_bytes else None,
-                      "note": f"useful_gflop = algorithmic flops of the MFMA classes per step (launcher counts, real token rows); floors at {MFMA_F32_PEAK_TFLOPS} "
-                              f"TFLOP/s fp32 MFMA and {HBM_COPY_GBPS / 1e3:.2f} TB/s (streaming-copy rate of this part); pmc_bytes = all kernels of a step, "
+                      "note": f"useful_gflop = algorithmic flops of the MFMA classes per step (launcher counts, real token rows); floors: every class at its own "
+                              f"ceiling ({MFMA_F32_PEAK_TFLOPS} TFLOP/s fp32-input MFMA; split-arithmetic classes {MFMA_BF16_PEAK_TFLOPS:.0f} / piece products) and {HBM_COPY_GBPS / 1e3:.2f} TB/s (streaming-copy rate of this part); pmc_bytes = all kernels of a step, "
                               f"from the same summary as roofline.traffic (null when none was taken on this tree)"}
     emb_bytes_per_example = 8 * (L + G) * d * 4   # fwd read + bwd/opt touched rows (w,m,v,grad)
     out = {
@@ -1086,10 +1116,11 @@ def main():
         # every MFMA-bound class, from the warm-up steps where all classes are bracketed (same definition as `roofline`: algorithmic flops
         # of the real token rows / device time of the class, in situ -- the weight-gradient GEMMs share the CUs with the main stream)
         "mfma_classes_warmup": {k: {"TFLOPs": round(v["work"] * (valid_frac if k in ("gemm_nt", "gemm_tn", "row_chain") else 1.0) / (v["ms"] * 1e-3) / 1e12, 2),
-                                    "frac": round(v["work"] * (valid_frac if k in ("gemm_nt", "gemm_tn", "row_chain") else 1.0) / (v["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                    "peak": round(class_peak_tflops(k), 1),
+                                    "frac": round(v["work"] * (valid_frac if k in ("gemm_nt", "gemm_tn", "row_chain") else 1.0) / (v["ms"] * 1e-3) / 1e12 / class_peak_tflops(k), 4),
                                     "launches_per_step": round(v["launches"] / max(1, n_prof), 1),
-                                    **({"frac_of_split_ceiling": round(v["work"] * valid_frac / (v["ms"] * 1e-3) / 1e12 / split_ceiling_tflops(), 4)}
-                                       if k == "gemm_tn" and split_ceiling_tflops() else {})}
+                                    **({"frac_of_fp32_mfma_peak": round(v["work"] * valid_frac / (v["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+                                       if class_terms(k) else {})}
                                 for k, v in warm.items() if k in MFMA_CLASSES and v["ms"] > 0 and v["work"] > 0},
     }
     if world == 1 and a.sharded_w1:

@@ -98,12 +98,15 @@ typedef struct UrSasrecCfg {
   float p_attn;         /* attn_dropout_prob */
   int64_t drop_seed;
   int64_t drop_step;
-  int32_t mfma_arith;   /* arithmetic of the weight-gradient products (autograd of modules.py:285-287,312,347-355): 0 = exact fp32-input
-                         * MFMA; 6 / 9 = the fp32 operands split exactly into three bf16 pieces, six / nine piece products accumulated in
-                         * fp32 on the bf16 pipes (fp32-equivalent: measured error vs fp64 <= the exact kernel's, profiles/r06_*_stage_a*);
-                         * see ur_set_mfma_arith.  128-wide products take the wide form (128 x 128 tiles), 64-wide ones the narrow form; products that
-                         * fill < 70 % of even 64 x 64 tiles, and groups too small to put two wide workgroups on a CU, keep the exact kernel
-                         * unless 0x100 is added (unit tests). */
+  int32_t mfma_arith;   /* arithmetic of the encoder's dense contractions: 0 = exact fp32-input MFMA everywhere; 6 / 9 = the fp32 operands
+                         * split exactly into three bf16 pieces, six / nine piece products accumulated in fp32 on the bf16 pipes
+                         * (fp32-equivalent: measured error vs fp64 <= the exact kernels', profiles/r06_a_stage_a*, r06_k_*); see
+                         * ur_set_mfma_arith.  Runs in the split form: (a) the weight-gradient products (autograd of modules.py:285-287,
+                         * 312,347-355) -- 128-wide products the wide form (128 x 128 tiles), 64-wide ones the narrow form; products that
+                         * fill < 70 % of even 64 x 64 tiles keep the exact kernel unless 0x100 is added (unit tests); (b) the row-chain
+                         * kernels of the full-sequence layers, forward and backward (d = 32 / 64 / 128; always six terms; the weights are
+                         * pre-split by ur_sasrec_fwd, so ur_sasrec_bwd must be given the SAME mfma_arith).  Attention, the last-row
+                         * layer and one-product-per-launch GEMMs stay on the fp32-input MFMA. */
   int32_t reserved_;
 } UrSasrecCfg;
 

@@ -61,9 +61,10 @@ def embedding_gather(table: torch.Tensor, idx: torch.Tensor, out: torch.Tensor =
 
 # --------------------------------------------------------------------------------------------- SASRec
 def default_mfma_arith() -> int:
-    """Arithmetic of the weight-gradient products when a model's config does not say (``mfma_arith``): 6 = the fp32 operands split
-    exactly into three bf16 pieces, six piece products accumulated in fp32 on the bf16 matrix pipes (fp32-equivalent; include/
-    unirec_amd.h: ur_set_mfma_arith); ``UR_MFMA_ARITH=0`` (or 9) in the environment selects the exact fp32-input MFMA (all nine terms)."""
+    """Arithmetic of the encoder's weight-gradient products and row-chain kernels when a model's config does not say (``mfma_arith``):
+    6 = the fp32 operands split exactly into three bf16 pieces, six piece products accumulated in fp32 on the bf16 matrix pipes
+    (fp32-equivalent; include/unirec_amd.h: UrSasrecCfg.mfma_arith, ur_set_mfma_arith); ``UR_MFMA_ARITH=0`` (or 9) in the environment
+    selects the exact fp32-input MFMA (all nine terms in the weight-gradient products)."""
     v = os.environ.get("UR_MFMA_ARITH", "")
     return int(v) if v in ("0", "6", "9") else 6
 
