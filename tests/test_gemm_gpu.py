@@ -35,10 +35,26 @@ def _close(got, ref, tol=1e-4):
     assert err < tol, err
 
 
+@pytest.fixture
+def arith(request):
+    """the arithmetic of the weight-gradient products for ONE test (ur_set_mfma_arith is process-wide): 0 = exact fp32-input MFMA,
+    6 / 9 = split-bf16 terms; the raw hooks take the split kernel at every shape"""
+    from unirec_amd._lib import check, lib
+    check(lib.ur_set_mfma_arith(request.param), "ur_set_mfma_arith")
+    assert lib.ur_get_mfma_arith() == request.param
+    yield request.param
+    check(lib.ur_set_mfma_arith(0), "ur_set_mfma_arith")
+
+
+ARITHS = pytest.mark.parametrize("arith", [0, 6, 9], indirect=True)
+
+
+@ARITHS
 @pytest.mark.parametrize("M,N,K", [(25600, 384, 128), (700, 128, 512), (512, 512, 128), (512, 128, 128), (33, 100, 36), (1, 128, 128),
                                    (1025, 256, 64), (2000, 132, 260), (64, 200, 512)])
 @pytest.mark.parametrize("pro,epi", [(0, 0), (0, 1), (0, 2), (1, 2), (0, 3), (0, 4)])
-def test_gemm_nt(M, N, K, pro, epi):
+def test_gemm_nt(M, N, K, pro, epi, arith):
+    """arith 6 / 9: the plain-epilogue products (epi 0, 1, 3, 4) run the six-term split-bf16 K loop (round 6d); the LayerNorm epilogue stays exact"""
     from unirec_amd._lib import check, lib
     if epi == 2 and N > 256:
         pytest.skip("fused LayerNorm epilogue: N <= 256")
@@ -75,18 +91,6 @@ def test_gemm_nt(M, N, K, pro, epi):
     _close(Cc, ref, 2e-4 if epi == 2 else 1e-4)
 
 
-@pytest.fixture
-def arith(request):
-    """the arithmetic of the weight-gradient products for ONE test (ur_set_mfma_arith is process-wide): 0 = exact fp32-input MFMA,
-    6 / 9 = split-bf16 terms; the raw hooks take the split kernel at every shape"""
-    from unirec_amd._lib import check, lib
-    check(lib.ur_set_mfma_arith(request.param), "ur_set_mfma_arith")
-    assert lib.ur_get_mfma_arith() == request.param
-    yield request.param
-    check(lib.ur_set_mfma_arith(0), "ur_set_mfma_arith")
-
-
-ARITHS = pytest.mark.parametrize("arith", [0, 6, 9], indirect=True)
 
 
 @ARITHS
@@ -144,6 +148,37 @@ def test_gemm_tn_128_tile_shapes(T, R, Cc_, act, arith):
     ref = P64.T @ (_ACTS[act](Q64) if act >= 0 else Q64)
     _close(out, ref)
     _close(bo, P64.sum(0))
+
+
+@pytest.mark.parametrize("kind", ["randn", "scaled", "cancelling"])
+@pytest.mark.parametrize("M,N,K", [(25600, 384, 128), (25600, 128, 384), (4096, 2304, 128), (25600, 128, 2304)])
+def test_split_bf16_nt_products_are_fp32_equivalent(M, N, K, kind):
+    """the same gate for ur_gemm_nt's split K loop (the GRU's input projection and its gradient at H = 128 / 768): error against an
+    fp64 product of the same fp32 operands, measured in units of sum_k |a w|, at most 1.5 x the exact fp32-MFMA loop's"""
+    from unirec_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A, W = torch.randn(M, K, device=dev, generator=g), torch.randn(N, K, device=dev, generator=g)
+    if kind == "scaled":          # column scales over four decades on both operands
+        A = A * torch.exp(torch.randn(K, device=dev, generator=g) * 2.3)
+        W = W * torch.exp(torch.randn(K, device=dev, generator=g) * 2.3) * 1e-3
+    elif kind == "cancelling":    # the exact sum nearly cancels
+        h = K // 2
+        A[:, h:2 * h] = -A[:, :h] * (1 + 1e-3 * torch.randn(M, h, device=dev, generator=g))
+        W[:, h:2 * h] = W[:, :h]
+    ref = A.double() @ W.double().T
+    yard = A.double().abs() @ W.double().abs().T
+    err = {}
+    try:
+        for a in (0, 6):
+            check(lib.ur_set_mfma_arith(a), "ur_set_mfma_arith")
+            out = torch.full((M, N), float("nan"), device=dev)
+            check(lib.ur_gemm_nt(_p(A), K, _p(W), K, _p(out), N, M, N, K, 0, 0, ACT, None, None, 0, None, None, 1e-10, None, None, _st()), "ur_gemm_nt")
+            err[a] = float(((out.double() - ref).abs() / yard).max())
+    finally:
+        check(lib.ur_set_mfma_arith(0), "ur_set_mfma_arith")
+    assert err[0] < 5e-6, err                 # (the worst of M x N outputs, each an fmaf chain over K products)
+    assert err[6] <= 1.5 * err[0], err
 
 
 @pytest.mark.parametrize("kind", ["randn", "grad-like", "cancelling"])

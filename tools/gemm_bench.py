@@ -42,6 +42,15 @@ def tn(T, R, Cc_, act=0):
 
 
 if __name__ == "__main__":
+    if os.environ.get("NT_ONLY"):   # the one-product-per-launch shapes of the GRU (H = 128 / 768) in both arithmetics
+        for arith in (0, 6):
+            check(lib.ur_set_mfma_arith(arith))
+            print(f"--- mfma_arith = {arith}")
+            for (M, N, K, epi) in [(25600, 384, 128, 1), (25600, 128, 384, 0), (25600, 2304, 128, 1), (25600, 128, 2304, 0), (25600, 512, 128, 1),
+                                   (25600, 128, 512, 4), (512, 2304, 768, 0)]:
+                nt(M, N, K, 0, epi)
+        check(lib.ur_set_mfma_arith(0))
+        sys.exit(0)
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 25600
     for (N, K, pro, epi) in [(384, 128, 0, 1), (256, 128, 0, 1), (128, 128, 0, 2), (512, 128, 0, 1), (128, 512, 1, 2), (512, 128, 0, 3),
                              (128, 512, 0, 4), (128, 128, 0, 0), (128, 384, 0, 4), (128, 256, 0, 0)]:

@@ -195,7 +195,31 @@ __device__ __forceinline__ void epilogue_from_lds(const float* Cs, int m0, int n
   }
 }
 
-template <int BM, int BN, int PRO, int EPI, int BK = 32>
+// split-bf16 arithmetic (see gemm_tn_split_kernel below): the three bf16 pieces of the eight fp32 values of one lane's fragment of a
+// 16-wide K slice (k offsets fk .. fk+3 and 8 + fk .. 8 + fk+3: the fragment layout of v_mfma_f32_32x32x16_bf16 with the k order
+// permuted the same way on both operands); 9 VALU instructions per pair of values
+typedef __bf16 nt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float nt_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int nt_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_split8(const float4 a0, const float4 a1, nt_bf16x8 (&pc)[3]) {
+  const nt_f32x2 x[4] = {{a0.x, a0.y}, {a0.z, a0.w}, {a1.x, a1.y}, {a1.z, a1.w}};
+  nt_u32x4 h, m, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const nt_f32x2 r = x[j] - __builtin_bit_cast(nt_f32x2, __builtin_bit_cast(nt_u32x2, x[j]) & 0xFFFF0000u);
+    const nt_f32x2 t = r - __builtin_bit_cast(nt_f32x2, __builtin_bit_cast(nt_u32x2, r) & 0xFFFF0000u);
+    h[j] = __builtin_amdgcn_perm(__float_as_uint(x[j][1]), __float_as_uint(x[j][0]), 0x07060302u);
+    m[j] = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
+    l[j] = __builtin_amdgcn_perm(__float_as_uint(t[1]), __float_as_uint(t[0]), 0x07060302u);
+  }
+  pc[0] = __builtin_bit_cast(nt_bf16x8, h); pc[1] = __builtin_bit_cast(nt_bf16x8, m); pc[2] = __builtin_bit_cast(nt_bf16x8, l);
+}
+
+// SPL (round 6d): the K loop in split-bf16 arithmetic -- both fragments split in registers where they are consumed, six piece products per
+// (row block, column block, 16-wide slice) on v_mfma_f32_32x32x16_bf16 (6 x 8 passes where the fp32-input MFMA takes 8 x 16).  Staging,
+// LDS image and epilogues are the exact kernel's.
+template <int BM, int BN, int PRO, int EPI, int BK = 32, bool SPL = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   constexpr int LS = BK + 4;            // padded LDS row stride (floats): conflict-free ds_read_b128 for BK = 16 and 32
   constexpr int C4N = BK / 4;           // float4 columns per tile row
@@ -285,6 +309,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
       if (kt + 1 < nk) load_global(kt + 1);   // the next tile is in flight during this one's MFMAs
       const float* Ab = As + buf * BM * LS + (wr * (BM / WM) + frow) * LS + fk;
       const float* Wb = Ws + buf * BN * LS + (wc * (BN / WN) + frow) * LS + fk;
+      if constexpr (SPL) {
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+          nt_bf16x8 ap[TM][3], bp[TN][3];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) nt_split8(*(const float4*)(Ab + i * 32 * LS + kk), *(const float4*)(Ab + i * 32 * LS + kk + 8), ap[i]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) nt_split8(*(const float4*)(Wb + j * 32 * LS + kk), *(const float4*)(Wb + j * 32 * LS + kk + 8), bp[j]);
+          // small terms first, the leading product last (gemm_tn_split_kernel's order)
+          constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+          for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][PA[tm]], bp[j][PB[tm]], acc[i][j], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 8) {
         float4 af[TM], bf[TN];
@@ -301,6 +343,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
           }
+      }
       }
       if (kt + 1 < nk) store_lds(buf ^ 1);
       __syncthreads();
@@ -328,7 +371,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   epilogue_from_lds<BM, BN, EPI>(Cs, m0, n0, tid, a);
 }
 
-template <int BM, int BN, int PRO, int EPI, int BK = 32>
+template <int BM, int BN, int PRO, int EPI, int BK = 32, bool SPL = false>
 static int launch_nt(const GemmArgs& a, hipStream_t st) {
   constexpr int LS = BK + 4;
   const long long nblk = 8LL * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN);
@@ -337,10 +380,10 @@ static int launch_nt(const GemmArgs& a, hipStream_t st) {
   size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
   const size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
   if (cs > lds) lds = cs;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI, BK>,
+  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, PRO, EPI, BK, SPL>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
-  UR_LAUNCH_EV((gemm_nt_kernel<BM, BN, PRO, EPI, BK>), grid, dim3(256), lds, st, a);
+  UR_LAUNCH_EV((gemm_nt_kernel<BM, BN, PRO, EPI, BK, SPL>), grid, dim3(256), lds, st, a);
   UR_LAUNCH_CHECK();
   return UR_OK;
 }
@@ -349,23 +392,34 @@ static int launch_nt(const GemmArgs& a, hipStream_t st) {
 // on its own K loop (M = 512, N = 128, K = 512: 8 workgroups x 13.7 us of MFMA).  32-row tiles double the workgroups.
 static bool small_m(const GemmArgs& a) { return a.M <= 1024; }
 
+// the arithmetic of the plain-epilogue products (dispatch_tile): split bf16 (six terms) when mfma_arith names a split form -- inside an
+// encoder call its cfg's field, for the raw hook ur_gemm_nt the process-wide setting (test hook nt_split=0: exact whatever it says).
+// The LayerNorm-epilogue launches and the ranking count (integer results compared bit for bit) stay on the fp32-input MFMA.
+static bool nt_split_on() {
+  static const bool hook = ur_test_hook("nt_split", 1) != 0;
+  const int base = mfma_arith() & 0xFF;
+  return hook && (base == 6 || base == 9);
+}
+#define UR_NT_GO(BM_, BN_, BK_) (spl ? launch_nt<BM_, BN_, PRO, EPI, BK_, true>(a, st) : launch_nt<BM_, BN_, PRO, EPI, BK_, false>(a, st))
 template <int PRO, int EPI>
 static int dispatch_tile(const GemmArgs& a, hipStream_t st) {
+  const bool spl = EPI != EPI_COUNT_GT && nt_split_on();
   // enough 128x128 tiles to fill 256 CUs twice? otherwise use 64-row tiles for more workgroups
   const long long big = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
-  if (a.N <= 64) return launch_nt<64, 64, PRO, EPI>(a, st);
-  if (small_m(a)) return launch_nt<32, 128, PRO, EPI>(a, st);
+  if (a.N <= 64) return UR_NT_GO(64, 64, 32);
+  if (small_m(a)) return UR_NT_GO(32, 128, 32);
   // compacted rows and a one-tile-wide output: the 64-row grid (M/64 workgroups, ~1.5 per CU) hides the rows that were
   // skipped behind wave quantisation; 64 x 64 tiles (as many workgroups as 32 x 128, 16 KB instead of 20 KB of operands per K-step)
   // let the saving through
-  if (a.m_dev && a.N <= 128 && a.N > 64) return launch_nt<64, 64, PRO, EPI>(a, st);
-  if (a.m_dev && a.N <= 128) return launch_nt<32, 128, PRO, EPI>(a, st);
+  if (a.m_dev && a.N <= 128 && a.N > 64) return UR_NT_GO(64, 64, 32);
+  if (a.m_dev && a.N <= 128) return UR_NT_GO(32, 128, 32);
   // short K, wide N (QKV, FFN-1, d-act): the 16-deep K-step variant keeps 4 workgroups per CU resident and measured
   // 6-10 % faster at M = 25600; elsewhere the 32-deep step wins
-  if (a.K <= 128 && a.N >= 256) return launch_nt<64, 128, PRO, EPI, 16>(a, st);
-  if (big >= 512) return launch_nt<128, 128, PRO, EPI>(a, st);
-  return launch_nt<64, 128, PRO, EPI>(a, st);
+  if (a.K <= 128 && a.N >= 256) return UR_NT_GO(64, 128, 16);
+  if (big >= 512) return UR_NT_GO(128, 128, 32);
+  return UR_NT_GO(64, 128, 32);
 }
+#undef UR_NT_GO
 
 // The launches whose epilogue needs whole rows (LayerNorm forward / backward: BN = 128 = one row) use 32-row tiles (64- / 96- / 128-row
 // tiles measured slower at the C5 shapes: round 2, profiles/r02_c_ln_tile_rows.txt).

@@ -715,6 +715,7 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   if (rc) return rc;
   UR_REQUIRE(item_table && dense && item_seq && user_emb && ws && n_items > 0, UR_ERR_ARG, "ur_gru_fwd: null pointer");
   const UrGruCfg& c = *cfg;
+  const ur::ArithScope arith_scope(c.mfma_arith);   // (the input projection: gemm.hip dispatch_tile)
   hipStream_t st = as_stream(stream);
   const GruLayout lay = gru_layout(c);
   GruWs w = gru_carve(c, (float*)ws);

@@ -335,7 +335,9 @@ SideCtx* side_ctx(bool even_if_disabled = false) {
     const char* e = getenv("UR_SASREC_SIDE");
     if (e && atoi(e) == 0) return nullptr;
     SideCtx* c = new SideCtx();
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // (test hook side_prio = -1 / 1: the side stream's queue at high / low priority -- measured +- 0, profiles/HISTORY.md)
+    const int prio = ur_test_hook("side_prio", 0);
+    if ((prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return nullptr;
     // Events that order two streams of ONE device need no system-scope fence: a plain event makes the recording stream write back
     // and invalidate its caches for the host and for other devices, a 6-7 us bubble in front of the next kernel of the main stream at
     // every fork (measured: five per backward pass).
@@ -381,6 +383,7 @@ extern "C" int ur_sasrec_fwd(const UrSasrecCfg* cfg, const float* item_table, in
   UR_REQUIRE(n_items > 0, UR_ERR_ARG, "ur_sasrec_fwd: n_items=%lld", (long long)n_items);
   const UrSasrecCfg& c = *cfg;
   stamp_forward(ws, dense, item_seq, c);
+  const ArithScope arith_scope(c.mfma_arith);   // (the one-product-per-launch GEMMs of this pass: gemm.hip dispatch_tile)
   hipStream_t st = as_stream(stream);
   const Layout lay = make_layout(c);
   Ws w = carve(c, (float*)ws);
