@@ -1176,16 +1176,19 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb)
   while (j + 1 < tb.n && (int)blockIdx.x >= tb.item[j + 1].first_block) ++j;
   const TransposeItem it = tb.item[j];
   if (it.mode) {   // split copy: a thread = (K-slice kb, k group g, column n) = one 16-byte cell of each of the three piece planes
-    const int K = it.mode == 1 ? it.rows : it.cols, N = it.mode == 1 ? it.cols : it.rows;
+    const int om = it.mode & 3, SL = (it.mode & 4) ? 32 : 16, NG = SL / 8;   // slice depth, k groups per slice
+    const int K = om == 1 ? it.rows : it.cols, N = om == 1 ? it.cols : it.rows;
     const long long cell = (long long)(blockIdx.x - it.first_block) * 256 + threadIdx.x;
-    if (cell >= (long long)(K / 16) * 2 * N) return;
-    const int n = (int)(cell % N), g = (int)(cell / N) & 1, kb = (int)(cell / (2LL * N));
+    if (cell >= (long long)(K / SL) * NG * N) return;
+    const int n = (int)(cell % N), g = (int)(cell / N) % NG, kb = (int)(cell / ((long long)NG * N));
+    // the eight k of the cell: lay 16 = {4 g .. 4 g + 3, 8 + 4 g ..} of the slice, lay 32 = 8 g .. 8 g + 7
+    const int k0 = SL * kb + (SL == 16 ? 4 * g : 8 * g), k1 = SL == 16 ? k0 + 8 : k0 + 4;
     float x[8];
-    if (it.mode == 1) {
+    if (om == 1) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) x[q] = it.src[(long long)(16 * kb + 4 * g + (q & 3) + 8 * (q >> 2)) * N + n];
+      for (int q = 0; q < 8; ++q) x[q] = it.src[(long long)((q < 4 ? k0 : k1 - 4) + q) * N + n];
     } else {
-      const float4 lo4 = *(const float4*)(it.src + (long long)n * K + 16 * kb + 4 * g), hi4 = *(const float4*)(it.src + (long long)n * K + 16 * kb + 8 + 4 * g);
+      const float4 lo4 = *(const float4*)(it.src + (long long)n * K + k0), hi4 = *(const float4*)(it.src + (long long)n * K + k1);
       x[0] = lo4.x; x[1] = lo4.y; x[2] = lo4.z; x[3] = lo4.w; x[4] = hi4.x; x[5] = hi4.y; x[6] = hi4.z; x[7] = hi4.w;
     }
     typedef unsigned int tu32x4 __attribute__((ext_vector_type(4)));
@@ -1200,7 +1203,7 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb)
       pc[2][h] = __builtin_amdgcn_perm(__float_as_uint(so), __float_as_uint(se), 0x07060302u);
     }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) ((tu32x4*)it.dst)[((long long)(kb * 3 + q) * 2 + g) * N + n] = pc[q];
+    for (int q = 0; q < 3; ++q) ((tu32x4*)it.dst)[((long long)(kb * 3 + q) * NG + g) * N + n] = pc[q];
     return;
   }
   const int t = blockIdx.x - it.first_block, tcols = (it.cols + 31) / 32;
@@ -1220,9 +1223,10 @@ int transpose_batch(TransposeBatch& tb, hipStream_t st) {
   for (int i = 0; i < tb.n; ++i) {
     tb.item[i].first_block = blocks;
     if (tb.item[i].mode) {
-      const int K = tb.item[i].mode == 1 ? tb.item[i].rows : tb.item[i].cols, N = tb.item[i].mode == 1 ? tb.item[i].cols : tb.item[i].rows;
-      if (K % 16) return fail(UR_ERR_ARG, "transpose_batch: split copy of a matrix with K=%d", K);
-      blocks += cdiv((long long)(K / 16) * 2 * N, 256);
+      const int om = tb.item[i].mode & 3, SL = (tb.item[i].mode & 4) ? 32 : 16;
+      const int K = om == 1 ? tb.item[i].rows : tb.item[i].cols, N = om == 1 ? tb.item[i].cols : tb.item[i].rows;
+      if (K % SL) return fail(UR_ERR_ARG, "transpose_batch: split copy of a matrix with K=%d", K);
+      blocks += cdiv((long long)(K / 8) * N, 256);   // one thread per 8 k of a column
       continue;
     }
     blocks += cdiv(tb.item[i].cols, 32) * cdiv(tb.item[i].rows, 32);

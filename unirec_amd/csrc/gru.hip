@@ -32,7 +32,7 @@ static GruLayout gru_layout(const UrGruCfg& c) {
 struct GruWs {
   int* seq_tm;
   float *x, *gi, *gh, *h_all, *r, *z, *n, *hn;          // saved by forward
-  float *dh, *dh_carry, *dh_parts, *dgi, *dgh, *dx_tm, *w_ihT, *w_hhT, *w_dT, *tn_ws, *tn_ws2;
+  float *dh, *dh_carry, *dh_parts, *dgi, *dgh, *dx_tm, *w_ihT, *w_hhT, *w_dT, *tn_ws, *tn_ws2, *s_whh;
   long long total_floats;
 };
 // pieces of the K dimension of a per-step GEMM (few rows, K = H forward / 3H backward): ~192 columns each, so that B / 32 x N / 128 x pieces
@@ -59,6 +59,7 @@ static GruWs gru_carve(const UrGruCfg& c, float* base) {
   w.r = take(M * H); w.z = take(M * H); w.n = take(M * H); w.hn = take(M * H);
   w.dh = take(B * H); w.dh_carry = take(B * H); w.dh_parts = take(gru_ksplit(3 * H) * B * H); w.dgi = take(M * 3 * H); w.dgh = take(M * 3 * H); w.dx_tm = take(M * d);
   w.w_ihT = take(3 * H * d); w.w_hhT = take(3 * H * H); w.w_dT = take(d * H);
+  w.s_whh = (H % 128 == 0) ? take(3 * H * H * 3 / 2) : nullptr;   // split-bf16 copy of W_hh for the step kernels (made by the pass that streams it)
   long long tn = gemm_tn_ws_floats((int)M, (int)(3 * H), (int)H);
   if (gemm_tn_ws_floats((int)M, (int)(3 * H), (int)d) > tn) tn = gemm_tn_ws_floats((int)M, (int)(3 * H), (int)d);
   if (gemm_tn_ws_floats((int)B, (int)d, (int)H) > tn) tn = gemm_tn_ws_floats((int)B, (int)d, (int)H);
@@ -500,6 +501,7 @@ struct __attribute__((packed, aligned(4))) GsF2 { float a, b; };
 struct GruStepArgs {
   const float* A; int lda;            // [B][K]: h_{t-1} (forward) / dgh_t (backward)
   const float* W; int ldw;            // [K][cols], K-major: W_hh^T [H][3H] (forward: column g * H + unit) / W_hh [3H][H] (backward)
+  const float* Ws = nullptr;          // nullable: the split-bf16 copy of W (kernels.h: TransposeBatch::add_split, lay = 32) -> gru_step_split_kernel
   int B, K, H, unit_blocks;
   const float *gi, *b_hh, *hprev;     // forward: gi_t [B][3H], b_hh [3H], h_{t-1} [B][H]
   float *h_out, *r_s, *z_s, *n_s, *hn_s;
@@ -646,6 +648,157 @@ __global__ __launch_bounds__(256) void gru_step_kernel(GruStepArgs a) {
   }
 }
 
+// The same launch in split-bf16 arithmetic (round 6d; gemm.hip: every fp32 value = the exact sum of three bf16 pieces, six piece products
+// per product accumulated in fp32): the step product is MATRIX-PIPE bound (one wave per SIMD, 0.47 / 0.57 of the fp32-input rate), and
+// v_mfma_f32_16x16x32_bf16 does a 16 x 16 x 32 block of six piece products in 6 x 4 passes where v_mfma_f32_16x16x4_f32 takes 8 x 8.
+// Same decomposition, same partial tiles, same epilogue.  W comes PRE-SPLIT (a.Ws, made once per pass: [K/32][piece][k group of 4]
+// [column][8 consecutive k] bf16 -- a lane's B fragment of a column tile is one 16-byte load per piece, the 16 lanes of a k group read
+// 256 contiguous bytes); the A fragment (8 consecutive k of the lane's row: two float4 loads) is split in registers -- the four waves
+// split K, so no value is split twice.  K / 4 must be a multiple of 32 (H % 128 == 0).
+typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int gs_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int gs_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gs_split8(const float4 a0, const float4 a1, gs_bf16x8 (&pc)[3]) {
+  const gs_f32x2 x[4] = {{a0.x, a0.y}, {a0.z, a0.w}, {a1.x, a1.y}, {a1.z, a1.w}};
+  gs_u32x4 h, m, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const gs_f32x2 r = x[j] - __builtin_bit_cast(gs_f32x2, __builtin_bit_cast(gs_u32x2, x[j]) & 0xFFFF0000u);
+    const gs_f32x2 t = r - __builtin_bit_cast(gs_f32x2, __builtin_bit_cast(gs_u32x2, r) & 0xFFFF0000u);
+    h[j] = __builtin_amdgcn_perm(__float_as_uint(x[j][1]), __float_as_uint(x[j][0]), 0x07060302u);
+    m[j] = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
+    l[j] = __builtin_amdgcn_perm(__float_as_uint(t[1]), __float_as_uint(t[0]), 0x07060302u);
+  }
+  pc[0] = __builtin_bit_cast(gs_bf16x8, h); pc[1] = __builtin_bit_cast(gs_bf16x8, m); pc[2] = __builtin_bit_cast(gs_bf16x8, l);
+}
+
+template <int NUT, bool FWD>
+__global__ __launch_bounds__(256) void gru_step_split_kernel(GruStepArgs a) {
+  constexpr int NU = 16 * NUT;
+  constexpr int NT = FWD ? 3 * NUT : NUT;
+  constexpr int NG = FWD ? 3 : 1;
+  constexpr int LDP = 16 * NT + 4;
+  extern __shared__ __attribute__((aligned(16))) float part[];   // [4 waves][32 rows][LDP]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+  int ub, rb;
+  const int bid = blockIdx.x;
+  if (a.unit_blocks % 8 == 0) {
+    const int per = a.unit_blocks / 8, xcd = bid & 7, loc = bid >> 3;
+    ub = xcd * per + loc % per;
+    rb = loc / per;
+  } else {
+    ub = bid % a.unit_blocks;
+    rb = bid / a.unit_blocks;
+  }
+  const int m0 = rb * GS_ROWS, u0 = ub * NU;
+  const int KQ = a.K / 4, ns = KQ / 32;
+  const int kb0 = __builtin_amdgcn_readfirstlane(w) * ns;   // this wave's 32-wide k blocks: kb0 .. kb0 + ns - 1 (an SGPR: the scalar offset of
+                                                            // every W load derives from it -- as a VGPR each load became a waterfall loop)
+  const float* ap[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) ap[rt] = a.A + (long long)min(m0 + 16 * rt + c16, a.B - 1) * a.lda + w * KQ + 8 * kq;
+  // cell (kb, piece, k group, column) of the split copy = 16 B at ((kb * 3 + piece) * 4 + k group) * N + column: the lane part (k group,
+  // its column inside a tile) is ONE 32-bit offset, everything else is wave-uniform and goes into the scalar offset
+  const int N = a.ldw;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.Ws, 0, 0x7fffffff, 0x00020000);
+  const int wvoff = (kq * N + u0 + c16) * 16;
+  constexpr int EPT = GS_ROWS * NU / 256;
+  float e_gi[FWD ? EPT : 1][3], e_bh[FWD ? EPT : 1][3], e_x[EPT];
+#pragma unroll
+  for (int it = 0; it < EPT; ++it) {
+    const int e = tid + 256 * it, m = e / NU, u = e % NU, b = min(m0 + m, a.B - 1), j = u0 + u;
+    if constexpr (FWD) {
+      const float* gp = a.gi + (long long)b * 3 * a.H;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) { e_gi[it][g] = gp[g * a.H + j]; e_bh[it][g] = a.b_hh[g * a.H + j]; }
+      e_x[it] = a.hprev[(long long)b * a.H + j];
+    } else {
+      e_x[it] = a.carry[(long long)b * a.H + j];
+    }
+  }
+  floatx4 acc[2][NT];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[rt][ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+  // a ring of NS 32-wide k blocks, requested NS - 1 blocks ahead (forward: 27 + 4 loads and 108 + 16 registers a block: two blocks are
+  // what the 6-bit count of loads in flight and the register file hold; backward: 9 + 4 loads a block)
+  constexpr int NS = FWD ? 2 : 4;
+  float4 af[NS][2][2];
+  gs_bf16x8 wf[NS][NT][3];
+  auto fetch = [&](int slot, int blk) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      af[slot][rt][0] = *(const float4*)(ap[rt] + blk * 32);
+      af[slot][rt][1] = *(const float4*)(ap[rt] + blk * 32 + 4);
+    }
+    const int sb = (kb0 + blk) * 3 * 4 * N;      // cells in front of this block
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        wf[slot][ct][q] = __builtin_bit_cast(gs_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, (sb + q * 4 * N + (FWD ? (ct / NUT) * a.H : 0) + 16 * (ct % NUT)) * 16, 0));
+  };
+#pragma unroll
+  for (int p = 0; p < NS - 1; ++p) fetch(p, min(p, ns - 1));
+  for (int s = 0; s < ns; s += NS) {
+#pragma unroll
+    for (int ph = 0; ph < NS; ++ph) {
+      const int cur = ph, nxt = (ph + NS - 1) % NS;
+      fetch(nxt, min(s + ph + NS - 1, ns - 1));          // (beyond the end: re-reads the last block, no branch around a load)
+      if (s + ph < ns) {
+        gs_bf16x8 pa[2][3];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) gs_split8(af[cur][rt][0], af[cur][rt][1], pa[rt]);
+        // small terms first, the leading product last (gemm_tn_split_kernel's order)
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+              acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[rt][PA[tm]], wf[cur][ct][PB[tm]], acc[rt][ct], 0, 0, 0);
+      }
+    }
+  }
+  // partial tiles -> LDS (accumulator register r: row 4 kq + r, column c16 of tile ct = columns 16 t .. 16 t + 15 of its gate)
+  float* mine = part + (long long)w * GS_ROWS * LDP;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(16 * rt + 4 * kq + r) * LDP + (ct / NUT) * NU + 16 * (ct % NUT) + c16] = acc[rt][ct][r];
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < EPT; ++it) {
+    const int e = tid + 256 * it, m = e / NU, u = e % NU, b = m0 + m;
+    if (b >= a.B) continue;
+    if constexpr (FWD) {
+      float pr = 0.f, pz = 0.f, pn = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* p = part + ((long long)q * GS_ROWS + m) * LDP;
+        pr += p[u]; pz += p[NU + u]; pn += p[2 * NU + u];
+      }
+      const float rr = 1.0f / (1.0f + expf(-(e_gi[it][0] + (pr + e_bh[it][0]))));
+      const float zz = 1.0f / (1.0f + expf(-(e_gi[it][1] + (pz + e_bh[it][1]))));
+      const float hn = pn + e_bh[it][2];
+      const float nn = tanhf(e_gi[it][2] + rr * hn);
+      const long long o = (long long)b * a.H + u0 + u;
+      a.h_out[o] = (1.0f - zz) * nn + zz * e_x[it];
+      a.r_s[o] = rr; a.z_s[o] = zz; a.n_s[o] = nn; a.hn_s[o] = hn;
+    } else {
+      float sacc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sacc += part[((long long)q * GS_ROWS + m) * LDP + u];
+      a.dh_out[(long long)b * a.H + u0 + u] = sacc + e_x[it];
+    }
+  }
+}
+
 // units per workgroup (in 16s) of the step kernels, 0 = not applicable: the widest tile that still gives ~a workgroup per CU
 static int gru_step_nut(int B, int H) {
   static const bool off = ur_test_hook("gru_no_step") != 0;   // test hook: the gemm_nt + cell-kernel path (what H % 64 != 0 takes)
@@ -654,6 +807,22 @@ static int gru_step_nut(int B, int H) {
   for (int nut = 3; nut >= 1; --nut)
     if (H % (16 * nut) == 0 && (nut == 1 || (long long)rbs * (H / (16 * nut)) >= 200)) return nut;
   return 0;
+}
+// the step kernels' arithmetic: split bf16 when the cfg's mfma_arith names a split form and the shape allows (test hook gru_step_split=0: exact)
+static bool gru_step_split_on(const UrGruCfg& c, bool fwd) {
+  // measured (tools/r6_gru3.sh, ms per encoder step, exact / both / forward only / backward only): H = 768 3.63 / 3.47 / 3.47 / 3.64,
+  // H = 512 2.30 / 2.26 / 2.26 / 2.31, H = 256 1.38 / 1.43 / 1.36 / 1.44 -- the forward launch (nine column tiles a wave) was matrix-pipe
+  // bound, the backward one (three) is bound by its operand stream, which the 6-byte weights make longer: the FORWARD sweep only
+  static const int hook = ur_test_hook("gru_step_split", 2);   // 0: exact, 1: both sweeps, 2 / 3: the forward / backward sweep only
+  const int base = c.mfma_arith & 0xFF;
+  static const int hmin = ur_test_hook("gru_step_split_hmin", 128);
+  return (hook == 1 || hook == (fwd ? 2 : 3)) && (base == 6 || base == 9) && c.H % 128 == 0 && c.H >= hmin;
+}
+// the split copy of W_hh one pass's step launches stream: forward W_hh^T [K = H][3H], backward W_hh as stored [K = 3H][H]
+static int gru_split_whh(const float* w_hh, int H, float* dst, bool fwd, hipStream_t st) {
+  TransposeBatch tb;
+  tb.add_split(w_hh, 3 * H, H, dst, !fwd, 32);
+  return transpose_batch(tb, st);
 }
 template <bool FWD>
 static int gru_step_launch(int nut, GruStepArgs a, hipStream_t st) {
@@ -668,6 +837,14 @@ static int gru_step_launch(int nut, GruStepArgs a, hipStream_t st) {
       UR_HIP(hipFuncSetAttribute((const void*)gru_step_kernel<N_, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));        \
       big_lds_set = true;                                                                                                             \
     }                                                                                                                                 \
+    if (a.Ws) {                                                                                                                       \
+      static bool big_lds_set_s = false;                                                                                              \
+      if (lds > 64 * 1024 && !big_lds_set_s) {                                                                                        \
+        UR_HIP(hipFuncSetAttribute((const void*)gru_step_split_kernel<N_, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+        big_lds_set_s = true;                                                                                                         \
+      }                                                                                                                               \
+      UR_LAUNCH_EV((gru_step_split_kernel<N_, FWD>), dim3(grid), dim3(256), lds, st, a);                                              \
+    } else                                                                                                                            \
     UR_LAUNCH_EV((gru_step_kernel<N_, FWD>), dim3(grid), dim3(256), lds, st, a);                                                      \
   } while (0)
   switch (nut) {
@@ -753,10 +930,13 @@ extern "C" int ur_gru_fwd(const UrGruCfg* cfg, const float* item_table, int64_t 
     UR_LAUNCH_CHECK();
   } else if (const int nut = gru_step_nut(B, H)) {   // wide hidden state: one fused launch per step (product + gates)
     if ((rc = transpose(dense + lay.w_hh, 3 * H, H, w.w_hhT, st))) return rc;   // [H, 3H]: the K-major operand of the step kernel
+    const bool ssp = gru_step_split_on(c, true) && w.s_whh;
+    if (ssp && (rc = gru_split_whh(dense + lay.w_hh, H, w.s_whh, true, st))) return rc;
     for (int t = 0; t < L; ++t) {
       const long long o = (long long)t * B * H;
       GruStepArgs sa{};
       sa.A = w.h_all + o; sa.lda = H; sa.W = w.w_hhT; sa.ldw = 3 * H; sa.B = B; sa.K = H; sa.H = H;
+      if (ssp) sa.Ws = w.s_whh;
       sa.gi = w.gi + (long long)t * B * 3 * H; sa.b_hh = dense + lay.b_hh; sa.hprev = w.h_all + o;
       sa.h_out = w.h_all + o + (long long)B * H; sa.r_s = w.r + o; sa.z_s = w.z + o; sa.n_s = w.n + o; sa.hn_s = w.hn + o;
       if ((rc = gru_step_launch<true>(nut, sa, st))) return rc;
@@ -823,6 +1003,8 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
     UR_LAUNCH_CHECK();
   } else if (const int nut = gru_step_nut(B, H)) {   // wide hidden state: cell backward + one fused launch (product + carry) per step
     const float* dh_cur = w.dh;
+    const bool ssp = gru_step_split_on(c, false) && w.s_whh;
+    if (ssp && (rc = gru_split_whh(dense + lay.w_hh, H, w.s_whh, false, st))) return rc;
     for (int t = L - 1; t >= 0; --t) {
       const long long o = (long long)t * B * H, o3 = (long long)t * B * 3 * H;
       {
@@ -834,6 +1016,7 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
       if (t == 0) break;   // (dh_{-1} has no reader: h_0 = 0)
       GruStepArgs sa{};
       sa.A = w.dgh + o3; sa.lda = 3 * H; sa.W = dense + lay.w_hh; sa.ldw = H; sa.B = B; sa.K = 3 * H; sa.H = H;
+      if (ssp) sa.Ws = w.s_whh;
       sa.carry = w.dh_carry; sa.dh_out = w.dh_parts;
       if ((rc = gru_step_launch<false>(nut, sa, st))) return rc;
       dh_cur = w.dh_parts;

@@ -119,7 +119,7 @@ int set_mfma_arith(int terms);
 struct ArithScope { int prev; explicit ArithScope(int terms); ~ArithScope(); ArithScope(const ArithScope&) = delete; ArithScope& operator=(const ArithScope&) = delete; };
 // dst[c,r] = src[r,c]
 int transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
-struct TransposeItem { const float* src; float* dst; int rows, cols, first_block, mode; };   // mode 0: transpose; 1 / 2: split copy (add_split)
+struct TransposeItem { const float* src; float* dst; int rows, cols, first_block, mode; };   // mode 0: transpose; 1 / 2 (| 4): split copy (add_split)
 struct TransposeBatch {
   static constexpr int MAX = 48;
   TransposeItem item[MAX]; int n = 0;
@@ -133,10 +133,12 @@ struct TransposeBatch {
     return true;
   }
   // the SPLIT copy the row-chain kernels stream in split-bf16 arithmetic (rowchain.hip: RcW<true>) of the K-major matrix Wt [K, N]:
-  // Wt = src [rows = K, cols = N] (as_stored) or Wt = src^T with src [rows = N, cols = K].  K % 16 == 0; dst: 3/2 K N floats
-  bool add_split(const float* src, int rows, int cols, float* dst, bool as_stored) {
+  // Wt = src [rows = K, cols = N] (as_stored) or Wt = src^T with src [rows = N, cols = K].  dst: 3/2 K N floats.
+  // lay = 16 (K % 16 == 0): [K/16][piece][k group of 2][n][8 bf16 = k 16 kb + 4 g + {0..3}, 16 kb + 8 + 4 g + {0..3}]: v_mfma_f32_32x32x16_bf16
+  // fragments in the row chains' k order; lay = 32 (K % 32 == 0): [K/32][piece][k group of 4][n][8 consecutive k]: v_mfma_f32_16x16x32_bf16 (gru.hip)
+  bool add_split(const float* src, int rows, int cols, float* dst, bool as_stored, int lay = 16) {
     if (n >= MAX) return false;
-    item[n++] = TransposeItem{src, dst, rows, cols, 0, as_stored ? 1 : 2};
+    item[n++] = TransposeItem{src, dst, rows, cols, 0, (as_stored ? 1 : 2) | (lay == 32 ? 4 : 0)};
     return true;
   }
 };
