@@ -23,8 +23,12 @@
 // (tools/occupancy.sh).  The backward kernel at 196 registers ran them in two rounds, the second 30 % full: 103 us; bounded to 168
 // (__launch_bounds__(256, 3)): 88 us, the whole step - 12 us.  (Element-wise epilogues done on the accumulator registers where they are
 // -- no LDS round trip, one barrier less per chunk -- were measured and dropped: the 16 dword stores per lane they need are slower than
-// the transposed float4 stores, + 4 us per kernel.)  The K order of every contraction equals gemm_nt's, so forward results are
-// bit-identical to the unfused path.
+// the transposed float4 stores, + 4 us per kernel.)  In the exact arithmetic (SP = false: mfma_arith = 0) the K order of every
+// contraction equals gemm_nt's, so forward results are bit-identical to the unfused path.
+// Round 6c: SP = true (the default arithmetic, mfma_arith = 6 / 9) runs every product of the chain as six bf16 piece products of exactly
+// split fp32 operands on v_mfma_f32_32x32x16_bf16 (gemm.hip: fp32-equivalent, error-gated against fp64): the streamed weights are
+// pre-split copies (RcW<true> below), the activation fragment is split in registers by the wave that consumes it.  Same tiles, same
+// epilogues, same residency; 188 -> 152 us for the four kernels of a step (profiles/r06_l_chain_split.txt).
 #include <stdlib.h>
 
 #include "common.h"
