@@ -241,4 +241,14 @@ def test_backward_on_a_workspace_of_another_forward_is_refused():
     ops.sasrec_fwd(cfg, table, dense2, seq, ws)
     with pytest.raises(_lib.UnirecAmdError, match="last ur_sasrec_fwd on this workspace"):
         ops.sasrec_bwd(cfg, table, dense, seq, torch.ones_like(ue), ws)
+    # round 6: the forward pass pre-splits the weights for both passes' row chains when its mfma_arith names a split form -- a backward
+    # pass in the other arithmetic would stream copies that were never made
+    cfg6 = ops.sasrec_cfg(8, 10, 32, 4, 64, 2, "gelu", True, 1e-10, mfma_arith=6)
+    cfg0 = ops.sasrec_cfg(8, 10, 32, 4, 64, 2, "gelu", True, 1e-10, mfma_arith=0)
+    for a, b in ((cfg0, cfg6), (cfg6, cfg0)):
+        ops.sasrec_fwd(a, table, dense, seq, ws)
+        with pytest.raises(_lib.UnirecAmdError, match="mfma_arith"):
+            ops.sasrec_bwd(b, table, dense, seq, torch.ones_like(ue), ws)
+        ops.sasrec_fwd(b, table, dense, seq, ws)
+        ops.sasrec_bwd(b, table, dense, seq, torch.ones_like(ue), ws)
     torch.cuda.synchronize()
