@@ -163,8 +163,10 @@ def _l2(a, ref):
     return float((a.double() - ref.double()).norm() / max(1e-300, float(ref.double().norm())))
 
 
-@pytest.mark.parametrize("d,L,heads,B", [(128, 50, 16, 256), (64, 50, 16, 256), (32, 20, 4, 128), (128, 200, 16, 32)])
-def test_split_row_chains_are_fp32_equivalent(d, L, heads, B):
+@pytest.mark.parametrize("d,L,heads,B,extra", [(128, 50, 16, 256, {}), (64, 50, 16, 256, {}), (32, 20, 4, 128, {}), (128, 200, 16, 32, {}),
+                                               (64, 20, 8, 96, dict(n_layers=3, last_row_only=0)),      # every layer a full-sequence chain
+                                               (128, 30, 16, 64, dict(n_layers=4, skip_padding=0, hidden_act="gelu"))])   # 48 copies: the batch's limit
+def test_split_row_chains_are_fp32_equivalent(d, L, heads, B, extra):
     """The row-chain kernels in split-bf16 arithmetic (mfma_arith = 6, the default: six piece products per product of two fp32 values on
     the bf16 matrix pipe) against the same kernels on the fp32-input MFMA (mfma_arith = 0), both measured against the ORACLE EVALUATED
     IN fp64: the relative L2 error of the user vectors, of every dense gradient and of the item-table gradient in split arithmetic may
@@ -179,6 +181,7 @@ def test_split_row_chains_are_fp32_equivalent(d, L, heads, B):
                distance_type="dot", tau=1.0, train_file_format="user-item", exp_name="t", n_layers=2, n_heads=heads, inner_size=4 * d,
                hidden_dropout_prob=0.0, attn_dropout_prob=0.0, hidden_act="swish", layer_norm_eps=1e-10, max_seq_len=L,
                use_position_emb=True, seed=2022)
+    cfg.update(extra)
     g = torch.Generator().manual_seed(d + L)
     seq = torch.randint(1, N, (B, L), generator=g, dtype=torch.int64).to(torch.int32)
     lens = torch.randint(1, L + 1, (B,), generator=g)
@@ -223,7 +226,7 @@ def test_split_row_chains_are_fp32_equivalent(d, L, heads, B):
         worst = max(worst, e6 / max(e0, 1e-30))
         gate = 1.5 if ref[k].numel() >= 1024 else 2.0   # (a d-element vector: few samples, the L2 statistic itself scatters by ~ 30 %)
         assert e6 <= gate * e0 + 1e-9, (k, e6, e0)
-    text = f"d={d} L={L} heads={heads} B={B} inner={4 * d} 2 layers: relative L2 error vs the fp64 oracle; worst ratio {worst:.2f}\n" + "\n".join(lines)
+    text = f"d={d} L={L} heads={heads} B={B} inner={4 * d} {cfg['n_layers']} layers {extra}: relative L2 error vs the fp64 oracle; worst ratio {worst:.2f}\n" + "\n".join(lines)
     print(text)
     if os.environ.get("UR_ERROR_TABLE_OUT"):
         with open(os.environ["UR_ERROR_TABLE_OUT"], "a") as f:
