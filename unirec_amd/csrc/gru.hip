@@ -973,9 +973,13 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
   const GruLayout lay = gru_layout(c);
   GruWs w = gru_carve(c, (float*)ws);
   const int B = c.B, L = c.L, d = c.d, H = c.H, M = B * L;
-  if ((rc = transpose(dense + lay.w_ih, 3 * H, d, w.w_ihT, st))) return rc;   // [d, 3H]
-  if ((rc = transpose(dense + lay.w_hh, 3 * H, H, w.w_hhT, st))) return rc;   // [H, 3H]
-  if ((rc = transpose(dense + lay.w_d, d, H, w.w_dT, st))) return rc;         // [H, d]
+  {   // the K-major copies this pass's GEMMs read, one launch (w_hhT: only the GEMM-per-step path reads it)
+    TransposeBatch tb;
+    tb.add(dense + lay.w_ih, 3 * H, d, w.w_ihT);   // [d, 3H]
+    tb.add(dense + lay.w_d, d, H, w.w_dT);         // [H, d]
+    if (!gru_seq_supported(H) && !gru_step_nut(B, H)) tb.add(dense + lay.w_hh, 3 * H, H, w.w_hhT);   // [H, 3H]
+    if ((rc = transpose_batch(tb, st))) return rc;
+  }
   // dense head: dW_d = d_out^T h_L ; db_d ; dh_L = d_out W_d
   const float* hL = w.h_all + (long long)L * B * H;
   if ((rc = gemm_tn(d_user_emb, d, hL, H, B, d, H, 0, 0, dense_grad + lay.w_d, H, dense_grad + lay.b_d, w.tn_ws, st))) return rc;
@@ -1038,7 +1042,8 @@ extern "C" int ur_gru_bwd(const UrGruCfg* cfg, const float* item_table, int64_t 
     if ((rc = gemm_nt(g, PRO_NONE, EPI_NONE, st))) return rc;
   }
   // weight gradients over all (t, b) tokens at once (time-major rows on both operands)
-  {   // (one grouped launch: dW_hh and dW_ih share the token dimension)
+  {   // (one grouped launch: dW_hh and dW_ih share the token dimension.  On a side stream under the input-gradient GEMM below -- fork event,
+      // join at the end of the call -- the step was SLOWER: H = 128 0.451 / 0.436, H = 768 3.65 / 3.48 ms, profiles/r06_m_gru_nt_split.txt)
     const TnReq rq[2] = {{w.dgh, 3 * H, w.h_all, H, M, 3 * H, H, 0, 0, dense_grad + lay.w_hh, H, dense_grad + lay.b_hh, w.tn_ws, nullptr},
                          {w.dgi, 3 * H, w.x, d, M, 3 * H, d, 0, 0, dense_grad + lay.w_ih, d, dense_grad + lay.b_ih, w.tn_ws2, nullptr}};
     if ((rc = gemm_tn_group(rq, 2, st))) return rc;
